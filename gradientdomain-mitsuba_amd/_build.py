@@ -1,0 +1,31 @@
+"""Builds the in-tree gfx950 shared library `lib/libgdpt_hip.so` (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "lib", "libgdpt_hip.so")
+SOURCES = [os.path.join(PKG, "csrc", f) for f in ("poisson_capi.hip",)]
+DEPS = SOURCES + [os.path.join(PKG, "csrc", "poisson_kernels.hip.h"), os.path.join(ROOT, "include", "gdpt_poisson.h")]
+# -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB

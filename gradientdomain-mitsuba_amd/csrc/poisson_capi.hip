@@ -1,0 +1,679 @@
+// poisson_capi.hip -- C-ABI (include/gdpt_poisson.h) over the gfx950 Poisson kernels.
+//
+// Solver level mirrors poisson::Solver (reference Solver.cpp:196-582); backend-op level mirrors the
+// poisson::Backend virtuals (Backend.hpp:66-100).  Host code here is launch logic only: every byte of
+// image arithmetic happens in poisson_kernels.hip.h on the device.  There is no CPU fallback.
+#include "../../include/gdpt_poisson.h"
+#include "poisson_kernels.hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace gdpt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(GDPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline int imin(int a, int b) { return a < b ? a : b; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+int grid_generic(long n) { return imin(cdiv(n, BLK), 2 * MAXP); }
+int grid_reduce(long n) { return imin(cdiv(n, BLK), MAXP); }
+int grid_flat(long total4) { return imin(cdiv(total4, FLAT_TILE), MAXP); }
+
+int ensure_device(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(GDPT_ERR_NO_DEVICE, "no HIP device visible: the gfx950 Poisson backend has no CPU fallback");
+    if (device >= 0) {
+        if (device >= count) return fail(GDPT_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+        HIPCHK(hipSetDevice(device));
+    }
+    return GDPT_OK;
+}
+
+// ---- op launchers shared by both ABI levels -----------------------------------------------------
+
+struct Lattice {
+    int W, H;
+    float alpha;
+    bool fast() const { return W % 4 == 0; }
+    long n() const { return (long)W * H; }
+    int tilesX() const { return cdiv(W, TW); }
+    int tiles() const { return tilesX() * cdiv(H, TH); }
+};
+
+// Ap = A p and block partials of p.Ap; returns the number of partials written.
+int launch_Ax(hipStream_t st, const Lattice &L, bool unitw, float *Ap, float4 *part, const float *w2, const float *p)
+{
+    if (L.fast() && aligned16(Ap) && aligned16(p) && aligned16(w2)) {
+        const int G = imin(L.tiles(), MAXP);
+        if (unitw) hipLaunchKernelGGL(kf_Ax<true>, dim3(G), dim3(BLK), 0, st, (float4 *)Ap, part, w2, p, L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+        else       hipLaunchKernelGGL(kf_Ax<false>, dim3(G), dim3(BLK), 0, st, (float4 *)Ap, part, w2, p, L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+        return G;
+    }
+    const int G = grid_reduce(3 * L.n());
+    hipLaunchKernelGGL(kg_Ax, dim3(G), dim3(BLK), 0, st, Ap, part, w2, p, L.W, L.H, L.alpha);
+    return G;
+}
+
+int launch_r_rz(hipStream_t st, long n3, float *r, float4 *part_rz, const float *Ap, const float *s_rz2, const float *s_pAp,
+                const float4 *part_pAp, int G_in, float *s_pAp_out, float *s_rz_old_out)
+{
+    if (n3 % 4 == 0 && aligned16(r) && aligned16(Ap)) {
+        const int G = grid_flat(n3 / 4);
+        hipLaunchKernelGGL(kf_r_rz, dim3(G), dim3(BLK), 0, st, (float4 *)r, part_rz, (const float4 *)Ap, s_rz2, s_pAp, part_pAp, G_in, s_pAp_out, s_rz_old_out, (int)(n3 / 4));
+        return G;
+    }
+    const int G = grid_reduce(n3);
+    hipLaunchKernelGGL(kg_r_rz, dim3(G), dim3(BLK), 0, st, r, part_rz, Ap, s_rz2, s_pAp, part_pAp, G_in, s_pAp_out, s_rz_old_out, (int)n3);
+    return G;
+}
+
+void launch_x_p(hipStream_t st, long n3, float *x, float *p, const float *r, const float *s_rz, const float *s_rz2, const float *s_pAp,
+                const float4 *part_rz, int G_in, float *s_rz_out)
+{
+    if (n3 % 4 == 0 && aligned16(x) && aligned16(p) && aligned16(r)) {
+        hipLaunchKernelGGL(kf_x_p, dim3(grid_flat(n3 / 4)), dim3(BLK), 0, st, (float4 *)x, (float4 *)p, (const float4 *)r, s_rz, s_rz2, s_pAp, part_rz, G_in, s_rz_out, (int)(n3 / 4));
+        return;
+    }
+    hipLaunchKernelGGL(kg_x_p, dim3(grid_generic(n3)), dim3(BLK), 0, st, x, p, r, s_rz, s_rz2, s_pAp, part_rz, G_in, s_rz_out, (int)n3);
+}
+
+} // namespace
+
+// =================================================================================================
+// solver level
+// =================================================================================================
+
+struct gdpt_poisson_solver {
+    gdpt_poisson_params P;
+    gdpt_log_fn log_fn = nullptr;
+    void *log_user = nullptr;
+
+    int W = -1, H = -1;
+    const float *in[4] = {nullptr, nullptr, nullptr, nullptr}; // dx, dy, tp, direct (borrowed)
+    bool in_on_device = false;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ready = false;
+
+    float *d_in[4] = {nullptr, nullptr, nullptr, nullptr}; // owned staging when inputs are host pointers
+    float *b = nullptr, *e = nullptr, *w2 = nullptr, *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *Ap = nullptr, *rec = nullptr;
+    float4 *part_pAp = nullptr, *part_rz = nullptr, *part_w = nullptr;
+    float *scal = nullptr; // [0..3] pAp  [4..7] rz_old  [8..11] rz_next
+    float *regtab = nullptr;
+    int *counter = nullptr;
+    float alpha_eff = 0.0f;
+    const float *dev_direct = nullptr; // device pointer of `direct` (borrowed or staged), or null
+
+    int fusion = 1;
+    hipGraphExec_t g0 = nullptr, gK = nullptr;
+    int graph_fusion = -1;
+    float graph_alpha = -1.0f;
+
+    float last_seconds = 0.0f;
+    long last_iters = 0;
+
+    float *s_pAp() const { return scal; }
+    float *s_rz_old() const { return scal + 4; }
+    float *s_rz_next() const { return scal + 8; }
+    Lattice lat() const { return Lattice{W, H, alpha_eff}; }
+
+    void log(const char *fmt, ...)
+    {
+        if (!log_fn) return;
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        log_fn(buf, log_user);
+    }
+
+    void release_graphs()
+    {
+        if (g0) hipGraphExecDestroy(g0);
+        if (gK) hipGraphExecDestroy(gK);
+        g0 = gK = nullptr;
+        graph_fusion = -1;
+    }
+
+    void release_buffers()
+    {
+        release_graphs();
+        float **bufs[] = {&d_in[0], &d_in[1], &d_in[2], &d_in[3], &b, &e, &w2, &x, &r, &p[0], &p[1], &Ap, &rec, &scal, &regtab};
+        for (float **q : bufs) { if (*q) hipFree(*q); *q = nullptr; }
+        float4 **pb[] = {&part_pAp, &part_rz, &part_w};
+        for (float4 **q : pb) { if (*q) hipFree(*q); *q = nullptr; }
+        if (counter) hipFree(counter);
+        counter = nullptr;
+        ready = false;
+    }
+};
+
+namespace {
+
+// The per-IRLS-iteration op sequence of Solver::solveIndirect (Solver.cpp:382-405) followed by `cg` CG
+// iterations (Solver.cpp:464-470), enqueued on the solver's stream.  first == (irlsIter == 0).
+void enqueue_irls_prologue(gdpt_poisson_solver *s, bool first)
+{
+    const Lattice L = s->lat();
+    const long n = L.n(), n3 = 3 * n;
+    hipStream_t st = s->stream;
+    hipLaunchKernelGGL(kg_residual, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->e, s->b, s->x, L.W, L.H, L.alpha); // e = b - P x
+    if (first) {
+        hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->w2, 1.0f, (size_t)n3);          // w2 = 1
+    } else {
+        const int G = grid_reduce(n3);
+        hipLaunchKernelGGL(kg_w2_raw, dim3(G), dim3(BLK), 0, st, s->w2, s->part_w, s->e, (const float *)s->regtab, (const int *)s->counter, 0.0f, (int)n3);
+        hipLaunchKernelGGL(kg_w2_scale, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->w2, s->part_w, G, s->counter, (int)n3);
+    }
+    const int G = grid_reduce(n3);
+    hipLaunchKernelGGL(kg_PTW2x<true>, dim3(G), dim3(BLK), 0, st, s->r, s->p[0], s->part_rz, s->w2, s->e, L.W, L.H, L.alpha); // r, p = r, r.r
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLK), 0, st, s->s_rz_next(), (float *)nullptr, s->part_rz, G);
+}
+
+// `cg` iterations in the reference's 3-op form; p stays in p[0].
+void enqueue_cg_unfused(gdpt_poisson_solver *s, bool unitw, int cg)
+{
+    const Lattice L = s->lat();
+    const long n3 = 3 * L.n();
+    hipStream_t st = s->stream;
+    for (int k = 0; k < cg; k++) {
+        const int Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
+        const int Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
+        launch_x_p(st, n3, s->x, s->p[0], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
+    }
+}
+
+// `cg` iterations with x_p(k) fused into the stencil of iteration k+1: 2*cg + 1 kernels.
+void enqueue_cg_fused(gdpt_poisson_solver *s, bool unitw, int cg)
+{
+    const Lattice L = s->lat();
+    const long n3 = 3 * L.n();
+    hipStream_t st = s->stream;
+    const int Gt = imin(L.tiles(), MAXP);
+    int Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
+    int Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
+    for (int k = 1; k < cg; k++) {
+        float *po = s->p[(k - 1) & 1], *pn = s->p[k & 1];
+        if (unitw)
+            hipLaunchKernelGGL(kf_xp_Ax<true>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
+                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+        else
+            hipLaunchKernelGGL(kf_xp_Ax<false>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
+                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+        Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Gt, s->s_pAp(), s->s_rz_old());
+    }
+    launch_x_p(st, n3, s->x, s->p[(cg - 1) & 1], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
+}
+
+bool can_fuse(const gdpt_poisson_solver *s) { return s->fusion >= 1 && s->W % 4 == 0; }
+
+int capture(gdpt_poisson_solver *s, bool first, hipGraphExec_t *out)
+{
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_irls_prologue(s, first);
+    if (can_fuse(s)) enqueue_cg_fused(s, first, s->P.cgIterMax);
+    else enqueue_cg_unfused(s, first, s->P.cgIterMax);
+    HIPCHK(hipStreamEndCapture(s->stream, &graph));
+    hipError_t e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(GDPT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return GDPT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *gdpt_last_error(void) { return g_err.c_str(); }
+
+void gdpt_poisson_params_defaults(gdpt_poisson_params *p)
+{
+    p->alpha = 0.2f;
+    p->device = -1;
+    p->verbose = 0;
+    gdpt_poisson_params_preset(p, "L1D");
+}
+
+int gdpt_poisson_params_preset(gdpt_poisson_params *p, const char *preset)
+{
+    p->irlsIterMax = 1; p->irlsRegInit = 0.0f; p->irlsRegIter = 0.0f;
+    p->cgIterMax = 1; p->cgIterCheck = 100; p->cgPrecond = 0; p->cgTolerance = 0.0f;
+    if (!preset) return 0;
+    if (!strcmp(preset, "L1D")) { p->irlsIterMax = 20; p->irlsRegInit = 0.05f; p->irlsRegIter = 0.5f; p->cgIterMax = 50; return 1; }
+    if (!strcmp(preset, "L1Q")) { p->irlsIterMax = 64; p->irlsRegInit = 1.0f; p->irlsRegIter = 0.7f; p->cgIterMax = 1000; return 1; }
+    if (!strcmp(preset, "L1L")) { p->irlsIterMax = 7; p->irlsRegInit = 1.0e-4f; p->irlsRegIter = 1.0e-1f; p->cgIterMax = 20000; p->cgTolerance = 1.0e-20f; return 1; }
+    if (!strcmp(preset, "L2D")) { p->cgIterMax = 50; return 1; }
+    if (!strcmp(preset, "L2Q")) { p->cgIterMax = 500; return 1; }
+    return 0;
+}
+
+int gdpt_poisson_create(const gdpt_poisson_params *p, gdpt_poisson_solver **out)
+{
+    if (!p || !out) return fail(GDPT_ERR_INVALID, "null argument");
+    if (p->cgPrecond) return fail(GDPT_ERR_UNSUPPORTED, "cgPrecond (Backend::calc_MIx) is not carried by the HIP backend; no reference preset enables it");
+    int rc = ensure_device(p->device);
+    if (rc) return rc;
+    gdpt_poisson_solver *s = new gdpt_poisson_solver;
+    s->P = *p;
+    // Params::sanitize, Solver.cpp:182-192
+    s->P.alpha = fmaxf(s->P.alpha, 0.0f);
+    if (s->P.irlsIterMax < 1) s->P.irlsIterMax = 1;
+    s->P.irlsRegInit = fmaxf(s->P.irlsRegInit, 0.0f);
+    s->P.irlsRegIter = fmaxf(s->P.irlsRegIter, 0.0f);
+    if (s->P.cgIterMax < 1) s->P.cgIterMax = 1;
+    if (s->P.cgIterCheck < 1) s->P.cgIterCheck = 1;
+    s->P.cgTolerance = fmaxf(s->P.cgTolerance, 0.0f);
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+        delete s;
+        return fail(GDPT_ERR_HIP, "stream/event creation failed");
+    }
+    *out = s;
+    return GDPT_OK;
+}
+
+void gdpt_poisson_destroy(gdpt_poisson_solver *s)
+{
+    if (!s) return;
+    if (s->stream) hipStreamSynchronize(s->stream);
+    s->release_buffers();
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int gdpt_poisson_set_log(gdpt_poisson_solver *s, gdpt_log_fn fn, void *user)
+{
+    if (!s) return fail(GDPT_ERR_INVALID, "null solver");
+    s->log_fn = fn;
+    s->log_user = user;
+    return GDPT_OK;
+}
+
+static int import_common(gdpt_poisson_solver *s, const float *dx, const float *dy, const float *tp, const float *direct, int w, int h, bool dev)
+{
+    if (!s) return fail(GDPT_ERR_INVALID, "null solver");
+    if (!dx || !dy) return fail(GDPT_ERR_INVALID, "dx and dy are required (Solver.cpp:259 asserts them)");
+    if (w <= 0 || h <= 0) return fail(GDPT_ERR_INVALID, "image size must be positive (Solver.cpp:260)");
+    if ((long)w * h * 9 >= (1L << 31)) return fail(GDPT_ERR_INVALID, "image too large for 32-bit element indices");
+    if (s->ready && (w != s->W || h != s->H)) s->release_buffers();
+    s->W = w; s->H = h;
+    s->in[0] = dx; s->in[1] = dy; s->in[2] = tp; s->in[3] = direct;
+    s->in_on_device = dev;
+    return GDPT_OK;
+}
+
+int gdpt_poisson_import_images(gdpt_poisson_solver *s, const float *dx, const float *dy, const float *tp, const float *direct, int w, int h)
+{
+    return import_common(s, dx, dy, tp, direct, w, h, false);
+}
+
+int gdpt_poisson_import_images_device(gdpt_poisson_solver *s, const float *dx, const float *dy, const float *tp, const float *direct, int w, int h)
+{
+    return import_common(s, dx, dy, tp, direct, w, h, true);
+}
+
+int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
+{
+    if (!s || !s->in[0] || !s->in[1] || s->W <= 0) return fail(GDPT_ERR_INVALID, "setup_backend before import_images");
+    const long n = (long)s->W * s->H, n3 = 3 * n;
+    const size_t B3 = sizeof(float) * n3;
+    if (!s->ready) {
+        s->log("Using HIP (gfx950) backend\n");
+        HIPCHK(hipMalloc(&s->b, 3 * B3));
+        HIPCHK(hipMalloc(&s->e, 3 * B3));
+        HIPCHK(hipMalloc(&s->w2, B3));
+        HIPCHK(hipMalloc(&s->x, B3));
+        HIPCHK(hipMalloc(&s->r, B3));
+        HIPCHK(hipMalloc(&s->p[0], B3));
+        HIPCHK(hipMalloc(&s->p[1], B3));
+        HIPCHK(hipMalloc(&s->Ap, B3));
+        HIPCHK(hipMalloc(&s->rec, B3));
+        HIPCHK(hipMalloc(&s->part_pAp, sizeof(float4) * MAXP));
+        HIPCHK(hipMalloc(&s->part_rz, sizeof(float4) * MAXP));
+        HIPCHK(hipMalloc(&s->part_w, sizeof(float4) * MAXP));
+        HIPCHK(hipMalloc(&s->scal, sizeof(float) * 16));
+        HIPCHK(hipMalloc(&s->regtab, sizeof(float) * (s->P.irlsIterMax + 1)));
+        HIPCHK(hipMalloc(&s->counter, sizeof(int) * 4));
+        // reg_k = regInit * regIter^(k-1), Solver.cpp:395 (host powf like the reference)
+        std::vector<float> reg(s->P.irlsIterMax + 1, 0.0f);
+        for (int k = 1; k < s->P.irlsIterMax; k++) reg[k] = s->P.irlsRegInit * powf(s->P.irlsRegIter, (float)(k - 1));
+        HIPCHK(hipMemcpy(s->regtab, reg.data(), sizeof(float) * reg.size(), hipMemcpyHostToDevice));
+        s->ready = true;
+    }
+    const float *src[4];
+    for (int k = 0; k < 4; k++) {
+        src[k] = s->in[k];
+        if (s->in[k] && !s->in_on_device) {
+            if (!s->d_in[k]) HIPCHK(hipMalloc(&s->d_in[k], B3));
+            HIPCHK(hipMemcpyAsync(s->d_in[k], s->in[k], B3, hipMemcpyHostToDevice, s->stream));
+            src[k] = s->d_in[k];
+        }
+    }
+    s->alpha_eff = src[2] ? s->P.alpha : 0.0f; // Solver.cpp:319
+    hipLaunchKernelGGL(kg_setup, dim3(grid_generic(n3)), dim3(BLK), 0, s->stream, s->b, s->x, src[0], src[1], src[2], s->alpha_eff, (int)n3);
+    s->dev_direct = src[3];
+    HIPCHK(hipGetLastError());
+    // (re)capture the per-IRLS-iteration graphs when geometry/alpha/fusion changed
+    if (s->graph_fusion != s->fusion || s->graph_alpha != s->alpha_eff) {
+        s->release_graphs();
+        if (s->P.cgTolerance == 0.0f && !s->P.verbose) {
+            int rc = capture(s, true, &s->g0);
+            if (rc) return rc;
+            if (s->P.irlsIterMax > 1) { rc = capture(s, false, &s->gK); if (rc) return rc; }
+        }
+        s->graph_fusion = s->fusion;
+        s->graph_alpha = s->alpha_eff;
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return GDPT_OK;
+}
+
+int gdpt_poisson_solve_indirect_async(gdpt_poisson_solver *s)
+{
+    if (!s || !s->ready) return fail(GDPT_ERR_INVALID, "solve_indirect before setup_backend");
+    hipStream_t st = s->stream;
+    HIPCHK(hipEventRecord(s->ev0, st));
+    const int one = 1;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)s->counter, one, 1, st));
+    s->last_iters = 0;
+    if (s->g0) {
+        // cgTolerance == 0: the convergence test of Solver.cpp:438 can only fire on r.z == 0 exactly, and CG
+        // steps taken from that state leave x bit-identical (a = 0/FLT_MIN = 0), so no host round trip is needed.
+        for (int irls = 0; irls < s->P.irlsIterMax; irls++) {
+            HIPCHK(hipGraphLaunch(irls == 0 ? s->g0 : s->gK, st));
+            s->last_iters += s->P.cgIterMax;
+        }
+    } else {
+        // cgTolerance > 0 or verbose: reference control flow with the host read of r.z every cgIterCheck iterations.
+        for (int irls = 0; irls < s->P.irlsIterMax; irls++) {
+            enqueue_irls_prologue(s, irls == 0);
+            for (int cg = 0;;) {
+                float rz[3];
+                HIPCHK(hipMemcpyAsync(rz, s->s_rz_next(), sizeof rz, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                const float errL2W = rz[0] + rz[1] + rz[2];
+                if (s->P.verbose)
+                    s->log("IRLS = %-3d/ %d, CG = %-4d/ %d, errL2W = %9.2e\n", irls, s->P.irlsIterMax, cg, s->P.cgIterMax, errL2W);
+                if (cg == s->P.cgIterMax || errL2W <= s->P.cgTolerance) break;
+                const int chunk = imin(s->P.cgIterCheck - cg % s->P.cgIterCheck, s->P.cgIterMax - cg);
+                enqueue_cg_unfused(s, irls == 0, chunk);
+                cg += chunk;
+                s->last_iters += chunk;
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(s->ev1, st));
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_poisson_sync(gdpt_poisson_solver *s)
+{
+    if (!s) return fail(GDPT_ERR_INVALID, "null solver");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_seconds = ms * 1.0e-3f;
+    return GDPT_OK;
+}
+
+int gdpt_poisson_solve_indirect(gdpt_poisson_solver *s)
+{
+    int rc = gdpt_poisson_solve_indirect_async(s);
+    if (rc) return rc;
+    rc = gdpt_poisson_sync(s);
+    if (rc) return rc;
+    s->log("Execution time = %.2f s\n", s->last_seconds); // Solver.cpp:500
+    return GDPT_OK;
+}
+
+static int export_common(gdpt_poisson_solver *s, float *dst, hipMemcpyKind kind)
+{
+    if (!s || !s->ready || !dst) return fail(GDPT_ERR_INVALID, "export_images before setup_backend / null destination");
+    const long n3 = 3L * s->W * s->H;
+    const float *final_ = s->x;
+    if (s->dev_direct) { // Solver.cpp:563-566: r = direct ; r = 1*r + x
+        hipLaunchKernelGGL(kg_axpy, dim3(grid_generic(n3)), dim3(BLK), 0, s->stream, s->rec, 1.0f, 1.0f, 1.0f, s->dev_direct, s->x, (int)n3);
+        final_ = s->rec;
+    }
+    HIPCHK(hipMemcpyAsync(dst, final_, sizeof(float) * n3, kind, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return GDPT_OK;
+}
+
+int gdpt_poisson_export_images(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToHost); }
+int gdpt_poisson_export_images_device(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToDevice); }
+
+int gdpt_poisson_solution_device(gdpt_poisson_solver *s, float **x)
+{
+    if (!s || !s->ready || !x) return fail(GDPT_ERR_INVALID, "no solution yet");
+    *x = s->x;
+    return GDPT_OK;
+}
+
+float gdpt_poisson_last_solve_seconds(const gdpt_poisson_solver *s) { return s ? s->last_seconds : 0.0f; }
+long gdpt_poisson_last_iterations(const gdpt_poisson_solver *s) { return s ? s->last_iters : 0; }
+void *gdpt_poisson_stream(gdpt_poisson_solver *s) { return s ? (void *)s->stream : nullptr; }
+
+int gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level)
+{
+    if (!s) return fail(GDPT_ERR_INVALID, "null solver");
+    s->fusion = level ? 1 : 0;
+    return GDPT_OK;
+}
+
+
+// Bench hook: average standalone duration (microseconds, HIP events on the handle's stream) of each CG kernel
+// at the handle's geometry: us[0] stencil (calc_Ax_xAx), us[1] calc_r_rz, us[2] calc_x_p, us[3] fused x_p+stencil
+// (0 when the geometry cannot fuse).  Clobbers the iterate: call setup_backend again before the next solve.
+int gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4])
+{
+    if (!s || !s->ready || reps < 1 || !us) return fail(GDPT_ERR_INVALID, "profile_kernels needs a set-up solver");
+    const Lattice L = s->lat();
+    const long n3 = 3 * L.n();
+    const bool unitw = s->P.irlsIterMax == 1;
+    hipStream_t st = s->stream;
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->w2, 1.0f, (size_t)n3);
+    hipLaunchKernelGGL(kg_set, dim3(16), dim3(BLK), 0, st, s->scal, 1.0f, (size_t)16);
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->p[0], 0.5f, (size_t)n3);
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->r, 0.25f, (size_t)n3);
+    const int Gt = imin(L.tiles(), MAXP);
+    int Ga = 0, Gr = 0;
+    for (int which = 0; which < 4; which++) {
+        us[which] = 0.0f;
+        if (which == 3 && !can_fuse(s)) continue;
+        for (int pass = 0; pass < 2; pass++) { // pass 0 = warm-up
+            const int R = pass ? reps : 3;
+            HIPCHK(hipEventRecord(s->ev0, st));
+            for (int k = 0; k < R; k++) {
+                if (which == 0) Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
+                if (which == 1) Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
+                if (which == 2) launch_x_p(st, n3, s->x, s->p[0], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
+                if (which == 3) {
+                    if (unitw) hipLaunchKernelGGL(kf_xp_Ax<true>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
+                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+                    else       hipLaunchKernelGGL(kf_xp_Ax<false>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
+                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+                }
+            }
+            HIPCHK(hipEventRecord(s->ev1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            float ms = 0.0f;
+            HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+            if (pass) us[which] = ms * 1000.0f / (float)R;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+// =================================================================================================
+// backend-op level
+// =================================================================================================
+
+void *gdpt_backend_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (ensure_device(-1)) return nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { fail(GDPT_ERR_HIP, "Out of memory!"); return nullptr; }
+    return p;
+}
+
+void gdpt_backend_free(void *ptr) { if (ptr) hipFree(ptr); }
+
+int gdpt_backend_set(float *x, float y, size_t numFloats, void *stream)
+{
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic((long)numFloats)), dim3(BLK), 0, (hipStream_t)stream, x, y, numFloats);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_copy(void *x, const void *y, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(x, y, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GDPT_OK;
+}
+
+int gdpt_backend_read(void *host, const void *x, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(host, x, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return GDPT_OK;
+}
+
+int gdpt_backend_write(void *x, const void *host, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(x, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return GDPT_OK;
+}
+
+int gdpt_backend_sync(void *stream)
+{
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return GDPT_OK;
+}
+
+static int lattice_ok(int w, int h)
+{
+    if (w <= 0 || h <= 0 || (long)w * h * 9 >= (1L << 31)) return fail(GDPT_ERR_INVALID, "bad lattice %dx%d", w, h);
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_Px(float *Px, int w, int h, float alpha, const float *x, void *stream)
+{
+    if (lattice_ok(w, h)) return GDPT_ERR_INVALID;
+    hipLaunchKernelGGL(kg_Px, dim3(grid_generic(3L * w * h)), dim3(BLK), 0, (hipStream_t)stream, Px, x, w, h, alpha);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_PTW2x(float *out, int w, int h, float alpha, const float *w2, const float *x, void *stream)
+{
+    if (lattice_ok(w, h)) return GDPT_ERR_INVALID;
+    hipLaunchKernelGGL(kg_PTW2x<false>, dim3(grid_generic(3L * w * h)), dim3(BLK), 0, (hipStream_t)stream, out, (float *)nullptr, (float4 *)nullptr, w2, x, w, h, alpha);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+// scratch for block partials of the op-level reductions: stream-ordered allocation
+struct PartScratch {
+    float4 *p = nullptr;
+    hipStream_t st;
+    explicit PartScratch(hipStream_t s) : st(s) { if (hipMallocAsync((void **)&p, sizeof(float4) * MAXP, st) != hipSuccess) p = nullptr; }
+    ~PartScratch() { if (p) hipFreeAsync(p, st); }
+};
+
+int gdpt_backend_calc_Ax_xAx(float *Ax, float *xAx, int w, int h, float alpha, const float *w2, const float *x, void *stream)
+{
+    if (lattice_ok(w, h)) return GDPT_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    PartScratch ps(st);
+    if (!ps.p) return fail(GDPT_ERR_HIP, "Out of memory!");
+    const int G = launch_Ax(st, Lattice{w, h, alpha}, false, Ax, ps.p, w2, x);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLK), 0, st, xAx, (float *)nullptr, ps.p, G);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_axpy(float *out, const float a[3], const float *x, const float *y, int numElems, void *stream)
+{
+    hipLaunchKernelGGL(kg_axpy, dim3(grid_generic(3L * numElems)), dim3(BLK), 0, (hipStream_t)stream, out, a[0], a[1], a[2], x, y, 3 * numElems);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_xdoty(float *xdoty, const float *x, const float *y, int numElems, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    PartScratch ps(st);
+    if (!ps.p) return fail(GDPT_ERR_HIP, "Out of memory!");
+    const int G = grid_reduce(3L * numElems);
+    hipLaunchKernelGGL(kg_xdoty, dim3(G), dim3(BLK), 0, st, ps.p, x, y, 3 * numElems);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLK), 0, st, xdoty, (float *)nullptr, ps.p, G);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_r_rz(float *r, float *rz, const float *Ap, const float *rz2, const float *pAp, int numElems, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    PartScratch ps(st);
+    if (!ps.p) return fail(GDPT_ERR_HIP, "Out of memory!");
+    const int G = launch_r_rz(st, 3L * numElems, r, ps.p, Ap, rz2, pAp, nullptr, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLK), 0, st, rz, (float *)nullptr, ps.p, G);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_x_p(float *x, float *p, const float *r, const float *rz, const float *rz2, const float *pAp, int numElems, void *stream)
+{
+    launch_x_p((hipStream_t)stream, 3L * numElems, x, p, r, rz, rz2, pAp, nullptr, 0, nullptr);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_backend_calc_w2(float *w2, const float *e, float reg, int numElems, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    PartScratch ps(st);
+    if (!ps.p) return fail(GDPT_ERR_HIP, "Out of memory!");
+    const int G = grid_reduce(numElems);
+    hipLaunchKernelGGL(kg_w2_raw, dim3(G), dim3(BLK), 0, st, w2, ps.p, e, (const float *)nullptr, (const int *)nullptr, reg, numElems);
+    hipLaunchKernelGGL(kg_w2_scale, dim3(grid_generic(numElems)), dim3(BLK), 0, st, w2, ps.p, G, (int *)nullptr, numElems);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+} // extern "C"

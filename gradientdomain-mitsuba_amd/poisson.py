@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference's `poisson::Solver` interface over the C-ABI of include/gdpt_poisson.h.
+
+Same names, argument meaning and call order as /root/reference/src/integrators/poisson_solver/Solver.hpp:
+`Params` (+ `setConfigPreset`), `Solver.importImagesMTS / setupBackend / solveIndirect / exportImagesMTS`,
+used exactly as gpt.cpp:1445-1462 uses them.  The `Backend` class mirrors the `poisson::Backend` virtuals
+(Backend.hpp:66-100) on device vectors.  All arithmetic runs in the gfx950 library; nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import GdptError, check, lib
+
+_fp = C.POINTER(C.c_float)
+
+
+class Params(C.Structure):
+    """Solver::Params (Solver.hpp:49-107), solver-configuration subset + device/verbose."""
+    _fields_ = [("alpha", C.c_float), ("irlsIterMax", C.c_int), ("irlsRegInit", C.c_float), ("irlsRegIter", C.c_float),
+                ("cgIterMax", C.c_int), ("cgIterCheck", C.c_int), ("cgPrecond", C.c_int), ("cgTolerance", C.c_float),
+                ("device", C.c_int), ("verbose", C.c_int)]
+
+    def __init__(self, preset=None, alpha=None, **kw):
+        super().__init__()
+        lib().gdpt_poisson_params_defaults(C.byref(self))      # Params::setDefaults, Solver.cpp:57-88
+        if preset is not None and not self.setConfigPreset(preset):
+            raise ValueError("unknown preset %r" % (preset,))
+        if alpha is not None:
+            self.alpha = alpha
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def setConfigPreset(self, preset):
+        """Params::setConfigPreset (Solver.cpp:94-178); returns False for an unknown name like the reference."""
+        return bool(lib().gdpt_poisson_params_preset(C.byref(self), preset.encode()))
+
+
+_LOG = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+
+
+def _ptr(a):
+    """float* of a numpy fp32 array, a torch tensor, an int address, or None."""
+    if a is None:
+        return None, None, False
+    if isinstance(a, int):
+        return C.cast(a, _fp), None, True
+    if hasattr(a, "data_ptr"):                                   # torch tensor
+        if a.dtype.__str__() != "torch.float32" or not a.is_contiguous():
+            raise TypeError("tensor must be contiguous float32")
+        return C.cast(a.data_ptr(), _fp), a, a.is_cuda
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    return arr.ctypes.data_as(_fp), arr, False
+
+
+class Solver:
+    """poisson::Solver (Solver.hpp:43-157)."""
+
+    def __init__(self, params):
+        L = lib()
+        self._h = C.c_void_p()
+        check(L.gdpt_poisson_create(C.byref(params), C.byref(self._h)))
+        self._keep = []
+        self._log = None
+        self._size = None
+
+    def setLogFunction(self, fn):
+        """Params::setLogFunction (Solver.cpp:194-197): fn(str)."""
+        self._log = _LOG(lambda msg, _user: fn(msg.decode()))
+        check(lib().gdpt_poisson_set_log(self._h, self._log, None))
+
+    def importImagesMTS(self, dx, dy, tp, direct, width, height):
+        """Solver::importImagesMTS (Solver.cpp:220-228).  Accepts host numpy arrays or device torch tensors."""
+        ptrs, keep, dev = [], [], []
+        for a in (dx, dy, tp, direct):
+            p, k, d = _ptr(a)
+            ptrs.append(p); keep.append(k)
+            if a is not None:
+                dev.append(d)
+        if len(set(dev)) > 1:
+            raise TypeError("inputs must be all host or all device")
+        self._keep = keep
+        self._size = (width, height)
+        fn = lib().gdpt_poisson_import_images_device if (dev and dev[0]) else lib().gdpt_poisson_import_images
+        check(fn(self._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], width, height))
+
+    def setupBackend(self):
+        check(lib().gdpt_poisson_setup_backend(self._h))
+
+    def solveIndirect(self):
+        check(lib().gdpt_poisson_solve_indirect(self._h))
+
+    def solveIndirectAsync(self):
+        check(lib().gdpt_poisson_solve_indirect_async(self._h))
+
+    def sync(self):
+        check(lib().gdpt_poisson_sync(self._h))
+
+    def exportImagesMTS(self, rec=None):
+        """Solver::exportImagesMTS (Solver.cpp:542-582): returns / fills 3*w*h floats."""
+        w, h = self._size
+        if rec is not None and hasattr(rec, "data_ptr"):
+            check(lib().gdpt_poisson_export_images_device(self._h, C.cast(rec.data_ptr(), _fp)))
+            return rec
+        out = np.empty(3 * w * h, np.float32) if rec is None else rec
+        check(lib().gdpt_poisson_export_images(self._h, out.ctypes.data_as(_fp)))
+        return out
+
+    def profileKernels(self, reps=50):
+        """Bench hook: mean standalone microseconds of (stencil, r_rz, x_p, fused x_p+stencil)."""
+        us = (C.c_float * 4)()
+        check(lib().gdpt_poisson_profile_kernels(self._h, int(reps), us))
+        return [float(v) for v in us]
+
+    def setFusion(self, level):
+        check(lib().gdpt_poisson_set_fusion(self._h, int(level)))
+
+    @property
+    def stream(self):
+        lib().gdpt_poisson_stream.restype = C.c_void_p
+        return lib().gdpt_poisson_stream(self._h)
+
+    @property
+    def lastSolveSeconds(self):
+        lib().gdpt_poisson_last_solve_seconds.restype = C.c_float
+        return float(lib().gdpt_poisson_last_solve_seconds(self._h))
+
+    @property
+    def lastIterations(self):
+        lib().gdpt_poisson_last_iterations.restype = C.c_long
+        return int(lib().gdpt_poisson_last_iterations(self._h))
+
+    def close(self):
+        if self._h:
+            lib().gdpt_poisson_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reconstruct(dx, dy, tp, direct, width, height, preset="L1D", alpha=0.2):
+    """The reconstruction block of GradientPathIntegrator::render (gpt.cpp:1445-1462) in one call."""
+    s = Solver(Params(preset, alpha))
+    s.importImagesMTS(dx, dy, tp, direct, width, height)
+    s.setupBackend()
+    s.solveIndirect()
+    rec = s.exportImagesMTS()
+    s.close()
+    return rec
+
+
+class Backend:
+    """poisson::Backend virtuals (Backend.hpp:66-100) on device vectors (reference layouts).  Vectors are
+    plain device addresses (ints); `upload`/`download` play Backend::write/read."""
+
+    def __init__(self, stream=None):
+        self.L = lib()
+        self.stream = C.c_void_p(stream)
+        self.L.gdpt_backend_alloc.restype = C.c_void_p
+        self.L.gdpt_backend_alloc.argtypes = [C.c_size_t]
+        self.L.gdpt_backend_free.argtypes = [C.c_void_p]
+        self._owned = []
+
+    def allocVector(self, numElems, bytesPerElem):
+        p = self.L.gdpt_backend_alloc(numElems * bytesPerElem)
+        if not p:
+            raise GdptError(self.L.gdpt_last_error().decode())
+        self._owned.append(p)
+        return p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        p = self.allocVector(arr.size, 4)
+        check(self.L.gdpt_backend_write(C.c_void_p(p), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), self.stream))
+        return p
+
+    def download(self, p, numFloats):
+        out = np.empty(numFloats, np.float32)
+        check(self.L.gdpt_backend_read(out.ctypes.data_as(C.c_void_p), C.c_void_p(p), C.c_size_t(out.nbytes), self.stream))
+        return out
+
+    def _f(self, p):
+        return C.cast(C.c_void_p(p), _fp)
+
+    def set(self, x, y, numFloats):
+        check(self.L.gdpt_backend_set(self._f(x), C.c_float(y), C.c_size_t(numFloats), self.stream))
+
+    def copy(self, x, y, nbytes):
+        check(self.L.gdpt_backend_copy(C.c_void_p(x), C.c_void_p(y), C.c_size_t(nbytes), self.stream))
+
+    def calc_Px(self, Px, w, h, alpha, x):
+        check(self.L.gdpt_backend_calc_Px(self._f(Px), w, h, C.c_float(alpha), self._f(x), self.stream))
+
+    def calc_PTW2x(self, out, w, h, alpha, w2, x):
+        check(self.L.gdpt_backend_calc_PTW2x(self._f(out), w, h, C.c_float(alpha), self._f(w2), self._f(x), self.stream))
+
+    def calc_Ax_xAx(self, Ax, xAx, w, h, alpha, w2, x):
+        check(self.L.gdpt_backend_calc_Ax_xAx(self._f(Ax), self._f(xAx), w, h, C.c_float(alpha), self._f(w2), self._f(x), self.stream))
+
+    def calc_axpy(self, out, a, x, y, numElems):
+        a3 = (C.c_float * 3)(*a)
+        check(self.L.gdpt_backend_calc_axpy(self._f(out), a3, self._f(x), self._f(y), numElems, self.stream))
+
+    def calc_xdoty(self, out, x, y, numElems):
+        check(self.L.gdpt_backend_calc_xdoty(self._f(out), self._f(x), self._f(y), numElems, self.stream))
+
+    def calc_r_rz(self, r, rz, Ap, rz2, pAp, numElems):
+        check(self.L.gdpt_backend_calc_r_rz(self._f(r), self._f(rz), self._f(Ap), self._f(rz2), self._f(pAp), numElems, self.stream))
+
+    def calc_x_p(self, x, p, r, rz, rz2, pAp, numElems):
+        check(self.L.gdpt_backend_calc_x_p(self._f(x), self._f(p), self._f(r), self._f(rz), self._f(rz2), self._f(pAp), numElems, self.stream))
+
+    def calc_w2(self, w2, e, reg, numElems):
+        check(self.L.gdpt_backend_calc_w2(self._f(w2), self._f(e), C.c_float(reg), numElems, self.stream))
+
+    def close(self):
+        for p in self._owned:
+            self.L.gdpt_backend_free(C.c_void_p(p))
+        self._owned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

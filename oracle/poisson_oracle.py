@@ -1,0 +1,134 @@
+"""oracle/poisson_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes face of oracle/poisson_oracle.c (the sequential-fp32 CPU restatement of the reference's
+`poisson::Backend` ops and `poisson::Solver` driver).  Importable only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.  PARITY UNPINNED: see the header of
+poisson_oracle.c and DESIGN.md "Oracle pinning".
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgdpt_oracle_poisson.so")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+class Params(C.Structure):
+    """Solver::Params solver-configuration fields (Solver.hpp:85-93)."""
+    _fields_ = [("alpha", C.c_float), ("irlsIterMax", C.c_int), ("irlsRegInit", C.c_float),
+                ("irlsRegIter", C.c_float), ("cgIterMax", C.c_int), ("cgIterCheck", C.c_int),
+                ("cgPrecond", C.c_int), ("cgTolerance", C.c_float)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "poisson_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.gdo_calc_Px.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, _f32p]
+        L.gdo_calc_PTW2x.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, _f32p, _f32p]
+        L.gdo_calc_Ax_xAx.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_float, _f32p, _f32p]
+        L.gdo_calc_axpy.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_long]
+        L.gdo_calc_xdoty.argtypes = [_f32p, _f32p, _f32p, C.c_long]
+        L.gdo_calc_r_rz.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_long]
+        L.gdo_calc_x_p.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_long]
+        L.gdo_calc_w2.argtypes = [_f32p, _f32p, C.c_float, C.c_long]
+        L.gdo_calc_MIx.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, _f32p, _f32p]
+        L.gdo_params_preset.argtypes = [C.POINTER(Params), C.c_char_p]
+        L.gdo_params_preset.restype = C.c_int
+        L.gdo_solve.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_int, _f32p, C.c_void_p]
+        L.gdo_solve.restype = C.c_long
+        L.gdo_synth_inputs.argtypes = [C.c_int, C.c_int, C.c_uint, _f32p, _f32p, _f32p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def preset(name, alpha=0.2):
+    p = Params()
+    if not lib().gdo_params_preset(C.byref(p), name.encode()):
+        raise ValueError("unknown preset %r" % name)
+    p.alpha = alpha
+    return p
+
+
+def calc_Px(x, w, h, alpha):
+    x = _f(x); out = np.empty(9 * w * h, np.float32)
+    lib().gdo_calc_Px(out, w, h, alpha, x); return out
+
+
+def calc_PTW2x(w2, e, w, h, alpha):
+    out = np.empty(3 * w * h, np.float32)
+    lib().gdo_calc_PTW2x(out, w, h, alpha, _f(w2), _f(e)); return out
+
+
+def calc_Ax_xAx(w2, x, w, h, alpha):
+    Ax = np.empty(3 * w * h, np.float32); s = np.empty(3, np.float32)
+    lib().gdo_calc_Ax_xAx(Ax, s, w, h, alpha, _f(w2), _f(x)); return Ax, s
+
+
+def calc_axpy(a, x, y):
+    x = _f(x); out = np.empty_like(x)
+    lib().gdo_calc_axpy(out, _f(a), x, _f(y), x.size // 3); return out
+
+
+def calc_xdoty(x, y):
+    x = _f(x); s = np.empty(3, np.float32)
+    lib().gdo_calc_xdoty(s, x, _f(y), x.size // 3); return s
+
+
+def calc_r_rz(r, Ap, rz2, pAp):
+    r = _f(r).copy(); rz = np.empty(3, np.float32)
+    lib().gdo_calc_r_rz(r, rz, _f(Ap), _f(rz2), _f(pAp), r.size // 3); return r, rz
+
+
+def calc_x_p(x, p, r, rz, rz2, pAp):
+    x = _f(x).copy(); p = _f(p).copy()
+    lib().gdo_calc_x_p(x, p, _f(r), _f(rz), _f(rz2), _f(pAp), x.size // 3); return x, p
+
+
+def calc_w2(e, reg):
+    e = _f(e); w2 = np.empty(e.size // 3, np.float32)
+    lib().gdo_calc_w2(w2, e, reg, w2.size); return w2
+
+
+def calc_MIx(w2, x, w, h, alpha):
+    out = np.empty(3 * w * h, np.float32)
+    lib().gdo_calc_MIx(out, w, h, alpha, _f(w2), _f(x)); return out
+
+
+def solve(params, dx, dy, tp, direct, w, h, return_x=False):
+    """Solver::importImagesMTS/setupBackend/solveIndirect/exportImagesMTS in one call."""
+    keep = [_f(a) if a is not None else None for a in (dx, dy, tp, direct)]
+    ptr = [a.ctypes.data_as(C.c_void_p) if a is not None else None for a in keep]
+    rec = np.empty(3 * w * h, np.float32)
+    xo = np.empty(3 * w * h, np.float32) if return_x else None
+    iters = lib().gdo_solve(C.byref(params), ptr[0], ptr[1], ptr[2], ptr[3], w, h, rec,
+                            xo.ctypes.data_as(C.c_void_p) if return_x else None)
+    return (rec, xo, iters) if return_x else rec
+
+
+def synth_inputs(w, h, seed=12345, with_direct=True):
+    """SURVEY.md 8(d) synthetic solver input (dx, dy, throughput, direct)."""
+    n3 = 3 * w * h
+    dx, dy, tp = (np.empty(n3, np.float32) for _ in range(3))
+    direct = np.empty(n3, np.float32) if with_direct else None
+    lib().gdo_synth_inputs(w, h, seed, dx, dy, tp, direct.ctypes.data_as(C.c_void_p) if with_direct else None)
+    return dx, dy, tp, direct
