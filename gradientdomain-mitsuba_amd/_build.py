@@ -5,8 +5,9 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "lib", "libgdpt_hip.so")
-SOURCES = [os.path.join(PKG, "csrc", f) for f in ("poisson_capi.hip",)]
-DEPS = SOURCES + [os.path.join(PKG, "csrc", "poisson_kernels.hip.h"), os.path.join(ROOT, "include", "gdpt_poisson.h")]
+SOURCES = [os.path.join(PKG, "csrc", f) for f in ("poisson_capi.hip", "gpt_capi.hip")]
+DEPS = SOURCES + [os.path.join(PKG, "csrc", f) for f in ("poisson_kernels.hip.h", "gpt_kernels.hip.h", "gpt_render.hip.h")] + \
+    [os.path.join(ROOT, "include", f) for f in ("gdpt_poisson.h", "gdpt_tracer.h")]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]

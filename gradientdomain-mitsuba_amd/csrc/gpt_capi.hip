@@ -1,0 +1,529 @@
+// gpt_capi.hip -- C-ABI (include/gdpt_tracer.h) over the gfx950 G-PT kernels: scene upload (host-side BVH build and
+// triangle record precomputation), film management, render/resolve/develop launches.  No CPU fallback: every image
+// value is produced by the kernels of gpt_render.hip.h.
+#include "../../include/gdpt_tracer.h"
+#include "gpt_render.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gdpt_tr;
+
+extern "C" int gdpt_internal_fail(int code, const char *msg);   // shares the thread-local error string of poisson_capi.hip
+
+namespace {
+
+int tfail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return gdpt_internal_fail(code, buf);
+}
+
+#define THIPCHK(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return tfail(GDPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct H3 { double x, y, z; };
+inline H3 h3(double x, double y, double z) { H3 r = {x, y, z}; return r; }
+inline H3 operator-(H3 a, H3 b) { return h3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline H3 operator*(H3 a, double s) { return h3(a.x * s, a.y * s, a.z * s); }
+inline double hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return h3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline double hlen(H3 a) { return std::sqrt(hdot(a, a)); }
+inline double hc(H3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline d3 to_d3(H3 a) { d3 r; r.x = a.x; r.y = a.y; r.z = a.z; return r; }
+
+inline float round_down(double v) { float f = (float)v; return ((double)f > v) ? std::nextafterf(f, -INFINITY) : f; }
+inline float round_up(double v) { float f = (float)v; return ((double)f < v) ? std::nextafterf(f, INFINITY) : f; }
+
+// TriAccel::load, reference include/mitsuba/render/triaccel.h:61-94
+void make_isect(TriIsect &ta, H3 A, H3 B, H3 C)
+{
+    static const int waldModulo[4] = {1, 2, 0, 1};
+    const H3 b = C - A, c = B - A, N = hcross(c, b);
+    int k = 0;
+    for (int j = 0; j < 3; j++)
+        if (std::fabs(hc(N, j)) > std::fabs(hc(N, k))) k = j;
+    const int u = waldModulo[k], v = waldModulo[k + 1];
+    const double n_k = hc(N, k), denom = hc(b, u) * hc(c, v) - hc(b, v) * hc(c, u);
+    std::memset(&ta, 0, sizeof ta);
+    if (denom == 0) { ta.k = 3; return; }
+    ta.k = k;
+    ta.n_u = hc(N, u) / n_k;
+    ta.n_v = hc(N, v) / n_k;
+    ta.n_d = hdot(A, N) / n_k;
+    ta.b_nu = hc(b, u) / denom;
+    ta.b_nv = -hc(b, v) / denom;
+    ta.a_u = hc(A, u);
+    ta.a_v = hc(A, v);
+    ta.c_nu = hc(c, v) / denom;
+    ta.c_nv = -hc(c, u) / denom;
+}
+
+// ---- binned-SAH BVH2 over triangle bounds ----------------------------------------------------------------
+struct Box { double lo[3], hi[3]; };
+inline Box empty_box() { Box b; for (int i = 0; i < 3; i++) { b.lo[i] = INFINITY; b.hi[i] = -INFINITY; } return b; }
+inline void grow(Box &b, const Box &o) { for (int i = 0; i < 3; i++) { b.lo[i] = std::min(b.lo[i], o.lo[i]); b.hi[i] = std::max(b.hi[i], o.hi[i]); } }
+inline double half_area(const Box &b)
+{
+    const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return (dx < 0) ? 0.0 : dx * dy + dy * dz + dz * dx;
+}
+
+struct Builder {
+    const std::vector<Box> &tb;
+    std::vector<int> order;
+    std::vector<BvhNode> nodes;
+    int maxDepth = 0;
+    explicit Builder(const std::vector<Box> &b) : tb(b), order(b.size()) { for (size_t i = 0; i < b.size(); i++) order[i] = (int)i; }
+
+    void set_bounds(BvhNode &n, const Box &b)
+    {
+        for (int i = 0; i < 3; i++) { n.lo[i] = round_down(b.lo[i]); n.hi[i] = round_up(b.hi[i]); }
+    }
+
+    int build(int first, int count, int depth)
+    {
+        const int me = (int)nodes.size();
+        nodes.push_back(BvhNode());
+        maxDepth = std::max(maxDepth, depth);
+        Box bounds = empty_box(), cb = empty_box();
+        for (int i = first; i < first + count; i++) {
+            grow(bounds, tb[order[i]]);
+            Box c;
+            for (int a = 0; a < 3; a++) c.lo[a] = c.hi[a] = 0.5 * (tb[order[i]].lo[a] + tb[order[i]].hi[a]);
+            grow(cb, c);
+        }
+        set_bounds(nodes[me], bounds);
+        int axis = -1, splitBin = -1;
+        const int NB = 16;
+        if (count > 4) {
+            double best = INFINITY;
+            for (int a = 0; a < 3; a++) {
+                const double ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0)) continue;
+                Box bb[NB];
+                int cnt[NB] = {0};
+                for (int j = 0; j < NB; j++) bb[j] = empty_box();
+                for (int i = first; i < first + count; i++) {
+                    const Box &t = tb[order[i]];
+                    int bin = (int)(NB * ((0.5 * (t.lo[a] + t.hi[a]) - cb.lo[a]) / ext));
+                    bin = std::min(NB - 1, std::max(0, bin));
+                    grow(bb[bin], t);
+                    cnt[bin]++;
+                }
+                double rightArea[NB];
+                int rightCnt[NB];
+                Box r = empty_box();
+                int rc = 0;
+                for (int j = NB - 1; j > 0; j--) { grow(r, bb[j]); rc += cnt[j]; rightArea[j] = half_area(r); rightCnt[j] = rc; }
+                Box l = empty_box();
+                int lc = 0;
+                for (int j = 0; j < NB - 1; j++) {
+                    grow(l, bb[j]);
+                    lc += cnt[j];
+                    if (lc == 0 || rightCnt[j + 1] == 0) continue;
+                    const double cost = half_area(l) * lc + rightArea[j + 1] * rightCnt[j + 1];
+                    if (cost < best) { best = cost; axis = a; splitBin = j; }
+                }
+            }
+        }
+        if (axis < 0) {
+            if (count <= 8 || depth >= STACK_DEPTH - 2) {     // leaf
+                nodes[me].a = (uint32_t)first;
+                nodes[me].b = 0x80000000u | (uint32_t)count;
+                return me;
+            }
+            // degenerate centroids: median split by index
+            const int mid = first + count / 2;
+            const int l = build(first, mid - first, depth + 1), r = build(mid, first + count - mid, depth + 1);
+            nodes[me].a = (uint32_t)l; nodes[me].b = (uint32_t)r;
+            return me;
+        }
+        const double ext = cb.hi[axis] - cb.lo[axis];
+        auto binOf = [&](int t) {
+            int bin = (int)(NB * ((0.5 * (tb[t].lo[axis] + tb[t].hi[axis]) - cb.lo[axis]) / ext));
+            return std::min(NB - 1, std::max(0, bin));
+        };
+        int *b0 = order.data() + first;
+        int *mid = std::partition(b0, b0 + count, [&](int t) { return binOf(t) <= splitBin; });
+        int nl = (int)(mid - b0);
+        if (nl == 0 || nl == count) nl = count / 2;
+        if (depth >= STACK_DEPTH - 2) {                       // depth guard: stop splitting (bounded leaf scan instead of stack overflow)
+            nodes[me].a = (uint32_t)first;
+            nodes[me].b = 0x80000000u | (uint32_t)count;
+            return me;
+        }
+        const int l = build(first, nl, depth + 1), r = build(first + nl, count - nl, depth + 1);
+        nodes[me].a = (uint32_t)l; nodes[me].b = (uint32_t)r;
+        return me;
+    }
+};
+
+template <class T>
+int upload(T **dst, const std::vector<T> &v)
+{
+    const size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 16);
+    THIPCHK(hipMalloc((void **)dst, bytes));
+    if (!v.empty()) THIPCHK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return GDPT_OK;
+}
+
+} // namespace
+
+struct gdpt_scene {
+    SceneD d;
+    std::vector<void *> allocs;
+    int device = 0;
+    int bvhDepth = 0;
+};
+
+struct gdpt_film {
+    gdpt_scene *scene = nullptr;
+    FilmD d;
+    Float *accum = nullptr;     // resolved [5][rows][W][4]
+    hipStream_t stream = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    bool resolved = false;
+};
+
+extern "C" {
+
+int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, int numMaterials, const gdpt_material *materials,
+                      int numEmitters, const gdpt_emitter *emitters, const gdpt_camera *camera, int device, gdpt_scene **out)
+{
+    if (!verts || !triMaterial || !materials || !camera || !out || numTris <= 0 || numMaterials <= 0)
+        return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
+    if (numEmitters <= 0 || !emitters) return tfail(GDPT_ERR_INVALID, "scene_create: at least one area emitter is required");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return tfail(GDPT_ERR_NO_DEVICE, "no HIP device visible: the gfx950 tracer has no CPU fallback");
+    if (device >= 0) { if (device >= count) return tfail(GDPT_ERR_INVALID, "device out of range"); THIPCHK(hipSetDevice(device)); }
+    for (int i = 0; i < numTris; i++)
+        if (triMaterial[i] < 0 || triMaterial[i] >= numMaterials) return tfail(GDPT_ERR_INVALID, "triangle %d has material %d out of range", i, triMaterial[i]);
+
+    // per-triangle bounds, BVH
+    std::vector<Box> tb(numTris);
+    for (int i = 0; i < numTris; i++) {
+        tb[i] = empty_box();
+        for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) { const double c = verts[9 * i + 3 * v + a]; tb[i].lo[a] = std::min(tb[i].lo[a], c); tb[i].hi[a] = std::max(tb[i].hi[a], c); }
+    }
+    Builder bld(tb);
+    bld.build(0, numTris, 0);
+
+    std::vector<int> emitterOf(numTris, -1);
+    for (int e = 0; e < numEmitters; e++) {
+        if (emitters[e].firstTri < 0 || emitters[e].numTris <= 0 || emitters[e].firstTri + emitters[e].numTris > numTris)
+            return tfail(GDPT_ERR_INVALID, "emitter %d triangle range out of bounds", e);
+        for (int i = 0; i < emitters[e].numTris; i++) emitterOf[emitters[e].firstTri + i] = e;
+    }
+
+    // triangle records in leaf order
+    std::vector<TriIsect> isect(numTris);
+    std::vector<TriShade> shade(numTris);
+    for (int li = 0; li < numTris; li++) {
+        const int t = bld.order[li];
+        const H3 p0 = h3(verts[9 * t], verts[9 * t + 1], verts[9 * t + 2]), p1 = h3(verts[9 * t + 3], verts[9 * t + 4], verts[9 * t + 5]),
+                 p2 = h3(verts[9 * t + 6], verts[9 * t + 7], verts[9 * t + 8]);
+        make_isect(isect[li], p0, p1, p2);
+        TriShade &s = shade[li];
+        s.p0 = to_d3(p0); s.p1 = to_d3(p1); s.p2 = to_d3(p2);
+        const H3 side1 = p1 - p0, side2 = p2 - p0;
+        H3 fn = hcross(side1, side2);
+        const double len = hlen(fn);
+        if (!(fn.x == 0 && fn.y == 0 && fn.z == 0)) fn = fn * (1.0 / len);       // skdtree.h:369-371 (Normal /= length multiplies by the reciprocal)
+        H3 sv = side1 - fn * hdot(fn, side1);                                     // computeShadingFrame, util.cpp:603-608
+        sv = sv * (1.0 / hlen(sv));
+        s.n = to_d3(fn); s.s = to_d3(sv); s.t = to_d3(hcross(fn, sv));
+        s.material = triMaterial[t];
+        s.emitter = emitterOf[t];
+        s.origIndex = t;
+        s.pad = 0;
+    }
+
+    std::vector<MaterialD> mats(numMaterials);
+    for (int i = 0; i < numMaterials; i++) {
+        const gdpt_material &m = materials[i];
+        if (m.type < 0 || m.type > 2) return tfail(GDPT_ERR_UNSUPPORTED, "material %d: BSDF type %d is not carried (diffuse/conductor/roughconductor only)", i, m.type);
+        if (m.type == 2 && (m.distribution < 0 || m.distribution > 1)) return tfail(GDPT_ERR_UNSUPPORTED, "material %d: only beckmann and ggx distributions are carried", i);
+        MaterialD &o = mats[i];
+        o.type = m.type; o.distribution = m.distribution; o.sampleVisible = m.sampleVisible; o.pad = 0;
+        o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));
+        o.eta = to_d3(h3(m.eta[0], m.eta[1], m.eta[2]));
+        o.k = to_d3(h3(m.k[0], m.k[1], m.k[2]));
+        o.alphaU = m.alphaU; o.alphaV = m.alphaV;
+    }
+
+    // emitters: DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h:95-108), scene-level emitter pdf (scene.cpp:357-380)
+    std::vector<EmitterD> ems(numEmitters);
+    std::vector<EmTri> emTris;
+    std::vector<double> emCdf, sceneCdf(1, 0.0);
+    for (int e = 0; e < numEmitters; e++) {
+        EmitterD &o = ems[e];
+        o.firstEmTri = (int)emTris.size(); o.numTris = emitters[e].numTris; o.cdfOffset = (int)emCdf.size(); o.pad = 0;
+        o.radiance = to_d3(h3(emitters[e].radiance[0], emitters[e].radiance[1], emitters[e].radiance[2]));
+        std::vector<double> cdf(1, 0.0);
+        for (int i = 0; i < o.numTris; i++) {
+            const int t = emitters[e].firstTri + i;
+            const H3 p0 = h3(verts[9 * t], verts[9 * t + 1], verts[9 * t + 2]), p1 = h3(verts[9 * t + 3], verts[9 * t + 4], verts[9 * t + 5]),
+                     p2 = h3(verts[9 * t + 6], verts[9 * t + 7], verts[9 * t + 8]);
+            EmTri et; et.p0 = to_d3(p0); et.p1 = to_d3(p1); et.p2 = to_d3(p2);
+            emTris.push_back(et);
+            cdf.push_back(cdf.back() + 0.5 * hlen(hcross(p1 - p0, p2 - p0)));
+        }
+        const double sum = cdf.back(), norm = 1.0 / sum;
+        for (size_t i = 1; i < cdf.size(); i++) cdf[i] *= norm;
+        cdf.back() = 1.0;
+        o.invSurfaceArea = 1.0 / sum;
+        emCdf.insert(emCdf.end(), cdf.begin(), cdf.end());
+        sceneCdf.push_back(sceneCdf.back() + 1.0);
+    }
+    const double sceneNorm = 1.0 / sceneCdf.back();
+    for (size_t i = 1; i < sceneCdf.size(); i++) sceneCdf[i] *= sceneNorm;
+    sceneCdf.back() = 1.0;
+
+    gdpt_scene *s = new gdpt_scene;
+    s->bvhDepth = bld.maxDepth;
+    hipGetDevice(&s->device);
+    SceneD &d = s->d;
+    std::memset(&d, 0, sizeof d);
+    BvhNode *dn; TriIsect *di; TriShade *ds; MaterialD *dm; EmitterD *de; EmTri *det; double *dc, *dsc;
+    int rc;
+    if ((rc = upload(&dn, bld.nodes)) || (rc = upload(&di, isect)) || (rc = upload(&ds, shade)) || (rc = upload(&dm, mats)) ||
+        (rc = upload(&de, ems)) || (rc = upload(&det, emTris)) || (rc = upload(&dc, emCdf)) || (rc = upload(&dsc, sceneCdf))) { delete s; return rc; }
+    s->allocs = {dn, di, ds, dm, de, det, dc, dsc};
+    d.nodes = dn; d.isect = di; d.shade = ds; d.mats = dm; d.emitters = de; d.emTris = det; d.emCdf = dc; d.emitterCdf = dsc;
+    d.emitterNormalization = sceneNorm;
+    d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = numEmitters;
+    d.ldsScene = ((size_t)d.numNodes * sizeof(BvhNode) + (size_t)numTris * sizeof(TriIsect) <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
+    CameraD &c = d.cam;
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 4; k++) c.m[4 * r + k] = camera->toWorld[4 * r + k];
+    c.nearClip = camera->nearClip; c.farClip = camera->farClip;
+    c.tanHalf = std::tan((camera->fovX * 0.5) * (GD_PI / 180.0));
+    c.aspect = (double)camera->width / (double)camera->height;
+    c.invW = 1.0 / camera->width; c.invH = 1.0 / camera->height;
+    c.width = camera->width; c.height = camera->height;
+    *out = s;
+    return GDPT_OK;
+}
+
+void gdpt_scene_destroy(gdpt_scene *s)
+{
+    if (!s) return;
+    for (void *p : s->allocs) if (p) hipFree(p);
+    delete s;
+}
+
+int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
+{
+    if (!s || !out) return tfail(GDPT_ERR_INVALID, "film_create: null argument");
+    const int W = s->d.cam.width, H = s->d.cam.height;
+    if (y0 < 0 || y1 > H || y0 >= y1) return tfail(GDPT_ERR_INVALID, "film_create: rows [%d,%d) outside the %dx%d film", y0, y1, W, H);
+    gdpt_film *f = new gdpt_film;
+    f->scene = s;
+    FilmD &d = f->d;
+    d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
+    d.recStride = (size_t)d.recRows * W;
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
+    if (hipMalloc((void **)&d.rec, sizeof(Float) * NREC * d.recStride) != hipSuccess ||
+        hipMalloc((void **)&d.spill, sizeof(Float) * 5 * d.recStride * 4) != hipSuccess ||
+        hipMalloc((void **)&d.stats, sizeof(unsigned long long) * 4) != hipSuccess ||
+        hipMalloc((void **)&f->accum, sizeof(Float) * 5 * (size_t)(y1 - y0) * W * 4) != hipSuccess) {
+        gdpt_film_destroy(f);
+        return tfail(GDPT_ERR_HIP, "Out of memory!");
+    }
+    *out = f;
+    return gdpt_film_clear(f);
+}
+
+void gdpt_film_destroy(gdpt_film *f)
+{
+    if (!f) return;
+    if (f->stream) hipStreamSynchronize(f->stream);
+    for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (f->d.rec) hipFree(f->d.rec);
+    if (f->d.spill) hipFree(f->d.spill);
+    if (f->d.stats) hipFree(f->d.stats);
+    if (f->accum) hipFree(f->accum);
+    if (f->stream) hipStreamDestroy(f->stream);
+    delete f;
+}
+
+int gdpt_film_clear(gdpt_film *f)
+{
+    if (!f) return tfail(GDPT_ERR_INVALID, "null film");
+    FilmD &d = f->d;
+    THIPCHK(hipMemsetAsync(d.rec, 0, sizeof(Float) * NREC * d.recStride, f->stream));
+    THIPCHK(hipMemsetAsync(d.spill, 0, sizeof(Float) * 5 * d.recStride * 4, f->stream));
+    THIPCHK(hipMemsetAsync(d.stats, 0, sizeof(unsigned long long) * 4, f->stream));
+    THIPCHK(hipStreamSynchronize(f->stream));
+    for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    f->events.clear();
+    f->resolved = false;
+    return GDPT_OK;
+}
+
+int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int x1, int y1, gdpt_film *f)
+{
+    if (!s || !cfg || !f || f->scene != s) return tfail(GDPT_ERR_INVALID, "render_rect: null argument or film of another scene");
+    if (x0 < 0 || x1 > f->d.W || x0 >= x1 || y0 < f->d.y0 || y1 > f->d.y1 || y0 >= y1) return tfail(GDPT_ERR_INVALID, "render_rect: rectangle outside the film rows");
+    if (cfg->spp <= 0) return tfail(GDPT_ERR_INVALID, "spp must be positive");
+    if (cfg->maxDepth <= 0 && cfg->maxDepth != -1) return tfail(GDPT_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); // gpt.cpp:1212
+    if (s->bvhDepth >= STACK_DEPTH) return tfail(GDPT_ERR_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", s->bvhDepth);
+    ConfigD c;
+    c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
+    c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    const int tilesX = (x1 - x0 + 15) / 16, tilesY = (y1 - y0 + 15) / 16;
+    hipEvent_t e0, e1;
+    THIPCHK(hipEventCreate(&e0));
+    THIPCHK(hipEventCreate(&e1));
+    THIPCHK(hipEventRecord(e0, f->stream));
+    hipLaunchKernelGGL(k_render, dim3(tilesX * tilesY), dim3(TBLK), 0, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipEventRecord(e1, f->stream));
+    f->events.push_back(std::make_pair(e0, e1));
+    f->resolved = false;
+    return GDPT_OK;
+}
+
+int gdpt_film_sync(gdpt_film *f)
+{
+    if (!f) return tfail(GDPT_ERR_INVALID, "null film");
+    THIPCHK(hipStreamSynchronize(f->stream));
+    return GDPT_OK;
+}
+
+static int ensure_resolved(gdpt_film *f)
+{
+    if (f->resolved) return GDPT_OK;
+    const int n = (f->d.y1 - f->d.y0) * f->d.W;
+    hipLaunchKernelGGL(k_resolve, dim3(std::min((n + TBLK - 1) / TBLK, 4096)), dim3(TBLK), 0, f->stream, f->d, f->accum);
+    THIPCHK(hipGetLastError());
+    f->resolved = true;
+    return GDPT_OK;
+}
+
+int gdpt_film_halo_bytes(gdpt_film *f, size_t *bytes)
+{
+    if (!f || !bytes) return tfail(GDPT_ERR_INVALID, "null argument");
+    *bytes = sizeof(Float) * ((size_t)NREC * f->d.W + (size_t)5 * f->d.W * 4);
+    return GDPT_OK;
+}
+
+int gdpt_film_pack_halo(gdpt_film *f, int which, void *devBuf)
+{
+    if (!f || !devBuf || which < 0 || which > 1) return tfail(GDPT_ERR_INVALID, "pack_halo: bad argument");
+    hipLaunchKernelGGL(k_pack_halo, dim3(64), dim3(TBLK), 0, f->stream, f->d, which, (Float *)devBuf);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipStreamSynchronize(f->stream));
+    return GDPT_OK;
+}
+
+int gdpt_film_unpack_halo(gdpt_film *f, int which, const void *devBuf)
+{
+    if (!f || !devBuf || which < 0 || which > 1) return tfail(GDPT_ERR_INVALID, "unpack_halo: bad argument");
+    hipLaunchKernelGGL(k_unpack_halo, dim3(64), dim3(TBLK), 0, f->stream, f->d, which, (const Float *)devBuf);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipStreamSynchronize(f->stream));
+    f->resolved = false;
+    return GDPT_OK;
+}
+
+int gdpt_film_accum(gdpt_film *f, double *accum)
+{
+    if (!f || !accum) return tfail(GDPT_ERR_INVALID, "film_accum: null argument");
+    int rc = ensure_resolved(f);
+    if (rc) return rc;
+    THIPCHK(hipMemcpyAsync(accum, f->accum, sizeof(Float) * 5 * (size_t)(f->d.y1 - f->d.y0) * f->d.W * 4, hipMemcpyDeviceToHost, f->stream));
+    THIPCHK(hipStreamSynchronize(f->stream));
+    return GDPT_OK;
+}
+
+int gdpt_film_develop_device(gdpt_film *f, int buffer, float *rgbDevice)
+{
+    if (!f || !rgbDevice || buffer < 0 || buffer > 4) return tfail(GDPT_ERR_INVALID, "film_develop: bad argument");
+    int rc = ensure_resolved(f);
+    if (rc) return rc;
+    const int n = (f->d.y1 - f->d.y0) * f->d.W;
+    hipLaunchKernelGGL(k_develop, dim3(std::min((n + TBLK - 1) / TBLK, 4096)), dim3(TBLK), 0, f->stream, f->accum + (size_t)buffer * n * 4, rgbDevice, n);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipStreamSynchronize(f->stream));
+    return GDPT_OK;
+}
+
+int gdpt_film_develop(gdpt_film *f, int buffer, float *rgbHost)
+{
+    if (!f || !rgbHost) return tfail(GDPT_ERR_INVALID, "film_develop: null argument");
+    const size_t n = (size_t)(f->d.y1 - f->d.y0) * f->d.W;
+    float *tmp = nullptr;
+    THIPCHK(hipMalloc((void **)&tmp, sizeof(float) * 3 * n));
+    int rc = gdpt_film_develop_device(f, buffer, tmp);
+    if (!rc && hipMemcpy(rgbHost, tmp, sizeof(float) * 3 * n, hipMemcpyDeviceToHost) != hipSuccess) rc = tfail(GDPT_ERR_HIP, "copy failed");
+    hipFree(tmp);
+    return rc;
+}
+
+int gdpt_film_stats(gdpt_film *f, unsigned long long stats[4])
+{
+    if (!f || !stats) return tfail(GDPT_ERR_INVALID, "null argument");
+    THIPCHK(hipStreamSynchronize(f->stream));
+    THIPCHK(hipMemcpy(stats, f->d.stats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return GDPT_OK;
+}
+
+float gdpt_film_render_ms(gdpt_film *f)
+{
+    if (!f) return 0.0f;
+    hipStreamSynchronize(f->stream);
+    float total = 0.0f;
+    for (auto &e : f->events) { float ms = 0.0f; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) total += ms; }
+    return total;
+}
+
+void *gdpt_film_stream(gdpt_film *f) { return f ? (void *)f->stream : nullptr; }
+
+int gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *od, int *prim, double *tp)
+{
+    if (!s || !od || !prim || !tp || numRays <= 0) return tfail(GDPT_ERR_INVALID, "scene_intersect: bad argument");
+    double *dod = nullptr, *dtp = nullptr;
+    int *dprim = nullptr;
+    THIPCHK(hipMalloc((void **)&dod, sizeof(double) * 6 * numRays));
+    THIPCHK(hipMalloc((void **)&dtp, sizeof(double) * 4 * numRays));
+    THIPCHK(hipMalloc((void **)&dprim, sizeof(int) * numRays));
+    THIPCHK(hipMemcpy(dod, od, sizeof(double) * 6 * numRays, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_intersect, dim3((numRays + TBLK - 1) / TBLK), dim3(TBLK), 0, 0, s->d, numRays, dod, dprim, dtp);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipMemcpy(prim, dprim, sizeof(int) * numRays, hipMemcpyDeviceToHost));
+    THIPCHK(hipMemcpy(tp, dtp, sizeof(double) * 4 * numRays, hipMemcpyDeviceToHost));
+    hipFree(dod); hipFree(dtp); hipFree(dprim);
+    return GDPT_OK;
+}
+
+int gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int py, int sample, double out33[33])
+{
+    if (!s || !cfg || !out33) return tfail(GDPT_ERR_INVALID, "evaluate_point: null argument");
+    ConfigD c;
+    c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
+    c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    double *d = nullptr;
+    THIPCHK(hipMalloc((void **)&d, sizeof(double) * 33));
+    hipLaunchKernelGGL(k_eval_point, dim3(1), dim3(TBLK), 0, 0, s->d, c, px, py, sample, d);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipMemcpy(out33, d, sizeof(double) * 33, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return GDPT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,698 @@
+// gpt_kernels.hip.h -- gfx950 kernels of the gradient-domain path tracer's per-pixel sampling.
+//
+// What the reference does per sample on a CPU thread (/root/reference/src/integrators/gpt/gpt.cpp:
+// renderBlock :1220-1355, evaluatePoint :397-436, evaluate :468-1180, the shifts :242-369, vertex
+// classification :176-231) and the Mitsuba pieces those call (cited inline, paths relative to
+// /root/reference/), re-designed for CDNA4:
+//
+//   * one lane = one pixel, walking its spp base paths with the four offset paths carried alongside;
+//     a wave = an 8x8 pixel tile (coherent primaries), a block = 4 waves.  Lanes whose base path has
+//     ended wait until at least GDPT_REGEN_MIN lanes of the wave are idle, then regenerate together, so
+//     both the "start a sample" code and the "bounce" code run with well-filled exec masks
+//     (persistent wavefront, no cross-lane state shuffling).
+//   * BVH2 flattened to HBM: 32-byte nodes (fp32 bounds rounded outward, tested in fp64), triangles in
+//     leaf order as 80-byte projection records (the reference's TriAccel test, triaccel.h:96-158, in fp64)
+//     plus 160-byte shading records.  Scenes whose node+triangle arrays fit the LDS budget are staged into
+//     LDS once per block; the traversal stack always lives in LDS ([level][lane], conflict-free).
+//   * fp64 throughout, like the reference's DOUBLE_PRECISION build (MI355X vector fp64 is half the fp32
+//     rate, not 1/16th).  Compiled with -ffp-contract=off.
+//   * film: per-pixel sample SUMS in HBM (31 doubles per pixel, component-major so a wave's update is one
+//     contiguous run per component) instead of 15 scattered splats per sample; a resolve kernel gathers
+//     the 4 neighbours and reproduces the ImageBlock::put arithmetic.  Samples whose box-filter footprint
+//     is not the expected single pixel (|u| within 1e-5 of a pixel edge) take an exact generic path with
+//     fp64 atomics into a spill film.
+//   * random numbers: one SplitMix64 counter stream per (seed, pixel, sample); double in [0,1) from the top
+//     52 bits as Random::nextFloat does (src/libcore/random.cpp).  Consumption order per sample = SURVEY A.4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gdpt_tr {
+
+typedef double Float;
+#define GD_EPSILON        1e-7                 /* include/mitsuba/core/constants.h:25 (double build) */
+#define GD_SHADOW_EPSILON 1e-5                 /* constants.h:26 */
+#define GD_DELTA_EPSILON  ((double)1e-3f)      /* constants.h:31 */
+#define GD_D_EPSILON      1e-14                /* gpt.cpp:63 */
+#define GD_PI             3.14159265358979323846
+#define GD_INV_PI         0.31830988618379067154
+#define GD_INF            (__builtin_huge_val())
+
+constexpr int TBLK = 256;          // threads per block (16x16 px)
+constexpr int STACK_DEPTH = 28;    // BVH traversal stack entries per lane (LDS)
+constexpr int REGEN_MIN = 24;      // idle lanes in a wave before they regenerate together
+constexpr int NREC = 31;           // per-pixel record components
+constexpr int LDS_SCENE_BYTES = 40 * 1024;
+
+struct d3 { Float x, y, z; };
+__device__ __forceinline__ d3 mk(Float x, Float y, Float z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 mk(Float a) { return mk(a, a, a); }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator-(d3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ d3 operator*(d3 a, Float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ d3 operator*(Float s, d3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ d3 operator*(d3 a, d3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ d3 operator/(d3 a, Float s) { const Float r = 1.0 / s; return mk(a.x * r, a.y * r, a.z * r); } // TVector3::operator/ multiplies by the reciprocal
+__device__ __forceinline__ Float dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ Float len2(d3 a) { return dot(a, a); }
+__device__ __forceinline__ Float len(d3 a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ d3 normalize(d3 a) { return a / len(a); }
+__device__ __forceinline__ Float maxc(d3 a) { return fmax(a.x, fmax(a.y, a.z)); }
+__device__ __forceinline__ Float safe_sqrt(Float v) { return sqrt(fmax(0.0, v)); }
+__device__ __forceinline__ Float signum(Float v) { return v < 0 ? -1.0 : (v > 0 ? 1.0 : 0.0); }
+__device__ __forceinline__ Float comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// ---- device scene ---------------------------------------------------------------------------------
+struct BvhNode {            // 32 B.  leaf: b has the top bit set, a = first triangle, b & 0x7fffffff = count
+    float lo[3], hi[3];
+    uint32_t a, b;
+};
+struct TriIsect {           // 80 B: the reference's TriAccel (triaccel.h:37-57) in fp64
+    Float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_nv;
+    int k, pad;
+};
+struct TriShade {           // 160 B: what fillIntersectionRecord needs (skdtree.h:343-428), constant per flat triangle
+    d3 p0, p1, p2;
+    d3 n, s, t;             // shading frame == geometric frame normal for meshes without vertex normals
+    int material, emitter;  // emitter = -1 if none
+    int origIndex, pad;
+};
+struct MaterialD {
+    int type, distribution, sampleVisible, pad;
+    d3 reflectance, eta, k;
+    Float alphaU, alphaV;
+};
+struct EmitterD {
+    int firstEmTri, numTris, cdfOffset, pad;
+    d3 radiance;
+    Float invSurfaceArea;
+};
+struct EmTri { d3 p0, p1, p2; };
+struct CameraD {
+    Float m[12];            // rows of the 3x4 camera-to-world
+    Float nearClip, farClip, tanHalf, aspect, invW, invH;
+    int width, height;
+};
+struct SceneD {
+    const BvhNode *nodes;
+    const TriIsect *isect;
+    const TriShade *shade;
+    const MaterialD *mats;
+    const EmitterD *emitters;
+    const EmTri *emTris;
+    const Float *emCdf;         // per-emitter triangle-area cdfs, concatenated
+    const Float *emitterCdf;    // scene-level emitter cdf (numEmitters + 1)
+    Float emitterNormalization;
+    int numNodes, numTris, numEmitters, ldsScene;
+    CameraD cam;
+};
+struct ConfigD {
+    int maxDepth, rrDepth, strictNormals, spp;
+    Float shiftThreshold;
+    unsigned long long seed;
+};
+struct FilmD {
+    Float *rec;                 // [NREC][recRows][W] per-pixel sample sums; row index = y - (y0 - 1)
+    Float *spill;               // [5][recRows][W][4] exact generic puts (R,G,B,weight)
+    unsigned long long *stats;  // [4]
+    int W, H, y0, y1, recRows;
+    size_t recStride;           // recRows * W
+};
+
+// ---- RNG --------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t s;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t pixel, uint64_t sample)
+    {
+        s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
+        s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+    }
+    __device__ __forceinline__ Float next1D()
+    {
+        s += 0x9E3779B97F4A7C15ULL;
+        return __longlong_as_double((long long)((mix64(s) >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+    }
+};
+
+// ---- frames -------------------------------------------------------------------------------------------
+struct Frame3 { d3 s, t, n; };
+__device__ __forceinline__ d3 toLocal(const Frame3 &f, d3 v) { return mk(dot(v, f.s), dot(v, f.t), dot(v, f.n)); }
+__device__ __forceinline__ d3 toWorld(const Frame3 &f, d3 v) { return f.s * v.x + f.t * v.y + f.n * v.z; }
+__device__ __forceinline__ Float tanTheta(d3 v) { const Float t = 1 - v.z * v.z; return t <= 0.0 ? 0.0 : sqrt(t) / v.z; } // frame.h:122
+
+// ---- ray / hit ----------------------------------------------------------------------------------------
+struct Hit { Float t, u, v; int prim; };   // prim = index in leaf order, -1 = miss
+
+// Scene accessors: LDS-staged copy for small scenes, HBM otherwise.
+struct SceneView {
+    const BvhNode *nodes;
+    const TriIsect *isect;
+};
+
+// TriAccel::rayIntersect, triaccel.h:96-158
+__device__ __forceinline__ bool tri_test(const TriIsect &ta, d3 o, d3 d, Float mint, Float maxt, Float &u, Float &v, Float &t)
+{
+    Float o_u, o_v, o_k, d_u, d_v, d_k;
+    if (ta.k == 0) { o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; }
+    else if (ta.k == 1) { o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; }
+    else if (ta.k == 2) { o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; }
+    else return false;
+    t = (ta.n_d - o_u * ta.n_u - o_v * ta.n_v - o_k) / (d_u * ta.n_u + d_v * ta.n_v + d_k);
+    if (t < mint || t > maxt) return false;
+    const Float hu = o_u + t * d_u - ta.a_u;
+    const Float hv = o_v + t * d_v - ta.a_v;
+    u = hv * ta.b_nu + hu * ta.b_nv;
+    v = hu * ta.c_nu + hv * ta.c_nv;
+    return u >= 0 && v >= 0 && u + v <= 1.0;
+}
+
+// fp64 slab test against fp32 bounds that were rounded outward on the host (so no true hit is ever culled).
+__device__ __forceinline__ bool box_test(const BvhNode &n, d3 o, d3 rd, Float mint, Float maxt, Float &tn)
+{
+    Float t0 = ((Float)n.lo[0] - o.x) * rd.x, t1 = ((Float)n.hi[0] - o.x) * rd.x;
+    Float tmin = fmin(t0, t1), tmax = fmax(t0, t1);
+    t0 = ((Float)n.lo[1] - o.y) * rd.y; t1 = ((Float)n.hi[1] - o.y) * rd.y;
+    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    t0 = ((Float)n.lo[2] - o.z) * rd.z; t1 = ((Float)n.hi[2] - o.z) * rd.z;
+    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    tn = tmin;
+    // widen by 2 ulp-ish so that fp64 rounding in the slab arithmetic itself cannot cull a boundary hit
+    return tmin <= fmin(tmax, maxt) * (1.0 + 4e-16) + 1e-300 && tmax * (1.0 + 4e-16) >= mint;
+}
+
+// ShapeKDTree::rayIntersect (closest, skdtree.cpp:112-142) / rayIntersect(ray) (shadow, :207-226) on the BVH.
+// The adaptive epsilon of :126-129 / :214-217 is applied by the callers (ray_mint_*).  Returns closest hit
+// (ANY = false) or whether anything is hit (ANY = true).
+template <bool ANY>
+__device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_DEPTH][TBLK] + tid */, d3 o, d3 d, Float mint, Float maxt, Hit &hit)
+{
+    hit.prim = -1;
+    hit.t = GD_INF;
+    if (!(maxt > mint)) return false;
+    const d3 rd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    int sp = 0;
+    uint32_t node = 0;
+    {
+        Float tn;
+        if (!box_test(sv.nodes[0], o, rd, mint, maxt, tn)) return false;
+    }
+    while (true) {
+        const BvhNode n = sv.nodes[node];
+        if (n.b & 0x80000000u) {
+            const uint32_t cnt = n.b & 0x7fffffffu;
+            for (uint32_t i = 0; i < cnt; i++) {
+                Float u, v, t;
+                if (tri_test(sv.isect[n.a + i], o, d, mint, maxt, u, v, t)) {
+                    if (ANY) return true;
+                    maxt = t;
+                    hit.t = t; hit.u = u; hit.v = v; hit.prim = (int)(n.a + i);
+                }
+            }
+        } else {
+            Float tl, tr;
+            const bool hl = box_test(sv.nodes[n.a], o, rd, mint, maxt, tl);
+            const bool hr = box_test(sv.nodes[n.b], o, rd, mint, maxt, tr);
+            if (hl && hr) {
+                const bool leftFirst = tl <= tr;
+                if (sp < STACK_DEPTH) { stack[sp * TBLK] = leftFirst ? n.b : n.a; sp++; }
+                node = leftFirst ? n.a : n.b;
+                continue;
+            } else if (hl) { node = n.a; continue; }
+            else if (hr) { node = n.b; continue; }
+        }
+        if (sp == 0) break;
+        sp--;
+        node = (uint32_t)stack[sp * TBLK];
+    }
+    return hit.prim >= 0;
+}
+
+__device__ __forceinline__ Float ray_mint_closest(d3 o, Float mint)
+{ // skdtree.cpp:126-129
+    if (mint == GD_EPSILON) mint *= fmax(fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), GD_EPSILON);
+    return mint;
+}
+__device__ __forceinline__ Float ray_mint_shadow(d3 o, Float mint)
+{ // skdtree.cpp:214-217 (no floor)
+    if (mint == GD_EPSILON) mint *= fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    return mint;
+}
+
+// ---- warps (src/libcore/warp.cpp) ----------------------------------------------------------------------
+__device__ __forceinline__ d3 squareToCosineHemisphere(Float sx, Float sy)
+{ // warp.cpp:43-52, 81-102
+    const Float r1 = 2.0 * sx - 1.0, r2 = 2.0 * sy - 1.0;
+    Float phi, r;
+    if (r1 == 0 && r2 == 0) { r = phi = 0; }
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (GD_PI / 4.0) * (r2 / r1); }
+    else { r = r2; phi = (GD_PI / 2.0) - (r1 / r2) * (GD_PI / 4.0); }
+    const Float px = r * cos(phi), py = r * sin(phi);
+    Float z = safe_sqrt(1.0 - px * px - py * py);
+    if (z == 0) z = (Float)1e-10f;
+    return mk(px, py, z);
+}
+
+// ---- Fresnel (util.cpp:739-761, per channel) ----------------------------------------------------------------
+__device__ __forceinline__ Float fresnel1(Float cosThetaI, Float e, Float kk)
+{
+    const Float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    const Float temp1 = e * e - kk * kk - sinThetaI2;
+    const Float a2pb2 = safe_sqrt(temp1 * temp1 + kk * kk * e * e * 4);
+    const Float a = safe_sqrt((a2pb2 + temp1) * 0.5);
+    const Float term1 = a2pb2 + cosThetaI2, term2 = a * (2 * cosThetaI);
+    const Float Rs2 = (term1 - term2) / (term1 + term2);
+    const Float term3 = a2pb2 * cosThetaI2 + sinThetaI4, term4 = term2 * sinThetaI2;
+    const Float Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+    return 0.5 * (Rp2 + Rs2);
+}
+__device__ __forceinline__ d3 fresnelConductorExact(Float c, d3 eta, d3 k) { return mk(fresnel1(c, eta.x, k.x), fresnel1(c, eta.y, k.y), fresnel1(c, eta.z, k.z)); }
+
+// ---- math.cpp:25-72 -----------------------------------------------------------------------------------------
+__device__ __forceinline__ Float erfinv_m(Float x)
+{
+    Float w = -log((1.0 - x) * (1.0 + x)), p;
+    if (w < 5.0) {
+        w = w - 2.5;
+        p = 2.81022636e-08; p = 3.43273939e-07 + p * w; p = -3.5233877e-06 + p * w; p = -4.39150654e-06 + p * w;
+        p = 0.00021858087 + p * w; p = -0.00125372503 + p * w; p = -0.00417768164 + p * w; p = 0.246640727 + p * w; p = 1.50140941 + p * w;
+    } else {
+        w = sqrt(w) - 3.0;
+        p = -0.000200214257; p = 0.000100950558 + p * w; p = 0.00134934322 + p * w; p = -0.00367342844 + p * w;
+        p = 0.00573950773 + p * w; p = -0.0076224613 + p * w; p = 0.00943887047 + p * w; p = 1.00167406 + p * w; p = 2.83297682 + p * w;
+    }
+    return p * x;
+}
+__device__ __forceinline__ Float erf_m(Float x)
+{
+    const Float a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429, p = 0.3275911;
+    const Float sign = signum(x);
+    x = fabs(x);
+    const Float t = 1.0 / (1.0 + p * x);
+    const Float y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * exp(-x * x);
+    return sign * y;
+}
+__device__ __forceinline__ Float hypot2(Float a, Float b)
+{
+    Float r;
+    if (fabs(a) > fabs(b)) { r = b / a; r = fabs(a) * sqrt(1.0 + r * r); }
+    else if (b != 0.0) { r = a / b; r = fabs(b) * sqrt(1.0 + r * r); }
+    else r = 0.0;
+    return r;
+}
+
+// ---- MicrofacetDistribution (src/bsdfs/microfacet.h), Beckmann and GGX ---------------------------------------
+struct Mf { int type; Float aU, aV; bool sv; };
+__device__ __forceinline__ Mf mf_of(const MaterialD &m) { Mf d; d.type = m.distribution; d.aU = fmax(m.alphaU, (Float)1e-4f); d.aV = fmax(m.alphaV, (Float)1e-4f); d.sv = m.sampleVisible != 0; return d; } // :70-71
+__device__ __forceinline__ Float mf_eval(const Mf &d, d3 m)
+{ // :191-234
+    if (m.z <= 0) return 0.0;
+    const Float cosTheta2 = m.z * m.z;
+    const Float be = ((m.x * m.x) / (d.aU * d.aU) + (m.y * m.y) / (d.aV * d.aV)) / cosTheta2;
+    Float result;
+    if (d.type == 0) result = exp(-be) / (GD_PI * d.aU * d.aV * cosTheta2 * cosTheta2);
+    else { const Float root = (1.0 + be) * cosTheta2; result = 1.0 / (GD_PI * d.aU * d.aV * root * root); }
+    if (result * m.z < (Float)1e-20f) result = 0;
+    return result;
+}
+__device__ __forceinline__ Float mf_projectRoughness(const Mf &d, d3 v)
+{ // :531-541
+    const Float invSinTheta2 = 1 / (1.0 - v.z * v.z);
+    if (d.aU == d.aV || invSinTheta2 <= 0) return d.aU;
+    const Float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+    return sqrt(cosPhi2 * d.aU * d.aU + sinPhi2 * d.aV * d.aV);
+}
+__device__ __forceinline__ Float mf_G1(const Mf &d, d3 v, d3 m)
+{ // :477-514
+    if (dot(v, m) * v.z <= 0) return 0.0;
+    const Float tanT = fabs(tanTheta(v));
+    if (tanT == 0.0) return 1.0;
+    const Float alpha = mf_projectRoughness(d, v);
+    if (d.type == 0) {
+        const Float a = 1.0 / (alpha * tanT);
+        if (a >= (Float)1.6f) return 1.0;
+        const Float aSqr = a * a;
+        return ((Float)3.535f * a + (Float)2.181f * aSqr) / (1.0 + (Float)2.276f * a + (Float)2.577f * aSqr);
+    }
+    const Float root = alpha * tanT;
+    return 2.0 / (1.0 + hypot2(1.0, root));
+}
+__device__ __forceinline__ Float mf_pdfVisible(const Mf &d, d3 wi, d3 m)
+{ // :470-474
+    if (wi.z == 0) return 0.0;
+    return mf_G1(d, wi, m) * fabs(dot(wi, m)) * mf_eval(d, m) / fabs(wi.z);
+}
+__device__ void mf_sampleVisible11(const Mf &d, Float thetaI, Float sx, Float sy, Float &slx, Float &sly)
+{ // :573-702
+    const Float SQRT_PI_INV = 1 / sqrt(GD_PI);
+    if (d.type == 0) {
+        if (thetaI < (Float)1e-4f) {
+            const Float r = sqrt(-log(1.0 - sx)), ph = 2 * GD_PI * sy;
+            slx = r * cos(ph); sly = r * sin(ph);
+            return;
+        }
+        const Float tanThetaI = tan(thetaI), cotThetaI = 1 / tanThetaI;
+        Float a = -1, c = erf_m(cotThetaI);
+        const Float sample_x = fmax(sx, (Float)1e-6f);
+        const Float fit = 1 + thetaI * ((Float)-0.876f + thetaI * ((Float)0.4265f - (Float)0.0594f * thetaI));
+        Float b = c - (1 + c) * pow(1 - sample_x, fit);
+        const Float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * exp(-cotThetaI * cotThetaI));
+        int it = 0;
+        while (++it < 10) {
+            if (!(b >= a && b <= c)) b = 0.5 * (a + c);
+            const Float invErf = erfinv_m(b);
+            const Float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * exp(-invErf * invErf)) - sample_x;
+            const Float derivative = normalization * (1 - invErf * tanThetaI);
+            if (fabs(value) < (Float)1e-5f) break;
+            if (value > 0) c = b; else a = b;
+            b -= value / derivative;
+        }
+        slx = erfinv_m(b);
+        sly = erfinv_m(2.0 * fmax(sy, (Float)1e-6f) - 1.0);
+        return;
+    }
+    if (thetaI < (Float)1e-4f) {
+        const Float r = safe_sqrt(sx / (1 - sx)), ph = 2 * GD_PI * sy;
+        slx = r * cos(ph); sly = r * sin(ph);
+        return;
+    }
+    const Float tanThetaI = tan(thetaI), a = 1 / tanThetaI;
+    const Float G1 = 2.0 / (1.0 + safe_sqrt(1.0 + 1.0 / (a * a)));
+    Float A = 2.0 * sx / G1 - 1.0;
+    if (fabs(A) == 1) A -= signum(A) * GD_EPSILON;
+    const Float tmp = 1.0 / (A * A - 1.0);
+    const Float B = tanThetaI;
+    const Float D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+    const Float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
+    slx = (A < 0.0 || slope_x_2 > 1.0 / tanThetaI) ? slope_x_1 : slope_x_2;
+    Float S;
+    if (sy > (Float)0.5f) { S = 1.0; sy = 2.0 * (sy - 0.5); }
+    else { S = -1.0; sy = 2.0 * (0.5 - sy); }
+    const Float z = (sy * (sy * (sy * (-0.365728915865723) + 0.790235037209296) - 0.424965825137544) + 0.000152998850436920) /
+                    (sy * (sy * (sy * (sy * 0.169507819808272 - 0.397203533833404) - 0.232500544458471) + 1) - 0.539825872510702);
+    sly = S * z * sqrt(1.0 + slx * slx);
+}
+__device__ d3 mf_sample(const Mf &d, d3 _wi, Float sx, Float sy, Float &pdf)
+{ // :240-250 -> sampleVisible :421-467 / sampleAll :300-414
+    if (d.sv) {
+        const d3 wi = normalize(mk(d.aU * _wi.x, d.aV * _wi.y, _wi.z));
+        Float theta = 0, phi = 0;
+        if (wi.z < (Float)0.99999) { theta = acos(wi.z); phi = atan2(wi.y, wi.x); }
+        const Float sinPhi = sin(phi), cosPhi = cos(phi);
+        Float slx, sly;
+        mf_sampleVisible11(d, theta, sx, sy, slx, sly);
+        Float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+        rx *= d.aU; ry *= d.aV;
+        const Float normalization = 1.0 / sqrt(rx * rx + ry * ry + 1.0);
+        const d3 m = mk(-rx * normalization, -ry * normalization, normalization);
+        pdf = mf_pdfVisible(d, _wi, m);
+        return m;
+    }
+    Float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
+    if (d.aU == d.aV) {
+        const Float ph = (2.0 * GD_PI) * sy;
+        sinPhiM = sin(ph); cosPhiM = cos(ph);
+        alphaSqr = d.aU * d.aU;
+    } else {
+        const Float phiM = atan(d.aV / d.aU * tan(GD_PI + 2 * GD_PI * sy)) + GD_PI * floor(2 * sy + 0.5);
+        sinPhiM = sin(phiM); cosPhiM = cos(phiM);
+        const Float cosSc = cosPhiM / d.aU, sinSc = sinPhiM / d.aV;
+        alphaSqr = 1.0 / (cosSc * cosSc + sinSc * sinSc);
+    }
+    if (d.type == 0) {
+        const Float tanThetaMSqr = alphaSqr * -log(1.0 - sx);
+        cosThetaM = 1.0 / sqrt(1.0 + tanThetaMSqr);
+        pdf = (1.0 - sx) / (GD_PI * d.aU * d.aV * cosThetaM * cosThetaM * cosThetaM);
+    } else {
+        const Float tanThetaMSqr = alphaSqr * sx / (1.0 - sx);
+        cosThetaM = 1.0 / sqrt(1.0 + tanThetaMSqr);
+        const Float temp = 1 + tanThetaMSqr / alphaSqr;
+        pdf = GD_INV_PI / (d.aU * d.aV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+    }
+    if (pdf < (Float)1e-20f) pdf = 0;
+    const Float sinThetaM = sqrt(fmax(0.0, 1 - cosThetaM * cosThetaM));
+    return mk(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+}
+
+// ---- BSDFs --------------------------------------------------------------------------------------------------
+enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, ESmooth = 0x5, EDelta = 0x10 };
+enum { MEASURE_SOLID_ANGLE = 0, MEASURE_DISCRETE = 1 };
+__device__ __forceinline__ int bsdfType(const MaterialD &m) { return m.type == 0 ? EDiffuseReflection : (m.type == 1 ? EDeltaReflection : EGlossyReflection); }
+
+// BSDF::eval and BSDF::pdf together (every call site of the hot path wants both):
+// diffuse.cpp:110-127, conductor.cpp:223-254, roughconductor.cpp:257-319
+__device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 &f, Float &pdf)
+{
+    f = mk(0.0); pdf = 0.0;
+    if (wi.z <= 0 || wo.z <= 0) return;
+    if (m.type == 0) {
+        if (measure != MEASURE_SOLID_ANGLE) return;
+        f = m.reflectance * (GD_INV_PI * wo.z);
+        pdf = GD_INV_PI * wo.z;
+    } else if (m.type == 1) {
+        if (measure != MEASURE_DISCRETE || fabs(dot(mk(-wi.x, -wi.y, wi.z), wo) - 1) > GD_DELTA_EPSILON) return;
+        f = m.reflectance * fresnelConductorExact(wi.z, m.eta, m.k);
+        pdf = 1.0;
+    } else {
+        if (measure != MEASURE_SOLID_ANGLE) return;
+        const d3 H = normalize(wo + wi);
+        const Mf d = mf_of(m);
+        const Float D = mf_eval(d, H);
+        const Float G1i = mf_G1(d, wi, H);
+        if (d.sv) pdf = D * G1i / (4.0 * wi.z);
+        else pdf = (D * H.z) / (4 * fabs(dot(wo, H)));
+        if (D == 0) return;
+        const d3 F = fresnelConductorExact(dot(wi, H), m.eta, m.k) * m.reflectance;
+        const Float G = G1i * mf_G1(d, wo, H);
+        const Float model = D * G / (4.0 * wi.z);
+        f = F * model;
+    }
+}
+
+struct BSDFSample { d3 wo, weight; Float pdf; int sampledType; };
+// the pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
+__device__ void bsdf_sample(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
+{
+    r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.sampledType = 0;   // gpt.cpp:450-454: pdf starts at 0
+    if (m.type == 0) {
+        if (wi.z <= 0) return;
+        r.wo = squareToCosineHemisphere(sx, sy);
+        r.sampledType = EDiffuseReflection;
+        r.pdf = GD_INV_PI * r.wo.z;
+        r.weight = m.reflectance;
+    } else if (m.type == 1) {
+        if (wi.z <= 0) return;
+        r.sampledType = EDeltaReflection;
+        r.wo = mk(-wi.x, -wi.y, wi.z);
+        r.pdf = 1;
+        r.weight = m.reflectance * fresnelConductorExact(wi.z, m.eta, m.k);
+    } else {
+        if (wi.z < 0) return;
+        const Mf d = mf_of(m);
+        Float temporaryPdf = 0;
+        const d3 mm = mf_sample(d, wi, sx, sy, temporaryPdf);
+        if (temporaryPdf == 0) return;
+        r.wo = 2 * dot(wi, mm) * mm - wi;
+        r.sampledType = EGlossyReflection;
+        if (r.wo.z <= 0) return;
+        const d3 F = fresnelConductorExact(dot(wi, mm), m.eta, m.k) * m.reflectance;
+        Float weight;
+        if (d.sv) weight = mf_G1(d, r.wo, mm);
+        else weight = mf_eval(d, mm) * (mf_G1(d, wi, mm) * mf_G1(d, r.wo, mm)) * dot(wi, mm) / (temporaryPdf * wi.z);
+        if (weight > 0) {
+            r.pdf = temporaryPdf / (4.0 * dot(r.wo, mm));
+            r.weight = F * weight;
+        }
+    }
+}
+
+// getVertexType (gpt.cpp:176-231) for single-component BSDFs; getRoughness: diffuse.cpp:167, conductor.cpp:275, roughconductor.cpp:437
+__device__ __forceinline__ bool vertex_is_diffuse(const MaterialD &m, const ConfigD &cfg, int bsdfTypeMask)
+{
+    const Float r = m.type == 0 ? GD_INF : (m.type == 1 ? 0.0 : 0.5 * (m.alphaU + m.alphaV));
+    Float lowest = GD_INF;
+    bool found_smooth = false, found_dirac = false, skip = false;
+    if (r == 0) { found_dirac = true; if (!(bsdfTypeMask & EDelta)) skip = true; }
+    else found_smooth = true;
+    if (!skip && r < lowest) lowest = r;
+    if (!found_smooth && found_dirac && !(bsdfTypeMask & EDelta)) lowest = 0;
+    return !(lowest <= cfg.shiftThreshold);
+}
+
+// ---- emitters -----------------------------------------------------------------------------------------------
+struct DRec { d3 ref, refN, p, n, d; Float dist, pdf; int object; };
+
+__device__ __forceinline__ int cdf_sample(const Float *cdf, int n /*entries = n+1*/, Float v)
+{ // DiscreteDistribution::sample, pmf.h:110-123: lower_bound, step back one, skip zero-probability entries
+    int lo = 0, hi = n + 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] < v) lo = mid + 1; else hi = mid; }
+    int index = lo - 1;
+    if (index < 0) index = 0;
+    if (index > n - 1) index = n - 1;
+    while ((cdf[index + 1] - cdf[index]) == 0 && index < n) ++index;
+    return index;
+}
+
+// Scene::sampleEmitterDirectVisible (scene.cpp:855-879) minus the shadow ray, which the caller casts:
+// AreaLight::sampleDirect (area.cpp:158-172) -> Shape::sampleDirect (shape.cpp:102-116) -> TriMesh::samplePosition
+// (trimesh.cpp:412-423) -> Triangle::sample (triangle.cpp:24-).  Returns value (already / emPdf); dRec.pdf includes emPdf.
+__device__ d3 sample_emitter_direct(const SceneD &S, DRec &dRec, Float sx, Float sy)
+{
+    const int index = cdf_sample(S.emitterCdf, S.numEmitters, sx);
+    const Float emPdf = S.emitterCdf[index + 1] - S.emitterCdf[index];
+    sx = (sx - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
+    const EmitterD em = S.emitters[index];
+    const Float *cdf = S.emCdf + em.cdfOffset;
+    const int ti = cdf_sample(cdf, em.numTris, sy);
+    sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
+    const EmTri tr = S.emTris[em.firstEmTri + ti];
+    const Float a = safe_sqrt(1.0 - sx);                  // warp.cpp:76-79
+    const Float bx = 1 - a, by = a * sy;
+    const d3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
+    dRec.p = tr.p0 + (sideA * bx) + (sideB * by);
+    dRec.n = normalize(cross(sideA, sideB));
+    dRec.pdf = em.invSurfaceArea;
+    dRec.d = dRec.p - dRec.ref;
+    const Float distSquared = len2(dRec.d);
+    dRec.dist = sqrt(distSquared);
+    dRec.d = dRec.d / dRec.dist;
+    const Float dp = fabs(dot(dRec.d, dRec.n));
+    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0;
+    d3 value;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = em.radiance / dRec.pdf;
+    else { dRec.pdf = 0.0; value = mk(0.0); }
+    dRec.object = index;
+    dRec.pdf *= emPdf;
+    value = value / emPdf;
+    return value;
+}
+
+// Scene::pdfEmitterDirect, scene.cpp:976-979 -> area.cpp:174-183 -> shape.cpp:118-126 (solid-angle measure)
+__device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, int object, d3 d, d3 refN, d3 n, Float dist)
+{
+    Float pd = 0.0;
+    if (dot(d, refN) >= 0 && dot(d, n) < 0) pd = S.emitters[object].invSurfaceArea * (dist * dist) / fabs(dot(d, n));
+    return pd * (1.0 * S.emitterNormalization);
+}
+
+// ---- sensor: perspective.cpp:271-298 with the composite of :150-156 written out for crop == film ----------------
+__device__ __forceinline__ void camera_ray(const CameraD &c, Float px, Float py, d3 &o, d3 &d, Float &mint, Float &maxt)
+{
+    const Float sxn = px * c.invW, syn = py * c.invH;
+    const d3 nearP = mk((1 - 2 * sxn) * c.nearClip * c.tanHalf, (1 - 2 * syn) / c.aspect * c.nearClip * c.tanHalf, c.nearClip);
+    const d3 dl = normalize(nearP);
+    const Float invZ = 1.0 / dl.z;
+    mint = c.nearClip * invZ;
+    maxt = c.farClip * invZ;
+    o = mk(c.m[3], c.m[7], c.m[11]);
+    d = mk(c.m[0] * dl.x + c.m[1] * dl.y + c.m[2] * dl.z, c.m[4] * dl.x + c.m[5] * dl.y + c.m[6] * dl.z, c.m[8] * dl.x + c.m[9] * dl.y + c.m[10] * dl.z);
+}
+
+// ---- shifts -------------------------------------------------------------------------------------------------
+// halfVectorShift, gpt.cpp:242-305, reflection branch (no carried BSDF transmits); returns false for a would-be refraction
+__device__ __forceinline__ bool half_vector_shift(d3 mainWi, d3 mainWo, d3 shiftedWi, Float &jacobian, d3 &wo)
+{
+    if (mainWi.z * mainWo.z < 0) return false;       // refraction with eta == 1 on both sides: gpt.cpp:249-253
+    const d3 h = normalize(mainWi + mainWo);
+    wo = 2 * dot(shiftedWi, h) * h - shiftedWi;       // reflect(), util.cpp:763
+    jacobian = fabs(dot(wo, h) / dot(mainWo, h));
+    return true;
+}
+
+// ---- per-lane path state ------------------------------------------------------------------------------------
+enum { RAY_NOT_CONNECTED = 0, RAY_RECENTLY_CONNECTED = 1, RAY_CONNECTED = 2 };   // gpt.cpp:127-131
+
+struct Vertex {             // the part of Mitsuba's Intersection the path needs
+    d3 p, wi;               // position, incident direction in the shading frame
+    int prim;               // leaf-order triangle, -1 = invalid
+};
+struct Offset {             // RayState of an offset path, gpt.cpp:135-173
+    d3 throughput, radiance, gradient;
+    Float pdf;
+    Vertex v;
+    d3 rayD;                // direction of the ray that arrived at v
+    int alive, status;
+};
+
+__device__ __forceinline__ Frame3 frame_of(const TriShade &t) { Frame3 f; f.s = t.s; f.t = t.t; f.n = t.n; return f; }
+
+// fillIntersectionRecord<true>, skdtree.h:343-428 (flat triangle): barycentric position, wi in the shading frame
+__device__ __forceinline__ void fill_vertex(const SceneD &S, const Hit &h, d3 rayD, Vertex &v)
+{
+    v.prim = h.prim;
+    if (h.prim < 0) return;
+    const TriShade &ts = S.shade[h.prim];
+    const d3 b = mk(1 - h.u - h.v, h.u, h.v);
+    v.p = ts.p0 * b.x + ts.p1 * b.y + ts.p2 * b.z;
+    v.wi = toLocal(frame_of(ts), -rayD);
+}
+
+// AreaLight::eval via Intersection::Le, area.cpp:104-109
+__device__ __forceinline__ d3 emitted(const SceneD &S, int prim, d3 d)
+{
+    const TriShade &ts = S.shade[prim];
+    if (ts.emitter < 0 || dot(ts.n, d) <= 0) return mk(0.0);
+    return S.emitters[ts.emitter].radiance;
+}
+
+// ---- film ---------------------------------------------------------------------------------------------------
+// record components: 0 count | 1..3 T | 4..6 veryDirect | 7+3d+c neighbour throughput d | 19+3d+c gradient d, d = R,B,L,T
+struct FilterD { Float radius, scale, c; };     // box.cpp:38, rfilter.cpp:37-55: every in-range table entry == c = 1/(2r)
+__device__ __forceinline__ FilterD box_filter()
+{
+    FilterD f;
+    f.radius = 0.5 + (Float)1e-5f;
+    f.scale = 31 / f.radius;
+    Float sum = 0;
+    for (int i = 0; i < 31; i++) sum += 1.0;
+    sum *= 2 * f.radius / 31;
+    f.c = 1.0 * (1.0 / sum);
+    return f;
+}
+__device__ __forceinline__ Float eval_discretized(const FilterD &f, Float x)
+{ // rfilter.h:76-77
+    int idx = (int)fabs(x * f.scale);
+    if (idx > 31) idx = 31;
+    return idx < 31 ? f.c : 0.0;
+}
+
+// ImageBlock::put (imageblock.h:150-199) restricted to the film, with fp64 atomics: the exact generic path.
+__device__ void spill_put(const FilmD &F, const FilterD &flt, Float px, Float py, d3 spec, Float weight, int b)
+{
+    const Float posx = px - 0.5, posy = py - 0.5;
+    int x0 = (int)ceil(posx - flt.radius), y0 = (int)ceil(posy - flt.radius);
+    int x1 = (int)floor(posx + flt.radius), y1 = (int)floor(posy + flt.radius);
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > F.W - 1) x1 = F.W - 1;
+    if (y1 > F.H - 1) y1 = F.H - 1;
+    for (int y = y0; y <= y1; ++y) {
+        if (y < F.y0 - 1 || y > F.y1) continue;               // outside this film's rows + halo: another strip's sample
+        const Float wy = eval_discretized(flt, y - posy);
+        for (int x = x0; x <= x1; ++x) {
+            const Float w = eval_discretized(flt, x - posx) * wy;
+            Float *dest = F.spill + (((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4;
+            atomicAdd(dest + 0, w * spec.x);
+            atomicAdd(dest + 1, w * spec.y);
+            atomicAdd(dest + 2, w * spec.z);
+            atomicAdd(dest + 3, w * weight);
+        }
+    }
+}
+
+// true iff the put at (px,py) covers exactly pixel (ex,ey) before clipping
+__device__ __forceinline__ bool single_pixel(const FilterD &flt, Float px, Float py, int ex, int ey)
+{
+    const Float posx = px - 0.5, posy = py - 0.5;
+    return (int)ceil(posx - flt.radius) == ex && (int)floor(posx + flt.radius) == ex &&
+           (int)ceil(posy - flt.radius) == ey && (int)floor(posy + flt.radius) == ey;
+}
+
+} // namespace gdpt_tr

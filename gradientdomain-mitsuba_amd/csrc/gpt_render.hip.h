@@ -1,0 +1,559 @@
+// gpt_render.hip.h -- the render / resolve / develop kernels of the gfx950 G-PT sampler.
+// See gpt_kernels.hip.h for the design notes and the device-side restatements these kernels call.
+#pragma once
+#include "gpt_kernels.hip.h"
+
+namespace gdpt_tr {
+
+struct Lane {
+    // base path ("main" RayState, gpt.cpp:135-173)
+    d3 throughput, radiance;
+    Float pdf, eta;
+    Vertex v;
+    d3 rayO, rayD;
+    Float depthT;           // ray parameter of the last base-path hit (Intersection::t)
+    int depth;
+    Offset off[4];
+    d3 veryDirect;
+    Float sx, sy;
+    Rng rng;
+    unsigned nClosest, nShadow;
+};
+
+__device__ __forceinline__ bool cast_shadow(const SceneView &sv, int *stack, Lane &L, d3 o, d3 d, Float maxt)
+{
+    Hit h;
+    L.nShadow++;
+    return trace<true>(sv, stack, o, d, ray_mint_shadow(o, GD_EPSILON), maxt, h);
+}
+
+// testVisibility, gpt.cpp:84-93: unnormalised direction, maxt = 1 - ShadowEpsilon
+__device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack, Lane &L, d3 p1, d3 p2)
+{
+    return !cast_shadow(sv, stack, L, p1, p2 - p1, 1.0 - GD_SHADOW_EPSILON);
+}
+
+// Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
+// Returns false if the base path is already over.
+__device__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, int px, int py, int sample)
+{
+    const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
+    L.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
+    L.sx = px + L.rng.next1D();                                                  // gpt.cpp:1261
+    L.sy = py + L.rng.next1D();
+    L.throughput = mk(1.0); L.radiance = mk(0.0); L.pdf = 1.0; L.eta = 1.0; L.veryDirect = mk(0.0); L.depth = 1;
+#pragma unroll 1
+    for (int r = 0; r < 5; r++) {
+        d3 o, d;
+        Float mint, maxt;
+        camera_ray(S.cam, L.sx + (r ? shx[r - 1] : 0.0), L.sy + (r ? shy[r - 1] : 0.0), o, d, mint, maxt);
+        Hit h;
+        L.nClosest++;
+        trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, h);
+        if (r == 0) { fill_vertex(S, h, d, L.v); L.rayO = o; L.rayD = d; }
+        else {
+            Offset &s = L.off[r - 1];
+            fill_vertex(S, h, d, s.v);
+            s.rayD = d;
+            s.throughput = mk(1.0); s.radiance = mk(0.0); s.gradient = mk(0.0); s.pdf = 1.0;
+            s.alive = h.prim >= 0;                                               // :508-513
+            s.status = RAY_NOT_CONNECTED;
+        }
+    }
+    if (L.v.prim < 0) return false;                                              // :482-492 (no environment emitter)
+    L.veryDirect = L.veryDirect + L.throughput * emitted(S, L.v.prim, -L.rayD);  // :497-499
+    if (cfg.strictNormals) {                                                     // :516-531
+        if (dot(L.rayD, S.shade[L.v.prim].n) * L.v.wi.z >= 0) return false;
+        for (int i = 0; i < 4; i++) {
+            Offset &s = L.off[i];
+            if (s.alive && dot(s.rayD, S.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
+        }
+    }
+    return true;
+}
+
+// One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
+__device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L)
+{
+    if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
+    const TriShade &mts = S.shade[L.v.prim];
+    const Frame3 mfr = frame_of(mts);
+    const d3 mGeoN = mts.n;
+    if (cfg.strictNormals) {                                                     // :541-556
+        if (dot(L.rayD, mGeoN) * L.v.wi.z >= 0) return false;
+        for (int i = 0; i < 4; i++) {
+            Offset &s = L.off[i];
+            if (s.alive && dot(s.rayD, S.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
+        }
+    }
+    const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
+    const MaterialD &mainBSDF = S.mats[mts.material];
+
+    // ================= direct illumination sampling, :565-730 =================
+    if (bsdfType(mainBSDF) & ESmooth) {
+        DRec dRec;
+        dRec.ref = L.v.p; dRec.refN = mfr.n;                                     // records.inl:160-164
+        const Float lsx = L.rng.next1D(), lsy = L.rng.next1D();                  // :572
+        d3 value = sample_emitter_direct(S, dRec, lsx, lsy);
+        const bool mainEmitterVisible = !cast_shadow(sv, stack, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
+        if (!mainEmitterVisible) value = mk(0.0);
+        const d3 mainEmitterRadiance = value * dRec.pdf;                         // :575
+        const d3 mainWoL = toLocal(mfr, dRec.d);
+        d3 mainBSDFValue;
+        Float mainBsdfPdfRaw;
+        bsdf_eval_pdf(mainBSDF, L.v.wi, mainWoL, MEASURE_SOLID_ANGLE, mainBSDFValue, mainBsdfPdfRaw);   // :588
+        const Float mainBsdfPdf = mainEmitterVisible ? mainBsdfPdfRaw : 0;       // :592
+        const Float mainDistanceSquared = len2(L.v.p - dRec.p);
+        const Float mainOpposingCosine = dot(dRec.n, (L.v.p - dRec.p)) / sqrt(mainDistanceSquared);
+        const Float mainWeightNumerator = L.pdf * dRec.pdf;                      // :599-600
+        const Float mainWeightDenominator = (L.pdf * L.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
+        const d3 mainContributionAll = L.throughput * (mainBSDFValue * mainEmitterRadiance);
+        if (!cfg.strictNormals || dot(mGeoN, dRec.d) * mainWoL.z > 0) {         // :607
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) {
+                Offset &s = L.off[i];
+                d3 shiftedContribution = mk(0.0);
+                Float weight = 0;
+                bool assigned = false;          // false: weight and both contributions stay 0 (:613-615 with no branch taken)
+                bool shiftSuccessful = s.alive != 0;
+                if (shiftSuccessful) {
+                    if (s.status == RAY_CONNECTED) {                             // :622-637
+                        const Float den = (s.pdf * s.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
+                        weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                        shiftedContribution = 1.0 * s.throughput * (mainBSDFValue * mainEmitterRadiance);
+                        assigned = true;
+                    } else if (s.status == RAY_RECENTLY_CONNECTED) {             // :638-658
+                        const d3 incoming = normalize(s.v.p - L.v.p);
+                        d3 f;
+                        Float pdfRaw;
+                        bsdf_eval_pdf(mainBSDF, toLocal(mfr, incoming), toLocal(mfr, dRec.d), MEASURE_SOLID_ANGLE, f, pdfRaw);
+                        const Float shiftedBsdfPdf = mainEmitterVisible ? pdfRaw : 0;
+                        const Float den = (s.pdf * s.pdf) * ((dRec.pdf * dRec.pdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                        weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                        shiftedContribution = 1.0 * s.throughput * (f * mainEmitterRadiance);
+                        assigned = true;
+                    } else {                                                     // :659-705
+                        const TriShade &sts = S.shade[s.v.prim];
+                        const MaterialD &shiftedBSDF = S.mats[sts.material];
+                        if (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth)) {
+                            const Frame3 sfr = frame_of(sts);
+                            DRec sRec;
+                            sRec.ref = s.v.p; sRec.refN = sfr.n;
+                            d3 sv_ = sample_emitter_direct(S, sRec, lsx, lsy);
+                            const bool shiftedEmitterVisible = !cast_shadow(sv, stack, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
+                            if (!shiftedEmitterVisible) sv_ = mk(0.0);
+                            const d3 shiftedEmitterRadiance = sv_ * sRec.pdf;
+                            const Float shiftedDRecPdf = sRec.pdf;
+                            const Float shiftedDistanceSquared = len2(dRec.p - s.v.p);
+                            const d3 emitterDirection = (dRec.p - s.v.p) / sqrt(shiftedDistanceSquared);
+                            const Float shiftedOpposingCosine = -dot(dRec.n, emitterDirection);
+                            const d3 woL = toLocal(sfr, emitterDirection);
+                            if (cfg.strictNormals && dot(sts.n, emitterDirection) * woL.z < 0) {
+                                shiftSuccessful = false;
+                            } else {
+                                d3 f;
+                                Float pdfRaw;
+                                bsdf_eval_pdf(shiftedBSDF, s.v.wi, woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
+                                const Float shiftedBsdfPdf = shiftedEmitterVisible ? pdfRaw : 0;
+                                const Float jacobian = fabs(shiftedOpposingCosine * mainDistanceSquared) / (GD_EPSILON + fabs(mainOpposingCosine * shiftedDistanceSquared)); // :695
+                                const Float den = (jacobian * s.pdf) * (jacobian * s.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                                weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                                shiftedContribution = jacobian * s.throughput * (f * shiftedEmitterRadiance);
+                                assigned = true;
+                            }
+                        }
+                    }
+                }
+                if (!shiftSuccessful) {                                          // :708-717
+                    weight = mainWeightNumerator / (GD_D_EPSILON + mainWeightDenominator);
+                    shiftedContribution = mk(0.0);
+                    assigned = true;
+                }
+                const d3 mainContribution = assigned ? mainContributionAll : mk(0.0);
+                L.radiance = L.radiance + mainContribution * weight;              // :723-726
+                s.radiance = s.radiance + shiftedContribution * weight;
+                s.gradient = s.gradient + (shiftedContribution - mainContribution) * weight;
+            }
+        }
+    }
+
+    // ================= BSDF sampling and emitter hits, :737-1151 =================
+    const Float bsx = L.rng.next1D(), bsy = L.rng.next1D();                      // :456
+    BSDFSample bs;
+    bsdf_sample(mainBSDF, L.v.wi, bsx, bsy, bs);
+    if (bs.pdf <= 0.0) return false;                                             // :740
+    const d3 mainWo = toWorld(mfr, bs.wo);
+    if (cfg.strictNormals && dot(mGeoN, mainWo) * bs.wo.z <= 0) return false;    // :749
+    const d3 prevP = L.v.p, prevWi = L.v.wi;                                      // previousMainIts, :754
+    const bool mainVertexDiffuse = vertex_is_diffuse(mainBSDF, cfg, bs.sampledType);     // :765
+    L.rayO = prevP;
+    L.rayD = mainWo;                                                              // :768
+    {
+        Hit h;
+        L.nClosest++;
+        trace<false>(sv, stack, L.rayO, L.rayD, ray_mint_closest(L.rayO, GD_EPSILON), GD_INF, h);
+        if (h.prim < 0) return false;                                            // :802-804 (no environment)
+        fill_vertex(S, h, L.rayD, L.v);
+        L.depthT = h.t;
+    }
+    const TriShade &nts = S.shade[L.v.prim];
+    const bool mainHitEmitter = nts.emitter >= 0;                                 // :772-777
+    const d3 mainEmitterRadiance = mainHitEmitter ? emitted(S, L.v.prim, -L.rayD) : mk(0.0);
+    const bool mainNextVertexDiffuse = vertex_is_diffuse(S.mats[nts.material], cfg, bs.sampledType);  // :785
+    const Float mainBsdfPdf = bs.pdf, mainPreviousPdf = L.pdf;
+    L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
+    L.pdf *= bs.pdf;
+    // mainDRec: ref = previous vertex, refN = its shading normal; setQuery (records.inl:170-178): p, n, d, dist
+    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, nts.emitter, L.rayD, mfr.n, nts.n, L.depthT) : 0;  // :815
+    const Float mainWeightNumerator = mainPreviousPdf * bs.pdf;                   // :819-820
+    const Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
+    const d3 mainContribution = L.throughput * mainEmitterRadiance;
+    const int measure = (bs.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
+
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {                                                // :830
+        Offset &s = L.off[i];
+        d3 shiftedContribution = mk(0.0);
+        Float weight = 0;
+        bool assigned = false;
+        bool postponedShiftEnd = false;
+        if (s.alive) {
+            const Float shiftedPreviousPdf = s.pdf;
+            if (s.status == RAY_CONNECTED) {                                     // :844-861
+                s.throughput = s.throughput * (bs.weight * bs.pdf);
+                s.pdf *= mainBsdfPdf;
+                const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
+                weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                shiftedContribution = s.throughput * mainEmitterRadiance;
+                assigned = true;
+            } else if (s.status == RAY_RECENTLY_CONNECTED) {                     // :862-888
+                const d3 incoming = normalize(s.v.p - L.rayO);
+                d3 f;
+                Float shiftedBsdfPdf;
+                bsdf_eval_pdf(mainBSDF, toLocal(mfr, incoming), toLocal(mfr, L.rayD), measure, f, shiftedBsdfPdf);
+                s.throughput = s.throughput * f;
+                s.pdf *= shiftedBsdfPdf;
+                s.status = RAY_CONNECTED;
+                const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((mainLumPdf * mainLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                shiftedContribution = s.throughput * mainEmitterRadiance;
+                assigned = true;
+            } else {                                                             // :889-1126
+                const TriShade &sts = S.shade[s.v.prim];
+                const MaterialD &shiftedBSDF = S.mats[sts.material];
+                const Frame3 sfr = frame_of(sts);
+                const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
+                if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
+                    // ---- reconnection shift, :897-986 ----
+                    if (!lastSegment || mainHitEmitter) {                        // :901
+                        // reconnectShift, gpt.cpp:316-345
+                        if (!test_visibility(sv, stack, L, s.v.p, L.v.p)) { s.alive = 0; }
+                        else {
+                            const d3 mainEdge = L.rayO - L.v.p, shiftedEdge = s.v.p - L.v.p;
+                            const Float mainEdgeLengthSquared = len2(mainEdge), shiftedEdgeLengthSquared = len2(shiftedEdge);
+                            const d3 shiftedWo = -shiftedEdge / sqrt(shiftedEdgeLengthSquared);
+                            const Float mainOpposingCosine = dot(mainEdge, nts.n) / sqrt(mainEdgeLengthSquared);
+                            const Float shiftedOpposingCosine = dot(shiftedWo, nts.n);
+                            const Float jacobian = fabs(shiftedOpposingCosine * mainEdgeLengthSquared) / (GD_D_EPSILON + fabs(mainOpposingCosine * shiftedEdgeLengthSquared));
+                            const d3 woL = toLocal(sfr, shiftedWo);
+                            if (cfg.strictNormals && dot(shiftedWo, sts.n) * woL.z <= 0) { s.alive = 0; }
+                            else {
+                                d3 f;
+                                Float shiftedBsdfPdf;
+                                bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, shiftedBsdfPdf);
+                                s.throughput = s.throughput * (f * jacobian);    // :939-940
+                                s.pdf *= shiftedBsdfPdf * jacobian;
+                                s.status = RAY_RECENTLY_CONNECTED;
+                                if (mainHitEmitter) {                            // :944-986
+                                    const d3 shiftedEmitterRadiance = emitted(S, L.v.prim, -shiftedWo);
+                                    const Float sdist = len(L.v.p - s.v.p);
+                                    const d3 sd = (L.v.p - s.v.p) / sdist;
+                                    const Float shiftedLumPdf = pdf_emitter_direct(S, nts.emitter, sd, sfr.n, nts.n, sdist);
+                                    const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                                    weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                                    shiftedContribution = s.throughput * shiftedEmitterRadiance;
+                                    assigned = true;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // ---- half-vector duplication shift, :987-1126 ----
+                    d3 shiftedEmitterRadiance = mk(0.0);
+                    const d3 tsIn = toLocal(sfr, -s.rayD);
+                    const bool bothDelta = (bs.sampledType & EDelta) && (bsdfType(shiftedBSDF) & EDelta);     // :996-1001
+                    const bool bothSmooth = (bs.sampledType & ESmooth) && (bsdfType(shiftedBSDF) & ESmooth);
+                    bool ok = bothDelta || bothSmooth;
+                    d3 tsOut = mk(0.0);
+                    if (ok) {
+                        Float jacobian;
+                        ok = half_vector_shift(prevWi, bs.wo, tsIn, jacobian, tsOut);
+                        if (bs.sampledType & EDelta) jacobian = 1;               // :1008-1011
+                        if (ok) { s.throughput = s.throughput * jacobian; s.pdf *= jacobian; }
+                    }
+                    if (ok) {
+                        const d3 outgoing = toWorld(sfr, tsOut);
+                        d3 f;
+                        Float p;
+                        bsdf_eval_pdf(shiftedBSDF, tsIn, tsOut, measure, f, p);
+                        s.throughput = s.throughput * f;
+                        s.pdf *= p;
+                        if (s.pdf == 0) ok = false;                              // :1034
+                        else if (cfg.strictNormals && dot(outgoing, sts.n) * tsOut.z <= 0) ok = false;
+                        else {
+                            Hit h;
+                            L.nClosest++;
+                            trace<false>(sv, stack, s.v.p, outgoing, ray_mint_closest(s.v.p, GD_EPSILON), GD_INF, h);   // :1050-1052
+                            if (h.prim < 0) ok = false;                          // :1056-1058 (no environment)
+                            else {
+                                s.rayD = outgoing;
+                                fill_vertex(S, h, outgoing, s.v);
+                                const TriShade &snts = S.shade[s.v.prim];
+                                const bool shiftedNextVertexDiffuse = vertex_is_diffuse(S.mats[snts.material], cfg, bs.sampledType);
+                                if (mainVertexDiffuse && shiftedVertexDiffuse && shiftedNextVertexDiffuse) ok = false;   // :1089-1093
+                                else if (snts.emitter >= 0) shiftedEmitterRadiance = emitted(S, s.v.prim, -outgoing);
+                            }
+                        }
+                    }
+                    if (ok) {                                                    // :1106-1112
+                        weight = L.pdf / (s.pdf * s.pdf + L.pdf * L.pdf);
+                        shiftedContribution = s.throughput * shiftedEmitterRadiance;
+                    } else {                                                     // :1113-1124
+                        weight = 1.0 / L.pdf;
+                        shiftedContribution = mk(0.0);
+                        postponedShiftEnd = true;                                // alive stays true for this accumulation
+                    }
+                    assigned = true;
+                }
+            }
+        }
+        if (!s.alive) {                                                          // :1130-1136 (shift_failed)
+            weight = mainWeightNumerator / (GD_D_EPSILON + mainWeightDenominator);
+            shiftedContribution = mk(0.0);
+            assigned = true;
+        }
+        const d3 mc = assigned ? mainContribution : mk(0.0);
+        L.radiance = L.radiance + mc * weight;                                   // :1140-1146
+        s.radiance = s.radiance + shiftedContribution * weight;
+        s.gradient = s.gradient + (shiftedContribution - mc) * weight;
+        if (postponedShiftEnd) s.alive = 0;
+    }
+
+    if (L.depth++ >= cfg.rrDepth) {                                              // :1159-1174
+        const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
+        if (L.rng.next1D() >= q) return false;
+        L.pdf *= q;
+        for (int i = 0; i < 4; i++) L.off[i].pdf *= q;
+    }
+    return true;
+}
+
+// Accumulates one finished sample: the 15 puts of gpt.cpp:1314-1352.  Fast path = per-pixel sums (every put covers
+// exactly its expected pixel); otherwise the exact generic path.
+__device__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, int px, int py)
+{
+    enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
+    const bool fast = single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
+                      single_pixel(flt, L.sx + 1, L.sy, px + 1, py) && single_pixel(flt, L.sx, L.sy - 1, px, py - 1) &&
+                      single_pixel(flt, L.sx, L.sy + 1, px, py + 1);
+    if (fast) {
+        Float *r = F.rec + (size_t)(py - (F.y0 - 1)) * F.W + px;
+        const size_t st = F.recStride;
+        r[0] += 1.0;
+        r[1 * st] += L.radiance.x; r[2 * st] += L.radiance.y; r[3 * st] += L.radiance.z;
+        r[4 * st] += L.veryDirect.x; r[5 * st] += L.veryDirect.y; r[6 * st] += L.veryDirect.z;
+#pragma unroll 1
+        for (int d = 0; d < 4; d++) {
+            const Offset &s = L.off[d];
+            r[(7 + 3 * d) * st] += s.radiance.x; r[(8 + 3 * d) * st] += s.radiance.y; r[(9 + 3 * d) * st] += s.radiance.z;
+            r[(19 + 3 * d) * st] += s.gradient.x; r[(20 + 3 * d) * st] += s.gradient.y; r[(21 + 3 * d) * st] += s.gradient.z;
+        }
+    } else {
+        const d3 T = L.radiance, vd = L.veryDirect;
+        const Float sx = L.sx, sy = L.sy;
+        spill_put(F, flt, sx, sy, (8 * vd) + (2 * T), 4.0, 0);
+        spill_put(F, flt, sx - 1, sy, 2 * L.off[LEFT].radiance, 1.0, 0);
+        spill_put(F, flt, sx + 1, sy, 2 * L.off[RIGHT].radiance, 1.0, 0);
+        spill_put(F, flt, sx, sy - 1, 2 * L.off[TOP].radiance, 1.0, 0);
+        spill_put(F, flt, sx, sy + 1, 2 * L.off[BOTTOM].radiance, 1.0, 0);
+        spill_put(F, flt, sx, sy, 2 * T, 4.0, 1);
+        spill_put(F, flt, sx - 1, sy, 2 * L.off[LEFT].radiance, 1.0, 1);
+        spill_put(F, flt, sx + 1, sy, 2 * L.off[RIGHT].radiance, 1.0, 1);
+        spill_put(F, flt, sx, sy - 1, 2 * L.off[TOP].radiance, 1.0, 1);
+        spill_put(F, flt, sx, sy + 1, 2 * L.off[BOTTOM].radiance, 1.0, 1);
+        spill_put(F, flt, sx - 1, sy, -(2 * L.off[LEFT].gradient), 1.0, 2);
+        spill_put(F, flt, sx, sy, 2 * L.off[RIGHT].gradient, 1.0, 2);
+        spill_put(F, flt, sx, sy - 1, -(2 * L.off[TOP].gradient), 1.0, 3);
+        spill_put(F, flt, sx, sy, 2 * L.off[BOTTOM].gradient, 1.0, 3);
+        spill_put(F, flt, sx, sy, vd, 1.0, 4);
+    }
+}
+
+__global__ __launch_bounds__(TBLK) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE_BYTES];
+    SceneView sv;
+    if (S.ldsScene) {
+        // stage node packets and triangle records through LDS once per block (coalesced 16-byte copies)
+        const int nodeBytes = S.numNodes * (int)sizeof(BvhNode), triBytes = S.numTris * (int)sizeof(TriIsect);
+        const uint4 *gn = reinterpret_cast<const uint4 *>(S.nodes), *gt = reinterpret_cast<const uint4 *>(S.isect);
+        uint4 *ln = reinterpret_cast<uint4 *>(s_scene), *lt = reinterpret_cast<uint4 *>(s_scene + nodeBytes);
+        for (int i = threadIdx.x; i < nodeBytes / 16; i += TBLK) ln[i] = gn[i];
+        for (int i = threadIdx.x; i < triBytes / 16; i += TBLK) lt[i] = gt[i];
+        __syncthreads();
+        sv.nodes = reinterpret_cast<const BvhNode *>(s_scene);
+        sv.isect = reinterpret_cast<const TriIsect *>(s_scene + nodeBytes);
+    } else { sv.nodes = S.nodes; sv.isect = S.isect; }
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = px < rx1 && py < ry1;
+    int *stack = s_stack + threadIdx.x;
+    const FilterD flt = box_filter();
+
+    Lane L;
+    L.nClosest = L.nShadow = 0;
+    int next = valid ? 0 : cfg.spp;     // next sample to start
+    bool active = false;
+    unsigned long long pathLen = 0, paths = 0;
+    while (true) {
+        const bool idle = !active;
+        const unsigned long long idleMask = __ballot(idle);
+        const unsigned long long wantMask = __ballot(idle && next < cfg.spp);
+        if (wantMask == 0 && idleMask == ~0ULL) break;
+        // regenerate together: when enough lanes wait, or nothing else is running in this wave
+        if (idle && next < cfg.spp && (__popcll(wantMask) >= REGEN_MIN || idleMask == ~0ULL)) {
+            active = start_path(S, sv, cfg, stack, L, px, py, next);
+            next++;
+            if (!active) { finish_path(F, flt, L, px, py); paths++; pathLen += L.depth; }
+        }
+        if (active) {
+            if (!bounce(S, sv, cfg, stack, L)) {
+                active = false;
+                finish_path(F, flt, L, px, py);
+                paths++; pathLen += L.depth;
+            }
+        }
+    }
+    // statistics: wave-level integer reduction, one atomic per wave and counter
+    const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
+    const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
+    if (lane == 0) {
+        atomicAdd(&F.stats[0], (unsigned long long)c0);
+        atomicAdd(&F.stats[1], (unsigned long long)c1);
+        atomicAdd(&F.stats[2], (unsigned long long)c2);
+        atomicAdd(&F.stats[3], (unsigned long long)c3);
+    }
+}
+
+// ---- resolve: per-pixel sums -> the five accumulation buffers, as 15 puts per sample would have produced -------------
+// out[5][rows][W][4] (R,G,B,weight), rows = y1 - y0.
+__global__ __launch_bounds__(TBLK) void k_resolve(FilmD F, Float *__restrict__ out)
+{
+    const FilterD flt = box_filter();
+    const Float w = flt.c * flt.c;                        // weightX * weightY of imageblock.h:186-191
+    const int rows = F.y1 - F.y0;
+    const int n = rows * F.W;
+    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n; i += gridDim.x * TBLK) {
+        const int x = i % F.W, y = F.y0 + i / F.W;
+        const size_t st = F.recStride;
+        auto rec = [&](int xx, int yy, int k) -> Float {
+            if (xx < 0 || xx >= F.W || yy < 0 || yy >= F.H) return 0.0;
+            return F.rec[(size_t)k * st + (size_t)(yy - (F.y0 - 1)) * F.W + xx];
+        };
+        const Float cnt = rec(x, y, 0);
+        const Float cL = rec(x - 1, y, 0), cR = rec(x + 1, y, 0), cT = rec(x, y - 1, 0), cB = rec(x, y + 1, 0);
+        Float o[5][4];
+        for (int c = 0; c < 3; c++) {
+            const Float T = rec(x, y, 1 + c), vd = rec(x, y, 4 + c);
+            // neighbour throughput landing here: sample at x-1 shifts RIGHT(0); at x+1 LEFT(2); at y-1 BOTTOM(1); at y+1 TOP(3)
+            const Float nb = 2 * rec(x - 1, y, 7 + 0 + c) + 2 * rec(x + 1, y, 7 + 6 + c) + 2 * rec(x, y - 1, 7 + 3 + c) + 2 * rec(x, y + 1, 7 + 9 + c);
+            o[0][c] = w * ((8 * vd + 2 * T) + nb);
+            o[1][c] = w * (2 * T + nb);
+            o[2][c] = w * (2 * rec(x, y, 19 + 0 + c) - 2 * rec(x + 1, y, 19 + 6 + c));      // +2 g_RIGHT here, -2 g_LEFT of the sample at x+1
+            o[3][c] = w * (2 * rec(x, y, 19 + 3 + c) - 2 * rec(x, y + 1, 19 + 9 + c));      // +2 g_BOTTOM here, -2 g_TOP of the sample at y+1
+            o[4][c] = w * vd;
+        }
+        o[0][3] = o[1][3] = w * (4 * cnt + cL + cR + cT + cB);
+        o[2][3] = w * (cnt + cR);
+        o[3][3] = w * (cnt + cB);
+        o[4][3] = w * cnt;
+        for (int b = 0; b < 5; b++)
+            for (int k = 0; k < 4; k++) {
+                const size_t si = (((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4 + k;
+                out[(((size_t)b * rows + (y - F.y0)) * F.W + x) * 4 + k] = o[b][k] + F.spill[si];
+            }
+    }
+}
+
+// MultiFilm::developMulti: rgb * (w != 0 ? 1/w : w) (fmtconv.cpp:955-1058), cast to fp32 (gpt.cpp:1439-1442)
+__global__ __launch_bounds__(TBLK) void k_develop(const Float *__restrict__ accumBuf /* [n][4] */, float *__restrict__ rgb, int n)
+{
+    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n; i += gridDim.x * TBLK) {
+        const Float wgt = accumBuf[4 * (size_t)i + 3], inv = (wgt != 0) ? 1.0 / wgt : wgt;
+        for (int c = 0; c < 3; c++) rgb[3 * (size_t)i + c] = (float)(accumBuf[4 * (size_t)i + c] * inv);
+    }
+}
+
+// halo exchange payload: [NREC][W] records of an owned boundary row, then [5][W][4] spill of the halo row beyond it
+__global__ __launch_bounds__(TBLK) void k_pack_halo(FilmD F, int which, Float *__restrict__ buf)
+{
+    const int ownRow = which == 0 ? F.y0 : F.y1 - 1, haloRow = which == 0 ? F.y0 - 1 : F.y1;
+    const int n1 = NREC * F.W, n2 = 5 * F.W * 4;
+    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n1 + n2; i += gridDim.x * TBLK) {
+        if (i < n1) { const int k = i / F.W, x = i % F.W; buf[i] = F.rec[(size_t)k * F.recStride + (size_t)(ownRow - (F.y0 - 1)) * F.W + x]; }
+        else { const int j = i - n1, b = j / (F.W * 4), r = j % (F.W * 4); buf[i] = F.spill[((size_t)b * F.recRows + (haloRow - (F.y0 - 1))) * F.W * 4 + r]; }
+    }
+}
+// receive from the neighbour on side `which`: its boundary-row records become my halo row; its spill of my boundary row is added
+__global__ __launch_bounds__(TBLK) void k_unpack_halo(FilmD F, int which, const Float *__restrict__ buf)
+{
+    const int ownRow = which == 0 ? F.y0 : F.y1 - 1, haloRow = which == 0 ? F.y0 - 1 : F.y1;
+    const int n1 = NREC * F.W, n2 = 5 * F.W * 4;
+    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n1 + n2; i += gridDim.x * TBLK) {
+        if (i < n1) { const int k = i / F.W, x = i % F.W; F.rec[(size_t)k * F.recStride + (size_t)(haloRow - (F.y0 - 1)) * F.W + x] = buf[i]; }
+        else { const int j = i - n1, b = j / (F.W * 4), r = j % (F.W * 4); F.spill[((size_t)b * F.recRows + (ownRow - (F.y0 - 1))) * F.W * 4 + r] += buf[i]; }
+    }
+}
+
+// probe: closest hit of arbitrary rays (tests)
+__global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float *__restrict__ od, int *__restrict__ prim, Float *__restrict__ tp)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    SceneView sv;
+    sv.nodes = S.nodes; sv.isect = S.isect;
+    const int i = blockIdx.x * TBLK + threadIdx.x;
+    if (i >= n) return;
+    const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
+    Hit h;
+    trace<false>(sv, s_stack + threadIdx.x, o, d, ray_mint_closest(o, GD_EPSILON), GD_INF, h);
+    Vertex v;
+    fill_vertex(S, h, d, v);
+    prim[i] = h.prim < 0 ? -1 : S.shade[h.prim].origIndex;
+    tp[4 * i] = h.t;
+    tp[4 * i + 1] = h.prim < 0 ? 0.0 : v.p.x; tp[4 * i + 2] = h.prim < 0 ? 0.0 : v.p.y; tp[4 * i + 3] = h.prim < 0 ? 0.0 : v.p.z;
+}
+
+// probe: the raw outputs of evaluatePoint (gpt.cpp:397-436) for one (pixel, sample): veryDirect(3), throughput(3),
+// gradients[4](12), neighbourThroughputs[4](12), then closest/shadow ray counts and the final depth as doubles.
+__global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int px, int py, int sample, Float *__restrict__ out33)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    SceneView sv;
+    sv.nodes = S.nodes; sv.isect = S.isect;
+    Lane L;
+    L.nClosest = L.nShadow = 0;
+    bool active = start_path(S, sv, cfg, s_stack, L, px, py, sample);
+    while (active) active = bounce(S, sv, cfg, s_stack, L);
+    Float *o = out33;
+    *o++ = L.veryDirect.x; *o++ = L.veryDirect.y; *o++ = L.veryDirect.z;
+    *o++ = L.radiance.x; *o++ = L.radiance.y; *o++ = L.radiance.z;
+    for (int i = 0; i < 4; i++) { *o++ = L.off[i].gradient.x; *o++ = L.off[i].gradient.y; *o++ = L.off[i].gradient.z; }
+    for (int i = 0; i < 4; i++) { *o++ = L.off[i].radiance.x; *o++ = L.off[i].radiance.y; *o++ = L.off[i].radiance.z; }
+    *o++ = (Float)L.nClosest; *o++ = (Float)L.nShadow; *o++ = (Float)L.depth;
+}
+
+} // namespace gdpt_tr

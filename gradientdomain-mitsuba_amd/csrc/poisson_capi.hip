@@ -252,6 +252,8 @@ int capture(gdpt_poisson_solver *s, bool first, hipGraphExec_t *out)
 
 } // namespace
 
+extern "C" int gdpt_internal_fail(int code, const char *msg) { g_err = msg; return code; }
+
 extern "C" {
 
 const char *gdpt_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's `gpt` integrator plugin over the C-ABI of include/gdpt_tracer.h.
+
+`GradientPathIntegrator` takes the plugin's properties with the reference's names, defaults and error behaviour
+(/root/reference/src/integrators/gpt/gpt.cpp:1190-1213, 1358-1480) and its `render()` walks the same steps:
+five MultiFilm buffers `-final -throughput -dx -dy -direct`, block rendering, develop, screened-Poisson
+reconstruction (L1D or L2D preset), reconstruction written to `-final`.  All arithmetic runs in lib/libgdpt_hip.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import poisson as _poisson
+from ._lib import GdptError, check, lib
+
+BUFFER_NAMES = ["-final", "-throughput", "-dx", "-dy", "-direct"]      # gpt.cpp:1380
+BUFFER_FINAL, BUFFER_THROUGHPUT, BUFFER_DX, BUFFER_DY, BUFFER_VERY_DIRECT = range(5)   # gpt.cpp:76-80
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int), ("distribution", C.c_int), ("sampleVisible", C.c_int), ("pad", C.c_int),
+                ("reflectance", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3),
+                ("alphaU", C.c_double), ("alphaV", C.c_double)]
+
+
+class Emitter(C.Structure):
+    _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class Config(C.Structure):
+    _fields_ = [("maxDepth", C.c_int), ("rrDepth", C.c_int), ("strictNormals", C.c_int), ("spp", C.c_int),
+                ("shiftThreshold", C.c_double), ("seed", C.c_ulonglong)]
+
+
+def _material(m):
+    out = Material()
+    out.type = m["type"]
+    out.distribution = m.get("distribution", 0)
+    out.sampleVisible = m.get("sampleVisible", 1)
+    out.reflectance = (C.c_double * 3)(*m.get("reflectance", (0.5, 0.5, 0.5)))
+    out.eta = (C.c_double * 3)(*m.get("eta", (0.0, 0.0, 0.0)))
+    out.k = (C.c_double * 3)(*m.get("k", (1.0, 1.0, 1.0)))
+    out.alphaU = m.get("alphaU", 0.1)
+    out.alphaV = m.get("alphaV", 0.1)
+    return out
+
+
+class Scene:
+    """Device-resident scene (flat BVH + triangle records in HBM) built from a `scenes.Scene` description."""
+
+    def __init__(self, desc, device=-1):
+        self.desc = desc
+        self.width, self.height = desc.width, desc.height
+        verts = np.ascontiguousarray(desc.verts, dtype=np.float64)
+        tm = np.ascontiguousarray(desc.tri_material, dtype=np.int32)
+        mats = (Material * len(desc.materials))(*[_material(m) for m in desc.materials])
+        ems = (Emitter * max(1, len(desc.emitters)))()
+        for i, (f, n, rad) in enumerate(desc.emitters):
+            ems[i].firstTri, ems[i].numTris, ems[i].radiance = f, n, (C.c_double * 3)(*rad)
+        cam = Camera()
+        cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
+        cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height
+        self._h = C.c_void_p()
+        check(lib().gdpt_scene_create(verts.shape[0], verts.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p),
+                                      len(desc.materials), C.byref(mats), len(desc.emitters), C.byref(ems), C.byref(cam),
+                                      device, C.byref(self._h)))
+
+    def intersect(self, origins, dirs):
+        od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))
+        n = od.shape[0]
+        prim = np.empty(n, np.int32)
+        tp = np.empty((n, 4), np.float64)
+        check(lib().gdpt_scene_intersect(self._h, n, od.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p)))
+        return prim, tp[:, 0], tp[:, 1:4]
+
+    def evaluate_point(self, cfg, px, py, sample):
+        out = np.zeros(33, np.float64)
+        check(lib().gdpt_scene_evaluate_point(self._h, C.byref(cfg), px, py, sample, out.ctypes.data_as(C.c_void_p)))
+        return dict(veryDirect=out[0:3], throughput=out[3:6], gradients=out[6:18].reshape(4, 3), neighbours=out[18:30].reshape(4, 3),
+                    raysTraced=int(out[30]), shadowRaysTraced=int(out[31]), depth=int(out[32]))
+
+    def close(self):
+        if self._h:
+            lib().gdpt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Film:
+    """The five G-PT buffers over rows [y0, y1) (MultiFilm with `setBuffers`, multifilm.cpp:293-319), device-resident."""
+
+    def __init__(self, scene, y0=0, y1=None):
+        self.scene = scene
+        self.y0, self.y1 = y0, scene.height if y1 is None else y1
+        self.rows, self.width = self.y1 - self.y0, scene.width
+        self._h = C.c_void_p()
+        check(lib().gdpt_film_create(scene._h, self.y0, self.y1, C.byref(self._h)))
+
+    def clear(self):
+        check(lib().gdpt_film_clear(self._h))
+
+    def accum(self):
+        out = np.empty((5, self.rows, self.width, 4), np.float64)
+        check(lib().gdpt_film_accum(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def develop(self, buffer):
+        """developMulti of one buffer -> float32 [rows, W, 3] on the host."""
+        out = np.empty((self.rows, self.width, 3), np.float32)
+        check(lib().gdpt_film_develop(self._h, buffer, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def develop_device(self, buffer, tensor):
+        check(lib().gdpt_film_develop_device(self._h, buffer, C.c_void_p(tensor.data_ptr())))
+        return tensor
+
+    def halo_bytes(self):
+        n = C.c_size_t()
+        check(lib().gdpt_film_halo_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def pack_halo(self, which, tensor):
+        check(lib().gdpt_film_pack_halo(self._h, which, C.c_void_p(tensor.data_ptr())))
+
+    def unpack_halo(self, which, tensor):
+        check(lib().gdpt_film_unpack_halo(self._h, which, C.c_void_p(tensor.data_ptr())))
+
+    def stats(self):
+        s = (C.c_ulonglong * 4)()
+        check(lib().gdpt_film_stats(self._h, s))
+        return dict(raysTraced=int(s[0]), shadowRaysTraced=int(s[1]), paths=int(s[2]), pathLengthSum=int(s[3]))
+
+    def render_ms(self):
+        lib().gdpt_film_render_ms.restype = C.c_float
+        return float(lib().gdpt_film_render_ms(self._h))
+
+    def sync(self):
+        check(lib().gdpt_film_sync(self._h))
+
+    def close(self):
+        if self._h:
+            lib().gdpt_film_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GradientPathIntegrator:
+    """`<integrator type="gpt">` (gpt.cpp:1190-1213): same property names, defaults and errors."""
+
+    def __init__(self, maxDepth=-1, minDepth=-1, rrDepth=5, strictNormals=False, shiftThreshold=0.001,
+                 reconstructL1=True, reconstructL2=False, reconstructAlpha=0.2, hideEmitters=False):
+        if reconstructL1 and reconstructL2:
+            raise RuntimeError("Disable 'reconstructL1' or 'reconstructL2': Cannot display two reconstructions at a time!")  # gpt.cpp:1203
+        if reconstructAlpha <= 0.0:
+            raise RuntimeError("'reconstructAlpha' must be set to a value greater than zero!")                             # gpt.cpp:1206
+        if maxDepth <= 0 and maxDepth != -1:
+            raise RuntimeError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!")                     # gpt.cpp:1209
+        if hideEmitters:
+            raise RuntimeError("Option 'hideEmitters' not implemented for Gradient-Domain Path Tracing!")                   # gpt.cpp:1362
+        self.maxDepth, self.rrDepth, self.strictNormals, self.shiftThreshold = maxDepth, rrDepth, strictNormals, shiftThreshold
+        self.minDepth = 1                                             # gpt.cpp:1369 overrides whatever was given
+        self.reconstructL1, self.reconstructL2, self.reconstructAlpha = reconstructL1, reconstructL2, reconstructAlpha
+        self.stats = {}
+
+    def config(self, spp, seed=5489):
+        return Config(self.maxDepth, self.rrDepth, int(self.strictNormals), spp, self.shiftThreshold, seed)
+
+    def renderBlock(self, scene, film, cfg, rect):
+        """GPTBlockRenderer::process + GPTRenderProcess::processResult for one rectangle (x0, y0, x1, y1)."""
+        x0, y0, x1, y1 = rect
+        check(lib().gdpt_render_rect(scene._h, C.byref(cfg), x0, y0, x1, y1, film._h))
+
+    def render(self, scene, spp, seed=5489, film=None):
+        """GradientPathIntegrator::render (gpt.cpp:1358-1480).  Returns {suffix: float32 [H,W,3]}."""
+        own = film is None
+        film = film or Film(scene)
+        cfg = self.config(spp, seed)
+        self.renderBlock(scene, film, cfg, (0, film.y0, scene.width, film.y1))
+        film.sync()
+        out = {name: film.develop(i) for i, name in enumerate(BUFFER_NAMES)}
+        self.stats = film.stats()
+        self.stats["render_ms"] = film.render_ms()
+        if self.reconstructL1 or self.reconstructL2:                  # gpt.cpp:1415-1476
+            preset = "L1D" if self.reconstructL1 else "L2D"
+            rec = _poisson.reconstruct(out["-dx"].ravel(), out["-dy"].ravel(), out["-throughput"].ravel(), out["-direct"].ravel(),
+                                       scene.width, film.rows, preset=preset, alpha=self.reconstructAlpha)
+            out["-final"] = rec.reshape(film.rows, scene.width, 3)     # setBitmapMulti(reconstruction, 1, BUFFER_FINAL)
+        if own:
+            film.close()
+        return out
+
+
+def write_pfm(path, rgb):
+    """MultiFilm `fileFormat=pfm` output (multifilm.cpp:123-124, 223-235): little-endian float32, bottom row first."""
+    a = np.asarray(rgb, np.float32)
+    h, w, _ = a.shape
+    with open(path, "wb") as f:
+        f.write(("PF\n%d %d\n-1.0\n" % (w, h)).encode())
+        f.write(a[::-1].astype("<f4").tobytes())
+
+
+def write_buffers(dest, buffers):
+    """MultiFilm::develop naming: `<dest><suffix>.pfm` (multifilm.cpp:453-517)."""
+    paths = []
+    for suffix, img in buffers.items():
+        p = dest + suffix + ".pfm"
+        write_pfm(p, img)
+        paths.append(p)
+    return paths

@@ -1,0 +1,188 @@
+"""Build-authored scenes (the reference ships none: SURVEY.md 8d) as flat arrays for the tracer C-ABI.
+
+A scene is what `gdpt_scene_create` (include/gdpt_tracer.h) takes: a triangle soup (ntri x 9 float64, no vertex
+normals/texcoords), one material index per triangle, a material table, area emitters given as contiguous triangle
+ranges (one emitter per emissive mesh, as in Mitsuba where an `area` emitter is attached to a shape), and a
+perspective sensor.  One-sided BSDFs only (the reference's diffuse/conductor/roughconductor are front-side), so
+every face is wound so that cross(p1-p0, p2-p0) points into the space light arrives from.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MAT_DIFFUSE, MAT_CONDUCTOR, MAT_ROUGHCONDUCTOR = 0, 1, 2
+DISTR_BECKMANN, DISTR_GGX = 0, 1
+
+
+def diffuse(rgb):
+    return dict(type=MAT_DIFFUSE, reflectance=tuple(rgb))
+
+
+def conductor(eta, k, specular=(1.0, 1.0, 1.0)):
+    return dict(type=MAT_CONDUCTOR, reflectance=tuple(specular), eta=tuple(eta), k=tuple(k))
+
+
+def roughconductor(alpha, eta, k, specular=(1.0, 1.0, 1.0), distribution=DISTR_BECKMANN, alphaV=None, sampleVisible=True):
+    return dict(type=MAT_ROUGHCONDUCTOR, reflectance=tuple(specular), eta=tuple(eta), k=tuple(k), alphaU=float(alpha),
+                alphaV=float(alpha if alphaV is None else alphaV), distribution=distribution, sampleVisible=int(sampleVisible))
+
+
+# measured-looking constants for copper/aluminium at RGB wavelengths (scene authors pass explicit eta/k; data/ior is not needed)
+CU = dict(eta=(0.200438, 0.924033, 1.102212), k=(3.912949, 2.452848, 2.142188))
+AL = dict(eta=(1.657460, 0.880369, 0.521229), k=(9.223869, 6.269523, 4.837001))
+
+
+def lookat(origin, target, up):
+    """Transform::lookAt (reference src/libcore/transform.cpp:191-214): columns = left, newUp, dir, origin."""
+    p, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))
+    d = t - p
+    d /= np.linalg.norm(d)
+    left = np.cross(u, d)
+    left /= np.linalg.norm(left)
+    new_up = np.cross(d, left)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, p
+    return m
+
+
+@dataclass
+class Scene:
+    verts: np.ndarray            # (ntri, 9) float64
+    tri_material: np.ndarray     # (ntri,) int32
+    materials: list
+    emitters: list               # [(firstTri, numTris, (r,g,b))]
+    to_world: np.ndarray         # 4x4 camera-to-world
+    fov_x: float
+    near: float = 1e-2
+    far: float = 1e4
+    width: int = 512
+    height: int = 512
+    name: str = "scene"
+
+    @property
+    def ntri(self):
+        return int(self.verts.shape[0])
+
+
+class _Builder:
+    def __init__(self):
+        self.tris, self.mat_ids, self.materials, self.emitters = [], [], [], []
+
+    def material(self, m):
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def quad(self, a, b, c, d, mat, toward):
+        """Two triangles (a,b,c),(a,c,d), re-wound so the face normal has a positive dot with `toward - centroid`."""
+        q = [np.asarray(v, np.float64) for v in (a, b, c, d)]
+        n = np.cross(q[1] - q[0], q[2] - q[0])
+        if np.dot(n, np.asarray(toward, np.float64) - (q[0] + q[1] + q[2] + q[3]) / 4) < 0:
+            q = [q[0], q[3], q[2], q[1]]
+        self.tris += [np.concatenate([q[0], q[1], q[2]]), np.concatenate([q[0], q[2], q[3]])]
+        self.mat_ids += [mat, mat]
+
+    def box(self, top4, height_y0, mat):
+        """Cornell-style block: `top4` = top face corners (counter-clockwise seen from above), extruded down to y0."""
+        top = [np.asarray(v, np.float64) for v in top4]
+        bot = [np.array([v[0], height_y0, v[2]]) for v in top]
+        c = sum(top + bot) / 8
+        far = lambda pts: c + 1e3 * (sum(pts) / len(pts) - c)   # a point outside the block beyond that face
+        self.quad(*top, mat, far(top))
+        for i in range(4):
+            j = (i + 1) % 4
+            self.quad(top[i], top[j], bot[j], bot[i], mat, far([top[i], top[j], bot[j], bot[i]]))
+
+    def emitter(self, first_tri, num_tris, radiance):
+        self.emitters.append((first_tri, num_tris, tuple(radiance)))
+
+    def finish(self, **cam):
+        return Scene(np.asarray(self.tris, np.float64).reshape(-1, 9), np.asarray(self.mat_ids, np.int32),
+                     self.materials, self.emitters, **cam)
+
+
+def cornell_box(width=512, height=512, variant="diffuse"):
+    """The Cornell box (Cornell Program of Computer Graphics measurement data, 555-unit room), all triangle meshes:
+    5 walls, short block, tall block, one area-light quad.  variant: "diffuse" (BASELINE configs 1-2) |
+    "glossy" (rough-copper floor, mirror back wall, GGX block: exercises the half-vector shift) | "nearspecular"."""
+    b = _Builder()
+    white = b.material(diffuse((0.725, 0.71, 0.68)))
+    red = b.material(diffuse((0.63, 0.065, 0.05)))
+    green = b.material(diffuse((0.14, 0.45, 0.091)))
+    lightm = b.material(diffuse((0.78, 0.78, 0.78)))
+    floor_m = back_m = white
+    if variant == "glossy":           # rough-copper floor, aluminium mirror back wall, GGX block (the box front is open: blocks would mirror the void)
+        floor_m = b.material(roughconductor(0.1, **CU))
+        back_m = b.material(conductor(**AL))
+        tall_m = b.material(roughconductor(0.05, **AL, distribution=DISTR_GGX))
+        short_m = white
+    elif variant == "nearspecular":   # roughness <= shiftThreshold (0.001): a glossy-sampled vertex that is classified GLOSSY
+        floor_m = b.material(roughconductor(0.0008, **CU))
+        back_m = b.material(roughconductor(0.2, **AL, alphaV=0.05))
+        tall_m = short_m = white
+    else:
+        tall_m = short_m = white
+    room = (278.0, 274.4, 279.6)
+    b.quad((552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2), floor_m, room)             # floor
+    b.quad((556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0), white, room)   # ceiling
+    b.quad((549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2), back_m, room)  # back wall
+    b.quad((0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2), green, room)                # right wall
+    b.quad((552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0), red, room)      # left wall
+    b.box([(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)], 0.0, short_m)         # short block
+    b.box([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 0.0, tall_m)        # tall block
+    first = len(b.tris)
+    b.quad((343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227), lightm, room)  # light, just below the ceiling
+    b.emitter(first, 2, (17.0, 12.0, 4.0))
+    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))      # 0.025 sensor, 0.035 focal length
+    if width != height:                                     # keep the vertical extent of the square original: fov is the x-fov
+        fov = 2 * math.degrees(math.atan(math.tan(math.radians(fov) / 2) * width / height))
+    return b.finish(to_world=lookat((278, 273, -800), (278, 273, -799), (0, 1, 0)), fov_x=fov, near=10.0, far=2800.0,
+                    width=width, height=height, name="cornell-" + variant)
+
+
+def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):
+    """Sponza-class stand-in (the Sponza asset is not available offline): a two-storey colonnaded atrium, procedurally
+    tessellated -- faceted columns, arches, floor tiles, 80 % diffuse / 20 % rough-conductor (Beckmann alpha 0.1), lit by
+    an opening-sized area light.  `columns` x `segments` set the triangle count (~columns*segments*2*rings + tiles)."""
+    rng = np.random.default_rng(seed)
+    b = _Builder()
+    stone = [b.material(diffuse(c)) for c in ((0.62, 0.56, 0.47), (0.55, 0.5, 0.43), (0.7, 0.66, 0.6), (0.45, 0.32, 0.25))]
+    metal = b.material(roughconductor(0.1, **CU))
+    lightm = b.material(diffuse((0.5, 0.5, 0.5)))
+    L, Wd, Hh = 40.0, 16.0, 14.0
+    room = (0.0, Hh / 2, 0.0)
+    tiles = 48
+    for i in range(tiles):                                   # floor tiles (each its own quad; some metallic inlays)
+        for j in range(tiles // 2):
+            x0, x1 = -L / 2 + L * i / tiles, -L / 2 + L * (i + 1) / tiles
+            z0, z1 = -Wd / 2 + Wd * j / (tiles // 2), -Wd / 2 + Wd * (j + 1) / (tiles // 2)
+            m = metal if rng.random() < 0.2 else stone[(i + j) % 3]
+            b.quad((x0, 0, z0), (x1, 0, z0), (x1, 0, z1), (x0, 0, z1), m, room)
+    b.quad((-L / 2, 0, -Wd / 2), (-L / 2, Hh, -Wd / 2), (L / 2, Hh, -Wd / 2), (L / 2, 0, -Wd / 2), stone[1], room)
+    b.quad((-L / 2, 0, Wd / 2), (-L / 2, Hh, Wd / 2), (L / 2, Hh, Wd / 2), (L / 2, 0, Wd / 2), stone[1], room)
+    b.quad((-L / 2, 0, -Wd / 2), (-L / 2, Hh, -Wd / 2), (-L / 2, Hh, Wd / 2), (-L / 2, 0, Wd / 2), stone[3], room)
+    b.quad((L / 2, 0, -Wd / 2), (L / 2, Hh, -Wd / 2), (L / 2, Hh, Wd / 2), (L / 2, 0, Wd / 2), stone[3], room)
+    b.quad((-L / 2, Hh, -Wd / 2), (L / 2, Hh, -Wd / 2), (L / 2, Hh, Wd / 2), (-L / 2, Hh, Wd / 2), stone[2], room)
+    rings = 24
+    for ci in range(columns):                                # faceted columns in two rows, two storeys
+        side = -1 if ci % 2 == 0 else 1
+        cx = -L / 2 + L * (ci // 2 + 0.5) / (columns // 2)
+        cz = side * (Wd / 2 - 2.5)
+        m = metal if rng.random() < 0.2 else stone[ci % 3]
+        for storey in range(2):
+            ybase = storey * (Hh / 2)
+            for r in range(rings):
+                y0, y1 = ybase + (Hh / 2 - 0.6) * r / rings, ybase + (Hh / 2 - 0.6) * (r + 1) / rings
+                rad0 = 0.55 + 0.06 * math.sin(3.1 * y0)
+                rad1 = 0.55 + 0.06 * math.sin(3.1 * y1)
+                for s in range(segments):
+                    a0, a1 = 2 * math.pi * s / segments, 2 * math.pi * (s + 1) / segments
+                    p = lambda rad, a, y: (cx + rad * math.cos(a), y, cz + rad * math.sin(a))
+                    q = [p(rad0, a0, y0), p(rad0, a1, y0), p(rad1, a1, y1), p(rad1, a0, y1)]
+                    mid = (cx + 10 * math.cos((a0 + a1) / 2), (y0 + y1) / 2, cz + 10 * math.sin((a0 + a1) / 2))
+                    b.quad(*q, m, mid)
+    first = len(b.tris)
+    b.quad((-6, Hh - 0.05, -3), (6, Hh - 0.05, -3), (6, Hh - 0.05, 3), (-6, Hh - 0.05, 3), lightm, room)
+    b.emitter(first, 2, (30.0, 28.0, 24.0))
+    return b.finish(to_world=lookat((-17.0, 3.2, 0.6), (0.0, 4.5, 0.0), (0, 1, 0)), fov_x=70.0, near=0.1, far=200.0,
+                    width=width, height=height, name="atrium")

@@ -1,0 +1,123 @@
+/*
+ * include/gdpt_tracer.h -- C-ABI of the MI355X gradient-domain path tracer (G-PT sampling stage).
+ *
+ * Drop-in boundary for the per-block work of the reference's `gpt` integrator plugin
+ * (/root/reference/src/integrators/gpt/): what GPTBlockRenderer::process -> GradientPathIntegrator::
+ * renderBlock -> GradientPathTracer::evaluatePoint/evaluate compute for a rectangle of pixels
+ * (gpt_proc.cpp:75-93, gpt.cpp:1220-1355, 397-436, 468-1180), and what GPTRenderProcess::processResult +
+ * MultiFilm::putMulti/developMulti do with the result (gpt_proc.cpp:137-149, multifilm.cpp:366-416).
+ * A maintainer's `GradientPathIntegrator::render` keeps its own scheduling and film; it hands this
+ * library the scene once and then asks for tiles.  See INTEGRATION.md for the binding.
+ *
+ * Scene subset carried: triangle soups without vertex normals/texcoords, `area` emitters on
+ * meshes, `diffuse` / `conductor` / `roughconductor` BSDFs, `perspective` sensor, `box` rfilter, independent
+ * sampling.  Arithmetic is fp64 like the reference's DOUBLE_PRECISION build.  Random numbers: one counter-based
+ * stream per (seed, pixel, sample) -- a GPU cannot consume the reference's serial SFMT stream.
+ *
+ * Plain C; status codes and gdpt_last_error() as in gdpt_poisson.h.  No CPU fallback.
+ */
+#ifndef GDPT_TRACER_H
+#define GDPT_TRACER_H
+
+#include "gdpt_poisson.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDPT_MAT_DIFFUSE        0   /* src/bsdfs/diffuse.cpp        */
+#define GDPT_MAT_CONDUCTOR      1   /* src/bsdfs/conductor.cpp      */
+#define GDPT_MAT_ROUGHCONDUCTOR 2   /* src/bsdfs/roughconductor.cpp */
+#define GDPT_DISTR_BECKMANN     0   /* src/bsdfs/microfacet.h EBeckmann */
+#define GDPT_DISTR_GGX          1   /* EGGX */
+
+typedef struct gdpt_material {
+    int    type;            /* GDPT_MAT_*                                                        */
+    int    distribution;    /* GDPT_DISTR_* (roughconductor `distribution`)                      */
+    int    sampleVisible;   /* roughconductor `sampleVisible` (default 1)                        */
+    int    pad;
+    double reflectance[3];  /* diffuse `reflectance`; conductors `specularReflectance`           */
+    double eta[3], k[3];    /* conductors `eta`, `k` (RGB)                                       */
+    double alphaU, alphaV;  /* roughconductor `alpha` / `alphaU`,`alphaV`                        */
+} gdpt_material;
+
+typedef struct gdpt_emitter {   /* an `area` emitter attached to one mesh (src/emitters/area.cpp) */
+    int    firstTri, numTris;   /* that mesh's triangles, contiguous in the soup                  */
+    double radiance[3];
+} gdpt_emitter;
+
+typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp), crop == film */
+    double toWorld[16];         /* row-major camera-to-world, Transform::lookAt convention         */
+    double fovX;                /* degrees (`fov`, fovAxis = x)                                    */
+    double nearClip, farClip;
+    int    width, height;       /* film size in pixels                                             */
+} gdpt_camera;
+
+/* GradientPathTracerConfig (gpt.h:35-68) + sampler settings.  minDepth is forced to 1 (gpt.cpp:1369). */
+typedef struct gdpt_config {
+    int    maxDepth;            /* -1 = unbounded (gpt.cpp:1194)                                   */
+    int    rrDepth;             /* 5                                                               */
+    int    strictNormals;       /* 0                                                               */
+    int    spp;                 /* sampler sampleCount                                             */
+    double shiftThreshold;      /* 0.001                                                           */
+    unsigned long long seed;    /* 5489 echoes random.h:113                                        */
+} gdpt_config;
+
+typedef struct gdpt_scene gdpt_scene;
+typedef struct gdpt_film  gdpt_film;
+
+/* Upload a scene: builds the flat BVH on the host, lays triangles out in leaf order in HBM. device: -1 = current. */
+GDPT_API int  gdpt_scene_create(int numTris, const double *verts9, const int *triMaterial,
+                                int numMaterials, const gdpt_material *materials,
+                                int numEmitters, const gdpt_emitter *emitters,
+                                const gdpt_camera *camera, int device, gdpt_scene **out);
+GDPT_API void gdpt_scene_destroy(gdpt_scene *s);
+
+/* A film = the five G-PT buffers `-final -throughput -dx -dy -direct` (gpt.cpp:1380) over rows [y0, y1) of the
+ * image plus a one-pixel halo row above and below (GPTWorkResult's extraBorder, gpt_proc.cpp:52-56), as
+ * per-pixel sample sums on the device.  Single GPU: y0 = 0, y1 = height. */
+GDPT_API int  gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out);
+GDPT_API void gdpt_film_destroy(gdpt_film *f);
+GDPT_API int  gdpt_film_clear(gdpt_film *f);
+
+/* Render pixels [x0,x1) x [y0,y1) (must lie inside the film's rows) with cfg->spp samples each, ADDING into the
+ * film (GPTBlockRenderer::process + processResult).  Asynchronous on the film's stream; gdpt_film_sync waits. */
+GDPT_API int  gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int x1, int y1, gdpt_film *f);
+GDPT_API int  gdpt_film_sync(gdpt_film *f);
+
+/* Halo exchange for row-strip sharding (DESIGN.md "multi-GPU").  A strip's pixels need the per-pixel sample sums of the
+ * rows just outside it (the neighbour samples that splat into it) -- the reference's block border merged by addition
+ * (gpt_proc.cpp:52-56,137-149).  pack(which) writes this strip's boundary payload for the neighbour ABOVE (which = 0) or
+ * BELOW (which = 1) into a device buffer of gdpt_film_halo_bytes(); unpack(which, buf) consumes the payload received
+ * from the neighbour on that side.  Transport (RCCL send/recv) is the caller's. */
+GDPT_API int  gdpt_film_halo_bytes(gdpt_film *f, size_t *bytes);
+GDPT_API int  gdpt_film_pack_halo(gdpt_film *f, int which, void *devBuf);
+GDPT_API int  gdpt_film_unpack_halo(gdpt_film *f, int which, const void *devBuf);
+
+/* Resolve the per-pixel sums into the five accumulation buffers exactly as 15 ImageBlock::put calls per sample with
+ * the box filter would have (gpt.cpp:1314-1352, imageblock.h:150-199): accum[5][rows][width][4] doubles (R,G,B,weight)
+ * on the HOST, rows = y1 - y0. */
+GDPT_API int  gdpt_film_accum(gdpt_film *f, double *accum);
+/* MultiFilm::developMulti (multifilm.cpp:366-416; weight division fmtconv.cpp:955-1058) of one buffer to fp32 RGB
+ * (the std::transform casts of gpt.cpp:1439-1442) into a DEVICE buffer of 3*rows*width floats -- the solver's input. */
+GDPT_API int  gdpt_film_develop_device(gdpt_film *f, int buffer, float *rgbDevice);
+GDPT_API int  gdpt_film_develop(gdpt_film *f, int buffer, float *rgbHost);
+
+/* Counters since the last clear: [0] closest-hit queries, [1] any-hit queries (raysTraced / shadowRaysTraced,
+ * skdtree.cpp:46-47,123,151,211), [2] base paths, [3] sum of base-path lengths (avgPathLength, gpt.cpp:72,1178). */
+GDPT_API int  gdpt_film_stats(gdpt_film *f, unsigned long long stats[4]);
+/* HIP-event time of the render kernels enqueued since the last clear (milliseconds). */
+GDPT_API float gdpt_film_render_ms(gdpt_film *f);
+GDPT_API void *gdpt_film_stream(gdpt_film *f);
+
+/* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */
+GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *tp4);
+
+/* Probe for tests: one sample's raw evaluatePoint outputs (gpt.cpp:397-436): veryDirect(3), throughput(3), gradients[4](12),
+ * neighbourThroughputs[4](12), then closest-hit count, any-hit count, final depth. */
+GDPT_API int  gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int py, int sample, double out33[33]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDPT_TRACER_H */

@@ -1,0 +1,1411 @@
+/*
+ * oracle/gpt_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (C++17, double precision like the reference's DOUBLE_PRECISION build,
+ * single-threaded, brute-force ray casting) of the reference's G-PT per-sample hot path:
+ * GradientPathTracer::evaluatePoint/evaluate, the shift mappings, vertex classification, the 15-put
+ * accumulation of GradientPathIntegrator::renderBlock, and the Mitsuba pieces those call for the
+ * scene subset the build carries (triangle soups without vertex normals/texcoords, area lights,
+ * diffuse / conductor / roughconductor BSDFs, perspective sensor, box filter).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED.  The reference tracer cannot be built here (mitsuba.h needs boost; scene loading
+ * Xerces-C; films OpenEXR -- none in the image, none may be stood in for) and holds no test or fixture
+ * for gpt.  Nothing in this file has been compared with output of the
+ * reference.  What checks it (tests/test_gpt_oracle.py): closed-form KATs of the shifts/BSDFs,
+ * furnace/energy identities, sample-vs-pdf consistency of the BSDF restatements, convergence of
+ * `-throughput` to an independent plain path tracer written against the rendering equation.
+ *
+ * One deliberate, stated deviation: the reference draws random numbers from one serial SFMT stream
+ * in spiral-block x Hilbert-pixel order (independent.cpp:82-103, random.cpp); a GPU cannot consume
+ * that, so BOTH this oracle and the HIP path use the same counter-based generator keyed by
+ * (seed, pixel, sample) -- see Rng below.  The consumption ORDER within a sample follows the
+ * reference.
+ *
+ * Citations are relative to /root/reference/.  "gpt.cpp" = src/integrators/gpt/gpt.cpp.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#define GPO_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+typedef double Float;
+const Float Epsilon = 1e-7;               // include/mitsuba/core/constants.h:25 (double build)
+const Float ShadowEpsilon = 1e-5;         // constants.h:26
+const Float DeltaEpsilon = (Float)1e-3f;  // constants.h:31
+const Float D_EPSILON = (Float)(1e-14);   // gpt.cpp:63
+const Float PI = 3.14159265358979323846;
+const Float INV_PI = 0.31830988618379067154;
+const Float INF = std::numeric_limits<Float>::infinity();
+
+struct V3 {
+    Float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(Float a) : x(a), y(a), z(a) {}
+    V3(Float a, Float b, Float c) : x(a), y(b), z(c) {}
+    Float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, Float s) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(Float s, V3 a) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(V3 a, V3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator/(V3 a, Float s) { Float r = 1.0 / s; return V3(a.x * r, a.y * r, a.z * r); } // TVector3::operator/ multiplies by the reciprocal
+inline V3 divc(V3 a, V3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline Float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline Float lengthSquared(V3 a) { return dot(a, a); }
+inline Float length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { return a / length(a); }
+inline bool isZero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+inline Float maxc(V3 a) { return std::max(a.x, std::max(a.y, a.z)); }
+inline Float safe_sqrt(Float v) { return std::sqrt(std::max(0.0, v)); } // math.h:265
+inline Float signum(Float v) { return v < 0 ? -1.0 : (v > 0 ? 1.0 : 0.0); }
+
+// ---- counter-based generator shared (by specification, not by code) with the HIP path --------------
+// One SplitMix64 stream per (seed, pixel, sample); double in [0,1) from the top 52 bits exactly like
+// Random::nextFloat in the double build (random.cpp: ((u64 >> 12) | 0x3ff0000000000000) - 1.0).
+inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t s;
+    Rng(uint64_t seed, uint64_t pixel, uint64_t sample)
+    {
+        s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
+        s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+    }
+    Float next1D()
+    {
+        s += 0x9E3779B97F4A7C15ULL;
+        const uint64_t bits = (mix64(s) >> 12) | 0x3FF0000000000000ULL;
+        Float d;
+        std::memcpy(&d, &bits, 8);
+        return d - 1.0;
+    }
+};
+
+// ---- Frame: include/mitsuba/core/frame.h:37-, util.cpp:592-608 ------------------------------------
+struct Frame {
+    V3 s, t, n;
+    V3 toLocal(V3 v) const { return V3(dot(v, s), dot(v, t), dot(v, n)); }
+    V3 toWorld(V3 v) const { return s * v.x + t * v.y + n * v.z; }
+};
+inline Float cosTheta(V3 v) { return v.z; }
+inline Float tanTheta(V3 v) { Float t = 1 - v.z * v.z; return t <= 0.0 ? 0.0 : std::sqrt(t) / v.z; } // frame.h:122
+inline void coordinateSystem(V3 a, V3 &b, V3 &c)
+{ // util.cpp:592-601
+    if (std::abs(a.x) > std::abs(a.y)) {
+        Float invLen = 1.0 / std::sqrt(a.x * a.x + a.z * a.z);
+        c = V3(a.z * invLen, 0.0, -a.x * invLen);
+    } else {
+        Float invLen = 1.0 / std::sqrt(a.y * a.y + a.z * a.z);
+        c = V3(0.0, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+
+// ---- materials --------------------------------------------------------------------------------------
+enum { MAT_DIFFUSE = 0, MAT_CONDUCTOR = 1, MAT_ROUGHCONDUCTOR = 2 };
+enum { DISTR_BECKMANN = 0, DISTR_GGX = 1 };
+// BSDF::EBSDFType bits used here (include/mitsuba/render/bsdf.h): diffuse/glossy reflection are smooth, delta is not
+enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, ESmooth = 0x1 | 0x4, EDelta = 0x10 };
+enum { MEASURE_SOLID_ANGLE = 0, MEASURE_DISCRETE = 1 };
+
+} // namespace
+
+// Plain-C scene description, identical in meaning to include/gdpt_tracer.h (defined separately on purpose).
+extern "C" {
+typedef struct gpo_material {
+    int type;            // MAT_*
+    int distribution;    // DISTR_* (roughconductor)
+    int sampleVisible;   // roughconductor.cpp m_sampleVisible (default true)
+    int pad;
+    double reflectance[3]; // diffuse: reflectance; conductors: specularReflectance
+    double eta[3], k[3];
+    double alphaU, alphaV;
+} gpo_material;
+
+typedef struct gpo_emitter {
+    int firstTri, numTris; // the triangles of the emissive mesh (contiguous)
+    double radiance[3];
+} gpo_emitter;
+
+typedef struct gpo_camera {
+    double toWorld[16]; // row-major camera-to-world (Transform::lookAt convention, transform.cpp:191-214)
+    double fovX;        // degrees
+    double nearClip, farClip;
+    int width, height;
+} gpo_camera;
+
+typedef struct gpo_config {
+    int maxDepth, rrDepth, strictNormals, spp;
+    double shiftThreshold;
+    unsigned long long seed;
+} gpo_config;
+}
+
+namespace {
+
+struct TriAccel { // include/mitsuba/render/triaccel.h:37-94
+    uint32_t k;
+    Float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_nv;
+};
+
+struct Tri {
+    V3 p0, p1, p2;
+    TriAccel acc;
+    int material, emitter;
+    V3 faceNormal; // normalized cross(side1, side2)   (skdtree.h:367-371)
+    Frame sh;      // shading frame: n = faceNormal, s,t from dpdu = side1   (skdtree.h:379,396; util.cpp:603-608)
+    V3 geoN;
+};
+
+struct Emitter {
+    int firstTri, numTris;
+    V3 radiance;
+    std::vector<Float> cdf; // DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h)
+    Float invSurfaceArea;
+};
+
+struct Distribution { // include/mitsuba/core/pmf.h
+    std::vector<Float> cdf;
+    Float sum, normalization;
+    Distribution() : cdf(1, 0.0), sum(0), normalization(0) {}
+    void append(Float v) { cdf.push_back(cdf.back() + v); }
+    Float normalize()
+    { // pmf.h:95-108
+        sum = cdf.back();
+        if (sum > 0) {
+            normalization = 1.0 / sum;
+            for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= normalization;
+            cdf.back() = 1.0;
+        } else normalization = 0.0;
+        return sum;
+    }
+    Float operator[](size_t i) const { return cdf[i + 1] - cdf[i]; }
+    size_t sample(Float v) const
+    { // pmf.h:110-123
+        auto entry = std::lower_bound(cdf.begin(), cdf.end(), v);
+        size_t index = std::min(cdf.size() - 2, (size_t)std::max((std::ptrdiff_t)0, (std::ptrdiff_t)(entry - cdf.begin()) - 1));
+        while ((*this)[index] == 0 && index < cdf.size() - 1) ++index;
+        return index;
+    }
+    size_t sampleReuse(Float &v) const
+    { // pmf.h:164-169
+        size_t index = sample(v);
+        v = (v - cdf[index]) / (cdf[index + 1] - cdf[index]);
+        return index;
+    }
+    size_t sampleReuse(Float &v, Float &pdf) const
+    {
+        size_t index = sample(v);
+        pdf = (*this)[index];
+        v = (v - cdf[index]) / (cdf[index + 1] - cdf[index]);
+        return index;
+    }
+};
+
+struct Ray {
+    V3 o, d;
+    Float mint, maxt;
+    Ray() : mint(Epsilon), maxt(INF) {}
+    Ray(V3 o_, V3 d_) : o(o_), d(d_), mint(Epsilon), maxt(INF) {}                       // ray.h: Ray(o, d, time)
+    Ray(V3 o_, V3 d_, Float mn, Float mx) : o(o_), d(d_), mint(mn), maxt(mx) {}
+};
+
+struct Intersection {
+    Float t;
+    int prim;
+    V3 p, wi;
+    Frame sh;
+    V3 geoN;
+    Intersection() : t(INF), prim(-1) {}
+    bool isValid() const { return t != INF; }
+};
+
+struct Scene {
+    std::vector<Tri> tris;
+    std::vector<gpo_material> mats;
+    std::vector<Emitter> emitters;
+    Distribution emitterPDF; // scene.cpp:357-380, every emitter has sampling weight 1
+    gpo_camera cam;
+    // camera constants (perspective.cpp:125-163)
+    Float aspect, tanHalf;
+    V3 aabbMin, aabbMax;
+    mutable uint64_t raysTraced = 0, shadowRaysTraced = 0; // skdtree.cpp:46-47
+};
+
+int triaccel_load(TriAccel &ta, V3 A, V3 B, V3 C)
+{ // triaccel.h:61-94
+    static const int waldModulo[4] = {1, 2, 0, 1};
+    V3 b = C - A, c = B - A, N = cross(c, b);
+    uint32_t k = 0;
+    for (int j = 0; j < 3; j++)
+        if (std::abs(N[j]) > std::abs(N[k])) k = j;
+    uint32_t u = waldModulo[k], v = waldModulo[k + 1];
+    const Float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
+    if (denom == 0) { ta.k = 3; return 1; }
+    ta.k = k;
+    ta.n_u = N[u] / n_k;
+    ta.n_v = N[v] / n_k;
+    ta.n_d = dot(A, N) / n_k;
+    ta.b_nu = b[u] / denom;
+    ta.b_nv = -b[v] / denom;
+    ta.a_u = A[u];
+    ta.a_v = A[v];
+    ta.c_nu = c[v] / denom;
+    ta.c_nv = -c[u] / denom;
+    return 0;
+}
+
+inline bool triaccel_intersect(const TriAccel &ta, const Ray &ray, Float mint, Float maxt, Float &u, Float &v, Float &t)
+{ // triaccel.h:96-158
+    Float o_u, o_v, o_k, d_u, d_v, d_k;
+    switch (ta.k) {
+    case 0: o_u = ray.o.y; o_v = ray.o.z; o_k = ray.o.x; d_u = ray.d.y; d_v = ray.d.z; d_k = ray.d.x; break;
+    case 1: o_u = ray.o.z; o_v = ray.o.x; o_k = ray.o.y; d_u = ray.d.z; d_v = ray.d.x; d_k = ray.d.y; break;
+    case 2: o_u = ray.o.x; o_v = ray.o.y; o_k = ray.o.z; d_u = ray.d.x; d_v = ray.d.y; d_k = ray.d.z; break;
+    default: return false;
+    }
+    t = (ta.n_d - o_u * ta.n_u - o_v * ta.n_v - o_k) / (d_u * ta.n_u + d_v * ta.n_v + d_k);
+    if (t < mint || t > maxt) return false;
+    const Float hu = o_u + t * d_u - ta.a_u;
+    const Float hv = o_v + t * d_v - ta.a_v;
+    u = hv * ta.b_nu + hu * ta.b_nv;
+    v = hu * ta.c_nu + hv * ta.c_nv;
+    return u >= 0 && v >= 0 && u + v <= 1.0;
+}
+
+// AABB::rayIntersect (include/mitsuba/core/aabb.h) for the scene bounds test of skdtree.cpp:123,211
+bool aabb_ray(const Scene &sc, const Ray &ray, Float &nearT, Float &farT)
+{
+    nearT = -INF; farT = INF;
+    for (int i = 0; i < 3; i++) {
+        const Float origin = ray.o[i], minVal = sc.aabbMin[i], maxVal = sc.aabbMax[i], dir = ray.d[i];
+        if (dir == 0) {
+            if (origin < minVal || origin > maxVal) return false;
+        } else {
+            const Float rcp = 1.0 / dir;
+            Float t1 = (minVal - origin) * rcp, t2 = (maxVal - origin) * rcp;
+            if (t1 > t2) std::swap(t1, t2);
+            nearT = std::max(t1, nearT);
+            farT = std::min(t2, farT);
+            if (!(nearT <= farT)) return false;
+        }
+    }
+    return true;
+}
+
+// ShapeKDTree::rayIntersect(ray, its), skdtree.cpp:112-142 + fillIntersectionRecord<true>, skdtree.h:343-428
+bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
+{
+    its.t = INF;
+    its.prim = -1;
+    Float mint, maxt;
+    ++sc.raysTraced;
+    if (!aabb_ray(sc, ray, mint, maxt)) return false;
+    Float rayMinT = ray.mint;
+    if (rayMinT == Epsilon) // adaptive ray epsilon, skdtree.cpp:126-129
+        rayMinT *= std::max(std::max(std::max(std::abs(ray.o.x), std::abs(ray.o.y)), std::abs(ray.o.z)), Epsilon);
+    if (rayMinT > mint) mint = rayMinT;
+    if (ray.maxt < maxt) maxt = ray.maxt;
+    if (!(maxt > mint)) return false;
+    Float bu = 0, bv = 0;
+    for (size_t i = 0; i < sc.tris.size(); ++i) { // closest hit; the traversal order of the kd-tree is not restated
+        Float u, v, t;
+        if (triaccel_intersect(sc.tris[i].acc, ray, mint, maxt, u, v, t)) {
+            maxt = t;
+            its.t = t; its.prim = (int)i; bu = u; bv = v;
+        }
+    }
+    if (its.prim < 0) return false;
+    const Tri &tr = sc.tris[its.prim];
+    const V3 b(1 - bu - bv, bu, bv);
+    its.p = tr.p0 * b.x + tr.p1 * b.y + tr.p2 * b.z;
+    its.sh = tr.sh;
+    its.geoN = tr.geoN;
+    its.wi = its.sh.toLocal(-ray.d);
+    return true;
+}
+
+// ShapeKDTree::rayIntersect(ray) (shadow), skdtree.cpp:207-226
+bool rayIntersectShadow(const Scene &sc, const Ray &ray)
+{
+    Float mint, maxt;
+    ++sc.shadowRaysTraced;
+    if (!aabb_ray(sc, ray, mint, maxt)) return false;
+    Float rayMinT = ray.mint;
+    if (rayMinT == Epsilon) // no floor here, skdtree.cpp:214-217
+        rayMinT *= std::max(std::max(std::abs(ray.o.x), std::abs(ray.o.y)), std::abs(ray.o.z));
+    if (rayMinT > mint) mint = rayMinT;
+    if (ray.maxt < maxt) maxt = ray.maxt;
+    if (!(maxt > mint)) return false;
+    for (size_t i = 0; i < sc.tris.size(); ++i) {
+        Float u, v, t;
+        if (triaccel_intersect(sc.tris[i].acc, ray, mint, maxt, u, v, t)) return true;
+    }
+    return false;
+}
+
+// ---- warps: src/libcore/warp.cpp ------------------------------------------------------------------------
+void squareToUniformDiskConcentric(Float sx, Float sy, Float &ox, Float &oy)
+{ // warp.cpp:81-102
+    Float r1 = 2.0 * sx - 1.0, r2 = 2.0 * sy - 1.0, phi, r;
+    if (r1 == 0 && r2 == 0) { r = phi = 0; }
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (PI / 4.0) * (r2 / r1); }
+    else { r = r2; phi = (PI / 2.0) - (r1 / r2) * (PI / 4.0); }
+    ox = r * std::cos(phi);
+    oy = r * std::sin(phi);
+}
+V3 squareToCosineHemisphere(Float sx, Float sy)
+{ // warp.cpp:43-52
+    Float px, py;
+    squareToUniformDiskConcentric(sx, sy, px, py);
+    Float z = safe_sqrt(1.0 - px * px - py * py);
+    if (z == 0) z = (Float)1e-10f;
+    return V3(px, py, z);
+}
+
+// ---- Fresnel: util.cpp:739-761 (Spectrum version, per channel) -----------------------------------------
+V3 fresnelConductorExact(Float cosThetaI, V3 eta, V3 k)
+{
+    Float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    Float out[3];
+    for (int c = 0; c < 3; c++) {
+        const Float e = eta[c], kk = k[c];
+        Float temp1 = e * e - kk * kk - sinThetaI2;
+        Float a2pb2 = safe_sqrt(temp1 * temp1 + kk * kk * e * e * 4);
+        Float a = safe_sqrt((a2pb2 + temp1) * 0.5);
+        Float term1 = a2pb2 + cosThetaI2, term2 = a * (2 * cosThetaI);
+        Float Rs2 = (term1 - term2) / (term1 + term2);
+        Float term3 = a2pb2 * cosThetaI2 + sinThetaI4, term4 = term2 * sinThetaI2;
+        Float Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+        out[c] = 0.5 * (Rp2 + Rs2);
+    }
+    return V3(out[0], out[1], out[2]);
+}
+
+// ---- math: src/libcore/math.cpp:25-72 -------------------------------------------------------------------
+Float erfinv_m(Float x)
+{
+    Float w = -std::log((1.0 - x) * (1.0 + x)), p;
+    if (w < 5.0) {
+        w = w - 2.5;
+        p = 2.81022636e-08; p = 3.43273939e-07 + p * w; p = -3.5233877e-06 + p * w; p = -4.39150654e-06 + p * w;
+        p = 0.00021858087 + p * w; p = -0.00125372503 + p * w; p = -0.00417768164 + p * w; p = 0.246640727 + p * w; p = 1.50140941 + p * w;
+    } else {
+        w = std::sqrt(w) - 3.0;
+        p = -0.000200214257; p = 0.000100950558 + p * w; p = 0.00134934322 + p * w; p = -0.00367342844 + p * w;
+        p = 0.00573950773 + p * w; p = -0.0076224613 + p * w; p = 0.00943887047 + p * w; p = 1.00167406 + p * w; p = 2.83297682 + p * w;
+    }
+    return p * x;
+}
+Float erf_m(Float x)
+{
+    const Float a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429, p = 0.3275911;
+    Float sign = signum(x);
+    x = std::abs(x);
+    Float t = 1.0 / (1.0 + p * x);
+    Float y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+    return sign * y;
+}
+Float hypot2(Float a, Float b)
+{
+    Float r;
+    if (std::abs(a) > std::abs(b)) { r = b / a; r = std::abs(a) * std::sqrt(1.0 + r * r); }
+    else if (b != 0.0) { r = a / b; r = std::abs(b) * std::sqrt(1.0 + r * r); }
+    else r = 0.0;
+    return r;
+}
+
+// ---- MicrofacetDistribution: src/bsdfs/microfacet.h ------------------------------------------------------
+struct Microfacet {
+    int type;
+    Float alphaU, alphaV;
+    bool sampleVisible;
+    Microfacet(int t, Float au, Float av, bool sv) : type(t), alphaU(std::max(au, (Float)1e-4f)), alphaV(std::max(av, (Float)1e-4f)), sampleVisible(sv) {} // :70-71
+    bool isIsotropic() const { return alphaU == alphaV; }
+    Float eval(V3 m) const
+    { // :191-234
+        if (cosTheta(m) <= 0) return 0.0;
+        Float cosTheta2 = m.z * m.z;
+        Float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
+        Float result;
+        if (type == DISTR_BECKMANN) result = std::exp(-beckmannExponent) / (PI * alphaU * alphaV * cosTheta2 * cosTheta2);
+        else { Float root = (1.0 + beckmannExponent) * cosTheta2; result = 1.0 / (PI * alphaU * alphaV * root * root); }
+        if (result * cosTheta(m) < (Float)1e-20f) result = 0;
+        return result;
+    }
+    Float projectRoughness(V3 v) const
+    { // :531-541
+        Float invSinTheta2 = 1 / (1.0 - v.z * v.z);
+        if (isIsotropic() || invSinTheta2 <= 0) return alphaU;
+        Float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+        return std::sqrt(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
+    }
+    Float smithG1(V3 v, V3 m) const
+    { // :477-514
+        if (dot(v, m) * cosTheta(v) <= 0) return 0.0;
+        Float tanT = std::abs(tanTheta(v));
+        if (tanT == 0.0) return 1.0;
+        Float alpha = projectRoughness(v);
+        if (type == DISTR_BECKMANN) {
+            Float a = 1.0 / (alpha * tanT);
+            if (a >= (Float)1.6f) return 1.0;
+            Float aSqr = a * a;
+            return ((Float)3.535f * a + (Float)2.181f * aSqr) / (1.0 + (Float)2.276f * a + (Float)2.577f * aSqr);
+        }
+        Float root = alpha * tanT;
+        return 2.0 / (1.0 + hypot2(1.0, root));
+    }
+    Float G(V3 wi, V3 wo, V3 m) const { return smithG1(wi, m) * smithG1(wo, m); }
+    Float pdfVisible(V3 wi, V3 m) const
+    { // :470-474
+        if (cosTheta(wi) == 0) return 0.0;
+        return smithG1(wi, m) * std::abs(dot(wi, m)) * eval(m) / std::abs(cosTheta(wi));
+    }
+    Float pdfAll(V3 m) const { return eval(m) * cosTheta(m); } // :417-420
+    Float pdf(V3 wi, V3 m) const { return sampleVisible ? pdfVisible(wi, m) : pdfAll(m); }
+    void sampleVisible11(Float thetaI, Float sx, Float sy, Float &slx, Float &sly) const
+    { // :573-702
+        const Float SQRT_PI_INV = 1 / std::sqrt(PI);
+        if (type == DISTR_BECKMANN) {
+            if (thetaI < (Float)1e-4f) {
+                Float r = std::sqrt(-std::log(1.0 - sx));
+                Float ph = 2 * PI * sy;
+                slx = r * std::cos(ph); sly = r * std::sin(ph);
+                return;
+            }
+            Float tanThetaI = std::tan(thetaI), cotThetaI = 1 / tanThetaI;
+            Float a = -1, c = erf_m(cotThetaI);
+            Float sample_x = std::max(sx, (Float)1e-6f);
+            Float fit = 1 + thetaI * ((Float)-0.876f + thetaI * ((Float)0.4265f - (Float)0.0594f * thetaI));
+            Float b = c - (1 + c) * std::pow(1 - sample_x, fit);
+            Float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * std::exp(-cotThetaI * cotThetaI));
+            int it = 0;
+            while (++it < 10) {
+                if (!(b >= a && b <= c)) b = 0.5 * (a + c);
+                Float invErf = erfinv_m(b);
+                Float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * std::exp(-invErf * invErf)) - sample_x;
+                Float derivative = normalization * (1 - invErf * tanThetaI);
+                if (std::abs(value) < (Float)1e-5f) break;
+                if (value > 0) c = b; else a = b;
+                b -= value / derivative;
+            }
+            slx = erfinv_m(b);
+            sly = erfinv_m(2.0 * std::max(sy, (Float)1e-6f) - 1.0);
+            return;
+        }
+        // GGX
+        if (thetaI < (Float)1e-4f) {
+            Float r = safe_sqrt(sx / (1 - sx));
+            Float ph = 2 * PI * sy;
+            slx = r * std::cos(ph); sly = r * std::sin(ph);
+            return;
+        }
+        Float tanThetaI = std::tan(thetaI), a = 1 / tanThetaI;
+        Float G1 = 2.0 / (1.0 + safe_sqrt(1.0 + 1.0 / (a * a)));
+        Float A = 2.0 * sx / G1 - 1.0;
+        if (std::abs(A) == 1) A -= signum(A) * Epsilon;
+        Float tmp = 1.0 / (A * A - 1.0);
+        Float B = tanThetaI;
+        Float D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+        Float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
+        slx = (A < 0.0 || slope_x_2 > 1.0 / tanThetaI) ? slope_x_1 : slope_x_2;
+        Float S;
+        if (sy > (Float)0.5f) { S = 1.0; sy = 2.0 * (sy - 0.5); }
+        else { S = -1.0; sy = 2.0 * (0.5 - sy); }
+        Float z = (sy * (sy * (sy * (-0.365728915865723) + 0.790235037209296) - 0.424965825137544) + 0.000152998850436920) /
+                  (sy * (sy * (sy * (sy * 0.169507819808272 - 0.397203533833404) - 0.232500544458471) + 1) - 0.539825872510702);
+        sly = S * z * std::sqrt(1.0 + slx * slx);
+    }
+    V3 sampleVisibleM(V3 _wi, Float sx, Float sy) const
+    { // :421-467
+        V3 wi = normalize(V3(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
+        Float theta = 0, phi = 0;
+        if (wi.z < (Float)0.99999) { theta = std::acos(wi.z); phi = std::atan2(wi.y, wi.x); }
+        Float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+        Float slx, sly;
+        sampleVisible11(theta, sx, sy, slx, sly);
+        Float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+        rx *= alphaU; ry *= alphaV;
+        Float normalization = 1.0 / std::sqrt(rx * rx + ry * ry + 1.0);
+        return V3(-rx * normalization, -ry * normalization, normalization);
+    }
+    V3 sampleAll(Float sx, Float sy, Float &pdf) const
+    { // :300-414 (Beckmann/GGX)
+        Float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
+        if (isIsotropic()) {
+            Float ph = (2.0 * PI) * sy;
+            sinPhiM = std::sin(ph); cosPhiM = std::cos(ph);
+            alphaSqr = alphaU * alphaU;
+        } else {
+            Float phiM = std::atan(alphaV / alphaU * std::tan(PI + 2 * PI * sy)) + PI * std::floor(2 * sy + 0.5);
+            sinPhiM = std::sin(phiM); cosPhiM = std::cos(phiM);
+            Float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
+            alphaSqr = 1.0 / (cosSc * cosSc + sinSc * sinSc);
+        }
+        if (type == DISTR_BECKMANN) {
+            Float tanThetaMSqr = alphaSqr * -std::log(1.0 - sx);
+            cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
+            pdf = (1.0 - sx) / (PI * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            Float tanThetaMSqr = alphaSqr * sx / (1.0 - sx);
+            cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
+            Float temp = 1 + tanThetaMSqr / alphaSqr;
+            pdf = INV_PI / (alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+        if (pdf < (Float)1e-20f) pdf = 0;
+        Float sinThetaM = std::sqrt(std::max(0.0, 1 - cosThetaM * cosThetaM));
+        return V3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+    }
+    V3 sample(V3 wi, Float sx, Float sy, Float &pdf) const
+    { // :240-250
+        if (sampleVisible) { V3 m = sampleVisibleM(wi, sx, sy); pdf = pdfVisible(wi, m); return m; }
+        return sampleAll(sx, sy, pdf);
+    }
+};
+
+// ---- BSDFs --------------------------------------------------------------------------------------------
+struct BSDFSample { V3 wo; Float eta; int sampledType; V3 weight; Float pdf; };
+
+inline V3 rgb(const double *a) { return V3(a[0], a[1], a[2]); }
+inline int bsdfType(const gpo_material &m) { return m.type == MAT_DIFFUSE ? EDiffuseReflection : (m.type == MAT_CONDUCTOR ? EDeltaReflection : EGlossyReflection); }
+inline Microfacet distr(const gpo_material &m) { return Microfacet(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0); }
+// BSDF::getRoughness: diffuse.cpp:167-169 (+inf), conductor.cpp:275-277 (0), roughconductor.cpp:437-440
+inline Float getRoughness(const gpo_material &m) { return m.type == MAT_DIFFUSE ? INF : (m.type == MAT_CONDUCTOR ? 0.0 : 0.5 * (m.alphaU + m.alphaV)); }
+
+V3 bsdfEval(const gpo_material &m, V3 wi, V3 wo, int measure)
+{
+    switch (m.type) {
+    case MAT_DIFFUSE: // diffuse.cpp:110-118
+        if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0);
+        return rgb(m.reflectance) * (INV_PI * cosTheta(wo));
+    case MAT_CONDUCTOR: // conductor.cpp:223-239
+        if (measure != MEASURE_DISCRETE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0 || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return V3(0.0);
+        return rgb(m.reflectance) * fresnelConductorExact(cosTheta(wi), rgb(m.eta), rgb(m.k));
+    default: { // roughconductor.cpp:257-293
+        if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0);
+        V3 H = normalize(wo + wi);
+        Microfacet d = distr(m);
+        const Float D = d.eval(H);
+        if (D == 0) return V3(0.0);
+        const V3 F = fresnelConductorExact(dot(wi, H), rgb(m.eta), rgb(m.k)) * rgb(m.reflectance);
+        const Float G = d.G(wi, wo, H);
+        Float model = D * G / (4.0 * cosTheta(wi));
+        return F * model;
+    }
+    }
+}
+
+Float bsdfPdf(const gpo_material &m, V3 wi, V3 wo, int measure)
+{
+    switch (m.type) {
+    case MAT_DIFFUSE: // diffuse.cpp:120-127
+        if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0;
+        return INV_PI * cosTheta(wo);
+    case MAT_CONDUCTOR: // conductor.cpp:241-254
+        if (measure != MEASURE_DISCRETE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0 || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return 0.0;
+        return 1.0;
+    default: { // roughconductor.cpp:295-319
+        if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0;
+        V3 H = normalize(wo + wi);
+        Microfacet d = distr(m);
+        if (d.sampleVisible) return d.eval(H) * d.smithG1(wi, H) / (4.0 * cosTheta(wi));
+        return d.pdf(wi, H) / (4 * std::abs(dot(wo, H)));
+    }
+    }
+}
+
+// The pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
+BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy)
+{
+    BSDFSample r;
+    r.wo = V3(0.0); r.eta = 1.0; r.sampledType = 0; r.weight = V3(0.0); r.pdf = 0.0; // gpt.cpp:450-454: result.pdf starts at 0
+    switch (m.type) {
+    case MAT_DIFFUSE:
+        if (cosTheta(wi) <= 0) return r;
+        r.wo = squareToCosineHemisphere(sx, sy);
+        r.sampledType = EDiffuseReflection;
+        r.pdf = INV_PI * cosTheta(r.wo);
+        r.weight = rgb(m.reflectance);
+        return r;
+    case MAT_CONDUCTOR:
+        if (cosTheta(wi) <= 0) return r;
+        r.sampledType = EDeltaReflection;
+        r.wo = V3(-wi.x, -wi.y, wi.z);
+        r.pdf = 1;
+        r.weight = rgb(m.reflectance) * fresnelConductorExact(cosTheta(wi), rgb(m.eta), rgb(m.k));
+        return r;
+    default: {
+        if (cosTheta(wi) < 0) return r;
+        Microfacet d = distr(m);
+        Float temporaryPdf = 0;
+        V3 mm = d.sample(wi, sx, sy, temporaryPdf);
+        if (temporaryPdf == 0) return r;
+        r.wo = 2 * dot(wi, mm) * mm - wi;
+        r.sampledType = EGlossyReflection;
+        if (cosTheta(r.wo) <= 0) return r;
+        V3 F = fresnelConductorExact(dot(wi, mm), rgb(m.eta), rgb(m.k)) * rgb(m.reflectance);
+        Float weight;
+        if (d.sampleVisible) weight = d.smithG1(r.wo, mm);
+        else weight = d.eval(mm) * d.G(wi, r.wo, mm) * dot(wi, mm) / (temporaryPdf * cosTheta(wi));
+        if (weight > 0) {
+            r.pdf = temporaryPdf / (4.0 * dot(r.wo, mm));
+            r.weight = F * weight;
+        }
+        return r;
+    }
+    }
+}
+
+// ---- emitters -----------------------------------------------------------------------------------------
+struct DirectSamplingRecord { V3 ref, refN, p, n, d; Float dist, pdf; int measure; int object; };
+
+// Intersection::Le -> AreaLight::eval, area.cpp:104-109
+V3 Le(const Scene &sc, const Intersection &its, V3 d)
+{
+    const int e = sc.tris[its.prim].emitter;
+    if (e < 0) return V3(0.0);
+    if (dot(its.sh.n, d) <= 0) return V3(0.0);
+    return sc.emitters[e].radiance;
+}
+
+// Scene::sampleEmitterDirectVisible, scene.cpp:855-879 -> AreaLight::sampleDirect (area.cpp:158-172) ->
+// Shape::sampleDirect (shape.cpp:102-116) -> TriMesh::samplePosition (trimesh.cpp:412-423) -> Triangle::sample (triangle.cpp:24-)
+V3 sampleEmitterDirectVisible(const Scene &sc, DirectSamplingRecord &dRec, Float sx, Float sy, bool &visible)
+{
+    Float emPdf;
+    size_t index = sc.emitterPDF.sampleReuse(sx, emPdf);
+    const Emitter &em = sc.emitters[index];
+    // TriMesh::samplePosition
+    {
+        const std::vector<Float> &cdf = em.cdf;
+        auto entry = std::lower_bound(cdf.begin(), cdf.end(), sy);
+        size_t ti = std::min(cdf.size() - 2, (size_t)std::max((std::ptrdiff_t)0, (std::ptrdiff_t)(entry - cdf.begin()) - 1));
+        while ((cdf[ti + 1] - cdf[ti]) == 0 && ti < cdf.size() - 1) ++ti;
+        sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
+        const Tri &tr = sc.tris[em.firstTri + ti];
+        Float a = safe_sqrt(1.0 - sx);             // warp.cpp:76-79 squareToUniformTriangle
+        Float bx = 1 - a, by = a * sy;
+        V3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
+        dRec.p = tr.p0 + (sideA * bx) + (sideB * by);
+        dRec.n = normalize(cross(sideA, sideB));
+        dRec.pdf = em.invSurfaceArea;
+    }
+    // Shape::sampleDirect
+    dRec.d = dRec.p - dRec.ref;
+    Float distSquared = lengthSquared(dRec.d);
+    dRec.dist = std::sqrt(distSquared);
+    dRec.d = dRec.d / dRec.dist;
+    Float dp = std::abs(dot(dRec.d, dRec.n));
+    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0;
+    dRec.measure = MEASURE_SOLID_ANGLE;
+    // AreaLight::sampleDirect
+    V3 value;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = em.radiance / dRec.pdf;
+    else { dRec.pdf = 0.0; value = V3(0.0); }
+    dRec.object = (int)index;
+    dRec.pdf *= emPdf;
+    value = value / emPdf;
+    Ray ray(dRec.ref, dRec.d, Epsilon, dRec.dist * (1 - ShadowEpsilon));
+    if (rayIntersectShadow(sc, ray)) { visible = false; return V3(0.0); }
+    visible = true;
+    return value;
+}
+
+// Scene::pdfEmitterDirect, scene.cpp:976-979 -> AreaLight::pdfDirect (area.cpp:174-183) -> Shape::pdfDirect (shape.cpp:118-126)
+Float pdfEmitterDirect(const Scene &sc, const DirectSamplingRecord &dRec)
+{
+    const Emitter &em = sc.emitters[dRec.object];
+    Float pd = 0.0;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+        Float pdfPos = em.invSurfaceArea;
+        if (dRec.measure == MEASURE_SOLID_ANGLE) pd = pdfPos * (dRec.dist * dRec.dist) / std::abs(dot(dRec.d, dRec.n));
+        else pd = 0.0;
+    }
+    return pd * (1.0 * sc.emitterPDF.normalization); // Scene::pdfEmitterDiscrete, scene.h:855-857
+}
+
+// ---- sensor: PerspectiveCameraImpl::sampleRayDifferential, perspective.cpp:271-298 -----------------------
+void sampleRay(const Scene &sc, Float px, Float py, Ray &ray)
+{
+    const gpo_camera &c = sc.cam;
+    const Float sxn = px * (1.0 / c.width), syn = py * (1.0 / c.height);
+    // m_sampleToCamera(Point(sx, sy, 0)) for the composite of perspective.cpp:150-156 with crop == film, written out:
+    V3 nearP((1 - 2 * sxn) * c.nearClip * sc.tanHalf, (1 - 2 * syn) / sc.aspect * c.nearClip * sc.tanHalf, c.nearClip);
+    V3 d = normalize(nearP);
+    Float invZ = 1.0 / d.z;
+    ray.mint = c.nearClip * invZ;
+    ray.maxt = c.farClip * invZ;
+    const double *M = c.toWorld;
+    ray.o = V3(M[3], M[7], M[11]);
+    ray.d = V3(M[0] * d.x + M[1] * d.y + M[2] * d.z, M[4] * d.x + M[5] * d.y + M[6] * d.z, M[8] * d.x + M[9] * d.y + M[10] * d.z);
+}
+
+// ================================================================================================================
+// gpt.cpp
+// ================================================================================================================
+enum VertexType { VERTEX_TYPE_GLOSSY, VERTEX_TYPE_DIFFUSE };                         // gpt.cpp:122-125
+enum RayConnection { RAY_NOT_CONNECTED, RAY_RECENTLY_CONNECTED, RAY_CONNECTED };    // gpt.cpp:127-131
+
+struct RayState { // gpt.cpp:135-173
+    Ray ray;
+    V3 throughput;
+    Float pdf;
+    V3 radiance, gradient;
+    Intersection its;
+    Float eta;
+    bool alive;
+    RayConnection connection_status;
+    RayState() : throughput(0.0), pdf(1.0), radiance(0.0), gradient(0.0), eta(1.0), alive(true), connection_status(RAY_NOT_CONNECTED) {}
+    void addRadiance(V3 c, Float w) { radiance = radiance + c * w; }
+    void addGradient(V3 c, Float w) { gradient = gradient + c * w; }
+};
+
+// getVertexType, gpt.cpp:176-231, for single-component BSDFs
+VertexType getVertexType(const gpo_material &m, const gpo_config &cfg, unsigned bsdfTypeMask)
+{
+    Float lowest = INF;
+    bool found_smooth = false, found_dirac = false;
+    Float r = getRoughness(m);
+    bool skip = false;
+    if (r == 0) { found_dirac = true; if (!(bsdfTypeMask & EDelta)) skip = true; }
+    else found_smooth = true;
+    if (!skip && r < lowest) lowest = r;
+    if (!found_smooth && found_dirac && !(bsdfTypeMask & EDelta)) lowest = 0;
+    return lowest <= cfg.shiftThreshold ? VERTEX_TYPE_GLOSSY : VERTEX_TYPE_DIFFUSE;
+}
+
+struct HalfVectorShiftResult { bool success; Float jacobian; V3 wo; };
+V3 reflect(V3 wi, V3 n) { return 2 * dot(wi, n) * n - wi; } // util.cpp:763
+V3 refract(V3 wi, V3 n, Float eta)
+{ // util.cpp:774-792
+    if (eta == 1) return -wi;
+    Float cosThetaI = dot(wi, n);
+    if (cosThetaI > 0) eta = 1 / eta;
+    Float cosThetaTSqr = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
+    if (cosThetaTSqr <= 0.0) return V3(0.0);
+    return n * (cosThetaI * eta - signum(cosThetaI) * std::sqrt(cosThetaTSqr)) - wi * eta;
+}
+
+// halfVectorShift, gpt.cpp:242-305
+HalfVectorShiftResult halfVectorShift(V3 mainWi, V3 mainWo, V3 shiftedWi, Float mainEta, Float shiftedEta)
+{
+    HalfVectorShiftResult result;
+    result.success = false; result.jacobian = 0; result.wo = V3(0.0);
+    if (cosTheta(mainWi) * cosTheta(mainWo) < 0) {
+        if (mainEta == 1 || shiftedEta == 1) return result;
+        V3 hMain = cosTheta(mainWi) < 0 ? -(mainWi * mainEta + mainWo) : -(mainWi + mainWo * mainEta);
+        V3 h = normalize(hMain);
+        V3 shiftedWo = refract(shiftedWi, h, shiftedEta);
+        if (isZero(shiftedWo)) return result;
+        V3 hShifted = cosTheta(shiftedWi) < 0 ? -(shiftedWi * shiftedEta + shiftedWo) : -(shiftedWi + shiftedWo * shiftedEta);
+        Float hLengthSquared = lengthSquared(hShifted) / (D_EPSILON + lengthSquared(hMain));
+        Float WoDotH = std::abs(dot(mainWo, h)) / (D_EPSILON + std::abs(dot(shiftedWo, h)));
+        result.success = true; result.wo = shiftedWo; result.jacobian = hLengthSquared * WoDotH;
+    } else {
+        V3 h = normalize(mainWi + mainWo);
+        V3 shiftedWo = reflect(shiftedWi, h);
+        Float WoDotH = dot(shiftedWo, h) / dot(mainWo, h);
+        result.success = true; result.wo = shiftedWo; result.jacobian = std::abs(WoDotH);
+    }
+    return result;
+}
+
+// testVisibility, gpt.cpp:84-93
+bool testVisibility(const Scene &sc, V3 p1, V3 p2)
+{
+    Ray shadowRay(p1, p2 - p1, Epsilon, 1.0 - ShadowEpsilon);
+    return !rayIntersectShadow(sc, shadowRay);
+}
+
+struct ReconnectionShiftResult { bool success; Float jacobian; V3 wo; };
+// reconnectShift, gpt.cpp:316-345
+ReconnectionShiftResult reconnectShift(const Scene &sc, V3 mainSourceVertex, V3 targetVertex, V3 shiftSourceVertex, V3 targetNormal)
+{
+    ReconnectionShiftResult result;
+    result.success = false; result.jacobian = 0; result.wo = V3(0.0);
+    if (!testVisibility(sc, shiftSourceVertex, targetVertex)) return result;
+    V3 mainEdge = mainSourceVertex - targetVertex, shiftedEdge = shiftSourceVertex - targetVertex;
+    Float mainEdgeLengthSquared = lengthSquared(mainEdge), shiftedEdgeLengthSquared = lengthSquared(shiftedEdge);
+    V3 shiftedWo = -shiftedEdge / std::sqrt(shiftedEdgeLengthSquared);
+    Float mainOpposingCosine = dot(mainEdge, targetNormal) / std::sqrt(mainEdgeLengthSquared);
+    Float shiftedOpposingCosine = dot(shiftedWo, targetNormal);
+    result.jacobian = std::abs(shiftedOpposingCosine * mainEdgeLengthSquared) / (D_EPSILON + std::abs(mainOpposingCosine * shiftedEdgeLengthSquared));
+    result.success = true;
+    result.wo = shiftedWo;
+    return result;
+}
+
+inline const gpo_material &matOf(const Scene &sc, const Intersection &its) { return sc.mats[sc.tris[its.prim].material]; }
+
+// GradientPathTracer::evaluate, gpt.cpp:468-1180 (no environment emitter, no sub-surface scattering in the carried subset)
+void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, RayState *shiftedRays, int secondaryCount, V3 &out_veryDirect)
+{
+    rayIntersect(sc, main.ray, main.its);                                                  // :472
+    main.ray.mint = Epsilon;
+    for (int i = 0; i < secondaryCount; ++i) { rayIntersect(sc, shiftedRays[i].ray, shiftedRays[i].its); shiftedRays[i].ray.mint = Epsilon; }
+    if (!main.its.isValid()) return;                                                       // :482-492 (no environment)
+    if (sc.tris[main.its.prim].emitter >= 0) out_veryDirect = out_veryDirect + main.throughput * Le(sc, main.its, -main.ray.d); // :497-499
+    for (int i = 0; i < secondaryCount; ++i) if (!shiftedRays[i].its.isValid()) shiftedRays[i].alive = false; // :508-513
+    if (cfg.strictNormals) {                                                               // :516-531
+        if (dot(main.ray.d, main.its.geoN) * cosTheta(main.its.wi) >= 0) return;
+        for (int i = 0; i < secondaryCount; ++i) {
+            RayState &s = shiftedRays[i];
+            if (s.its.isValid() && dot(s.ray.d, s.its.geoN) * cosTheta(s.its.wi) >= 0) s.alive = false;
+            else if (!s.its.isValid()) s.alive = false;
+        }
+    }
+    int depth = 1;                                                                         // :535
+    while (depth < cfg.maxDepth || cfg.maxDepth < 0) {                                     // :537
+        if (cfg.strictNormals) {                                                           // :541-556
+            if (dot(main.ray.d, main.its.geoN) * cosTheta(main.its.wi) >= 0) return;
+            for (int i = 0; i < secondaryCount; ++i) {
+                RayState &s = shiftedRays[i];
+                if (s.alive && dot(s.ray.d, s.its.geoN) * cosTheta(s.its.wi) >= 0) s.alive = false;
+            }
+        }
+        const bool lastSegment = (depth + 1 == cfg.maxDepth);                              // :559
+        const gpo_material &mainBSDF = matOf(sc, main.its);
+
+        // ---- direct illumination sampling, :565-730 (minDepth is forced to 1, gpt.cpp:1369) ----
+        if (bsdfType(mainBSDF) & ESmooth) {
+            DirectSamplingRecord dRec;                                                     // records.inl:160-164
+            dRec.ref = main.its.p; dRec.refN = main.its.sh.n;
+            const Float lsx = rng.next1D(), lsy = rng.next1D();                            // :572
+            bool mainEmitterVisible;
+            V3 value = sampleEmitterDirectVisible(sc, dRec, lsx, lsy, mainEmitterVisible);
+            V3 mainEmitterRadiance = value * dRec.pdf;                                     // :575
+            const V3 mainWoL = main.its.sh.toLocal(dRec.d);
+            V3 mainBSDFValue = bsdfEval(mainBSDF, main.its.wi, mainWoL, MEASURE_SOLID_ANGLE); // :588
+            Float mainBsdfPdf = (dRec.measure == MEASURE_SOLID_ANGLE && mainEmitterVisible) ? bsdfPdf(mainBSDF, main.its.wi, mainWoL, MEASURE_SOLID_ANGLE) : 0; // :592
+            Float mainDistanceSquared = lengthSquared(main.its.p - dRec.p);
+            Float mainOpposingCosine = dot(dRec.n, (main.its.p - dRec.p)) / std::sqrt(mainDistanceSquared);
+            Float mainWeightNumerator = main.pdf * dRec.pdf;                               // :599
+            Float mainWeightDenominator = (main.pdf * main.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
+            if (!cfg.strictNormals || dot(main.its.geoN, dRec.d) * cosTheta(mainWoL) > 0) { // :607
+                for (int i = 0; i < secondaryCount; ++i) {
+                    RayState &shifted = shiftedRays[i];
+                    V3 mainContribution(0.0), shiftedContribution(0.0);
+                    Float weight = 0;
+                    bool shiftSuccessful = shifted.alive;
+                    if (shiftSuccessful) {
+                        if (shifted.connection_status == RAY_CONNECTED) {                  // :622-637
+                            Float shiftedBsdfPdf = mainBsdfPdf, shiftedDRecPdf = dRec.pdf, jacobian = 1;
+                            Float shiftedWeightDenominator = (jacobian * shifted.pdf) * (jacobian * shifted.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                            weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
+                            mainContribution = main.throughput * (mainBSDFValue * mainEmitterRadiance);
+                            shiftedContribution = jacobian * shifted.throughput * (mainBSDFValue * mainEmitterRadiance);
+                        } else if (shifted.connection_status == RAY_RECENTLY_CONNECTED) {  // :638-658
+                            V3 incomingDirection = normalize(shifted.its.p - main.its.p);
+                            V3 wiL = main.its.sh.toLocal(incomingDirection), woL = main.its.sh.toLocal(dRec.d);
+                            Float shiftedBsdfPdf = (dRec.measure == MEASURE_SOLID_ANGLE && mainEmitterVisible) ? bsdfPdf(mainBSDF, wiL, woL, MEASURE_SOLID_ANGLE) : 0;
+                            Float shiftedDRecPdf = dRec.pdf;
+                            V3 shiftedBsdfValue = bsdfEval(mainBSDF, wiL, woL, MEASURE_SOLID_ANGLE);
+                            Float jacobian = 1;
+                            Float shiftedWeightDenominator = (jacobian * shifted.pdf) * (jacobian * shifted.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                            weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
+                            mainContribution = main.throughput * (mainBSDFValue * mainEmitterRadiance);
+                            shiftedContribution = jacobian * shifted.throughput * (shiftedBsdfValue * mainEmitterRadiance);
+                        } else {                                                           // :659-705
+                            const gpo_material &shiftedBSDF = matOf(sc, shifted.its);
+                            VertexType mainVertexType = getVertexType(mainBSDF, cfg, ESmooth);
+                            VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, ESmooth);
+                            if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE) { // area lights are never EDiscrete
+                                DirectSamplingRecord shiftedDRec;
+                                shiftedDRec.ref = shifted.its.p; shiftedDRec.refN = shifted.its.sh.n;
+                                bool shiftedEmitterVisible;
+                                V3 sv = sampleEmitterDirectVisible(sc, shiftedDRec, lsx, lsy, shiftedEmitterVisible);
+                                V3 shiftedEmitterRadiance = sv * shiftedDRec.pdf;
+                                Float shiftedDRecPdf = shiftedDRec.pdf;
+                                Float shiftedDistanceSquared = lengthSquared(dRec.p - shifted.its.p);
+                                V3 emitterDirection = (dRec.p - shifted.its.p) / std::sqrt(shiftedDistanceSquared);
+                                Float shiftedOpposingCosine = -dot(dRec.n, emitterDirection);
+                                V3 woL = shifted.its.sh.toLocal(emitterDirection);
+                                if (cfg.strictNormals && dot(shifted.its.geoN, emitterDirection) * cosTheta(woL) < 0) {
+                                    shiftSuccessful = false;
+                                } else {
+                                    V3 shiftedBsdfValue = bsdfEval(shiftedBSDF, shifted.its.wi, woL, MEASURE_SOLID_ANGLE);
+                                    Float shiftedBsdfPdf = (dRec.measure == MEASURE_SOLID_ANGLE && shiftedEmitterVisible) ? bsdfPdf(shiftedBSDF, shifted.its.wi, woL, MEASURE_SOLID_ANGLE) : 0;
+                                    Float jacobian = std::abs(shiftedOpposingCosine * mainDistanceSquared) / (Epsilon + std::abs(mainOpposingCosine * shiftedDistanceSquared)); // :695 (Epsilon, not D_EPSILON)
+                                    Float shiftedWeightDenominator = (jacobian * shifted.pdf) * (jacobian * shifted.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                                    weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
+                                    mainContribution = main.throughput * (mainBSDFValue * mainEmitterRadiance);
+                                    shiftedContribution = jacobian * shifted.throughput * (shiftedBsdfValue * shiftedEmitterRadiance);
+                                }
+                            }
+                        }
+                    }
+                    if (!shiftSuccessful) {                                                // :708-717
+                        weight = mainWeightNumerator / (D_EPSILON + mainWeightDenominator);
+                        mainContribution = main.throughput * (mainBSDFValue * mainEmitterRadiance);
+                        shiftedContribution = V3(0.0);
+                    }
+                    main.addRadiance(mainContribution, weight);                            // :723-726
+                    shifted.addRadiance(shiftedContribution, weight);
+                    shifted.addGradient(shiftedContribution - mainContribution, weight);
+                }
+            }
+        }
+
+        // ---- BSDF sampling and emitter hits, :737-1151 ----
+        const Float bsx = rng.next1D(), bsy = rng.next1D();                                // :456
+        BSDFSample mainBsdfResult = bsdfSample(mainBSDF, main.its.wi, bsx, bsy);
+        if (mainBsdfResult.pdf <= 0.0) break;                                             // :740
+        const V3 mainWo = main.its.sh.toWorld(mainBsdfResult.wo);
+        Float mainWoDotGeoN = dot(main.its.geoN, mainWo);
+        if (cfg.strictNormals && mainWoDotGeoN * cosTheta(mainBsdfResult.wo) <= 0) break;  // :749
+        Intersection previousMainIts = main.its;                                           // :754
+        const V3 mainBsdfWi = main.its.wi;                                                 // bRec.wi
+        bool mainHitEmitter = false;
+        V3 mainEmitterRadiance(0.0);
+        DirectSamplingRecord mainDRec;
+        mainDRec.ref = main.its.p; mainDRec.refN = main.its.sh.n; mainDRec.object = -1; mainDRec.measure = MEASURE_SOLID_ANGLE;
+        VertexType mainVertexType = getVertexType(mainBSDF, cfg, mainBsdfResult.sampledType); // :765
+        VertexType mainNextVertexType;
+        main.ray = Ray(main.its.p, mainWo);                                                // :768
+        if (rayIntersect(sc, main.ray, main.its)) {
+            if (sc.tris[main.its.prim].emitter >= 0) {                                     // :772-777
+                mainEmitterRadiance = Le(sc, main.its, -main.ray.d);
+                mainDRec.p = main.its.p; mainDRec.n = main.its.sh.n; mainDRec.d = main.ray.d; mainDRec.dist = main.its.t; // records.inl:170-178
+                mainDRec.object = sc.tris[main.its.prim].emitter;
+                mainHitEmitter = true;
+            }
+            mainNextVertexType = getVertexType(matOf(sc, main.its), cfg, mainBsdfResult.sampledType); // :785
+        } else break;                                                                      // :802-804 (no environment)
+        Float mainBsdfPdf = mainBsdfResult.pdf, mainPreviousPdf = main.pdf;
+        main.throughput = main.throughput * (mainBsdfResult.weight * mainBsdfResult.pdf);  // :810-812
+        main.pdf *= mainBsdfResult.pdf;
+        main.eta *= mainBsdfResult.eta;
+        const Float mainLumPdf = (mainHitEmitter && !(mainBsdfResult.sampledType & EDelta)) ? pdfEmitterDirect(sc, mainDRec) : 0; // :815
+        Float mainWeightNumerator = mainPreviousPdf * mainBsdfResult.pdf;                  // :819
+        Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
+
+        for (int i = 0; i < secondaryCount; ++i) {                                         // :830
+            RayState &shifted = shiftedRays[i];
+            V3 mainContribution(0.0), shiftedContribution(0.0);
+            Float weight = 0;
+            bool postponedShiftEnd = false;
+            if (shifted.alive) {
+                Float shiftedPreviousPdf = shifted.pdf;
+                if (shifted.connection_status == RAY_CONNECTED) {                          // :844-861
+                    V3 shiftedBsdfValue = mainBsdfResult.weight * mainBsdfResult.pdf;
+                    Float shiftedBsdfPdf = mainBsdfPdf, shiftedLumPdf = mainLumPdf;
+                    shifted.throughput = shifted.throughput * shiftedBsdfValue;
+                    shifted.pdf *= shiftedBsdfPdf;
+                    Float shiftedWeightDenominator = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                    weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
+                    mainContribution = main.throughput * mainEmitterRadiance;
+                    shiftedContribution = shifted.throughput * mainEmitterRadiance;
+                } else if (shifted.connection_status == RAY_RECENTLY_CONNECTED) {          // :862-888
+                    V3 incomingDirection = normalize(shifted.its.p - main.ray.o);
+                    V3 wiL = previousMainIts.sh.toLocal(incomingDirection), woL = previousMainIts.sh.toLocal(main.ray.d);
+                    int measure = (mainBsdfResult.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
+                    V3 shiftedBsdfValue = bsdfEval(mainBSDF, wiL, woL, measure);
+                    Float shiftedBsdfPdf = bsdfPdf(mainBSDF, wiL, woL, measure);
+                    Float shiftedLumPdf = mainLumPdf;
+                    shifted.throughput = shifted.throughput * shiftedBsdfValue;
+                    shifted.pdf *= shiftedBsdfPdf;
+                    shifted.connection_status = RAY_CONNECTED;
+                    Float shiftedWeightDenominator = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                    weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
+                    mainContribution = main.throughput * mainEmitterRadiance;
+                    shiftedContribution = shifted.throughput * mainEmitterRadiance;
+                } else {                                                                   // :889-1126
+                    const gpo_material &shiftedBSDF = matOf(sc, shifted.its);
+                    VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, mainBsdfResult.sampledType);
+                    if (mainVertexType == VERTEX_TYPE_DIFFUSE && mainNextVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE) {
+                        if (!lastSegment || mainHitEmitter) {                              // :901
+                            ReconnectionShiftResult shiftResult = reconnectShift(sc, main.ray.o, main.its.p, shifted.its.p, main.its.geoN);
+                            if (!shiftResult.success) { shifted.alive = false; goto shift_failed; }
+                            V3 incomingDirection = -shifted.ray.d, outgoingDirection = shiftResult.wo;
+                            V3 wiL = shifted.its.sh.toLocal(incomingDirection), woL = shifted.its.sh.toLocal(outgoingDirection);
+                            if (cfg.strictNormals && dot(outgoingDirection, shifted.its.geoN) * cosTheta(woL) <= 0) { shifted.alive = false; goto shift_failed; }
+                            V3 shiftedBsdfValue = bsdfEval(shiftedBSDF, wiL, woL, MEASURE_SOLID_ANGLE);
+                            Float shiftedBsdfPdf = bsdfPdf(shiftedBSDF, wiL, woL, MEASURE_SOLID_ANGLE);
+                            shifted.throughput = shifted.throughput * (shiftedBsdfValue * shiftResult.jacobian); // :939-940
+                            shifted.pdf *= shiftedBsdfPdf * shiftResult.jacobian;
+                            shifted.connection_status = RAY_RECENTLY_CONNECTED;
+                            if (mainHitEmitter) {                                          // :944-986
+                                V3 shiftedEmitterRadiance = Le(sc, main.its, -outgoingDirection);
+                                DirectSamplingRecord shiftedDRec;
+                                shiftedDRec.p = mainDRec.p; shiftedDRec.n = mainDRec.n;
+                                shiftedDRec.dist = length(mainDRec.p - shifted.its.p);
+                                shiftedDRec.d = (mainDRec.p - shifted.its.p) / shiftedDRec.dist;
+                                shiftedDRec.ref = mainDRec.ref; shiftedDRec.refN = shifted.its.sh.n;
+                                shiftedDRec.object = mainDRec.object; shiftedDRec.measure = MEASURE_SOLID_ANGLE;
+                                Float shiftedLumPdf = pdfEmitterDirect(sc, shiftedDRec);
+                                Float shiftedWeightDenominator = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                                weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
+                                mainContribution = main.throughput * mainEmitterRadiance;
+                                shiftedContribution = shifted.throughput * shiftedEmitterRadiance;
+                            }
+                        }
+                    } else {                                                               // half-vector duplication, :987-1126
+                        V3 tangentSpaceIncomingDirection = shifted.its.sh.toLocal(-shifted.ray.d);
+                        V3 tangentSpaceOutgoingDirection;
+                        V3 shiftedEmitterRadiance(0.0);
+                        {
+                            bool bothDelta = (mainBsdfResult.sampledType & EDelta) && (bsdfType(shiftedBSDF) & EDelta);   // :996-1001
+                            bool bothSmooth = (mainBsdfResult.sampledType & ESmooth) && (bsdfType(shiftedBSDF) & ESmooth);
+                            if (!(bothDelta || bothSmooth)) { shifted.alive = false; goto half_vector_shift_failed; }
+                            HalfVectorShiftResult shiftResult = halfVectorShift(mainBsdfWi, mainBsdfResult.wo, shifted.its.sh.toLocal(-shifted.ray.d), 1.0, 1.0); // getEta() == 1 for all carried BSDFs
+                            if (mainBsdfResult.sampledType & EDelta) shiftResult.jacobian = 1;                             // :1008-1011
+                            if (shiftResult.success) {
+                                shifted.throughput = shifted.throughput * shiftResult.jacobian;
+                                shifted.pdf *= shiftResult.jacobian;
+                                tangentSpaceOutgoingDirection = shiftResult.wo;
+                            } else { shifted.alive = false; goto half_vector_shift_failed; }
+                            V3 outgoingDirection = shifted.its.sh.toWorld(tangentSpaceOutgoingDirection);
+                            int measure = (mainBsdfResult.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
+                            shifted.throughput = shifted.throughput * bsdfEval(shiftedBSDF, tangentSpaceIncomingDirection, tangentSpaceOutgoingDirection, measure);
+                            shifted.pdf *= bsdfPdf(shiftedBSDF, tangentSpaceIncomingDirection, tangentSpaceOutgoingDirection, measure);
+                            if (shifted.pdf == 0) { shifted.alive = false; goto half_vector_shift_failed; }                // :1034
+                            if (cfg.strictNormals && dot(outgoingDirection, shifted.its.geoN) * cosTheta(tangentSpaceOutgoingDirection) <= 0) { shifted.alive = false; goto half_vector_shift_failed; }
+                            VertexType shiftedVertexType2 = getVertexType(shiftedBSDF, cfg, mainBsdfResult.sampledType);
+                            shifted.ray = Ray(shifted.its.p, outgoingDirection);                                           // :1050
+                            if (!rayIntersect(sc, shifted.ray, shifted.its)) { shifted.alive = false; goto half_vector_shift_failed; } // :1056-1058 (no env)
+                            VertexType shiftedNextVertexType = getVertexType(matOf(sc, shifted.its), cfg, mainBsdfResult.sampledType);
+                            if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType2 == VERTEX_TYPE_DIFFUSE && shiftedNextVertexType == VERTEX_TYPE_DIFFUSE) { // :1089-1093
+                                shifted.alive = false; goto half_vector_shift_failed;
+                            }
+                            if (sc.tris[shifted.its.prim].emitter >= 0) shiftedEmitterRadiance = Le(sc, shifted.its, -shifted.ray.d);
+                        }
+                    half_vector_shift_failed:
+                        if (shifted.alive) {                                               // :1106-1112
+                            weight = main.pdf / (shifted.pdf * shifted.pdf + main.pdf * main.pdf);
+                            mainContribution = main.throughput * mainEmitterRadiance;
+                            shiftedContribution = shifted.throughput * shiftedEmitterRadiance;
+                        } else {                                                           // :1113-1124
+                            weight = 1.0 / main.pdf;
+                            mainContribution = main.throughput * mainEmitterRadiance;
+                            shiftedContribution = V3(0.0);
+                            shifted.alive = true;
+                            postponedShiftEnd = true;
+                        }
+                    }
+                }
+            }
+        shift_failed:
+            if (!shifted.alive) {                                                          // :1130-1136
+                weight = mainWeightNumerator / (D_EPSILON + mainWeightDenominator);
+                mainContribution = main.throughput * mainEmitterRadiance;
+                shiftedContribution = V3(0.0);
+            }
+            main.addRadiance(mainContribution, weight);                                    // :1140-1146 (depth+1 >= minDepth==1 always)
+            shifted.addRadiance(shiftedContribution, weight);
+            shifted.addGradient(shiftedContribution - mainContribution, weight);
+            if (postponedShiftEnd) shifted.alive = false;
+        }
+        if (!main.its.isValid()) break;                                                    // :1155-1157
+        if (depth++ >= cfg.rrDepth) {                                                      // :1159-1174
+            Float q = std::min(maxc(main.throughput / main.pdf) * main.eta * main.eta, (Float)0.95f);
+            if (rng.next1D() >= q) break;
+            main.pdf *= q;
+            for (int i = 0; i < secondaryCount; ++i) shiftedRays[i].pdf *= q;
+        }
+    }
+}
+
+// ---- film: GPTWorkResult::put (gpt_wr.h:56-64) -> ImageBlock::put (imageblock.h:150-199) with the box filter ----
+struct Film {
+    int W, H;
+    std::vector<double> buf[5]; // [H][W][4]: R,G,B,weight (alpha == 1 carried implicitly)
+    double filterRadius, filterScale, filterValues[32];
+    Film(int w, int h) : W(w), H(h)
+    {
+        for (auto &b : buf) b.assign((size_t)w * h * 4, 0.0);
+        filterRadius = 0.5 + (double)1e-5f;                       // box.cpp:38
+        double sum = 0;                                           // rfilter.cpp:37-55
+        for (int i = 0; i < 31; ++i) { double pos = (filterRadius * i) / 31; double v = std::abs(pos) <= filterRadius ? 1.0 : 0.0; filterValues[i] = v; sum += v; }
+        filterValues[31] = 0.0;
+        filterScale = 31 / filterRadius;
+        sum *= 2 * filterRadius / 31;
+        double normalization = 1.0 / sum;
+        for (int i = 0; i < 31; ++i) filterValues[i] *= normalization;
+    }
+    double evalDiscretized(double x) const { return filterValues[std::min((int)std::abs(x * filterScale), 31)]; } // rfilter.h:76-77
+    void put(double px, double py, V3 spec, double weight, int b)
+    {
+        // Blocks carry a border and are merged by addition with clipping to the film (gpt_proc.cpp:52-56,137-149); net
+        // effect on the film: the footprint of imageblock.h:172-176, restricted to [0,W)x[0,H).
+        const double posx = px - 0.5, posy = py - 0.5;
+        const int x0 = std::max((int)std::ceil(posx - filterRadius), 0), y0 = std::max((int)std::ceil(posy - filterRadius), 0);
+        const int x1 = std::min((int)std::floor(posx + filterRadius), W - 1), y1 = std::min((int)std::floor(posy + filterRadius), H - 1);
+        const double value[4] = {spec.x, spec.y, spec.z, weight};
+        for (int y = y0; y <= y1; ++y) {
+            const double wy = evalDiscretized(y - posy);
+            for (int x = x0; x <= x1; ++x) {
+                const double w = evalDiscretized(x - posx) * wy;
+                double *dest = &buf[b][((size_t)y * W + x) * 4];
+                for (int k = 0; k < 4; ++k) dest[k] += w * value[k];
+            }
+        }
+    }
+};
+
+enum { BUFFER_FINAL = 0, BUFFER_THROUGHPUT = 1, BUFFER_DX = 2, BUFFER_DY = 3, BUFFER_VERY_DIRECT = 4 }; // gpt.cpp:76-80
+
+// GradientPathIntegrator::renderBlock, gpt.cpp:1220-1355, for the pixels of [x0,x1) x [y0,y1)
+void renderRect(const Scene &sc, const gpo_config &cfg, int x0, int y0, int x1, int y1, Film &film)
+{
+    static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};                 // gpt.cpp:410-415
+    for (int py = y0; py < y1; ++py)
+        for (int px = x0; px < x1; ++px)
+            for (int j = 0; j < cfg.spp; ++j) {
+                Rng rng(cfg.seed, (uint64_t)py * sc.cam.width + px, (uint64_t)j);
+                const double sx = px + rng.next1D(), sy = py + rng.next1D();               // :1261
+                RayState mainRay;
+                sampleRay(sc, sx, sy, mainRay.ray);                                        // evaluatePoint, :397-436
+                mainRay.throughput = V3(1.0);
+                RayState shiftedRays[4];
+                for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], shiftedRays[i].ray); shiftedRays[i].throughput = V3(1.0); }
+                V3 veryDirect(0.0);
+                evaluate(sc, cfg, rng, mainRay, shiftedRays, 4, veryDirect);
+                const V3 T = mainRay.radiance;
+                enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
+                // :1314-1352
+                film.put(sx, sy, (8 * veryDirect) + (2 * T), 4.0, BUFFER_FINAL);
+                film.put(sx - 1, sy, 2 * shiftedRays[LEFT].radiance, 1.0, BUFFER_FINAL);
+                film.put(sx + 1, sy, 2 * shiftedRays[RIGHT].radiance, 1.0, BUFFER_FINAL);
+                film.put(sx, sy - 1, 2 * shiftedRays[TOP].radiance, 1.0, BUFFER_FINAL);
+                film.put(sx, sy + 1, 2 * shiftedRays[BOTTOM].radiance, 1.0, BUFFER_FINAL);
+                film.put(sx, sy, 2 * T, 4.0, BUFFER_THROUGHPUT);
+                film.put(sx - 1, sy, 2 * shiftedRays[LEFT].radiance, 1.0, BUFFER_THROUGHPUT);
+                film.put(sx + 1, sy, 2 * shiftedRays[RIGHT].radiance, 1.0, BUFFER_THROUGHPUT);
+                film.put(sx, sy - 1, 2 * shiftedRays[TOP].radiance, 1.0, BUFFER_THROUGHPUT);
+                film.put(sx, sy + 1, 2 * shiftedRays[BOTTOM].radiance, 1.0, BUFFER_THROUGHPUT);
+                film.put(sx - 1, sy, -(2 * shiftedRays[LEFT].gradient), 1.0, BUFFER_DX);
+                film.put(sx, sy, 2 * shiftedRays[RIGHT].gradient, 1.0, BUFFER_DX);
+                film.put(sx, sy - 1, -(2 * shiftedRays[TOP].gradient), 1.0, BUFFER_DY);
+                film.put(sx, sy, 2 * shiftedRays[BOTTOM].gradient, 1.0, BUFFER_DY);
+                film.put(sx, sy, veryDirect, 1.0, BUFFER_VERY_DIRECT);
+            }
+}
+
+} // namespace
+
+// ================================================================================================================
+// C entry points (ctypes)
+// ================================================================================================================
+struct gpo_scene { Scene sc; };
+
+GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *triMaterial, int nmat, const gpo_material *mats,
+                                    int nemit, const gpo_emitter *emitters, const gpo_camera *cam)
+{
+    gpo_scene *h = new gpo_scene;
+    Scene &sc = h->sc;
+    sc.cam = *cam;
+    sc.aspect = (double)cam->width / (double)cam->height;             // sensor.cpp: m_aspect
+    sc.tanHalf = std::tan((cam->fovX * 0.5) * (PI / 180.0));
+    sc.mats.assign(mats, mats + nmat);
+    sc.tris.resize(ntri);
+    sc.aabbMin = V3(INF); sc.aabbMax = V3(-INF);
+    for (int i = 0; i < ntri; ++i) {
+        Tri &t = sc.tris[i];
+        t.p0 = V3(verts[9 * i], verts[9 * i + 1], verts[9 * i + 2]);
+        t.p1 = V3(verts[9 * i + 3], verts[9 * i + 4], verts[9 * i + 5]);
+        t.p2 = V3(verts[9 * i + 6], verts[9 * i + 7], verts[9 * i + 8]);
+        triaccel_load(t.acc, t.p0, t.p1, t.p2);
+        t.material = triMaterial[i];
+        t.emitter = -1;
+        V3 side1 = t.p1 - t.p0, side2 = t.p2 - t.p0;
+        V3 fn = cross(side1, side2);
+        Float len = length(fn);
+        if (!isZero(fn)) fn = fn / len;                               // skdtree.h:369-371
+        t.faceNormal = fn;
+        t.geoN = fn;
+        t.sh.n = fn;                                                   // no vertex normals: shFrame.n = faceNormal (skdtree.h:396)
+        t.sh.s = normalize(side1 - fn * dot(fn, side1));               // computeShadingFrame, util.cpp:603-608
+        t.sh.t = cross(fn, t.sh.s);
+        const V3 ps[3] = {t.p0, t.p1, t.p2};
+        for (const V3 &p : ps) {
+            sc.aabbMin = V3(std::min(sc.aabbMin.x, p.x), std::min(sc.aabbMin.y, p.y), std::min(sc.aabbMin.z, p.z));
+            sc.aabbMax = V3(std::max(sc.aabbMax.x, p.x), std::max(sc.aabbMax.y, p.y), std::max(sc.aabbMax.z, p.z));
+        }
+    }
+    {   // GenericKDTree::buildInternal slightly enlarges the scene bounds (gkdtree.h:1213-1219, MTS_KD_AABB_EPSILON 1e-3f,
+        // gkdtree.h:50); note the second line sees the already-moved min, as in the reference.
+        const Float eps = (Float)1e-3f;
+        sc.aabbMin = sc.aabbMin - ((sc.aabbMax - sc.aabbMin) * eps + V3(eps));
+        sc.aabbMax = sc.aabbMax + ((sc.aabbMax - sc.aabbMin) * eps + V3(eps));
+    }
+    for (int e = 0; e < nemit; ++e) {
+        Emitter em;
+        em.firstTri = emitters[e].firstTri; em.numTris = emitters[e].numTris;
+        em.radiance = V3(emitters[e].radiance[0], emitters[e].radiance[1], emitters[e].radiance[2]);
+        Distribution d;
+        for (int i = 0; i < em.numTris; ++i) {
+            const Tri &t = sc.tris[em.firstTri + i];
+            d.append(0.5 * length(cross(t.p1 - t.p0, t.p2 - t.p0)));   // Triangle::surfaceArea
+            sc.tris[em.firstTri + i].emitter = e;
+        }
+        Float area = d.normalize();
+        em.cdf = d.cdf;
+        em.invSurfaceArea = 1.0 / area;
+        sc.emitters.push_back(em);
+        sc.emitterPDF.append(1.0);                                     // getSamplingWeight() == 1
+    }
+    if (nemit > 0) sc.emitterPDF.normalize();
+    return h;
+}
+
+GPO_API void gpo_scene_destroy(gpo_scene *h) { delete h; }
+
+// Renders pixels [x0,x1) x [y0,y1).  accum: 5 buffers x H x W x 4 doubles (R,G,B,weight sums; film-sized; contributions
+// of the rendered pixels only).  rays[2]: closest-hit and shadow ray counts (skdtree.cpp:46-47 semantics).
+GPO_API void gpo_render(gpo_scene *h, const gpo_config *cfg, int x0, int y0, int x1, int y1, double *accum, unsigned long long *rays)
+{
+    Scene &sc = h->sc;
+    sc.raysTraced = sc.shadowRaysTraced = 0;
+    Film film(sc.cam.width, sc.cam.height);
+    renderRect(sc, *cfg, x0, y0, x1, y1, film);
+    const size_t n = (size_t)sc.cam.width * sc.cam.height * 4;
+    for (int b = 0; b < 5; ++b) std::memcpy(accum + b * n, film.buf[b].data(), n * sizeof(double));
+    if (rays) { rays[0] = sc.raysTraced; rays[1] = sc.shadowRaysTraced; }
+}
+
+// MultiFilm::developMulti -> weight division of fmtconv.cpp:955-1058: invWeight = w != 0 ? 1/w : w ; rgb * invWeight
+GPO_API void gpo_develop(const double *accum, int numPixels, double *rgbOut)
+{
+    for (int i = 0; i < numPixels; ++i) {
+        const double w = accum[4 * i + 3], inv = (w != 0) ? 1.0 / w : w;
+        for (int c = 0; c < 3; ++c) rgbOut[3 * i + c] = accum[4 * i + c] * inv;
+    }
+}
+
+// One sample's raw outputs (for KATs): out = veryDirect(3), throughput(3), gradients[4](12), neighbourThroughputs[4](12)
+GPO_API void gpo_evaluate_point(gpo_scene *h, const gpo_config *cfg, int px, int py, int sampleIndex, double *out30)
+{
+    const Scene &sc = h->sc;
+    static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+    Rng rng(cfg->seed, (uint64_t)py * sc.cam.width + px, (uint64_t)sampleIndex);
+    const double sx = px + rng.next1D(), sy = py + rng.next1D();
+    RayState mainRay;
+    sampleRay(sc, sx, sy, mainRay.ray);
+    mainRay.throughput = V3(1.0);
+    RayState sh[4];
+    for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], sh[i].ray); sh[i].throughput = V3(1.0); }
+    V3 vd(0.0);
+    evaluate(sc, *cfg, rng, mainRay, sh, 4, vd);
+    double *o = out30;
+    *o++ = vd.x; *o++ = vd.y; *o++ = vd.z;
+    *o++ = mainRay.radiance.x; *o++ = mainRay.radiance.y; *o++ = mainRay.radiance.z;
+    for (int i = 0; i < 4; ++i) { *o++ = sh[i].gradient.x; *o++ = sh[i].gradient.y; *o++ = sh[i].gradient.z; }
+    for (int i = 0; i < 4; ++i) { *o++ = sh[i].radiance.x; *o++ = sh[i].radiance.y; *o++ = sh[i].radiance.z; }
+}
+
+// ---- small probes for known-answer tests ----
+GPO_API void gpo_half_vector_shift(const double *mainWi, const double *mainWo, const double *shiftedWi, double mainEta, double shiftedEta, double *out5)
+{
+    HalfVectorShiftResult r = halfVectorShift(V3(mainWi[0], mainWi[1], mainWi[2]), V3(mainWo[0], mainWo[1], mainWo[2]), V3(shiftedWi[0], shiftedWi[1], shiftedWi[2]), mainEta, shiftedEta);
+    out5[0] = r.success; out5[1] = r.jacobian; out5[2] = r.wo.x; out5[3] = r.wo.y; out5[4] = r.wo.z;
+}
+GPO_API void gpo_bsdf_eval_pdf(const gpo_material *m, const double *wi, const double *wo, int measure, double *out4)
+{
+    V3 f = bsdfEval(*m, V3(wi[0], wi[1], wi[2]), V3(wo[0], wo[1], wo[2]), measure);
+    out4[0] = f.x; out4[1] = f.y; out4[2] = f.z; out4[3] = bsdfPdf(*m, V3(wi[0], wi[1], wi[2]), V3(wo[0], wo[1], wo[2]), measure);
+}
+GPO_API void gpo_bsdf_sample(const gpo_material *m, const double *wi, double sx, double sy, double *out8)
+{
+    BSDFSample s = bsdfSample(*m, V3(wi[0], wi[1], wi[2]), sx, sy);
+    out8[0] = s.wo.x; out8[1] = s.wo.y; out8[2] = s.wo.z; out8[3] = s.weight.x; out8[4] = s.weight.y; out8[5] = s.weight.z; out8[6] = s.pdf; out8[7] = s.sampledType;
+}
+GPO_API void gpo_fresnel_conductor(double cosThetaI, const double *eta, const double *k, double *out3)
+{
+    V3 f = fresnelConductorExact(cosThetaI, V3(eta[0], eta[1], eta[2]), V3(k[0], k[1], k[2]));
+    out3[0] = f.x; out3[1] = f.y; out3[2] = f.z;
+}
+GPO_API int gpo_intersect(gpo_scene *h, const double *o, const double *d, double *out_t_p_wi /*7*/)
+{
+    Ray r(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]));
+    Intersection its;
+    if (!rayIntersect(h->sc, r, its)) return -1;
+    out_t_p_wi[0] = its.t; out_t_p_wi[1] = its.p.x; out_t_p_wi[2] = its.p.y; out_t_p_wi[3] = its.p.z;
+    out_t_p_wi[4] = its.wi.x; out_t_p_wi[5] = its.wi.y; out_t_p_wi[6] = its.wi.z;
+    return its.prim;
+}
+GPO_API void gpo_camera_ray(gpo_scene *h, double px, double py, double *out8)
+{
+    Ray r;
+    sampleRay(h->sc, px, py, r);
+    out8[0] = r.o.x; out8[1] = r.o.y; out8[2] = r.o.z; out8[3] = r.d.x; out8[4] = r.d.y; out8[5] = r.d.z; out8[6] = r.mint; out8[7] = r.maxt;
+}
+GPO_API double gpo_rng(unsigned long long seed, unsigned long long pixel, unsigned long long sample, int n)
+{
+    Rng r(seed, pixel, sample);
+    double v = 0;
+    for (int i = 0; i <= n; ++i) v = r.next1D();
+    return v;
+}
+
+// An INDEPENDENT plain path tracer (throughput-only, MIS of light and BSDF sampling, written against the rendering
+// equation rather than gpt.cpp) used only to check that E[-throughput] of the G-PT restatement is the radiance integral.
+// Returns mean radiance (excluding directly visible emitters) of `n` paths through the centre region of pixel (px,py).
+GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int py, int n, double *rgbOut)
+{
+    const Scene &sc = h->sc;
+    V3 sum(0.0);
+    for (int j = 0; j < n; ++j) {
+        Rng rng(cfg->seed ^ 0xABCDEF1234567ULL, (uint64_t)py * sc.cam.width + px, (uint64_t)j);
+        Ray ray;
+        sampleRay(sc, px + rng.next1D(), py + rng.next1D(), ray);
+        Intersection its;
+        if (!rayIntersect(sc, ray, its)) continue;
+        V3 beta(1.0), L(0.0);
+        for (int depth = 1; depth < cfg->maxDepth || cfg->maxDepth < 0; ++depth) {
+            const gpo_material &m = matOf(sc, its);
+            if (bsdfType(m) & ESmooth) {
+                DirectSamplingRecord dRec;
+                dRec.ref = its.p; dRec.refN = its.sh.n;
+                bool vis;
+                const Float u1 = rng.next1D(), u2 = rng.next1D();
+                V3 val = sampleEmitterDirectVisible(sc, dRec, u1, u2, vis);
+                if (vis && dRec.pdf > 0) {
+                    V3 woL = its.sh.toLocal(dRec.d);
+                    V3 f = bsdfEval(m, its.wi, woL, MEASURE_SOLID_ANGLE);
+                    Float pb = bsdfPdf(m, its.wi, woL, MEASURE_SOLID_ANGLE);
+                    Float wgt = (dRec.pdf * dRec.pdf) / (dRec.pdf * dRec.pdf + pb * pb);
+                    L = L + beta * f * val * wgt;
+                }
+            }
+            const Float b1 = rng.next1D(), b2 = rng.next1D();
+            BSDFSample s = bsdfSample(m, its.wi, b1, b2);
+            if (s.pdf <= 0) break;
+            V3 wo = its.sh.toWorld(s.wo);
+            DirectSamplingRecord q;
+            q.ref = its.p; q.refN = its.sh.n;
+            Ray next(its.p, wo);
+            beta = beta * s.weight;
+            if (!rayIntersect(sc, next, its)) break;
+            if (sc.tris[its.prim].emitter >= 0) {
+                V3 le = Le(sc, its, -next.d);
+                q.p = its.p; q.n = its.sh.n; q.d = next.d; q.dist = its.t; q.object = sc.tris[its.prim].emitter; q.measure = MEASURE_SOLID_ANGLE;
+                Float pl = (s.sampledType & EDelta) ? 0.0 : pdfEmitterDirect(sc, q);
+                Float wgt = (s.pdf * s.pdf) / (s.pdf * s.pdf + pl * pl);
+                L = L + beta * le * wgt;
+            }
+            if (depth >= cfg->rrDepth) {
+                Float qv = std::min(maxc(beta), 0.95);
+                if (rng.next1D() >= qv) break;
+                beta = beta / qv;
+            }
+        }
+        sum = sum + L;
+    }
+    rgbOut[0] = sum.x / n; rgbOut[1] = sum.y / n; rgbOut[2] = sum.z / n;
+}

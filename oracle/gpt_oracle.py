@@ -1,0 +1,188 @@
+"""oracle/gpt_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes face of oracle/gpt_oracle.cpp (the double-precision CPU restatement of the reference's G-PT sampler).
+PARITY UNPINNED: see the header of gpt_oracle.cpp and DESIGN.md "Oracle pinning".
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgdpt_oracle_gpt.so")
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int), ("distribution", C.c_int), ("sampleVisible", C.c_int), ("pad", C.c_int),
+                ("reflectance", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3),
+                ("alphaU", C.c_double), ("alphaV", C.c_double)]
+
+
+class Emitter(C.Structure):
+    _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class Config(C.Structure):
+    _fields_ = [("maxDepth", C.c_int), ("rrDepth", C.c_int), ("strictNormals", C.c_int), ("spp", C.c_int),
+                ("shiftThreshold", C.c_double), ("seed", C.c_ulonglong)]
+
+
+def config(maxDepth=-1, rrDepth=5, strictNormals=False, spp=1, shiftThreshold=0.001, seed=5489):
+    """GradientPathTracerConfig defaults of gpt.cpp:1194-1201; seed 5489 echoes random.h:113."""
+    return Config(maxDepth, rrDepth, int(strictNormals), spp, shiftThreshold, seed)
+
+
+def material(m):
+    out = Material()
+    out.type = m["type"]
+    out.distribution = m.get("distribution", 0)
+    out.sampleVisible = m.get("sampleVisible", 1)
+    out.reflectance = (C.c_double * 3)(*m.get("reflectance", (0.5, 0.5, 0.5)))
+    out.eta = (C.c_double * 3)(*m.get("eta", (0.0, 0.0, 0.0)))
+    out.k = (C.c_double * 3)(*m.get("k", (1.0, 1.0, 1.0)))
+    out.alphaU = m.get("alphaU", 0.1)
+    out.alphaV = m.get("alphaV", 0.1)
+    return out
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "gpt_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.gpo_scene_create.restype = C.c_void_p
+        L.gpo_scene_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.gpo_scene_destroy.argtypes = [C.c_void_p]
+        L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.gpo_half_vector_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_bsdf_eval_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.gpo_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_fresnel_conductor.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_camera_ray.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_rng.restype = C.c_double
+        L.gpo_rng.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_int]
+        L.gpo_reference_pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """Oracle-side scene built from a gradientdomain_mitsuba_amd.scenes.Scene-shaped description."""
+
+    def __init__(self, desc):
+        self.desc = desc
+        verts = _d(desc.verts)
+        tm = np.ascontiguousarray(desc.tri_material, dtype=np.int32)
+        mats = (Material * len(desc.materials))(*[material(m) for m in desc.materials])
+        ems = (Emitter * max(1, len(desc.emitters)))()
+        for i, (f, n, rad) in enumerate(desc.emitters):
+            ems[i].firstTri, ems[i].numTris, ems[i].radiance = f, n, (C.c_double * 3)(*rad)
+        cam = Camera()
+        cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
+        cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height
+        self.W, self.H = desc.width, desc.height
+        self._h = lib().gpo_scene_create(verts.shape[0], _p(verts), _p(tm), len(desc.materials), C.byref(mats),
+                                         len(desc.emitters), C.byref(ems), C.byref(cam))
+
+    def render(self, cfg, rect=None):
+        """-> (accum[5,H,W,4] float64, (closest_rays, shadow_rays))."""
+        x0, y0, x1, y1 = rect if rect else (0, 0, self.W, self.H)
+        acc = np.zeros((5, self.H, self.W, 4), np.float64)
+        rays = np.zeros(2, np.uint64)
+        lib().gpo_render(self._h, C.byref(cfg), x0, y0, x1, y1, _p(acc), _p(rays))
+        return acc, (int(rays[0]), int(rays[1]))
+
+    def evaluate_point(self, cfg, px, py, sample):
+        out = np.zeros(30, np.float64)
+        lib().gpo_evaluate_point(self._h, C.byref(cfg), px, py, sample, _p(out))
+        return dict(veryDirect=out[0:3], throughput=out[3:6], gradients=out[6:18].reshape(4, 3), neighbours=out[18:30].reshape(4, 3))
+
+    def intersect(self, o, d):
+        out = np.zeros(7)
+        prim = lib().gpo_intersect(self._h, _p(_d(o)), _p(_d(d)), _p(out))
+        return prim, out[0], out[1:4], out[4:7]
+
+    def camera_ray(self, px, py):
+        out = np.zeros(8)
+        lib().gpo_camera_ray(self._h, px, py, _p(out))
+        return out[0:3], out[3:6], out[6], out[7]
+
+    def reference_pt(self, cfg, px, py, n):
+        out = np.zeros(3)
+        lib().gpo_reference_pt(self._h, C.byref(cfg), px, py, n, _p(out))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().gpo_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def develop(accum):
+    """accum[..., 4] -> rgb[..., 3] (MultiFilm weight division)."""
+    a = _d(accum)
+    out = np.zeros(a.shape[:-1] + (3,), np.float64)
+    lib().gpo_develop(_p(a), int(np.prod(a.shape[:-1])), _p(out))
+    return out
+
+
+def half_vector_shift(main_wi, main_wo, shifted_wi, main_eta=1.0, shifted_eta=1.0):
+    out = np.zeros(5)
+    lib().gpo_half_vector_shift(_p(_d(main_wi)), _p(_d(main_wo)), _p(_d(shifted_wi)), main_eta, shifted_eta, _p(out))
+    return bool(out[0]), out[1], out[2:5]
+
+
+def bsdf_eval_pdf(m, wi, wo, measure=0):
+    mm = material(m)
+    out = np.zeros(4)
+    lib().gpo_bsdf_eval_pdf(C.byref(mm), _p(_d(wi)), _p(_d(wo)), measure, _p(out))
+    return out[0:3], out[3]
+
+
+def bsdf_sample(m, wi, sx, sy):
+    mm = material(m)
+    out = np.zeros(8)
+    lib().gpo_bsdf_sample(C.byref(mm), _p(_d(wi)), sx, sy, _p(out))
+    return out[0:3], out[3:6], out[6], int(out[7])
+
+
+def fresnel_conductor(cos_theta, eta, k):
+    out = np.zeros(3)
+    lib().gpo_fresnel_conductor(cos_theta, _p(_d(eta)), _p(_d(k)), _p(out))
+    return out
+
+
+def rng(seed, pixel, sample, n):
+    return lib().gpo_rng(seed, pixel, sample, n)
