@@ -133,9 +133,8 @@ def cornell_box(width=512, height=512, variant="diffuse"):
     first = len(b.tris)
     b.quad((343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227), lightm, room)  # light, just below the ceiling
     b.emitter(first, 2, (17.0, 12.0, 4.0))
-    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))      # 0.025 sensor, 0.035 focal length
-    if width != height:                                     # keep the vertical extent of the square original: fov is the x-fov
-        fov = 2 * math.degrees(math.atan(math.tan(math.radians(fov) / 2) * width / height))
+    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))      # 0.025 sensor, 0.035 focal length; `fov` is the x-fov (fovAxis = x), so a
+                                                            # wide film crops the square original top and bottom and every pixel sees the box
     return b.finish(to_world=lookat((278, 273, -800), (278, 273, -799), (0, 1, 0)), fov_x=fov, near=10.0, far=2800.0,
                     width=width, height=height, name="cornell-" + variant)
 

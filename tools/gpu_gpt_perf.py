@@ -1,0 +1,16 @@
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from gradientdomain_mitsuba_amd import scenes, gpt
+W, H = 1280, 720
+for variant, spp, md in (("diffuse", 8, -1), ("diffuse", 16, 12), ("glossy", 8, 12)):
+    sc = scenes.cornell_box(W, H, variant)
+    S = gpt.Scene(sc); F = gpt.Film(S)
+    integ = gpt.GradientPathIntegrator(maxDepth=md)
+    cfg = integ.config(spp)
+    integ.renderBlock(S, F, cfg, (0, 0, W, H)); F.sync()
+    st = F.stats(); ms = F.render_ms()
+    rays = st['raysTraced'] + st['shadowRaysTraced']
+    print("%s %dx%d spp%d depth%d: %.1f ms, %.1f Mray/s, %.2f Msample/s, rays/sample %.1f, avg path len %.2f" % (
+        variant, W, H, spp, md, ms, rays / ms / 1e3, W * H * spp / ms / 1e3, rays / (W * H * spp), st['pathLengthSum'] / st['paths']))
+    F.close(); S.close()
