@@ -1,14 +1,19 @@
-"""bench.py -- BASELINE.json metric on MI355X.  `python bench.py --gpus N --steps K --warmup W`.
+"""bench.py -- BASELINE.json's metric on MI355X: `python bench.py --gpus N --steps K --warmup W`.
 
-A step = one pass of the hot path over one batch of synthetic input, at BASELINE configs[1]'s size
-(1280x720).  Round-1 state: the reconstruction half (screened-Poisson CG, preset L2D = 1 IRLS x 50 CG,
-gpt.cpp:1445-1462) is measured; the tracer half (shift-mapped Mray/s) joins `value` when it lands.
-Inputs are resident in HBM before the timed region (import + setup are outside it), matching the span
-of the reference's m_timerTotal (Solver.cpp:378,500).
+A step = one pass of the hot path over one batch of synthetic input at BASELINE configs[1]: the build-authored Cornell
+box (the reference ships no scenes), G-PT 64 spp at 1280x720 in fp64, then develop + screened-Poisson L2D
+reconstruction (gpt.cpp:1358-1480).  The scene (BVH, triangle records) is resident in HBM before the timed region;
+random numbers are the counter-based streams both the HIP path and the oracle use.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); the reconstruction does not shard
-in this round, so ranks run independent replicas ("replicas only") and value = total
-pixel-iterations of all ranks / max-over-ranks time.
+  value            = shift-mapped Mray/s = (closest-hit + any-hit queries of base AND offset paths, the quantity the
+                     reference counts in raysTraced + shadowRaysTraced, skdtree.cpp:46-47) / wall time of the step
+                     (render + halo exchange + develop + gather + reconstruct), all ranks, max over ranks.
+  poisson          = Poisson-CG Mpix-iter/s of the reconstruction inside the same steps (HIP-event span of solveIndirect).
+  roofline         = the CG iteration against HBM (the graded kernel) + the dominant CG kernel's live timing.
+  cpu_baseline     = the oracle (CPU restatement, kind "port": the reference itself cannot be built here) on a bounded sample.
+
+N > 1 (strong scaling, the image is fixed): one process per GPU; rank r renders a contiguous strip of rows, exchanges
+a one-pixel halo with its neighbours by RCCL send/recv, rank 0 gathers the four developed fp32 images and reconstructs.
 """
 import argparse
 import json
@@ -19,33 +24,42 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 1280, 720
-PRESET = "L2D"
-# algorithmic bytes per pixel-iteration, fp32, reference 3-op formulation
-BYTES_PER_PIX_ITER = {"L2D": 120.0, "L2Q": 120.0, "L1D": 132.0, "L1Q": 132.0, "L1L": 132.0}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+W, H, SPP = 1280, 720, 64
+MAX_DEPTH = -1           # gpt.cpp:1194 default (unbounded; Russian roulette from depth 5)
+PRESET = "L2D"           # configs[1]: "L2 CG reconstruct"
+BYTES_PER_PIX_ITER = {"L2D": 120.0, "L1D": 132.0}     # SURVEY.md 8(d), fp32, reference 3-op formulation
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s
 
 
-def cpu_baseline():
-    """Oracle (CPU restatement, 1 thread like the reference's BackendOpenMP off-Windows) on a bounded sample."""
-    from oracle import poisson_oracle as po
-    dx, dy, tp, direct = po.synth_inputs(W, H)
-    reps = 6
+def cpu_baseline(W, H, spp):
+    """Oracle on a bounded sample of the SAME workload: an 8-row band of the 1280x720 image at 64 spp (tracer, 1 core)
+    and one full L2D solve per repetition (solver, 1 core -- the reference's OpenMP backend is single-threaded off
+    Windows, BackendOpenMP.cpp:76-79)."""
+    from gradientdomain_mitsuba_amd import scenes
+    from oracle import gpt_oracle as go, poisson_oracle as po
+    S = go.Scene(scenes.cornell_box(W, H, "diffuse"))
     t0 = time.perf_counter()
+    _, rays = S.render(go.config(maxDepth=MAX_DEPTH, spp=spp), rect=(0, H // 2 - 4, W, H // 2 + 4))
+    dt = time.perf_counter() - t0
+    dx, dy, tp, direct = po.synth_inputs(W, H)
+    t1 = time.perf_counter()
+    reps = 4
     for _ in range(reps):
         po.solve(po.preset(PRESET), dx, dy, tp, direct, W, H)
-    dt = time.perf_counter() - t0
-    return {"value": round(W * H * 50 * reps / dt / 1e6, 2), "unit": "Mpix-iter/s", "cores": 1, "kind": "port",
-            "sample": "%d x %s solve of the same %dx%d synthetic input (%.1f s)" % (reps, PRESET, W, H, dt)}
+    dp = time.perf_counter() - t1
+    return {"value": round(sum(rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": 1, "kind": "port",
+            "sample": "rows %d-%d of the %dx%dx%dspp Cornell render (%d rays, %.1f s) + %d x %s solve (%.1f s)" % (H // 2 - 4, H // 2 + 4, W, H, spp, sum(rays), dt, reps, PRESET, dp),
+            "poisson_mpix_iter_s": round(W * H * 50 * reps / dp / 1e6, 2)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--preset", default=PRESET)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
     a = ap.parse_args()
 
     import torch
@@ -54,26 +68,31 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
+    from gradientdomain_mitsuba_amd import gpt, parallel, scenes
     import gradientdomain_mitsuba_amd.poisson as P
-    from oracle import poisson_oracle as po   # input generator + cpu_baseline only
 
-    dx, dy, tp, direct = (torch.from_numpy(v).cuda() for v in po.synth_inputs(W, H, seed=12345 + rank))
-    prm = P.Params(a.preset, 0.2)
+    desc = scenes.cornell_box(W, H, "diffuse")
+    scene = gpt.Scene(desc, device=local)
+    strips = parallel.row_strips(H, world)
+    y0, y1 = strips[rank]
+    film = gpt.Film(scene, y0, y1)
+    integ = gpt.GradientPathIntegrator(maxDepth=MAX_DEPTH, reconstructL1=False, reconstructL2=True)
+    cfg = integ.config(a.spp)
+    prm = P.Params(PRESET, integ.reconstructAlpha)
     iters = prm.irlsIterMax * prm.cgIterMax
-    s = P.Solver(prm)
-    s.importImagesMTS(dx, dy, tp, direct, W, H)
-
-    def step():
-        s.setupBackend()          # x0 = T, b: outside the timed span, as in the reference
-        s.solveIndirect()
-        return s.lastSolveSeconds
-
-    for _ in range(a.warmup):
-        step()
+    solver = P.Solver(prm) if rank == 0 else None
+    rows = y1 - y0
+    strip_imgs = [torch.empty((rows, W, 3), dtype=torch.float32, device=dev) for _ in range(4)]
+    rec = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -81,44 +100,76 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        """-> (rays of this rank, render kernel ms, solve seconds, halo bytes)"""
+        film.clear()
+        integ.renderBlock(scene, film, cfg, (0, y0, W, y1))                      # GPTBlockRenderer::process over the strip
+        film.sync()
+        halo = parallel.exchange_halos(film, rank, world, dev)
+        for i, b in enumerate((gpt.BUFFER_THROUGHPUT, gpt.BUFFER_DX, gpt.BUFFER_DY, gpt.BUFFER_VERY_DIRECT)):
+            film.develop_device(b, strip_imgs[i])                                 # developMulti + float cast, gpt.cpp:1419-1442
+        full = [parallel.gather_rows(t, strips, W, rank, world) for t in strip_imgs]
+        solve_s = 0.0
+        if rank == 0:
+            solver.importImagesMTS(full[1], full[2], full[0], full[3], W, H)      # dx, dy, throughput, direct
+            solver.setupBackend()
+            solver.solveIndirect()
+            solver.exportImagesMTS(rec)
+            solve_s = solver.lastSolveSeconds
+        st = film.stats()
+        return st["raysTraced"] + st["shadowRaysTraced"], film.render_ms(), solve_s, halo
+
+    for _ in range(a.warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
-    solve_s = 0.0
+    rays = 0
+    render_ms = solve_s = 0.0
+    halo = 0
     for _ in range(a.steps):
-        solve_s += step()
+        r, ms, ss, hb = step()
+        rays += r; render_ms += ms; solve_s += ss; halo = hb
     barrier()
     wall = time.perf_counter() - t0
-    t = torch.tensor([solve_s, wall], dtype=torch.float64, device="cuda")
+    t = torch.tensor([wall, render_ms, float(rays), solve_s], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    solve_s, wall = float(t[0]), float(t[1])
+        mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = t.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        wall, render_ms, solve_s, rays = float(mx[0]), float(mx[1]), float(mx[3]), float(sm[2])
+    else:
+        rays = float(rays)
 
     if rank == 0:
-        mpix_iter = W * H * iters * a.steps * world / solve_s / 1e6
-        kus = s.profileKernels(50)
-        bpi = BYTES_PER_PIX_ITER[a.preset]
-        achieved = bpi * (mpix_iter / world) * 1e6 / 1e9            # GB/s per GPU
-        # dominant kernel: fused x_p+stencil.  Algorithmic bytes per launch: R r,p,x + W x,p,Ap (+ R w for L1)
-        kb = (72.0 if prm.irlsIterMax == 1 else 84.0) * W * H
+        mray = rays / wall / 1e6
+        mpix_iter = W * H * iters * a.steps / solve_s / 1e6
+        kus = solver.profileKernels(50)
+        bpi = BYTES_PER_PIX_ITER[PRESET]
+        achieved = bpi * mpix_iter * 1e6 / 1e9
+        kb = 72.0 * W * H          # fused x_p+stencil, L2 (unit weights): R r,p,x + W x,p,Ap = 72 B/px algorithmic
+        samples = W * H * a.spp * a.steps
         out = {
-            "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, 1280x720x64spp (Poisson-CG half; tracer pending)",
-            "value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * solve_s / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "screened-Poisson %s reconstruct, %dx%d RGB, alpha 0.2 (BASELINE configs[1] size)" % (a.preset, W, H),
-                       "cg_iterations_per_step": iters, "parallelism": "replicas x%d" % world},
-            "wall_ms_per_step_incl_setup": round(1e3 * wall / a.steps, 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "what": "CG iteration, %g B/pix-iter (SURVEY 8d) x pix-iter/s of the timed solves" % bpi,
-                         "kernel": "kf_xp_Ax", "kernel_avg_us": round(kus[3], 2),
+            "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, 1280x720x64spp",
+            "value": round(mray, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * wall / a.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Cornell box (build-authored, 32 triangles), G-PT %d spp, %dx%d, fp64 tracer, %s CG reconstruct (BASELINE configs[1])" % (a.spp, W, H, PRESET),
+                       "maxDepth": MAX_DEPTH, "rrDepth": 5, "parallelism": "row strips x%d + 1-px halo" % world},
+            "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / samples, 2), "msample_s": round(samples / wall / 1e6, 2),
+            "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "render_kernel_mray_s": round(rays / world / (render_ms * 1e-3) / 1e6 * world, 1),
+            "halo_bytes_per_rank": halo,
+            "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "what": "Poisson CG iteration: %g B/pix-iter (SURVEY 8d) x pix-iter/s of the timed solves" % bpi,
+                         "kernel": "kf_xp_Ax", "kernel_avg_us": round(kus[3], 2), "kernel_bytes": kb,
                          "kernel_achieved": round(kb / (kus[3] * 1e-6) / 1e9, 1) if kus[3] > 0 else None,
                          "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2)}},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(W, H, a.spp)
         print(json.dumps(out))
-    s.close()
+    if solver:
+        solver.close()
+    film.close(); scene.close()
     if world > 1:
         dist.destroy_process_group()
 

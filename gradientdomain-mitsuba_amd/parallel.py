@@ -1,0 +1,66 @@
+"""Row-strip sharding of the G-PT hot path over the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference shards by 32x32 image blocks over CPU worker threads and merges block borders by addition
+(/root/reference/src/librender/imageproc.cpp:28-78, gpt_proc.cpp:52-56,137-149).  Here each rank owns a contiguous strip of
+rows; the only coupling is the one-pixel halo: a strip needs the per-pixel sample sums of the row just above and below it
+(and passes on the exact-put spill it produced for its neighbours' rows).  That is two point-to-point messages per rank
+(<= 2 xGMI links, no collective on the data path).  Reconstruction runs on rank 0 after a gather of the four developed
+fp32 images (44 MB at 1280x720; the CG at this size is latency-bound and does not profit from splitting -- DESIGN.md).
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_strips(height, world):
+    """Contiguous row ranges [y0, y1) per rank; earlier ranks take the remainder."""
+    base, rem = divmod(height, world)
+    out, y = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((y, y + n))
+        y += n
+    return out
+
+
+def _wire(t):
+    """gloo (CPU tests, single-GPU functional runs) cannot move device tensors point-to-point: stage through the host."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
+def exchange_halos(film, rank, world, device, group=None):
+    """film: object with halo_bytes(), pack_halo(which, tensor), unpack_halo(which, tensor) (gpt.Film or a test double).
+    which = 0 talks to rank-1 (the strip above), which = 1 to rank+1 (below).  Returns bytes sent."""
+    if world == 1:
+        return 0
+    n = film.halo_bytes() // 8
+    ops, recv, sent = [], {}, 0
+    for which, peer in ((0, rank - 1), (1, rank + 1)):
+        if peer < 0 or peer >= world:
+            continue
+        out = torch.empty(n, dtype=torch.float64, device=device)
+        film.pack_halo(which, out)
+        recv[which] = _wire(torch.empty(n, dtype=torch.float64, device=device))
+        ops.append(dist.P2POp(dist.isend, _wire(out), peer, group=group))
+        ops.append(dist.P2POp(dist.irecv, recv[which], peer, group=group))
+        sent += out.numel() * 8
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for which, buf in recv.items():
+        film.unpack_halo(which, buf.to(device))
+    return sent
+
+
+def gather_rows(strip, strips, width, rank, world, group=None):
+    """Gather per-rank [rows_r, width, 3] fp32 strips to rank 0 as one [H, width, 3] image (None elsewhere)."""
+    if world == 1:
+        return strip
+    if rank == 0:
+        parts = [_wire(torch.empty((y1 - y0, width, 3), dtype=strip.dtype, device=strip.device)) for (y0, y1) in strips]
+        reqs = [dist.irecv(parts[r], r, group=group) for r in range(1, world)]
+        for q in reqs:
+            q.wait()
+        parts[0] = strip
+        return torch.cat([p.to(strip.device) for p in parts], dim=0)
+    dist.send(_wire(strip.contiguous()), 0, group=group)
+    return None

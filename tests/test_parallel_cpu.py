@@ -1,0 +1,107 @@
+"""CPU (gloo, world_size 2 and 3) tests of the row-strip halo protocol of gradientdomain-mitsuba_amd/parallel.py.
+The film here is a numpy double of gpt.Film's pack/unpack contract (csrc/gpt_render.hip.h k_pack_halo/k_unpack_halo);
+the same protocol against real device films is tested on the GPU in tests/test_gpt_gpu.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gradientdomain_mitsuba_amd import parallel
+
+NREC = 31
+
+
+class FakeFilm:
+    """rec[NREC][rows+2][W] (row 0 / -1 = halo), spill[5][rows+2][W][4]; same payload layout as the device film."""
+
+    def __init__(self, W, y0, y1, seed):
+        rng = np.random.default_rng(seed)
+        self.W, self.y0, self.y1 = W, y0, y1
+        rows = y1 - y0 + 2
+        self.rec = rng.standard_normal((NREC, rows, W))
+        self.rec[:, 0] = 0; self.rec[:, -1] = 0
+        self.spill = rng.standard_normal((5, rows, W, 4))
+
+    def halo_bytes(self):
+        return 8 * (NREC * self.W + 5 * self.W * 4)
+
+    def pack_halo(self, which, t):
+        own, halo = (1, 0) if which == 0 else (-2, -1)
+        t.copy_(torch.from_numpy(np.concatenate([self.rec[:, own].ravel(), self.spill[:, halo].ravel()])))
+
+    def unpack_halo(self, which, t):
+        own, halo = (1, 0) if which == 0 else (-2, -1)
+        a = t.numpy()
+        self.rec[:, halo] = a[:NREC * self.W].reshape(NREC, self.W)
+        self.spill[:, own] += a[NREC * self.W:].reshape(5, self.W, 4)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, W, H, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    strips = parallel.row_strips(H, world)
+    y0, y1 = strips[rank]
+    film = FakeFilm(W, y0, y1, seed=100 + rank)
+    before_spill = film.spill.copy()
+    sent = parallel.exchange_halos(film, rank, world, torch.device("cpu"))
+    strip = torch.from_numpy(np.full((y1 - y0, W, 3), float(rank), np.float32))
+    img = parallel.gather_rows(strip, strips, W, rank, world)
+    q.put((rank, film.rec[:, 0].copy(), film.rec[:, -1].copy(), film.rec[:, 1].copy(), film.rec[:, -2].copy(),
+           (film.spill - before_spill)[:, 1].copy(), (film.spill - before_spill)[:, -2].copy(), before_spill[:, 0].copy(), before_spill[:, -1].copy(),
+           sent, None if img is None else img.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_and_gather_over_gloo(world):
+    W, H = 24, 17
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    strips = parallel.row_strips(H, world)
+    assert strips[0][0] == 0 and strips[-1][1] == H and all(a[1] == b[0] for a, b in zip(strips, strips[1:]))
+    for r in range(world):
+        _, halo_top, halo_bot, own_top, own_bot, dsp_top, dsp_bot, sp_halo_top, sp_halo_bot, sent, img = res[r]
+        if r > 0:      # my top halo row == upper neighbour's last owned row; its bottom-halo spill was added to my first row
+            assert np.array_equal(halo_top, res[r - 1][4]) and np.allclose(dsp_top, res[r - 1][8])
+        else:
+            assert not halo_top.any() and not dsp_top.any()
+        if r < world - 1:
+            assert np.array_equal(halo_bot, res[r + 1][3]) and np.allclose(dsp_bot, res[r + 1][7])
+        else:
+            assert not halo_bot.any() and not dsp_bot.any()
+        assert sent == 8 * (NREC * W + 20 * W) * ((r > 0) + (r < world - 1))
+        if r == 0:
+            assert img.shape == (H, W, 3)
+            for rr, (y0, y1) in enumerate(strips):
+                assert (img[y0:y1] == rr).all()
+        else:
+            assert img is None
+
+
+def test_row_strips_cover_the_image():
+    for H in (1, 7, 720, 1080):
+        for world in (1, 2, 3, 8):
+            if world > H:
+                continue
+            s = parallel.row_strips(H, world)
+            assert s[0][0] == 0 and s[-1][1] == H and max(b - a for a, b in s) - min(b - a for a, b in s) <= 1
