@@ -262,7 +262,7 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
         o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));
         o.eta = to_d3(h3(m.eta[0], m.eta[1], m.eta[2]));
         o.k = to_d3(h3(m.k[0], m.k[1], m.k[2]));
-        o.alphaU = m.alphaU; o.alphaV = m.alphaV;
+        o.alphaU = m.alphaU; o.alphaV = m.alphaV; o.pad2 = 0.0;
     }
 
     // emitters: DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h:95-108), scene-level emitter pdf (scene.cpp:357-380)
@@ -306,7 +306,9 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     d.nodes = dn; d.isect = di; d.shade = ds; d.mats = dm; d.emitters = de; d.emTris = det; d.emCdf = dc; d.emitterCdf = dsc;
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = numEmitters;
-    d.ldsScene = ((size_t)d.numNodes * sizeof(BvhNode) + (size_t)numTris * sizeof(TriIsect) <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
+    d.numMats = numMaterials;
+    d.ldsScene = ((size_t)d.numNodes * sizeof(BvhNode) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) + (size_t)numMaterials * sizeof(MaterialD) +
+                      (size_t)numEmitters * sizeof(EmitterD) + 64 <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
     CameraD &c = d.cam;
     for (int r = 0; r < 3; r++)
         for (int k = 0; k < 4; k++) c.m[4 * r + k] = camera->toWorld[4 * r + k];
@@ -390,7 +392,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     THIPCHK(hipEventCreate(&e0));
     THIPCHK(hipEventCreate(&e1));
     THIPCHK(hipEventRecord(e0, f->stream));
-    hipLaunchKernelGGL(k_render, dim3(tilesX * tilesY), dim3(TBLK), 0, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX);
+    if (s->d.ldsScene) hipLaunchKernelGGL(k_render<true>, dim3(tilesX * tilesY), dim3(TBLK), 0, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX);
+    else hipLaunchKernelGGL(k_render<false>, dim3(tilesX * tilesY), dim3(TBLK), 0, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX);
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));

@@ -42,7 +42,7 @@ constexpr int TBLK = 256;          // threads per block (16x16 px)
 constexpr int STACK_DEPTH = 28;    // BVH traversal stack entries per lane (LDS)
 constexpr int REGEN_MIN = 24;      // idle lanes in a wave before they regenerate together
 constexpr int NREC = 31;           // per-pixel record components
-constexpr int LDS_SCENE_BYTES = 40 * 1024;
+constexpr int LDS_SCENE_BYTES = 40 * 1024;   // node + triangle + shading + material + emitter tables of a small scene
 
 struct d3 { Float x, y, z; };
 __device__ __forceinline__ d3 mk(Float x, Float y, Float z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -79,17 +79,19 @@ struct TriShade {           // 160 B: what fillIntersectionRecord needs (skdtree
     int material, emitter;  // emitter = -1 if none
     int origIndex, pad;
 };
-struct MaterialD {
+struct MaterialD {           // 112 B (a multiple of 16: tables are staged into LDS with 16-byte copies)
     int type, distribution, sampleVisible, pad;
     d3 reflectance, eta, k;
-    Float alphaU, alphaV;
+    Float alphaU, alphaV, pad2;
 };
+static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {
     int firstEmTri, numTris, cdfOffset, pad;
     d3 radiance;
     Float invSurfaceArea;
 };
 struct EmTri { d3 p0, p1, p2; };
+static_assert(sizeof(EmitterD) % 16 == 0, "LDS staging copies 16-byte words");
 struct CameraD {
     Float m[12];            // rows of the 3x4 camera-to-world
     Float nearClip, farClip, tanHalf, aspect, invW, invH;
@@ -105,7 +107,7 @@ struct SceneD {
     const Float *emCdf;         // per-emitter triangle-area cdfs, concatenated
     const Float *emitterCdf;    // scene-level emitter cdf (numEmitters + 1)
     Float emitterNormalization;
-    int numNodes, numTris, numEmitters, ldsScene;
+    int numNodes, numTris, numEmitters, numMats, ldsScene;
     CameraD cam;
 };
 struct ConfigD {
@@ -155,6 +157,9 @@ struct Hit { Float t, u, v; int prim; };   // prim = index in leaf order, -1 = m
 struct SceneView {
     const BvhNode *nodes;
     const TriIsect *isect;
+    const TriShade *shade;
+    const MaterialD *mats;
+    const EmitterD *emitters;
 };
 
 // TriAccel::rayIntersect, triaccel.h:96-158
@@ -543,12 +548,12 @@ __device__ __forceinline__ int cdf_sample(const Float *cdf, int n /*entries = n+
 // Scene::sampleEmitterDirectVisible (scene.cpp:855-879) minus the shadow ray, which the caller casts:
 // AreaLight::sampleDirect (area.cpp:158-172) -> Shape::sampleDirect (shape.cpp:102-116) -> TriMesh::samplePosition
 // (trimesh.cpp:412-423) -> Triangle::sample (triangle.cpp:24-).  Returns value (already / emPdf); dRec.pdf includes emPdf.
-__device__ d3 sample_emitter_direct(const SceneD &S, DRec &dRec, Float sx, Float sy)
+__device__ d3 sample_emitter_direct(const SceneD &S, const SceneView &V, DRec &dRec, Float sx, Float sy)
 {
     const int index = cdf_sample(S.emitterCdf, S.numEmitters, sx);
     const Float emPdf = S.emitterCdf[index + 1] - S.emitterCdf[index];
     sx = (sx - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
-    const EmitterD em = S.emitters[index];
+    const EmitterD em = V.emitters[index];
     const Float *cdf = S.emCdf + em.cdfOffset;
     const int ti = cdf_sample(cdf, em.numTris, sy);
     sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
@@ -575,10 +580,10 @@ __device__ d3 sample_emitter_direct(const SceneD &S, DRec &dRec, Float sx, Float
 }
 
 // Scene::pdfEmitterDirect, scene.cpp:976-979 -> area.cpp:174-183 -> shape.cpp:118-126 (solid-angle measure)
-__device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, int object, d3 d, d3 refN, d3 n, Float dist)
+__device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, const SceneView &V, int object, d3 d, d3 refN, d3 n, Float dist)
 {
     Float pd = 0.0;
-    if (dot(d, refN) >= 0 && dot(d, n) < 0) pd = S.emitters[object].invSurfaceArea * (dist * dist) / fabs(dot(d, n));
+    if (dot(d, refN) >= 0 && dot(d, n) < 0) pd = V.emitters[object].invSurfaceArea * (dist * dist) / fabs(dot(d, n));
     return pd * (1.0 * S.emitterNormalization);
 }
 
@@ -624,7 +629,7 @@ struct Offset {             // RayState of an offset path, gpt.cpp:135-173
 __device__ __forceinline__ Frame3 frame_of(const TriShade &t) { Frame3 f; f.s = t.s; f.t = t.t; f.n = t.n; return f; }
 
 // fillIntersectionRecord<true>, skdtree.h:343-428 (flat triangle): barycentric position, wi in the shading frame
-__device__ __forceinline__ void fill_vertex(const SceneD &S, const Hit &h, d3 rayD, Vertex &v)
+__device__ __forceinline__ void fill_vertex(const SceneView &S, const Hit &h, d3 rayD, Vertex &v)
 {
     v.prim = h.prim;
     if (h.prim < 0) return;
@@ -635,7 +640,7 @@ __device__ __forceinline__ void fill_vertex(const SceneD &S, const Hit &h, d3 ra
 }
 
 // AreaLight::eval via Intersection::Le, area.cpp:104-109
-__device__ __forceinline__ d3 emitted(const SceneD &S, int prim, d3 d)
+__device__ __forceinline__ d3 emitted(const SceneView &S, int prim, d3 d)
 {
     const TriShade &ts = S.shade[prim];
     if (ts.emitter < 0 || dot(ts.n, d) <= 0) return mk(0.0);

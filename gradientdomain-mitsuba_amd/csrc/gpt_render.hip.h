@@ -35,25 +35,34 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
-__device__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, int px, int py, int sample)
+__device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, int px, int py, int sample)
 {
     const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
     L.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
     L.sx = px + L.rng.next1D();                                                  // gpt.cpp:1261
     L.sy = py + L.rng.next1D();
     L.throughput = mk(1.0); L.radiance = mk(0.0); L.pdf = 1.0; L.eta = 1.0; L.veryDirect = mk(0.0); L.depth = 1;
+    // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
+    Hit hits[5];
 #pragma unroll 1
     for (int r = 0; r < 5; r++) {
         d3 o, d;
         Float mint, maxt;
-        camera_ray(S.cam, L.sx + (r ? shx[r - 1] : 0.0), L.sy + (r ? shy[r - 1] : 0.0), o, d, mint, maxt);
-        Hit h;
+        const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);
+        camera_ray(S.cam, L.sx + ox, L.sy + oy, o, d, mint, maxt);
         L.nClosest++;
-        trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, h);
-        if (r == 0) { fill_vertex(S, h, d, L.v); L.rayO = o; L.rayD = d; }
+        trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, hits[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        d3 o, d;
+        Float mint, maxt;
+        camera_ray(S.cam, L.sx + (r ? shx[r - 1] : 0.0), L.sy + (r ? shy[r - 1] : 0.0), o, d, mint, maxt);
+        const Hit h = hits[r];
+        if (r == 0) { fill_vertex(sv, h, d, L.v); L.rayO = o; L.rayD = d; }
         else {
             Offset &s = L.off[r - 1];
-            fill_vertex(S, h, d, s.v);
+            fill_vertex(sv, h, d, s.v);
             s.rayD = d;
             s.throughput = mk(1.0); s.radiance = mk(0.0); s.gradient = mk(0.0); s.pdf = 1.0;
             s.alive = h.prim >= 0;                                               // :508-513
@@ -61,40 +70,42 @@ __device__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &
         }
     }
     if (L.v.prim < 0) return false;                                              // :482-492 (no environment emitter)
-    L.veryDirect = L.veryDirect + L.throughput * emitted(S, L.v.prim, -L.rayD);  // :497-499
+    L.veryDirect = L.veryDirect + L.throughput * emitted(sv, L.v.prim, -L.rayD);  // :497-499
     if (cfg.strictNormals) {                                                     // :516-531
-        if (dot(L.rayD, S.shade[L.v.prim].n) * L.v.wi.z >= 0) return false;
+        if (dot(L.rayD, sv.shade[L.v.prim].n) * L.v.wi.z >= 0) return false;
+#pragma unroll
         for (int i = 0; i < 4; i++) {
             Offset &s = L.off[i];
-            if (s.alive && dot(s.rayD, S.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
+            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
         }
     }
     return true;
 }
 
 // One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
-__device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L)
+__device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
-    const TriShade &mts = S.shade[L.v.prim];
+    const TriShade &mts = sv.shade[L.v.prim];
     const Frame3 mfr = frame_of(mts);
     const d3 mGeoN = mts.n;
     if (cfg.strictNormals) {                                                     // :541-556
         if (dot(L.rayD, mGeoN) * L.v.wi.z >= 0) return false;
+#pragma unroll
         for (int i = 0; i < 4; i++) {
             Offset &s = L.off[i];
-            if (s.alive && dot(s.rayD, S.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
+            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
         }
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
-    const MaterialD &mainBSDF = S.mats[mts.material];
+    const MaterialD &mainBSDF = sv.mats[mts.material];
 
     // ================= direct illumination sampling, :565-730 =================
     if (bsdfType(mainBSDF) & ESmooth) {
         DRec dRec;
         dRec.ref = L.v.p; dRec.refN = mfr.n;                                     // records.inl:160-164
         const Float lsx = L.rng.next1D(), lsy = L.rng.next1D();                  // :572
-        d3 value = sample_emitter_direct(S, dRec, lsx, lsy);
+        d3 value = sample_emitter_direct(S, sv, dRec, lsx, lsy);
         const bool mainEmitterVisible = !cast_shadow(sv, stack, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
         if (!mainEmitterVisible) value = mk(0.0);
         const d3 mainEmitterRadiance = value * dRec.pdf;                         // :575
@@ -109,7 +120,7 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
         const Float mainWeightDenominator = (L.pdf * L.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
         const d3 mainContributionAll = L.throughput * (mainBSDFValue * mainEmitterRadiance);
         if (!cfg.strictNormals || dot(mGeoN, dRec.d) * mainWoL.z > 0) {         // :607
-#pragma unroll 1
+#pragma unroll
             for (int i = 0; i < 4; i++) {
                 Offset &s = L.off[i];
                 d3 shiftedContribution = mk(0.0);
@@ -133,13 +144,13 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
                         shiftedContribution = 1.0 * s.throughput * (f * mainEmitterRadiance);
                         assigned = true;
                     } else {                                                     // :659-705
-                        const TriShade &sts = S.shade[s.v.prim];
-                        const MaterialD &shiftedBSDF = S.mats[sts.material];
+                        const TriShade &sts = sv.shade[s.v.prim];
+                        const MaterialD &shiftedBSDF = sv.mats[sts.material];
                         if (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth)) {
                             const Frame3 sfr = frame_of(sts);
                             DRec sRec;
                             sRec.ref = s.v.p; sRec.refN = sfr.n;
-                            d3 sv_ = sample_emitter_direct(S, sRec, lsx, lsy);
+                            d3 sv_ = sample_emitter_direct(S, sv, sRec, lsx, lsy);
                             const bool shiftedEmitterVisible = !cast_shadow(sv, stack, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
                             if (!shiftedEmitterVisible) sv_ = mk(0.0);
                             const d3 shiftedEmitterRadiance = sv_ * sRec.pdf;
@@ -193,24 +204,24 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
         L.nClosest++;
         trace<false>(sv, stack, L.rayO, L.rayD, ray_mint_closest(L.rayO, GD_EPSILON), GD_INF, h);
         if (h.prim < 0) return false;                                            // :802-804 (no environment)
-        fill_vertex(S, h, L.rayD, L.v);
+        fill_vertex(sv, h, L.rayD, L.v);
         L.depthT = h.t;
     }
-    const TriShade &nts = S.shade[L.v.prim];
+    const TriShade &nts = sv.shade[L.v.prim];
     const bool mainHitEmitter = nts.emitter >= 0;                                 // :772-777
-    const d3 mainEmitterRadiance = mainHitEmitter ? emitted(S, L.v.prim, -L.rayD) : mk(0.0);
-    const bool mainNextVertexDiffuse = vertex_is_diffuse(S.mats[nts.material], cfg, bs.sampledType);  // :785
+    const d3 mainEmitterRadiance = mainHitEmitter ? emitted(sv, L.v.prim, -L.rayD) : mk(0.0);
+    const bool mainNextVertexDiffuse = vertex_is_diffuse(sv.mats[nts.material], cfg, bs.sampledType);  // :785
     const Float mainBsdfPdf = bs.pdf, mainPreviousPdf = L.pdf;
     L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
     L.pdf *= bs.pdf;
     // mainDRec: ref = previous vertex, refN = its shading normal; setQuery (records.inl:170-178): p, n, d, dist
-    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, nts.emitter, L.rayD, mfr.n, nts.n, L.depthT) : 0;  // :815
+    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, mfr.n, nts.n, L.depthT) : 0;  // :815
     const Float mainWeightNumerator = mainPreviousPdf * bs.pdf;                   // :819-820
     const Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
     const int measure = (bs.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
 
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 4; i++) {                                                // :830
         Offset &s = L.off[i];
         d3 shiftedContribution = mk(0.0);
@@ -239,8 +250,8 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
                 shiftedContribution = s.throughput * mainEmitterRadiance;
                 assigned = true;
             } else {                                                             // :889-1126
-                const TriShade &sts = S.shade[s.v.prim];
-                const MaterialD &shiftedBSDF = S.mats[sts.material];
+                const TriShade &sts = sv.shade[s.v.prim];
+                const MaterialD &shiftedBSDF = sv.mats[sts.material];
                 const Frame3 sfr = frame_of(sts);
                 const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
                 if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
@@ -265,10 +276,10 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
                                 s.pdf *= shiftedBsdfPdf * jacobian;
                                 s.status = RAY_RECENTLY_CONNECTED;
                                 if (mainHitEmitter) {                            // :944-986
-                                    const d3 shiftedEmitterRadiance = emitted(S, L.v.prim, -shiftedWo);
+                                    const d3 shiftedEmitterRadiance = emitted(sv, L.v.prim, -shiftedWo);
                                     const Float sdist = len(L.v.p - s.v.p);
                                     const d3 sd = (L.v.p - s.v.p) / sdist;
-                                    const Float shiftedLumPdf = pdf_emitter_direct(S, nts.emitter, sd, sfr.n, nts.n, sdist);
+                                    const Float shiftedLumPdf = pdf_emitter_direct(S, sv, nts.emitter, sd, sfr.n, nts.n, sdist);
                                     const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                                     weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                                     shiftedContribution = s.throughput * shiftedEmitterRadiance;
@@ -307,11 +318,11 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
                             if (h.prim < 0) ok = false;                          // :1056-1058 (no environment)
                             else {
                                 s.rayD = outgoing;
-                                fill_vertex(S, h, outgoing, s.v);
-                                const TriShade &snts = S.shade[s.v.prim];
-                                const bool shiftedNextVertexDiffuse = vertex_is_diffuse(S.mats[snts.material], cfg, bs.sampledType);
+                                fill_vertex(sv, h, outgoing, s.v);
+                                const TriShade &snts = sv.shade[s.v.prim];
+                                const bool shiftedNextVertexDiffuse = vertex_is_diffuse(sv.mats[snts.material], cfg, bs.sampledType);
                                 if (mainVertexDiffuse && shiftedVertexDiffuse && shiftedNextVertexDiffuse) ok = false;   // :1089-1093
-                                else if (snts.emitter >= 0) shiftedEmitterRadiance = emitted(S, s.v.prim, -outgoing);
+                                else if (snts.emitter >= 0) shiftedEmitterRadiance = emitted(sv, s.v.prim, -outgoing);
                             }
                         }
                     }
@@ -343,6 +354,7 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
         const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
         if (L.rng.next1D() >= q) return false;
         L.pdf *= q;
+#pragma unroll
         for (int i = 0; i < 4; i++) L.off[i].pdf *= q;
     }
     return true;
@@ -350,7 +362,7 @@ __device__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg,
 
 // Accumulates one finished sample: the 15 puts of gpt.cpp:1314-1352.  Fast path = per-pixel sums (every put covers
 // exactly its expected pixel); otherwise the exact generic path.
-__device__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, int px, int py)
+__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, int px, int py)
 {
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
     const bool fast = single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
@@ -362,7 +374,7 @@ __device__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, int px,
         r[0] += 1.0;
         r[1 * st] += L.radiance.x; r[2 * st] += L.radiance.y; r[3 * st] += L.radiance.z;
         r[4 * st] += L.veryDirect.x; r[5 * st] += L.veryDirect.y; r[6 * st] += L.veryDirect.z;
-#pragma unroll 1
+#pragma unroll
         for (int d = 0; d < 4; d++) {
             const Offset &s = L.off[d];
             r[(7 + 3 * d) * st] += s.radiance.x; r[(8 + 3 * d) * st] += s.radiance.y; r[(9 + 3 * d) * st] += s.radiance.z;
@@ -389,22 +401,33 @@ __device__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, int px,
     }
 }
 
+template <bool LDS_SCENE>
 __global__ __launch_bounds__(TBLK) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
-    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? LDS_SCENE_BYTES : 16];
     SceneView sv;
-    if (S.ldsScene) {
-        // stage node packets and triangle records through LDS once per block (coalesced 16-byte copies)
-        const int nodeBytes = S.numNodes * (int)sizeof(BvhNode), triBytes = S.numTris * (int)sizeof(TriIsect);
-        const uint4 *gn = reinterpret_cast<const uint4 *>(S.nodes), *gt = reinterpret_cast<const uint4 *>(S.isect);
-        uint4 *ln = reinterpret_cast<uint4 *>(s_scene), *lt = reinterpret_cast<uint4 *>(s_scene + nodeBytes);
-        for (int i = threadIdx.x; i < nodeBytes / 16; i += TBLK) ln[i] = gn[i];
-        for (int i = threadIdx.x; i < triBytes / 16; i += TBLK) lt[i] = gt[i];
+    if (LDS_SCENE) {
+        // stage node packets, triangle records and the shading tables through LDS once per block (coalesced 16-byte copies);
+        // the compile-time branch lets the compiler address them with ds_read instead of flat loads
+        const int nb[5] = {S.numNodes * (int)sizeof(BvhNode), S.numTris * (int)sizeof(TriIsect), S.numTris * (int)sizeof(TriShade),
+                           S.numMats * (int)sizeof(MaterialD), S.numEmitters * (int)sizeof(EmitterD)};
+        const void *src[5] = {S.nodes, S.isect, S.shade, S.mats, S.emitters};
+        int off = 0, offs[5];
+        for (int a = 0; a < 5; a++) {
+            offs[a] = off;
+            const uint4 *g = reinterpret_cast<const uint4 *>(src[a]);
+            uint4 *l = reinterpret_cast<uint4 *>(s_scene + off);
+            for (int i = threadIdx.x; i < nb[a] / 16; i += TBLK) l[i] = g[i];
+            off += (nb[a] + 15) & ~15;
+        }
         __syncthreads();
-        sv.nodes = reinterpret_cast<const BvhNode *>(s_scene);
-        sv.isect = reinterpret_cast<const TriIsect *>(s_scene + nodeBytes);
-    } else { sv.nodes = S.nodes; sv.isect = S.isect; }
+        sv.nodes = reinterpret_cast<const BvhNode *>(s_scene + offs[0]);
+        sv.isect = reinterpret_cast<const TriIsect *>(s_scene + offs[1]);
+        sv.shade = reinterpret_cast<const TriShade *>(s_scene + offs[2]);
+        sv.mats = reinterpret_cast<const MaterialD *>(s_scene + offs[3]);
+        sv.emitters = reinterpret_cast<const EmitterD *>(s_scene + offs[4]);
+    } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; }
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
@@ -523,15 +546,15 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     if (i >= n) return;
     const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
     Hit h;
     trace<false>(sv, s_stack + threadIdx.x, o, d, ray_mint_closest(o, GD_EPSILON), GD_INF, h);
     Vertex v;
-    fill_vertex(S, h, d, v);
-    prim[i] = h.prim < 0 ? -1 : S.shade[h.prim].origIndex;
+    fill_vertex(sv, h, d, v);
+    prim[i] = h.prim < 0 ? -1 : sv.shade[h.prim].origIndex;
     tp[4 * i] = h.t;
     tp[4 * i + 1] = h.prim < 0 ? 0.0 : v.p.x; tp[4 * i + 2] = h.prim < 0 ? 0.0 : v.p.y; tp[4 * i + 3] = h.prim < 0 ? 0.0 : v.p.z;
 }
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters;
     Lane L;
     L.nClosest = L.nShadow = 0;
     bool active = start_path(S, sv, cfg, s_stack, L, px, py, sample);

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import numpy as np
 from gradientdomain_mitsuba_amd import scenes, gpt
 W, H = 1280, 720
-for variant, spp, md in (("diffuse", 8, -1), ("diffuse", 16, 12), ("glossy", 8, 12)):
+for variant, spp, md in (("diffuse", 32, -1), ("glossy", 16, 12)):
     sc = scenes.cornell_box(W, H, variant)
     S = gpt.Scene(sc); F = gpt.Film(S)
     integ = gpt.GradientPathIntegrator(maxDepth=md)
