@@ -187,6 +187,7 @@ struct gdpt_scene {
     std::vector<void *> allocs;
     int device = 0;
     int bvhDepth = 0;
+    size_t ldsSceneBytes = 0;
 };
 
 struct gdpt_film {
@@ -196,6 +197,7 @@ struct gdpt_film {
     hipStream_t stream = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     bool resolved = false;
+    int wavesPerSimd = 2;       // occupancy target the render kernel is compiled for (register budget = 512 / this)
 };
 
 extern "C" {
@@ -307,6 +309,8 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = numEmitters;
     d.numMats = numMaterials;
+    s->ldsSceneBytes = (((size_t)d.numNodes * sizeof(BvhNode) + 15) & ~(size_t)15) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) +
+                       (size_t)numMaterials * sizeof(MaterialD) + (size_t)numEmitters * sizeof(EmitterD) + 64;
     d.ldsScene = ((size_t)d.numNodes * sizeof(BvhNode) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) + (size_t)numMaterials * sizeof(MaterialD) +
                       (size_t)numEmitters * sizeof(EmitterD) + 64 <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
     CameraD &c = d.cam;
@@ -392,8 +396,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     THIPCHK(hipEventCreate(&e0));
     THIPCHK(hipEventCreate(&e1));
     THIPCHK(hipEventRecord(e0, f->stream));
-    if (s->d.ldsScene) hipLaunchKernelGGL(k_render<true>, dim3(tilesX * tilesY), dim3(TBLK), 0, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX);
-    else hipLaunchKernelGGL(k_render<false>, dim3(tilesX * tilesY), dim3(TBLK), 0, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX);
+    // LDS: stack sized to the BVH (each level costs 1 KiB per block), plus the staged tables of a small scene
+    const int stackDepth = std::min(STACK_DEPTH, std::max(4, s->bvhDepth + 2));
+    size_t lds = (size_t)stackDepth * TBLK * sizeof(int);
+    if (s->d.ldsScene) lds += s->ldsSceneBytes;
+    const int wps = f->wavesPerSimd;
+    const dim3 grid(tilesX * tilesY), block(TBLK);
+#define GDPT_LAUNCH(LDSV, WPS) hipLaunchKernelGGL((k_render<LDSV, WPS>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, stackDepth)
+    if (s->d.ldsScene) { if (wps == 1) GDPT_LAUNCH(true, 1); else if (wps == 2) GDPT_LAUNCH(true, 2); else if (wps == 3) GDPT_LAUNCH(true, 3); else GDPT_LAUNCH(true, 4); }
+    else               { if (wps == 1) GDPT_LAUNCH(false, 1); else if (wps == 2) GDPT_LAUNCH(false, 2); else if (wps == 3) GDPT_LAUNCH(false, 3); else GDPT_LAUNCH(false, 4); }
+#undef GDPT_LAUNCH
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
@@ -496,6 +508,13 @@ float gdpt_film_render_ms(gdpt_film *f)
 }
 
 void *gdpt_film_stream(gdpt_film *f) { return f ? (void *)f->stream : nullptr; }
+
+int gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd)
+{
+    if (!f || wavesPerSimd < 1 || wavesPerSimd > 4) return tfail(GDPT_ERR_INVALID, "occupancy target must be 1..4 waves per SIMD");
+    f->wavesPerSimd = wavesPerSimd;
+    return GDPT_OK;
+}
 
 int gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *od, int *prim, double *tp)
 {

@@ -401,11 +401,14 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
     }
 }
 
-template <bool LDS_SCENE>
-__global__ __launch_bounds__(TBLK) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX)
+template <bool LDS_SCENE, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int stackDepth)
 {
-    __shared__ int s_stack[STACK_DEPTH * TBLK];
-    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? LDS_SCENE_BYTES : 16];
+    // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)]; sized by the host from
+    // the actual BVH depth and table bytes so that small scenes leave room for more resident blocks per CU
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int *s_stack = reinterpret_cast<int *>(s_dyn);
+    unsigned char *s_scene = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
     SceneView sv;
     if (LDS_SCENE) {
         // stage node packets, triangle records and the shading tables through LDS once per block (coalesced 16-byte copies);

@@ -144,6 +144,9 @@ class Film:
         lib().gdpt_film_render_ms.restype = C.c_float
         return float(lib().gdpt_film_render_ms(self._h))
 
+    def set_occupancy(self, waves_per_simd):
+        check(lib().gdpt_film_set_occupancy(self._h, int(waves_per_simd)))
+
     def sync(self):
         check(lib().gdpt_film_sync(self._h))
 
