@@ -58,6 +58,8 @@ int ensure_device(int device)
 
 // ---- op launchers shared by both ABI levels -----------------------------------------------------
 
+constexpr int TH_F = 8;   // tile rows of kf_xp_Ax (ring overhead 10/8 on the r,p reads; 31 KB LDS)
+
 struct Lattice {
     int W, H;
     float alpha;
@@ -65,6 +67,7 @@ struct Lattice {
     long n() const { return (long)W * H; }
     int tilesX() const { return cdiv(W, TW); }
     int tiles() const { return tilesX() * cdiv(H, TH); }
+    int tilesF() const { return tilesX() * cdiv(H, TH_F); }     // tiles of the fused x_p+stencil kernel
 };
 
 // Ap = A p and block partials of p.Ap; returns the number of partials written.
@@ -218,17 +221,17 @@ void enqueue_cg_fused(gdpt_poisson_solver *s, bool unitw, int cg)
     const Lattice L = s->lat();
     const long n3 = 3 * L.n();
     hipStream_t st = s->stream;
-    const int Gt = imin(L.tiles(), MAXP);
+    const int Gt = imin(L.tilesF(), MAXP);
     int Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
     int Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
     for (int k = 1; k < cg; k++) {
         float *po = s->p[(k - 1) & 1], *pn = s->p[k & 1];
         if (unitw)
-            hipLaunchKernelGGL(kf_xp_Ax<true>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
-                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+            hipLaunchKernelGGL((kf_xp_Ax<true, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
+                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
         else
-            hipLaunchKernelGGL(kf_xp_Ax<false>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
-                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+            hipLaunchKernelGGL((kf_xp_Ax<false, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
+                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
         Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Gt, s->s_pAp(), s->s_rz_old());
     }
     launch_x_p(st, n3, s->x, s->p[(cg - 1) & 1], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
@@ -510,7 +513,7 @@ int gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4])
     hipLaunchKernelGGL(kg_set, dim3(16), dim3(BLK), 0, st, s->scal, 1.0f, (size_t)16);
     hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->p[0], 0.5f, (size_t)n3);
     hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->r, 0.25f, (size_t)n3);
-    const int Gt = imin(L.tiles(), MAXP);
+    const int Gt = imin(L.tilesF(), MAXP);
     int Ga = 0, Gr = 0;
     for (int which = 0; which < 4; which++) {
         us[which] = 0.0f;
@@ -523,10 +526,10 @@ int gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4])
                 if (which == 1) Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
                 if (which == 2) launch_x_p(st, n3, s->x, s->p[0], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
                 if (which == 3) {
-                    if (unitw) hipLaunchKernelGGL(kf_xp_Ax<true>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
-                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
-                    else       hipLaunchKernelGGL(kf_xp_Ax<false>, dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
-                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tiles());
+                    if (unitw) hipLaunchKernelGGL((kf_xp_Ax<true, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
+                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
+                    else       hipLaunchKernelGGL((kf_xp_Ax<false, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
+                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
                 }
             }
             HIPCHK(hipEventRecord(s->ev1, st));

@@ -326,6 +326,14 @@ __global__ __launch_bounds__(BLK) void kf_r_rz(float4 *__restrict__ r, float4 *_
     const int t = threadIdx.x, rot = t % 3;
     // issue the first tile's loads before the scalar reduction so their latency overlaps it
     int T = blockIdx.x * FLAT_TILE;
+    float4 rv[3], av[3];
+    bool ok[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int q = T + t + BLK * j;
+        ok[j] = q < total4;
+        if (ok[j]) { rv[j] = r[q]; av[j] = Ap[q]; }
+    }
     float pAp[3], rz2[3], a[3], aR[3];
     if (part_pAp) { reduce_parts(part_pAp, G_in, pAp, sm); if (s_pAp_out) store3(s_pAp_out, pAp); }
     else load3(s_pAp, pAp);
@@ -335,15 +343,7 @@ __global__ __launch_bounds__(BLK) void kf_r_rz(float4 *__restrict__ r, float4 *_
     for (int c = 0; c < 3; c++) a[c] = rz2[c] / fmaxf(pAp[c], FLT_MIN);
     rotate3(a, rot, aR);
     float accR[3] = {0.0f, 0.0f, 0.0f};
-    for (; T < total4; T += gridDim.x * FLAT_TILE) {
-        float4 rv[3], av[3];
-        bool ok[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int q = T + t + BLK * j;
-            ok[j] = q < total4;
-            if (ok[j]) { rv[j] = r[q]; av[j] = Ap[q]; }
-        }
+    while (T < total4) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             if (!ok[j]) continue;
@@ -357,6 +357,13 @@ __global__ __launch_bounds__(BLK) void kf_r_rz(float4 *__restrict__ r, float4 *_
             accR[(j + 1) % 3] += o.y * o.y;
             accR[(j + 2) % 3] += o.z * o.z;
             accR[(j + 3) % 3] += o.w * o.w;
+        }
+        T += gridDim.x * FLAT_TILE;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int q = T + t + BLK * j;
+            ok[j] = q < total4;
+            if (ok[j]) { rv[j] = r[q]; av[j] = Ap[q]; }
         }
     }
     float acc[3];
@@ -515,70 +522,97 @@ __global__ __launch_bounds__(BLK) void kf_Ax(float4 *__restrict__ Ax4, float4 *_
 // counterpart).  Stages p_new = r + p_old*b for the tile AND its ring straight into LDS, so the
 // stencil never re-reads p from HBM; interior rows also store p_new (to the OTHER p buffer: a
 // neighbouring block may still be reading p_old for its ring) and update x += p_old*a.
-template <bool UNITW>
+// TH_ = tile rows (ring overhead (TH_+2)/TH_ on the r,p reads); the first tile's loads are issued BEFORE
+// the block reduces the previous kernel's partials, so that fixed latency hides under the HBM/MALL fetch.
+template <bool UNITW, int TH_>
 __global__ __launch_bounds__(BLK) void kf_xp_Ax(float4 *__restrict__ Ax4, float4 *__restrict__ part_pAp, const float *__restrict__ w2,
                                                 float4 *__restrict__ x4, const float *__restrict__ p_old, float4 *__restrict__ p_new4,
                                                 const float *__restrict__ r, const float *__restrict__ s_rz2, const float *__restrict__ s_pAp,
                                                 const float4 *__restrict__ part_rz, int G_in, float *s_rz_out,
                                                 int W, int H, float alpha, int tilesX, int tiles)
 {
-    __shared__ __attribute__((aligned(16))) float tile[SROWS * RS];
+    constexpr int SR = TH_ + 2, ITEMS = SR * ROW4, M = (ITEMS + BLK - 1) / BLK;
+    __shared__ __attribute__((aligned(16))) float tile[SR * RS];
     __shared__ float sm[16];
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, rot = t % 3;
     const float alphaSqr = alpha * alpha;
     const int row4 = 3 * W / 4;
     const float4 *po4 = reinterpret_cast<const float4 *>(p_old);
     const float4 *r4 = reinterpret_cast<const float4 *>(r);
-    float rz[3], rz2[3], pAp[3], a[3], b[3], aR[3], bR[3];
-    reduce_parts(part_rz, G_in, rz, sm);
-    store3(s_rz_out, rz);
-    load3(s_rz2, rz2);
-    load3(s_pAp, pAp);
-#pragma unroll
-    for (int c = 0; c < 3; c++) { a[c] = rz2[c] / fmaxf(pAp[c], FLT_MIN); b[c] = rz[c] / fmaxf(rz2[c], FLT_MIN); }
-    rotate3(a, rot, aR);
-    rotate3(b, rot, bR);
+    float a[3], b[3], aR[3], bR[3];
     float acc[3] = {0.0f, 0.0f, 0.0f};
+    bool first = true;
     for (int tl = blockIdx.x; tl < tiles; tl += gridDim.x) {
-        const int x0 = (tl % tilesX) * TW, y0 = (tl / tilesX) * TH;
+        const int x0 = (tl % tilesX) * TW, y0 = (tl / tilesX) * TH_;
         const int q0 = 3 * x0 / 4;
-        __syncthreads();
-        // it = t + 256*m; ROW4 % 3 == 0 and 256 % 3 == 1  =>  colour of component k is (rot + m + k) % 3
+        // ---- issue every load of this tile ----
+        float4 pv[M], rv[M], xv[M];
+        int gi[M];          // float4 index in the image, -1 = nothing to do
+        bool own[M];
 #pragma unroll
-        for (int m = 0; m < (SROWS * ROW4 + BLK - 1) / BLK; m++) {
+        for (int m = 0; m < M; m++) {
             const int it = t + BLK * m;
-            if (it >= SROWS * ROW4) continue;
             const int rr = it / ROW4, q = it - rr * ROW4, y = y0 - 1 + rr;
-            if (!(y >= 0 && y < H && q0 + q < row4)) continue;
-            const size_t g = (size_t)y * row4 + q0 + q;
-            const float4 pv = po4[g], rv = r4[g];
-            float4 pn;
-            pn.x = rv.x + pv.x * bR[(m + 0) % 3];
-            pn.y = rv.y + pv.y * bR[(m + 1) % 3];
-            pn.z = rv.z + pv.z * bR[(m + 2) % 3];
-            pn.w = rv.w + pv.w * bR[(m + 3) % 3];
-            *reinterpret_cast<float4 *>(tile + rr * RS + 4 + 4 * q) = pn;
-            if (rr >= 1 && rr <= TH) {
-                p_new4[g] = pn;
-                const float4 xv = x4[g];
-                float4 xo;
-                xo.x = xv.x + pv.x * aR[(m + 0) % 3];
-                xo.y = xv.y + pv.y * aR[(m + 1) % 3];
-                xo.z = xv.z + pv.z * aR[(m + 2) % 3];
-                xo.w = xv.w + pv.w * aR[(m + 3) % 3];
-                x4[g] = xo;
+            gi[m] = (it < ITEMS && y >= 0 && y < H && q0 + q < row4) ? y * row4 + q0 + q : -1;
+            own[m] = rr >= 1 && rr <= TH_;
+            if (gi[m] >= 0) {
+                pv[m] = po4[gi[m]];
+                rv[m] = r4[gi[m]];
+                if (own[m]) xv[m] = x4[gi[m]];
             }
         }
-        if (t < SROWS * 6) {
-            const int rr = t / 6, s = (t % 6) / 3, c = t % 3, y = y0 - 1 + rr;
-            const int xs = s ? x0 + TW : x0 - 1;
+        float hr = 0.0f, hp = 0.0f;
+        int hslot = -1, hc = 0;
+        if (t < SR * 6) {
+            const int rr = t / 6, sd = (t % 6) / 3, c = t % 3, y = y0 - 1 + rr;
+            const int xs = sd ? x0 + TW : x0 - 1;
             if (y >= 0 && y < H && xs >= 0 && xs < W) {
                 const size_t g = 3 * ((size_t)y * W + xs) + c;
-                tile[rr * RS + (s ? 4 + 3 * TW : 1) + c] = r[g] + p_old[g] * sel3(c, b[0], b[1], b[2]);
+                hr = r[g]; hp = p_old[g];
+                hslot = rr * RS + (sd ? 4 + 3 * TW : 1) + c;
+                hc = c;
             }
         }
+        if (first) {        // scalars of this iteration: rz (new) from the previous kernel's block partials
+            float rz[3], rz2[3], pAp[3];
+            reduce_parts(part_rz, G_in, rz, sm);
+            store3(s_rz_out, rz);
+            load3(s_rz2, rz2);
+            load3(s_pAp, pAp);
+#pragma unroll
+            for (int c = 0; c < 3; c++) { a[c] = rz2[c] / fmaxf(pAp[c], FLT_MIN); b[c] = rz[c] / fmaxf(rz2[c], FLT_MIN); }
+            rotate3(a, rot, aR);
+            rotate3(b, rot, bR);
+            first = false;
+        }
+        __syncthreads();    // the previous tile's stencil reads are done
+        // it = t + 256*m; ROW4 % 3 == 0 and 256 % 3 == 1  =>  colour of component k is (rot + m + k) % 3
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if (gi[m] < 0) continue;
+            const int it = t + BLK * m;
+            const int rr = it / ROW4, q = it - rr * ROW4;
+            float4 pn;
+            pn.x = rv[m].x + pv[m].x * bR[(m + 0) % 3];
+            pn.y = rv[m].y + pv[m].y * bR[(m + 1) % 3];
+            pn.z = rv[m].z + pv[m].z * bR[(m + 2) % 3];
+            pn.w = rv[m].w + pv[m].w * bR[(m + 3) % 3];
+            *reinterpret_cast<float4 *>(tile + rr * RS + 4 + 4 * q) = pn;
+            if (own[m]) {
+                p_new4[gi[m]] = pn;
+                float4 xo;
+                xo.x = xv[m].x + pv[m].x * aR[(m + 0) % 3];
+                xo.y = xv[m].y + pv[m].y * aR[(m + 1) % 3];
+                xo.z = xv[m].z + pv[m].z * aR[(m + 2) % 3];
+                xo.w = xv[m].w + pv[m].w * aR[(m + 3) % 3];
+                x4[gi[m]] = xo;
+            }
+        }
+        if (hslot >= 0) tile[hslot] = hr + hp * sel3(hc, b[0], b[1], b[2]);
         __syncthreads();
-        stencil_lane<UNITW>(tile, wv, ln, x0, y0, W, H, w2, alphaSqr, Ax4, acc);
+#pragma unroll
+        for (int row = 0; row < TH_; row += BLK / 64)
+            stencil_lane<UNITW>(tile, row + wv, ln, x0, y0, W, H, w2, alphaSqr, Ax4, acc);
     }
     block_sum3(acc, sm);
     if (t == 0) part_pAp[blockIdx.x] = make_float4(acc[0], acc[1], acc[2], 0.0f);
