@@ -22,6 +22,7 @@ def stale():
 
 def build(force=False, verbose=False):
     if not force and not stale():
+        build_host(verbose)
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -29,4 +30,14 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_host(verbose)
     return LIB
+
+
+HOST_BIN = os.path.join(PKG, "bin", "gdpt_mitsuba")
+
+
+def build_host(verbose=False):
+    """The C++ host front end (host/gdpt_mitsuba.cpp: scene-XML subset reader + the reference CLI's flags) over the C-ABI."""
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host")] + ([] if verbose else ["-s"]))
+    return HOST_BIN

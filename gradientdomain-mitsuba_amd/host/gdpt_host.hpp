@@ -1,0 +1,270 @@
+// gdpt_host.hpp -- C++ host side above the C-ABI (include/gdpt_poisson.h, include/gdpt_tracer.h), in the reference's own
+// language and with the reference's class / method / property names, so that code written against
+//   poisson::Solver               (/root/reference/src/integrators/poisson_solver/Solver.hpp:43-157)
+//   GradientPathIntegrator        (/root/reference/src/integrators/gpt/gpt.h:71-113, gpt.cpp:1190-1480)
+//   MultiFilm                     (/root/reference/src/films/multifilm.cpp: setBuffers / developMulti / develop)
+// reads the same here.  Everything numerical happens behind the C-ABI on the GPU; this header only marshals.
+// Errors: the reference's Log(EError, ...) throws std::runtime_error (src/libcore/logger.cpp:147) -- so does this.
+#pragma once
+#include "../../include/gdpt_tracer.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace gdpt {
+
+inline std::string format(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return buf;
+}
+
+[[noreturn]] inline void logError(const std::string &msg) { throw std::runtime_error(msg); }   // Log(EError, ...)
+
+inline void check(int rc)
+{
+    if (rc != GDPT_OK) logError(format("gdpt error %d: %s", rc, gdpt_last_error()));
+}
+
+/// Properties (include/mitsuba/core/properties.h): typed name -> value map with defaulted getters.
+class Properties {
+public:
+    Properties() {}
+    explicit Properties(const std::string &pluginName) : m_plugin(pluginName) {}
+    const std::string &getPluginName() const { return m_plugin; }
+    void setPluginName(const std::string &n) { m_plugin = n; }
+    const std::string &getID() const { return m_id; }
+    void setID(const std::string &id) { m_id = id; }
+    bool hasProperty(const std::string &n) const { return m_values.count(n) != 0; }
+    void setString(const std::string &n, const std::string &v) { m_values[n] = v; }
+    void setInteger(const std::string &n, int v) { m_values[n] = std::to_string(v); }
+    void setFloat(const std::string &n, double v) { m_values[n] = format("%.17g", v); }
+    void setBoolean(const std::string &n, bool v) { m_values[n] = v ? "true" : "false"; }
+    std::string getString(const std::string &n, const std::string &def) const { auto it = m_values.find(n); return it == m_values.end() ? def : it->second; }
+    std::string getString(const std::string &n) const
+    {
+        auto it = m_values.find(n);
+        if (it == m_values.end()) logError(format("Property \"%s\" has not been specified!", n.c_str()));
+        return it->second;
+    }
+    int getInteger(const std::string &n, int def) const { auto it = m_values.find(n); return it == m_values.end() ? def : std::stoi(it->second); }
+    double getFloat(const std::string &n, double def) const { auto it = m_values.find(n); return it == m_values.end() ? def : std::stod(it->second); }
+    bool getBoolean(const std::string &n, bool def) const
+    {
+        auto it = m_values.find(n);
+        if (it == m_values.end()) return def;
+        if (it->second == "true") return true;
+        if (it->second == "false") return false;
+        logError(format("Could not parse boolean value \"%s\" -- must be \"true\" or \"false\"", it->second.c_str()));
+    }
+    const std::map<std::string, std::string> &values() const { return m_values; }
+
+private:
+    std::string m_plugin, m_id;
+    std::map<std::string, std::string> m_values;
+};
+
+namespace poisson {
+
+/// poisson::Solver (Solver.hpp:43-157) over gdpt_poisson_*.
+class Solver {
+public:
+    struct Params {                     // Solver.hpp:49-107 (the fields the solver reads)
+        float alpha;
+        std::string backend;            // "Auto" | "HIP": the only backend of this build
+        int cudaDevice;                 // kept under the reference's name; a HIP device ordinal here
+        bool verbose;
+        int irlsIterMax;
+        float irlsRegInit, irlsRegIter;
+        int cgIterMax, cgIterCheck;
+        bool cgPrecond;
+        float cgTolerance;
+        typedef std::function<void(const std::string &)> LogFunction;
+        LogFunction logFunc;
+
+        Params() { setDefaults(); }
+        void setDefaults()              // Solver.cpp:57-88
+        {
+            alpha = 0.2f; verbose = false; backend = "Auto"; cudaDevice = -1;
+            logFunc = LogFunction([](const std::string &m) { fputs(m.c_str(), stdout); });
+            setConfigPreset("L1D");
+        }
+        bool setConfigPreset(const char *preset)    // Solver.cpp:94-178, forwarded so the numbers live in ONE place
+        {
+            gdpt_poisson_params p;
+            const int ok = gdpt_poisson_params_preset(&p, preset);
+            irlsIterMax = p.irlsIterMax; irlsRegInit = p.irlsRegInit; irlsRegIter = p.irlsRegIter;
+            cgIterMax = p.cgIterMax; cgIterCheck = p.cgIterCheck; cgPrecond = p.cgPrecond != 0; cgTolerance = p.cgTolerance;
+            return ok != 0;
+        }
+        void setLogFunction(LogFunction f) { logFunc = f; }
+    };
+
+    explicit Solver(const Params &params) : m_params(params), m_handle(nullptr)
+    {
+        if (params.backend != "Auto" && params.backend != "HIP")
+            logError(format("Invalid backend specified '%s'!", params.backend.c_str()));                // Solver.cpp:292-294
+        gdpt_poisson_params p;
+        p.alpha = params.alpha; p.irlsIterMax = params.irlsIterMax; p.irlsRegInit = params.irlsRegInit; p.irlsRegIter = params.irlsRegIter;
+        p.cgIterMax = params.cgIterMax; p.cgIterCheck = params.cgIterCheck; p.cgPrecond = params.cgPrecond; p.cgTolerance = params.cgTolerance;
+        p.device = params.cudaDevice; p.verbose = params.verbose;
+        check(gdpt_poisson_create(&p, &m_handle));
+        check(gdpt_poisson_set_log(m_handle, &Solver::logThunk, this));
+    }
+    ~Solver() { gdpt_poisson_destroy(m_handle); }
+    Solver(const Solver &) = delete;
+    Solver &operator=(const Solver &) = delete;
+
+    void importImagesMTS(float *dx, float *dy, float *tp, float *direct, int width, int height) { check(gdpt_poisson_import_images(m_handle, dx, dy, tp, direct, width, height)); }
+    void importImagesDevice(const float *dx, const float *dy, const float *tp, const float *direct, int width, int height) { check(gdpt_poisson_import_images_device(m_handle, dx, dy, tp, direct, width, height)); }
+    void setupBackend() { check(gdpt_poisson_setup_backend(m_handle)); }
+    void solveIndirect() { check(gdpt_poisson_solve_indirect(m_handle)); }
+    void exportImagesMTS(float *rec) { check(gdpt_poisson_export_images(m_handle, rec)); }
+    float lastSolveSeconds() const { return gdpt_poisson_last_solve_seconds(m_handle); }
+
+private:
+    static void logThunk(const char *msg, void *self) { static_cast<Solver *>(self)->m_params.logFunc(msg); }
+    Params m_params;
+    gdpt_poisson_solver *m_handle;
+};
+
+} // namespace poisson
+
+/// What the scene-XML subset reader produces and gdpt_scene_create consumes.
+struct SceneData {
+    std::vector<double> verts;              // 9 per triangle
+    std::vector<int> triMaterial;
+    std::vector<gdpt_material> materials;
+    std::vector<gdpt_emitter> emitters;
+    gdpt_camera camera;
+    Properties integrator, film, sampler, rfilter;
+    int numTriangles() const { return (int)triMaterial.size(); }
+};
+
+/// MultiFilm (src/films/multifilm.cpp): N named buffers over one image, written as <dest><suffix>.pfm.
+class MultiFilm {
+public:
+    explicit MultiFilm(const Properties &props)
+    {
+        m_width = props.getInteger("width", 768);                                                   // film.cpp defaults
+        m_height = props.getInteger("height", 576);
+        m_fileFormat = props.getString("fileFormat", "openexr");                                    // multifilm.cpp:104
+        if (m_fileFormat != "pfm")
+            logError("MultiFilm: this build writes fileFormat=\"pfm\" only (multifilm.cpp:123-124); OpenEXR/RGBE are not carried");
+    }
+    bool setBuffers(const std::vector<std::string> &names)                                          // multifilm.cpp:293-319
+    {
+        m_names = names;
+        m_images.assign(names.size(), std::vector<float>((size_t)3 * m_width * m_height, 0.0f));
+        return true;
+    }
+    int getWidth() const { return m_width; }
+    int getHeight() const { return m_height; }
+    std::vector<float> &buffer(size_t i) { return m_images[i]; }
+    void setDestinationFile(const std::string &dest) { m_dest = dest; }
+    /// MultiFilm::develop (multifilm.cpp:423-518): one file per buffer, then <dest>-log.txt.
+    std::vector<std::string> develop(const std::string &log) const
+    {
+        std::vector<std::string> written;
+        for (size_t i = 0; i < m_names.size(); ++i) {
+            const std::string path = m_dest + m_names[i] + ".pfm";
+            std::ofstream f(path, std::ios::binary);
+            if (!f) logError(format("Cannot write \"%s\"", path.c_str()));
+            f << "PF\n" << m_width << " " << m_height << "\n-1.0\n";
+            for (int y = m_height - 1; y >= 0; --y)                                                 // PFM stores the bottom row first
+                f.write(reinterpret_cast<const char *>(&m_images[i][(size_t)3 * m_width * y]), sizeof(float) * 3 * m_width);
+            written.push_back(path);
+        }
+        std::ofstream lf(m_dest + "-log.txt");
+        lf << log;
+        return written;
+    }
+
+private:
+    int m_width, m_height;
+    std::string m_fileFormat, m_dest;
+    std::vector<std::string> m_names;
+    std::vector<std::vector<float>> m_images;
+};
+
+/// GradientPathIntegrator (gpt.h:71-113; gpt.cpp:1190-1213 constructor, :1358-1480 render).
+class GradientPathIntegrator {
+public:
+    explicit GradientPathIntegrator(const Properties &props)
+    {
+        m_maxDepth = props.getInteger("maxDepth", -1);
+        m_rrDepth = props.getInteger("rrDepth", 5);
+        m_strictNormals = props.getBoolean("strictNormals", false);
+        m_hideEmitters = props.getBoolean("hideEmitters", false);
+        m_shiftThreshold = props.getFloat("shiftThreshold", 0.001);
+        m_reconstructL1 = props.getBoolean("reconstructL1", true);
+        m_reconstructL2 = props.getBoolean("reconstructL2", false);
+        m_reconstructAlpha = props.getFloat("reconstructAlpha", 0.2);
+        if (m_reconstructL1 && m_reconstructL2)
+            logError("Disable 'reconstructL1' or 'reconstructL2': Cannot display two reconstructions at a time!");
+        if (m_reconstructAlpha <= 0.0)
+            logError("'reconstructAlpha' must be set to a value greater than zero!");
+        if (m_maxDepth <= 0 && m_maxDepth != -1)
+            logError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
+    }
+
+    /// render (gpt.cpp:1358-1480): five buffers, blocks, develop, reconstruct, -final := reconstruction.
+    bool render(const SceneData &sd, MultiFilm &film, int sampleCount, unsigned long long seed, std::string &log)
+    {
+        if (m_hideEmitters) logError("Option 'hideEmitters' not implemented for Gradient-Domain Path Tracing!");
+        const std::vector<std::string> outNames = {"-final", "-throughput", "-dx", "-dy", "-direct"};
+        if (!film.setBuffers(outNames)) logError("Cannot render image! G-PT has been called without MultiFilm.");
+        const int W = film.getWidth(), H = film.getHeight();
+        gdpt_scene *scene = nullptr;
+        gdpt_film *gf = nullptr;
+        check(gdpt_scene_create(sd.numTriangles(), sd.verts.data(), sd.triMaterial.data(), (int)sd.materials.size(), sd.materials.data(),
+                                (int)sd.emitters.size(), sd.emitters.data(), &sd.camera, -1, &scene));
+        check(gdpt_film_create(scene, 0, H, &gf));
+        gdpt_config cfg;
+        cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;
+        cfg.shiftThreshold = m_shiftThreshold; cfg.seed = seed;
+        log += format("Starting render job (GPT::render) (%ix%i, %i %s, 1 MI355X) ..\n", W, H, sampleCount, sampleCount == 1 ? "sample" : "samples");
+        check(gdpt_render_rect(scene, &cfg, 0, 0, W, H, gf));
+        check(gdpt_film_sync(gf));
+        for (int b = 0; b < 5; ++b) check(gdpt_film_develop(gf, b, film.buffer(b).data()));
+        unsigned long long st[4];
+        check(gdpt_film_stats(gf, st));
+        const float ms = gdpt_film_render_ms(gf);
+        log += format("Render time: %.3f s, %llu rays + %llu shadow rays (%.1f Mray/s), average path length %.3f\n", ms * 1e-3, st[0], st[1],
+                      (st[0] + st[1]) / (ms * 1e3), st[2] ? (double)st[3] / st[2] : 0.0);
+        if (m_reconstructL1 || m_reconstructL2) {                                               // gpt.cpp:1415-1476
+            poisson::Solver::Params params;
+            params.setConfigPreset(m_reconstructL1 ? "L1D" : "L2D");
+            params.alpha = (float)m_reconstructAlpha;
+            params.setLogFunction([&log](const std::string &m) { log += m; });
+            poisson::Solver solver(params);
+            std::vector<float> rec((size_t)3 * W * H);
+            solver.importImagesMTS(film.buffer(2).data(), film.buffer(3).data(), film.buffer(1).data(), film.buffer(4).data(), W, H);
+            solver.setupBackend();
+            solver.solveIndirect();
+            solver.exportImagesMTS(rec.data());
+            film.buffer(0) = rec;                                                                // setBitmapMulti(reconstruction, 1, BUFFER_FINAL)
+        }
+        gdpt_film_destroy(gf);
+        gdpt_scene_destroy(scene);
+        return true;
+    }
+
+private:
+    int m_maxDepth, m_rrDepth;
+    bool m_strictNormals, m_hideEmitters, m_reconstructL1, m_reconstructL2;
+    double m_shiftThreshold, m_reconstructAlpha;
+};
+
+} // namespace gdpt

@@ -1,0 +1,57 @@
+// gdpt_mitsuba -- command line front end with the reference CLI's flags for this path
+// (/root/reference/src/mitsuba/mitsuba.cpp:154-250): gdpt_mitsuba [-o dest] [-D key=val]... [-p n] [-b n] [-x] [-q] scene.xml
+//   -o  output destination stem: writes <dest>-final|-throughput|-dx|-dy|-direct.pfm and <dest>-log.txt (multifilm.cpp:453-517)
+//   -D  parameter substitution for $key in the scene file
+//   -p, -b  accepted for compatibility (CPU core count / block size have no meaning for the GPU path) and ignored
+//   -x  skip rendering if <dest>-final.pfm exists;  -q  quiet;  --parse-only  load the scene, print a summary, do not touch the GPU
+#include "scene_xml.hpp"
+
+#include <sys/stat.h>
+
+int main(int argc, char **argv)
+{
+    std::string dest, scenePath;
+    bool skipExisting = false, quiet = false, parseOnly = false;
+    unsigned long long seed = 5489;     // include/mitsuba/core/random.h:113
+    gdpt::SceneLoader loader;
+    try {
+        for (int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto need = [&](const char *what) -> std::string { if (i + 1 >= argc) gdpt::logError(std::string("missing value after ") + what); return argv[++i]; };
+            if (a == "-o") dest = need("-o");
+            else if (a == "-D") { const std::string kv = need("-D"); const size_t eq = kv.find('='); if (eq == std::string::npos) gdpt::logError("-D expects key=value"); loader.params[kv.substr(0, eq)] = kv.substr(eq + 1); }
+            else if (a.rfind("-D", 0) == 0 && a.size() > 2) { const std::string kv = a.substr(2); const size_t eq = kv.find('='); if (eq == std::string::npos) gdpt::logError("-D expects key=value"); loader.params[kv.substr(0, eq)] = kv.substr(eq + 1); }
+            else if (a == "-p" || a == "-b") need(a.c_str());
+            else if (a == "-x") skipExisting = true;
+            else if (a == "-q") quiet = true;
+            else if (a == "--seed") seed = std::stoull(need("--seed"));
+            else if (a == "--parse-only") parseOnly = true;
+            else if (a == "-h" || a == "--help") { printf("usage: gdpt_mitsuba [-o dest] [-D key=val] [-p n] [-b n] [-x] [-q] [--seed n] [--parse-only] scene.xml\n"); return 0; }
+            else if (a[0] == '-') gdpt::logError("unknown option " + a);
+            else scenePath = a;
+        }
+        if (scenePath.empty()) gdpt::logError("no scene file given");
+        if (dest.empty()) { dest = scenePath; const size_t dot = dest.rfind(".xml"); if (dot != std::string::npos) dest.erase(dot); }   // mitsuba.cpp: default destination = scene name
+        gdpt::SceneData sd = loader.load(scenePath);
+        const int spp = sd.sampler.getInteger("sampleCount", 4);                                                                       // independent.cpp default
+        if (parseOnly) {
+            printf("{\"triangles\": %d, \"materials\": %zu, \"emitters\": %zu, \"width\": %d, \"height\": %d, \"fovX\": %.9g, \"sampleCount\": %d, \"maxDepth\": %d, \"firstVertex\": [%.9g, %.9g, %.9g], \"cameraOrigin\": [%.9g, %.9g, %.9g]}\n",
+                   sd.numTriangles(), sd.materials.size(), sd.emitters.size(), sd.camera.width, sd.camera.height, sd.camera.fovX, spp,
+                   sd.integrator.getInteger("maxDepth", -1), sd.verts[0], sd.verts[1], sd.verts[2], sd.camera.toWorld[3], sd.camera.toWorld[7], sd.camera.toWorld[11]);
+            return 0;
+        }
+        struct stat stt;
+        if (skipExisting && stat((dest + "-final.pfm").c_str(), &stt) == 0) { if (!quiet) printf("Skipping %s (output exists)\n", scenePath.c_str()); return 0; }
+        gdpt::GradientPathIntegrator integrator(sd.integrator);
+        gdpt::MultiFilm film(sd.film);
+        film.setDestinationFile(dest);
+        std::string log;
+        integrator.render(sd, film, spp, seed, log);
+        for (const std::string &p : film.develop(log)) if (!quiet) printf("Writing image to \"%s\" ..\n", p.c_str());
+        if (!quiet) fputs(log.c_str(), stdout);
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "Error: %s\n", e.what());       // Log(EError) -> exception -> non-zero exit, as mitsuba.cpp's top-level handler
+        return 1;
+    }
+}

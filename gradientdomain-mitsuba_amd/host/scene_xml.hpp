@@ -1,0 +1,463 @@
+// scene_xml.hpp -- reader for the subset of Mitsuba 0.5 scene XML that the carried hot path can render
+// (tag table: /root/reference/src/librender/scenehandler.cpp:70-106; grammar: data/schema/scene.xsd).
+//
+// Carried:  <scene>, <default>, $parameter substitution (+ -D overrides), <integrator type="gpt">, <sensor type="perspective">
+// (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
+// fileFormat="pfm") with <rfilter type="box">, <bsdf type="diffuse|conductor|roughconductor"> (top-level with id, or nested in a
+// shape), <shape type="obj|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
+// <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
+// Anything else raises std::runtime_error naming the tag or plugin, like the reference's "unsupported" errors.
+#pragma once
+#include "gdpt_host.hpp"
+
+#include <cctype>
+#include <cmath>
+#include <memory>
+#include <sstream>
+
+namespace gdpt {
+namespace xml {
+
+struct Node {
+    std::string tag;
+    std::map<std::string, std::string> attr;
+    std::vector<std::unique_ptr<Node>> children;
+    const std::string &get(const std::string &k) const
+    {
+        auto it = attr.find(k);
+        if (it == attr.end()) logError(format("<%s>: missing attribute \"%s\"", tag.c_str(), k.c_str()));
+        return it->second;
+    }
+    std::string get(const std::string &k, const std::string &def) const { auto it = attr.find(k); return it == attr.end() ? def : it->second; }
+};
+
+/// A small non-validating XML parser: elements, attributes, comments, <?...?> declarations.  No entities beyond the basic five.
+class Parser {
+public:
+    explicit Parser(const std::string &text) : s(text), i(0) {}
+    std::unique_ptr<Node> parse()
+    {
+        skipMisc();
+        std::unique_ptr<Node> root = element();
+        skipMisc();
+        return root;
+    }
+
+private:
+    const std::string &s;
+    size_t i;
+    [[noreturn]] void fail(const char *what) const
+    {
+        size_t line = 1;
+        for (size_t k = 0; k < i && k < s.size(); ++k) line += s[k] == '\n';
+        logError(format("XML parse error near line %zu: %s", line, what));
+    }
+    void skipWs() { while (i < s.size() && std::isspace((unsigned char)s[i])) ++i; }
+    bool starts(const char *p) const { return s.compare(i, std::strlen(p), p) == 0; }
+    void skipMisc()
+    {
+        for (;;) {
+            skipWs();
+            if (starts("<!--")) { size_t e = s.find("-->", i); if (e == std::string::npos) fail("unterminated comment"); i = e + 3; }
+            else if (starts("<?")) { size_t e = s.find("?>", i); if (e == std::string::npos) fail("unterminated declaration"); i = e + 2; }
+            else if (starts("<!")) { size_t e = s.find('>', i); if (e == std::string::npos) fail("unterminated <!...>"); i = e + 1; }
+            else return;
+        }
+    }
+    std::string name()
+    {
+        size_t b = i;
+        while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '-' || s[i] == ':' || s[i] == '.')) ++i;
+        if (b == i) fail("expected a name");
+        return s.substr(b, i - b);
+    }
+    static std::string unescape(const std::string &v)
+    {
+        std::string o;
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (v[k] == '&') {
+                if (!v.compare(k, 4, "&lt;")) { o += '<'; k += 3; continue; }
+                if (!v.compare(k, 4, "&gt;")) { o += '>'; k += 3; continue; }
+                if (!v.compare(k, 5, "&amp;")) { o += '&'; k += 4; continue; }
+                if (!v.compare(k, 6, "&quot;")) { o += '"'; k += 5; continue; }
+                if (!v.compare(k, 6, "&apos;")) { o += '\''; k += 5; continue; }
+            }
+            o += v[k];
+        }
+        return o;
+    }
+    std::unique_ptr<Node> element()
+    {
+        if (i >= s.size() || s[i] != '<') fail("expected '<'");
+        ++i;
+        std::unique_ptr<Node> n(new Node);
+        n->tag = name();
+        for (;;) {
+            skipWs();
+            if (i >= s.size()) fail("unterminated tag");
+            if (s[i] == '/') { if (!starts("/>")) fail("expected '/>'"); i += 2; return n; }
+            if (s[i] == '>') { ++i; break; }
+            std::string k = name();
+            skipWs();
+            if (i >= s.size() || s[i] != '=') fail("expected '='");
+            ++i;
+            skipWs();
+            if (i >= s.size() || (s[i] != '"' && s[i] != '\'')) fail("expected a quoted attribute value");
+            const char q = s[i++];
+            size_t e = s.find(q, i);
+            if (e == std::string::npos) fail("unterminated attribute value");
+            n->attr[k] = unescape(s.substr(i, e - i));
+            i = e + 1;
+        }
+        for (;;) {
+            skipMisc();
+            if (i >= s.size()) fail("unterminated element");
+            if (starts("</")) {
+                i += 2;
+                if (name() != n->tag) fail("mismatched closing tag");
+                skipWs();
+                if (i >= s.size() || s[i] != '>') fail("expected '>'");
+                ++i;
+                return n;
+            }
+            if (s[i] == '<') n->children.push_back(element());
+            else { while (i < s.size() && s[i] != '<') ++i; }      // character data is not used by the scene grammar
+        }
+    }
+};
+
+} // namespace xml
+
+struct Mat4 {
+    double m[16];
+    static Mat4 identity() { Mat4 r; for (int k = 0; k < 16; ++k) r.m[k] = (k % 5 == 0); return r; }
+    Mat4 operator*(const Mat4 &o) const
+    {
+        Mat4 r;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) { double v = 0; for (int k = 0; k < 4; ++k) v += m[4 * a + k] * o.m[4 * k + b]; r.m[4 * a + b] = v; }
+        return r;
+    }
+    void point(const double p[3], double out[3]) const
+    {
+        double w = m[12] * p[0] + m[13] * p[1] + m[14] * p[2] + m[15];
+        for (int a = 0; a < 3; ++a) out[a] = (m[4 * a] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3]) / w;
+    }
+    double det3() const
+    {
+        return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    }
+};
+
+class SceneLoader {
+public:
+    std::map<std::string, std::string> params;      // -D key=value and <default>
+
+    SceneData load(const std::string &path)
+    {
+        std::ifstream f(path);
+        if (!f) logError(format("Cannot open scene file \"%s\"", path.c_str()));
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const size_t slash = path.find_last_of('/');
+        m_dir = slash == std::string::npos ? "." : path.substr(0, slash);
+        return loadString(ss.str());
+    }
+
+    SceneData loadString(const std::string &text)
+    {
+        xml::Parser parser(text);
+        std::unique_ptr<xml::Node> root = parser.parse();
+        if (root->tag != "scene") logError("root element must be <scene>");
+        SceneData sd;
+        std::memset(&sd.camera, 0, sizeof sd.camera);
+        bool haveSensor = false, haveIntegrator = false;
+        for (auto &c : root->children) {
+            const xml::Node &n = *c;
+            if (n.tag == "default") { if (!params.count(n.get("name"))) params[n.get("name")] = subst(n.get("value")); }
+            else if (n.tag == "integrator") {
+                if (subst(n.get("type")) != "gpt") logError(format("integrator \"%s\" is not carried: this build is the gpt hot path only", n.get("type").c_str()));
+                sd.integrator = props(n);
+                haveIntegrator = true;
+            } else if (n.tag == "sensor") { sensor(n, sd); haveSensor = true; }
+            else if (n.tag == "bsdf") { const std::string id = n.get("id", ""); const int idx = bsdf(n, sd); if (!id.empty()) m_bsdfIds[id] = idx; }
+            else if (n.tag == "shape") shape(n, sd);
+            else if (n.tag == "emitter") logError(format("top-level emitter \"%s\" is not carried: only `area` emitters attached to shapes", n.get("type").c_str()));
+            else logError(format("<%s> is not carried by this build", n.tag.c_str()));
+        }
+        if (!haveIntegrator) sd.integrator = Properties("gpt");
+        if (!haveSensor) logError("scene has no <sensor>");
+        if (sd.emitters.empty()) logError("scene has no area emitter");
+        return sd;
+    }
+
+private:
+    std::string m_dir;
+    std::map<std::string, int> m_bsdfIds;
+
+    std::string subst(const std::string &v) const
+    { // $name substitution (scenehandler.cpp: parameter map from -D and <default>)
+        std::string o;
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (v[k] == '$') {
+                size_t e = k + 1;
+                while (e < v.size() && (std::isalnum((unsigned char)v[e]) || v[e] == '_')) ++e;
+                const std::string key = v.substr(k + 1, e - k - 1);
+                auto it = params.find(key);
+                if (it == params.end()) logError(format("The scene references an undefined parameter \"$%s\" (use -D %s=...)", key.c_str(), key.c_str()));
+                o += it->second;
+                k = e - 1;
+            } else o += v[k];
+        }
+        return o;
+    }
+
+    static std::vector<double> numbers(const std::string &v)
+    {
+        std::string t = v;
+        for (char &c : t) if (c == ',') c = ' ';
+        std::stringstream ss(t);
+        std::vector<double> out;
+        double d;
+        while (ss >> d) out.push_back(d);
+        return out;
+    }
+
+    void rgb3(const xml::Node &n, double out[3]) const
+    {
+        std::vector<double> v = numbers(subst(n.get("value")));
+        if (v.size() == 1) out[0] = out[1] = out[2] = v[0];
+        else if (v.size() == 3) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; }
+        else logError(format("<%s name=\"%s\">: expected 1 or 3 values (wavelength:value spectra need data files this build does not carry)", n.tag.c_str(), n.get("name").c_str()));
+    }
+
+    Properties props(const xml::Node &n) const
+    {
+        Properties p(subst(n.get("type", "")));
+        p.setID(n.get("id", ""));
+        for (auto &c : n.children) {
+            const std::string &t = c->tag;
+            if (t == "integer" || t == "float" || t == "boolean" || t == "string") p.setString(c->get("name"), subst(c->get("value")));
+        }
+        return p;
+    }
+
+    Mat4 transform(const xml::Node &n) const
+    { // every child left-multiplies the accumulated transform (scenehandler.cpp: m_transform = op * m_transform)
+        Mat4 T = Mat4::identity();
+        for (auto &c : n.children) {
+            Mat4 M = Mat4::identity();
+            auto num = [&](const char *k, double def) { auto it = c->attr.find(k); return it == c->attr.end() ? def : std::stod(subst(it->second)); };
+            if (c->tag == "translate") { M.m[3] = num("x", 0); M.m[7] = num("y", 0); M.m[11] = num("z", 0); }
+            else if (c->tag == "scale") {
+                if (c->attr.count("value")) { const double v = num("value", 1); M.m[0] = M.m[5] = M.m[10] = v; }
+                else { M.m[0] = num("x", 1); M.m[5] = num("y", 1); M.m[10] = num("z", 1); }
+            } else if (c->tag == "rotate") {
+                double ax = num("x", 0), ay = num("y", 0), az = num("z", 0);
+                const double len = std::sqrt(ax * ax + ay * ay + az * az);
+                if (len == 0) logError("<rotate>: zero axis");
+                ax /= len; ay /= len; az /= len;
+                const double a = num("angle", 0) * M_PI / 180.0, s = std::sin(a), co = std::cos(a);     // Transform::rotate, transform.cpp
+                M.m[0] = ax * ax + (1 - ax * ax) * co; M.m[1] = ax * ay * (1 - co) - az * s; M.m[2] = ax * az * (1 - co) + ay * s;
+                M.m[4] = ax * ay * (1 - co) + az * s; M.m[5] = ay * ay + (1 - ay * ay) * co; M.m[6] = ay * az * (1 - co) - ax * s;
+                M.m[8] = ax * az * (1 - co) - ay * s; M.m[9] = ay * az * (1 - co) + ax * s; M.m[10] = az * az + (1 - az * az) * co;
+            } else if (c->tag == "lookat" || c->tag == "lookAt") {
+                std::vector<double> o = numbers(subst(c->get("origin"))), t = numbers(subst(c->get("target"))), u = numbers(subst(c->get("up", "0, 1, 0")));
+                if (o.size() != 3 || t.size() != 3 || u.size() != 3) logError("<lookat>: origin/target/up need 3 values each");
+                double d[3] = {t[0] - o[0], t[1] - o[1], t[2] - o[2]};
+                double dl = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                if (dl == 0) logError("lookAt(): 'origin' and 'target' coincide!");
+                for (double &x : d) x /= dl;
+                double l[3] = {u[1] * d[2] - u[2] * d[1], u[2] * d[0] - u[0] * d[2], u[0] * d[1] - u[1] * d[0]};   // cross(up, dir)
+                double ll = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+                if (ll == 0) logError("lookAt(): the forward and upward direction must be linearly independent!");
+                for (double &x : l) x /= ll;
+                double nu[3] = {d[1] * l[2] - d[2] * l[1], d[2] * l[0] - d[0] * l[2], d[0] * l[1] - d[1] * l[0]};   // cross(dir, left)
+                for (int a = 0; a < 3; ++a) { M.m[4 * a] = l[a]; M.m[4 * a + 1] = nu[a]; M.m[4 * a + 2] = d[a]; M.m[4 * a + 3] = o[a]; }
+            } else if (c->tag == "matrix") {
+                std::vector<double> v = numbers(subst(c->get("value")));
+                if (v.size() != 16) logError("<matrix>: expected 16 values");
+                for (int k = 0; k < 16; ++k) M.m[k] = v[k];
+            } else logError(format("<%s> inside <transform> is not carried", c->tag.c_str()));
+            T = M * T;
+        }
+        return T;
+    }
+
+    void sensor(const xml::Node &n, SceneData &sd)
+    {
+        if (subst(n.get("type")) != "perspective") logError(format("sensor \"%s\" is not carried: `perspective` only", n.get("type").c_str()));
+        Properties p = props(n);
+        Mat4 toWorld = Mat4::identity();
+        bool haveFilm = false;
+        for (auto &c : n.children) {
+            if (c->tag == "transform" && c->get("name") == "toWorld") toWorld = transform(*c);
+            else if (c->tag == "sampler") {
+                if (subst(c->get("type")) != "independent") logError(format("sampler \"%s\" is not carried: `independent` only (G-PT never calls advance(), SURVEY.md 2a)", c->get("type").c_str()));
+                sd.sampler = props(*c);
+            } else if (c->tag == "film") {
+                if (subst(c->get("type")) != "multifilm") logError("Cannot render image! G-PT has been called without MultiFilm.");   // gpt.cpp:1381-1384
+                sd.film = props(*c);
+                bool box = false;
+                for (auto &fc : c->children)
+                    if (fc->tag == "rfilter") {
+                        if (subst(fc->get("type")) != "box") logError(format("rfilter \"%s\" is not carried: `box` only", fc->get("type").c_str()));
+                        box = true;
+                    }
+                if (!box) logError("the film needs <rfilter type=\"box\"/> (Mitsuba's default is gaussian, which this build does not carry)");
+                haveFilm = true;
+            }
+        }
+        if (!haveFilm) logError("the sensor has no <film type=\"multifilm\">");
+        const int W = sd.film.getInteger("width", 768), H = sd.film.getInteger("height", 576);
+        double fov = p.getFloat("fov", 50.0);
+        const std::string axis = p.getString("fovAxis", "x");
+        if (axis == "y") fov = 2 * std::atan(std::tan(fov * M_PI / 360.0) * (double)W / H) * 180.0 / M_PI;
+        else if (axis != "x") logError(format("fovAxis \"%s\" is not carried (x or y)", axis.c_str()));
+        for (int k = 0; k < 16; ++k) sd.camera.toWorld[k] = toWorld.m[k];
+        sd.camera.fovX = fov;
+        sd.camera.nearClip = p.getFloat("nearClip", 1e-2);
+        sd.camera.farClip = p.getFloat("farClip", 1e4);
+        sd.camera.width = W;
+        sd.camera.height = H;
+    }
+
+    int bsdf(const xml::Node &n, SceneData &sd)
+    {
+        const std::string type = subst(n.get("type"));
+        gdpt_material m;
+        std::memset(&m, 0, sizeof m);
+        m.sampleVisible = 1;
+        bool haveEta = false, haveK = false;
+        for (int c = 0; c < 3; ++c) { m.reflectance[c] = type == "diffuse" ? 0.5 : 1.0; m.eta[c] = 0; m.k[c] = 1; }
+        m.alphaU = m.alphaV = 0.1;
+        for (auto &c : n.children) {
+            const std::string nm = c->get("name", "");
+            if (c->tag == "rgb" || c->tag == "spectrum" || c->tag == "srgb") {
+                double v[3];
+                rgb3(*c, v);
+                double *dst = nullptr;
+                if (nm == "reflectance" || nm == "diffuseReflectance" || nm == "specularReflectance") dst = m.reflectance;
+                else if (nm == "eta") { dst = m.eta; haveEta = true; }
+                else if (nm == "k") { dst = m.k; haveK = true; }
+                else logError(format("bsdf \"%s\": parameter \"%s\" is not carried", type.c_str(), nm.c_str()));
+                for (int k = 0; k < 3; ++k) dst[k] = v[k];
+            } else if (c->tag == "float") {
+                const double v = std::stod(subst(c->get("value")));
+                if (nm == "alpha") m.alphaU = m.alphaV = v;
+                else if (nm == "alphaU") m.alphaU = v;
+                else if (nm == "alphaV") m.alphaV = v;
+                else if (nm == "eta") { m.eta[0] = m.eta[1] = m.eta[2] = v; haveEta = true; }
+                else if (nm == "k") { m.k[0] = m.k[1] = m.k[2] = v; haveK = true; }
+                else logError(format("bsdf \"%s\": parameter \"%s\" is not carried", type.c_str(), nm.c_str()));
+            } else if (c->tag == "string") {
+                const std::string v = subst(c->get("value"));
+                if (nm == "distribution") {
+                    if (v == "beckmann") m.distribution = GDPT_DISTR_BECKMANN;
+                    else if (v == "ggx") m.distribution = GDPT_DISTR_GGX;
+                    else logError(format("microfacet distribution \"%s\" is not carried (beckmann, ggx)", v.c_str()));
+                } else if (nm == "material") logError("conductor `material` presets need Mitsuba's data/ior tables, which this build does not carry: give explicit eta and k");
+                else logError(format("bsdf \"%s\": parameter \"%s\" is not carried", type.c_str(), nm.c_str()));
+            } else if (c->tag == "boolean") {
+                if (nm == "sampleVisible") m.sampleVisible = subst(c->get("value")) == "true";
+                else logError(format("bsdf \"%s\": parameter \"%s\" is not carried", type.c_str(), nm.c_str()));
+            } else if (c->tag == "texture") logError("textures are not carried by this build");
+            else if (c->tag == "bsdf") logError(format("nested BSDFs (\"%s\") are not carried", type.c_str()));
+        }
+        if (type == "diffuse") m.type = GDPT_MAT_DIFFUSE;
+        else if (type == "conductor") m.type = GDPT_MAT_CONDUCTOR;
+        else if (type == "roughconductor") m.type = GDPT_MAT_ROUGHCONDUCTOR;
+        else logError(format("bsdf \"%s\" is not carried: diffuse, conductor, roughconductor (twosided/dielectric are the next candidates)", type.c_str()));
+        if (m.type != GDPT_MAT_DIFFUSE && !(haveEta && haveK)) logError(format("bsdf \"%s\": explicit eta and k are required (the default `material=Cu` needs data/ior)", type.c_str()));
+        sd.materials.push_back(m);
+        return (int)sd.materials.size() - 1;
+    }
+
+    void addTri(SceneData &sd, const Mat4 &T, bool flip, const double *a, const double *b, const double *c, int mat)
+    {
+        double A[3], B[3], C[3];
+        T.point(a, A);
+        T.point(flip ? c : b, B);
+        T.point(flip ? b : c, C);
+        sd.verts.insert(sd.verts.end(), A, A + 3);
+        sd.verts.insert(sd.verts.end(), B, B + 3);
+        sd.verts.insert(sd.verts.end(), C, C + 3);
+        sd.triMaterial.push_back(mat);
+    }
+
+    void shape(const xml::Node &n, SceneData &sd)
+    {
+        const std::string type = subst(n.get("type"));
+        Mat4 T = Mat4::identity();
+        int mat = -1;
+        bool flipNormals = false, emits = false;
+        double radiance[3] = {1, 1, 1};
+        std::string filename;
+        for (auto &c : n.children) {
+            if (c->tag == "transform" && c->get("name") == "toWorld") T = transform(*c);
+            else if (c->tag == "ref") {
+                auto it = m_bsdfIds.find(c->get("id"));
+                if (it == m_bsdfIds.end()) logError(format("Referenced object \"%s\" not found (BSDFs must be declared before the shapes that use them)", c->get("id").c_str()));
+                mat = it->second;
+            } else if (c->tag == "bsdf") mat = bsdf(*c, sd);
+            else if (c->tag == "emitter") {
+                if (subst(c->get("type")) != "area") logError(format("emitter \"%s\" is not carried: `area` only", c->get("type").c_str()));
+                emits = true;
+                for (auto &ec : c->children)
+                    if ((ec->tag == "rgb" || ec->tag == "spectrum") && ec->get("name") == "radiance") rgb3(*ec, radiance);
+            } else if (c->tag == "string" && c->get("name") == "filename") filename = subst(c->get("value"));
+            else if (c->tag == "boolean" && c->get("name") == "flipNormals") flipNormals = subst(c->get("value")) == "true";
+            else if (c->tag == "boolean" && c->get("name") == "faceNormals") { /* flat shading is the only mode carried */ }
+            else logError(format("shape \"%s\": <%s name=\"%s\"> is not carried", type.c_str(), c->tag.c_str(), c->get("name", "").c_str()));
+        }
+        if (mat < 0) { gdpt_material m; std::memset(&m, 0, sizeof m); m.type = GDPT_MAT_DIFFUSE; m.sampleVisible = 1; m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5; m.alphaU = m.alphaV = 0.1; sd.materials.push_back(m); mat = (int)sd.materials.size() - 1; }   // shape.cpp: default diffuse
+        const bool flip = flipNormals != (T.det3() < 0);        // a mirroring transform reverses the winding (obj.cpp does the same swap)
+        const int first = sd.numTriangles();
+        if (type == "rectangle") {                               // src/shapes/rectangle.cpp: [-1,1]^2 in z = 0, normal +z
+            const double v[4][3] = {{-1, -1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 1, 0}};
+            addTri(sd, T, flip, v[0], v[1], v[2], mat);
+            addTri(sd, T, flip, v[2], v[3], v[0], mat);
+        } else if (type == "cube") {                             // src/shapes/cube.cpp: [-1,1]^3, outward normals
+            const double c[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+            const int f[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {1, 2, 6, 5}, {0, 4, 7, 3}};
+            for (auto &q : f) { addTri(sd, T, flip, c[q[0]], c[q[1]], c[q[2]], mat); addTri(sd, T, flip, c[q[0]], c[q[2]], c[q[3]], mat); }
+        } else if (type == "obj") {
+            if (filename.empty()) logError("shape \"obj\": missing filename");
+            loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flip, mat);
+        } else logError(format("shape \"%s\" is not carried: obj, rectangle, cube", type.c_str()));
+        if (emits) {
+            gdpt_emitter e;
+            e.firstTri = first; e.numTris = sd.numTriangles() - first;
+            for (int k = 0; k < 3; ++k) e.radiance[k] = radiance[k];
+            sd.emitters.push_back(e);
+        }
+    }
+
+    void loadObj(const std::string &path, SceneData &sd, const Mat4 &T, bool flip, int mat)
+    { // Wavefront OBJ subset (src/shapes/obj.cpp): v, f with v / v/vt / v//vn / v/vt/vn and negative indices, polygons fanned.
+      // vn / vt are read past: this build shades flat (no vertex normals).
+        std::ifstream f(path);
+        if (!f) logError(format("Cannot open OBJ file \"%s\"", path.c_str()));
+        std::vector<double> pos;
+        std::string line;
+        while (std::getline(f, line)) {
+            std::stringstream ss(line);
+            std::string tag;
+            if (!(ss >> tag)) continue;
+            if (tag == "v") { double x, y, z; ss >> x >> y >> z; pos.push_back(x); pos.push_back(y); pos.push_back(z); }
+            else if (tag == "f") {
+                std::vector<int> idx;
+                std::string tok;
+                while (ss >> tok) {
+                    int vi = std::stoi(tok.substr(0, tok.find('/')));
+                    if (vi < 0) vi = (int)pos.size() / 3 + vi; else vi -= 1;
+                    if (vi < 0 || vi >= (int)pos.size() / 3) logError(format("%s: face references vertex %d out of range", path.c_str(), vi + 1));
+                    idx.push_back(vi);
+                }
+                for (size_t k = 1; k + 1 < idx.size(); ++k) addTri(sd, T, flip, &pos[3 * idx[0]], &pos[3 * idx[k]], &pos[3 * idx[k + 1]], mat);
+            }
+        }
+    }
+};
+
+} // namespace gdpt

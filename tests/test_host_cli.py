@@ -1,0 +1,112 @@
+"""The C++ host front end (gradientdomain-mitsuba_amd/host): scene-XML subset reader and the reference CLI's flags.
+CPU tests use --parse-only (no GPU); the GPU test renders through the CLI and through the Python mirror and expects
+the same bytes, since both marshal the same scene into the same C-ABI calls."""
+import json
+import os
+import subprocess
+import textwrap
+
+import numpy as np
+import pytest
+
+from gradientdomain_mitsuba_amd import _build, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+XML = os.path.join(ROOT, "scenes", "cornell_box.xml")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    _build.build()
+    return _build.HOST_BIN
+
+
+def run(cli, *args):
+    return subprocess.run([cli] + list(args), capture_output=True, text=True)
+
+
+def test_parse_only_matches_the_python_scene(cli):
+    r = run(cli, "--parse-only", "-D", "width=1280", "-D", "height=720", "-D", "spp=16", XML)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    sc = scenes.cornell_box(1280, 720)
+    assert d["triangles"] == sc.ntri == 32 and d["materials"] == 4 and d["emitters"] == 1
+    assert (d["width"], d["height"], d["sampleCount"], d["maxDepth"]) == (1280, 720, 16, -1)
+    assert d["fovX"] == pytest.approx(sc.fov_x, rel=1e-9) and d["cameraOrigin"] == [278, 273, -800]
+    assert d["firstVertex"] == list(sc.verts[0][:3])
+    assert json.loads(run(cli, "--parse-only", XML).stdout)["width"] == 512            # <default> values
+
+
+def scene_with(tmp_path, body, film='<film type="multifilm"><integer name="width" value="8"/><integer name="height" value="4"/><string name="fileFormat" value="pfm"/><rfilter type="box"/></film>'):
+    p = tmp_path / "s.xml"
+    p.write_text(textwrap.dedent('''<scene version="0.5.0">
+        <integrator type="gpt"/>
+        <sensor type="perspective"><float name="fov" value="40"/>
+            <transform name="toWorld"><lookat origin="0,0,-5" target="0,0,0" up="0,1,0"/></transform>
+            <sampler type="independent"><integer name="sampleCount" value="2"/></sampler>%s</sensor>
+        %s
+        </scene>''') % (film, body))
+    return str(p)
+
+
+LIGHT = '<shape type="rectangle"><emitter type="area"><rgb name="radiance" value="3"/></emitter></shape>'
+
+
+def test_transforms_compose_in_document_order(cli, tmp_path):
+    # scale then translate: the rectangle's corner (-1,-1,0) -> (-2,-2,0) -> (8,-2,0); translate then scale would give (18,-2,0)
+    s = scene_with(tmp_path, '<shape type="rectangle"><transform name="toWorld"><scale value="2"/><translate x="10"/></transform></shape>' + LIGHT)
+    d = json.loads(run(cli, "--parse-only", s).stdout)
+    assert d["firstVertex"] == [8, -2, 0] and d["triangles"] == 4 and d["materials"] == 2
+    s = scene_with(tmp_path, '<shape type="rectangle"><transform name="toWorld"><rotate z="1" angle="90"/></transform></shape>' + LIGHT)
+    assert np.allclose(json.loads(run(cli, "--parse-only", s).stdout)["firstVertex"], [1, -1, 0], atol=1e-12)
+    s = scene_with(tmp_path, '<shape type="cube"><bsdf type="roughconductor"><float name="alpha" value="0.2"/><rgb name="eta" value="1,1,1"/><rgb name="k" value="2,2,2"/><string name="distribution" value="ggx"/></bsdf></shape>' + LIGHT)
+    assert json.loads(run(cli, "--parse-only", s).stdout)["triangles"] == 14
+
+
+@pytest.mark.parametrize("body,film,needle", [
+    ('<shape type="sphere"/>' + LIGHT, None, "shape \"sphere\" is not carried"),
+    ('<shape type="rectangle"><bsdf type="twosided"><bsdf type="diffuse"/></bsdf></shape>' + LIGHT, None, "not carried"),
+    ('<shape type="rectangle"><bsdf type="conductor"/></shape>' + LIGHT, None, "explicit eta and k"),
+    ('<shape type="rectangle"/>', None, "no area emitter"),
+    (LIGHT, '<film type="hdrfilm"><rfilter type="box"/></film>', "without MultiFilm"),
+    (LIGHT, '<film type="multifilm"><string name="fileFormat" value="pfm"/><rfilter type="gaussian"/></film>', "`box` only"),
+    ('<emitter type="envmap"/>' + LIGHT, None, "not carried"),
+    ('<shape type="rectangle"><ref id="nope"/></shape>' + LIGHT, None, "not found"),
+])
+def test_unsupported_input_is_an_error_with_a_reason(cli, tmp_path, body, film, needle):
+    s = scene_with(tmp_path, body, film) if film else scene_with(tmp_path, body)
+    r = run(cli, "--parse-only", s)
+    assert r.returncode == 1 and needle in r.stderr, r.stderr
+
+
+def test_cli_errors(cli, tmp_path):
+    assert run(cli).returncode == 1 and "no scene file" in run(cli).stderr
+    assert "undefined parameter" in run(cli, "--parse-only", scene_with(tmp_path, '<shape type="rectangle"><transform name="toWorld"><translate x="$dx"/></transform></shape>' + LIGHT)).stderr
+    bad = tmp_path / "bad.xml"; bad.write_text("<scene><shape></scene>")
+    assert run(cli, "--parse-only", str(bad)).returncode == 1
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0
+        return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)[::-1]
+
+
+@pytest.mark.gpu
+def test_cli_render_equals_python_mirror(cli, tmp_path, gpu_required):
+    import gradientdomain_mitsuba_amd.gpt as G
+    dest = str(tmp_path / "cbox")
+    r = run(cli, "-o", dest, "-D", "width=48", "-D", "height=40", "-D", "spp=6", "-D", "maxDepth=6", "-p", "3", XML)
+    assert r.returncode == 0, r.stderr
+    assert "Writing image" in r.stdout and "Using HIP" in r.stdout and "Execution time" in r.stdout
+    out = G.GradientPathIntegrator(maxDepth=6).render(G.Scene(scenes.cornell_box(48, 40)), 6)
+    for suffix in G.BUFFER_NAMES:
+        img = read_pfm(dest + suffix + ".pfm")
+        assert img.shape == (40, 48, 3)
+        assert np.array_equal(img, out[suffix]), suffix
+    assert os.path.exists(dest + "-log.txt") and "Render time" in open(dest + "-log.txt").read()
+    assert run(cli, "-o", dest, "-x", "-D", "width=48", "-D", "height=40", XML).stdout.startswith("Skipping")
+    bad = run(cli, "-o", dest, "-D", "width=16", "-D", "height=16", "-D", "maxDepth=0", XML)
+    assert bad.returncode == 1 and "maxDepth" in bad.stderr
