@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 W, H, SPP = 1280, 720, 64
 MAX_DEPTH = -1           # gpt.cpp:1194 default (unbounded; Russian roulette from depth 5)
 PRESET = "L2D"           # configs[1]: "L2 CG reconstruct"
+SCENE = "cornell"
+# BASELINE.json configs (1-based); the default run is configs[1] = --config 2.  The others are for the record, not bench lines.
+CONFIGS = {1: ("cornell", 512, 512, 64, "L2D"), 2: ("cornell", 1280, 720, 64, "L2D"), 3: ("atrium", 1920, 1080, 256, "L1D"), 4: ("atrium", 3840, 2160, 256, "L2D")}
 BYTES_PER_PIX_ITER = {"L2D": 120.0, "L1D": 132.0}     # SURVEY.md 8(d), fp32, reference 3-op formulation
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s
 
@@ -59,8 +62,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-4); 2 is the metric's configuration")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
     a = ap.parse_args()
+    global W, H, PRESET, SCENE
+    SCENE, W, H, spp_cfg, PRESET = CONFIGS[a.config]
+    if a.spp == SPP:
+        a.spp = spp_cfg
 
     import torch
     import torch.distributed as dist
@@ -80,7 +88,7 @@ def main():
     from gradientdomain_mitsuba_amd import gpt, parallel, scenes
     import gradientdomain_mitsuba_amd.poisson as P
 
-    desc = scenes.cornell_box(W, H, "diffuse")
+    desc = scenes.cornell_box(W, H, "diffuse") if SCENE == "cornell" else scenes.atrium(W, H)
     scene = gpt.Scene(desc, device=local)
     strips = parallel.row_strips(H, world)
     y0, y1 = strips[rank]
@@ -145,14 +153,14 @@ def main():
         kus = solver.profileKernels(50)
         bpi = BYTES_PER_PIX_ITER[PRESET]
         achieved = bpi * mpix_iter * 1e6 / 1e9
-        kb = 72.0 * W * H          # fused x_p+stencil, L2 (unit weights): R r,p,x + W x,p,Ap = 72 B/px algorithmic
+        kb = (72.0 if prm.irlsIterMax == 1 else 84.0) * W * H          # fused x_p+stencil: R r,p,x + W x,p,Ap = 72 B/px algorithmic (+12 for w in IRLS)
         samples = W * H * a.spp * a.steps
         out = {
-            "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, 1280x720x64spp",
+            "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp" % (W, H, a.spp),
             "value": round(mray, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * wall / a.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Cornell box (build-authored, 32 triangles), G-PT %d spp, %dx%d, fp64 tracer, %s CG reconstruct (BASELINE configs[1])" % (a.spp, W, H, PRESET),
+            "config": {"workload": "%s (build-authored, %d triangles), G-PT %d spp, %dx%d, fp64 tracer, %s reconstruct (BASELINE configs[%d])" % ("Cornell box" if SCENE == "cornell" else "atrium (Sponza-class stand-in)", desc.ntri, a.spp, W, H, PRESET, a.config - 1),
                        "maxDepth": MAX_DEPTH, "rrDepth": 5, "parallelism": "row strips x%d + 1-px halo" % world},
             "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / samples, 2), "msample_s": round(samples / wall / 1e6, 2),
             "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "render_kernel_mray_s": round(rays / world / (render_ms * 1e-3) / 1e6 * world, 1),
@@ -164,7 +172,7 @@ def main():
                          "kernel_achieved": round(kb / (kus[3] * 1e-6) / 1e9, 1) if kus[3] > 0 else None,
                          "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2)}},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and a.config == 2:
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)
         print(json.dumps(out))
     if solver:

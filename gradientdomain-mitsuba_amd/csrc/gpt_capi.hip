@@ -339,6 +339,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     if (y0 < 0 || y1 > H || y0 >= y1) return tfail(GDPT_ERR_INVALID, "film_create: rows [%d,%d) outside the %dx%d film", y0, y1, W, H);
     gdpt_film *f = new gdpt_film;
     f->scene = s;
+    f->wavesPerSimd = s->d.ldsScene ? 2 : 4;    // measured: LDS-resident scenes peak at 2 waves/SIMD, HBM-resident BVHs want 4
     FilmD &d = f->d;
     d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
     d.recStride = (size_t)d.recRows * W;

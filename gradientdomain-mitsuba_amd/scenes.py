@@ -182,6 +182,6 @@ def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):
                     b.quad(*q, m, mid)
     first = len(b.tris)
     b.quad((-6, Hh - 0.05, -3), (6, Hh - 0.05, -3), (6, Hh - 0.05, 3), (-6, Hh - 0.05, 3), lightm, room)
-    b.emitter(first, 2, (30.0, 28.0, 24.0))
+    b.emitter(first, 2, (7.0, 6.5, 5.5))
     return b.finish(to_world=lookat((-17.0, 3.2, 0.6), (0.0, 4.5, 0.0), (0, 1, 0)), fov_x=70.0, near=0.1, far=200.0,
                     width=width, height=height, name="atrium")

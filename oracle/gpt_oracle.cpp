@@ -246,6 +246,11 @@ struct Scene {
     Float aspect, tanHalf;
     V3 aabbMin, aabbMax;
     mutable uint64_t raysTraced = 0, shadowRaysTraced = 0; // skdtree.cpp:46-47
+    // Oracle-side acceleration for large scenes only (> 64 triangles): a plain midpoint-split bounding-volume tree over double
+    // bounds.  It changes which triangles are TESTED, never the test or the answer (closest t wins); small scenes stay brute force.
+    struct BNode { V3 lo, hi; int left, right, first, count; };
+    std::vector<BNode> bvh;
+    std::vector<int> bvhOrder;
 };
 
 int triaccel_load(TriAccel &ta, V3 A, V3 B, V3 C)
@@ -309,6 +314,74 @@ bool aabb_ray(const Scene &sc, const Ray &ray, Float &nearT, Float &farT)
     return true;
 }
 
+inline bool boxHit(const Scene::BNode &n, const Ray &ray, Float mint, Float maxt)
+{
+    Float t0 = mint, t1 = maxt;
+    for (int a = 0; a < 3; a++) {
+        const Float o = ray.o[a], d = ray.d[a];
+        if (d == 0) { if (o < n.lo[a] || o > n.hi[a]) return false; continue; }
+        Float ta = (n.lo[a] - o) / d, tb = (n.hi[a] - o) / d;
+        if (ta > tb) std::swap(ta, tb);
+        // conservative: widen by a relative margin so that rounding in this culling test can never drop a true hit
+        ta -= std::abs(ta) * 1e-12 + 1e-300; tb += std::abs(tb) * 1e-12 + 1e-300;
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+
+// Visits every triangle whose leaf box the ray segment [mint, maxt] touches; `visit` returns the (possibly shortened) maxt,
+// or a negative value to stop (any-hit).
+template <class F> void bvhVisit(const Scene &sc, const Ray &ray, Float mint, Float maxt, F visit)
+{
+    if (sc.bvh.empty()) {
+        for (size_t i = 0; i < sc.tris.size(); ++i) { maxt = visit((int)i, maxt); if (maxt < 0) return; }
+        return;
+    }
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const Scene::BNode &n = sc.bvh[stack[--sp]];
+        if (!boxHit(n, ray, mint, maxt)) continue;
+        if (n.count) {
+            for (int i = 0; i < n.count; ++i) { maxt = visit(sc.bvhOrder[n.first + i], maxt); if (maxt < 0) return; }
+        } else { stack[sp++] = n.left; stack[sp++] = n.right; }
+    }
+}
+
+int bvhBuild(Scene &sc, int first, int count)
+{
+    const int me = (int)sc.bvh.size();
+    sc.bvh.push_back(Scene::BNode());
+    V3 lo(INF), hi(-INF), clo(INF), chi(-INF);
+    for (int i = first; i < first + count; ++i) {
+        const Tri &t = sc.tris[sc.bvhOrder[i]];
+        const V3 ps[3] = {t.p0, t.p1, t.p2};
+        V3 c(0.0);
+        for (const V3 &p : ps) {
+            lo = V3(std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z));
+            hi = V3(std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z));
+            c = c + p;
+        }
+        c = c * (1.0 / 3.0);
+        clo = V3(std::min(clo.x, c.x), std::min(clo.y, c.y), std::min(clo.z, c.z));
+        chi = V3(std::max(chi.x, c.x), std::max(chi.y, c.y), std::max(chi.z, c.z));
+    }
+    sc.bvh[me].lo = lo; sc.bvh[me].hi = hi; sc.bvh[me].left = sc.bvh[me].right = -1; sc.bvh[me].first = first; sc.bvh[me].count = 0;
+    const V3 ext = chi - clo;
+    const int axis = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
+    if (count <= 4 || !(ext[axis] > 0)) { sc.bvh[me].count = count; return me; }
+    const Float mid = 0.5 * (clo[axis] + chi[axis]);
+    auto centroid = [&](int ti) { const Tri &t = sc.tris[ti]; return (t.p0[axis] + t.p1[axis] + t.p2[axis]) * (1.0 / 3.0); };
+    int *b = sc.bvhOrder.data() + first;
+    int nl = (int)(std::partition(b, b + count, [&](int ti) { return centroid(ti) < mid; }) - b);
+    if (nl == 0 || nl == count) nl = count / 2;
+    const int l = bvhBuild(sc, first, nl), r = bvhBuild(sc, first + nl, count - nl);
+    sc.bvh[me].left = l; sc.bvh[me].right = r;
+    return me;
+}
+
 // ShapeKDTree::rayIntersect(ray, its), skdtree.cpp:112-142 + fillIntersectionRecord<true>, skdtree.h:343-428
 bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
 {
@@ -324,13 +397,15 @@ bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
     if (ray.maxt < maxt) maxt = ray.maxt;
     if (!(maxt > mint)) return false;
     Float bu = 0, bv = 0;
-    for (size_t i = 0; i < sc.tris.size(); ++i) { // closest hit; the traversal order of the kd-tree is not restated
+    bvhVisit(sc, ray, mint, maxt, [&](int i, Float mx) { // closest hit; the traversal order of the kd-tree is not restated
         Float u, v, t;
-        if (triaccel_intersect(sc.tris[i].acc, ray, mint, maxt, u, v, t)) {
-            maxt = t;
-            its.t = t; its.prim = (int)i; bu = u; bv = v;
+        // ties in t between triangles sharing an edge go to the lowest triangle index (brute-force order), whatever the visiting order
+        if (triaccel_intersect(sc.tris[i].acc, ray, mint, mx, u, v, t) && (t < its.t || (t == its.t && i < its.prim))) {
+            its.t = t; its.prim = i; bu = u; bv = v;
+            return t;
         }
-    }
+        return mx;
+    });
     if (its.prim < 0) return false;
     const Tri &tr = sc.tris[its.prim];
     const V3 b(1 - bu - bv, bu, bv);
@@ -353,11 +428,13 @@ bool rayIntersectShadow(const Scene &sc, const Ray &ray)
     if (rayMinT > mint) mint = rayMinT;
     if (ray.maxt < maxt) maxt = ray.maxt;
     if (!(maxt > mint)) return false;
-    for (size_t i = 0; i < sc.tris.size(); ++i) {
+    bool hit = false;
+    bvhVisit(sc, ray, mint, maxt, [&](int i, Float mx) {
         Float u, v, t;
-        if (triaccel_intersect(sc.tris[i].acc, ray, mint, maxt, u, v, t)) return true;
-    }
-    return false;
+        if (triaccel_intersect(sc.tris[i].acc, ray, mint, mx, u, v, t)) { hit = true; return (Float)-1.0; }
+        return mx;
+    });
+    return hit;
 }
 
 // ---- warps: src/libcore/warp.cpp ------------------------------------------------------------------------
@@ -1261,6 +1338,11 @@ GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *tr
         sc.emitterPDF.append(1.0);                                     // getSamplingWeight() == 1
     }
     if (nemit > 0) sc.emitterPDF.normalize();
+    if (ntri > 64) {
+        sc.bvhOrder.resize(ntri);
+        for (int i = 0; i < ntri; ++i) sc.bvhOrder[i] = i;
+        bvhBuild(sc, 0, ntri);
+    }
     return h;
 }
 

@@ -79,6 +79,22 @@ def test_film_matches_oracle(G, variant, W, H, spp, md, strict):
         assert close(acc[b], oacc[b]), (G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
 
 
+def test_atrium_hbm_bvh_film_matches_oracle(G):
+    """Sponza-class stand-in (20k triangles): the BVH and triangle tables do not fit the LDS budget, so traversal reads
+    node packets from HBM/L2 and the shading tables through the global path; diffuse + rough-conductor materials."""
+    W, H, spp = 64, 36, 4
+    sc = scenes.atrium(W, H, columns=12, segments=16)
+    assert sc.ntri > 20000
+    S = G.Scene(sc); F = G.Film(S)
+    integ = G.GradientPathIntegrator(maxDepth=7)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    oacc, orays = go.Scene(sc).render(go.config(maxDepth=7, spp=spp))
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+
+
 def test_large_film_including_filter_edge_samples(G):
     """590k samples: ~24 of them fall within 1e-5 of a pixel edge, where the box filter's footprint is two pixels wide
     (box.cpp:38, imageblock.h:172-176) and the HIP path switches from per-pixel sums to exact atomic puts."""
