@@ -260,7 +260,7 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
         if (m.type < 0 || m.type > 2) return tfail(GDPT_ERR_UNSUPPORTED, "material %d: BSDF type %d is not carried (diffuse/conductor/roughconductor only)", i, m.type);
         if (m.type == 2 && (m.distribution < 0 || m.distribution > 1)) return tfail(GDPT_ERR_UNSUPPORTED, "material %d: only beckmann and ggx distributions are carried", i);
         MaterialD &o = mats[i];
-        o.type = m.type; o.distribution = m.distribution; o.sampleVisible = m.sampleVisible; o.pad = 0;
+        o.type = m.type; o.distribution = m.distribution; o.sampleVisible = m.sampleVisible; o.twoSided = m.twoSided != 0;
         o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));
         o.eta = to_d3(h3(m.eta[0], m.eta[1], m.eta[2]));
         o.k = to_d3(h3(m.k[0], m.k[1], m.k[2]));

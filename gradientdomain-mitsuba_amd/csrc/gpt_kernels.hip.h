@@ -80,7 +80,7 @@ struct TriShade {           // 160 B: what fillIntersectionRecord needs (skdtree
     int origIndex, pad;
 };
 struct MaterialD {           // 112 B (a multiple of 16: tables are staged into LDS with 16-byte copies)
-    int type, distribution, sampleVisible, pad;
+    int type, distribution, sampleVisible, twoSided;
     d3 reflectance, eta, k;
     Float alphaU, alphaV, pad2;
 };
@@ -456,6 +456,7 @@ __device__ __forceinline__ int bsdfType(const MaterialD &m) { return m.type == 0
 __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 &f, Float &pdf)
 {
     f = mk(0.0); pdf = 0.0;
+    if (m.twoSided && !(wi.z > 0)) { wi.z = -wi.z; wo.z = -wo.z; }      // TwoSided::eval/pdf, twosided.cpp:100-124
     if (wi.z <= 0 || wo.z <= 0) return;
     if (m.type == 0) {
         if (measure != MEASURE_SOLID_ANGLE) return;
@@ -483,7 +484,7 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
 
 struct BSDFSample { d3 wo, weight; Float pdf; int sampledType; };
 // the pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
-__device__ void bsdf_sample(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
+__device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
 {
     r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.sampledType = 0;   // gpt.cpp:450-454: pdf starts at 0
     if (m.type == 0) {
@@ -516,6 +517,14 @@ __device__ void bsdf_sample(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFS
             r.weight = F * weight;
         }
     }
+}
+
+__device__ __forceinline__ void bsdf_sample(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
+{ // TwoSided::sample (pdf overload), twosided.cpp:148-168, around the one-sided models
+    const bool flipped = m.twoSided && wi.z < 0;
+    if (flipped) wi.z = -wi.z;
+    bsdf_sample_one(m, wi, sx, sy, r);
+    if (flipped && !(r.weight.x == 0 && r.weight.y == 0 && r.weight.z == 0) && r.pdf != 0) r.wo.z = -r.wo.z;
 }
 
 // getVertexType (gpt.cpp:176-231) for single-component BSDFs; getRoughness: diffuse.cpp:167, conductor.cpp:275, roughconductor.cpp:437

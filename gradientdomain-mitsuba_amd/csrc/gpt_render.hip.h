@@ -103,7 +103,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     // ================= direct illumination sampling, :565-730 =================
     if (bsdfType(mainBSDF) & ESmooth) {
         DRec dRec;
-        dRec.ref = L.v.p; dRec.refN = mfr.n;                                     // records.inl:160-164
+        dRec.ref = L.v.p; dRec.refN = mainBSDF.twoSided ? mk(0.0) : mfr.n;       // records.inl:160-164 (no refN behind a back-sided BSDF)
         const Float lsx = L.rng.next1D(), lsy = L.rng.next1D();                  // :572
         d3 value = sample_emitter_direct(S, sv, dRec, lsx, lsy);
         const bool mainEmitterVisible = !cast_shadow(sv, stack, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
@@ -149,7 +149,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                         if (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth)) {
                             const Frame3 sfr = frame_of(sts);
                             DRec sRec;
-                            sRec.ref = s.v.p; sRec.refN = sfr.n;
+                            sRec.ref = s.v.p; sRec.refN = shiftedBSDF.twoSided ? mk(0.0) : sfr.n;
                             d3 sv_ = sample_emitter_direct(S, sv, sRec, lsx, lsy);
                             const bool shiftedEmitterVisible = !cast_shadow(sv, stack, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
                             if (!shiftedEmitterVisible) sv_ = mk(0.0);
@@ -215,7 +215,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
     L.pdf *= bs.pdf;
     // mainDRec: ref = previous vertex, refN = its shading normal; setQuery (records.inl:170-178): p, n, d, dist
-    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, mfr.n, nts.n, L.depthT) : 0;  // :815
+    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, mainBSDF.twoSided ? mk(0.0) : mfr.n, nts.n, L.depthT) : 0;  // :815
     const Float mainWeightNumerator = mainPreviousPdf * bs.pdf;                   // :819-820
     const Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
     const d3 mainContribution = L.throughput * mainEmitterRadiance;

@@ -18,7 +18,7 @@ BUFFER_FINAL, BUFFER_THROUGHPUT, BUFFER_DX, BUFFER_DY, BUFFER_VERY_DIRECT = rang
 
 
 class Material(C.Structure):
-    _fields_ = [("type", C.c_int), ("distribution", C.c_int), ("sampleVisible", C.c_int), ("pad", C.c_int),
+    _fields_ = [("type", C.c_int), ("distribution", C.c_int), ("sampleVisible", C.c_int), ("twoSided", C.c_int),
                 ("reflectance", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3),
                 ("alphaU", C.c_double), ("alphaV", C.c_double)]
 
@@ -42,6 +42,7 @@ def _material(m):
     out.type = m["type"]
     out.distribution = m.get("distribution", 0)
     out.sampleVisible = m.get("sampleVisible", 1)
+    out.twoSided = int(m.get("twoSided", 0))
     out.reflectance = (C.c_double * 3)(*m.get("reflectance", (0.5, 0.5, 0.5)))
     out.eta = (C.c_double * 3)(*m.get("eta", (0.0, 0.0, 0.0)))
     out.k = (C.c_double * 3)(*m.get("k", (1.0, 1.0, 1.0)))

@@ -324,6 +324,16 @@ private:
 
     int bsdf(const xml::Node &n, SceneData &sd)
     {
+        if (subst(n.get("type")) == "twosided") {            // src/bsdfs/twosided.cpp with ONE nested BRDF (used for both faces)
+            const xml::Node *inner = nullptr;
+            for (auto &c : n.children)
+                if (c->tag == "bsdf") { if (inner) logError("twosided: a second nested BRDF (different front/back models) is not carried"); inner = c.get(); }
+            if (!inner) logError("A nested one-sided material is required!");                        // twosided.cpp:85
+            if (subst(inner->get("type")) == "twosided") logError("twosided inside twosided is not carried");
+            const int idx = bsdf(*inner, sd);
+            sd.materials[idx].twoSided = 1;
+            return idx;
+        }
         const std::string type = subst(n.get("type"));
         gdpt_material m;
         std::memset(&m, 0, sizeof m);
@@ -367,7 +377,7 @@ private:
         if (type == "diffuse") m.type = GDPT_MAT_DIFFUSE;
         else if (type == "conductor") m.type = GDPT_MAT_CONDUCTOR;
         else if (type == "roughconductor") m.type = GDPT_MAT_ROUGHCONDUCTOR;
-        else logError(format("bsdf \"%s\" is not carried: diffuse, conductor, roughconductor (twosided/dielectric are the next candidates)", type.c_str()));
+        else logError(format("bsdf \"%s\" is not carried: diffuse, conductor, roughconductor, twosided (dielectric is the next candidate)", type.c_str()));
         if (m.type != GDPT_MAT_DIFFUSE && !(haveEta && haveK)) logError(format("bsdf \"%s\": explicit eta and k are required (the default `material=Cu` needs data/ior)", type.c_str()));
         sd.materials.push_back(m);
         return (int)sd.materials.size() - 1;

@@ -28,6 +28,13 @@ def roughconductor(alpha, eta, k, specular=(1.0, 1.0, 1.0), distribution=DISTR_B
                 alphaV=float(alpha if alphaV is None else alphaV), distribution=distribution, sampleVisible=int(sampleVisible))
 
 
+def twosided(inner):
+    """`twosided` around a one-sided BRDF (reference src/bsdfs/twosided.cpp): the same model on both faces."""
+    m = dict(inner)
+    m["twoSided"] = 1
+    return m
+
+
 # measured-looking constants for copper/aluminium at RGB wavelengths (scene authors pass explicit eta/k; data/ior is not needed)
 CU = dict(eta=(0.200438, 0.924033, 1.102212), k=(3.912949, 2.452848, 2.142188))
 AL = dict(eta=(1.657460, 0.880369, 0.521229), k=(9.223869, 6.269523, 4.837001))
@@ -120,6 +127,9 @@ def cornell_box(width=512, height=512, variant="diffuse"):
         floor_m = b.material(roughconductor(0.0008, **CU))
         back_m = b.material(roughconductor(0.2, **AL, alphaV=0.05))
         tall_m = short_m = white
+    elif variant == "twosided":       # two-sided walls and a free-standing two-sided GGX panel lit and seen from both faces
+        white = b.material(twosided(diffuse((0.725, 0.71, 0.68))))
+        floor_m = back_m = tall_m = short_m = white
     else:
         tall_m = short_m = white
     room = (278.0, 274.4, 279.6)
@@ -130,6 +140,9 @@ def cornell_box(width=512, height=512, variant="diffuse"):
     b.quad((552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0), red, room)      # left wall
     b.box([(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)], 0.0, short_m)         # short block
     b.box([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 0.0, tall_m)        # tall block
+    if variant == "twosided":
+        panel = b.material(twosided(roughconductor(0.15, **AL, distribution=DISTR_GGX)))
+        b.quad((60, 20, 150), (200, 20, 60), (200, 300, 60), (60, 300, 150), panel, room)
     first = len(b.tris)
     b.quad((343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227), lightm, room)  # light, just below the ceiling
     b.emitter(first, 2, (17.0, 12.0, 4.0))

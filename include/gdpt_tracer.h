@@ -35,7 +35,7 @@ typedef struct gdpt_material {
     int    type;            /* GDPT_MAT_*                                                        */
     int    distribution;    /* GDPT_DISTR_* (roughconductor `distribution`)                      */
     int    sampleVisible;   /* roughconductor `sampleVisible` (default 1)                        */
-    int    pad;
+    int    twoSided;        /* 1 = wrapped in `twosided` (src/bsdfs/twosided.cpp), same BRDF both sides */
     double reflectance[3];  /* diffuse `reflectance`; conductors `specularReflectance`           */
     double eta[3], k[3];    /* conductors `eta`, `k` (RGB)                                       */
     double alphaU, alphaV;  /* roughconductor `alpha` / `alphaU`,`alphaV`                        */

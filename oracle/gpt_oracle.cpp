@@ -132,7 +132,7 @@ typedef struct gpo_material {
     int type;            // MAT_*
     int distribution;    // DISTR_* (roughconductor)
     int sampleVisible;   // roughconductor.cpp m_sampleVisible (default true)
-    int pad;
+    int twoSided;        // wrapped in src/bsdfs/twosided.cpp (the same BRDF on both sides)
     double reflectance[3]; // diffuse: reflectance; conductors: specularReflectance
     double eta[3], k[3];
     double alphaU, alphaV;
@@ -665,7 +665,7 @@ inline Microfacet distr(const gpo_material &m) { return Microfacet(m.distributio
 // BSDF::getRoughness: diffuse.cpp:167-169 (+inf), conductor.cpp:275-277 (0), roughconductor.cpp:437-440
 inline Float getRoughness(const gpo_material &m) { return m.type == MAT_DIFFUSE ? INF : (m.type == MAT_CONDUCTOR ? 0.0 : 0.5 * (m.alphaU + m.alphaV)); }
 
-V3 bsdfEval(const gpo_material &m, V3 wi, V3 wo, int measure)
+V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure)
 {
     switch (m.type) {
     case MAT_DIFFUSE: // diffuse.cpp:110-118
@@ -688,7 +688,7 @@ V3 bsdfEval(const gpo_material &m, V3 wi, V3 wo, int measure)
     }
 }
 
-Float bsdfPdf(const gpo_material &m, V3 wi, V3 wo, int measure)
+Float bsdfPdfOne(const gpo_material &m, V3 wi, V3 wo, int measure)
 {
     switch (m.type) {
     case MAT_DIFFUSE: // diffuse.cpp:120-127
@@ -708,7 +708,7 @@ Float bsdfPdf(const gpo_material &m, V3 wi, V3 wo, int measure)
 }
 
 // The pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
-BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy)
+BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy)
 {
     BSDFSample r;
     r.wo = V3(0.0); r.eta = 1.0; r.sampledType = 0; r.weight = V3(0.0); r.pdf = 0.0; // gpt.cpp:450-454: result.pdf starts at 0
@@ -748,6 +748,30 @@ BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy)
     }
     }
 }
+
+// TwoSided (src/bsdfs/twosided.cpp:100-168) around the one-sided models, nestedBRDF[1] == nestedBRDF[0]
+V3 bsdfEval(const gpo_material &m, V3 wi, V3 wo, int measure)
+{
+    if (!m.twoSided || cosTheta(wi) > 0) return bsdfEvalOne(m, wi, wo, measure);
+    wi.z *= -1; wo.z *= -1;
+    return bsdfEvalOne(m, wi, wo, measure);
+}
+Float bsdfPdf(const gpo_material &m, V3 wi, V3 wo, int measure)
+{
+    if (!m.twoSided || wi.z > 0) return bsdfPdfOne(m, wi, wo, measure);
+    wi.z *= -1; wo.z *= -1;
+    return bsdfPdfOne(m, wi, wo, measure);
+}
+BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy)
+{
+    bool flipped = false;
+    if (m.twoSided && cosTheta(wi) < 0) { wi.z *= -1; flipped = true; }
+    BSDFSample r = bsdfSampleOne(m, wi, sx, sy);
+    if (flipped && !isZero(r.weight) && r.pdf != 0) r.wo.z *= -1;
+    return r;
+}
+// DirectSamplingRecord(const Intersection&), records.inl:160-164: refN stays 0 when the BSDF has a back side (twosided)
+inline V3 refNormal(const gpo_material &m, const Intersection &its) { return m.twoSided ? V3(0.0) : its.sh.n; }
 
 // ---- emitters -----------------------------------------------------------------------------------------
 struct DirectSamplingRecord { V3 ref, refN, p, n, d; Float dist, pdf; int measure; int object; };
@@ -962,7 +986,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
         // ---- direct illumination sampling, :565-730 (minDepth is forced to 1, gpt.cpp:1369) ----
         if (bsdfType(mainBSDF) & ESmooth) {
             DirectSamplingRecord dRec;                                                     // records.inl:160-164
-            dRec.ref = main.its.p; dRec.refN = main.its.sh.n;
+            dRec.ref = main.its.p; dRec.refN = refNormal(mainBSDF, main.its);
             const Float lsx = rng.next1D(), lsy = rng.next1D();                            // :572
             bool mainEmitterVisible;
             V3 value = sampleEmitterDirectVisible(sc, dRec, lsx, lsy, mainEmitterVisible);
@@ -1004,7 +1028,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, ESmooth);
                             if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE) { // area lights are never EDiscrete
                                 DirectSamplingRecord shiftedDRec;
-                                shiftedDRec.ref = shifted.its.p; shiftedDRec.refN = shifted.its.sh.n;
+                                shiftedDRec.ref = shifted.its.p; shiftedDRec.refN = refNormal(shiftedBSDF, shifted.its);
                                 bool shiftedEmitterVisible;
                                 V3 sv = sampleEmitterDirectVisible(sc, shiftedDRec, lsx, lsy, shiftedEmitterVisible);
                                 V3 shiftedEmitterRadiance = sv * shiftedDRec.pdf;
@@ -1051,7 +1075,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
         bool mainHitEmitter = false;
         V3 mainEmitterRadiance(0.0);
         DirectSamplingRecord mainDRec;
-        mainDRec.ref = main.its.p; mainDRec.refN = main.its.sh.n; mainDRec.object = -1; mainDRec.measure = MEASURE_SOLID_ANGLE;
+        mainDRec.ref = main.its.p; mainDRec.refN = refNormal(mainBSDF, main.its); mainDRec.object = -1; mainDRec.measure = MEASURE_SOLID_ANGLE;
         VertexType mainVertexType = getVertexType(mainBSDF, cfg, mainBsdfResult.sampledType); // :765
         VertexType mainNextVertexType;
         main.ray = Ray(main.its.p, mainWo);                                                // :768
@@ -1453,7 +1477,7 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
             const gpo_material &m = matOf(sc, its);
             if (bsdfType(m) & ESmooth) {
                 DirectSamplingRecord dRec;
-                dRec.ref = its.p; dRec.refN = its.sh.n;
+                dRec.ref = its.p; dRec.refN = refNormal(m, its);
                 bool vis;
                 const Float u1 = rng.next1D(), u2 = rng.next1D();
                 V3 val = sampleEmitterDirectVisible(sc, dRec, u1, u2, vis);
@@ -1470,7 +1494,7 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
             if (s.pdf <= 0) break;
             V3 wo = its.sh.toWorld(s.wo);
             DirectSamplingRecord q;
-            q.ref = its.p; q.refN = its.sh.n;
+            q.ref = its.p; q.refN = refNormal(m, its);
             Ray next(its.p, wo);
             beta = beta * s.weight;
             if (!rayIntersect(sc, next, its)) break;

@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "_build", "libgdpt_oracle_gpt.so")
 
 
 class Material(C.Structure):
-    _fields_ = [("type", C.c_int), ("distribution", C.c_int), ("sampleVisible", C.c_int), ("pad", C.c_int),
+    _fields_ = [("type", C.c_int), ("distribution", C.c_int), ("sampleVisible", C.c_int), ("twoSided", C.c_int),
                 ("reflectance", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3),
                 ("alphaU", C.c_double), ("alphaV", C.c_double)]
 
@@ -43,6 +43,7 @@ def material(m):
     out.type = m["type"]
     out.distribution = m.get("distribution", 0)
     out.sampleVisible = m.get("sampleVisible", 1)
+    out.twoSided = int(m.get("twoSided", 0))
     out.reflectance = (C.c_double * 3)(*m.get("reflectance", (0.5, 0.5, 0.5)))
     out.eta = (C.c_double * 3)(*m.get("eta", (0.0, 0.0, 0.0)))
     out.k = (C.c_double * 3)(*m.get("k", (1.0, 1.0, 1.0)))

@@ -100,6 +100,22 @@ def test_bsdf_sample_weight_pdf_eval_are_consistent(mat):
     assert 0.85 < integral < 1.05
 
 
+def test_twosided_wraps_the_one_sided_model():
+    # twosided.cpp:100-168: the nested BRDF evaluated with both z components mirrored when wi arrives from below
+    inner = scenes.roughconductor(0.2, **scenes.CU)
+    two = scenes.twosided(inner)
+    wi, wo = unit([0.3, 0.1, 0.9]), unit([-0.2, 0.3, 0.8])
+    flip = lambda v: np.array([v[0], v[1], -v[2]])
+    f1, p1 = go.bsdf_eval_pdf(inner, wi, wo)
+    f2, p2 = go.bsdf_eval_pdf(two, flip(wi), flip(wo))
+    assert p1 > 0 and np.array_equal(f1, f2) and p1 == p2
+    assert go.bsdf_eval_pdf(inner, flip(wi), flip(wo))[1] == 0                    # the one-sided model is black from behind
+    assert np.array_equal(go.bsdf_eval_pdf(two, wi, wo)[0], f1)
+    assert go.bsdf_eval_pdf(two, wi, flip(wo))[1] == 0                            # no transmission
+    a = go.bsdf_sample(inner, wi, 0.3, 0.6); b = go.bsdf_sample(two, flip(wi), 0.3, 0.6)
+    assert np.allclose(b[0], flip(a[0]), atol=0) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
 def test_camera_and_intersection_geometry():
     sc = scenes.cornell_box(64, 64)
     S = go.Scene(sc)
