@@ -7,6 +7,7 @@
 // Errors: the reference's Log(EError, ...) throws std::runtime_error (src/libcore/logger.cpp:147) -- so does this.
 #pragma once
 #include "../../include/gdpt_tracer.h"
+#include "exr_writer.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -160,8 +161,12 @@ public:
         m_width = props.getInteger("width", 768);                                                   // film.cpp defaults
         m_height = props.getInteger("height", 576);
         m_fileFormat = props.getString("fileFormat", "openexr");                                    // multifilm.cpp:104
-        if (m_fileFormat != "pfm")
-            logError("MultiFilm: this build writes fileFormat=\"pfm\" only (multifilm.cpp:123-124); OpenEXR/RGBE are not carried");
+        m_componentFormat = props.getString("componentFormat", "float16");                          // multifilm.cpp:116-117
+        if (m_fileFormat != "pfm" && m_fileFormat != "openexr")
+            logError(format("MultiFilm: fileFormat \"%s\" is not carried (openexr, pfm)", m_fileFormat.c_str()));
+        if (m_componentFormat != "float16" && m_componentFormat != "float32")
+            logError(format("MultiFilm: componentFormat \"%s\" is not carried (float16, float32)", m_componentFormat.c_str()));
+        if (m_fileFormat == "pfm") m_componentFormat = "float32";                                   // multifilm.cpp:223-235: pfm forces float32
     }
     bool setBuffers(const std::vector<std::string> &names)                                          // multifilm.cpp:293-319
     {
@@ -178,6 +183,13 @@ public:
     {
         std::vector<std::string> written;
         for (size_t i = 0; i < m_names.size(); ++i) {
+            if (m_fileFormat == "openexr") {
+                const std::string path = m_dest + m_names[i] + ".exr";
+                if (!ExrWriter::write(path, m_images[i].data(), m_width, m_height, m_componentFormat == "float16", log))
+                    logError(format("Cannot write \"%s\"", path.c_str()));
+                written.push_back(path);
+                continue;
+            }
             const std::string path = m_dest + m_names[i] + ".pfm";
             std::ofstream f(path, std::ios::binary);
             if (!f) logError(format("Cannot write \"%s\"", path.c_str()));
@@ -193,7 +205,7 @@ public:
 
 private:
     int m_width, m_height;
-    std::string m_fileFormat, m_dest;
+    std::string m_fileFormat, m_componentFormat, m_dest;
     std::vector<std::string> m_names;
     std::vector<std::vector<float>> m_images;
 };

@@ -1,6 +1,6 @@
 // gdpt_mitsuba -- command line front end with the reference CLI's flags for this path
 // (/root/reference/src/mitsuba/mitsuba.cpp:154-250): gdpt_mitsuba [-o dest] [-D key=val]... [-p n] [-b n] [-x] [-q] scene.xml
-//   -o  output destination stem: writes <dest>-final|-throughput|-dx|-dy|-direct.pfm and <dest>-log.txt (multifilm.cpp:453-517)
+//   -o  output destination stem: writes <dest>-final|-throughput|-dx|-dy|-direct.{exr|pfm} and <dest>-log.txt (multifilm.cpp:453-517)
 //   -D  parameter substitution for $key in the scene file
 //   -p, -b  accepted for compatibility (CPU core count / block size have no meaning for the GPU path) and ignored
 //   -x  skip rendering if <dest>-final.pfm exists;  -q  quiet;  --parse-only  load the scene, print a summary, do not touch the GPU
@@ -26,6 +26,18 @@ int main(int argc, char **argv)
             else if (a == "-q") quiet = true;
             else if (a == "--seed") seed = std::stoull(need("--seed"));
             else if (a == "--parse-only") parseOnly = true;
+            else if (a == "--pfm2exr") {      // utility (and CPU-testable face of the EXR writer): --pfm2exr in.pfm out.exr [float16|float32]
+                const std::string in = need("--pfm2exr"), out = need("--pfm2exr"), fmt = (i + 1 < argc) ? argv[++i] : "float16";
+                std::ifstream f(in, std::ios::binary);
+                std::string magic; int w = 0, h = 0; float scale = 0;
+                f >> magic >> w >> h >> scale;
+                f.get();
+                if (!f || magic != "PF" || scale >= 0 || w <= 0 || h <= 0) gdpt::logError("--pfm2exr: expected a little-endian colour PFM");
+                std::vector<float> img((size_t)3 * w * h);
+                for (int y = h - 1; y >= 0; --y) f.read(reinterpret_cast<char *>(&img[(size_t)3 * w * y]), sizeof(float) * 3 * w);
+                if (!gdpt::ExrWriter::write(out, img.data(), w, h, fmt == "float16")) gdpt::logError("cannot write " + out);
+                return 0;
+            }
             else if (a == "-h" || a == "--help") { printf("usage: gdpt_mitsuba [-o dest] [-D key=val] [-p n] [-b n] [-x] [-q] [--seed n] [--parse-only] scene.xml\n"); return 0; }
             else if (a[0] == '-') gdpt::logError("unknown option " + a);
             else scenePath = a;
@@ -41,7 +53,7 @@ int main(int argc, char **argv)
             return 0;
         }
         struct stat stt;
-        if (skipExisting && stat((dest + "-final.pfm").c_str(), &stt) == 0) { if (!quiet) printf("Skipping %s (output exists)\n", scenePath.c_str()); return 0; }
+        if (skipExisting && (stat((dest + "-final.pfm").c_str(), &stt) == 0 || stat((dest + "-final.exr").c_str(), &stt) == 0)) { if (!quiet) printf("Skipping %s (output exists)\n", scenePath.c_str()); return 0; }
         gdpt::GradientPathIntegrator integrator(sd.integrator);
         gdpt::MultiFilm film(sd.film);
         film.setDestinationFile(dest);

@@ -89,6 +89,56 @@ def test_cli_errors(cli, tmp_path):
     assert run(cli, "--parse-only", str(bad)).returncode == 1
 
 
+def read_exr(path):
+    """Minimal reader for the uncompressed scanline RGB OpenEXR files MultiFilm's default format produces here."""
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack("<II", b[:8]) == (20000630, 2)
+    i, attrs = 8, {}
+    while b[i] != 0:
+        e = b.index(b"\0", i); name = b[i:e].decode(); i = e + 1
+        e = b.index(b"\0", i); typ = b[i:e].decode(); i = e + 1
+        (sz,) = struct.unpack("<i", b[i:i + 4]); i += 4
+        attrs[name] = (typ, b[i:i + sz]); i += sz
+    i += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    ch, j, names, types = attrs["channels"][1], 0, [], []
+    while ch[j] != 0:
+        e = ch.index(b"\0", j); names.append(ch[j:e].decode()); j = e + 1
+        types.append(struct.unpack("<i", ch[j:j + 4])[0]); j += 16
+    assert names == ["B", "G", "R"] and len(set(types)) == 1
+    dt = {1: "<f2", 2: "<f4"}[types[0]]
+    offs = struct.unpack("<%dQ" % h, b[i:i + 8 * h])
+    img = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        yy, sz = struct.unpack("<ii", b[offs[y]:offs[y] + 8])
+        assert yy == y and sz == w * 3 * np.dtype(dt).itemsize
+        line = np.frombuffer(b[offs[y] + 8:offs[y] + 8 + sz], dt).reshape(3, w)
+        img[y, :, 2], img[y, :, 1], img[y, :, 0] = line[0], line[1], line[2]
+    return img, attrs
+
+
+def write_pfm(path, a):
+    with open(path, "wb") as f:
+        f.write(("PF\n%d %d\n-1.0\n" % (a.shape[1], a.shape[0])).encode()); f.write(a[::-1].astype("<f4").tobytes())
+
+
+def test_exr_writer_round_trip(cli, tmp_path):
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal((7, 13, 3)) * 10).astype(np.float32)
+    a[0, 0] = [0.0, 65504.0, 1e-7]; a[1, 1] = [1e6, -1e-3, 6.1e-5]        # half extremes: max, subnormal, overflow -> inf
+    write_pfm(str(tmp_path / "a.pfm"), a)
+    assert run(cli, "--pfm2exr", str(tmp_path / "a.pfm"), str(tmp_path / "f.exr"), "float32").returncode == 0
+    img, attrs = read_exr(str(tmp_path / "f.exr"))
+    assert np.array_equal(img, a) and attrs["channels"][0] == "chlist"
+    assert run(cli, "--pfm2exr", str(tmp_path / "a.pfm"), str(tmp_path / "h.exr"), "float16").returncode == 0
+    imgh, _ = read_exr(str(tmp_path / "h.exr"))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(imgh, a.astype(np.float16).astype(np.float32))                                    # round-to-nearest-even, like numpy
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"
@@ -111,5 +161,14 @@ def test_cli_render_equals_python_mirror(cli, tmp_path, gpu_required):
         assert np.array_equal(img, out[suffix]), suffix
     assert os.path.exists(dest + "-log.txt") and "Render time" in open(dest + "-log.txt").read()
     assert run(cli, "-o", dest, "-x", "-D", "width=48", "-D", "height=40", XML).stdout.startswith("Skipping")
+    # MultiFilm's default output format: OpenEXR (float32 here; the default componentFormat is float16)
+    xml32 = str(tmp_path / "exr.xml")
+    open(xml32, "w").write(open(XML).read().replace('<string name="fileFormat" value="pfm"/>', '<string name="fileFormat" value="openexr"/>'))
+    import shutil; shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    r = run(cli, "-o", dest + "e", "-D", "width=48", "-D", "height=40", "-D", "spp=6", "-D", "maxDepth=6", xml32)
+    assert r.returncode == 0, r.stderr
+    for suffix in G.BUFFER_NAMES:
+        img, attrs = read_exr(dest + "e" + suffix + ".exr")
+        assert np.array_equal(img, out[suffix]) and b"Render time" in attrs["log"][1]
     bad = run(cli, "-o", dest, "-D", "width=16", "-D", "height=16", "-D", "maxDepth=0", XML)
     assert bad.returncode == 1 and "maxDepth" in bad.stderr
