@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    cmd = [hipcc] + FLAGS + os.environ.get("GDPT_EXTRA_FLAGS", "").split() + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

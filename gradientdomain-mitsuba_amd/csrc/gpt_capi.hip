@@ -198,6 +198,7 @@ struct gdpt_film {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     bool resolved = false;
     int wavesPerSimd = 2;       // occupancy target the render kernel is compiled for (register budget = 512 / this)
+    bool accInLds = true;       // keep the per-sample sums in LDS when the block budget allows
 };
 
 extern "C" {
@@ -397,15 +398,22 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     THIPCHK(hipEventCreate(&e0));
     THIPCHK(hipEventCreate(&e1));
     THIPCHK(hipEventRecord(e0, f->stream));
-    // LDS: stack sized to the BVH (each level costs 1 KiB per block), plus the staged tables of a small scene
+    // LDS: stack sized to the BVH (each level costs 1 KiB per block), the staged tables of a small scene, and -- when two blocks
+    // per CU still fit -- the per-sample sums (60 KiB), which frees 60 long-lived VGPRs per lane
     const int stackDepth = std::min(STACK_DEPTH, std::max(4, s->bvhDepth + 2));
     size_t lds = (size_t)stackDepth * TBLK * sizeof(int);
-    if (s->d.ldsScene) lds += s->ldsSceneBytes;
+    const int sceneBytes = s->d.ldsScene ? (int)((s->ldsSceneBytes + 15) & ~(size_t)15) : 0;
+    lds += sceneBytes;
     const int wps = f->wavesPerSimd;
+    const size_t accBytes = sizeof(Float) * ACC_N * TBLK;
+    const bool accLds = f->accInLds && (lds + accBytes) * (size_t)std::max(1, wps) <= (size_t)160 * 1024;
+    if (accLds) lds += accBytes;
     const dim3 grid(tilesX * tilesY), block(TBLK);
-#define GDPT_LAUNCH(LDSV, WPS) hipLaunchKernelGGL((k_render<LDSV, WPS>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, stackDepth)
-    if (s->d.ldsScene) { if (wps == 1) GDPT_LAUNCH(true, 1); else if (wps == 2) GDPT_LAUNCH(true, 2); else if (wps == 3) GDPT_LAUNCH(true, 3); else GDPT_LAUNCH(true, 4); }
-    else               { if (wps == 1) GDPT_LAUNCH(false, 1); else if (wps == 2) GDPT_LAUNCH(false, 2); else if (wps == 3) GDPT_LAUNCH(false, 3); else GDPT_LAUNCH(false, 4); }
+#define GDPT_LAUNCH(LDSV, ACCV, WPS) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, stackDepth, sceneBytes)
+#define GDPT_LAUNCH_W(LDSV, ACCV) do { if (wps == 1) GDPT_LAUNCH(LDSV, ACCV, 1); else if (wps == 2) GDPT_LAUNCH(LDSV, ACCV, 2); else if (wps == 3) GDPT_LAUNCH(LDSV, ACCV, 3); else GDPT_LAUNCH(LDSV, ACCV, 4); } while (0)
+    if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
+    else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
+#undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
@@ -512,7 +520,9 @@ void *gdpt_film_stream(gdpt_film *f) { return f ? (void *)f->stream : nullptr; }
 
 int gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd)
 {
-    if (!f || wavesPerSimd < 1 || wavesPerSimd > 4) return tfail(GDPT_ERR_INVALID, "occupancy target must be 1..4 waves per SIMD");
+    if (!f || wavesPerSimd < -4 || wavesPerSimd > 4 || wavesPerSimd == 0) return tfail(GDPT_ERR_INVALID, "occupancy target must be 1..4 waves per SIMD (negative: same, with the per-sample sums kept in registers)");
+    f->accInLds = wavesPerSimd > 0;
+    if (wavesPerSimd < 0) wavesPerSimd = -wavesPerSimd;
     f->wavesPerSimd = wavesPerSimd;
     return GDPT_OK;
 }

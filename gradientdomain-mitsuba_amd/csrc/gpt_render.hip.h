@@ -3,18 +3,25 @@
 #pragma once
 #include "gpt_kernels.hip.h"
 
+#ifndef GDPT_OFFSET_UNROLL
+#define GDPT_OFFSET_UNROLL 1     // 1: the four offset paths are unrolled (state in registers); 0: rolled loops (state in scratch)
+#endif
+#if GDPT_OFFSET_UNROLL
+#define GDPT_OFFSET_LOOP _Pragma("unroll")
+#else
+#define GDPT_OFFSET_LOOP _Pragma("unroll 1")
+#endif
+
 namespace gdpt_tr {
 
 struct Lane {
-    // base path ("main" RayState, gpt.cpp:135-173)
-    d3 throughput, radiance;
-    Float pdf, eta;
+    // base path ("main" RayState, gpt.cpp:135-173); eta is identically 1 for every carried BSDF (getEta() == 1) and is not stored
+    d3 throughput;
+    Float pdf;
     Vertex v;
     d3 rayO, rayD;
-    Float depthT;           // ray parameter of the last base-path hit (Intersection::t)
     int depth;
     Offset off[4];
-    d3 veryDirect;
     Float sx, sy;
     Rng rng;
     unsigned nClosest, nShadow;
@@ -35,13 +42,15 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
-__device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, int px, int py, int sample)
+template <class ACC>
+__device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample)
 {
     const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
     L.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
     L.sx = px + L.rng.next1D();                                                  // gpt.cpp:1261
     L.sy = py + L.rng.next1D();
-    L.throughput = mk(1.0); L.radiance = mk(0.0); L.pdf = 1.0; L.eta = 1.0; L.veryDirect = mk(0.0); L.depth = 1;
+    L.throughput = mk(1.0); L.pdf = 1.0; L.depth = 1;
+    A.zero();
     // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
     Hit hits[5];
 #pragma unroll 1
@@ -51,7 +60,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
         const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);
         camera_ray(S.cam, L.sx + ox, L.sy + oy, o, d, mint, maxt);
         L.nClosest++;
-        trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, hits[r]);
+        hits[r] = trace_closest_call(sv, stack, o, d, ray_mint_closest(o, mint), maxt);
     }
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -64,37 +73,39 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
             Offset &s = L.off[r - 1];
             fill_vertex(sv, h, d, s.v);
             s.rayD = d;
-            s.throughput = mk(1.0); s.radiance = mk(0.0); s.gradient = mk(0.0); s.pdf = 1.0;
+            s.throughput = mk(1.0); s.pdf = 1.0;
             s.alive = h.prim >= 0;                                               // :508-513
             s.status = RAY_NOT_CONNECTED;
         }
     }
     if (L.v.prim < 0) return false;                                              // :482-492 (no environment emitter)
-    L.veryDirect = L.veryDirect + L.throughput * emitted(sv, L.v.prim, -L.rayD);  // :497-499
+    A.add3(ACC_VD, L.throughput * emitted(sv, L.v.prim, -L.rayD));                // :497-499
     if (cfg.strictNormals) {                                                     // :516-531
-        if (dot(L.rayD, sv.shade[L.v.prim].n) * L.v.wi.z >= 0) return false;
+        if (dot(L.rayD, sv.shade[L.v.prim].n) * local_wi(sv, L.v.prim, L.rayD).z >= 0) return false;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Offset &s = L.off[i];
-            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
+            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * local_wi(sv, s.v.prim, s.rayD).z >= 0) s.alive = 0;
         }
     }
     return true;
 }
 
 // One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
-__device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L)
+template <class ACC>
+__device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
     const TriShade &mts = sv.shade[L.v.prim];
     const Frame3 mfr = frame_of(mts);
     const d3 mGeoN = mts.n;
+    const d3 mainWi = toLocal(mfr, -L.rayD);                                     // its.wi
     if (cfg.strictNormals) {                                                     // :541-556
-        if (dot(L.rayD, mGeoN) * L.v.wi.z >= 0) return false;
+        if (dot(L.rayD, mGeoN) * mainWi.z >= 0) return false;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Offset &s = L.off[i];
-            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * s.v.wi.z >= 0) s.alive = 0;
+            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * local_wi(sv, s.v.prim, s.rayD).z >= 0) s.alive = 0;
         }
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
@@ -112,7 +123,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const d3 mainWoL = toLocal(mfr, dRec.d);
         d3 mainBSDFValue;
         Float mainBsdfPdfRaw;
-        bsdf_eval_pdf(mainBSDF, L.v.wi, mainWoL, MEASURE_SOLID_ANGLE, mainBSDFValue, mainBsdfPdfRaw);   // :588
+        bsdf_eval_pdf(mainBSDF, mainWi, mainWoL, MEASURE_SOLID_ANGLE, mainBSDFValue, mainBsdfPdfRaw);   // :588
         const Float mainBsdfPdf = mainEmitterVisible ? mainBsdfPdfRaw : 0;       // :592
         const Float mainDistanceSquared = len2(L.v.p - dRec.p);
         const Float mainOpposingCosine = dot(dRec.n, (L.v.p - dRec.p)) / sqrt(mainDistanceSquared);
@@ -120,7 +131,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const Float mainWeightDenominator = (L.pdf * L.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
         const d3 mainContributionAll = L.throughput * (mainBSDFValue * mainEmitterRadiance);
         if (!cfg.strictNormals || dot(mGeoN, dRec.d) * mainWoL.z > 0) {         // :607
-#pragma unroll
+GDPT_OFFSET_LOOP
             for (int i = 0; i < 4; i++) {
                 Offset &s = L.off[i];
                 d3 shiftedContribution = mk(0.0);
@@ -164,7 +175,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             } else {
                                 d3 f;
                                 Float pdfRaw;
-                                bsdf_eval_pdf(shiftedBSDF, s.v.wi, woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
+                                bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
                                 const Float shiftedBsdfPdf = shiftedEmitterVisible ? pdfRaw : 0;
                                 const Float jacobian = fabs(shiftedOpposingCosine * mainDistanceSquared) / (GD_EPSILON + fabs(mainOpposingCosine * shiftedDistanceSquared)); // :695
                                 const Float den = (jacobian * s.pdf) * (jacobian * s.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
@@ -181,9 +192,9 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                     assigned = true;
                 }
                 const d3 mainContribution = assigned ? mainContributionAll : mk(0.0);
-                L.radiance = L.radiance + mainContribution * weight;              // :723-726
-                s.radiance = s.radiance + shiftedContribution * weight;
-                s.gradient = s.gradient + (shiftedContribution - mainContribution) * weight;
+                A.add3(ACC_T, mainContribution * weight);                          // :723-726
+                A.add3(ACC_NBR + 3 * i, shiftedContribution * weight);
+                A.add3(ACC_GRAD + 3 * i, (shiftedContribution - mainContribution) * weight);
             }
         }
     }
@@ -191,21 +202,22 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     // ================= BSDF sampling and emitter hits, :737-1151 =================
     const Float bsx = L.rng.next1D(), bsy = L.rng.next1D();                      // :456
     BSDFSample bs;
-    bsdf_sample(mainBSDF, L.v.wi, bsx, bsy, bs);
+    bsdf_sample(mainBSDF, mainWi, bsx, bsy, bs);
     if (bs.pdf <= 0.0) return false;                                             // :740
     const d3 mainWo = toWorld(mfr, bs.wo);
     if (cfg.strictNormals && dot(mGeoN, mainWo) * bs.wo.z <= 0) return false;    // :749
-    const d3 prevP = L.v.p, prevWi = L.v.wi;                                      // previousMainIts, :754
+    const d3 prevP = L.v.p, prevWi = mainWi;                                      // previousMainIts, :754
     const bool mainVertexDiffuse = vertex_is_diffuse(mainBSDF, cfg, bs.sampledType);     // :765
     L.rayO = prevP;
     L.rayD = mainWo;                                                              // :768
+    Float hitT;                                                                   // Intersection::t of the new base vertex
     {
         Hit h;
         L.nClosest++;
         trace<false>(sv, stack, L.rayO, L.rayD, ray_mint_closest(L.rayO, GD_EPSILON), GD_INF, h);
         if (h.prim < 0) return false;                                            // :802-804 (no environment)
         fill_vertex(sv, h, L.rayD, L.v);
-        L.depthT = h.t;
+        hitT = h.t;
     }
     const TriShade &nts = sv.shade[L.v.prim];
     const bool mainHitEmitter = nts.emitter >= 0;                                 // :772-777
@@ -215,13 +227,13 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
     L.pdf *= bs.pdf;
     // mainDRec: ref = previous vertex, refN = its shading normal; setQuery (records.inl:170-178): p, n, d, dist
-    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, mainBSDF.twoSided ? mk(0.0) : mfr.n, nts.n, L.depthT) : 0;  // :815
+    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, mainBSDF.twoSided ? mk(0.0) : mfr.n, nts.n, hitT) : 0;  // :815
     const Float mainWeightNumerator = mainPreviousPdf * bs.pdf;                   // :819-820
     const Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
     const int measure = (bs.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
 
-#pragma unroll
+GDPT_OFFSET_LOOP
     for (int i = 0; i < 4; i++) {                                                // :830
         Offset &s = L.off[i];
         d3 shiftedContribution = mk(0.0);
@@ -344,14 +356,14 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
             assigned = true;
         }
         const d3 mc = assigned ? mainContribution : mk(0.0);
-        L.radiance = L.radiance + mc * weight;                                   // :1140-1146
-        s.radiance = s.radiance + shiftedContribution * weight;
-        s.gradient = s.gradient + (shiftedContribution - mc) * weight;
+        A.add3(ACC_T, mc * weight);                                              // :1140-1146
+        A.add3(ACC_NBR + 3 * i, shiftedContribution * weight);
+        A.add3(ACC_GRAD + 3 * i, (shiftedContribution - mc) * weight);
         if (postponedShiftEnd) s.alive = 0;
     }
 
     if (L.depth++ >= cfg.rrDepth) {                                              // :1159-1174
-        const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
+        const Float q = fmin(maxc(L.throughput / L.pdf) * 1.0 * 1.0, (Float)0.95f);   // main.eta == 1
         if (L.rng.next1D() >= q) return false;
         L.pdf *= q;
 #pragma unroll
@@ -362,7 +374,8 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
 
 // Accumulates one finished sample: the 15 puts of gpt.cpp:1314-1352.  Fast path = per-pixel sums (every put covers
 // exactly its expected pixel); otherwise the exact generic path.
-__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, int px, int py)
+template <class ACC>
+__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, const ACC &A, int px, int py)
 {
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
     const bool fast = single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
@@ -372,39 +385,40 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
         Float *r = F.rec + (size_t)(py - (F.y0 - 1)) * F.W + px;
         const size_t st = F.recStride;
         r[0] += 1.0;
-        r[1 * st] += L.radiance.x; r[2 * st] += L.radiance.y; r[3 * st] += L.radiance.z;
-        r[4 * st] += L.veryDirect.x; r[5 * st] += L.veryDirect.y; r[6 * st] += L.veryDirect.z;
+        const d3 T = A.get3(ACC_T), vd = A.get3(ACC_VD);
+        r[1 * st] += T.x; r[2 * st] += T.y; r[3 * st] += T.z;
+        r[4 * st] += vd.x; r[5 * st] += vd.y; r[6 * st] += vd.z;
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const Offset &s = L.off[d];
-            r[(7 + 3 * d) * st] += s.radiance.x; r[(8 + 3 * d) * st] += s.radiance.y; r[(9 + 3 * d) * st] += s.radiance.z;
-            r[(19 + 3 * d) * st] += s.gradient.x; r[(20 + 3 * d) * st] += s.gradient.y; r[(21 + 3 * d) * st] += s.gradient.z;
+            const d3 nb = A.get3(ACC_NBR + 3 * d), g = A.get3(ACC_GRAD + 3 * d);
+            r[(7 + 3 * d) * st] += nb.x; r[(8 + 3 * d) * st] += nb.y; r[(9 + 3 * d) * st] += nb.z;
+            r[(19 + 3 * d) * st] += g.x; r[(20 + 3 * d) * st] += g.y; r[(21 + 3 * d) * st] += g.z;
         }
     } else {
-        const d3 T = L.radiance, vd = L.veryDirect;
+        const d3 T = A.get3(ACC_T), vd = A.get3(ACC_VD);
         const Float sx = L.sx, sy = L.sy;
         spill_put(F, flt, sx, sy, (8 * vd) + (2 * T), 4.0, 0);
-        spill_put(F, flt, sx - 1, sy, 2 * L.off[LEFT].radiance, 1.0, 0);
-        spill_put(F, flt, sx + 1, sy, 2 * L.off[RIGHT].radiance, 1.0, 0);
-        spill_put(F, flt, sx, sy - 1, 2 * L.off[TOP].radiance, 1.0, 0);
-        spill_put(F, flt, sx, sy + 1, 2 * L.off[BOTTOM].radiance, 1.0, 0);
+        spill_put(F, flt, sx - 1, sy, 2 * A.get3(ACC_NBR + 3 * LEFT), 1.0, 0);
+        spill_put(F, flt, sx + 1, sy, 2 * A.get3(ACC_NBR + 3 * RIGHT), 1.0, 0);
+        spill_put(F, flt, sx, sy - 1, 2 * A.get3(ACC_NBR + 3 * TOP), 1.0, 0);
+        spill_put(F, flt, sx, sy + 1, 2 * A.get3(ACC_NBR + 3 * BOTTOM), 1.0, 0);
         spill_put(F, flt, sx, sy, 2 * T, 4.0, 1);
-        spill_put(F, flt, sx - 1, sy, 2 * L.off[LEFT].radiance, 1.0, 1);
-        spill_put(F, flt, sx + 1, sy, 2 * L.off[RIGHT].radiance, 1.0, 1);
-        spill_put(F, flt, sx, sy - 1, 2 * L.off[TOP].radiance, 1.0, 1);
-        spill_put(F, flt, sx, sy + 1, 2 * L.off[BOTTOM].radiance, 1.0, 1);
-        spill_put(F, flt, sx - 1, sy, -(2 * L.off[LEFT].gradient), 1.0, 2);
-        spill_put(F, flt, sx, sy, 2 * L.off[RIGHT].gradient, 1.0, 2);
-        spill_put(F, flt, sx, sy - 1, -(2 * L.off[TOP].gradient), 1.0, 3);
-        spill_put(F, flt, sx, sy, 2 * L.off[BOTTOM].gradient, 1.0, 3);
+        spill_put(F, flt, sx - 1, sy, 2 * A.get3(ACC_NBR + 3 * LEFT), 1.0, 1);
+        spill_put(F, flt, sx + 1, sy, 2 * A.get3(ACC_NBR + 3 * RIGHT), 1.0, 1);
+        spill_put(F, flt, sx, sy - 1, 2 * A.get3(ACC_NBR + 3 * TOP), 1.0, 1);
+        spill_put(F, flt, sx, sy + 1, 2 * A.get3(ACC_NBR + 3 * BOTTOM), 1.0, 1);
+        spill_put(F, flt, sx - 1, sy, -(2 * A.get3(ACC_GRAD + 3 * LEFT)), 1.0, 2);
+        spill_put(F, flt, sx, sy, 2 * A.get3(ACC_GRAD + 3 * RIGHT), 1.0, 2);
+        spill_put(F, flt, sx, sy - 1, -(2 * A.get3(ACC_GRAD + 3 * TOP)), 1.0, 3);
+        spill_put(F, flt, sx, sy, 2 * A.get3(ACC_GRAD + 3 * BOTTOM), 1.0, 3);
         spill_put(F, flt, sx, sy, vd, 1.0, 4);
     }
 }
 
-template <bool LDS_SCENE, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int stackDepth)
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int stackDepth, int sceneBytes)
 {
-    // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)]; sized by the host from
+    // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)][per-sample sums (ACC_LDS only)]; sized by the host from
     // the actual BVH depth and table bytes so that small scenes leave room for more resident blocks per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int *s_stack = reinterpret_cast<int *>(s_dyn);
@@ -441,6 +455,8 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
 
     Lane L;
     L.nClosest = L.nShadow = 0;
+    Acc<ACC_LDS> A;
+    if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_scene + sceneBytes) + threadIdx.x;
     int next = valid ? 0 : cfg.spp;     // next sample to start
     bool active = false;
     unsigned long long pathLen = 0, paths = 0;
@@ -451,14 +467,14 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         if (wantMask == 0 && idleMask == ~0ULL) break;
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < cfg.spp && (__popcll(wantMask) >= REGEN_MIN || idleMask == ~0ULL)) {
-            active = start_path(S, sv, cfg, stack, L, px, py, next);
+            active = start_path(S, sv, cfg, stack, L, A, px, py, next);
             next++;
-            if (!active) { finish_path(F, flt, L, px, py); paths++; pathLen += L.depth; }
+            if (!active) { finish_path(F, flt, L, A, px, py); paths++; pathLen += L.depth; }
         }
         if (active) {
-            if (!bounce(S, sv, cfg, stack, L)) {
+            if (!bounce(S, sv, cfg, stack, L, A)) {
                 active = false;
-                finish_path(F, flt, L, px, py);
+                finish_path(F, flt, L, A, px, py);
                 paths++; pathLen += L.depth;
             }
         }
@@ -572,13 +588,14 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters;
     Lane L;
     L.nClosest = L.nShadow = 0;
-    bool active = start_path(S, sv, cfg, s_stack, L, px, py, sample);
-    while (active) active = bounce(S, sv, cfg, s_stack, L);
+    Acc<false> A;
+    bool active = start_path(S, sv, cfg, s_stack, L, A, px, py, sample);
+    while (active) active = bounce(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
-    *o++ = L.veryDirect.x; *o++ = L.veryDirect.y; *o++ = L.veryDirect.z;
-    *o++ = L.radiance.x; *o++ = L.radiance.y; *o++ = L.radiance.z;
-    for (int i = 0; i < 4; i++) { *o++ = L.off[i].gradient.x; *o++ = L.off[i].gradient.y; *o++ = L.off[i].gradient.z; }
-    for (int i = 0; i < 4; i++) { *o++ = L.off[i].radiance.x; *o++ = L.off[i].radiance.y; *o++ = L.off[i].radiance.z; }
+    for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
+    for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];
+    for (int k = 0; k < 12; k++) *o++ = A.a[ACC_GRAD + k];
+    for (int k = 0; k < 12; k++) *o++ = A.a[ACC_NBR + k];
     *o++ = (Float)L.nClosest; *o++ = (Float)L.nShadow; *o++ = (Float)L.depth;
 }
 

@@ -110,7 +110,8 @@ GDPT_API int  gdpt_film_stats(gdpt_film *f, unsigned long long stats[4]);
 GDPT_API float gdpt_film_render_ms(gdpt_film *f);
 GDPT_API void *gdpt_film_stream(gdpt_film *f);
 /* Tuning knob (no reference counterpart): which build of the render kernel to launch -- the one compiled for 1, 2 (default),
- * 3 or 4 resident waves per SIMD (register budget 512 / n per lane).  Results are identical; only speed differs. */
+ * 3 or 4 resident waves per SIMD (register budget 512 / n per lane); a negative value selects the same build with the
+ * per-sample sums kept in registers instead of LDS.  Results are identical; only speed differs. */
 GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
 
 /* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */

@@ -1,10 +1,9 @@
-import sys, time
+import sys, time, itertools
 sys.path.insert(0, '.')
 import numpy as np
 from gradientdomain_mitsuba_amd import scenes, gpt
 W, H = 1280, 720
-import itertools
-for (variant, spp, md), occ in itertools.product((("diffuse", 32, -1), ("glossy", 16, 12)), (1, 2, 3, 4)):
+for (variant, spp, md), occ in itertools.product((("diffuse", 32, -1), ("glossy", 16, 12)), (2, -2, 3, 4, -4)):
     sc = scenes.cornell_box(W, H, variant)
     S = gpt.Scene(sc); F = gpt.Film(S); F.set_occupancy(occ)
     integ = gpt.GradientPathIntegrator(maxDepth=md)
@@ -12,6 +11,5 @@ for (variant, spp, md), occ in itertools.product((("diffuse", 32, -1), ("glossy"
     integ.renderBlock(S, F, cfg, (0, 0, W, H)); F.sync()
     st = F.stats(); ms = F.render_ms()
     rays = st['raysTraced'] + st['shadowRaysTraced']
-    print("occ%d %s %dx%d spp%d depth%d: %.1f ms, %.1f Mray/s, %.2f Msample/s, rays/sample %.1f, avg path len %.2f" % (
-        occ, variant, W, H, spp, md, ms, rays / ms / 1e3, W * H * spp / ms / 1e3, rays / (W * H * spp), st['pathLengthSum'] / st['paths']))
+    print("occ%+d %s %dx%d spp%d depth%d: %.1f ms, %.1f Mray/s, %.2f Msample/s" % (occ, variant, W, H, spp, md, ms, rays / ms / 1e3, W * H * spp / ms / 1e3))
     F.close(); S.close()
