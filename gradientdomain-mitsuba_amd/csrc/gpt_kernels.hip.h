@@ -457,9 +457,30 @@ __device__ d3 mf_sample(const Mf &d, d3 _wi, Float sx, Float sy, Float &pdf)
 }
 
 // ---- BSDFs --------------------------------------------------------------------------------------------------
-enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, ESmooth = 0x5, EDelta = 0x10 };
+enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, EDeltaTransmission = 0x20, ESmooth = 0x5, EDelta = 0x30 };
 enum { MEASURE_SOLID_ANGLE = 0, MEASURE_DISCRETE = 1 };
-__device__ __forceinline__ int bsdfType(const MaterialD &m) { return m.type == 0 ? EDiffuseReflection : (m.type == 1 ? EDeltaReflection : EGlossyReflection); }
+__device__ __forceinline__ int bsdfType(const MaterialD &m) { return m.type == 0 ? EDiffuseReflection : (m.type == 1 ? EDeltaReflection : (m.type == 3 ? (EDeltaReflection | EDeltaTransmission) : EGlossyReflection)); }
+__device__ __forceinline__ Float bsdf_eta(const MaterialD &m) { return m.type == 3 ? m.eta.x : 1.0; }      // BSDF::getEta (dielectric.cpp:395; 1 elsewhere)
+
+// fresnelDielectricExt, util.cpp:651-681
+__device__ __forceinline__ Float fresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta)
+{
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0; }
+    const Float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0) { cosThetaT_ = 0.0; return 1.0; }
+    const Float cosThetaI = fabs(cosThetaI_), cosThetaT = sqrt(cosThetaTSqr);
+    const Float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    const Float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5 * (Rs * Rs + Rp * Rp);
+}
+// SmoothDielectric::refract, dielectric.cpp:222-225
+__device__ __forceinline__ d3 dielectric_refract(const MaterialD &m, d3 wi, Float cosThetaT)
+{
+    const Float eta = m.eta.x, invEta = 1 / eta;
+    const Float scale = -(cosThetaT < 0 ? invEta : eta);
+    return mk(scale * wi.x, scale * wi.y, cosThetaT);
+}
 
 // BSDF::eval and BSDF::pdf together (every call site of the hot path wants both):
 // diffuse.cpp:110-127, conductor.cpp:223-254, roughconductor.cpp:257-319
@@ -467,6 +488,20 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
 {
     f = mk(0.0); pdf = 0.0;
     if (m.twoSided && !(wi.z > 0)) { wi.z = -wi.z; wo.z = -wo.z; }      // TwoSided::eval/pdf, twosided.cpp:100-124
+    if (m.type == 3) {                                                   // SmoothDielectric::eval/pdf, dielectric.cpp:227-275 (ERadiance)
+        Float cosThetaT;
+        const Float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta.x);
+        if (measure != MEASURE_DISCRETE) return;
+        if (wi.z * wo.z >= 0) {
+            if (fabs(dot(mk(-wi.x, -wi.y, wi.z), wo) - 1) > GD_DELTA_EPSILON) return;
+            f = m.reflectance * F; pdf = F;
+        } else {
+            if (fabs(dot(dielectric_refract(m, wi, cosThetaT), wo) - 1) > GD_DELTA_EPSILON) return;
+            const Float factor = cosThetaT < 0 ? 1 / m.eta.x : m.eta.x;
+            f = m.k * factor * factor * (1 - F); pdf = 1 - F;
+        }
+        return;
+    }
     if (wi.z <= 0 || wo.z <= 0) return;
     if (m.type == 0) {
         if (measure != MEASURE_SOLID_ANGLE) return;
@@ -492,11 +527,29 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
     }
 }
 
-struct BSDFSample { d3 wo, weight; Float pdf; int sampledType; };
+struct BSDFSample { d3 wo, weight; Float pdf, eta; int sampledType; };
 // the pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
 __device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
 {
-    r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.sampledType = 0;   // gpt.cpp:450-454: pdf starts at 0
+    r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.eta = 1.0; r.sampledType = 0;   // gpt.cpp:450-454: pdf starts at 0
+    if (m.type == 3) {                                                    // SmoothDielectric::sample, dielectric.cpp:277-305
+        Float cosThetaT;
+        const Float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta.x);
+        if (sx <= F) {
+            r.sampledType = EDeltaReflection;
+            r.wo = mk(-wi.x, -wi.y, wi.z);
+            r.pdf = F;
+            r.weight = m.reflectance;
+        } else {
+            r.sampledType = EDeltaTransmission;
+            r.wo = dielectric_refract(m, wi, cosThetaT);
+            r.eta = cosThetaT < 0 ? m.eta.x : 1 / m.eta.x;
+            r.pdf = 1 - F;
+            const Float factor = cosThetaT < 0 ? 1 / m.eta.x : m.eta.x;
+            r.weight = m.k * (factor * factor);
+        }
+        return;
+    }
     if (m.type == 0) {
         if (wi.z <= 0) return;
         r.wo = squareToCosineHemisphere(sx, sy);
@@ -540,7 +593,7 @@ __device__ __forceinline__ void bsdf_sample(const MaterialD &m, d3 wi, Float sx,
 // getVertexType (gpt.cpp:176-231) for single-component BSDFs; getRoughness: diffuse.cpp:167, conductor.cpp:275, roughconductor.cpp:437
 __device__ __forceinline__ bool vertex_is_diffuse(const MaterialD &m, const ConfigD &cfg, int bsdfTypeMask)
 {
-    const Float r = m.type == 0 ? GD_INF : (m.type == 1 ? 0.0 : 0.5 * (m.alphaU + m.alphaV));
+    const Float r = m.type == 0 ? GD_INF : ((m.type == 1 || m.type == 3) ? 0.0 : 0.5 * (m.alphaU + m.alphaV));
     Float lowest = GD_INF;
     bool found_smooth = false, found_dirac = false, skip = false;
     if (r == 0) { found_dirac = true; if (!(bsdfTypeMask & EDelta)) skip = true; }
@@ -620,11 +673,33 @@ __device__ __forceinline__ void camera_ray(const CameraD &c, Float px, Float py,
 }
 
 // ---- shifts -------------------------------------------------------------------------------------------------
-// halfVectorShift, gpt.cpp:242-305, reflection branch (no carried BSDF transmits); returns false for a would-be refraction
-__device__ __forceinline__ bool half_vector_shift(d3 mainWi, d3 mainWo, d3 shiftedWi, Float &jacobian, d3 &wo)
+// refract(wi, n, eta), util.cpp:774-792: the zero vector on total internal reflection
+__device__ __forceinline__ d3 refract_dir(d3 wi, d3 n, Float eta)
 {
-    if (mainWi.z * mainWo.z < 0) return false;       // refraction with eta == 1 on both sides: gpt.cpp:249-253
-    const d3 h = normalize(mainWi + mainWo);
+    if (eta == 1) return -wi;
+    const Float cosThetaI = dot(wi, n);
+    if (cosThetaI > 0) eta = 1 / eta;
+    const Float cosThetaTSqr = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
+    if (cosThetaTSqr <= 0.0) return mk(0.0);
+    return n * (cosThetaI * eta - signum(cosThetaI) * sqrt(cosThetaTSqr)) - wi * eta;
+}
+
+// halfVectorShift, gpt.cpp:242-305
+__device__ __forceinline__ bool half_vector_shift(d3 mainWi, d3 mainWo, d3 shiftedWi, Float mainEta, Float shiftedEta, Float &jacobian, d3 &wo)
+{
+    if (mainWi.z * mainWo.z < 0) {                    // refraction, :245-290
+        if (mainEta == 1 || shiftedEta == 1) return false;
+        const d3 hMain = mainWi.z < 0 ? -(mainWi * mainEta + mainWo) : -(mainWi + mainWo * mainEta);
+        const d3 h = normalize(hMain);
+        wo = refract_dir(shiftedWi, h, shiftedEta);
+        if (wo.x == 0 && wo.y == 0 && wo.z == 0) return false;
+        const d3 hShifted = shiftedWi.z < 0 ? -(shiftedWi * shiftedEta + wo) : -(shiftedWi + wo * shiftedEta);
+        const Float hLengthSquared = len2(hShifted) / (GD_D_EPSILON + len2(hMain));
+        const Float WoDotH = fabs(dot(mainWo, h)) / (GD_D_EPSILON + fabs(dot(wo, h)));
+        jacobian = hLengthSquared * WoDotH;
+        return true;
+    }
+    const d3 h = normalize(mainWi + mainWo);          // reflection, :291-302
     wo = 2 * dot(shiftedWi, h) * h - shiftedWi;       // reflect(), util.cpp:763
     jacobian = fabs(dot(wo, h) / dot(mainWo, h));
     return true;

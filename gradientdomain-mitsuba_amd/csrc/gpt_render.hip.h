@@ -15,9 +15,9 @@
 namespace gdpt_tr {
 
 struct Lane {
-    // base path ("main" RayState, gpt.cpp:135-173); eta is identically 1 for every carried BSDF (getEta() == 1) and is not stored
+    // base path ("main" RayState, gpt.cpp:135-173)
     d3 throughput;
-    Float pdf;
+    Float pdf, eta;
     Vertex v;
     d3 rayO, rayD;
     int depth;
@@ -49,7 +49,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     L.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
     L.sx = px + L.rng.next1D();                                                  // gpt.cpp:1261
     L.sy = py + L.rng.next1D();
-    L.throughput = mk(1.0); L.pdf = 1.0; L.depth = 1;
+    L.throughput = mk(1.0); L.pdf = 1.0; L.eta = 1.0; L.depth = 1;
     A.zero();
     // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
     Hit hits[5];
@@ -114,7 +114,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     // ================= direct illumination sampling, :565-730 =================
     if (bsdfType(mainBSDF) & ESmooth) {
         DRec dRec;
-        dRec.ref = L.v.p; dRec.refN = mainBSDF.twoSided ? mk(0.0) : mfr.n;       // records.inl:160-164 (no refN behind a back-sided BSDF)
+        dRec.ref = L.v.p; dRec.refN = (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n;       // records.inl:160-164 (no refN behind a back-sided BSDF)
         const Float lsx = L.rng.next1D(), lsy = L.rng.next1D();                  // :572
         d3 value = sample_emitter_direct(S, sv, dRec, lsx, lsy);
         const bool mainEmitterVisible = !cast_shadow(sv, stack, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
@@ -160,7 +160,7 @@ GDPT_OFFSET_LOOP
                         if (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth)) {
                             const Frame3 sfr = frame_of(sts);
                             DRec sRec;
-                            sRec.ref = s.v.p; sRec.refN = shiftedBSDF.twoSided ? mk(0.0) : sfr.n;
+                            sRec.ref = s.v.p; sRec.refN = (shiftedBSDF.twoSided || shiftedBSDF.type == 3) ? mk(0.0) : sfr.n;
                             d3 sv_ = sample_emitter_direct(S, sv, sRec, lsx, lsy);
                             const bool shiftedEmitterVisible = !cast_shadow(sv, stack, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
                             if (!shiftedEmitterVisible) sv_ = mk(0.0);
@@ -226,8 +226,9 @@ GDPT_OFFSET_LOOP
     const Float mainBsdfPdf = bs.pdf, mainPreviousPdf = L.pdf;
     L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
     L.pdf *= bs.pdf;
+    L.eta *= bs.eta;
     // mainDRec: ref = previous vertex, refN = its shading normal; setQuery (records.inl:170-178): p, n, d, dist
-    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, mainBSDF.twoSided ? mk(0.0) : mfr.n, nts.n, hitT) : 0;  // :815
+    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n, nts.n, hitT) : 0;  // :815
     const Float mainWeightNumerator = mainPreviousPdf * bs.pdf;                   // :819-820
     const Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
@@ -310,7 +311,7 @@ GDPT_OFFSET_LOOP
                     d3 tsOut = mk(0.0);
                     if (ok) {
                         Float jacobian;
-                        ok = half_vector_shift(prevWi, bs.wo, tsIn, jacobian, tsOut);
+                        ok = half_vector_shift(prevWi, bs.wo, tsIn, bsdf_eta(mainBSDF), bsdf_eta(shiftedBSDF), jacobian, tsOut);   // :1006
                         if (bs.sampledType & EDelta) jacobian = 1;               // :1008-1011
                         if (ok) { s.throughput = s.throughput * jacobian; s.pdf *= jacobian; }
                     }
@@ -363,7 +364,7 @@ GDPT_OFFSET_LOOP
     }
 
     if (L.depth++ >= cfg.rrDepth) {                                              // :1159-1174
-        const Float q = fmin(maxc(L.throughput / L.pdf) * 1.0 * 1.0, (Float)0.95f);   // main.eta == 1
+        const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
         if (L.rng.next1D() >= q) return false;
         L.pdf *= q;
 #pragma unroll

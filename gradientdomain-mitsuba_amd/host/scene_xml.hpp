@@ -3,7 +3,7 @@
 //
 // Carried:  <scene>, <default>, $parameter substitution (+ -D overrides), <integrator type="gpt">, <sensor type="perspective">
 // (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
-// fileFormat="pfm") with <rfilter type="box">, <bsdf type="diffuse|conductor|roughconductor"> (top-level with id, or nested in a
+// fileFormat="openexr"|"pfm") with <rfilter type="box">, <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
 // shape), <shape type="obj|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
 // <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
 // Anything else raises std::runtime_error naming the tag or plugin, like the reference's "unsupported" errors.
@@ -330,11 +330,13 @@ private:
                 if (c->tag == "bsdf") { if (inner) logError("twosided: a second nested BRDF (different front/back models) is not carried"); inner = c.get(); }
             if (!inner) logError("A nested one-sided material is required!");                        // twosided.cpp:85
             if (subst(inner->get("type")) == "twosided") logError("twosided inside twosided is not carried");
+            if (subst(inner->get("type")) == "dielectric") logError("Only materials without a transmission component can be nested!");   // twosided.cpp:96-98
             const int idx = bsdf(*inner, sd);
             sd.materials[idx].twoSided = 1;
             return idx;
         }
         const std::string type = subst(n.get("type"));
+        if (type == "dielectric") return dielectric(n, sd);
         gdpt_material m;
         std::memset(&m, 0, sizeof m);
         m.sampleVisible = 1;
@@ -377,8 +379,48 @@ private:
         if (type == "diffuse") m.type = GDPT_MAT_DIFFUSE;
         else if (type == "conductor") m.type = GDPT_MAT_CONDUCTOR;
         else if (type == "roughconductor") m.type = GDPT_MAT_ROUGHCONDUCTOR;
-        else logError(format("bsdf \"%s\" is not carried: diffuse, conductor, roughconductor, twosided (dielectric is the next candidate)", type.c_str()));
+        else logError(format("bsdf \"%s\" is not carried: diffuse, conductor, roughconductor, dielectric, twosided", type.c_str()));
         if (m.type != GDPT_MAT_DIFFUSE && !(haveEta && haveK)) logError(format("bsdf \"%s\": explicit eta and k are required (the default `material=Cu` needs data/ior)", type.c_str()));
+        sd.materials.push_back(m);
+        return (int)sd.materials.size() - 1;
+    }
+
+    /// lookupIOR (src/bsdfs/ior.h:40-80): a number, or one of the named media (float literals there, hence the casts)
+    static double lookupIOR(const std::string &v)
+    {
+        static const struct { const char *name; float value; } table[] = {
+            {"vacuum", 1.0f}, {"helium", 1.000036f}, {"hydrogen", 1.000132f}, {"air", 1.000277f}, {"carbon dioxide", 1.00045f}, {"water", 1.3330f},
+            {"acetone", 1.36f}, {"ethanol", 1.361f}, {"carbon tetrachloride", 1.461f}, {"glycerol", 1.4729f}, {"benzene", 1.501f},
+            {"silicone oil", 1.52045f}, {"bromine", 1.661f}, {"water ice", 1.31f}, {"fused quartz", 1.458f}, {"pyrex", 1.470f},
+            {"acrylic glass", 1.49f}, {"polypropylene", 1.49f}, {"bk7", 1.5046f}, {"sodium chloride", 1.544f}, {"amber", 1.55f}, {"pet", 1.5750f},
+            {"diamond", 2.419f}};
+        std::string lower = v;
+        for (char &c : lower) c = (char)std::tolower((unsigned char)c);
+        for (const auto &e : table) if (lower == e.name) return (double)e.value;
+        logError(format("Unable to find an IOR value for \"%s\"!", v.c_str()));
+    }
+
+    int dielectric(const xml::Node &n, SceneData &sd)
+    { // src/bsdfs/dielectric.cpp:141-160: intIOR (default bk7), extIOR (default air), specularReflectance, specularTransmittance
+        gdpt_material m;
+        std::memset(&m, 0, sizeof m);
+        m.type = GDPT_MAT_DIELECTRIC;
+        m.sampleVisible = 1;
+        m.alphaU = m.alphaV = 0.1;
+        double intIOR = lookupIOR("bk7"), extIOR = lookupIOR("air");
+        for (int c = 0; c < 3; ++c) { m.reflectance[c] = 1.0; m.k[c] = 1.0; }
+        for (auto &c : n.children) {
+            const std::string nm = c->get("name", "");
+            if ((c->tag == "float" || c->tag == "string") && (nm == "intIOR" || nm == "extIOR")) {
+                const std::string v = subst(c->get("value"));
+                const double ior = c->tag == "float" ? std::stod(v) : lookupIOR(v);
+                (nm == "intIOR" ? intIOR : extIOR) = ior;
+            } else if ((c->tag == "rgb" || c->tag == "spectrum") && nm == "specularReflectance") rgb3(*c, m.reflectance);
+            else if ((c->tag == "rgb" || c->tag == "spectrum") && nm == "specularTransmittance") rgb3(*c, m.k);
+            else logError(format("bsdf \"dielectric\": <%s name=\"%s\"> is not carried", c->tag.c_str(), nm.c_str()));
+        }
+        if (intIOR < 0 || extIOR < 0) logError("The interior and exterior indices of refraction must be positive!");     // dielectric.cpp:152-154
+        m.eta[0] = m.eta[1] = m.eta[2] = intIOR / extIOR;
         sd.materials.push_back(m);
         return (int)sd.materials.size() - 1;
     }

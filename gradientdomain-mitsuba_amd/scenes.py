@@ -11,7 +11,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-MAT_DIFFUSE, MAT_CONDUCTOR, MAT_ROUGHCONDUCTOR = 0, 1, 2
+MAT_DIFFUSE, MAT_CONDUCTOR, MAT_ROUGHCONDUCTOR, MAT_DIELECTRIC = 0, 1, 2, 3
 DISTR_BECKMANN, DISTR_GGX = 0, 1
 
 
@@ -26,6 +26,12 @@ def conductor(eta, k, specular=(1.0, 1.0, 1.0)):
 def roughconductor(alpha, eta, k, specular=(1.0, 1.0, 1.0), distribution=DISTR_BECKMANN, alphaV=None, sampleVisible=True):
     return dict(type=MAT_ROUGHCONDUCTOR, reflectance=tuple(specular), eta=tuple(eta), k=tuple(k), alphaU=float(alpha),
                 alphaV=float(alpha if alphaV is None else alphaV), distribution=distribution, sampleVisible=int(sampleVisible))
+
+
+def dielectric(int_ior=float(np.float32(1.5046)), ext_ior=float(np.float32(1.000277)), specular_reflectance=(1.0, 1.0, 1.0), specular_transmittance=(1.0, 1.0, 1.0)):
+    """`dielectric` (reference src/bsdfs/dielectric.cpp); defaults = bk7 glass in air (src/bsdfs/ior.h, float literals)."""
+    eta = int_ior / ext_ior
+    return dict(type=MAT_DIELECTRIC, reflectance=tuple(specular_reflectance), eta=(eta, eta, eta), k=tuple(specular_transmittance))
 
 
 def twosided(inner):
@@ -127,6 +133,9 @@ def cornell_box(width=512, height=512, variant="diffuse"):
         floor_m = b.material(roughconductor(0.0008, **CU))
         back_m = b.material(roughconductor(0.2, **AL, alphaV=0.05))
         tall_m = short_m = white
+    elif variant == "glass":          # the tall block is solid bk7 glass, the short one an aluminium mirror: refraction branch of the half-vector shift
+        tall_m = b.material(dielectric())
+        short_m = b.material(conductor(**AL))
     elif variant == "twosided":       # two-sided walls and a free-standing two-sided GGX panel lit and seen from both faces
         white = b.material(twosided(diffuse((0.725, 0.71, 0.68))))
         floor_m = back_m = tall_m = short_m = white

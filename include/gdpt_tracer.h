@@ -28,6 +28,7 @@ extern "C" {
 #define GDPT_MAT_DIFFUSE        0   /* src/bsdfs/diffuse.cpp        */
 #define GDPT_MAT_CONDUCTOR      1   /* src/bsdfs/conductor.cpp      */
 #define GDPT_MAT_ROUGHCONDUCTOR 2   /* src/bsdfs/roughconductor.cpp */
+#define GDPT_MAT_DIELECTRIC     3   /* src/bsdfs/dielectric.cpp: eta[0] = intIOR/extIOR, reflectance = specularReflectance, k = specularTransmittance */
 #define GDPT_DISTR_BECKMANN     0   /* src/bsdfs/microfacet.h EBeckmann */
 #define GDPT_DISTR_GGX          1   /* EGGX */
 

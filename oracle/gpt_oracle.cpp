@@ -118,10 +118,10 @@ inline void coordinateSystem(V3 a, V3 &b, V3 &c)
 }
 
 // ---- materials --------------------------------------------------------------------------------------
-enum { MAT_DIFFUSE = 0, MAT_CONDUCTOR = 1, MAT_ROUGHCONDUCTOR = 2 };
+enum { MAT_DIFFUSE = 0, MAT_CONDUCTOR = 1, MAT_ROUGHCONDUCTOR = 2, MAT_DIELECTRIC = 3 };
 enum { DISTR_BECKMANN = 0, DISTR_GGX = 1 };
 // BSDF::EBSDFType bits used here (include/mitsuba/render/bsdf.h): diffuse/glossy reflection are smooth, delta is not
-enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, ESmooth = 0x1 | 0x4, EDelta = 0x10 };
+enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, EDeltaTransmission = 0x20, ESmooth = 0x1 | 0x4, EDelta = 0x10 | 0x20 };
 enum { MEASURE_SOLID_ANGLE = 0, MEASURE_DISCRETE = 1 };
 
 } // namespace
@@ -134,7 +134,7 @@ typedef struct gpo_material {
     int sampleVisible;   // roughconductor.cpp m_sampleVisible (default true)
     int twoSided;        // wrapped in src/bsdfs/twosided.cpp (the same BRDF on both sides)
     double reflectance[3]; // diffuse: reflectance; conductors: specularReflectance
-    double eta[3], k[3];
+    double eta[3], k[3];   // dielectric: eta[0] = intIOR/extIOR, reflectance = specularReflectance, k = specularTransmittance
     double alphaU, alphaV;
 } gpo_material;
 
@@ -660,13 +660,46 @@ struct Microfacet {
 struct BSDFSample { V3 wo; Float eta; int sampledType; V3 weight; Float pdf; };
 
 inline V3 rgb(const double *a) { return V3(a[0], a[1], a[2]); }
-inline int bsdfType(const gpo_material &m) { return m.type == MAT_DIFFUSE ? EDiffuseReflection : (m.type == MAT_CONDUCTOR ? EDeltaReflection : EGlossyReflection); }
+inline int bsdfType(const gpo_material &m) { return m.type == MAT_DIFFUSE ? EDiffuseReflection : (m.type == MAT_CONDUCTOR ? EDeltaReflection : (m.type == MAT_DIELECTRIC ? (EDeltaReflection | EDeltaTransmission) : EGlossyReflection)); }
+inline Float getEta(const gpo_material &m) { return m.type == MAT_DIELECTRIC ? m.eta[0] : 1.0; }   // BSDF::getEta: dielectric.cpp:395, 1 elsewhere
 inline Microfacet distr(const gpo_material &m) { return Microfacet(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0); }
 // BSDF::getRoughness: diffuse.cpp:167-169 (+inf), conductor.cpp:275-277 (0), roughconductor.cpp:437-440
-inline Float getRoughness(const gpo_material &m) { return m.type == MAT_DIFFUSE ? INF : (m.type == MAT_CONDUCTOR ? 0.0 : 0.5 * (m.alphaU + m.alphaV)); }
+inline Float getRoughness(const gpo_material &m) { return m.type == MAT_DIFFUSE ? INF : ((m.type == MAT_CONDUCTOR || m.type == MAT_DIELECTRIC) ? 0.0 : 0.5 * (m.alphaU + m.alphaV)); }   // dielectric.cpp:399: both components 0
+
+// fresnelDielectricExt, util.cpp:651-681
+Float fresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta)
+{
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0; }
+    Float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0) { cosThetaT_ = 0.0; return 1.0; }
+    Float cosThetaI = std::abs(cosThetaI_), cosThetaT = std::sqrt(cosThetaTSqr);
+    Float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    Float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5 * (Rs * Rs + Rp * Rp);
+}
+// SmoothDielectric::refract, dielectric.cpp:222-225
+inline V3 dielectricRefract(const gpo_material &m, V3 wi, Float cosThetaT)
+{
+    const Float eta = m.eta[0], invEta = 1 / eta;
+    Float scale = -(cosThetaT < 0 ? invEta : eta);
+    return V3(scale * wi.x, scale * wi.y, cosThetaT);
+}
 
 V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure)
 {
+    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:227-252 (mode == ERadiance)
+        Float cosThetaT;
+        Float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, m.eta[0]);
+        if (measure != MEASURE_DISCRETE) return V3(0.0);
+        if (cosTheta(wi) * cosTheta(wo) >= 0) {
+            if (std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return V3(0.0);
+            return rgb(m.reflectance) * F;
+        }
+        if (std::abs(dot(dielectricRefract(m, wi, cosThetaT), wo) - 1) > DeltaEpsilon) return V3(0.0);
+        Float factor = cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0];
+        return rgb(m.k) * factor * factor * (1 - F);
+    }
     switch (m.type) {
     case MAT_DIFFUSE: // diffuse.cpp:110-118
         if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0);
@@ -690,6 +723,17 @@ V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure)
 
 Float bsdfPdfOne(const gpo_material &m, V3 wi, V3 wo, int measure)
 {
+    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:254-275
+        Float cosThetaT;
+        Float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, m.eta[0]);
+        if (measure != MEASURE_DISCRETE) return 0.0;
+        if (cosTheta(wi) * cosTheta(wo) >= 0) {
+            if (std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return 0.0;
+            return F;
+        }
+        if (std::abs(dot(dielectricRefract(m, wi, cosThetaT), wo) - 1) > DeltaEpsilon) return 0.0;
+        return 1 - F;
+    }
     switch (m.type) {
     case MAT_DIFFUSE: // diffuse.cpp:120-127
         if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0;
@@ -712,6 +756,25 @@ BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy)
 {
     BSDFSample r;
     r.wo = V3(0.0); r.eta = 1.0; r.sampledType = 0; r.weight = V3(0.0); r.pdf = 0.0; // gpt.cpp:450-454: result.pdf starts at 0
+    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:277-305 (both components requested)
+        Float cosThetaT;
+        Float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, m.eta[0]);
+        if (sx <= F) {
+            r.sampledType = EDeltaReflection;
+            r.wo = V3(-wi.x, -wi.y, wi.z);
+            r.eta = 1.0;
+            r.pdf = F;
+            r.weight = rgb(m.reflectance);
+        } else {
+            r.sampledType = EDeltaTransmission;
+            r.wo = dielectricRefract(m, wi, cosThetaT);
+            r.eta = cosThetaT < 0 ? m.eta[0] : 1 / m.eta[0];
+            r.pdf = 1 - F;
+            Float factor = cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0];
+            r.weight = rgb(m.k) * (factor * factor);
+        }
+        return r;
+    }
     switch (m.type) {
     case MAT_DIFFUSE:
         if (cosTheta(wi) <= 0) return r;
@@ -771,7 +834,7 @@ BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy)
     return r;
 }
 // DirectSamplingRecord(const Intersection&), records.inl:160-164: refN stays 0 when the BSDF has a back side (twosided)
-inline V3 refNormal(const gpo_material &m, const Intersection &its) { return m.twoSided ? V3(0.0) : its.sh.n; }
+inline V3 refNormal(const gpo_material &m, const Intersection &its) { return (m.twoSided || m.type == MAT_DIELECTRIC) ? V3(0.0) : its.sh.n; }
 
 // ---- emitters -----------------------------------------------------------------------------------------
 struct DirectSamplingRecord { V3 ref, refN, p, n, d; Float dist, pdf; int measure; int object; };
@@ -1164,7 +1227,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             bool bothDelta = (mainBsdfResult.sampledType & EDelta) && (bsdfType(shiftedBSDF) & EDelta);   // :996-1001
                             bool bothSmooth = (mainBsdfResult.sampledType & ESmooth) && (bsdfType(shiftedBSDF) & ESmooth);
                             if (!(bothDelta || bothSmooth)) { shifted.alive = false; goto half_vector_shift_failed; }
-                            HalfVectorShiftResult shiftResult = halfVectorShift(mainBsdfWi, mainBsdfResult.wo, shifted.its.sh.toLocal(-shifted.ray.d), 1.0, 1.0); // getEta() == 1 for all carried BSDFs
+                            HalfVectorShiftResult shiftResult = halfVectorShift(mainBsdfWi, mainBsdfResult.wo, shifted.its.sh.toLocal(-shifted.ray.d), getEta(mainBSDF), getEta(shiftedBSDF)); // :1006
                             if (mainBsdfResult.sampledType & EDelta) shiftResult.jacobian = 1;                             // :1008-1011
                             if (shiftResult.success) {
                                 shifted.throughput = shifted.throughput * shiftResult.jacobian;

@@ -50,7 +50,7 @@ def test_bvh_closest_hit_matches_brute_force(G, builder):
     assert (prim >= 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("variant,md", [("diffuse", -1), ("diffuse", 3), ("glossy", 10), ("nearspecular", 10), ("twosided", 9)])
+@pytest.mark.parametrize("variant,md", [("diffuse", -1), ("diffuse", 3), ("glossy", 10), ("nearspecular", 10), ("twosided", 9), ("glass", 12)])
 def test_samples_match_oracle(G, variant, md):
     sc = scenes.cornell_box(40, 32, variant)
     S, O = G.Scene(sc), go.Scene(sc)
@@ -66,7 +66,8 @@ def test_samples_match_oracle(G, variant, md):
 
 @pytest.mark.parametrize("variant,W,H,spp,md,strict", [("diffuse", 48, 40, 6, -1, False), ("glossy", 40, 40, 6, 9, False),
                                                         ("nearspecular", 32, 32, 5, 8, True), ("diffuse", 35, 21, 3, 2, False),
-                                                        ("twosided", 40, 36, 6, 9, False), ("twosided", 24, 24, 4, 6, True)])
+                                                        ("twosided", 40, 36, 6, 9, False), ("twosided", 24, 24, 4, 6, True),
+                                                        ("glass", 40, 40, 8, 12, False), ("glass", 24, 24, 4, -1, True)])
 def test_film_matches_oracle(G, variant, W, H, spp, md, strict):
     sc = scenes.cornell_box(W, H, variant)
     S = G.Scene(sc); F = G.Film(S)

@@ -100,6 +100,33 @@ def test_bsdf_sample_weight_pdf_eval_are_consistent(mat):
     assert 0.85 < integral < 1.05
 
 
+def test_dielectric_closed_forms():
+    m = scenes.dielectric(1.5, 1.0)
+    wi = unit([0.3, 0.2, 0.8])
+    # Fresnel reflectance at normal incidence ((n-1)/(n+1))^2 shows up as the reflection pdf
+    f, p = go.bsdf_eval_pdf(m, [0, 0, 1.0], [0, 0, 1.0], measure=1)
+    assert np.isclose(p, 0.04, rtol=1e-12) and np.allclose(f, 0.04, rtol=1e-12)
+    # sampling: u <= F reflects, otherwise refracts by Snell with the radiance scaling 1/eta^2 entering the medium (dielectric.cpp:292-297)
+    wo, w, pdf, typ = go.bsdf_sample(m, wi, 0.999, 0.5)
+    assert typ == 0x20 and wo[2] < 0 and np.isclose(np.hypot(wo[0], wo[1]) * 1.5, np.hypot(wi[0], wi[1]), rtol=1e-12)
+    assert np.allclose(w, 1 / 1.5 ** 2, rtol=1e-12)
+    f, p = go.bsdf_eval_pdf(m, wi, wo, measure=1)
+    assert np.isclose(p, pdf, rtol=1e-12) and np.allclose(f, w * pdf, rtol=1e-12)      # eval == weight * pdf
+    wo_r, w_r, pdf_r, typ_r = go.bsdf_sample(m, wi, 0.0, 0.5)
+    assert typ_r == 0x10 and np.allclose(wo_r, [-wi[0], -wi[1], wi[2]]) and np.isclose(pdf + pdf_r, 1.0, rtol=1e-12)
+    assert go.bsdf_eval_pdf(m, wi, wo, measure=0)[1] == 0                              # delta lobes have no solid-angle density
+    # total internal reflection from inside
+    inside = unit([0.9, 0.0, -0.3])
+    wo_t, w_t, pdf_t, typ_t = go.bsdf_sample(m, inside, 0.7, 0.5)
+    assert typ_t == 0x10 and pdf_t == 1.0
+    # the half-vector shift across the interface reproduces Snell for the shifted direction
+    ok, J, wo2 = go.half_vector_shift(wi, wo, unit([0.25, 0.25, 0.85]), 1.5, 1.5)
+    wi2 = unit([0.25, 0.25, 0.85])
+    assert ok and wo2[2] < 0 and J > 0
+    ok0, J0, wo0 = go.half_vector_shift(wi, wo, wi, 1.5, 1.5)
+    assert ok0 and np.allclose(wo0, wo, atol=1e-12) and np.isclose(J0, 1.0, rtol=1e-9)
+
+
 def test_twosided_wraps_the_one_sided_model():
     # twosided.cpp:100-168: the nested BRDF evaluated with both z components mirrored when wi arrives from below
     inner = scenes.roughconductor(0.2, **scenes.CU)

@@ -61,13 +61,17 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     assert np.allclose(json.loads(run(cli, "--parse-only", s).stdout)["firstVertex"], [1, -1, 0], atol=1e-12)
     s = scene_with(tmp_path, '<shape type="cube"><bsdf type="roughconductor"><float name="alpha" value="0.2"/><rgb name="eta" value="1,1,1"/><rgb name="k" value="2,2,2"/><string name="distribution" value="ggx"/></bsdf></shape>' + LIGHT)
     assert json.loads(run(cli, "--parse-only", s).stdout)["triangles"] == 14
+    s = scene_with(tmp_path, '<shape type="cube"><bsdf type="dielectric"><string name="intIOR" value="water"/><float name="extIOR" value="1.0"/></bsdf></shape>' + LIGHT)
+    assert json.loads(run(cli, "--parse-only", s).stdout)["materials"] == 2
     s = scene_with(tmp_path, '<bsdf type="twosided" id="w"><bsdf type="diffuse"/></bsdf><shape type="rectangle"><ref id="w"/></shape>' + LIGHT)
     assert json.loads(run(cli, "--parse-only", s).stdout)["materials"] == 2
 
 
 @pytest.mark.parametrize("body,film,needle", [
     ('<shape type="sphere"/>' + LIGHT, None, "shape \"sphere\" is not carried"),
-    ('<shape type="rectangle"><bsdf type="dielectric"/></shape>' + LIGHT, None, "not carried"),
+    ('<shape type="rectangle"><bsdf type="plastic"/></shape>' + LIGHT, None, "not carried"),
+    ('<shape type="rectangle"><bsdf type="dielectric"><string name="intIOR" value="unobtainium"/></bsdf></shape>' + LIGHT, None, "Unable to find an IOR"),
+    ('<shape type="rectangle"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>' + LIGHT, None, "transmission component"),
     ('<shape type="rectangle"><bsdf type="twosided"/></shape>' + LIGHT, None, "nested one-sided material is required"),
     ('<shape type="rectangle"><bsdf type="conductor"/></shape>' + LIGHT, None, "explicit eta and k"),
     ('<shape type="rectangle"/>', None, "no area emitter"),
