@@ -6,7 +6,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "lib", "libgdpt_hip.so")
 SOURCES = [os.path.join(PKG, "csrc", f) for f in ("poisson_capi.hip", "gpt_capi.hip")]
-DEPS = SOURCES + [os.path.join(PKG, "csrc", f) for f in ("poisson_kernels.hip.h", "gpt_kernels.hip.h", "gpt_render.hip.h")] + \
+DEPS = SOURCES + [os.path.join(PKG, "csrc", f) for f in ("poisson_kernels.hip.h", "poisson_persistent.hip.h", "gpt_kernels.hip.h", "gpt_render.hip.h")] + \
     [os.path.join(ROOT, "include", f) for f in ("gdpt_poisson.h", "gdpt_tracer.h")]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

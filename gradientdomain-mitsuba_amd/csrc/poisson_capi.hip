@@ -5,6 +5,7 @@
 // image arithmetic happens in poisson_kernels.hip.h on the device.  There is no CPU fallback.
 #include "../../include/gdpt_poisson.h"
 #include "poisson_kernels.hip.h"
+#include "poisson_persistent.hip.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -135,7 +136,11 @@ struct gdpt_poisson_solver {
     float alpha_eff = 0.0f;
     const float *dev_direct = nullptr; // device pointer of `direct` (borrowed or staged), or null
 
-    int fusion = 1;
+    int fusion = 1;             // 0: reference op sequence; 1: x_p fused into the stencil; 2: persistent cooperative CG (when the geometry allows)
+    float *halo = nullptr;      // persistent CG: per-tile boundary records
+    unsigned *bar = nullptr;    // persistent CG: [0] arrival counter, [1] error flag
+    int ptTilesX = 0, ptTilesY = 0, ptTH = 0;
+    bool usedPersistent = false;
     hipGraphExec_t g0 = nullptr, gK = nullptr;
     int graph_fusion = -1;
     float graph_alpha = -1.0f;
@@ -176,6 +181,9 @@ struct gdpt_poisson_solver {
         for (float4 **q : pb) { if (*q) hipFree(*q); *q = nullptr; }
         if (counter) hipFree(counter);
         counter = nullptr;
+        if (halo) hipFree(halo);
+        if (bar) hipFree(bar);
+        halo = nullptr; bar = nullptr;
         ready = false;
     }
 };
@@ -238,6 +246,37 @@ void enqueue_cg_fused(gdpt_poisson_solver *s, bool unitw, int cg)
 }
 
 bool can_fuse(const gdpt_poisson_solver *s) { return s->fusion >= 1 && s->W % 4 == 0; }
+
+// Persistent CG geometry: 64-px wide tiles, one workgroup per CU, every tile resident.  Returns false when the
+// image does not fit that scheme (then the multi-kernel graph path runs).
+bool persistent_geometry(gdpt_poisson_solver *s)
+{
+    if (s->fusion < 2 || s->W % 4 != 0 || s->P.cgTolerance != 0.0f || s->P.verbose) return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
+    const int tilesX = cdiv(s->W, PT_W);
+    const int maxTY = cus / tilesX;
+    if (maxTY < 1) return false;
+    int TH = cdiv(s->H, maxTY);
+    if (TH < 8) TH = imin(8, s->H);
+    if (TH > PT_MAXH) return false;
+    s->ptTilesX = tilesX; s->ptTH = TH; s->ptTilesY = cdiv(s->H, TH);
+    return s->ptTilesX * s->ptTilesY <= cus;
+}
+
+int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
+{
+    PersistArgs A;
+    A.x = s->x; A.r = s->r; A.p = s->p[0]; A.w2 = s->w2;
+    A.part_a = s->part_pAp; A.part_b = s->part_rz; A.halo = s->halo; A.bar = s->bar; A.s_rz = s->s_rz_next();
+    A.W = s->W; A.H = s->H; A.tilesX = s->ptTilesX; A.tilesY = s->ptTilesY; A.TH = s->ptTH; A.iters = cg; A.alpha = s->alpha_eff;
+    HIPCHK(hipMemsetAsync(s->bar + 32, 0, sizeof(unsigned) * (PT_BAR_WORDS - 32), s->stream));   // counters and generation words; the error word stays sticky over the solve
+    void *args[] = {&A};
+    const dim3 grid(s->ptTilesX * s->ptTilesY), block(((16 * s->ptTH + 63) / 64) * 64);
+    const void *fn = unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>;
+    HIPCHK(hipLaunchCooperativeKernel(fn, grid, block, args, 0, s->stream));
+    return GDPT_OK;
+}
 
 int capture(gdpt_poisson_solver *s, bool first, hipGraphExec_t *out)
 {
@@ -371,6 +410,8 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
         HIPCHK(hipMalloc(&s->scal, sizeof(float) * 16));
         HIPCHK(hipMalloc(&s->regtab, sizeof(float) * (s->P.irlsIterMax + 1)));
         HIPCHK(hipMalloc(&s->counter, sizeof(int) * 4));
+        HIPCHK(hipMalloc(&s->halo, sizeof(float) * (size_t)PT_HALO * MAXP));
+        HIPCHK(hipMalloc(&s->bar, sizeof(unsigned) * PT_BAR_WORDS));
         // reg_k = regInit * regIter^(k-1), Solver.cpp:395 (host powf like the reference)
         std::vector<float> reg(s->P.irlsIterMax + 1, 0.0f);
         for (int k = 1; k < s->P.irlsIterMax; k++) reg[k] = s->P.irlsRegInit * powf(s->P.irlsRegIter, (float)(k - 1));
@@ -413,7 +454,18 @@ int gdpt_poisson_solve_indirect_async(gdpt_poisson_solver *s)
     const int one = 1;
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)s->counter, one, 1, st));
     s->last_iters = 0;
-    if (s->g0) {
+    s->usedPersistent = false;
+    if (persistent_geometry(s) && s->ptTilesX * s->ptTilesY <= MAXP) {
+        // fusion level 2: the CG loop of every IRLS iteration is one cooperative launch (poisson_persistent.hip.h)
+        s->usedPersistent = true;
+        HIPCHK(hipMemsetAsync(s->bar, 0, sizeof(unsigned) * PT_BAR_WORDS, st));
+        for (int irls = 0; irls < s->P.irlsIterMax; irls++) {
+            enqueue_irls_prologue(s, irls == 0);
+            int rc = enqueue_cg_persistent(s, irls == 0, s->P.cgIterMax);
+            if (rc) return rc;
+            s->last_iters += s->P.cgIterMax;
+        }
+    } else if (s->g0) {
         // cgTolerance == 0: the convergence test of Solver.cpp:438 can only fire on r.z == 0 exactly, and CG
         // steps taken from that state leave x bit-identical (a = 0/FLT_MIN = 0), so no host round trip is needed.
         for (int irls = 0; irls < s->P.irlsIterMax; irls++) {
@@ -450,6 +502,11 @@ int gdpt_poisson_sync(gdpt_poisson_solver *s)
     HIPCHK(hipStreamSynchronize(s->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_seconds = ms * 1.0e-3f;
+    if (s->usedPersistent) {
+        unsigned flag[2] = {0, 0};
+        HIPCHK(hipMemcpy(flag, s->bar, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag[1]) return fail(GDPT_ERR_HIP, "persistent CG: a grid barrier timed out (workgroups not co-resident?); rerun with gdpt_poisson_set_fusion(s, 1)");
+    }
     return GDPT_OK;
 }
 
@@ -494,7 +551,7 @@ void *gdpt_poisson_stream(gdpt_poisson_solver *s) { return s ? (void *)s->stream
 int gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level)
 {
     if (!s) return fail(GDPT_ERR_INVALID, "null solver");
-    s->fusion = level ? 1 : 0;
+    s->fusion = level < 0 ? 0 : (level > 2 ? 2 : level);
     return GDPT_OK;
 }
 

@@ -94,8 +94,10 @@ GDPT_API float gdpt_poisson_last_solve_seconds(const gdpt_poisson_solver *s);
 GDPT_API long gdpt_poisson_last_iterations(const gdpt_poisson_solver *s);
 /* The HIP stream (hipStream_t as void*) the handle launches on. */
 GDPT_API void *gdpt_poisson_stream(gdpt_poisson_solver *s);
-/* 0: reference op sequence, 3 kernels per CG iteration; 1 (default): x_p fused into the next
- * iteration's stencil, 2 kernels per CG iteration (same arithmetic per element). */
+/* 0: reference op sequence, 3 kernels per CG iteration; 1 (default): x_p fused into the next iteration's stencil, 2 kernels
+ * per CG iteration; 2: the CG loop of an IRLS iteration as ONE persistent cooperative kernel that keeps the iterate in
+ * registers (used when every 64-px-wide tile gets its own CU, cgTolerance == 0 and not verbose; otherwise falls back to 1).
+ * Same arithmetic per element at every level; only the dot products' summation tree differs. */
 GDPT_API int  gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level);
 
 /* Bench hook (no reference counterpart): mean standalone duration in microseconds, by HIP events on the
