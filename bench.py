@@ -9,7 +9,8 @@ random numbers are the counter-based streams both the HIP path and the oracle us
                      reference counts in raysTraced + shadowRaysTraced, skdtree.cpp:46-47) / wall time of the step
                      (render + halo exchange + develop + gather + reconstruct), all ranks, max over ranks.
   poisson          = Poisson-CG Mpix-iter/s of the reconstruction inside the same steps (HIP-event span of solveIndirect).
-  roofline         = the CG iteration against HBM (the graded kernel) + the dominant CG kernel's live timing.
+  roofline         = the dominant Poisson CG kernel against HBM (the graded kernel): algorithmic bytes per launch /
+                     launch duration by HIP events on the solver's stream; solve_achieved = the same over the whole solve.
   cpu_baseline     = the oracle (CPU restatement, kind "port": the reference itself cannot be built here) on a bounded sample.
 
 N > 1 (strong scaling, the image is fixed): one process per GPU; rank r renders a contiguous strip of rows, exchanges
@@ -151,9 +152,17 @@ def main():
         mray = rays / wall / 1e6
         mpix_iter = W * H * iters * a.steps / solve_s / 1e6
         kus = solver.profileKernels(50)
+        pus = solver.profilePersistent(20)
         bpi = BYTES_PER_PIX_ITER[PRESET]
-        achieved = bpi * mpix_iter * 1e6 / 1e9
-        kb = (72.0 if prm.irlsIterMax == 1 else 84.0) * W * H          # fused x_p+stencil: R r,p,x + W x,p,Ap = 72 B/px algorithmic (+12 for w in IRLS)
+        solve_achieved = bpi * mpix_iter * 1e6 / 1e9
+        if pus > 0.0:
+            # the persistent CG kernel: one launch = cgIterMax iterations over the image; algorithmic bytes = SURVEY 8(d)'s
+            # per pix-iter figure x the pix-iters of one launch (the iterate itself never leaves the register file)
+            kname, kavg, kb = "kp_cg", pus, bpi * W * H * prm.cgIterMax
+        else:
+            # fused x_p+stencil: R r,p,x + W x,p,Ap = 72 B/px algorithmic (+12 for w in IRLS); with kf_r_rz (48 B/px) it is the iteration
+            kname, kavg, kb = "kf_xp_Ax", kus[3], (72.0 if prm.irlsIterMax == 1 else 84.0) * W * H
+        achieved = kb / (kavg * 1e-6) / 1e9 if kavg > 0 else 0.0
         samples = W * H * a.spp * a.steps
         out = {
             "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp" % (W, H, a.spp),
@@ -167,10 +176,10 @@ def main():
             "halo_bytes_per_rank": halo,
             "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "what": "Poisson CG iteration: %g B/pix-iter (SURVEY 8d) x pix-iter/s of the timed solves" % bpi,
-                         "kernel": "kf_xp_Ax", "kernel_avg_us": round(kus[3], 2), "kernel_bytes": kb,
-                         "kernel_achieved": round(kb / (kus[3] * 1e-6) / 1e9, 1) if kus[3] > 0 else None,
-                         "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2)}},
+                         "what": "dominant Poisson CG kernel: algorithmic bytes per launch (%g B/pix-iter, SURVEY 8d) / HIP-event launch duration" % bpi,
+                         "kernel": kname, "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
+                         "solve_achieved": round(solve_achieved, 1), "solve_frac": round(solve_achieved / HBM_PEAK_GBS, 4),
+                         "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2), "kp_cg": round(pus, 2)}},
         }
         if not a.no_cpu_baseline and a.config == 2:
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)

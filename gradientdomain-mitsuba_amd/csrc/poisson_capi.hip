@@ -136,9 +136,11 @@ struct gdpt_poisson_solver {
     float alpha_eff = 0.0f;
     const float *dev_direct = nullptr; // device pointer of `direct` (borrowed or staged), or null
 
-    int fusion = 1;             // 0: reference op sequence; 1: x_p fused into the stencil; 2: persistent cooperative CG (when the geometry allows)
-    float *halo = nullptr;      // persistent CG: per-tile boundary records
-    unsigned *bar = nullptr;    // persistent CG: [0] arrival counter, [1] error flag
+    int fusion = 2;             // 0: reference op sequence; 1: x_p fused into the stencil; 2: persistent cooperative CG when the image fits, else 1
+    unsigned long long *halo = nullptr;   // persistent CG: per-tile boundary records (tagged floats)
+    unsigned *bar = nullptr;    // persistent CG: [1] sticky error flag
+    unsigned long long *gat = nullptr;  // persistent CG: tagged partial tables (gather A, gather B)
+    unsigned ptLaunch = 0;      // persistent CG: launch number (upper half of every tag)
     int ptTilesX = 0, ptTilesY = 0, ptTH = 0;
     bool usedPersistent = false;
     hipGraphExec_t g0 = nullptr, gK = nullptr;
@@ -183,7 +185,8 @@ struct gdpt_poisson_solver {
         counter = nullptr;
         if (halo) hipFree(halo);
         if (bar) hipFree(bar);
-        halo = nullptr; bar = nullptr;
+        if (gat) hipFree(gat);
+        halo = nullptr; bar = nullptr; gat = nullptr; ptLaunch = 0;
         ready = false;
     }
 };
@@ -251,7 +254,7 @@ bool can_fuse(const gdpt_poisson_solver *s) { return s->fusion >= 1 && s->W % 4 
 // image does not fit that scheme (then the multi-kernel graph path runs).
 bool persistent_geometry(gdpt_poisson_solver *s)
 {
-    if (s->fusion < 2 || s->W % 4 != 0 || s->P.cgTolerance != 0.0f || s->P.verbose) return false;
+    if (s->fusion < 2 || s->W % 4 != 0 || s->P.cgTolerance != 0.0f || s->P.verbose || s->P.cgIterMax >= 0xffff) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
     const int tilesX = cdiv(s->W, PT_W);
@@ -261,16 +264,21 @@ bool persistent_geometry(gdpt_poisson_solver *s)
     if (TH < 8) TH = imin(8, s->H);
     if (TH > PT_MAXH) return false;
     s->ptTilesX = tilesX; s->ptTH = TH; s->ptTilesY = cdiv(s->H, TH);
-    return s->ptTilesX * s->ptTilesY <= cus;
+    return s->ptTilesX * s->ptTilesY <= imin(cus, PT_MAXG);
 }
 
 int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
 {
     PersistArgs A;
     A.x = s->x; A.r = s->r; A.p = s->p[0]; A.w2 = s->w2;
-    A.part_a = s->part_pAp; A.part_b = s->part_rz; A.halo = s->halo; A.bar = s->bar; A.s_rz = s->s_rz_next();
+    A.gat = s->gat; A.halo = s->halo; A.bar = s->bar; A.s_rz = s->s_rz_next();
     A.W = s->W; A.H = s->H; A.tilesX = s->ptTilesX; A.tilesY = s->ptTilesY; A.TH = s->ptTH; A.iters = cg; A.alpha = s->alpha_eff;
-    HIPCHK(hipMemsetAsync(s->bar + 32, 0, sizeof(unsigned) * (PT_BAR_WORDS - 32), s->stream));   // counters and generation words; the error word stays sticky over the solve
+    if (s->ptLaunch == 0 || s->ptLaunch == 0xffffu) {      // fresh tables, or the 16-bit launch number is about to wrap: forget all tags
+        HIPCHK(hipMemsetAsync(s->gat, 0, sizeof(unsigned long long) * 6 * PT_MAXG, s->stream));
+        HIPCHK(hipMemsetAsync(s->halo, 0, sizeof(unsigned long long) * (size_t)PT_HALO * PT_MAXG, s->stream));
+        s->ptLaunch = 0;
+    }
+    A.tagBase = (++s->ptLaunch) << 16;
     void *args[] = {&A};
     const dim3 grid(s->ptTilesX * s->ptTilesY), block(((16 * s->ptTH + 63) / 64) * 64);
     const void *fn = unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>;
@@ -410,8 +418,9 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
         HIPCHK(hipMalloc(&s->scal, sizeof(float) * 16));
         HIPCHK(hipMalloc(&s->regtab, sizeof(float) * (s->P.irlsIterMax + 1)));
         HIPCHK(hipMalloc(&s->counter, sizeof(int) * 4));
-        HIPCHK(hipMalloc(&s->halo, sizeof(float) * (size_t)PT_HALO * MAXP));
+        HIPCHK(hipMalloc(&s->halo, sizeof(unsigned long long) * (size_t)PT_HALO * PT_MAXG));
         HIPCHK(hipMalloc(&s->bar, sizeof(unsigned) * PT_BAR_WORDS));
+        HIPCHK(hipMalloc(&s->gat, sizeof(unsigned long long) * 6 * PT_MAXG));
         // reg_k = regInit * regIter^(k-1), Solver.cpp:395 (host powf like the reference)
         std::vector<float> reg(s->P.irlsIterMax + 1, 0.0f);
         for (int k = 1; k < s->P.irlsIterMax; k++) reg[k] = s->P.irlsRegInit * powf(s->P.irlsRegIter, (float)(k - 1));
@@ -431,6 +440,7 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
     hipLaunchKernelGGL(kg_setup, dim3(grid_generic(n3)), dim3(BLK), 0, s->stream, s->b, s->x, src[0], src[1], src[2], s->alpha_eff, (int)n3);
     s->dev_direct = src[3];
     HIPCHK(hipGetLastError());
+    if (persistent_geometry(s)) HIPCHK(hipMemcpyAsync(s->rec, s->x, B3, hipMemcpyDeviceToDevice, s->stream));   // x0, should the cooperative launch have to be redone (gdpt_poisson_sync)
     // (re)capture the per-IRLS-iteration graphs when geometry/alpha/fusion changed
     if (s->graph_fusion != s->fusion || s->graph_alpha != s->alpha_eff) {
         s->release_graphs();
@@ -505,7 +515,25 @@ int gdpt_poisson_sync(gdpt_poisson_solver *s)
     if (s->usedPersistent) {
         unsigned flag[2] = {0, 0};
         HIPCHK(hipMemcpy(flag, s->bar, sizeof flag, hipMemcpyDeviceToHost));
-        if (flag[1]) return fail(GDPT_ERR_HIP, "persistent CG: a grid barrier timed out (workgroups not co-resident?); rerun with gdpt_poisson_set_fusion(s, 1)");
+#ifdef GDPT_PT_TIMING
+        unsigned tk[16];
+        HIPCHK(hipMemcpy(tk, s->bar + 16, sizeof tk, hipMemcpyDeviceToHost));
+        for (int b = 0; b < 2; b++)
+            fprintf(stderr, "persistent CG phase clocks (10 ns, last launch, tile %s): stencil+sum %u | gather A %u | update+sum %u | gather B %u | ring %u | ring wait %u\n",
+                    b ? "G/2" : "0", tk[8 * b], tk[8 * b + 1], tk[8 * b + 2], tk[8 * b + 3], tk[8 * b + 4], tk[8 * b + 5]);
+#endif
+        if (flag[1]) {
+            // A gather timed out (the workgroups were not all resident, e.g. the device is shared).  Not an error of the
+            // solve: redo it from x0 with the multi-kernel graphs and stay on them.
+            s->log("persistent CG: a grid-wide gather timed out; falling back to the multi-kernel path\n");
+            s->fusion = 1;
+            if (!s->g0) return fail(GDPT_ERR_HIP, "persistent CG timed out and no graph path was captured");
+            HIPCHK(hipMemcpyAsync(s->x, s->rec, sizeof(float) * 3 * (size_t)s->W * s->H, hipMemcpyDeviceToDevice, s->stream));
+            int rc = gdpt_poisson_solve_indirect_async(s);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(s->stream));
+            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_seconds = ms * 1.0e-3f;
+        }
     }
     return GDPT_OK;
 }
@@ -595,6 +623,36 @@ int gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4])
             HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             if (pass) us[which] = ms * 1000.0f / (float)R;
         }
+    }
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_poisson_profile_persistent(gdpt_poisson_solver *s, int reps, float *us)
+{
+    if (!s || !s->ready || reps < 1 || !us) return fail(GDPT_ERR_INVALID, "profile_persistent needs a set-up solver");
+    *us = 0.0f;
+    if (!persistent_geometry(s)) return GDPT_OK;
+    const long n3 = 3L * s->W * s->H;
+    const bool unitw = s->P.irlsIterMax == 1;
+    hipStream_t st = s->stream;
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->w2, 1.0f, (size_t)n3);
+    hipLaunchKernelGGL(kg_set, dim3(16), dim3(BLK), 0, st, s->scal, 1.0f, (size_t)16);
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->r, 0.25f, (size_t)n3);
+    hipLaunchKernelGGL(kg_set, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->x, 0.5f, (size_t)n3);
+    HIPCHK(hipMemsetAsync(s->bar, 0, sizeof(unsigned) * PT_BAR_WORDS, st));
+    for (int pass = 0; pass < 2; pass++) { // pass 0 = warm-up
+        const int R = pass ? reps : 2;
+        HIPCHK(hipEventRecord(s->ev0, st));
+        for (int k = 0; k < R; k++) {
+            int rc = enqueue_cg_persistent(s, unitw, s->P.cgIterMax);
+            if (rc) return rc;
+        }
+        HIPCHK(hipEventRecord(s->ev1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        if (pass) *us = ms * 1000.0f / (float)R;
     }
     HIPCHK(hipGetLastError());
     return GDPT_OK;

@@ -3,21 +3,24 @@
 // Why: at the image sizes G-PT renders (1280x720: x, r, p, Ap, w = 55 MB) the CG iterate fits the chip's register file
 // (256 CUs x 512 KB), so the only thing that has to leave a CU per iteration is a one-pixel ring of r and two 3-float dot
 // products.  Each workgroup owns a 64 x TH tile for the whole solve, keeps x, r, p (and w) of its 4 px per lane in VGPRs,
-// stages p (+ring) through LDS for the 5-point stencil, and meets the other workgroups at TWO grid barriers per iteration
-// (after p.Ap, after r.r) -- the two global reductions the CG recurrence of the reference has (Solver.cpp:466-469); nothing
+// stages p (+ring) through LDS for the 5-point stencil, and meets the other workgroups at TWO all-gathers per iteration
+// (p.Ap, then r.r) -- the two global reductions the CG recurrence of the reference has (Solver.cpp:466-469); nothing
 // else is synchronised and no array is streamed through HBM.  The arithmetic per element is that of kf_Ax / kf_r_rz / kf_x_p
-// (reference association order, -ffp-contract=off); only the summation tree of the dot products differs (per-tile partials).
+// (reference association order, -ffp-contract=off); only the summation tree of the dot products differs (per-tile partials,
+// summed by every workgroup in the same fixed order so that all of them derive bit-identical step sizes).
 //
-// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, form "agent-scope atomics on both sides"): everything one
-// workgroup hands to another in-launch -- its tile partial and the boundary ring of r -- is written with relaxed AGENT-scope
-// atomic stores (write-through, sc1) and read with relaxed agent-scope atomic loads (L1 bypassed), so no release/acquire cache
-// maintenance is needed; every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup arrives.  The grid
-// barrier is hierarchical: 8 arrival counters (workgroup b reports to counter b % 8, the observed XCD of block b, so that the
-// 32 arrivals per counter stay on one L2), the last arriver of each group reports to a top counter, waits for all groups and
-// then releases its group through a generation word the others poll with s_sleep.  Grouping by b % 8 is only a speed choice:
-// correctness does not depend on where a workgroup runs.  All words are zeroed by a memset node before every launch, every
-// spin is bounded, and a timeout raises a sticky flag the host turns into GDPT_ERR_HIP instead of hanging.  Residency comes
-// from the grid size (tiles <= CUs, one workgroup per CU) and is checked by hipLaunchCooperativeKernel.
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, form "8-byte agent-scope atomics on both sides"): a tile
+// partial travels as three 8-byte words {float bits, iteration tag}, written with relaxed AGENT-scope atomic stores
+// (write-through) into the tile's slot of a G x 3 table; every workgroup polls the whole table (one word per lane, relaxed
+// agent-scope atomic loads, s_sleep between polls) until each word carries the tag of the current iteration.  The gather is
+// data and barrier in one: no arrival counter, no second round trip.  The boundary ring of r travels the same way -- every
+// float of it is an 8-byte {float bits, iteration tag} word the neighbouring tile's ring lane polls -- so nothing has to be
+// drained or fenced: each word validates itself.  Slot reuse is safe because a workgroup only writes gather A of iteration i+1
+// after it has seen every gather-B word of iteration i, which each workgroup publishes after it consumed gather A of
+// iteration i; the ring of iteration i+1 is written after gather A of i+1 completed, which every neighbour publishes after it
+// consumed the ring of iteration i.  Correctness does not depend on where a workgroup runs.  Tags carry the launch number in their upper half, so the tables need no clearing between launches; every spin is bounded, and a timeout raises a
+// sticky flag that makes every workgroup leave and that the host reports (and recovers from, poisson_capi.hip) instead of
+// hanging.  Residency comes from the grid size (tiles <= CUs, one workgroup per CU), checked by hipLaunchCooperativeKernel.
 #pragma once
 #include "poisson_kernels.hip.h"
 
@@ -25,58 +28,78 @@ namespace gdpt {
 
 constexpr int PT_W = 64;                 // tile width in pixels: 16 lanes x 4 px
 constexpr int PT_MAXH = 64;              // tile rows <= 64 (16 lanes per row -> <= 1024 threads)
-constexpr int PT_RS = (PT_W + 2) * 3 + 2; // LDS row stride in floats (ring pixel each side, +2 pad)
+// LDS image of p: three colour planes of (TH+2) x 64 floats (row 0 / TH+1: the ring rows) and the two ring columns.  A lane's
+// 4 px of one colour are one aligned 16-byte access, and 8 consecutive lanes cover the 32 banks: conflict-free.  (The AoS
+// layout of the first version put 64 lanes on 8 banks; the stencil phase took 5.5 us of a 15 us iteration.)
+constexpr int PT_PLANE = (PT_MAXH + 2) * PT_W;
+constexpr int PT_COLL = 3 * PT_PLANE, PT_COLR = PT_COLL + 3 * PT_MAXH, PT_LDS = PT_COLR + 3 * PT_MAXH;
+__device__ __forceinline__ int pt_plane(int c, int row, int x) { return c * PT_PLANE + row * PT_W + x; }
+
+// value of `v` in the lane one to the left / right inside the 16-lane row (0 at the row's end)
+__device__ __forceinline__ float pt_from_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true)); }
+__device__ __forceinline__ float pt_from_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true)); }
 constexpr int PT_HALO = (2 * PT_W + 2 * PT_MAXH) * 3;   // floats a tile publishes per iteration: top, bottom, left, right
 constexpr unsigned PT_SPIN_LIMIT = 4000000u;
 
 struct PersistArgs {
     float *x, *r, *p;                    // images (AoS RGB); p is written back at the end
     const float *w2;                     // 3n weights (ignored when UNITW)
-    float4 *part_a, *part_b;             // per-tile partials of p.Ap and r.r
-    float *halo;                         // [tiles][PT_HALO] boundary r of every tile
-    unsigned *bar;                       // PT_BAR_WORDS words: [1] error flag, arrival counters, top counter, generation words
+    unsigned long long *gat;             // [2][PT_MAXG*3] tagged partials: gather A (p.Ap) and gather B (r.r)
+    unsigned long long *halo;            // [tiles][PT_HALO] boundary r of every tile, each float tagged with its iteration
+    unsigned *bar;                       // [1] sticky error flag
     float *s_rz;                         // in: r.r of the prologue; out: final r.r
     int W, H, tilesX, tilesY, TH, iters;
+    unsigned tagBase;                    // launch number << 16: tags of earlier launches never match
     float alpha;
 };
 
 #define PT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr int PT_BAR_WORDS = 32 * 20;    // [1] error flag; counters and generation words 128 B apart
+constexpr int PT_MAXG = 256;             // workgroups (tiles) at most
+constexpr int PT_BAR_WORDS = 64;         // [1] sticky error flag; [16..] phase clocks of the GDPT_PT_TIMING build
 
-__device__ __forceinline__ void pt_store(float *p, float v) { __hip_atomic_store(p, v, PT_RLX_AGENT); }
-__device__ __forceinline__ float pt_load(float *p) { return __hip_atomic_load(p, PT_RLX_AGENT); }
+// Workgroup barrier for LDS traffic only.  __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0): every
+// barrier would wait for the write-through stores of the boundary record and the partials to reach memory (~2-3 us with 240
+// workgroups storing) although no lane of this workgroup ever reads them.  LDS operations are all this kernel orders here.
+__device__ __forceinline__ void pt_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ bool pt_spin(unsigned *word, unsigned target, unsigned *err)
+__device__ __forceinline__ void pt_store(unsigned long long *p, float v, unsigned tag)
 {
-    unsigned spins = 0;
-    while (__hip_atomic_load(word, PT_RLX_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0 && __hip_atomic_load(err, PT_RLX_AGENT) != 0) return false;
-        if (spins > PT_SPIN_LIMIT) { __hip_atomic_store(err, 1u, PT_RLX_AGENT); return false; }
-    }
-    return true;
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(v), PT_RLX_AGENT);
 }
 
-// Grid barrier number `epoch` (1, 2, ...) over G workgroups.
-__device__ __forceinline__ bool pt_barrier(unsigned *bar, unsigned epoch, int G)
+// Poll a tagged word until it carries `tag` (w: a value already loaded from it); bounded, raises the sticky flag on timeout.
+__device__ __forceinline__ float pt_wait(unsigned long long *p, unsigned long long w, unsigned tag, int *s_fail, unsigned *err)
 {
-    __shared__ int s_ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY wave drains its write-through stores before arriving
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int g = blockIdx.x & 7, groups = G < 8 ? G : 8;
-        const unsigned members = (unsigned)((G - g + 7) / 8);
-        unsigned *cnt = bar + 32 * (1 + g), *top = bar + 32 * 9, *gen = bar + 32 * (10 + g), *err = bar + 1;
-        bool ok;
-        if (__hip_atomic_fetch_add(cnt, 1u, PT_RLX_AGENT) + 1u == members * epoch) {      // last arriver of its group
-            __hip_atomic_fetch_add(top, 1u, PT_RLX_AGENT);
-            ok = pt_spin(top, (unsigned)groups * epoch, err);
-            __hip_atomic_store(gen, epoch, PT_RLX_AGENT);
-        } else ok = pt_spin(gen, epoch, err);
-        s_ok = ok ? 1 : 0;
+    unsigned spins = 0;
+    while ((unsigned)(w >> 32) != tag) {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if (((spins & 1023u) == 0 && __hip_atomic_load(err, PT_RLX_AGENT) != 0) || spins > PT_SPIN_LIMIT) {
+            __hip_atomic_store(err, 1u, PT_RLX_AGENT);
+            *s_fail = 1;
+            break;
+        }
+        w = __hip_atomic_load(p, PT_RLX_AGENT);
     }
-    __syncthreads();
-    return s_ok != 0;
+    return __uint_as_float((unsigned)w);
+}
+
+// All-gather + fixed-order sum of one 3-float partial per workgroup.  `mine` (the same in every thread) is published under
+// `tag`; on return v holds the totals over the G workgroups, identical in every thread of every workgroup.  gsm: >= 3*G floats.
+__device__ __forceinline__ bool pt_allgather_sum(unsigned long long *gat, unsigned tag, int G, int tile, const float (&mine)[3],
+                                                 float (&v)[3], float *gsm, int *s_fail, unsigned *err)
+{
+    const int t = threadIdx.x;
+    if (t < 3) pt_store(&gat[tile * 3 + t], mine[t], tag);
+    for (int idx = t; idx < 3 * G; idx += blockDim.x)
+        gsm[idx] = pt_wait(&gat[idx], __hip_atomic_load(&gat[idx], PT_RLX_AGENT), tag, s_fail, err);
+    pt_sync();
+    // every wave sums the table itself, in one fixed order: lane l takes tiles l, l+64, ...; then the xor butterfly
+    const int ln = t & 63;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int i = ln; i < G; i += 64) { a0 += gsm[3 * i]; a1 += gsm[3 * i + 1]; a2 += gsm[3 * i + 2]; }
+    v[0] = wave_sum(a0); v[1] = wave_sum(a1); v[2] = wave_sum(a2);
+    return *s_fail == 0;
 }
 
 // Sum a[0..2] over a block of up to 16 waves; every thread receives the totals.  sm: >= 64 floats.
@@ -85,30 +108,22 @@ __device__ __forceinline__ void pt_block_sum3(float (&a)[3], float *sm, int nwav
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < 3; c++) a[c] = wave_sum(a[c]);
-    __syncthreads();
+    pt_sync();
     if (ln == 0) { sm[wv * 4 + 0] = a[0]; sm[wv * 4 + 1] = a[1]; sm[wv * 4 + 2] = a[2]; }
-    __syncthreads();
+    pt_sync();
     float t[3] = {0.0f, 0.0f, 0.0f};
     for (int w = 0; w < nwaves; w++) { t[0] += sm[w * 4]; t[1] += sm[w * 4 + 1]; t[2] += sm[w * 4 + 2]; }
     a[0] = t[0]; a[1] = t[1]; a[2] = t[2];
 }
 
-// Fixed-order total of the G tile partials (agent-scope atomic loads: L1 is bypassed, the scalar cache never involved).
-__device__ __forceinline__ void pt_reduce_parts(float4 *part, int G, float (&v)[3], float *sm, int nwaves)
-{
-    v[0] = v[1] = v[2] = 0.0f;
-    for (int i = threadIdx.x; i < G; i += blockDim.x) {
-        float *q = reinterpret_cast<float *>(&part[i]);
-        v[0] += pt_load(q); v[1] += pt_load(q + 1); v[2] += pt_load(q + 2);
-    }
-    pt_block_sum3(v, sm, nwaves);
-}
-
 template <bool UNITW>
 __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float lp[(PT_MAXH + 2) * PT_RS];   // p of the tile with its ring
+    __shared__ __attribute__((aligned(16))) float lp[PT_LDS];                  // p of the tile with its ring
     __shared__ float sm[64];
+    __shared__ float gsm[3 * PT_MAXG];
+    __shared__ float hs[PT_HALO];
+    __shared__ int s_fail;
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4, nwaves = (blockDim.x + 63) >> 6;
     const int tile = blockIdx.x, tX = tile % A.tilesX, tY = tile / A.tilesX;
     const int X0 = tX * PT_W, Y0 = tY * A.TH;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
     const int i = y * W + x;
     const float alphaSqr = A.alpha * A.alpha;
     const int G = A.tilesX * A.tilesY;
-    float *myHalo = A.halo + (size_t)tile * PT_HALO;
+    unsigned long long *myHalo = A.halo + (size_t)tile * PT_HALO;
 
     // ---- load the tile: x, r (p := r, Solver.cpp:405) and the weights, once ----
     float xv[12], rv[12], pv[12];
@@ -153,54 +168,90 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
     for (int e = t; e < ringN; e += blockDim.x) {
         const int c = e % 3, q = e / 3;
         int gx, gy, slot;
-        if (q < TWv) { gx = X0 + q; gy = Y0 - 1; slot = 0 * PT_RS + (q + 1) * 3 + c; }
-        else if (q < 2 * TWv) { gx = X0 + (q - TWv); gy = Y0 + THv; slot = (THv + 1) * PT_RS + (q - TWv + 1) * 3 + c; }
-        else if (q < 2 * TWv + THv) { gx = X0 - 1; gy = Y0 + (q - 2 * TWv); slot = (q - 2 * TWv + 1) * PT_RS + 0 * 3 + c; }
-        else { gx = X0 + TWv; gy = Y0 + (q - 2 * TWv - THv); slot = (q - 2 * TWv - THv + 1) * PT_RS + (TWv + 1) * 3 + c; }
+        if (q < TWv) { gx = X0 + q; gy = Y0 - 1; slot = pt_plane(c, 0, q); }
+        else if (q < 2 * TWv) { gx = X0 + (q - TWv); gy = Y0 + THv; slot = pt_plane(c, THv + 1, q - TWv); }
+        else if (q < 2 * TWv + THv) { gx = X0 - 1; gy = Y0 + (q - 2 * TWv); slot = PT_COLL + c * PT_MAXH + (q - 2 * TWv); }
+        else { gx = X0 + TWv; gy = Y0 + (q - 2 * TWv - THv); slot = PT_COLR + c * PT_MAXH + (q - 2 * TWv - THv); }
         lp[slot] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? A.r[3 * ((size_t)gy * W + gx) + c] : 0.0f;
+    }
+    // where ring float e comes from: neighbour tile, offset in ITS boundary record, my LDS slot, colour
+    auto ring_source = [&](int e, int &nt, int &off, int &slot, int &c) -> bool {
+        c = e % 3;
+        const int q = e / 3;
+        bool have;
+        if (q < TWv) { have = tY > 0; nt = tile - A.tilesX; off = PT_W * 3 + q * 3 + c; slot = pt_plane(c, 0, q); }                                 // its bottom row
+        else if (q < 2 * TWv) { have = Y0 + THv < H; nt = tile + A.tilesX; off = (q - TWv) * 3 + c; slot = pt_plane(c, THv + 1, q - TWv); }        // its top row
+        else if (q < 2 * TWv + THv) { have = tX > 0; nt = tile - 1; off = 2 * PT_W * 3 + PT_MAXH * 3 + (q - 2 * TWv) * 3 + c; slot = PT_COLL + c * PT_MAXH + (q - 2 * TWv); }   // its right column
+        else { have = X0 + TWv < W; nt = tile + 1; off = 2 * PT_W * 3 + (q - 2 * TWv - THv) * 3 + c; slot = PT_COLR + c * PT_MAXH + (q - 2 * TWv - THv); }      // its left column
+        return have;
+    };
+    int h_slot = 0, h_c = 0;
+    unsigned long long *h_ptr = A.halo;
+    bool h_have = false;
+    if (t < ringN) {
+        int nt, off;
+        h_have = ring_source(t, nt, off, h_slot, h_c);
+        if (h_have) h_ptr = &A.halo[(size_t)nt * PT_HALO + off];
     }
     float rz[3];
     rz[0] = A.s_rz[0]; rz[1] = A.s_rz[1]; rz[2] = A.s_rz[2];
-    unsigned epoch = 0;
     bool ok = true;
+    if (t == 0) s_fail = 0;
+    unsigned long long *gatA = A.gat, *gatB = A.gat + 3 * PT_MAXG;
+    unsigned *err = A.bar + 1;
 
+#ifdef GDPT_PT_TIMING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tn;
+#define PT_TICK(k) { tn = wall_clock64(); tph[k] += tn - tc; tc = tn; }
+#else
+#define PT_TICK(k)
+#endif
     for (int it = 0; it < A.iters && ok; it++) {
         // ---- Ap = A p (tile staged in LDS), partial p.Ap ----
-        __syncthreads();
+        pt_sync();
+        PT_TICK(5)
         if (valid) {
-            float *row = lp + (ty + 1) * PT_RS + (4 * tx + 1) * 3;
 #pragma unroll
-            for (int k = 0; k < 12; k++) row[k] = pv[k];
+            for (int c = 0; c < 3; c++)
+                *reinterpret_cast<float4 *>(&lp[pt_plane(c, ty + 1, 4 * tx)]) = make_float4(pv[c], pv[3 + c], pv[6 + c], pv[9 + c]);
         }
-        __syncthreads();
+        float lft[3], rgt[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lft[c] = pt_from_left(pv[9 + c]); rgt[c] = pt_from_right(pv[c]); }   // all lanes take part
+        pt_sync();
         float Ap[12], acc[3] = {0.0f, 0.0f, 0.0f};
         if (valid) {
-            const float *c0 = lp + (ty + 1) * PT_RS + (4 * tx + 1) * 3;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int xx = x + k;
+            for (int c = 0; c < 3; c++) {
+                const float4 u4 = *reinterpret_cast<const float4 *>(&lp[pt_plane(c, ty, 4 * tx)]);
+                const float4 d4 = *reinterpret_cast<const float4 *>(&lp[pt_plane(c, ty + 2, 4 * tx)]);
+                const float up[4] = {u4.x, u4.y, u4.z, u4.w}, dn[4] = {d4.x, d4.y, d4.z, d4.w};
+                if (tx == 0) lft[c] = lp[PT_COLL + c * PT_MAXH + ty];
+                if (4 * tx + 4 == TWv) rgt[c] = lp[PT_COLR + c * PT_MAXH + ty];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
+                for (int k = 0; k < 4; k++) {
+                    const int xx = x + k;
                     const float xi = pv[3 * k + c];
                     const float wl = (k == 0) ? w1l : w1[k - 1];
+                    const float xl = (k == 0) ? lft[c] : pv[3 * (k - 1) + c], xr = (k == 3) ? rgt[c] : pv[3 * (k + 1) + c];
                     float a = w0[k] * xi * alphaSqr;                                   // Backend.cpp:228-233
-                    if (xx != 0)     a = a + wl * (xi - c0[3 * (k - 1) + c]);
-                    if (xx != W - 1) a = a + w1[k] * (xi - c0[3 * (k + 1) + c]);
-                    if (y != 0)      a = a + wu[k] * (xi - c0[3 * k + c - PT_RS]);
-                    if (y != H - 1)  a = a + wv_[k] * (xi - c0[3 * k + c + PT_RS]);
+                    if (xx != 0)     a = a + wl * (xi - xl);
+                    if (xx != W - 1) a = a + w1[k] * (xi - xr);
+                    if (y != 0)      a = a + wu[k] * (xi - up[k]);
+                    if (y != H - 1)  a = a + wv_[k] * (xi - dn[k]);
                     Ap[3 * k + c] = a;
                     acc[c] += xi * a;
                 }
             }
         }
         pt_block_sum3(acc, sm, nwaves);
-        if (t == 0) { float *q = reinterpret_cast<float *>(&A.part_a[tile]); pt_store(q, acc[0]); pt_store(q + 1, acc[1]); pt_store(q + 2, acc[2]); }
-        ok = pt_barrier(A.bar, ++epoch, G);
+        PT_TICK(0)
+        float pAp[3], a[3];
+        ok = pt_allgather_sum(gatA, A.tagBase + (unsigned)it + 1u, G, tile, acc, pAp, gsm, &s_fail, err);
         if (!ok) break;
+        PT_TICK(1)
 
         // ---- a = rz / pAp ; x += p a ; r -= Ap a ; partial r.r ; publish the boundary of r ----
-        float pAp[3], a[3];
-        pt_reduce_parts(A.part_a, G, pAp, sm, nwaves);
 #pragma unroll
         for (int c = 0; c < 3; c++) a[c] = rz[c] / fmaxf(pAp[c], FLT_MIN);              // Backend.cpp:301
         float acc2[3] = {0.0f, 0.0f, 0.0f};
@@ -214,19 +265,23 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
                     rv[3 * k + c] = ri;
                     acc2[c] += ri * ri;
                 }
-            if (ty == 0) for (int k = 0; k < 12; k++) pt_store(&myHalo[(4 * tx) * 3 + k], rv[k]);
-            if (ty == THv - 1) for (int k = 0; k < 12; k++) pt_store(&myHalo[PT_W * 3 + (4 * tx) * 3 + k], rv[k]);
-            if (tx == 0) for (int c = 0; c < 3; c++) pt_store(&myHalo[2 * PT_W * 3 + ty * 3 + c], rv[c]);
-            if (4 * tx + 4 == TWv) for (int c = 0; c < 3; c++) pt_store(&myHalo[2 * PT_W * 3 + PT_MAXH * 3 + ty * 3 + c], rv[9 + c]);
+            // boundary of r -> LDS record (top row, bottom row, left column, right column)
+            if (ty == 0) for (int k = 0; k < 12; k++) hs[(4 * tx) * 3 + k] = rv[k];
+            if (ty == THv - 1) for (int k = 0; k < 12; k++) hs[PT_W * 3 + (4 * tx) * 3 + k] = rv[k];
+            if (tx == 0) for (int c = 0; c < 3; c++) hs[2 * PT_W * 3 + ty * 3 + c] = rv[c];
+            if (4 * tx + 4 == TWv) for (int c = 0; c < 3; c++) hs[2 * PT_W * 3 + PT_MAXH * 3 + ty * 3 + c] = rv[9 + c];
         }
         pt_block_sum3(acc2, sm, nwaves);
-        if (t == 0) { float *q = reinterpret_cast<float *>(&A.part_b[tile]); pt_store(q, acc2[0]); pt_store(q + 1, acc2[1]); pt_store(q + 2, acc2[2]); }
-        ok = pt_barrier(A.bar, ++epoch, G);
+        // publish the record: consecutive lanes write consecutive tagged words (coalesced write-through, not one fabric write per lane)
+        for (int e = t; e < PT_HALO; e += blockDim.x) pt_store(&myHalo[e], hs[e], A.tagBase + (unsigned)it + 1u);
+        PT_TICK(2)
+        const unsigned long long hw0 = h_have ? __hip_atomic_load(h_ptr, PT_RLX_AGENT) : 0ull;   // in flight during the gather
+        float rzn[3], b[3];
+        ok = pt_allgather_sum(gatB, A.tagBase + (unsigned)it + 1u, G, tile, acc2, rzn, gsm, &s_fail, err);
         if (!ok) break;
+        PT_TICK(3)
 
         // ---- b = rz_new / rz ; p = r + p b, for the tile and (redundantly) its ring ----
-        float rzn[3], b[3];
-        pt_reduce_parts(A.part_b, G, rzn, sm, nwaves);
 #pragma unroll
         for (int c = 0; c < 3; c++) { b[c] = rzn[c] / fmaxf(rz[c], FLT_MIN); rz[c] = rzn[c]; }   // Backend.cpp:336
         if (valid) {
@@ -235,20 +290,23 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
 #pragma unroll
                 for (int c = 0; c < 3; c++) pv[3 * k + c] = rv[3 * k + c] + pv[3 * k + c] * b[c];  // Backend.cpp:344
         }
-        for (int e = t; e < ringN; e += blockDim.x) {
-            const int c = e % 3, q = e / 3;
-            int nt, off, slot;          // neighbour tile, offset of the wanted float in ITS halo record, my LDS slot
-            bool have;
-            if (q < TWv) { have = tY > 0; nt = tile - A.tilesX; off = PT_W * 3 + q * 3 + c; slot = 0 * PT_RS + (q + 1) * 3 + c; }                                 // its bottom row
-            else if (q < 2 * TWv) { have = Y0 + THv < H; nt = tile + A.tilesX; off = (q - TWv) * 3 + c; slot = (THv + 1) * PT_RS + (q - TWv + 1) * 3 + c; }        // its top row
-            else if (q < 2 * TWv + THv) { have = tX > 0; nt = tile - 1; off = 2 * PT_W * 3 + PT_MAXH * 3 + (q - 2 * TWv) * 3 + c; slot = (q - 2 * TWv + 1) * PT_RS + c; }   // its right column
-            else { have = X0 + TWv < W; nt = tile + 1; off = 2 * PT_W * 3 + (q - 2 * TWv - THv) * 3 + c; slot = (q - 2 * TWv - THv + 1) * PT_RS + (TWv + 1) * 3 + c; }      // its left column
-            if (have) {
-                const float rn = pt_load(&A.halo[(size_t)nt * PT_HALO + off]);
+        if (h_have) {
+            const float rn = pt_wait(h_ptr, hw0, A.tagBase + (unsigned)it + 1u, &s_fail, err);
+            lp[h_slot] = rn + lp[h_slot] * b[h_c];
+        }
+        for (int e = t + blockDim.x; e < ringN; e += blockDim.x) {         // tiles so small that a lane serves several ring floats
+            int nt, off, slot, c;
+            if (ring_source(e, nt, off, slot, c)) {
+                unsigned long long *hp = &A.halo[(size_t)nt * PT_HALO + off];
+                const float rn = pt_wait(hp, __hip_atomic_load(hp, PT_RLX_AGENT), A.tagBase + (unsigned)it + 1u, &s_fail, err);
                 lp[slot] = rn + lp[slot] * b[c];
             }
         }
+        PT_TICK(4)
     }
+#ifdef GDPT_PT_TIMING
+    if (t == 0 && (tile == 0 || tile == G / 2)) for (int k = 0; k < 6; k++) A.bar[16 + (tile ? 8 : 0) + k] = (unsigned)tph[k];
+#endif
 
     // ---- write the iterate back ----
     if (valid) {

@@ -111,6 +111,12 @@ class Solver:
         check(lib().gdpt_poisson_profile_kernels(self._h, int(reps), us))
         return [float(v) for v in us]
 
+    def profilePersistent(self, reps=20):
+        """Bench hook: mean microseconds of one launch of the persistent CG kernel (cgIterMax iterations); 0 if not used."""
+        us = C.c_float(0.0)
+        check(lib().gdpt_poisson_profile_persistent(self._h, int(reps), C.byref(us)))
+        return float(us.value)
+
     def setFusion(self, level):
         check(lib().gdpt_poisson_set_fusion(self._h, int(level)))
 

@@ -94,9 +94,10 @@ GDPT_API float gdpt_poisson_last_solve_seconds(const gdpt_poisson_solver *s);
 GDPT_API long gdpt_poisson_last_iterations(const gdpt_poisson_solver *s);
 /* The HIP stream (hipStream_t as void*) the handle launches on. */
 GDPT_API void *gdpt_poisson_stream(gdpt_poisson_solver *s);
-/* 0: reference op sequence, 3 kernels per CG iteration; 1 (default): x_p fused into the next iteration's stencil, 2 kernels
- * per CG iteration; 2: the CG loop of an IRLS iteration as ONE persistent cooperative kernel that keeps the iterate in
- * registers (used when every 64-px-wide tile gets its own CU, cgTolerance == 0 and not verbose; otherwise falls back to 1).
+/* 0: reference op sequence, 3 kernels per CG iteration; 1: x_p fused into the next iteration's stencil, 2 kernels per CG
+ * iteration; 2 (default): the CG loop of an IRLS iteration as ONE persistent cooperative kernel that keeps the iterate in
+ * registers -- used when every 64-px-wide tile gets its own CU (up to ~1 Mpixel on 256 CUs), cgTolerance == 0 and not
+ * verbose; otherwise, and if its workgroups turn out not to be co-resident, level 1 runs.
  * Same arithmetic per element at every level; only the dot products' summation tree differs. */
 GDPT_API int  gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level);
 
@@ -104,6 +105,9 @@ GDPT_API int  gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level);
  * handle's stream, of the CG kernels at the handle's geometry: us[0] stencil, us[1] r_rz, us[2] x_p,
  * us[3] fused x_p+stencil.  Clobbers the iterate; call setup_backend again before the next solve. */
 GDPT_API int  gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4]);
+/* Same for the persistent CG kernel of fusion level 2: mean duration in microseconds of ONE launch (= cgIterMax CG
+ * iterations), 0 when the handle's geometry does not use it.  Clobbers the iterate like profile_kernels. */
+GDPT_API int  gdpt_poisson_profile_persistent(gdpt_poisson_solver *s, int reps, float *us);
 
 /* ---- (2) backend-op level ----------------------------------------------------------------- */
 /* Device-pointer forms of the `poisson::Backend` virtuals.  `stream` is a hipStream_t (NULL =
