@@ -187,6 +187,7 @@ struct gdpt_scene {
     std::vector<void *> allocs;
     int device = 0;
     int bvhDepth = 0;
+    int numCUs = 256;
     size_t ldsSceneBytes = 0;
 };
 
@@ -199,6 +200,9 @@ struct gdpt_film {
     bool resolved = false;
     int wavesPerSimd = 2;       // occupancy target the render kernel is compiled for (register budget = 512 / this)
     bool accInLds = true;       // keep the per-sample sums in LDS when the block budget allows
+    int slices = 0;             // sample slices per launch; 0 = chosen per launch
+    int extraPlanes = 0;        // record planes allocated behind d.recExtra
+    int lastSlices = 1;
 };
 
 extern "C" {
@@ -324,6 +328,7 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     c.aspect = (double)camera->width / (double)camera->height;
     c.invW = 1.0 / camera->width; c.invH = 1.0 / camera->height;
     c.width = camera->width; c.height = camera->height;
+    { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) s->numCUs = cus; }
     *out = s;
     return GDPT_OK;
 }
@@ -344,6 +349,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     f->scene = s;
     f->wavesPerSimd = s->d.ldsScene ? 2 : 4;    // measured: LDS-resident scenes peak at 2 waves/SIMD, HBM-resident BVHs want 4
     FilmD &d = f->d;
+    d.recExtra = nullptr;
     d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
     d.recStride = (size_t)d.recRows * W;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
@@ -364,6 +370,7 @@ void gdpt_film_destroy(gdpt_film *f)
     if (f->stream) hipStreamSynchronize(f->stream);
     for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (f->d.rec) hipFree(f->d.rec);
+    if (f->d.recExtra) hipFree(f->d.recExtra);
     if (f->d.spill) hipFree(f->d.spill);
     if (f->d.stats) hipFree(f->d.stats);
     if (f->accum) hipFree(f->accum);
@@ -410,13 +417,33 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     const size_t accBytes = sizeof(Float) * ACC_N * TBLK;
     const bool accLds = f->accInLds && (lds + accBytes) * (size_t)std::max(1, wps) <= (size_t)160 * 1024;
     if (accLds) lds += accBytes;
-    const dim3 grid(tilesX * tilesY), block(TBLK);
-#define GDPT_LAUNCH(LDSV, ACCV, WPS) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, stackDepth, sceneBytes)
+    // sample slices (gpt_render.hip.h): enough work items to keep every CU busy to the end of the launch
+    const int tiles = tilesX * tilesY;
+    int slices = f->slices;
+    if (slices <= 0) {
+        const int resident = s->numCUs * std::max(1, wps);                  // one 256-thread block = one wave per SIMD
+        slices = (SLICE_FILL * resident + tiles - 1) / tiles;
+        slices = std::max(1, std::min(slices, std::max(1, cfg->spp / SLICE_MIN_SPP)));
+    }
+    slices = std::max(1, std::min(slices, cfg->spp));
+    if (slices - 1 > f->extraPlanes) {
+        THIPCHK(hipStreamSynchronize(f->stream));
+        if (f->d.recExtra) hipFree(f->d.recExtra);
+        f->d.recExtra = nullptr; f->extraPlanes = 0;
+        const size_t bytes = sizeof(Float) * NREC * f->d.recStride * (size_t)(slices - 1);
+        if (hipMalloc((void **)&f->d.recExtra, bytes) != hipSuccess) return tfail(GDPT_ERR_HIP, "Out of memory!");
+        f->extraPlanes = slices - 1;
+        THIPCHK(hipMemsetAsync(f->d.recExtra, 0, bytes, f->stream));      // planes stay zero between launches (k_fold_slices clears them)
+    }
+    f->lastSlices = slices;
+    const dim3 grid(tiles * slices), block(TBLK);
+#define GDPT_LAUNCH(LDSV, ACCV, WPS) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { if (wps == 1) GDPT_LAUNCH(LDSV, ACCV, 1); else if (wps == 2) GDPT_LAUNCH(LDSV, ACCV, 2); else if (wps == 3) GDPT_LAUNCH(LDSV, ACCV, 3); else GDPT_LAUNCH(LDSV, ACCV, 4); } while (0)
     if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
     else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
+    if (slices > 1) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
@@ -519,6 +546,13 @@ float gdpt_film_render_ms(gdpt_film *f)
 }
 
 void *gdpt_film_stream(gdpt_film *f) { return f ? (void *)f->stream : nullptr; }
+
+int gdpt_film_set_slices(gdpt_film *f, int slices)
+{
+    if (!f || slices < 0) return tfail(GDPT_ERR_INVALID, "slices must be >= 0 (0 = chosen per launch)");
+    f->slices = slices;
+    return GDPT_OK;
+}
 
 int gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd)
 {

@@ -41,6 +41,8 @@ typedef double Float;
 constexpr int TBLK = 256;          // threads per block (16x16 px)
 constexpr int STACK_DEPTH = 28;    // BVH traversal stack entries per lane (LDS)
 constexpr int REGEN_MIN = 24;      // idle lanes in a wave before they regenerate together
+constexpr int SLICE_FILL = 6;      // sample slices: aim at this many work items per resident block slot ...
+constexpr int SLICE_MIN_SPP = 8;   // ... but never fewer samples than this per slice (the end of a slice runs with idle lanes)
 constexpr int NREC = 31;           // per-pixel record components
 constexpr int LDS_SCENE_BYTES = 40 * 1024;   // node + triangle + shading + material + emitter tables of a small scene
 
@@ -117,6 +119,7 @@ struct ConfigD {
 };
 struct FilmD {
     Float *rec;                 // [NREC][recRows][W] per-pixel sample sums; row index = y - (y0 - 1)
+    Float *recExtra;            // [slices-1][NREC][recRows][W]: the sums of sample slices 1.. of a launch, folded into rec after it
     Float *spill;               // [5][recRows][W][4] exact generic puts (R,G,B,weight)
     unsigned long long *stats;  // [4]
     int W, H, y0, y1, recRows;

@@ -417,7 +417,7 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
 }
 
 template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int stackDepth, int sceneBytes)
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
 {
     // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)][per-sample sums (ACC_LDS only)]; sized by the host from
     // the actual BVH depth and table bytes so that small scenes leave room for more resident blocks per CU
@@ -448,7 +448,12 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; }
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    // work item = (16x16 pixel tile, slice of the spp samples).  Slices exist so that a launch smaller than the chip (a strip of
+    // a multi-GPU frame) or the tail of a large one still fills it: each slice sums into its own record plane, folded in order.
+    const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int s0 = (int)((long long)cfg.spp * slice / slices), s1 = (int)((long long)cfg.spp * (slice + 1) / slices);
+    if (slice > 0) F.rec = F.recExtra + (size_t)(slice - 1) * NREC * F.recStride;
     const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool valid = px < rx1 && py < ry1;
     int *stack = s_stack + threadIdx.x;
@@ -458,16 +463,16 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     L.nClosest = L.nShadow = 0;
     Acc<ACC_LDS> A;
     if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_scene + sceneBytes) + threadIdx.x;
-    int next = valid ? 0 : cfg.spp;     // next sample to start
+    int next = valid ? s0 : s1;         // next sample to start
     bool active = false;
     unsigned long long pathLen = 0, paths = 0;
     while (true) {
         const bool idle = !active;
         const unsigned long long idleMask = __ballot(idle);
-        const unsigned long long wantMask = __ballot(idle && next < cfg.spp);
+        const unsigned long long wantMask = __ballot(idle && next < s1);
         if (wantMask == 0 && idleMask == ~0ULL) break;
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
-        if (idle && next < cfg.spp && (__popcll(wantMask) >= REGEN_MIN || idleMask == ~0ULL)) {
+        if (idle && next < s1 && (__popcll(wantMask) >= REGEN_MIN || idleMask == ~0ULL)) {
             active = start_path(S, sv, cfg, stack, L, A, px, py, next);
             next++;
             if (!active) { finish_path(F, flt, L, A, px, py); paths++; pathLen += L.depth; }
@@ -488,6 +493,17 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         atomicAdd(&F.stats[1], (unsigned long long)c1);
         atomicAdd(&F.stats[2], (unsigned long long)c2);
         atomicAdd(&F.stats[3], (unsigned long long)c3);
+    }
+}
+
+// rec += the slice planes, in slice order (a fixed association, so a render is reproducible bit for bit), and clear them
+__global__ __launch_bounds__(TBLK) void k_fold_slices(FilmD F, int slices)
+{
+    const size_t n = (size_t)NREC * F.recStride;
+    for (size_t i = (size_t)blockIdx.x * TBLK + threadIdx.x; i < n; i += (size_t)gridDim.x * TBLK) {
+        Float v = F.rec[i];
+        for (int s = 0; s < slices - 1; s++) { v += F.recExtra[(size_t)s * n + i]; F.recExtra[(size_t)s * n + i] = 0.0; }
+        F.rec[i] = v;
     }
 }
 

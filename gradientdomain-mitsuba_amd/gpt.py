@@ -148,6 +148,10 @@ class Film:
     def set_occupancy(self, waves_per_simd):
         check(lib().gdpt_film_set_occupancy(self._h, int(waves_per_simd)))
 
+    def set_slices(self, slices):
+        """Sample slices per launch (0 = chosen per launch); a tuning knob, see include/gdpt_tracer.h."""
+        check(lib().gdpt_film_set_slices(self._h, int(slices)))
+
     def sync(self):
         check(lib().gdpt_film_sync(self._h))
 

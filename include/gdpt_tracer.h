@@ -114,6 +114,11 @@ GDPT_API void *gdpt_film_stream(gdpt_film *f);
  * 3 or 4 resident waves per SIMD (register budget 512 / n per lane); a negative value selects the same build with the
  * per-sample sums kept in registers instead of LDS.  Results are identical; only speed differs. */
 GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
+/* Tuning knob (no reference counterpart): into how many slices the spp samples of a launch are split (one work item = one
+ * 16x16 tile x one slice).  0 (default) = chosen per launch from the rectangle, spp and the device so that small launches
+ * (strips of a multi-GPU frame) still fill the chip.  Samples and their random numbers do not depend on it; the per-pixel sums
+ * are folded in slice order, so results differ from slices = 1 only in the association of an fp64 sum. */
+GDPT_API int  gdpt_film_set_slices(gdpt_film *f, int slices);
 
 /* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */
 GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *tp4);

@@ -189,11 +189,27 @@ def test_full_size_properties_1280x720x64(G):
     assert np.median(inner) == pytest.approx(8 * spp * c2, rel=1e-12) and (np.abs(inner - 8 * spp * c2) < 10 * c2).all()
     assert (acc[4][..., :3] >= 0).all() and (acc[1][..., :3] >= -1e-12).all()
     # tiles rendered in pieces into one film == the one-call film, bit for bit where no edge-sample atomics landed
-    F2 = G.Film(S)
+    # (sample slices off: a smaller launch would otherwise split its spp over several work items and fold their sums, which
+    # changes the association of the fp64 sums, not the samples)
+    F2 = G.Film(S); F2.set_slices(1)
     for (x0, y0, x1, y1) in ((0, 0, 640, 360), (640, 0, 1280, 360), (0, 360, 1280, 720)):
         integ.renderBlock(S, F2, cfg, (x0, y0, x1, y1))
     acc2 = F2.accum()
     assert np.allclose(acc2, acc, rtol=1e-13, atol=1e-13) and (acc2 == acc).mean() > 0.999
+    F2.close()
+    # the same with the launch's own choice of slices, and with a forced 5 (64 spp does not divide evenly): same samples, same
+    # ray counts, sums equal to rounding; and reproducible bit for bit run to run
+    for slices in (0, 5):
+        runs = []
+        for rep in range(2):
+            F3 = G.Film(S); F3.set_slices(slices)
+            for (x0, y0, x1, y1) in ((0, 0, 640, 360), (640, 0, 1280, 360), (0, 360, 1280, 720)):
+                integ.renderBlock(S, F3, cfg, (x0, y0, x1, y1))
+            runs.append((F3.accum(), F3.stats()))
+            F3.close()
+        assert runs[0][1] == st and np.allclose(runs[0][0], acc, rtol=1e-12, atol=1e-12)
+        # (the rare filter-edge samples go through fp64 atomics whose order is free)
+        assert (runs[0][0] == runs[1][0]).mean() > 0.999
     # spot checks of individual samples against the oracle at this geometry
     O = go.Scene(sc)
     rng = np.random.default_rng(2)
