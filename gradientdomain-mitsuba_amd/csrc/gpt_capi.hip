@@ -201,6 +201,7 @@ struct gdpt_film {
     int wavesPerSimd = 2;       // occupancy target the render kernel is compiled for (register budget = 512 / this)
     bool accInLds = true;       // keep the per-sample sums in LDS when the block budget allows
     int slices = 0;             // sample slices per launch; 0 = chosen per launch
+    int regenMin = REGEN_MIN;   // idle lanes of a wave before they regenerate together
     int extraPlanes = 0;        // record planes allocated behind d.recExtra
     int lastSlices = 1;
 };
@@ -402,6 +403,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     ConfigD c;
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    c.regenMin = f->regenMin;
     const int tilesX = (x1 - x0 + 15) / 16, tilesY = (y1 - y0 + 15) / 16;
     hipEvent_t e0, e1;
     THIPCHK(hipEventCreate(&e0));
@@ -554,6 +556,13 @@ int gdpt_film_set_slices(gdpt_film *f, int slices)
     return GDPT_OK;
 }
 
+int gdpt_film_set_regeneration(gdpt_film *f, int idleLanes)
+{
+    if (!f || idleLanes < 1 || idleLanes > 64) return tfail(GDPT_ERR_INVALID, "regeneration threshold must be 1..64 idle lanes");
+    f->regenMin = idleLanes;
+    return GDPT_OK;
+}
+
 int gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd)
 {
     if (!f || wavesPerSimd < -4 || wavesPerSimd > 4 || wavesPerSimd == 0) return tfail(GDPT_ERR_INVALID, "occupancy target must be 1..4 waves per SIMD (negative: same, with the per-sample sums kept in registers)");
@@ -586,6 +595,7 @@ int gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int
     ConfigD c;
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    c.regenMin = REGEN_MIN;
     double *d = nullptr;
     THIPCHK(hipMalloc((void **)&d, sizeof(double) * 33));
     hipLaunchKernelGGL(k_eval_point, dim3(1), dim3(TBLK), 0, 0, s->d, c, px, py, sample, d);

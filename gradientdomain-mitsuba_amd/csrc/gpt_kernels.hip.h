@@ -7,8 +7,11 @@
 //
 //   * one lane = one pixel, walking its spp base paths with the four offset paths carried alongside;
 //     a wave = an 8x8 pixel tile (coherent primaries), a block = 4 waves.  Lanes whose base path has
-//     ended wait until at least GDPT_REGEN_MIN lanes of the wave are idle, then regenerate together, so
-//     both the "start a sample" code and the "bounce" code run with well-filled exec masks
+//     ended wait until at least regenMin (56) lanes of the wave are idle, then regenerate together.  The first bounce of a
+//     sample (five primaries, four unconnected offsets: ~11 rays) costs as much as all its later bounces together, and in a
+//     wave that mixes the two both codes run every iteration with partial exec masks: measured on the config-2 frame,
+//     regenerating at 24 idle lanes gives 3.5 Gray/s, at 56 4.0 Gray/s, never (64) 3.6 Gray/s -- the late threshold keeps the
+//     first bounces together and still overlaps the few long Russian-roulette survivors with the next generation
 //     (persistent wavefront, no cross-lane state shuffling).
 //   * BVH2 flattened to HBM: 32-byte nodes (fp32 bounds rounded outward, tested in fp64), triangles in
 //     leaf order as 80-byte projection records (the reference's TriAccel test, triaccel.h:96-158, in fp64)
@@ -40,7 +43,7 @@ typedef double Float;
 
 constexpr int TBLK = 256;          // threads per block (16x16 px)
 constexpr int STACK_DEPTH = 28;    // BVH traversal stack entries per lane (LDS)
-constexpr int REGEN_MIN = 24;      // idle lanes in a wave before they regenerate together
+constexpr int REGEN_MIN = 56;      // default number of idle lanes in a wave before they regenerate together (ConfigD::regenMin)
 constexpr int SLICE_FILL = 6;      // sample slices: aim at this many work items per resident block slot ...
 constexpr int SLICE_MIN_SPP = 8;   // ... but never fewer samples than this per slice (the end of a slice runs with idle lanes)
 constexpr int NREC = 31;           // per-pixel record components
@@ -114,6 +117,7 @@ struct SceneD {
 };
 struct ConfigD {
     int maxDepth, rrDepth, strictNormals, spp;
+    int regenMin;               // idle lanes of a wave before they start new samples together (tuning, not a reference parameter)
     Float shiftThreshold;
     unsigned long long seed;
 };

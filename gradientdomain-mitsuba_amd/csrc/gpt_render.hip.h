@@ -472,7 +472,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         const unsigned long long wantMask = __ballot(idle && next < s1);
         if (wantMask == 0 && idleMask == ~0ULL) break;
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
-        if (idle && next < s1 && (__popcll(wantMask) >= REGEN_MIN || idleMask == ~0ULL)) {
+        if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
             active = start_path(S, sv, cfg, stack, L, A, px, py, next);
             next++;
             if (!active) { finish_path(F, flt, L, A, px, py); paths++; pathLen += L.depth; }

@@ -152,6 +152,10 @@ class Film:
         """Sample slices per launch (0 = chosen per launch); a tuning knob, see include/gdpt_tracer.h."""
         check(lib().gdpt_film_set_slices(self._h, int(slices)))
 
+    def set_regeneration(self, idle_lanes):
+        """Idle lanes of a wave before they start new samples together (1..64); a tuning knob."""
+        check(lib().gdpt_film_set_regeneration(self._h, int(idle_lanes)))
+
     def sync(self):
         check(lib().gdpt_film_sync(self._h))
 

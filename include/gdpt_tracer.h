@@ -119,6 +119,9 @@ GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
  * (strips of a multi-GPU frame) still fill the chip.  Samples and their random numbers do not depend on it; the per-pixel sums
  * are folded in slice order, so results differ from slices = 1 only in the association of an fp64 sum. */
 GDPT_API int  gdpt_film_set_slices(gdpt_film *f, int slices);
+/* Tuning knob (no reference counterpart): how many lanes of a wave must be idle before they start new samples together
+ * (1..64, default 56; 64 = only when the whole wave is idle).  Results do not depend on it. */
+GDPT_API int  gdpt_film_set_regeneration(gdpt_film *f, int idleLanes);
 
 /* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */
 GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *tp4);
