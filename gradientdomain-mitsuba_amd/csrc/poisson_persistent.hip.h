@@ -84,6 +84,24 @@ __device__ __forceinline__ float pt_wait(unsigned long long *p, unsigned long lo
     return __uint_as_float((unsigned)w);
 }
 
+// Wave total in every lane without touching LDS: quad, half-row and row steps as DPP adds (every lane of a 16-lane row ends with
+// the row's sum -- the operands only swap sides, so all lanes hold the same bits), then the four row sums through readlane,
+// added in a fixed order.  (__shfl_xor compiles to ds_bpermute_b32 here: 6 dependent LDS round trips per reduction, four
+// reductions per CG iteration on the critical path.)
+__device__ __forceinline__ float pt_wave_sum(float v)
+{
+#define PT_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+    PT_DPP_ADD(0xB1);        // quad_perm:[1,0,3,2]
+    PT_DPP_ADD(0x4E);        // quad_perm:[2,3,0,1]
+    PT_DPP_ADD(0x141);       // row_half_mirror
+    PT_DPP_ADD(0x140);       // row_mirror
+#undef PT_DPP_ADD
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return ((r0 + r1) + r2) + r3;
+}
+
 // All-gather + fixed-order sum of one 3-float partial per workgroup.  `mine` (the same in every thread) is published under
 // `tag`; on return v holds the totals over the G workgroups, identical in every thread of every workgroup.  gsm: >= 3*G floats.
 __device__ __forceinline__ bool pt_allgather_sum(unsigned long long *gat, unsigned tag, int G, int tile, const float (&mine)[3],
@@ -98,7 +116,7 @@ __device__ __forceinline__ bool pt_allgather_sum(unsigned long long *gat, unsign
     const int ln = t & 63;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
     for (int i = ln; i < G; i += 64) { a0 += gsm[3 * i]; a1 += gsm[3 * i + 1]; a2 += gsm[3 * i + 2]; }
-    v[0] = wave_sum(a0); v[1] = wave_sum(a1); v[2] = wave_sum(a2);
+    v[0] = pt_wave_sum(a0); v[1] = pt_wave_sum(a1); v[2] = pt_wave_sum(a2);
     return *s_fail == 0;
 }
 
@@ -107,7 +125,7 @@ __device__ __forceinline__ void pt_block_sum3(float (&a)[3], float *sm, int nwav
 {
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < 3; c++) a[c] = wave_sum(a[c]);
+    for (int c = 0; c < 3; c++) a[c] = pt_wave_sum(a[c]);
     pt_sync();
     if (ln == 0) { sm[wv * 4 + 0] = a[0]; sm[wv * 4 + 1] = a[1]; sm[wv * 4 + 2] = a[2]; }
     pt_sync();
