@@ -128,7 +128,7 @@ struct gdpt_poisson_solver {
     bool ready = false;
 
     float *d_in[4] = {nullptr, nullptr, nullptr, nullptr}; // owned staging when inputs are host pointers
-    float *b = nullptr, *e = nullptr, *w2 = nullptr, *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *Ap = nullptr, *rec = nullptr;
+    float *b = nullptr, *e = nullptr, *w2 = nullptr, *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *Ap = nullptr, *rec = nullptr, *z = nullptr;
     float4 *part_pAp = nullptr, *part_rz = nullptr, *part_w = nullptr;
     float *scal = nullptr; // [0..3] pAp  [4..7] rz_old  [8..11] rz_next
     float *regtab = nullptr;
@@ -179,6 +179,8 @@ struct gdpt_poisson_solver {
         release_graphs();
         float **bufs[] = {&d_in[0], &d_in[1], &d_in[2], &d_in[3], &b, &e, &w2, &x, &r, &p[0], &p[1], &Ap, &rec, &scal, &regtab};
         for (float **q : bufs) { if (*q) hipFree(*q); *q = nullptr; }
+        if (z) hipFree(z);
+        z = nullptr;
         float4 **pb[] = {&part_pAp, &part_rz, &part_w};
         for (float4 **q : pb) { if (*q) hipFree(*q); *q = nullptr; }
         if (counter) hipFree(counter);
@@ -226,6 +228,29 @@ void enqueue_cg_unfused(gdpt_poisson_solver *s, bool unitw, int cg)
     }
 }
 
+// `cg` iterations of the preconditioned form, Solver.cpp:474-489 -- including the reference's choice of handing r (not z) to
+// calc_x_p.  first == (cgIter == 0): z = inv(M) r ; rz = r.z ; p = z.
+void enqueue_cg_precond(gdpt_poisson_solver *s, bool unitw, int cg, bool first)
+{
+    const Lattice L = s->lat();
+    const long n3 = 3 * L.n();
+    hipStream_t st = s->stream;
+    const int Gx = grid_reduce(n3);
+    if (first) {
+        hipLaunchKernelGGL(kg_MIx, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->z, s->w2, s->r, L.W, L.H, L.alpha);
+        hipLaunchKernelGGL(kg_xdoty, dim3(Gx), dim3(BLK), 0, st, s->part_rz, s->r, s->z, (int)n3);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLK), 0, st, s->s_rz_next(), (float *)nullptr, s->part_rz, Gx);
+        hipMemcpyAsync(s->p[0], s->z, sizeof(float) * n3, hipMemcpyDeviceToDevice, st);
+    }
+    for (int k = 0; k < cg; k++) {
+        const int Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
+        launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());   // its r.r is overwritten below
+        hipLaunchKernelGGL(kg_MIx, dim3(grid_generic(n3)), dim3(BLK), 0, st, s->z, s->w2, s->r, L.W, L.H, L.alpha);
+        hipLaunchKernelGGL(kg_xdoty, dim3(Gx), dim3(BLK), 0, st, s->part_rz, s->r, s->z, (int)n3);
+        launch_x_p(st, n3, s->x, s->p[0], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gx, s->s_rz_next());
+    }
+}
+
 // `cg` iterations with x_p(k) fused into the stencil of iteration k+1: 2*cg + 1 kernels.
 void enqueue_cg_fused(gdpt_poisson_solver *s, bool unitw, int cg)
 {
@@ -254,7 +279,7 @@ bool can_fuse(const gdpt_poisson_solver *s) { return s->fusion >= 1 && s->W % 4 
 // image does not fit that scheme (then the multi-kernel graph path runs).
 bool persistent_geometry(gdpt_poisson_solver *s)
 {
-    if (s->fusion < 2 || s->W % 4 != 0 || s->P.cgTolerance != 0.0f || s->P.verbose || s->P.cgIterMax >= 0xffff) return false;
+    if (s->fusion < 2 || s->W % 4 != 0 || s->P.cgTolerance != 0.0f || s->P.verbose || s->P.cgPrecond || s->P.cgIterMax >= 0xffff) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
     const int tilesX = cdiv(s->W, PT_W);
@@ -332,7 +357,6 @@ int gdpt_poisson_params_preset(gdpt_poisson_params *p, const char *preset)
 int gdpt_poisson_create(const gdpt_poisson_params *p, gdpt_poisson_solver **out)
 {
     if (!p || !out) return fail(GDPT_ERR_INVALID, "null argument");
-    if (p->cgPrecond) return fail(GDPT_ERR_UNSUPPORTED, "cgPrecond (Backend::calc_MIx) is not carried by the HIP backend; no reference preset enables it");
     int rc = ensure_device(p->device);
     if (rc) return rc;
     gdpt_poisson_solver *s = new gdpt_poisson_solver;
@@ -412,6 +436,7 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
         HIPCHK(hipMalloc(&s->p[1], B3));
         HIPCHK(hipMalloc(&s->Ap, B3));
         HIPCHK(hipMalloc(&s->rec, B3));
+        if (s->P.cgPrecond) HIPCHK(hipMalloc(&s->z, B3));
         HIPCHK(hipMalloc(&s->part_pAp, sizeof(float4) * MAXP));
         HIPCHK(hipMalloc(&s->part_rz, sizeof(float4) * MAXP));
         HIPCHK(hipMalloc(&s->part_w, sizeof(float4) * MAXP));
@@ -444,7 +469,7 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
     // (re)capture the per-IRLS-iteration graphs when geometry/alpha/fusion changed
     if (s->graph_fusion != s->fusion || s->graph_alpha != s->alpha_eff) {
         s->release_graphs();
-        if (s->P.cgTolerance == 0.0f && !s->P.verbose) {
+        if (s->P.cgTolerance == 0.0f && !s->P.verbose && !s->P.cgPrecond) {
             int rc = capture(s, true, &s->g0);
             if (rc) return rc;
             if (s->P.irlsIterMax > 1) { rc = capture(s, false, &s->gK); if (rc) return rc; }
@@ -483,19 +508,28 @@ int gdpt_poisson_solve_indirect_async(gdpt_poisson_solver *s)
             s->last_iters += s->P.cgIterMax;
         }
     } else {
-        // cgTolerance > 0 or verbose: reference control flow with the host read of r.z every cgIterCheck iterations.
+        // cgTolerance > 0, verbose or cgPrecond: reference control flow with the host read of the error every cgIterCheck iterations.
+        const long n3 = 3L * s->W * s->H;
         for (int irls = 0; irls < s->P.irlsIterMax; irls++) {
             enqueue_irls_prologue(s, irls == 0);
             for (int cg = 0;;) {
                 float rz[3];
-                HIPCHK(hipMemcpyAsync(rz, s->s_rz_next(), sizeof rz, hipMemcpyDeviceToHost, st));
+                const float *src = s->s_rz_next();
+                if (s->P.cgPrecond && cg != 0) {                                   // Solver.cpp:423-429: r.r, not r.z
+                    const int G = grid_reduce(n3);
+                    hipLaunchKernelGGL(kg_xdoty, dim3(G), dim3(BLK), 0, st, s->part_w, s->r, s->r, (int)n3);
+                    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLK), 0, st, s->scal + 12, (float *)nullptr, s->part_w, G);
+                    src = s->scal + 12;
+                }
+                HIPCHK(hipMemcpyAsync(rz, src, sizeof rz, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 const float errL2W = rz[0] + rz[1] + rz[2];
                 if (s->P.verbose)
                     s->log("IRLS = %-3d/ %d, CG = %-4d/ %d, errL2W = %9.2e\n", irls, s->P.irlsIterMax, cg, s->P.cgIterMax, errL2W);
                 if (cg == s->P.cgIterMax || errL2W <= s->P.cgTolerance) break;
                 const int chunk = imin(s->P.cgIterCheck - cg % s->P.cgIterCheck, s->P.cgIterMax - cg);
-                enqueue_cg_unfused(s, irls == 0, chunk);
+                if (s->P.cgPrecond) enqueue_cg_precond(s, irls == 0, chunk, cg == 0);
+                else enqueue_cg_unfused(s, irls == 0, chunk);
                 cg += chunk;
                 s->last_iters += chunk;
             }
@@ -661,6 +695,15 @@ int gdpt_poisson_profile_persistent(gdpt_poisson_solver *s, int reps, float *us)
 // =================================================================================================
 // backend-op level
 // =================================================================================================
+
+int gdpt_backend_calc_MIx(float *MIx, int w, int h, float alpha, const float *w2, const float *x, void *stream)
+{
+    if (!MIx || !w2 || !x || w <= 0 || h <= 0) return fail(GDPT_ERR_INVALID, "calc_MIx: bad argument");
+    const long n3 = 3L * w * h;
+    hipLaunchKernelGGL(kg_MIx, dim3(grid_generic(n3)), dim3(BLK), 0, (hipStream_t)stream, MIx, w2, x, w, h, alpha);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
 
 void *gdpt_backend_alloc(size_t bytes)
 {

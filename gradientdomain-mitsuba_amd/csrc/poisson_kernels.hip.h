@@ -182,6 +182,38 @@ __global__ __launch_bounds__(BLK) void kg_xdoty(float4 *__restrict__ part, const
     if (threadIdx.x == 0) part[blockIdx.x] = make_float4(acc[0], acc[1], acc[2], 0.0f);
 }
 
+// Backend::calc_MIx, Backend.cpp:387-438: z = K' inv(D) K x with K = I - L inv(D), the incomplete-Poisson preconditioner of
+// Ament et al. (cited there).  The reference makes two passes with two n-element temporaries (t = x - Ux/D, DIt = t/D; then
+// MIx = t - L*DIt); DIt of the left and upper neighbour is all the second pass needs, so one pass recomputes those two
+// values (same expression, same bits) instead of storing them.
+__device__ __forceinline__ void mi_t(const float *__restrict__ w2, const float *__restrict__ x, int W, int H, int n, float alphaSqr,
+                                     int xx, int yy, int i, int c, float &t, float &DIt)
+{
+    float Di = w2[i] * alphaSqr;
+    float Uxi = 0.0f;
+    if (xx != 0)     Di = Di + w2[n + i - 1];
+    if (xx != W - 1) { Di = Di + w2[n + i]; Uxi = Uxi - w2[n + i] * x[3 * (i + 1) + c]; }
+    if (yy != 0)     Di = Di + w2[2 * n + i - W];
+    if (yy != H - 1) { Di = Di + w2[2 * n + i]; Uxi = Uxi - w2[2 * n + i] * x[3 * (i + W) + c]; }
+    t = x[3 * i + c] - Uxi / Di;
+    DIt = t / Di;
+}
+
+__global__ __launch_bounds__(BLK) void kg_MIx(float *__restrict__ MIx, const float *__restrict__ w2, const float *__restrict__ x, int W, int H, float alpha)
+{
+    const int n = W * H, n3 = 3 * n;
+    const float alphaSqr = alpha * alpha;
+    for (int f = blockIdx.x * BLK + threadIdx.x; f < n3; f += gridDim.x * BLK) {
+        const int i = f / 3, c = f - 3 * i, yy = i / W, xx = i - yy * W;
+        float t, d, tn, dn;
+        mi_t(w2, x, W, H, n, alphaSqr, xx, yy, i, c, t, d);
+        float L = 0.0f;
+        if (xx != 0) { mi_t(w2, x, W, H, n, alphaSqr, xx - 1, yy, i - 1, c, tn, dn); L = L - w2[n + i - 1] * dn; }
+        if (yy != 0) { mi_t(w2, x, W, H, n, alphaSqr, xx, yy - 1, i - W, c, tn, dn); L = L - w2[2 * n + i - W] * dn; }
+        MIx[f] = t - L;
+    }
+}
+
 // Fixed-order total of block partials into a 3-float device scalar (and an optional second copy).
 __global__ __launch_bounds__(BLK) void k_finalize(float *__restrict__ out, float *__restrict__ out2, const float4 *__restrict__ part, int G)
 {

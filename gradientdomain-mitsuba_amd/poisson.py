@@ -219,6 +219,9 @@ class Backend:
     def calc_x_p(self, x, p, r, rz, rz2, pAp, numElems):
         check(self.L.gdpt_backend_calc_x_p(self._f(x), self._f(p), self._f(r), self._f(rz), self._f(rz2), self._f(pAp), numElems, self.stream))
 
+    def calc_MIx(self, MIx, w, h, alpha, w2, x):
+        check(self.L.gdpt_backend_calc_MIx(self._f(MIx), w, h, C.c_float(alpha), self._f(w2), self._f(x), self.stream))
+
     def calc_w2(self, w2, e, reg, numElems):
         check(self.L.gdpt_backend_calc_w2(self._f(w2), self._f(e), C.c_float(reg), numElems, self.stream))
 

@@ -46,7 +46,7 @@ typedef struct gdpt_poisson_params {
     float irlsRegIter;
     int   cgIterMax;
     int   cgIterCheck;
-    int   cgPrecond;      /* must be 0: calc_MIx is not carried (no preset enables it)          */
+    int   cgPrecond;      /* Solver.cpp:474-489 (calc_MIx); no preset enables it; host-checked loop */
     float cgTolerance;
     int   device;
     int   verbose;
@@ -127,6 +127,7 @@ GDPT_API int   gdpt_backend_calc_xdoty(float *xdoty, const float *x, const float
 GDPT_API int   gdpt_backend_calc_r_rz(float *r, float *rz, const float *Ap, const float *rz2, const float *pAp, int numElems, void *stream); /* :287 */
 GDPT_API int   gdpt_backend_calc_x_p(float *x, float *p, const float *r, const float *rz, const float *rz2, const float *pAp, int numElems, void *stream); /* :319 */
 GDPT_API int   gdpt_backend_calc_w2(float *w2, const float *e, float reg, int numElems, void *stream);                           /* :354 */
+GDPT_API int   gdpt_backend_calc_MIx(float *MIx, int w, int h, float alpha, const float *w2, const float *x, void *stream);      /* :387 */
 GDPT_API int   gdpt_backend_sync(void *stream);
 
 #ifdef __cplusplus
