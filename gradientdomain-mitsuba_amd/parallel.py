@@ -28,6 +28,14 @@ def _wire(t):
     return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
 
 
+def _settle(t):
+    """The HIP library launches on its own streams; torch (RCCL receives, copies, cat) on torch's current stream.  Before a
+    buffer torch produced is handed to the library, that stream has to be finished (req.wait() only orders the STREAM
+    after an RCCL operation, not the host)."""
+    if t is not None and t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def exchange_halos(film, rank, world, device, group=None):
     """film: object with halo_bytes(), pack_halo(which, tensor), unpack_halo(which, tensor) (gpt.Film or a test double).
     which = 0 talks to rank-1 (the strip above), which = 1 to rank+1 (below).  Returns bytes sent."""
@@ -47,7 +55,9 @@ def exchange_halos(film, rank, world, device, group=None):
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     for which, buf in recv.items():
-        film.unpack_halo(which, buf.to(device))
+        buf = buf.to(device)
+        _settle(buf)
+        film.unpack_halo(which, buf)
     return sent
 
 
@@ -57,10 +67,13 @@ def gather_rows(strip, strips, width, rank, world, group=None):
         return strip
     if rank == 0:
         parts = [_wire(torch.empty((y1 - y0, width, 3), dtype=strip.dtype, device=strip.device)) for (y0, y1) in strips]
-        reqs = [dist.irecv(parts[r], r, group=group) for r in range(1, world)]
-        for q in reqs:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, parts[r], r, group=group) for r in range(1, world)]):
             q.wait()
         parts[0] = strip
-        return torch.cat([p.to(strip.device) for p in parts], dim=0)
-    dist.send(_wire(strip.contiguous()), 0, group=group)
+        full = torch.cat([p.to(strip.device) for p in parts], dim=0)
+        _settle(full)
+        return full
+    for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, _wire(strip.contiguous()), 0, group=group)]):
+        q.wait()
+    _settle(strip)          # the library reuses the strip buffer on its own stream next step
     return None
