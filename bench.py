@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-4); 2 is the metric's configuration")
+    ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-height strips instead of rebalancing them after the warm-up pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
     a = ap.parse_args()
     global W, H, PRESET, SCENE
@@ -114,6 +115,7 @@ def main():
 
     def step():
         """-> (rays of this rank, render kernel ms, solve seconds, halo bytes)"""
+        nonlocal film, strip_imgs, strips, y0, y1
         film.clear()
         integ.renderBlock(scene, film, cfg, (0, y0, W, y1))                      # GPTBlockRenderer::process over the strip
         film.sync()
@@ -131,8 +133,25 @@ def main():
         st = film.stats()
         return st["raysTraced"] + st["shadowRaysTraced"], film.render_ms(), solve_s, halo
 
+    def make_strip(y0_, y1_):
+        f = gpt.Film(scene, y0_, y1_)
+        imgs = [torch.empty((y1_ - y0_, W, 3), dtype=torch.float32, device=dev) for _ in range(4)]
+        return f, imgs
+
     for _ in range(a.warmup):
-        step()
+        _, ms, _, _ = step()
+        if world > 1 and not a.no_rebalance:
+            # the reference hands blocks to whichever worker is free; with one strip per GPU the analogue is to move the strip
+            # boundaries by the render times of the warm-up pass (same total image; untimed)
+            tms = torch.tensor([ms], dtype=torch.float64, device=dev)
+            allms = [torch.zeros_like(tms) for _ in range(world)]
+            dist.all_gather(allms, tms)
+            new = parallel.rebalance_strips(strips, [float(v.item()) for v in allms], min_rows=2)
+            if new != strips:
+                strips = new
+                y0, y1 = strips[rank]
+                film.close()
+                film, strip_imgs = make_strip(y0, y1)
     barrier()
     t0 = time.perf_counter()
     rays = 0
@@ -173,7 +192,7 @@ def main():
             "ms_per_step": round(1e3 * wall / a.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (build-authored, %d triangles), G-PT %d spp, %dx%d, fp64 tracer, %s reconstruct (BASELINE configs[%d])" % ("Cornell box" if SCENE == "cornell" else "atrium (Sponza-class stand-in)", desc.ntri, a.spp, W, H, PRESET, a.config - 1),
-                       "maxDepth": MAX_DEPTH, "rrDepth": 5, "parallelism": "row strips x%d + 1-px halo" % world},
+                       "maxDepth": MAX_DEPTH, "rrDepth": 5, "parallelism": "row strips x%d + 1-px halo" % world, "strip_rows": [s1 - s0 for (s0, s1) in strips]},
             "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / samples, 2), "msample_s": round(samples / wall / 1e6, 2),
             "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "render_kernel_mray_s": round(rays / world / (render_ms * 1e-3) / 1e6 * world, 1),
             "halo_bytes_per_rank": halo,

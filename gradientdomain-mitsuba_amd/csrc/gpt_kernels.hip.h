@@ -44,7 +44,7 @@ typedef double Float;
 constexpr int TBLK = 256;          // threads per block (16x16 px)
 constexpr int STACK_DEPTH = 28;    // BVH traversal stack entries per lane (LDS)
 constexpr int REGEN_MIN = 56;      // default number of idle lanes in a wave before they regenerate together (ConfigD::regenMin)
-constexpr int SLICE_FILL = 6;      // sample slices: aim at this many work items per resident block slot ...
+constexpr int SLICE_FILL = 2;      // sample slices: aim at this many work items per resident block slot ...
 constexpr int SLICE_MIN_SPP = 8;   // ... but never fewer samples than this per slice (the end of a slice runs with idle lanes)
 constexpr int NREC = 31;           // per-pixel record components
 constexpr int LDS_SCENE_BYTES = 40 * 1024;   // node + triangle + shading + material + emitter tables of a small scene

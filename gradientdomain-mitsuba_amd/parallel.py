@@ -23,6 +23,36 @@ def row_strips(height, world):
     return out
 
 
+def rebalance_strips(strips, times, min_rows=1):
+    """New contiguous strips [y0, y1) with (approximately) equal render time, from the times the current strips took.
+    The reference balances by handing 32x32 blocks to whichever worker is free (sched.cpp:427-496); with one strip per GPU
+    the analogue is to move the strip boundaries: cost per row is taken as constant inside each old strip, the new
+    boundaries cut the cumulative cost at k/world.  Deterministic (same inputs on every rank -> same partition)."""
+    world = len(strips)
+    height = strips[-1][1]
+    if world == 1 or min(times) <= 0.0:
+        return list(strips)
+    cum = [0.0]                                   # cumulative cost at row boundaries 0..height
+    for (y0, y1), t in zip(strips, times):
+        per_row = float(t) / (y1 - y0)
+        for _ in range(y0, y1):
+            cum.append(cum[-1] + per_row)
+    total = cum[-1]
+    cuts, y = [0], 0
+    for k in range(1, world):
+        target = total * k / world
+        while y < height and cum[y + 1] <= target:
+            y += 1
+        # the boundary nearer to the target
+        if y < height and (target - cum[y]) > (cum[y + 1] - target):
+            y += 1
+        y = max(y, cuts[-1] + min_rows)
+        y = min(y, height - (world - k) * min_rows)
+        cuts.append(y)
+    cuts.append(height)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def _wire(t):
     """gloo (CPU tests, single-GPU functional runs) cannot move device tensors point-to-point: stage through the host."""
     return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t

@@ -105,3 +105,21 @@ def test_row_strips_cover_the_image():
                 continue
             s = parallel.row_strips(H, world)
             assert s[0][0] == 0 and s[-1][1] == H and max(b - a for a, b in s) - min(b - a for a, b in s) <= 1
+
+
+def test_rebalance_strips_equalises_cost():
+    """Boundaries move towards equal render time; partitions stay contiguous, complete and deterministic."""
+    import numpy as np
+    from gradientdomain_mitsuba_amd import parallel as PP
+    strips = PP.row_strips(720, 8)
+    times = [36.5, 37.0, 38.0, 39.0, 39.8, 40.5, 41.0, 41.3]
+    new = PP.rebalance_strips(strips, times, min_rows=2)
+    assert new[0][0] == 0 and new[-1][1] == 720 and all(a[1] == b[0] for a, b in zip(new, new[1:]))
+    cost = np.concatenate([np.full(b - a, t / (b - a)) for (a, b), t in zip(strips, times)])
+    pred = [cost[a:b].sum() for a, b in new]
+    assert max(pred) - min(pred) < 0.6 and max(pred) < max(times) - 1.5
+    assert PP.rebalance_strips(strips, times, min_rows=2) == new
+    assert PP.rebalance_strips([(0, 4), (4, 8)], [1.0, 3.0]) == [(0, 5), (5, 8)]
+    assert PP.rebalance_strips([(0, 1), (1, 2)], [1.0, 9.0]) == [(0, 1), (1, 2)]          # nothing to move
+    assert PP.rebalance_strips([(0, 10)], [5.0]) == [(0, 10)]
+    assert PP.rebalance_strips(PP.row_strips(16, 4), [0.0, 1.0, 1.0, 1.0]) == PP.row_strips(16, 4)   # no timing yet: unchanged
