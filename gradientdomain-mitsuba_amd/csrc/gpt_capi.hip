@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <cstdlib>
 
 using namespace gdpt_tr;
 
@@ -88,27 +89,30 @@ struct Builder {
     int maxDepth = 0;
     explicit Builder(const std::vector<Box> &b) : tb(b), order(b.size()) { for (size_t i = 0; i < b.size(); i++) order[i] = (int)i; }
 
-    void set_bounds(BvhNode &n, const Box &b)
+    static uint32_t leaf_ref(int first, int count) { return BVH_LEAF | ((uint32_t)first << 3) | (uint32_t)(count - 1); }
+
+    Box bounds_of(int first, int count) const
     {
-        for (int i = 0; i < 3; i++) { n.lo[i] = round_down(b.lo[i]); n.hi[i] = round_up(b.hi[i]); }
+        Box b = empty_box();
+        for (int i = first; i < first + count; i++) grow(b, tb[order[i]]);
+        return b;
     }
 
-    int build(int first, int count, int depth)
+    int leafMax = 2;            // split while a node holds more triangles than this (measured: 1 -> 4.40, 2 -> 4.56, 4 -> 4.04, 8 -> 4.16 Gray/s, Cornell)
+
+    // Returns the reference of the subtree over order[first .. first+count): a leaf reference, or the index of a new inner node.
+    uint32_t build(int first, int count, int depth)
     {
-        const int me = (int)nodes.size();
-        nodes.push_back(BvhNode());
         maxDepth = std::max(maxDepth, depth);
-        Box bounds = empty_box(), cb = empty_box();
+        Box cb = empty_box();
         for (int i = first; i < first + count; i++) {
-            grow(bounds, tb[order[i]]);
             Box c;
             for (int a = 0; a < 3; a++) c.lo[a] = c.hi[a] = 0.5 * (tb[order[i]].lo[a] + tb[order[i]].hi[a]);
             grow(cb, c);
         }
-        set_bounds(nodes[me], bounds);
         int axis = -1, splitBin = -1;
         const int NB = 16;
-        if (count > 4) {
+        if (count > leafMax && depth < STACK_DEPTH - 2) {
             double best = INFINITY;
             for (int a = 0; a < 3; a++) {
                 const double ext = cb.hi[a] - cb.lo[a];
@@ -139,36 +143,36 @@ struct Builder {
                 }
             }
         }
+        int nl;
         if (axis < 0) {
-            if (count <= 8 || depth >= STACK_DEPTH - 2) {     // leaf
-                nodes[me].a = (uint32_t)first;
-                nodes[me].b = 0x80000000u | (uint32_t)count;
-                return me;
-            }
-            // degenerate centroids: median split by index
-            const int mid = first + count / 2;
-            const int l = build(first, mid - first, depth + 1), r = build(mid, first + count - mid, depth + 1);
-            nodes[me].a = (uint32_t)l; nodes[me].b = (uint32_t)r;
-            return me;
+            // no SAH split: small enough, too deep (bounded leaf scan instead of a stack overflow), or degenerate centroids
+            if (count <= 8) return leaf_ref(first, count);
+            if (depth >= STACK_DEPTH - 2) { tooDeep = true; return leaf_ref(first, 8); }
+            nl = count / 2;                                   // degenerate centroids: median split by index
+        } else {
+            const double ext = cb.hi[axis] - cb.lo[axis];
+            auto binOf = [&](int t) {
+                int bin = (int)(NB * ((0.5 * (tb[t].lo[axis] + tb[t].hi[axis]) - cb.lo[axis]) / ext));
+                return std::min(NB - 1, std::max(0, bin));
+            };
+            int *b0 = order.data() + first;
+            int *mid = std::partition(b0, b0 + count, [&](int t) { return binOf(t) <= splitBin; });
+            nl = (int)(mid - b0);
+            if (nl == 0 || nl == count) nl = count / 2;
         }
-        const double ext = cb.hi[axis] - cb.lo[axis];
-        auto binOf = [&](int t) {
-            int bin = (int)(NB * ((0.5 * (tb[t].lo[axis] + tb[t].hi[axis]) - cb.lo[axis]) / ext));
-            return std::min(NB - 1, std::max(0, bin));
-        };
-        int *b0 = order.data() + first;
-        int *mid = std::partition(b0, b0 + count, [&](int t) { return binOf(t) <= splitBin; });
-        int nl = (int)(mid - b0);
-        if (nl == 0 || nl == count) nl = count / 2;
-        if (depth >= STACK_DEPTH - 2) {                       // depth guard: stop splitting (bounded leaf scan instead of stack overflow)
-            nodes[me].a = (uint32_t)first;
-            nodes[me].b = 0x80000000u | (uint32_t)count;
-            return me;
+        const int me = (int)nodes.size();
+        nodes.push_back(BvhNode());
+        const uint32_t l = build(first, nl, depth + 1), r = build(first + nl, count - nl, depth + 1);
+        const Box bl = bounds_of(first, nl), br = bounds_of(first + nl, count - nl);
+        BvhNode &n = nodes[me];
+        for (int i = 0; i < 3; i++) {
+            n.lo[0][i] = round_down(bl.lo[i]); n.hi[0][i] = round_up(bl.hi[i]);
+            n.lo[1][i] = round_down(br.lo[i]); n.hi[1][i] = round_up(br.hi[i]);
         }
-        const int l = build(first, nl, depth + 1), r = build(first + nl, count - nl, depth + 1);
-        nodes[me].a = (uint32_t)l; nodes[me].b = (uint32_t)r;
-        return me;
+        n.child[0] = l; n.child[1] = r; n.pad[0] = n.pad[1] = 0;
+        return (uint32_t)me;
     }
+    bool tooDeep = false;
 };
 
 template <class T>
@@ -227,8 +231,12 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
         for (int v = 0; v < 3; v++)
             for (int a = 0; a < 3; a++) { const double c = verts[9 * i + 3 * v + a]; tb[i].lo[a] = std::min(tb[i].lo[a], c); tb[i].hi[a] = std::max(tb[i].hi[a], c); }
     }
+    if ((long)numTris >= (1L << 28)) return tfail(GDPT_ERR_UNSUPPORTED, "more than 2^28 triangles");
     Builder bld(tb);
-    bld.build(0, numTris, 0);
+    if (const char *e = getenv("GDPT_BVH_LEAF")) bld.leafMax = std::max(1, std::min(8, atoi(e)));   // experiment knob (tools/gpu_leaf_sweep.py)
+    const uint32_t rootRef = bld.build(0, numTris, 0);
+    if (bld.tooDeep) return tfail(GDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (%d levels) on degenerate geometry", STACK_DEPTH);
+    if (bld.nodes.empty()) bld.nodes.push_back(BvhNode());        // a scene of one leaf: keep the table non-empty
 
     std::vector<int> emitterOf(numTris, -1);
     for (int e = 0; e < numEmitters; e++) {
@@ -316,6 +324,7 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     d.nodes = dn; d.isect = di; d.shade = ds; d.mats = dm; d.emitters = de; d.emTris = det; d.emCdf = dc; d.emitterCdf = dsc;
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = numEmitters;
+    d.rootRef = rootRef;
     d.numMats = numMaterials;
     s->ldsSceneBytes = (((size_t)d.numNodes * sizeof(BvhNode) + 15) & ~(size_t)15) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) +
                        (size_t)numMaterials * sizeof(MaterialD) + (size_t)numEmitters * sizeof(EmitterD) + 64;

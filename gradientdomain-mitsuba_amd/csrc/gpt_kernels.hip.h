@@ -13,7 +13,8 @@
 //     regenerating at 24 idle lanes gives 3.5 Gray/s, at 56 4.0 Gray/s, never (64) 3.6 Gray/s -- the late threshold keeps the
 //     first bounces together and still overlaps the few long Russian-roulette survivors with the next generation
 //     (persistent wavefront, no cross-lane state shuffling).
-//   * BVH2 flattened to HBM: 32-byte nodes (fp32 bounds rounded outward, tested in fp64), triangles in
+//   * BVH2 flattened to HBM: 64-byte inner nodes holding both children's fp32 bounds (rounded outward, tested in fp64) and
+//     references (leaves of <= 2 triangles are referenced directly and cost no node fetch), triangles in
 //     leaf order as 80-byte projection records (the reference's TriAccel test, triaccel.h:96-158, in fp64)
 //     plus 160-byte shading records.  Scenes whose node+triangle arrays fit the LDS budget are staged into
 //     LDS once per block; the traversal stack always lives in LDS ([level][lane], conflict-free).
@@ -70,10 +71,15 @@ __device__ __forceinline__ Float signum(Float v) { return v < 0 ? -1.0 : (v > 0 
 __device__ __forceinline__ Float comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // ---- device scene ---------------------------------------------------------------------------------
-struct BvhNode {            // 32 B.  leaf: b has the top bit set, a = first triangle, b & 0x7fffffff = count
-    float lo[3], hi[3];
-    uint32_t a, b;
+// 64 B inner node: the bounds of BOTH children (fp32, rounded outward on the host) and their references, so a visit is one
+// record and a leaf never costs a node fetch.  Reference: top bit set = leaf, (first triangle << 3) | (count - 1); else the
+// index of an inner node.
+struct BvhNode {
+    float lo[2][3], hi[2][3];
+    uint32_t child[2];
+    uint32_t pad[2];
 };
+constexpr uint32_t BVH_LEAF = 0x80000000u;
 struct TriIsect {           // 80 B: the reference's TriAccel (triaccel.h:37-57) in fp64
     Float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_nv;
     int k, pad;
@@ -113,6 +119,7 @@ struct SceneD {
     const Float *emitterCdf;    // scene-level emitter cdf (numEmitters + 1)
     Float emitterNormalization;
     int numNodes, numTris, numEmitters, numMats, ldsScene;
+    uint32_t rootRef;
     CameraD cam;
 };
 struct ConfigD {
@@ -167,6 +174,7 @@ struct SceneView {
     const TriShade *shade;
     const MaterialD *mats;
     const EmitterD *emitters;
+    uint32_t rootRef;
 };
 
 // TriAccel::rayIntersect, triaccel.h:96-158
@@ -187,13 +195,13 @@ __device__ __forceinline__ bool tri_test(const TriIsect &ta, d3 o, d3 d, Float m
 }
 
 // fp64 slab test against fp32 bounds that were rounded outward on the host (so no true hit is ever culled).
-__device__ __forceinline__ bool box_test(const BvhNode &n, d3 o, d3 rd, Float mint, Float maxt, Float &tn)
+__device__ __forceinline__ bool box_test(const float (&lo)[3], const float (&hi)[3], d3 o, d3 rd, Float mint, Float maxt, Float &tn)
 {
-    Float t0 = ((Float)n.lo[0] - o.x) * rd.x, t1 = ((Float)n.hi[0] - o.x) * rd.x;
+    Float t0 = ((Float)lo[0] - o.x) * rd.x, t1 = ((Float)hi[0] - o.x) * rd.x;
     Float tmin = fmin(t0, t1), tmax = fmax(t0, t1);
-    t0 = ((Float)n.lo[1] - o.y) * rd.y; t1 = ((Float)n.hi[1] - o.y) * rd.y;
+    t0 = ((Float)lo[1] - o.y) * rd.y; t1 = ((Float)hi[1] - o.y) * rd.y;
     tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-    t0 = ((Float)n.lo[2] - o.z) * rd.z; t1 = ((Float)n.hi[2] - o.z) * rd.z;
+    t0 = ((Float)lo[2] - o.z) * rd.z; t1 = ((Float)hi[2] - o.z) * rd.z;
     tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
     tn = tmin;
     // widen by 2 ulp-ish so that fp64 rounding in the slab arithmetic itself cannot cull a boundary hit
@@ -211,38 +219,34 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
     if (!(maxt > mint)) return false;
     const d3 rd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     int sp = 0;
-    uint32_t node = 0;
-    {
-        Float tn;
-        if (!box_test(sv.nodes[0], o, rd, mint, maxt, tn)) return false;
-    }
+    uint32_t ref = sv.rootRef;
     while (true) {
-        const BvhNode n = sv.nodes[node];
-        if (n.b & 0x80000000u) {
-            const uint32_t cnt = n.b & 0x7fffffffu;
+        if (ref & BVH_LEAF) {
+            const uint32_t first = (ref & ~BVH_LEAF) >> 3, cnt = (ref & 7u) + 1u;
             for (uint32_t i = 0; i < cnt; i++) {
                 Float u, v, t;
-                if (tri_test(sv.isect[n.a + i], o, d, mint, maxt, u, v, t)) {
+                if (tri_test(sv.isect[first + i], o, d, mint, maxt, u, v, t)) {
                     if (ANY) return true;
                     maxt = t;
-                    hit.t = t; hit.u = u; hit.v = v; hit.prim = (int)(n.a + i);
+                    hit.t = t; hit.u = u; hit.v = v; hit.prim = (int)(first + i);
                 }
             }
         } else {
+            const BvhNode n = sv.nodes[ref];
             Float tl, tr;
-            const bool hl = box_test(sv.nodes[n.a], o, rd, mint, maxt, tl);
-            const bool hr = box_test(sv.nodes[n.b], o, rd, mint, maxt, tr);
+            const bool hl = box_test(n.lo[0], n.hi[0], o, rd, mint, maxt, tl);
+            const bool hr = box_test(n.lo[1], n.hi[1], o, rd, mint, maxt, tr);
             if (hl && hr) {
                 const bool leftFirst = tl <= tr;
-                if (sp < STACK_DEPTH) { stack[sp * TBLK] = leftFirst ? n.b : n.a; sp++; }
-                node = leftFirst ? n.a : n.b;
+                if (sp < STACK_DEPTH) { stack[sp * TBLK] = (int)(leftFirst ? n.child[1] : n.child[0]); sp++; }
+                ref = leftFirst ? n.child[0] : n.child[1];
                 continue;
-            } else if (hl) { node = n.a; continue; }
-            else if (hr) { node = n.b; continue; }
+            } else if (hl) { ref = n.child[0]; continue; }
+            else if (hr) { ref = n.child[1]; continue; }
         }
         if (sp == 0) break;
         sp--;
-        node = (uint32_t)stack[sp * TBLK];
+        ref = (uint32_t)stack[sp * TBLK];
     }
     return hit.prim >= 0;
 }

@@ -446,6 +446,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         sv.mats = reinterpret_cast<const MaterialD *>(s_scene + offs[3]);
         sv.emitters = reinterpret_cast<const EmitterD *>(s_scene + offs[4]);
     } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; }
+    sv.rootRef = S.rootRef;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // work item = (16x16 pixel tile, slice of the spp samples).  Slices exist so that a launch smaller than the chip (a strip of
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     if (i >= n) return;
     const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef;
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
