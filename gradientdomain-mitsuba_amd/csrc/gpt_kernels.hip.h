@@ -218,20 +218,13 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
     hit.t = GD_INF;
     if (!(maxt > mint)) return false;
     const d3 rd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    // "while-while" form: every lane first walks inner nodes until it holds a leaf (or is done), then the wave tests its
+    // leaves together -- the two codes run with fuller exec masks than one loop that alternates per lane.
+    constexpr uint32_t DONE = 0xffffffffu;                 // never a valid reference (a leaf's first triangle is < 2^28)
     int sp = 0;
     uint32_t ref = sv.rootRef;
     while (true) {
-        if (ref & BVH_LEAF) {
-            const uint32_t first = (ref & ~BVH_LEAF) >> 3, cnt = (ref & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; i++) {
-                Float u, v, t;
-                if (tri_test(sv.isect[first + i], o, d, mint, maxt, u, v, t)) {
-                    if (ANY) return true;
-                    maxt = t;
-                    hit.t = t; hit.u = u; hit.v = v; hit.prim = (int)(first + i);
-                }
-            }
-        } else {
+        while (!(ref & BVH_LEAF)) {
             const BvhNode n = sv.nodes[ref];
             Float tl, tr;
             const bool hl = box_test(n.lo[0], n.hi[0], o, rd, mint, maxt, tl);
@@ -240,9 +233,20 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
                 const bool leftFirst = tl <= tr;
                 if (sp < STACK_DEPTH) { stack[sp * TBLK] = (int)(leftFirst ? n.child[1] : n.child[0]); sp++; }
                 ref = leftFirst ? n.child[0] : n.child[1];
-                continue;
-            } else if (hl) { ref = n.child[0]; continue; }
-            else if (hr) { ref = n.child[1]; continue; }
+            } else if (hl) ref = n.child[0];
+            else if (hr) ref = n.child[1];
+            else if (sp == 0) ref = DONE;
+            else { sp--; ref = (uint32_t)stack[sp * TBLK]; }
+        }
+        if (ref == DONE) break;
+        const uint32_t first = (ref & ~BVH_LEAF) >> 3, cnt = (ref & 7u) + 1u;
+        for (uint32_t i = 0; i < cnt; i++) {
+            Float u, v, t;
+            if (tri_test(sv.isect[first + i], o, d, mint, maxt, u, v, t)) {
+                if (ANY) return true;
+                maxt = t;
+                hit.t = t; hit.u = u; hit.v = v; hit.prim = (int)(first + i);
+            }
         }
         if (sp == 0) break;
         sp--;
