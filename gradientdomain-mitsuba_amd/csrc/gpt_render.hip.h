@@ -466,6 +466,10 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_scene + sceneBytes) + threadIdx.x;
     int next = valid ? s0 : s1;         // next sample to start
     bool active = false;
+    bool pending = false;               // a finished sample whose sums still sit in A: flushed to the pixel record when the lane
+                                        // regenerates (together with >= regenMin others) or at the end -- not one lane at a time
+                                        // (31 loads + 31 stores per flush; done per finished path they were ~1e9 wave-level memory
+                                        // instructions per frame issued for one or two lanes each, with their latency exposed)
     unsigned long long pathLen = 0, paths = 0;
     while (true) {
         const bool idle = !active;
@@ -474,18 +478,21 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         if (wantMask == 0 && idleMask == ~0ULL) break;
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
+            if (pending) finish_path(F, flt, L, A, px, py);
             active = start_path(S, sv, cfg, stack, L, A, px, py, next);
             next++;
-            if (!active) { finish_path(F, flt, L, A, px, py); paths++; pathLen += L.depth; }
+            pending = !active;
+            if (!active) { paths++; pathLen += L.depth; }
         }
         if (active) {
             if (!bounce(S, sv, cfg, stack, L, A)) {
                 active = false;
-                finish_path(F, flt, L, A, px, py);
+                pending = true;
                 paths++; pathLen += L.depth;
             }
         }
     }
+    if (pending) finish_path(F, flt, L, A, px, py);
     // statistics: wave-level integer reduction, one atomic per wave and counter
     const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
     const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
