@@ -33,9 +33,9 @@ SCENE = "cornell"
 CONFIGS = {1: ("cornell", 512, 512, 64, "L2D"), 2: ("cornell", 1280, 720, 64, "L2D"), 3: ("atrium", 1920, 1080, 256, "L1D"), 4: ("atrium", 3840, 2160, 256, "L2D")}
 BYTES_PER_PIX_ITER = {"L2D": 120.0, "L1D": 132.0}     # SURVEY.md 8(d), fp32, reference 3-op formulation
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s
-# HBM-side bytes per launch of the dominant CG kernel from the PMC passes of profiles/r01c_hotpath_1280x720x64_pmc.csv
+# HBM-side bytes per launch of the dominant CG kernel from the PMC passes of profiles/r01d_hotpath_1280x720x64_pmc.csv
 # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KiB); PMC counters cannot be read inside a plain bench run.
-PROFILED_TRAFFIC = {("kp_cg", 2): (2 * 53840.5 + 105740.3) * 1024.0}
+PROFILED_TRAFFIC = {("kp_cg", 2): (2 * 53980.5 + 105749.8) * 1024.0}
 
 
 def _usable_cores():
@@ -239,13 +239,13 @@ def main():
             "halo_bytes_per_rank": halo,
             "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PROFILED_TRAFFIC.get((kname, a.config)),
-                         "traffic_source": "profiles/r01c_hotpath_1280x720x64_pmc.csv" if (kname, a.config) in PROFILED_TRAFFIC else None,
+                         "traffic_source": "profiles/r01d_hotpath_1280x720x64_pmc.csv" if (kname, a.config) in PROFILED_TRAFFIC else None,
                          "what": "dominant Poisson CG kernel: algorithmic bytes per launch (%g B/pix-iter, SURVEY 8d) / HIP-event launch duration" % bpi,
                          "kernel": kname, "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
                          "solve_achieved": round(solve_achieved, 1), "solve_frac": round(solve_achieved / HBM_PEAK_GBS, 4),
                          "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2), "kp_cg": round(pus, 2)}},
         }
-        if not a.no_cpu_baseline and a.config == 2:
+        if not a.no_cpu_baseline and a.config == 2 and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)
         print(json.dumps(out))
     if solver:
