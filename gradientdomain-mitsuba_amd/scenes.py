@@ -114,7 +114,28 @@ class _Builder:
                      self.materials, self.emitters, **cam)
 
 
-def cornell_box(width=512, height=512, variant="diffuse"):
+def _random_material(rng):
+    """One material drawn from everything the path carries (fuzz tests)."""
+    kind = int(rng.integers(0, 6))
+    metal = {"eta": tuple(float(v) for v in rng.uniform(0.1, 2.5, 3)), "k": tuple(float(v) for v in rng.uniform(1.5, 7.0, 3))}
+    if kind == 0:
+        m = diffuse(tuple(float(v) for v in rng.uniform(0.05, 0.9, 3)))
+    elif kind == 1:
+        m = conductor(**metal)
+    elif kind in (2, 3):
+        au = float(10.0 ** rng.uniform(-3.3, -0.4))                      # straddles shiftThreshold = 1e-3
+        m = roughconductor(au, **metal, distribution=DISTR_GGX if rng.random() < 0.5 else DISTR_BECKMANN,
+                           alphaV=float(au * rng.uniform(0.3, 3.0)) if rng.random() < 0.5 else None, sampleVisible=bool(rng.random() < 0.7))
+    elif kind == 4:
+        m = dielectric(int_ior=float(rng.uniform(1.2, 2.4)), ext_ior=float(rng.uniform(1.0, 1.1)))
+    else:
+        m = diffuse(tuple(float(v) for v in rng.uniform(0.05, 0.9, 3)))
+    if m["type"] != 3 and rng.random() < 0.3:
+        m = twosided(m)
+    return m
+
+
+def cornell_box(width=512, height=512, variant="diffuse", seed=0):
     """The Cornell box (Cornell Program of Computer Graphics measurement data, 555-unit room), all triangle meshes:
     5 walls, short block, tall block, one area-light quad.  variant: "diffuse" (BASELINE configs 1-2) |
     "glossy" (rough-copper floor, mirror back wall, GGX block: exercises the half-vector shift) | "nearspecular"."""
@@ -139,6 +160,9 @@ def cornell_box(width=512, height=512, variant="diffuse"):
     elif variant == "twosided":       # two-sided walls and a free-standing two-sided GGX panel lit and seen from both faces
         white = b.material(twosided(diffuse((0.725, 0.71, 0.68))))
         floor_m = back_m = tall_m = short_m = white
+    elif variant == "random":         # fuzz: floor, back wall and both blocks draw their materials from `seed`
+        rng = np.random.default_rng(seed)
+        floor_m, back_m, tall_m, short_m = (b.material(_random_material(rng)) for _ in range(4))
     else:
         tall_m = short_m = white
     room = (278.0, 274.4, 279.6)

@@ -64,6 +64,30 @@ def test_samples_match_oracle(G, variant, md):
             assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (variant, px, py, s, k)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzzed_materials_and_settings_match_oracle(G, seed):
+    """Random materials (all carried BSDFs, both distributions, anisotropic and near-specular roughness, visible-normal
+    sampling on/off, two-sided wrappers, dielectrics of random IOR) on the Cornell geometry, random integrator settings,
+    random (pixel, sample) probes: every output of evaluatePoint and both ray counters against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = 40, 32
+    sc = scenes.cornell_box(W, H, "random", seed=seed)
+    md = int(rng.choice([-1, 2, 3, 5, 9]))
+    rr = int(rng.choice([1, 3, 5]))
+    strict = bool(rng.random() < 0.35)
+    thr = float(rng.choice([0.001, 0.02, 0.0]))
+    S = G.Scene(sc); O = go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, rrDepth=rr, strictNormals=strict, shiftThreshold=thr)
+    cfg = integ.config(8)
+    ocfg = go.config(maxDepth=md, rrDepth=rr, strictNormals=strict, spp=8, shiftThreshold=thr)
+    for _ in range(60):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 8))
+        g = S.evaluate_point(cfg, px, py, s); o = O.evaluate_point(ocfg, px, py, s)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-9, atol=1e-13), (seed, px, py, s, key, g[key], o[key])
+    S.close(); O.close()
+
+
 @pytest.mark.parametrize("variant,W,H,spp,md,strict", [("diffuse", 48, 40, 6, -1, False), ("glossy", 40, 40, 6, 9, False),
                                                         ("nearspecular", 32, 32, 5, 8, True), ("diffuse", 35, 21, 3, 2, False),
                                                         ("twosided", 40, 36, 6, 9, False), ("twosided", 24, 24, 4, 6, True),
@@ -79,6 +103,26 @@ def test_film_matches_oracle(G, variant, W, H, spp, md, strict):
     assert st["paths"] == W * H * spp
     for b in range(5):
         assert close(acc[b], oacc[b]), (G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+
+
+@pytest.mark.parametrize("seed", range(100, 106))
+def test_fuzzed_films_match_oracle(G, seed):
+    """Whole small films of fuzzed scenes: the five buffers and both ray counters, with odd sizes, odd spp, forced slices and
+    regeneration thresholds (none of which may change a result beyond the association of the per-pixel sums)."""
+    rng = np.random.default_rng(seed)
+    W, H, spp = int(rng.integers(17, 40)), int(rng.integers(9, 30)), int(rng.integers(1, 7))
+    sc = scenes.cornell_box(W, H, "random", seed=seed)
+    md, strict = int(rng.choice([-1, 3, 7])), bool(rng.random() < 0.3)
+    S = G.Scene(sc); F = G.Film(S)
+    F.set_slices(int(rng.integers(0, spp + 1))); F.set_regeneration(int(rng.choice([1, 24, 56, 64])))
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    oacc, orays = go.Scene(sc).render(go.config(maxDepth=md, spp=spp, strictNormals=strict))
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays and st["paths"] == W * H * spp
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (seed, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    F.close(); S.close()
 
 
 def test_atrium_hbm_bvh_film_matches_oracle(G):
