@@ -215,9 +215,17 @@ extern "C" {
 int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, int numMaterials, const gdpt_material *materials,
                       int numEmitters, const gdpt_emitter *emitters, const gdpt_camera *camera, int device, gdpt_scene **out)
 {
+    return gdpt_scene_create_env(numTris, verts, triMaterial, numMaterials, materials, numEmitters, emitters, nullptr, camera, device, out);
+}
+
+int gdpt_scene_create_env(int numTris, const double *verts, const int *triMaterial, int numMaterials, const gdpt_material *materials,
+                          int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env, const gdpt_camera *camera, int device, gdpt_scene **out)
+{
     if (!verts || !triMaterial || !materials || !camera || !out || numTris <= 0 || numMaterials <= 0)
         return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
-    if (numEmitters <= 0 || !emitters) return tfail(GDPT_ERR_INVALID, "scene_create: at least one area emitter is required");
+    if (numEmitters < 0 || (numEmitters > 0 && !emitters)) return tfail(GDPT_ERR_INVALID, "scene_create: bad emitter list");
+    if (numEmitters == 0 && !env) return tfail(GDPT_ERR_INVALID, "scene_create: at least one emitter (area or environment) is required");
+    const int envIndex = env ? ((env->index < 0 || env->index > numEmitters) ? numEmitters : env->index) : -1;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return tfail(GDPT_ERR_NO_DEVICE, "no HIP device visible: the gfx950 tracer has no CPU fallback");
     if (device >= 0) { if (device >= count) return tfail(GDPT_ERR_INVALID, "device out of range"); THIPCHK(hipSetDevice(device)); }
@@ -242,7 +250,7 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     for (int e = 0; e < numEmitters; e++) {
         if (emitters[e].firstTri < 0 || emitters[e].numTris <= 0 || emitters[e].firstTri + emitters[e].numTris > numTris)
             return tfail(GDPT_ERR_INVALID, "emitter %d triangle range out of bounds", e);
-        for (int i = 0; i < emitters[e].numTris; i++) emitterOf[emitters[e].firstTri + i] = e;
+        for (int i = 0; i < emitters[e].numTris; i++) emitterOf[emitters[e].firstTri + i] = (envIndex >= 0 && e >= envIndex) ? e + 1 : e;   // index in the scene's emitter list
     }
 
     // triangle records in leaf order
@@ -284,11 +292,19 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     }
 
     // emitters: DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h:95-108), scene-level emitter pdf (scene.cpp:357-380)
-    std::vector<EmitterD> ems(numEmitters);
+    const int totalEmitters = numEmitters + (env ? 1 : 0);
+    std::vector<EmitterD> ems(totalEmitters);
     std::vector<EmTri> emTris;
     std::vector<double> emCdf, sceneCdf(1, 0.0);
-    for (int e = 0; e < numEmitters; e++) {
-        EmitterD &o = ems[e];
+    for (int slot = 0, e = 0; slot < totalEmitters; slot++) {
+        EmitterD &o = ems[slot];
+        if (slot == envIndex) {                               // `constant` environment emitter: no triangles
+            o.firstEmTri = 0; o.numTris = 0; o.cdfOffset = 0; o.pad = 0;
+            o.radiance = to_d3(h3(env->radiance[0], env->radiance[1], env->radiance[2]));
+            o.invSurfaceArea = 0.0;
+            sceneCdf.push_back(sceneCdf.back() + 1.0);
+            continue;
+        }
         o.firstEmTri = (int)emTris.size(); o.numTris = emitters[e].numTris; o.cdfOffset = (int)emCdf.size(); o.pad = 0;
         o.radiance = to_d3(h3(emitters[e].radiance[0], emitters[e].radiance[1], emitters[e].radiance[2]));
         std::vector<double> cdf(1, 0.0);
@@ -306,6 +322,7 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
         o.invSurfaceArea = 1.0 / sum;
         emCdf.insert(emCdf.end(), cdf.begin(), cdf.end());
         sceneCdf.push_back(sceneCdf.back() + 1.0);
+        e++;
     }
     const double sceneNorm = 1.0 / sceneCdf.back();
     for (size_t i = 1; i < sceneCdf.size(); i++) sceneCdf[i] *= sceneNorm;
@@ -323,13 +340,36 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
     s->allocs = {dn, di, ds, dm, de, det, dc, dsc};
     d.nodes = dn; d.isect = di; d.shade = ds; d.mats = dm; d.emitters = de; d.emTris = det; d.emCdf = dc; d.emitterCdf = dsc;
     d.emitterNormalization = sceneNorm;
-    d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = numEmitters;
+    d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = totalEmitters;
     d.rootRef = rootRef;
+    d.envIndex = envIndex;
+    if (env) {
+        // ConstantBackgroundEmitter::createShape (constant.cpp:67-70): bounding sphere of Scene::getAABB() at that moment = the
+        // kd-tree's AABB (enlarged by MTS_KD_AABB_EPSILON, gkdtree.h:1213-1219 -- the second line sees the moved min) + the
+        // sensor's position (scene.cpp:386-395), radius x 1.5f
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < numTris; i++)
+            for (int v = 0; v < 3; v++)
+                for (int a = 0; a < 3; a++) { const double c = verts[9 * i + 3 * v + a]; mn[a] = std::min(mn[a], c); mx[a] = std::max(mx[a], c); }
+        const double eps = (double)1e-3f;
+        double ctr[3], r2 = 0.0;
+        for (int a = 0; a < 3; a++) {
+            mn[a] = mn[a] - ((mx[a] - mn[a]) * eps + eps);
+            mx[a] = mx[a] + ((mx[a] - mn[a]) * eps + eps);
+            const double cam = camera->toWorld[4 * a + 3];
+            mn[a] = std::min(mn[a], cam); mx[a] = std::max(mx[a], cam);
+            ctr[a] = (mx[a] + mn[a]) * 0.5;
+        }
+        const double dx = ctr[0] - mx[0], dy = ctr[1] - mx[1], dz = ctr[2] - mx[2];
+        r2 = dx * dx + dy * dy + dz * dz;
+        d.bsCenter = to_d3(h3(ctr[0], ctr[1], ctr[2]));
+        d.bsRadius = std::max((double)GD_EPSILON, std::sqrt(r2) * (double)1.5f);
+    }
     d.numMats = numMaterials;
     s->ldsSceneBytes = (((size_t)d.numNodes * sizeof(BvhNode) + 15) & ~(size_t)15) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) +
-                       (size_t)numMaterials * sizeof(MaterialD) + (size_t)numEmitters * sizeof(EmitterD) + 64;
+                       (size_t)numMaterials * sizeof(MaterialD) + (size_t)totalEmitters * sizeof(EmitterD) + 64;
     d.ldsScene = ((size_t)d.numNodes * sizeof(BvhNode) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) + (size_t)numMaterials * sizeof(MaterialD) +
-                      (size_t)numEmitters * sizeof(EmitterD) + 64 <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
+                      (size_t)totalEmitters * sizeof(EmitterD) + 64 <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
     CameraD &c = d.cam;
     for (int r = 0; r < 3; r++)
         for (int k = 0; k < 4; k++) c.m[4 * r + k] = camera->toWorld[4 * r + k];
@@ -424,7 +464,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     size_t lds = (size_t)stackDepth * TBLK * sizeof(int);
     const int sceneBytes = s->d.ldsScene ? (int)((s->ldsSceneBytes + 15) & ~(size_t)15) : 0;
     lds += sceneBytes;
-    const int wps = f->wavesPerSimd;
+    const int wps = s->d.envIndex >= 0 ? (f->wavesPerSimd <= 2 ? 2 : 4) : f->wavesPerSimd;   // environment scenes: 2- and 4-wave builds only
     const size_t accBytes = sizeof(Float) * ACC_N * TBLK;
     const bool accLds = f->accInLds && (lds + accBytes) * (size_t)std::max(1, wps) <= (size_t)160 * 1024;
     if (accLds) lds += accBytes;
@@ -448,8 +488,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     }
     f->lastSlices = slices;
     const dim3 grid(tiles * slices), block(TBLK);
-#define GDPT_LAUNCH(LDSV, ACCV, WPS) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
-#define GDPT_LAUNCH_W(LDSV, ACCV) do { if (wps == 1) GDPT_LAUNCH(LDSV, ACCV, 1); else if (wps == 2) GDPT_LAUNCH(LDSV, ACCV, 2); else if (wps == 3) GDPT_LAUNCH(LDSV, ACCV, 3); else GDPT_LAUNCH(LDSV, ACCV, 4); } while (0)
+#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
+    // scenes without an environment emitter run builds with its branches compiled out (1..4 waves/SIMD); scenes with one have the 2- and 4-wave builds
+#define GDPT_LAUNCH_W(LDSV, ACCV) do { \
+        if (s->d.envIndex >= 0) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true); else GDPT_LAUNCH(LDSV, ACCV, 4, true); } \
+        else if (wps == 1) GDPT_LAUNCH(LDSV, ACCV, 1, false); else if (wps == 2) GDPT_LAUNCH(LDSV, ACCV, 2, false); \
+        else if (wps == 3) GDPT_LAUNCH(LDSV, ACCV, 3, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false); } while (0)
     if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
     else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #undef GDPT_LAUNCH_W

@@ -96,7 +96,7 @@ struct MaterialD {           // 112 B (a multiple of 16: tables are staged into 
     Float alphaU, alphaV, pad2;
 };
 static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0, "LDS staging copies 16-byte words");
-struct EmitterD {
+struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp)
     int firstEmTri, numTris, cdfOffset, pad;
     d3 radiance;
     Float invSurfaceArea;
@@ -120,6 +120,9 @@ struct SceneD {
     Float emitterNormalization;
     int numNodes, numTris, numEmitters, numMats, ldsScene;
     uint32_t rootRef;
+    int envIndex;               // position of the environment emitter in the emitter list, -1: none
+    d3 bsCenter;                // its bounding sphere (ConstantBackgroundEmitter::m_sceneBSphere)
+    Float bsRadius;
     CameraD cam;
 };
 struct ConfigD {
@@ -635,42 +638,114 @@ __device__ __forceinline__ int cdf_sample(const Float *cdf, int n /*entries = n+
 // Scene::sampleEmitterDirectVisible (scene.cpp:855-879) minus the shadow ray, which the caller casts:
 // AreaLight::sampleDirect (area.cpp:158-172) -> Shape::sampleDirect (shape.cpp:102-116) -> TriMesh::samplePosition
 // (trimesh.cpp:412-423) -> Triangle::sample (triangle.cpp:24-).  Returns value (already / emPdf); dRec.pdf includes emPdf.
+// ---- the `constant` environment emitter (src/emitters/constant.cpp) ------------------------------------------------
+__device__ __forceinline__ bool solve_quadratic(Float a, Float b, Float c, Float &x0, Float &x1)
+{ // util.cpp:447-485
+    if (a == 0) {
+        if (b != 0) { x0 = x1 = -c / b; return true; }
+        return false;
+    }
+    const Float discrim = b * b - 4.0 * a * c;
+    if (discrim < 0) return false;
+    const Float sqrtDiscrim = sqrt(discrim);
+    const Float temp = (b < 0) ? -0.5 * (b - sqrtDiscrim) : -0.5 * (b + sqrtDiscrim);
+    x0 = temp / a;
+    x1 = c / temp;
+    if (x0 > x1) { const Float t = x0; x0 = x1; x1 = t; }
+    return true;
+}
+__device__ __forceinline__ bool bsphere_hit(const SceneD &S, d3 ro, d3 rd, Float &nearT, Float &farT)
+{ // bsphere.h:88-95
+    const d3 o = ro - S.bsCenter;
+    return solve_quadratic(len2(rd), 2 * dot(o, rd), len2(o) - S.bsRadius * S.bsRadius, nearT, farT);
+}
+__device__ __forceinline__ bool is_zero(d3 v) { return v.x == 0 && v.y == 0 && v.z == 0; }
+// ConstantBackgroundEmitter::fillDirectSamplingRecord, constant.cpp:245-261
+__device__ __forceinline__ bool env_fill_drec(const SceneD &S, DRec &dRec, d3 o, d3 d)
+{
+    Float nearT, farT;
+    if (!bsphere_hit(S, o, d, nearT, farT) || nearT > 0 || farT < 0) return false;
+    dRec.p = o + d * farT;
+    dRec.n = normalize(S.bsCenter - dRec.p);
+    dRec.object = S.envIndex;
+    dRec.d = d;
+    dRec.dist = farT;
+    return true;
+}
+// ConstantBackgroundEmitter::sampleDirect, constant.cpp:179-219
+__device__ __forceinline__ d3 env_sample_direct(const SceneD &S, d3 radiance, DRec &dRec, Float sx, Float sy)
+{
+    d3 d;
+    Float pdf;
+    const bool hasN = !is_zero(dRec.refN);
+    if (hasN) {
+        d = squareToCosineHemisphere(sx, sy);
+        pdf = GD_INV_PI * d.z;
+        Frame3 f;                                                    // Frame(n): coordinateSystem, util.cpp:592-601
+        f.n = dRec.refN;
+        if (fabs(f.n.x) > fabs(f.n.y)) { const Float il = 1.0 / sqrt(f.n.x * f.n.x + f.n.z * f.n.z); f.t = mk(f.n.z * il, 0.0, -f.n.x * il); }
+        else { const Float il = 1.0 / sqrt(f.n.y * f.n.y + f.n.z * f.n.z); f.t = mk(0.0, f.n.z * il, -f.n.y * il); }
+        f.s = cross(f.t, f.n);
+        d = toWorld(f, d);
+    } else {
+        const Float z = 1.0 - 2.0 * sy, r = safe_sqrt(1.0 - z * z), phi = 2.0 * GD_PI * sx;    // warp.cpp:25-31
+        d = mk(r * cos(phi), r * sin(phi), z);
+        pdf = 1.0 / (4.0 * GD_PI);
+    }
+    Float nearT, farT;
+    dRec.pdf = 0.0;
+    dRec.d = d; dRec.dist = 0.0; dRec.p = dRec.ref; dRec.n = mk(0.0);
+    if (!bsphere_hit(S, dRec.ref, d, nearT, farT)) return mk(0.0);
+    if (!(nearT < 0 && farT > 0)) return mk(0.0);
+    dRec.p = dRec.ref + d * farT;
+    dRec.n = normalize(S.bsCenter - dRec.p);
+    dRec.dist = farT;
+    dRec.pdf = pdf;
+    if (hasN && dot(dRec.d, dRec.refN) <= 0) return mk(0.0);
+    return radiance / pdf;
+}
+
+template <bool ENV>
 __device__ d3 sample_emitter_direct(const SceneD &S, const SceneView &V, DRec &dRec, Float sx, Float sy)
 {
     const int index = cdf_sample(S.emitterCdf, S.numEmitters, sx);
     const Float emPdf = S.emitterCdf[index + 1] - S.emitterCdf[index];
     sx = (sx - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
     const EmitterD em = V.emitters[index];
-    const Float *cdf = S.emCdf + em.cdfOffset;
-    const int ti = cdf_sample(cdf, em.numTris, sy);
-    sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
-    const EmTri tr = S.emTris[em.firstEmTri + ti];
-    const Float a = safe_sqrt(1.0 - sx);                  // warp.cpp:76-79
-    const Float bx = 1 - a, by = a * sy;
-    const d3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
-    dRec.p = tr.p0 + (sideA * bx) + (sideB * by);
-    dRec.n = normalize(cross(sideA, sideB));
-    dRec.pdf = em.invSurfaceArea;
-    dRec.d = dRec.p - dRec.ref;
-    const Float distSquared = len2(dRec.d);
-    dRec.dist = sqrt(distSquared);
-    dRec.d = dRec.d / dRec.dist;
-    const Float dp = fabs(dot(dRec.d, dRec.n));
-    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0;
     d3 value;
-    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = em.radiance / dRec.pdf;
-    else { dRec.pdf = 0.0; value = mk(0.0); }
+    if (ENV && em.numTris == 0) {
+        value = env_sample_direct(S, em.radiance, dRec, sx, sy);
+    } else {
+        const Float *cdf = S.emCdf + em.cdfOffset;
+        const int ti = cdf_sample(cdf, em.numTris, sy);
+        sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
+        const EmTri tr = S.emTris[em.firstEmTri + ti];
+        const Float a = safe_sqrt(1.0 - sx);                  // warp.cpp:76-79
+        const Float bx = 1 - a, by = a * sy;
+        const d3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
+        dRec.p = tr.p0 + (sideA * bx) + (sideB * by);
+        dRec.n = normalize(cross(sideA, sideB));
+        dRec.pdf = em.invSurfaceArea;
+        dRec.d = dRec.p - dRec.ref;
+        const Float distSquared = len2(dRec.d);
+        dRec.dist = sqrt(distSquared);
+        dRec.d = dRec.d / dRec.dist;
+        const Float dp = fabs(dot(dRec.d, dRec.n));
+        dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0;
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = em.radiance / dRec.pdf;
+        else { dRec.pdf = 0.0; value = mk(0.0); }
+    }
     dRec.object = index;
     dRec.pdf *= emPdf;
     value = value / emPdf;
     return value;
 }
-
-// Scene::pdfEmitterDirect, scene.cpp:976-979 -> area.cpp:174-183 -> shape.cpp:118-126 (solid-angle measure)
+template <bool ENV>
 __device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, const SceneView &V, int object, d3 d, d3 refN, d3 n, Float dist)
 {
     Float pd = 0.0;
-    if (dot(d, refN) >= 0 && dot(d, n) < 0) pd = V.emitters[object].invSurfaceArea * (dist * dist) / fabs(dot(d, n));
+    if (ENV && S.envIndex >= 0 && object == S.envIndex) pd = is_zero(refN) ? 1.0 / (4.0 * GD_PI) : GD_INV_PI * fmax((Float)0.0, dot(d, refN));   // constant.cpp:221-236
+    else if (dot(d, refN) >= 0 && dot(d, n) < 0) pd = V.emitters[object].invSurfaceArea * (dist * dist) / fabs(dot(d, n));
     return pd * (1.0 * S.emitterNormalization);
 }
 

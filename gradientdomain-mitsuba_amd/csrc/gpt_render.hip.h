@@ -42,7 +42,7 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
-template <class ACC>
+template <bool ENV, class ACC>
 __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample)
 {
     const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
@@ -78,7 +78,10 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
             s.status = RAY_NOT_CONNECTED;
         }
     }
-    if (L.v.prim < 0) return false;                                              // :482-492 (no environment emitter)
+    if (L.v.prim < 0) {                                                          // :482-492
+        if (ENV && S.envIndex >= 0) A.add3(ACC_VD, L.throughput * sv.emitters[S.envIndex].radiance);   // evalEnvironment, constant.cpp:241-243
+        return false;
+    }
     A.add3(ACC_VD, L.throughput * emitted(sv, L.v.prim, -L.rayD));                // :497-499
     if (cfg.strictNormals) {                                                     // :516-531
         if (dot(L.rayD, sv.shade[L.v.prim].n) * local_wi(sv, L.v.prim, L.rayD).z >= 0) return false;
@@ -92,7 +95,8 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 }
 
 // One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
-template <class ACC>
+// ENV: the scene may have an environment emitter (compiled out otherwise: its branches cost the closed scenes 5-8 %).
+template <bool ENV, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
@@ -116,7 +120,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         DRec dRec;
         dRec.ref = L.v.p; dRec.refN = (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n;       // records.inl:160-164 (no refN behind a back-sided BSDF)
         const Float lsx = L.rng.next1D(), lsy = L.rng.next1D();                  // :572
-        d3 value = sample_emitter_direct(S, sv, dRec, lsx, lsy);
+        d3 value = sample_emitter_direct<ENV>(S, sv, dRec, lsx, lsy);
         const bool mainEmitterVisible = !cast_shadow(sv, stack, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
         if (!mainEmitterVisible) value = mk(0.0);
         const d3 mainEmitterRadiance = value * dRec.pdf;                         // :575
@@ -161,7 +165,7 @@ GDPT_OFFSET_LOOP
                             const Frame3 sfr = frame_of(sts);
                             DRec sRec;
                             sRec.ref = s.v.p; sRec.refN = (shiftedBSDF.twoSided || shiftedBSDF.type == 3) ? mk(0.0) : sfr.n;
-                            d3 sv_ = sample_emitter_direct(S, sv, sRec, lsx, lsy);
+                            d3 sv_ = sample_emitter_direct<ENV>(S, sv, sRec, lsx, lsy);
                             const bool shiftedEmitterVisible = !cast_shadow(sv, stack, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
                             if (!shiftedEmitterVisible) sv_ = mk(0.0);
                             const d3 shiftedEmitterRadiance = sv_ * sRec.pdf;
@@ -211,24 +215,36 @@ GDPT_OFFSET_LOOP
     L.rayO = prevP;
     L.rayD = mainWo;                                                              // :768
     Float hitT;                                                                   // Intersection::t of the new base vertex
+    bool mainHitEnvV = false;                                                     // the base path left the scene into the environment emitter
+    DRec envRec;                                                                  // mainDRec of an environment hit (:790-797)
     {
         Hit h;
         L.nClosest++;
         trace<false>(sv, stack, L.rayO, L.rayD, ray_mint_closest(L.rayO, GD_EPSILON), GD_INF, h);
-        if (h.prim < 0) return false;                                            // :802-804 (no environment)
-        fill_vertex(sv, h, L.rayD, L.v);
+        if (h.prim < 0) {                                                        // :786-804
+            if (!ENV || S.envIndex < 0) return false;
+            envRec.ref = prevP; envRec.refN = (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n;
+            if (!env_fill_drec(S, envRec, L.rayO, L.rayD)) return false;
+            mainHitEnvV = true;
+            L.v.prim = -1;
+        } else {
+            fill_vertex(sv, h, L.rayD, L.v);
+        }
         hitT = h.t;
     }
-    const TriShade &nts = sv.shade[L.v.prim];
-    const bool mainHitEmitter = nts.emitter >= 0;                                 // :772-777
-    const d3 mainEmitterRadiance = mainHitEmitter ? emitted(sv, L.v.prim, -L.rayD) : mk(0.0);
-    const bool mainNextVertexDiffuse = vertex_is_diffuse(sv.mats[nts.material], cfg, bs.sampledType);  // :785
+    const bool mainHitEnv = ENV && mainHitEnvV;
+    const TriShade &nts = sv.shade[mainHitEnv ? 0 : L.v.prim];
+    const bool mainHitEmitter = mainHitEnv || nts.emitter >= 0;                   // :772-777, :793
+    const d3 mainEmitterRadiance = mainHitEnv ? sv.emitters[S.envIndex].radiance : (mainHitEmitter ? emitted(sv, L.v.prim, -L.rayD) : mk(0.0));
+    const bool mainNextVertexDiffuse = mainHitEnv ? true : vertex_is_diffuse(sv.mats[nts.material], cfg, bs.sampledType);  // :785, :799
     const Float mainBsdfPdf = bs.pdf, mainPreviousPdf = L.pdf;
     L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
     L.pdf *= bs.pdf;
     L.eta *= bs.eta;
     // mainDRec: ref = previous vertex, refN = its shading normal; setQuery (records.inl:170-178): p, n, d, dist
-    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta)) ? pdf_emitter_direct(S, sv, nts.emitter, L.rayD, (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n, nts.n, hitT) : 0;  // :815
+    const Float mainLumPdf = (mainHitEmitter && !(bs.sampledType & EDelta))
+        ? (mainHitEnv ? pdf_emitter_direct<ENV>(S, sv, S.envIndex, envRec.d, envRec.refN, envRec.n, envRec.dist)
+                      : pdf_emitter_direct<ENV>(S, sv, nts.emitter, L.rayD, (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n, nts.n, hitT)) : 0;  // :815
     const Float mainWeightNumerator = mainPreviousPdf * bs.pdf;                   // :819-820
     const Float mainWeightDenominator = (mainPreviousPdf * mainPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
@@ -270,9 +286,33 @@ GDPT_OFFSET_LOOP
                 if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
                     // ---- reconnection shift, :897-986 ----
                     if (!lastSegment || mainHitEmitter) {                        // :901
-                        // reconnectShift, gpt.cpp:316-345
-                        if (!test_visibility(sv, stack, L, s.v.p, L.v.p)) { s.alive = 0; }
-                        else {
+                        // reconnectShift, gpt.cpp:316-345; environmentShift + testEnvironmentVisibility, :96-114,348-369
+                        bool visible;
+                        if (mainHitEnv) {
+                            DRec er;
+                            er.dist = 0.0;
+                            env_fill_drec(S, er, s.v.p, L.rayD);
+                            visible = !cast_shadow(sv, stack, L, s.v.p, L.rayD, (1.0 - GD_SHADOW_EPSILON) * er.dist);
+                        } else visible = test_visibility(sv, stack, L, s.v.p, L.v.p);
+                        if (!visible) { s.alive = 0; }
+                        else if (mainHitEnv) {
+                            // reconnection at infinity: J = 1, wo = the base direction (:364-366); radiance and light pdf of the base (:972-976)
+                            const d3 shiftedWo = L.rayD;
+                            const d3 woL = toLocal(sfr, shiftedWo);
+                            if (cfg.strictNormals && dot(shiftedWo, sts.n) * woL.z <= 0) { s.alive = 0; }
+                            else {
+                                d3 f;
+                                Float shiftedBsdfPdf;
+                                bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, shiftedBsdfPdf);
+                                s.throughput = s.throughput * (f * 1.0);
+                                s.pdf *= shiftedBsdfPdf * 1.0;
+                                s.status = RAY_RECENTLY_CONNECTED;
+                                const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((mainLumPdf * mainLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+                                weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
+                                shiftedContribution = s.throughput * mainEmitterRadiance;
+                                assigned = true;
+                            }
+                        } else {
                             const d3 mainEdge = L.rayO - L.v.p, shiftedEdge = s.v.p - L.v.p;
                             const Float mainEdgeLengthSquared = len2(mainEdge), shiftedEdgeLengthSquared = len2(shiftedEdge);
                             const d3 shiftedWo = -shiftedEdge / sqrt(shiftedEdgeLengthSquared);
@@ -292,7 +332,7 @@ GDPT_OFFSET_LOOP
                                     const d3 shiftedEmitterRadiance = emitted(sv, L.v.prim, -shiftedWo);
                                     const Float sdist = len(L.v.p - s.v.p);
                                     const d3 sd = (L.v.p - s.v.p) / sdist;
-                                    const Float shiftedLumPdf = pdf_emitter_direct(S, sv, nts.emitter, sd, sfr.n, nts.n, sdist);
+                                    const Float shiftedLumPdf = pdf_emitter_direct<ENV>(S, sv, nts.emitter, sd, sfr.n, nts.n, sdist);
                                     const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                                     weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                                     shiftedContribution = s.throughput * shiftedEmitterRadiance;
@@ -304,6 +344,7 @@ GDPT_OFFSET_LOOP
                 } else {
                     // ---- half-vector duplication shift, :987-1126 ----
                     d3 shiftedEmitterRadiance = mk(0.0);
+                    bool envEnd = false;
                     const d3 tsIn = toLocal(sfr, -s.rayD);
                     const bool bothDelta = (bs.sampledType & EDelta) && (bsdfType(shiftedBSDF) & EDelta);     // :996-1001
                     const bool bothSmooth = (bs.sampledType & ESmooth) && (bsdfType(shiftedBSDF) & ESmooth);
@@ -328,7 +369,10 @@ GDPT_OFFSET_LOOP
                             Hit h;
                             L.nClosest++;
                             trace<false>(sv, stack, s.v.p, outgoing, ray_mint_closest(s.v.p, GD_EPSILON), GD_INF, h);   // :1050-1052
-                            if (h.prim < 0) ok = false;                          // :1056-1058 (no environment)
+                            if (h.prim < 0) {                                    // :1052-1074
+                                if (!ENV || S.envIndex < 0 || !mainHitEnv || (mainVertexDiffuse && shiftedVertexDiffuse)) ok = false;
+                                else { shiftedEmitterRadiance = sv.emitters[S.envIndex].radiance; envEnd = true; }
+                            } else if (mainHitEnv) ok = false;                    // :1078-1082: no shifts between env and non-env
                             else {
                                 s.rayD = outgoing;
                                 fill_vertex(sv, h, outgoing, s.v);
@@ -342,6 +386,7 @@ GDPT_OFFSET_LOOP
                     if (ok) {                                                    // :1106-1112
                         weight = L.pdf / (s.pdf * s.pdf + L.pdf * L.pdf);
                         shiftedContribution = s.throughput * shiftedEmitterRadiance;
+                        if (envEnd) postponedShiftEnd = true;                    // :1073: the offset path ends with this segment
                     } else {                                                     // :1113-1124
                         weight = 1.0 / L.pdf;
                         shiftedContribution = mk(0.0);
@@ -363,6 +408,7 @@ GDPT_OFFSET_LOOP
         if (postponedShiftEnd) s.alive = 0;
     }
 
+    if (mainHitEnv) return false;                                                // :1155-1157
     if (L.depth++ >= cfg.rrDepth) {                                              // :1159-1174
         const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
         if (L.rng.next1D() >= q) return false;
@@ -416,7 +462,7 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
     }
 }
 
-template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD>
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV>
 __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
 {
     // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)][per-sample sums (ACC_LDS only)]; sized by the host from
@@ -479,13 +525,13 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
             if (pending) finish_path(F, flt, L, A, px, py);
-            active = start_path(S, sv, cfg, stack, L, A, px, py, next);
+            active = start_path<ENV>(S, sv, cfg, stack, L, A, px, py, next);
             next++;
             pending = !active;
             if (!active) { paths++; pathLen += L.depth; }
         }
         if (active) {
-            if (!bounce(S, sv, cfg, stack, L, A)) {
+            if (!bounce<ENV>(S, sv, cfg, stack, L, A)) {
                 active = false;
                 pending = true;
                 paths++; pathLen += L.depth;
@@ -614,8 +660,8 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
-    bool active = start_path(S, sv, cfg, s_stack, L, A, px, py, sample);
-    while (active) active = bounce(S, sv, cfg, s_stack, L, A);
+    bool active = start_path<true>(S, sv, cfg, s_stack, L, A, px, py, sample);
+    while (active) active = bounce<true>(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];

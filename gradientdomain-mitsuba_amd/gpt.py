@@ -27,6 +27,10 @@ class Emitter(C.Structure):
     _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3)]
 
 
+class Environment(C.Structure):
+    _fields_ = [("radiance", C.c_double * 3), ("index", C.c_int)]
+
+
 class Camera(C.Structure):
     _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
                 ("width", C.c_int), ("height", C.c_int)]
@@ -67,9 +71,13 @@ class Scene:
         cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
         cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height
         self._h = C.c_void_p()
-        check(lib().gdpt_scene_create(verts.shape[0], verts.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p),
-                                      len(desc.materials), C.byref(mats), len(desc.emitters), C.byref(ems), C.byref(cam),
-                                      device, C.byref(self._h)))
+        envd = getattr(desc, "environment", None)
+        env = None
+        if envd is not None:                                 # `<emitter type="constant">`: (radiance rgb, position in the emitter list)
+            env = Environment((C.c_double * 3)(*envd[0]), int(envd[1]))
+        check(lib().gdpt_scene_create_env(verts.shape[0], verts.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p),
+                                          len(desc.materials), C.byref(mats), len(desc.emitters), C.byref(ems),
+                                          C.byref(env) if env is not None else None, C.byref(cam), device, C.byref(self._h)))
 
     def intersect(self, origins, dirs):
         od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))

@@ -148,6 +148,8 @@ struct SceneData {
     std::vector<int> triMaterial;
     std::vector<gdpt_material> materials;
     std::vector<gdpt_emitter> emitters;
+    bool hasEnvironment = false;            // <emitter type="constant">
+    gdpt_environment environment = {{0, 0, 0}, -1};
     gdpt_camera camera;
     Properties integrator, film, sampler, rfilter;
     int numTriangles() const { return (int)triMaterial.size(); }
@@ -240,8 +242,8 @@ public:
         const int W = film.getWidth(), H = film.getHeight();
         gdpt_scene *scene = nullptr;
         gdpt_film *gf = nullptr;
-        check(gdpt_scene_create(sd.numTriangles(), sd.verts.data(), sd.triMaterial.data(), (int)sd.materials.size(), sd.materials.data(),
-                                (int)sd.emitters.size(), sd.emitters.data(), &sd.camera, -1, &scene));
+        check(gdpt_scene_create_env(sd.numTriangles(), sd.verts.data(), sd.triMaterial.data(), (int)sd.materials.size(), sd.materials.data(),
+                                    (int)sd.emitters.size(), sd.emitters.data(), sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, -1, &scene));
         check(gdpt_film_create(scene, 0, H, &gf));
         gdpt_config cfg;
         cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;

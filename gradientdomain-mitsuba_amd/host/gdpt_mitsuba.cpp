@@ -47,9 +47,10 @@ int main(int argc, char **argv)
         gdpt::SceneData sd = loader.load(scenePath);
         const int spp = sd.sampler.getInteger("sampleCount", 4);                                                                       // independent.cpp default
         if (parseOnly) {
-            printf("{\"triangles\": %d, \"materials\": %zu, \"emitters\": %zu, \"width\": %d, \"height\": %d, \"fovX\": %.9g, \"sampleCount\": %d, \"maxDepth\": %d, \"firstVertex\": [%.9g, %.9g, %.9g], \"cameraOrigin\": [%.9g, %.9g, %.9g]}\n",
+            printf("{\"triangles\": %d, \"materials\": %zu, \"emitters\": %zu, \"width\": %d, \"height\": %d, \"fovX\": %.9g, \"sampleCount\": %d, \"maxDepth\": %d, \"firstVertex\": [%.9g, %.9g, %.9g], \"cameraOrigin\": [%.9g, %.9g, %.9g], \"environment\": [%.9g, %.9g, %.9g, %d]}\n",
                    sd.numTriangles(), sd.materials.size(), sd.emitters.size(), sd.camera.width, sd.camera.height, sd.camera.fovX, spp,
-                   sd.integrator.getInteger("maxDepth", -1), sd.verts[0], sd.verts[1], sd.verts[2], sd.camera.toWorld[3], sd.camera.toWorld[7], sd.camera.toWorld[11]);
+                   sd.integrator.getInteger("maxDepth", -1), sd.verts[0], sd.verts[1], sd.verts[2], sd.camera.toWorld[3], sd.camera.toWorld[7], sd.camera.toWorld[11],
+                   sd.environment.radiance[0], sd.environment.radiance[1], sd.environment.radiance[2], sd.hasEnvironment ? sd.environment.index : -1);
             return 0;
         }
         struct stat stt;

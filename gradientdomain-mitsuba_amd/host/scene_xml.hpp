@@ -5,6 +5,7 @@
 // (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
 // fileFormat="openexr"|"pfm") with <rfilter type="box">, <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
 // shape), <shape type="obj|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
+// top-level <emitter type="constant"> (radiance),
 // <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
 // Anything else raises std::runtime_error naming the tag or plugin, like the reference's "unsupported" errors.
 #pragma once
@@ -182,12 +183,24 @@ public:
             } else if (n.tag == "sensor") { sensor(n, sd); haveSensor = true; }
             else if (n.tag == "bsdf") { const std::string id = n.get("id", ""); const int idx = bsdf(n, sd); if (!id.empty()) m_bsdfIds[id] = idx; }
             else if (n.tag == "shape") shape(n, sd);
-            else if (n.tag == "emitter") logError(format("top-level emitter \"%s\" is not carried: only `area` emitters attached to shapes", n.get("type").c_str()));
+            else if (n.tag == "emitter") {                                       // src/emitters/constant.cpp: the only top-level emitter carried
+                if (subst(n.get("type")) != "constant") logError(format("top-level emitter \"%s\" is not carried: `constant` (and `area` on shapes)", n.get("type").c_str()));
+                if (sd.hasEnvironment) logError("Only one environment emitter can be used at a time!");          // scene.cpp: addChild
+                double radiance[3] = {1.0, 1.0, 1.0};                            // constant.cpp:44: default radiance = D65 white
+                for (auto &ec : n.children) {
+                    if ((ec->tag == "rgb" || ec->tag == "spectrum") && ec->get("name") == "radiance") rgb3(*ec, radiance);
+                    else if (ec->tag == "float" && ec->get("name") == "samplingWeight") { if (std::atof(subst(ec->get("value")).c_str()) != 1.0) logError("emitter \"constant\": samplingWeight other than 1 is not carried"); }
+                    else logError(format("emitter \"constant\": <%s name=\"%s\"> is not carried", ec->tag.c_str(), ec->get("name", "").c_str()));
+                }
+                sd.hasEnvironment = true;
+                for (int k = 0; k < 3; ++k) sd.environment.radiance[k] = radiance[k];
+                sd.environment.index = (int)sd.emitters.size();                  // its place in the emitter list = XML order
+            }
             else logError(format("<%s> is not carried by this build", n.tag.c_str()));
         }
         if (!haveIntegrator) sd.integrator = Properties("gpt");
         if (!haveSensor) logError("scene has no <sensor>");
-        if (sd.emitters.empty()) logError("scene has no area emitter");
+        if (sd.emitters.empty() && !sd.hasEnvironment) logError("scene has no emitter");
         return sd;
     }
 

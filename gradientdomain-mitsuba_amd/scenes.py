@@ -72,6 +72,7 @@ class Scene:
     width: int = 512
     height: int = 512
     name: str = "scene"
+    environment: tuple = None    # ((r, g, b), position in the scene's emitter list) for `<emitter type="constant">`, or None
 
     @property
     def ntri(self):
@@ -135,7 +136,7 @@ def _random_material(rng):
     return m
 
 
-def cornell_box(width=512, height=512, variant="diffuse", seed=0):
+def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=None):
     """The Cornell box (Cornell Program of Computer Graphics measurement data, 555-unit room), all triangle meshes:
     5 walls, short block, tall block, one area-light quad.  variant: "diffuse" (BASELINE configs 1-2) |
     "glossy" (rough-copper floor, mirror back wall, GGX block: exercises the half-vector shift) | "nearspecular"."""
@@ -181,8 +182,11 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0):
     b.emitter(first, 2, (17.0, 12.0, 4.0))
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))      # 0.025 sensor, 0.035 focal length; `fov` is the x-fov (fovAxis = x), so a
                                                             # wide film crops the square original top and bottom and every pixel sees the box
-    return b.finish(to_world=lookat((278, 273, -800), (278, 273, -799), (0, 1, 0)), fov_x=fov, near=10.0, far=2800.0,
-                    width=width, height=height, name="cornell-" + variant)
+    sc = b.finish(to_world=lookat((278, 273, -800), (278, 273, -799), (0, 1, 0)), fov_x=fov, near=10.0, far=2800.0,
+                  width=width, height=height, name="cornell-" + variant)
+    if environment is not None:        # a constant environment emitter seen through the open front and in the wide film's margins
+        sc.environment = (tuple(float(v) for v in environment), 0 if variant == "random" and seed % 2 else len(sc.emitters))
+    return sc
 
 
 def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):

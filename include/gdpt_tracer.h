@@ -47,6 +47,11 @@ typedef struct gdpt_emitter {   /* an `area` emitter attached to one mesh (src/e
     double radiance[3];
 } gdpt_emitter;
 
+typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters/constant.cpp): uniform radiance from all directions */
+    double radiance[3];
+    int    index;               /* its position in the scene's emitter list (XML order; Scene::sampleEmitterDirect picks by it); <0: last */
+} gdpt_environment;
+
 typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp), crop == film */
     double toWorld[16];         /* row-major camera-to-world, Transform::lookAt convention         */
     double fovX;                /* degrees (`fov`, fovAxis = x)                                    */
@@ -72,6 +77,13 @@ GDPT_API int  gdpt_scene_create(int numTris, const double *verts9, const int *tr
                                 int numMaterials, const gdpt_material *materials,
                                 int numEmitters, const gdpt_emitter *emitters,
                                 const gdpt_camera *camera, int device, gdpt_scene **out);
+/* The same with an environment emitter (NULL = none; then at least one area emitter is required).  Carries the environment
+ * branches of the integrator: environment hits of base and offset paths, environmentShift / testEnvironmentVisibility
+ * (gpt.cpp:96-114,348-369,786-804,1052-1074), light sampling of the environment with the bounding sphere of constant.cpp:67-70. */
+GDPT_API int  gdpt_scene_create_env(int numTris, const double *verts9, const int *triMaterial,
+                                    int numMaterials, const gdpt_material *materials,
+                                    int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env,
+                                    const gdpt_camera *camera, int device, gdpt_scene **out);
 GDPT_API void gdpt_scene_destroy(gdpt_scene *s);
 
 /* A film = the five G-PT buffers `-final -throughput -dx -dy -direct` (gpt.cpp:1380) over rows [y0, y1) of the

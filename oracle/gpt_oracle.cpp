@@ -174,7 +174,7 @@ struct Tri {
 };
 
 struct Emitter {
-    int firstTri, numTris;
+    int firstTri, numTris;      // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp)
     V3 radiance;
     std::vector<Float> cdf; // DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h)
     Float invSurfaceArea;
@@ -245,6 +245,9 @@ struct Scene {
     // camera constants (perspective.cpp:125-163)
     Float aspect, tanHalf;
     V3 aabbMin, aabbMax;
+    int envIndex = -1;          // position of the environment emitter in `emitters` (scene order), -1: none
+    V3 bsCenter;                // ConstantBackgroundEmitter::m_sceneBSphere (constant.cpp:67-70)
+    Float bsRadius = 0;
     mutable uint64_t raysTraced = 0, shadowRaysTraced = 0; // skdtree.cpp:46-47
     // Oracle-side acceleration for large scenes only (> 64 triangles): a plain midpoint-split bounding-volume tree over double
     // bounds.  It changes which triangles are TESTED, never the test or the answer (closest t wins); small scenes stay brute force.
@@ -848,6 +851,87 @@ V3 Le(const Scene &sc, const Intersection &its, V3 d)
     return sc.emitters[e].radiance;
 }
 
+// solveQuadratic, util.cpp:447-485
+bool solveQuadratic(Float a, Float b, Float c, Float &x0, Float &x1)
+{
+    if (a == 0) {
+        if (b != 0) { x0 = x1 = -c / b; return true; }
+        return false;
+    }
+    Float discrim = b * b - 4.0 * a * c;
+    if (discrim < 0) return false;
+    Float temp, sqrtDiscrim = std::sqrt(discrim);
+    if (b < 0) temp = -0.5 * (b - sqrtDiscrim);
+    else temp = -0.5 * (b + sqrtDiscrim);
+    x0 = temp / a;
+    x1 = c / temp;
+    if (x0 > x1) std::swap(x0, x1);
+    return true;
+}
+// BSphere::rayIntersect, bsphere.h:88-95
+bool bsphereRayIntersect(const Scene &sc, V3 ro, V3 rd, Float &nearHit, Float &farHit)
+{
+    V3 o = ro - sc.bsCenter;
+    Float A = lengthSquared(rd), B = 2 * dot(o, rd), C = lengthSquared(o) - sc.bsRadius * sc.bsRadius;
+    return solveQuadratic(A, B, C, nearHit, farHit);
+}
+V3 squareToUniformSphere(Float sx, Float sy)
+{ // warp.cpp:25-31
+    Float z = 1.0 - 2.0 * sy;
+    Float r = safe_sqrt(1.0 - z * z);
+    Float phi = 2.0 * PI * sx;
+    return V3(r * std::cos(phi), r * std::sin(phi), z);
+}
+// ConstantBackgroundEmitter::fillDirectSamplingRecord, constant.cpp:245-261
+bool envFillDirectSamplingRecord(const Scene &sc, DirectSamplingRecord &dRec, const Ray &ray)
+{
+    Float nearT, farT;
+    if (!bsphereRayIntersect(sc, ray.o, ray.d, nearT, farT) || nearT > 0 || farT < 0) return false;
+    dRec.p = ray.o + ray.d * farT;
+    dRec.n = normalize(sc.bsCenter - dRec.p);
+    dRec.measure = MEASURE_SOLID_ANGLE;
+    dRec.object = sc.envIndex;
+    dRec.d = ray.d;
+    dRec.dist = farT;
+    return true;
+}
+// ConstantBackgroundEmitter::sampleDirect, constant.cpp:179-219
+V3 envSampleDirect(const Scene &sc, const Emitter &em, DirectSamplingRecord &dRec, Float sx, Float sy)
+{
+    V3 d;
+    Float pdf;
+    const bool hasN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
+    if (hasN) {
+        d = squareToCosineHemisphere(sx, sy);
+        pdf = INV_PI * d.z;                                       // squareToCosineHemispherePdf, warp.h
+        Frame f; f.n = dRec.refN; coordinateSystem(f.n, f.s, f.t); // Frame(n), frame.h
+        d = f.toWorld(d);
+    } else {
+        d = squareToUniformSphere(sx, sy);
+        pdf = 1.0 / (4.0 * PI);
+    }
+    Float nearT, farT;
+    dRec.pdf = 0.0;
+    // (the reference leaves d/dist unset on these two early exits; they cannot be taken from inside the sphere)
+    dRec.d = d; dRec.dist = 0.0; dRec.p = dRec.ref; dRec.n = V3(0.0); dRec.measure = MEASURE_SOLID_ANGLE;
+    if (!bsphereRayIntersect(sc, dRec.ref, d, nearT, farT)) return V3(0.0);
+    if (!(nearT < 0 && farT > 0)) return V3(0.0);
+    dRec.p = dRec.ref + d * farT;
+    dRec.n = normalize(sc.bsCenter - dRec.p);
+    dRec.dist = farT;
+    dRec.pdf = pdf;
+    if (hasN && dot(dRec.d, dRec.refN) <= 0) return V3(0.0);
+    return em.radiance / pdf;
+}
+// ConstantBackgroundEmitter::pdfDirect, constant.cpp:221-236
+Float envPdfDirect(const DirectSamplingRecord &dRec)
+{
+    const bool hasN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
+    Float pdfSA = hasN ? INV_PI * std::max((Float)0.0, dot(dRec.d, dRec.refN)) : 1.0 / (4.0 * PI);
+    if (dRec.measure == MEASURE_SOLID_ANGLE) return pdfSA;
+    return 0.0;
+}
+
 // Scene::sampleEmitterDirectVisible, scene.cpp:855-879 -> AreaLight::sampleDirect (area.cpp:158-172) ->
 // Shape::sampleDirect (shape.cpp:102-116) -> TriMesh::samplePosition (trimesh.cpp:412-423) -> Triangle::sample (triangle.cpp:24-)
 V3 sampleEmitterDirectVisible(const Scene &sc, DirectSamplingRecord &dRec, Float sx, Float sy, bool &visible)
@@ -855,6 +939,10 @@ V3 sampleEmitterDirectVisible(const Scene &sc, DirectSamplingRecord &dRec, Float
     Float emPdf;
     size_t index = sc.emitterPDF.sampleReuse(sx, emPdf);
     const Emitter &em = sc.emitters[index];
+    V3 value;
+    if (em.numTris == 0) {
+        value = envSampleDirect(sc, em, dRec, sx, sy);
+    } else {
     // TriMesh::samplePosition
     {
         const std::vector<Float> &cdf = em.cdf;
@@ -879,9 +967,9 @@ V3 sampleEmitterDirectVisible(const Scene &sc, DirectSamplingRecord &dRec, Float
     dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0;
     dRec.measure = MEASURE_SOLID_ANGLE;
     // AreaLight::sampleDirect
-    V3 value;
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = em.radiance / dRec.pdf;
     else { dRec.pdf = 0.0; value = V3(0.0); }
+    }
     dRec.object = (int)index;
     dRec.pdf *= emPdf;
     value = value / emPdf;
@@ -896,12 +984,29 @@ Float pdfEmitterDirect(const Scene &sc, const DirectSamplingRecord &dRec)
 {
     const Emitter &em = sc.emitters[dRec.object];
     Float pd = 0.0;
-    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+    if (em.numTris == 0) pd = envPdfDirect(dRec);
+    else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
         Float pdfPos = em.invSurfaceArea;
         if (dRec.measure == MEASURE_SOLID_ANGLE) pd = pdfPos * (dRec.dist * dRec.dist) / std::abs(dot(dRec.d, dRec.n));
         else pd = 0.0;
     }
     return pd * (1.0 * sc.emitterPDF.normalization); // Scene::pdfEmitterDiscrete, scene.h:855-857
+}
+
+// testEnvironmentVisibility + environmentShift, gpt.cpp:96-114,348-369
+struct EnvShiftResult { bool success; Float jacobian; V3 wo; };
+EnvShiftResult environmentShift(const Scene &sc, const Ray &mainRay, V3 shiftSourceVertex)
+{
+    EnvShiftResult r; r.success = false; r.jacobian = 1; r.wo = mainRay.d;
+    if (sc.envIndex < 0) return r;
+    Ray shadowRay(shiftSourceVertex, mainRay.d);
+    DirectSamplingRecord rec;
+    rec.dist = 0.0;
+    envFillDirectSamplingRecord(sc, rec, shadowRay);
+    shadowRay.mint = Epsilon;
+    shadowRay.maxt = (1.0 - ShadowEpsilon) * rec.dist;
+    r.success = !rayIntersectShadow(sc, shadowRay);
+    return r;
 }
 
 // ---- sensor: PerspectiveCameraImpl::sampleRayDifferential, perspective.cpp:271-298 -----------------------
@@ -1017,13 +1122,16 @@ ReconnectionShiftResult reconnectShift(const Scene &sc, V3 mainSourceVertex, V3 
 
 inline const gpo_material &matOf(const Scene &sc, const Intersection &its) { return sc.mats[sc.tris[its.prim].material]; }
 
-// GradientPathTracer::evaluate, gpt.cpp:468-1180 (no environment emitter, no sub-surface scattering in the carried subset)
+// GradientPathTracer::evaluate, gpt.cpp:468-1180 (no sub-surface scattering in the carried subset; the environment emitter is `constant`)
 void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, RayState *shiftedRays, int secondaryCount, V3 &out_veryDirect)
 {
     rayIntersect(sc, main.ray, main.its);                                                  // :472
     main.ray.mint = Epsilon;
     for (int i = 0; i < secondaryCount; ++i) { rayIntersect(sc, shiftedRays[i].ray, shiftedRays[i].its); shiftedRays[i].ray.mint = Epsilon; }
-    if (!main.its.isValid()) return;                                                       // :482-492 (no environment)
+    if (!main.its.isValid()) {                                                             // :482-492
+        if (sc.envIndex >= 0) out_veryDirect = out_veryDirect + main.throughput * sc.emitters[sc.envIndex].radiance; // evalEnvironment, constant.cpp:241-243
+        return;
+    }
     if (sc.tris[main.its.prim].emitter >= 0) out_veryDirect = out_veryDirect + main.throughput * Le(sc, main.its, -main.ray.d); // :497-499
     for (int i = 0; i < secondaryCount; ++i) if (!shiftedRays[i].its.isValid()) shiftedRays[i].alive = false; // :508-513
     if (cfg.strictNormals) {                                                               // :516-531
@@ -1150,7 +1258,13 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                 mainHitEmitter = true;
             }
             mainNextVertexType = getVertexType(matOf(sc, main.its), cfg, mainBsdfResult.sampledType); // :785
-        } else break;                                                                      // :802-804 (no environment)
+        } else {                                                                           // :786-804
+            if (sc.envIndex < 0) break;
+            mainEmitterRadiance = sc.emitters[sc.envIndex].radiance;                       // evalEnvironment
+            if (!envFillDirectSamplingRecord(sc, mainDRec, main.ray)) break;
+            mainHitEmitter = true;
+            mainNextVertexType = VERTEX_TYPE_DIFFUSE;                                      // "environment connection as diffuse"
+        }
         Float mainBsdfPdf = mainBsdfResult.pdf, mainPreviousPdf = main.pdf;
         main.throughput = main.throughput * (mainBsdfResult.weight * mainBsdfResult.pdf);  // :810-812
         main.pdf *= mainBsdfResult.pdf;
@@ -1194,7 +1308,12 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                     VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, mainBsdfResult.sampledType);
                     if (mainVertexType == VERTEX_TYPE_DIFFUSE && mainNextVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE) {
                         if (!lastSegment || mainHitEmitter) {                              // :901
-                            ReconnectionShiftResult shiftResult = reconnectShift(sc, main.ray.o, main.its.p, shifted.its.p, main.its.geoN);
+                            ReconnectionShiftResult shiftResult;
+                            if (main.its.isValid()) shiftResult = reconnectShift(sc, main.ray.o, main.its.p, shifted.its.p, main.its.geoN);
+                            else {                                                         // reconnection at infinity, :908-915
+                                EnvShiftResult e = environmentShift(sc, main.ray, shifted.its.p);
+                                shiftResult.success = e.success; shiftResult.jacobian = e.jacobian; shiftResult.wo = e.wo;
+                            }
                             if (!shiftResult.success) { shifted.alive = false; goto shift_failed; }
                             V3 incomingDirection = -shifted.ray.d, outgoingDirection = shiftResult.wo;
                             V3 wiL = shifted.its.sh.toLocal(incomingDirection), woL = shifted.its.sh.toLocal(outgoingDirection);
@@ -1205,14 +1324,18 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             shifted.pdf *= shiftedBsdfPdf * shiftResult.jacobian;
                             shifted.connection_status = RAY_RECENTLY_CONNECTED;
                             if (mainHitEmitter) {                                          // :944-986
-                                V3 shiftedEmitterRadiance = Le(sc, main.its, -outgoingDirection);
+                                V3 shiftedEmitterRadiance;
+                                Float shiftedLumPdf;
+                                if (main.its.isValid()) {
+                                shiftedEmitterRadiance = Le(sc, main.its, -outgoingDirection);
                                 DirectSamplingRecord shiftedDRec;
                                 shiftedDRec.p = mainDRec.p; shiftedDRec.n = mainDRec.n;
                                 shiftedDRec.dist = length(mainDRec.p - shifted.its.p);
                                 shiftedDRec.d = (mainDRec.p - shifted.its.p) / shiftedDRec.dist;
                                 shiftedDRec.ref = mainDRec.ref; shiftedDRec.refN = shifted.its.sh.n;
                                 shiftedDRec.object = mainDRec.object; shiftedDRec.measure = MEASURE_SOLID_ANGLE;
-                                Float shiftedLumPdf = pdfEmitterDirect(sc, shiftedDRec);
+                                shiftedLumPdf = pdfEmitterDirect(sc, shiftedDRec);
+                                } else { shiftedEmitterRadiance = mainEmitterRadiance; shiftedLumPdf = mainLumPdf; }   // :972-976
                                 Float shiftedWeightDenominator = (shiftedPreviousPdf * shiftedPreviousPdf) * ((shiftedLumPdf * shiftedLumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                                 weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
                                 mainContribution = main.throughput * mainEmitterRadiance;
@@ -1242,7 +1365,15 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             if (cfg.strictNormals && dot(outgoingDirection, shifted.its.geoN) * cosTheta(tangentSpaceOutgoingDirection) <= 0) { shifted.alive = false; goto half_vector_shift_failed; }
                             VertexType shiftedVertexType2 = getVertexType(shiftedBSDF, cfg, mainBsdfResult.sampledType);
                             shifted.ray = Ray(shifted.its.p, outgoingDirection);                                           // :1050
-                            if (!rayIntersect(sc, shifted.ray, shifted.its)) { shifted.alive = false; goto half_vector_shift_failed; } // :1056-1058 (no env)
+                            if (!rayIntersect(sc, shifted.ray, shifted.its)) {                                             // :1052-1074
+                                if (sc.envIndex < 0) { shifted.alive = false; goto half_vector_shift_failed; }
+                                if (main.its.isValid()) { shifted.alive = false; goto half_vector_shift_failed; }            // no shifts between env and non-env
+                                if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType2 == VERTEX_TYPE_DIFFUSE) { shifted.alive = false; goto half_vector_shift_failed; }
+                                shiftedEmitterRadiance = sc.emitters[sc.envIndex].radiance;
+                                postponedShiftEnd = true;
+                                goto half_vector_shift_failed;                                                             // (label name only: alive stays true)
+                            }
+                            if (!main.its.isValid()) { shifted.alive = false; goto half_vector_shift_failed; }             // :1078-1082
                             VertexType shiftedNextVertexType = getVertexType(matOf(sc, shifted.its), cfg, mainBsdfResult.sampledType);
                             if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType2 == VERTEX_TYPE_DIFFUSE && shiftedNextVertexType == VERTEX_TYPE_DIFFUSE) { // :1089-1093
                                 shifted.alive = false; goto half_vector_shift_failed;
@@ -1433,6 +1564,32 @@ GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *tr
     return h;
 }
 
+// Adds `<emitter type="constant">` (src/emitters/constant.cpp) as entry `index` of the scene's emitter list (XML order decides
+// which part of the light sample selects it, scene.cpp:855-862).  Bounding sphere as ConstantBackgroundEmitter::createShape
+// builds it (constant.cpp:67-70) from Scene::getAABB() at that moment = kd-tree AABB (already enlarged) + the sensor's
+// position (scene.cpp:386-395, perspective.cpp:444-446).
+GPO_API void gpo_scene_set_environment(gpo_scene *h, const double *radiance, int index)
+{
+    Scene &sc = h->sc;
+    if (sc.envIndex >= 0) return;
+    const int n = (int)sc.emitters.size();
+    if (index < 0 || index > n) index = n;
+    Emitter em;
+    em.firstTri = 0; em.numTris = 0; em.radiance = V3(radiance[0], radiance[1], radiance[2]); em.invSurfaceArea = 0;
+    sc.emitters.insert(sc.emitters.begin() + index, em);
+    for (Tri &t : sc.tris) if (t.emitter >= index) t.emitter++;
+    sc.envIndex = index;
+    sc.emitterPDF = Distribution();
+    for (size_t i = 0; i < sc.emitters.size(); ++i) sc.emitterPDF.append(1.0);
+    sc.emitterPDF.normalize();
+    V3 mn = sc.aabbMin, mx = sc.aabbMax;
+    const V3 camPos(sc.cam.toWorld[3], sc.cam.toWorld[7], sc.cam.toWorld[11]);
+    mn = V3(std::min(mn.x, camPos.x), std::min(mn.y, camPos.y), std::min(mn.z, camPos.z));
+    mx = V3(std::max(mx.x, camPos.x), std::max(mx.y, camPos.y), std::max(mx.z, camPos.z));
+    sc.bsCenter = (mx + mn) * 0.5;                                   // AABB::getCenter, aabb.h:132-134
+    sc.bsRadius = std::max(Epsilon, length(sc.bsCenter - mx) * (Float)1.5f);   // aabb.cpp:44-47, constant.cpp:69
+}
+
 GPO_API void gpo_scene_destroy(gpo_scene *h) { delete h; }
 
 // Renders pixels [x0,x1) x [y0,y1).  accum: 5 buffers x H x W x 4 doubles (R,G,B,weight sums; film-sized; contributions
@@ -1560,7 +1717,14 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
             q.ref = its.p; q.refN = refNormal(m, its);
             Ray next(its.p, wo);
             beta = beta * s.weight;
-            if (!rayIntersect(sc, next, its)) break;
+            if (!rayIntersect(sc, next, its)) {
+                if (sc.envIndex >= 0 && envFillDirectSamplingRecord(sc, q, next)) {       // the environment, MIS against its light sampling
+                    Float pl = (s.sampledType & EDelta) ? 0.0 : pdfEmitterDirect(sc, q);
+                    Float wgt = (s.pdf * s.pdf) / (s.pdf * s.pdf + pl * pl);
+                    L = L + beta * sc.emitters[sc.envIndex].radiance * wgt;
+                }
+                break;
+            }
             if (sc.tris[its.prim].emitter >= 0) {
                 V3 le = Le(sc, its, -next.d);
                 q.p = its.p; q.n = its.sh.n; q.d = next.d; q.dist = its.t; q.object = sc.tris[its.prim].emitter; q.measure = MEASURE_SOLID_ANGLE;

@@ -69,6 +69,7 @@ def lib():
         L.gpo_scene_create.restype = C.c_void_p
         L.gpo_scene_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_scene_destroy.argtypes = [C.c_void_p]
+        L.gpo_scene_set_environment.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -110,6 +111,9 @@ class Scene:
         self.W, self.H = desc.width, desc.height
         self._h = lib().gpo_scene_create(verts.shape[0], _p(verts), _p(tm), len(desc.materials), C.byref(mats),
                                          len(desc.emitters), C.byref(ems), C.byref(cam))
+        env = getattr(desc, "environment", None)
+        if env is not None:                                  # (radiance rgb, position in the emitter list)
+            lib().gpo_scene_set_environment(self._h, _p(_d(env[0])), int(env[1]))
 
     def render(self, cfg, rect=None):
         """-> (accum[5,H,W,4] float64, (closest_rays, shadow_rays))."""

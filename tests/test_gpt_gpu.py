@@ -64,6 +64,55 @@ def test_samples_match_oracle(G, variant, md):
             assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (variant, px, py, s, k)
 
 
+@pytest.mark.parametrize("variant,md,strict", [("diffuse", -1, False), ("diffuse", 4, True), ("glossy", 9, False), ("glass", 10, False), ("twosided", 8, True)])
+def test_environment_emitter_samples_and_film_match_oracle(G, variant, md, strict):
+    """`<emitter type="constant">`: environment hits of base and offset paths, environmentShift, the environment in light
+    sampling (gpt.cpp:96-114,348-369,786-804,1052-1074; constant.cpp).  The wide film sees the environment past the box."""
+    W, H, spp = 44, 30, 5
+    sc = scenes.cornell_box(W, H, variant, environment=(0.6, 0.8, 1.1))
+    S = G.Scene(sc); O = go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict)
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=md, spp=spp, strictNormals=strict)
+    rng = np.random.default_rng(5)
+    hit_env = 0
+    for _ in range(120):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g = S.evaluate_point(cfg, px, py, s); o = O.evaluate_point(ocfg, px, py, s)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-9, atol=1e-13), (variant, px, py, s, key, g[key], o[key])
+        hit_env += int(np.allclose(o["veryDirect"], (0.6, 0.8, 1.1)))
+    assert hit_env > 0                                   # some primaries do leave the scene
+    F = G.Film(S)
+    integ.renderBlock(S, F, cfg, (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    oacc, orays = O.render(ocfg)
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (variant, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    F.close(); S.close(); O.close()
+
+
+def test_environment_only_scene_and_emitter_order(G):
+    """No area light at all (the environment is the only emitter), and the environment first in the emitter list."""
+    W, H, spp = 36, 24, 4
+    sc = scenes.cornell_box(W, H, "diffuse", environment=(1.0, 0.9, 0.7))
+    sc_first = scenes.cornell_box(W, H, "diffuse", environment=(1.0, 0.9, 0.7)); sc_first.environment = (sc_first.environment[0], 0)
+    only = scenes.cornell_box(W, H, "diffuse", environment=(1.0, 0.9, 0.7)); only.emitters = []
+    for sc_ in (sc_first, only):
+        S = G.Scene(sc_); O = go.Scene(sc_); F = G.Film(S)
+        integ = G.GradientPathIntegrator(maxDepth=6)
+        integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+        oacc, orays = O.render(go.config(maxDepth=6, spp=spp))
+        st = F.stats(); acc = F.accum()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b])
+        F.close(); S.close(); O.close()
+    a = go.Scene(sc).render(go.config(maxDepth=6, spp=spp))[0]
+    b = go.Scene(sc_first).render(go.config(maxDepth=6, spp=spp))[0]
+    assert not np.allclose(a[1], b[1])                   # the order decides which light samples pick the environment
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzzed_materials_and_settings_match_oracle(G, seed):
     """Random materials (all carried BSDFs, both distributions, anisotropic and near-specular roughness, visible-normal
@@ -71,7 +120,7 @@ def test_fuzzed_materials_and_settings_match_oracle(G, seed):
     random (pixel, sample) probes: every output of evaluatePoint and both ray counters against the oracle."""
     rng = np.random.default_rng(1000 + seed)
     W, H = 40, 32
-    sc = scenes.cornell_box(W, H, "random", seed=seed)
+    sc = scenes.cornell_box(W, H, "random", seed=seed, environment=(0.5, 0.7, 0.9) if seed % 3 == 0 else None)
     md = int(rng.choice([-1, 2, 3, 5, 9]))
     rr = int(rng.choice([1, 3, 5]))
     strict = bool(rng.random() < 0.35)
@@ -111,7 +160,7 @@ def test_fuzzed_films_match_oracle(G, seed):
     regeneration thresholds (none of which may change a result beyond the association of the per-pixel sums)."""
     rng = np.random.default_rng(seed)
     W, H, spp = int(rng.integers(17, 40)), int(rng.integers(9, 30)), int(rng.integers(1, 7))
-    sc = scenes.cornell_box(W, H, "random", seed=seed)
+    sc = scenes.cornell_box(W, H, "random", seed=seed, environment=(0.4, 0.5, 0.6) if seed % 2 == 0 else None)
     md, strict = int(rng.choice([-1, 3, 7])), bool(rng.random() < 0.3)
     S = G.Scene(sc); F = G.Film(S)
     F.set_slices(int(rng.integers(0, spp + 1))); F.set_regeneration(int(rng.choice([1, 24, 56, 64])))

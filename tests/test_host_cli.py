@@ -65,6 +65,13 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     assert json.loads(run(cli, "--parse-only", s).stdout)["materials"] == 2
     s = scene_with(tmp_path, '<bsdf type="twosided" id="w"><bsdf type="diffuse"/></bsdf><shape type="rectangle"><ref id="w"/></shape>' + LIGHT)
     assert json.loads(run(cli, "--parse-only", s).stdout)["materials"] == 2
+    # <emitter type="constant">: radiance and its place in the emitter list (XML order)
+    s = scene_with(tmp_path, '<emitter type="constant"><rgb name="radiance" value="0.5, 0.75, 1"/></emitter><shape type="rectangle"/>' + LIGHT)
+    assert json.loads(run(cli, "--parse-only", s).stdout)["environment"] == [0.5, 0.75, 1, 0]
+    s = scene_with(tmp_path, LIGHT + '<shape type="rectangle"/><emitter type="constant"/>')
+    assert json.loads(run(cli, "--parse-only", s).stdout)["environment"] == [1, 1, 1, 1]
+    s = scene_with(tmp_path, '<shape type="rectangle"/><emitter type="constant"/>')          # the environment alone lights the scene
+    assert json.loads(run(cli, "--parse-only", s).stdout)["emitters"] == 0
 
 
 @pytest.mark.parametrize("body,film,needle", [
@@ -74,7 +81,8 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     ('<shape type="rectangle"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>' + LIGHT, None, "transmission component"),
     ('<shape type="rectangle"><bsdf type="twosided"/></shape>' + LIGHT, None, "nested one-sided material is required"),
     ('<shape type="rectangle"><bsdf type="conductor"/></shape>' + LIGHT, None, "explicit eta and k"),
-    ('<shape type="rectangle"/>', None, "no area emitter"),
+    ('<shape type="rectangle"/>', None, "no emitter"),
+    ('<emitter type="constant"/><emitter type="constant"/>' + LIGHT, None, "Only one environment emitter"),
     (LIGHT, '<film type="hdrfilm"><rfilter type="box"/></film>', "without MultiFilm"),
     (LIGHT, '<film type="multifilm"><string name="fileFormat" value="pfm"/><rfilter type="gaussian"/></film>', "`box` only"),
     ('<emitter type="envmap"/>' + LIGHT, None, "not carried"),
@@ -174,5 +182,14 @@ def test_cli_render_equals_python_mirror(cli, tmp_path, gpu_required):
     for suffix in G.BUFFER_NAMES:
         img, attrs = read_exr(dest + "e" + suffix + ".exr")
         assert np.array_equal(img, out[suffix]) and b"Render time" in attrs["log"][1]
+    # the same box under a constant environment emitter (declared last: entry 1 of the emitter list)
+    xmlenv = str(tmp_path / "env.xml")
+    open(xmlenv, "w").write(open(XML).read().replace("</scene>", '<emitter type="constant"><rgb name="radiance" value="0.6, 0.8, 1.1"/></emitter></scene>'))
+    r = run(cli, "-o", dest + "v", "-D", "width=48", "-D", "height=40", "-D", "spp=6", "-D", "maxDepth=6", xmlenv)
+    assert r.returncode == 0, r.stderr
+    oute = G.GradientPathIntegrator(maxDepth=6).render(G.Scene(scenes.cornell_box(48, 40, environment=(0.6, 0.8, 1.1))), 6)
+    for suffix in G.BUFFER_NAMES:
+        assert np.array_equal(read_pfm(dest + "v" + suffix + ".pfm"), oute[suffix]), suffix
+    assert not np.array_equal(oute["-final"], out["-final"])
     bad = run(cli, "-o", dest, "-D", "width=16", "-D", "height=16", "-D", "maxDepth=0", XML)
     assert bad.returncode == 1 and "maxDepth" in bad.stderr
