@@ -25,7 +25,13 @@ from oracle import poisson_oracle as po           # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 POISSON_CASES = [("L2D", 40, 28), ("L1D", 40, 28), ("L2D", 33, 17), ("L2Q", 24, 16)]
-GPT_CASES = [("diffuse", -1), ("glossy", 8), ("nearspecular", 8), ("twosided", -1), ("glass", 10)]
+GPT_CASES = [("diffuse", -1), ("glossy", 8), ("nearspecular", 8), ("twosided", -1), ("glass", 10), ("glossy+env", 8)]
+ENV = (0.6, 0.8, 1.1)        # radiance of the `constant` environment emitter of the "+env" cases
+
+
+def build_scene(case, W, H):
+    variant, _, env = case.partition("+")
+    return scenes.cornell_box(W, H, variant, environment=ENV if env else None)
 GPT_SIZE = (48, 36)
 GPT_POINTS = 12
 
@@ -50,7 +56,7 @@ def main():
     rec = {}
     W, H = GPT_SIZE
     for variant, md in GPT_CASES:
-        O = go.Scene(scenes.cornell_box(W, H, variant))
+        O = go.Scene(build_scene(variant, W, H))
         cfg = go.config(maxDepth=md, spp=16)
         pts = []
         for (px, py, s) in gpt_points(variant):

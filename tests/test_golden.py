@@ -1,5 +1,6 @@
 """The frozen fixtures of tests/golden/ (see make_golden.py there for what they are and are not) against the restatement
 (CPU) and against the HIP path through the C-ABI (GPU).  Inputs are regenerated from their seeds; only outputs are stored."""
+import importlib.util
 import json
 import os
 
@@ -11,6 +12,12 @@ from oracle import gpt_oracle as go
 from oracle import poisson_oracle as po
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _build_scene(case, W, H):
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    return mg.build_scene(case, W, H)
 
 
 def _gpt_cases():
@@ -44,7 +51,7 @@ def test_gpt_restatement_is_frozen():
     d, cases = _gpt_cases()
     W, H = d["size"]
     for variant, md, pts in cases:
-        O = go.Scene(scenes.cornell_box(W, H, variant))
+        O = go.Scene(_build_scene(variant, W, H))
         cfg = go.config(maxDepth=md, spp=d["spp"], seed=d["seed"])
         for p in pts:
             e = O.evaluate_point(cfg, p["px"], p["py"], p["sample"])
@@ -76,7 +83,7 @@ def test_hip_gpt_against_golden(gpu_required):
     d, cases = _gpt_cases()
     W, H = d["size"]
     for variant, md, pts in cases:
-        S = gpt.Scene(scenes.cornell_box(W, H, variant))
+        S = gpt.Scene(_build_scene(variant, W, H))
         cfg = gpt.GradientPathIntegrator(maxDepth=md).config(d["spp"])
         for p in pts:
             e = S.evaluate_point(cfg, p["px"], p["py"], p["sample"])
