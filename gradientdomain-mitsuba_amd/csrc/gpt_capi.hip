@@ -282,7 +282,7 @@ int gdpt_scene_create_env(int numTris, const double *verts, const int *triMateri
         if (m.type < 0 || m.type > 3) return tfail(GDPT_ERR_UNSUPPORTED, "material %d: BSDF type %d is not carried (diffuse/conductor/roughconductor/dielectric only)", i, m.type);
         if (m.type == 3 && m.twoSided) return tfail(GDPT_ERR_INVALID, "material %d: Only materials without a transmission component can be nested!", i);   // twosided.cpp:96-98
         if (m.type == 3 && !(m.eta[0] > 0)) return tfail(GDPT_ERR_INVALID, "material %d: The interior and exterior indices of refraction must be positive!", i);
-        if (m.type == 2 && (m.distribution < 0 || m.distribution > 1)) return tfail(GDPT_ERR_UNSUPPORTED, "material %d: only beckmann and ggx distributions are carried", i);
+        if (m.type == 2 && (m.distribution < 0 || m.distribution > 2)) return tfail(GDPT_ERR_INVALID, "material %d: Specified an invalid distribution, must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!", i);   // microfacet.h:113-115
         MaterialD &o = mats[i];
         o.type = m.type; o.distribution = m.distribution; o.sampleVisible = m.sampleVisible; o.twoSided = m.twoSided != 0;
         o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));

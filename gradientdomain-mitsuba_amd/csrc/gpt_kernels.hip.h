@@ -40,6 +40,7 @@ typedef double Float;
 #define GD_D_EPSILON      1e-14                /* gpt.cpp:63 */
 #define GD_PI             3.14159265358979323846
 #define GD_INV_PI         0.31830988618379067154
+#define GD_INV_TWOPI      0.15915494309189533577
 #define GD_INF            (__builtin_huge_val())
 
 constexpr int TBLK = 256;          // threads per block (16x16 px)
@@ -341,9 +342,43 @@ __device__ __forceinline__ Float hypot2(Float a, Float b)
     return r;
 }
 
-// ---- MicrofacetDistribution (src/bsdfs/microfacet.h), Beckmann and GGX ---------------------------------------
+// ---- MicrofacetDistribution (src/bsdfs/microfacet.h): Beckmann (0), GGX (1), Phong / Ashikhmin-Shirley (2) -------------------
 struct Mf { int type; Float aU, aV; bool sv; };
-__device__ __forceinline__ Mf mf_of(const MaterialD &m) { Mf d; d.type = m.distribution; d.aU = fmax(m.alphaU, (Float)1e-4f); d.aV = fmax(m.alphaV, (Float)1e-4f); d.sv = m.sampleVisible != 0; return d; } // :70-71
+__device__ __forceinline__ Mf mf_of(const MaterialD &m)
+{ // :70-71,135-144: visible-normal sampling is not supported for Phong
+    Mf d; d.type = m.distribution; d.aU = fmax(m.alphaU, (Float)1e-4f); d.aV = fmax(m.alphaV, (Float)1e-4f); d.sv = m.sampleVisible != 0 && m.distribution != 2; return d;
+}
+// The Phong pieces are real calls (pow is large, and the two common distributions should not pay for its registers).
+__device__ __forceinline__ Float phong_exponent(Float a) { return fmax(2.0 / (a * a) - 2.0, (Float)0.0); }   // computePhongExponent, :701-704
+__device__ __noinline__ Float mf_phong_eval(Float aU, Float aV, d3 m)
+{ // :215-221 with interpolatePhongExponent :554-565
+    const Float eU = phong_exponent(aU), eV = phong_exponent(aV);
+    const Float sinTheta2 = 1.0 - m.z * m.z;
+    Float e = eU;
+    if (!(aU == aV || sinTheta2 <= 0x1p-1024)) { const Float inv = 1 / sinTheta2; e = eU * (m.x * m.x * inv) + eV * (m.y * m.y * inv); }
+    return sqrt((eU + 2) * (eV + 2)) * GD_INV_TWOPI * pow(m.z, e);
+}
+__device__ __noinline__ d3 mf_phong_sample(Float aU, Float aV, Float sx, Float sy, Float &pdf)
+{ // sampleAll, :349-375 with sampleFirstQuadrant :707-715
+    const Float eU = phong_exponent(aU), eV = phong_exponent(aV);
+    Float phiM, exponent;
+    auto quadrant = [&](Float u1) {
+        phiM = atan(sqrt((eU + 2.0) / (eV + 2.0)) * tan(GD_PI * u1 * 0.5));
+        const Float c = cos(phiM), sn = sin(phiM);
+        exponent = eU * c * c + eV * sn * sn;
+    };
+    if (aU == aV) { phiM = (2.0 * GD_PI) * sy; exponent = eU; }
+    else if (sy < (Float)0.25f) quadrant(4 * sy);
+    else if (sy < (Float)0.5f) { quadrant(4 * (0.5 - sy)); phiM = GD_PI - phiM; }
+    else if (sy < (Float)0.75f) { quadrant(4 * (sy - 0.5)); phiM += GD_PI; }
+    else { quadrant(4 * (1 - sy)); phiM = 2 * GD_PI - phiM; }
+    const Float sinPhiM = sin(phiM), cosPhiM = cos(phiM);
+    const Float cosThetaM = pow(sx, 1.0 / (exponent + 2.0));
+    pdf = sqrt((eU + 2.0) * (eV + 2.0)) * GD_INV_TWOPI * pow(cosThetaM, exponent + 1.0);
+    if (pdf < (Float)1e-20f) pdf = 0;
+    const Float sinThetaM = sqrt(fmax((Float)0.0, 1 - cosThetaM * cosThetaM));
+    return mk(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+}
 __device__ __forceinline__ Float mf_eval(const Mf &d, d3 m)
 { // :191-234
     if (m.z <= 0) return 0.0;
@@ -351,6 +386,7 @@ __device__ __forceinline__ Float mf_eval(const Mf &d, d3 m)
     const Float be = ((m.x * m.x) / (d.aU * d.aU) + (m.y * m.y) / (d.aV * d.aV)) / cosTheta2;
     Float result;
     if (d.type == 0) result = exp(-be) / (GD_PI * d.aU * d.aV * cosTheta2 * cosTheta2);
+    else if (d.type == 2) result = mf_phong_eval(d.aU, d.aV, m);
     else { const Float root = (1.0 + be) * cosTheta2; result = 1.0 / (GD_PI * d.aU * d.aV * root * root); }
     if (result * m.z < (Float)1e-20f) result = 0;
     return result;
@@ -368,7 +404,7 @@ __device__ __forceinline__ Float mf_G1(const Mf &d, d3 v, d3 m)
     const Float tanT = fabs(tanTheta(v));
     if (tanT == 0.0) return 1.0;
     const Float alpha = mf_projectRoughness(d, v);
-    if (d.type == 0) {
+    if (d.type != 1) {                                        // Beckmann and Phong share the rational approximation, :489-501
         const Float a = 1.0 / (alpha * tanT);
         if (a >= (Float)1.6f) return 1.0;
         const Float aSqr = a * a;
@@ -448,6 +484,7 @@ __device__ d3 mf_sample(const Mf &d, d3 _wi, Float sx, Float sy, Float &pdf)
         pdf = mf_pdfVisible(d, _wi, m);
         return m;
     }
+    if (d.type == 2) return mf_phong_sample(d.aU, d.aV, sx, sy, pdf);
     Float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
     if (d.aU == d.aV) {
         const Float ph = (2.0 * GD_PI) * sy;

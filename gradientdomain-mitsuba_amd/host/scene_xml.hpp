@@ -380,7 +380,8 @@ private:
                 if (nm == "distribution") {
                     if (v == "beckmann") m.distribution = GDPT_DISTR_BECKMANN;
                     else if (v == "ggx") m.distribution = GDPT_DISTR_GGX;
-                    else logError(format("microfacet distribution \"%s\" is not carried (beckmann, ggx)", v.c_str()));
+                    else if (v == "phong" || v == "as") m.distribution = GDPT_DISTR_PHONG;          // microfacet.h:108-112
+                    else logError("Specified an invalid distribution \"" + v + "\", must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!");
                 } else if (nm == "material") logError("conductor `material` presets need Mitsuba's data/ior tables, which this build does not carry: give explicit eta and k");
                 else logError(format("bsdf \"%s\": parameter \"%s\" is not carried", type.c_str(), nm.c_str()));
             } else if (c->tag == "boolean") {

@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 MAT_DIFFUSE, MAT_CONDUCTOR, MAT_ROUGHCONDUCTOR, MAT_DIELECTRIC = 0, 1, 2, 3
-DISTR_BECKMANN, DISTR_GGX = 0, 1
+DISTR_BECKMANN, DISTR_GGX, DISTR_PHONG = 0, 1, 2
 
 
 def diffuse(rgb):
@@ -125,7 +125,7 @@ def _random_material(rng):
         m = conductor(**metal)
     elif kind in (2, 3):
         au = float(10.0 ** rng.uniform(-3.3, -0.4))                      # straddles shiftThreshold = 1e-3
-        m = roughconductor(au, **metal, distribution=DISTR_GGX if rng.random() < 0.5 else DISTR_BECKMANN,
+        m = roughconductor(au, **metal, distribution=int(rng.choice([DISTR_GGX, DISTR_BECKMANN, DISTR_PHONG])),
                            alphaV=float(au * rng.uniform(0.3, 3.0)) if rng.random() < 0.5 else None, sampleVisible=bool(rng.random() < 0.7))
     elif kind == 4:
         m = dielectric(int_ior=float(rng.uniform(1.2, 2.4)), ext_ior=float(rng.uniform(1.0, 1.1)))

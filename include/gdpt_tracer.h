@@ -31,6 +31,7 @@ extern "C" {
 #define GDPT_MAT_DIELECTRIC     3   /* src/bsdfs/dielectric.cpp: eta[0] = intIOR/extIOR, reflectance = specularReflectance, k = specularTransmittance */
 #define GDPT_DISTR_BECKMANN     0   /* src/bsdfs/microfacet.h EBeckmann */
 #define GDPT_DISTR_GGX          1   /* EGGX */
+#define GDPT_DISTR_PHONG        2   /* EPhong: Phong / Ashikhmin-Shirley ("phong" or "as"); never sampled by visible normals */
 
 typedef struct gdpt_material {
     int    type;            /* GDPT_MAT_*                                                        */

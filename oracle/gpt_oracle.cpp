@@ -119,7 +119,9 @@ inline void coordinateSystem(V3 a, V3 &b, V3 &c)
 
 // ---- materials --------------------------------------------------------------------------------------
 enum { MAT_DIFFUSE = 0, MAT_CONDUCTOR = 1, MAT_ROUGHCONDUCTOR = 2, MAT_DIELECTRIC = 3 };
-enum { DISTR_BECKMANN = 0, DISTR_GGX = 1 };
+enum { DISTR_BECKMANN = 0, DISTR_GGX = 1, DISTR_PHONG = 2 };     // MicrofacetDistribution::EType, microfacet.h:47-57
+const Float RCPOVERFLOW = 0x1p-1024;                              // constants.h:59,97
+const Float INV_TWOPI = 0.15915494309189533577;                   // constants.h
 // BSDF::EBSDFType bits used here (include/mitsuba/render/bsdf.h): diffuse/glossy reflection are smooth, delta is not
 enum { EDiffuseReflection = 0x1, EGlossyReflection = 0x4, EDeltaReflection = 0x10, EDeltaTransmission = 0x20, ESmooth = 0x1 | 0x4, EDelta = 0x10 | 0x20 };
 enum { MEASURE_SOLID_ANGLE = 0, MEASURE_DISCRETE = 1 };
@@ -516,8 +518,31 @@ struct Microfacet {
     int type;
     Float alphaU, alphaV;
     bool sampleVisible;
-    Microfacet(int t, Float au, Float av, bool sv) : type(t), alphaU(std::max(au, (Float)1e-4f)), alphaV(std::max(av, (Float)1e-4f)), sampleVisible(sv) {} // :70-71
+    Float exponentU, exponentV;                     // Phong / Ashikhmin-Shirley exponents, computePhongExponent :701-704
+    Microfacet(int t, Float au, Float av, bool sv) : type(t), alphaU(std::max(au, (Float)1e-4f)), alphaV(std::max(av, (Float)1e-4f)), sampleVisible(sv)
+    { // :135-144
+        exponentU = exponentV = 0;
+        if (type == DISTR_PHONG) {                  // visible-normal sampling is not supported for Phong
+            sampleVisible = false;
+            exponentU = std::max(2.0 / (alphaU * alphaU) - 2.0, (Float)0.0);
+            exponentV = std::max(2.0 / (alphaV * alphaV) - 2.0, (Float)0.0);
+        }
+    }
     bool isIsotropic() const { return alphaU == alphaV; }
+    Float interpolatePhongExponent(V3 v) const
+    { // :554-565
+        const Float sinTheta2 = 1.0 - v.z * v.z;
+        if (isIsotropic() || sinTheta2 <= RCPOVERFLOW) return exponentU;
+        Float invSinTheta2 = 1 / sinTheta2;
+        Float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+        return exponentU * cosPhi2 + exponentV * sinPhi2;
+    }
+    void sampleFirstQuadrant(Float u1, Float &phi, Float &exponent) const
+    { // :707-715
+        phi = std::atan(std::sqrt((exponentU + 2.0) / (exponentV + 2.0)) * std::tan(PI * u1 * 0.5));
+        Float cosPhi = std::cos(phi), sinPhi = std::sin(phi);
+        exponent = exponentU * cosPhi * cosPhi + exponentV * sinPhi * sinPhi;
+    }
     Float eval(V3 m) const
     { // :191-234
         if (cosTheta(m) <= 0) return 0.0;
@@ -525,6 +550,7 @@ struct Microfacet {
         Float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
         Float result;
         if (type == DISTR_BECKMANN) result = std::exp(-beckmannExponent) / (PI * alphaU * alphaV * cosTheta2 * cosTheta2);
+        else if (type == DISTR_PHONG) result = std::sqrt((exponentU + 2) * (exponentV + 2)) * INV_TWOPI * std::pow(cosTheta(m), interpolatePhongExponent(m)); // :215-221
         else { Float root = (1.0 + beckmannExponent) * cosTheta2; result = 1.0 / (PI * alphaU * alphaV * root * root); }
         if (result * cosTheta(m) < (Float)1e-20f) result = 0;
         return result;
@@ -542,7 +568,7 @@ struct Microfacet {
         Float tanT = std::abs(tanTheta(v));
         if (tanT == 0.0) return 1.0;
         Float alpha = projectRoughness(v);
-        if (type == DISTR_BECKMANN) {
+        if (type == DISTR_BECKMANN || type == DISTR_PHONG) {                    // :489-501
             Float a = 1.0 / (alpha * tanT);
             if (a >= (Float)1.6f) return 1.0;
             Float aSqr = a * a;
@@ -626,8 +652,22 @@ struct Microfacet {
         return V3(-rx * normalization, -ry * normalization, normalization);
     }
     V3 sampleAll(Float sx, Float sy, Float &pdf) const
-    { // :300-414 (Beckmann/GGX)
+    { // :300-414
         Float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
+        if (type == DISTR_PHONG) {                                              // :349-375
+            Float phiM, exponent;
+            if (isIsotropic()) { phiM = (2.0 * PI) * sy; exponent = exponentU; }
+            else if (sy < (Float)0.25f) sampleFirstQuadrant(4 * sy, phiM, exponent);
+            else if (sy < (Float)0.5f) { sampleFirstQuadrant(4 * (0.5 - sy), phiM, exponent); phiM = PI - phiM; }
+            else if (sy < (Float)0.75f) { sampleFirstQuadrant(4 * (sy - 0.5), phiM, exponent); phiM += PI; }
+            else { sampleFirstQuadrant(4 * (1 - sy), phiM, exponent); phiM = 2 * PI - phiM; }
+            sinPhiM = std::sin(phiM); cosPhiM = std::cos(phiM);
+            cosThetaM = std::pow(sx, 1.0 / (exponent + 2.0));
+            pdf = std::sqrt((exponentU + 2.0) * (exponentV + 2.0)) * INV_TWOPI * std::pow(cosThetaM, exponent + 1.0);
+            if (pdf < (Float)1e-20f) pdf = 0;
+            Float sinThetaM = std::sqrt(std::max(0.0, 1 - cosThetaM * cosThetaM));
+            return V3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+        }
         if (isIsotropic()) {
             Float ph = (2.0 * PI) * sy;
             sinPhiM = std::sin(ph); cosPhiM = std::cos(ph);

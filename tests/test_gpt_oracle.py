@@ -232,3 +232,23 @@ def test_environment_emitter_restatement():
     acc, _ = O.render(go.config(maxDepth=6, spp=4000), rect=(px - 1, py - 1, px + 2, py + 2))
     thr = go.develop(acc)[1][py, px]
     assert np.allclose(thr, ref, rtol=0.06), (thr, ref)
+
+
+def test_phong_distribution_restatement():
+    """MicrofacetDistribution EPhong (microfacet.h:215-221,349-375,489-501,554-565,701-715): sampleAll's pdf is eval*cos,
+    the BSDF's sample weight is f/pdf, visible-normal sampling is switched off, and the isotropic pdf integrates to one."""
+    rng = np.random.default_rng(11)
+    for alphaV in (None, 0.12):
+        m = scenes.roughconductor(0.3, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), distribution=scenes.DISTR_PHONG, alphaV=alphaV, sampleVisible=True)
+        wi = unit([0.3, -0.2, 0.9])
+        for _ in range(400):
+            wo, w, pdf, _t = go.bsdf_sample(m, wi, rng.random(), rng.random())
+            if pdf > 0:
+                f, p = go.bsdf_eval_pdf(m, wi, wo)
+                assert np.isclose(p, pdf, rtol=1e-9) and np.allclose(f / pdf, w, rtol=1e-9, atol=1e-12)
+    m = scenes.roughconductor(0.4, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), distribution=scenes.DISTR_PHONG)
+    wi = unit([0.1, 0.2, 0.97])
+    u = rng.random((30000, 2))
+    z = u[:, 0]; r = np.sqrt(1 - z * z); ph = 2 * np.pi * u[:, 1]
+    tot = sum(go.bsdf_eval_pdf(m, wi, (r[i] * np.cos(ph[i]), r[i] * np.sin(ph[i]), z[i]))[1] for i in range(len(z)))
+    assert abs(tot / len(z) * 2 * np.pi - 1.0) < 0.05
