@@ -221,6 +221,12 @@ int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, 
 int gdpt_scene_create_env(int numTris, const double *verts, const int *triMaterial, int numMaterials, const gdpt_material *materials,
                           int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env, const gdpt_camera *camera, int device, gdpt_scene **out)
 {
+    return gdpt_scene_create_ex(numTris, verts, nullptr, triMaterial, numMaterials, materials, numEmitters, emitters, env, camera, device, out);
+}
+
+int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals, const int *triMaterial, int numMaterials, const gdpt_material *materials,
+                         int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env, const gdpt_camera *camera, int device, gdpt_scene **out)
+{
     if (!verts || !triMaterial || !materials || !camera || !out || numTris <= 0 || numMaterials <= 0)
         return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
     if (numEmitters < 0 || (numEmitters > 0 && !emitters)) return tfail(GDPT_ERR_INVALID, "scene_create: bad emitter list");
@@ -256,6 +262,7 @@ int gdpt_scene_create_env(int numTris, const double *verts, const int *triMateri
     // triangle records in leaf order
     std::vector<TriIsect> isect(numTris);
     std::vector<TriShade> shade(numTris);
+    std::vector<TriNormals> vn;                               // leaf order; stays empty when no triangle has vertex normals
     for (int li = 0; li < numTris; li++) {
         const int t = bld.order[li];
         const H3 p0 = h3(verts[9 * t], verts[9 * t + 1], verts[9 * t + 2]), p1 = h3(verts[9 * t + 3], verts[9 * t + 4], verts[9 * t + 5]),
@@ -273,7 +280,19 @@ int gdpt_scene_create_env(int numTris, const double *verts, const int *triMateri
         s.material = triMaterial[t];
         s.emitter = emitterOf[t];
         s.origIndex = t;
-        s.pad = 0;
+        s.smooth = 0;
+        if (normals) {                                        // per-vertex normals; three zero vectors = none for this triangle
+            const double *n = normals + 9 * (size_t)t;
+            bool any = false;
+            for (int k = 0; k < 9; k++) any = any || n[k] != 0.0;
+            if (any) {
+                if (emitterOf[t] >= 0) return tfail(GDPT_ERR_UNSUPPORTED, "triangle %d: per-vertex normals on an emitter mesh are not carried (AreaLight::eval / TriMesh::samplePosition with interpolated normals)", t);
+                if (vn.empty()) vn.resize(numTris);
+                TriNormals &o = vn[li];
+                o.n0 = to_d3(h3(n[0], n[1], n[2])); o.n1 = to_d3(h3(n[3], n[4], n[5])); o.n2 = to_d3(h3(n[6], n[7], n[8])); o.pad = 0.0;
+                s.smooth = 1;
+            }
+        }
     }
 
     std::vector<MaterialD> mats(numMaterials);
@@ -342,6 +361,8 @@ int gdpt_scene_create_env(int numTris, const double *verts, const int *triMateri
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = totalEmitters;
     d.rootRef = rootRef;
+    d.vn = nullptr;
+    if (!vn.empty()) { TriNormals *dvn; if ((rc = upload(&dvn, vn))) { gdpt_scene_destroy(s); return rc; } s->allocs.push_back(dvn); d.vn = dvn; }
     d.envIndex = envIndex;
     if (env) {
         // ConstantBackgroundEmitter::createShape (constant.cpp:67-70): bounding sphere of Scene::getAABB() at that moment = the
@@ -464,7 +485,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     size_t lds = (size_t)stackDepth * TBLK * sizeof(int);
     const int sceneBytes = s->d.ldsScene ? (int)((s->ldsSceneBytes + 15) & ~(size_t)15) : 0;
     lds += sceneBytes;
-    const int wps = s->d.envIndex >= 0 ? (f->wavesPerSimd <= 2 ? 2 : 4) : f->wavesPerSimd;   // environment scenes: 2- and 4-wave builds only
+    const int wps = f->wavesPerSimd <= 2 ? 2 : 4;          // the render kernel is built for 2 and for 4 resident waves per SIMD
     const size_t accBytes = sizeof(Float) * ACC_N * TBLK;
     const bool accLds = f->accInLds && (lds + accBytes) * (size_t)std::max(1, wps) <= (size_t)160 * 1024;
     if (accLds) lds += accBytes;
@@ -488,12 +509,13 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     }
     f->lastSlices = slices;
     const dim3 grid(tiles * slices), block(TBLK);
-#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
-    // scenes without an environment emitter run builds with its branches compiled out (1..4 waves/SIMD); scenes with one have the 2- and 4-wave builds
+#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
+    // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment emitter | + per-vertex normals (environment tested at run time)};
+    // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { \
-        if (s->d.envIndex >= 0) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true); else GDPT_LAUNCH(LDSV, ACCV, 4, true); } \
-        else if (wps == 1) GDPT_LAUNCH(LDSV, ACCV, 1, false); else if (wps == 2) GDPT_LAUNCH(LDSV, ACCV, 2, false); \
-        else if (wps == 3) GDPT_LAUNCH(LDSV, ACCV, 3, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false); } while (0)
+        if (s->d.vn)                { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, true);   else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
+        else if (s->d.envIndex >= 0) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, false); } \
+        else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
     else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #undef GDPT_LAUNCH_W

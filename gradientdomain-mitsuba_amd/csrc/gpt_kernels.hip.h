@@ -89,14 +89,15 @@ struct TriShade {           // 160 B: what fillIntersectionRecord needs (skdtree
     d3 p0, p1, p2;
     d3 n, s, t;             // shading frame == geometric frame normal for meshes without vertex normals
     int material, emitter;  // emitter = -1 if none
-    int origIndex, pad;
+    int origIndex, smooth;  // smooth = 1: the triangle has per-vertex normals (TriNormals table), its frame depends on the hit
 };
+struct TriNormals { d3 n0, n1, n2; Float pad; };   // 80 B: per-vertex normals in leaf order (only scenes that have any)
 struct MaterialD {           // 112 B (a multiple of 16: tables are staged into LDS with 16-byte copies)
     int type, distribution, sampleVisible, twoSided;
     d3 reflectance, eta, k;
     Float alphaU, alphaV, pad2;
 };
-static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0, "LDS staging copies 16-byte words");
+static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp)
     int firstEmTri, numTris, cdfOffset, pad;
     d3 radiance;
@@ -121,6 +122,7 @@ struct SceneD {
     Float emitterNormalization;
     int numNodes, numTris, numEmitters, numMats, ldsScene;
     uint32_t rootRef;
+    const TriNormals *vn;       // per-vertex normals in leaf order, nullptr if the scene has none
     int envIndex;               // position of the environment emitter in the emitter list, -1: none
     d3 bsCenter;                // its bounding sphere (ConstantBackgroundEmitter::m_sceneBSphere)
     Float bsRadius;
@@ -178,6 +180,7 @@ struct SceneView {
     const TriShade *shade;
     const MaterialD *mats;
     const EmitterD *emitters;
+    const TriNormals *vn;       // nullptr: no triangle has vertex normals
     uint32_t rootRef;
 };
 
@@ -838,6 +841,7 @@ enum { RAY_NOT_CONNECTED = 0, RAY_RECENTLY_CONNECTED = 1, RAY_CONNECTED = 2 };  
 struct Vertex {             // the part of Mitsuba's Intersection the path keeps; wi = toLocal(frame(prim), -rayD) is recomputed
     d3 p;                   // position
     int prim;               // leaf-order triangle, -1 = invalid
+    Float u, v;             // barycentrics of the hit (only kept live in builds for scenes with vertex normals)
 };
 struct Offset {             // RayState of an offset path, gpt.cpp:135-173 (its radiance/gradient sums live in the Acc)
     d3 throughput;
@@ -849,7 +853,31 @@ struct Offset {             // RayState of an offset path, gpt.cpp:135-173 (its 
 
 __device__ __forceinline__ Frame3 frame_of(const TriShade &t) { Frame3 f; f.s = t.s; f.t = t.t; f.n = t.n; return f; }
 
-// fillIntersectionRecord<true>, skdtree.h:343-428 (flat triangle): barycentric position (wi: see local_wi)
+// Shading frame and geometric normal at a vertex (fillIntersectionRecord, skdtree.h:367-397,426).  Flat triangles: the constants of
+// the triangle.  With per-vertex normals (SMOOTH builds): n = normalize(sum b_i n_i), the geometric normal is flipped to the side of
+// n, and (s, t) come from computeShadingFrame(n, dpdu = p1 - p0) (util.cpp:603-608).
+struct Shading { Frame3 fr; d3 geoN; };
+template <bool SMOOTH>
+__device__ __forceinline__ Shading shading_at(const SceneView &S, const Vertex &v)
+{
+    const TriShade &ts = S.shade[v.prim];
+    Shading sh;
+    sh.fr = frame_of(ts);
+    sh.geoN = ts.n;
+    if (SMOOTH && ts.smooth) {
+        const TriNormals vn = S.vn[v.prim];
+        const d3 b = mk(1 - v.u - v.v, v.u, v.v);
+        const d3 n = normalize(vn.n0 * b.x + vn.n1 * b.y + vn.n2 * b.z);
+        if (dot(ts.n, n) < 0) sh.geoN = -ts.n;
+        const d3 dpdu = ts.p1 - ts.p0;
+        sh.fr.n = n;
+        sh.fr.s = normalize(dpdu - n * dot(n, dpdu));
+        sh.fr.t = cross(n, sh.fr.s);
+    }
+    return sh;
+}
+
+// fillIntersectionRecord<true>, skdtree.h:343-428: barycentric position (frame: shading_at; wi: local_wi)
 __device__ __forceinline__ void fill_vertex(const SceneView &S, const Hit &h, d3 rayD, Vertex &v)
 {
     v.prim = h.prim;
@@ -857,10 +885,12 @@ __device__ __forceinline__ void fill_vertex(const SceneView &S, const Hit &h, d3
     const TriShade &ts = S.shade[h.prim];
     const d3 b = mk(1 - h.u - h.v, h.u, h.v);
     v.p = ts.p0 * b.x + ts.p1 * b.y + ts.p2 * b.z;
+    v.u = h.u; v.v = h.v;
 }
 
 // its.wi = its.toLocal(-ray.d), skdtree.h:427
-__device__ __forceinline__ d3 local_wi(const SceneView &S, int prim, d3 rayD) { return toLocal(frame_of(S.shade[prim]), -rayD); }
+template <bool SMOOTH>
+__device__ __forceinline__ d3 local_wi(const SceneView &S, const Vertex &v, d3 rayD) { return toLocal(shading_at<SMOOTH>(S, v).fr, -rayD); }
 
 // AreaLight::eval via Intersection::Le, area.cpp:104-109
 __device__ __forceinline__ d3 emitted(const SceneView &S, int prim, d3 d)

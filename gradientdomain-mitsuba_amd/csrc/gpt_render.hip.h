@@ -42,7 +42,7 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
-template <bool ENV, class ACC>
+template <bool ENV, bool SMOOTH, class ACC>
 __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample)
 {
     const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
@@ -84,11 +84,11 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     }
     A.add3(ACC_VD, L.throughput * emitted(sv, L.v.prim, -L.rayD));                // :497-499
     if (cfg.strictNormals) {                                                     // :516-531
-        if (dot(L.rayD, sv.shade[L.v.prim].n) * local_wi(sv, L.v.prim, L.rayD).z >= 0) return false;
+        { const Shading sh = shading_at<SMOOTH>(sv, L.v); if (dot(L.rayD, sh.geoN) * toLocal(sh.fr, -L.rayD).z >= 0) return false; }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Offset &s = L.off[i];
-            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * local_wi(sv, s.v.prim, s.rayD).z >= 0) s.alive = 0;
+            if (s.alive) { const Shading sh = shading_at<SMOOTH>(sv, s.v); if (dot(s.rayD, sh.geoN) * toLocal(sh.fr, -s.rayD).z >= 0) s.alive = 0; }
         }
     }
     return true;
@@ -96,20 +96,22 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 
 // One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
 // ENV: the scene may have an environment emitter (compiled out otherwise: its branches cost the closed scenes 5-8 %).
-template <bool ENV, class ACC>
+// SMOOTH: the scene has triangles with per-vertex normals (shading frame and geometric normal depend on the hit).
+template <bool ENV, bool SMOOTH, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
     const TriShade &mts = sv.shade[L.v.prim];
-    const Frame3 mfr = frame_of(mts);
-    const d3 mGeoN = mts.n;
+    const Shading msh = shading_at<SMOOTH>(sv, L.v);
+    const Frame3 mfr = msh.fr;
+    const d3 mGeoN = msh.geoN;
     const d3 mainWi = toLocal(mfr, -L.rayD);                                     // its.wi
     if (cfg.strictNormals) {                                                     // :541-556
         if (dot(L.rayD, mGeoN) * mainWi.z >= 0) return false;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Offset &s = L.off[i];
-            if (s.alive && dot(s.rayD, sv.shade[s.v.prim].n) * local_wi(sv, s.v.prim, s.rayD).z >= 0) s.alive = 0;
+            if (s.alive) { const Shading sh = shading_at<SMOOTH>(sv, s.v); if (dot(s.rayD, sh.geoN) * toLocal(sh.fr, -s.rayD).z >= 0) s.alive = 0; }
         }
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
@@ -162,7 +164,8 @@ GDPT_OFFSET_LOOP
                         const TriShade &sts = sv.shade[s.v.prim];
                         const MaterialD &shiftedBSDF = sv.mats[sts.material];
                         if (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth)) {
-                            const Frame3 sfr = frame_of(sts);
+                            const Shading ssh = shading_at<SMOOTH>(sv, s.v);
+                            const Frame3 sfr = ssh.fr;
                             DRec sRec;
                             sRec.ref = s.v.p; sRec.refN = (shiftedBSDF.twoSided || shiftedBSDF.type == 3) ? mk(0.0) : sfr.n;
                             d3 sv_ = sample_emitter_direct<ENV>(S, sv, sRec, lsx, lsy);
@@ -174,7 +177,7 @@ GDPT_OFFSET_LOOP
                             const d3 emitterDirection = (dRec.p - s.v.p) / sqrt(shiftedDistanceSquared);
                             const Float shiftedOpposingCosine = -dot(dRec.n, emitterDirection);
                             const d3 woL = toLocal(sfr, emitterDirection);
-                            if (cfg.strictNormals && dot(sts.n, emitterDirection) * woL.z < 0) {
+                            if (cfg.strictNormals && dot(ssh.geoN, emitterDirection) * woL.z < 0) {
                                 shiftSuccessful = false;
                             } else {
                                 d3 f;
@@ -281,7 +284,8 @@ GDPT_OFFSET_LOOP
             } else {                                                             // :889-1126
                 const TriShade &sts = sv.shade[s.v.prim];
                 const MaterialD &shiftedBSDF = sv.mats[sts.material];
-                const Frame3 sfr = frame_of(sts);
+                const Shading ssh = shading_at<SMOOTH>(sv, s.v);
+                const Frame3 sfr = ssh.fr;
                 const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
                 if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
                     // ---- reconnection shift, :897-986 ----
@@ -299,7 +303,7 @@ GDPT_OFFSET_LOOP
                             // reconnection at infinity: J = 1, wo = the base direction (:364-366); radiance and light pdf of the base (:972-976)
                             const d3 shiftedWo = L.rayD;
                             const d3 woL = toLocal(sfr, shiftedWo);
-                            if (cfg.strictNormals && dot(shiftedWo, sts.n) * woL.z <= 0) { s.alive = 0; }
+                            if (cfg.strictNormals && dot(shiftedWo, ssh.geoN) * woL.z <= 0) { s.alive = 0; }
                             else {
                                 d3 f;
                                 Float shiftedBsdfPdf;
@@ -316,11 +320,12 @@ GDPT_OFFSET_LOOP
                             const d3 mainEdge = L.rayO - L.v.p, shiftedEdge = s.v.p - L.v.p;
                             const Float mainEdgeLengthSquared = len2(mainEdge), shiftedEdgeLengthSquared = len2(shiftedEdge);
                             const d3 shiftedWo = -shiftedEdge / sqrt(shiftedEdgeLengthSquared);
-                            const Float mainOpposingCosine = dot(mainEdge, nts.n) / sqrt(mainEdgeLengthSquared);
-                            const Float shiftedOpposingCosine = dot(shiftedWo, nts.n);
+                            const d3 nGeoN = SMOOTH ? shading_at<SMOOTH>(sv, L.v).geoN : nts.n;      // main.rRec.its.geoFrame.n, :911
+                            const Float mainOpposingCosine = dot(mainEdge, nGeoN) / sqrt(mainEdgeLengthSquared);
+                            const Float shiftedOpposingCosine = dot(shiftedWo, nGeoN);
                             const Float jacobian = fabs(shiftedOpposingCosine * mainEdgeLengthSquared) / (GD_D_EPSILON + fabs(mainOpposingCosine * shiftedEdgeLengthSquared));
                             const d3 woL = toLocal(sfr, shiftedWo);
-                            if (cfg.strictNormals && dot(shiftedWo, sts.n) * woL.z <= 0) { s.alive = 0; }
+                            if (cfg.strictNormals && dot(shiftedWo, ssh.geoN) * woL.z <= 0) { s.alive = 0; }
                             else {
                                 d3 f;
                                 Float shiftedBsdfPdf;
@@ -364,7 +369,7 @@ GDPT_OFFSET_LOOP
                         s.throughput = s.throughput * f;
                         s.pdf *= p;
                         if (s.pdf == 0) ok = false;                              // :1034
-                        else if (cfg.strictNormals && dot(outgoing, sts.n) * tsOut.z <= 0) ok = false;
+                        else if (cfg.strictNormals && dot(outgoing, ssh.geoN) * tsOut.z <= 0) ok = false;
                         else {
                             Hit h;
                             L.nClosest++;
@@ -462,7 +467,7 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
     }
 }
 
-template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV>
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
 __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
 {
     // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)][per-sample sums (ACC_LDS only)]; sized by the host from
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         sv.emitters = reinterpret_cast<const EmitterD *>(s_scene + offs[4]);
     } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; }
     sv.rootRef = S.rootRef;
+    sv.vn = S.vn;                      // per-vertex normals stay in HBM (scenes that have them are rarely LDS-resident)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // work item = (16x16 pixel tile, slice of the spp samples).  Slices exist so that a launch smaller than the chip (a strip of
@@ -525,13 +531,13 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
             if (pending) finish_path(F, flt, L, A, px, py);
-            active = start_path<ENV>(S, sv, cfg, stack, L, A, px, py, next);
+            active = start_path<ENV, SMOOTH>(S, sv, cfg, stack, L, A, px, py, next);
             next++;
             pending = !active;
             if (!active) { paths++; pathLen += L.depth; }
         }
         if (active) {
-            if (!bounce<ENV>(S, sv, cfg, stack, L, A)) {
+            if (!bounce<ENV, SMOOTH>(S, sv, cfg, stack, L, A)) {
                 active = false;
                 pending = true;
                 paths++; pathLen += L.depth;
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.vn = S.vn;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     if (i >= n) return;
     const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
@@ -656,12 +662,12 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.vn = S.vn;
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
-    bool active = start_path<true>(S, sv, cfg, s_stack, L, A, px, py, sample);
-    while (active) active = bounce<true>(S, sv, cfg, s_stack, L, A);
+    bool active = start_path<true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
+    while (active) active = bounce<true, true>(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];

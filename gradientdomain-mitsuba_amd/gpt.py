@@ -75,9 +75,12 @@ class Scene:
         env = None
         if envd is not None:                                 # `<emitter type="constant">`: (radiance rgb, position in the emitter list)
             env = Environment((C.c_double * 3)(*envd[0]), int(envd[1]))
-        check(lib().gdpt_scene_create_env(verts.shape[0], verts.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p),
-                                          len(desc.materials), C.byref(mats), len(desc.emitters), C.byref(ems),
-                                          C.byref(env) if env is not None else None, C.byref(cam), device, C.byref(self._h)))
+        nrm = getattr(desc, "normals", None)
+        nrm = np.ascontiguousarray(nrm, dtype=np.float64) if nrm is not None else None
+        check(lib().gdpt_scene_create_ex(verts.shape[0], verts.ctypes.data_as(C.c_void_p),
+                                         nrm.ctypes.data_as(C.c_void_p) if nrm is not None else None, tm.ctypes.data_as(C.c_void_p),
+                                         len(desc.materials), C.byref(mats), len(desc.emitters), C.byref(ems),
+                                         C.byref(env) if env is not None else None, C.byref(cam), device, C.byref(self._h)))
 
     def intersect(self, origins, dirs):
         od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))

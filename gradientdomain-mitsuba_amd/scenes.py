@@ -73,6 +73,7 @@ class Scene:
     height: int = 512
     name: str = "scene"
     environment: tuple = None    # ((r, g, b), position in the scene's emitter list) for `<emitter type="constant">`, or None
+    normals: np.ndarray = None   # (ntri, 9) per-vertex normals (TriMesh vertex normals), all-zero rows = flat triangle; or None
 
     @property
     def ntri(self):
@@ -82,6 +83,37 @@ class Scene:
 class _Builder:
     def __init__(self):
         self.tris, self.mat_ids, self.materials, self.emitters = [], [], [], []
+        self.normals = {}            # triangle index -> 9 floats
+
+    def sphere(self, centre, radius, mat, level=1, bend=0.0, seed=0):
+        """Icosphere with per-vertex normals (position - centre, optionally bent by up to `bend` radians so that shading
+        and geometric normals disagree noticeably)."""
+        t = (1 + 5 ** 0.5) / 2
+        v = [np.array(q, np.float64) / np.linalg.norm(q) for q in
+             [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]]
+        f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+        for _ in range(level):
+            nf = []
+            for (a, b, c) in f:
+                ab, bc, ca = [x / np.linalg.norm(x) for x in (v[a] + v[b], v[b] + v[c], v[c] + v[a])]
+                i = len(v); v += [ab, bc, ca]
+                nf += [(a, i, i + 2), (b, i + 1, i), (c, i + 2, i + 1), (i, i + 1, i + 2)]
+            f = nf
+        rng = np.random.default_rng(seed)
+        nrm = []
+        for q in v:
+            n = q.copy()
+            if bend > 0:
+                d = rng.normal(size=3); d -= n * np.dot(d, n); d /= np.linalg.norm(d)
+                a = bend * rng.random()
+                n = n * np.cos(a) + d * np.sin(a)
+            nrm.append(n / np.linalg.norm(n))
+        c = np.asarray(centre, np.float64)
+        for (a, b, cc) in f:
+            self.normals[len(self.tris)] = np.concatenate([nrm[a], nrm[b], nrm[cc]])
+            self.tris.append(np.concatenate([c + radius * v[a], c + radius * v[b], c + radius * v[cc]]))
+            self.mat_ids.append(mat)
 
     def material(self, m):
         self.materials.append(m)
@@ -111,8 +143,13 @@ class _Builder:
         self.emitters.append((first_tri, num_tris, tuple(radiance)))
 
     def finish(self, **cam):
-        return Scene(np.asarray(self.tris, np.float64).reshape(-1, 9), np.asarray(self.mat_ids, np.int32),
-                     self.materials, self.emitters, **cam)
+        sc = Scene(np.asarray(self.tris, np.float64).reshape(-1, 9), np.asarray(self.mat_ids, np.int32),
+                   self.materials, self.emitters, **cam)
+        if self.normals:
+            sc.normals = np.zeros((len(self.tris), 9), np.float64)
+            for i, n in self.normals.items():
+                sc.normals[i] = n
+        return sc
 
 
 def _random_material(rng):
@@ -161,6 +198,9 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
     elif variant == "twosided":       # two-sided walls and a free-standing two-sided GGX panel lit and seen from both faces
         white = b.material(twosided(diffuse((0.725, 0.71, 0.68))))
         floor_m = back_m = tall_m = short_m = white
+    elif variant in ("smooth", "bent"):  # spheres with interpolated shading normals instead of the blocks ("bent": normals tilted up to 0.6 rad)
+        tall_m = b.material(roughconductor(0.12, **AL, distribution=DISTR_GGX))
+        short_m = white
     elif variant == "random":         # fuzz: floor, back wall and both blocks draw their materials from `seed`
         rng = np.random.default_rng(seed)
         floor_m, back_m, tall_m, short_m = (b.material(_random_material(rng)) for _ in range(4))
@@ -172,8 +212,12 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
     b.quad((549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2), back_m, room)  # back wall
     b.quad((0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2), green, room)                # right wall
     b.quad((552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0), red, room)      # left wall
-    b.box([(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)], 0.0, short_m)         # short block
-    b.box([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 0.0, tall_m)        # tall block
+    if variant in ("smooth", "bent"):
+        b.sphere((186, 90, 169), 90.0, short_m, level=1, bend=0.6 if variant == "bent" else 0.0, seed=1)
+        b.sphere((368, 150, 351), 150.0, tall_m, level=1, bend=0.6 if variant == "bent" else 0.0, seed=2)
+    else:
+        b.box([(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)], 0.0, short_m)         # short block
+        b.box([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 0.0, tall_m)        # tall block
     if variant == "twosided":
         panel = b.material(twosided(roughconductor(0.15, **AL, distribution=DISTR_GGX)))
         b.quad((60, 20, 150), (200, 20, 60), (200, 300, 60), (60, 300, 150), panel, room)

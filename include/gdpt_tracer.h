@@ -85,6 +85,14 @@ GDPT_API int  gdpt_scene_create_env(int numTris, const double *verts9, const int
                                     int numMaterials, const gdpt_material *materials,
                                     int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env,
                                     const gdpt_camera *camera, int device, gdpt_scene **out);
+/* The same with per-vertex normals: normals9 = 9 doubles per triangle (n0, n1, n2), three zero vectors = that triangle is flat;
+ * NULL = no vertex normals at all.  Shading frame and geometric normal then follow fillIntersectionRecord (skdtree.h:382-397):
+ * interpolated shading normal, geometric normal flipped to its side, (s, t) from computeShadingFrame with dpdu = p1 - p0.
+ * Emitter triangles must be flat (GDPT_ERR_UNSUPPORTED otherwise). */
+GDPT_API int  gdpt_scene_create_ex(int numTris, const double *verts9, const double *normals9, const int *triMaterial,
+                                   int numMaterials, const gdpt_material *materials,
+                                   int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env,
+                                   const gdpt_camera *camera, int device, gdpt_scene **out);
 GDPT_API void gdpt_scene_destroy(gdpt_scene *s);
 
 /* A film = the five G-PT buffers `-final -throughput -dx -dy -direct` (gpt.cpp:1380) over rows [y0, y1) of the
@@ -124,7 +132,8 @@ GDPT_API int  gdpt_film_stats(gdpt_film *f, unsigned long long stats[4]);
 GDPT_API float gdpt_film_render_ms(gdpt_film *f);
 GDPT_API void *gdpt_film_stream(gdpt_film *f);
 /* Tuning knob (no reference counterpart): which build of the render kernel to launch -- the one compiled for 1, 2 (default),
- * 3 or 4 resident waves per SIMD (register budget 512 / n per lane); a negative value selects the same build with the
+ * 3 or 4 resident waves per SIMD (register budget 512 / n per lane; builds exist for 2 and 4: 1 runs the 2-wave build, 3 the
+ * 4-wave build); a negative value selects the same build with the
  * per-sample sums kept in registers instead of LDS.  Results are identical; only speed differs. */
 GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
 /* Tuning knob (no reference counterpart): into how many slices the spp samples of a launch are split (one work item = one

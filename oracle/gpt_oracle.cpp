@@ -173,6 +173,8 @@ struct Tri {
     V3 faceNormal; // normalized cross(side1, side2)   (skdtree.h:367-371)
     Frame sh;      // shading frame: n = faceNormal, s,t from dpdu = side1   (skdtree.h:379,396; util.cpp:603-608)
     V3 geoN;
+    bool hasNormals = false;   // per-vertex normals (TriMesh::getVertexNormals): interpolated shading normal, skdtree.h:382-394
+    V3 n0, n1, n2;
 };
 
 struct Emitter {
@@ -417,6 +419,13 @@ bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
     its.p = tr.p0 * b.x + tr.p1 * b.y + tr.p2 * b.z;
     its.sh = tr.sh;
     its.geoN = tr.geoN;
+    if (tr.hasNormals) {                                                 // skdtree.h:382-394,426
+        its.sh.n = normalize(tr.n0 * b.x + tr.n1 * b.y + tr.n2 * b.z);
+        if (dot(tr.faceNormal, its.sh.n) < 0) its.geoN = -tr.faceNormal; // geometric and shading normals face the same way
+        const V3 dpdu = tr.p1 - tr.p0;
+        its.sh.s = normalize(dpdu - its.sh.n * dot(its.sh.n, dpdu));     // computeShadingFrame, util.cpp:603-608
+        its.sh.t = cross(its.sh.n, its.sh.s);
+    }
     its.wi = its.sh.toLocal(-ray.d);
     return true;
 }
@@ -1628,6 +1637,24 @@ GPO_API void gpo_scene_set_environment(gpo_scene *h, const double *radiance, int
     mx = V3(std::max(mx.x, camPos.x), std::max(mx.y, camPos.y), std::max(mx.z, camPos.z));
     sc.bsCenter = (mx + mn) * 0.5;                                   // AABB::getCenter, aabb.h:132-134
     sc.bsRadius = std::max(Epsilon, length(sc.bsCenter - mx) * (Float)1.5f);   // aabb.cpp:44-47, constant.cpp:69
+}
+
+// Per-vertex normals (9 doubles per triangle; three zero vectors = that triangle has none).  Emitter triangles must be flat:
+// AreaLight::eval and TriMesh::samplePosition would otherwise use interpolated normals, which this build does not carry.
+GPO_API int gpo_scene_set_normals(gpo_scene *h, const double *n9)
+{
+    Scene &sc = h->sc;
+    for (size_t i = 0; i < sc.tris.size(); ++i) {
+        Tri &t = sc.tris[i];
+        const double *n = n9 + 9 * i;
+        bool any = false;
+        for (int k = 0; k < 9; ++k) any = any || n[k] != 0.0;
+        if (!any) continue;
+        if (t.emitter >= 0) return -1;
+        t.hasNormals = true;
+        t.n0 = V3(n[0], n[1], n[2]); t.n1 = V3(n[3], n[4], n[5]); t.n2 = V3(n[6], n[7], n[8]);
+    }
+    return 0;
 }
 
 GPO_API void gpo_scene_destroy(gpo_scene *h) { delete h; }

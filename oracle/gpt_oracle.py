@@ -70,6 +70,7 @@ def lib():
         L.gpo_scene_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_scene_destroy.argtypes = [C.c_void_p]
         L.gpo_scene_set_environment.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.gpo_scene_set_normals.argtypes = [C.c_void_p, C.c_void_p]
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -111,6 +112,10 @@ class Scene:
         self.W, self.H = desc.width, desc.height
         self._h = lib().gpo_scene_create(verts.shape[0], _p(verts), _p(tm), len(desc.materials), C.byref(mats),
                                          len(desc.emitters), C.byref(ems), C.byref(cam))
+        nrm = getattr(desc, "normals", None)
+        if nrm is not None:                                  # (ntri, 9) per-vertex normals, zero rows = flat triangle
+            if lib().gpo_scene_set_normals(self._h, _p(_d(nrm))) != 0:
+                raise ValueError("vertex normals on emitter triangles are not carried")
         env = getattr(desc, "environment", None)
         if env is not None:                                  # (radiance rgb, position in the emitter list)
             lib().gpo_scene_set_environment(self._h, _p(_d(env[0])), int(env[1]))
