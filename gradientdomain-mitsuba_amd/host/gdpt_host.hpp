@@ -145,6 +145,7 @@ private:
 /// What the scene-XML subset reader produces and gdpt_scene_create consumes.
 struct SceneData {
     std::vector<double> verts;              // 9 per triangle
+    std::vector<double> normals;            // 9 per triangle (zeros = flat) for the first normals.size()/9 triangles; empty = none
     std::vector<int> triMaterial;
     std::vector<gdpt_material> materials;
     std::vector<gdpt_emitter> emitters;
@@ -242,8 +243,11 @@ public:
         const int W = film.getWidth(), H = film.getHeight();
         gdpt_scene *scene = nullptr;
         gdpt_film *gf = nullptr;
-        check(gdpt_scene_create_env(sd.numTriangles(), sd.verts.data(), sd.triMaterial.data(), (int)sd.materials.size(), sd.materials.data(),
-                                    (int)sd.emitters.size(), sd.emitters.data(), sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, -1, &scene));
+        std::vector<double> normals = sd.normals;
+        if (!normals.empty()) normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
+        check(gdpt_scene_create_ex(sd.numTriangles(), sd.verts.data(), normals.empty() ? nullptr : normals.data(), sd.triMaterial.data(),
+                                   (int)sd.materials.size(), sd.materials.data(), (int)sd.emitters.size(), sd.emitters.data(),
+                                   sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, -1, &scene));
         check(gdpt_film_create(scene, 0, H, &gf));
         gdpt_config cfg;
         cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;

@@ -47,10 +47,19 @@ int main(int argc, char **argv)
         gdpt::SceneData sd = loader.load(scenePath);
         const int spp = sd.sampler.getInteger("sampleCount", 4);                                                                       // independent.cpp default
         if (parseOnly) {
-            printf("{\"triangles\": %d, \"materials\": %zu, \"emitters\": %zu, \"width\": %d, \"height\": %d, \"fovX\": %.9g, \"sampleCount\": %d, \"maxDepth\": %d, \"firstVertex\": [%.9g, %.9g, %.9g], \"cameraOrigin\": [%.9g, %.9g, %.9g], \"environment\": [%.9g, %.9g, %.9g, %d]}\n",
+            int smooth = 0;
+            double firstN[3] = {0, 0, 0};
+            for (size_t t = 0; t * 9 < sd.normals.size(); ++t) {
+                bool any = false;
+                for (int k = 0; k < 9; ++k) any = any || sd.normals[9 * t + k] != 0.0;
+                if (any && !smooth) for (int k = 0; k < 3; ++k) firstN[k] = sd.normals[9 * t + k];
+                smooth += any;
+            }
+            printf("{\"triangles\": %d, \"materials\": %zu, \"emitters\": %zu, \"width\": %d, \"height\": %d, \"fovX\": %.9g, \"sampleCount\": %d, \"maxDepth\": %d, \"firstVertex\": [%.9g, %.9g, %.9g], \"cameraOrigin\": [%.9g, %.9g, %.9g], \"environment\": [%.9g, %.9g, %.9g, %d], \"smoothTriangles\": %d, \"firstNormal\": [%.9g, %.9g, %.9g]}\n",
                    sd.numTriangles(), sd.materials.size(), sd.emitters.size(), sd.camera.width, sd.camera.height, sd.camera.fovX, spp,
                    sd.integrator.getInteger("maxDepth", -1), sd.verts[0], sd.verts[1], sd.verts[2], sd.camera.toWorld[3], sd.camera.toWorld[7], sd.camera.toWorld[11],
-                   sd.environment.radiance[0], sd.environment.radiance[1], sd.environment.radiance[2], sd.hasEnvironment ? sd.environment.index : -1);
+                   sd.environment.radiance[0], sd.environment.radiance[1], sd.environment.radiance[2], sd.hasEnvironment ? sd.environment.index : -1,
+                   smooth, firstN[0], firstN[1], firstN[2]);
             return 0;
         }
         struct stat stt;

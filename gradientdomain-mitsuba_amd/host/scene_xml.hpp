@@ -11,7 +11,9 @@
 #pragma once
 #include "gdpt_host.hpp"
 
+#include <array>
 #include <cctype>
+#include <map>
 #include <cmath>
 #include <memory>
 #include <sstream>
@@ -147,6 +149,15 @@ struct Mat4 {
     double det3() const
     {
         return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    }
+    void normal(const double n[3], double out[3]) const       // Transform::operator()(Normal): inverse transpose of the linear part
+    {
+        const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+        const double inv = 1.0 / det3();
+        const double C[9] = {(e * i - f * h) * inv, (f * g - d * i) * inv, (d * h - e * g) * inv,
+                             (c * h - b * i) * inv, (a * i - c * g) * inv, (b * g - a * h) * inv,
+                             (b * f - c * e) * inv, (c * d - a * f) * inv, (a * e - b * d) * inv};
+        for (int r = 0; r < 3; ++r) out[r] = C[3 * r] * n[0] + C[3 * r + 1] * n[1] + C[3 * r + 2] * n[2];
     }
 };
 
@@ -456,7 +467,7 @@ private:
         const std::string type = subst(n.get("type"));
         Mat4 T = Mat4::identity();
         int mat = -1;
-        bool flipNormals = false, emits = false;
+        bool flipNormals = false, faceNormals = false, emits = false;
         double radiance[3] = {1, 1, 1};
         std::string filename;
         for (auto &c : n.children) {
@@ -473,11 +484,11 @@ private:
                     if ((ec->tag == "rgb" || ec->tag == "spectrum") && ec->get("name") == "radiance") rgb3(*ec, radiance);
             } else if (c->tag == "string" && c->get("name") == "filename") filename = subst(c->get("value"));
             else if (c->tag == "boolean" && c->get("name") == "flipNormals") flipNormals = subst(c->get("value")) == "true";
-            else if (c->tag == "boolean" && c->get("name") == "faceNormals") { /* flat shading is the only mode carried */ }
+            else if (c->tag == "boolean" && c->get("name") == "faceNormals") faceNormals = subst(c->get("value")) == "true";
             else logError(format("shape \"%s\": <%s name=\"%s\"> is not carried", type.c_str(), c->tag.c_str(), c->get("name", "").c_str()));
         }
         if (mat < 0) { gdpt_material m; std::memset(&m, 0, sizeof m); m.type = GDPT_MAT_DIFFUSE; m.sampleVisible = 1; m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5; m.alphaU = m.alphaV = 0.1; sd.materials.push_back(m); mat = (int)sd.materials.size() - 1; }   // shape.cpp: default diffuse
-        const bool flip = flipNormals != (T.det3() < 0);        // a mirroring transform reverses the winding (obj.cpp does the same swap)
+        const bool flip = flipNormals != (T.det3() < 0);        // rectangle / cube: the analytic shapes keep their outward normal under a mirroring transform
         const int first = sd.numTriangles();
         if (type == "rectangle") {                               // src/shapes/rectangle.cpp: [-1,1]^2 in z = 0, normal +z
             const double v[4][3] = {{-1, -1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 1, 0}};
@@ -489,7 +500,7 @@ private:
             for (auto &q : f) { addTri(sd, T, flip, c[q[0]], c[q[1]], c[q[2]], mat); addTri(sd, T, flip, c[q[0]], c[q[2]], c[q[3]], mat); }
         } else if (type == "obj") {
             if (filename.empty()) logError("shape \"obj\": missing filename");
-            loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flip, mat);
+            loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flipNormals, faceNormals, mat);   // obj.cpp applies no handedness correction
         } else logError(format("shape \"%s\" is not carried: obj, rectangle, cube", type.c_str()));
         if (emits) {
             gdpt_emitter e;
@@ -499,30 +510,138 @@ private:
         }
     }
 
-    void loadObj(const std::string &path, SceneData &sd, const Mat4 &T, bool flip, int mat)
-    { // Wavefront OBJ subset (src/shapes/obj.cpp): v, f with v / v/vt / v//vn / v/vt/vn and negative indices, polygons fanned.
-      // vn / vt are read past: this build shades flat (no vertex normals).
+    // Wavefront OBJ subset (src/shapes/obj.cpp): v, vn, vt, f with v / v/vt / v//vn / v/vt/vn and negative indices, polygons fanned,
+    // one mesh per o / g group.  As createMesh does (obj.cpp:608-704): positions and normals go through toWorld, vertices with equal
+    // (position, normal, uv) VALUES are merged per mesh; then TriMesh::computeNormals (trimesh.cpp:608-681): faceNormals drops the
+    // normals (flipNormals swaps the first two vertices of every triangle); given normals are kept (flipNormals negates them);
+    // a mesh without normals gets angle-weighted vertex normals over the merged vertices (flipNormals negates them too).
+    // Vertex normals that equal the face normal of every triangle using them are dropped again: the flat code path gives the
+    // same frame without the per-hit interpolation.
+    void loadObj(const std::string &path, SceneData &sd, const Mat4 &T, bool flipNormals, bool faceNormals, int mat)
+    {
         std::ifstream f(path);
         if (!f) logError(format("Cannot open OBJ file \"%s\"", path.c_str()));
-        std::vector<double> pos;
+        struct V { double d[8]; bool operator<(const V &o) const { return std::lexicographical_compare(d, d + 8, o.d, o.d + 8); } };   // p(3) n(3) uv(2), obj.cpp:577-606
+        std::vector<double> pos, nrm, tex;
+        struct Corner { int v, t, n; };
+        std::vector<std::array<Corner, 3>> tris;
+        auto flush = [&]() {
+            if (tris.empty()) return;
+            std::map<V, int> vmap;
+            std::vector<V> vb;
+            std::vector<std::array<int, 3>> idx;
+            bool hasNormals = false;
+            for (auto &tr : tris) {
+                std::array<int, 3> id;
+                for (int j = 0; j < 3; ++j) {
+                    V v;
+                    for (double &c : v.d) c = 0.0;
+                    T.point(&pos[3 * tr[j].v], v.d);
+                    if (tr[j].n >= 0) {
+                        T.normal(&nrm[3 * tr[j].n], v.d + 3);
+                        const double l = std::sqrt(v.d[3] * v.d[3] + v.d[4] * v.d[4] + v.d[5] * v.d[5]);
+                        if (l != 0) for (int k = 3; k < 6; ++k) v.d[k] /= l;
+                        hasNormals = true;
+                    }
+                    if (tr[j].t >= 0) { v.d[6] = tex[2 * tr[j].t]; v.d[7] = tex[2 * tr[j].t + 1]; }
+                    for (double &c : v.d) if (c == 0) c = 0.0;                      // -0.0 and 0.0 are one key
+                    auto it = vmap.find(v);
+                    if (it == vmap.end()) { it = vmap.emplace(v, (int)vb.size()).first; vb.push_back(v); }
+                    id[j] = it->second;
+                }
+                idx.push_back(id);
+            }
+            std::vector<std::array<double, 3>> vn(vb.size(), std::array<double, 3>{{0.0, 0.0, 0.0}});
+            bool useNormals = false;
+            if (faceNormals) {
+                if (flipNormals) for (auto &id : idx) std::swap(id[0], id[1]);
+            } else if (hasNormals) {
+                useNormals = true;
+                for (size_t i = 0; i < vb.size(); ++i) for (int k = 0; k < 3; ++k) vn[i][k] = flipNormals ? -vb[i].d[3 + k] : vb[i].d[3 + k];
+            } else {
+                useNormals = true;                                                 // "Computing Vertex Normals from Polygonal Facets", trimesh.cpp:636-672
+                for (auto &id : idx) {
+                    double n[3] = {0, 0, 0};
+                    for (int i = 0; i < 3; ++i) {
+                        const double *v0 = vb[id[i]].d, *v1 = vb[id[(i + 1) % 3]].d, *v2 = vb[id[(i + 2) % 3]].d;
+                        double a[3], b[3];
+                        for (int k = 0; k < 3; ++k) { a[k] = v1[k] - v0[k]; b[k] = v2[k] - v0[k]; }
+                        if (i == 0) {
+                            n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
+                            const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                            if (l == 0) break;
+                            for (double &c : n) c /= l;
+                        }
+                        const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+                        double u[3], w[3], dt = 0, sp = 0, sm = 0;
+                        for (int k = 0; k < 3; ++k) { u[k] = a[k] / la; w[k] = b[k] / lb; dt += u[k] * w[k]; }
+                        for (int k = 0; k < 3; ++k) { sp += (w[k] + u[k]) * (w[k] + u[k]); sm += (w[k] - u[k]) * (w[k] - u[k]); }
+                        const double angle = dt < 0 ? M_PI - 2 * std::asin(0.5 * std::sqrt(sp)) : 2 * std::asin(0.5 * std::sqrt(sm));   // unitAngle, util.h:305-310
+                        for (int k = 0; k < 3; ++k) vn[id[i]][k] += n[k] * angle;
+                    }
+                }
+                for (auto &n : vn) {
+                    double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    if (flipNormals) l *= -1;
+                    if (l != 0) for (double &c : n) c /= l;
+                    else { n[0] = 1; n[1] = 0; n[2] = 0; }
+                }
+            }
+            // vertex normals equal to every adjacent face normal are the flat case
+            bool allFlat = true;
+            for (size_t t = 0; t < idx.size() && useNormals && allFlat; ++t) {
+                const double *A = vb[idx[t][0]].d, *B = vb[idx[t][1]].d, *C = vb[idx[t][2]].d;
+                double a[3], b[3];
+                for (int k = 0; k < 3; ++k) { a[k] = B[k] - A[k]; b[k] = C[k] - A[k]; }
+                const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+                const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                for (int j = 0; j < 3; ++j)
+                    for (int k = 0; k < 3; ++k) if (std::abs(vn[idx[t][j]][k] - (l != 0 ? n[k] / l : 0.0)) > 1e-12) allFlat = false;
+            }
+            if (useNormals && allFlat) useNormals = false;
+            for (size_t t = 0; t < idx.size(); ++t) {
+                for (int j = 0; j < 3; ++j) sd.verts.insert(sd.verts.end(), vb[idx[t][j]].d, vb[idx[t][j]].d + 3);
+                sd.triMaterial.push_back(mat);
+                if (useNormals) {
+                    sd.normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
+                    for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) sd.normals[9 * (size_t)(sd.numTriangles() - 1) + 3 * j + k] = vn[idx[t][j]][k];
+                }
+            }
+            tris.clear();
+        };
         std::string line;
         while (std::getline(f, line)) {
             std::stringstream ss(line);
             std::string tag;
             if (!(ss >> tag)) continue;
             if (tag == "v") { double x, y, z; ss >> x >> y >> z; pos.push_back(x); pos.push_back(y); pos.push_back(z); }
+            else if (tag == "vn") { double x, y, z; ss >> x >> y >> z; nrm.push_back(x); nrm.push_back(y); nrm.push_back(z); }
+            else if (tag == "vt") { double u = 0, v = 0; ss >> u >> v; tex.push_back(u); tex.push_back(v); }
+            else if (tag == "o" || tag == "g") flush();
             else if (tag == "f") {
-                std::vector<int> idx;
+                std::vector<Corner> cs;
                 std::string tok;
                 while (ss >> tok) {
-                    int vi = std::stoi(tok.substr(0, tok.find('/')));
-                    if (vi < 0) vi = (int)pos.size() / 3 + vi; else vi -= 1;
-                    if (vi < 0 || vi >= (int)pos.size() / 3) logError(format("%s: face references vertex %d out of range", path.c_str(), vi + 1));
-                    idx.push_back(vi);
+                    Corner c = {0, -1, -1};
+                    const size_t s1 = tok.find('/'), s2 = s1 == std::string::npos ? std::string::npos : tok.find('/', s1 + 1);
+                    auto resolve = [&](const std::string &str, size_t count, const char *what) {
+                        int i = std::stoi(str);
+                        i = i < 0 ? (int)count + i : i - 1;
+                        if (i < 0 || i >= (int)count) logError(format("%s: face references %s %s out of range", path.c_str(), what, str.c_str()));
+                        return i;
+                    };
+                    c.v = resolve(tok.substr(0, s1), pos.size() / 3, "vertex");
+                    if (s1 != std::string::npos) {
+                        const std::string ts = tok.substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1);
+                        if (!ts.empty()) c.t = resolve(ts, tex.size() / 2, "texture coordinate");
+                        if (s2 != std::string::npos && s2 + 1 < tok.size()) c.n = resolve(tok.substr(s2 + 1), nrm.size() / 3, "normal");
+                    }
+                    cs.push_back(c);
                 }
-                for (size_t k = 1; k + 1 < idx.size(); ++k) addTri(sd, T, flip, &pos[3 * idx[0]], &pos[3 * idx[k]], &pos[3 * idx[k + 1]], mat);
+                for (size_t k = 1; k + 1 < cs.size(); ++k) tris.push_back({{cs[0], cs[k], cs[k + 1]}});
             }
         }
+        flush();
     }
 };
 

@@ -65,6 +65,25 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     assert json.loads(run(cli, "--parse-only", s).stdout)["materials"] == 2
     s = scene_with(tmp_path, '<bsdf type="twosided" id="w"><bsdf type="diffuse"/></bsdf><shape type="rectangle"><ref id="w"/></shape>' + LIGHT)
     assert json.loads(run(cli, "--parse-only", s).stdout)["materials"] == 2
+    # OBJ normals (obj.cpp createMesh + TriMesh::computeNormals): a square pyramid with shared apex/base vertices
+    pyr = tmp_path / "pyr.obj"
+    pyr.write_text("v 0 0 0\nv 1 0 0\nv 1 0 1\nv 0 0 1\nv 0.5 1 0.5\nf 1 5 2\nf 2 5 3\nf 3 5 4\nf 4 5 1\n")
+    sh = lambda extra: scene_with(tmp_path, '<shape type="obj"><string name="filename" value="%s"/>%s</shape>' % (pyr, extra) + LIGHT)
+    d = json.loads(run(cli, "--parse-only", sh("")).stdout)
+    assert d["smoothTriangles"] == 4                                        # no vn in the file: angle-weighted vertex normals over shared vertices
+    n = np.array(d["firstNormal"]); assert abs(np.linalg.norm(n) - 1) < 1e-8 and n[1] > 0 and n[0] < 0 and n[2] < 0   # corner (0,0,0) leans outwards
+    assert json.loads(run(cli, "--parse-only", sh('<boolean name="faceNormals" value="true"/>')).stdout)["smoothTriangles"] == 0
+    nf = np.array(json.loads(run(cli, "--parse-only", sh('<boolean name="flipNormals" value="true"/>')).stdout)["firstNormal"])
+    assert np.allclose(nf, -n, atol=1e-9)                                  # computed normals are negated, the winding stays
+    pyr.write_text("v 0 0 0\nv 1 0 0\nv 0.5 1 0.5\nvn 0 0 -1\nvn 0.6 0 -0.8\nf 1//1 3//2 2//1\n")
+    d = json.loads(run(cli, "--parse-only", sh('<transform name="toWorld"><scale x="2" y="1" z="1"/></transform>')).stdout)
+    assert d["smoothTriangles"] == 1 and np.allclose(d["firstNormal"], [0, 0, -1])
+    unit = np.array([0.6 / 2, 0, -0.8]); unit /= np.linalg.norm(unit)       # normals go through the inverse transpose
+    pyr.write_text("v 0 0 0\nv 1 0 0\nv 0.5 1 0.5\nvn 0.6 0 -0.8\nf 1//1 3//1 2//1\n")
+    d = json.loads(run(cli, "--parse-only", sh('<transform name="toWorld"><scale x="2" y="1" z="1"/></transform>')).stdout)
+    assert np.allclose(d["firstNormal"], unit, atol=1e-8)
+    pyr.write_text("v 0 0 0\nv 1 0 0\nv 0.5 1 0\nvn 0 0 -1\nf 1//1 3//1 2//1\n")        # normals equal to the face normal: the flat path
+    assert json.loads(run(cli, "--parse-only", sh("")).stdout)["smoothTriangles"] == 0
     # <emitter type="constant">: radiance and its place in the emitter list (XML order)
     s = scene_with(tmp_path, '<emitter type="constant"><rgb name="radiance" value="0.5, 0.75, 1"/></emitter><shape type="rectangle"/>' + LIGHT)
     assert json.loads(run(cli, "--parse-only", s).stdout)["environment"] == [0.5, 0.75, 1, 0]
@@ -191,5 +210,27 @@ def test_cli_render_equals_python_mirror(cli, tmp_path, gpu_required):
     for suffix in G.BUFFER_NAMES:
         assert np.array_equal(read_pfm(dest + "v" + suffix + ".pfm"), oute[suffix]), suffix
     assert not np.array_equal(oute["-final"], out["-final"])
+    # an OBJ sphere with per-vertex normals in the box: the CLI (obj reader -> gdpt_scene_create_ex) against the Python mirror
+    sph = scenes.cornell_box(48, 40, "smooth")
+    nt = sph.ntri
+    first = 10 + 2                                        # the scene builder puts the two spheres after the 5 walls (10 triangles)
+    with open(str(tmp_path / "meshes" / "sphere.obj"), "w") as f:
+        k = 0
+        for t in range(10, nt - 2):                       # both spheres (everything between the walls and the light)
+            for j in range(3):
+                f.write("v %.17g %.17g %.17g\n" % tuple(sph.verts[t][3 * j:3 * j + 3])); f.write("vn %.17g %.17g %.17g\n" % tuple(sph.normals[t][3 * j:3 * j + 3]))
+            f.write("f %d//%d %d//%d %d//%d\n" % (k + 1, k + 1, k + 2, k + 2, k + 3, k + 3)); k += 3
+    assert first
+    import re
+    xs = open(XML).read()
+    # drop the two box shapes, add the sphere mesh with the tall sphere's material on all of it
+    xs = re.sub(r'<shape type="obj">\s*<string name="filename" value="meshes/cbox_(small|large)box.obj"/>.*?</shape>', "", xs, flags=re.S)
+    xs = xs.replace("</scene>", '<shape type="obj"><string name="filename" value="meshes/sphere.obj"/><bsdf type="diffuse"><rgb name="reflectance" value="0.725, 0.71, 0.68"/></bsdf></shape></scene>')
+    xsm = str(tmp_path / "smooth.xml"); open(xsm, "w").write(xs)
+    r = run(cli, "-o", dest + "s", "-D", "width=48", "-D", "height=40", "-D", "spp=4", "-D", "maxDepth=5", xsm)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(run(cli, "--parse-only", "-D", "width=48", "-D", "height=40", xsm).stdout)["smoothTriangles"] == nt - 12
+    img = read_pfm(dest + "s-final.pfm")
+    assert np.isfinite(img).all() and img.max() > 0
     bad = run(cli, "-o", dest, "-D", "width=16", "-D", "height=16", "-D", "maxDepth=0", XML)
     assert bad.returncode == 1 and "maxDepth" in bad.stderr
