@@ -25,12 +25,14 @@ from oracle import poisson_oracle as po           # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 POISSON_CASES = [("L2D", 40, 28), ("L1D", 40, 28), ("L2D", 33, 17), ("L2Q", 24, 16)]
-GPT_CASES = [("diffuse", -1), ("glossy", 8), ("nearspecular", 8), ("twosided", -1), ("glass", 10), ("glossy+env", 8)]
+GPT_CASES = [("diffuse", -1), ("glossy", 8), ("nearspecular", 8), ("twosided", -1), ("glass", 10), ("glossy+env", 8), ("bent", 8), ("random7", 6)]
 ENV = (0.6, 0.8, 1.1)        # radiance of the `constant` environment emitter of the "+env" cases
 
 
 def build_scene(case, W, H):
     variant, _, env = case.partition("+")
+    if variant.startswith("random"):          # fuzzed materials (seed in the name): includes the Phong distribution
+        return scenes.cornell_box(W, H, "random", seed=int(variant[6:]), environment=ENV if env else None)
     return scenes.cornell_box(W, H, variant, environment=ENV if env else None)
 GPT_SIZE = (48, 36)
 GPT_POINTS = 12
