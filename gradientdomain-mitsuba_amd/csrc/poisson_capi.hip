@@ -13,6 +13,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <cstdlib>
 
 using namespace gdpt;
 
@@ -298,6 +299,7 @@ int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
     A.x = s->x; A.r = s->r; A.p = s->p[0]; A.w2 = s->w2;
     A.gat = s->gat; A.halo = s->halo; A.bar = s->bar; A.s_rz = s->s_rz_next();
     A.W = s->W; A.H = s->H; A.tilesX = s->ptTilesX; A.tilesY = s->ptTilesY; A.TH = s->ptTH; A.iters = cg; A.alpha = s->alpha_eff;
+    { const char *e = getenv("GDPT_DEBUG_PERSISTENT_FAIL"); A.debugFail = (e && e[0] == '1') ? 1 : 0; }
     if (s->ptLaunch == 0 || s->ptLaunch == 0xffffu) {      // fresh tables, or the 16-bit launch number is about to wrap: forget all tags
         HIPCHK(hipMemsetAsync(s->gat, 0, sizeof(unsigned long long) * 6 * PT_MAXG, s->stream));
         HIPCHK(hipMemsetAsync(s->halo, 0, sizeof(unsigned long long) * (size_t)PT_HALO * PT_MAXG, s->stream));

@@ -51,6 +51,7 @@ struct PersistArgs {
     int W, H, tilesX, tilesY, TH, iters;
     unsigned tagBase;                    // launch number << 16: tags of earlier launches never match
     float alpha;
+    int debugFail;                       // test hook (GDPT_DEBUG_PERSISTENT_FAIL=1): raise the time-out flag at once, to exercise the recovery
 };
 
 #define PT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
     rz[0] = A.s_rz[0]; rz[1] = A.s_rz[1]; rz[2] = A.s_rz[2];
     bool ok = true;
     if (t == 0) s_fail = 0;
+    if (A.debugFail && tile == 0 && t == 0) __hip_atomic_store(A.bar + 1, 1u, PT_RLX_AGENT);
     unsigned long long *gatA = A.gat, *gatB = A.gat + 3 * PT_MAXG;
     unsigned *err = A.bar + 1;
 

@@ -148,6 +148,25 @@ def test_persistent_handle_reuse_and_resize(P):
     s.close()
 
 
+def test_persistent_timeout_recovers_on_the_multi_kernel_path(P, monkeypatch):
+    """A grid-wide gather that times out (workgroups not co-resident) must not fail the solve: the flag is raised, every
+    workgroup leaves, gdpt_poisson_sync redoes the solve from the saved x0 on the graph path and stays there."""
+    w, h = 192, 100
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    ref1, _ = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 1)
+    monkeypatch.setenv("GDPT_DEBUG_PERSISTENT_FAIL", "1")
+    msgs = []
+    s = P.Solver(P.Params("L1D", 0.2)); s.setLogFunction(msgs.append); s.setFusion(2)
+    s.importImagesMTS(dx, dy, tp, direct, w, h); s.setupBackend(); s.solveIndirect()
+    rec = s.exportImagesMTS()
+    assert any("falling back" in m for m in msgs) and s.lastIterations == 1000
+    assert np.array_equal(rec, ref1)                                   # exactly the multi-kernel result
+    monkeypatch.delenv("GDPT_DEBUG_PERSISTENT_FAIL")
+    s.setupBackend(); s.solveIndirect()                                # stays on the multi-kernel path afterwards
+    assert np.array_equal(s.exportImagesMTS(), ref1)
+    s.close()
+
+
 def test_null_throughput_and_null_direct(P):
     w, h = 64, 48
     dx, dy, tp, direct = po.synth_inputs(w, h)
