@@ -226,6 +226,20 @@ def main():
             # fused x_p+stencil: R r,p,x + W x,p,Ap = 72 B/px algorithmic (+12 for w in IRLS); with kf_r_rz (48 B/px) it is the iteration
             kname, kavg, kb = "kf_xp_Ax", kus[3], (72.0 if prm.irlsIterMax == 1 else 84.0) * W * H
         achieved = kb / (kavg * 1e-6) / 1e9 if kavg > 0 else 0.0
+        # algorithmic bytes per ray = ray record 32 B + hit record 16 B + nodes fetched x 64 B + triangles tested x 80 B
+        # (this build's node packet and fp64 TriAccel record), with the traversal counts measured on the device BVH for a
+        # secondary-ray-like set (origins uniform in the scene's box, uniform directions), closest-hit and any-hit weighted by
+        # the render's own ray mix.  Not an HBM-roofline workload (the Cornell tables are LDS-resident): stated with that caveat.
+        import numpy as np
+        rng = np.random.default_rng(1)
+        vv = np.asarray(desc.verts, np.float64).reshape(-1, 3)
+        oo = vv.min(0) + (vv.max(0) - vv.min(0)) * rng.random((1 << 16, 3))
+        dd = rng.normal(size=(1 << 16, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        tstat = scene.trace_stats(oo, dd)
+        st_ = film.stats()
+        fc = st_["raysTraced"] / max(1, st_["raysTraced"] + st_["shadowRaysTraced"])
+        bytes_per_ray = 48.0 + 64.0 * (fc * tstat["nodes_closest"] + (1 - fc) * tstat["nodes_any"]) + 80.0 * (fc * tstat["tris_closest"] + (1 - fc) * tstat["tris_any"])
+        tracer_gbs = bytes_per_ray * (rays / world / (render_ms * 1e-3) * world) / 1e9
         samples = W * H * a.spp * a.steps
         out = {
             "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp" % (W, H, a.spp),
@@ -237,6 +251,9 @@ def main():
             "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / samples, 2), "msample_s": round(samples / wall / 1e6, 2),
             "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "render_kernel_mray_s": round(rays / world / (render_ms * 1e-3) / 1e6 * world, 1),
             "halo_bytes_per_rank": halo,
+            "tracer_roofline": {"bound": "hbm", "achieved": round(tracer_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tracer_gbs / HBM_PEAK_GBS, 4),
+                                "bytes_per_ray": round(bytes_per_ray, 1), "traversal": {k: round(v, 2) for k, v in tstat.items()},
+                                "caveat": "algorithmic bytes per ray x render-kernel ray rate (SURVEY 8d-B); the traversal is latency/issue bound and its tables sit in LDS (small scenes) or L2/Infinity Cache -- not an HBM figure"},
             "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PROFILED_TRAFFIC.get((kname, a.config)),
                          "traffic_source": "profiles/r01d_hotpath_1280x720x64_pmc.csv" if (kname, a.config) in PROFILED_TRAFFIC else None,

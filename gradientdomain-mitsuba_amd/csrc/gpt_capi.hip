@@ -664,6 +664,22 @@ int gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *od, int *prim
     return GDPT_OK;
 }
 
+int gdpt_scene_trace_stats(gdpt_scene *s, int numRays, const double *od, unsigned long long sums[4])
+{
+    if (!s || !od || !sums || numRays <= 0) return tfail(GDPT_ERR_INVALID, "scene_trace_stats: bad argument");
+    double *dod = nullptr;
+    unsigned long long *ds = nullptr;
+    THIPCHK(hipMalloc((void **)&dod, sizeof(double) * 6 * numRays));
+    THIPCHK(hipMalloc((void **)&ds, sizeof(unsigned long long) * 4));
+    THIPCHK(hipMemset(ds, 0, sizeof(unsigned long long) * 4));
+    THIPCHK(hipMemcpy(dod, od, sizeof(double) * 6 * numRays, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_stats, dim3((numRays + TBLK - 1) / TBLK), dim3(TBLK), 0, 0, s->d, numRays, dod, ds);
+    THIPCHK(hipGetLastError());
+    THIPCHK(hipMemcpy(sums, ds, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    hipFree(dod); hipFree(ds);
+    return GDPT_OK;
+}
+
 int gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int py, int sample, double out33[33])
 {
     if (!s || !cfg || !out33) return tfail(GDPT_ERR_INVALID, "evaluate_point: null argument");

@@ -218,8 +218,9 @@ __device__ __forceinline__ bool box_test(const float (&lo)[3], const float (&hi)
 // ShapeKDTree::rayIntersect (closest, skdtree.cpp:112-142) / rayIntersect(ray) (shadow, :207-226) on the BVH.
 // The adaptive epsilon of :126-129 / :214-217 is applied by the callers (ray_mint_*).  Returns closest hit
 // (ANY = false) or whether anything is hit (ANY = true).
-template <bool ANY>
-__device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_DEPTH][TBLK] + tid */, d3 o, d3 d, Float mint, Float maxt, Hit &hit)
+struct TravCount { unsigned nodes, tris; };     // traversal statistics of the probe kernel (never live in the render kernel)
+template <bool ANY, bool COUNT = false>
+__device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_DEPTH][TBLK] + tid */, d3 o, d3 d, Float mint, Float maxt, Hit &hit, TravCount *tc = nullptr)
 {
     hit.prim = -1;
     hit.t = GD_INF;
@@ -233,6 +234,7 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
     while (true) {
         while (!(ref & BVH_LEAF)) {
             const BvhNode n = sv.nodes[ref];
+            if (COUNT) tc->nodes++;
             Float tl, tr;
             const bool hl = box_test(n.lo[0], n.hi[0], o, rd, mint, maxt, tl);
             const bool hr = box_test(n.lo[1], n.hi[1], o, rd, mint, maxt, tr);
@@ -247,6 +249,7 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
         }
         if (ref == DONE) break;
         const uint32_t first = (ref & ~BVH_LEAF) >> 3, cnt = (ref & 7u) + 1u;
+        if (COUNT) tc->tris += cnt;
         for (uint32_t i = 0; i < cnt; i++) {
             Float u, v, t;
             if (tri_test(sv.isect[first + i], o, d, mint, maxt, u, v, t)) {

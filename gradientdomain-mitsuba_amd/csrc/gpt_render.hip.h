@@ -655,6 +655,28 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
     tp[4 * i + 1] = h.prim < 0 ? 0.0 : v.p.x; tp[4 * i + 2] = h.prim < 0 ? 0.0 : v.p.y; tp[4 * i + 3] = h.prim < 0 ? 0.0 : v.p.z;
 }
 
+// probe: traversal statistics -- inner nodes fetched and triangles tested, closest-hit and any-hit, summed over n rays (od: origin,
+// direction; maxt = infinity).  sums[0..3] = nodes (closest), tris (closest), nodes (any), tris (any).
+__global__ __launch_bounds__(TBLK) void k_trace_stats(SceneD S, int n, const Float *__restrict__ od, unsigned long long *__restrict__ sums)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    SceneView sv;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.vn = S.vn;
+    const int i = blockIdx.x * TBLK + threadIdx.x;
+    TravCount c0 = {0, 0}, c1 = {0, 0};
+    if (i < n) {
+        const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
+        Hit h;
+        trace<false, true>(sv, s_stack + threadIdx.x, o, d, ray_mint_closest(o, GD_EPSILON), GD_INF, h, &c0);
+        trace<true, true>(sv, s_stack + threadIdx.x, o, d, ray_mint_shadow(o, GD_EPSILON), GD_INF, h, &c1);
+    }
+    const unsigned v[4] = {c0.nodes, c0.tris, c1.nodes, c1.tris};
+    for (int k = 0; k < 4; k++) {
+        const unsigned w = __builtin_amdgcn_wave_reduce_add_u32(v[k], 0);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sums[k], (unsigned long long)w);
+    }
+}
+
 // probe: the raw outputs of evaluatePoint (gpt.cpp:397-436) for one (pixel, sample): veryDirect(3), throughput(3),
 // gradients[4](12), neighbourThroughputs[4](12), then closest/shadow ray counts and the final depth as doubles.
 __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int px, int py, int sample, Float *__restrict__ out33)

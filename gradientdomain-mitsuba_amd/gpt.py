@@ -90,6 +90,14 @@ class Scene:
         check(lib().gdpt_scene_intersect(self._h, n, od.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p)))
         return prim, tp[:, 0], tp[:, 1:4]
 
+    def trace_stats(self, origins, dirs):
+        """-> dict of mean inner nodes fetched / triangles tested per ray, closest-hit and any-hit (SURVEY 8d-B bytes per ray)."""
+        od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))
+        sums = (C.c_ulonglong * 4)()
+        check(lib().gdpt_scene_trace_stats(self._h, od.shape[0], od.ctypes.data_as(C.c_void_p), sums))
+        n = float(od.shape[0])
+        return dict(nodes_closest=sums[0] / n, tris_closest=sums[1] / n, nodes_any=sums[2] / n, tris_any=sums[3] / n)
+
     def evaluate_point(self, cfg, px, py, sample):
         out = np.zeros(33, np.float64)
         check(lib().gdpt_scene_evaluate_point(self._h, C.byref(cfg), px, py, sample, out.ctypes.data_as(C.c_void_p)))

@@ -145,6 +145,9 @@ GDPT_API int  gdpt_film_set_slices(gdpt_film *f, int slices);
  * (1..64, default 56; 64 = only when the whole wave is idle).  Results do not depend on it. */
 GDPT_API int  gdpt_film_set_regeneration(gdpt_film *f, int idleLanes);
 
+/* Probe for the roofline note of SURVEY 8(d)-B: traversal statistics of numRays rays (origin, direction; unbounded), traced once as
+ * closest-hit and once as any-hit queries: sums[0..3] = inner nodes fetched / triangles tested (closest), the same (any-hit). */
+GDPT_API int  gdpt_scene_trace_stats(gdpt_scene *s, int numRays, const double *originsDirs6, unsigned long long sums[4]);
 /* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */
 GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *tp4);
 
