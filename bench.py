@@ -93,11 +93,19 @@ def cpu_baseline(W, H, spp):
     for _ in range(reps):
         po.solve(po.preset(PRESET), dx, dy, tp, direct, W, H)
     dp = time.perf_counter() - t1
+    # the same solve on all usable cores (the reference's BackendOpenMP parallelises these loops; off Windows it runs one thread)
+    os.environ["OMP_NUM_THREADS"] = str(_usable_cores())
+    po.solve_allcores(po.preset(PRESET), dx, dy, tp, direct, W, H)
+    t2 = time.perf_counter()
+    for _ in range(reps):
+        po.solve_allcores(po.preset(PRESET), dx, dy, tp, direct, W, H)
+    dpa = time.perf_counter() - t2
     return {"value": round(rays / slowest / 1e6, 3), "unit": "Mray/s", "cores": len(bands), "kind": "port",
             "sample": "%d band(s) of %d rows of the %dx%dx%dspp Cornell render, one process per core (%d rays, slowest worker %.1f s, %.1f s with process start-up) + %d x %s solve on 1 core (%.1f s)" % (
                 len(bands), bands[0][5] - bands[0][4], W, H, spp, rays, slowest, wall, reps, PRESET, dp),
             "value_1core": round(one[0] / one[1] / 1e6, 3),
-            "poisson_mpix_iter_s": round(W * H * 50 * reps / dp / 1e6, 2), "poisson_cores": 1}
+            "poisson_mpix_iter_s": round(W * H * 50 * reps / dp / 1e6, 2), "poisson_cores": 1,
+            "poisson_allcores_mpix_iter_s": round(W * H * 50 * reps / dpa / 1e6, 2), "poisson_allcores": _usable_cores()}
 
 
 def main():

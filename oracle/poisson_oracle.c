@@ -34,6 +34,20 @@
 
 #define GDO_API __attribute__((visibility("default")))
 
+/* The checker is this file compiled WITHOUT OpenMP: the pragmas below vanish and every sum runs in index order.  The second
+ * build (-fopenmp -DGDO_OMP, libgdpt_oracle_poisson_omp.so) exists only for the all-cores CPU baseline of bench.py (SURVEY 8d:
+ * the reference's BackendOpenMP parallelises the same loops, BackendOpenMP.cpp:192-330); its sums are per-thread partials. */
+#ifdef GDO_OMP
+#define GDO_PRAGMA(x) _Pragma(#x)
+#define GDO_PARALLEL_FOR GDO_PRAGMA(omp parallel for schedule(static))
+#define GDO_PARALLEL_FOR_SUM3 GDO_PRAGMA(omp parallel for schedule(static) reduction(+ : acc[:3]))
+#define GDO_PARALLEL_FOR_SUM1 GDO_PRAGMA(omp parallel for schedule(static) reduction(+ : w2sum))
+#else
+#define GDO_PARALLEL_FOR
+#define GDO_PARALLEL_FOR_SUM3
+#define GDO_PARALLEL_FOR_SUM1
+#endif
+
 static inline float fmax_ref(float a, float b) { return (a > b) ? a : b; } /* Defs.hpp:57 */
 
 /* Backend::calc_Px, Backend.cpp:150-174 (== BackendOpenMP.cpp:192-214).
@@ -42,10 +56,11 @@ static inline float fmax_ref(float a, float b) { return (a > b) ? a : b; } /* De
 GDO_API void gdo_calc_Px(float *Px, int w, int h, float alpha, const float *x)
 {
     const long n = (long)w * h;
-    long i = 0;
+    GDO_PARALLEL_FOR
     for (int yy = 0; yy < h; yy++)
-        for (int xx = 0; xx < w; xx++, i++)
+        for (int xx = 0; xx < w; xx++)
             for (int c = 0; c < 3; c++) {
+                const long i = (long)yy * w + xx;
                 const float xi = x[3 * i + c];
                 Px[3 * (n * 0 + i) + c] = xi * alpha;
                 Px[3 * (n * 1 + i) + c] = (xx != w - 1) ? x[3 * (i + 1) + c] - xi : 0.0f;
@@ -58,10 +73,11 @@ GDO_API void gdo_calc_Px(float *Px, int w, int h, float alpha, const float *x)
 GDO_API void gdo_calc_PTW2x(float *out, int w, int h, float alpha, const float *w2, const float *x)
 {
     const long n = (long)w * h;
-    long i = 0;
+    GDO_PARALLEL_FOR
     for (int yy = 0; yy < h; yy++)
-        for (int xx = 0; xx < w; xx++, i++)
+        for (int xx = 0; xx < w; xx++)
             for (int c = 0; c < 3; c++) {
+                const long i = (long)yy * w + xx;
                 float v = w2[n * 0 + i] * x[3 * (n * 0 + i) + c] * alpha;
                 if (xx != 0)     v = v + w2[n * 1 + i - 1] * x[3 * (n * 1 + i - 1) + c];
                 if (xx != w - 1) v = v - w2[n * 1 + i]     * x[3 * (n * 1 + i) + c];
@@ -79,10 +95,11 @@ GDO_API void gdo_calc_Ax_xAx(float *Ax, float *xAx, int w, int h, float alpha, c
     const long n = (long)w * h;
     const float alphaSqr = alpha * alpha;
     float acc[3] = {0.0f, 0.0f, 0.0f};
-    long i = 0;
+    GDO_PARALLEL_FOR_SUM3
     for (int yy = 0; yy < h; yy++)
-        for (int xx = 0; xx < w; xx++, i++)
+        for (int xx = 0; xx < w; xx++)
             for (int c = 0; c < 3; c++) {
+                const long i = (long)yy * w + xx;
                 const float xi = x[3 * i + c];
                 float a = w2[n * 0 + i] * xi * alphaSqr;
                 if (xx != 0)     a = a + w2[n * 1 + i - 1] * (xi - x[3 * (i - 1) + c]);
@@ -98,6 +115,7 @@ GDO_API void gdo_calc_Ax_xAx(float *Ax, float *xAx, int w, int h, float alpha, c
 /* Backend::calc_axpy, Backend.cpp:246-262: out = a*x + y, a is RGB. In-place safe. */
 GDO_API void gdo_calc_axpy(float *out, const float *a, const float *x, const float *y, long numElems)
 {
+    GDO_PARALLEL_FOR
     for (long i = 0; i < numElems; i++)
         for (int c = 0; c < 3; c++)
             out[3 * i + c] = a[c] * x[3 * i + c] + y[3 * i + c];
@@ -107,6 +125,7 @@ GDO_API void gdo_calc_axpy(float *out, const float *a, const float *x, const flo
 GDO_API void gdo_calc_xdoty(float *out, const float *x, const float *y, long numElems)
 {
     float acc[3] = {0.0f, 0.0f, 0.0f};
+    GDO_PARALLEL_FOR_SUM3
     for (long i = 0; i < numElems; i++)
         for (int c = 0; c < 3; c++)
             acc[c] = acc[c] + x[3 * i + c] * y[3 * i + c];
@@ -118,6 +137,7 @@ GDO_API void gdo_calc_r_rz(float *r, float *rz, const float *Ap, const float *rz
 {
     float a[3], acc[3] = {0.0f, 0.0f, 0.0f};
     for (int c = 0; c < 3; c++) a[c] = rz2[c] / fmax_ref(pAp[c], FLT_MIN);
+    GDO_PARALLEL_FOR_SUM3
     for (long i = 0; i < numElems; i++)
         for (int c = 0; c < 3; c++) {
             const float ri = r[3 * i + c] - Ap[3 * i + c] * a[c];
@@ -135,6 +155,7 @@ GDO_API void gdo_calc_x_p(float *x, float *p, const float *r, const float *rz, c
         a[c] = rz2[c] / fmax_ref(pAp[c], FLT_MIN);
         b[c] = rz[c] / fmax_ref(rz2[c], FLT_MIN);
     }
+    GDO_PARALLEL_FOR
     for (long i = 0; i < numElems; i++)
         for (int c = 0; c < 3; c++) {
             const float pi = p[3 * i + c];
@@ -149,6 +170,7 @@ GDO_API void gdo_calc_x_p(float *x, float *p, const float *r, const float *rz, c
 GDO_API void gdo_calc_w2(float *w2, const float *e, float reg, long numElems)
 {
     float w2sum = 0.0f;
+    GDO_PARALLEL_FOR_SUM1
     for (long i = 0; i < numElems; i++) {
         const float ex = e[3 * i], ey = e[3 * i + 1], ez = e[3 * i + 2];
         const float len = sqrtf(ex * ex + ey * ey + ez * ez); /* Defs.hpp:105-106 */
@@ -157,6 +179,7 @@ GDO_API void gdo_calc_w2(float *w2, const float *e, float reg, long numElems)
         w2sum = w2sum + wi;
     }
     const float coef = (float)numElems / w2sum;
+    GDO_PARALLEL_FOR
     for (long i = 0; i < numElems; i++)
         w2[i] = w2[i] * coef;
 }

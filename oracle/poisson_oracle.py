@@ -57,6 +57,26 @@ def lib():
     return _lib
 
 
+_lib_omp = None
+
+
+def solve_allcores(params, dx, dy, tp, direct, w, h):
+    """The same solve through the OpenMP build of the restatement (libgdpt_oracle_poisson_omp.so).  ONLY for the all-cores CPU
+    baseline of bench.py: its dot products are per-thread partial sums, so it is not the checker."""
+    global _lib_omp
+    if _lib_omp is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "_build", "libgdpt_oracle_poisson_omp.so"))
+        L.gdo_solve.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _f32p, C.c_void_p]
+        L.gdo_solve.restype = C.c_long
+        _lib_omp = L
+    keep = [_f(a) if a is not None else None for a in (dx, dy, tp, direct)]
+    ptr = [a.ctypes.data_as(C.c_void_p) if a is not None else None for a in keep]
+    rec = np.empty(3 * w * h, np.float32)
+    _lib_omp.gdo_solve(C.byref(params), ptr[0], ptr[1], ptr[2], ptr[3], w, h, rec, None)
+    return rec
+
+
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
