@@ -153,7 +153,7 @@ def main():
     iters = prm.irlsIterMax * prm.cgIterMax
     solver = P.Solver(prm) if rank == 0 else None
     rows = y1 - y0
-    strip_imgs = [torch.empty((rows, W, 3), dtype=torch.float32, device=dev) for _ in range(4)]
+    strip_imgs = torch.empty((4, rows, W, 3), dtype=torch.float32, device=dev)     # throughput, dx, dy, direct of this strip
     rec = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
 
     def barrier():
@@ -171,7 +171,7 @@ def main():
         halo = parallel.exchange_halos(film, rank, world, dev)
         for i, b in enumerate((gpt.BUFFER_THROUGHPUT, gpt.BUFFER_DX, gpt.BUFFER_DY, gpt.BUFFER_VERY_DIRECT)):
             film.develop_device(b, strip_imgs[i])                                 # developMulti + float cast, gpt.cpp:1419-1442
-        full = [parallel.gather_rows(t, strips, W, rank, world) for t in strip_imgs]
+        full = parallel.gather_rows(strip_imgs, strips, W, rank, world)           # one message per rank for the four images
         solve_s = 0.0
         if rank == 0:
             solver.importImagesMTS(full[1], full[2], full[0], full[3], W, H)      # dx, dy, throughput, direct
@@ -184,7 +184,7 @@ def main():
 
     def make_strip(y0_, y1_):
         f = gpt.Film(scene, y0_, y1_)
-        imgs = [torch.empty((y1_ - y0_, W, 3), dtype=torch.float32, device=dev) for _ in range(4)]
+        imgs = torch.empty((4, y1_ - y0_, W, 3), dtype=torch.float32, device=dev)
         return f, imgs
 
     for _ in range(a.warmup):

@@ -92,15 +92,18 @@ def exchange_halos(film, rank, world, device, group=None):
 
 
 def gather_rows(strip, strips, width, rank, world, group=None):
-    """Gather per-rank [rows_r, width, 3] fp32 strips to rank 0 as one [H, width, 3] image (None elsewhere)."""
+    """Gather per-rank strips to rank 0 (None elsewhere).  strip: [rows_r, width, 3] -> [H, width, 3], or a stack of images
+    [k, rows_r, width, 3] -> [k, H, width, 3] (one message per rank for all k images instead of k)."""
     if world == 1:
         return strip
+    stacked = strip.dim() == 4
+    lead = (strip.shape[0],) if stacked else ()
     if rank == 0:
-        parts = [_wire(torch.empty((y1 - y0, width, 3), dtype=strip.dtype, device=strip.device)) for (y0, y1) in strips]
+        parts = [_wire(torch.empty(lead + (y1 - y0, width, 3), dtype=strip.dtype, device=strip.device)) for (y0, y1) in strips]
         for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, parts[r], r, group=group) for r in range(1, world)]):
             q.wait()
         parts[0] = strip
-        full = torch.cat([p.to(strip.device) for p in parts], dim=0)
+        full = torch.cat([p.to(strip.device) for p in parts], dim=1 if stacked else 0)
         _settle(full)
         return full
     for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, _wire(strip.contiguous()), 0, group=group)]):

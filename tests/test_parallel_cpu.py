@@ -54,6 +54,12 @@ def _worker(rank, world, port, W, H, q):
     sent = parallel.exchange_halos(film, rank, world, torch.device("cpu"))
     strip = torch.from_numpy(np.full((y1 - y0, W, 3), float(rank), np.float32))
     img = parallel.gather_rows(strip, strips, W, rank, world)
+    stack = torch.stack([strip + 10.0 * k for k in range(4)])                  # the four solver images of a strip in one message
+    img4 = parallel.gather_rows(stack, strips, W, rank, world)
+    if rank == 0:
+        assert img4.shape == (4, H, W, 3) and all(torch.equal(img4[k], img + 10.0 * k) for k in range(4))
+    else:
+        assert img4 is None
     q.put((rank, film.rec[:, 0].copy(), film.rec[:, -1].copy(), film.rec[:, 1].copy(), film.rec[:, -2].copy(),
            (film.spill - before_spill)[:, 1].copy(), (film.spill - before_spill)[:, -2].copy(), before_spill[:, 0].copy(), before_spill[:, -1].copy(),
            sent, None if img is None else img.numpy()))
