@@ -421,6 +421,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     f->wavesPerSimd = s->d.ldsScene ? 2 : 4;    // measured: LDS-resident scenes peak at 2 waves/SIMD, HBM-resident BVHs want 4
     FilmD &d = f->d;
     d.recExtra = nullptr;
+    d.fValues = nullptr; d.fRadius = 0.0; d.fScale = 0.0;       // box filter
     d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
     d.recStride = (size_t)d.recRows * W;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
@@ -441,6 +442,7 @@ void gdpt_film_destroy(gdpt_film *f)
     if (f->stream) hipStreamSynchronize(f->stream);
     for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (f->d.rec) hipFree(f->d.rec);
+    if (f->d.fValues) hipFree((void *)f->d.fValues);
     if (f->d.recExtra) hipFree(f->d.recExtra);
     if (f->d.spill) hipFree(f->d.spill);
     if (f->d.stats) hipFree(f->d.stats);
@@ -623,6 +625,60 @@ float gdpt_film_render_ms(gdpt_film *f)
 }
 
 void *gdpt_film_stream(gdpt_film *f) { return f ? (void *)f->stream : nullptr; }
+
+// The reconstruction filters of src/rfilters/*.cpp, discretised as ReconstructionFilter::configure does (rfilter.cpp:37-55).
+static double rfilter_eval(int kind, double p0, double p1, double radius, double x)
+{
+    auto cubic = [](double B, double C, double x) {              // mitchell.cpp:55-68, catmullrom.cpp:40-55
+        x = std::fabs(x);
+        const double x2 = x * x, x3 = x2 * x;
+        if (x < 1) return 1.0 / 6.0 * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+        else if (x < 2) return 1.0 / 6.0 * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+        return 0.0;
+    };
+    switch (kind) {
+        case GDPT_RFILTER_TENT: return std::max(0.0, 1.0 - std::fabs(x / radius));                                    // tent.cpp:42-44
+        case GDPT_RFILTER_GAUSSIAN: { const double alpha = -1.0 / (2.0 * p0 * p0); return std::max(0.0, std::exp(alpha * x * x) - std::exp(alpha * radius * radius)); }   // gaussian.cpp:52-57
+        case GDPT_RFILTER_MITCHELL: return cubic(p0, p1, x);
+        case GDPT_RFILTER_CATMULLROM: return cubic(0.0, 0.5, x);
+        case GDPT_RFILTER_LANCZOS: {                                                                                   // lanczos.cpp:43-55
+            x = std::fabs(x);
+            if (x < GD_EPSILON) return 1.0;
+            else if (x > radius) return 0.0;
+            const double x1 = GD_PI * x, x2 = x1 / radius;
+            return (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+        }
+        default: return std::fabs(x) <= radius ? 1.0 : 0.0;
+    }
+}
+
+int gdpt_film_set_rfilter(gdpt_film *f, int kind, double p0, double p1)
+{
+    if (!f || kind < GDPT_RFILTER_BOX || kind > GDPT_RFILTER_LANCZOS) return tfail(GDPT_ERR_INVALID, "set_rfilter: unknown reconstruction filter");
+    THIPCHK(hipStreamSynchronize(f->stream));
+    if (f->d.fValues) { hipFree((void *)f->d.fValues); f->d.fValues = nullptr; }
+    if (kind == GDPT_RFILTER_BOX) return GDPT_OK;                    // the per-pixel-sums fast path
+    double radius;
+    switch (kind) {
+        case GDPT_RFILTER_TENT: radius = 1.0; break;                  // tent.cpp:34
+        case GDPT_RFILTER_GAUSSIAN: if (!(p0 > 0)) return tfail(GDPT_ERR_INVALID, "gaussian: stddev must be positive"); radius = 4 * p0; break;   // gaussian.cpp:38
+        case GDPT_RFILTER_LANCZOS: if (!(p0 >= 1)) return tfail(GDPT_ERR_INVALID, "lanczos: lobes must be >= 1"); radius = p0; break;           // lanczos.cpp:35
+        default: radius = 2.0; break;                                 // mitchell.cpp:35, catmullrom.cpp:32
+    }
+    if (f->d.y0 != 0 || f->d.y1 != f->d.H)
+        return tfail(GDPT_ERR_UNSUPPORTED, "reconstruction filters wider than box need a film over all rows: the strip halo is one pixel (border %d needed)", 1 + (int)std::ceil(radius - 0.5));
+    double v[32], sum = 0.0;
+    for (int i = 0; i < 31; i++) { v[i] = rfilter_eval(kind, p0, p1, radius, (radius * i) / 31); sum += v[i]; }
+    v[31] = 0.0;
+    sum *= 2 * radius / 31;
+    const double normalization = 1.0 / sum;
+    for (int i = 0; i < 31; i++) v[i] *= normalization;
+    Float *dv = nullptr;
+    THIPCHK(hipMalloc((void **)&dv, sizeof v));
+    THIPCHK(hipMemcpy(dv, v, sizeof v, hipMemcpyHostToDevice));
+    f->d.fValues = dv; f->d.fRadius = radius; f->d.fScale = 31 / radius;
+    return GDPT_OK;
+}
 
 int gdpt_film_set_slices(gdpt_film *f, int slices)
 {

@@ -138,6 +138,8 @@ struct FilmD {
     Float *rec;                 // [NREC][recRows][W] per-pixel sample sums; row index = y - (y0 - 1)
     Float *recExtra;            // [slices-1][NREC][recRows][W]: the sums of sample slices 1.. of a launch, folded into rec after it
     Float *spill;               // [5][recRows][W][4] exact generic puts (R,G,B,weight)
+    const Float *fValues;       // nullptr: box filter (the fast path below); else the 32-entry table of ReconstructionFilter::configure
+    Float fRadius, fScale;      // of that table (rfilter.cpp:37-55)
     unsigned long long *stats;  // [4]
     int W, H, y0, y1, recRows;
     size_t recStride;           // recRows * W
@@ -945,18 +947,25 @@ __device__ __forceinline__ Float eval_discretized(const FilterD &f, Float x)
 // ImageBlock::put (imageblock.h:150-199) restricted to the film, with fp64 atomics: the exact generic path.
 __device__ void spill_put(const FilmD &F, const FilterD &flt, Float px, Float py, d3 spec, Float weight, int b)
 {
+    const bool box = F.fValues == nullptr;
+    const Float radius = box ? flt.radius : F.fRadius, scale = box ? flt.scale : F.fScale;
+    auto evalD = [&](Float x) -> Float {                       // evalDiscretized, rfilter.h:76-77
+        int idx = (int)fabs(x * scale);
+        if (idx > 31) idx = 31;
+        return box ? (idx < 31 ? flt.c : 0.0) : F.fValues[idx];
+    };
     const Float posx = px - 0.5, posy = py - 0.5;
-    int x0 = (int)ceil(posx - flt.radius), y0 = (int)ceil(posy - flt.radius);
-    int x1 = (int)floor(posx + flt.radius), y1 = (int)floor(posy + flt.radius);
+    int x0 = (int)ceil(posx - radius), y0 = (int)ceil(posy - radius);
+    int x1 = (int)floor(posx + radius), y1 = (int)floor(posy + radius);
     if (x0 < 0) x0 = 0;
     if (y0 < 0) y0 = 0;
     if (x1 > F.W - 1) x1 = F.W - 1;
     if (y1 > F.H - 1) y1 = F.H - 1;
     for (int y = y0; y <= y1; ++y) {
         if (y < F.y0 - 1 || y > F.y1) continue;               // outside this film's rows + halo: another strip's sample
-        const Float wy = eval_discretized(flt, y - posy);
+        const Float wy = evalD(y - posy);
         for (int x = x0; x <= x1; ++x) {
-            const Float w = eval_discretized(flt, x - posx) * wy;
+            const Float w = evalD(x - posx) * wy;
             Float *dest = F.spill + (((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4;
             atomicAdd(dest + 0, w * spec.x);
             atomicAdd(dest + 1, w * spec.y);

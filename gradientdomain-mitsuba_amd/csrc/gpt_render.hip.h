@@ -430,7 +430,8 @@ template <class ACC>
 __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, const ACC &A, int px, int py)
 {
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
-    const bool fast = single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
+    // (other reconstruction filters than box spread every put over several pixels: they always take the generic path)
+    const bool fast = F.fValues == nullptr && single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
                       single_pixel(flt, L.sx + 1, L.sy, px + 1, py) && single_pixel(flt, L.sx, L.sy - 1, px, py - 1) &&
                       single_pixel(flt, L.sx, L.sy + 1, px, py + 1);
     if (fast) {

@@ -125,6 +125,9 @@ class Film:
         self.rows, self.width = self.y1 - self.y0, scene.width
         self._h = C.c_void_p()
         check(lib().gdpt_film_create(scene._h, self.y0, self.y1, C.byref(self._h)))
+        rf = getattr(scene.desc, "rfilter", None)
+        if rf is not None:                                   # the scene description's <rfilter>
+            self.set_rfilter(*rf)
 
     def clear(self):
         check(lib().gdpt_film_clear(self._h))
@@ -166,6 +169,11 @@ class Film:
 
     def set_occupancy(self, waves_per_simd):
         check(lib().gdpt_film_set_occupancy(self._h, int(waves_per_simd)))
+
+    def set_rfilter(self, kind, p0=0.0, p1=0.0):
+        """`<rfilter>` of the film (scenes.RFILTER_*); box is the default and the fast path."""
+        lib().gdpt_film_set_rfilter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        check(lib().gdpt_film_set_rfilter(self._h, int(kind), float(p0), float(p1)))
 
     def set_slices(self, slices):
         """Sample slices per launch (0 = chosen per launch); a tuning knob, see include/gdpt_tracer.h."""

@@ -249,6 +249,16 @@ public:
                                    (int)sd.materials.size(), sd.materials.data(), (int)sd.emitters.size(), sd.emitters.data(),
                                    sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, -1, &scene));
         check(gdpt_film_create(scene, 0, H, &gf));
+        {   // <rfilter>: src/rfilters/*.cpp with their default parameters
+            const std::string ft = sd.rfilter.getPluginName();
+            int kind = GDPT_RFILTER_BOX; double p0 = 0, p1 = 0;
+            if (ft == "tent") kind = GDPT_RFILTER_TENT;
+            else if (ft == "gaussian") { kind = GDPT_RFILTER_GAUSSIAN; p0 = sd.rfilter.getFloat("stddev", 0.5); }
+            else if (ft == "mitchell") { kind = GDPT_RFILTER_MITCHELL; p0 = sd.rfilter.getFloat("B", 1.0 / 3.0); p1 = sd.rfilter.getFloat("C", 1.0 / 3.0); }
+            else if (ft == "catmullrom") kind = GDPT_RFILTER_CATMULLROM;
+            else if (ft == "lanczos") { kind = GDPT_RFILTER_LANCZOS; p0 = (double)sd.rfilter.getInteger("lobes", 3); }
+            check(gdpt_film_set_rfilter(gf, kind, p0, p1));
+        }
         gdpt_config cfg;
         cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;
         cfg.shiftThreshold = m_shiftThreshold; cfg.seed = seed;

@@ -3,7 +3,7 @@
 //
 // Carried:  <scene>, <default>, $parameter substitution (+ -D overrides), <integrator type="gpt">, <sensor type="perspective">
 // (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
-// fileFormat="openexr"|"pfm") with <rfilter type="box">, <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
+// fileFormat="openexr"|"pfm") with <rfilter type="box|tent|gaussian|mitchell|catmullrom|lanczos"> (gaussian when absent, film.cpp:93), <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
 // shape), <shape type="obj|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
 // top-level <emitter type="constant"> (radiance),
 // <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
@@ -322,13 +322,14 @@ private:
             } else if (c->tag == "film") {
                 if (subst(c->get("type")) != "multifilm") logError("Cannot render image! G-PT has been called without MultiFilm.");   // gpt.cpp:1381-1384
                 sd.film = props(*c);
-                bool box = false;
+                sd.rfilter = Properties("gaussian");                             // Film's default reconstruction filter, film.cpp:93
                 for (auto &fc : c->children)
                     if (fc->tag == "rfilter") {
-                        if (subst(fc->get("type")) != "box") logError(format("rfilter \"%s\" is not carried: `box` only", fc->get("type").c_str()));
-                        box = true;
+                        const std::string ft = subst(fc->get("type"));
+                        if (ft != "box" && ft != "tent" && ft != "gaussian" && ft != "mitchell" && ft != "catmullrom" && ft != "lanczos")
+                            logError(format("rfilter \"%s\" is not carried: box, tent, gaussian, mitchell, catmullrom, lanczos", ft.c_str()));
+                        sd.rfilter = props(*fc);
                     }
-                if (!box) logError("the film needs <rfilter type=\"box\"/> (Mitsuba's default is gaussian, which this build does not carry)");
                 haveFilm = true;
             }
         }

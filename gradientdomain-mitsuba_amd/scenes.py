@@ -13,6 +13,9 @@ import numpy as np
 
 MAT_DIFFUSE, MAT_CONDUCTOR, MAT_ROUGHCONDUCTOR, MAT_DIELECTRIC = 0, 1, 2, 3
 DISTR_BECKMANN, DISTR_GGX, DISTR_PHONG = 0, 1, 2
+# reconstruction filters (src/rfilters): (kind, p0, p1) with the reference's default parameters
+RFILTER_BOX, RFILTER_TENT, RFILTER_GAUSSIAN, RFILTER_MITCHELL, RFILTER_CATMULLROM, RFILTER_LANCZOS = range(6)
+RFILTER_DEFAULTS = {0: (0, 0.0, 0.0), 1: (1, 0.0, 0.0), 2: (2, 0.5, 0.0), 3: (3, 1.0 / 3.0, 1.0 / 3.0), 4: (4, 0.0, 0.0), 5: (5, 3.0, 0.0)}
 
 
 def diffuse(rgb):
@@ -73,6 +76,7 @@ class Scene:
     height: int = 512
     name: str = "scene"
     environment: tuple = None    # ((r, g, b), position in the scene's emitter list) for `<emitter type="constant">`, or None
+    rfilter: tuple = None        # (kind, p0, p1) of the film's reconstruction filter (RFILTER_*); None = box
     normals: np.ndarray = None   # (ntri, 9) per-vertex normals (TriMesh vertex normals), all-zero rows = flat triangle; or None
 
     @property

@@ -136,6 +136,17 @@ GDPT_API void *gdpt_film_stream(gdpt_film *f);
  * 4-wave build); a negative value selects the same build with the
  * per-sample sums kept in registers instead of LDS.  Results are identical; only speed differs. */
 GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
+/* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/*.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
+ * (default: every put covers one pixel, the per-pixel-sums fast path), TENT, GAUSSIAN (p0 = stddev, 0.5), MITCHELL (p0 = B, p1 = C,
+ * 1/3 each), CATMULLROM, LANCZOS (p0 = lobes, 3).  The wider filters run every put through the exact generic path (fp64 atomics
+ * over the footprint): correct, several times slower, and only for a film over all rows (one-pixel strip halo).  Call before rendering. */
+#define GDPT_RFILTER_BOX        0
+#define GDPT_RFILTER_TENT       1
+#define GDPT_RFILTER_GAUSSIAN   2
+#define GDPT_RFILTER_MITCHELL   3
+#define GDPT_RFILTER_CATMULLROM 4
+#define GDPT_RFILTER_LANCZOS    5
+GDPT_API int  gdpt_film_set_rfilter(gdpt_film *f, int kind, double p0, double p1);
 /* Tuning knob (no reference counterpart): into how many slices the spp samples of a launch are split (one work item = one
  * 16x16 tile x one slice).  0 (default) = chosen per launch from the rectangle, spp and the device so that small launches
  * (strips of a multi-GPU frame) still fill the chip.  Samples and their random numbers do not depend on it; the per-pixel sums

@@ -249,6 +249,8 @@ struct Scene {
     // camera constants (perspective.cpp:125-163)
     Float aspect, tanHalf;
     V3 aabbMin, aabbMax;
+    int rfilterKind = 0;        // the film's reconstruction filter (Film::filterEval)
+    double rfilterP0 = 0, rfilterP1 = 0;
     int envIndex = -1;          // position of the environment emitter in `emitters` (scene order), -1: none
     V3 bsCenter;                // ConstantBackgroundEmitter::m_sceneBSphere (constant.cpp:67-70)
     Float bsRadius = 0;
@@ -1470,12 +1472,48 @@ struct Film {
     int W, H;
     std::vector<double> buf[5]; // [H][W][4]: R,G,B,weight (alpha == 1 carried implicitly)
     double filterRadius, filterScale, filterValues[32];
-    Film(int w, int h) : W(w), H(h)
+    // the reconstruction filters of src/rfilters/*.cpp; kind: 0 box, 1 tent, 2 gaussian (p0 = stddev), 3 mitchell (p0 = B, p1 = C),
+    // 4 catmullrom, 5 lanczos (p0 = lobes)
+    static double filterRadiusOf(int kind, double p0)
+    {
+        switch (kind) {
+            case 1: return 1.0;                                       // tent.cpp:34
+            case 2: return 4 * p0;                                    // gaussian.cpp:38
+            case 3: case 4: return 2.0;                               // mitchell.cpp:35, catmullrom.cpp:32
+            case 5: return p0;                                        // lanczos.cpp:35
+            default: return 0.5 + (double)1e-5f;                      // box.cpp:38
+        }
+    }
+    static double filterEval(int kind, double p0, double p1, double radius, double x)
+    {
+        auto cubic = [](double B, double C, double x) {              // mitchell.cpp:55-68, catmullrom.cpp:40-55
+            x = std::abs(x);
+            double x2 = x * x, x3 = x2 * x;
+            if (x < 1) return 1.0 / 6.0 * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+            else if (x < 2) return 1.0 / 6.0 * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+            return 0.0;
+        };
+        switch (kind) {
+            case 1: return std::max(0.0, 1.0 - std::abs(x / radius));                                                 // tent.cpp:42-44
+            case 2: { double alpha = -1.0 / (2.0 * p0 * p0); return std::max(0.0, std::exp(alpha * x * x) - std::exp(alpha * radius * radius)); }   // gaussian.cpp:52-57
+            case 3: return cubic(p0, p1, x);
+            case 4: return cubic(0.0, 0.5, x);
+            case 5: {                                                                                                 // lanczos.cpp:43-55
+                x = std::abs(x);
+                if (x < Epsilon) return 1.0;
+                else if (x > radius) return 0.0;
+                double x1 = PI * x, x2 = x1 / radius;
+                return (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+            }
+            default: return std::abs(x) <= radius ? 1.0 : 0.0;                                                        // box.cpp:44-46
+        }
+    }
+    Film(int w, int h, int kind = 0, double p0 = 0, double p1 = 0) : W(w), H(h)
     {
         for (auto &b : buf) b.assign((size_t)w * h * 4, 0.0);
-        filterRadius = 0.5 + (double)1e-5f;                       // box.cpp:38
-        double sum = 0;                                           // rfilter.cpp:37-55
-        for (int i = 0; i < 31; ++i) { double pos = (filterRadius * i) / 31; double v = std::abs(pos) <= filterRadius ? 1.0 : 0.0; filterValues[i] = v; sum += v; }
+        filterRadius = filterRadiusOf(kind, p0);
+        double sum = 0;                                           // ReconstructionFilter::configure, rfilter.cpp:37-55
+        for (int i = 0; i < 31; ++i) { double v = filterEval(kind, p0, p1, filterRadius, (filterRadius * i) / 31); filterValues[i] = v; sum += v; }
         filterValues[31] = 0.0;
         filterScale = 31 / filterRadius;
         sum *= 2 * filterRadius / 31;
@@ -1657,6 +1695,9 @@ GPO_API int gpo_scene_set_normals(gpo_scene *h, const double *n9)
     return 0;
 }
 
+// `<rfilter>` of the film: kind as in Film::filterEval, p0/p1 its parameters (defaults are the caller's business)
+GPO_API void gpo_scene_set_rfilter(gpo_scene *h, int kind, double p0, double p1) { h->sc.rfilterKind = kind; h->sc.rfilterP0 = p0; h->sc.rfilterP1 = p1; }
+
 GPO_API void gpo_scene_destroy(gpo_scene *h) { delete h; }
 
 // Renders pixels [x0,x1) x [y0,y1).  accum: 5 buffers x H x W x 4 doubles (R,G,B,weight sums; film-sized; contributions
@@ -1665,7 +1706,7 @@ GPO_API void gpo_render(gpo_scene *h, const gpo_config *cfg, int x0, int y0, int
 {
     Scene &sc = h->sc;
     sc.raysTraced = sc.shadowRaysTraced = 0;
-    Film film(sc.cam.width, sc.cam.height);
+    Film film(sc.cam.width, sc.cam.height, sc.rfilterKind, sc.rfilterP0, sc.rfilterP1);
     renderRect(sc, *cfg, x0, y0, x1, y1, film);
     const size_t n = (size_t)sc.cam.width * sc.cam.height * 4;
     for (int b = 0; b < 5; ++b) std::memcpy(accum + b * n, film.buf[b].data(), n * sizeof(double));

@@ -71,6 +71,7 @@ def lib():
         L.gpo_scene_destroy.argtypes = [C.c_void_p]
         L.gpo_scene_set_environment.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpo_scene_set_normals.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpo_scene_set_rfilter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -116,6 +117,9 @@ class Scene:
         if nrm is not None:                                  # (ntri, 9) per-vertex normals, zero rows = flat triangle
             if lib().gpo_scene_set_normals(self._h, _p(_d(nrm))) != 0:
                 raise ValueError("vertex normals on emitter triangles are not carried")
+        rf = getattr(desc, "rfilter", None)
+        if rf is not None:                                   # (kind, p0, p1), kinds as scenes.RFILTER_*
+            lib().gpo_scene_set_rfilter(self._h, int(rf[0]), float(rf[1]), float(rf[2]))
         env = getattr(desc, "environment", None)
         if env is not None:                                  # (radiance rgb, position in the emitter list)
             lib().gpo_scene_set_environment(self._h, _p(_d(env[0])), int(env[1]))

@@ -103,7 +103,7 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     ('<shape type="rectangle"/>', None, "no emitter"),
     ('<emitter type="constant"/><emitter type="constant"/>' + LIGHT, None, "Only one environment emitter"),
     (LIGHT, '<film type="hdrfilm"><rfilter type="box"/></film>', "without MultiFilm"),
-    (LIGHT, '<film type="multifilm"><string name="fileFormat" value="pfm"/><rfilter type="gaussian"/></film>', "`box` only"),
+    (LIGHT, '<film type="multifilm"><string name="fileFormat" value="pfm"/><rfilter type="sinc"/></film>', "rfilter \"sinc\" is not carried"),
     ('<emitter type="envmap"/>' + LIGHT, None, "not carried"),
     ('<shape type="rectangle"><ref id="nope"/></shape>' + LIGHT, None, "not found"),
 ])
@@ -232,5 +232,16 @@ def test_cli_render_equals_python_mirror(cli, tmp_path, gpu_required):
     assert json.loads(run(cli, "--parse-only", "-D", "width=48", "-D", "height=40", xsm).stdout)["smoothTriangles"] == nt - 12
     img = read_pfm(dest + "s-final.pfm")
     assert np.isfinite(img).all() and img.max() > 0
+    # <rfilter type="gaussian"> (Mitsuba's default film filter) through the CLI == the Python mirror with the same filter
+    xg = str(tmp_path / "gauss.xml")
+    open(xg, "w").write(open(XML).read().replace('<rfilter type="box"/>', '<rfilter type="gaussian"><float name="stddev" value="0.4"/></rfilter>'))
+    assert '<rfilter type="gaussian">' in open(xg).read()
+    r = run(cli, "-o", dest + "g", "-D", "width=32", "-D", "height=24", "-D", "spp=2", "-D", "maxDepth=4", xg)
+    assert r.returncode == 0, r.stderr
+    scg = scenes.cornell_box(32, 24); scg.rfilter = (scenes.RFILTER_GAUSSIAN, 0.4, 0.0)
+    outg = G.GradientPathIntegrator(maxDepth=4).render(G.Scene(scg), 2)
+    for suffix in G.BUFFER_NAMES:
+        a, b = read_pfm(dest + "g" + suffix + ".pfm"), outg[suffix]
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-6), suffix          # fp32 images of fp64 sums accumulated by atomics in free order, then a solve
     bad = run(cli, "-o", dest, "-D", "width=16", "-D", "height=16", "-D", "maxDepth=0", XML)
     assert bad.returncode == 1 and "maxDepth" in bad.stderr
