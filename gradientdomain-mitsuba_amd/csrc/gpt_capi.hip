@@ -422,6 +422,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     FilmD &d = f->d;
     d.recExtra = nullptr;
     d.fValues = nullptr; d.fRadius = 0.0; d.fScale = 0.0;       // box filter
+    d.log = nullptr; d.logChunk = 0;
     d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
     d.recStride = (size_t)d.recRows * W;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
@@ -443,6 +444,7 @@ void gdpt_film_destroy(gdpt_film *f)
     for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (f->d.rec) hipFree(f->d.rec);
     if (f->d.fValues) hipFree((void *)f->d.fValues);
+    if (f->d.log) hipFree(f->d.log);
     if (f->d.recExtra) hipFree(f->d.recExtra);
     if (f->d.spill) hipFree(f->d.spill);
     if (f->d.stats) hipFree(f->d.stats);
@@ -511,6 +513,19 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     }
     f->lastSlices = slices;
     const dim3 grid(tiles * slices), block(TBLK);
+    // A reconstruction filter wider than box: samples are rendered in chunks into the sample log and gathered after each chunk
+    int chunk = cfg->spp;
+    if (f->d.fValues) {
+        if (x0 != 0 || x1 != f->d.W || y0 != f->d.y0 || y1 != f->d.y1) return tfail(GDPT_ERR_UNSUPPORTED, "with a reconstruction filter wider than box the rectangle must be the whole film");
+        chunk = std::min(cfg->spp, LOG_CHUNK);
+        if (f->d.logChunk < chunk) {
+            THIPCHK(hipStreamSynchronize(f->stream));
+            if (f->d.log) hipFree(f->d.log);
+            f->d.log = nullptr; f->d.logChunk = 0;
+            if (hipMalloc((void **)&f->d.log, sizeof(Float) * 32 * (size_t)chunk * f->d.H * f->d.W) != hipSuccess) return tfail(GDPT_ERR_HIP, "Out of memory!");
+            f->d.logChunk = chunk;
+        }
+    }
 #define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
     // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment emitter | + per-vertex normals (environment tested at run time)};
     // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
@@ -518,11 +533,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (s->d.vn)                { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, true);   else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
         else if (s->d.envIndex >= 0) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, false); } \
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
-    if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
-    else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
+    for (int base = 0; base < cfg->spp; base += chunk) {
+        c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);
+        if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
+        else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
+        if (f->d.fValues)
+            hipLaunchKernelGGL(k_gather_log, dim3((f->d.W + 15) / 16, (f->d.H + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount);
+    }
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
-    if (slices > 1) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
+    if (slices > 1 && !f->d.fValues) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
@@ -657,6 +677,7 @@ int gdpt_film_set_rfilter(gdpt_film *f, int kind, double p0, double p1)
     if (!f || kind < GDPT_RFILTER_BOX || kind > GDPT_RFILTER_LANCZOS) return tfail(GDPT_ERR_INVALID, "set_rfilter: unknown reconstruction filter");
     THIPCHK(hipStreamSynchronize(f->stream));
     if (f->d.fValues) { hipFree((void *)f->d.fValues); f->d.fValues = nullptr; }
+    if (f->d.log) { hipFree(f->d.log); f->d.log = nullptr; f->d.logChunk = 0; }
     if (kind == GDPT_RFILTER_BOX) return GDPT_OK;                    // the per-pixel-sums fast path
     double radius;
     switch (kind) {
@@ -743,6 +764,7 @@ int gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
     c.regenMin = REGEN_MIN;
+    c.sBase = 0; c.sCount = cfg->spp;
     double *d = nullptr;
     THIPCHK(hipMalloc((void **)&d, sizeof(double) * 33));
     hipLaunchKernelGGL(k_eval_point, dim3(1), dim3(TBLK), 0, 0, s->d, c, px, py, sample, d);

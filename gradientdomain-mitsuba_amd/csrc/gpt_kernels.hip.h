@@ -47,6 +47,7 @@ constexpr int TBLK = 256;          // threads per block (16x16 px)
 constexpr int STACK_DEPTH = 28;    // BVH traversal stack entries per lane (LDS)
 constexpr int REGEN_MIN = 56;      // default number of idle lanes in a wave before they regenerate together (ConfigD::regenMin)
 constexpr int SLICE_FILL = 2;      // sample slices: aim at this many work items per resident block slot ...
+constexpr int LOG_CHUNK = 16;      // wider reconstruction filters: samples per pixel logged between two gathers (32 doubles each)
 constexpr int SLICE_MIN_SPP = 8;   // ... but never fewer samples than this per slice (the end of a slice runs with idle lanes)
 constexpr int NREC = 31;           // per-pixel record components
 constexpr int LDS_SCENE_BYTES = 40 * 1024;   // node + triangle + shading + material + emitter tables of a small scene
@@ -131,6 +132,7 @@ struct SceneD {
 struct ConfigD {
     int maxDepth, rrDepth, strictNormals, spp;
     int regenMin;               // idle lanes of a wave before they start new samples together (tuning, not a reference parameter)
+    int sBase, sCount;          // the samples [sBase, sBase + sCount) of every pixel are rendered by this launch (spp = the whole count)
     Float shiftThreshold;
     unsigned long long seed;
 };
@@ -140,6 +142,8 @@ struct FilmD {
     Float *spill;               // [5][recRows][W][4] exact generic puts (R,G,B,weight)
     const Float *fValues;       // nullptr: box filter (the fast path below); else the 32-entry table of ReconstructionFilter::configure
     Float fRadius, fScale;      // of that table (rfilter.cpp:37-55)
+    Float *log;                 // wider filters: sample log [32][logChunk][H][W] (30 sums, sx, sy of every sample of a chunk), gathered by k_gather_log
+    int logChunk;
     unsigned long long *stats;  // [4]
     int W, H, y0, y1, recRows;
     size_t recStride;           // recRows * W
@@ -915,12 +919,14 @@ template <> struct Acc<false> {
     __device__ __forceinline__ void zero() { for (int k = 0; k < ACC_N; k++) a[k] = 0.0; }
     __device__ __forceinline__ void add3(int k, d3 v) { a[k] += v.x; a[k + 1] += v.y; a[k + 2] += v.z; }
     __device__ __forceinline__ d3 get3(int k) const { return mk(a[k], a[k + 1], a[k + 2]); }
+    __device__ __forceinline__ Float get(int k) const { return a[k]; }
 };
 template <> struct Acc<true> {
     Float *p;               // LDS, already offset by the lane
     __device__ __forceinline__ void zero() { for (int k = 0; k < ACC_N; k++) p[k * TBLK] = 0.0; }
     __device__ __forceinline__ void add3(int k, d3 v) { p[k * TBLK] += v.x; p[(k + 1) * TBLK] += v.y; p[(k + 2) * TBLK] += v.z; }
     __device__ __forceinline__ d3 get3(int k) const { return mk(p[k * TBLK], p[(k + 1) * TBLK], p[(k + 2) * TBLK]); }
+    __device__ __forceinline__ Float get(int k) const { return p[k * TBLK]; }
 };
 
 // ---- film ---------------------------------------------------------------------------------------------------

@@ -427,8 +427,18 @@ GDPT_OFFSET_LOOP
 // Accumulates one finished sample: the 15 puts of gpt.cpp:1314-1352.  Fast path = per-pixel sums (every put covers
 // exactly its expected pixel); otherwise the exact generic path.
 template <class ACC>
-__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, const ACC &A, int px, int py)
+__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, const ACC &A, int px, int py, int logSlot)
 {
+    if (F.log) {
+        // a reconstruction filter wider than box: no put here -- the sample's sums and position go to the log, and k_gather_log
+        // evaluates every put from the side of the pixel that receives it (no atomics, a fixed order)
+        const size_t plane = (size_t)F.H * F.W, at = (size_t)logSlot * plane + (size_t)py * F.W + px, comp = (size_t)F.logChunk * plane;
+#pragma unroll
+        for (int k = 0; k < ACC_N; k++) F.log[(size_t)k * comp + at] = A.get(k);
+        F.log[(size_t)30 * comp + at] = L.sx;
+        F.log[(size_t)31 * comp + at] = L.sy;
+        return;
+    }
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
     // (other reconstruction filters than box spread every put over several pixels: they always take the generic path)
     const bool fast = F.fValues == nullptr && single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     // a multi-GPU frame) or the tail of a large one still fills it: each slice sums into its own record plane, folded in order.
     const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
     const int tx = tile % tilesX, ty = tile / tilesX;
-    const int s0 = (int)((long long)cfg.spp * slice / slices), s1 = (int)((long long)cfg.spp * (slice + 1) / slices);
+    const int s0 = cfg.sBase + (int)((long long)cfg.sCount * slice / slices), s1 = cfg.sBase + (int)((long long)cfg.sCount * (slice + 1) / slices);
     if (slice > 0) F.rec = F.recExtra + (size_t)(slice - 1) * NREC * F.recStride;
     const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool valid = px < rx1 && py < ry1;
@@ -531,7 +541,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         if (wantMask == 0 && idleMask == ~0ULL) break;
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
-            if (pending) finish_path(F, flt, L, A, px, py);
+            if (pending) finish_path(F, flt, L, A, px, py, next - 1 - cfg.sBase);
             active = start_path<ENV, SMOOTH>(S, sv, cfg, stack, L, A, px, py, next);
             next++;
             pending = !active;
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
             }
         }
     }
-    if (pending) finish_path(F, flt, L, A, px, py);
+    if (pending) finish_path(F, flt, L, A, px, py, next - 1 - cfg.sBase);
     // statistics: wave-level integer reduction, one atomic per wave and counter
     const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
     const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
@@ -555,6 +565,48 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         atomicAdd(&F.stats[2], (unsigned long long)c2);
         atomicAdd(&F.stats[3], (unsigned long long)c3);
     }
+}
+
+// Wider reconstruction filters: the 15 puts of gpt.cpp:1314-1352 for the `count` logged samples of every pixel, evaluated from
+// the side of the receiving pixel.  One thread = one output pixel: it visits the pixels within reach (filter radius + the one-pixel
+// shift of the neighbour puts), reads each sample's position, forms the weights of the five put positions from the discretised
+// filter (ImageBlock::put, imageblock.h:150-199: w = wx * wy; beyond the radius the table gives 0) and adds into its own 5 x 4
+// sums in (row, column, sample) order -- no atomics, reproducible.  Adjacent threads read adjacent log entries.
+__global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
+{
+    enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= F.W || y >= F.H) return;
+    const int R = (int)ceil(F.fRadius) + 1;
+    const size_t plane = (size_t)F.H * F.W, comp = (size_t)F.logChunk * plane;
+    auto evalD = [&](Float d) -> Float { int idx = (int)fabs(d * F.fScale); if (idx > 31) idx = 31; return F.fValues[idx]; };
+    Float o[5][4];
+    for (int b = 0; b < 5; b++) for (int k = 0; k < 4; k++) o[b][k] = 0.0;
+    for (int yy = max(0, y - R); yy <= min(F.H - 1, y + R); yy++)
+        for (int xx = max(0, x - R); xx <= min(F.W - 1, x + R); xx++)
+            for (int c = 0; c < count; c++) {
+                const size_t at = (size_t)c * plane + (size_t)yy * F.W + xx;
+                const Float sx = F.log[(size_t)30 * comp + at], sy = F.log[(size_t)31 * comp + at];
+                // distances of this pixel from the put positions (pos = sample - 0.5; neighbour puts one pixel away)
+                const Float dx0 = x - (sx - 0.5), dy0 = y - (sy - 0.5);
+                const Float wx0 = evalD(dx0), wxm = evalD(dx0 + 1.0), wxp = evalD(dx0 - 1.0);     // puts at sx, sx - 1, sx + 1
+                const Float wy0 = evalD(dy0), wym = evalD(dy0 + 1.0), wyp = evalD(dy0 - 1.0);
+                const Float w0 = wx0 * wy0, wL = wxm * wy0, wR = wxp * wy0, wT = wx0 * wym, wB = wx0 * wyp;
+                if (w0 == 0 && wL == 0 && wR == 0 && wT == 0 && wB == 0) continue;
+                auto get3 = [&](int k0) -> d3 { return mk(F.log[(size_t)k0 * comp + at], F.log[(size_t)(k0 + 1) * comp + at], F.log[(size_t)(k0 + 2) * comp + at]); };
+                const d3 T = get3(ACC_T), vd = get3(ACC_VD);
+                const d3 nL = 2 * get3(ACC_NBR + 3 * LEFT), nR = 2 * get3(ACC_NBR + 3 * RIGHT), nT = 2 * get3(ACC_NBR + 3 * TOP), nB = 2 * get3(ACC_NBR + 3 * BOTTOM);
+                auto put = [&](int b, Float w, d3 spec, Float weight) {
+                    o[b][0] += w * spec.x; o[b][1] += w * spec.y; o[b][2] += w * spec.z; o[b][3] += w * weight;
+                };
+                put(0, w0, (8 * vd) + (2 * T), 4.0); put(0, wL, nL, 1.0); put(0, wR, nR, 1.0); put(0, wT, nT, 1.0); put(0, wB, nB, 1.0);
+                put(1, w0, 2 * T, 4.0);              put(1, wL, nL, 1.0); put(1, wR, nR, 1.0); put(1, wT, nT, 1.0); put(1, wB, nB, 1.0);
+                put(2, wL, -(2 * get3(ACC_GRAD + 3 * LEFT)), 1.0); put(2, w0, 2 * get3(ACC_GRAD + 3 * RIGHT), 1.0);
+                put(3, wT, -(2 * get3(ACC_GRAD + 3 * TOP)), 1.0);  put(3, w0, 2 * get3(ACC_GRAD + 3 * BOTTOM), 1.0);
+                put(4, w0, vd, 1.0);
+            }
+    for (int b = 0; b < 5; b++)
+        for (int k = 0; k < 4; k++) F.spill[(((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4 + k] += o[b][k];
 }
 
 // rec += the slice planes, in slice order (a fixed association, so a render is reproducible bit for bit), and clear them
