@@ -4,7 +4,7 @@
 // Carried:  <scene>, <default>, $parameter substitution (+ -D overrides), <integrator type="gpt">, <sensor type="perspective">
 // (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
 // fileFormat="openexr"|"pfm") with <rfilter type="box|tent|gaussian|mitchell|catmullrom|lanczos"> (gaussian when absent, film.cpp:93), <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
-// shape), <shape type="obj|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
+// shape), <shape type="obj|serialized|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
 // top-level <emitter type="constant"> (radiance),
 // <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
 // Anything else raises std::runtime_error naming the tag or plugin, like the reference's "unsupported" errors.
@@ -12,6 +12,8 @@
 #include "gdpt_host.hpp"
 
 #include <array>
+#include <iterator>
+#include <zlib.h>
 #include <cctype>
 #include <map>
 #include <cmath>
@@ -469,6 +471,7 @@ private:
         Mat4 T = Mat4::identity();
         int mat = -1;
         bool flipNormals = false, faceNormals = false, emits = false;
+        int shapeIndex = 0;
         double radiance[3] = {1, 1, 1};
         std::string filename;
         for (auto &c : n.children) {
@@ -486,6 +489,7 @@ private:
             } else if (c->tag == "string" && c->get("name") == "filename") filename = subst(c->get("value"));
             else if (c->tag == "boolean" && c->get("name") == "flipNormals") flipNormals = subst(c->get("value")) == "true";
             else if (c->tag == "boolean" && c->get("name") == "faceNormals") faceNormals = subst(c->get("value")) == "true";
+            else if (c->tag == "integer" && c->get("name") == "shapeIndex") shapeIndex = std::atoi(subst(c->get("value")).c_str());
             else logError(format("shape \"%s\": <%s name=\"%s\"> is not carried", type.c_str(), c->tag.c_str(), c->get("name", "").c_str()));
         }
         if (mat < 0) { gdpt_material m; std::memset(&m, 0, sizeof m); m.type = GDPT_MAT_DIFFUSE; m.sampleVisible = 1; m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5; m.alphaU = m.alphaV = 0.1; sd.materials.push_back(m); mat = (int)sd.materials.size() - 1; }   // shape.cpp: default diffuse
@@ -502,13 +506,153 @@ private:
         } else if (type == "obj") {
             if (filename.empty()) logError("shape \"obj\": missing filename");
             loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flipNormals, faceNormals, mat);   // obj.cpp applies no handedness correction
-        } else logError(format("shape \"%s\" is not carried: obj, rectangle, cube", type.c_str()));
+        } else if (type == "serialized") {
+            if (filename.empty()) logError("shape \"serialized\": missing filename");
+            loadSerialized(filename[0] == '/' ? filename : m_dir + "/" + filename, shapeIndex, sd, T, flipNormals, faceNormals, mat);
+        } else logError(format("shape \"%s\" is not carried: obj, serialized, rectangle, cube", type.c_str()));
         if (emits) {
             gdpt_emitter e;
             e.firstTri = first; e.numTris = sd.numTriangles() - first;
             for (int k = 0; k < 3; ++k) e.radiance[k] = radiance[k];
             sd.emitters.push_back(e);
         }
+    }
+
+    // TriMesh::computeNormals (trimesh.cpp:608-681) on a mesh of world-space vertices (position 3 + normal 3) and index triples, then
+    // the triangles go to the scene: faceNormals drops the normals (flipNormals swaps the first two vertices of every triangle); given
+    // normals are kept (flipNormals negates them); a mesh without normals gets angle-weighted vertex normals (flipNormals negates
+    // them too).  Vertex normals that equal the face normal of every triangle using them are dropped again: the flat code path gives
+    // the same frame without the per-hit interpolation.
+    void finishMesh(SceneData &sd, const std::vector<std::array<double, 6>> &vb, std::vector<std::array<int, 3>> idx, bool hasNormals, bool flipNormals, bool faceNormals, int mat)
+    {
+        std::vector<std::array<double, 3>> vn(vb.size(), std::array<double, 3>{{0.0, 0.0, 0.0}});
+        bool useNormals = false;
+        if (faceNormals) {
+            if (flipNormals) for (auto &id : idx) std::swap(id[0], id[1]);
+        } else if (hasNormals) {
+            useNormals = true;
+            for (size_t i = 0; i < vb.size(); ++i) for (int k = 0; k < 3; ++k) vn[i][k] = flipNormals ? -vb[i][3 + k] : vb[i][3 + k];
+        } else {
+            useNormals = true;                                                 // "Computing Vertex Normals from Polygonal Facets", trimesh.cpp:636-672
+            for (auto &id : idx) {
+                double n[3] = {0, 0, 0};
+                for (int i = 0; i < 3; ++i) {
+                    const double *v0 = vb[id[i]].data(), *v1 = vb[id[(i + 1) % 3]].data(), *v2 = vb[id[(i + 2) % 3]].data();
+                    double a[3], b[3];
+                    for (int k = 0; k < 3; ++k) { a[k] = v1[k] - v0[k]; b[k] = v2[k] - v0[k]; }
+                    if (i == 0) {
+                        n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
+                        const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                        if (l == 0) break;
+                        for (double &c : n) c /= l;
+                    }
+                    const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+                    double u[3], w[3], dt = 0, sp = 0, sm = 0;
+                    for (int k = 0; k < 3; ++k) { u[k] = a[k] / la; w[k] = b[k] / lb; dt += u[k] * w[k]; }
+                    for (int k = 0; k < 3; ++k) { sp += (w[k] + u[k]) * (w[k] + u[k]); sm += (w[k] - u[k]) * (w[k] - u[k]); }
+                    const double angle = dt < 0 ? M_PI - 2 * std::asin(0.5 * std::sqrt(sp)) : 2 * std::asin(0.5 * std::sqrt(sm));   // unitAngle, util.h:305-310
+                    for (int k = 0; k < 3; ++k) vn[id[i]][k] += n[k] * angle;
+                }
+            }
+            for (auto &n : vn) {
+                double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (flipNormals) l *= -1;
+                if (l != 0) for (double &c : n) c /= l;
+                else { n[0] = 1; n[1] = 0; n[2] = 0; }
+            }
+        }
+        // vertex normals equal to every adjacent face normal are the flat case
+        bool allFlat = true;
+        for (size_t t = 0; t < idx.size() && useNormals && allFlat; ++t) {
+            const double *A = vb[idx[t][0]].data(), *B = vb[idx[t][1]].data(), *C = vb[idx[t][2]].data();
+            double a[3], b[3];
+            for (int k = 0; k < 3; ++k) { a[k] = B[k] - A[k]; b[k] = C[k] - A[k]; }
+            const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) if (std::abs(vn[idx[t][j]][k] - (l != 0 ? n[k] / l : 0.0)) > 1e-12) allFlat = false;
+        }
+        if (useNormals && allFlat) useNormals = false;
+        for (size_t t = 0; t < idx.size(); ++t) {
+            for (int j = 0; j < 3; ++j) sd.verts.insert(sd.verts.end(), vb[idx[t][j]].data(), vb[idx[t][j]].data() + 3);
+            sd.triMaterial.push_back(mat);
+            if (useNormals) {
+                sd.normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
+                for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) sd.normals[9 * (size_t)(sd.numTriangles() - 1) + 3 * j + k] = vn[idx[t][j]][k];
+            }
+        }
+    }
+
+    // `<shape type="serialized">` (src/shapes/serialized.cpp:146-210) reading Mitsuba's compressed mesh format
+    // (TriMesh::loadCompressed, trimesh.cpp:175-252: header 0x041C, version 3|4, then a zlib stream holding flags, [name,]
+    // vertex and triangle counts, positions, [normals,] [texcoords,] [colors,] uint32 indices; multi-mesh files end with an
+    // offset dictionary, trimesh.cpp:272-294).  Positions and normals go through toWorld; a mirroring transform swaps the first
+    // two vertices of every triangle (serialized.cpp:197-202); the file's face-normal flag is overridden by the property.
+    void loadSerialized(const std::string &path, int shapeIndex, SceneData &sd, const Mat4 &T, bool flipNormals, bool faceNormals, int mat)
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) logError(format("Cannot open serialized mesh \"%s\"", path.c_str()));
+        std::vector<unsigned char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        auto u16 = [&](size_t o) { if (o + 2 > file.size()) logError(path + ": truncated"); return (unsigned)(file[o] | (file[o + 1] << 8)); };
+        auto rd = [&](size_t o, size_t n) { unsigned long long v = 0; if (o + n > file.size()) logError(path + ": truncated"); for (size_t k = 0; k < n; ++k) v |= (unsigned long long)file[o + k] << (8 * k); return v; };
+        if (u16(0) == 0x1C04) logError("Encountered a geometry file generated by an old version of Mitsuba. Please re-import the scene to update this file to the current format.");
+        if (u16(0) != 0x041C) logError("Encountered an invalid file format!");
+        const unsigned version = u16(2);
+        if (version != 3 && version != 4) logError("Encountered an incompatible file version!");
+        if (shapeIndex < 0) logError("Shape index must be nonnegative!");
+        size_t offset = 0;
+        if (shapeIndex != 0) {
+            const size_t size = file.size();
+            const unsigned count = (unsigned)rd(size - 4, 4);
+            if (shapeIndex > (int)count) logError(format("Unable to unserialize mesh, shape index is out of range! (requested %i out of 0..%i)", shapeIndex, (int)count - 1));
+            offset = version == 4 ? (size_t)rd(size - 8 * (size_t)(count - shapeIndex) - 4, 8) : (size_t)rd(size - 4 * (size_t)(count - shapeIndex + 1), 4);
+        }
+        offset += 4;                                            // the (sub)stream's own header
+        std::vector<unsigned char> data;
+        {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit(&zs) != Z_OK) logError("zlib: inflateInit failed");
+            zs.next_in = file.data() + offset;
+            zs.avail_in = (uInt)std::min<size_t>(file.size() - offset, 0xffffffffu);
+            unsigned char buf[1 << 16];
+            int rc;
+            do {
+                zs.next_out = buf; zs.avail_out = sizeof buf;
+                rc = inflate(&zs, Z_NO_FLUSH);
+                if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); logError(path + ": zlib stream is corrupt"); }
+                data.insert(data.end(), buf, buf + (sizeof buf - zs.avail_out));
+            } while (rc != Z_STREAM_END);
+            inflateEnd(&zs);
+        }
+        size_t p = 0;
+        auto need = [&](size_t n) { if (p + n > data.size()) logError(path + ": mesh data is truncated"); };
+        auto r32 = [&]() { need(4); unsigned v; std::memcpy(&v, &data[p], 4); p += 4; return v; };
+        auto r64 = [&]() { need(8); unsigned long long v; std::memcpy(&v, &data[p], 8); p += 8; return v; };
+        const unsigned flags = r32();
+        if (version == 4) { need(1); while (data[p] != 0) { ++p; need(1); } ++p; }        // name
+        const size_t nv = (size_t)r64(), nt = (size_t)r64();
+        const bool dbl = (flags & 0x2000) != 0;
+        auto rfl = [&]() -> double { if (dbl) { need(8); double v; std::memcpy(&v, &data[p], 8); p += 8; return v; } need(4); float v; std::memcpy(&v, &data[p], 4); p += 4; return (double)v; };
+        std::vector<std::array<double, 6>> vb(nv, std::array<double, 6>{{0, 0, 0, 0, 0, 0}});
+        for (size_t i = 0; i < nv; ++i) { double q[3] = {rfl(), rfl(), rfl()}; T.point(q, vb[i].data()); }
+        const bool hasNormals = (flags & 0x0001) != 0;
+        if (hasNormals)
+            for (size_t i = 0; i < nv; ++i) {
+                double q[3] = {rfl(), rfl(), rfl()}, n[3];
+                T.normal(q, n);
+                const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                for (int k = 0; k < 3; ++k) vb[i][3 + k] = n[k] / l;                 // serialized.cpp:191-194
+            }
+        if (flags & 0x0002) for (size_t i = 0; i < 2 * nv; ++i) rfl();                // texture coordinates: read past (no carried BSDF uses them)
+        if (flags & 0x0008) for (size_t i = 0; i < 3 * nv; ++i) rfl();                // vertex colours
+        std::vector<std::array<int, 3>> idx(nt);
+        const bool mirror = T.det3() < 0;
+        for (size_t t = 0; t < nt; ++t) {
+            for (int j = 0; j < 3; ++j) { const unsigned v = r32(); if (v >= nv) logError(path + ": triangle references a vertex out of range"); idx[t][j] = (int)v; }
+            if (mirror) std::swap(idx[t][0], idx[t][1]);
+        }
+        finishMesh(sd, vb, idx, hasNormals, flipNormals, faceNormals, mat);
     }
 
     // Wavefront OBJ subset (src/shapes/obj.cpp): v, vn, vt, f with v / v/vt / v//vn / v/vt/vn and negative indices, polygons fanned,
@@ -552,62 +696,9 @@ private:
                 }
                 idx.push_back(id);
             }
-            std::vector<std::array<double, 3>> vn(vb.size(), std::array<double, 3>{{0.0, 0.0, 0.0}});
-            bool useNormals = false;
-            if (faceNormals) {
-                if (flipNormals) for (auto &id : idx) std::swap(id[0], id[1]);
-            } else if (hasNormals) {
-                useNormals = true;
-                for (size_t i = 0; i < vb.size(); ++i) for (int k = 0; k < 3; ++k) vn[i][k] = flipNormals ? -vb[i].d[3 + k] : vb[i].d[3 + k];
-            } else {
-                useNormals = true;                                                 // "Computing Vertex Normals from Polygonal Facets", trimesh.cpp:636-672
-                for (auto &id : idx) {
-                    double n[3] = {0, 0, 0};
-                    for (int i = 0; i < 3; ++i) {
-                        const double *v0 = vb[id[i]].d, *v1 = vb[id[(i + 1) % 3]].d, *v2 = vb[id[(i + 2) % 3]].d;
-                        double a[3], b[3];
-                        for (int k = 0; k < 3; ++k) { a[k] = v1[k] - v0[k]; b[k] = v2[k] - v0[k]; }
-                        if (i == 0) {
-                            n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
-                            const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                            if (l == 0) break;
-                            for (double &c : n) c /= l;
-                        }
-                        const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
-                        double u[3], w[3], dt = 0, sp = 0, sm = 0;
-                        for (int k = 0; k < 3; ++k) { u[k] = a[k] / la; w[k] = b[k] / lb; dt += u[k] * w[k]; }
-                        for (int k = 0; k < 3; ++k) { sp += (w[k] + u[k]) * (w[k] + u[k]); sm += (w[k] - u[k]) * (w[k] - u[k]); }
-                        const double angle = dt < 0 ? M_PI - 2 * std::asin(0.5 * std::sqrt(sp)) : 2 * std::asin(0.5 * std::sqrt(sm));   // unitAngle, util.h:305-310
-                        for (int k = 0; k < 3; ++k) vn[id[i]][k] += n[k] * angle;
-                    }
-                }
-                for (auto &n : vn) {
-                    double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                    if (flipNormals) l *= -1;
-                    if (l != 0) for (double &c : n) c /= l;
-                    else { n[0] = 1; n[1] = 0; n[2] = 0; }
-                }
-            }
-            // vertex normals equal to every adjacent face normal are the flat case
-            bool allFlat = true;
-            for (size_t t = 0; t < idx.size() && useNormals && allFlat; ++t) {
-                const double *A = vb[idx[t][0]].d, *B = vb[idx[t][1]].d, *C = vb[idx[t][2]].d;
-                double a[3], b[3];
-                for (int k = 0; k < 3; ++k) { a[k] = B[k] - A[k]; b[k] = C[k] - A[k]; }
-                const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-                const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                for (int j = 0; j < 3; ++j)
-                    for (int k = 0; k < 3; ++k) if (std::abs(vn[idx[t][j]][k] - (l != 0 ? n[k] / l : 0.0)) > 1e-12) allFlat = false;
-            }
-            if (useNormals && allFlat) useNormals = false;
-            for (size_t t = 0; t < idx.size(); ++t) {
-                for (int j = 0; j < 3; ++j) sd.verts.insert(sd.verts.end(), vb[idx[t][j]].d, vb[idx[t][j]].d + 3);
-                sd.triMaterial.push_back(mat);
-                if (useNormals) {
-                    sd.normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
-                    for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) sd.normals[9 * (size_t)(sd.numTriangles() - 1) + 3 * j + k] = vn[idx[t][j]][k];
-                }
-            }
+            std::vector<std::array<double, 6>> verts6(vb.size());
+            for (size_t i = 0; i < vb.size(); ++i) for (int k = 0; k < 6; ++k) verts6[i][k] = vb[i].d[k];
+            finishMesh(sd, verts6, idx, hasNormals, flipNormals, faceNormals, mat);
             tris.clear();
         };
         std::string line;

@@ -93,6 +93,57 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     assert json.loads(run(cli, "--parse-only", s).stdout)["emitters"] == 0
 
 
+def _write_serialized(path, meshes, version=4, double=False):
+    """Mitsuba's compressed mesh format (TriMesh::serialize, trimesh.cpp:789-870): per mesh header 0x041C + version, then a zlib
+    stream: flags, [name\\0 (v4)], u64 vertex count, u64 triangle count, positions, [normals], u32 indices; for several meshes
+    an offset dictionary at the end (u64 offsets in v4, u32 in v3) + u32 count."""
+    import struct, zlib
+    blob, offsets = b"", []
+    fl = "d" if double else "f"
+    for (pos, nrm, idx) in meshes:
+        offsets.append(len(blob))
+        flags = (0x2000 if double else 0x1000) | (0x0001 if nrm is not None else 0)
+        body = struct.pack("<I", flags) + (b"mesh\0" if version == 4 else b"") + struct.pack("<QQ", len(pos), len(idx))
+        body += struct.pack("<%d%s" % (3 * len(pos), fl), *np.asarray(pos, float).ravel())
+        if nrm is not None:
+            body += struct.pack("<%d%s" % (3 * len(pos), fl), *np.asarray(nrm, float).ravel())
+        body += struct.pack("<%dI" % (3 * len(idx)), *np.asarray(idx, int).ravel())
+        blob += struct.pack("<HH", 0x041C, version) + zlib.compress(body)
+    if len(meshes) > 1:
+        blob += b"".join(struct.pack("<Q" if version == 4 else "<I", o) for o in offsets) + struct.pack("<I", len(meshes))
+    open(path, "wb").write(blob)
+
+
+def test_serialized_meshes(cli, tmp_path):
+    """`<shape type="serialized">` (serialized.cpp, TriMesh::loadCompressed): v3/v4, float/double, shapeIndex through the offset
+    dictionary, normals through the inverse transpose, the winding swap under a mirroring transform, computed normals."""
+    quad = ([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], None, [[0, 1, 2], [0, 2, 3]])
+    pyr_pos = [[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1], [0.5, 1, 0.5]]
+    pyr = (pyr_pos, None, [[0, 4, 1], [1, 4, 2], [2, 4, 3], [3, 4, 0]])
+    tilted = ([[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], [[0.6, 0, -0.8]] * 3, [[0, 2, 1]])
+    sh = lambda fn, extra="": scene_with(tmp_path, '<shape type="serialized"><string name="filename" value="%s"/>%s</shape>' % (fn, extra) + LIGHT)
+    for version, dbl in ((3, False), (4, False), (4, True)):
+        fn = str(tmp_path / ("m%d%d.serialized" % (version, dbl)))
+        _write_serialized(fn, [quad, pyr, tilted], version, dbl)
+        d0 = json.loads(run(cli, "--parse-only", sh(fn)).stdout)
+        assert d0["triangles"] == 2 + 2 and d0["smoothTriangles"] == 0 and d0["firstVertex"] == [0, 0, 0]     # shape 0: the planar quad (+ the light)
+        d1 = json.loads(run(cli, "--parse-only", sh(fn, '<integer name="shapeIndex" value="1"/>')).stdout)
+        assert d1["triangles"] == 4 + 2 and d1["smoothTriangles"] == 4                                        # pyramid: angle-weighted vertex normals
+        d1f = json.loads(run(cli, "--parse-only", sh(fn, '<integer name="shapeIndex" value="1"/><boolean name="faceNormals" value="true"/>')).stdout)
+        assert d1f["smoothTriangles"] == 0
+        d2 = json.loads(run(cli, "--parse-only", sh(fn, '<integer name="shapeIndex" value="2"/><transform name="toWorld"><scale x="2"/></transform>')).stdout)
+        n = np.array([0.3, 0, -0.8]); n /= np.linalg.norm(n)
+        assert d2["smoothTriangles"] == 1 and np.allclose(d2["firstNormal"], n, atol=1e-6)
+        d2m = json.loads(run(cli, "--parse-only", sh(fn, '<integer name="shapeIndex" value="2"/><transform name="toWorld"><scale x="-1"/></transform>')).stdout)
+        assert d2m["firstVertex"] == [-0.5, 1, 0]                         # mirrored: the first two vertices of the triangle are swapped
+        r = run(cli, "--parse-only", sh(fn, '<integer name="shapeIndex" value="7"/>'))
+        assert r.returncode == 1 and "out of range" in r.stderr
+    for blob, needle in ((b"\x34\x12\x04\x00garbage", "invalid file format"), (b"\x04\x1c\x04\x00garbage", "old version of Mitsuba"),
+                         (b"\x1c\x04\x09\x00garbage", "incompatible file version"), (b"\x1c\x04\x04\x00garbage", "corrupt")):
+        bad = str(tmp_path / "bad.serialized"); open(bad, "wb").write(blob)
+        r = run(cli, "--parse-only", sh(bad)); assert r.returncode == 1 and needle in r.stderr, r.stderr
+
+
 @pytest.mark.parametrize("body,film,needle", [
     ('<shape type="sphere"/>' + LIGHT, None, "shape \"sphere\" is not carried"),
     ('<shape type="rectangle"><bsdf type="plastic"/></shape>' + LIGHT, None, "not carried"),
