@@ -192,6 +192,7 @@ struct gdpt_scene {
     int device = 0;
     int bvhDepth = 0;
     int numCUs = 256;
+    bool specialEmitters = false;   // an environment or point emitter: the ENV builds of the render kernel
     size_t ldsSceneBytes = 0;
 };
 
@@ -254,6 +255,7 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
 
     std::vector<int> emitterOf(numTris, -1);
     for (int e = 0; e < numEmitters; e++) {
+        if (emitters[e].numTris == -1) continue;              // a `point` emitter: no triangles
         if (emitters[e].firstTri < 0 || emitters[e].numTris <= 0 || emitters[e].firstTri + emitters[e].numTris > numTris)
             return tfail(GDPT_ERR_INVALID, "emitter %d triangle range out of bounds", e);
         for (int i = 0; i < emitters[e].numTris; i++) emitterOf[emitters[e].firstTri + i] = (envIndex >= 0 && e >= envIndex) ? e + 1 : e;   // index in the scene's emitter list
@@ -312,6 +314,7 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
 
     // emitters: DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h:95-108), scene-level emitter pdf (scene.cpp:357-380)
     const int totalEmitters = numEmitters + (env ? 1 : 0);
+    bool hasPoint = false;
     std::vector<EmitterD> ems(totalEmitters);
     std::vector<EmTri> emTris;
     std::vector<double> emCdf, sceneCdf(1, 0.0);
@@ -321,11 +324,20 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
             o.firstEmTri = 0; o.numTris = 0; o.cdfOffset = 0; o.pad = 0;
             o.radiance = to_d3(h3(env->radiance[0], env->radiance[1], env->radiance[2]));
             o.invSurfaceArea = 0.0;
+            o.position = to_d3(h3(0.0, 0.0, 0.0)); o.pad2 = 0.0;
             sceneCdf.push_back(sceneCdf.back() + 1.0);
             continue;
         }
         o.firstEmTri = (int)emTris.size(); o.numTris = emitters[e].numTris; o.cdfOffset = (int)emCdf.size(); o.pad = 0;
         o.radiance = to_d3(h3(emitters[e].radiance[0], emitters[e].radiance[1], emitters[e].radiance[2]));
+        o.position = to_d3(h3(emitters[e].position[0], emitters[e].position[1], emitters[e].position[2])); o.pad2 = 0.0;
+        if (o.numTris == -1) {                                // `point` emitter (src/emitters/point.cpp): sampled, never hit
+            o.invSurfaceArea = 0.0;
+            hasPoint = true;
+            sceneCdf.push_back(sceneCdf.back() + 1.0);
+            e++;
+            continue;
+        }
         std::vector<double> cdf(1, 0.0);
         for (int i = 0; i < o.numTris; i++) {
             const int t = emitters[e].firstTri + i;
@@ -364,6 +376,7 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
     d.vn = nullptr;
     if (!vn.empty()) { TriNormals *dvn; if ((rc = upload(&dvn, vn))) { gdpt_scene_destroy(s); return rc; } s->allocs.push_back(dvn); d.vn = dvn; }
     d.envIndex = envIndex;
+    s->specialEmitters = env != nullptr || hasPoint;
     if (env) {
         // ConstantBackgroundEmitter::createShape (constant.cpp:67-70): bounding sphere of Scene::getAABB() at that moment = the
         // kd-tree's AABB (enlarged by MTS_KD_AABB_EPSILON, gkdtree.h:1213-1219 -- the second line sees the moved min) + the
@@ -527,11 +540,11 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         }
     }
 #define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
-    // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment emitter | + per-vertex normals (environment tested at run time)};
+    // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment / point emitters | + per-vertex normals (environment tested at run time)};
     // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { \
         if (s->d.vn)                { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, true);   else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
-        else if (s->d.envIndex >= 0) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, false); } \
+        else if (s->specialEmitters) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, false); } \
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
         c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);

@@ -99,10 +99,12 @@ struct MaterialD {           // 112 B (a multiple of 16: tables are staged into 
     Float alphaU, alphaV, pad2;
 };
 static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
-struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp)
+struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
     int firstEmTri, numTris, cdfOffset, pad;
-    d3 radiance;
+    d3 radiance;            // point: intensity
     Float invSurfaceArea;
+    d3 position;            // point emitters only
+    Float pad2;
 };
 struct EmTri { d3 p0, p1, p2; };
 static_assert(sizeof(EmitterD) % 16 == 0, "LDS staging copies 16-byte words");
@@ -671,7 +673,7 @@ __device__ __forceinline__ bool vertex_is_diffuse(const MaterialD &m, const Conf
 }
 
 // ---- emitters -----------------------------------------------------------------------------------------------
-struct DRec { d3 ref, refN, p, n, d; Float dist, pdf; int object; };
+struct DRec { d3 ref, refN, p, n, d; Float dist, pdf; int object; int offSurfaceDiscrete; };   // last: a `point` emitter was sampled (measure EDiscrete, not EOnSurface)
 
 __device__ __forceinline__ int cdf_sample(const Float *cdf, int n /*entries = n+1*/, Float v)
 { // DiscreteDistribution::sample, pmf.h:110-123: lower_bound, step back one, skip zero-probability entries
@@ -762,8 +764,19 @@ __device__ d3 sample_emitter_direct(const SceneD &S, const SceneView &V, DRec &d
     sx = (sx - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
     const EmitterD em = V.emitters[index];
     d3 value;
+    dRec.offSurfaceDiscrete = 0;
     if (ENV && em.numTris == 0) {
         value = env_sample_direct(S, em.radiance, dRec, sx, sy);
+    } else if (ENV && em.numTris < 0) {                       // PointEmitter::sampleDirect, point.cpp:120-134
+        dRec.p = em.position;
+        dRec.pdf = 1.0;
+        dRec.offSurfaceDiscrete = 1;
+        dRec.d = dRec.p - dRec.ref;
+        dRec.dist = len(dRec.d);
+        const Float invDist = 1.0 / dRec.dist;
+        dRec.d = dRec.d * invDist;
+        dRec.n = mk(0.0);
+        value = em.radiance * (invDist * invDist);
     } else {
         const Float *cdf = S.emCdf + em.cdfOffset;
         const int ti = cdf_sample(cdf, em.numTris, sy);

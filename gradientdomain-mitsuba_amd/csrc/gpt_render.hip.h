@@ -130,7 +130,8 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         d3 mainBSDFValue;
         Float mainBsdfPdfRaw;
         bsdf_eval_pdf(mainBSDF, mainWi, mainWoL, MEASURE_SOLID_ANGLE, mainBSDFValue, mainBsdfPdfRaw);   // :588
-        const Float mainBsdfPdf = mainEmitterVisible ? mainBsdfPdfRaw : 0;       // :592
+        const bool lightOnSurfaceSA = !(ENV && dRec.offSurfaceDiscrete);          // emitter->isOnSurface() && dRec.measure == ESolidAngle
+        const Float mainBsdfPdf = (lightOnSurfaceSA && mainEmitterVisible) ? mainBsdfPdfRaw : 0;       // :592
         const Float mainDistanceSquared = len2(L.v.p - dRec.p);
         const Float mainOpposingCosine = dot(dRec.n, (L.v.p - dRec.p)) / sqrt(mainDistanceSquared);
         const Float mainWeightNumerator = L.pdf * dRec.pdf;                      // :599-600
@@ -155,7 +156,7 @@ GDPT_OFFSET_LOOP
                         d3 f;
                         Float pdfRaw;
                         bsdf_eval_pdf(mainBSDF, toLocal(mfr, incoming), toLocal(mfr, dRec.d), MEASURE_SOLID_ANGLE, f, pdfRaw);
-                        const Float shiftedBsdfPdf = mainEmitterVisible ? pdfRaw : 0;
+                        const Float shiftedBsdfPdf = (lightOnSurfaceSA && mainEmitterVisible) ? pdfRaw : 0;
                         const Float den = (s.pdf * s.pdf) * ((dRec.pdf * dRec.pdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                         weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                         shiftedContribution = 1.0 * s.throughput * (f * mainEmitterRadiance);
@@ -163,7 +164,7 @@ GDPT_OFFSET_LOOP
                     } else {                                                     // :659-705
                         const TriShade &sts = sv.shade[s.v.prim];
                         const MaterialD &shiftedBSDF = sv.mats[sts.material];
-                        if (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth)) {
+                        if (!lightOnSurfaceSA || (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth))) {   // mainAtPointLight || both diffuse, :667-672
                             const Shading ssh = shading_at<SMOOTH>(sv, s.v);
                             const Frame3 sfr = ssh.fr;
                             DRec sRec;
@@ -183,7 +184,7 @@ GDPT_OFFSET_LOOP
                                 d3 f;
                                 Float pdfRaw;
                                 bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
-                                const Float shiftedBsdfPdf = shiftedEmitterVisible ? pdfRaw : 0;
+                                const Float shiftedBsdfPdf = (lightOnSurfaceSA && shiftedEmitterVisible) ? pdfRaw : 0;
                                 const Float jacobian = fabs(shiftedOpposingCosine * mainDistanceSquared) / (GD_EPSILON + fabs(mainOpposingCosine * shiftedDistanceSquared)); // :695
                                 const Float den = (jacobian * s.pdf) * (jacobian * s.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                                 weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);

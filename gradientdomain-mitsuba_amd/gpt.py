@@ -24,7 +24,7 @@ class Material(C.Structure):
 
 
 class Emitter(C.Structure):
-    _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3)]
+    _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3), ("position", C.c_double * 3)]
 
 
 class Environment(C.Structure):
@@ -65,8 +65,11 @@ class Scene:
         tm = np.ascontiguousarray(desc.tri_material, dtype=np.int32)
         mats = (Material * len(desc.materials))(*[_material(m) for m in desc.materials])
         ems = (Emitter * max(1, len(desc.emitters)))()
-        for i, (f, n, rad) in enumerate(desc.emitters):
-            ems[i].firstTri, ems[i].numTris, ems[i].radiance = f, n, (C.c_double * 3)(*rad)
+        for i, em in enumerate(desc.emitters):                # (firstTri, numTris, radiance) or ("point", position, intensity)
+            if em[0] == "point":
+                ems[i].firstTri, ems[i].numTris, ems[i].position, ems[i].radiance = 0, -1, (C.c_double * 3)(*em[1]), (C.c_double * 3)(*em[2])
+            else:
+                ems[i].firstTri, ems[i].numTris, ems[i].radiance = em[0], em[1], (C.c_double * 3)(*em[2])
         cam = Camera()
         cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
         cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height

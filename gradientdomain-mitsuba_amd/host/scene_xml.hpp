@@ -5,7 +5,7 @@
 // (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
 // fileFormat="openexr"|"pfm") with <rfilter type="box|tent|gaussian|mitchell|catmullrom|lanczos"> (gaussian when absent, film.cpp:93), <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
 // shape), <shape type="obj|serialized|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
-// top-level <emitter type="constant"> (radiance),
+// top-level <emitter type="constant"> (radiance) and <emitter type="point"> (position | toWorld, intensity),
 // <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
 // Anything else raises std::runtime_error naming the tag or plugin, like the reference's "unsupported" errors.
 #pragma once
@@ -197,7 +197,25 @@ public:
             else if (n.tag == "bsdf") { const std::string id = n.get("id", ""); const int idx = bsdf(n, sd); if (!id.empty()) m_bsdfIds[id] = idx; }
             else if (n.tag == "shape") shape(n, sd);
             else if (n.tag == "emitter") {                                       // src/emitters/constant.cpp: the only top-level emitter carried
-                if (subst(n.get("type")) != "constant") logError(format("top-level emitter \"%s\" is not carried: `constant` (and `area` on shapes)", n.get("type").c_str()));
+                if (subst(n.get("type")) == "point") {                           // src/emitters/point.cpp
+                    gdpt_emitter e;
+                    std::memset(&e, 0, sizeof e);
+                    e.numTris = -1;
+                    double intensity[3] = {1.0, 1.0, 1.0};
+                    bool havePos = false, haveXf = false;
+                    for (auto &ec : n.children) {
+                        if ((ec->tag == "rgb" || ec->tag == "spectrum") && ec->get("name") == "intensity") rgb3(*ec, intensity);
+                        else if (ec->tag == "point" && ec->get("name") == "position") { e.position[0] = std::atof(subst(ec->get("x", "0")).c_str()); e.position[1] = std::atof(subst(ec->get("y", "0")).c_str()); e.position[2] = std::atof(subst(ec->get("z", "0")).c_str()); havePos = true; }
+                        else if (ec->tag == "transform" && ec->get("name") == "toWorld") { const Mat4 T = transform(*ec); const double o[3] = {0, 0, 0}; T.point(o, e.position); haveXf = true; }
+                        else if (ec->tag == "float" && ec->get("name") == "samplingWeight") { if (std::atof(subst(ec->get("value")).c_str()) != 1.0) logError("emitter \"point\": samplingWeight other than 1 is not carried"); }
+                        else logError(format("emitter \"point\": <%s name=\"%s\"> is not carried", ec->tag.c_str(), ec->get("name", "").c_str()));
+                    }
+                    if (havePos && haveXf) logError("Only one of the parameters 'position' and 'toWorld' can be used!'");          // point.cpp:61-63
+                    for (int k = 0; k < 3; ++k) e.radiance[k] = intensity[k];
+                    sd.emitters.push_back(e);
+                    continue;
+                }
+                if (subst(n.get("type")) != "constant") logError(format("top-level emitter \"%s\" is not carried: `constant`, `point` (and `area` on shapes)", n.get("type").c_str()));
                 if (sd.hasEnvironment) logError("Only one environment emitter can be used at a time!");          // scene.cpp: addChild
                 double radiance[3] = {1.0, 1.0, 1.0};                            // constant.cpp:44: default radiance = D65 white
                 for (auto &ec : n.children) {
@@ -512,6 +530,7 @@ private:
         } else logError(format("shape \"%s\" is not carried: obj, serialized, rectangle, cube", type.c_str()));
         if (emits) {
             gdpt_emitter e;
+            std::memset(&e, 0, sizeof e);
             e.firstTri = first; e.numTris = sd.numTriangles() - first;
             for (int k = 0; k < 3; ++k) e.radiance[k] = radiance[k];
             sd.emitters.push_back(e);

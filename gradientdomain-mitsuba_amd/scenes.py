@@ -67,7 +67,7 @@ class Scene:
     verts: np.ndarray            # (ntri, 9) float64
     tri_material: np.ndarray     # (ntri,) int32
     materials: list
-    emitters: list               # [(firstTri, numTris, (r,g,b))]
+    emitters: list               # [(firstTri, numTris, (r,g,b))] area lights and [("point", (x,y,z), (r,g,b) intensity)], in scene order
     to_world: np.ndarray         # 4x4 camera-to-world
     fov_x: float
     near: float = 1e-2
@@ -177,7 +177,7 @@ def _random_material(rng):
     return m
 
 
-def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=None):
+def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=None, point_light=None):
     """The Cornell box (Cornell Program of Computer Graphics measurement data, 555-unit room), all triangle meshes:
     5 walls, short block, tall block, one area-light quad.  variant: "diffuse" (BASELINE configs 1-2) |
     "glossy" (rough-copper floor, mirror back wall, GGX block: exercises the half-vector shift) | "nearspecular"."""
@@ -232,6 +232,9 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
                                                             # wide film crops the square original top and bottom and every pixel sees the box
     sc = b.finish(to_world=lookat((278, 273, -800), (278, 273, -799), (0, 1, 0)), fov_x=fov, near=10.0, far=2800.0,
                   width=width, height=height, name="cornell-" + variant)
+    if point_light is not None:        # ((x, y, z), (r, g, b) intensity[, first]): a `point` emitter after (or before) the area light
+        pl = ("point", tuple(float(c) for c in point_light[0]), tuple(float(c) for c in point_light[1]))
+        sc.emitters = [pl] + sc.emitters if len(point_light) > 2 and point_light[2] else sc.emitters + [pl]
     if environment is not None:        # a constant environment emitter seen through the open front and in the wide film's margins
         sc.environment = (tuple(float(v) for v in environment), 0 if variant == "random" and seed % 2 else len(sc.emitters))
     return sc

@@ -43,9 +43,10 @@ typedef struct gdpt_material {
     double alphaU, alphaV;  /* roughconductor `alpha` / `alphaU`,`alphaV`                        */
 } gdpt_material;
 
-typedef struct gdpt_emitter {   /* an `area` emitter attached to one mesh (src/emitters/area.cpp) */
-    int    firstTri, numTris;   /* that mesh's triangles, contiguous in the soup                  */
-    double radiance[3];
+typedef struct gdpt_emitter {   /* an `area` emitter attached to one mesh (src/emitters/area.cpp), or a `point` emitter (point.cpp) */
+    int    firstTri, numTris;   /* area: that mesh's triangles, contiguous in the soup; point: numTris = -1                  */
+    double radiance[3];         /* area: radiance; point: intensity                                                           */
+    double position[3];         /* point emitters only (the `position` / translation of `toWorld`)                          */
 } gdpt_emitter;
 
 typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters/constant.cpp): uniform radiance from all directions */

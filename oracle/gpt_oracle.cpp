@@ -141,8 +141,9 @@ typedef struct gpo_material {
 } gpo_material;
 
 typedef struct gpo_emitter {
-    int firstTri, numTris; // the triangles of the emissive mesh (contiguous)
-    double radiance[3];
+    int firstTri, numTris; // the triangles of the emissive mesh (contiguous); numTris == -1: a `point` emitter (src/emitters/point.cpp)
+    double radiance[3];    // area: radiance; point: intensity
+    double position[3];    // point emitters only
 } gpo_emitter;
 
 typedef struct gpo_camera {
@@ -178,8 +179,10 @@ struct Tri {
 };
 
 struct Emitter {
-    int firstTri, numTris;      // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp)
+    int firstTri, numTris;      // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
     V3 radiance;
+    V3 position;
+    bool onSurface() const { return numTris >= 0; }   // Emitter::isOnSurface: area and constant set EOnSurface, point does not
     std::vector<Float> cdf; // DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h)
     Float invSurfaceArea;
 };
@@ -993,6 +996,16 @@ V3 sampleEmitterDirectVisible(const Scene &sc, DirectSamplingRecord &dRec, Float
     V3 value;
     if (em.numTris == 0) {
         value = envSampleDirect(sc, em, dRec, sx, sy);
+    } else if (em.numTris < 0) {                                   // PointEmitter::sampleDirect, point.cpp:120-134
+        dRec.p = em.position;
+        dRec.pdf = 1.0;
+        dRec.measure = MEASURE_DISCRETE;
+        dRec.d = dRec.p - dRec.ref;
+        dRec.dist = length(dRec.d);
+        Float invDist = 1.0 / dRec.dist;
+        dRec.d = dRec.d * invDist;
+        dRec.n = V3(0.0);
+        value = em.radiance * (invDist * invDist);
     } else {
     // TriMesh::samplePosition
     {
@@ -1036,6 +1049,7 @@ Float pdfEmitterDirect(const Scene &sc, const DirectSamplingRecord &dRec)
     const Emitter &em = sc.emitters[dRec.object];
     Float pd = 0.0;
     if (em.numTris == 0) pd = envPdfDirect(dRec);
+    else if (em.numTris < 0) pd = dRec.measure == MEASURE_DISCRETE ? 1.0 : 0.0;   // point.cpp:136-138
     else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
         Float pdfPos = em.invSurfaceArea;
         if (dRec.measure == MEASURE_SOLID_ANGLE) pd = pdfPos * (dRec.dist * dRec.dist) / std::abs(dot(dRec.d, dRec.n));
@@ -1215,7 +1229,8 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
             V3 mainEmitterRadiance = value * dRec.pdf;                                     // :575
             const V3 mainWoL = main.its.sh.toLocal(dRec.d);
             V3 mainBSDFValue = bsdfEval(mainBSDF, main.its.wi, mainWoL, MEASURE_SOLID_ANGLE); // :588
-            Float mainBsdfPdf = (dRec.measure == MEASURE_SOLID_ANGLE && mainEmitterVisible) ? bsdfPdf(mainBSDF, main.its.wi, mainWoL, MEASURE_SOLID_ANGLE) : 0; // :592
+            const bool emitterOnSurface = sc.emitters[dRec.object].onSurface();
+            Float mainBsdfPdf = (emitterOnSurface && dRec.measure == MEASURE_SOLID_ANGLE && mainEmitterVisible) ? bsdfPdf(mainBSDF, main.its.wi, mainWoL, MEASURE_SOLID_ANGLE) : 0; // :592
             Float mainDistanceSquared = lengthSquared(main.its.p - dRec.p);
             Float mainOpposingCosine = dot(dRec.n, (main.its.p - dRec.p)) / std::sqrt(mainDistanceSquared);
             Float mainWeightNumerator = main.pdf * dRec.pdf;                               // :599
@@ -1236,7 +1251,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                         } else if (shifted.connection_status == RAY_RECENTLY_CONNECTED) {  // :638-658
                             V3 incomingDirection = normalize(shifted.its.p - main.its.p);
                             V3 wiL = main.its.sh.toLocal(incomingDirection), woL = main.its.sh.toLocal(dRec.d);
-                            Float shiftedBsdfPdf = (dRec.measure == MEASURE_SOLID_ANGLE && mainEmitterVisible) ? bsdfPdf(mainBSDF, wiL, woL, MEASURE_SOLID_ANGLE) : 0;
+                            Float shiftedBsdfPdf = (emitterOnSurface && dRec.measure == MEASURE_SOLID_ANGLE && mainEmitterVisible) ? bsdfPdf(mainBSDF, wiL, woL, MEASURE_SOLID_ANGLE) : 0;
                             Float shiftedDRecPdf = dRec.pdf;
                             V3 shiftedBsdfValue = bsdfEval(mainBSDF, wiL, woL, MEASURE_SOLID_ANGLE);
                             Float jacobian = 1;
@@ -1248,7 +1263,8 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             const gpo_material &shiftedBSDF = matOf(sc, shifted.its);
                             VertexType mainVertexType = getVertexType(mainBSDF, cfg, ESmooth);
                             VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, ESmooth);
-                            if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE) { // area lights are never EDiscrete
+                            const bool mainAtPointLight = (dRec.measure == MEASURE_DISCRETE);                        // :667
+                            if (mainAtPointLight || (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE)) {
                                 DirectSamplingRecord shiftedDRec;
                                 shiftedDRec.ref = shifted.its.p; shiftedDRec.refN = refNormal(shiftedBSDF, shifted.its);
                                 bool shiftedEmitterVisible;
@@ -1263,7 +1279,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                                     shiftSuccessful = false;
                                 } else {
                                     V3 shiftedBsdfValue = bsdfEval(shiftedBSDF, shifted.its.wi, woL, MEASURE_SOLID_ANGLE);
-                                    Float shiftedBsdfPdf = (dRec.measure == MEASURE_SOLID_ANGLE && shiftedEmitterVisible) ? bsdfPdf(shiftedBSDF, shifted.its.wi, woL, MEASURE_SOLID_ANGLE) : 0;
+                                    Float shiftedBsdfPdf = (emitterOnSurface && dRec.measure == MEASURE_SOLID_ANGLE && shiftedEmitterVisible) ? bsdfPdf(shiftedBSDF, shifted.its.wi, woL, MEASURE_SOLID_ANGLE) : 0;   // :693
                                     Float jacobian = std::abs(shiftedOpposingCosine * mainDistanceSquared) / (Epsilon + std::abs(mainOpposingCosine * shiftedDistanceSquared)); // :695 (Epsilon, not D_EPSILON)
                                     Float shiftedWeightDenominator = (jacobian * shifted.pdf) * (jacobian * shifted.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                                     weight = mainWeightNumerator / (D_EPSILON + shiftedWeightDenominator + mainWeightDenominator);
@@ -1630,6 +1646,8 @@ GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *tr
         Emitter em;
         em.firstTri = emitters[e].firstTri; em.numTris = emitters[e].numTris;
         em.radiance = V3(emitters[e].radiance[0], emitters[e].radiance[1], emitters[e].radiance[2]);
+        em.position = V3(emitters[e].position[0], emitters[e].position[1], emitters[e].position[2]);
+        if (em.numTris < 0) { em.firstTri = 0; em.invSurfaceArea = 0; sc.emitters.push_back(em); sc.emitterPDF.append(1.0); continue; }
         Distribution d;
         for (int i = 0; i < em.numTris; ++i) {
             const Tri &t = sc.tris[em.firstTri + i];
@@ -1812,7 +1830,7 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
                 if (vis && dRec.pdf > 0) {
                     V3 woL = its.sh.toLocal(dRec.d);
                     V3 f = bsdfEval(m, its.wi, woL, MEASURE_SOLID_ANGLE);
-                    Float pb = bsdfPdf(m, its.wi, woL, MEASURE_SOLID_ANGLE);
+                    Float pb = (sc.emitters[dRec.object].onSurface() && dRec.measure == MEASURE_SOLID_ANGLE) ? bsdfPdf(m, its.wi, woL, MEASURE_SOLID_ANGLE) : 0.0;   // a point light cannot be hit by BSDF sampling
                     Float wgt = (dRec.pdf * dRec.pdf) / (dRec.pdf * dRec.pdf + pb * pb);
                     L = L + beta * f * val * wgt;
                 }

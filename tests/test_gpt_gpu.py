@@ -156,6 +156,34 @@ def test_vertex_normals_on_emitters_are_refused(G):
         go.Scene(sc)
 
 
+@pytest.mark.parametrize("variant,md,strict,first,only", [("diffuse", 6, False, False, False), ("glossy", 8, False, True, False), ("glass", 9, True, False, False), ("diffuse", 5, False, False, True)])
+def test_point_emitter_samples_and_film_match_oracle(G, variant, md, strict, first, only):
+    """`<emitter type="point">` (point.cpp): EDiscrete light samples, no BSDF-sampling pdf against them (not EOnSurface), and the
+    mainAtPointLight branch of the unconnected light-sample shift (gpt.cpp:667-672) also at glossy vertices."""
+    W, H, spp = 40, 28, 4
+    sc = scenes.cornell_box(W, H, variant, point_light=((278, 420, 279.5), (3e5, 2.5e5, 2e5), first))
+    if only:
+        sc.emitters = [e for e in sc.emitters if e[0] == "point"]
+    S = G.Scene(sc); O = go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict)
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=md, spp=spp, strictNormals=strict)
+    rng = np.random.default_rng(3)
+    for _ in range(120):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g = S.evaluate_point(cfg, px, py, s); o = O.evaluate_point(ocfg, px, py, s)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-9, atol=1e-13), (variant, px, py, s, key, g[key], o[key])
+    F = G.Film(S)
+    integ.renderBlock(S, F, cfg, (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    oacc, orays = O.render(ocfg)
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (variant, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    assert np.abs(oacc[1][..., :3]).max() > 0
+    F.close(); S.close(); O.close()
+
+
 def test_environment_only_scene_and_emitter_order(G):
     """No area light at all (the environment is the only emitter), and the environment first in the emitter list."""
     W, H, spp = 36, 24, 4

@@ -89,6 +89,10 @@ def test_transforms_compose_in_document_order(cli, tmp_path):
     assert json.loads(run(cli, "--parse-only", s).stdout)["environment"] == [0.5, 0.75, 1, 0]
     s = scene_with(tmp_path, LIGHT + '<shape type="rectangle"/><emitter type="constant"/>')
     assert json.loads(run(cli, "--parse-only", s).stdout)["environment"] == [1, 1, 1, 1]
+    s = scene_with(tmp_path, '<emitter type="point"><point name="position" x="1" y="2" z="3"/><rgb name="intensity" value="5, 6, 7"/></emitter><shape type="rectangle"/>')
+    assert json.loads(run(cli, "--parse-only", s).stdout)["emitters"] == 1               # a point light alone is a valid scene
+    s = scene_with(tmp_path, '<emitter type="point"><point name="position" x="1" y="2" z="3"/><transform name="toWorld"><translate x="1"/></transform></emitter><shape type="rectangle"/>')
+    r = run(cli, "--parse-only", s); assert r.returncode == 1 and "Only one of the parameters" in r.stderr
     s = scene_with(tmp_path, '<shape type="rectangle"/><emitter type="constant"/>')          # the environment alone lights the scene
     assert json.loads(run(cli, "--parse-only", s).stdout)["emitters"] == 0
 
