@@ -144,17 +144,11 @@ def main():
 
     desc = scenes.cornell_box(W, H, "diffuse") if SCENE == "cornell" else scenes.atrium(W, H)
     scene = gpt.Scene(desc, device=local)
-    strips = parallel.row_strips(H, world)
-    y0, y1 = strips[rank]
-    film = gpt.Film(scene, y0, y1)
-    integ = gpt.GradientPathIntegrator(maxDepth=MAX_DEPTH, reconstructL1=False, reconstructL2=True)
-    cfg = integ.config(a.spp)
+    integ = gpt.GradientPathIntegrator(maxDepth=MAX_DEPTH, reconstructL1=(PRESET == "L1D"), reconstructL2=(PRESET != "L1D"))
     prm = P.Params(PRESET, integ.reconstructAlpha)
     iters = prm.irlsIterMax * prm.cgIterMax
-    solver = P.Solver(prm) if rank == 0 else None
-    rows = y1 - y0
-    strip_imgs = torch.empty((4, rows, W, 3), dtype=torch.float32, device=dev)     # throughput, dx, dy, direct of this strip
-    rec = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    # the product's multi-GPU render: strips, halo exchange, gather, reconstruction on rank 0 (parallel.StripRenderer)
+    sr = parallel.StripRenderer(scene, integ, rank, world, dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -164,43 +158,15 @@ def main():
 
     def step():
         """-> (rays of this rank, render kernel ms, solve seconds, halo bytes)"""
-        nonlocal film, strip_imgs, strips, y0, y1
-        film.clear()
-        integ.renderBlock(scene, film, cfg, (0, y0, W, y1))                      # GPTBlockRenderer::process over the strip
-        film.sync()
-        halo = parallel.exchange_halos(film, rank, world, dev)
-        for i, b in enumerate((gpt.BUFFER_THROUGHPUT, gpt.BUFFER_DX, gpt.BUFFER_DY, gpt.BUFFER_VERY_DIRECT)):
-            film.develop_device(b, strip_imgs[i])                                 # developMulti + float cast, gpt.cpp:1419-1442
-        full = parallel.gather_rows(strip_imgs, strips, W, rank, world)           # one message per rank for the four images
-        solve_s = 0.0
-        if rank == 0:
-            solver.importImagesMTS(full[1], full[2], full[0], full[3], W, H)      # dx, dy, throughput, direct
-            solver.setupBackend()
-            solver.solveIndirect()
-            solver.exportImagesMTS(rec)
-            solve_s = solver.lastSolveSeconds
-        st = film.stats()
-        return st["raysTraced"] + st["shadowRaysTraced"], film.render_ms(), solve_s, halo
-
-    def make_strip(y0_, y1_):
-        f = gpt.Film(scene, y0_, y1_)
-        imgs = torch.empty((4, y1_ - y0_, W, 3), dtype=torch.float32, device=dev)
-        return f, imgs
+        sr.render(a.spp)
+        return sr.last["rays"], sr.last["render_ms"], sr.last["solve_s"], sr.last["halo_bytes"]
 
     for _ in range(a.warmup):
-        _, ms, _, _ = step()
+        step()
         if world > 1 and not a.no_rebalance:
             # the reference hands blocks to whichever worker is free; with one strip per GPU the analogue is to move the strip
             # boundaries by the render times of the warm-up pass (same total image; untimed)
-            tms = torch.tensor([ms], dtype=torch.float64, device=dev)
-            allms = [torch.zeros_like(tms) for _ in range(world)]
-            dist.all_gather(allms, tms)
-            new = parallel.rebalance_strips(strips, [float(v.item()) for v in allms], min_rows=2)
-            if new != strips:
-                strips = new
-                y0, y1 = strips[rank]
-                film.close()
-                film, strip_imgs = make_strip(y0, y1)
+            sr.rebalance(min_rows=2)
     barrier()
     t0 = time.perf_counter()
     rays = 0
@@ -222,6 +188,7 @@ def main():
     if rank == 0:
         mray = rays / wall / 1e6
         mpix_iter = W * H * iters * a.steps / solve_s / 1e6
+        solver, film, strips = sr.solver, sr.film, sr.strips
         kus = solver.profileKernels(50)
         pus = solver.profilePersistent(20)
         bpi = BYTES_PER_PIX_ITER[PRESET]
@@ -273,9 +240,7 @@ def main():
         if not a.no_cpu_baseline and a.config == 2 and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)
         print(json.dumps(out))
-    if solver:
-        solver.close()
-    film.close(); scene.close()
+    sr.close(); scene.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -435,7 +435,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     FilmD &d = f->d;
     d.recExtra = nullptr;
     d.fValues = nullptr; d.fRadius = 0.0; d.fScale = 0.0;       // box filter
-    d.log = nullptr; d.logChunk = 0;
+    d.log = nullptr; d.logChunk = 0; d.logY0 = 0; d.logRows = 0;
     d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
     d.recStride = (size_t)d.recRows * W;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
@@ -491,6 +491,11 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
     c.regenMin = f->regenMin;
+    if (f->d.fValues) {
+        // a reconstruction filter wider than box: the launch covers the film's rows plus the filter's reach (the log's rows)
+        if (x0 != 0 || x1 != f->d.W || y0 != f->d.y0 || y1 != f->d.y1) return tfail(GDPT_ERR_UNSUPPORTED, "with a reconstruction filter wider than box the rectangle must be the whole film");
+        y0 = f->d.logY0; y1 = f->d.logY0 + f->d.logRows;
+    }
     const int tilesX = (x1 - x0 + 15) / 16, tilesY = (y1 - y0 + 15) / 16;
     hipEvent_t e0, e1;
     THIPCHK(hipEventCreate(&e0));
@@ -529,13 +534,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // A reconstruction filter wider than box: samples are rendered in chunks into the sample log and gathered after each chunk
     int chunk = cfg->spp;
     if (f->d.fValues) {
-        if (x0 != 0 || x1 != f->d.W || y0 != f->d.y0 || y1 != f->d.y1) return tfail(GDPT_ERR_UNSUPPORTED, "with a reconstruction filter wider than box the rectangle must be the whole film");
         chunk = std::min(cfg->spp, LOG_CHUNK);
         if (f->d.logChunk < chunk) {
             THIPCHK(hipStreamSynchronize(f->stream));
             if (f->d.log) hipFree(f->d.log);
             f->d.log = nullptr; f->d.logChunk = 0;
-            if (hipMalloc((void **)&f->d.log, sizeof(Float) * 32 * (size_t)chunk * f->d.H * f->d.W) != hipSuccess) return tfail(GDPT_ERR_HIP, "Out of memory!");
+            if (hipMalloc((void **)&f->d.log, sizeof(Float) * 32 * (size_t)chunk * f->d.logRows * f->d.W) != hipSuccess) return tfail(GDPT_ERR_HIP, "Out of memory!");
             f->d.logChunk = chunk;
         }
     }
@@ -551,7 +555,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
         if (f->d.fValues)
-            hipLaunchKernelGGL(k_gather_log, dim3((f->d.W + 15) / 16, (f->d.H + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount);
+            hipLaunchKernelGGL(k_gather_log, dim3((f->d.W + 15) / 16, (f->d.y1 - f->d.y0 + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount);
     }
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
@@ -699,8 +703,6 @@ int gdpt_film_set_rfilter(gdpt_film *f, int kind, double p0, double p1)
         case GDPT_RFILTER_LANCZOS: if (!(p0 >= 1)) return tfail(GDPT_ERR_INVALID, "lanczos: lobes must be >= 1"); radius = p0; break;           // lanczos.cpp:35
         default: radius = 2.0; break;                                 // mitchell.cpp:35, catmullrom.cpp:32
     }
-    if (f->d.y0 != 0 || f->d.y1 != f->d.H)
-        return tfail(GDPT_ERR_UNSUPPORTED, "reconstruction filters wider than box need a film over all rows: the strip halo is one pixel (border %d needed)", 1 + (int)std::ceil(radius - 0.5));
     double v[32], sum = 0.0;
     for (int i = 0; i < 31; i++) { v[i] = rfilter_eval(kind, p0, p1, radius, (radius * i) / 31); sum += v[i]; }
     v[31] = 0.0;
@@ -711,6 +713,11 @@ int gdpt_film_set_rfilter(gdpt_film *f, int kind, double p0, double p1)
     THIPCHK(hipMalloc((void **)&dv, sizeof v));
     THIPCHK(hipMemcpy(dv, v, sizeof v, hipMemcpyHostToDevice));
     f->d.fValues = dv; f->d.fRadius = radius; f->d.fScale = 31 / radius;
+    // A strip renders the rows within the filter's reach of its own rows as well (k_gather_log's R), instead of receiving their samples:
+    // samples depend on (seed, pixel, sample index) only, so the strip's rows come out bit-identical to a whole-image film's.
+    const int reach = (int)std::ceil(radius) + 1;
+    f->d.logY0 = std::max(0, f->d.y0 - reach);
+    f->d.logRows = std::min(f->d.H, f->d.y1 + reach) - f->d.logY0;
     return GDPT_OK;
 }
 

@@ -144,8 +144,10 @@ struct FilmD {
     Float *spill;               // [5][recRows][W][4] exact generic puts (R,G,B,weight)
     const Float *fValues;       // nullptr: box filter (the fast path below); else the 32-entry table of ReconstructionFilter::configure
     Float fRadius, fScale;      // of that table (rfilter.cpp:37-55)
-    Float *log;                 // wider filters: sample log [32][logChunk][H][W] (30 sums, sx, sy of every sample of a chunk), gathered by k_gather_log
+    Float *log;                 // wider filters: sample log [32][logChunk][logRows][W] (30 sums, sx, sy of every sample of a chunk), gathered by k_gather_log
     int logChunk;
+    int logY0, logRows;         // the log covers the film's rows plus the filter's reach above and below (clipped to the image): a strip renders those rows
+                                // itself instead of receiving them, so its gathered rows are bit-identical to the same rows of a whole-image film
     unsigned long long *stats;  // [4]
     int W, H, y0, y1, recRows;
     size_t recStride;           // recRows * W

@@ -433,7 +433,7 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
     if (F.log) {
         // a reconstruction filter wider than box: no put here -- the sample's sums and position go to the log, and k_gather_log
         // evaluates every put from the side of the pixel that receives it (no atomics, a fixed order)
-        const size_t plane = (size_t)F.H * F.W, at = (size_t)logSlot * plane + (size_t)py * F.W + px, comp = (size_t)F.logChunk * plane;
+        const size_t plane = (size_t)F.logRows * F.W, at = (size_t)logSlot * plane + (size_t)(py - F.logY0) * F.W + px, comp = (size_t)F.logChunk * plane;
 #pragma unroll
         for (int k = 0; k < ACC_N; k++) F.log[(size_t)k * comp + at] = A.get(k);
         F.log[(size_t)30 * comp + at] = L.sx;
@@ -576,17 +576,17 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
 __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
 {
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
-    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= F.W || y >= F.H) return;
-    const int R = (int)ceil(F.fRadius) + 1;
-    const size_t plane = (size_t)F.H * F.W, comp = (size_t)F.logChunk * plane;
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = F.y0 + blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= F.W || y >= F.y1) return;
+    const int R = (int)ceil(F.fRadius) + 1;                 // (the host sizes logY0 / logRows with the same reach)
+    const size_t plane = (size_t)F.logRows * F.W, comp = (size_t)F.logChunk * plane;
     auto evalD = [&](Float d) -> Float { int idx = (int)fabs(d * F.fScale); if (idx > 31) idx = 31; return F.fValues[idx]; };
     Float o[5][4];
     for (int b = 0; b < 5; b++) for (int k = 0; k < 4; k++) o[b][k] = 0.0;
-    for (int yy = max(0, y - R); yy <= min(F.H - 1, y + R); yy++)
+    for (int yy = max(F.logY0, y - R); yy <= min(F.logY0 + F.logRows - 1, y + R); yy++)
         for (int xx = max(0, x - R); xx <= min(F.W - 1, x + R); xx++)
             for (int c = 0; c < count; c++) {
-                const size_t at = (size_t)c * plane + (size_t)yy * F.W + xx;
+                const size_t at = (size_t)c * plane + (size_t)(yy - F.logY0) * F.W + xx;
                 const Float sx = F.log[(size_t)30 * comp + at], sy = F.log[(size_t)31 * comp + at];
                 // distances of this pixel from the put positions (pos = sample - 0.5; neighbour puts one pixel away)
                 const Float dx0 = x - (sx - 0.5), dy0 = y - (sy - 0.5);

@@ -128,6 +128,7 @@ class Film:
         self.rows, self.width = self.y1 - self.y0, scene.width
         self._h = C.c_void_p()
         check(lib().gdpt_film_create(scene._h, self.y0, self.y1, C.byref(self._h)))
+        self.renders_own_border = False                      # True with a filter wider than box: no halo exchange between strips
         rf = getattr(scene.desc, "rfilter", None)
         if rf is not None:                                   # the scene description's <rfilter>
             self.set_rfilter(*rf)
@@ -177,6 +178,7 @@ class Film:
         """`<rfilter>` of the film (scenes.RFILTER_*); box is the default and the fast path."""
         lib().gdpt_film_set_rfilter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         check(lib().gdpt_film_set_rfilter(self._h, int(kind), float(p0), float(p1)))
+        self.renders_own_border = int(kind) != 0
 
     def set_slices(self, slices):
         """Sample slices per launch (0 = chosen per launch); a tuning knob, see include/gdpt_tracer.h."""

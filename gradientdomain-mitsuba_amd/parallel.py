@@ -7,6 +7,7 @@ rows; the only coupling is the one-pixel halo: a strip needs the per-pixel sampl
 (and passes on the exact-put spill it produced for its neighbours' rows).  That is two point-to-point messages per rank
 (<= 2 xGMI links, no collective on the data path).  Reconstruction runs on rank 0 after a gather of the four developed
 fp32 images (44 MB at 1280x720; the CG at this size is latency-bound and does not profit from splitting -- DESIGN.md).
+`StripRenderer` below is the entry point: one frame = render strip, settle borders, develop, gather, reconstruct on rank 0.
 """
 import torch
 import torch.distributed as dist
@@ -110,3 +111,99 @@ def gather_rows(strip, strips, width, rank, world, group=None):
         q.wait()
     _settle(strip)          # the library reuses the strip buffer on its own stream next step
     return None
+
+
+class StripRenderer:
+    """GradientPathIntegrator::render (/root/reference/src/integrators/gpt/gpt.cpp:1358-1480) over the ranks of a process group:
+    every rank renders its strip (GPTBlockRenderer::process), strips settle their borders, the four developed solver images
+    travel to rank 0 as one message per rank, and rank 0 reconstructs (`poisson::Solver`).
+
+    Borders: with the box filter a sample touches only its own pixel and the four neighbours, so the one-pixel halo sums are
+    exchanged and added (gpt_proc.cpp:52-56,137-149).  With a wider reconstruction filter (Mitsuba's film default is gaussian) a
+    strip's film renders the rows within the filter's reach itself (`gdpt_film_set_rfilter`), so nothing is exchanged and the
+    result is bit-identical to a one-GPU render; the price is 2 x reach redundant rows per strip.
+
+    scene, integ: gpt.Scene / gpt.GradientPathIntegrator (or test doubles with the same methods); film_factory(scene, y0, y1)
+    and solver_factory(preset, alpha) default to gpt.Film and poisson.Solver."""
+
+    def __init__(self, scene, integ, rank, world, device, group=None, strips=None, film_factory=None, solver_factory=None):
+        self.scene, self.integ, self.rank, self.world, self.device, self.group = scene, integ, rank, world, device, group
+        self.width, self.height = scene.width, scene.height
+        if film_factory is None:
+            from . import gpt
+            film_factory = gpt.Film
+        if solver_factory is None:
+            from . import poisson
+
+            def solver_factory(preset, alpha):
+                return poisson.Solver(poisson.Params(preset, alpha))
+        self._film_factory = film_factory
+        self.preset = "L1D" if getattr(integ, "reconstructL1", False) else ("L2D" if getattr(integ, "reconstructL2", False) else None)
+        self.solver = solver_factory(self.preset, integ.reconstructAlpha) if (rank == 0 and self.preset) else None
+        self.film = None
+        self.set_strips(strips or row_strips(self.height, world))
+        self.last = {}
+
+    def set_strips(self, strips):
+        """(Re)partition the image; every rank must pass the same list."""
+        assert len(strips) == self.world and strips[0][0] == 0 and strips[-1][1] == self.height
+        self.strips = list(strips)
+        self.y0, self.y1 = self.strips[self.rank]
+        if self.film is not None:
+            self.film.close()
+        self.film = self._film_factory(self.scene, self.y0, self.y1)
+        self.strip_imgs = torch.empty((4, self.y1 - self.y0, self.width, 3), dtype=torch.float32, device=self.device)
+        self.rec = torch.empty((self.height, self.width, 3), dtype=torch.float32, device=self.device) if self.rank == 0 else None
+
+    def rebalance(self, min_rows=2):
+        """Move the strip boundaries by the render-kernel times of the last render (collective).  Returns True if they moved."""
+        if self.world == 1:
+            return False
+        t = torch.tensor([self.last.get("render_ms", 0.0)], dtype=torch.float64, device=self.device)
+        allt = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(allt, t, group=self.group)
+        new = rebalance_strips(self.strips, [float(v.item()) for v in allt], min_rows=min_rows)
+        if new == self.strips:
+            return False
+        self.set_strips(new)
+        return True
+
+    def render(self, spp, seed=5489):
+        """One frame.  Rank 0 returns the reconstruction [H, W, 3] (device tensor; the primal image if the integrator does not
+        reconstruct) -- other ranks None.  self.last: rays, render_ms, solve_s, halo_bytes of this rank; on rank 0 also the four
+        gathered solver images under "images" ([4, H, W, 3]: throughput, dx, dy, direct)."""
+        film, integ = self.film, self.integ
+        cfg = integ.config(spp, seed)
+        film.clear()
+        integ.renderBlock(self.scene, film, cfg, (0, self.y0, self.width, self.y1))       # GPTBlockRenderer::process over the strip
+        film.sync()
+        halo = 0
+        if not getattr(film, "renders_own_border", False):
+            halo = exchange_halos(film, self.rank, self.world, self.device, self.group)
+        for i, b in enumerate((1, 2, 3, 4)):                                               # BUFFER_THROUGHPUT, DX, DY, VERY_DIRECT
+            film.develop_device(b, self.strip_imgs[i])                                     # developMulti + float cast, gpt.cpp:1419-1442
+        full = gather_rows(self.strip_imgs, self.strips, self.width, self.rank, self.world, self.group)
+        solve_s = 0.0
+        out = None
+        if self.rank == 0:
+            if self.solver is not None:
+                self.solver.importImagesMTS(full[1], full[2], full[0], full[3], self.width, self.height)   # dx, dy, throughput, direct
+                self.solver.setupBackend()
+                self.solver.solveIndirect()
+                self.solver.exportImagesMTS(self.rec)
+                solve_s = self.solver.lastSolveSeconds
+                out = self.rec
+            else:
+                out = full[0]
+        st = film.stats()
+        self.last = dict(rays=st["raysTraced"] + st["shadowRaysTraced"], render_ms=film.render_ms(), solve_s=solve_s, halo_bytes=halo,
+                         images=full if self.rank == 0 else None)
+        return out
+
+    def close(self):
+        if self.solver is not None:
+            self.solver.close()
+            self.solver = None
+        if self.film is not None:
+            self.film.close()
+            self.film = None

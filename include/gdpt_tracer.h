@@ -140,8 +140,10 @@ GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
 /* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/*.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
  * (default: every put covers one pixel, the per-pixel-sums fast path), TENT, GAUSSIAN (p0 = stddev, 0.5), MITCHELL (p0 = B, p1 = C,
  * 1/3 each), CATMULLROM, LANCZOS (p0 = lobes, 3).  The wider filters log every sample and gather the puts per receiving pixel
- * (no atomics; 1.3-2.3x the box render time); they need a film over all rows (one-pixel strip halo) and whole-film
- * rectangles.  Call before rendering. */
+ * (no atomics; 1.3-2.3x the box render time) and take whole-film rectangles only.  A film over a strip of rows then renders the
+ * rows within the filter's reach (ceil(radius) + 1 above and below, clipped to the image) as well, so that its own rows come
+ * out bit-identical to the same rows of a whole-image film and strips need no exchange (gdpt_film_stats counts those rays too).
+ * Call before rendering. */
 #define GDPT_RFILTER_BOX        0
 #define GDPT_RFILTER_TENT       1
 #define GDPT_RFILTER_GAUSSIAN   2

@@ -140,10 +140,36 @@ def test_reconstruction_filters_match_oracle(G, kind):
         assert np.abs(acc[b] - oacc[b]).max() <= 1e-10 * scale, (kind, G.BUFFER_NAMES[b])     # atomics: order of the fp64 sums is free
     box = scenes.cornell_box(W, H, "glossy")
     assert not np.allclose(go.Scene(box).render(go.config(maxDepth=5, spp=spp))[0][1], oacc[1])
-    F.close()
-    with pytest.raises(GdptError, match="all rows"):                  # strips keep a one-pixel halo
-        G.Film(S, 0, H // 2)
-    S.close()
+    # strips: each renders the rows within the filter's reach itself, so three strips side by side ARE the whole film, bit for bit,
+    # with no exchange (samples depend on seed, pixel and sample index only)
+    parts = []
+    for y0, y1 in ((0, 7), (7, 9), (9, H)):
+        Fs = G.Film(S, y0, y1)
+        integ.renderBlock(S, Fs, integ.config(spp), (0, y0, W, y1))
+        parts.append(Fs.accum())
+        with pytest.raises(GdptError, match="whole film"):
+            integ.renderBlock(S, Fs, integ.config(spp), (0, y0, W // 2, y1))
+        Fs.close()
+    assert np.array_equal(np.concatenate(parts, axis=1), acc)
+    F.close(); S.close()
+
+
+def test_filter_strips_over_several_log_chunks(G):
+    W, H, spp = 40, 30, 19                                  # 19 spp = two chunks of the sample log (16 + 3)
+    sc = scenes.cornell_box(W, H, "diffuse")
+    sc.rfilter = scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN]
+    S = G.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=4)
+    F = G.Film(S)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    whole = F.accum()
+    parts = []
+    for y0, y1 in ((0, 16), (16, H)):
+        Fs = G.Film(S, y0, y1)
+        integ.renderBlock(S, Fs, integ.config(spp), (0, y0, W, y1))
+        parts.append(Fs.accum()); Fs.close()
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+    F.close(); S.close()
 
 
 def test_vertex_normals_on_emitters_are_refused(G):
@@ -422,3 +448,25 @@ def test_full_size_properties_1280x720x64(G):
         px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
         g = S.evaluate_point(cfg, px, py, s); o = O.evaluate_point(go.config(maxDepth=-1, spp=spp), px, py, s)
         assert np.allclose(g["throughput"], o["throughput"], rtol=1e-10, atol=1e-14) and np.allclose(g["gradients"], o["gradients"], rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("kind", [0, 2])
+def test_strip_renderer_single_rank_equals_integrator_render(G, kind):
+    """parallel.StripRenderer (the multi-GPU entry, here with one rank) == GradientPathIntegrator.render, box and gaussian film."""
+    import torch
+    from gradientdomain_mitsuba_amd import parallel
+    W, H, spp = 48, 32, 4
+    sc = scenes.cornell_box(W, H, "glossy")
+    sc.rfilter = scenes.RFILTER_DEFAULTS[kind]
+    S = G.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=6, reconstructL1=False, reconstructL2=True)
+    ref = integ.render(S, spp)
+    sr = parallel.StripRenderer(S, integ, 0, 1, torch.device("cuda", 0))
+    out = sr.render(spp).cpu().numpy()
+    assert sr.film.renders_own_border == (kind != 0) and sr.last["halo_bytes"] == 0
+    assert np.array_equal(out, ref["-final"])
+    imgs = sr.last["images"].cpu().numpy()
+    for i, name in enumerate(("-throughput", "-dx", "-dy", "-direct")):
+        assert np.array_equal(imgs[i], ref[name])
+    assert sr.last["rays"] == integ.stats["raysTraced"] + integ.stats["shadowRaysTraced"]
+    sr.close(); S.close()

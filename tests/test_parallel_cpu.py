@@ -129,3 +129,151 @@ def test_rebalance_strips_equalises_cost():
     assert PP.rebalance_strips([(0, 1), (1, 2)], [1.0, 9.0]) == [(0, 1), (1, 2)]          # nothing to move
     assert PP.rebalance_strips([(0, 10)], [5.0]) == [(0, 10)]
     assert PP.rebalance_strips(PP.row_strips(16, 4), [0.0, 1.0, 1.0, 1.0]) == PP.row_strips(16, 4)   # no timing yet: unchanged
+
+
+# ---- parallel.StripRenderer over gloo with doubles of the film / integrator / solver -------------------------------------
+class _ToyScene:
+    def __init__(self, W, H):
+        self.width, self.height = W, H
+
+
+class _ToyFilm:
+    """Integer-valued double of gpt.Film: per-pixel sums that the developed image reads from the row above and below (the one-pixel
+    halo of rec) and splats that land on neighbouring rows (spill), so a strip is only right after the halo exchange."""
+    own_border = False
+
+    def __init__(self, scene, y0, y1):
+        self.W, self.H, self.y0, self.y1 = scene.width, scene.height, y0, y1
+        self.renders_own_border = self.own_border
+        self.clear()
+        self.exchanged = 0
+
+    def clear(self):
+        rows = self.y1 - self.y0 + 2
+        self.rec = np.zeros((NREC, rows, self.W)); self.spill = np.zeros((5, rows, self.W, 4))
+
+    def render(self, spp):
+        lo, hi = (max(0, self.y0 - 1), min(self.H, self.y1 + 1)) if self.own_border else (self.y0, self.y1)
+        for y in range(lo, hi):
+            x = np.arange(self.W)
+            if self.y0 <= y < self.y1 or self.own_border:
+                if self.y0 - 1 <= y <= self.y1:
+                    for k in range(NREC):
+                        self.rec[k, y - (self.y0 - 1)] = spp * ((k + 1) * 1000 + 7 * y + x)
+            for t in (y - 1, y, y + 1):
+                if 0 <= t < self.H and self.y0 - 1 <= t <= self.y1 and (not self.own_border or self.y0 <= t < self.y1):
+                    for b in range(5):
+                        self.spill[b, t - (self.y0 - 1), :, :] += (b + 1) * (3 * y + t) + x[:, None]
+
+    def sync(self):
+        pass
+
+    def halo_bytes(self):
+        self.exchanged += 1
+        return 8 * (NREC * self.W + 5 * self.W * 4)
+
+    pack_halo = FakeFilm.pack_halo
+    unpack_halo = FakeFilm.unpack_halo
+
+    def develop_device(self, b, t):
+        r = self.rec[b]
+        img = r[1:-1] + 2 * r[:-2] + 3 * r[2:]
+        t.copy_(torch.from_numpy((img[:, :, None] + self.spill[b, 1:-1, :, :3]).astype(np.float32)))
+
+    def stats(self):
+        return dict(raysTraced=10 * (self.y1 - self.y0), shadowRaysTraced=self.y1 - self.y0)
+
+    def render_ms(self):
+        return float((self.y1 - self.y0) * (1 + self.y0))        # later rows cost more: rebalance must move the boundary up
+
+    def close(self):
+        pass
+
+
+class _ToyFilmOwnBorder(_ToyFilm):
+    own_border = True
+
+
+class _ToyIntegrator:
+    reconstructL1, reconstructL2, reconstructAlpha = False, True, 0.2
+
+    def config(self, spp, seed=5489):
+        return spp
+
+    def renderBlock(self, scene, film, cfg, rect):
+        assert rect == (0, film.y0, scene.width, film.y1)
+        film.render(cfg)
+
+
+class _ToySolver:
+    lastSolveSeconds = 0.25
+
+    def importImagesMTS(self, dx, dy, tp, direct, w, h):
+        self.v = tp + 2 * dx - dy + 4 * direct
+
+    def setupBackend(self):
+        pass
+
+    def solveIndirect(self):
+        pass
+
+    def exportImagesMTS(self, rec):
+        rec.copy_(self.v)
+
+    def close(self):
+        pass
+
+
+def _toy_render(rank, world, W, H, film_cls, rebalance):
+    sr = parallel.StripRenderer(_ToyScene(W, H), _ToyIntegrator(), rank, world, torch.device("cpu"), film_factory=film_cls,
+                                solver_factory=lambda preset, alpha: _ToySolver())
+    assert sr.preset == "L2D"
+    out = sr.render(3)
+    moved = False
+    if rebalance:
+        moved = sr.rebalance(min_rows=2)
+        out = sr.render(3)
+    res = (None if out is None else out.numpy().copy(), sr.last["rays"], sr.last["halo_bytes"], sr.film.exchanged, list(sr.strips), moved)
+    sr.close()
+    return res
+
+
+def _strip_worker(rank, world, port, W, H, own_border, rebalance, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _toy_render(rank, world, W, H, _ToyFilmOwnBorder if own_border else _ToyFilm, rebalance))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,own_border,rebalance", [(2, False, False), (3, False, True), (2, True, False), (3, True, True)])
+def test_strip_renderer_equals_one_rank(world, own_border, rebalance):
+    """Strips + halo exchange (box filter) or strips that render their own border (wider filters) + gather + solve on rank 0
+    give exactly the one-rank image; rebalancing moves the boundaries and changes nothing in the image."""
+    W, H = 12, 19
+    whole = _toy_render(0, 1, W, H, _ToyFilmOwnBorder if own_border else _ToyFilm, False)[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, W, H, own_border, rebalance, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], whole)
+    assert all(res[r][0] is None for r in range(1, world))
+    assert sum(res[r][1] for r in range(world)) == 11 * H
+    for r in range(world):
+        img, rays, halo, exchanged, strips, moved = res[r]
+        assert strips == res[0][4] and moved == rebalance
+        if own_border:
+            assert halo == 0 and exchanged == 0                     # nothing exchanged: the strip rendered its border itself
+        else:
+            assert halo == 8 * (NREC * W + 20 * W) * ((r > 0) + (r < world - 1))
+    if rebalance:
+        assert res[0][4] != parallel.row_strips(H, world) and res[0][4][0][1] > parallel.row_strips(H, world)[0][1]
