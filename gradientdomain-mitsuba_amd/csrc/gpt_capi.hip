@@ -166,8 +166,8 @@ struct Builder {
         const Box bl = bounds_of(first, nl), br = bounds_of(first + nl, count - nl);
         BvhNode &n = nodes[me];
         for (int i = 0; i < 3; i++) {
-            n.lo[0][i] = round_down(bl.lo[i]); n.hi[0][i] = round_up(bl.hi[i]);
-            n.lo[1][i] = round_down(br.lo[i]); n.hi[1][i] = round_up(br.hi[i]);
+            n.b[0][i] = (f2){round_down(bl.lo[i]), round_up(bl.hi[i])};
+            n.b[1][i] = (f2){round_down(br.lo[i]), round_up(br.hi[i])};
         }
         n.child[0] = l; n.child[1] = r; n.pad[0] = n.pad[1] = 0;
         return (uint32_t)me;
@@ -373,6 +373,11 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = totalEmitters;
     d.rootRef = rootRef;
+    {   // error-bound scale of the fp32 slab test: the largest |coordinate| any node bound can hold
+        double m = 0.0;
+        for (int i = 0; i < numTris; i++) for (int a = 0; a < 3; a++) m = std::max(m, std::max(std::fabs(tb[i].lo[a]), std::fabs(tb[i].hi[a])));
+        d.boundM = round_up(m);
+    }
     d.vn = nullptr;
     if (!vn.empty()) { TriNormals *dvn; if ((rc = upload(&dvn, vn))) { gdpt_scene_destroy(s); return rc; } s->allocs.push_back(dvn); d.vn = dvn; }
     d.envIndex = envIndex;
@@ -552,8 +557,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
         c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);
+#ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 3): one build per scene kind */
+        if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH(true, true, 2, true, true); else GDPT_LAUNCH(true, false, 2, true, true); } else GDPT_LAUNCH(false, false, 4, true, true);
+#else
         if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
+#endif
         if (f->d.fValues)
             hipLaunchKernelGGL(k_gather_log, dim3((f->d.W + 15) / 16, (f->d.y1 - f->d.y0 + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount);
     }

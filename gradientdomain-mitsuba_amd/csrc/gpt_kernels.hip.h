@@ -76,8 +76,9 @@ __device__ __forceinline__ Float comp(d3 a, int i) { return i == 0 ? a.x : (i ==
 // 64 B inner node: the bounds of BOTH children (fp32, rounded outward on the host) and their references, so a visit is one
 // record and a leaf never costs a node fetch.  Reference: top bit set = leaf, (first triangle << 3) | (count - 1); else the
 // index of an inner node.
+typedef float f2 __attribute__((ext_vector_type(2)));
 struct BvhNode {
-    float lo[2][3], hi[2][3];
+    f2 b[2][3];                 // per child and axis: (lo, hi) -- one packed-FMA operand of the slab test
     uint32_t child[2];
     uint32_t pad[2];
 };
@@ -125,6 +126,7 @@ struct SceneD {
     Float emitterNormalization;
     int numNodes, numTris, numEmitters, numMats, ldsScene;
     uint32_t rootRef;
+    float boundM;               // largest |coordinate| of the node bounds
     const TriNormals *vn;       // per-vertex normals in leaf order, nullptr if the scene has none
     int envIndex;               // position of the environment emitter in the emitter list, -1: none
     d3 bsCenter;                // its bounding sphere (ConstantBackgroundEmitter::m_sceneBSphere)
@@ -192,6 +194,7 @@ struct SceneView {
     const EmitterD *emitters;
     const TriNormals *vn;       // nullptr: no triangle has vertex normals
     uint32_t rootRef;
+    float boundM;               // largest |coordinate| of the node bounds (error bound of the fp32 slab test)
 };
 
 // TriAccel::rayIntersect, triaccel.h:96-158
@@ -211,18 +214,46 @@ __device__ __forceinline__ bool tri_test(const TriIsect &ta, d3 o, d3 d, Float m
     return u >= 0 && v >= 0 && u + v <= 1.0;
 }
 
-// fp64 slab test against fp32 bounds that were rounded outward on the host (so no true hit is ever culled).
-__device__ __forceinline__ bool box_test(const float (&lo)[3], const float (&hi)[3], d3 o, d3 rd, Float mint, Float maxt, Float &tn)
+// Ray/box slab test, conservative in fp32.  The bounds are fp32 already (rounded outward on the host); per ray the test keeps
+// rdf = fl32(1/d) and, per axis, the two offsets a0/a1 = fl32(o*rdf) -/+ E so that t = b*rdf - a is ONE packed FMA for a (lo, hi)
+// pair, already pushed outward by the error bound E = 2^-21 (M + |o|) |rdf| of that axis (M = largest |bound| of the scene): the
+// exact slab parameter differs from the computed one by at most 2^-24 (|b rdf| + |o rdf| + |t|) (roundings of rdf, o*rdf and
+// the FMA).  The plane the ray meets first gets -E, the other +E (chosen by the sign of rdf), so a box is never culled that the exact
+// test would visit; the extra visits cost time, not correctness -- triangles are still tested in fp64.  14 VALU instructions per
+// box (3 v_pk_fma_f32, 3 min, 3 max, max3/min3 with the ray interval, 1 compare) against 28 fp64 ones.
+struct RayF {
+    f2 rx, ry, rz;              // (rdf, rdf)
+    f2 ax, ay, az;              // -(a0, a1)
+    float mint, maxt;           // ray interval, rounded outward
+};
+__device__ __forceinline__ float slab_rdf(Float d) { return fabs(d) < 1e-30 ? (d < 0 ? -1e30f : 1e30f) : fmaxf(fminf((float)(1.0 / d), 1e30f), -1e30f); }
+__device__ __forceinline__ float up_f(Float v) { return (float)v * (1.0f + 0x1p-22f) + 1e-37f; }
+__device__ __forceinline__ float down_f(Float v) { return (float)v * (1.0f - 0x1p-22f) - 1e-37f; }
+__device__ __forceinline__ void slab_axis(Float o, Float d, float M, f2 &r, f2 &na)
 {
-    Float t0 = ((Float)lo[0] - o.x) * rd.x, t1 = ((Float)hi[0] - o.x) * rd.x;
-    Float tmin = fmin(t0, t1), tmax = fmax(t0, t1);
-    t0 = ((Float)lo[1] - o.y) * rd.y; t1 = ((Float)hi[1] - o.y) * rd.y;
-    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-    t0 = ((Float)lo[2] - o.z) * rd.z; t1 = ((Float)hi[2] - o.z) * rd.z;
-    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
-    tn = tmin;
-    // widen by 2 ulp-ish so that fp64 rounding in the slab arithmetic itself cannot cull a boundary hit
-    return tmin <= fmin(tmax, maxt) * (1.0 + 4e-16) + 1e-300 && tmax * (1.0 + 4e-16) >= mint;
+    const float rdf = slab_rdf(d);
+    const float orf = (float)(o * (Float)rdf);
+    const float E = 0x1p-21f * (M + fabsf((float)o) + 0x1p-100f) * fabsf(rdf) + 1e-37f;
+    const float s = rdf < 0 ? -E : E;
+    r = (f2){rdf, rdf};
+    na = (f2){-(orf + s), -(orf - s)};            // t(lo) = lo*rdf - orf - s,  t(hi) = hi*rdf - orf + s
+}
+__device__ __forceinline__ RayF ray_f(d3 o, d3 d, Float mint, Float maxt, float M)
+{
+    RayF R;
+    slab_axis(o.x, d.x, M, R.rx, R.ax);
+    slab_axis(o.y, d.y, M, R.ry, R.ay);
+    slab_axis(o.z, d.z, M, R.rz, R.az);
+    R.mint = down_f(mint); R.maxt = up_f(maxt);
+    return R;
+}
+__device__ __forceinline__ bool box_test(const f2 (&b)[3], const RayF &R, float &tn)
+{
+    const f2 tx = __builtin_elementwise_fma(b[0], R.rx, R.ax), ty = __builtin_elementwise_fma(b[1], R.ry, R.ay), tz = __builtin_elementwise_fma(b[2], R.rz, R.az);
+    const float n = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), R.mint));
+    const float f = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), R.maxt));
+    tn = n;
+    return n <= f;
 }
 
 // ShapeKDTree::rayIntersect (closest, skdtree.cpp:112-142) / rayIntersect(ray) (shadow, :207-226) on the BVH.
@@ -235,7 +266,7 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
     hit.prim = -1;
     hit.t = GD_INF;
     if (!(maxt > mint)) return false;
-    const d3 rd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    RayF R = ray_f(o, d, mint, maxt, sv.boundM);
     // "while-while" form: every lane first walks inner nodes until it holds a leaf (or is done), then the wave tests its
     // leaves together -- the two codes run with fuller exec masks than one loop that alternates per lane.
     constexpr uint32_t DONE = 0xffffffffu;                 // never a valid reference (a leaf's first triangle is < 2^28)
@@ -245,9 +276,9 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
         while (!(ref & BVH_LEAF)) {
             const BvhNode n = sv.nodes[ref];
             if (COUNT) tc->nodes++;
-            Float tl, tr;
-            const bool hl = box_test(n.lo[0], n.hi[0], o, rd, mint, maxt, tl);
-            const bool hr = box_test(n.lo[1], n.hi[1], o, rd, mint, maxt, tr);
+            float tl, tr;
+            const bool hl = box_test(n.b[0], R, tl);
+            const bool hr = box_test(n.b[1], R, tr);
             if (hl && hr) {
                 const bool leftFirst = tl <= tr;
                 if (sp < STACK_DEPTH) { stack[sp * TBLK] = (int)(leftFirst ? n.child[1] : n.child[0]); sp++; }
@@ -265,6 +296,7 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
             if (tri_test(sv.isect[first + i], o, d, mint, maxt, u, v, t)) {
                 if (ANY) return true;
                 maxt = t;
+                R.maxt = up_f(t);
                 hit.t = t; hit.u = u; hit.v = v; hit.prim = (int)(first + i);
             }
         }
@@ -278,11 +310,19 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
 // The same traversal as a real function.  Used where little caller state is live (the five primary rays of a fresh sample): the
 // callee gets its own tight register allocation and the call costs almost nothing; measured 47 -> 23 ms on the primary-only
 // 1280x720x32 Cornell pass.  Inside bounce(), where ~150 registers of path state are live, inlining is the faster form.
-__device__ __noinline__ Hit trace_closest_call(const SceneView sv, int *stack, d3 o, d3 d, Float mint, Float maxt)
+// Arguments of a real call travel in VGPRs: only the four fields of the scene view the traversal reads are passed, which keeps the
+// callee within the 128 registers of the 4-wave builds (with the whole view it needs 132 and costs them a wave per SIMD).
+__device__ __noinline__ Hit trace_closest_fn(const BvhNode *nodes, const TriIsect *isect, uint32_t rootRef, float boundM, int *stack, d3 o, d3 d, Float mint, Float maxt)
 {
+    SceneView sv;
+    sv.nodes = nodes; sv.isect = isect; sv.rootRef = rootRef; sv.boundM = boundM;
     Hit h;
     trace<false>(sv, stack, o, d, mint, maxt, h);
     return h;
+}
+__device__ __forceinline__ Hit trace_closest_call(const SceneView &sv, int *stack, d3 o, d3 d, Float mint, Float maxt)
+{
+    return trace_closest_fn(sv.nodes, sv.isect, sv.rootRef, sv.boundM, stack, o, d, mint, maxt);
 }
 
 __device__ __forceinline__ Float ray_mint_closest(d3 o, Float mint)

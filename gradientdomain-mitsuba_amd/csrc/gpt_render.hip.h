@@ -42,7 +42,9 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
-template <bool ENV, bool SMOOTH, class ACC>
+// CALLS: the five primary traversals go through the real-call form (the 2-wave builds); the 4-wave builds inline them, because the callee
+// needs 132 registers and would cost them a wave per SIMD.
+template <bool ENV, bool SMOOTH, bool CALLS, class ACC>
 __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample)
 {
     const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
@@ -60,7 +62,8 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
         const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);
         camera_ray(S.cam, L.sx + ox, L.sy + oy, o, d, mint, maxt);
         L.nClosest++;
-        hits[r] = trace_closest_call(sv, stack, o, d, ray_mint_closest(o, mint), maxt);
+        if constexpr (CALLS) hits[r] = trace_closest_call(sv, stack, o, d, ray_mint_closest(o, mint), maxt);
+        else trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, hits[r]);
     }
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -482,11 +485,12 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
 template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
 __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
 {
-    // dynamic LDS: [traversal stack: stackDepth x TBLK ints][staged scene tables (LDS_SCENE only)][per-sample sums (ACC_LDS only)]; sized by the host from
+    // dynamic LDS: [traversal stack: stackDepth x TBLK ints][per-sample sums (ACC_LDS only)][staged scene tables (LDS_SCENE only)]; sized by the host from
     // the actual BVH depth and table bytes so that small scenes leave room for more resident blocks per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int *s_stack = reinterpret_cast<int *>(s_dyn);
-    unsigned char *s_scene = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
+    unsigned char *s_acc = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
+    unsigned char *s_scene = s_acc + (ACC_LDS ? sizeof(Float) * ACC_N * TBLK : 0);
     SceneView sv;
     if (LDS_SCENE) {
         // stage node packets, triangle records and the shading tables through LDS once per block (coalesced 16-byte copies);
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         sv.mats = reinterpret_cast<const MaterialD *>(s_scene + offs[3]);
         sv.emitters = reinterpret_cast<const EmitterD *>(s_scene + offs[4]);
     } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; }
-    sv.rootRef = S.rootRef;
+    sv.rootRef = S.rootRef; sv.boundM = S.boundM;
     sv.vn = S.vn;                      // per-vertex normals stay in HBM (scenes that have them are rarely LDS-resident)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<ACC_LDS> A;
-    if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_scene + sceneBytes) + threadIdx.x;
+    if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_acc) + threadIdx.x;
     int next = valid ? s0 : s1;         // next sample to start
     bool active = false;
     bool pending = false;               // a finished sample whose sums still sit in A: flushed to the pixel record when the lane
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
             if (pending) finish_path(F, flt, L, A, px, py, next - 1 - cfg.sBase);
-            active = start_path<ENV, SMOOTH>(S, sv, cfg, stack, L, A, px, py, next);
+            active = start_path<ENV, SMOOTH, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A, px, py, next);
             next++;
             pending = !active;
             if (!active) { paths++; pathLen += L.depth; }
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     if (i >= n) return;
     const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(TBLK) void k_trace_stats(SceneD S, int n, const Flo
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     TravCount c0 = {0, 0}, c1 = {0, 0};
     if (i < n) {
@@ -738,11 +742,11 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
-    bool active = start_path<true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
+    bool active = start_path<true, true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
     while (active) active = bounce<true, true>(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
