@@ -557,8 +557,11 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
         c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);
+#ifndef GDPT_DEV_WPS
+#define GDPT_DEV_WPS 2
+#endif
 #ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 3): one build per scene kind */
-        if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH(true, true, 2, true, true); else GDPT_LAUNCH(true, false, 2, true, true); } else GDPT_LAUNCH(false, false, 4, true, true);
+        if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, true);
 #else
         if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }

@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r01c
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG:-r01c}
 rm -rf $OUT; mkdir -p $OUT
 B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o r1 -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
