@@ -33,9 +33,9 @@ SCENE = "cornell"
 CONFIGS = {1: ("cornell", 512, 512, 64, "L2D"), 2: ("cornell", 1280, 720, 64, "L2D"), 3: ("atrium", 1920, 1080, 256, "L1D"), 4: ("atrium", 3840, 2160, 256, "L2D")}
 BYTES_PER_PIX_ITER = {"L2D": 120.0, "L1D": 132.0}     # SURVEY.md 8(d), fp32, reference 3-op formulation
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s
-# HBM-side bytes per launch of the dominant CG kernel from the PMC passes of profiles/r01e_hotpath_1280x720x64_pmc.csv
+# HBM-side bytes per launch of the dominant CG kernel from the PMC passes of profiles/r01f_hotpath_1280x720x64_pmc.csv
 # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KiB); PMC counters cannot be read inside a plain bench run.
-PROFILED_TRAFFIC = {("kp_cg", 2): (2 * 54210.4 + 105757.7) * 1024.0}
+PROFILED_TRAFFIC = {("kp_cg", 2): (2 * 54328.6 + 105769.4) * 1024.0}
 
 
 def _usable_cores():
@@ -231,7 +231,7 @@ def main():
                                 "caveat": "algorithmic bytes per ray x render-kernel ray rate (SURVEY 8d-B); the traversal is latency/issue bound and its tables sit in LDS (small scenes) or L2/Infinity Cache -- not an HBM figure"},
             "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PROFILED_TRAFFIC.get((kname, a.config)),
-                         "traffic_source": "profiles/r01e_hotpath_1280x720x64_pmc.csv" if (kname, a.config) in PROFILED_TRAFFIC else None,
+                         "traffic_source": "profiles/r01f_hotpath_1280x720x64_pmc.csv" if (kname, a.config) in PROFILED_TRAFFIC else None,
                          "what": "dominant Poisson CG kernel: algorithmic bytes per launch (%g B/pix-iter, SURVEY 8d) / HIP-event launch duration" % bpi,
                          "kernel": kname, "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
                          "solve_achieved": round(solve_achieved, 1), "solve_frac": round(solve_achieved / HBM_PEAK_GBS, 4),
