@@ -13,8 +13,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
 
 
+STAMP = LIB + ".flags"          # the flags the library was built with: a development build (GDPT_EXTRA_FLAGS) never passes for the product
+
+
+def _flags_line():
+    return " ".join(FLAGS + os.environ.get("GDPT_EXTRA_FLAGS", "").split())
+
+
 def stale():
     if not os.path.exists(LIB):
+        return True
+    if not os.path.exists(STAMP) or open(STAMP).read().strip() != _flags_line():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
@@ -30,6 +39,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_flags_line() + "\n")
     build_host(verbose)
     return LIB
 
