@@ -470,3 +470,42 @@ def test_strip_renderer_single_rank_equals_integrator_render(G, kind):
         assert np.array_equal(imgs[i], ref[name])
     assert sr.last["rays"] == integ.stats["raysTraced"] + integ.stats["shadowRaysTraced"]
     sr.close(); S.close()
+
+
+def test_config3_geometry_properties_atrium_1920x1080(G):
+    """BASELINE config 3's scene and resolution (HBM-resident BVH, 4-wave build) at 16 of its 256 spp: run-to-run reproducibility, two
+    strips + halo exchange == one film, samples spot-checked against the oracle at this geometry."""
+    import torch
+    W, H, spp = 1920, 1080, 16
+    sc = scenes.atrium(W, H)
+    S = G.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=-1)
+    cfg = integ.config(spp)
+    F = G.Film(S)
+    integ.renderBlock(S, F, cfg, (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    F.clear(); integ.renderBlock(S, F, cfg, (0, 0, W, H))
+    assert F.stats() == st and (F.accum() == acc).mean() > 0.999          # (filter-edge samples go through fp64 atomics)
+    assert st["paths"] == W * H * spp and np.isfinite(acc).all()
+    top, bot = G.Film(S, 0, 500), G.Film(S, 500, H)
+    integ.renderBlock(S, top, cfg, (0, 0, W, 500)); integ.renderBlock(S, bot, cfg, (0, 500, W, H))
+    n = top.halo_bytes() // 8
+    a, b = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+    top.pack_halo(1, a); bot.pack_halo(0, b)
+    top.unpack_halo(1, b); bot.unpack_halo(0, a)
+    both = np.concatenate([top.accum(), bot.accum()], axis=1)
+    for k in range(5):
+        assert close(both[k], acc[k], 1e-12), G.BUFFER_NAMES[k]
+    ts, bs = top.stats(), bot.stats()
+    assert ts["raysTraced"] + bs["raysTraced"] == st["raysTraced"] and ts["shadowRaysTraced"] + bs["shadowRaysTraced"] == st["shadowRaysTraced"]
+    O = go.Scene(sc)
+    rng = np.random.default_rng(5)
+    ocfg = go.config(maxDepth=-1, spp=spp)
+    for _ in range(12):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, s), O.evaluate_point(ocfg, px, py, s)
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (px, py, s, k)
+    for f in (F, top, bot):
+        f.close()
+    S.close(); O.close()

@@ -260,3 +260,36 @@ def test_full_size_l1d_1280x720(P):
         a, it = run_solver(P, "L1D", dx, dy, tp, direct, w, h, fusion)
         assert it == 1000
         assert np.abs(a - ref).max() <= 1e-3 and np.abs(a - ref).mean() <= 2e-5
+
+
+def test_full_size_l1d_1920x1080_config3(P):
+    """BASELINE config 3 size (2.07 Mpixel, above the persistent kernel's range: the multi-kernel graphs run).  The oracle takes
+    minutes here, so: determinism, the fused path against the reference op sequence (itself checked against the oracle at the
+    smaller sizes), and the first IRLS iteration (== an L2 solve from x0 = throughput) against the oracle."""
+    w, h = 1920, 1080
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    a, it = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 2)
+    b, _ = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 2)
+    assert it == 1000 and np.array_equal(a, b)
+    u, _ = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 0)
+    assert np.abs(u - a).max() <= 1e-3 and np.abs(u - a).mean() <= 2e-5
+    l2, _ = run_solver(P, "L2D", dx, dy, tp, direct, w, h, 2)
+    ref = po.solve(po.preset("L2D"), dx, dy, tp, direct, w, h)
+    assert np.abs(l2 - ref).max() <= 5e-5
+    assert np.isfinite(a).all()
+
+
+def test_full_size_l2d_3840x2160_config4(P):
+    """BASELINE config 4 size (8.3 Mpixel; on 8 GPUs the strips are gathered and rank 0 solves this).  Linearity (exact for a
+    power of two), determinism, fused vs reference op sequence, and the oracle itself (about 10 s)."""
+    w, h = 3840, 2160
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    a, it = run_solver(P, "L2D", dx, dy, tp, None, w, h, 2)
+    b, _ = run_solver(P, "L2D", dx, dy, tp, None, w, h, 2)
+    assert it == 50 and np.array_equal(a, b)
+    c, _ = run_solver(P, "L2D", 2 * dx, 2 * dy, 2 * tp, None, w, h, 2)
+    assert np.array_equal(c, 2 * a)
+    u, _ = run_solver(P, "L2D", dx, dy, tp, None, w, h, 0)
+    assert np.abs(u - a).max() <= 5e-5
+    ref = po.solve(po.preset("L2D"), dx, dy, tp, None, w, h)
+    assert np.abs(a - ref).max() <= 5e-5
