@@ -201,6 +201,8 @@ struct gdpt_film {
     FilmD d;
     Float *accum = nullptr;     // resolved [5][rows][W][4]
     hipStream_t stream = nullptr;
+    hipStream_t cancelStream = nullptr;   // gdpt_film_cancel writes the flag from here while the render kernel runs on `stream`
+    int *cancelFlag = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     bool resolved = false;
     int wavesPerSimd = 2;       // occupancy target the render kernel is compiled for (register budget = 512 / this)
@@ -447,10 +449,12 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     if (hipMalloc((void **)&d.rec, sizeof(Float) * NREC * d.recStride) != hipSuccess ||
         hipMalloc((void **)&d.spill, sizeof(Float) * 5 * d.recStride * 4) != hipSuccess ||
         hipMalloc((void **)&d.stats, sizeof(unsigned long long) * 4) != hipSuccess ||
+        hipMalloc((void **)&f->cancelFlag, sizeof(int)) != hipSuccess || hipStreamCreateWithFlags(&f->cancelStream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&f->accum, sizeof(Float) * 5 * (size_t)(y1 - y0) * W * 4) != hipSuccess) {
         gdpt_film_destroy(f);
         return tfail(GDPT_ERR_HIP, "Out of memory!");
     }
+    d.cancel = f->cancelFlag;
     *out = f;
     return gdpt_film_clear(f);
 }
@@ -466,6 +470,8 @@ void gdpt_film_destroy(gdpt_film *f)
     if (f->d.recExtra) hipFree(f->d.recExtra);
     if (f->d.spill) hipFree(f->d.spill);
     if (f->d.stats) hipFree(f->d.stats);
+    if (f->cancelFlag) hipFree(f->cancelFlag);
+    if (f->cancelStream) hipStreamDestroy(f->cancelStream);
     if (f->accum) hipFree(f->accum);
     if (f->stream) hipStreamDestroy(f->stream);
     delete f;
@@ -478,6 +484,7 @@ int gdpt_film_clear(gdpt_film *f)
     THIPCHK(hipMemsetAsync(d.rec, 0, sizeof(Float) * NREC * d.recStride, f->stream));
     THIPCHK(hipMemsetAsync(d.spill, 0, sizeof(Float) * 5 * d.recStride * 4, f->stream));
     THIPCHK(hipMemsetAsync(d.stats, 0, sizeof(unsigned long long) * 4, f->stream));
+    THIPCHK(hipMemsetAsync(f->cancelFlag, 0, sizeof(int), f->stream));             // a new frame is not cancelled
     THIPCHK(hipStreamSynchronize(f->stream));
     for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     f->events.clear();
@@ -576,6 +583,23 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
     f->resolved = false;
+    return GDPT_OK;
+}
+
+int gdpt_film_cancel(gdpt_film *f)
+{
+    if (!f) return tfail(GDPT_ERR_INVALID, "null film");
+    static const int one = 1;
+    THIPCHK(hipMemcpyAsync(f->cancelFlag, &one, sizeof(int), hipMemcpyHostToDevice, f->cancelStream));
+    THIPCHK(hipStreamSynchronize(f->cancelStream));
+    return GDPT_OK;
+}
+
+int gdpt_film_cancelled(gdpt_film *f, int *out)
+{
+    if (!f || !out) return tfail(GDPT_ERR_INVALID, "film_cancelled: null argument");
+    THIPCHK(hipMemcpyAsync(out, f->cancelFlag, sizeof(int), hipMemcpyDeviceToHost, f->cancelStream));
+    THIPCHK(hipStreamSynchronize(f->cancelStream));
     return GDPT_OK;
 }
 

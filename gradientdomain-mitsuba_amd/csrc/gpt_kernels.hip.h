@@ -151,6 +151,7 @@ struct FilmD {
     int logY0, logRows;         // the log covers the film's rows plus the filter's reach above and below (clipped to the image): a strip renders those rows
                                 // itself instead of receiving them, so its gathered rows are bit-identical to the same rows of a whole-image film
     unsigned long long *stats;  // [4]
+    const int *cancel;          // device flag set by gdpt_film_cancel: waves stop starting samples (Integrator::cancel, the `stop` flag of gpt.cpp:1246,1254)
     int W, H, y0, y1, recRows;
     size_t recStride;           // recRows * W
 };

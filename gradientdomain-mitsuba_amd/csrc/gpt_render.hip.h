@@ -546,6 +546,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         if (wantMask == 0 && idleMask == ~0ULL) break;
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
+            if (__hip_atomic_load(F.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { next = s1; continue; }   // cancelled: no new samples; running paths finish
             if (pending) finish_path(F, flt, L, A, px, py, next - 1 - cfg.sBase);
             active = start_path<ENV, SMOOTH, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A, px, py, next);
             next++;
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = F.y0 + blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= F.W || y >= F.y1) return;
+    if (__hip_atomic_load(F.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;      // a cancelled chunk is incomplete: dropped
     const int R = (int)ceil(F.fRadius) + 1;                 // (the host sizes logY0 / logRows with the same reach)
     const size_t plane = (size_t)F.logRows * F.W, comp = (size_t)F.logChunk * plane;
     auto evalD = [&](Float d) -> Float { int idx = (int)fabs(d * F.fScale); if (idx > 31) idx = 31; return F.fValues[idx]; };

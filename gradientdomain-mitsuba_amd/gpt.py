@@ -191,6 +191,15 @@ class Film:
     def sync(self):
         check(lib().gdpt_film_sync(self._h))
 
+    def cancel(self):
+        """Integrator::cancel: stop the frame being rendered into this film (callable from another thread); clear() starts a new one."""
+        check(lib().gdpt_film_cancel(self._h))
+
+    def cancelled(self):
+        v = C.c_int()
+        check(lib().gdpt_film_cancelled(self._h, C.byref(v)))
+        return bool(v.value)
+
     def close(self):
         if self._h:
             lib().gdpt_film_destroy(self._h)

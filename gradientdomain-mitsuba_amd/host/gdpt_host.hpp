@@ -8,6 +8,7 @@
 #pragma once
 #include "../../include/gdpt_tracer.h"
 #include "exr_writer.hpp"
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdio>
@@ -263,8 +264,18 @@ public:
         cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;
         cfg.shiftThreshold = m_shiftThreshold; cfg.seed = seed;
         log += format("Starting render job (GPT::render) (%ix%i, %i %s, 1 MI355X) ..\n", W, H, sampleCount, sampleCount == 1 ? "sample" : "samples");
+        m_film.store(gf);
         check(gdpt_render_rect(scene, &cfg, 0, 0, W, H, gf));
         check(gdpt_film_sync(gf));
+        m_film.store(nullptr);
+        int cancelled = 0;
+        check(gdpt_film_cancelled(gf, &cancelled));
+        if (cancelled) {                                                                         // sched->cancel: no develop, no reconstruction, render() == false
+            log += "Render job cancelled.\n";
+            gdpt_film_destroy(gf);
+            gdpt_scene_destroy(scene);
+            return false;
+        }
         for (int b = 0; b < 5; ++b) check(gdpt_film_develop(gf, b, film.buffer(b).data()));
         unsigned long long st[4];
         check(gdpt_film_stats(gf, st));
@@ -289,7 +300,15 @@ public:
         return true;
     }
 
+    /// Integrator::cancel (integrator.h:88): callable from another thread while render() runs.
+    void cancel()
+    {
+        gdpt_film *f = m_film.load();
+        if (f) gdpt_film_cancel(f);
+    }
+
 private:
+    std::atomic<gdpt_film *> m_film{nullptr};
     int m_maxDepth, m_rrDepth;
     bool m_strictNormals, m_hideEmitters, m_reconstructL1, m_reconstructL2;
     double m_shiftThreshold, m_reconstructAlpha;

@@ -107,6 +107,12 @@ GDPT_API int  gdpt_film_clear(gdpt_film *f);
  * film (GPTBlockRenderer::process + processResult).  Asynchronous on the film's stream; gdpt_film_sync waits. */
 GDPT_API int  gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int x1, int y1, gdpt_film *f);
 GDPT_API int  gdpt_film_sync(gdpt_film *f);
+/* Integrator::cancel (include/mitsuba/render/integrator.h:88; the `stop` flag polled per pixel and sample, gpt.cpp:1246,1254): may be
+ * called from another thread while a gdpt_render_rect is running.  Waves stop starting samples, running base paths finish, the film
+ * keeps what was accumulated (with a filter wider than box: the chunks gathered so far) and later gdpt_render_rect calls into this
+ * frame render nothing.  gdpt_film_clear starts a new, uncancelled frame.  gdpt_film_cancelled reports the flag. */
+GDPT_API int  gdpt_film_cancel(gdpt_film *f);
+GDPT_API int  gdpt_film_cancelled(gdpt_film *f, int *out);
 
 /* Halo exchange for row-strip sharding (DESIGN.md "multi-GPU").  A strip's pixels need the per-pixel sample sums of the
  * rows just outside it (the neighbour samples that splat into it) -- the reference's block border merged by addition

@@ -509,3 +509,40 @@ def test_config3_geometry_properties_atrium_1920x1080(G):
     for f in (F, top, bot):
         f.close()
     S.close(); O.close()
+
+
+def test_cancel_stops_a_running_frame(G):
+    """Integrator::cancel: gdpt_render_rect is asynchronous; a cancel while it runs ends the frame early with whole samples only, and
+    the film works again after clear()."""
+    W, H, spp = 1280, 720, 256                       # ~0.7 s uncancelled
+    sc = scenes.cornell_box(W, H, "diffuse")
+    S = G.Scene(sc); F = G.Film(S)
+    integ = G.GradientPathIntegrator(maxDepth=-1)
+    import time
+    integ.renderBlock(S, F, integ.config(1), (0, 0, W, H)); F.sync(); F.clear()      # (first launch loads the code object)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    assert not F.cancelled()
+    time.sleep(0.05)
+    F.cancel()
+    F.sync()
+    st = F.stats()
+    assert F.cancelled() and 0 < st["paths"] < W * H * spp // 2 and F.render_ms() < 400.0
+    acc = F.accum()
+    assert np.isfinite(acc).all()
+    c2 = (1 / (2 * (0.5 + float(np.float32(1e-5))))) ** 2
+    assert acc[1][1:-1, 1:-1, 3].mean() < 0.5 * 8 * c2 * spp                  # (weight 8 c^2 per sample and pixel in the interior)
+    integ.renderBlock(S, F, integ.config(4), (0, 0, W, H)); F.sync()
+    assert F.stats() == st                                     # a cancelled frame takes no more samples
+    F.clear()
+    assert not F.cancelled()
+    integ.renderBlock(S, F, integ.config(4), (0, 0, W, H)); F.sync()
+    assert F.stats()["paths"] == W * H * 4
+    # with a filter wider than box the interrupted chunk is dropped, earlier chunks stay
+    sc.rfilter = scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN]
+    S2 = G.Scene(sc); F2 = G.Film(S2)
+    integ.renderBlock(S2, F2, integ.config(128), (0, 0, W, H))
+    F2.cancel(); F2.sync()
+    assert np.isfinite(F2.accum()).all()
+    for f in (F, F2):
+        f.close()
+    S.close(); S2.close()
