@@ -9,6 +9,7 @@
 #include "../../include/gdpt_tracer.h"
 #include "exr_writer.hpp"
 #include <atomic>
+#include <cmath>
 
 #include <cstdarg>
 #include <cstdio>
@@ -157,6 +158,44 @@ struct SceneData {
     int numTriangles() const { return (int)triMaterial.size(); }
 };
 
+/// The three StatsCounters on the path, printed as Statistics::getStats does (src/libcore/statistics.cpp:152-272):
+/// "Normal rays traced" / "Shadow rays traced" (skdtree.cpp:46-47) and "Average path length" (gpt.cpp:72,1178-1179).
+struct Statistics {
+    unsigned long long raysTraced = 0, shadowRaysTraced = 0, paths = 0, pathLengthSum = 0;
+    static std::string number(const char *name, double value)
+    {   // ENumberValue, statistics.cpp:201-212
+        static const char *suffix[] = {"", " K", " M", " G", " T"};
+        int s = 0;
+        float v = (float)value;
+        while (v > 1000.0f && s <= 4) { v /= 1000.0f; s++; }
+        return (v - std::floor(v) < 0.001f) ? format("    -  %s : %.0f%s", name, v, suffix[s]) : format("    -  %s : %.3f%s", name, v, suffix[s]);
+    }
+    std::string getStats() const
+    {
+        static const char *suffix[] = {"", " K", " M", " G", " T"};
+        std::string o = "------------------------------------------------------------\n";
+        o += " * Loaded plugins :\n    -  libgdpt_hip.so [G-PT hot path and screened Poisson reconstruction on MI355X]\n";
+        int entries = 0;
+        if (raysTraced || shadowRaysTraced) {
+            o += "\n  * General :\n";
+            if (raysTraced) { o += number("Normal rays traced", (double)raysTraced) + "\n"; entries++; }
+            if (shadowRaysTraced) { o += number("Shadow rays traced", (double)shadowRaysTraced) + "\n"; entries++; }
+        }
+        if (pathLengthSum) {                                   // EAverage, statistics.cpp:243-258
+            float v2 = (float)pathLengthSum, v3 = (float)paths;
+            int s2 = 0, s3 = 0;
+            while (v2 > 1000.0f && s2 < 4) { v2 /= 1000.0f; s2++; }
+            while (v3 > 1000.0f && s3 < 4) { v3 /= 1000.0f; s3++; }
+            o += "\n  * Gradient Path Tracer :\n";
+            o += format("    -  Average path length : %.2f (%.2f%s / %.2f%s)\n", (double)pathLengthSum / (double)paths, v2, suffix[s2], v3, suffix[s3]);
+            entries++;
+        }
+        if (!entries) o += " * Statistics:\n     none.\n";
+        o += "------------------------------------------------------------";
+        return o;
+    }
+};
+
 /// MultiFilm (src/films/multifilm.cpp): N named buffers over one image, written as <dest><suffix>.pfm.
 class MultiFilm {
 public:
@@ -182,8 +221,8 @@ public:
     int getHeight() const { return m_height; }
     std::vector<float> &buffer(size_t i) { return m_images[i]; }
     void setDestinationFile(const std::string &dest) { m_dest = dest; }
-    /// MultiFilm::develop (multifilm.cpp:423-518): one file per buffer, then <dest>-log.txt.
-    std::vector<std::string> develop(const std::string &log) const
+    /// MultiFilm::develop (multifilm.cpp:423-518): one file per buffer, then <dest>-log.txt and <dest>-stats.txt (:493-516).
+    std::vector<std::string> develop(const std::string &log, const Statistics &stats = Statistics()) const
     {
         std::vector<std::string> written;
         for (size_t i = 0; i < m_names.size(); ++i) {
@@ -204,6 +243,8 @@ public:
         }
         std::ofstream lf(m_dest + "-log.txt");
         lf << log;
+        std::ofstream sf(m_dest + "-stats.txt");
+        sf << stats.getStats();
         return written;
     }
 
@@ -279,6 +320,7 @@ public:
         for (int b = 0; b < 5; ++b) check(gdpt_film_develop(gf, b, film.buffer(b).data()));
         unsigned long long st[4];
         check(gdpt_film_stats(gf, st));
+        m_stats.raysTraced = st[0]; m_stats.shadowRaysTraced = st[1]; m_stats.paths = st[2]; m_stats.pathLengthSum = st[3];
         const float ms = gdpt_film_render_ms(gf);
         log += format("Render time: %.3f s, %llu rays + %llu shadow rays (%.1f Mray/s), average path length %.3f\n", ms * 1e-3, st[0], st[1],
                       (st[0] + st[1]) / (ms * 1e3), st[2] ? (double)st[3] / st[2] : 0.0);
@@ -307,7 +349,10 @@ public:
         if (f) gdpt_film_cancel(f);
     }
 
+    const Statistics &getStatistics() const { return m_stats; }
+
 private:
+    Statistics m_stats;
     std::atomic<gdpt_film *> m_film{nullptr};
     int m_maxDepth, m_rrDepth;
     bool m_strictNormals, m_hideEmitters, m_reconstructL1, m_reconstructL2;

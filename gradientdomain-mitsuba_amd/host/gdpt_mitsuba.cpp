@@ -1,6 +1,6 @@
 // gdpt_mitsuba -- command line front end with the reference CLI's flags for this path
 // (/root/reference/src/mitsuba/mitsuba.cpp:154-250): gdpt_mitsuba [-o dest] [-D key=val]... [-p n] [-b n] [-x] [-q] scene.xml
-//   -o  output destination stem: writes <dest>-final|-throughput|-dx|-dy|-direct.{exr|pfm} and <dest>-log.txt (multifilm.cpp:453-517)
+//   -o  output destination stem: writes <dest>-final|-throughput|-dx|-dy|-direct.{exr|pfm} and <dest>-log.txt, <dest>-stats.txt (multifilm.cpp:453-517)
 //   -D  parameter substitution for $key in the scene file
 //   -p, -b  accepted for compatibility (CPU core count / block size have no meaning for the GPU path) and ignored
 //   -x  skip rendering if <dest>-final.pfm exists;  -q  quiet;  --parse-only  load the scene, print a summary, do not touch the GPU
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
         film.setDestinationFile(dest);
         std::string log;
         integrator.render(sd, film, spp, seed, log);
-        for (const std::string &p : film.develop(log)) if (!quiet) printf("Writing image to \"%s\" ..\n", p.c_str());
+        for (const std::string &p : film.develop(log, integrator.getStatistics())) if (!quiet) printf("Writing image to \"%s\" ..\n", p.c_str());
         if (!quiet) fputs(log.c_str(), stdout);
         return 0;
     } catch (const std::exception &e) {

@@ -143,7 +143,7 @@ GDPT_API void *gdpt_film_stream(gdpt_film *f);
  * 4-wave build); a negative value selects the same build with the
  * per-sample sums kept in registers instead of LDS.  Results are identical; only speed differs. */
 GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
-/* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/*.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
+/* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/<type>.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
  * (default: every put covers one pixel, the per-pixel-sums fast path), TENT, GAUSSIAN (p0 = stddev, 0.5), MITCHELL (p0 = B, p1 = C,
  * 1/3 each), CATMULLROM, LANCZOS (p0 = lobes, 3).  The wider filters log every sample and gather the puts per receiving pixel
  * (no atomics; 1.3-2.3x the box render time) and take whole-film rectangles only.  A film over a strip of rows then renders the

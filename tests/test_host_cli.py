@@ -246,6 +246,10 @@ def test_cli_render_equals_python_mirror(cli, tmp_path, gpu_required):
         assert img.shape == (40, 48, 3)
         assert np.array_equal(img, out[suffix]), suffix
     assert os.path.exists(dest + "-log.txt") and "Render time" in open(dest + "-log.txt").read()
+    stats = open(dest + "-stats.txt").read()                     # Statistics::getStats layout (statistics.cpp:152-272)
+    assert stats.startswith("-" * 60 + "\n * Loaded plugins :") and stats.endswith("-" * 60)
+    assert "\n  * General :\n    -  Normal rays traced : " in stats and "    -  Shadow rays traced : " in stats
+    assert "\n  * Gradient Path Tracer :\n    -  Average path length : " in stats and " K / 11.52 K)" in stats    # 48 x 40 x 6 paths
     assert run(cli, "-o", dest, "-x", "-D", "width=48", "-D", "height=40", XML).stdout.startswith("Skipping")
     # MultiFilm's default output format: OpenEXR (float32 here; the default componentFormat is float16)
     xml32 = str(tmp_path / "exr.xml")
