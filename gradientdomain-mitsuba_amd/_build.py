@@ -17,7 +17,8 @@ STAMP = LIB + ".flags"          # the flags the library was built with: a develo
 
 
 def _flags_line():
-    return " ".join(FLAGS + os.environ.get("GDPT_EXTRA_FLAGS", "").split())
+    # (the checkout's own path is taken out: the same library is up to date wherever the tree is copied to)
+    return " ".join(FLAGS + os.environ.get("GDPT_EXTRA_FLAGS", "").split()).replace(ROOT, "$ROOT")
 
 
 def stale():
