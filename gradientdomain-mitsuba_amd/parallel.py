@@ -143,6 +143,23 @@ class StripRenderer:
         self.film = None
         self.set_strips(strips or row_strips(self.height, world))
         self.last = {}
+        self._open_links()
+
+    def _open_links(self):
+        """RCCL sets a peer-to-peer channel up on its first use (tens of milliseconds each): touch every link the frame loop
+        uses -- strip neighbours and every rank -> rank 0 -- once, here, so that the first frame does not pay for it."""
+        if self.world == 1:
+            return
+        one = torch.zeros(1, dtype=torch.float32, device=self.device)
+        ops, keep = [], []
+        for peer in (self.rank - 1, self.rank + 1):
+            if 0 <= peer < self.world:
+                keep.append(_wire(torch.empty_like(one)))
+                ops.append(dist.P2POp(dist.isend, _wire(one), peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, keep[-1], peer, group=self.group))
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+        gather_rows(one.view(1, 1, 1).expand(1, 1, 3).contiguous(), [(r, r + 1) for r in range(self.world)], 1, self.rank, self.world, self.group)
 
     def set_strips(self, strips):
         """(Re)partition the image; every rank must pass the same list."""
