@@ -176,7 +176,8 @@ class StripRenderer:
         """Move the strip boundaries by the render-kernel times of the last render (collective).  Returns True if they moved."""
         if self.world == 1:
             return False
-        t = torch.tensor([self.last.get("render_ms", 0.0)], dtype=torch.float64, device=self.device)
+        # rank 0 also reconstructs while the others already render the next frame: its strip is charged with the solve
+        t = torch.tensor([self.last.get("render_ms", 0.0) + 1e3 * self.last.get("solve_s", 0.0)], dtype=torch.float64, device=self.device)
         allt = [torch.zeros_like(t) for _ in range(self.world)]
         dist.all_gather(allt, t, group=self.group)
         new = rebalance_strips(self.strips, [float(v.item()) for v in allt], min_rows=min_rows)
