@@ -206,7 +206,7 @@ class _ToyIntegrator:
 
 
 class _ToySolver:
-    lastSolveSeconds = 0.25
+    lastSolveSeconds = 1e-4
 
     def importImagesMTS(self, dx, dy, tp, direct, w, h):
         self.v = tp + 2 * dx - dy + 4 * direct
