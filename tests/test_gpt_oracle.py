@@ -267,3 +267,49 @@ def test_vertex_normals_restatement():
     assert np.allclose(thr, ref, rtol=0.08), (thr, ref)
     flat = scenes.cornell_box(W, H, "bent"); flat.normals = None
     assert not np.allclose(go.Scene(flat).render(go.config(maxDepth=5, spp=2))[0][1], O.render(go.config(maxDepth=5, spp=2))[0][1])
+
+
+@pytest.mark.parametrize("mat", [scenes.diffuse((0.7, 0.6, 0.5)), scenes.roughconductor(0.3, **scenes.CU),
+                                 scenes.roughconductor(0.15, **scenes.AL, distribution=scenes.DISTR_GGX),
+                                 scenes.roughconductor(0.25, **scenes.CU, alphaV=0.1), scenes.roughconductor(0.2, **scenes.AL, sampleVisible=False),
+                                 scenes.roughconductor(0.2, **scenes.AL, distribution=scenes.DISTR_PHONG)])
+def test_bsdf_samples_follow_their_pdf_chi_square(mat):
+    """The reference's own way of pinning a BSDF's sample()/pdf() pair (src/tests/test_chisquare.cpp, include/mitsuba/core/chisquare.h):
+    histogram the sampled directions over a (cos theta, phi) grid, integrate pdf() over the same cells, pool cells with an expected
+    count below 5, Pearson chi-square at the 1 % level."""
+    from scipy.stats import chi2
+    rng = np.random.default_rng(17)
+    wi = unit([0.35, 0.2, 0.9])
+    NT, NP, N = 10, 20, 20000
+    obs = np.zeros((NT, NP))
+    lost = 0
+    for _ in range(N):
+        sx, sy = rng.random(2)
+        wo, _w, pdf, _t = go.bsdf_sample(mat, wi, sx, sy)
+        if pdf <= 0 or wo[2] <= 0:
+            lost += 1
+            continue
+        it = min(NT - 1, int(wo[2] * NT)); ip = min(NP - 1, int((np.arctan2(wo[1], wo[0]) % (2 * np.pi)) / (2 * np.pi) * NP))
+        obs[it, ip] += 1
+    # expected counts: pdf integrated over each cell (d omega = d cos(theta) d phi), 6 x 6 midpoints per cell
+    K = 6
+    exp = np.zeros((NT, NP))
+    for it in range(NT):
+        for ip in range(NP):
+            acc = 0.0
+            for a in range(K):
+                z = (it + (a + 0.5) / K) / NT
+                r = np.sqrt(max(0.0, 1 - z * z))
+                for b in range(K):
+                    phi = (ip + (b + 0.5) / K) / NP * 2 * np.pi
+                    acc += go.bsdf_eval_pdf(mat, wi, [r * np.cos(phi), r * np.sin(phi), z])[1]
+            exp[it, ip] = acc / (K * K) * (1.0 / NT) * (2 * np.pi / NP) * N
+    assert abs(exp.sum() + lost - N) < 0.03 * N                   # the pdf accounts for every sample that was not a failed one
+    o, e = obs.ravel(), exp.ravel()
+    big = e >= 5
+    stat = ((o[big] - e[big]) ** 2 / e[big]).sum()
+    dof = int(big.sum()) - 1
+    if (~big).any() and e[~big].sum() > 0:                        # the pooled cell (chisquare.h: cells below 5 are merged)
+        stat += (o[~big].sum() - e[~big].sum()) ** 2 / max(e[~big].sum(), 1e-9)
+        dof += 1
+    assert dof > 5 and stat < chi2.ppf(0.99, dof), (stat, dof, chi2.ppf(0.99, dof))
