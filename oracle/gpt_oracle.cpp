@@ -30,6 +30,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -1264,6 +1266,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             VertexType mainVertexType = getVertexType(mainBSDF, cfg, ESmooth);
                             VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, ESmooth);
                             const bool mainAtPointLight = (dRec.measure == MEASURE_DISCRETE);                        // :667
+                            if (getenv("GPO_TRACE_MAIN")) fprintf(stderr, "gpo nee depth %d offset %d: unconnected, main prim %d type %d, shifted prim %d mat type %d vertex type %d\n", depth, i, main.its.prim, (int)mainVertexType, shifted.its.prim, (int)shiftedBSDF.type, (int)shiftedVertexType);
                             if (mainAtPointLight || (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE)) {
                                 DirectSamplingRecord shiftedDRec;
                                 shiftedDRec.ref = shifted.its.p; shiftedDRec.refN = refNormal(shiftedBSDF, shifted.its);
@@ -1317,7 +1320,11 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
         VertexType mainVertexType = getVertexType(mainBSDF, cfg, mainBsdfResult.sampledType); // :765
         VertexType mainNextVertexType;
         main.ray = Ray(main.its.p, mainWo);                                                // :768
-        if (rayIntersect(sc, main.ray, main.its)) {
+        const bool mainHitSomething = rayIntersect(sc, main.ray, main.its);
+        if (getenv("GPO_TRACE_MAIN"))                                                      // debugging aid of tools/gpu_fuzz_locate.py
+            fprintf(stderr, "gpo main ray depth %d: o %.17g %.17g %.17g d %.17g %.17g %.17g -> prim %d t %.17g\n", depth, main.ray.o.x, main.ray.o.y, main.ray.o.z,
+                    main.ray.d.x, main.ray.d.y, main.ray.d.z, mainHitSomething ? main.its.prim : -1, mainHitSomething ? main.its.t : -1.0);
+        if (mainHitSomething) {
             if (sc.tris[main.its.prim].emitter >= 0) {                                     // :772-777
                 mainEmitterRadiance = Le(sc, main.its, -main.ray.d);
                 mainDRec.p = main.its.p; mainDRec.n = main.its.sh.n; mainDRec.d = main.ray.d; mainDRec.dist = main.its.t; // records.inl:170-178
@@ -1759,6 +1766,15 @@ GPO_API void gpo_evaluate_point(gpo_scene *h, const gpo_config *cfg, int px, int
     *o++ = mainRay.radiance.x; *o++ = mainRay.radiance.y; *o++ = mainRay.radiance.z;
     for (int i = 0; i < 4; ++i) { *o++ = sh[i].gradient.x; *o++ = sh[i].gradient.y; *o++ = sh[i].gradient.z; }
     for (int i = 0; i < 4; ++i) { *o++ = sh[i].radiance.x; *o++ = sh[i].radiance.y; *o++ = sh[i].radiance.z; }
+}
+
+// The same, plus the sample's own ray counts: rays2 = {closest-hit, shadow} queries issued by this sample alone.
+GPO_API void gpo_evaluate_point_counted(gpo_scene *h, const gpo_config *cfg, int px, int py, int sampleIndex, double *out30, uint64_t *rays2)
+{
+    const Scene &sc = h->sc;
+    const uint64_t r0 = sc.raysTraced, s0 = sc.shadowRaysTraced;
+    gpo_evaluate_point(h, cfg, px, py, sampleIndex, out30);
+    rays2[0] = sc.raysTraced - r0; rays2[1] = sc.shadowRaysTraced - s0;
 }
 
 // ---- small probes for known-answer tests ----

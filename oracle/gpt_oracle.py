@@ -75,6 +75,7 @@ def lib():
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.gpo_evaluate_point_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_half_vector_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.gpo_bsdf_eval_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.gpo_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
@@ -137,8 +138,10 @@ class Scene:
 
     def evaluate_point(self, cfg, px, py, sample):
         out = np.zeros(30, np.float64)
-        lib().gpo_evaluate_point(self._h, C.byref(cfg), px, py, sample, _p(out))
-        return dict(veryDirect=out[0:3], throughput=out[3:6], gradients=out[6:18].reshape(4, 3), neighbours=out[18:30].reshape(4, 3))
+        rays = np.zeros(2, np.uint64)
+        lib().gpo_evaluate_point_counted(self._h, C.byref(cfg), px, py, sample, _p(out), rays.ctypes.data_as(C.c_void_p))
+        return dict(veryDirect=out[0:3], throughput=out[3:6], gradients=out[6:18].reshape(4, 3), neighbours=out[18:30].reshape(4, 3),
+                    raysTraced=int(rays[0]), shadowRaysTraced=int(rays[1]))
 
     def intersect(self, o, d):
         out = np.zeros(7)
