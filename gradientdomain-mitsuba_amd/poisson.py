@@ -177,6 +177,12 @@ class Backend:
         self._owned.append(p)
         return p
 
+    def freeVector(self, p):
+        """Backend::freeVector (Backend.cpp:78)."""
+        if p in self._owned:
+            self._owned.remove(p)
+            self.L.gdpt_backend_free(C.c_void_p(p))
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         p = self.allocVector(arr.size, 4)
