@@ -5,8 +5,10 @@
  * single-threaded, brute-force ray casting) of the reference's G-PT per-sample hot path:
  * GradientPathTracer::evaluatePoint/evaluate, the shift mappings, vertex classification, the 15-put
  * accumulation of GradientPathIntegrator::renderBlock, and the Mitsuba pieces those call for the
- * scene subset the build carries (triangle soups without vertex normals/texcoords, area lights,
- * diffuse / conductor / roughconductor BSDFs, perspective sensor, box filter).  Only tests/,
+ * scene subset the build carries (triangle soups with optional per-vertex normals, area / point / constant
+ * environment emitters, diffuse / conductor / roughconductor (Beckmann, GGX, Phong) / dielectric BSDFs and the
+ * twosided adapter, perspective sensor, the six reconstruction filters).  GPO_TRACE_MAIN=1 in the environment
+ * makes evaluate() print its main path and light-sample decisions (tools/gpu_fuzz_locate.py).  Only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
  * PARITY UNPINNED.  The reference tracer cannot be built here (mitsuba.h needs boost; scene loading
@@ -36,6 +38,8 @@
 #include <vector>
 
 #define GPO_API extern "C" __attribute__((visibility("default")))
+
+static const bool g_traceMain = std::getenv("GPO_TRACE_MAIN") != nullptr;      // read once: the hot loops only test a bool
 
 namespace {
 
@@ -1266,7 +1270,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             VertexType mainVertexType = getVertexType(mainBSDF, cfg, ESmooth);
                             VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, ESmooth);
                             const bool mainAtPointLight = (dRec.measure == MEASURE_DISCRETE);                        // :667
-                            if (getenv("GPO_TRACE_MAIN")) fprintf(stderr, "gpo nee depth %d offset %d: unconnected, main prim %d type %d, shifted prim %d mat type %d vertex type %d\n", depth, i, main.its.prim, (int)mainVertexType, shifted.its.prim, (int)shiftedBSDF.type, (int)shiftedVertexType);
+                            if (g_traceMain) fprintf(stderr, "gpo nee depth %d offset %d: unconnected, main prim %d type %d, shifted prim %d mat type %d vertex type %d\n", depth, i, main.its.prim, (int)mainVertexType, shifted.its.prim, (int)shiftedBSDF.type, (int)shiftedVertexType);
                             if (mainAtPointLight || (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE)) {
                                 DirectSamplingRecord shiftedDRec;
                                 shiftedDRec.ref = shifted.its.p; shiftedDRec.refN = refNormal(shiftedBSDF, shifted.its);
@@ -1321,7 +1325,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
         VertexType mainNextVertexType;
         main.ray = Ray(main.its.p, mainWo);                                                // :768
         const bool mainHitSomething = rayIntersect(sc, main.ray, main.its);
-        if (getenv("GPO_TRACE_MAIN"))                                                      // debugging aid of tools/gpu_fuzz_locate.py
+        if (g_traceMain)                                                                  // debugging aid of tools/gpu_fuzz_locate.py
             fprintf(stderr, "gpo main ray depth %d: o %.17g %.17g %.17g d %.17g %.17g %.17g -> prim %d t %.17g\n", depth, main.ray.o.x, main.ray.o.y, main.ray.o.z,
                     main.ray.d.x, main.ray.d.y, main.ray.d.z, mainHitSomething ? main.its.prim : -1, mainHitSomething ? main.its.t : -1.0);
         if (mainHitSomething) {
