@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's peer mappings fail (hipIpcGetMemHandle: invalid argument)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
