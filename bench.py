@@ -9,8 +9,16 @@ random numbers are the counter-based streams both the HIP path and the oracle us
                      reference counts in raysTraced + shadowRaysTraced, skdtree.cpp:46-47) / wall time of the step
                      (render + halo exchange + develop + gather + reconstruct), all ranks, max over ranks.
   poisson          = Poisson-CG Mpix-iter/s of the reconstruction inside the same steps (HIP-event span of solveIndirect).
-  roofline         = the dominant Poisson CG kernel against HBM (the graded kernel): algorithmic bytes per launch /
-                     launch duration by HIP events on the solver's stream; solve_achieved = the same over the whole solve.
+  roofline         = the HBM-resident Poisson CG kernel against the 8 TB/s HBM peak (the graded kernel): the fused
+                     x_p + stencil kernel `kf_xp_Ax` at 3840x2160 (working set 1.2 GB, beyond the 256 MB Infinity Cache), algorithmic
+                     bytes per launch (72 B/px) / launch duration by HIP events on the solver's stream, measured live in this run;
+                     `traffic` = FETCH_SIZE x 2 + WRITE_SIZE per launch from the committed PMC pass of THIS binary (profiles/*_counters.json,
+                     keyed by a hash of csrc/; null when the sources changed since).  frac <= 1 by construction.
+  persistent_cg    = the cooperative CG kernel that runs the metric's own 1280x720 solve: NOT an HBM workload (the iterate lives in
+                     VGPRs, counter traffic is 25x below the algorithmic bytes), so it is reported as latency-bound with its
+                     per-iteration phase budget, never as an HBM fraction.
+  tracer_issue     = issue-slot view of the render kernel (98.8 % of a step): VALU wave-instructions per second against
+                     1024 SIMDs x 2.4 GHz / 4 cycles (the fp64 VALU issue rate), lane utilisation, scratch traffic (committed SQ / TCC counters).
   cpu_baseline     = the oracle (CPU restatement, kind "port": the reference itself cannot be built here) on a bounded sample.
 
 N > 1 (strong scaling, the image is fixed): one process per GPU; rank r renders a contiguous strip of rows, exchanges
@@ -36,9 +44,76 @@ SCENE = "cornell"
 CONFIGS = {1: ("cornell", 512, 512, 64, "L2D"), 2: ("cornell", 1280, 720, 64, "L2D"), 3: ("atrium", 1920, 1080, 256, "L1D"), 4: ("atrium", 3840, 2160, 256, "L2D")}
 BYTES_PER_PIX_ITER = {"L2D": 120.0, "L1D": 132.0}     # SURVEY.md 8(d), fp32, reference 3-op formulation
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s
-# HBM-side bytes per launch of the dominant CG kernel from the PMC passes of profiles/r01f_hotpath_1280x720x64_pmc.csv
-# (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KiB); PMC counters cannot be read inside a plain bench run.
-PROFILED_TRAFFIC = {("kp_cg", 2): (2 * 54328.6 + 105769.4) * 1024.0}
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0     # wave-instructions/s: 256 CUs x 4 SIMDs, one fp64 VALU wave-instruction per 4 cycles (MI355X_MICROARCH.md: 78.6 TFLOP/s fp64 vector)
+HBM_W, HBM_H = 3840, 2160                # the HBM-resident Poisson size (BASELINE configs[3]'s reconstruction)
+
+
+def _source_hash():
+    """Hash of the device sources: PMC counters cannot be read inside a plain bench run, so they come from a committed rocprofv3
+    pass (tools/prof_r02.sh -> tools/profile_json.py -> profiles/*_counters.json) and are only quoted while csrc/ is what was profiled."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "gradientdomain-mitsuba_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _profiled_counters():
+    """-> (dict kernel-name-prefix -> counters, file name) of the newest committed counter file whose source hash matches, else ({}, None)."""
+    import glob
+    sh = _source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("source_hash") == sh:
+            return d.get("kernels", {}), os.path.relpath(f, ROOT)
+    return {}, None
+
+
+def _kernel_counters(kernels, prefix, **match):
+    for name, c in kernels.items():
+        if name.startswith(prefix) and all(c.get(k) == v for k, v in match.items()):
+            return c
+    return None
+
+
+def _traffic_bytes(c):
+    """FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both KiB per launch -> bytes."""
+    if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+
+
+def poisson_hbm_roofline(P, dev, preset="L2D"):
+    """The HBM-resident case of the Poisson CG: 3840x2160 (x, r, p, Ap, b, e, w2 = 1.2 GB), multi-kernel graphs.  Inputs are made on the
+    device (smooth image + noise; the arithmetic does not depend on the values).  -> dict for the bench line."""
+    import torch
+    w, h = HBM_W, HBM_H
+    g = torch.Generator(device=dev); g.manual_seed(12345)
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    gt = torch.stack([0.5 + 0.4 * torch.sin(0.2 * xx + c) * torch.cos(0.15 * yy) for c in range(3)], dim=-1).contiguous()
+    tp = (gt + 0.2 * (torch.rand(gt.shape, device=dev, generator=g) - 0.5)).contiguous()
+    dx = torch.zeros_like(gt); dx[:, :-1] = gt[:, 1:] - gt[:, :-1] + 0.01 * (torch.rand((h, w - 1, 3), device=dev, generator=g) - 0.5)
+    dy = torch.zeros_like(gt); dy[:-1] = gt[1:] - gt[:-1] + 0.01 * (torch.rand((h - 1, w, 3), device=dev, generator=g) - 0.5)
+    direct = torch.zeros_like(gt)
+    torch.cuda.synchronize()
+    prm = P.Params(preset, 0.2)
+    sv = P.Solver(prm)
+    sv.importImagesMTS(dx, dy, tp, direct, w, h); sv.setupBackend()
+    sv.solveIndirect()                                  # warm-up
+    t = []
+    for _ in range(3):
+        sv.setupBackend(); sv.solveIndirect(); t.append(sv.lastSolveSeconds)
+    kus = sv.profileKernels(30)
+    pus = sv.profilePersistent(2)
+    sv.close()
+    solve_s = sorted(t)[1]
+    iters = prm.irlsIterMax * prm.cgIterMax
+    return dict(w=w, h=h, preset=preset, solve_ms=1e3 * solve_s, mpix_iter_s=w * h * iters / solve_s / 1e6, kus=kus, persistent_us=pus)
+
 
 
 def _usable_cores():
@@ -175,9 +250,12 @@ def main():
     rays = 0
     render_ms = solve_s = 0.0
     halo = 0
+    phase_ms = {}
     for _ in range(a.steps):
         r, ms, ss, hb = step()
         rays += r; render_ms += ms; solve_s += ss; halo = hb
+        for k, v in sr.last.get("phases_ms", {}).items():
+            phase_ms[k] = phase_ms.get(k, 0.0) + v
     barrier()
     wall = time.perf_counter() - t0
     t = torch.tensor([wall, render_ms, float(rays), solve_s], dtype=torch.float64, device=dev)
@@ -196,29 +274,64 @@ def main():
         pus = solver.profilePersistent(20)
         bpi = BYTES_PER_PIX_ITER[PRESET]
         solve_achieved = bpi * mpix_iter * 1e6 / 1e9
-        if pus > 0.0:
-            # the persistent CG kernel: one launch = cgIterMax iterations over the image; algorithmic bytes = SURVEY 8(d)'s
-            # per pix-iter figure x the pix-iters of one launch (the iterate itself never leaves the register file)
-            kname, kavg, kb = "kp_cg", pus, bpi * W * H * prm.cgIterMax
-        else:
-            # fused x_p+stencil: R r,p,x + W x,p,Ap = 72 B/px algorithmic (+12 for w in IRLS); with kf_r_rz (48 B/px) it is the iteration
-            kname, kavg, kb = "kf_xp_Ax", kus[3], (72.0 if prm.irlsIterMax == 1 else 84.0) * W * H
-        achieved = kb / (kavg * 1e-6) / 1e9 if kavg > 0 else 0.0
-        # algorithmic bytes per ray = ray record 32 B + hit record 16 B + nodes fetched x 64 B + triangles tested x 80 B
-        # (this build's node packet and fp64 TriAccel record), with the traversal counts measured on the device BVH for a
-        # secondary-ray-like set (origins uniform in the scene's box, uniform directions), closest-hit and any-hit weighted by
-        # the render's own ray mix.  Not an HBM-roofline workload (the Cornell tables are LDS-resident): stated with that caveat.
-        import numpy as np
-        rng = np.random.default_rng(1)
-        vv = np.asarray(desc.verts, np.float64).reshape(-1, 3)
-        oo = vv.min(0) + (vv.max(0) - vv.min(0)) * rng.random((1 << 16, 3))
-        dd = rng.normal(size=(1 << 16, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
-        tstat = scene.trace_stats(oo, dd)
+        counters, counters_file = _profiled_counters()
         st_ = film.stats()
-        fc = st_["raysTraced"] / max(1, st_["raysTraced"] + st_["shadowRaysTraced"])
-        bytes_per_ray = 48.0 + 64.0 * (fc * tstat["nodes_closest"] + (1 - fc) * tstat["nodes_any"]) + 80.0 * (fc * tstat["tris_closest"] + (1 - fc) * tstat["tris_any"])
-        tracer_gbs = bytes_per_ray * (rays / world / (render_ms * 1e-3) * world) / 1e9
         samples = W * H * a.spp * a.steps
+        rays_per_launch = rays / a.steps / world
+        launch_s = render_ms * 1e-3 / a.steps
+        # --- the render kernel (98.8 % of a step): an issue-slot view, not an HBM one.  Its tables sit in LDS (Cornell) or L2 / Infinity
+        # Cache; what limits it is instruction issue under divergence and the latency of its scratch traffic.  Counters per launch come from
+        # the committed PMC passes of this binary (null if csrc/ changed since); the launch duration and ray count are this run's.
+        kc = _kernel_counters(counters, "void gdpt_tr::k_render", grid_x=(((W + 15) // 16) * ((H + 15) // 16)) * 256) or _kernel_counters(counters, "void gdpt_tr::k_render")
+        tracer_issue = {"bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                        "peak_what": "1024 SIMDs x 2.4 GHz / 4 cycles per fp64 VALU wave-instruction",
+                        "kernel": "k_render", "kernel_avg_ms": round(1e3 * launch_s, 3), "counters_file": counters_file if kc else None}
+        if kc and "SQ_INSTS_VALU" in kc and world == 1:
+            valu = kc["SQ_INSTS_VALU"]
+            tracer_issue.update({"achieved": round(valu / launch_s / 1e9, 1), "frac": round(valu / launch_s / VALU_ISSUE_PEAK, 4),
+                                 "valu_wave_instr_per_ray": round(valu / rays_per_launch, 2)})
+            if "SQ_THREAD_CYCLES_VALU" in kc and "SQ_ACTIVE_INST_VALU" in kc:
+                tracer_issue["lane_utilisation"] = round(kc["SQ_THREAD_CYCLES_VALU"] / (kc["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+            if "SQ_WAIT_ANY" in kc and "SQ_WAVE_CYCLES" in kc:
+                tracer_issue["wait_any_frac_of_wave_cycles"] = round(kc["SQ_WAIT_ANY"] / kc["SQ_WAVE_CYCLES"], 4)
+            tb = _traffic_bytes(kc)
+            if tb is not None:
+                tracer_issue.update({"fabric_traffic_gb_per_launch": round(tb / 1e9, 2), "fabric_traffic_bytes_per_ray": round(tb / rays_per_launch, 1),
+                                     "fabric_traffic_what": "FETCH_SIZE x2 + WRITE_SIZE of the launch: scratch (spilled path state) + per-pixel record flushes; the algorithmic HBM bytes are the film records, %.2f GB" % (31 * 8 * 2 * W * H / 1e9)})
+        else:
+            tracer_issue.update({"achieved": None, "frac": None})
+        # --- the persistent CG kernel that runs THIS configuration's solve: latency-bound, never an HBM fraction
+        persistent = None
+        if pus > 0.0:
+            pc = _kernel_counters(counters, "void gdpt::kp_cg")
+            persistent = {"bound": "latency", "kernel": "kp_cg", "kernel_avg_us": round(pus, 2), "iterations_per_launch": prm.cgIterMax,
+                          "us_per_iteration": round(pus / prm.cgIterMax, 3),
+                          "what": "one cooperative launch = cgIterMax CG iterations with the iterate in VGPRs; per iteration two grid-wide all-gathers (p.Ap, r.r) + the ring exchange bound it, not bandwidth",
+                          "algorithmic_bytes_if_streamed": bpi * W * H * prm.cgIterMax,
+                          "counter_traffic_bytes": _traffic_bytes(pc), "counters_file": counters_file if pc else None,
+                          "phase_clocks_us": (pc or {}).get("phase_clocks_us")}
+            if persistent["counter_traffic_bytes"]:
+                persistent["counter_traffic_gbs"] = round(persistent["counter_traffic_bytes"] / (pus * 1e-6) / 1e9, 1)
+        # --- the graded HBM roofline: the same CG on an HBM-resident image (3840x2160), measured live
+        hb = poisson_hbm_roofline(P, dev, "L2D") if world == 1 else None
+        roofline = None
+        if hb is not None:
+            npx = hb["w"] * hb["h"]
+            kb = 72.0 * npx                                    # kf_xp_Ax<unit w>: R r, p, x + W x, p, Ap = 72 B/px (x_p 60 + stencil's p read / Ap write counted once)
+            kavg = hb["kus"][3]
+            ach = kb / (kavg * 1e-6) / 1e9
+            hc = _kernel_counters(counters, "void gdpt::kf_xp_Ax", grid_x=npx // 8)
+            iter_bytes = 120.0 * npx
+            iter_us = hb["kus"][3] + hb["kus"][1]
+            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": _traffic_bytes(hc), "traffic_source": counters_file if hc else None,
+                        "kernel": "kf_xp_Ax", "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
+                        "what": "fused x_p + 5-point stencil of the screened-Poisson CG at %dx%d L2D (HBM-resident: 1.2 GB working set), algorithmic 72 B/px per launch / HIP-event launch duration, measured in this run" % (hb["w"], hb["h"]),
+                        "iteration": {"kernels_us": {"kf_xp_Ax": round(hb["kus"][3], 2), "kf_r_rz": round(hb["kus"][1], 2)}, "bytes": iter_bytes,
+                                      "achieved": round(iter_bytes / (iter_us * 1e-6) / 1e9, 1), "frac": round(iter_bytes / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "what": "one CG iteration = kf_xp_Ax + kf_r_rz against SURVEY 8d's 120 B/pix-iter"},
+                        "solve": {"ms": round(hb["solve_ms"], 3), "mpix_iter_s": round(hb["mpix_iter_s"], 1),
+                                  "achieved": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9, 1), "frac": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)}}
         out = {
             "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp" % (W, H, a.spp),
             "value": round(mray, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -229,16 +342,14 @@ def main():
             "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / samples, 2), "msample_s": round(samples / wall / 1e6, 2),
             "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "render_kernel_mray_s": round(rays / world / (render_ms * 1e-3) / 1e6 * world, 1),
             "halo_bytes_per_rank": halo,
-            "tracer_roofline": {"bound": "hbm", "achieved": round(tracer_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tracer_gbs / HBM_PEAK_GBS, 4),
-                                "bytes_per_ray": round(bytes_per_ray, 1), "traversal": {k: round(v, 2) for k, v in tstat.items()},
-                                "caveat": "algorithmic bytes per ray x render-kernel ray rate (SURVEY 8d-B); the traversal is latency/issue bound and its tables sit in LDS (small scenes) or L2/Infinity Cache -- not an HBM figure"},
-            "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PROFILED_TRAFFIC.get((kname, a.config)),
-                         "traffic_source": "profiles/r01f_hotpath_1280x720x64_pmc.csv" if (kname, a.config) in PROFILED_TRAFFIC else None,
-                         "what": "dominant Poisson CG kernel: algorithmic bytes per launch (%g B/pix-iter, SURVEY 8d) / HIP-event launch duration" % bpi,
-                         "kernel": kname, "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
-                         "solve_achieved": round(solve_achieved, 1), "solve_frac": round(solve_achieved / HBM_PEAK_GBS, 4),
-                         "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2), "kp_cg": round(pus, 2)}},
+            "phases_ms_per_step": {k: round(v / a.steps, 4) for k, v in phase_ms.items()},
+            "tracer_issue": tracer_issue,
+            "poisson": {"value": round(mpix_iter, 1), "unit": "Mpix-iter/s", "preset": PRESET, "solve_ms_per_step": round(1e3 * solve_s / a.steps, 4), "dtype": "f32",
+                        "path": "persistent cooperative CG" if pus > 0.0 else "multi-kernel graphs",
+                        "kernels_us": {"kf_Ax": round(kus[0], 2), "kf_r_rz": round(kus[1], 2), "kf_x_p": round(kus[2], 2), "kf_xp_Ax": round(kus[3], 2), "kp_cg": round(pus, 2)},
+                        "reference_cpu_mpix_iter_s": {"L2D": 65.8, "L1D": 80.8, "what": "BASELINE.md section 2: the reference's own solver, 1 thread, survey-stage shimmed build (supplementary)"}},
+            "persistent_cg": persistent,
+            "roofline": roofline,
         }
         if not a.no_cpu_baseline and a.config == 2 and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)

@@ -448,7 +448,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
     if (hipMalloc((void **)&d.rec, sizeof(Float) * NREC * d.recStride) != hipSuccess ||
         hipMalloc((void **)&d.spill, sizeof(Float) * 5 * d.recStride * 4) != hipSuccess ||
-        hipMalloc((void **)&d.stats, sizeof(unsigned long long) * 4) != hipSuccess ||
+        hipMalloc((void **)&d.stats, sizeof(unsigned long long) * 5) != hipSuccess ||
         hipMalloc((void **)&f->cancelFlag, sizeof(int)) != hipSuccess || hipStreamCreateWithFlags(&f->cancelStream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&f->accum, sizeof(Float) * 5 * (size_t)(y1 - y0) * W * 4) != hipSuccess) {
         gdpt_film_destroy(f);
@@ -483,7 +483,7 @@ int gdpt_film_clear(gdpt_film *f)
     FilmD &d = f->d;
     THIPCHK(hipMemsetAsync(d.rec, 0, sizeof(Float) * NREC * d.recStride, f->stream));
     THIPCHK(hipMemsetAsync(d.spill, 0, sizeof(Float) * 5 * d.recStride * 4, f->stream));
-    THIPCHK(hipMemsetAsync(d.stats, 0, sizeof(unsigned long long) * 4, f->stream));
+    THIPCHK(hipMemsetAsync(d.stats, 0, sizeof(unsigned long long) * 5, f->stream));
     THIPCHK(hipMemsetAsync(f->cancelFlag, 0, sizeof(int), f->stream));             // a new frame is not cancelled
     THIPCHK(hipStreamSynchronize(f->stream));
     for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -685,6 +685,14 @@ int gdpt_film_stats(gdpt_film *f, unsigned long long stats[4])
     if (!f || !stats) return tfail(GDPT_ERR_INVALID, "null argument");
     THIPCHK(hipStreamSynchronize(f->stream));
     THIPCHK(hipMemcpy(stats, f->d.stats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return GDPT_OK;
+}
+
+int gdpt_film_invalid_puts(gdpt_film *f, unsigned long long *count)
+{
+    if (!f || !count) return tfail(GDPT_ERR_INVALID, "null argument");
+    THIPCHK(hipStreamSynchronize(f->stream));
+    THIPCHK(hipMemcpy(count, f->d.stats + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return GDPT_OK;
 }
 

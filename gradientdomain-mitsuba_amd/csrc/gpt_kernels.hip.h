@@ -150,7 +150,7 @@ struct FilmD {
     int logChunk;
     int logY0, logRows;         // the log covers the film's rows plus the filter's reach above and below (clipped to the image): a strip renders those rows
                                 // itself instead of receiving them, so its gathered rows are bit-identical to the same rows of a whole-image film
-    unsigned long long *stats;  // [4]
+    unsigned long long *stats;  // [5]: closest rays, shadow rays, paths, path length sum, puts dropped as invalid
     const int *cancel;          // device flag set by gdpt_film_cancel: waves stop starting samples (Integrator::cancel, the `stop` flag of gpt.cpp:1246,1254)
     int W, H, y0, y1, recRows;
     size_t recStride;           // recRows * W
@@ -1006,9 +1006,21 @@ __device__ __forceinline__ Float eval_discretized(const FilterD &f, Float x)
     return idx < 31 ? f.c : 0.0;
 }
 
+// The validity check of ImageBlock::put (imageblock.h:154-158; the blocks of a GPTWorkResult are created with warn = true and only
+// dx / dy allow negative values, gpt_wr.cpp:38-42): a put with a non-finite channel, or a negative one where that is not allowed, is
+// dropped whole -- value AND weight.  (The alpha and weight channels are positive constants.)
+__device__ __forceinline__ bool is_finite(Float v) { return (v - v) == 0; }
+__device__ __forceinline__ bool put_valid(d3 spec, int b)
+{
+    const bool allowNegative = (b == 2 || b == 3);
+    if (!(is_finite(spec.x) && is_finite(spec.y) && is_finite(spec.z))) return false;
+    return allowNegative || !(spec.x < 0 || spec.y < 0 || spec.z < 0);
+}
+
 // ImageBlock::put (imageblock.h:150-199) restricted to the film, with fp64 atomics: the exact generic path.
 __device__ void spill_put(const FilmD &F, const FilterD &flt, Float px, Float py, d3 spec, Float weight, int b)
 {
+    if (!put_valid(spec, b)) { atomicAdd(&F.stats[4], 1ULL); return; }
     const bool box = F.fValues == nullptr;
     const Float radius = box ? flt.radius : F.fRadius, scale = box ? flt.scale : F.fScale;
     auto evalD = [&](Float x) -> Float {                       // evalDiscretized, rfilter.h:76-77

@@ -445,7 +445,13 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
     }
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
     // (other reconstruction filters than box spread every put over several pixels: they always take the generic path)
-    const bool fast = F.fValues == nullptr && single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
+    // The per-pixel sums stand for 15 puts that are all accepted.  A sample with a non-finite sum, or a negative throughput / very-direct
+    // sum (only dx and dy accept negative values), takes the generic path, which checks every put as ImageBlock::put does.
+    Float nonFinite = 0.0, lowest = 0.0;
+#pragma unroll
+    for (int k = 0; k < ACC_N; k++) { const Float v = A.get(k); nonFinite += v - v; if (k < ACC_GRAD) lowest = fmin(lowest, v); }
+    const bool allValid = nonFinite == 0.0 && !(lowest < 0.0);
+    const bool fast = allValid && F.fValues == nullptr && single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
                       single_pixel(flt, L.sx + 1, L.sy, px + 1, py) && single_pixel(flt, L.sx, L.sy - 1, px, py - 1) &&
                       single_pixel(flt, L.sx, L.sy + 1, px, py + 1);
     if (fast) {
@@ -588,6 +594,7 @@ __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
     const size_t plane = (size_t)F.logRows * F.W, comp = (size_t)F.logChunk * plane;
     auto evalD = [&](Float d) -> Float { int idx = (int)fabs(d * F.fScale); if (idx > 31) idx = 31; return F.fValues[idx]; };
     Float o[5][4];
+    unsigned invalid = 0;
     for (int b = 0; b < 5; b++) for (int k = 0; k < 4; k++) o[b][k] = 0.0;
     for (int yy = max(F.logY0, y - R); yy <= min(F.logY0 + F.logRows - 1, y + R); yy++)
         for (int xx = max(0, x - R); xx <= min(F.W - 1, x + R); xx++)
@@ -599,11 +606,13 @@ __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
                 const Float wx0 = evalD(dx0), wxm = evalD(dx0 + 1.0), wxp = evalD(dx0 - 1.0);     // puts at sx, sx - 1, sx + 1
                 const Float wy0 = evalD(dy0), wym = evalD(dy0 + 1.0), wyp = evalD(dy0 - 1.0);
                 const Float w0 = wx0 * wy0, wL = wxm * wy0, wR = wxp * wy0, wT = wx0 * wym, wB = wx0 * wyp;
-                if (w0 == 0 && wL == 0 && wR == 0 && wT == 0 && wB == 0) continue;
+                const bool own = xx == x && yy == y;
+                if (!own && w0 == 0 && wL == 0 && wR == 0 && wT == 0 && wB == 0) continue;
                 auto get3 = [&](int k0) -> d3 { return mk(F.log[(size_t)k0 * comp + at], F.log[(size_t)(k0 + 1) * comp + at], F.log[(size_t)(k0 + 2) * comp + at]); };
                 const d3 T = get3(ACC_T), vd = get3(ACC_VD);
                 const d3 nL = 2 * get3(ACC_NBR + 3 * LEFT), nR = 2 * get3(ACC_NBR + 3 * RIGHT), nT = 2 * get3(ACC_NBR + 3 * TOP), nB = 2 * get3(ACC_NBR + 3 * BOTTOM);
                 auto put = [&](int b, Float w, d3 spec, Float weight) {
+                    if (!put_valid(spec, b)) { if (own) invalid++; return; }      // ImageBlock::put drops an invalid put whole; counted once, by the sample's own pixel
                     o[b][0] += w * spec.x; o[b][1] += w * spec.y; o[b][2] += w * spec.z; o[b][3] += w * weight;
                 };
                 put(0, w0, (8 * vd) + (2 * T), 4.0); put(0, wL, nL, 1.0); put(0, wR, nR, 1.0); put(0, wT, nT, 1.0); put(0, wB, nB, 1.0);
@@ -614,6 +623,7 @@ __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
             }
     for (int b = 0; b < 5; b++)
         for (int k = 0; k < 4; k++) F.spill[(((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4 + k] += o[b][k];
+    if (invalid) atomicAdd(&F.stats[4], (unsigned long long)invalid);
 }
 
 // rec += the slice planes, in slice order (a fixed association, so a render is reproducible bit for bit), and clear them

@@ -130,6 +130,9 @@ struct gdpt_poisson_solver {
 
     float *d_in[4] = {nullptr, nullptr, nullptr, nullptr}; // owned staging when inputs are host pointers
     float *b = nullptr, *e = nullptr, *w2 = nullptr, *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *Ap = nullptr, *rec = nullptr, *z = nullptr;
+    float *x0 = nullptr;        // persistent CG: the iterate a solve started from, should it have to be redone on the multi-kernel path
+    bool x0_valid = false;      // x0 holds the CURRENT x (taken by setup_backend; a second solve without setup retakes it)
+    bool unchecked = false;     // a persistent solve was enqueued and its time-out flag has not been looked at yet
     float4 *part_pAp = nullptr, *part_rz = nullptr, *part_w = nullptr;
     float *scal = nullptr; // [0..3] pAp  [4..7] rz_old  [8..11] rz_next
     float *regtab = nullptr;
@@ -178,7 +181,7 @@ struct gdpt_poisson_solver {
     void release_buffers()
     {
         release_graphs();
-        float **bufs[] = {&d_in[0], &d_in[1], &d_in[2], &d_in[3], &b, &e, &w2, &x, &r, &p[0], &p[1], &Ap, &rec, &scal, &regtab};
+        float **bufs[] = {&d_in[0], &d_in[1], &d_in[2], &d_in[3], &b, &e, &w2, &x, &r, &p[0], &p[1], &Ap, &rec, &x0, &scal, &regtab};
         for (float **q : bufs) { if (*q) hipFree(*q); *q = nullptr; }
         if (z) hipFree(z);
         z = nullptr;
@@ -293,13 +296,14 @@ bool persistent_geometry(gdpt_poisson_solver *s)
     return s->ptTilesX * s->ptTilesY <= imin(cus, PT_MAXG);
 }
 
+constexpr int PT_LAUNCH_REFUSED = -1000;     // internal: hipLaunchCooperativeKernel failed (never crosses the ABI)
 int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
 {
     PersistArgs A;
     A.x = s->x; A.r = s->r; A.p = s->p[0]; A.w2 = s->w2;
     A.gat = s->gat; A.halo = s->halo; A.bar = s->bar; A.s_rz = s->s_rz_next();
     A.W = s->W; A.H = s->H; A.tilesX = s->ptTilesX; A.tilesY = s->ptTilesY; A.TH = s->ptTH; A.iters = cg; A.alpha = s->alpha_eff;
-    { const char *e = getenv("GDPT_DEBUG_PERSISTENT_FAIL"); A.debugFail = (e && e[0] == '1') ? 1 : 0; }
+    { const char *e = getenv("GDPT_DEBUG_PERSISTENT_FAIL"); A.debugFail = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }   // test hooks: 1 = a gather times out, 2 = the launch is refused
     if (s->ptLaunch == 0 || s->ptLaunch == 0xffffu) {      // fresh tables, or the 16-bit launch number is about to wrap: forget all tags
         HIPCHK(hipMemsetAsync(s->gat, 0, sizeof(unsigned long long) * 6 * PT_MAXG, s->stream));
         HIPCHK(hipMemsetAsync(s->halo, 0, sizeof(unsigned long long) * (size_t)PT_HALO * PT_MAXG, s->stream));
@@ -309,7 +313,10 @@ int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
     void *args[] = {&A};
     const dim3 grid(s->ptTilesX * s->ptTilesY), block(((16 * s->ptTH + 63) / 64) * 64);
     const void *fn = unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>;
-    HIPCHK(hipLaunchCooperativeKernel(fn, grid, block, args, 0, s->stream));
+    if (A.debugFail == 2 || hipLaunchCooperativeKernel(fn, grid, block, args, 0, s->stream) != hipSuccess) {
+        (void)hipGetLastError();            // cooperative launch refused (unsupported, partitioned device, grid not co-resident): the caller falls back
+        return PT_LAUNCH_REFUSED;
+    }
     return GDPT_OK;
 }
 
@@ -467,7 +474,12 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
     hipLaunchKernelGGL(kg_setup, dim3(grid_generic(n3)), dim3(BLK), 0, s->stream, s->b, s->x, src[0], src[1], src[2], s->alpha_eff, (int)n3);
     s->dev_direct = src[3];
     HIPCHK(hipGetLastError());
-    if (persistent_geometry(s)) HIPCHK(hipMemcpyAsync(s->rec, s->x, B3, hipMemcpyDeviceToDevice, s->stream));   // x0, should the cooperative launch have to be redone (gdpt_poisson_sync)
+    s->x0_valid = false;
+    if (persistent_geometry(s)) {           // x0, should the cooperative launch have to be redone (gdpt_poisson_sync); its own buffer: export writes s->rec
+        if (!s->x0) HIPCHK(hipMalloc(&s->x0, B3));
+        HIPCHK(hipMemcpyAsync(s->x0, s->x, B3, hipMemcpyDeviceToDevice, s->stream));
+        s->x0_valid = true;
+    }
     // (re)capture the per-IRLS-iteration graphs when geometry/alpha/fusion changed
     if (s->graph_fusion != s->fusion || s->graph_alpha != s->alpha_eff) {
         s->release_graphs();
@@ -492,16 +504,35 @@ int gdpt_poisson_solve_indirect_async(gdpt_poisson_solver *s)
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)s->counter, one, 1, st));
     s->last_iters = 0;
     s->usedPersistent = false;
-    if (persistent_geometry(s) && s->ptTilesX * s->ptTilesY <= MAXP) {
+    bool persistent = persistent_geometry(s) && s->ptTilesX * s->ptTilesY <= MAXP && s->x0;
+    if (persistent) {
         // fusion level 2: the CG loop of every IRLS iteration is one cooperative launch (poisson_persistent.hip.h)
+        const size_t B3 = sizeof(float) * 3 * (size_t)s->W * s->H;
+        if (!s->x0_valid) HIPCHK(hipMemcpyAsync(s->x0, s->x, B3, hipMemcpyDeviceToDevice, st));      // a further solve without setup_backend continues from the current x
+        s->x0_valid = false;
         s->usedPersistent = true;
+        s->unchecked = true;
         HIPCHK(hipMemsetAsync(s->bar, 0, sizeof(unsigned) * PT_BAR_WORDS, st));
         for (int irls = 0; irls < s->P.irlsIterMax; irls++) {
             enqueue_irls_prologue(s, irls == 0);
             int rc = enqueue_cg_persistent(s, irls == 0, s->P.cgIterMax);
+            if (rc == PT_LAUNCH_REFUSED && s->g0) {
+                // include/gdpt_poisson.h: level 2 falls back to level 1 when the persistent kernel cannot run.  Start over from x0 on the graphs.
+                s->log("persistent CG: cooperative launch refused; falling back to the multi-kernel path\n");
+                s->fusion = 1;
+                s->usedPersistent = false; s->unchecked = false;
+                HIPCHK(hipMemcpyAsync(s->x, s->x0, B3, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)s->counter, one, 1, st));
+                s->last_iters = 0;
+                persistent = false;
+                break;
+            }
+            if (rc == PT_LAUNCH_REFUSED) return fail(GDPT_ERR_HIP, "cooperative launch refused and no graph path was captured");
             if (rc) return rc;
             s->last_iters += s->P.cgIterMax;
         }
+    }
+    if (persistent) {
     } else if (s->g0) {
         // cgTolerance == 0: the convergence test of Solver.cpp:438 can only fire on r.z == 0 exactly, and CG
         // steps taken from that state leave x bit-identical (a = 0/FLT_MIN = 0), so no host round trip is needed.
@@ -548,7 +579,8 @@ int gdpt_poisson_sync(gdpt_poisson_solver *s)
     HIPCHK(hipStreamSynchronize(s->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_seconds = ms * 1.0e-3f;
-    if (s->usedPersistent) {
+    if (s->usedPersistent && s->unchecked) {
+        s->unchecked = false;
         unsigned flag[2] = {0, 0};
         HIPCHK(hipMemcpy(flag, s->bar, sizeof flag, hipMemcpyDeviceToHost));
 #ifdef GDPT_PT_TIMING
@@ -564,7 +596,7 @@ int gdpt_poisson_sync(gdpt_poisson_solver *s)
             s->log("persistent CG: a grid-wide gather timed out; falling back to the multi-kernel path\n");
             s->fusion = 1;
             if (!s->g0) return fail(GDPT_ERR_HIP, "persistent CG timed out and no graph path was captured");
-            HIPCHK(hipMemcpyAsync(s->x, s->rec, sizeof(float) * 3 * (size_t)s->W * s->H, hipMemcpyDeviceToDevice, s->stream));
+            HIPCHK(hipMemcpyAsync(s->x, s->x0, sizeof(float) * 3 * (size_t)s->W * s->H, hipMemcpyDeviceToDevice, s->stream));
             int rc = gdpt_poisson_solve_indirect_async(s);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(s->stream));
@@ -587,6 +619,7 @@ int gdpt_poisson_solve_indirect(gdpt_poisson_solver *s)
 static int export_common(gdpt_poisson_solver *s, float *dst, hipMemcpyKind kind)
 {
     if (!s || !s->ready || !dst) return fail(GDPT_ERR_INVALID, "export_images before setup_backend / null destination");
+    if (s->unchecked) { const int rc = gdpt_poisson_sync(s); if (rc) return rc; }     // solve_indirect_async + export: a timed-out persistent solve is redone before anything is exported
     const long n3 = 3L * s->W * s->H;
     const float *final_ = s->x;
     if (s->dev_direct) { // Solver.cpp:563-566: r = direct ; r = 1*r + x

@@ -147,8 +147,16 @@ class Film:
         check(lib().gdpt_film_develop(self._h, buffer, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    @staticmethod
+    def _device_tensor(tensor, dtype_name, numel, what):
+        """The C-ABI takes raw device pointers: refuse anything that is not a contiguous device tensor of the right type and size."""
+        import torch
+        if not (hasattr(tensor, "data_ptr") and tensor.is_cuda and tensor.is_contiguous() and tensor.dtype == getattr(torch, dtype_name) and tensor.numel() >= numel):
+            raise ValueError("%s: needs a contiguous %s device tensor of at least %d elements" % (what, dtype_name, numel))
+        return C.c_void_p(tensor.data_ptr())
+
     def develop_device(self, buffer, tensor):
-        check(lib().gdpt_film_develop_device(self._h, buffer, C.c_void_p(tensor.data_ptr())))
+        check(lib().gdpt_film_develop_device(self._h, buffer, self._device_tensor(tensor, "float32", 3 * self.rows * self.width, "develop_device")))
         return tensor
 
     def halo_bytes(self):
@@ -157,15 +165,21 @@ class Film:
         return n.value
 
     def pack_halo(self, which, tensor):
-        check(lib().gdpt_film_pack_halo(self._h, which, C.c_void_p(tensor.data_ptr())))
+        check(lib().gdpt_film_pack_halo(self._h, which, self._device_tensor(tensor, "float64", self.halo_bytes() // 8, "pack_halo")))
 
     def unpack_halo(self, which, tensor):
-        check(lib().gdpt_film_unpack_halo(self._h, which, C.c_void_p(tensor.data_ptr())))
+        check(lib().gdpt_film_unpack_halo(self._h, which, self._device_tensor(tensor, "float64", self.halo_bytes() // 8, "unpack_halo")))
 
     def stats(self):
         s = (C.c_ulonglong * 4)()
         check(lib().gdpt_film_stats(self._h, s))
         return dict(raysTraced=int(s[0]), shadowRaysTraced=int(s[1]), paths=int(s[2]), pathLengthSum=int(s[3]))
+
+    def invalid_puts(self):
+        """Puts dropped by ImageBlock::put's validity check (non-finite, or negative outside dx/dy) since the last clear."""
+        n = C.c_ulonglong(0)
+        check(lib().gdpt_film_invalid_puts(self._h, C.byref(n)))
+        return int(n.value)
 
     def render_ms(self):
         lib().gdpt_film_render_ms.restype = C.c_float

@@ -622,10 +622,14 @@ private:
         size_t offset = 0;
         if (shapeIndex != 0) {
             const size_t size = file.size();
+            if (size < 8) logError(path + ": truncated");
             const unsigned count = (unsigned)rd(size - 4, 4);
-            if (shapeIndex > (int)count) logError(format("Unable to unserialize mesh, shape index is out of range! (requested %i out of 0..%i)", shapeIndex, (int)count - 1));
+            // (trimesh.cpp:279 rejects idx > count only; idx == count would read the count word as an offset, so it is rejected here too, and a
+            // dictionary larger than the file is a corrupt file)
+            if ((unsigned)shapeIndex >= count || (unsigned long long)count * (version == 4 ? 8 : 4) + 4 > size) logError(format("Unable to unserialize mesh, shape index is out of range! (requested %i out of 0..%i)", shapeIndex, (int)count - 1));
             offset = version == 4 ? (size_t)rd(size - 8 * (size_t)(count - shapeIndex) - 4, 8) : (size_t)rd(size - 4 * (size_t)(count - shapeIndex + 1), 4);
         }
+        if (offset > file.size() || file.size() - offset < 4) logError(path + ": sub-mesh offset points outside the file");
         offset += 4;                                            // the (sub)stream's own header
         std::vector<unsigned char> data;
         {

@@ -9,6 +9,8 @@ rows; the only coupling is the one-pixel halo: a strip needs the per-pixel sampl
 fp32 images (44 MB at 1280x720; the CG at this size is latency-bound and does not profit from splitting -- DESIGN.md).
 `StripRenderer` below is the entry point: one frame = render strip, settle borders, develop, gather, reconstruct on rank 0.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -169,7 +171,9 @@ class StripRenderer:
         if self.film is not None:
             self.film.close()
         self.film = self._film_factory(self.scene, self.y0, self.y1)
-        self.strip_imgs = torch.empty((4, self.y1 - self.y0, self.width, 3), dtype=torch.float32, device=self.device)
+        # four solver images; without a reconstruction a fifth: buffer 0, the (8 veryDirect + 2 throughput + neighbours) / weight
+        # preview that the reference leaves in -final (gpt.cpp:1314-1322)
+        self.strip_imgs = torch.empty((4 if self.preset else 5, self.y1 - self.y0, self.width, 3), dtype=torch.float32, device=self.device)
         self.rec = torch.empty((self.height, self.width, 3), dtype=torch.float32, device=self.device) if self.rank == 0 else None
 
     def rebalance(self, min_rows=2):
@@ -187,20 +191,31 @@ class StripRenderer:
         return True
 
     def render(self, spp, seed=5489):
-        """One frame.  Rank 0 returns the reconstruction [H, W, 3] (device tensor; the primal image if the integrator does not
-        reconstruct) -- other ranks None.  self.last: rays, render_ms, solve_s, halo_bytes of this rank; on rank 0 also the four
+        """One frame.  Rank 0 returns the reconstruction [H, W, 3] (device tensor; if the integrator does not reconstruct, the -final
+        preview of gpt.cpp:1314-1322 = what gpt.GradientPathIntegrator.render()['-final'] holds in that mode) -- other ranks None.  self.last: rays, render_ms, solve_s, halo_bytes of this rank; on rank 0 also the four
         gathered solver images under "images" ([4, H, W, 3]: throughput, dx, dy, direct)."""
         film, integ = self.film, self.integ
         cfg = integ.config(spp, seed)
+        tick = [time.perf_counter()]
+        phases = {}
+
+        def lap(name):                                   # host wall time of a phase (each ends synchronised)
+            now = time.perf_counter()
+            phases[name] = 1e3 * (now - tick[0])
+            tick[0] = now
         film.clear()
         integ.renderBlock(self.scene, film, cfg, (0, self.y0, self.width, self.y1))       # GPTBlockRenderer::process over the strip
         film.sync()
+        lap("render")
         halo = 0
         if not getattr(film, "renders_own_border", False):
             halo = exchange_halos(film, self.rank, self.world, self.device, self.group)
-        for i, b in enumerate((1, 2, 3, 4)):                                               # BUFFER_THROUGHPUT, DX, DY, VERY_DIRECT
+        lap("halo")
+        for i, b in enumerate((1, 2, 3, 4) if self.preset else (1, 2, 3, 4, 0)):          # BUFFER_THROUGHPUT, DX, DY, VERY_DIRECT (, BUFFER_FINAL)
             film.develop_device(b, self.strip_imgs[i])                                     # developMulti + float cast, gpt.cpp:1419-1442
+        lap("develop")
         full = gather_rows(self.strip_imgs, self.strips, self.width, self.rank, self.world, self.group)
+        lap("gather")
         solve_s = 0.0
         out = None
         if self.rank == 0:
@@ -212,9 +227,10 @@ class StripRenderer:
                 solve_s = self.solver.lastSolveSeconds
                 out = self.rec
             else:
-                out = full[0]
+                out = full[4]                                                              # no reconstruction: -final keeps the preview
+        lap("reconstruct")
         st = film.stats()
-        self.last = dict(rays=st["raysTraced"] + st["shadowRaysTraced"], render_ms=film.render_ms(), solve_s=solve_s, halo_bytes=halo,
+        self.last = dict(phases_ms=phases, rays=st["raysTraced"] + st["shadowRaysTraced"], render_ms=film.render_ms(), solve_s=solve_s, halo_bytes=halo,
                          images=full if self.rank == 0 else None)
         return out
 

@@ -98,9 +98,16 @@ class Solver:
     def exportImagesMTS(self, rec=None):
         """Solver::exportImagesMTS (Solver.cpp:542-582): returns / fills 3*w*h floats."""
         w, h = self._size
-        if rec is not None and hasattr(rec, "data_ptr"):
-            check(lib().gdpt_poisson_export_images_device(self._h, C.cast(rec.data_ptr(), _fp)))
+        if rec is not None and hasattr(rec, "data_ptr"):                   # a torch tensor: device or host export by where it lives
+            import torch
+            if rec.dtype != torch.float32 or not rec.is_contiguous() or rec.numel() < 3 * w * h:
+                raise ValueError("exportImagesMTS: rec must be a contiguous float32 tensor of at least 3*w*h = %d elements" % (3 * w * h))
+            fn = lib().gdpt_poisson_export_images_device if rec.is_cuda else lib().gdpt_poisson_export_images
+            check(fn(self._h, C.cast(rec.data_ptr(), _fp)))
             return rec
+        if rec is not None and (not isinstance(rec, np.ndarray) or rec.dtype != np.float32 or not rec.flags["C_CONTIGUOUS"]
+                                or not rec.flags["WRITEABLE"] or rec.size < 3 * w * h):
+            raise ValueError("exportImagesMTS: rec must be a writable C-contiguous float32 array of at least 3*w*h = %d elements" % (3 * w * h))
         out = np.empty(3 * w * h, np.float32) if rec is None else rec
         check(lib().gdpt_poisson_export_images(self._h, out.ctypes.data_as(_fp)))
         return out

@@ -135,6 +135,11 @@ GDPT_API int  gdpt_film_develop(gdpt_film *f, int buffer, float *rgbHost);
 /* Counters since the last clear: [0] closest-hit queries, [1] any-hit queries (raysTraced / shadowRaysTraced,
  * skdtree.cpp:46-47,123,151,211), [2] base paths, [3] sum of base-path lengths (avgPathLength, gpt.cpp:72,1178). */
 GDPT_API int  gdpt_film_stats(gdpt_film *f, unsigned long long stats[4]);
+/* Puts dropped since the last clear by the validity check of ImageBlock::put (imageblock.h:154-158: a non-finite channel, or a
+ * negative one in a buffer other than dx / dy, gpt_wr.cpp:38-42) -- the reference's "Invalid sample value" warnings.  A dropped
+ * put leaves neither value nor weight; one such sample no longer poisons its pixel (and, through the CG's global dot products,
+ * the whole reconstruction). */
+GDPT_API int  gdpt_film_invalid_puts(gdpt_film *f, unsigned long long *count);
 /* HIP-event time of the render kernels enqueued since the last clear (milliseconds). */
 GDPT_API float gdpt_film_render_ms(gdpt_film *f);
 GDPT_API void *gdpt_film_stream(gdpt_film *f);

@@ -264,6 +264,7 @@ struct Scene {
     V3 bsCenter;                // ConstantBackgroundEmitter::m_sceneBSphere (constant.cpp:67-70)
     Float bsRadius = 0;
     mutable uint64_t raysTraced = 0, shadowRaysTraced = 0; // skdtree.cpp:46-47
+    unsigned long long lastInvalidPuts = 0;                // puts dropped by ImageBlock::put's validity check in the last render
     // Oracle-side acceleration for large scenes only (> 64 triangles): a plain midpoint-split bounding-volume tree over double
     // bounds.  It changes which triangles are TESTED, never the test or the answer (closest t wins); small scenes stay brute force.
     struct BNode { V3 lo, hi; int left, right, first, count; };
@@ -1499,6 +1500,7 @@ struct Film {
     int W, H;
     std::vector<double> buf[5]; // [H][W][4]: R,G,B,weight (alpha == 1 carried implicitly)
     double filterRadius, filterScale, filterValues[32];
+    unsigned long long invalidPuts = 0;   // puts dropped by the validity check of ImageBlock::put
     // the reconstruction filters of src/rfilters/*.cpp; kind: 0 box, 1 tent, 2 gaussian (p0 = stddev), 3 mitchell (p0 = B, p1 = C),
     // 4 catmullrom, 5 lanczos (p0 = lobes)
     static double filterRadiusOf(int kind, double p0)
@@ -1552,6 +1554,15 @@ struct Film {
     {
         // Blocks carry a border and are merged by addition with clipping to the film (gpt_proc.cpp:52-56,137-149); net
         // effect on the film: the footprint of imageblock.h:172-176, restricted to [0,W)x[0,H).
+        // imageblock.h:154-158: a put with a non-finite channel -- or, where negative values are not allowed (every buffer but
+        // dx and dy, gpt_wr.cpp:41-42; blocks are created with warn = true, :38), a negative one -- is dropped whole, value and weight
+        // (the reference logs "Invalid sample value" and goes on).  Channels: spec, alpha = 1, weight.
+        const bool allowNegative = (b == 2 || b == 3);
+        {
+            const double chk[5] = {spec.x, spec.y, spec.z, 1.0, weight};
+            for (int k = 0; k < 5; ++k)
+                if (!std::isfinite(chk[k]) || (!allowNegative && chk[k] < 0)) { invalidPuts++; return; }
+        }
         const double posx = px - 0.5, posy = py - 0.5;
         const int x0 = std::max((int)std::ceil(posx - filterRadius), 0), y0 = std::max((int)std::ceil(posy - filterRadius), 0);
         const int x1 = std::min((int)std::floor(posx + filterRadius), W - 1), y1 = std::min((int)std::floor(posy + filterRadius), H - 1);
@@ -1740,7 +1751,11 @@ GPO_API void gpo_render(gpo_scene *h, const gpo_config *cfg, int x0, int y0, int
     const size_t n = (size_t)sc.cam.width * sc.cam.height * 4;
     for (int b = 0; b < 5; ++b) std::memcpy(accum + b * n, film.buf[b].data(), n * sizeof(double));
     if (rays) { rays[0] = sc.raysTraced; rays[1] = sc.shadowRaysTraced; }
+    sc.lastInvalidPuts = film.invalidPuts;
 }
+
+// puts the last gpo_render dropped as invalid (ImageBlock::put's "Invalid sample value" warnings)
+GPO_API unsigned long long gpo_last_invalid_puts(gpo_scene *h) { return h->sc.lastInvalidPuts; }
 
 // MultiFilm::developMulti -> weight division of fmtconv.cpp:955-1058: invWeight = w != 0 ? 1/w : w ; rgb * invWeight
 GPO_API void gpo_develop(const double *accum, int numPixels, double *rgbOut)

@@ -73,6 +73,8 @@ def lib():
         L.gpo_scene_set_normals.argtypes = [C.c_void_p, C.c_void_p]
         L.gpo_scene_set_rfilter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.gpo_last_invalid_puts.restype = C.c_ulonglong
+        L.gpo_last_invalid_puts.argtypes = [C.c_void_p]
         L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.gpo_evaluate_point_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -135,6 +137,10 @@ class Scene:
         rays = np.zeros(2, np.uint64)
         lib().gpo_render(self._h, C.byref(cfg), x0, y0, x1, y1, _p(acc), _p(rays))
         return acc, (int(rays[0]), int(rays[1]))
+
+    def invalid_puts(self):
+        """Puts the last render() dropped as invalid (ImageBlock::put, imageblock.h:154-158)."""
+        return int(lib().gpo_last_invalid_puts(self._h))
 
     def evaluate_point(self, cfg, px, py, sample):
         out = np.zeros(30, np.float64)

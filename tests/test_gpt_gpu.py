@@ -511,6 +511,57 @@ def test_config3_geometry_properties_atrium_1920x1080(G):
     S.close(); O.close()
 
 
+def test_config4_atrium_3840x2160_one_film_equals_eight_strips(G):
+    """BASELINE config 4's tracer half (3840x2160 atrium, the 8-GPU headline), reduced spp: the frame rendered as ONE film equals the
+    frame rendered as EIGHT strip films (the strips 8 GPUs would own, here one after the other on one device) whose one-pixel
+    halos are packed / unpacked between neighbours exactly as parallel.exchange_halos ships them (gpt_proc.cpp:52-56,137-149: a
+    block's border is merged into its neighbour by addition).  Equality to 1e-12 of each buffer's scale, identical ray sums;
+    samples spot-checked against the oracle at this geometry."""
+    import torch
+    from gradientdomain_mitsuba_amd import parallel
+    W, H, spp, N = 3840, 2160, 2, 8
+    sc = scenes.atrium(W, H)
+    S = G.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=-1)
+    cfg = integ.config(spp)
+    F = G.Film(S)
+    integ.renderBlock(S, F, cfg, (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    assert st["paths"] == W * H * spp and np.isfinite(acc).all() and F.invalid_puts() == 0
+    F.close()
+    strips = parallel.row_strips(H, N)
+    films = [G.Film(S, y0, y1) for (y0, y1) in strips]
+    for f, (y0, y1) in zip(films, strips):
+        integ.renderBlock(S, f, cfg, (0, y0, W, y1))
+    n = films[0].halo_bytes() // 8
+    down = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(N)]      # payload of strip r for strip r+1
+    up = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(N)]        # payload of strip r for strip r-1
+    for r, f in enumerate(films):                                                      # every rank packs before anyone unpacks
+        if r + 1 < N: f.pack_halo(1, down[r])
+        if r > 0: f.pack_halo(0, up[r])
+    for r, f in enumerate(films):
+        if r > 0: f.unpack_halo(0, down[r - 1])
+        if r + 1 < N: f.unpack_halo(1, up[r + 1])
+    rays = [0, 0]
+    y = 0
+    for f, (y0, y1) in zip(films, strips):
+        a = f.accum()
+        for k in range(5):
+            assert close(a[k], acc[k][y0:y1], 1e-12), (G.BUFFER_NAMES[k], y0, y1)
+        s2 = f.stats(); rays[0] += s2["raysTraced"]; rays[1] += s2["shadowRaysTraced"]
+        f.close()
+    assert (rays[0], rays[1]) == (st["raysTraced"], st["shadowRaysTraced"])
+    O = go.Scene(sc)
+    rng = np.random.default_rng(9)
+    ocfg = go.config(maxDepth=-1, spp=spp)
+    for _ in range(10):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, s), O.evaluate_point(ocfg, px, py, s)
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (px, py, s, k)
+    S.close(); O.close()
+
+
 def test_cancel_stops_a_running_frame(G):
     """Integrator::cancel: gdpt_render_rect is asynchronous; a cancel while it runs ends the frame early with whole samples only, and
     the film works again after clear()."""
@@ -546,3 +597,29 @@ def test_cancel_stops_a_running_frame(G):
     for f in (F, F2):
         f.close()
     S.close(); S2.close()
+
+
+@pytest.mark.parametrize("radiance", [(-17.0, 12.0, 4.0), (float("inf"), 12.0, 4.0), (float("nan"), 1.0, 1.0)])
+@pytest.mark.parametrize("rfilter", [None, scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN]])
+def test_invalid_puts_are_dropped_like_imageblock_put(G, radiance, rfilter):
+    """one NaN sample must not poison its pixel (and, through the CG's global dot products, the whole reconstruction).
+    ImageBlock::put drops a put with a non-finite channel -- or a negative one outside dx / dy -- value and weight; the HIP film
+    (per-pixel sums fast path, generic spill path, filter gather) must leave exactly what the oracle's 15 checked puts leave."""
+    sc = scenes.cornell_box(40, 24, "diffuse")
+    sc.emitters = [(sc.emitters[0][0], sc.emitters[0][1], radiance)]
+    sc.rfilter = rfilter
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=5)
+    spp = 3
+    F = G.Film(S)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, 40, 24))
+    acc = F.accum()
+    oacc, orays = O.render(go.config(maxDepth=5, spp=spp))
+    st = F.stats()
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+    assert all(np.isfinite(acc[b]).all() for b in range(5))
+    assert F.invalid_puts() == O.invalid_puts() > 0
+    for b in range(5):
+        assert close(acc[b], oacc[b]), G.BUFFER_NAMES[b]
+    out = integ.render(S, spp)                                   # the reconstruction stays finite
+    assert all(np.isfinite(v).all() for v in out.values())

@@ -313,3 +313,31 @@ def test_bsdf_samples_follow_their_pdf_chi_square(mat):
         stat += (o[~big].sum() - e[~big].sum()) ** 2 / max(e[~big].sum(), 1e-9)
         dof += 1
     assert dof > 5 and stat < chi2.ppf(0.99, dof), (stat, dof, chi2.ppf(0.99, dof))
+
+
+def test_invalid_puts_are_dropped_as_imageblock_put_drops_them():
+    """ImageBlock::put (imageblock.h:154-158) with the flags GPTWorkResult sets (gpt_wr.cpp:38-42): a put with a non-finite
+    channel is dropped whole, and so is a negative one except on dx / dy.  An emitter with a negative (or infinite) channel makes
+    exactly the samples that see light invalid."""
+    base = scenes.cornell_box(24, 20, "diffuse")
+    cfg = go.config(maxDepth=4, spp=2)
+    ref, _ = go.Scene(base).render(cfg)
+    # negative red: puts on -final/-throughput/-direct that carry light are dropped (value AND weight), gradients are kept
+    neg = scenes.cornell_box(24, 20, "diffuse")
+    neg.emitters = [(neg.emitters[0][0], neg.emitters[0][1], (-17.0, 12.0, 4.0))]
+    O = go.Scene(neg)
+    acc, _ = O.render(cfg)
+    assert O.invalid_puts() > 0
+    for b in (0, 1, 4):
+        assert (acc[b][..., :3] >= 0).all() and np.isfinite(acc[b]).all()
+        assert (acc[b][..., 3] <= ref[b][..., 3] + 1e-12).all() and (acc[b][..., 3] < ref[b][..., 3] - 1e-9).any()     # weights went with the values
+    for b in (2, 3):
+        assert np.array_equal(acc[b][..., 3], ref[b][..., 3]) and (acc[b][..., 0] != 0).any()
+        assert np.allclose(acc[b][..., 1:3], ref[b][..., 1:3], rtol=1e-12, atol=0)                                       # green / blue gradients unchanged
+    # an infinite channel: inf - inf gradients are NaN; every put that carries light is dropped, nothing non-finite reaches the film
+    inf = scenes.cornell_box(24, 20, "diffuse")
+    inf.emitters = [(inf.emitters[0][0], inf.emitters[0][1], (float("inf"), 12.0, 4.0))]
+    O2 = go.Scene(inf)
+    acc2, _ = O2.render(cfg)
+    assert O2.invalid_puts() > 0 and all(np.isfinite(acc2[b]).all() for b in range(5))
+    assert go.Scene(base).invalid_puts() == 0

@@ -167,6 +167,52 @@ def test_persistent_timeout_recovers_on_the_multi_kernel_path(P, monkeypatch):
     s.close()
 
 
+def test_refused_cooperative_launch_falls_back_to_the_multi_kernel_path(P, monkeypatch):
+    """include/gdpt_poisson.h: fusion level 2 falls back to level 1 when the persistent kernel cannot run.  A refused
+    hipLaunchCooperativeKernel (test hook) must not fail the solve."""
+    w, h = 192, 100
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    ref1, _ = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 1)
+    monkeypatch.setenv("GDPT_DEBUG_PERSISTENT_FAIL", "2")
+    msgs = []
+    s = P.Solver(P.Params("L1D", 0.2)); s.setLogFunction(msgs.append); s.setFusion(2)
+    s.importImagesMTS(dx, dy, tp, direct, w, h); s.setupBackend(); s.solveIndirect()
+    assert any("launch refused" in m for m in msgs) and s.lastIterations == 1000
+    assert np.array_equal(s.exportImagesMTS(), ref1)
+    s.close()
+
+
+def test_async_solve_then_export_sees_the_timeout_and_a_second_solve_continues_from_x(P, monkeypatch):
+    """solve_indirect_async + export_images (no explicit sync) after a timed-out persistent launch must export the redone
+    solve, not the abandoned iterate; and the x0 backup is not the export scratch: two solves in a row without setupBackend
+    give what the multi-kernel path gives for two solves in a row."""
+    w, h = 192, 100
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    a = P.Solver(P.Params("L2D", 0.2)); a.setFusion(1)
+    a.importImagesMTS(dx, dy, tp, direct, w, h); a.setupBackend(); a.solveIndirect()
+    ref_one = a.exportImagesMTS().copy()
+    a.solveIndirect()                                                  # continues from the current x
+    ref_two = a.exportImagesMTS().copy()
+    a.close()
+    assert not np.array_equal(ref_one, ref_two)
+    monkeypatch.setenv("GDPT_DEBUG_PERSISTENT_FAIL", "1")
+    s = P.Solver(P.Params("L2D", 0.2)); s.setFusion(2)
+    s.importImagesMTS(dx, dy, tp, direct, w, h); s.setupBackend()
+    s.solveIndirectAsync()
+    assert np.array_equal(s.exportImagesMTS(), ref_one)                # export noticed the flag and redid the solve
+    s.close()
+    # second solve on a healthy persistent path: export in between (direct != NULL writes the solver's rec scratch) must not disturb x0
+    monkeypatch.delenv("GDPT_DEBUG_PERSISTENT_FAIL")
+    s = P.Solver(P.Params("L2D", 0.2)); s.setFusion(2)
+    s.importImagesMTS(dx, dy, tp, direct, w, h); s.setupBackend(); s.solveIndirect()
+    one = s.exportImagesMTS().copy()
+    monkeypatch.setenv("GDPT_DEBUG_PERSISTENT_FAIL", "1")              # the second solve times out and is redone from ITS x0 = the first result
+    s.solveIndirect()
+    two = s.exportImagesMTS().copy()
+    s.close()
+    assert np.abs(one - ref_one).max() <= 5e-5 and np.abs(two - ref_two).max() <= 5e-5
+
+
 def test_null_throughput_and_null_direct(P):
     w, h = 64, 48
     dx, dy, tp, direct = po.synth_inputs(w, h)
