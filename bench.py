@@ -73,11 +73,17 @@ def _profiled_counters():
     return {}, None
 
 
-def _kernel_counters(kernels, prefix, **match):
-    for name, c in kernels.items():
-        if name.startswith(prefix) and all(c.get(k) == v for k, v in match.items()):
-            return c
-    return None
+def _kernel_counters(kernels, prefix, pick=None, **match):
+    """Counters of the kernel whose name starts with `prefix`; the same kernel runs at several sizes in one bench run (the 1280x720
+    solve and the 3840x2160 one), told apart by grid size: pick = "max_grid" | "min_grid", or exact fields in `match`."""
+    c = [v for name, v in kernels.items() if name.startswith(prefix) and all(v.get(k) == w for k, w in match.items())]
+    if not c:
+        return None
+    if pick == "max_grid":
+        return max(c, key=lambda v: v.get("grid_x", 0))
+    if pick == "min_grid":
+        return min(c, key=lambda v: v.get("grid_x", 0))
+    return c[0]
 
 
 def _traffic_bytes(c):
@@ -282,7 +288,7 @@ def main():
         # --- the render kernel (98.8 % of a step): an issue-slot view, not an HBM one.  Its tables sit in LDS (Cornell) or L2 / Infinity
         # Cache; what limits it is instruction issue under divergence and the latency of its scratch traffic.  Counters per launch come from
         # the committed PMC passes of this binary (null if csrc/ changed since); the launch duration and ray count are this run's.
-        kc = _kernel_counters(counters, "void gdpt_tr::k_render", grid_x=(((W + 15) // 16) * ((H + 15) // 16)) * 256) or _kernel_counters(counters, "void gdpt_tr::k_render")
+        kc = _kernel_counters(counters, "void gdpt_tr::k_render", grid_x=(((W + 15) // 16) * ((H + 15) // 16)) * 256)
         tracer_issue = {"bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
                         "peak_what": "1024 SIMDs x 2.4 GHz / 4 cycles per fp64 VALU wave-instruction",
                         "kernel": "k_render", "kernel_avg_ms": round(1e3 * launch_s, 3), "counters_file": counters_file if kc else None}
@@ -320,7 +326,7 @@ def main():
             kb = 72.0 * npx                                    # kf_xp_Ax<unit w>: R r, p, x + W x, p, Ap = 72 B/px (x_p 60 + stencil's p read / Ap write counted once)
             kavg = hb["kus"][3]
             ach = kb / (kavg * 1e-6) / 1e9
-            hc = _kernel_counters(counters, "void gdpt::kf_xp_Ax", grid_x=npx // 8)
+            hc = _kernel_counters(counters, "void gdpt::kf_xp_Ax", pick="max_grid")
             iter_bytes = 120.0 * npx
             iter_us = hb["kus"][3] + hb["kus"][1]
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -37,6 +37,8 @@
 #include <limits>
 #include <vector>
 
+#include "sfmt_random.hpp"
+
 #define GPO_API extern "C" __attribute__((visibility("default")))
 
 static const bool g_traceMain = std::getenv("GPO_TRACE_MAIN") != nullptr;      // read once: the hot loops only test a bool
@@ -88,13 +90,16 @@ inline uint64_t mix64(uint64_t z)
 }
 struct Rng {
     uint64_t s;
+    sfmt_oracle::Random *serial = nullptr;   // the reference's own generator: ONE serial SFMT-19937 stream (IndependentSampler::next1D, independent.cpp:94-96)
     Rng(uint64_t seed, uint64_t pixel, uint64_t sample)
     {
         s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
         s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
     }
+    explicit Rng(sfmt_oracle::Random *stream) : s(0), serial(stream) {}
     Float next1D()
     {
+        if (serial) return serial->nextFloat();
         s += 0x9E3779B97F4A7C15ULL;
         const uint64_t bits = (mix64(s) >> 12) | 0x3FF0000000000000ULL;
         Float d;
@@ -1580,41 +1585,69 @@ struct Film {
 
 enum { BUFFER_FINAL = 0, BUFFER_THROUGHPUT = 1, BUFFER_DX = 2, BUFFER_DY = 3, BUFFER_VERY_DIRECT = 4 }; // gpt.cpp:76-80
 
+void renderSample(const Scene &sc, const gpo_config &cfg, Rng &rng, int px, int py, Film &film);
+
 // GradientPathIntegrator::renderBlock, gpt.cpp:1220-1355, for the pixels of [x0,x1) x [y0,y1)
 void renderRect(const Scene &sc, const gpo_config &cfg, int x0, int y0, int x1, int y1, Film &film)
 {
-    static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};                 // gpt.cpp:410-415
     for (int py = y0; py < y1; ++py)
         for (int px = x0; px < x1; ++px)
             for (int j = 0; j < cfg.spp; ++j) {
                 Rng rng(cfg.seed, (uint64_t)py * sc.cam.width + px, (uint64_t)j);
-                const double sx = px + rng.next1D(), sy = py + rng.next1D();               // :1261
-                RayState mainRay;
-                sampleRay(sc, sx, sy, mainRay.ray);                                        // evaluatePoint, :397-436
-                mainRay.throughput = V3(1.0);
-                RayState shiftedRays[4];
-                for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], shiftedRays[i].ray); shiftedRays[i].throughput = V3(1.0); }
-                V3 veryDirect(0.0);
-                evaluate(sc, cfg, rng, mainRay, shiftedRays, 4, veryDirect);
-                const V3 T = mainRay.radiance;
-                enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
-                // :1314-1352
-                film.put(sx, sy, (8 * veryDirect) + (2 * T), 4.0, BUFFER_FINAL);
-                film.put(sx - 1, sy, 2 * shiftedRays[LEFT].radiance, 1.0, BUFFER_FINAL);
-                film.put(sx + 1, sy, 2 * shiftedRays[RIGHT].radiance, 1.0, BUFFER_FINAL);
-                film.put(sx, sy - 1, 2 * shiftedRays[TOP].radiance, 1.0, BUFFER_FINAL);
-                film.put(sx, sy + 1, 2 * shiftedRays[BOTTOM].radiance, 1.0, BUFFER_FINAL);
-                film.put(sx, sy, 2 * T, 4.0, BUFFER_THROUGHPUT);
-                film.put(sx - 1, sy, 2 * shiftedRays[LEFT].radiance, 1.0, BUFFER_THROUGHPUT);
-                film.put(sx + 1, sy, 2 * shiftedRays[RIGHT].radiance, 1.0, BUFFER_THROUGHPUT);
-                film.put(sx, sy - 1, 2 * shiftedRays[TOP].radiance, 1.0, BUFFER_THROUGHPUT);
-                film.put(sx, sy + 1, 2 * shiftedRays[BOTTOM].radiance, 1.0, BUFFER_THROUGHPUT);
-                film.put(sx - 1, sy, -(2 * shiftedRays[LEFT].gradient), 1.0, BUFFER_DX);
-                film.put(sx, sy, 2 * shiftedRays[RIGHT].gradient, 1.0, BUFFER_DX);
-                film.put(sx, sy - 1, -(2 * shiftedRays[TOP].gradient), 1.0, BUFFER_DY);
-                film.put(sx, sy, 2 * shiftedRays[BOTTOM].gradient, 1.0, BUFFER_DY);
-                film.put(sx, sy, veryDirect, 1.0, BUFFER_VERY_DIRECT);
+                renderSample(sc, cfg, rng, px, py, film);
             }
+}
+
+// the body of renderBlock's sample loop, gpt.cpp:1254-1352
+void renderSample(const Scene &sc, const gpo_config &cfg, Rng &rng, int px, int py, Film &film)
+{
+    static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};                 // gpt.cpp:410-415
+    const double sx = px + rng.next1D(), sy = py + rng.next1D();               // :1261
+    RayState mainRay;
+    sampleRay(sc, sx, sy, mainRay.ray);                                        // evaluatePoint, :397-436
+    mainRay.throughput = V3(1.0);
+    RayState shiftedRays[4];
+    for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], shiftedRays[i].ray); shiftedRays[i].throughput = V3(1.0); }
+    V3 veryDirect(0.0);
+    evaluate(sc, cfg, rng, mainRay, shiftedRays, 4, veryDirect);
+    const V3 T = mainRay.radiance;
+    enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
+    // :1314-1352
+    film.put(sx, sy, (8 * veryDirect) + (2 * T), 4.0, BUFFER_FINAL);
+    film.put(sx - 1, sy, 2 * shiftedRays[LEFT].radiance, 1.0, BUFFER_FINAL);
+    film.put(sx + 1, sy, 2 * shiftedRays[RIGHT].radiance, 1.0, BUFFER_FINAL);
+    film.put(sx, sy - 1, 2 * shiftedRays[TOP].radiance, 1.0, BUFFER_FINAL);
+    film.put(sx, sy + 1, 2 * shiftedRays[BOTTOM].radiance, 1.0, BUFFER_FINAL);
+    film.put(sx, sy, 2 * T, 4.0, BUFFER_THROUGHPUT);
+    film.put(sx - 1, sy, 2 * shiftedRays[LEFT].radiance, 1.0, BUFFER_THROUGHPUT);
+    film.put(sx + 1, sy, 2 * shiftedRays[RIGHT].radiance, 1.0, BUFFER_THROUGHPUT);
+    film.put(sx, sy - 1, 2 * shiftedRays[TOP].radiance, 1.0, BUFFER_THROUGHPUT);
+    film.put(sx, sy + 1, 2 * shiftedRays[BOTTOM].radiance, 1.0, BUFFER_THROUGHPUT);
+    film.put(sx - 1, sy, -(2 * shiftedRays[LEFT].gradient), 1.0, BUFFER_DX);
+    film.put(sx, sy, 2 * shiftedRays[RIGHT].gradient, 1.0, BUFFER_DX);
+    film.put(sx, sy - 1, -(2 * shiftedRays[TOP].gradient), 1.0, BUFFER_DY);
+    film.put(sx, sy, 2 * shiftedRays[BOTTOM].gradient, 1.0, BUFFER_DY);
+    film.put(sx, sy, veryDirect, 1.0, BUFFER_VERY_DIRECT);
+}
+
+// What `mitsuba -p 1` accumulates: worker 0's sampler is a clone of the scene's IndependentSampler (renderjob.cpp:59-66), i.e. an
+// SFMT-19937 stream seeded by init_by_array from 312 draws of the parent `Random()` (seed 5489; independent.cpp:58,71-80,
+// random.cpp:519-524) -- provided nothing drew from the scene's sampler before the render job cloned it, which holds for gpt
+// (no preprocess pass samples).  Work units are the spiral blocks of BlockedImageProcess (imageproc.cpp:28-78); inside a block
+// GPTBlockRenderer::process walks the pixels in Hilbert order (gpt_proc.cpp:84-87) and renderBlock the samples in index order
+// (gpt.cpp:1245-1268; sampler->generate() draws nothing for the independent sampler without requested arrays).  Merging blocks
+// into the film is addition (gpt_proc.cpp:137-149), so film sums depend on the order only through fp64 rounding.
+void renderSerial(const Scene &sc, const gpo_config &cfg, int blockSize, uint64_t parentSeed, Film &film)
+{
+    sfmt_oracle::Random parent(parentSeed);
+    sfmt_oracle::Random stream(parent);
+    Rng rng(&stream);
+    sfmt_oracle::HilbertPoints hilbert;                                                    // one curve object per worker, kept between blocks
+    for (const sfmt_oracle::Block &b : sfmt_oracle::spiralBlocks(sc.cam.width, sc.cam.height, blockSize)) {
+        hilbert.initialize(b.w, b.h);
+        for (const auto &pt : hilbert.pts)
+            for (int j = 0; j < cfg.spp; ++j) renderSample(sc, cfg, rng, b.x + pt.first, b.y + pt.second, film);
+    }
 }
 
 } // namespace
@@ -1756,6 +1789,45 @@ GPO_API void gpo_render(gpo_scene *h, const gpo_config *cfg, int x0, int y0, int
 
 // puts the last gpo_render dropped as invalid (ImageBlock::put's "Invalid sample value" warnings)
 GPO_API unsigned long long gpo_last_invalid_puts(gpo_scene *h) { return h->sc.lastInvalidPuts; }
+
+// The reference's own sample stream: the whole film as a 1-core run of the reference accumulates it (see renderSerial).
+// blockSize: Scene::getBlockSize() (32 by default, `-b`).  parentSeed: the seed of the scene sampler's Random (5489, random.h:113).
+GPO_API void gpo_render_serial(gpo_scene *h, const gpo_config *cfg, int blockSize, unsigned long long parentSeed, double *accum, unsigned long long *rays)
+{
+    Scene &sc = h->sc;
+    sc.raysTraced = sc.shadowRaysTraced = 0;
+    Film film(sc.cam.width, sc.cam.height, sc.rfilterKind, sc.rfilterP0, sc.rfilterP1);
+    renderSerial(sc, *cfg, blockSize, parentSeed, film);
+    const size_t n = (size_t)sc.cam.width * sc.cam.height * 4;
+    for (int b = 0; b < 5; ++b) std::memcpy(accum + b * n, film.buf[b].data(), n * sizeof(double));
+    if (rays) { rays[0] = sc.raysTraced; rays[1] = sc.shadowRaysTraced; }
+    sc.lastInvalidPuts = film.invalidPuts;
+}
+
+// ---- `Random` (SFMT-19937) and the work order, for the pinning tests ----
+GPO_API void *gpo_random_create(unsigned long long seed) { return new sfmt_oracle::Random((uint64_t)seed); }
+GPO_API void *gpo_random_clone(void *parent) { return new sfmt_oracle::Random(*static_cast<sfmt_oracle::Random *>(parent)); }   // Random(Random *)
+GPO_API void gpo_random_destroy(void *r) { delete static_cast<sfmt_oracle::Random *>(r); }
+GPO_API void gpo_random_ulongs(void *r, int n, unsigned long long *out) { for (int i = 0; i < n; ++i) out[i] = static_cast<sfmt_oracle::Random *>(r)->nextULong(); }
+GPO_API void gpo_random_floats(void *r, int n, double *out) { for (int i = 0; i < n; ++i) out[i] = static_cast<sfmt_oracle::Random *>(r)->nextFloat(); }
+GPO_API void gpo_random_floats_single(void *r, int n, float *out) { for (int i = 0; i < n; ++i) out[i] = static_cast<sfmt_oracle::Random *>(r)->nextFloatSingle(); }
+GPO_API unsigned gpo_random_uint(void *r, unsigned n) { return static_cast<sfmt_oracle::Random *>(r)->nextUInt(n); }
+GPO_API void gpo_random_seed_array(void *r, const unsigned long long *key, unsigned long long length) { static_cast<sfmt_oracle::Random *>(r)->seed((const uint64_t *)key, (uint64_t)length); }
+GPO_API void gpo_random_set(void *r, void *other) { static_cast<sfmt_oracle::Random *>(r)->set(*static_cast<sfmt_oracle::Random *>(other)); }
+// -> number of blocks; out4 (x, y, w, h per block) may be null to query the count
+GPO_API int gpo_spiral_blocks(int width, int height, int blockSize, int *out4)
+{
+    const std::vector<sfmt_oracle::Block> b = sfmt_oracle::spiralBlocks(width, height, blockSize);
+    if (out4) for (size_t i = 0; i < b.size(); ++i) { out4[4 * i] = b[i].x; out4[4 * i + 1] = b[i].y; out4[4 * i + 2] = b[i].w; out4[4 * i + 3] = b[i].h; }
+    return (int)b.size();
+}
+GPO_API int gpo_hilbert_points(int w, int h, unsigned char *outXY)
+{
+    sfmt_oracle::HilbertPoints hp;
+    hp.initialize(w, h);
+    if (outXY) for (size_t i = 0; i < hp.pts.size(); ++i) { outXY[2 * i] = hp.pts[i].first; outXY[2 * i + 1] = hp.pts[i].second; }
+    return (int)hp.pts.size();
+}
 
 // MultiFilm::developMulti -> weight division of fmtconv.cpp:955-1058: invWeight = w != 0 ? 1/w : w ; rgb * invWeight
 GPO_API void gpo_develop(const double *accum, int numPixels, double *rgbOut)

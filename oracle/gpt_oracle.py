@@ -53,8 +53,8 @@ def material(m):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "gpt_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gpt_oracle.cpp", "sfmt_random.hpp")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -76,6 +76,21 @@ def lib():
         L.gpo_last_invalid_puts.restype = C.c_ulonglong
         L.gpo_last_invalid_puts.argtypes = [C.c_void_p]
         L.gpo_develop.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpo_render_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+        L.gpo_random_create.restype = C.c_void_p
+        L.gpo_random_create.argtypes = [C.c_ulonglong]
+        L.gpo_random_clone.restype = C.c_void_p
+        L.gpo_random_clone.argtypes = [C.c_void_p]
+        L.gpo_random_destroy.argtypes = [C.c_void_p]
+        L.gpo_random_ulongs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpo_random_floats.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpo_random_floats_single.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gpo_random_uint.restype = C.c_uint
+        L.gpo_random_uint.argtypes = [C.c_void_p, C.c_uint]
+        L.gpo_random_seed_array.argtypes = [C.c_void_p, C.c_void_p, C.c_ulonglong]
+        L.gpo_random_set.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpo_spiral_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.gpo_hilbert_points.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.gpo_evaluate_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.gpo_evaluate_point_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_half_vector_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
@@ -136,6 +151,14 @@ class Scene:
         acc = np.zeros((5, self.H, self.W, 4), np.float64)
         rays = np.zeros(2, np.uint64)
         lib().gpo_render(self._h, C.byref(cfg), x0, y0, x1, y1, _p(acc), _p(rays))
+        return acc, (int(rays[0]), int(rays[1]))
+
+    def render_serial(self, cfg, block_size=32, parent_seed=5489):
+        """The film as a 1-core run of the reference accumulates it: ONE serial SFMT-19937 stream (the clone of the scene sampler's
+        Random(5489)) consumed in spiral-block x Hilbert-pixel x sample order.  -> (accum[5,H,W,4], (closest, shadow))."""
+        acc = np.zeros((5, self.H, self.W, 4), np.float64)
+        rays = np.zeros(2, np.uint64)
+        lib().gpo_render_serial(self._h, C.byref(cfg), int(block_size), int(parent_seed), _p(acc), _p(rays))
         return acc, (int(rays[0]), int(rays[1]))
 
     def invalid_puts(self):
@@ -212,3 +235,61 @@ def fresnel_conductor(cos_theta, eta, k):
 
 def rng(seed, pixel, sample, n):
     return lib().gpo_rng(seed, pixel, sample, n)
+
+
+class Random:
+    """`Random` of the reference (SFMT-19937, src/libcore/random.cpp) as restated in oracle/sfmt_random.hpp."""
+
+    def __init__(self, seed=5489, _h=None):
+        self._h = _h if _h is not None else lib().gpo_random_create(int(seed))
+
+    def clone(self):
+        """Random(Random *): a new generator seeded from 312 draws of this one (what IndependentSampler::clone does)."""
+        return Random(_h=lib().gpo_random_clone(self._h))
+
+    def ulongs(self, n):
+        out = np.zeros(n, np.uint64)
+        lib().gpo_random_ulongs(self._h, n, _p(out))
+        return out
+
+    def floats(self, n):
+        out = np.zeros(n, np.float64)
+        lib().gpo_random_floats(self._h, n, _p(out))
+        return out
+
+    def floats_single(self, n):
+        out = np.zeros(n, np.float32)
+        lib().gpo_random_floats_single(self._h, n, _p(out))
+        return out
+
+    def uint(self, n):
+        return int(lib().gpo_random_uint(self._h, int(n)))
+
+    def seed_array(self, key):
+        key = np.ascontiguousarray(key, np.uint64)
+        lib().gpo_random_seed_array(self._h, _p(key), key.size)
+
+    def set(self, other):
+        lib().gpo_random_set(self._h, other._h)
+
+    def __del__(self):
+        try:
+            lib().gpo_random_destroy(self._h)
+        except Exception:
+            pass
+
+
+def spiral_blocks(width, height, block_size=32):
+    """BlockedImageProcess's work order -> int array [n, 4] of (x, y, w, h)."""
+    n = lib().gpo_spiral_blocks(width, height, block_size, None)
+    out = np.zeros((n, 4), np.int32)
+    lib().gpo_spiral_blocks(width, height, block_size, _p(out))
+    return out
+
+
+def hilbert_points(w, h):
+    """HilbertCurve2D<uint8_t>::getPoints() for a w x h block -> uint8 array [n, 2] of (x, y)."""
+    n = lib().gpo_hilbert_points(w, h, None)
+    out = np.zeros((n, 2), np.uint8)
+    lib().gpo_hilbert_points(w, h, _p(out))
+    return out
