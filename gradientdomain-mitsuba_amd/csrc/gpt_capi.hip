@@ -178,8 +178,9 @@ struct Builder {
 template <class T>
 int upload(T **dst, const std::vector<T> &v)
 {
-    const size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 16);
+    const size_t bytes = (std::max<size_t>(sizeof(T) * v.size(), 16) + 15) & ~(size_t)15;     // whole 16-byte words: LDS staging copies uint4
     THIPCHK(hipMalloc((void **)dst, bytes));
+    THIPCHK(hipMemset(*dst, 0, bytes));
     if (!v.empty()) THIPCHK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
     return GDPT_OK;
 }
@@ -210,6 +211,11 @@ struct gdpt_film {
     int slices = 0;             // sample slices per launch; 0 = chosen per launch
     int regenMin = REGEN_MIN;   // idle lanes of a wave before they regenerate together
     int extraPlanes = 0;        // record planes allocated behind d.recExtra
+    bool continuation = true;   // hand samples whose offsets are all connected to the continuation kernel (k_continue)
+    int contWaves = 2;          // build of k_continue (resident waves per SIMD it is compiled for)
+    int contRefill = 16;        // idle lanes of a wave of k_continue before they take new records together
+    size_t qBytes = 0;          // allocation behind d.qRec
+    bool primaryPass = true;    // trace the primary rays in their own kernel (k_primary)
     int lastSlices = 1;
 };
 
@@ -372,6 +378,7 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
         (rc = upload(&de, ems)) || (rc = upload(&det, emTris)) || (rc = upload(&dc, emCdf)) || (rc = upload(&dsc, sceneCdf))) { delete s; return rc; }
     s->allocs = {dn, di, ds, dm, de, det, dc, dsc};
     d.nodes = dn; d.isect = di; d.shade = ds; d.mats = dm; d.emitters = de; d.emTris = det; d.emCdf = dc; d.emitterCdf = dsc;
+    d.numEmTris = (int)emTris.size(); d.numEmCdf = (int)emCdf.size();
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = totalEmitters;
     d.rootRef = rootRef;
@@ -407,10 +414,14 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
         d.bsRadius = std::max((double)GD_EPSILON, std::sqrt(r2) * (double)1.5f);
     }
     d.numMats = numMaterials;
-    s->ldsSceneBytes = (((size_t)d.numNodes * sizeof(BvhNode) + 15) & ~(size_t)15) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) +
-                       (size_t)numMaterials * sizeof(MaterialD) + (size_t)totalEmitters * sizeof(EmitterD) + 64;
-    d.ldsScene = ((size_t)d.numNodes * sizeof(BvhNode) + (size_t)numTris * (sizeof(TriIsect) + sizeof(TriShade)) + (size_t)numMaterials * sizeof(MaterialD) +
-                      (size_t)totalEmitters * sizeof(EmitterD) + 64 <= (size_t)LDS_SCENE_BYTES) ? 1 : 0;
+    {
+        const size_t parts[8] = {(size_t)d.numNodes * sizeof(BvhNode), (size_t)numTris * sizeof(TriIsect), (size_t)numTris * sizeof(TriShade), (size_t)numMaterials * sizeof(MaterialD),
+                                 (size_t)totalEmitters * sizeof(EmitterD), emTris.size() * sizeof(EmTri), emCdf.size() * sizeof(double), ((size_t)totalEmitters + 1) * sizeof(double)};
+        size_t tot = 0;
+        for (size_t b : parts) tot += (b + 15) & ~(size_t)15;                 // block_setup's layout: every table starts on a 16-byte word
+        s->ldsSceneBytes = tot;
+        d.ldsScene = tot <= (size_t)LDS_SCENE_BYTES ? 1 : 0;
+    }
     CameraD &c = d.cam;
     for (int r = 0; r < 3; r++)
         for (int k = 0; k < 4; k++) c.m[4 * r + k] = camera->toWorld[4 * r + k];
@@ -443,6 +454,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     d.recExtra = nullptr;
     d.fValues = nullptr; d.fRadius = 0.0; d.fScale = 0.0;       // box filter
     d.log = nullptr; d.logChunk = 0; d.logY0 = 0; d.logRows = 0;
+    d.qRec = nullptr; d.qList = nullptr; d.qCount = nullptr; d.qCapacity = 0; d.qPixels = 0; d.pHit = nullptr; d.pPrim = nullptr;
     d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
     d.recStride = (size_t)d.recRows * W;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
@@ -468,6 +480,11 @@ void gdpt_film_destroy(gdpt_film *f)
     if (f->d.fValues) hipFree((void *)f->d.fValues);
     if (f->d.log) hipFree(f->d.log);
     if (f->d.recExtra) hipFree(f->d.recExtra);
+    if (f->d.qRec) hipFree(f->d.qRec);
+    if (f->d.qList) hipFree(f->d.qList);
+    if (f->d.qCount) hipFree(f->d.qCount);
+    if (f->d.pHit) hipFree(f->d.pHit);
+    if (f->d.pPrim) hipFree(f->d.pPrim);
     if (f->d.spill) hipFree(f->d.spill);
     if (f->d.stats) hipFree(f->d.stats);
     if (f->cancelFlag) hipFree(f->cancelFlag);
@@ -512,7 +529,6 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     hipEvent_t e0, e1;
     THIPCHK(hipEventCreate(&e0));
     THIPCHK(hipEventCreate(&e1));
-    THIPCHK(hipEventRecord(e0, f->stream));
     // LDS: stack sized to the BVH (each level costs 1 KiB per block), the staged tables of a small scene, and -- when two blocks
     // per CU still fit -- the per-sample sums (60 KiB), which frees 60 long-lived VGPRs per lane
     const int stackDepth = std::min(STACK_DEPTH, std::max(4, s->bvhDepth + 2));
@@ -555,7 +571,44 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
             f->d.logChunk = chunk;
         }
     }
-#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, f->d, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
+    // Continuation queue: one record slot per (sample of the chunk, pixel of the launch); the chunk is sized to a memory budget
+    // (GDPT_QUEUE_MB, default 24 GiB of the 288) and the chunks are made equal.
+    const bool useQueue = f->continuation && !getenv("GDPT_NO_CONTINUATION");
+    const unsigned qPixels = (unsigned)tiles * TBLK;
+    if (useQueue) {
+        size_t budget = (size_t)24 << 30;
+        if (const char *e = getenv("GDPT_QUEUE_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;
+        const size_t perSample = (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int));
+        int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)0xffffffffu / qPixels));
+        maxChunk = std::min(maxChunk, chunk);
+        const int nChunks = (cfg->spp + maxChunk - 1) / maxChunk;
+        chunk = std::min(chunk, (cfg->spp + nChunks - 1) / nChunks);
+        const size_t need = (size_t)chunk * perSample;
+        if (f->qBytes < need) {
+            THIPCHK(hipStreamSynchronize(f->stream));
+            if (f->d.qRec) hipFree(f->d.qRec);
+            if (f->d.qList) hipFree(f->d.qList);
+            if (f->d.pHit) hipFree(f->d.pHit);
+            if (f->d.pPrim) hipFree(f->d.pPrim);
+            f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr; f->qBytes = 0;
+            if (hipMalloc((void **)&f->d.qRec, (size_t)chunk * qPixels * NQ * sizeof(Float)) != hipSuccess ||
+                hipMalloc((void **)&f->d.qList, (size_t)chunk * qPixels * sizeof(unsigned)) != hipSuccess ||
+                hipMalloc((void **)&f->d.pHit, (size_t)chunk * qPixels * 15 * sizeof(Float)) != hipSuccess ||
+                hipMalloc((void **)&f->d.pPrim, (size_t)chunk * qPixels * 5 * sizeof(int)) != hipSuccess) return tfail(GDPT_ERR_HIP, "Out of memory!");
+            f->qBytes = need;
+        }
+        if (!f->d.qCount) THIPCHK(hipMalloc((void **)&f->d.qCount, 2 * sizeof(unsigned)));
+    }
+    THIPCHK(hipEventRecord(e0, f->stream));          // (after the allocations: a first launch's hipMalloc is not render time)
+    FilmD fd = f->d;                     // the descriptor of this launch (queue geometry filled in; without a queue qRec stays null)
+    const bool usePrimary = useQueue && f->primaryPass && !getenv("GDPT_NO_PRIMARY_PASS");
+    if (!useQueue) fd.qRec = nullptr;
+    if (!usePrimary) { fd.pHit = nullptr; fd.pPrim = nullptr; }
+    fd.qPixels = qPixels; fd.qCapacity = (unsigned)chunk * qPixels;
+    const dim3 cgrid(s->numCUs * wps);
+#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) do { \
+        hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
+        if (useQueue) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fd, stackDepth, f->contRefill); } while (0)
     // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment / point emitters | + per-vertex normals (environment tested at run time)};
     // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { \
@@ -564,6 +617,17 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
         c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);
+        if (useQueue) {
+            // (the "finished" mark of every slot of the chunk and the two queue counters)
+            THIPCHK(hipMemsetAsync(fd.qRec + (size_t)13 * fd.qCapacity, 0, sizeof(Float) * (size_t)c.sCount * qPixels, f->stream));
+            THIPCHK(hipMemsetAsync(fd.qCount, 0, 2 * sizeof(unsigned), f->stream));
+        }
+        if (usePrimary) {
+            const size_t plds = (size_t)stackDepth * TBLK * sizeof(int) + sceneBytes;
+            const dim3 pgrid((unsigned)tiles * (unsigned)c.sCount);
+            if (s->d.ldsScene) hipLaunchKernelGGL(k_primary<true>, pgrid, block, plds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, stackDepth);
+            else hipLaunchKernelGGL(k_primary<false>, pgrid, block, plds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, stackDepth);
+        }
 #ifndef GDPT_DEV_WPS
 #define GDPT_DEV_WPS 2
 #endif
@@ -573,12 +637,13 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #endif
+        if (useQueue) hipLaunchKernelGGL(k_fold_cont, dim3(tiles), block, 0, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX);
         if (f->d.fValues)
             hipLaunchKernelGGL(k_gather_log, dim3((f->d.W + 15) / 16, (f->d.y1 - f->d.y0 + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount);
     }
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
-    if (slices > 1 && !f->d.fValues) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
+    if (slices > 1 && !f->d.fValues && !useQueue) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
@@ -776,6 +841,15 @@ int gdpt_film_set_regeneration(gdpt_film *f, int idleLanes)
 {
     if (!f || idleLanes < 1 || idleLanes > 64) return tfail(GDPT_ERR_INVALID, "regeneration threshold must be 1..64 idle lanes");
     f->regenMin = idleLanes;
+    return GDPT_OK;
+}
+
+int gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes)
+{
+    if (!f || stages < 0 || stages > 2 || refillLanes < 0 || refillLanes > 64) return tfail(GDPT_ERR_INVALID, "pipeline: stages 0..2, refill threshold 1..64 idle lanes (0 = keep)");
+    f->continuation = stages >= 1;
+    f->primaryPass = stages >= 2;
+    if (refillLanes > 0) f->contRefill = refillLanes;
     return GDPT_OK;
 }
 

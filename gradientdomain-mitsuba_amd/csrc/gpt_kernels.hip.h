@@ -50,6 +50,7 @@ constexpr int SLICE_FILL = 2;      // sample slices: aim at this many work items
 constexpr int LOG_CHUNK = 16;      // wider reconstruction filters: samples per pixel logged between two gathers (32 doubles each)
 constexpr int SLICE_MIN_SPP = 8;   // ... but never fewer samples than this per slice (the end of a slice runs with idle lanes)
 constexpr int NREC = 31;           // per-pixel record components
+constexpr int NQ = 62;             // doubles per continuation record (layout: gpt_render.hip.h, q_store / q_load)
 constexpr int LDS_SCENE_BYTES = 40 * 1024;   // node + triangle + shading + material + emitter tables of a small scene
 
 struct d3 { Float x, y, z; };
@@ -125,6 +126,7 @@ struct SceneD {
     const Float *emitterCdf;    // scene-level emitter cdf (numEmitters + 1)
     Float emitterNormalization;
     int numNodes, numTris, numEmitters, numMats, ldsScene;
+    int numEmTris, numEmCdf;    // entries of emTris / emCdf (emitterCdf has numEmitters + 1)
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds
     const TriNormals *vn;       // per-vertex normals in leaf order, nullptr if the scene has none
@@ -150,6 +152,16 @@ struct FilmD {
     int logChunk;
     int logY0, logRows;         // the log covers the film's rows plus the filter's reach above and below (clipped to the image): a strip renders those rows
                                 // itself instead of receiving them, so its gathered rows are bit-identical to the same rows of a whole-image film
+    // Continuation queue (gpt_render.hip.h, k_continue): a sample whose four offset paths are all connected to the base path (or dead) leaves
+    // the general kernel; its state travels through HBM to a lean kernel that runs the rest of the base path with dense waves.
+    Float *qRec;                // [NQ][qCapacity] records, slot = (sample - sBase) * qPixels + tile * TBLK + thread; nullptr: no hand-off
+    unsigned *qList;            // slots of the handed-off samples in arrival order
+    unsigned *qCount;           // [0] entries in qList, [1] next entry to take
+    unsigned qCapacity, qPixels;
+    // Primary hits of the launch's samples (k_primary): [15][qCapacity] doubles (t, u, v of the base ray and the four offset rays) and
+    // [5][qCapacity] leaf-order triangle indices, in the same slots as the continuation records.  nullptr: start_path traces them itself.
+    Float *pHit;
+    int *pPrim;
     unsigned long long *stats;  // [5]: closest rays, shadow rays, paths, path length sum, puts dropped as invalid
     const int *cancel;          // device flag set by gdpt_film_cancel: waves stop starting samples (Integrator::cancel, the `stop` flag of gpt.cpp:1246,1254)
     int W, H, y0, y1, recRows;
@@ -193,6 +205,9 @@ struct SceneView {
     const TriShade *shade;
     const MaterialD *mats;
     const EmitterD *emitters;
+    const EmTri *emTris;        // light-sampling tables: LDS copies for small scenes (sample_emitter_direct walks them with dependent loads)
+    const Float *emCdf;
+    const Float *emitterCdf;
     const TriNormals *vn;       // nullptr: no triangle has vertex normals
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds (error bound of the fp32 slab test)
@@ -802,9 +817,9 @@ __device__ __forceinline__ d3 env_sample_direct(const SceneD &S, d3 radiance, DR
 template <bool ENV>
 __device__ d3 sample_emitter_direct(const SceneD &S, const SceneView &V, DRec &dRec, Float sx, Float sy)
 {
-    const int index = cdf_sample(S.emitterCdf, S.numEmitters, sx);
-    const Float emPdf = S.emitterCdf[index + 1] - S.emitterCdf[index];
-    sx = (sx - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
+    const int index = cdf_sample(V.emitterCdf, S.numEmitters, sx);
+    const Float emPdf = V.emitterCdf[index + 1] - V.emitterCdf[index];
+    sx = (sx - V.emitterCdf[index]) / (V.emitterCdf[index + 1] - V.emitterCdf[index]);
     const EmitterD em = V.emitters[index];
     d3 value;
     dRec.offSurfaceDiscrete = 0;
@@ -821,10 +836,10 @@ __device__ d3 sample_emitter_direct(const SceneD &S, const SceneView &V, DRec &d
         dRec.n = mk(0.0);
         value = em.radiance * (invDist * invDist);
     } else {
-        const Float *cdf = S.emCdf + em.cdfOffset;
+        const Float *cdf = V.emCdf + em.cdfOffset;
         const int ti = cdf_sample(cdf, em.numTris, sy);
         sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
-        const EmTri tr = S.emTris[em.firstEmTri + ti];
+        const EmTri tr = V.emTris[em.firstEmTri + ti];
         const Float a = safe_sqrt(1.0 - sx);                  // warp.cpp:76-79
         const Float bx = 1 - a, by = a * sy;
         const d3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
@@ -976,6 +991,7 @@ template <> struct Acc<false> {
     __device__ __forceinline__ void add3(int k, d3 v) { a[k] += v.x; a[k + 1] += v.y; a[k + 2] += v.z; }
     __device__ __forceinline__ d3 get3(int k) const { return mk(a[k], a[k + 1], a[k + 2]); }
     __device__ __forceinline__ Float get(int k) const { return a[k]; }
+    __device__ __forceinline__ void set(int k, Float v) { a[k] = v; }
 };
 template <> struct Acc<true> {
     Float *p;               // LDS, already offset by the lane
@@ -983,6 +999,7 @@ template <> struct Acc<true> {
     __device__ __forceinline__ void add3(int k, d3 v) { p[k * TBLK] += v.x; p[(k + 1) * TBLK] += v.y; p[(k + 2) * TBLK] += v.z; }
     __device__ __forceinline__ d3 get3(int k) const { return mk(p[k * TBLK], p[(k + 1) * TBLK], p[(k + 2) * TBLK]); }
     __device__ __forceinline__ Float get(int k) const { return p[k * TBLK]; }
+    __device__ __forceinline__ void set(int k, Float v) { p[k * TBLK] = v; }
 };
 
 // ---- film ---------------------------------------------------------------------------------------------------

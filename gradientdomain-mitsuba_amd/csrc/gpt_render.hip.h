@@ -45,7 +45,8 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 // CALLS: the five primary traversals go through the real-call form (the 2-wave builds); the 4-wave builds inline them, because the callee
 // needs 132 registers and would cost them a wave per SIMD.
 template <bool ENV, bool SMOOTH, bool CALLS, class ACC>
-__device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample)
+__device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample,
+                                           const FilmD *F = nullptr, unsigned slot = 0)
 {
     const Float shx[4] = {1.0, 0.0, -1.0, 0.0}, shy[4] = {0.0, 1.0, 0.0, -1.0};   // gpt.cpp:410-415
     L.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
@@ -55,8 +56,19 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     A.zero();
     // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
     Hit hits[5];
+    const bool traced = F && F->pHit;           // the five primary rays were traced by k_primary (a lean traversal-only kernel at full occupancy)
+    if (traced) {
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            hits[r].t = F->pHit[(size_t)(3 * r) * F->qCapacity + slot];
+            hits[r].u = F->pHit[(size_t)(3 * r + 1) * F->qCapacity + slot];
+            hits[r].v = F->pHit[(size_t)(3 * r + 2) * F->qCapacity + slot];
+            hits[r].prim = F->pPrim[(size_t)r * F->qCapacity + slot];
+        }
+        L.nClosest += 5;
+    }
 #pragma unroll 1
-    for (int r = 0; r < 5; r++) {
+    for (int r = 0; r < (traced ? 0 : 5); r++) {
         d3 o, d;
         Float mint, maxt;
         const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);
@@ -100,7 +112,11 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 // One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
 // ENV: the scene may have an environment emitter (compiled out otherwise: its branches cost the closed scenes 5-8 %).
 // SMOOTH: the scene has triangles with per-vertex normals (shading frame and geometric normal depend on the hit).
-template <bool ENV, bool SMOOTH, class ACC>
+// CONN: every offset path is RAY_CONNECTED or dead (the continuation kernel): the other two connection states are compiled out, and
+// with them every use of an offset's own vertex and direction.  The strict-normals test of the offsets (:547-554) is dropped there
+// too: it reads the offset's LAST OWN vertex and direction, which stop changing when the offset connects, and with those very values
+// it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
+template <bool ENV, bool SMOOTH, bool CONN, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
@@ -111,10 +127,12 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     const d3 mainWi = toLocal(mfr, -L.rayD);                                     // its.wi
     if (cfg.strictNormals) {                                                     // :541-556
         if (dot(L.rayD, mGeoN) * mainWi.z >= 0) return false;
+        if (!CONN) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            Offset &s = L.off[i];
-            if (s.alive) { const Shading sh = shading_at<SMOOTH>(sv, s.v); if (dot(s.rayD, sh.geoN) * toLocal(sh.fr, -s.rayD).z >= 0) s.alive = 0; }
+            for (int i = 0; i < 4; i++) {
+                Offset &s = L.off[i];
+                if (s.alive) { const Shading sh = shading_at<SMOOTH>(sv, s.v); if (dot(s.rayD, sh.geoN) * toLocal(sh.fr, -s.rayD).z >= 0) s.alive = 0; }
+            }
         }
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
@@ -148,13 +166,14 @@ GDPT_OFFSET_LOOP
                 Float weight = 0;
                 bool assigned = false;          // false: weight and both contributions stay 0 (:613-615 with no branch taken)
                 bool shiftSuccessful = s.alive != 0;
+                const int status = CONN ? (int)RAY_CONNECTED : s.status;
                 if (shiftSuccessful) {
-                    if (s.status == RAY_CONNECTED) {                             // :622-637
+                    if (status == RAY_CONNECTED) {                               // :622-637
                         const Float den = (s.pdf * s.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
                         weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                         shiftedContribution = 1.0 * s.throughput * (mainBSDFValue * mainEmitterRadiance);
                         assigned = true;
-                    } else if (s.status == RAY_RECENTLY_CONNECTED) {             // :638-658
+                    } else if (status == RAY_RECENTLY_CONNECTED) {               // :638-658
                         const d3 incoming = normalize(s.v.p - L.v.p);
                         d3 f;
                         Float pdfRaw;
@@ -266,14 +285,15 @@ GDPT_OFFSET_LOOP
         bool postponedShiftEnd = false;
         if (s.alive) {
             const Float shiftedPreviousPdf = s.pdf;
-            if (s.status == RAY_CONNECTED) {                                     // :844-861
+            const int status = CONN ? (int)RAY_CONNECTED : s.status;
+            if (status == RAY_CONNECTED) {                                       // :844-861
                 s.throughput = s.throughput * (bs.weight * bs.pdf);
                 s.pdf *= mainBsdfPdf;
                 const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((mainLumPdf * mainLumPdf) + (mainBsdfPdf * mainBsdfPdf));
                 weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                 shiftedContribution = s.throughput * mainEmitterRadiance;
                 assigned = true;
-            } else if (s.status == RAY_RECENTLY_CONNECTED) {                     // :862-888
+            } else if (status == RAY_RECENTLY_CONNECTED) {                       // :862-888
                 const d3 incoming = normalize(s.v.p - L.rayO);
                 d3 f;
                 Float shiftedBsdfPdf;
@@ -430,8 +450,20 @@ GDPT_OFFSET_LOOP
 
 // Accumulates one finished sample: the 15 puts of gpt.cpp:1314-1352.  Fast path = per-pixel sums (every put covers
 // exactly its expected pixel); otherwise the exact generic path.
+// A sample's sums can stand for 15 accepted single-pixel puts (the per-pixel record) iff every sum is valid as ImageBlock::put checks it and
+// every put covers exactly its expected pixel.
 template <class ACC>
-__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Lane &L, const ACC &A, int px, int py, int logSlot)
+__device__ __forceinline__ bool sample_is_fast(const FilmD &F, const FilterD &flt, Float sx, Float sy, const ACC &A, int px, int py)
+{
+    Float nonFinite = 0.0, lowest = 0.0;
+#pragma unroll
+    for (int k = 0; k < ACC_N; k++) { const Float v = A.get(k); nonFinite += v - v; if (k < ACC_GRAD) lowest = fmin(lowest, v); }
+    return nonFinite == 0.0 && !(lowest < 0.0) && F.fValues == nullptr && single_pixel(flt, sx, sy, px, py) && single_pixel(flt, sx - 1, sy, px - 1, py) &&
+           single_pixel(flt, sx + 1, sy, px + 1, py) && single_pixel(flt, sx, sy - 1, px, py - 1) && single_pixel(flt, sx, sy + 1, px, py + 1);
+}
+
+template <class ACC>
+__device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, Float sx, Float sy, const ACC &A, int px, int py, int logSlot, Float *pixelSums = nullptr)
 {
     if (F.log) {
         // a reconstruction filter wider than box: no put here -- the sample's sums and position go to the log, and k_gather_log
@@ -439,22 +471,23 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
         const size_t plane = (size_t)F.logRows * F.W, at = (size_t)logSlot * plane + (size_t)(py - F.logY0) * F.W + px, comp = (size_t)F.logChunk * plane;
 #pragma unroll
         for (int k = 0; k < ACC_N; k++) F.log[(size_t)k * comp + at] = A.get(k);
-        F.log[(size_t)30 * comp + at] = L.sx;
-        F.log[(size_t)31 * comp + at] = L.sy;
+        F.log[(size_t)30 * comp + at] = sx;
+        F.log[(size_t)31 * comp + at] = sy;
         return;
     }
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
     // (other reconstruction filters than box spread every put over several pixels: they always take the generic path)
     // The per-pixel sums stand for 15 puts that are all accepted.  A sample with a non-finite sum, or a negative throughput / very-direct
     // sum (only dx and dy accept negative values), takes the generic path, which checks every put as ImageBlock::put does.
-    Float nonFinite = 0.0, lowest = 0.0;
+    const bool fast = sample_is_fast(F, flt, sx, sy, A, px, py);
+    if (fast && pixelSums) {
+        // (k_fold_cont: the pixel's samples of a chunk are summed in registers, the record is touched once)
+        pixelSums[0] += 1.0;
 #pragma unroll
-    for (int k = 0; k < ACC_N; k++) { const Float v = A.get(k); nonFinite += v - v; if (k < ACC_GRAD) lowest = fmin(lowest, v); }
-    const bool allValid = nonFinite == 0.0 && !(lowest < 0.0);
-    const bool fast = allValid && F.fValues == nullptr && single_pixel(flt, L.sx, L.sy, px, py) && single_pixel(flt, L.sx - 1, L.sy, px - 1, py) &&
-                      single_pixel(flt, L.sx + 1, L.sy, px + 1, py) && single_pixel(flt, L.sx, L.sy - 1, px, py - 1) &&
-                      single_pixel(flt, L.sx, L.sy + 1, px, py + 1);
-    if (fast) {
+        for (int k = 0; k < 3; k++) { pixelSums[1 + k] += A.get(ACC_T + k); pixelSums[4 + k] += A.get(ACC_VD + k); }
+#pragma unroll
+        for (int k = 0; k < 12; k++) { pixelSums[7 + k] += A.get(ACC_NBR + k); pixelSums[19 + k] += A.get(ACC_GRAD + k); }
+    } else if (fast) {
         Float *r = F.rec + (size_t)(py - (F.y0 - 1)) * F.W + px;
         const size_t st = F.recStride;
         r[0] += 1.0;
@@ -469,7 +502,6 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
         }
     } else {
         const d3 T = A.get3(ACC_T), vd = A.get3(ACC_VD);
-        const Float sx = L.sx, sy = L.sy;
         spill_put(F, flt, sx, sy, (8 * vd) + (2 * T), 4.0, 0);
         spill_put(F, flt, sx - 1, sy, 2 * A.get3(ACC_NBR + 3 * LEFT), 1.0, 0);
         spill_put(F, flt, sx + 1, sy, 2 * A.get3(ACC_NBR + 3 * RIGHT), 1.0, 0);
@@ -488,28 +520,29 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
     }
 }
 
-template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
-__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
+// Block prologue shared by the render and the continuation kernel.  Dynamic LDS: [traversal stack: stackDepth x TBLK ints][per-sample
+// sums (ACC_LDS only)][staged scene tables (LDS_SCENE only)]; sized by the host from the actual BVH depth and table bytes so that small
+// scenes leave room for more resident blocks per CU.
+template <bool LDS_SCENE, bool ACC_LDS>
+__device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, unsigned char *s_dyn, SceneView &sv, int *&stack, unsigned char *&s_acc)
 {
-    // dynamic LDS: [traversal stack: stackDepth x TBLK ints][per-sample sums (ACC_LDS only)][staged scene tables (LDS_SCENE only)]; sized by the host from
-    // the actual BVH depth and table bytes so that small scenes leave room for more resident blocks per CU
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int *s_stack = reinterpret_cast<int *>(s_dyn);
-    unsigned char *s_acc = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
+    s_acc = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
     unsigned char *s_scene = s_acc + (ACC_LDS ? sizeof(Float) * ACC_N * TBLK : 0);
-    SceneView sv;
     if (LDS_SCENE) {
         // stage node packets, triangle records and the shading tables through LDS once per block (coalesced 16-byte copies);
         // the compile-time branch lets the compiler address them with ds_read instead of flat loads
-        const int nb[5] = {S.numNodes * (int)sizeof(BvhNode), S.numTris * (int)sizeof(TriIsect), S.numTris * (int)sizeof(TriShade),
-                           S.numMats * (int)sizeof(MaterialD), S.numEmitters * (int)sizeof(EmitterD)};
-        const void *src[5] = {S.nodes, S.isect, S.shade, S.mats, S.emitters};
-        int off = 0, offs[5];
-        for (int a = 0; a < 5; a++) {
+        // (every table is allocated in whole 16-byte words, see upload() on the host)
+        const int nb[8] = {S.numNodes * (int)sizeof(BvhNode), S.numTris * (int)sizeof(TriIsect), S.numTris * (int)sizeof(TriShade),
+                           S.numMats * (int)sizeof(MaterialD), S.numEmitters * (int)sizeof(EmitterD),
+                           S.numEmTris * (int)sizeof(EmTri), S.numEmCdf * (int)sizeof(Float), (S.numEmitters + 1) * (int)sizeof(Float)};
+        const void *src[8] = {S.nodes, S.isect, S.shade, S.mats, S.emitters, S.emTris, S.emCdf, S.emitterCdf};
+        int off = 0, offs[8];
+        for (int a = 0; a < 8; a++) {
             offs[a] = off;
             const uint4 *g = reinterpret_cast<const uint4 *>(src[a]);
             uint4 *l = reinterpret_cast<uint4 *>(s_scene + off);
-            for (int i = threadIdx.x; i < nb[a] / 16; i += TBLK) l[i] = g[i];
+            for (int i = threadIdx.x; i < (nb[a] + 15) / 16; i += TBLK) l[i] = g[i];
             off += (nb[a] + 15) & ~15;
         }
         __syncthreads();
@@ -518,9 +551,96 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         sv.shade = reinterpret_cast<const TriShade *>(s_scene + offs[2]);
         sv.mats = reinterpret_cast<const MaterialD *>(s_scene + offs[3]);
         sv.emitters = reinterpret_cast<const EmitterD *>(s_scene + offs[4]);
-    } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; }
+        sv.emTris = reinterpret_cast<const EmTri *>(s_scene + offs[5]);
+        sv.emCdf = reinterpret_cast<const Float *>(s_scene + offs[6]);
+        sv.emitterCdf = reinterpret_cast<const Float *>(s_scene + offs[7]);
+    } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; }
     sv.rootRef = S.rootRef; sv.boundM = S.boundM;
     sv.vn = S.vn;                      // per-vertex normals stay in HBM (scenes that have them are rarely LDS-resident)
+    stack = s_stack + threadIdx.x;
+}
+
+// ---- continuation records ---------------------------------------------------------------------------------------------------------
+// A sample leaves the general kernel as soon as each of its four offset paths is RAY_CONNECTED or dead (for diffuse and rough scenes:
+// after the second bounce).  From there the offsets are four (throughput, pdf) pairs that follow the base path arithmetically
+// (gpt.cpp:622-637,844-861), so the rest of the base path runs in k_continue: one small state per lane, one code path, waves refilled
+// from the queue as lanes finish -- instead of the general kernel's deep-bounce phase, where under half of a wave's lanes are alive and
+// every bounce drags the code of all three connection states along.  Record = NQ doubles, component-major ([k][slot]):
+//   0-2 throughput | 3 pdf | 4 eta | 5-7 v.p | 8-10 rayD | 11-12 v.u, v.v | 13 prim (low 32 bits), depth (high) -- all ones once finished |
+//   14 rng state | 15+4i..18+4i offset i: throughput, pdf | 31 alive mask | 32-61 the sample's 30 sums so far (finished: its final sums)
+constexpr unsigned long long Q_DONE = ~0ULL;
+template <class ACC>
+__device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lane &L, const ACC &A)
+{
+    Float *q = F.qRec + slot;
+    const size_t st = F.qCapacity;
+    q[0 * st] = L.throughput.x; q[1 * st] = L.throughput.y; q[2 * st] = L.throughput.z;
+    q[3 * st] = L.pdf; q[4 * st] = L.eta;
+    q[5 * st] = L.v.p.x; q[6 * st] = L.v.p.y; q[7 * st] = L.v.p.z;
+    q[8 * st] = L.rayD.x; q[9 * st] = L.rayD.y; q[10 * st] = L.rayD.z;
+    q[11 * st] = L.v.u; q[12 * st] = L.v.v;
+    q[13 * st] = __longlong_as_double((long long)(((unsigned long long)(unsigned)L.depth << 32) | (unsigned)L.v.prim));
+    q[14 * st] = __longlong_as_double((long long)L.rng.s);
+    unsigned alive = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const Offset &o = L.off[i];
+        q[(15 + 4 * i) * st] = o.throughput.x; q[(16 + 4 * i) * st] = o.throughput.y; q[(17 + 4 * i) * st] = o.throughput.z; q[(18 + 4 * i) * st] = o.pdf;
+        alive |= (o.alive ? 1u : 0u) << i;
+    }
+    q[31 * st] = __longlong_as_double((long long)alive);
+#pragma unroll
+    for (int k = 0; k < ACC_N; k++) q[(32 + k) * st] = A.get(k);
+}
+template <class ACC>
+__device__ __forceinline__ void q_load(const FilmD &F, unsigned slot, Lane &L, ACC &A)
+{
+    const Float *q = F.qRec + slot;
+    const size_t st = F.qCapacity;
+    L.throughput = mk(q[0 * st], q[1 * st], q[2 * st]);
+    L.pdf = q[3 * st]; L.eta = q[4 * st];
+    L.v.p = mk(q[5 * st], q[6 * st], q[7 * st]);
+    L.rayD = mk(q[8 * st], q[9 * st], q[10 * st]);
+    L.v.u = q[11 * st]; L.v.v = q[12 * st];
+    const unsigned long long pk = (unsigned long long)__double_as_longlong(q[13 * st]);
+    L.v.prim = (int)(unsigned)(pk & 0xffffffffu); L.depth = (int)(unsigned)(pk >> 32);
+    L.rng.s = (uint64_t)__double_as_longlong(q[14 * st]);
+    const unsigned alive = (unsigned)__double_as_longlong(q[31 * st]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        Offset &o = L.off[i];
+        o.throughput = mk(q[(15 + 4 * i) * st], q[(16 + 4 * i) * st], q[(17 + 4 * i) * st]); o.pdf = q[(18 + 4 * i) * st];
+        o.alive = (alive >> i) & 1; o.status = RAY_CONNECTED;
+    }
+#pragma unroll
+    for (int k = 0; k < ACC_N; k++) A.set(k, q[(32 + k) * st]);
+}
+// a sample that ended in the render kernel: its sums go to its slot like a continued one's (k_fold_cont adds them to the pixel)
+template <class ACC>
+__device__ __forceinline__ void q_finish(const FilmD &F, unsigned slot, const ACC &A)
+{
+    Float *q = F.qRec + slot;
+    const size_t st = F.qCapacity;
+#pragma unroll
+    for (int k = 0; k < ACC_N; k++) q[(32 + k) * st] = A.get(k);
+    q[13 * st] = __longlong_as_double((long long)Q_DONE);
+}
+__device__ __forceinline__ bool all_connected(const Lane &L)
+{
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) ok = ok && (!L.off[i].alive || L.off[i].status == RAY_CONNECTED);
+    return ok;
+}
+
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    SceneView sv;
+    int *stack;
+    unsigned char *s_acc;
+    block_setup<LDS_SCENE, ACC_LDS>(S, stackDepth, s_dyn, sv, stack, s_acc);
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // work item = (16x16 pixel tile, slice of the spp samples).  Slices exist so that a launch smaller than the chip (a strip of
@@ -531,7 +651,6 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     if (slice > 0) F.rec = F.recExtra + (size_t)(slice - 1) * NREC * F.recStride;
     const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool valid = px < rx1 && py < ry1;
-    int *stack = s_stack + threadIdx.x;
     const FilterD flt = box_filter();
 
     Lane L;
@@ -540,7 +659,8 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_acc) + threadIdx.x;
     int next = valid ? s0 : s1;         // next sample to start
     bool active = false;
-    bool pending = false;               // a finished sample whose sums still sit in A: flushed to the pixel record when the lane
+    unsigned slot = 0;                  // queue slot of the lane's current sample
+    bool pending = false;               // (no queue) a finished sample whose sums still sit in A: flushed to the pixel record when the lane
                                         // regenerates (together with >= regenMin others) or at the end -- not one lane at a time
                                         // (31 loads + 31 stores per flush; done per finished path they were ~1e9 wave-level memory
                                         // instructions per frame issued for one or two lanes each, with their latency exposed)
@@ -553,21 +673,33 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
             if (__hip_atomic_load(F.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { next = s1; continue; }   // cancelled: no new samples; running paths finish
-            if (pending) finish_path(F, flt, L, A, px, py, next - 1 - cfg.sBase);
-            active = start_path<ENV, SMOOTH, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A, px, py, next);
+            if (pending) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase);
+            slot = (unsigned)(next - cfg.sBase) * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
+            active = start_path<ENV, SMOOTH, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A, px, py, next, &F, slot);
             next++;
-            pending = !active;
-            if (!active) { paths++; pathLen += L.depth; }
+            if (!active) { paths++; pathLen += L.depth; if (F.qRec) q_finish(F, slot, A); else pending = true; }
         }
         if (active) {
-            if (!bounce<ENV, SMOOTH>(S, sv, cfg, stack, L, A)) {
+            if (!bounce<ENV, SMOOTH, false>(S, sv, cfg, stack, L, A)) {
                 active = false;
-                pending = true;
                 paths++; pathLen += L.depth;
+                // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
+                // chunk; without one they wait in A for the lane's next regeneration (`pending`)
+                if (F.qRec) q_finish(F, slot, A); else pending = true;
+            } else if (F.qRec && all_connected(L)) {
+                // every offset is connected or dead: the rest of this base path belongs to k_continue (the sums so far travel with it)
+                q_store(F, slot, L, A);
+                const unsigned long long mask = __ballot(true);
+                const int leader = __ffsll((unsigned long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&F.qCount[0], (unsigned)__popcll(mask));
+                base = __shfl(base, leader);
+                F.qList[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = slot;
+                active = false;
             }
         }
     }
-    if (pending) finish_path(F, flt, L, A, px, py, next - 1 - cfg.sBase);
+    if (pending) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase);
     // statistics: wave-level integer reduction, one atomic per wave and counter
     const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
     const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
@@ -576,6 +708,125 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         atomicAdd(&F.stats[1], (unsigned long long)c1);
         atomicAdd(&F.stats[2], (unsigned long long)c2);
         atomicAdd(&F.stats[3], (unsigned long long)c3);
+    }
+}
+
+// The five primary rays of every sample of the launch (evaluatePoint, gpt.cpp:397-436: the base ray and the four pixel-shifted ones),
+// traced ahead of the render kernel by a kernel that is traversal only: ~70 registers, 5+ waves per SIMD, coherent rays -- inside the
+// render kernel the same traversals run at 2 waves per SIMD under 256 registers of path state and were 30 % of its time.
+// One thread = one (pixel, sample); blockIdx = tile + tiles * (sample - sBase).
+template <bool LDS_SCENE>
+__global__ __launch_bounds__(TBLK) void k_primary(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int stackDepth)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    SceneView sv;
+    int *stack;
+    unsigned char *s_acc;
+    block_setup<LDS_SCENE, false>(S, stackDepth, s_dyn, sv, stack, s_acc);
+    const int tile = blockIdx.x % tiles, sRel = blockIdx.x / tiles, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= rx1 || py >= ry1) return;
+    Rng rng;
+    rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)(cfg.sBase + sRel));
+    const Float sx = px + rng.next1D(), sy = py + rng.next1D();                  // gpt.cpp:1261
+    const unsigned slot = (unsigned)sRel * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
+#pragma unroll 1
+    for (int r = 0; r < 5; r++) {
+        d3 o, d;
+        Float mint, maxt;
+        const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);     // gpt.cpp:410-415
+        camera_ray(S.cam, sx + ox, sy + oy, o, d, mint, maxt);
+        Hit h;
+        trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, h);
+        F.pHit[(size_t)(3 * r) * F.qCapacity + slot] = h.t;
+        F.pHit[(size_t)(3 * r + 1) * F.qCapacity + slot] = h.u;
+        F.pHit[(size_t)(3 * r + 2) * F.qCapacity + slot] = h.v;
+        F.pPrim[(size_t)r * F.qCapacity + slot] = h.prim;
+    }
+}
+
+// The continuation kernel: persistent waves that run handed-off base paths (all offsets connected or dead) to their end.  A lane that
+// finishes writes the sample's final sums back into its record and marks it; idle lanes take the next entries of the queue together
+// (one atomic per wave and refill), so waves stay dense whatever the path lengths are.
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, ConfigD cfg, FilmD F, int stackDepth, int refillMin)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    SceneView sv;
+    int *stack;
+    unsigned char *s_acc;
+    block_setup<LDS_SCENE, ACC_LDS>(S, stackDepth, s_dyn, sv, stack, s_acc);
+    const int lane = threadIdx.x & 63;
+    const unsigned total = __hip_atomic_load(&F.qCount[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Lane L;
+    L.nClosest = L.nShadow = 0;
+    L.depth = 0; L.v.prim = 0;
+    Acc<ACC_LDS> A;
+    if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_acc) + threadIdx.x;
+    bool active = false, exhausted = false;
+    unsigned slot = 0;
+    unsigned long long pathLen = 0, paths = 0;
+    while (true) {
+        const unsigned long long idleMask = __ballot(!active);
+        if (!exhausted && (__popcll(idleMask) >= refillMin || idleMask == ~0ULL)) {
+            const int leader = __ffsll((unsigned long long)idleMask) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&F.qCount[1], (unsigned)__popcll(idleMask));
+            base = __shfl(base, leader);
+            if (base + (unsigned)__popcll(idleMask) >= total) exhausted = true;        // (uniform: the queue has been handed out)
+            if (!active) {
+                const unsigned e = base + (unsigned)__popcll(idleMask & ((1ULL << lane) - 1ULL));
+                if (e < total) { slot = F.qList[e]; q_load(F, slot, L, A); active = true; }
+            }
+        }
+        if (__ballot(active) == 0) { if (exhausted) break; continue; }
+        if (active && !bounce<ENV, SMOOTH, true>(S, sv, cfg, stack, L, A)) {
+            active = false;
+            paths++; pathLen += L.depth;
+            q_finish(F, slot, A);
+        }
+    }
+    const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
+    const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
+    if (lane == 0) {
+        atomicAdd(&F.stats[0], (unsigned long long)c0);
+        atomicAdd(&F.stats[1], (unsigned long long)c1);
+        atomicAdd(&F.stats[2], (unsigned long long)c2);
+        atomicAdd(&F.stats[3], (unsigned long long)c3);
+    }
+}
+
+// finish_path for the samples of a chunk, all of which left their final sums in their queue slots (from the render kernel or from
+// k_continue): one thread per pixel of the launch adds them in sample order -- a fixed association, so a render is reproducible bit for
+// bit -- in registers, and touches the pixel's record once.  Reads are coalesced ([component][slot], consecutive lanes = consecutive slots).
+__global__ __launch_bounds__(TBLK) void k_fold_cont(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX)
+{
+    const int tile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= rx1 || py >= ry1) return;
+    const FilterD flt = box_filter();
+    const size_t st = F.qCapacity;
+    Float P[NREC];
+#pragma unroll
+    for (int k = 0; k < NREC; k++) P[k] = 0.0;
+    for (int s = 0; s < cfg.sCount; s++) {
+        const unsigned slot = (unsigned)s * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
+        const Float *q = F.qRec + slot;
+        if ((unsigned long long)__double_as_longlong(q[13 * st]) != Q_DONE) continue;         // (a cancelled frame: the sample was never started)
+        Acc<false> A;
+#pragma unroll
+        for (int k = 0; k < ACC_N; k++) A.a[k] = q[(32 + k) * st];
+        Rng rng;
+        rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)(cfg.sBase + s));
+        const Float sx = px + rng.next1D(), sy = py + rng.next1D();              // the sample's position, as start_path drew it (gpt.cpp:1261)
+        finish_path(F, flt, sx, sy, A, px, py, s, P);
+    }
+    if (P[0] != 0.0) {
+        Float *r = F.rec + (size_t)(py - (F.y0 - 1)) * F.W + px;
+#pragma unroll
+        for (int k = 0; k < NREC; k++) r[(size_t)k * F.recStride] += P[k];
     }
 }
 
@@ -712,7 +963,7 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     if (i >= n) return;
     const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
@@ -731,7 +982,7 @@ __global__ __launch_bounds__(TBLK) void k_trace_stats(SceneD S, int n, const Flo
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     TravCount c0 = {0, 0}, c1 = {0, 0};
     if (i < n) {
@@ -754,12 +1005,12 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
     bool active = start_path<true, true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
-    while (active) active = bounce<true, true>(S, sv, cfg, s_stack, L, A);
+    while (active) active = bounce<true, true, false>(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];

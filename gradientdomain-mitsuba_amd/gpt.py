@@ -185,6 +185,11 @@ class Film:
         lib().gdpt_film_render_ms.restype = C.c_float
         return float(lib().gdpt_film_render_ms(self._h))
 
+    def set_pipeline(self, stages, refill_lanes=0):
+        """Device staging of a render (2 = primary pass + general kernel + continuation kernel, the default; 1 = no primary pass;
+        0 = one kernel).  A tuning knob: results do not depend on it beyond rounding of the per-pixel sums."""
+        check(lib().gdpt_film_set_pipeline(self._h, int(stages), int(refill_lanes)))
+
     def set_occupancy(self, waves_per_simd):
         check(lib().gdpt_film_set_occupancy(self._h, int(waves_per_simd)))
 

@@ -148,6 +148,16 @@ GDPT_API void *gdpt_film_stream(gdpt_film *f);
  * 4-wave build); a negative value selects the same build with the
  * per-sample sums kept in registers instead of LDS.  Results are identical; only speed differs. */
 GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
+/* Tuning knob (no reference counterpart): how gdpt_render_rect is staged on the device.  stages = 2 (default): the five primary rays
+ * of every sample are traced by a traversal-only kernel (k_primary), the general kernel (k_render) walks a sample until each of its
+ * four offset paths is connected to the base path or dead (diffuse / rough scenes: two bounces), the rest of the base path runs in
+ * the continuation kernel (k_continue), and every sample's sums are added to its pixel once per chunk of samples (k_fold_cont).
+ * stages = 1: no separate primary pass.  stages = 0: everything in k_render (the round-1 form).  Samples, random numbers, ray counts
+ * and the order in which a pixel's samples are summed do not depend on the setting; results agree to rounding of the per-pixel sums.
+ * refillLanes: idle lanes of a wave of k_continue before they take new records together (0 = keep the current value, default 16).
+ * Environment: GDPT_NO_CONTINUATION / GDPT_NO_PRIMARY_PASS (set = off) and GDPT_QUEUE_MB (memory budget of the sample queue, default
+ * 24576) override at render time. */
+GDPT_API int  gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes);
 /* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/<type>.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
  * (default: every put covers one pixel, the per-pixel-sums fast path), TENT, GAUSSIAN (p0 = stddev, 0.5), MITCHELL (p0 = B, p1 = C,
  * 1/3 each), CATMULLROM, LANCZOS (p0 = lobes, 3).  The wider filters log every sample and gather the puts per receiving pixel

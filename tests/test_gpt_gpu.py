@@ -419,15 +419,24 @@ def test_full_size_properties_1280x720x64(G):
     inner = acc[1][1:-1, 1:-1, 3]
     assert np.median(inner) == pytest.approx(8 * spp * c2, rel=1e-12) and (np.abs(inner - 8 * spp * c2) < 10 * c2).all()
     assert (acc[4][..., :3] >= 0).all() and (acc[1][..., :3] >= -1e-12).all()
-    # tiles rendered in pieces into one film == the one-call film, bit for bit where no edge-sample atomics landed
-    # (sample slices off: a smaller launch would otherwise split its spp over several work items and fold their sums, which
-    # changes the association of the fp64 sums, not the samples)
+    # tiles rendered in pieces into one film == the one-call film: same samples, same ray counts; a pixel's samples are summed per
+    # chunk of the sample queue (gdpt_film_set_pipeline) and the chunk length follows the launch's pixel count, so the fp64 sums of
+    # differently shaped launches agree to rounding -- and bit for bit once the chunking is the same (everything in one kernel)
     F2 = G.Film(S); F2.set_slices(1)
     for (x0, y0, x1, y1) in ((0, 0, 640, 360), (640, 0, 1280, 360), (0, 360, 1280, 720)):
         integ.renderBlock(S, F2, cfg, (x0, y0, x1, y1))
     acc2 = F2.accum()
-    assert np.allclose(acc2, acc, rtol=1e-13, atol=1e-13) and (acc2 == acc).mean() > 0.999
+    assert np.allclose(acc2, acc, rtol=1e-13, atol=1e-13) and F2.stats() == st
     F2.close()
+    Fa, Fb = G.Film(S), G.Film(S)
+    for f in (Fa, Fb):
+        f.set_pipeline(0); f.set_slices(1)
+    integ.renderBlock(S, Fa, cfg, (0, 0, W, H))
+    for (x0, y0, x1, y1) in ((0, 0, 640, 360), (640, 0, 1280, 360), (0, 360, 1280, 720)):
+        integ.renderBlock(S, Fb, cfg, (x0, y0, x1, y1))
+    a0, b0 = Fa.accum(), Fb.accum()
+    assert (a0 == b0).mean() > 0.999 and np.allclose(a0, acc, rtol=1e-13, atol=1e-13) and Fa.stats() == st       # (the edge-sample atomics are the 0.1 %)
+    Fa.close(); Fb.close()
     # the same with the launch's own choice of slices, and with a forced 5 (64 spp does not divide evenly): same samples, same
     # ray counts, sums equal to rounding; and reproducible bit for bit run to run
     for slices in (0, 5):
@@ -623,3 +632,63 @@ def test_invalid_puts_are_dropped_like_imageblock_put(G, radiance, rfilter):
         assert close(acc[b], oacc[b]), G.BUFFER_NAMES[b]
     out = integ.render(S, spp)                                   # the reconstruction stays finite
     assert all(np.isfinite(v).all() for v in out.values())
+
+
+def _pipeline_cases():
+    env = lambda: scenes.cornell_box(48, 40, "glossy", environment=(0.6, 0.7, 0.9))
+    gauss = lambda: _with_rfilter(scenes.cornell_box(48, 40, "diffuse"), scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN])
+    return [("diffuse", lambda: scenes.cornell_box(48, 40, "diffuse"), dict(maxDepth=-1)),
+            ("glossy", lambda: scenes.cornell_box(48, 40, "glossy"), dict(maxDepth=12)),
+            ("glass", lambda: scenes.cornell_box(48, 40, "glass"), dict(maxDepth=14)),          # specular chains: offsets stay unconnected for many bounces
+            ("nearspecular-strict", lambda: scenes.cornell_box(48, 40, "nearspecular"), dict(maxDepth=10, strictNormals=True)),
+            ("bent-normals-strict", lambda: scenes.cornell_box(48, 40, "bent"), dict(maxDepth=9, strictNormals=True)),
+            ("environment", env, dict(maxDepth=8)),
+            ("gaussian-film", gauss, dict(maxDepth=6)),
+            ("atrium", lambda: scenes.atrium(64, 36, columns=8, segments=12), dict(maxDepth=-1))]
+
+
+def _with_rfilter(sc, rf):
+    sc.rfilter = rf
+    return sc
+
+
+@pytest.mark.parametrize("name,builder,kw", _pipeline_cases(), ids=[c[0] for c in _pipeline_cases()])
+def test_staged_pipeline_equals_the_single_kernel_and_the_oracle(G, name, builder, kw):
+    """gdpt_film_set_pipeline: primary pass + general kernel + continuation kernel + per-chunk fold (the default) against everything in
+    one kernel (the round-1 form) and against the oracle: identical ray counts and path statistics, films equal to rounding of the
+    per-pixel sums; forced small queue chunks (several chunks per launch) and sample slices give the same; reproducible run to run."""
+    import os
+    sc = builder()
+    W, H, spp = sc.width, sc.height, 5
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(**kw)
+    cfg = integ.config(spp)
+    out = {}
+    for stages in (0, 1, 2):
+        F = G.Film(S); F.set_pipeline(stages)
+        integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        out[stages] = (F.accum(), F.stats(), F.invalid_puts())
+        F.close()
+    oacc, orays = O.render(go.config(spp=spp, **kw))
+    for stages in (0, 1, 2):
+        acc, st, inv = out[stages]
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays, stages
+        assert st == out[0][1] and inv == out[0][2] == O.invalid_puts()
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (stages, G.BUFFER_NAMES[b])
+            assert close(acc[b], out[0][0][b], 1e-12), (stages, G.BUFFER_NAMES[b])
+    # several queue chunks per launch (1 MB budget -> one sample per chunk), odd refill threshold, sample slices
+    os.environ["GDPT_QUEUE_MB"] = "1"
+    try:
+        runs = []
+        for rep in range(2):
+            F = G.Film(S); F.set_pipeline(2, 7); F.set_slices(2)
+            integ.renderBlock(S, F, cfg, (0, 0, W, H))
+            runs.append((F.accum(), F.stats()))
+            F.close()
+    finally:
+        del os.environ["GDPT_QUEUE_MB"]
+    assert runs[0][1] == out[0][1] and (runs[0][0] == runs[1][0]).mean() > 0.999       # (filter-edge samples go through fp64 atomics)
+    for b in range(5):
+        assert close(runs[0][0][b], out[2][0][b], 1e-12), G.BUFFER_NAMES[b]
+    S.close(); O.close()
