@@ -435,9 +435,12 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
     return GDPT_OK;
 }
 
+int gdpt_scene_device(const gdpt_scene *s) { return s ? s->device : -1; }
+
 void gdpt_scene_destroy(gdpt_scene *s)
 {
     if (!s) return;
+    (void)hipSetDevice(s->device);
     for (void *p : s->allocs) if (p) hipFree(p);
     delete s;
 }
@@ -447,6 +450,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     if (!s || !out) return tfail(GDPT_ERR_INVALID, "film_create: null argument");
     const int W = s->d.cam.width, H = s->d.cam.height;
     if (y0 < 0 || y1 > H || y0 >= y1) return tfail(GDPT_ERR_INVALID, "film_create: rows [%d,%d) outside the %dx%d film", y0, y1, W, H);
+    THIPCHK(hipSetDevice(s->device));
     gdpt_film *f = new gdpt_film;
     f->scene = s;
     f->wavesPerSimd = s->d.ldsScene ? 2 : 4;    // measured: LDS-resident scenes peak at 2 waves/SIMD, HBM-resident BVHs want 4
@@ -474,6 +478,7 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
 void gdpt_film_destroy(gdpt_film *f)
 {
     if (!f) return;
+    if (f->scene) (void)hipSetDevice(f->scene->device);
     if (f->stream) hipStreamSynchronize(f->stream);
     for (auto &e : f->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (f->d.rec) hipFree(f->d.rec);
@@ -497,6 +502,7 @@ void gdpt_film_destroy(gdpt_film *f)
 int gdpt_film_clear(gdpt_film *f)
 {
     if (!f) return tfail(GDPT_ERR_INVALID, "null film");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     FilmD &d = f->d;
     THIPCHK(hipMemsetAsync(d.rec, 0, sizeof(Float) * NREC * d.recStride, f->stream));
     THIPCHK(hipMemsetAsync(d.spill, 0, sizeof(Float) * 5 * d.recStride * 4, f->stream));
@@ -514,6 +520,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     if (!s || !cfg || !f || f->scene != s) return tfail(GDPT_ERR_INVALID, "render_rect: null argument or film of another scene");
     if (x0 < 0 || x1 > f->d.W || x0 >= x1 || y0 < f->d.y0 || y1 > f->d.y1 || y0 >= y1) return tfail(GDPT_ERR_INVALID, "render_rect: rectangle outside the film rows");
     if (cfg->spp <= 0) return tfail(GDPT_ERR_INVALID, "spp must be positive");
+    THIPCHK(hipSetDevice(s->device));
     if (cfg->maxDepth <= 0 && cfg->maxDepth != -1) return tfail(GDPT_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); // gpt.cpp:1212
     if (s->bvhDepth >= STACK_DEPTH) return tfail(GDPT_ERR_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", s->bvhDepth);
     ConfigD c;
@@ -654,6 +661,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 int gdpt_film_cancel(gdpt_film *f)
 {
     if (!f) return tfail(GDPT_ERR_INVALID, "null film");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     static const int one = 1;
     THIPCHK(hipMemcpyAsync(f->cancelFlag, &one, sizeof(int), hipMemcpyHostToDevice, f->cancelStream));
     THIPCHK(hipStreamSynchronize(f->cancelStream));
@@ -663,6 +671,7 @@ int gdpt_film_cancel(gdpt_film *f)
 int gdpt_film_cancelled(gdpt_film *f, int *out)
 {
     if (!f || !out) return tfail(GDPT_ERR_INVALID, "film_cancelled: null argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     THIPCHK(hipMemcpyAsync(out, f->cancelFlag, sizeof(int), hipMemcpyDeviceToHost, f->cancelStream));
     THIPCHK(hipStreamSynchronize(f->cancelStream));
     return GDPT_OK;
@@ -671,6 +680,7 @@ int gdpt_film_cancelled(gdpt_film *f, int *out)
 int gdpt_film_sync(gdpt_film *f)
 {
     if (!f) return tfail(GDPT_ERR_INVALID, "null film");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     THIPCHK(hipStreamSynchronize(f->stream));
     return GDPT_OK;
 }
@@ -688,6 +698,7 @@ static int ensure_resolved(gdpt_film *f)
 int gdpt_film_halo_bytes(gdpt_film *f, size_t *bytes)
 {
     if (!f || !bytes) return tfail(GDPT_ERR_INVALID, "null argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     *bytes = sizeof(Float) * ((size_t)NREC * f->d.W + (size_t)5 * f->d.W * 4);
     return GDPT_OK;
 }
@@ -695,6 +706,7 @@ int gdpt_film_halo_bytes(gdpt_film *f, size_t *bytes)
 int gdpt_film_pack_halo(gdpt_film *f, int which, void *devBuf)
 {
     if (!f || !devBuf || which < 0 || which > 1) return tfail(GDPT_ERR_INVALID, "pack_halo: bad argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     hipLaunchKernelGGL(k_pack_halo, dim3(64), dim3(TBLK), 0, f->stream, f->d, which, (Float *)devBuf);
     THIPCHK(hipGetLastError());
     THIPCHK(hipStreamSynchronize(f->stream));
@@ -704,6 +716,7 @@ int gdpt_film_pack_halo(gdpt_film *f, int which, void *devBuf)
 int gdpt_film_unpack_halo(gdpt_film *f, int which, const void *devBuf)
 {
     if (!f || !devBuf || which < 0 || which > 1) return tfail(GDPT_ERR_INVALID, "unpack_halo: bad argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     hipLaunchKernelGGL(k_unpack_halo, dim3(64), dim3(TBLK), 0, f->stream, f->d, which, (const Float *)devBuf);
     THIPCHK(hipGetLastError());
     THIPCHK(hipStreamSynchronize(f->stream));
@@ -714,6 +727,7 @@ int gdpt_film_unpack_halo(gdpt_film *f, int which, const void *devBuf)
 int gdpt_film_accum(gdpt_film *f, double *accum)
 {
     if (!f || !accum) return tfail(GDPT_ERR_INVALID, "film_accum: null argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     int rc = ensure_resolved(f);
     if (rc) return rc;
     THIPCHK(hipMemcpyAsync(accum, f->accum, sizeof(Float) * 5 * (size_t)(f->d.y1 - f->d.y0) * f->d.W * 4, hipMemcpyDeviceToHost, f->stream));
@@ -724,6 +738,7 @@ int gdpt_film_accum(gdpt_film *f, double *accum)
 int gdpt_film_develop_device(gdpt_film *f, int buffer, float *rgbDevice)
 {
     if (!f || !rgbDevice || buffer < 0 || buffer > 4) return tfail(GDPT_ERR_INVALID, "film_develop: bad argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     int rc = ensure_resolved(f);
     if (rc) return rc;
     const int n = (f->d.y1 - f->d.y0) * f->d.W;
@@ -736,6 +751,7 @@ int gdpt_film_develop_device(gdpt_film *f, int buffer, float *rgbDevice)
 int gdpt_film_develop(gdpt_film *f, int buffer, float *rgbHost)
 {
     if (!f || !rgbHost) return tfail(GDPT_ERR_INVALID, "film_develop: null argument");
+    (void)hipSetDevice(f->scene->device);
     const size_t n = (size_t)(f->d.y1 - f->d.y0) * f->d.W;
     float *tmp = nullptr;
     THIPCHK(hipMalloc((void **)&tmp, sizeof(float) * 3 * n));
@@ -748,6 +764,7 @@ int gdpt_film_develop(gdpt_film *f, int buffer, float *rgbHost)
 int gdpt_film_stats(gdpt_film *f, unsigned long long stats[4])
 {
     if (!f || !stats) return tfail(GDPT_ERR_INVALID, "null argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     THIPCHK(hipStreamSynchronize(f->stream));
     THIPCHK(hipMemcpy(stats, f->d.stats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
     return GDPT_OK;
@@ -756,6 +773,7 @@ int gdpt_film_stats(gdpt_film *f, unsigned long long stats[4])
 int gdpt_film_invalid_puts(gdpt_film *f, unsigned long long *count)
 {
     if (!f || !count) return tfail(GDPT_ERR_INVALID, "null argument");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     THIPCHK(hipStreamSynchronize(f->stream));
     THIPCHK(hipMemcpy(count, f->d.stats + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return GDPT_OK;
@@ -764,6 +782,7 @@ int gdpt_film_invalid_puts(gdpt_film *f, unsigned long long *count)
 float gdpt_film_render_ms(gdpt_film *f)
 {
     if (!f) return 0.0f;
+    (void)hipSetDevice(f->scene->device);
     hipStreamSynchronize(f->stream);
     float total = 0.0f;
     for (auto &e : f->events) { float ms = 0.0f; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) total += ms; }
@@ -801,6 +820,7 @@ static double rfilter_eval(int kind, double p0, double p1, double radius, double
 int gdpt_film_set_rfilter(gdpt_film *f, int kind, double p0, double p1)
 {
     if (!f || kind < GDPT_RFILTER_BOX || kind > GDPT_RFILTER_LANCZOS) return tfail(GDPT_ERR_INVALID, "set_rfilter: unknown reconstruction filter");
+    (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     THIPCHK(hipStreamSynchronize(f->stream));
     if (f->d.fValues) { hipFree((void *)f->d.fValues); f->d.fValues = nullptr; }
     if (f->d.log) { hipFree(f->d.log); f->d.log = nullptr; f->d.logChunk = 0; }

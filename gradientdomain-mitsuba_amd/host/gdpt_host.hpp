@@ -19,6 +19,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace gdpt {
@@ -276,9 +277,15 @@ public:
             logError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
     }
 
+    /// The GPUs a frame is sharded over (row strips + one-pixel halo, the multi-GPU form of the block scheduler: imageproc.cpp:28-78,
+    /// gpt_proc.cpp:52-56,137-149).  Device ordinals; an ordinal may repeat (several strips on one GPU: functional runs).  Empty or
+    /// one entry: the single-device path.  gdpt_mitsuba's -p sets it.
+    void setDevices(const std::vector<int> &devices) { m_devices = devices; }
+
     /// render (gpt.cpp:1358-1480): five buffers, blocks, develop, reconstruct, -final := reconstruction.
     bool render(const SceneData &sd, MultiFilm &film, int sampleCount, unsigned long long seed, std::string &log)
     {
+        if (m_devices.size() > 1) return renderStrips(sd, film, sampleCount, seed, log);
         if (m_hideEmitters) logError("Option 'hideEmitters' not implemented for Gradient-Domain Path Tracing!");
         const std::vector<std::string> outNames = {"-final", "-throughput", "-dx", "-dy", "-direct"};
         if (!film.setBuffers(outNames)) logError("Cannot render image! G-PT has been called without MultiFilm.");
@@ -291,14 +298,9 @@ public:
                                    (int)sd.materials.size(), sd.materials.data(), (int)sd.emitters.size(), sd.emitters.data(),
                                    sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, -1, &scene));
         check(gdpt_film_create(scene, 0, H, &gf));
-        {   // <rfilter>: src/rfilters/*.cpp with their default parameters
-            const std::string ft = sd.rfilter.getPluginName();
+        {
             int kind = GDPT_RFILTER_BOX; double p0 = 0, p1 = 0;
-            if (ft == "tent") kind = GDPT_RFILTER_TENT;
-            else if (ft == "gaussian") { kind = GDPT_RFILTER_GAUSSIAN; p0 = sd.rfilter.getFloat("stddev", 0.5); }
-            else if (ft == "mitchell") { kind = GDPT_RFILTER_MITCHELL; p0 = sd.rfilter.getFloat("B", 1.0 / 3.0); p1 = sd.rfilter.getFloat("C", 1.0 / 3.0); }
-            else if (ft == "catmullrom") kind = GDPT_RFILTER_CATMULLROM;
-            else if (ft == "lanczos") { kind = GDPT_RFILTER_LANCZOS; p0 = (double)sd.rfilter.getInteger("lobes", 3); }
+            rfilterOf(sd, kind, p0, p1);
             check(gdpt_film_set_rfilter(gf, kind, p0, p1));
         }
         gdpt_config cfg;
@@ -342,6 +344,135 @@ public:
         return true;
     }
 
+    /// One frame over several GPUs of the node, from ONE process: a thread per strip uploads the scene to its device and renders its rows
+    /// (GPTBlockRenderer::process over the strip); neighbouring strips then settle their one-pixel borders -- each ships its boundary
+    /// row's per-pixel sums and the exact puts it made into the neighbour's row (gdpt_film_pack_halo / unpack_halo), device to device over
+    /// xGMI (gdpt_device_copy = hipMemcpyPeer) -- every strip develops its rows of the five buffers on its own device, the solver inputs are
+    /// gathered on the first device by peer copies, and that device reconstructs.  With a reconstruction filter wider than box a strip
+    /// renders the filter's reach itself and nothing is exchanged (gdpt_film_set_rfilter).  Same strips, payloads and order as
+    /// parallel.StripRenderer (the one-process-per-GPU form over RCCL); samples depend on (seed, pixel, sample index) only, so the image
+    /// does not depend on the number of devices beyond the rounding of the border sums.
+    bool renderStrips(const SceneData &sd, MultiFilm &film, int sampleCount, unsigned long long seed, std::string &log)
+    {
+        if (m_hideEmitters) logError("Option 'hideEmitters' not implemented for Gradient-Domain Path Tracing!");
+        const std::vector<std::string> outNames = {"-final", "-throughput", "-dx", "-dy", "-direct"};
+        if (!film.setBuffers(outNames)) logError("Cannot render image! G-PT has been called without MultiFilm.");
+        const int W = film.getWidth(), H = film.getHeight(), N = (int)m_devices.size();
+        if (N > H) logError("more devices than image rows");
+        struct Strip { int device = 0, y0 = 0, y1 = 0; gdpt_scene *scene = nullptr; gdpt_film *film = nullptr; void *out[2] = {nullptr, nullptr}, *in[2] = {nullptr, nullptr}; float *imgs = nullptr; std::string error; };
+        std::vector<Strip> strips(N);
+        for (int r = 0, y = 0; r < N; ++r) {                       // contiguous rows, earlier strips take the remainder (parallel.row_strips)
+            const int n = H / N + (r < H % N ? 1 : 0);
+            strips[r].device = m_devices[r]; strips[r].y0 = y; strips[r].y1 = y + n; y += n;
+        }
+        std::vector<double> normals = sd.normals;
+        if (!normals.empty()) normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
+        gdpt_config cfg;
+        cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;
+        cfg.shiftThreshold = m_shiftThreshold; cfg.seed = seed;
+        int kind = GDPT_RFILTER_BOX; double p0 = 0, p1 = 0;
+        rfilterOf(sd, kind, p0, p1);
+        log += format("Starting render job (GPT::render) (%ix%i, %i %s, %d strips on %d MI355X) ..\n", W, H, sampleCount, sampleCount == 1 ? "sample" : "samples", N, N);
+        auto cleanup = [&]() {
+            for (Strip &s : strips) {
+                for (int k = 0; k < 2; ++k) { gdpt_device_free(s.device, s.out[k]); gdpt_device_free(s.device, s.in[k]); }
+                gdpt_device_free(s.device, s.imgs);
+                gdpt_film_destroy(s.film);
+                gdpt_scene_destroy(s.scene);
+            }
+        };
+        // (1) one thread per strip: scene upload + render
+        std::vector<std::thread> workers;
+        for (int r = 0; r < N; ++r)
+            workers.emplace_back([&, r]() {
+                Strip &s = strips[r];
+                try {
+                    check(gdpt_scene_create_ex(sd.numTriangles(), sd.verts.data(), normals.empty() ? nullptr : normals.data(), sd.triMaterial.data(),
+                                               (int)sd.materials.size(), sd.materials.data(), (int)sd.emitters.size(), sd.emitters.data(),
+                                               sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, s.device, &s.scene));
+                    check(gdpt_film_create(s.scene, s.y0, s.y1, &s.film));
+                    check(gdpt_film_set_rfilter(s.film, kind, p0, p1));
+                    check(gdpt_render_rect(s.scene, &cfg, 0, s.y0, W, s.y1, s.film));
+                    check(gdpt_film_sync(s.film));
+                } catch (const std::exception &e) { s.error = e.what(); }
+            });
+        for (std::thread &t : workers) t.join();
+        for (const Strip &s : strips) if (!s.error.empty()) { const std::string e = s.error; cleanup(); logError(e); }
+        try {
+            // (2) borders: box filter only (wider filters: the strips rendered the reach themselves)
+            size_t haloBytes = 0;
+            if (kind == GDPT_RFILTER_BOX) {
+                check(gdpt_film_halo_bytes(strips[0].film, &haloBytes));
+                for (int r = 0; r < N; ++r)
+                    for (int which = 0; which < 2; ++which) {
+                        const int peer = which == 0 ? r - 1 : r + 1;
+                        if (peer < 0 || peer >= N) continue;
+                        check(gdpt_device_alloc(strips[r].device, haloBytes, &strips[r].out[which]));
+                        check(gdpt_device_alloc(strips[r].device, haloBytes, &strips[r].in[which]));
+                        check(gdpt_film_pack_halo(strips[r].film, which, strips[r].out[which]));         // every strip packs before anyone unpacks
+                    }
+                for (int r = 0; r + 1 < N; ++r) {
+                    check(gdpt_device_copy(strips[r + 1].device, strips[r + 1].in[0], strips[r].device, strips[r].out[1], haloBytes));      // down
+                    check(gdpt_device_copy(strips[r].device, strips[r].in[1], strips[r + 1].device, strips[r + 1].out[0], haloBytes));      // up
+                }
+                for (int r = 0; r < N; ++r)
+                    for (int which = 0; which < 2; ++which)
+                        if (strips[r].in[which]) check(gdpt_film_unpack_halo(strips[r].film, which, strips[r].in[which]));
+            }
+            // (3) develop on every device, gather the five images on the first one
+            const int d0 = strips[0].device;
+            const size_t imgFloats = (size_t)3 * W * H;
+            void *full = nullptr;
+            check(gdpt_device_alloc(d0, sizeof(float) * 5 * imgFloats, &full));
+            float *fullImgs = static_cast<float *>(full);
+            try {
+                for (Strip &s : strips) {
+                    const size_t rows = (size_t)(s.y1 - s.y0), stripFloats = 3 * rows * W;
+                    void *p = nullptr;
+                    check(gdpt_device_alloc(s.device, sizeof(float) * 5 * stripFloats, &p));
+                    s.imgs = static_cast<float *>(p);
+                    for (int b = 0; b < 5; ++b) {
+                        check(gdpt_film_develop_device(s.film, b, s.imgs + b * stripFloats));
+                        check(gdpt_device_copy(d0, fullImgs + b * imgFloats + (size_t)3 * W * s.y0, s.device, s.imgs + b * stripFloats, sizeof(float) * stripFloats));
+                    }
+                }
+                for (int b = 0; b < 5; ++b) check(gdpt_device_download(d0, film.buffer(b).data(), fullImgs + b * imgFloats, sizeof(float) * imgFloats));
+                // statistics and timing: sums over the strips, the slowest strip's render time
+                unsigned long long tot[4] = {0, 0, 0, 0};
+                float slowest = 0.0f;
+                for (Strip &s : strips) {
+                    unsigned long long st[4];
+                    check(gdpt_film_stats(s.film, st));
+                    for (int k = 0; k < 4; ++k) tot[k] += st[k];
+                    const float ms = gdpt_film_render_ms(s.film);
+                    log += format("  strip rows [%d, %d) on device %d: %.3f s\n", s.y0, s.y1, s.device, ms * 1e-3);
+                    slowest = std::max(slowest, ms);
+                }
+                m_stats.raysTraced = tot[0]; m_stats.shadowRaysTraced = tot[1]; m_stats.paths = tot[2]; m_stats.pathLengthSum = tot[3];
+                log += format("Render time: %.3f s (slowest strip), %llu rays + %llu shadow rays (%.1f Mray/s), average path length %.3f, halo %zu bytes per border\n", slowest * 1e-3, tot[0], tot[1],
+                              (tot[0] + tot[1]) / (slowest * 1e3), tot[2] ? (double)tot[3] / tot[2] : 0.0, haloBytes);
+                // (4) reconstruction on the first device, inputs already resident there (gpt.cpp:1415-1476)
+                if (m_reconstructL1 || m_reconstructL2) {
+                    poisson::Solver::Params params;
+                    params.setConfigPreset(m_reconstructL1 ? "L1D" : "L2D");
+                    params.alpha = (float)m_reconstructAlpha;
+                    params.cudaDevice = d0;
+                    params.setLogFunction([&log](const std::string &m) { log += m; });
+                    poisson::Solver solver(params);
+                    std::vector<float> rec(imgFloats);
+                    solver.importImagesDevice(fullImgs + 2 * imgFloats, fullImgs + 3 * imgFloats, fullImgs + 1 * imgFloats, fullImgs + 4 * imgFloats, W, H);
+                    solver.setupBackend();
+                    solver.solveIndirect();
+                    solver.exportImagesMTS(rec.data());
+                    film.buffer(0) = rec;
+                }
+            } catch (...) { gdpt_device_free(d0, full); throw; }
+            gdpt_device_free(d0, full);
+        } catch (...) { cleanup(); throw; }
+        cleanup();
+        return true;
+    }
+
     /// Integrator::cancel (integrator.h:88): callable from another thread while render() runs.
     void cancel()
     {
@@ -352,6 +483,19 @@ public:
     const Statistics &getStatistics() const { return m_stats; }
 
 private:
+    /// <rfilter>: src/rfilters/*.cpp with their default parameters
+    static void rfilterOf(const SceneData &sd, int &kind, double &p0, double &p1)
+    {
+        const std::string ft = sd.rfilter.getPluginName();
+        kind = GDPT_RFILTER_BOX; p0 = 0; p1 = 0;
+        if (ft == "tent") kind = GDPT_RFILTER_TENT;
+        else if (ft == "gaussian") { kind = GDPT_RFILTER_GAUSSIAN; p0 = sd.rfilter.getFloat("stddev", 0.5); }
+        else if (ft == "mitchell") { kind = GDPT_RFILTER_MITCHELL; p0 = sd.rfilter.getFloat("B", 1.0 / 3.0); p1 = sd.rfilter.getFloat("C", 1.0 / 3.0); }
+        else if (ft == "catmullrom") kind = GDPT_RFILTER_CATMULLROM;
+        else if (ft == "lanczos") { kind = GDPT_RFILTER_LANCZOS; p0 = (double)sd.rfilter.getInteger("lobes", 3); }
+    }
+
+    std::vector<int> m_devices;
     Statistics m_stats;
     std::atomic<gdpt_film *> m_film{nullptr};
     int m_maxDepth, m_rrDepth;

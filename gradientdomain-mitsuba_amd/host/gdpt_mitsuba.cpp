@@ -2,7 +2,10 @@
 // (/root/reference/src/mitsuba/mitsuba.cpp:154-250): gdpt_mitsuba [-o dest] [-D key=val]... [-p n] [-b n] [-x] [-q] scene.xml
 //   -o  output destination stem: writes <dest>-final|-throughput|-dx|-dy|-direct.{exr|pfm} and <dest>-log.txt, <dest>-stats.txt (multifilm.cpp:453-517)
 //   -D  parameter substitution for $key in the scene file
-//   -p, -b  accepted for compatibility (CPU core count / block size have no meaning for the GPU path) and ignored
+//   -p  the reference's "number of local worker cores" (mitsuba.cpp:187-194) = here the number of GPUs the frame is sharded over: row strips
+//       with a one-pixel halo exchanged device to device (host/gdpt_host.hpp renderStrips); more strips than visible GPUs wrap around (a
+//       functional run with several strips per device).  --devices a,b,c names the ordinals explicitly.
+//   -b  accepted for compatibility (the block size has no meaning for the GPU path) and ignored
 //   -x  skip rendering if <dest>-final.pfm exists;  -q  quiet;  --parse-only  load the scene, print a summary, do not touch the GPU
 #include "scene_xml.hpp"
 
@@ -13,6 +16,8 @@ int main(int argc, char **argv)
     std::string dest, scenePath;
     bool skipExisting = false, quiet = false, parseOnly = false;
     unsigned long long seed = 5489;     // include/mitsuba/core/random.h:113
+    int numDevices = 1;
+    std::vector<int> deviceList;
     gdpt::SceneLoader loader;
     try {
         for (int i = 1; i < argc; ++i) {
@@ -21,7 +26,9 @@ int main(int argc, char **argv)
             if (a == "-o") dest = need("-o");
             else if (a == "-D") { const std::string kv = need("-D"); const size_t eq = kv.find('='); if (eq == std::string::npos) gdpt::logError("-D expects key=value"); loader.params[kv.substr(0, eq)] = kv.substr(eq + 1); }
             else if (a.rfind("-D", 0) == 0 && a.size() > 2) { const std::string kv = a.substr(2); const size_t eq = kv.find('='); if (eq == std::string::npos) gdpt::logError("-D expects key=value"); loader.params[kv.substr(0, eq)] = kv.substr(eq + 1); }
-            else if (a == "-p" || a == "-b") need(a.c_str());
+            else if (a == "-p") { numDevices = std::stoi(need("-p")); if (numDevices < 1) gdpt::logError("-p expects a positive number"); }
+            else if (a == "--devices") { const std::string l = need("--devices"); size_t at = 0; while (at <= l.size()) { const size_t c = l.find(',', at); deviceList.push_back(std::stoi(l.substr(at, c == std::string::npos ? std::string::npos : c - at))); if (c == std::string::npos) break; at = c + 1; } }
+            else if (a == "-b") need(a.c_str());
             else if (a == "-x") skipExisting = true;
             else if (a == "-q") quiet = true;
             else if (a == "--seed") seed = std::stoull(need("--seed"));
@@ -38,7 +45,7 @@ int main(int argc, char **argv)
                 if (!gdpt::ExrWriter::write(out, img.data(), w, h, fmt == "float16")) gdpt::logError("cannot write " + out);
                 return 0;
             }
-            else if (a == "-h" || a == "--help") { printf("usage: gdpt_mitsuba [-o dest] [-D key=val] [-p n] [-b n] [-x] [-q] [--seed n] [--parse-only] scene.xml\n"); return 0; }
+            else if (a == "-h" || a == "--help") { printf("usage: gdpt_mitsuba [-o dest] [-D key=val] [-p gpus] [--devices a,b,..] [-b n] [-x] [-q] [--seed n] [--parse-only] scene.xml\n"); return 0; }
             else if (a[0] == '-') gdpt::logError("unknown option " + a);
             else scenePath = a;
         }
@@ -65,6 +72,13 @@ int main(int argc, char **argv)
         struct stat stt;
         if (skipExisting && (stat((dest + "-final.pfm").c_str(), &stt) == 0 || stat((dest + "-final.exr").c_str(), &stt) == 0)) { if (!quiet) printf("Skipping %s (output exists)\n", scenePath.c_str()); return 0; }
         gdpt::GradientPathIntegrator integrator(sd.integrator);
+        if (deviceList.empty() && numDevices > 1) {
+            int visible = 0;
+            gdpt::check(gdpt_device_count(&visible));
+            if (visible <= 0) gdpt::logError("no HIP device visible");
+            for (int r = 0; r < numDevices; ++r) deviceList.push_back(r % visible);
+        }
+        integrator.setDevices(deviceList);
         gdpt::MultiFilm film(sd.film);
         film.setDestinationFile(dest);
         std::string log;

@@ -158,6 +158,19 @@ GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
  * Environment: GDPT_NO_CONTINUATION / GDPT_NO_PRIMARY_PASS (set = off) and GDPT_QUEUE_MB (memory budget of the sample queue, default
  * 24576) override at render time. */
 GDPT_API int  gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes);
+
+/* ---- multi-device helpers (csrc/device_capi.hip) ---------------------------------------------------------------------------------
+ * The reference shards a frame over CPU worker threads by image blocks and merges block borders by addition (imageproc.cpp:28-78,
+ * gpt_proc.cpp:52-56,137-149).  A C++ host that shards it over the GPUs of one node (host/gdpt_multi.hpp: one thread and one strip
+ * film per device) needs, besides the entry points above (gdpt_scene_create_ex takes the device, a film lives on its scene's device),
+ * device memory it can name and copies between devices.  A copy between two GPUs is a peer-to-peer DMA over xGMI. */
+GDPT_API int  gdpt_device_count(int *count);
+GDPT_API int  gdpt_device_alloc(int device, size_t bytes, void **ptr);
+GDPT_API int  gdpt_device_free(int device, void *ptr);
+GDPT_API int  gdpt_device_copy(int dstDevice, void *dst, int srcDevice, const void *src, size_t bytes);   /* synchronous */
+GDPT_API int  gdpt_device_download(int device, void *host, const void *dev, size_t bytes);
+/* The device a scene (and every film created on it) lives on. */
+GDPT_API int  gdpt_scene_device(const gdpt_scene *s);
 /* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/<type>.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
  * (default: every put covers one pixel, the per-pixel-sums fast path), TENT, GAUSSIAN (p0 = stddev, 0.5), MITCHELL (p0 = B, p1 = C,
  * 1/3 each), CATMULLROM, LANCZOS (p0 = lobes, 3).  The wider filters log every sample and gather the puts per receiving pixel
