@@ -194,6 +194,7 @@ struct gdpt_scene {
     int bvhDepth = 0;
     int numCUs = 256;
     bool specialEmitters = false;   // an environment or point emitter: the ENV builds of the render kernel
+    bool perVertex = false;         // vertex normals, texture coordinates or bitmap textures: the builds that keep a hit's barycentrics
     size_t ldsSceneBytes = 0;
 };
 
@@ -236,6 +237,24 @@ int gdpt_scene_create_env(int numTris, const double *verts, const int *triMateri
 int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals, const int *triMaterial, int numMaterials, const gdpt_material *materials,
                          int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env, const gdpt_camera *camera, int device, gdpt_scene **out)
 {
+    return gdpt_scene_create_tex(numTris, verts, normals, nullptr, nullptr, triMaterial, numMaterials, materials, nullptr, 0, nullptr, numEmitters, emitters, env, camera, device, out);
+}
+
+int gdpt_scene_create_tex(int numTris, const double *verts, const double *normals, const double *uvs, const unsigned char *triHasUV, const int *triMaterial,
+                          int numMaterials, const gdpt_material *materials, const int *materialTexture, int numTextures, const gdpt_texture *textures,
+                          int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env, const gdpt_camera *camera, int device, gdpt_scene **out)
+{
+    if (numTextures < 0 || (numTextures > 0 && !textures)) return tfail(GDPT_ERR_INVALID, "scene_create: bad texture list");
+    for (int i = 0; i < numTextures; i++) {
+        const gdpt_texture &t = textures[i];
+        if (t.width <= 0 || t.height <= 0 || !t.rgb) return tfail(GDPT_ERR_INVALID, "texture %d: empty bitmap", i);
+        if (t.filter != GDPT_TEXFILTER_NEAREST && t.filter != GDPT_TEXFILTER_BILINEAR)
+            return tfail(GDPT_ERR_UNSUPPORTED, "texture %d: only the filter types 'nearest' and 'bilinear' are carried ('ewa' and 'trilinear' read the MIP pyramid through ray differentials)", i);
+        if (t.wrapU < 0 || t.wrapU > 4 || t.wrapV < 0 || t.wrapV > 4) return tfail(GDPT_ERR_INVALID, "texture %d: Invalid wrap mode: must be one of 'repeat', 'clamp', 'black', or 'white'!", i);   // bitmap.cpp:336-337
+    }
+    if (materialTexture)
+        for (int i = 0; i < numMaterials; i++)
+            if (materialTexture[i] >= numTextures) return tfail(GDPT_ERR_INVALID, "material %d: texture %d out of range", i, materialTexture[i]);
     if (!verts || !triMaterial || !materials || !camera || !out || numTris <= 0 || numMaterials <= 0)
         return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
     if (numEmitters < 0 || (numEmitters > 0 && !emitters)) return tfail(GDPT_ERR_INVALID, "scene_create: bad emitter list");
@@ -273,6 +292,8 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
     std::vector<TriIsect> isect(numTris);
     std::vector<TriShade> shade(numTris);
     std::vector<TriNormals> vn;                               // leaf order; stays empty when no triangle has vertex normals
+    std::vector<TriUV> tuv;                                   // leaf order; stays empty when no triangle has texture coordinates
+    std::vector<unsigned char> tHasUV;
     for (int li = 0; li < numTris; li++) {
         const int t = bld.order[li];
         const H3 p0 = h3(verts[9 * t], verts[9 * t + 1], verts[9 * t + 2]), p1 = h3(verts[9 * t + 3], verts[9 * t + 4], verts[9 * t + 5]),
@@ -291,6 +312,11 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
         s.emitter = emitterOf[t];
         s.origIndex = t;
         s.smooth = 0;
+        if (uvs && (!triHasUV || triHasUV[t])) {              // per-vertex texture coordinates of this triangle's mesh (skdtree.h:398-402)
+            if (tuv.empty()) { tuv.resize(numTris); tHasUV.assign(((size_t)numTris + 15) & ~(size_t)15, 0); }
+            for (int k = 0; k < 6; k++) tuv[li].uv[k] = uvs[6 * (size_t)t + k];
+            tHasUV[li] = 1;
+        }
         if (normals) {                                        // per-vertex normals; three zero vectors = none for this triangle
             const double *n = normals + 9 * (size_t)t;
             bool any = false;
@@ -317,7 +343,9 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
         o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));
         o.eta = to_d3(h3(m.eta[0], m.eta[1], m.eta[2]));
         o.k = to_d3(h3(m.k[0], m.k[1], m.k[2]));
-        o.alphaU = m.alphaU; o.alphaV = m.alphaV; o.pad2 = 0.0;
+        o.alphaU = m.alphaU; o.alphaV = m.alphaV; o.pad2 = 0;
+        o.tex = materialTexture ? materialTexture[i] : -1;
+        if (o.tex < -1) o.tex = -1;
     }
 
     // emitters: DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h:95-108), scene-level emitter pdf (scene.cpp:357-380)
@@ -389,6 +417,32 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
     }
     d.vn = nullptr;
     if (!vn.empty()) { TriNormals *dvn; if ((rc = upload(&dvn, vn))) { gdpt_scene_destroy(s); return rc; } s->allocs.push_back(dvn); d.vn = dvn; }
+    d.uv = nullptr; d.hasUV = nullptr; d.tex = nullptr; d.numTex = numTextures;
+    if (!tuv.empty()) {
+        TriUV *duv; unsigned char *dh;
+        if ((rc = upload(&duv, tuv)) || (rc = upload(&dh, tHasUV))) { gdpt_scene_destroy(s); return rc; }
+        s->allocs.push_back(duv); s->allocs.push_back(dh);
+        d.uv = duv; d.hasUV = dh;
+    }
+    if (numTextures > 0) {
+        std::vector<TexD> tex(numTextures);
+        for (int i = 0; i < numTextures; i++) {
+            const gdpt_texture &t = textures[i];
+            TexD &o = tex[i];
+            o.w = t.width; o.h = t.height; o.wrapU = t.wrapU; o.wrapV = t.wrapV; o.filter = t.filter; o.pad = 0;
+            o.uscale = t.uscale; o.vscale = t.vscale; o.uoffset = t.uoffset; o.voffset = t.voffset; o.scale = t.scale;
+            const std::vector<double> texels(t.rgb, t.rgb + (size_t)3 * t.width * t.height);
+            double *dt;
+            if ((rc = upload(&dt, texels))) { gdpt_scene_destroy(s); return rc; }
+            s->allocs.push_back(dt);
+            o.texels = dt;
+        }
+        TexD *dtex;
+        if ((rc = upload(&dtex, tex))) { gdpt_scene_destroy(s); return rc; }
+        s->allocs.push_back(dtex);
+        d.tex = dtex;
+    }
+    s->perVertex = d.vn != nullptr || d.uv != nullptr || numTextures > 0;
     d.envIndex = envIndex;
     s->specialEmitters = env != nullptr || hasPoint;
     if (env) {
@@ -421,6 +475,7 @@ int gdpt_scene_create_ex(int numTris, const double *verts, const double *normals
         for (size_t b : parts) tot += (b + 15) & ~(size_t)15;                 // block_setup's layout: every table starts on a 16-byte word
         s->ldsSceneBytes = tot;
         d.ldsScene = tot <= (size_t)LDS_SCENE_BYTES ? 1 : 0;
+        d.ldsBytes = d.ldsScene ? (int)tot : 0;
     }
     CameraD &c = d.cam;
     for (int r = 0; r < 3; r++)
@@ -619,7 +674,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment / point emitters | + per-vertex normals (environment tested at run time)};
     // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { \
-        if (s->d.vn)                { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, true);   else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
+        if (s->perVertex)           { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, true);   else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
         else if (s->specialEmitters) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, false); } \
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
@@ -639,7 +694,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #define GDPT_DEV_WPS 2
 #endif
 #ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 3): one build per scene kind */
-        if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, true);
+        if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, true);
 #else
         if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }

@@ -72,6 +72,7 @@ __device__ __forceinline__ Float maxc(d3 a) { return fmax(a.x, fmax(a.y, a.z)); 
 __device__ __forceinline__ Float safe_sqrt(Float v) { return sqrt(fmax(0.0, v)); }
 __device__ __forceinline__ Float signum(Float v) { return v < 0 ? -1.0 : (v > 0 ? 1.0 : 0.0); }
 __device__ __forceinline__ Float comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ bool is_finite_d(Float v) { return (v - v) == 0; }
 
 // ---- device scene ---------------------------------------------------------------------------------
 // 64 B inner node: the bounds of BOTH children (fp32, rounded outward on the host) and their references, so a visit is one
@@ -98,7 +99,19 @@ struct TriNormals { d3 n0, n1, n2; Float pad; };   // 80 B: per-vertex normals i
 struct MaterialD {           // 112 B (a multiple of 16: tables are staged into LDS with 16-byte copies)
     int type, distribution, sampleVisible, twoSided;
     d3 reflectance, eta, k;
-    Float alphaU, alphaV, pad2;
+    Float alphaU, alphaV;
+    int tex, pad2;           // bitmap texture on `reflectance` / `specularReflectance` (index into SceneD::tex), -1 = the constant above
+};
+struct TriUV { Float uv[6]; };   // 48 B: per-vertex texture coordinates (u0 v0 u1 v1 u2 v2) in leaf order (only scenes that have any)
+// `<texture type="bitmap">` as the G-PT path evaluates it (src/textures/bitmap.cpp:431-452 -> MIPMap::evalBox / evalBilinear on level 0,
+// mipmap.h:566-596; filterType nearest | bilinear -- "ewa"/"trilinear" read the MIP pyramid through ray differentials and are refused by
+// the host).  Texels are doubles (the reference's MIP map holds Float), [h][w][3], top row first, in HBM.
+struct TexD {
+    int w, h, wrapU, wrapV;     // wrap: 0 repeat, 1 clamp, 2 mirror, 3 zero, 4 one (ReconstructionFilter::EBoundaryCondition as bitmap.cpp:324-338 names them)
+    int filter, pad;            // 0 nearest (evalBox), 1 bilinear
+    Float uscale, vscale, uoffset, voffset;   // Texture2D, texture.cpp:27-45,113
+    Float scale;                // BSDF::ensureEnergyConservation's ScaleTexture factor (1 = none)
+    const Float *texels;
 };
 static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
@@ -127,9 +140,14 @@ struct SceneD {
     Float emitterNormalization;
     int numNodes, numTris, numEmitters, numMats, ldsScene;
     int numEmTris, numEmCdf;    // entries of emTris / emCdf (emitterCdf has numEmitters + 1)
+    int ldsBytes;               // bytes of the staged tables (16-byte words per table), 0 if the scene is not LDS-resident
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds
     const TriNormals *vn;       // per-vertex normals in leaf order, nullptr if the scene has none
+    const TriUV *uv;            // per-vertex texture coordinates in leaf order, nullptr if the scene has none
+    const unsigned char *hasUV; // per triangle: 1 = its mesh has texture coordinates (else its.uv = the barycentrics, skdtree.h:403-405)
+    const TexD *tex;            // bitmap textures
+    int numTex;
     int envIndex;               // position of the environment emitter in the emitter list, -1: none
     d3 bsCenter;                // its bounding sphere (ConstantBackgroundEmitter::m_sceneBSphere)
     Float bsRadius;
@@ -209,6 +227,9 @@ struct SceneView {
     const Float *emCdf;
     const Float *emitterCdf;
     const TriNormals *vn;       // nullptr: no triangle has vertex normals
+    const TriUV *uv;            // nullptr: no triangle has texture coordinates
+    const unsigned char *hasUV;
+    const TexD *tex;
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds (error bound of the fp32 slab test)
 };
@@ -309,7 +330,10 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
         if (COUNT) tc->tris += cnt;
         for (uint32_t i = 0; i < cnt; i++) {
             Float u, v, t;
-            if (tri_test(sv.isect[first + i], o, d, mint, maxt, u, v, t)) {
+            // the whole 80-byte record in one go: read field by field as the test proceeds (k, then the plane, then the edge terms) it is
+            // three dependent LDS / L2 round trips per triangle, and the traversal is bound by exactly that latency chain, not by bandwidth
+            const TriIsect ta = sv.isect[first + i];
+            if (tri_test(ta, o, d, mint, maxt, u, v, t)) {
                 if (ANY) return true;
                 maxt = t;
                 R.maxt = up_f(t);
@@ -611,7 +635,8 @@ __device__ __forceinline__ d3 dielectric_refract(const MaterialD &m, d3 wi, Floa
 
 // BSDF::eval and BSDF::pdf together (every call site of the hot path wants both):
 // diffuse.cpp:110-127, conductor.cpp:223-254, roughconductor.cpp:257-319
-__device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 &f, Float &pdf)
+// R: the material's reflectance / specularReflectance at the vertex (reflectance_at: the constant, or its bitmap texture at its.uv)
+__device__ void bsdf_eval_pdf(const MaterialD &m, d3 R, d3 wi, d3 wo, int measure, d3 &f, Float &pdf)
 {
     f = mk(0.0); pdf = 0.0;
     if (m.twoSided && !(wi.z > 0)) { wi.z = -wi.z; wo.z = -wo.z; }      // TwoSided::eval/pdf, twosided.cpp:100-124
@@ -621,7 +646,7 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
         if (measure != MEASURE_DISCRETE) return;
         if (wi.z * wo.z >= 0) {
             if (fabs(dot(mk(-wi.x, -wi.y, wi.z), wo) - 1) > GD_DELTA_EPSILON) return;
-            f = m.reflectance * F; pdf = F;
+            f = R * F; pdf = F;
         } else {
             if (fabs(dot(dielectric_refract(m, wi, cosThetaT), wo) - 1) > GD_DELTA_EPSILON) return;
             const Float factor = cosThetaT < 0 ? 1 / m.eta.x : m.eta.x;
@@ -632,11 +657,11 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
     if (wi.z <= 0 || wo.z <= 0) return;
     if (m.type == 0) {
         if (measure != MEASURE_SOLID_ANGLE) return;
-        f = m.reflectance * (GD_INV_PI * wo.z);
+        f = R * (GD_INV_PI * wo.z);
         pdf = GD_INV_PI * wo.z;
     } else if (m.type == 1) {
         if (measure != MEASURE_DISCRETE || fabs(dot(mk(-wi.x, -wi.y, wi.z), wo) - 1) > GD_DELTA_EPSILON) return;
-        f = m.reflectance * fresnelConductorExact(wi.z, m.eta, m.k);
+        f = R * fresnelConductorExact(wi.z, m.eta, m.k);
         pdf = 1.0;
     } else {
         if (measure != MEASURE_SOLID_ANGLE) return;
@@ -647,7 +672,7 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
         if (d.sv) pdf = D * G1i / (4.0 * wi.z);
         else pdf = (D * H.z) / (4 * fabs(dot(wo, H)));
         if (D == 0) return;
-        const d3 F = fresnelConductorExact(dot(wi, H), m.eta, m.k) * m.reflectance;
+        const d3 F = fresnelConductorExact(dot(wi, H), m.eta, m.k) * R;
         const Float G = G1i * mf_G1(d, wo, H);
         const Float model = D * G / (4.0 * wi.z);
         f = F * model;
@@ -656,7 +681,7 @@ __device__ void bsdf_eval_pdf(const MaterialD &m, d3 wi, d3 wo, int measure, d3 
 
 struct BSDFSample { d3 wo, weight; Float pdf, eta; int sampledType; };
 // the pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
-__device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
+__device__ void bsdf_sample_one(const MaterialD &m, d3 R, d3 wi, Float sx, Float sy, BSDFSample &r)
 {
     r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.eta = 1.0; r.sampledType = 0;   // gpt.cpp:450-454: pdf starts at 0
     if (m.type == 3) {                                                    // SmoothDielectric::sample, dielectric.cpp:277-305
@@ -666,7 +691,7 @@ __device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, B
             r.sampledType = EDeltaReflection;
             r.wo = mk(-wi.x, -wi.y, wi.z);
             r.pdf = F;
-            r.weight = m.reflectance;
+            r.weight = R;
         } else {
             r.sampledType = EDeltaTransmission;
             r.wo = dielectric_refract(m, wi, cosThetaT);
@@ -682,13 +707,13 @@ __device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, B
         r.wo = squareToCosineHemisphere(sx, sy);
         r.sampledType = EDiffuseReflection;
         r.pdf = GD_INV_PI * r.wo.z;
-        r.weight = m.reflectance;
+        r.weight = R;
     } else if (m.type == 1) {
         if (wi.z <= 0) return;
         r.sampledType = EDeltaReflection;
         r.wo = mk(-wi.x, -wi.y, wi.z);
         r.pdf = 1;
-        r.weight = m.reflectance * fresnelConductorExact(wi.z, m.eta, m.k);
+        r.weight = R * fresnelConductorExact(wi.z, m.eta, m.k);
     } else {
         if (wi.z < 0) return;
         const Mf d = mf_of(m);
@@ -698,7 +723,7 @@ __device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, B
         r.wo = 2 * dot(wi, mm) * mm - wi;
         r.sampledType = EGlossyReflection;
         if (r.wo.z <= 0) return;
-        const d3 F = fresnelConductorExact(dot(wi, mm), m.eta, m.k) * m.reflectance;
+        const d3 F = fresnelConductorExact(dot(wi, mm), m.eta, m.k) * R;
         Float weight;
         if (d.sv) weight = mf_G1(d, r.wo, mm);
         else weight = mf_eval(d, mm) * (mf_G1(d, wi, mm) * mf_G1(d, r.wo, mm)) * dot(wi, mm) / (temporaryPdf * wi.z);
@@ -709,11 +734,11 @@ __device__ void bsdf_sample_one(const MaterialD &m, d3 wi, Float sx, Float sy, B
     }
 }
 
-__device__ __forceinline__ void bsdf_sample(const MaterialD &m, d3 wi, Float sx, Float sy, BSDFSample &r)
+__device__ __forceinline__ void bsdf_sample(const MaterialD &m, d3 R, d3 wi, Float sx, Float sy, BSDFSample &r)
 { // TwoSided::sample (pdf overload), twosided.cpp:148-168, around the one-sided models
     const bool flipped = m.twoSided && wi.z < 0;
     if (flipped) wi.z = -wi.z;
-    bsdf_sample_one(m, wi, sx, sy, r);
+    bsdf_sample_one(m, R, wi, sx, sy, r);
     if (flipped && !(r.weight.x == 0 && r.weight.y == 0 && r.weight.z == 0) && r.pdf != 0) r.wo.z = -r.wo.z;
 }
 
@@ -966,6 +991,55 @@ __device__ __forceinline__ void fill_vertex(const SceneView &S, const Hit &h, d3
     const d3 b = mk(1 - h.u - h.v, h.u, h.v);
     v.p = ts.p0 * b.x + ts.p1 * b.y + ts.p2 * b.z;
     v.u = h.u; v.v = h.v;
+}
+
+// MIPMap::evalTexel's boundary handling (mipmap.h:503-561): false = the lookup is the constant `c` (zero / one modes)
+__device__ __forceinline__ bool tex_wrap(int &x, int size, int mode, Float &c)
+{
+    if (x >= 0 && x < size) return true;
+    if (mode == 0) { x %= size; if (x < 0) x += size; return true; }                                   // math::modulo
+    if (mode == 1) { x = x < 0 ? 0 : size - 1; return true; }
+    if (mode == 2) { x %= 2 * size; if (x < 0) x += 2 * size; if (x >= size) x = 2 * size - x - 1; return true; }
+    c = mode == 3 ? 0.0 : 1.0;
+    return false;
+}
+__device__ __forceinline__ d3 tex_texel(const TexD &t, int x, int y)
+{
+    Float c = 0;
+    if (!tex_wrap(x, t.w, t.wrapU, c)) return mk(c);
+    if (!tex_wrap(y, t.h, t.wrapV, c)) return mk(c);
+    const Float *p = t.texels + ((size_t)y * t.w + x) * 3;
+    return mk(p[0], p[1], p[2]);
+}
+// Texture2D::eval (texture.cpp:112-121) -> BitmapTexture::eval -> evalBox / evalBilinear on level 0 (mipmap.h:566-596)
+__device__ d3 tex_eval(const TexD &t, Float u_, Float v_)
+{
+    const Float ux = u_ * t.uscale + t.uoffset, vy = v_ * t.vscale + t.voffset;
+    d3 value;
+    if (t.filter == 0) value = tex_texel(t, (int)floor(ux * t.w), (int)floor(vy * t.h));
+    else {
+        if (!is_finite_d(ux) || !is_finite_d(vy)) return mk(0.0) * t.scale;
+        const Float u = ux * t.w - 0.5, v = vy * t.h - 0.5;
+        const int xPos = (int)floor(u), yPos = (int)floor(v);
+        const Float dx1 = u - xPos, dx2 = 1.0 - dx1, dy1 = v - yPos, dy2 = 1.0 - dy1;
+        value = tex_texel(t, xPos, yPos) * dx2 * dy2 + tex_texel(t, xPos, yPos + 1) * dx2 * dy1 + tex_texel(t, xPos + 1, yPos) * dx1 * dy2 + tex_texel(t, xPos + 1, yPos + 1) * dx1 * dy1;
+    }
+    return value * t.scale;
+}
+// m_reflectance->eval(its) / m_specularReflectance->eval(its): the constant, or the bitmap at its.uv (skdtree.h:398-405: interpolated
+// texture coordinates, or the barycentrics (b1, b2) for a mesh without any).  PERVERTEX builds only; flat untextured scenes compile it out.
+template <bool PERVERTEX>
+__device__ __forceinline__ d3 reflectance_at(const SceneView &S, const MaterialD &m, const Vertex &v)
+{
+    if (!PERVERTEX || m.tex < 0) return m.reflectance;
+    Float tu = v.u, tv = v.v;
+    if (S.uv && S.hasUV[v.prim]) {
+        const TriUV t = S.uv[v.prim];
+        const Float b0 = 1 - v.u - v.v;
+        tu = t.uv[0] * b0 + t.uv[2] * v.u + t.uv[4] * v.v;
+        tv = t.uv[1] * b0 + t.uv[3] * v.u + t.uv[5] * v.v;
+    }
+    return tex_eval(S.tex[m.tex], tu, tv);
 }
 
 // its.wi = its.toLocal(-ray.d), skdtree.h:427

@@ -137,6 +137,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
     const MaterialD &mainBSDF = sv.mats[mts.material];
+    const d3 mainR = reflectance_at<SMOOTH>(sv, mainBSDF, L.v);                  // m_reflectance->eval(its): the constant or its bitmap texture at its.uv
 
     // ================= direct illumination sampling, :565-730 =================
     if (bsdfType(mainBSDF) & ESmooth) {
@@ -150,7 +151,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const d3 mainWoL = toLocal(mfr, dRec.d);
         d3 mainBSDFValue;
         Float mainBsdfPdfRaw;
-        bsdf_eval_pdf(mainBSDF, mainWi, mainWoL, MEASURE_SOLID_ANGLE, mainBSDFValue, mainBsdfPdfRaw);   // :588
+        bsdf_eval_pdf(mainBSDF, mainR, mainWi, mainWoL, MEASURE_SOLID_ANGLE, mainBSDFValue, mainBsdfPdfRaw);   // :588
         const bool lightOnSurfaceSA = !(ENV && dRec.offSurfaceDiscrete);          // emitter->isOnSurface() && dRec.measure == ESolidAngle
         const Float mainBsdfPdf = (lightOnSurfaceSA && mainEmitterVisible) ? mainBsdfPdfRaw : 0;       // :592
         const Float mainDistanceSquared = len2(L.v.p - dRec.p);
@@ -177,7 +178,7 @@ GDPT_OFFSET_LOOP
                         const d3 incoming = normalize(s.v.p - L.v.p);
                         d3 f;
                         Float pdfRaw;
-                        bsdf_eval_pdf(mainBSDF, toLocal(mfr, incoming), toLocal(mfr, dRec.d), MEASURE_SOLID_ANGLE, f, pdfRaw);
+                        bsdf_eval_pdf(mainBSDF, mainR, toLocal(mfr, incoming), toLocal(mfr, dRec.d), MEASURE_SOLID_ANGLE, f, pdfRaw);
                         const Float shiftedBsdfPdf = (lightOnSurfaceSA && mainEmitterVisible) ? pdfRaw : 0;
                         const Float den = (s.pdf * s.pdf) * ((dRec.pdf * dRec.pdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
                         weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
@@ -205,7 +206,7 @@ GDPT_OFFSET_LOOP
                             } else {
                                 d3 f;
                                 Float pdfRaw;
-                                bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
+                                bsdf_eval_pdf(shiftedBSDF, reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v), toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
                                 const Float shiftedBsdfPdf = (lightOnSurfaceSA && shiftedEmitterVisible) ? pdfRaw : 0;
                                 const Float jacobian = fabs(shiftedOpposingCosine * mainDistanceSquared) / (GD_EPSILON + fabs(mainOpposingCosine * shiftedDistanceSquared)); // :695
                                 const Float den = (jacobian * s.pdf) * (jacobian * s.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
@@ -232,7 +233,7 @@ GDPT_OFFSET_LOOP
     // ================= BSDF sampling and emitter hits, :737-1151 =================
     const Float bsx = L.rng.next1D(), bsy = L.rng.next1D();                      // :456
     BSDFSample bs;
-    bsdf_sample(mainBSDF, mainWi, bsx, bsy, bs);
+    bsdf_sample(mainBSDF, mainR, mainWi, bsx, bsy, bs);
     if (bs.pdf <= 0.0) return false;                                             // :740
     const d3 mainWo = toWorld(mfr, bs.wo);
     if (cfg.strictNormals && dot(mGeoN, mainWo) * bs.wo.z <= 0) return false;    // :749
@@ -297,7 +298,7 @@ GDPT_OFFSET_LOOP
                 const d3 incoming = normalize(s.v.p - L.rayO);
                 d3 f;
                 Float shiftedBsdfPdf;
-                bsdf_eval_pdf(mainBSDF, toLocal(mfr, incoming), toLocal(mfr, L.rayD), measure, f, shiftedBsdfPdf);
+                bsdf_eval_pdf(mainBSDF, mainR, toLocal(mfr, incoming), toLocal(mfr, L.rayD), measure, f, shiftedBsdfPdf);
                 s.throughput = s.throughput * f;
                 s.pdf *= shiftedBsdfPdf;
                 s.status = RAY_CONNECTED;
@@ -311,6 +312,7 @@ GDPT_OFFSET_LOOP
                 const Shading ssh = shading_at<SMOOTH>(sv, s.v);
                 const Frame3 sfr = ssh.fr;
                 const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
+                const d3 shiftedR = reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v);
                 if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
                     // ---- reconnection shift, :897-986 ----
                     if (!lastSegment || mainHitEmitter) {                        // :901
@@ -331,7 +333,7 @@ GDPT_OFFSET_LOOP
                             else {
                                 d3 f;
                                 Float shiftedBsdfPdf;
-                                bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, shiftedBsdfPdf);
+                                bsdf_eval_pdf(shiftedBSDF, shiftedR, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, shiftedBsdfPdf);
                                 s.throughput = s.throughput * (f * 1.0);
                                 s.pdf *= shiftedBsdfPdf * 1.0;
                                 s.status = RAY_RECENTLY_CONNECTED;
@@ -353,7 +355,7 @@ GDPT_OFFSET_LOOP
                             else {
                                 d3 f;
                                 Float shiftedBsdfPdf;
-                                bsdf_eval_pdf(shiftedBSDF, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, shiftedBsdfPdf);
+                                bsdf_eval_pdf(shiftedBSDF, shiftedR, toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, shiftedBsdfPdf);
                                 s.throughput = s.throughput * (f * jacobian);    // :939-940
                                 s.pdf *= shiftedBsdfPdf * jacobian;
                                 s.status = RAY_RECENTLY_CONNECTED;
@@ -389,7 +391,7 @@ GDPT_OFFSET_LOOP
                         const d3 outgoing = toWorld(sfr, tsOut);
                         d3 f;
                         Float p;
-                        bsdf_eval_pdf(shiftedBSDF, tsIn, tsOut, measure, f, p);
+                        bsdf_eval_pdf(shiftedBSDF, shiftedR, tsIn, tsOut, measure, f, p);
                         s.throughput = s.throughput * f;
                         s.pdf *= p;
                         if (s.pdf == 0) ok = false;                              // :1034
@@ -527,8 +529,22 @@ template <bool LDS_SCENE, bool ACC_LDS>
 __device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, unsigned char *s_dyn, SceneView &sv, int *&stack, unsigned char *&s_acc)
 {
     int *s_stack = reinterpret_cast<int *>(s_dyn);
+#ifdef GDPT_LDS_POISON              /* investigation build: every dynamic-LDS word starts as a signalling pattern (a NaN as double, a huge
+                                       index as int), so that any read of a stack slot, sum or table word before its first write shows up
+                                       as a wrong film or a fault instead of passing by luck */
+    {
+        const unsigned words = (unsigned)(((size_t)stackDepth * TBLK * sizeof(int) + (ACC_LDS ? sizeof(Float) * ACC_N * TBLK : 0) + (LDS_SCENE ? S.ldsBytes : 0)) / 4);
+        for (unsigned i = threadIdx.x; i < words; i += TBLK) reinterpret_cast<unsigned *>(s_dyn)[i] = 0x7ff7dead;
+        __syncthreads();
+    }
+#endif
+#ifdef GDPT_LAYOUT_SCENE_FIRST      /* investigation build: the round-1 layout [stack][scene][sums] that faulted in one build */
+    unsigned char *s_scene = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
+    s_acc = s_scene + S.ldsBytes;
+#else
     s_acc = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
     unsigned char *s_scene = s_acc + (ACC_LDS ? sizeof(Float) * ACC_N * TBLK : 0);
+#endif
     if (LDS_SCENE) {
         // stage node packets, triangle records and the shading tables through LDS once per block (coalesced 16-byte copies);
         // the compile-time branch lets the compiler address them with ds_read instead of flat loads
@@ -556,7 +572,8 @@ __device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, uns
         sv.emitterCdf = reinterpret_cast<const Float *>(s_scene + offs[7]);
     } else { sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; }
     sv.rootRef = S.rootRef; sv.boundM = S.boundM;
-    sv.vn = S.vn;                      // per-vertex normals stay in HBM (scenes that have them are rarely LDS-resident)
+    sv.vn = S.vn;                      // per-vertex normals, texture coordinates and textures stay in HBM
+    sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
     stack = s_stack + threadIdx.x;
 }
 
@@ -963,7 +980,7 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     if (i >= n) return;
     const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
@@ -982,7 +999,7 @@ __global__ __launch_bounds__(TBLK) void k_trace_stats(SceneD S, int n, const Flo
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
     const int i = blockIdx.x * TBLK + threadIdx.x;
     TravCount c0 = {0, 0}, c1 = {0, 0};
     if (i < n) {
@@ -1005,7 +1022,7 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
     Lane L;
     L.nClosest = L.nShadow = 0;
     Acc<false> A;

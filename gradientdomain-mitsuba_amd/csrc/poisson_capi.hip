@@ -14,6 +14,9 @@
 #include <string>
 #include <vector>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 using namespace gdpt;
 
@@ -806,11 +809,24 @@ int gdpt_backend_calc_PTW2x(float *out, int w, int h, float alpha, const float *
 }
 
 // scratch for block partials of the op-level reductions: stream-ordered allocation
+// Block partials of the op-level reductions: one buffer per (device, stream), allocated once and kept.  (Round 1 took it from the
+// stream-ordered allocator on every call -- hipMallocAsync / hipFreeAsync -- and one ad-hoc run saw calc_w2 return inf on the second
+// call of a fresh process, i.e. a zero sum of partials, which never reproduced; a pool block handed out again while a free was still
+// pending is the one thing in that path that was not plain stream order.  A persistent buffer per stream has no such state: consumers
+// follow producers on the same stream, and two streams never share a buffer.)
 struct PartScratch {
     float4 *p = nullptr;
-    hipStream_t st;
-    explicit PartScratch(hipStream_t s) : st(s) { if (hipMallocAsync((void **)&p, sizeof(float4) * MAXP, st) != hipSuccess) p = nullptr; }
-    ~PartScratch() { if (p) hipFreeAsync(p, st); }
+    explicit PartScratch(hipStream_t s)
+    {
+        static std::mutex m;
+        static std::map<std::pair<int, hipStream_t>, float4 *> pool;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        std::lock_guard<std::mutex> lock(m);
+        float4 *&slot = pool[std::make_pair(dev, s)];
+        if (!slot && hipMalloc((void **)&slot, sizeof(float4) * MAXP) != hipSuccess) { slot = nullptr; (void)hipGetLastError(); }
+        p = slot;
+    }
 };
 
 int gdpt_backend_calc_Ax_xAx(float *Ax, float *xAx, int w, int h, float alpha, const float *w2, const float *x, void *stream)

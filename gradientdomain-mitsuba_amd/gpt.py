@@ -23,6 +23,11 @@ class Material(C.Structure):
                 ("alphaU", C.c_double), ("alphaV", C.c_double)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rgb", C.c_void_p), ("wrapU", C.c_int), ("wrapV", C.c_int), ("filter", C.c_int),
+                ("uscale", C.c_double), ("vscale", C.c_double), ("uoffset", C.c_double), ("voffset", C.c_double), ("scale", C.c_double)]
+
+
 class Emitter(C.Structure):
     _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3), ("position", C.c_double * 3)]
 
@@ -80,10 +85,31 @@ class Scene:
             env = Environment((C.c_double * 3)(*envd[0]), int(envd[1]))
         nrm = getattr(desc, "normals", None)
         nrm = np.ascontiguousarray(nrm, dtype=np.float64) if nrm is not None else None
-        check(lib().gdpt_scene_create_ex(verts.shape[0], verts.ctypes.data_as(C.c_void_p),
-                                         nrm.ctypes.data_as(C.c_void_p) if nrm is not None else None, tm.ctypes.data_as(C.c_void_p),
-                                         len(desc.materials), C.byref(mats), len(desc.emitters), C.byref(ems),
-                                         C.byref(env) if env is not None else None, C.byref(cam), device, C.byref(self._h)))
+        # texture coordinates and bitmap textures (scenes.Scene.uvs / tri_has_uv / textures / material_textures)
+        uvs = getattr(desc, "uvs", None)
+        uvs = np.ascontiguousarray(uvs, dtype=np.float64) if uvs is not None else None
+        has = getattr(desc, "tri_has_uv", None)
+        has = np.ascontiguousarray(has, dtype=np.uint8) if (has is not None and uvs is not None) else None
+        texs = getattr(desc, "textures", None) or []
+        keep = []                                            # texel arrays must outlive the call
+        tarr = (Texture * max(1, len(texs)))()
+        for i, t in enumerate(texs):
+            rgb = np.ascontiguousarray(t["rgb"], dtype=np.float64)
+            keep.append(rgb)
+            tarr[i].height, tarr[i].width = rgb.shape[0], rgb.shape[1]
+            tarr[i].rgb = rgb.ctypes.data_as(C.c_void_p)
+            tarr[i].wrapU, tarr[i].wrapV, tarr[i].filter = t.get("wrapU", 0), t.get("wrapV", 0), t.get("filter", 1)
+            tarr[i].uscale, tarr[i].vscale, tarr[i].uoffset, tarr[i].voffset = t.get("uscale", 1.0), t.get("vscale", 1.0), t.get("uoffset", 0.0), t.get("voffset", 0.0)
+            tarr[i].scale = t.get("scale", 1.0)
+        mtex = getattr(desc, "material_textures", None)
+        mtex = np.ascontiguousarray(mtex, dtype=np.int32) if mtex is not None else None
+        check(lib().gdpt_scene_create_tex(verts.shape[0], verts.ctypes.data_as(C.c_void_p),
+                                          nrm.ctypes.data_as(C.c_void_p) if nrm is not None else None,
+                                          uvs.ctypes.data_as(C.c_void_p) if uvs is not None else None,
+                                          has.ctypes.data_as(C.c_void_p) if has is not None else None, tm.ctypes.data_as(C.c_void_p),
+                                          len(desc.materials), C.byref(mats), mtex.ctypes.data_as(C.c_void_p) if mtex is not None else None,
+                                          len(texs), C.byref(tarr) if texs else None, len(desc.emitters), C.byref(ems),
+                                          C.byref(env) if env is not None else None, C.byref(cam), device, C.byref(self._h)))
 
     def intersect(self, origins, dirs):
         od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))

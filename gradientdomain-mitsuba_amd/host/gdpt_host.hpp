@@ -150,6 +150,11 @@ struct SceneData {
     std::vector<double> verts;              // 9 per triangle
     std::vector<double> normals;            // 9 per triangle (zeros = flat) for the first normals.size()/9 triangles; empty = none
     std::vector<int> triMaterial;
+    std::vector<double> uvs;                // 6 per triangle (u0 v0 u1 v1 u2 v2) for the first uvs.size()/6 triangles; empty = no mesh has texture coordinates
+    std::vector<unsigned char> triHasUV;    // per triangle of that prefix: its mesh has texture coordinates
+    struct Texture { int width = 0, height = 0; std::vector<double> rgb; int wrapU = 0, wrapV = 0, filter = 1; double uscale = 1, vscale = 1, uoffset = 0, voffset = 0, scale = 1; };
+    std::vector<Texture> textures;          // `<texture type="bitmap">`
+    std::vector<int> materialTexture;       // per material: its reflectance / specularReflectance texture, -1 = constant (shorter than materials = -1)
     std::vector<gdpt_material> materials;
     std::vector<gdpt_emitter> emitters;
     bool hasEnvironment = false;            // <emitter type="constant">
@@ -292,11 +297,7 @@ public:
         const int W = film.getWidth(), H = film.getHeight();
         gdpt_scene *scene = nullptr;
         gdpt_film *gf = nullptr;
-        std::vector<double> normals = sd.normals;
-        if (!normals.empty()) normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
-        check(gdpt_scene_create_ex(sd.numTriangles(), sd.verts.data(), normals.empty() ? nullptr : normals.data(), sd.triMaterial.data(),
-                                   (int)sd.materials.size(), sd.materials.data(), (int)sd.emitters.size(), sd.emitters.data(),
-                                   sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, -1, &scene));
+        createScene(sd, -1, &scene);
         check(gdpt_film_create(scene, 0, H, &gf));
         {
             int kind = GDPT_RFILTER_BOX; double p0 = 0, p1 = 0;
@@ -365,8 +366,6 @@ public:
             const int n = H / N + (r < H % N ? 1 : 0);
             strips[r].device = m_devices[r]; strips[r].y0 = y; strips[r].y1 = y + n; y += n;
         }
-        std::vector<double> normals = sd.normals;
-        if (!normals.empty()) normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
         gdpt_config cfg;
         cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals; cfg.spp = sampleCount;
         cfg.shiftThreshold = m_shiftThreshold; cfg.seed = seed;
@@ -387,9 +386,7 @@ public:
             workers.emplace_back([&, r]() {
                 Strip &s = strips[r];
                 try {
-                    check(gdpt_scene_create_ex(sd.numTriangles(), sd.verts.data(), normals.empty() ? nullptr : normals.data(), sd.triMaterial.data(),
-                                               (int)sd.materials.size(), sd.materials.data(), (int)sd.emitters.size(), sd.emitters.data(),
-                                               sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, s.device, &s.scene));
+                    createScene(sd, s.device, &s.scene);
                     check(gdpt_film_create(s.scene, s.y0, s.y1, &s.film));
                     check(gdpt_film_set_rfilter(s.film, kind, p0, p1));
                     check(gdpt_render_rect(s.scene, &cfg, 0, s.y0, W, s.y1, s.film));
@@ -481,6 +478,28 @@ public:
     }
 
     const Statistics &getStatistics() const { return m_stats; }
+
+    /// gdpt_scene_create_tex from a SceneData (vertex normals, texture coordinates and bitmap textures padded to the scene's size)
+    static void createScene(const SceneData &sd, int device, gdpt_scene **scene)
+    {
+        const size_t nt = (size_t)sd.numTriangles();
+        std::vector<double> normals = sd.normals, uvs = sd.uvs;
+        if (!normals.empty()) normals.resize(9 * nt, 0.0);
+        std::vector<unsigned char> has = sd.triHasUV;
+        if (!uvs.empty()) { uvs.resize(6 * nt, 0.0); has.resize(nt, 0); }
+        std::vector<gdpt_texture> tex(sd.textures.size());
+        for (size_t i = 0; i < tex.size(); ++i) {
+            const SceneData::Texture &t = sd.textures[i];
+            tex[i].width = t.width; tex[i].height = t.height; tex[i].rgb = t.rgb.data(); tex[i].wrapU = t.wrapU; tex[i].wrapV = t.wrapV; tex[i].filter = t.filter;
+            tex[i].uscale = t.uscale; tex[i].vscale = t.vscale; tex[i].uoffset = t.uoffset; tex[i].voffset = t.voffset; tex[i].scale = t.scale;
+        }
+        std::vector<int> mtex = sd.materialTexture;
+        mtex.resize(sd.materials.size(), -1);
+        check(gdpt_scene_create_tex(sd.numTriangles(), sd.verts.data(), normals.empty() ? nullptr : normals.data(), uvs.empty() ? nullptr : uvs.data(),
+                                    uvs.empty() ? nullptr : has.data(), sd.triMaterial.data(), (int)sd.materials.size(), sd.materials.data(),
+                                    tex.empty() ? nullptr : mtex.data(), (int)tex.size(), tex.empty() ? nullptr : tex.data(),
+                                    (int)sd.emitters.size(), sd.emitters.data(), sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, device, scene));
+    }
 
 private:
     /// <rfilter>: src/rfilters/*.cpp with their default parameters

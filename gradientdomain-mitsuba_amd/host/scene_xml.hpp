@@ -386,6 +386,7 @@ private:
         std::memset(&m, 0, sizeof m);
         m.sampleVisible = 1;
         bool haveEta = false, haveK = false;
+        int texIndex = -1;
         for (int c = 0; c < 3; ++c) { m.reflectance[c] = type == "diffuse" ? 0.5 : 1.0; m.eta[c] = 0; m.k[c] = 1; }
         m.alphaU = m.alphaV = 0.1;
         for (auto &c : n.children) {
@@ -419,7 +420,11 @@ private:
             } else if (c->tag == "boolean") {
                 if (nm == "sampleVisible") m.sampleVisible = subst(c->get("value")) == "true";
                 else logError(format("bsdf \"%s\": parameter \"%s\" is not carried", type.c_str(), nm.c_str()));
-            } else if (c->tag == "texture") logError("textures are not carried by this build");
+            } else if (c->tag == "texture") {
+                if (nm != "reflectance" && nm != "diffuseReflectance" && nm != "specularReflectance")
+                    logError(format("bsdf \"%s\": a texture on \"%s\" is not carried (reflectance / specularReflectance only)", type.c_str(), nm.c_str()));
+                texIndex = texture(*c, sd);
+            }
             else if (c->tag == "bsdf") logError(format("nested BSDFs (\"%s\") are not carried", type.c_str()));
         }
         if (type == "diffuse") m.type = GDPT_MAT_DIFFUSE;
@@ -428,7 +433,193 @@ private:
         else logError(format("bsdf \"%s\" is not carried: diffuse, conductor, roughconductor, dielectric, twosided", type.c_str()));
         if (m.type != GDPT_MAT_DIFFUSE && !(haveEta && haveK)) logError(format("bsdf \"%s\": explicit eta and k are required (the default `material=Cu` needs data/ior)", type.c_str()));
         sd.materials.push_back(m);
+        if (texIndex >= 0) {
+            sd.materialTexture.resize(sd.materials.size(), -1);
+            sd.materialTexture.back() = texIndex;
+            // BSDF::ensureEnergyConservation (bsdf.cpp:88-113; diffuse.cpp:95, conductor.cpp / roughconductor.cpp likewise): a reflectance
+            // texture whose maximum exceeds 1 is wrapped in a ScaleTexture of 0.99f / max
+            SceneData::Texture &t = sd.textures[texIndex];
+            double mx = 0.0;
+            for (double v : t.rgb) mx = std::max(mx, v);
+            t.scale = mx > 1.0 ? (double)0.99f * (1.0 / mx) : 1.0;
+        }
         return (int)sd.materials.size() - 1;
+    }
+
+    // ---- `<texture type="bitmap">` (src/textures/bitmap.cpp) ------------------------------------------------------------------------
+    // Carried: filterType nearest | bilinear (the two whose lookups do not depend on ray differentials: level 0 of the MIP map,
+    // bitmap.cpp:431-452, mipmap.h:628-633), wrapMode / wrapModeU / wrapModeV, gamma, uscale / vscale / uoffset / voffset (Texture2D,
+    // texture.cpp:27-45).  Files: PFM and uncompressed OpenEXR (linear floats), binary PPM and 8-bit PNG (sRGB unless `gamma` says otherwise),
+    // converted to Float as Bitmap::convert does (fmtconv.cpp:1137-1160: value/255 with the float reciprocal, then the sRGB curve).
+    int texture(const xml::Node &n, SceneData &sd)
+    {
+        const std::string type = subst(n.get("type"));
+        if (type != "bitmap") logError(format("texture \"%s\" is not carried: bitmap", type.c_str()));
+        SceneData::Texture t;
+        std::string filename, filterType = "ewa", wrapMode = "repeat", wrapU, wrapV;
+        double gamma = 0;
+        for (auto &c : n.children) {
+            const std::string nm = c->get("name", ""), v = subst(c->get("value", ""));
+            if (c->tag == "string" && nm == "filename") filename = v;
+            else if (c->tag == "string" && nm == "filterType") { filterType = v; for (char &ch : filterType) ch = (char)std::tolower((unsigned char)ch); }
+            else if (c->tag == "string" && nm == "wrapMode") wrapMode = v;
+            else if (c->tag == "string" && nm == "wrapModeU") wrapU = v;
+            else if (c->tag == "string" && nm == "wrapModeV") wrapV = v;
+            else if (c->tag == "float" && nm == "gamma") gamma = std::stod(v);
+            else if (c->tag == "float" && nm == "uscale") t.uscale = std::stod(v);
+            else if (c->tag == "float" && nm == "vscale") t.vscale = std::stod(v);
+            else if (c->tag == "float" && nm == "uoffset") t.uoffset = std::stod(v);
+            else if (c->tag == "float" && nm == "voffset") t.voffset = std::stod(v);
+            else if (c->tag == "float" && nm == "maxAnisotropy") {}                        // only EWA reads it
+            else if (c->tag == "boolean" && nm == "cache") {}                              // the MIP-map cache file: nothing to cache here
+            else logError(format("texture \"bitmap\": <%s name=\"%s\"> is not carried", c->tag.c_str(), nm.c_str()));
+        }
+        if (filterType == "nearest") t.filter = GDPT_TEXFILTER_NEAREST;
+        else if (filterType == "bilinear") t.filter = GDPT_TEXFILTER_BILINEAR;
+        else if (filterType == "ewa" || filterType == "trilinear")
+            logError(format("texture \"bitmap\": filterType \"%s\" reads the MIP pyramid through ray differentials, which this build does not carry; set filterType to \"bilinear\" or \"nearest\" (the reference's default is \"ewa\")", filterType.c_str()));
+        else logError(format("Invalid filter type '%s' -- must be 'ewa', 'trilinear', or 'nearest'!", filterType.c_str()));      // bitmap.cpp:229-230
+        auto wrapOf = [&](const std::string &w) {
+            if (w == "repeat") return GDPT_TEXWRAP_REPEAT;
+            if (w == "clamp") return GDPT_TEXWRAP_CLAMP;
+            if (w == "mirror") return GDPT_TEXWRAP_MIRROR;
+            if (w == "zero" || w == "black") return GDPT_TEXWRAP_ZERO;
+            if (w == "one" || w == "white") return GDPT_TEXWRAP_ONE;
+            logError(format("Invalid wrap mode '%s' -- must be 'repeat', 'clamp', 'black', or 'white'!", w.c_str()));           // bitmap.cpp:336-337
+        };
+        t.wrapU = wrapOf(wrapU.empty() ? wrapMode : wrapU);
+        t.wrapV = wrapOf(wrapV.empty() ? wrapMode : wrapV);
+        if (filename.empty()) logError("texture \"bitmap\": missing filename");
+        loadImage(filename[0] == '/' ? filename : m_dir + "/" + filename, gamma, t);
+        sd.textures.push_back(std::move(t));
+        return (int)sd.textures.size() - 1;
+    }
+
+    // undoGamma of fmtconv.cpp:1093-1102 (gamma == -1: the sRGB curve)
+    static double undoGamma(double value, double gamma)
+    {
+        if (gamma == -1) return value <= 0.04045 ? value * (1.0 / 12.92) : std::pow((value + 0.055) * (1.0 / 1.055), 2.4);
+        return std::pow(value, gamma);
+    }
+
+    // -> t.width, t.height, t.rgb (linear, top row first).  fileGamma: what the format implies (-1 sRGB for the 8-bit formats, 1 for floats);
+    // `gamma` != 0 overrides it (bitmap.cpp:251-252).
+    void loadImage(const std::string &path, double gamma, SceneData::Texture &t)
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) logError(format("Cannot open texture \"%s\"", path.c_str()));
+        std::vector<unsigned char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        auto from8 = [&](const std::vector<unsigned char> &px, int w, int h, int channels) {          // fmtconv.cpp:1137-1160 (uint8 source, Float destination)
+            const double g = gamma != 0 ? gamma : -1.0;
+            double table[256];
+            for (int i = 0; i < 256; ++i) { double v = (double)i * (double)(1.0f / 255); if (g != 1) v = undoGamma(v, g); table[i] = v; }
+            t.width = w; t.height = h; t.rgb.resize((size_t)3 * w * h);
+            for (size_t i = 0; i < (size_t)w * h; ++i)
+                for (int c = 0; c < 3; ++c) t.rgb[3 * i + c] = table[px[i * channels + (channels >= 3 ? c : 0)]];
+        };
+        if (data.size() >= 2 && data[0] == 'P' && (data[1] == 'F' || data[1] == '6')) {
+            size_t at = 2;
+            auto token = [&]() { while (at < data.size() && std::isspace(data[at])) ++at; if (at < data.size() && data[at] == '#') { while (at < data.size() && data[at] != '\n') ++at; while (at < data.size() && std::isspace(data[at])) ++at; }
+                                 std::string tok; while (at < data.size() && !std::isspace(data[at])) tok += (char)data[at++]; return tok; };
+            const int w = std::atoi(token().c_str()), h = std::atoi(token().c_str());
+            const double third = std::atof(token().c_str());
+            ++at;                                                                                     // the single whitespace after the header
+            if (w <= 0 || h <= 0) logError(path + ": bad image header");
+            if (data[1] == 'F') {                                                                     // PFM: bottom row first, little endian when the scale is negative
+                if (!(third < 0)) logError(path + ": big-endian PFM is not carried");
+                if (at + sizeof(float) * 3 * (size_t)w * h > data.size()) logError(path + ": truncated");
+                t.width = w; t.height = h; t.rgb.resize((size_t)3 * w * h);
+                for (int y = 0; y < h; ++y)
+                    for (int x = 0; x < 3 * w; ++x) { float v; std::memcpy(&v, &data[at + sizeof(float) * ((size_t)(h - 1 - y) * 3 * w + x)], sizeof v); t.rgb[(size_t)y * 3 * w + x] = gamma != 0 && gamma != 1 ? undoGamma((double)v, gamma) : (double)v; }
+            } else {
+                if ((int)third != 255) logError(path + ": only 8-bit PPM is carried");
+                if (at + (size_t)3 * w * h > data.size()) logError(path + ": truncated");
+                from8(std::vector<unsigned char>(data.begin() + at, data.begin() + at + (size_t)3 * w * h), w, h, 3);
+            }
+            return;
+        }
+        if (data.size() >= 8 && data[0] == 0x89 && data[1] == 'P' && data[2] == 'N' && data[3] == 'G') {
+            // PNG: 8-bit greyscale / RGB / RGBA (+ grey-alpha), no interlace; zlib inflate + the five scanline filters
+            auto be32 = [&](size_t o) { if (o + 4 > data.size()) logError(path + ": truncated"); return ((unsigned)data[o] << 24) | ((unsigned)data[o + 1] << 16) | ((unsigned)data[o + 2] << 8) | data[o + 3]; };
+            size_t at = 8;
+            unsigned w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+            std::vector<unsigned char> z;
+            while (at + 12 <= data.size()) {
+                const unsigned len = be32(at);
+                const std::string tag(data.begin() + at + 4, data.begin() + at + 8);
+                if (at + 12 + len > data.size()) logError(path + ": truncated");
+                if (tag == "IHDR") { w = be32(at + 8); h = be32(at + 12); depth = data[at + 16]; ctype = data[at + 17]; interlace = data[at + 20]; }
+                else if (tag == "IDAT") z.insert(z.end(), data.begin() + at + 8, data.begin() + at + 8 + len);
+                else if (tag == "IEND") break;
+                at += 12 + len;
+            }
+            const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+            if (depth != 8 || !channels || interlace || !w || !h) logError(path + ": only 8-bit non-interlaced grey / RGB / RGBA PNG files are carried");
+            const size_t stride = (size_t)w * channels;
+            std::vector<unsigned char> raw((stride + 1) * h);
+            uLongf outLen = (uLongf)raw.size();
+            if (uncompress(raw.data(), &outLen, z.data(), (uLong)z.size()) != Z_OK || outLen != raw.size()) logError(path + ": PNG data is corrupt");
+            std::vector<unsigned char> px(stride * h);
+            for (unsigned y = 0; y < h; ++y) {
+                const unsigned char *in = &raw[(stride + 1) * y + 1], *up = y ? &px[stride * (y - 1)] : nullptr;
+                unsigned char *out = &px[stride * y];
+                const int ft = raw[(stride + 1) * y];
+                for (size_t i = 0; i < stride; ++i) {
+                    const int a = i >= (size_t)channels ? out[i - channels] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)channels) ? up[i - channels] : 0;
+                    int pred = 0;
+                    if (ft == 1) pred = a; else if (ft == 2) pred = b; else if (ft == 3) pred = (a + b) / 2;
+                    else if (ft == 4) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+                    else if (ft != 0) logError(path + ": PNG data is corrupt");
+                    out[i] = (unsigned char)(in[i] + pred);
+                }
+            }
+            if (channels == 2 || channels == 4) {                                                     // drop alpha (the texture reads the colour channels: bitmap.cpp:268-275)
+                const int keep = channels - 1;
+                std::vector<unsigned char> q((size_t)w * h * keep);
+                for (size_t i = 0; i < (size_t)w * h; ++i) for (int c = 0; c < keep; ++c) q[i * keep + c] = px[i * channels + c];
+                from8(q, (int)w, (int)h, keep);
+            } else from8(px, (int)w, (int)h, channels);
+            return;
+        }
+        if (data.size() >= 4 && data[0] == 0x76 && data[1] == 0x2f && data[2] == 0x31 && data[3] == 0x01) {
+            // OpenEXR, the subset this build writes itself (uncompressed scanlines, half or float channels B G R in file order)
+            size_t at = 8;
+            int w = 0, h = 0, compression = -1;
+            std::vector<std::pair<std::string, int>> channels;                                        // name, pixel type (1 half, 2 float)
+            auto cstr = [&]() { std::string r; while (at < data.size() && data[at]) r += (char)data[at++]; ++at; return r; };
+            auto le32 = [&](size_t o) { if (o + 4 > data.size()) logError(path + ": truncated"); unsigned v; std::memcpy(&v, &data[o], 4); return v; };
+            while (at < data.size() && data[at]) {
+                const std::string name = cstr(), atype = cstr();
+                const unsigned size = le32(at); at += 4;
+                if (name == "channels") { size_t p = at; while (data[p]) { std::string cn; while (data[p]) cn += (char)data[p++]; ++p; const int pt = (int)le32(p); p += 16; channels.emplace_back(cn, pt); } }
+                else if (name == "compression") compression = data[at];
+                else if (name == "dataWindow") { w = (int)le32(at + 8) - (int)le32(at) + 1; h = (int)le32(at + 12) - (int)le32(at + 4) + 1; }
+                at += size;
+            }
+            ++at;
+            if (compression != 0 || w <= 0 || h <= 0 || channels.empty()) logError(path + ": only uncompressed scanline OpenEXR files are carried");
+            size_t rowBytes = 0;
+            for (auto &c : channels) rowBytes += (size_t)w * (c.second == 1 ? 2 : 4);
+            t.width = w; t.height = h; t.rgb.assign((size_t)3 * w * h, 0.0);
+            auto half2d = [](unsigned short hv) { const int s = hv >> 15, e = (hv >> 10) & 31, m = hv & 1023; double v = e == 0 ? std::ldexp((double)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp((double)(m + 1024), e - 25)); return s ? -v : v; };
+            for (int y = 0; y < h; ++y) {
+                const size_t off = (size_t)(le32(at + 8 * (size_t)y)) | ((size_t)le32(at + 8 * (size_t)y + 4) << 32);
+                size_t p = off + 8;
+                for (auto &c : channels) {
+                    const int dst = c.first == "R" ? 0 : c.first == "G" ? 1 : c.first == "B" ? 2 : (c.first == "Y" ? 3 : -1);
+                    for (int x = 0; x < w; ++x) {
+                        double v;
+                        if (c.second == 1) { unsigned short hv; if (p + 2 > data.size()) logError(path + ": truncated"); std::memcpy(&hv, &data[p], 2); p += 2; v = half2d(hv); }
+                        else { float fv; if (p + 4 > data.size()) logError(path + ": truncated"); std::memcpy(&fv, &data[p], 4); p += 4; v = (double)fv; }
+                        if (gamma != 0 && gamma != 1) v = undoGamma(v, gamma);
+                        if (dst == 3) for (int k = 0; k < 3; ++k) t.rgb[((size_t)y * w + x) * 3 + k] = v;
+                        else if (dst >= 0) t.rgb[((size_t)y * w + x) * 3 + dst] = v;
+                    }
+                }
+            }
+            return;
+        }
+        logError(format("texture \"%s\": the file format is not carried (PFM, PPM, 8-bit PNG, uncompressed OpenEXR)", path.c_str()));
     }
 
     /// lookupIOR (src/bsdfs/ior.h:40-80): a number, or one of the named media (float literals there, hence the casts)
@@ -488,7 +679,7 @@ private:
         const std::string type = subst(n.get("type"));
         Mat4 T = Mat4::identity();
         int mat = -1;
-        bool flipNormals = false, faceNormals = false, emits = false;
+        bool flipNormals = false, faceNormals = false, emits = false, flipTexCoords = true;
         int shapeIndex = 0;
         double radiance[3] = {1, 1, 1};
         std::string filename;
@@ -507,6 +698,7 @@ private:
             } else if (c->tag == "string" && c->get("name") == "filename") filename = subst(c->get("value"));
             else if (c->tag == "boolean" && c->get("name") == "flipNormals") flipNormals = subst(c->get("value")) == "true";
             else if (c->tag == "boolean" && c->get("name") == "faceNormals") faceNormals = subst(c->get("value")) == "true";
+            else if (c->tag == "boolean" && c->get("name") == "flipTexCoords") flipTexCoords = subst(c->get("value")) == "true";
             else if (c->tag == "integer" && c->get("name") == "shapeIndex") shapeIndex = std::atoi(subst(c->get("value")).c_str());
             else logError(format("shape \"%s\": <%s name=\"%s\"> is not carried", type.c_str(), c->tag.c_str(), c->get("name", "").c_str()));
         }
@@ -517,13 +709,27 @@ private:
             const double v[4][3] = {{-1, -1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 1, 0}};
             addTri(sd, T, flip, v[0], v[1], v[2], mat);
             addTri(sd, T, flip, v[2], v[3], v[0], mat);
+            {   // Rectangle::fillIntersectionRecord: its.uv = (0.5 (x + 1), 0.5 (y + 1)) of the local hit point (rectangle.cpp) -- affine in the
+                // position, so per-vertex coordinates (0,0) (1,0) (1,1) (0,1) interpolate to the same value
+                const double q[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+                const int corners[2][3] = {{0, 1, 2}, {2, 3, 0}};
+                sd.uvs.resize(6 * (size_t)sd.numTriangles(), 0.0);
+                sd.triHasUV.resize((size_t)sd.numTriangles(), 0);
+                for (int t = 0; t < 2; ++t) {
+                    const size_t ti = (size_t)sd.numTriangles() - 2 + t;
+                    int order[3] = {corners[t][0], corners[t][1], corners[t][2]};
+                    if (flip) std::swap(order[1], order[2]);                      // addTri swaps the last two vertices of a flipped triangle
+                    for (int j = 0; j < 3; ++j) { sd.uvs[6 * ti + 2 * j] = q[order[j]][0]; sd.uvs[6 * ti + 2 * j + 1] = q[order[j]][1]; }
+                    sd.triHasUV[ti] = 1;
+                }
+            }
         } else if (type == "cube") {                             // src/shapes/cube.cpp: [-1,1]^3, outward normals
             const double c[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
             const int f[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {1, 2, 6, 5}, {0, 4, 7, 3}};
             for (auto &q : f) { addTri(sd, T, flip, c[q[0]], c[q[1]], c[q[2]], mat); addTri(sd, T, flip, c[q[0]], c[q[2]], c[q[3]], mat); }
         } else if (type == "obj") {
             if (filename.empty()) logError("shape \"obj\": missing filename");
-            loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flipNormals, faceNormals, mat);   // obj.cpp applies no handedness correction
+            loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flipNormals, faceNormals, mat, flipTexCoords);   // obj.cpp applies no handedness correction
         } else if (type == "serialized") {
             if (filename.empty()) logError("shape \"serialized\": missing filename");
             loadSerialized(filename[0] == '/' ? filename : m_dir + "/" + filename, shapeIndex, sd, T, flipNormals, faceNormals, mat);
@@ -542,7 +748,8 @@ private:
     // normals are kept (flipNormals negates them); a mesh without normals gets angle-weighted vertex normals (flipNormals negates
     // them too).  Vertex normals that equal the face normal of every triangle using them are dropped again: the flat code path gives
     // the same frame without the per-hit interpolation.
-    void finishMesh(SceneData &sd, const std::vector<std::array<double, 6>> &vb, std::vector<std::array<int, 3>> idx, bool hasNormals, bool flipNormals, bool faceNormals, int mat)
+    void finishMesh(SceneData &sd, const std::vector<std::array<double, 6>> &vb, std::vector<std::array<int, 3>> idx, bool hasNormals, bool flipNormals, bool faceNormals, int mat,
+                    const std::vector<std::array<double, 2>> *uv = nullptr)
     {
         std::vector<std::array<double, 3>> vn(vb.size(), std::array<double, 3>{{0.0, 0.0, 0.0}});
         bool useNormals = false;
@@ -595,6 +802,12 @@ private:
         for (size_t t = 0; t < idx.size(); ++t) {
             for (int j = 0; j < 3; ++j) sd.verts.insert(sd.verts.end(), vb[idx[t][j]].data(), vb[idx[t][j]].data() + 3);
             sd.triMaterial.push_back(mat);
+            if (uv) {                                                             // TriMesh::getVertexTexcoords of this mesh (skdtree.h:398-402)
+                sd.uvs.resize(6 * (size_t)sd.numTriangles(), 0.0);
+                sd.triHasUV.resize((size_t)sd.numTriangles(), 0);
+                for (int j = 0; j < 3; ++j) for (int k = 0; k < 2; ++k) sd.uvs[6 * (size_t)(sd.numTriangles() - 1) + 2 * j + k] = (*uv)[idx[t][j]][k];
+                sd.triHasUV[(size_t)sd.numTriangles() - 1] = 1;
+            }
             if (useNormals) {
                 sd.normals.resize(9 * (size_t)sd.numTriangles(), 0.0);
                 for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) sd.normals[9 * (size_t)(sd.numTriangles() - 1) + 3 * j + k] = vn[idx[t][j]][k];
@@ -667,7 +880,8 @@ private:
                 const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                 for (int k = 0; k < 3; ++k) vb[i][3 + k] = n[k] / l;                 // serialized.cpp:191-194
             }
-        if (flags & 0x0002) for (size_t i = 0; i < 2 * nv; ++i) rfl();                // texture coordinates: read past (no carried BSDF uses them)
+        std::vector<std::array<double, 2>> uv2;
+        if (flags & 0x0002) { uv2.resize(nv); for (size_t i = 0; i < nv; ++i) { uv2[i][0] = rfl(); uv2[i][1] = rfl(); } }   // texture coordinates (trimesh.cpp:222-226)
         if (flags & 0x0008) for (size_t i = 0; i < 3 * nv; ++i) rfl();                // vertex colours
         std::vector<std::array<int, 3>> idx(nt);
         const bool mirror = T.det3() < 0;
@@ -675,7 +889,7 @@ private:
             for (int j = 0; j < 3; ++j) { const unsigned v = r32(); if (v >= nv) logError(path + ": triangle references a vertex out of range"); idx[t][j] = (int)v; }
             if (mirror) std::swap(idx[t][0], idx[t][1]);
         }
-        finishMesh(sd, vb, idx, hasNormals, flipNormals, faceNormals, mat);
+        finishMesh(sd, vb, idx, hasNormals, flipNormals, faceNormals, mat, uv2.empty() ? nullptr : &uv2);
     }
 
     // Wavefront OBJ subset (src/shapes/obj.cpp): v, vn, vt, f with v / v/vt / v//vn / v/vt/vn and negative indices, polygons fanned,
@@ -685,7 +899,7 @@ private:
     // a mesh without normals gets angle-weighted vertex normals over the merged vertices (flipNormals negates them too).
     // Vertex normals that equal the face normal of every triangle using them are dropped again: the flat code path gives the
     // same frame without the per-hit interpolation.
-    void loadObj(const std::string &path, SceneData &sd, const Mat4 &T, bool flipNormals, bool faceNormals, int mat)
+    void loadObj(const std::string &path, SceneData &sd, const Mat4 &T, bool flipNormals, bool faceNormals, int mat, bool flipTexCoords = true)
     {
         std::ifstream f(path);
         if (!f) logError(format("Cannot open OBJ file \"%s\"", path.c_str()));
@@ -698,7 +912,7 @@ private:
             std::map<V, int> vmap;
             std::vector<V> vb;
             std::vector<std::array<int, 3>> idx;
-            bool hasNormals = false;
+            bool hasNormals = false, hasTexcoords = false;
             for (auto &tr : tris) {
                 std::array<int, 3> id;
                 for (int j = 0; j < 3; ++j) {
@@ -711,7 +925,7 @@ private:
                         if (l != 0) for (int k = 3; k < 6; ++k) v.d[k] /= l;
                         hasNormals = true;
                     }
-                    if (tr[j].t >= 0) { v.d[6] = tex[2 * tr[j].t]; v.d[7] = tex[2 * tr[j].t + 1]; }
+                    if (tr[j].t >= 0) { v.d[6] = tex[2 * tr[j].t]; v.d[7] = tex[2 * tr[j].t + 1]; hasTexcoords = true; }    // obj.cpp:664-669
                     for (double &c : v.d) if (c == 0) c = 0.0;                      // -0.0 and 0.0 are one key
                     auto it = vmap.find(v);
                     if (it == vmap.end()) { it = vmap.emplace(v, (int)vb.size()).first; vb.push_back(v); }
@@ -720,8 +934,9 @@ private:
                 idx.push_back(id);
             }
             std::vector<std::array<double, 6>> verts6(vb.size());
-            for (size_t i = 0; i < vb.size(); ++i) for (int k = 0; k < 6; ++k) verts6[i][k] = vb[i].d[k];
-            finishMesh(sd, verts6, idx, hasNormals, flipNormals, faceNormals, mat);
+            std::vector<std::array<double, 2>> uv2(vb.size());
+            for (size_t i = 0; i < vb.size(); ++i) { for (int k = 0; k < 6; ++k) verts6[i][k] = vb[i].d[k]; uv2[i] = {{vb[i].d[6], vb[i].d[7]}}; }
+            finishMesh(sd, verts6, idx, hasNormals, flipNormals, faceNormals, mat, hasTexcoords ? &uv2 : nullptr);
             tris.clear();
         };
         std::string line;
@@ -731,7 +946,7 @@ private:
             if (!(ss >> tag)) continue;
             if (tag == "v") { double x, y, z; ss >> x >> y >> z; pos.push_back(x); pos.push_back(y); pos.push_back(z); }
             else if (tag == "vn") { double x, y, z; ss >> x >> y >> z; nrm.push_back(x); nrm.push_back(y); nrm.push_back(z); }
-            else if (tag == "vt") { double u = 0, v = 0; ss >> u >> v; tex.push_back(u); tex.push_back(v); }
+            else if (tag == "vt") { double u = 0, v = 0; ss >> u >> v; if (flipTexCoords) v = 1 - v; tex.push_back(u); tex.push_back(v); }   // obj.cpp:304-308
             else if (tag == "o" || tag == "g") flush();
             else if (tag == "f") {
                 std::vector<Corner> cs;

@@ -15,6 +15,8 @@ MAT_DIFFUSE, MAT_CONDUCTOR, MAT_ROUGHCONDUCTOR, MAT_DIELECTRIC = 0, 1, 2, 3
 DISTR_BECKMANN, DISTR_GGX, DISTR_PHONG = 0, 1, 2
 # reconstruction filters (src/rfilters): (kind, p0, p1) with the reference's default parameters
 RFILTER_BOX, RFILTER_TENT, RFILTER_GAUSSIAN, RFILTER_MITCHELL, RFILTER_CATMULLROM, RFILTER_LANCZOS = range(6)
+TEXWRAP_REPEAT, TEXWRAP_CLAMP, TEXWRAP_MIRROR, TEXWRAP_ZERO, TEXWRAP_ONE = range(5)      # bitmap.cpp:324-338
+TEXFILTER_NEAREST, TEXFILTER_BILINEAR = 0, 1
 RFILTER_DEFAULTS = {0: (0, 0.0, 0.0), 1: (1, 0.0, 0.0), 2: (2, 0.5, 0.0), 3: (3, 1.0 / 3.0, 1.0 / 3.0), 4: (4, 0.0, 0.0), 5: (5, 3.0, 0.0)}
 
 
@@ -78,6 +80,10 @@ class Scene:
     environment: tuple = None    # ((r, g, b), position in the scene's emitter list) for `<emitter type="constant">`, or None
     rfilter: tuple = None        # (kind, p0, p1) of the film's reconstruction filter (RFILTER_*); None = box
     normals: np.ndarray = None   # (ntri, 9) per-vertex normals (TriMesh vertex normals), all-zero rows = flat triangle; or None
+    uvs: np.ndarray = None       # (ntri, 6) per-vertex texture coordinates u0 v0 u1 v1 u2 v2; or None (its.uv = the hit's barycentrics)
+    tri_has_uv: np.ndarray = None   # (ntri,) 1 = the triangle's mesh has texture coordinates (None = all, when uvs is given)
+    textures: list = None        # bitmap textures: dicts with rgb [h, w, 3] (linear), wrapU/wrapV (TEXWRAP_*), filter (TEXFILTER_*), uscale, vscale, uoffset, voffset, scale
+    material_textures: list = None   # per material: texture index on its reflectance / specularReflectance, -1 = constant
 
     @property
     def ntri(self):
@@ -286,3 +292,55 @@ def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):
     b.emitter(first, 2, (7.0, 6.5, 5.5))
     return b.finish(to_world=lookat((-17.0, 3.2, 0.6), (0.0, 4.5, 0.0), (0, 1, 0)), fov_x=70.0, near=0.1, far=200.0,
                     width=width, height=height, name="atrium")
+
+
+def bitmap_texture(rgb, wrap=TEXWRAP_REPEAT, filter=TEXFILTER_BILINEAR, uscale=1.0, vscale=1.0, uoffset=0.0, voffset=0.0, wrapV=None, conserve=True):
+    """`<texture type="bitmap">` with filterType nearest | bilinear (reference src/textures/bitmap.cpp).  rgb: [h, w, 3] LINEAR values,
+    top row first.  conserve: BSDF::ensureEnergyConservation (src/librender/bsdf.cpp) -- a reflectance texture whose maximum exceeds 1
+    is scaled by 0.99 / max."""
+    rgb = np.ascontiguousarray(rgb, np.float64)
+    mx = float(rgb.max())
+    scale = float(np.float32(0.99)) * (1.0 / mx) if (conserve and mx > 1.0) else 1.0      # bsdf.cpp:96: 0.99f * (max / actualMax)
+    return dict(rgb=rgb, wrapU=wrap, wrapV=wrap if wrapV is None else wrapV, filter=filter, uscale=uscale, vscale=vscale, uoffset=uoffset, voffset=voffset, scale=scale)
+
+
+def checker_rgb(w=16, h=12, seed=3):
+    """A small test bitmap: coloured checker with per-texel noise (so that every texel, wrap mode and the bilinear weights matter)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.where(((xx // 2 + yy // 2) % 2)[..., None] == 0, np.array([0.75, 0.2, 0.15]), np.array([0.15, 0.55, 0.8]))
+    return np.clip(base + 0.15 * rng.random((h, w, 3)), 0.0, 1.0)
+
+
+def textured_cornell_box(width=64, height=48, filter=TEXFILTER_BILINEAR, wrap=TEXWRAP_REPEAT, seed=0):
+    """The Cornell box with bitmap textures: the floor (texture coordinates tiled 3 x 2.5 over it, so the wrap mode shows), the back wall
+    (a mesh WITHOUT texture coordinates: its.uv = the barycentrics) and a rough-copper short block whose specularReflectance is textured."""
+    sc = cornell_box(width, height, "diffuse")
+    nt = sc.ntri
+    floor_m = len(sc.materials); sc.materials.append(diffuse((0.5, 0.5, 0.5)))
+    back_m = len(sc.materials); sc.materials.append(diffuse((0.5, 0.5, 0.5)))
+    block_m = len(sc.materials); sc.materials.append(roughconductor(0.15, **CU))
+    tm = np.array(sc.tri_material, np.int32).copy()
+    tm[0:2] = floor_m; tm[4:6] = back_m; tm[10:20] = block_m              # floor, back wall, the short block (10 triangles after the 5 walls)
+    sc.tri_material = tm
+    uvs = np.zeros((nt, 6)); has = np.zeros(nt, np.uint8)
+    v = np.asarray(sc.verts).reshape(nt, 3, 3)
+    for t in (0, 1):                                                      # floor: uv from x and z, running past [0, 1]
+        for j in range(3):
+            uvs[t, 2 * j] = v[t, j, 0] / 552.8 * 3.0 - 0.7
+            uvs[t, 2 * j + 1] = v[t, j, 2] / 559.2 * 2.5 - 0.4
+        has[t] = 1
+    for t in range(10, 20):                                               # the block: uv from x + y and z
+        for j in range(3):
+            uvs[t, 2 * j] = (v[t, j, 0] + v[t, j, 1]) / 200.0
+            uvs[t, 2 * j + 1] = v[t, j, 2] / 150.0
+        has[t] = 1
+    sc.uvs, sc.tri_has_uv = uvs, has
+    sc.textures = [bitmap_texture(checker_rgb(16, 12, seed), wrap=wrap, filter=filter),
+                   bitmap_texture(checker_rgb(7, 5, seed + 1) * 1.3, wrap=TEXWRAP_MIRROR, filter=filter, uscale=2.0, vscale=3.0, uoffset=0.25, voffset=-0.5),
+                   bitmap_texture(checker_rgb(9, 9, seed + 2), wrap=TEXWRAP_CLAMP, wrapV=TEXWRAP_ONE, filter=TEXFILTER_NEAREST)]
+    mt = [-1] * len(sc.materials)
+    mt[floor_m], mt[back_m], mt[block_m] = 0, 1, 2
+    sc.material_textures = mt
+    sc.name = "cornell-textured"
+    return sc

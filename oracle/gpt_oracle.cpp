@@ -187,6 +187,55 @@ struct Tri {
     V3 geoN;
     bool hasNormals = false;   // per-vertex normals (TriMesh::getVertexNormals): interpolated shading normal, skdtree.h:382-394
     V3 n0, n1, n2;
+    bool hasUV = false;        // per-vertex texture coordinates (TriMesh::getVertexTexcoords), skdtree.h:398-405
+    Float uv[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// `<texture type="bitmap">` (src/textures/bitmap.cpp) as the G-PT path evaluates it.  Texture2D::eval (texture.cpp:112-121) scales and
+// offsets its.uv; with filterType nearest / bilinear both BitmapTexture::eval overloads end in MIPMap::evalBox / evalBilinear on
+// level 0 (bitmap.cpp:431-452, mipmap.h:566-596,628-633), ray differentials or not -- the two filter types carried here ("ewa" and
+// "trilinear" read the MIP pyramid through the primary ray's differentials: not carried).  Texels are Float (the MIP map converts the
+// file to Bitmap::EFloat), wrap modes as evalTexel (mipmap.h:503-561).  `scale` is the factor of BSDF::ensureEnergyConservation
+// (bsdf.cpp: 0.99 / max when the texture exceeds 1), applied to the interpolated value as ScaleTexture does.
+struct Texture {
+    int w = 0, h = 0, wrapU = 0, wrapV = 0, filter = 1;      // wrap: 0 repeat, 1 clamp, 2 mirror, 3 zero, 4 one; filter: 0 nearest, 1 bilinear
+    Float uscale = 1, vscale = 1, uoffset = 0, voffset = 0, scale = 1;
+    std::vector<Float> rgb;                                   // [h][w][3], top row first
+    static int modulo(int a, int b) { const int r = a % b; return r < 0 ? r + b : r; }        // math::modulo, math.h
+    static int floorToInt(Float v) { return (int)std::floor(v); }
+    bool wrap(int &x, int size, int mode, Float &constant) const
+    {
+        if (x >= 0 && x < size) return true;
+        switch (mode) {
+            case 0: x = modulo(x, size); return true;
+            case 1: x = std::min(std::max(x, 0), size - 1); return true;
+            case 2: x = modulo(x, 2 * size); if (x >= size) x = 2 * size - x - 1; return true;
+            case 3: constant = 0.0; return false;
+            default: constant = 1.0; return false;
+        }
+    }
+    V3 texel(int x, int y) const
+    {
+        Float c = 0;
+        if (!wrap(x, w, wrapU, c)) return V3(c);
+        if (!wrap(y, h, wrapV, c)) return V3(c);
+        const Float *t = &rgb[((size_t)y * w + x) * 3];
+        return V3(t[0], t[1], t[2]);
+    }
+    V3 eval(Float u_, Float v_) const
+    {
+        const Float ux = u_ * uscale + uoffset, vy = v_ * vscale + voffset;                   // texture.cpp:113
+        V3 value;
+        if (filter == 0) value = texel(floorToInt(ux * w), floorToInt(vy * h));               // evalBox, mipmap.h:566-569
+        else {
+            if (!std::isfinite(ux) || !std::isfinite(vy)) return V3(0.0) * scale;             // mipmap.h:576-578
+            const Float u = ux * w - 0.5f, v = vy * h - 0.5f;                                 // :586
+            const int xPos = floorToInt(u), yPos = floorToInt(v);
+            const Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+            value = texel(xPos, yPos) * dx2 * dy2 + texel(xPos, yPos + 1) * dx2 * dy1 + texel(xPos + 1, yPos) * dx1 * dy2 + texel(xPos + 1, yPos + 1) * dx1 * dy1;   // :592-595
+        }
+        return value * scale;
+    }
 };
 
 struct Emitter {
@@ -247,6 +296,7 @@ struct Ray {
 struct Intersection {
     Float t;
     int prim;
+    Float u = 0, v = 0;         // its.uv
     V3 p, wi;
     Frame sh;
     V3 geoN;
@@ -257,6 +307,8 @@ struct Intersection {
 struct Scene {
     std::vector<Tri> tris;
     std::vector<gpo_material> mats;
+    std::vector<int> matTexture;    // per material: index of the bitmap texture on its `reflectance` / `specularReflectance`, -1 = constant
+    std::vector<Texture> textures;
     std::vector<Emitter> emitters;
     Distribution emitterPDF; // scene.cpp:357-380, every emitter has sampling weight 1
     gpo_camera cam;
@@ -443,6 +495,10 @@ bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
         its.sh.s = normalize(dpdu - its.sh.n * dot(its.sh.n, dpdu));     // computeShadingFrame, util.cpp:603-608
         its.sh.t = cross(its.sh.n, its.sh.s);
     }
+    if (tr.hasUV) {                                                      // skdtree.h:398-405
+        its.u = tr.uv[0] * b.x + tr.uv[2] * b.y + tr.uv[4] * b.z;
+        its.v = tr.uv[1] * b.x + tr.uv[3] * b.y + tr.uv[5] * b.z;
+    } else { its.u = b.y; its.v = b.z; }
     its.wi = its.sh.toLocal(-ray.d);
     return true;
 }
@@ -1197,7 +1253,16 @@ ReconnectionShiftResult reconnectShift(const Scene &sc, V3 mainSourceVertex, V3 
     return result;
 }
 
-inline const gpo_material &matOf(const Scene &sc, const Intersection &its) { return sc.mats[sc.tris[its.prim].material]; }
+// its.getBSDF(): the material of the hit, with a textured reflectance resolved at its.uv (diffuse.cpp:107,116,137,149: m_reflectance->eval(its);
+// likewise specularReflectance of the conductors and the dielectric)
+inline gpo_material matOf(const Scene &sc, const Intersection &its)
+{
+    const int mi = sc.tris[its.prim].material;
+    gpo_material m = sc.mats[mi];
+    const int ti = mi < (int)sc.matTexture.size() ? sc.matTexture[mi] : -1;
+    if (ti >= 0) { const V3 r = sc.textures[ti].eval(its.u, its.v); m.reflectance[0] = r.x; m.reflectance[1] = r.y; m.reflectance[2] = r.z; }
+    return m;
+}
 
 // GradientPathTracer::evaluate, gpt.cpp:468-1180 (no sub-surface scattering in the carried subset; the environment emitter is `constant`)
 void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, RayState *shiftedRays, int secondaryCount, V3 &out_veryDirect)
@@ -1766,6 +1831,38 @@ GPO_API int gpo_scene_set_normals(gpo_scene *h, const double *n9)
         t.n0 = V3(n[0], n[1], n[2]); t.n1 = V3(n[3], n[4], n[5]); t.n2 = V3(n[6], n[7], n[8]);
     }
     return 0;
+}
+
+// Per-vertex texture coordinates: 6 doubles per triangle (u0 v0 u1 v1 u2 v2); triangles of meshes without texcoords keep its.uv = (b1, b2).
+GPO_API void gpo_scene_set_uvs(gpo_scene *h, const double *uv6, const unsigned char *hasUV)
+{
+    Scene &sc = h->sc;
+    for (size_t i = 0; i < sc.tris.size(); ++i) {
+        if (hasUV && !hasUV[i]) continue;
+        sc.tris[i].hasUV = true;
+        for (int k = 0; k < 6; ++k) sc.tris[i].uv[k] = uv6[6 * i + k];
+    }
+}
+// Adds a bitmap texture (rgb: h x w x 3 doubles, top row first) and returns its index; params = {wrapU, wrapV, filter}, fparams = {uscale, vscale, uoffset, voffset, scale}
+GPO_API int gpo_scene_add_texture(gpo_scene *h, int w, int hgt, const double *rgb, const int *params, const double *fparams)
+{
+    Texture t;
+    t.w = w; t.h = hgt; t.wrapU = params[0]; t.wrapV = params[1]; t.filter = params[2];
+    t.uscale = fparams[0]; t.vscale = fparams[1]; t.uoffset = fparams[2]; t.voffset = fparams[3]; t.scale = fparams[4];
+    t.rgb.assign(rgb, rgb + (size_t)w * hgt * 3);
+    h->sc.textures.push_back(t);
+    return (int)h->sc.textures.size() - 1;
+}
+GPO_API void gpo_scene_set_material_texture(gpo_scene *h, int material, int texture)
+{
+    Scene &sc = h->sc;
+    if (sc.matTexture.size() < sc.mats.size()) sc.matTexture.resize(sc.mats.size(), -1);
+    sc.matTexture[material] = texture;
+}
+GPO_API void gpo_texture_eval(gpo_scene *h, int texture, double u, double v, double *rgb)
+{
+    const V3 r = h->sc.textures[texture].eval(u, v);
+    rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
 }
 
 // `<rfilter>` of the film: kind as in Film::filterEval, p0/p1 its parameters (defaults are the caller's business)

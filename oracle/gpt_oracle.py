@@ -72,6 +72,10 @@ def lib():
         L.gpo_scene_set_environment.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpo_scene_set_normals.argtypes = [C.c_void_p, C.c_void_p]
         L.gpo_scene_set_rfilter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.gpo_scene_set_uvs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_scene_set_material_texture.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.gpo_texture_eval.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_last_invalid_puts.restype = C.c_ulonglong
         L.gpo_last_invalid_puts.argtypes = [C.c_void_p]
@@ -138,6 +142,19 @@ class Scene:
         if nrm is not None:                                  # (ntri, 9) per-vertex normals, zero rows = flat triangle
             if lib().gpo_scene_set_normals(self._h, _p(_d(nrm))) != 0:
                 raise ValueError("vertex normals on emitter triangles are not carried")
+        uvs = getattr(desc, "uvs", None)
+        if uvs is not None:                                  # (ntri, 6) texture coordinates; tri_has_uv marks the meshes that have them
+            has = getattr(desc, "tri_has_uv", None)
+            has = np.ascontiguousarray(has, dtype=np.uint8) if has is not None else None
+            lib().gpo_scene_set_uvs(self._h, _p(_d(uvs)), _p(has) if has is not None else None)
+        for t in (getattr(desc, "textures", None) or []):
+            rgb = _d(t["rgb"])
+            ip = np.array([t.get("wrapU", 0), t.get("wrapV", 0), t.get("filter", 1)], np.int32)
+            fp = np.array([t.get("uscale", 1.0), t.get("vscale", 1.0), t.get("uoffset", 0.0), t.get("voffset", 0.0), t.get("scale", 1.0)], np.float64)
+            lib().gpo_scene_add_texture(self._h, rgb.shape[1], rgb.shape[0], _p(rgb), _p(ip), _p(fp))
+        for mi, ti in enumerate(getattr(desc, "material_textures", None) or []):
+            if ti >= 0:
+                lib().gpo_scene_set_material_texture(self._h, mi, int(ti))
         rf = getattr(desc, "rfilter", None)
         if rf is not None:                                   # (kind, p0, p1), kinds as scenes.RFILTER_*
             lib().gpo_scene_set_rfilter(self._h, int(rf[0]), float(rf[1]), float(rf[2]))
@@ -160,6 +177,11 @@ class Scene:
         rays = np.zeros(2, np.uint64)
         lib().gpo_render_serial(self._h, C.byref(cfg), int(block_size), int(parent_seed), _p(acc), _p(rays))
         return acc, (int(rays[0]), int(rays[1]))
+
+    def texture_eval(self, texture, u, v):
+        out = np.zeros(3, np.float64)
+        lib().gpo_texture_eval(self._h, int(texture), float(u), float(v), _p(out))
+        return out
 
     def invalid_puts(self):
         """Puts the last render() dropped as invalid (ImageBlock::put, imageblock.h:154-158)."""

@@ -341,3 +341,75 @@ def test_invalid_puts_are_dropped_as_imageblock_put_drops_them():
     acc2, _ = O2.render(cfg)
     assert O2.invalid_puts() > 0 and all(np.isfinite(acc2[b]).all() for b in range(5))
     assert go.Scene(base).invalid_puts() == 0
+
+
+def test_bitmap_texture_lookups_follow_mipmap_level0():
+    """MIPMap::evalBox / evalBilinear on level 0 with evalTexel's boundary conditions (mipmap.h:503-596), Texture2D's uv scale and
+    offset (texture.cpp:113), and ensureEnergyConservation's ScaleTexture factor -- against a numpy transcription of those formulas."""
+    rgb = scenes.checker_rgb(7, 5, 11)
+    H, W = rgb.shape[:2]
+
+    def wrap(x, size, mode):
+        if 0 <= x < size:
+            return x, None
+        if mode == scenes.TEXWRAP_REPEAT:
+            return x % size, None
+        if mode == scenes.TEXWRAP_CLAMP:
+            return min(max(x, 0), size - 1), None
+        if mode == scenes.TEXWRAP_MIRROR:
+            x %= 2 * size
+            return (2 * size - x - 1 if x >= size else x), None
+        return None, (0.0 if mode == scenes.TEXWRAP_ZERO else 1.0)
+
+    def texel(x, y, mu, mv):
+        x, c = wrap(x, W, mu)
+        if c is not None:
+            return np.full(3, c)
+        y, c = wrap(y, H, mv)
+        if c is not None:
+            return np.full(3, c)
+        return rgb[y, x] * 1.25
+
+    rng = np.random.default_rng(4)
+    for mu, mv, flt in ((0, 0, 1), (1, 2, 1), (3, 4, 1), (2, 1, 0), (4, 0, 0)):
+        sc = scenes.cornell_box(8, 8)
+        t = scenes.bitmap_texture(rgb * 1.25, wrap=mu, wrapV=mv, filter=flt, uscale=1.5, vscale=0.75, uoffset=0.1, voffset=-0.2)
+        assert t["scale"] == float(np.float32(0.99)) * (1.0 / float((rgb * 1.25).max()))
+        sc.textures = [t]; sc.material_textures = [-1] * len(sc.materials)
+        O = go.Scene(sc)
+        for _ in range(200):
+            u, v = rng.uniform(-2.5, 3.5, 2)
+            ux, vy = u * 1.5 + 0.1, v * 0.75 - 0.2
+            if flt == 0:
+                want = texel(int(np.floor(ux * W)), int(np.floor(vy * H)), mu, mv)
+            else:
+                a, b = ux * W - 0.5, vy * H - 0.5
+                x0, y0 = int(np.floor(a)), int(np.floor(b))
+                dx1, dy1 = a - x0, b - y0
+                dx2, dy2 = 1.0 - dx1, 1.0 - dy1
+                want = (texel(x0, y0, mu, mv) * dx2 * dy2 + texel(x0, y0 + 1, mu, mv) * dx2 * dy1 + texel(x0 + 1, y0, mu, mv) * dx1 * dy2 + texel(x0 + 1, y0 + 1, mu, mv) * dx1 * dy1)
+            got = O.texture_eval(0, u, v)
+            assert np.allclose(got, want * t["scale"], rtol=1e-14, atol=1e-15), (mu, mv, flt, u, v)
+        O.close()
+
+
+def test_textured_reflectance_reaches_the_film():
+    """A diffuse floor with a bitmap texture on its reflectance: the render differs from the untextured one, a constant texture equals
+    the constant reflectance of the same value, and a mesh without texture coordinates is looked up at its barycentrics."""
+    cfg = go.config(maxDepth=4, spp=3)
+    tex = scenes.textured_cornell_box(40, 30)
+    a, _ = go.Scene(tex).render(cfg)
+    flat = scenes.textured_cornell_box(40, 30)
+    for t in flat.textures:
+        t["rgb"] = np.full_like(t["rgb"], 0.5); t["scale"] = 1.0; t["wrapU"] = t["wrapV"] = scenes.TEXWRAP_REPEAT     # (the block's texture wraps to ONE in v)
+    b, _ = go.Scene(flat).render(cfg)
+    plain = scenes.textured_cornell_box(40, 30)
+    plain.textures, plain.material_textures = None, None
+    c, _ = go.Scene(plain).render(cfg)
+    assert not np.allclose(a[1], b[1]) and np.isfinite(a).all()
+    # constant 0.5 textures on the two diffuse walls == their constant reflectance 0.5 (the copper block's specularReflectance differs: 0.5 vs 1)
+    plain2 = scenes.textured_cornell_box(40, 30)
+    plain2.textures, plain2.material_textures = None, None
+    plain2.materials[-1]["reflectance"] = (0.5, 0.5, 0.5)
+    d, _ = go.Scene(plain2).render(cfg)
+    assert np.allclose(b, d, rtol=1e-13, atol=1e-13) and not np.allclose(c[1], d[1])

@@ -344,3 +344,92 @@ def test_cli_strips_over_devices_equal_one_device(cli, tmp_path, gpu_required):
         assert np.allclose(a, b, rtol=1e-6, atol=1e-6 * float(np.abs(a).max())), sfx
     bad = run(cli, "-o", base, *args, "--devices", "0,7", XML)
     assert bad.returncode == 1 and "out of range" in bad.stderr
+
+
+def write_pfm(path, img):
+    img = np.asarray(img, np.float32)
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
+        f.write(img[::-1].tobytes())
+
+
+def write_png(path, img8):
+    """A minimal 8-bit RGB PNG (filter type 0 and 1 rows alternating) for the reader's test."""
+    import struct
+    import zlib
+    h, w = img8.shape[:2]
+    raw = b""
+    for y in range(h):
+        row = img8[y].astype(np.int32).reshape(-1)
+        if y % 2 == 0:
+            raw += b"\x00" + img8[y].tobytes()
+        else:                                                # Sub filter: difference to the pixel on the left
+            left = np.concatenate([np.zeros(3, np.int32), row[:-3]])
+            raw += b"\x01" + ((row - left) & 255).astype(np.uint8).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.gpu
+def test_cli_bitmap_textures_equal_python_mirror(cli, tmp_path, gpu_required):
+    """`<texture type="bitmap">` on a diffuse reflectance through the scene reader (PFM and 8-bit sRGB PNG files, OBJ `vt` coordinates with
+    flipTexCoords, filterType / wrapMode / uscale) == the Python mirror given the same texels and coordinates; `ewa` is refused with a reason."""
+    import shutil
+    import gradientdomain_mitsuba_amd.gpt as G
+    shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    sc = scenes.cornell_box(40, 30)
+    v = np.asarray(sc.verts).reshape(-1, 3, 3)
+    rgb = scenes.checker_rgb(12, 9, 5).astype(np.float32).astype(np.float64)           # what a float32 PFM holds
+    write_pfm(str(tmp_path / "floor.pfm"), rgb)
+    img8 = (scenes.checker_rgb(10, 6, 8) * 255).astype(np.uint8)
+    write_png(str(tmp_path / "back.png"), img8)
+    # the floor as an OBJ with texture coordinates (vt): u = x / 552.8 * 2, v = z / 559.2 * 1.5
+    with open(str(tmp_path / "meshes" / "floor_uv.obj"), "w") as f:
+        k = 0
+        for t in (0, 1):
+            for j in range(3):
+                f.write("v %.17g %.17g %.17g\n" % tuple(v[t, j]))
+                f.write("vt %.17g %.17g\n" % (v[t, j, 0] / 552.8 * 2.0, v[t, j, 2] / 559.2 * 1.5))
+            f.write("f %d/%d %d/%d %d/%d\n" % (k + 1, k + 1, k + 2, k + 2, k + 3, k + 3)); k += 3
+    xml = open(XML).read()
+    xml = xml.replace('<string name="filename" value="meshes/cbox_floor.obj"/>\n\t\t<boolean name="faceNormals" value="true"/>\n\t\t<ref id="white"/>',
+                      '<string name="filename" value="meshes/floor_uv.obj"/>\n\t\t<boolean name="faceNormals" value="true"/>\n\t\t<bsdf type="diffuse"><texture type="bitmap" name="reflectance">'
+                      '<string name="filename" value="floor.pfm"/><string name="filterType" value="bilinear"/><string name="wrapMode" value="mirror"/><float name="uscale" value="1.5"/></texture></bsdf>')
+    xml = xml.replace('<string name="filename" value="meshes/cbox_back.obj"/>\n\t\t<boolean name="faceNormals" value="true"/>\n\t\t<ref id="white"/>',
+                      '<string name="filename" value="meshes/cbox_back.obj"/>\n\t\t<boolean name="faceNormals" value="true"/>\n\t\t<bsdf type="diffuse"><texture type="bitmap" name="reflectance">'
+                      '<string name="filename" value="back.png"/><string name="filterType" value="nearest"/></texture></bsdf>')
+    assert "floor.pfm" in xml and "back.png" in xml
+    xt = str(tmp_path / "tex.xml"); open(xt, "w").write(xml)
+    dest = str(tmp_path / "tex")
+    r = run(cli, "-o", dest, "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xt)
+    assert r.returncode == 0, r.stderr
+    # the Python mirror of the same scene
+    nt = sc.ntri
+    floor_m = len(sc.materials); sc.materials.append(scenes.diffuse((0.5, 0.5, 0.5)))
+    back_m = len(sc.materials); sc.materials.append(scenes.diffuse((0.5, 0.5, 0.5)))
+    tm = np.array(sc.tri_material, np.int32).copy(); tm[0:2] = floor_m; tm[4:6] = back_m
+    sc.tri_material = tm
+    uvs = np.zeros((nt, 6)); has = np.zeros(nt, np.uint8)
+    for t in (0, 1):
+        for j in range(3):
+            uvs[t, 2 * j] = v[t, j, 0] / 552.8 * 2.0
+            uvs[t, 2 * j + 1] = 1 - v[t, j, 2] / 559.2 * 1.5                      # flipTexCoords (obj.cpp:306-307)
+        has[t] = 1
+    sc.uvs, sc.tri_has_uv = uvs, has
+    srgb = np.array([(i * float(np.float32(1.0) / np.float32(255))) for i in range(256)])
+    lin = np.where(srgb <= 0.04045, srgb * (1.0 / 12.92), ((srgb + 0.055) * (1.0 / 1.055)) ** 2.4)      # fmtconv.cpp:1093-1098
+    sc.textures = [scenes.bitmap_texture(rgb, wrap=scenes.TEXWRAP_MIRROR, filter=scenes.TEXFILTER_BILINEAR, uscale=1.5),
+                   scenes.bitmap_texture(lin[img8], filter=scenes.TEXFILTER_NEAREST)]
+    mt = [-1] * len(sc.materials); mt[floor_m], mt[back_m] = 0, 1
+    sc.material_textures = mt
+    out = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
+    for suffix in G.BUFFER_NAMES:
+        img = read_pfm(dest + suffix + ".pfm")
+        assert np.allclose(img, out[suffix], rtol=2e-6, atol=1e-7), suffix         # (pow() of the sRGB table: glibc here, numpy there)
+    plain = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
+    assert not np.allclose(plain["-throughput"], out["-throughput"], rtol=1e-2, atol=1e-3)
+    bad = str(tmp_path / "ewa.xml"); open(bad, "w").write(xml.replace('<string name="filterType" value="bilinear"/>', ""))
+    r = run(cli, "-o", dest + "x", "-D", "width=16", "-D", "height=12", bad)
+    assert r.returncode == 1 and "ray differentials" in r.stderr and "bilinear" in r.stderr
