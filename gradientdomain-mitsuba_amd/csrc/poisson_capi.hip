@@ -634,6 +634,31 @@ static int export_common(gdpt_poisson_solver *s, float *dst, hipMemcpyKind kind)
     return GDPT_OK;
 }
 
+// Solver::evaluateMetricsMTS (Solver.cpp:511-541): e = b - P x on the device, then -- as the reference does through Backend::map -- the
+// 3n Vec3f rows on the host: errL1 / errL2 are sequential fp32 sums of their lengths / squared lengths over 3n, err the first n rows.
+int gdpt_poisson_evaluate_metrics(gdpt_poisson_solver *s, float *err, float *errL1, float *errL2)
+{
+    if (!s || !s->ready || !err || !errL1 || !errL2) return fail(GDPT_ERR_INVALID, "evaluate_metrics before setup_backend / null argument");
+    if (s->unchecked) { const int rc = gdpt_poisson_sync(s); if (rc) return rc; }
+    const long n = (long)s->W * s->H, n3 = 3 * n;
+    const Lattice L = s->lat();
+    hipLaunchKernelGGL(kg_residual, dim3(grid_generic(n3)), dim3(BLK), 0, s->stream, s->e, s->b, s->x, L.W, L.H, L.alpha);
+    HIPCHK(hipGetLastError());
+    std::vector<float> e((size_t)3 * n3);
+    HIPCHK(hipMemcpyAsync(e.data(), s->e, sizeof(float) * 3 * n3, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    float l1 = 0.0f, l2 = 0.0f;
+    for (long i = 0; i < 3 * n; i++) {
+        const float sq = e[3 * i] * e[3 * i] + e[3 * i + 1] * e[3 * i + 1] + e[3 * i + 2] * e[3 * i + 2];
+        l1 += sqrtf(sq);
+        l2 += sq;
+    }
+    *errL1 = l1 / (float)(n * 3);
+    *errL2 = l2 / (float)(n * 3);
+    memcpy(err, e.data(), sizeof(float) * n3);
+    return GDPT_OK;
+}
+
 int gdpt_poisson_export_images(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToHost); }
 int gdpt_poisson_export_images_device(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToDevice); }
 

@@ -134,6 +134,7 @@ public:
     void importImagesDevice(const float *dx, const float *dy, const float *tp, const float *direct, int width, int height) { check(gdpt_poisson_import_images_device(m_handle, dx, dy, tp, direct, width, height)); }
     void setupBackend() { check(gdpt_poisson_setup_backend(m_handle)); }
     void solveIndirect() { check(gdpt_poisson_solve_indirect(m_handle)); }
+    void evaluateMetricsMTS(float *err, float &errL1, float &errL2) { check(gdpt_poisson_evaluate_metrics(m_handle, err, &errL1, &errL2)); }      // Solver.cpp:511-541
     void exportImagesMTS(float *rec) { check(gdpt_poisson_export_images(m_handle, rec)); }
     float lastSolveSeconds() const { return gdpt_poisson_last_solve_seconds(m_handle); }
 

@@ -112,6 +112,14 @@ class Solver:
         check(lib().gdpt_poisson_export_images(self._h, out.ctypes.data_as(_fp)))
         return out
 
+    def evaluateMetricsMTS(self):
+        """Solver::evaluateMetricsMTS (Solver.cpp:511-541) -> (err float32 [3*w*h], errL1, errL2) for the current iterate."""
+        w, h = self._size
+        err = np.empty(3 * w * h, np.float32)
+        l1, l2 = C.c_float(0.0), C.c_float(0.0)
+        check(lib().gdpt_poisson_evaluate_metrics(self._h, err.ctypes.data_as(_fp), C.byref(l1), C.byref(l2)))
+        return err, float(l1.value), float(l2.value)
+
     def profileKernels(self, reps=50):
         """Bench hook: mean standalone microseconds of (stencil, r_rz, x_p, fused x_p+stencil)."""
         us = (C.c_float * 4)()

@@ -84,6 +84,10 @@ GDPT_API int  gdpt_poisson_solve_indirect(gdpt_poisson_solver *s);
 GDPT_API int  gdpt_poisson_solve_indirect_async(gdpt_poisson_solver *s);
 GDPT_API int  gdpt_poisson_sync(gdpt_poisson_solver *s);
 /* Solver::exportImagesMTS (Solver.cpp:542-582): rec = direct + x (or x), 3*w*h floats to HOST. */
+/* Solver::evaluateMetricsMTS (Solver.cpp:511-541; public, no caller in the reference): residual e = b - P x of the current iterate;
+ * errL1 / errL2 = mean length / squared length of its 3n stacked RGB rows (sequential fp32 on the host, as the reference sums the
+ * mapped vector), err (3*w*h floats, host) = the rows of the alpha*T block. */
+GDPT_API int  gdpt_poisson_evaluate_metrics(gdpt_poisson_solver *s, float *err, float *errL1, float *errL2);
 GDPT_API int  gdpt_poisson_export_images(gdpt_poisson_solver *s, float *rec);
 GDPT_API int  gdpt_poisson_export_images_device(gdpt_poisson_solver *s, float *rec_device);
 /* Device pointer of the current solution x (3*w*h floats), valid until destroy. */

@@ -350,6 +350,31 @@ GDO_API long gdo_solve(const gdo_params *params_in, const float *dx, const float
 
 /* Synthetic solver input of SURVEY.md section 8(d) (the generator the survey's oracle probe
  * used; not reference code).  All fp32; LCG s = s*1664525+1013904223 (u32), u=(s>>8)/2^24. */
+/* Solver::evaluateMetricsMTS, Solver.cpp:511-541 (public, no caller in the reference): e = b - P x for the given iterate x; errL1 / errL2 =
+ * mean length / squared length over the 3n stacked Vec3f rows, sequential fp32; err = the first n rows of e (the alpha*T block). */
+GDO_API void gdo_evaluate_metrics(const float *x, const float *dx, const float *dy, const float *tp, int w, int h, float alpha,
+                                  float *err, float *errL1, float *errL2)
+{
+    const long n = (long)w * h;
+    float *b = (float *)malloc(sizeof(float) * 9 * n), *e = (float *)malloc(sizeof(float) * 9 * n);
+    const float minus1[3] = {-1.0f, -1.0f, -1.0f};
+    if (!tp) alpha = 0.0f;                                          /* Solver.cpp:319 */
+    for (long i = 0; i < 3 * n; i++) { b[i] = tp ? tp[i] * alpha : 0.0f; b[3 * n + i] = dx[i]; b[6 * n + i] = dy[i]; }    /* Solver.cpp:323-332 */
+    gdo_calc_Px(e, w, h, alpha, x);
+    gdo_calc_axpy(e, minus1, e, b, 3 * n);
+    float l1 = 0.0f, l2 = 0.0f;
+    for (long i = 0; i < 3 * n; i++) {
+        const float ex = e[3 * i], ey = e[3 * i + 1], ez = e[3 * i + 2];
+        const float sq = ex * ex + ey * ey + ez * ez;               /* lenSqr, Defs.hpp */
+        l1 += sqrtf(sq);
+        l2 += sq;
+    }
+    *errL1 = l1 / (float)(n * 3);
+    *errL2 = l2 / (float)(n * 3);
+    memcpy(err, e, sizeof(float) * 3 * n);
+    free(b); free(e);
+}
+
 GDO_API void gdo_synth_inputs(int w, int h, unsigned seed, float *dx, float *dy, float *tp, float *direct)
 {
     const long n = (long)w * h;

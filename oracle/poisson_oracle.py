@@ -52,6 +52,7 @@ def lib():
         L.gdo_solve.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_int, _f32p, C.c_void_p]
         L.gdo_solve.restype = C.c_long
+        L.gdo_evaluate_metrics.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p]
         L.gdo_synth_inputs.argtypes = [C.c_int, C.c_int, C.c_uint, _f32p, _f32p, _f32p, C.c_void_p]
         _lib = L
     return _lib
@@ -152,3 +153,13 @@ def synth_inputs(w, h, seed=12345, with_direct=True):
     direct = np.empty(n3, np.float32) if with_direct else None
     lib().gdo_synth_inputs(w, h, seed, dx, dy, tp, direct.ctypes.data_as(C.c_void_p) if with_direct else None)
     return dx, dy, tp, direct
+
+
+def evaluate_metrics(x, dx, dy, tp, w, h, alpha):
+    """Solver::evaluateMetricsMTS for the iterate x (the indirect solution, before `direct` is added) -> (err[3n], errL1, errL2)."""
+    err = np.zeros(3 * w * h, np.float32)
+    l1, l2 = C.c_float(0), C.c_float(0)
+    tpp = None if tp is None else np.ascontiguousarray(tp, np.float32).ctypes.data_as(C.c_void_p)
+    lib().gdo_evaluate_metrics(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(dx, np.float32), np.ascontiguousarray(dy, np.float32), tpp,
+                               w, h, C.c_float(alpha), err, C.byref(l1), C.byref(l2))
+    return err, float(l1.value), float(l2.value)

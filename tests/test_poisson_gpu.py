@@ -339,3 +339,20 @@ def test_full_size_l2d_3840x2160_config4(P):
     assert np.abs(u - a).max() <= 5e-5
     ref = po.solve(po.preset("L2D"), dx, dy, tp, None, w, h)
     assert np.abs(a - ref).max() <= 5e-5
+
+
+def test_evaluate_metrics_matches_oracle(P):
+    """Solver::evaluateMetricsMTS (Solver.cpp:511-541): residual image and mean L1 / L2 of b - P x, before and after a solve."""
+    w, h = 96, 64
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    s = P.Solver(P.Params("L2D", 0.2))
+    s.importImagesMTS(dx, dy, tp, direct, w, h); s.setupBackend()
+    e0, a0, b0 = s.evaluateMetricsMTS()                        # x = T
+    oe, oa, ob = po.evaluate_metrics(tp, dx, dy, tp, w, h, 0.2)
+    assert np.array_equal(e0, oe) and a0 == oa and b0 == ob
+    s.solveIndirect()
+    x = s.exportImagesMTS() - direct.reshape(-1)               # the indirect solution (direct is zero in the synthetic inputs)
+    e1, a1, b1 = s.evaluateMetricsMTS()
+    oe, oa, ob = po.evaluate_metrics(x, dx, dy, tp, w, h, 0.2)
+    assert np.array_equal(e1, oe) and a1 == oa and b1 == ob and b1 < b0
+    s.close()
