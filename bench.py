@@ -288,22 +288,39 @@ def main():
         # --- the render kernel (98.8 % of a step): an issue-slot view, not an HBM one.  Its tables sit in LDS (Cornell) or L2 / Infinity
         # Cache; what limits it is instruction issue under divergence and the latency of its scratch traffic.  Counters per launch come from
         # the committed PMC passes of this binary (null if csrc/ changed since); the launch duration and ray count are this run's.
-        kc = _kernel_counters(counters, "void gdpt_tr::k_render", grid_x=(((W + 15) // 16) * ((H + 15) // 16)) * 256)
+        tracer_kernels = ("gdpt_tr::k_primary", "gdpt_tr::k_render", "gdpt_tr::k_continue", "gdpt_tr::k_fold_cont")
+        res = _kernel_counters(counters, "gdpt_tr::k_resolve")          # once per step: the profile's step count
+        per_step = {}
+        if res and res.get("calls") and world == 1:
+            for name, c in counters.items():
+                key = next((t for t in tracer_kernels if t in name), None)
+                if key and "SQ_INSTS_VALU" in c:
+                    n = c.get("calls", 0) / float(res["calls"])
+                    acc = per_step.setdefault(key, {"launches_per_step": 0.0, "avg_ms": 0.0})
+                    acc["launches_per_step"] += n
+                    acc["avg_ms"] += n * c.get("avg_us", 0.0) * 1e-3
+                    for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE"):
+                        if f in c:
+                            acc[f] = acc.get(f, 0.0) + n * c[f]
         tracer_issue = {"bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
                         "peak_what": "1024 SIMDs x 2.4 GHz / 4 cycles per fp64 VALU wave-instruction",
-                        "kernel": "k_render", "kernel_avg_ms": round(1e3 * launch_s, 3), "counters_file": counters_file if kc else None}
-        if kc and "SQ_INSTS_VALU" in kc and world == 1:
-            valu = kc["SQ_INSTS_VALU"]
+                        "kernels": "k_primary + k_render + k_continue + k_fold_cont (the staged render of one step)", "render_ms_per_step": round(1e3 * launch_s, 3),
+                        "counters_file": counters_file if per_step else None}
+        if per_step:
+            tot = {f: sum(k.get(f, 0.0) for k in per_step.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE")}
+            valu = tot["SQ_INSTS_VALU"]
             tracer_issue.update({"achieved": round(valu / launch_s / 1e9, 1), "frac": round(valu / launch_s / VALU_ISSUE_PEAK, 4),
-                                 "valu_wave_instr_per_ray": round(valu / rays_per_launch, 2)})
-            if "SQ_THREAD_CYCLES_VALU" in kc and "SQ_ACTIVE_INST_VALU" in kc:
-                tracer_issue["lane_utilisation"] = round(kc["SQ_THREAD_CYCLES_VALU"] / (kc["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
-            if "SQ_WAIT_ANY" in kc and "SQ_WAVE_CYCLES" in kc:
-                tracer_issue["wait_any_frac_of_wave_cycles"] = round(kc["SQ_WAIT_ANY"] / kc["SQ_WAVE_CYCLES"], 4)
-            tb = _traffic_bytes(kc)
-            if tb is not None:
-                tracer_issue.update({"fabric_traffic_gb_per_launch": round(tb / 1e9, 2), "fabric_traffic_bytes_per_ray": round(tb / rays_per_launch, 1),
-                                     "fabric_traffic_what": "FETCH_SIZE x2 + WRITE_SIZE of the launch: scratch (spilled path state) + per-pixel record flushes; the algorithmic HBM bytes are the film records, %.2f GB" % (31 * 8 * 2 * W * H / 1e9)})
+                                 "valu_wave_instr_per_ray": round(valu / rays_per_launch, 2),
+                                 "lane_utilisation": round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if tot["SQ_ACTIVE_INST_VALU"] else None,
+                                 "wait_any_frac_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4) if tot["SQ_WAVE_CYCLES"] else None})
+            tb = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
+            tracer_issue.update({"fabric_traffic_gb_per_step": round(tb / 1e9, 1), "fabric_traffic_bytes_per_ray": round(tb / rays_per_launch, 1),
+                                 "fabric_traffic_what": "FETCH_SIZE x2 + WRITE_SIZE of the step's render kernels: scratch (spilled path state) + the sample queue; the algorithmic HBM bytes are the film records, %.2f GB" % (31 * 8 * 2 * W * H / 1e9),
+                                 "per_kernel": {k.split("::")[1]: {"launches_per_step": round(v["launches_per_step"], 2), "ms_per_step": round(v["avg_ms"], 2),
+                                                                     "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 3) if v.get("SQ_ACTIVE_INST_VALU") else None,
+                                                                     "wait_any_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAVE_CYCLES") else None,
+                                                                     "traffic_gb_per_step": round((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / 1e9, 1)}
+                                                for k, v in per_step.items()}})
         else:
             tracer_issue.update({"achieved": None, "frac": None})
         # --- the persistent CG kernel that runs THIS configuration's solve: latency-bound, never an HBM fraction
