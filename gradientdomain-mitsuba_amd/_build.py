@@ -17,7 +17,7 @@ UNITS = {
 }
 SOURCES = [os.path.join(CSRC, f) for f in UNITS]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", os.environ.get("GDPT_OPT", "-O3"), "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
 
 

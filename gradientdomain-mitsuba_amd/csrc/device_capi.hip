@@ -102,12 +102,16 @@ int gdpt_device_copy(int dstDevice, void *dst, int srcDevice, const void *src, s
     if (bytes == 0) return GDPT_OK;
     if (dstDevice == srcDevice) {
         DHIPCHK(hipSetDevice(dstDevice));
-        DHIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+        // (a device-to-device hipMemcpy may return before the copy has run, and the films' streams are non-blocking: without the wait a
+        // strip could unpack a halo payload that is still in flight -- seen as an intermittent wrong border row with two strips on one GPU)
+        DHIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, nullptr));
+        DHIPCHK(hipStreamSynchronize(nullptr));
         return GDPT_OK;
     }
     if ((rc = enable_peer(srcDevice, dstDevice)) || (rc = enable_peer(dstDevice, srcDevice))) return rc;
     DHIPCHK(hipSetDevice(srcDevice));
-    DHIPCHK(hipMemcpyPeer(dst, dstDevice, src, srcDevice, bytes));       // xGMI DMA between two GPUs of the node
+    DHIPCHK(hipMemcpyPeerAsync(dst, dstDevice, src, srcDevice, bytes, nullptr));       // xGMI DMA between two GPUs of the node
+    DHIPCHK(hipStreamSynchronize(nullptr));                                             // complete on return, like every call of this ABI
     return GDPT_OK;
 }
 

@@ -474,7 +474,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         size_t tot = 0;
         for (size_t b : parts) tot += (b + 15) & ~(size_t)15;                 // block_setup's layout: every table starts on a 16-byte word
         s->ldsSceneBytes = tot;
-        d.ldsScene = tot <= (size_t)LDS_SCENE_BYTES ? 1 : 0;
+        d.ldsScene = (tot <= (size_t)LDS_SCENE_BYTES && !getenv("GDPT_SCENE_IN_HBM")) ? 1 : 0;     // (GDPT_SCENE_IN_HBM: test knob -- small scenes through the HBM-scene builds)
         d.ldsBytes = d.ldsScene ? (int)tot : 0;
     }
     CameraD &c = d.cam;
@@ -597,9 +597,13 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     size_t lds = (size_t)stackDepth * TBLK * sizeof(int);
     const int sceneBytes = s->d.ldsScene ? (int)((s->ldsSceneBytes + 15) & ~(size_t)15) : 0;
     lds += sceneBytes;
-    const int wps = f->wavesPerSimd <= 2 ? 2 : 4;          // the render kernel is built for 2 and for 4 resident waves per SIMD
+    // staged pipeline (k_primary -> k_render<STAGED> -> k_continue -> k_fold_cont) or everything in the round-1 kernel
+    const bool useQueue = f->continuation && !getenv("GDPT_NO_CONTINUATION");
+    // the render kernel is built for 2 and for 4 resident waves per SIMD; the staged kernels exist for the measured optimum of the scene's
+    // residency only (LDS-resident scene: 2, HBM-resident: 4) -- gdpt_film_set_occupancy applies to the single-kernel form
+    const int wps = useQueue ? (s->d.ldsScene ? 2 : 4) : (f->wavesPerSimd <= 2 ? 2 : 4);
     const size_t accBytes = sizeof(Float) * ACC_N * TBLK;
-    const bool accLds = f->accInLds && (lds + accBytes) * (size_t)std::max(1, wps) <= (size_t)160 * 1024;
+    const bool accLds = f->accInLds && (!useQueue || s->d.ldsScene) && (lds + accBytes) * (size_t)std::max(1, wps) <= (size_t)160 * 1024;
     if (accLds) lds += accBytes;
     // sample slices (gpt_render.hip.h): enough work items to keep every CU busy to the end of the launch
     const int tiles = tilesX * tilesY;
@@ -635,7 +639,6 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     }
     // Continuation queue: one record slot per (sample of the chunk, pixel of the launch); the chunk is sized to a memory budget
     // (GDPT_QUEUE_MB, default 24 GiB of the 288) and the chunks are made equal.
-    const bool useQueue = f->continuation && !getenv("GDPT_NO_CONTINUATION");
     const unsigned qPixels = (unsigned)tiles * TBLK;
     if (useQueue) {
         size_t budget = (size_t)24 << 30;
@@ -663,14 +666,29 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     }
     THIPCHK(hipEventRecord(e0, f->stream));          // (after the allocations: a first launch's hipMalloc is not render time)
     FilmD fd = f->d;                     // the descriptor of this launch (queue geometry filled in; without a queue qRec stays null)
-    const bool usePrimary = useQueue && f->primaryPass && !getenv("GDPT_NO_PRIMARY_PASS");
+    const bool usePrimary = useQueue;    // (the staged kernels take their primary hits from k_primary)
     if (!useQueue) fd.qRec = nullptr;
     if (!usePrimary) { fd.pHit = nullptr; fd.pPrim = nullptr; }
     fd.qPixels = qPixels; fd.qCapacity = (unsigned)chunk * qPixels;
     const dim3 cgrid(s->numCUs * wps);
-#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) do { \
-        hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
-        if (useQueue) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fd, stackDepth, f->contRefill); } while (0)
+#ifdef GDPT_DEV_TWO_BUILDS   /* investigation: GDPT_DEV_DUMP_QUEUE=<file> writes the sample queue as k_render left it (NQ x capacity doubles) */
+#define GDPT_DEV_DUMP_QUEUE() do { if (const char *qp = getenv("GDPT_DEV_DUMP_QUEUE")) { \
+        (void)hipStreamSynchronize(f->stream); std::vector<double> hq((size_t)NQ * fd.qCapacity); \
+        (void)hipMemcpy(hq.data(), fd.qRec, hq.size() * sizeof(double), hipMemcpyDeviceToHost); \
+        if (FILE *qf = fopen(qp, "wb")) { fwrite(hq.data(), sizeof(double), hq.size(), qf); fclose(qf); } } } while (0)
+#else
+#define GDPT_DEV_DUMP_QUEUE() do { } while (0)
+#endif
+#define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
+#define GDPT_STAGED(LDSV, ACCV, WPS, ENVV, SMV) do { \
+        if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
+        else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
+        GDPT_DEV_DUMP_QUEUE(); \
+        hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fd, stackDepth, f->contRefill); } while (0)
+#define GDPT_STAGED_F(LDSV, ACCV, WPS) do { \
+        if (s->perVertex) GDPT_STAGED(LDSV, ACCV, WPS, true, true); \
+        else if (s->specialEmitters) GDPT_STAGED(LDSV, ACCV, WPS, true, false); \
+        else GDPT_STAGED(LDSV, ACCV, WPS, false, false); } while (0)
     // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment / point emitters | + per-vertex normals (environment tested at run time)};
     // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { \
@@ -693,11 +711,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #ifndef GDPT_DEV_WPS
 #define GDPT_DEV_WPS 2
 #endif
-#ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 3): one build per scene kind */
-        if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, true);
+#ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 5): one build per scene kind */
+        if (useQueue) { if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_STAGED(true, true, 2, false, false); else GDPT_STAGED(true, false, 2, false, false); } else GDPT_STAGED(false, false, 4, true, true); }
+        else if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, true);
 #else
-        if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
-        else               { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
+        if (useQueue) {
+            // staged builds: {LDS scene, sums in LDS | LDS scene, sums in registers | HBM scene, sums in registers} x {flat | env | per-vertex}
+            if (s->d.ldsScene) { if (accLds) GDPT_STAGED_F(true, true, 2); else GDPT_STAGED_F(true, false, 2); }
+            else GDPT_STAGED_F(false, false, 4);
+        } else if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
+        else                      { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #endif
         if (useQueue) hipLaunchKernelGGL(k_fold_cont, dim3(tiles), block, 0, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX);
         if (f->d.fValues)
@@ -705,6 +728,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     }
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
+#undef GDPT_STAGED_F
+#undef GDPT_STAGED
     if (slices > 1 && !f->d.fValues && !useQueue) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
@@ -922,8 +947,8 @@ int gdpt_film_set_regeneration(gdpt_film *f, int idleLanes)
 int gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes)
 {
     if (!f || stages < 0 || stages > 2 || refillLanes < 0 || refillLanes > 64) return tfail(GDPT_ERR_INVALID, "pipeline: stages 0..2, refill threshold 1..64 idle lanes (0 = keep)");
-    f->continuation = stages >= 1;
-    f->primaryPass = stages >= 2;
+    f->continuation = stages >= 1;       // (1 and 2 are the same since the staged kernels are their own builds)
+    f->primaryPass = stages >= 1;
     if (refillLanes > 0) f->contRefill = refillLanes;
     return GDPT_OK;
 }

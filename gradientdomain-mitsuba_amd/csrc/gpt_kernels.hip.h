@@ -1012,7 +1012,7 @@ __device__ __forceinline__ d3 tex_texel(const TexD &t, int x, int y)
     return mk(p[0], p[1], p[2]);
 }
 // Texture2D::eval (texture.cpp:112-121) -> BitmapTexture::eval -> evalBox / evalBilinear on level 0 (mipmap.h:566-596)
-__device__ d3 tex_eval(const TexD &t, Float u_, Float v_)
+__device__ __noinline__ d3 tex_eval(const TexD &t, Float u_, Float v_)   // a real call: textured vertices only; inlined at its six sites it cost every per-vertex build ~25 % (register pressure)
 {
     const Float ux = u_ * t.uscale + t.uoffset, vy = v_ * t.vscale + t.voffset;
     d3 value;

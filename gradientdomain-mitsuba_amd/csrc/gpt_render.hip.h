@@ -3,16 +3,37 @@
 #pragma once
 #include "gpt_kernels.hip.h"
 
-#ifndef GDPT_OFFSET_UNROLL
-#define GDPT_OFFSET_UNROLL 1     // 1: the four offset paths are unrolled (state in registers); 0: rolled loops (state in scratch)
-#endif
-#if GDPT_OFFSET_UNROLL
-#define GDPT_OFFSET_LOOP _Pragma("unroll")
-#else
-#define GDPT_OFFSET_LOOP _Pragma("unroll 1")
-#endif
+#include <type_traits>
 
 namespace gdpt_tr {
+
+// The per-offset parts of a bounce are written once, as a generic lambda over (index, offset), and expanded by for_offsets:
+//  * UNROLL (the 2-wave builds): four instantiations with a compile-time index -- off[i] and the sums' slots are plain scalars, the
+//    Lane is register-allocated.  `#pragma unroll` is NOT what does this: the shift code is past LLVM's -pragma-unroll-threshold
+//    (16384 IR instructions x 4), the pragma was silently ignored, and a run-time index into a member array stops SROA for the whole
+//    struct -- the 2-wave builds ran with the entire Lane in scratch until this was found (config 2: 7.4 -> 8.5 Gray/s).
+//  * rolled (the 4-wave builds, 128 VGPRs): ONE copy of the shift code, off[] indexed at run time, i.e. the Lane and register-held
+//    sums live in scratch BY DESIGN -- measured on the atrium against the two alternatives: unrolled 1.81 Gray/s, rolled over a copy
+//    picked by a uniform switch (Lane in registers, spilled by the allocator instead) 1.76, this 2.33.
+template <bool UNROLL, class BODY>
+__device__ __forceinline__ void for_offsets(Offset (&off)[4], BODY &&body)
+{
+    if constexpr (UNROLL) {
+        body(std::integral_constant<int, 0>{}, off[0]); body(std::integral_constant<int, 1>{}, off[1]);
+        body(std::integral_constant<int, 2>{}, off[2]); body(std::integral_constant<int, 3>{}, off[3]);
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) body(i, off[i]);
+    }
+}
+// the three sums an offset adds to per bounce (gpt.cpp:723-726, 1140-1146)
+template <class ACC>
+__device__ __forceinline__ void add_offset_sums(ACC &A, int i, d3 t, d3 n, d3 g)
+{
+    A.add3(ACC_T, t);
+    A.add3(ACC_NBR + 3 * i, n);
+    A.add3(ACC_GRAD + 3 * i, g);
+}
 
 struct Lane {
     // base path ("main" RayState, gpt.cpp:135-173)
@@ -44,7 +65,8 @@ __device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack,
 // Returns false if the base path is already over.
 // CALLS: the five primary traversals go through the real-call form (the 2-wave builds); the 4-wave builds inline them, because the callee
 // needs 132 registers and would cost them a wave per SIMD.
-template <bool ENV, bool SMOOTH, bool CALLS, class ACC>
+// STAGED: the kernel is the staged pipeline's (primary hits and a sample queue are always there): the traversal loop below is compiled out.
+template <bool ENV, bool SMOOTH, bool CALLS, class ACC, bool STAGED = false>
 __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A, int px, int py, int sample,
                                            const FilmD *F = nullptr, unsigned slot = 0)
 {
@@ -56,7 +78,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     A.zero();
     // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
     Hit hits[5];
-    const bool traced = F && F->pHit;           // the five primary rays were traced by k_primary (a lean traversal-only kernel at full occupancy)
+    const bool traced = STAGED || (F && F->pHit);   // the five primary rays were traced by k_primary (a lean traversal-only kernel at full occupancy)
     if (traced) {
 #pragma unroll
         for (int r = 0; r < 5; r++) {
@@ -116,7 +138,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 // with them every use of an offset's own vertex and direction.  The strict-normals test of the offsets (:547-554) is dropped there
 // too: it reads the offset's LAST OWN vertex and direction, which stop changing when the offset connects, and with those very values
 // it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
-template <bool ENV, bool SMOOTH, bool CONN, class ACC>
+template <bool ENV, bool SMOOTH, bool CONN, bool UNROLL, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
@@ -160,9 +182,8 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const Float mainWeightDenominator = (L.pdf * L.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
         const d3 mainContributionAll = L.throughput * (mainBSDFValue * mainEmitterRadiance);
         if (!cfg.strictNormals || dot(mGeoN, dRec.d) * mainWoL.z > 0) {         // :607
-GDPT_OFFSET_LOOP
-            for (int i = 0; i < 4; i++) {
-                Offset &s = L.off[i];
+            for_offsets<UNROLL>(L.off, [&](auto ic, Offset &s) __attribute__((always_inline)) {
+                const int i = ic;
                 d3 shiftedContribution = mk(0.0);
                 Float weight = 0;
                 bool assigned = false;          // false: weight and both contributions stay 0 (:613-615 with no branch taken)
@@ -223,10 +244,8 @@ GDPT_OFFSET_LOOP
                     assigned = true;
                 }
                 const d3 mainContribution = assigned ? mainContributionAll : mk(0.0);
-                A.add3(ACC_T, mainContribution * weight);                          // :723-726
-                A.add3(ACC_NBR + 3 * i, shiftedContribution * weight);
-                A.add3(ACC_GRAD + 3 * i, (shiftedContribution - mainContribution) * weight);
-            }
+                add_offset_sums(A, i, mainContribution * weight, shiftedContribution * weight, (shiftedContribution - mainContribution) * weight);   // :723-726
+            });
         }
     }
 
@@ -277,9 +296,8 @@ GDPT_OFFSET_LOOP
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
     const int measure = (bs.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
 
-GDPT_OFFSET_LOOP
-    for (int i = 0; i < 4; i++) {                                                // :830
-        Offset &s = L.off[i];
+    for_offsets<UNROLL>(L.off, [&](auto ic, Offset &s) __attribute__((always_inline)) {      // :830
+        const int i = ic;
         d3 shiftedContribution = mk(0.0);
         Float weight = 0;
         bool assigned = false;
@@ -433,11 +451,9 @@ GDPT_OFFSET_LOOP
             assigned = true;
         }
         const d3 mc = assigned ? mainContribution : mk(0.0);
-        A.add3(ACC_T, mc * weight);                                              // :1140-1146
-        A.add3(ACC_NBR + 3 * i, shiftedContribution * weight);
-        A.add3(ACC_GRAD + 3 * i, (shiftedContribution - mc) * weight);
+        add_offset_sums(A, i, mc * weight, shiftedContribution * weight, (shiftedContribution - mc) * weight);   // :1140-1146
         if (postponedShiftEnd) s.alive = 0;
-    }
+    });
 
     if (mainHitEnv) return false;                                                // :1155-1157
     if (L.depth++ >= cfg.rrDepth) {                                              // :1159-1174
@@ -650,7 +666,10 @@ __device__ __forceinline__ bool all_connected(const Lane &L)
     return ok;
 }
 
-template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
+// STAGED: the build the staged pipeline launches (gdpt_film_set_pipeline(2)): primary hits come from k_primary and every sample ends in
+// its queue slot, so the primary traversals, finish_path and the exact generic puts (15 inlined copies with atomics) are not in it at all
+// -- code that never runs there, but that the register allocator would otherwise keep values alive for.
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH, bool STAGED = false>
 __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth, int sceneBytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -690,20 +709,23 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         // regenerate together: when enough lanes wait, or nothing else is running in this wave
         if (idle && next < s1 && (__popcll(wantMask) >= cfg.regenMin || idleMask == ~0ULL)) {
             if (__hip_atomic_load(F.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { next = s1; continue; }   // cancelled: no new samples; running paths finish
-            if (pending) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase);
+            if constexpr (!STAGED) { if (pending) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase); }
+#ifdef GDPT_PROBE_STAGED_WITH_COLD_CODE
+            else { if (cfg.spp < 0) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase); }
+#endif
             slot = (unsigned)(next - cfg.sBase) * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
-            active = start_path<ENV, SMOOTH, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A, px, py, next, &F, slot);
+            active = start_path<ENV, SMOOTH, (WAVES_PER_SIMD <= 2), Acc<ACC_LDS>, STAGED>(S, sv, cfg, stack, L, A, px, py, next, &F, slot);
             next++;
-            if (!active) { paths++; pathLen += L.depth; if (F.qRec) q_finish(F, slot, A); else pending = true; }
+            if (!active) { paths++; pathLen += L.depth; if (STAGED || F.qRec) q_finish(F, slot, A); else pending = true; }
         }
         if (active) {
-            if (!bounce<ENV, SMOOTH, false>(S, sv, cfg, stack, L, A)) {
+            if (!bounce<ENV, SMOOTH, false, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A)) {
                 active = false;
                 paths++; pathLen += L.depth;
                 // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
                 // chunk; without one they wait in A for the lane's next regeneration (`pending`)
-                if (F.qRec) q_finish(F, slot, A); else pending = true;
-            } else if (F.qRec && all_connected(L)) {
+                if (STAGED || F.qRec) q_finish(F, slot, A); else pending = true;
+            } else if ((STAGED || F.qRec) && all_connected(L)) {
                 // every offset is connected or dead: the rest of this base path belongs to k_continue (the sums so far travel with it)
                 q_store(F, slot, L, A);
                 const unsigned long long mask = __ballot(true);
@@ -716,7 +738,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
             }
         }
     }
-    if (pending) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase);
+    if constexpr (!STAGED) { if (pending) finish_path(F, flt, L.sx, L.sy, A, px, py, next - 1 - cfg.sBase); }
     // statistics: wave-level integer reduction, one atomic per wave and counter
     const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
     const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
@@ -798,7 +820,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
             }
         }
         if (__ballot(active) == 0) { if (exhausted) break; continue; }
-        if (active && !bounce<ENV, SMOOTH, true>(S, sv, cfg, stack, L, A)) {
+        if (active && !bounce<ENV, SMOOTH, true, true>(S, sv, cfg, stack, L, A)) {
             active = false;
             paths++; pathLen += L.depth;
             q_finish(F, slot, A);
@@ -1027,7 +1049,7 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
     bool active = start_path<true, true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
-    while (active) active = bounce<true, true, false>(S, sv, cfg, s_stack, L, A);
+    while (active) active = bounce<true, true, false, false>(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];

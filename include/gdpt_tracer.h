@@ -179,11 +179,12 @@ GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
  * of every sample are traced by a traversal-only kernel (k_primary), the general kernel (k_render) walks a sample until each of its
  * four offset paths is connected to the base path or dead (diffuse / rough scenes: two bounces), the rest of the base path runs in
  * the continuation kernel (k_continue), and every sample's sums are added to its pixel once per chunk of samples (k_fold_cont).
- * stages = 1: no separate primary pass.  stages = 0: everything in k_render (the round-1 form).  Samples, random numbers, ray counts
- * and the order in which a pixel's samples are summed do not depend on the setting; results agree to rounding of the per-pixel sums.
+ * stages = 0: everything in k_render (the round-1 form; gdpt_film_set_occupancy chooses its build); 1 is accepted and means 2.  Samples,
+ * random numbers, ray counts and the order in which a pixel's samples are summed do not depend on the setting; results agree to
+ * rounding of the per-pixel sums.
  * refillLanes: idle lanes of a wave of k_continue before they take new records together (0 = keep the current value, default 32).
- * Environment: GDPT_NO_CONTINUATION / GDPT_NO_PRIMARY_PASS (set = off) and GDPT_QUEUE_MB (memory budget of the sample queue, default
- * 24576) override at render time. */
+ * Environment: GDPT_NO_CONTINUATION and GDPT_QUEUE_MB (memory budget of the sample queue, default
+ * 24576) override at render time (GDPT_NO_CONTINUATION set = stages 0). */
 GDPT_API int  gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes);
 
 /* ---- multi-device helpers (csrc/device_capi.hip) ---------------------------------------------------------------------------------
