@@ -15,6 +15,11 @@ namespace gdpt_tr {
 //  * rolled (the 4-wave builds, 128 VGPRs): ONE copy of the shift code, off[] indexed at run time, i.e. the Lane and register-held
 //    sums live in scratch BY DESIGN -- measured on the atrium against the two alternatives: unrolled 1.81 Gray/s, rolled over a copy
 //    picked by a uniform switch (Lane in registers, spilled by the allocator instead) 1.76, this 2.33.
+#ifdef GDPT_FORCE_ROLLED      /* investigation build: the 2-wave kernels with the rolled loop, i.e. the configuration of "the lean-build fault"  */
+#define GDPT_UNROLL_OFFSETS(WPS) false
+#else
+#define GDPT_UNROLL_OFFSETS(WPS) ((WPS) <= 2)
+#endif
 template <bool UNROLL, class BODY>
 __device__ __forceinline__ void for_offsets(Offset (&off)[4], BODY &&body)
 {
@@ -22,7 +27,11 @@ __device__ __forceinline__ void for_offsets(Offset (&off)[4], BODY &&body)
         body(std::integral_constant<int, 0>{}, off[0]); body(std::integral_constant<int, 1>{}, off[1]);
         body(std::integral_constant<int, 2>{}, off[2]); body(std::integral_constant<int, 3>{}, off[3]);
     } else {
+#ifdef GDPT_FORCE_ROLLED
+#pragma unroll          /* (as the loop was written when the fault was seen: a full-unroll request that LLVM drops for its size) */
+#else
 #pragma unroll 1
+#endif
         for (int i = 0; i < 4; i++) body(i, off[i]);
     }
 }
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
             if (!active) { paths++; pathLen += L.depth; if (STAGED || F.qRec) q_finish(F, slot, A); else pending = true; }
         }
         if (active) {
-            if (!bounce<ENV, SMOOTH, false, (WAVES_PER_SIMD <= 2)>(S, sv, cfg, stack, L, A)) {
+            if (!bounce<ENV, SMOOTH, false, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD)>(S, sv, cfg, stack, L, A)) {
                 active = false;
                 paths++; pathLen += L.depth;
                 // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
