@@ -292,6 +292,25 @@ def test_fuzzed_films_match_oracle(G, seed):
     F.close(); S.close()
 
 
+@pytest.mark.parametrize("name,W,H,spp,md", [("cornell", 1280, 720, 2, -1), ("atrium", 1920, 1080, 1, 9)])
+def test_whole_frame_at_configuration_size_matches_oracle(G, name, W, H, spp, md):
+    """WHOLE frames at BASELINE's resolutions (config 2: the Cornell box at 1280x720; config 3: the atrium at 1920x1080, the scene
+    of the config with its 113 k triangles) against the oracle: every pixel of the five buffers and both ray counters.  Few samples
+    per pixel -- spp only lengthens the per-pixel loop (the 64 spp frame is held to the oracle by sample spot checks and by the
+    size-independent properties of test_full_size_properties_1280x720x64) -- but every tile, every wave position, the sample queue
+    with hundreds of thousands of slots and the continuation kernel's refills are in it."""
+    sc = scenes.cornell_box(W, H, "diffuse") if name == "cornell" else scenes.atrium(W, H)
+    S = G.Scene(sc); F = G.Film(S)
+    integ = G.GradientPathIntegrator(maxDepth=md)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    oacc, orays = go.Scene(sc).render(go.config(maxDepth=md, spp=spp))
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays and st["paths"] == W * H * spp
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (name, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    F.close(); S.close()
+
+
 def test_atrium_hbm_bvh_film_matches_oracle(G):
     """Sponza-class stand-in (20k triangles): the BVH and triangle tables do not fit the LDS budget, so traversal reads
     node packets from HBM/L2 and the shading tables through the global path; diffuse + rough-conductor materials."""
