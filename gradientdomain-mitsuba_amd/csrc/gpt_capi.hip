@@ -194,7 +194,7 @@ struct gdpt_scene {
     int bvhDepth = 0;
     int numCUs = 256;
     bool specialEmitters = false;   // an environment or point emitter: the ENV builds of the render kernel
-    bool perVertex = false;         // vertex normals, texture coordinates or bitmap textures: the builds that keep a hit's barycentrics
+    bool perVertex = false;         // vertex normals or bitmap textures: the builds that keep a hit's barycentrics
     size_t ldsSceneBytes = 0;
 };
 
@@ -305,18 +305,35 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         H3 fn = hcross(side1, side2);
         const double len = hlen(fn);
         if (!(fn.x == 0 && fn.y == 0 && fn.z == 0)) fn = fn * (1.0 / len);       // skdtree.h:369-371 (Normal /= length multiplies by the reciprocal)
-        H3 sv = side1 - fn * hdot(fn, side1);                                     // computeShadingFrame, util.cpp:603-608
+        H3 dpdu = side1;                                                          // its.dpdu, skdtree.h:373-380
+        if (uvs && (!triHasUV || triHasUV[t])) {              // per-vertex texture coordinates of this triangle's mesh (skdtree.h:398-402)
+            if (tuv.empty()) { tuv.resize(numTris); tHasUV.assign(((size_t)numTris + 15) & ~(size_t)15, 0); }
+            for (int k = 0; k < 6; k++) tuv[li].uv[k] = uvs[6 * (size_t)t + k];
+            tHasUV[li] = 1;
+            // a mesh with texture coordinates has UV tangents (TriMesh::configure calls computeUVTangents unconditionally, trimesh.cpp:362-386)
+            // and its shading frames follow the texture's u axis: computeUVTangents, trimesh.cpp:701-735
+            const double *q = uvs + 6 * (size_t)t;
+            const double dU1x = q[2] - q[0], dU1y = q[3] - q[1], dU2x = q[4] - q[0], dU2y = q[5] - q[1];
+            const double determinant = dU1x * dU2y - dU1y * dU2x;
+            if (len != 0) {
+                if (determinant == 0) {                       // degenerate parameterization: coordinateSystem(n / length, dpdu, dpdv), util.cpp:592-601
+                    H3 c;
+                    if (std::fabs(fn.x) > std::fabs(fn.y)) { const double il = 1.0 / std::sqrt(fn.x * fn.x + fn.z * fn.z); c = h3(fn.z * il, 0.0, -fn.x * il); }
+                    else { const double il = 1.0 / std::sqrt(fn.y * fn.y + fn.z * fn.z); c = h3(0.0, fn.z * il, -fn.y * il); }
+                    dpdu = hcross(c, fn);
+                } else {
+                    const double invDet = 1.0 / determinant;
+                    dpdu = (side1 * dU2y - side2 * dU1y) * invDet;
+                }
+            }
+        }
+        H3 sv = dpdu - fn * hdot(fn, dpdu);                                       // computeShadingFrame, util.cpp:603-608
         sv = sv * (1.0 / hlen(sv));
         s.n = to_d3(fn); s.s = to_d3(sv); s.t = to_d3(hcross(fn, sv));
         s.material = triMaterial[t];
         s.emitter = emitterOf[t];
         s.origIndex = t;
         s.smooth = 0;
-        if (uvs && (!triHasUV || triHasUV[t])) {              // per-vertex texture coordinates of this triangle's mesh (skdtree.h:398-402)
-            if (tuv.empty()) { tuv.resize(numTris); tHasUV.assign(((size_t)numTris + 15) & ~(size_t)15, 0); }
-            for (int k = 0; k < 6; k++) tuv[li].uv[k] = uvs[6 * (size_t)t + k];
-            tHasUV[li] = 1;
-        }
         if (normals) {                                        // per-vertex normals; three zero vectors = none for this triangle
             const double *n = normals + 9 * (size_t)t;
             bool any = false;
@@ -325,7 +342,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
                 if (emitterOf[t] >= 0) return tfail(GDPT_ERR_UNSUPPORTED, "triangle %d: per-vertex normals on an emitter mesh are not carried (AreaLight::eval / TriMesh::samplePosition with interpolated normals)", t);
                 if (vn.empty()) vn.resize(numTris);
                 TriNormals &o = vn[li];
-                o.n0 = to_d3(h3(n[0], n[1], n[2])); o.n1 = to_d3(h3(n[3], n[4], n[5])); o.n2 = to_d3(h3(n[6], n[7], n[8])); o.pad = 0.0;
+                o.n0 = to_d3(h3(n[0], n[1], n[2])); o.n1 = to_d3(h3(n[3], n[4], n[5])); o.n2 = to_d3(h3(n[6], n[7], n[8])); o.dpdu = to_d3(dpdu);
                 s.smooth = 1;
             }
         }
@@ -418,7 +435,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     d.vn = nullptr;
     if (!vn.empty()) { TriNormals *dvn; if ((rc = upload(&dvn, vn))) { gdpt_scene_destroy(s); return rc; } s->allocs.push_back(dvn); d.vn = dvn; }
     d.uv = nullptr; d.hasUV = nullptr; d.tex = nullptr; d.numTex = numTextures;
-    if (!tuv.empty()) {
+    if (!tuv.empty() && numTextures > 0) {         // (its.uv is read by bitmap textures only; the UV tangents are already in the frames / in TriNormals::dpdu)
         TriUV *duv; unsigned char *dh;
         if ((rc = upload(&duv, tuv)) || (rc = upload(&dh, tHasUV))) { gdpt_scene_destroy(s); return rc; }
         s->allocs.push_back(duv); s->allocs.push_back(dh);
@@ -442,7 +459,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         s->allocs.push_back(dtex);
         d.tex = dtex;
     }
-    s->perVertex = d.vn != nullptr || d.uv != nullptr || numTextures > 0;
+    s->perVertex = d.vn != nullptr || numTextures > 0;
     d.envIndex = envIndex;
     s->specialEmitters = env != nullptr || hasPoint;
     if (env) {

@@ -95,7 +95,8 @@ struct TriShade {           // 160 B: what fillIntersectionRecord needs (skdtree
     int material, emitter;  // emitter = -1 if none
     int origIndex, smooth;  // smooth = 1: the triangle has per-vertex normals (TriNormals table), its frame depends on the hit
 };
-struct TriNormals { d3 n0, n1, n2; Float pad; };   // 80 B: per-vertex normals in leaf order (only scenes that have any)
+struct TriNormals { d3 n0, n1, n2, dpdu; };         // 96 B: per-vertex normals in leaf order (only scenes that have any) + its.dpdu: the
+                                                    // first edge, or the UV tangent of a mesh with texture coordinates (skdtree.h:373-380)
 struct MaterialD {           // 112 B (a multiple of 16: tables are staged into LDS with 16-byte copies)
     int type, distribution, sampleVisible, twoSided;
     d3 reflectance, eta, k;
@@ -960,7 +961,7 @@ __device__ __forceinline__ Frame3 frame_of(const TriShade &t) { Frame3 f; f.s = 
 
 // Shading frame and geometric normal at a vertex (fillIntersectionRecord, skdtree.h:367-397,426).  Flat triangles: the constants of
 // the triangle.  With per-vertex normals (SMOOTH builds): n = normalize(sum b_i n_i), the geometric normal is flipped to the side of
-// n, and (s, t) come from computeShadingFrame(n, dpdu = p1 - p0) (util.cpp:603-608).
+// n, and (s, t) come from computeShadingFrame(n, its.dpdu) (util.cpp:603-608); its.dpdu = p1 - p0, or the UV tangent of a textured mesh.
 struct Shading { Frame3 fr; d3 geoN; };
 template <bool SMOOTH>
 __device__ __forceinline__ Shading shading_at(const SceneView &S, const Vertex &v)
@@ -974,7 +975,7 @@ __device__ __forceinline__ Shading shading_at(const SceneView &S, const Vertex &
         const d3 b = mk(1 - v.u - v.v, v.u, v.v);
         const d3 n = normalize(vn.n0 * b.x + vn.n1 * b.y + vn.n2 * b.z);
         if (dot(ts.n, n) < 0) sh.geoN = -ts.n;
-        const d3 dpdu = ts.p1 - ts.p0;
+        const d3 dpdu = vn.dpdu;
         sh.fr.n = n;
         sh.fr.s = normalize(dpdu - n * dot(n, dpdu));
         sh.fr.t = cross(n, sh.fr.s);

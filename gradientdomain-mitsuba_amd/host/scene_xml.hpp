@@ -723,10 +723,28 @@ private:
                     sd.triHasUV[ti] = 1;
                 }
             }
-        } else if (type == "cube") {                             // src/shapes/cube.cpp: [-1,1]^3, outward normals
-            const double c[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
-            const int f[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {1, 2, 6, 5}, {0, 4, 7, 3}};
-            for (auto &q : f) { addTri(sd, T, flip, c[q[0]], c[q[1]], c[q[2]], mat); addTri(sd, T, flip, c[q[0]], c[q[2]], c[q[3]], mat); }
+        } else if (type == "cube") {
+            // src/shapes/cube.cpp:23-29,74-110: a TriMesh of 24 vertices (four per face, each face mapped onto [0,1]^2) and 12 triangles, in
+            // the plugin's own vertex and triangle order -- the order fixes the barycentrics, the UV tangents (and with them the shading
+            // frames, since every mesh with texture coordinates gets them) and the triangle cdf of a cube used as an area light.  Its
+            // per-vertex normals are the face normals, so the interpolated normal is the face normal up to rounding: emitted as flat triangles.
+            static const double P[24][3] = {{1, -1, -1}, {1, -1, 1}, {-1, -1, 1}, {-1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, 1, 1}, {1, 1, 1},
+                                            {1, -1, -1}, {1, 1, -1}, {1, 1, 1}, {1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}, {-1, -1, 1},
+                                            {-1, -1, 1}, {-1, 1, 1}, {-1, 1, -1}, {-1, -1, -1}, {1, 1, -1}, {1, -1, -1}, {-1, -1, -1}, {-1, 1, -1}};
+            static const double Q[4][2] = {{0, 1}, {1, 1}, {1, 0}, {0, 0}};                 // texcoords of vertex 4 f + k
+            for (int f = 0; f < 6; ++f) {
+                const int tri[2][3] = {{4 * f, 4 * f + 1, 4 * f + 2}, {4 * f + 3, 4 * f, 4 * f + 2}};
+                for (int t = 0; t < 2; ++t) {
+                    addTri(sd, T, flip, P[tri[t][0]], P[tri[t][1]], P[tri[t][2]], mat);
+                    int order[3] = {tri[t][0], tri[t][1], tri[t][2]};
+                    if (flip) std::swap(order[1], order[2]);                              // addTri swaps the last two vertices of a flipped triangle
+                    sd.uvs.resize(6 * (size_t)sd.numTriangles(), 0.0);
+                    sd.triHasUV.resize((size_t)sd.numTriangles(), 0);
+                    const size_t ti = (size_t)sd.numTriangles() - 1;
+                    for (int j = 0; j < 3; ++j) { sd.uvs[6 * ti + 2 * j] = Q[order[j] % 4][0]; sd.uvs[6 * ti + 2 * j + 1] = Q[order[j] % 4][1]; }
+                    sd.triHasUV[ti] = 1;
+                }
+            }
         } else if (type == "obj") {
             if (filename.empty()) logError("shape \"obj\": missing filename");
             loadObj(filename[0] == '/' ? filename : m_dir + "/" + filename, sd, T, flipNormals, faceNormals, mat, flipTexCoords);   // obj.cpp applies no handedness correction

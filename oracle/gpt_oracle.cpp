@@ -183,7 +183,8 @@ struct Tri {
     TriAccel acc;
     int material, emitter;
     V3 faceNormal; // normalized cross(side1, side2)   (skdtree.h:367-371)
-    Frame sh;      // shading frame: n = faceNormal, s,t from dpdu = side1   (skdtree.h:379,396; util.cpp:603-608)
+    Frame sh;      // shading frame: n = faceNormal, s,t from dpdu   (skdtree.h:379,396; util.cpp:603-608)
+    V3 dpdu;       // its.dpdu: side1, or the UV tangent of a mesh with texture coordinates (skdtree.h:373-380, trimesh.cpp:683-735)
     V3 geoN;
     bool hasNormals = false;   // per-vertex normals (TriMesh::getVertexNormals): interpolated shading normal, skdtree.h:382-394
     V3 n0, n1, n2;
@@ -491,7 +492,7 @@ bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
     if (tr.hasNormals) {                                                 // skdtree.h:382-394,426
         its.sh.n = normalize(tr.n0 * b.x + tr.n1 * b.y + tr.n2 * b.z);
         if (dot(tr.faceNormal, its.sh.n) < 0) its.geoN = -tr.faceNormal; // geometric and shading normals face the same way
-        const V3 dpdu = tr.p1 - tr.p0;
+        const V3 dpdu = tr.dpdu;
         its.sh.s = normalize(dpdu - its.sh.n * dot(its.sh.n, dpdu));     // computeShadingFrame, util.cpp:603-608
         its.sh.t = cross(its.sh.n, its.sh.s);
     }
@@ -1748,6 +1749,7 @@ GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *tr
         t.faceNormal = fn;
         t.geoN = fn;
         t.sh.n = fn;                                                   // no vertex normals: shFrame.n = faceNormal (skdtree.h:396)
+        t.dpdu = side1;                                                // skdtree.h:377-379 (a mesh without UV tangents)
         t.sh.s = normalize(side1 - fn * dot(fn, side1));               // computeShadingFrame, util.cpp:603-608
         t.sh.t = cross(fn, t.sh.s);
         const V3 ps[3] = {t.p0, t.p1, t.p2};
@@ -1839,8 +1841,29 @@ GPO_API void gpo_scene_set_uvs(gpo_scene *h, const double *uv6, const unsigned c
     Scene &sc = h->sc;
     for (size_t i = 0; i < sc.tris.size(); ++i) {
         if (hasUV && !hasUV[i]) continue;
-        sc.tris[i].hasUV = true;
-        for (int k = 0; k < 6; ++k) sc.tris[i].uv[k] = uv6[6 * i + k];
+        Tri &t = sc.tris[i];
+        t.hasUV = true;
+        for (int k = 0; k < 6; ++k) t.uv[k] = uv6[6 * i + k];
+        // TriMesh::configure computes UV tangents for every mesh that has texture coordinates (trimesh.cpp:362-386: the second call is
+        // unconditional), and fillIntersectionRecord then takes its.dpdu from them (skdtree.h:373-376): the shading frame of such a
+        // mesh is oriented along the texture's u axis, not along the first edge.  computeUVTangents, trimesh.cpp:701-735:
+        const V3 dP1 = t.p1 - t.p0, dP2 = t.p2 - t.p0;
+        const Float dU1x = t.uv[2] - t.uv[0], dU1y = t.uv[3] - t.uv[1], dU2x = t.uv[4] - t.uv[0], dU2y = t.uv[5] - t.uv[1];
+        const V3 n = cross(dP1, dP2);
+        const Float len = length(n);
+        if (len == 0) continue;                                        // (a degenerate triangle keeps its entry as it was; it cannot be hit)
+        const Float determinant = dU1x * dU2y - dU1y * dU2x;
+        if (determinant == 0) {
+            V3 dpdv;
+            coordinateSystem(n / len, t.dpdu, dpdv);                   // degenerate parameterization: arbitrary tangents
+        } else {
+            const Float invDet = 1.0 / determinant;
+            t.dpdu = (dP1 * dU2y - dP2 * dU1y) * invDet;
+        }
+        if (!t.hasNormals) {                                           // the flat frame is a constant of the triangle: redo it with the new dpdu
+            t.sh.s = normalize(t.dpdu - t.sh.n * dot(t.sh.n, t.dpdu));
+            t.sh.t = cross(t.sh.n, t.sh.s);
+        }
     }
 }
 // Adds a bitmap texture (rgb: h x w x 3 doubles, top row first) and returns its index; params = {wrapU, wrapV, filter}, fparams = {uscale, vscale, uoffset, voffset, scale}

@@ -744,6 +744,50 @@ def test_bitmap_textures_match_oracle(G, flt, wrap):
     S.close(); O.close()
 
 
+@pytest.mark.parametrize("variant,textured", [("bent", False), ("smooth", True)])
+def test_uv_tangents_orient_the_shading_frames(G, variant, textured):
+    """A mesh with texture coordinates gets UV tangents (TriMesh::configure -> computeUVTangents, trimesh.cpp:362-386,683-735) and its
+    shading frames follow the texture's u axis (its.dpdu, skdtree.h:373-380) -- with or without a texture that reads the coordinates.
+    Spheres with interpolated normals + random per-triangle coordinates (some with a degenerate parameterization: the
+    coordinateSystem branch), rough-conductor so that the frame's orientation decides the sampled directions; samples and film
+    against the oracle, and the coordinates must matter."""
+    W, H, spp, md = 40, 32, 4, 6
+    sc = scenes.cornell_box(W, H, variant)
+    nt = sc.ntri
+    rng = np.random.default_rng(11)
+    uvs = rng.uniform(-1.5, 2.5, (nt, 6)); has = (rng.random(nt) < 0.8).astype(np.uint8)
+    degenerate = np.nonzero(has)[0][::7]
+    uvs[degenerate, 2:4] = uvs[degenerate, 0:2] + 0.25; uvs[degenerate, 4:6] = uvs[degenerate, 0:2] + 0.5      # collinear coordinates: determinant 0
+    sc.uvs, sc.tri_has_uv = uvs, has
+    mats = list(sc.materials)
+    rough = len(mats); mats.append(scenes.roughconductor(0.2, **scenes.CU)); sc.materials = mats
+    tm = np.array(sc.tri_material, np.int32).copy(); tm[np.abs(np.asarray(sc.normals)).sum(1) > 0] = rough; sc.tri_material = tm   # the spheres
+    if textured:
+        sc.textures = [scenes.bitmap_texture(scenes.checker_rgb(8, 6, 5), wrap=scenes.TEXWRAP_MIRROR, filter=scenes.TEXFILTER_BILINEAR)]
+        mt = [-1] * len(mats); mt[rough] = 0; sc.material_textures = mt
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=(variant == "bent"))
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=md, spp=spp, strictNormals=(variant == "bent"))
+    for _ in range(40):
+        px, py, k = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, k), O.evaluate_point(ocfg, px, py, k)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-10, atol=1e-14), (px, py, k, key)
+    oacc, orays = O.render(ocfg)
+    for stages in (0, 2):
+        F = G.Film(S); F.set_pipeline(stages)
+        integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (stages, G.BUFFER_NAMES[b])
+        F.close()
+    plain = scenes.cornell_box(W, H, variant); plain.materials, plain.tri_material = sc.materials, sc.tri_material
+    ref, _ = go.Scene(plain).render(ocfg)
+    assert not close(oacc[1], ref[1], 1e-6)                      # same geometry and materials without the coordinates: other frames, other samples
+    S.close(); O.close()
+
+
 def test_texture_arguments_are_checked(G):
     sc = scenes.textured_cornell_box(16, 12)
     sc.textures[0]["filter"] = 2                                # ewa / trilinear are not carried: refused with a reason, not approximated
