@@ -175,6 +175,95 @@ struct Builder {
     bool tooDeep = false;
 };
 
+// ---- MIP pyramid of a `trilinear` / `ewa` bitmap texture (host side; the lookups are in gpt_kernels.hip.h) ---------------------------
+// TMIPMap's constructor (include/mitsuba/render/mipmap.h:163-304): every level is the previous one run through Bitmap::resample
+// (src/libcore/bitmap.cpp:2230-2330) = Resampler<Float> along x into a temporary, then along y (include/mitsuba/core/rfilter.h:104-275,437-458),
+// with the 2-lobed Lanczos filter bitmap.cpp (src/textures/bitmap.cpp:282-287, src/rfilters/lanczos.cpp:42-54) hands it, the texture's wrap
+// modes as boundary conditions and the results clamped to [0, 1].
+struct MipResampler {
+    int bc, sourceRes, targetRes, taps;
+    std::vector<int> start;
+    std::vector<double> weights;
+    static int modulo(int a, int b) { const int r = a % b; return r < 0 ? r + b : r; }
+    static double lanczos2(double x)
+    {
+        x = std::fabs(x);
+        if (x < GD_EPSILON) return 1.0;
+        if (x > 2.0) return 0.0;
+        const double x1 = M_PI * x, x2 = x1 / 2.0;
+        return (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+    }
+    MipResampler(int bc_, int src, int dst) : bc(bc_), sourceRes(src), targetRes(dst)
+    {
+        double filterRadius = 2.0, invScale = 1.0;
+        if (dst < src) { const double scale = (double)src / (double)dst; invScale = 1 / scale; filterRadius *= scale; }
+        taps = (int)std::ceil(filterRadius * 2);
+        start.resize(dst);
+        weights.resize((size_t)taps * dst);
+        for (int i = 0; i < dst; i++) {
+            const double center = (i + 0.5) / dst * src;
+            start[i] = (int)std::floor(center - filterRadius + 0.5);
+            double sum = 0;
+            for (int j = 0; j < taps; j++) { const double wgt = lanczos2((start[i] + j + 0.5 - center) * invScale); weights[(size_t)i * taps + j] = wgt; sum += wgt; }
+            const double normalization = 1.0 / sum;
+            for (int j = 0; j < taps; j++) weights[(size_t)i * taps + j] *= normalization;
+        }
+    }
+    double lookup(const double *line, int pos, size_t stride, int ch) const
+    {
+        if (pos < 0 || pos >= sourceRes) {
+            switch (bc) {
+                case GDPT_TEXWRAP_CLAMP: pos = std::min(std::max(pos, 0), sourceRes - 1); break;
+                case GDPT_TEXWRAP_REPEAT: pos = modulo(pos, sourceRes); break;
+                case GDPT_TEXWRAP_MIRROR: pos = modulo(pos, 2 * sourceRes); if (pos >= sourceRes) pos = 2 * sourceRes - pos - 1; break;
+                case GDPT_TEXWRAP_ZERO: return 0.0;
+                default: return 1.0;
+            }
+        }
+        return line[stride * pos + ch];
+    }
+    void run(const double *line, size_t srcStride, double *out, size_t dstStride) const      // strides in doubles; 3 channels; clamp to [0, 1]
+    {
+        for (int i = 0; i < targetRes; ++i)
+            for (int ch = 0; ch < 3; ++ch) {
+                double result = 0;
+                for (int j = 0; j < taps; ++j) result += lookup(line, start[i] + j, srcStride, ch) * weights[(size_t)i * taps + j];
+                out[(size_t)i * dstStride + ch] = std::min(1.0, std::max(0.0, result));
+            }
+    }
+};
+// Appends the levels below `level0` (w x h x 3) to `texels`; fills the level tables of `o`.
+void build_pyramid(std::vector<double> &texels, TexD &o)
+{
+    o.levels = 1; o.lw[0] = o.w; o.lh[0] = o.h; o.loff[0] = 0; o.ratioX[0] = o.ratioY[0] = 1.0;
+    int sw = o.w, sh = o.h;
+    size_t prev = 0;
+    while ((sw > 1 || sh > 1) && o.levels < TEX_MAX_LEVELS) {
+        const int tw = std::max(1, (sw + 1) / 2), th = std::max(1, (sh + 1) / 2);
+        std::vector<double> temp, next((size_t)tw * th * 3);
+        const double *src = &texels[prev];
+        int curW = sw;
+        if (sw != tw) {
+            MipResampler r(o.wrapU, sw, tw);
+            std::vector<double> &dst = (sh != th) ? temp : next;
+            if (sh != th) temp.resize((size_t)tw * sh * 3);
+            for (int y = 0; y < sh; ++y) r.run(src + (size_t)y * sw * 3, 3, &dst[(size_t)y * tw * 3], 3);
+            src = dst.data();
+            curW = tw;
+        }
+        if (sh != th) {
+            MipResampler r(o.wrapV, sh, th);
+            for (int x = 0; x < curW; ++x) r.run(src + (size_t)x * 3, (size_t)curW * 3, &next[(size_t)x * 3], (size_t)tw * 3);
+        } else if (sw == tw) next.assign(src, src + (size_t)tw * th * 3);
+        const int l = o.levels++;
+        o.lw[l] = tw; o.lh[l] = th; o.loff[l] = (unsigned)(texels.size() / 3);
+        o.ratioX[l] = (double)tw / (double)o.w; o.ratioY[l] = (double)th / (double)o.h;
+        prev = texels.size();
+        texels.insert(texels.end(), next.begin(), next.end());
+        sw = tw; sh = th;
+    }
+}
+
 template <class T>
 int upload(T **dst, const std::vector<T> &v)
 {
@@ -248,8 +337,9 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     for (int i = 0; i < numTextures; i++) {
         const gdpt_texture &t = textures[i];
         if (t.width <= 0 || t.height <= 0 || !t.rgb) return tfail(GDPT_ERR_INVALID, "texture %d: empty bitmap", i);
-        if (t.filter != GDPT_TEXFILTER_NEAREST && t.filter != GDPT_TEXFILTER_BILINEAR)
-            return tfail(GDPT_ERR_UNSUPPORTED, "texture %d: only the filter types 'nearest' and 'bilinear' are carried ('ewa' and 'trilinear' read the MIP pyramid through ray differentials)", i);
+        if (t.filter < GDPT_TEXFILTER_NEAREST || t.filter > GDPT_TEXFILTER_EWA)
+            return tfail(GDPT_ERR_INVALID, "texture %d: Invalid filter type, must be 'ewa', 'trilinear', or 'nearest'!", i);                   // bitmap.cpp:228-230
+        if (t.filter == GDPT_TEXFILTER_EWA && !(t.maxAnisotropy >= 1.0)) return tfail(GDPT_ERR_INVALID, "texture %d: maxAnisotropy must be at least 1", i);
         if (t.wrapU < 0 || t.wrapU > 4 || t.wrapV < 0 || t.wrapV > 4) return tfail(GDPT_ERR_INVALID, "texture %d: Invalid wrap mode: must be one of 'repeat', 'clamp', 'black', or 'white'!", i);   // bitmap.cpp:336-337
     }
     if (materialTexture)
@@ -446,9 +536,19 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         for (int i = 0; i < numTextures; i++) {
             const gdpt_texture &t = textures[i];
             TexD &o = tex[i];
-            o.w = t.width; o.h = t.height; o.wrapU = t.wrapU; o.wrapV = t.wrapV; o.filter = t.filter; o.pad = 0;
+            std::memset(&o, 0, sizeof o);
+            o.w = t.width; o.h = t.height; o.wrapU = t.wrapU; o.wrapV = t.wrapV; o.filter = t.filter;
             o.uscale = t.uscale; o.vscale = t.vscale; o.uoffset = t.uoffset; o.voffset = t.voffset; o.scale = t.scale;
-            const std::vector<double> texels(t.rgb, t.rgb + (size_t)3 * t.width * t.height);
+            std::vector<double> texels(t.rgb, t.rgb + (size_t)3 * t.width * t.height);
+            for (double &v : texels) if (v < 0) v = 0;                          // the MIP map clamps negative texels, mipmap.h:234-242
+            o.levels = 1; o.lw[0] = o.w; o.lh[0] = o.h; o.loff[0] = 0; o.ratioX[0] = o.ratioY[0] = 1.0;
+            o.maxAnisotropy = t.filter == GDPT_TEXFILTER_EWA ? t.maxAnisotropy : 1.0;         // bitmap.cpp:232-235
+            if (t.filter >= GDPT_TEXFILTER_TRILINEAR) {
+                if ((long)t.width * t.height > (1L << 28)) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_UNSUPPORTED, "texture %d: larger than 2^28 texels", i); }
+                build_pyramid(texels, o);
+                // m_weightLut, mipmap.h:297-301: exp(-2 r2) in double minus math::fastexp(-2.0f), whose FLOAT overload returns (float) exp(-2.0)
+                for (int k = 0; k < TEX_LUT_SIZE; ++k) { const double r2 = (double)k / (double)(TEX_LUT_SIZE - 1); o.lut[k] = std::exp(-2.0 * r2) - (double)(float)std::exp(-2.0); }
+            }
             double *dt;
             if ((rc = upload(&dt, texels))) { gdpt_scene_destroy(s); return rc; }
             s->allocs.push_back(dt);

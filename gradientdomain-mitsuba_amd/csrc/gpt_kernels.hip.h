@@ -107,12 +107,18 @@ struct TriUV { Float uv[6]; };   // 48 B: per-vertex texture coordinates (u0 v0 
 // `<texture type="bitmap">` as the G-PT path evaluates it (src/textures/bitmap.cpp:431-452 -> MIPMap::evalBox / evalBilinear on level 0,
 // mipmap.h:566-596; filterType nearest | bilinear -- "ewa"/"trilinear" read the MIP pyramid through ray differentials and are refused by
 // the host).  Texels are doubles (the reference's MIP map holds Float), [h][w][3], top row first, in HBM.
+constexpr int TEX_MAX_LEVELS = 16, TEX_LUT_SIZE = 64;     // (MTS_MIPMAP_LUT_SIZE, mipmap.h:37)
 struct TexD {
     int w, h, wrapU, wrapV;     // wrap: 0 repeat, 1 clamp, 2 mirror, 3 zero, 4 one (ReconstructionFilter::EBoundaryCondition as bitmap.cpp:324-338 names them)
-    int filter, pad;            // 0 nearest (evalBox), 1 bilinear
+    int filter, levels;         // 0 nearest (evalBox), 1 bilinear, 2 trilinear, 3 ewa; MIP levels (1 for nearest / bilinear)
     Float uscale, vscale, uoffset, voffset;   // Texture2D, texture.cpp:27-45,113
     Float scale;                // BSDF::ensureEnergyConservation's ScaleTexture factor (1 = none)
-    const Float *texels;
+    const Float *texels;        // level 0, then the levels of the pyramid one after the other (host-built: gpt_capi.hip build_pyramid)
+    int lw[TEX_MAX_LEVELS], lh[TEX_MAX_LEVELS];
+    unsigned loff[TEX_MAX_LEVELS];            // first texel of a level in `texels`
+    Float ratioX[TEX_MAX_LEVELS], ratioY[TEX_MAX_LEVELS];   // m_sizeRatio
+    Float maxAnisotropy;
+    Float lut[TEX_LUT_SIZE];    // m_weightLut (Gaussian), mipmap.h:297-301
 };
 static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
@@ -1004,33 +1010,174 @@ __device__ __forceinline__ bool tex_wrap(int &x, int size, int mode, Float &c)
     c = mode == 3 ? 0.0 : 1.0;
     return false;
 }
-__device__ __forceinline__ d3 tex_texel(const TexD &t, int x, int y)
-{
+__device__ __forceinline__ d3 tex_texel(const TexD &t, int level, int x, int y)
+{ // evalTexel, mipmap.h:503-563
     Float c = 0;
-    if (!tex_wrap(x, t.w, t.wrapU, c)) return mk(c);
-    if (!tex_wrap(y, t.h, t.wrapV, c)) return mk(c);
-    const Float *p = t.texels + ((size_t)y * t.w + x) * 3;
+    const int w = t.lw[level], h = t.lh[level];
+    if (!tex_wrap(x, w, t.wrapU, c)) return mk(c);
+    if (!tex_wrap(y, h, t.wrapV, c)) return mk(c);
+    const Float *p = t.texels + ((size_t)t.loff[level] + (size_t)y * w + x) * 3;
     return mk(p[0], p[1], p[2]);
 }
-// Texture2D::eval (texture.cpp:112-121) -> BitmapTexture::eval -> evalBox / evalBilinear on level 0 (mipmap.h:566-596)
-__device__ __noinline__ d3 tex_eval(const TexD &t, Float u_, Float v_)   // a real call: textured vertices only; inlined at its six sites it cost every per-vertex build ~25 % (register pressure)
+__device__ __forceinline__ d3 tex_box(const TexD &t, int level, Float u, Float v) { return tex_texel(t, level, (int)floor(u * t.lw[level]), (int)floor(v * t.lh[level])); }   // :566-569
+__device__ __forceinline__ d3 tex_bilinear(const TexD &t, int level, Float u_, Float v_)
+{ // evalBilinear, mipmap.h:575-596
+    if (!is_finite_d(u_) || !is_finite_d(v_)) return mk(0.0);
+    if (level >= t.levels) return tex_box(t, t.levels - 1, u_, v_);
+    const Float u = u_ * t.lw[level] - 0.5, v = v_ * t.lh[level] - 0.5;
+    const int xPos = (int)floor(u), yPos = (int)floor(v);
+    const Float dx1 = u - xPos, dx2 = 1.0 - dx1, dy1 = v - yPos, dy2 = 1.0 - dy1;
+    return tex_texel(t, level, xPos, yPos) * dx2 * dy2 + tex_texel(t, level, xPos, yPos + 1) * dx2 * dy1 + tex_texel(t, level, xPos + 1, yPos) * dx1 * dy2 + tex_texel(t, level, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+__device__ __forceinline__ d3 tex_ewa(const TexD &t, int level, Float u_, Float v_, Float A, Float B, Float C)
+{ // evalEWA, mipmap.h:744-833
+    if (!is_finite_d(A + B + C + u_ + v_)) return mk(0.0);
+    if (level >= t.levels) return tex_box(t, t.levels - 1, u_, v_);
+    const Float u = u_ * t.lw[level] - 0.5, v = v_ * t.lh[level] - 0.5;
+    const Float rx = t.ratioX[level], ry = t.ratioY[level];
+    A /= rx * rx; B /= rx * ry; C /= ry * ry;
+    const Float invDet = 1.0 / (-B * B + 4.0 * A * C), deltaU = 2.0 * sqrt(C * invDet), deltaV = 2.0 * sqrt(A * invDet);
+    const int u0 = (int)ceil(u - deltaU), u1 = (int)floor(u + deltaU), v0 = (int)ceil(v - deltaV), v1 = (int)floor(v + deltaV);
+    const Float As = A * TEX_LUT_SIZE, Bs = B * TEX_LUT_SIZE, Cs = C * TEX_LUT_SIZE;
+    d3 result = mk(0.0);
+    Float denominator = 0.0;
+    const Float ddq = 2 * As, uu0 = (Float)u0 - u;
+    for (int vt = v0; vt <= v1; ++vt) {
+        const Float vv = (Float)vt - v;
+        Float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv;
+        Float dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < (Float)TEX_LUT_SIZE) {
+                const uint32_t qi = (uint32_t)q;
+                if (qi < (uint32_t)TEX_LUT_SIZE) {
+                    const Float weight = t.lut[(int)q];
+                    result = result + tex_texel(t, level, ut, vt) * weight;
+                    denominator += weight;
+                }
+            }
+            q += dq;
+            dq += ddq;
+        }
+    }
+    if (denominator == 0) return tex_bilinear(t, level, u_, v_);
+    return result / denominator;
+}
+__device__ __forceinline__ Float tex_hypot2(Float a, Float b)
+{ // math::hypot2, math.cpp:89-101
+    Float r;
+    if (fabs(a) > fabs(b)) { r = b / a; r = fabs(a) * sqrt(1.0 + r * r); }
+    else if (b != 0.0) { r = a / b; r = fabs(b) * sqrt(1.0 + r * r); }
+    else r = 0.0;
+    return r;
+}
+__device__ __forceinline__ Float tex_log2(Float v) { const Float invLn2 = 1.0 / log(2.0); return log(v) * invLn2; }   // math::log2, math.cpp:108-111
+// TMIPMap::eval(uv, d0, d1), mipmap.h:628-712 (trilinear / ewa; d0 = (dudx, dvdx), d1 = (dudy, dvdy), already scaled by uscale / vscale)
+__device__ __forceinline__ d3 tex_filtered(const TexD &t, Float u, Float v, Float d0x, Float d0y, Float d1x, Float d1y)
+{
+    const Float du0 = d0x * t.w, dv0 = d0y * t.h, du1 = d1x * t.w, dv1 = d1y * t.h;
+    Float A = dv0 * dv0 + dv1 * dv1, B = -2.0 * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25;
+    const Float root = tex_hypot2(A - C, B), Aprime = 0.5 * (A + C - root), Cprime = 0.5 * (A + C + root);
+    const Float majorRadius = Aprime != 0 ? sqrt(F / Aprime) : 0;
+    Float minorRadius = Cprime != 0 ? sqrt(F / Cprime) : 0;
+    if (t.filter == 2 || !(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        const Float level = tex_log2(fmax(majorRadius, GD_EPSILON));
+        const int ilevel = (int)floor(level);
+        if (ilevel < 0) return tex_bilinear(t, 0, u, v);
+        const Float a = level - ilevel;
+        return tex_bilinear(t, ilevel, u, v) * (1.0 - a) + tex_bilinear(t, ilevel + 1, u, v) * a;
+    }
+    if (minorRadius * t.maxAnisotropy < majorRadius) {
+        minorRadius = majorRadius / t.maxAnisotropy;
+        const Float theta = 0.5 * atan(B / (A - C));
+        const Float sinTheta = sin(theta), cosTheta = cos(theta);
+        const Float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta,
+                    sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2;
+        B = (a2 - b2) * sin2Theta;
+        C = a2 * sinTheta2 + b2 * cosTheta2;
+        F = a2 * b2;
+    }
+    const Float scale = 1.0 / F;
+    A *= scale; B *= scale; C *= scale;
+    const Float level = fmax((Float)0.0, tex_log2(minorRadius));
+    const int ilevel = (int)level;
+    const Float a = level - ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0)) return tex_bilinear(t, ilevel, u, v);
+    return tex_ewa(t, ilevel, u, v, A, B, C) * (1.0 - a) + tex_ewa(t, ilevel + 1, u, v, A, B, C) * a;
+}
+// Texture2D::eval(its) (texture.cpp:112-121) -> BitmapTexture::eval: level 0 by evalBox / evalBilinear (bitmap.cpp:431-452), or -- a hit with
+// UV partials under filterType trilinear / ewa -- the filtered lookup (bitmap.cpp:486-499).  partials = (dudx, dudy, dvdx, dvdy).
+__device__ __noinline__ d3 tex_eval(const TexD &t, Float u_, Float v_, bool hasPartials, Float dudx, Float dudy, Float dvdx, Float dvdy)   // a real call: textured vertices only; inlined at its six sites it cost every per-vertex build ~25 % (register pressure)
 {
     const Float ux = u_ * t.uscale + t.uoffset, vy = v_ * t.vscale + t.voffset;
     d3 value;
-    if (t.filter == 0) value = tex_texel(t, (int)floor(ux * t.w), (int)floor(vy * t.h));
-    else {
-        if (!is_finite_d(ux) || !is_finite_d(vy)) return mk(0.0) * t.scale;
-        const Float u = ux * t.w - 0.5, v = vy * t.h - 0.5;
-        const int xPos = (int)floor(u), yPos = (int)floor(v);
-        const Float dx1 = u - xPos, dx2 = 1.0 - dx1, dy1 = v - yPos, dy2 = 1.0 - dy1;
-        value = tex_texel(t, xPos, yPos) * dx2 * dy2 + tex_texel(t, xPos, yPos + 1) * dx2 * dy1 + tex_texel(t, xPos + 1, yPos) * dx1 * dy2 + tex_texel(t, xPos + 1, yPos + 1) * dx1 * dy1;
-    }
+    if (t.filter == 0) value = tex_box(t, 0, ux, vy);
+    else if (t.filter == 1 || !hasPartials) value = tex_bilinear(t, 0, ux, vy);
+    else value = tex_filtered(t, ux, vy, dudx * t.uscale, dvdx * t.vscale, dudy * t.uscale, dvdy * t.vscale);
     return value * t.scale;
+}
+// The hit of a CAMERA ray on a textured material: Intersection::getBSDF(ray) runs computePartials first (shape.h; intersection.cpp:5-78:
+// the texture coordinates' change per pixel step, from the two differential rays of perspective.cpp:291-295 and the triangle's dpdu /
+// dpdv), and the lookup is the filtered one.  (sxp, syp) = the film position of this path's camera ray.  A real call like tex_eval.
+__device__ __noinline__ d3 tex_eval_primary(const SceneView &S, const CameraD &c, const TexD &t, const Vertex &v, d3 geoN, Float tu, Float tv, Float sxp, Float syp)
+{
+    // differential directions: trafo(normalize(nearP + m_dx)), trafo(normalize(nearP + m_dy)); origins = the camera position
+    const Float sxn = sxp * c.invW, syn = syp * c.invH;
+    const d3 nearP = mk((1 - 2 * sxn) * c.nearClip * c.tanHalf, (1 - 2 * syn) / c.aspect * c.nearClip * c.tanHalf, c.nearClip);
+    const d3 mdx = mk(-2 * c.invW * c.nearClip * c.tanHalf, 0.0, 0.0), mdy = mk(0.0, -2 * c.invH / c.aspect * c.nearClip * c.tanHalf, 0.0);
+    const d3 lx = normalize(nearP + mdx), ly = normalize(nearP + mdy);
+    const d3 o = mk(c.m[3], c.m[7], c.m[11]);
+    const d3 rxD = mk(c.m[0] * lx.x + c.m[1] * lx.y + c.m[2] * lx.z, c.m[4] * lx.x + c.m[5] * lx.y + c.m[6] * lx.z, c.m[8] * lx.x + c.m[9] * lx.y + c.m[10] * lx.z);
+    const d3 ryD = mk(c.m[0] * ly.x + c.m[1] * ly.y + c.m[2] * ly.z, c.m[4] * ly.x + c.m[5] * ly.y + c.m[6] * ly.z, c.m[8] * ly.x + c.m[9] * ly.y + c.m[10] * ly.z);
+    // its.dpdu / its.dpdv: the edges, or the UV tangents of a mesh with texture coordinates (skdtree.h:373-380, trimesh.cpp:701-735)
+    const TriShade &ts = S.shade[v.prim];
+    const d3 dP1 = ts.p1 - ts.p0, dP2 = ts.p2 - ts.p0;
+    d3 dpdu = dP1, dpdv = dP2;
+    if (S.uv && S.hasUV[v.prim]) {
+        const TriUV q = S.uv[v.prim];
+        const Float dU1x = q.uv[2] - q.uv[0], dU1y = q.uv[3] - q.uv[1], dU2x = q.uv[4] - q.uv[0], dU2y = q.uv[5] - q.uv[1];
+        const d3 n = cross(dP1, dP2);
+        const Float nlen = len(n), determinant = dU1x * dU2y - dU1y * dU2x;
+        if (nlen != 0) {
+            if (determinant == 0) {
+                const d3 a = n * (1.0 / nlen);
+                if (fabs(a.x) > fabs(a.y)) { const Float il = 1.0 / sqrt(a.x * a.x + a.z * a.z); dpdv = mk(a.z * il, 0.0, -a.x * il); }
+                else { const Float il = 1.0 / sqrt(a.y * a.y + a.z * a.z); dpdv = mk(0.0, a.z * il, -a.y * il); }
+                dpdu = cross(dpdv, a);
+            } else {
+                const Float invDet = 1.0 / determinant;
+                dpdu = (dP1 * dU2y - dP2 * dU1y) * invDet;
+                dpdv = (dP1 * (-dU2x) + dP2 * dU1x) * invDet;
+            }
+        }
+    }
+    Float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
+    const Float pp = dot(geoN, v.p), po = dot(geoN, o), prx = dot(geoN, rxD), pry = dot(geoN, ryD);
+    if (!(is_zero(dpdu) && is_zero(dpdv)) && !(prx == 0 || pry == 0)) {
+        const Float tx = (pp - po) / prx, ty = (pp - po) / pry;
+        const Float absX = fabs(geoN.x), absY = fabs(geoN.y), absZ = fabs(geoN.z);
+        int a0, a1;
+        if (absX > absY && absX > absZ) { a0 = 1; a1 = 2; }
+        else if (absY > absZ) { a0 = 0; a1 = 2; }
+        else { a0 = 0; a1 = 1; }
+        const Float A00 = comp(dpdu, a0), A01 = comp(dpdv, a0), A10 = comp(dpdu, a1), A11 = comp(dpdv, a1);
+        const d3 px = o + rxD * tx, py = o + ryD * ty;
+        const Float Bx0 = comp(px, a0) - comp(v.p, a0), Bx1 = comp(px, a1) - comp(v.p, a1), By0 = comp(py, a0) - comp(v.p, a0), By1 = comp(py, a1) - comp(v.p, a1);
+        const Float det = A00 * A11 - A01 * A10;                                         // solveLinearSystem2x2, util.cpp:527-539
+        if (fabs(det) <= 0x1p-1024) { dudx = 1; dvdx = 0; dudy = 1; dvdy = 0; }          // (:66-76; the reference leaves dvdy unset there: taken as 0)
+        else {
+            const Float inverse = 1.0 / det;
+            dudx = (A11 * Bx0 - A01 * Bx1) * inverse; dvdx = (A00 * Bx1 - A10 * Bx0) * inverse;
+            dudy = (A11 * By0 - A01 * By1) * inverse; dvdy = (A00 * By1 - A10 * By0) * inverse;
+        }
+    }
+    return tex_eval(t, tu, tv, true, dudx, dudy, dvdx, dvdy);
 }
 // m_reflectance->eval(its) / m_specularReflectance->eval(its): the constant, or the bitmap at its.uv (skdtree.h:398-405: interpolated
 // texture coordinates, or the barycentrics (b1, b2) for a mesh without any).  PERVERTEX builds only; flat untextured scenes compile it out.
+// primary: v is the hit of the camera ray through film position (sxp, syp) -- the only hits that have UV partials.
 template <bool PERVERTEX>
-__device__ __forceinline__ d3 reflectance_at(const SceneView &S, const MaterialD &m, const Vertex &v)
+__device__ __forceinline__ d3 reflectance_at(const SceneView &S, const MaterialD &m, const Vertex &v, bool primary = false, const CameraD *cam = nullptr, Float sxp = 0, Float syp = 0)
 {
     if (!PERVERTEX || m.tex < 0) return m.reflectance;
     Float tu = v.u, tv = v.v;
@@ -1040,7 +1187,9 @@ __device__ __forceinline__ d3 reflectance_at(const SceneView &S, const MaterialD
         tu = t.uv[0] * b0 + t.uv[2] * v.u + t.uv[4] * v.v;
         tv = t.uv[1] * b0 + t.uv[3] * v.u + t.uv[5] * v.v;
     }
-    return tex_eval(S.tex[m.tex], tu, tv);
+    const TexD &t = S.tex[m.tex];
+    if (primary && t.filter >= 2) return tex_eval_primary(S, *cam, t, v, shading_at<PERVERTEX>(S, v).geoN, tu, tv, sxp, syp);
+    return tex_eval(t, tu, tv, false, 0.0, 0.0, 0.0, 0.0);
 }
 
 // its.wi = its.toLocal(-ray.d), skdtree.h:427

@@ -20,6 +20,9 @@ namespace gdpt_tr {
 #else
 #define GDPT_UNROLL_OFFSETS(WPS) ((WPS) <= 2)
 #endif
+// pixel shift of offset path i (gpt.cpp:410-415: right, down, left, up)
+__device__ __forceinline__ Float offset_shift_x(int i) { return i == 0 ? 1.0 : (i == 2 ? -1.0 : 0.0); }
+__device__ __forceinline__ Float offset_shift_y(int i) { return i == 1 ? 1.0 : (i == 3 ? -1.0 : 0.0); }
 template <bool UNROLL, class BODY>
 __device__ __forceinline__ void for_offsets(Offset (&off)[4], BODY &&body)
 {
@@ -168,7 +171,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
     const MaterialD &mainBSDF = sv.mats[mts.material];
-    const d3 mainR = reflectance_at<SMOOTH>(sv, mainBSDF, L.v);                  // m_reflectance->eval(its): the constant or its bitmap texture at its.uv
+    const d3 mainR = reflectance_at<SMOOTH>(sv, mainBSDF, L.v, L.depth == 1, &S.cam, L.sx, L.sy);                  // m_reflectance->eval(its): the constant or its bitmap texture at its.uv
 
     // ================= direct illumination sampling, :565-730 =================
     if (bsdfType(mainBSDF) & ESmooth) {
@@ -236,7 +239,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             } else {
                                 d3 f;
                                 Float pdfRaw;
-                                bsdf_eval_pdf(shiftedBSDF, reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v), toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
+                                bsdf_eval_pdf(shiftedBSDF, reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i)), toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
                                 const Float shiftedBsdfPdf = (lightOnSurfaceSA && shiftedEmitterVisible) ? pdfRaw : 0;
                                 const Float jacobian = fabs(shiftedOpposingCosine * mainDistanceSquared) / (GD_EPSILON + fabs(mainOpposingCosine * shiftedDistanceSquared)); // :695
                                 const Float den = (jacobian * s.pdf) * (jacobian * s.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
@@ -339,7 +342,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                 const Shading ssh = shading_at<SMOOTH>(sv, s.v);
                 const Frame3 sfr = ssh.fr;
                 const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
-                const d3 shiftedR = reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v);
+                const d3 shiftedR = reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i));   // (depth 1: still the offset's camera-ray hit)
                 if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
                     // ---- reconnection shift, :897-986 ----
                     if (!lastSegment || mainHitEmitter) {                        // :901

@@ -659,6 +659,92 @@ int gdpt_poisson_evaluate_metrics(gdpt_poisson_solver *s, float *err, float *err
     return GDPT_OK;
 }
 
+// ---- G-BDPT's reconstruction stage (gbdpt.cpp:178-247,264-280) ----------------------------------------------------------------------
+// prepareDataForSolver, element by element with the promotions of the C++ expressions: `out[i] = w*float(data[i])` is fp32;
+// `out[i] *= 0.5` and `out[i] -= 0.5*w*float(data2[io])` go through double (0.5 is a double literal) and round to fp32 on the store.
+__global__ __launch_bounds__(BLK) void k_gbdpt_prepare(float w, float *__restrict__ out, const double *__restrict__ data, long len,
+                                                       const double *__restrict__ data2, long off3)
+{
+    for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < len; i += (long)gridDim.x * BLK) {
+        float o = w * (float)data[i];
+        if (data2) {
+            const long io = i + off3;
+            if (io >= 0 && io < len) {
+                o = (float)((double)o * 0.5);
+                o = (float)((double)o - (0.5 * (double)w) * (double)(float)data2[io]);
+            }
+        }
+        out[i] = o;
+    }
+}
+
+int gdpt_gbdpt_prepare_data_device(float w, float *out, const double *data, int len, const double *data2, int offset, void *stream)
+{
+    if (!out || !data || len < 0) return fail(GDPT_ERR_INVALID, "gbdpt_prepare_data: null pointer or negative length");
+    if (len == 0) return GDPT_OK;
+    hipLaunchKernelGGL(k_gbdpt_prepare, dim3(grid_generic(len)), dim3(BLK), 0, (hipStream_t)stream, w, out, data, (long)len, data2, 3L * (long)offset);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_prepare_data(float w, float *out, const double *data, int len, const double *data2, int offset)
+{
+    if (!out || !data || len < 0) return fail(GDPT_ERR_INVALID, "gbdpt_prepare_data: null pointer or negative length");
+    if (len == 0) return GDPT_OK;
+    double *dd = nullptr, *dd2 = nullptr;
+    float *dout = nullptr;
+    int rc = GDPT_OK;
+    if (hipMalloc(&dd, sizeof(double) * len) != hipSuccess || hipMalloc(&dout, sizeof(float) * len) != hipSuccess ||
+        (data2 && hipMalloc(&dd2, sizeof(double) * len) != hipSuccess)) rc = fail(GDPT_ERR_HIP, "Out of memory!");
+    if (!rc && (hipMemcpy(dd, data, sizeof(double) * len, hipMemcpyHostToDevice) != hipSuccess ||
+                (data2 && hipMemcpy(dd2, data2, sizeof(double) * len, hipMemcpyHostToDevice) != hipSuccess))) rc = fail(GDPT_ERR_HIP, "upload failed");
+    if (!rc) rc = gdpt_gbdpt_prepare_data_device(w, dout, dd, len, dd2, offset, nullptr);
+    if (!rc && hipMemcpy(out, dout, sizeof(float) * len, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GDPT_ERR_HIP, "download failed");
+    hipFree(dd); hipFree(dd2); hipFree(dout);
+    return rc;
+}
+
+int gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
+                           int width, int height, float alpha, int device, float *recL2, float *recL1)
+{
+    if (!primal || !gradNegY || !gradNegX || !gradPosX || !gradPosY || width <= 0 || height <= 0)
+        return fail(GDPT_ERR_INVALID, "gbdpt_reconstruct: null buffer or empty image");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    const int len = 3 * width * height;
+    const double *host[5] = {primal, gradNegY, gradNegX, gradPosX, gradPosY};
+    double *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *in[3] = {nullptr, nullptr, nullptr};                  // imgf, dyf, dxf
+    int rc = GDPT_OK;
+    for (int k = 0; k < 5 && !rc; k++)
+        if (hipMalloc(&dev[k], sizeof(double) * len) != hipSuccess || hipMemcpy(dev[k], host[k], sizeof(double) * len, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(GDPT_ERR_HIP, "gbdpt_reconstruct: upload failed");
+    for (int k = 0; k < 3 && !rc; k++) if (hipMalloc(&in[k], sizeof(float) * len) != hipSuccess) rc = fail(GDPT_ERR_HIP, "Out of memory!");
+    if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[0], dev[0], len, nullptr, 0, nullptr);            // gbdpt.cpp:206
+    if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[1], dev[4], len, dev[1], width, nullptr);          // :207  dy: grad[3] (+y) with grad[0] (-y)
+    if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[2], dev[3], len, dev[2], 1, nullptr);              // :208  dx: grad[2] (+x) with grad[1] (-x)
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(GDPT_ERR_HIP, "gbdpt_reconstruct: prepare failed");
+    const char *presets[2] = {"L2D", "L1D"};                     // :213-218, both with m_reconstructAlpha
+    float *outs[2] = {recL2, recL1};
+    for (int k = 0; k < 2 && !rc; k++) {
+        if (!outs[k]) continue;
+        gdpt_poisson_params p;
+        gdpt_poisson_params_defaults(&p);
+        gdpt_poisson_params_preset(&p, presets[k]);
+        p.alpha = alpha;
+        p.device = device;
+        gdpt_poisson_solver *sv = nullptr;
+        rc = gdpt_poisson_create(&p, &sv);
+        if (!rc) rc = gdpt_poisson_import_images_device(sv, in[2], in[1], in[0], nullptr, width, height);   // importImagesMTS(dx, dy, img, NULL), :229,243
+        if (!rc) rc = gdpt_poisson_setup_backend(sv);
+        if (!rc) rc = gdpt_poisson_solve_indirect(sv);
+        if (!rc) rc = gdpt_poisson_export_images(sv, outs[k]);
+        gdpt_poisson_destroy(sv);
+    }
+    for (double *d : dev) hipFree(d);
+    for (float *f : in) hipFree(f);
+    return rc;
+}
+
 int gdpt_poisson_export_images(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToHost); }
 int gdpt_poisson_export_images_device(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToDevice); }
 

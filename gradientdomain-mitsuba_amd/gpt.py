@@ -25,7 +25,7 @@ class Material(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("rgb", C.c_void_p), ("wrapU", C.c_int), ("wrapV", C.c_int), ("filter", C.c_int),
-                ("uscale", C.c_double), ("vscale", C.c_double), ("uoffset", C.c_double), ("voffset", C.c_double), ("scale", C.c_double)]
+                ("uscale", C.c_double), ("vscale", C.c_double), ("uoffset", C.c_double), ("voffset", C.c_double), ("scale", C.c_double), ("maxAnisotropy", C.c_double)]
 
 
 class Emitter(C.Structure):
@@ -101,6 +101,7 @@ class Scene:
             tarr[i].wrapU, tarr[i].wrapV, tarr[i].filter = t.get("wrapU", 0), t.get("wrapV", 0), t.get("filter", 1)
             tarr[i].uscale, tarr[i].vscale, tarr[i].uoffset, tarr[i].voffset = t.get("uscale", 1.0), t.get("vscale", 1.0), t.get("uoffset", 0.0), t.get("voffset", 0.0)
             tarr[i].scale = t.get("scale", 1.0)
+            tarr[i].maxAnisotropy = t.get("maxAnisotropy", 20.0)
         mtex = getattr(desc, "material_textures", None)
         mtex = np.ascontiguousarray(mtex, dtype=np.int32) if mtex is not None else None
         check(lib().gdpt_scene_create_tex(verts.shape[0], verts.ctypes.data_as(C.c_void_p),

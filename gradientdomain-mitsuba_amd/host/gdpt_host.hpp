@@ -146,6 +146,17 @@ private:
 
 } // namespace poisson
 
+/// The reconstruction stage of the G-BDPT integrator (BASELINE config 5) -- the part of GBDPTIntegrator::render that is this library's
+/// kind of work (src/integrators/gbdpt/gbdpt.cpp:178-247,264-280); its bidirectional sampler is not carried.
+struct GBDPTReconstruction {
+    /// GBDPTIntegrator::prepareDataForSolver (gbdpt.cpp:264-280), same arguments
+    static void prepareDataForSolver(float w, float *out, const double *data, int len, const double *data2, int offset) { check(gdpt_gbdpt_prepare_data(w, out, data, len, data2, offset)); }
+    /// the three prepareDataForSolver calls + Solver(L2D) + Solver(L1D) without a direct image (gbdpt.cpp:206-247); recL2 / recL1 may be null
+    static void reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
+                            int width, int height, float reconstructAlpha, float *recL2, float *recL1, int device = -1)
+    { check(gdpt_gbdpt_reconstruct(primal, gradNegY, gradNegX, gradPosX, gradPosY, width, height, reconstructAlpha, device, recL2, recL1)); }
+};
+
 /// What the scene-XML subset reader produces and gdpt_scene_create consumes.
 struct SceneData {
     std::vector<double> verts;              // 9 per triangle
@@ -153,7 +164,7 @@ struct SceneData {
     std::vector<int> triMaterial;
     std::vector<double> uvs;                // 6 per triangle (u0 v0 u1 v1 u2 v2) for the first uvs.size()/6 triangles; empty = no mesh has texture coordinates
     std::vector<unsigned char> triHasUV;    // per triangle of that prefix: its mesh has texture coordinates
-    struct Texture { int width = 0, height = 0; std::vector<double> rgb; int wrapU = 0, wrapV = 0, filter = 1; double uscale = 1, vscale = 1, uoffset = 0, voffset = 0, scale = 1; };
+    struct Texture { int width = 0, height = 0; std::vector<double> rgb; int wrapU = 0, wrapV = 0, filter = 1; double uscale = 1, vscale = 1, uoffset = 0, voffset = 0, scale = 1, maxAnisotropy = 20; };
     std::vector<Texture> textures;          // `<texture type="bitmap">`
     std::vector<int> materialTexture;       // per material: its reflectance / specularReflectance texture, -1 = constant (shorter than materials = -1)
     std::vector<gdpt_material> materials;
@@ -492,7 +503,7 @@ public:
         for (size_t i = 0; i < tex.size(); ++i) {
             const SceneData::Texture &t = sd.textures[i];
             tex[i].width = t.width; tex[i].height = t.height; tex[i].rgb = t.rgb.data(); tex[i].wrapU = t.wrapU; tex[i].wrapV = t.wrapV; tex[i].filter = t.filter;
-            tex[i].uscale = t.uscale; tex[i].vscale = t.vscale; tex[i].uoffset = t.uoffset; tex[i].voffset = t.voffset; tex[i].scale = t.scale;
+            tex[i].uscale = t.uscale; tex[i].vscale = t.vscale; tex[i].uoffset = t.uoffset; tex[i].voffset = t.voffset; tex[i].scale = t.scale; tex[i].maxAnisotropy = t.maxAnisotropy;
         }
         std::vector<int> mtex = sd.materialTexture;
         mtex.resize(sd.materials.size(), -1);

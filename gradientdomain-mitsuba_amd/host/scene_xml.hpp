@@ -447,8 +447,8 @@ private:
     }
 
     // ---- `<texture type="bitmap">` (src/textures/bitmap.cpp) ------------------------------------------------------------------------
-    // Carried: filterType nearest | bilinear (the two whose lookups do not depend on ray differentials: level 0 of the MIP map,
-    // bitmap.cpp:431-452, mipmap.h:628-633), wrapMode / wrapModeU / wrapModeV, gamma, uscale / vscale / uoffset / voffset (Texture2D,
+    // Carried: filterType ewa (the default) | trilinear | bilinear | nearest with maxAnisotropy (the library builds the MIP pyramid and
+    // filters the lookups at camera-ray hits), wrapMode / wrapModeU / wrapModeV, gamma, uscale / vscale / uoffset / voffset (Texture2D,
     // texture.cpp:27-45).  Files: PFM and uncompressed OpenEXR (linear floats), binary PPM and 8-bit PNG (sRGB unless `gamma` says otherwise),
     // converted to Float as Bitmap::convert does (fmtconv.cpp:1137-1160: value/255 with the float reciprocal, then the sRGB curve).
     int texture(const xml::Node &n, SceneData &sd)
@@ -470,14 +470,14 @@ private:
             else if (c->tag == "float" && nm == "vscale") t.vscale = std::stod(v);
             else if (c->tag == "float" && nm == "uoffset") t.uoffset = std::stod(v);
             else if (c->tag == "float" && nm == "voffset") t.voffset = std::stod(v);
-            else if (c->tag == "float" && nm == "maxAnisotropy") {}                        // only EWA reads it
+            else if (c->tag == "float" && nm == "maxAnisotropy") t.maxAnisotropy = std::stod(v);     // bitmap.cpp:232
             else if (c->tag == "boolean" && nm == "cache") {}                              // the MIP-map cache file: nothing to cache here
             else logError(format("texture \"bitmap\": <%s name=\"%s\"> is not carried", c->tag.c_str(), nm.c_str()));
         }
         if (filterType == "nearest") t.filter = GDPT_TEXFILTER_NEAREST;
         else if (filterType == "bilinear") t.filter = GDPT_TEXFILTER_BILINEAR;
-        else if (filterType == "ewa" || filterType == "trilinear")
-            logError(format("texture \"bitmap\": filterType \"%s\" reads the MIP pyramid through ray differentials, which this build does not carry; set filterType to \"bilinear\" or \"nearest\" (the reference's default is \"ewa\")", filterType.c_str()));
+        else if (filterType == "trilinear") t.filter = GDPT_TEXFILTER_TRILINEAR;
+        else if (filterType == "ewa") t.filter = GDPT_TEXFILTER_EWA;
         else logError(format("Invalid filter type '%s' -- must be 'ewa', 'trilinear', or 'nearest'!", filterType.c_str()));      // bitmap.cpp:229-230
         auto wrapOf = [&](const std::string &w) {
             if (w == "repeat") return GDPT_TEXWRAP_REPEAT;

@@ -173,6 +173,38 @@ def reconstruct(dx, dy, tp, direct, width, height, preset="L1D", alpha=0.2):
     return rec
 
 
+def gbdpt_prepare_data(w, data, data2=None, offset=0):
+    """GBDPTIntegrator::prepareDataForSolver (gbdpt.cpp:264-280): the developed double buffer `data` (3*w*h) scaled into the solver's
+    fp32 input; with `data2` the entries that have a partner at i + 3*offset are merged with the partner's negated gradient."""
+    data = np.ascontiguousarray(data, np.float64).ravel()
+    out = np.zeros(data.size, np.float32)
+    d2 = None
+    if data2 is not None:
+        d2 = np.ascontiguousarray(data2, np.float64).ravel()
+        if d2.size != data.size:
+            raise ValueError("gbdpt_prepare_data: data2 must have the length of data")
+    check(lib().gdpt_gbdpt_prepare_data(C.c_float(w), out.ctypes.data_as(_fp), data.ctypes.data_as(C.POINTER(C.c_double)), data.size,
+                                        None if d2 is None else d2.ctypes.data_as(C.POINTER(C.c_double)), int(offset)))
+    return out
+
+
+def gbdpt_reconstruct(primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y, width, height, alpha=0.2, device=-1, l2=True, l1=True):
+    """The second half of GBDPTIntegrator::render (gbdpt.cpp:178-247) on the device: the three prepareDataForSolver calls, then the
+    L2D and the L1D solve without a direct image.  Buffers in the order of the integrator's MultiFilm ("-primal", "-gradientNegY",
+    "-gradientNegX", "-gradientPosX", "-gradientPosY"), developed doubles of 3*width*height each.  -> (L2 image, L1 image) as fp32."""
+    n3 = 3 * width * height
+    bufs = [np.ascontiguousarray(b, np.float64).ravel() for b in (primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y)]
+    for b in bufs:
+        if b.size != n3:
+            raise ValueError("gbdpt_reconstruct: every buffer holds 3*width*height values")
+    r2 = np.zeros(n3, np.float32) if l2 else None
+    r1 = np.zeros(n3, np.float32) if l1 else None
+    dp = C.POINTER(C.c_double)
+    check(lib().gdpt_gbdpt_reconstruct(*[b.ctypes.data_as(dp) for b in bufs], width, height, C.c_float(alpha), device,
+                                       None if r2 is None else r2.ctypes.data_as(_fp), None if r1 is None else r1.ctypes.data_as(_fp)))
+    return r2, r1
+
+
 class Backend:
     """poisson::Backend virtuals (Backend.hpp:66-100) on device vectors (reference layouts).  Vectors are
     plain device addresses (ints); `upload`/`download` play Backend::write/read."""

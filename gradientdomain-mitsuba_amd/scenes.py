@@ -16,7 +16,7 @@ DISTR_BECKMANN, DISTR_GGX, DISTR_PHONG = 0, 1, 2
 # reconstruction filters (src/rfilters): (kind, p0, p1) with the reference's default parameters
 RFILTER_BOX, RFILTER_TENT, RFILTER_GAUSSIAN, RFILTER_MITCHELL, RFILTER_CATMULLROM, RFILTER_LANCZOS = range(6)
 TEXWRAP_REPEAT, TEXWRAP_CLAMP, TEXWRAP_MIRROR, TEXWRAP_ZERO, TEXWRAP_ONE = range(5)      # bitmap.cpp:324-338
-TEXFILTER_NEAREST, TEXFILTER_BILINEAR = 0, 1
+TEXFILTER_NEAREST, TEXFILTER_BILINEAR, TEXFILTER_TRILINEAR, TEXFILTER_EWA = 0, 1, 2, 3
 RFILTER_DEFAULTS = {0: (0, 0.0, 0.0), 1: (1, 0.0, 0.0), 2: (2, 0.5, 0.0), 3: (3, 1.0 / 3.0, 1.0 / 3.0), 4: (4, 0.0, 0.0), 5: (5, 3.0, 0.0)}
 
 
@@ -294,14 +294,15 @@ def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):
                     width=width, height=height, name="atrium")
 
 
-def bitmap_texture(rgb, wrap=TEXWRAP_REPEAT, filter=TEXFILTER_BILINEAR, uscale=1.0, vscale=1.0, uoffset=0.0, voffset=0.0, wrapV=None, conserve=True):
-    """`<texture type="bitmap">` with filterType nearest | bilinear (reference src/textures/bitmap.cpp).  rgb: [h, w, 3] LINEAR values,
+def bitmap_texture(rgb, wrap=TEXWRAP_REPEAT, filter=TEXFILTER_BILINEAR, uscale=1.0, vscale=1.0, uoffset=0.0, voffset=0.0, wrapV=None, conserve=True, maxAnisotropy=20.0):
+    """`<texture type="bitmap">` with filterType nearest | bilinear | trilinear | ewa (reference src/textures/bitmap.cpp; ewa is its default).  rgb: [h, w, 3] LINEAR values,
     top row first.  conserve: BSDF::ensureEnergyConservation (src/librender/bsdf.cpp) -- a reflectance texture whose maximum exceeds 1
     is scaled by 0.99 / max."""
     rgb = np.ascontiguousarray(rgb, np.float64)
     mx = float(rgb.max())
     scale = float(np.float32(0.99)) * (1.0 / mx) if (conserve and mx > 1.0) else 1.0      # bsdf.cpp:96: 0.99f * (max / actualMax)
-    return dict(rgb=rgb, wrapU=wrap, wrapV=wrap if wrapV is None else wrapV, filter=filter, uscale=uscale, vscale=vscale, uoffset=uoffset, voffset=voffset, scale=scale)
+    return dict(rgb=rgb, wrapU=wrap, wrapV=wrap if wrapV is None else wrapV, filter=filter, uscale=uscale, vscale=vscale, uoffset=uoffset, voffset=voffset, scale=scale,
+                maxAnisotropy=float(maxAnisotropy))
 
 
 def checker_rgb(w=16, h=12, seed=3):
@@ -312,7 +313,7 @@ def checker_rgb(w=16, h=12, seed=3):
     return np.clip(base + 0.15 * rng.random((h, w, 3)), 0.0, 1.0)
 
 
-def textured_cornell_box(width=64, height=48, filter=TEXFILTER_BILINEAR, wrap=TEXWRAP_REPEAT, seed=0):
+def textured_cornell_box(width=64, height=48, filter=TEXFILTER_BILINEAR, wrap=TEXWRAP_REPEAT, seed=0, uvscale=1.0, maxAnisotropy=20.0, size=(16, 12)):
     """The Cornell box with bitmap textures: the floor (texture coordinates tiled 3 x 2.5 over it, so the wrap mode shows), the back wall
     (a mesh WITHOUT texture coordinates: its.uv = the barycentrics) and a rough-copper short block whose specularReflectance is textured."""
     sc = cornell_box(width, height, "diffuse")
@@ -336,8 +337,9 @@ def textured_cornell_box(width=64, height=48, filter=TEXFILTER_BILINEAR, wrap=TE
             uvs[t, 2 * j + 1] = v[t, j, 2] / 150.0
         has[t] = 1
     sc.uvs, sc.tri_has_uv = uvs, has
-    sc.textures = [bitmap_texture(checker_rgb(16, 12, seed), wrap=wrap, filter=filter),
-                   bitmap_texture(checker_rgb(7, 5, seed + 1) * 1.3, wrap=TEXWRAP_MIRROR, filter=filter, uscale=2.0, vscale=3.0, uoffset=0.25, voffset=-0.5),
+    sc.textures = [bitmap_texture(checker_rgb(size[0], size[1], seed), wrap=wrap, filter=filter, uscale=uvscale, vscale=uvscale, maxAnisotropy=maxAnisotropy),
+                   bitmap_texture(checker_rgb(7, 5, seed + 1) * 1.3, wrap=TEXWRAP_MIRROR, filter=filter, uscale=2.0 * uvscale, vscale=3.0 * uvscale, uoffset=0.25, voffset=-0.5,
+                                  maxAnisotropy=maxAnisotropy),
                    bitmap_texture(checker_rgb(9, 9, seed + 2), wrap=TEXWRAP_CLAMP, wrapV=TEXWRAP_ONE, filter=TEXFILTER_NEAREST)]
     mt = [-1] * len(sc.materials)
     mt[floor_m], mt[back_m], mt[block_m] = 0, 1, 2

@@ -113,6 +113,20 @@ GDPT_API int  gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, flo
  * iterations), 0 when the handle's geometry does not use it.  Clobbers the iterate like profile_kernels. */
 GDPT_API int  gdpt_poisson_profile_persistent(gdpt_poisson_solver *s, int reps, float *us);
 
+/* --- G-BDPT's reconstruction stage (BASELINE config 5; the sampler of that integrator is not part of this library) ------------------
+ * GBDPTIntegrator::prepareDataForSolver, src/integrators/gbdpt/gbdpt.cpp:264-280: out[i] = w * float(data[i]); with data2, every
+ * entry with a partner at i + 3*offset becomes 0.5 * out[i] - 0.5 * w * float(data2[i + 3*offset]) (the gradient towards +x / +y merged
+ * with the one the neighbour recorded towards -x / -y).  data, data2: developed Float (double) buffers of len = 3*w*h; HOST pointers. */
+GDPT_API int  gdpt_gbdpt_prepare_data(float w, float *out, const double *data, int len, const double *data2, int offset);
+/* the same on DEVICE pointers of the current device, enqueued on `stream` (NULL: the default stream), asynchronous */
+GDPT_API int  gdpt_gbdpt_prepare_data_device(float w, float *out, const double *data, int len, const double *data2, int offset, void *stream);
+/* The second half of GBDPTIntegrator::render, gbdpt.cpp:178-247: the three prepareDataForSolver calls (primal; +y with -y at offset
+ * `width`; +x with -x at offset 1), then Solver(L2D) and Solver(L1D) on them with no direct image, both with `alpha`.  Inputs: the five
+ * developed buffers (HOST, 3*w*h doubles each); outputs recL2 / recL1 (HOST, 3*w*h floats each; either may be NULL to skip that solve).
+ * Everything between the upload and the download stays on `device`. */
+GDPT_API int  gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
+                                     int width, int height, float alpha, int device, float *recL2, float *recL1);
+
 /* ---- (2) backend-op level ----------------------------------------------------------------- */
 /* Device-pointer forms of the `poisson::Backend` virtuals.  `stream` is a hipStream_t (NULL =
  * default stream).  Vectors use the reference layout; sizes in ELEMENTS as in Backend::Vector. */

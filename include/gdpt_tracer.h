@@ -95,23 +95,27 @@ GDPT_API int  gdpt_scene_create_ex(int numTris, const double *verts9, const doub
                                    int numEmitters, const gdpt_emitter *emitters, const gdpt_environment *env,
                                    const gdpt_camera *camera, int device, gdpt_scene **out);
 /* `<texture type="bitmap">` (src/textures/bitmap.cpp) on a material's `reflectance` (diffuse) / `specularReflectance` (conductor,
- * roughconductor, dielectric), as the G-PT path evaluates it: Texture2D::eval scales and offsets its.uv (texture.cpp:112-121) and, for
- * the filter types `nearest` and `bilinear`, both BitmapTexture::eval overloads end in MIPMap::evalBox / evalBilinear on level 0
- * (bitmap.cpp:431-452, mipmap.h:566-596,628-633) whether or not the ray carries differentials.  `ewa` (the reference's default) and
- * `trilinear` read the MIP pyramid through the primary ray's differentials and are refused (GDPT_ERR_UNSUPPORTED). */
+ * roughconductor, dielectric), as the G-PT path evaluates it: Texture2D::eval scales and offsets its.uv (texture.cpp:112-121); `nearest` and
+ * `bilinear` look level 0 up by MIPMap::evalBox / evalBilinear (bitmap.cpp:431-452, mipmap.h:566-596,628-633); `trilinear` and `ewa` (the
+ * reference's default) do the same EXCEPT at the hit of a camera ray, whose UV partials (Intersection::computePartials from the ray's
+ * differentials) select MIP levels / an elliptical footprint (mipmap.h:628-712,744-833).  The library builds the pyramid from level 0
+ * as TMIPMap does (Lanczos resampling, values clamped to [0, 1]); negative texels are clamped to 0 like there. */
 #define GDPT_TEXWRAP_REPEAT 0      /* ReconstructionFilter::ERepeat ... as bitmap.cpp:324-338 parses wrapMode */
 #define GDPT_TEXWRAP_CLAMP  1
 #define GDPT_TEXWRAP_MIRROR 2
 #define GDPT_TEXWRAP_ZERO   3      /* "zero" / "black" */
 #define GDPT_TEXWRAP_ONE    4      /* "one" / "white"  */
-#define GDPT_TEXFILTER_NEAREST  0
-#define GDPT_TEXFILTER_BILINEAR 1
+#define GDPT_TEXFILTER_NEAREST   0
+#define GDPT_TEXFILTER_BILINEAR  1
+#define GDPT_TEXFILTER_TRILINEAR 2
+#define GDPT_TEXFILTER_EWA       3   /* bitmap.cpp:213 default */
 typedef struct gdpt_texture {
     int width, height;
     const double *rgb;              /* height x width x 3 LINEAR values, top row first (what the MIP map's level 0 holds: the file converted to Float) */
     int wrapU, wrapV, filter;
     double uscale, vscale, uoffset, voffset;   /* Texture2D: `uscale`, `vscale`, `uoffset`, `voffset` */
     double scale;                   /* BSDF::ensureEnergyConservation (bsdf.cpp): 0.99 / max when the texture exceeds 1, else 1; applied to the looked-up value */
+    double maxAnisotropy;           /* `maxAnisotropy` (bitmap.cpp:232, default 20): bound on the EWA ellipse's aspect ratio; used by GDPT_TEXFILTER_EWA only */
 } gdpt_texture;
 /* The same as gdpt_scene_create_ex with texture coordinates and bitmap textures.  uvs6 = 6 doubles per triangle (u0 v0 u1 v1 u2 v2), NULL = no
  * mesh has texture coordinates; triHasUV (NULL = all) marks the triangles whose mesh has them -- the others get its.uv = the hit's

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "sfmt_random.hpp"
+#include "mipmap_oracle.hpp"
 
 #define GPO_API extern "C" __attribute__((visibility("default")))
 
@@ -185,6 +186,7 @@ struct Tri {
     V3 faceNormal; // normalized cross(side1, side2)   (skdtree.h:367-371)
     Frame sh;      // shading frame: n = faceNormal, s,t from dpdu   (skdtree.h:379,396; util.cpp:603-608)
     V3 dpdu;       // its.dpdu: side1, or the UV tangent of a mesh with texture coordinates (skdtree.h:373-380, trimesh.cpp:683-735)
+    V3 dpdv;
     V3 geoN;
     bool hasNormals = false;   // per-vertex normals (TriMesh::getVertexNormals): interpolated shading normal, skdtree.h:382-394
     V3 n0, n1, n2;
@@ -223,10 +225,20 @@ struct Texture {
         const Float *t = &rgb[((size_t)y * w + x) * 3];
         return V3(t[0], t[1], t[2]);
     }
-    V3 eval(Float u_, Float v_) const
+    // filter 2 = trilinear, 3 = ewa (the reference's default): the MIP pyramid and the filtered lookup of oracle/mipmap_oracle.hpp
+    mip_oracle::MipMap mip;
+    Float maxAnisotropy = 20;
+    // Texture2D::eval(its, filter = true), texture.cpp:112-121: scaled coordinates, and scaled partials if the hit has any
+    V3 eval(Float u_, Float v_, bool hasPartials = false, Float dudx = 0, Float dudy = 0, Float dvdx = 0, Float dvdy = 0) const
     {
         const Float ux = u_ * uscale + uoffset, vy = v_ * vscale + voffset;                   // texture.cpp:113
         V3 value;
+        if (filter >= 2) {
+            Float o[3];
+            if (hasPartials) mip.eval(ux, vy, dudx * uscale, dvdx * vscale, dudy * uscale, dvdy * vscale, o);   // BitmapTexture::eval(uv, d0, d1), bitmap.cpp:486-499
+            else mip.evalBilinear(0, ux, vy, o);                                                                // BitmapTexture::eval(uv), bitmap.cpp:431-452
+            return V3(o[0], o[1], o[2]) * scale;
+        }
         if (filter == 0) value = texel(floorToInt(ux * w), floorToInt(vy * h));               // evalBox, mipmap.h:566-569
         else {
             if (!std::isfinite(ux) || !std::isfinite(vy)) return V3(0.0) * scale;             // mipmap.h:576-578
@@ -286,9 +298,11 @@ struct Distribution { // include/mitsuba/core/pmf.h
     }
 };
 
-struct Ray {
-    V3 o, d;
+struct Ray {                    // RayDifferential: a camera ray carries the directions of the rays through the pixels to the right and below
+    V3 o, d;                    // (rxOrigin = ryOrigin = o for the perspective camera, perspective.cpp:291-295); every other ray has none
     Float mint, maxt;
+    bool hasDifferentials = false;
+    V3 rxD, ryD;
     Ray() : mint(Epsilon), maxt(INF) {}
     Ray(V3 o_, V3 d_) : o(o_), d(d_), mint(Epsilon), maxt(INF) {}                       // ray.h: Ray(o, d, time)
     Ray(V3 o_, V3 d_, Float mn, Float mx) : o(o_), d(d_), mint(mn), maxt(mx) {}
@@ -301,6 +315,9 @@ struct Intersection {
     V3 p, wi;
     Frame sh;
     V3 geoN;
+    V3 dpdu, dpdv;              // skdtree.h:373-380
+    bool hasUVPartials = false; // Intersection::computePartials ran for this hit (only a camera ray can make it, intersection.cpp:11)
+    Float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
     Intersection() : t(INF), prim(-1) {}
     bool isValid() const { return t != INF; }
 };
@@ -489,6 +506,8 @@ bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its)
     its.p = tr.p0 * b.x + tr.p1 * b.y + tr.p2 * b.z;
     its.sh = tr.sh;
     its.geoN = tr.geoN;
+    its.dpdu = tr.dpdu; its.dpdv = tr.dpdv;
+    its.hasUVPartials = false;
     if (tr.hasNormals) {                                                 // skdtree.h:382-394,426
         its.sh.n = normalize(tr.n0 * b.x + tr.n1 * b.y + tr.n2 * b.z);
         if (dot(tr.faceNormal, its.sh.n) < 0) its.geoN = -tr.faceNormal; // geometric and shading normals face the same way
@@ -1157,6 +1176,13 @@ void sampleRay(const Scene &sc, Float px, Float py, Ray &ray)
     const double *M = c.toWorld;
     ray.o = V3(M[3], M[7], M[11]);
     ray.d = V3(M[0] * d.x + M[1] * d.y + M[2] * d.z, M[4] * d.x + M[5] * d.y + M[6] * d.z, M[8] * d.x + M[9] * d.y + M[10] * d.z);
+    // rxDirection / ryDirection = trafo(normalize(nearP + m_dx / m_dy)), perspective.cpp:293-294; m_dx = sampleToCamera(1/width, 0, 0) -
+    // sampleToCamera(0), m_dy likewise (:160-163), with the same written-out composite
+    const V3 mdx(-2 * (1.0 / c.width) * c.nearClip * sc.tanHalf, 0.0, 0.0), mdy(0.0, -2 * (1.0 / c.height) / sc.aspect * c.nearClip * sc.tanHalf, 0.0);
+    const V3 dx = normalize(nearP + mdx), dy = normalize(nearP + mdy);
+    ray.rxD = V3(M[0] * dx.x + M[1] * dx.y + M[2] * dx.z, M[4] * dx.x + M[5] * dx.y + M[6] * dx.z, M[8] * dx.x + M[9] * dx.y + M[10] * dx.z);
+    ray.ryD = V3(M[0] * dy.x + M[1] * dy.y + M[2] * dy.z, M[4] * dy.x + M[5] * dy.y + M[6] * dy.z, M[8] * dy.x + M[9] * dy.y + M[10] * dy.z);
+    ray.hasDifferentials = true;
 }
 
 // ================================================================================================================
@@ -1256,12 +1282,50 @@ ReconnectionShiftResult reconnectShift(const Scene &sc, V3 mainSourceVertex, V3 
 
 // its.getBSDF(): the material of the hit, with a textured reflectance resolved at its.uv (diffuse.cpp:107,116,137,149: m_reflectance->eval(its);
 // likewise specularReflectance of the conductors and the dielectric)
-inline gpo_material matOf(const Scene &sc, const Intersection &its)
+// Intersection::computePartials, intersection.cpp:5-78: the texture coordinates' partials with respect to a one-pixel step on the screen
+inline void computePartials(Intersection &its, const Ray &ray)
+{
+    if (its.hasUVPartials || !ray.hasDifferentials) return;
+    its.hasUVPartials = true;
+    if (isZero(its.dpdu) && isZero(its.dpdv)) { its.dudx = its.dvdx = its.dudy = its.dvdy = 0.0; return; }
+    const V3 n = its.geoN;                                                               // geoFrame.n
+    const Float pp = dot(n, its.p), pox = dot(n, ray.o), poy = dot(n, ray.o), prx = dot(n, ray.rxD), pry = dot(n, ray.ryD);
+    if (prx == 0 || pry == 0) { its.dudx = its.dvdx = its.dudy = its.dvdy = 0.0; return; }
+    const Float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    const Float absX = std::abs(n.x), absY = std::abs(n.y), absZ = std::abs(n.z);
+    int axes[2];
+    if (absX > absY && absX > absZ) { axes[0] = 1; axes[1] = 2; }
+    else if (absY > absZ) { axes[0] = 0; axes[1] = 2; }
+    else { axes[0] = 0; axes[1] = 1; }
+    auto comp = [](const V3 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+    const Float A[2][2] = {{comp(its.dpdu, axes[0]), comp(its.dpdv, axes[0])}, {comp(its.dpdu, axes[1]), comp(its.dpdv, axes[1])}};
+    const V3 px = ray.o + ray.rxD * tx, py = ray.o + ray.ryD * ty;
+    const Float Bx[2] = {comp(px, axes[0]) - comp(its.p, axes[0]), comp(px, axes[1]) - comp(its.p, axes[1])};
+    const Float By[2] = {comp(py, axes[0]) - comp(its.p, axes[0]), comp(py, axes[1]) - comp(its.p, axes[1])};
+    const Float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];                             // solveLinearSystem2x2, util.cpp:527-539
+    if (std::abs(det) <= RCPOVERFLOW) {
+        its.dudx = 1; its.dvdx = 0;
+        its.dudy = 1; its.dvdy = 0;                                                      // (:74-76 writes `dudy = 0; dudy = 1;` and leaves dvdy as it was: taken as 0 here)
+        return;
+    }
+    const Float inverse = 1.0 / det;
+    its.dudx = (A[1][1] * Bx[0] - A[0][1] * Bx[1]) * inverse; its.dvdx = (A[0][0] * Bx[1] - A[1][0] * Bx[0]) * inverse;
+    its.dudy = (A[1][1] * By[0] - A[0][1] * By[1]) * inverse; its.dvdy = (A[0][0] * By[1] - A[1][0] * By[0]) * inverse;
+}
+
+// its.getBSDF(ray): the material of the hit, with a textured reflectance resolved at its.uv (diffuse.cpp:107,116,137,149: m_reflectance->eval(its);
+// likewise specularReflectance of the conductors and the dielectric).  A BSDF with a bitmap texture usesRayDifferentials(), so the hit of
+// a camera ray gets its UV partials first (shape.h getBSDF(ray)) and Texture2D::eval(its) passes them to the MIP map (texture.cpp:112-121).
+inline gpo_material matOf(const Scene &sc, Intersection &its, const Ray &ray)
 {
     const int mi = sc.tris[its.prim].material;
     gpo_material m = sc.mats[mi];
     const int ti = mi < (int)sc.matTexture.size() ? sc.matTexture[mi] : -1;
-    if (ti >= 0) { const V3 r = sc.textures[ti].eval(its.u, its.v); m.reflectance[0] = r.x; m.reflectance[1] = r.y; m.reflectance[2] = r.z; }
+    if (ti >= 0) {
+        computePartials(its, ray);
+        const V3 r = sc.textures[ti].eval(its.u, its.v, its.hasUVPartials, its.dudx, its.dudy, its.dvdx, its.dvdy);
+        m.reflectance[0] = r.x; m.reflectance[1] = r.y; m.reflectance[2] = r.z;
+    }
     return m;
 }
 
@@ -1295,7 +1359,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
             }
         }
         const bool lastSegment = (depth + 1 == cfg.maxDepth);                              // :559
-        const gpo_material &mainBSDF = matOf(sc, main.its);
+        const gpo_material &mainBSDF = matOf(sc, main.its, main.ray);
 
         // ---- direct illumination sampling, :565-730 (minDepth is forced to 1, gpt.cpp:1369) ----
         if (bsdfType(mainBSDF) & ESmooth) {
@@ -1338,7 +1402,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                             mainContribution = main.throughput * (mainBSDFValue * mainEmitterRadiance);
                             shiftedContribution = jacobian * shifted.throughput * (shiftedBsdfValue * mainEmitterRadiance);
                         } else {                                                           // :659-705
-                            const gpo_material &shiftedBSDF = matOf(sc, shifted.its);
+                            const gpo_material &shiftedBSDF = matOf(sc, shifted.its, shifted.ray);
                             VertexType mainVertexType = getVertexType(mainBSDF, cfg, ESmooth);
                             VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, ESmooth);
                             const bool mainAtPointLight = (dRec.measure == MEASURE_DISCRETE);                        // :667
@@ -1407,7 +1471,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                 mainDRec.object = sc.tris[main.its.prim].emitter;
                 mainHitEmitter = true;
             }
-            mainNextVertexType = getVertexType(matOf(sc, main.its), cfg, mainBsdfResult.sampledType); // :785
+            mainNextVertexType = getVertexType(matOf(sc, main.its, main.ray), cfg, mainBsdfResult.sampledType); // :785
         } else {                                                                           // :786-804
             if (sc.envIndex < 0) break;
             mainEmitterRadiance = sc.emitters[sc.envIndex].radiance;                       // evalEnvironment
@@ -1454,7 +1518,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                     mainContribution = main.throughput * mainEmitterRadiance;
                     shiftedContribution = shifted.throughput * mainEmitterRadiance;
                 } else {                                                                   // :889-1126
-                    const gpo_material &shiftedBSDF = matOf(sc, shifted.its);
+                    const gpo_material &shiftedBSDF = matOf(sc, shifted.its, shifted.ray);
                     VertexType shiftedVertexType = getVertexType(shiftedBSDF, cfg, mainBsdfResult.sampledType);
                     if (mainVertexType == VERTEX_TYPE_DIFFUSE && mainNextVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType == VERTEX_TYPE_DIFFUSE) {
                         if (!lastSegment || mainHitEmitter) {                              // :901
@@ -1524,7 +1588,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                                 goto half_vector_shift_failed;                                                             // (label name only: alive stays true)
                             }
                             if (!main.its.isValid()) { shifted.alive = false; goto half_vector_shift_failed; }             // :1078-1082
-                            VertexType shiftedNextVertexType = getVertexType(matOf(sc, shifted.its), cfg, mainBsdfResult.sampledType);
+                            VertexType shiftedNextVertexType = getVertexType(matOf(sc, shifted.its, shifted.ray), cfg, mainBsdfResult.sampledType);
                             if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType2 == VERTEX_TYPE_DIFFUSE && shiftedNextVertexType == VERTEX_TYPE_DIFFUSE) { // :1089-1093
                                 shifted.alive = false; goto half_vector_shift_failed;
                             }
@@ -1749,7 +1813,7 @@ GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *tr
         t.faceNormal = fn;
         t.geoN = fn;
         t.sh.n = fn;                                                   // no vertex normals: shFrame.n = faceNormal (skdtree.h:396)
-        t.dpdu = side1;                                                // skdtree.h:377-379 (a mesh without UV tangents)
+        t.dpdu = side1; t.dpdv = side2;                                // skdtree.h:377-379 (a mesh without UV tangents)
         t.sh.s = normalize(side1 - fn * dot(fn, side1));               // computeShadingFrame, util.cpp:603-608
         t.sh.t = cross(fn, t.sh.s);
         const V3 ps[3] = {t.p0, t.p1, t.p2};
@@ -1854,11 +1918,11 @@ GPO_API void gpo_scene_set_uvs(gpo_scene *h, const double *uv6, const unsigned c
         if (len == 0) continue;                                        // (a degenerate triangle keeps its entry as it was; it cannot be hit)
         const Float determinant = dU1x * dU2y - dU1y * dU2x;
         if (determinant == 0) {
-            V3 dpdv;
-            coordinateSystem(n / len, t.dpdu, dpdv);                   // degenerate parameterization: arbitrary tangents
+            coordinateSystem(n / len, t.dpdu, t.dpdv);                 // degenerate parameterization: arbitrary tangents
         } else {
             const Float invDet = 1.0 / determinant;
             t.dpdu = (dP1 * dU2y - dP2 * dU1y) * invDet;
+            t.dpdv = (dP1 * (-dU2x) + dP2 * dU1x) * invDet;
         }
         if (!t.hasNormals) {                                           // the flat frame is a constant of the triangle: redo it with the new dpdu
             t.sh.s = normalize(t.dpdu - t.sh.n * dot(t.sh.n, t.dpdu));
@@ -1866,13 +1930,16 @@ GPO_API void gpo_scene_set_uvs(gpo_scene *h, const double *uv6, const unsigned c
         }
     }
 }
-// Adds a bitmap texture (rgb: h x w x 3 doubles, top row first) and returns its index; params = {wrapU, wrapV, filter}, fparams = {uscale, vscale, uoffset, voffset, scale}
+// Adds a bitmap texture (rgb: h x w x 3 doubles, top row first) and returns its index; params = {wrapU, wrapV, filter}, fparams = {uscale, vscale, uoffset, voffset, scale, maxAnisotropy}
 GPO_API int gpo_scene_add_texture(gpo_scene *h, int w, int hgt, const double *rgb, const int *params, const double *fparams)
 {
     Texture t;
     t.w = w; t.h = hgt; t.wrapU = params[0]; t.wrapV = params[1]; t.filter = params[2];
     t.uscale = fparams[0]; t.vscale = fparams[1]; t.uoffset = fparams[2]; t.voffset = fparams[3]; t.scale = fparams[4];
+    t.maxAnisotropy = fparams[5];
     t.rgb.assign(rgb, rgb + (size_t)w * hgt * 3);
+    for (Float &v : t.rgb) if (v < 0) v = 0;                                                  // the MIP map clamps negative texels, mipmap.h:234-242
+    if (t.filter >= 2) t.mip.build(w, hgt, t.rgb.data(), t.wrapU, t.wrapV, t.filter, t.maxAnisotropy);
     h->sc.textures.push_back(t);
     return (int)h->sc.textures.size() - 1;
 }
@@ -1886,6 +1953,20 @@ GPO_API void gpo_texture_eval(gpo_scene *h, int texture, double u, double v, dou
 {
     const V3 r = h->sc.textures[texture].eval(u, v);
     rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
+}
+// the filtered lookup of a hit with UV partials: partials = {dudx, dudy, dvdx, dvdy}
+GPO_API void gpo_texture_eval_filtered(gpo_scene *h, int texture, double u, double v, const double *partials, double *rgb)
+{
+    const V3 r = h->sc.textures[texture].eval(u, v, true, partials[0], partials[1], partials[2], partials[3]);
+    rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
+}
+// MIP pyramid of a trilinear / ewa texture: number of levels; size and texels of one level (rgb may be NULL)
+GPO_API int gpo_texture_levels(gpo_scene *h, int texture) { return h->sc.textures[texture].mip.levels(); }
+GPO_API void gpo_texture_level(gpo_scene *h, int texture, int level, int *wh, double *rgb)
+{
+    const mip_oracle::Level &L = h->sc.textures[texture].mip.pyramid[level];
+    wh[0] = L.w; wh[1] = L.h;
+    if (rgb) std::memcpy(rgb, L.rgb.data(), sizeof(double) * L.rgb.size());
 }
 
 // `<rfilter>` of the film: kind as in Film::filterEval, p0/p1 its parameters (defaults are the caller's business)
@@ -2047,7 +2128,8 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
         if (!rayIntersect(sc, ray, its)) continue;
         V3 beta(1.0), L(0.0);
         for (int depth = 1; depth < cfg->maxDepth || cfg->maxDepth < 0; ++depth) {
-            const gpo_material &m = matOf(sc, its);
+            const Ray plain;                                       // (this checker looks textures up unfiltered)
+            const gpo_material &m = matOf(sc, its, plain);
             if (bsdfType(m) & ESmooth) {
                 DirectSamplingRecord dRec;
                 dRec.ref = its.p; dRec.refN = refNormal(m, its);

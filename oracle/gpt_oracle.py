@@ -76,6 +76,9 @@ def lib():
         L.gpo_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_scene_set_material_texture.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.gpo_texture_eval.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_texture_eval_filtered.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.gpo_texture_levels.argtypes = [C.c_void_p, C.c_int]
+        L.gpo_texture_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_last_invalid_puts.restype = C.c_ulonglong
         L.gpo_last_invalid_puts.argtypes = [C.c_void_p]
@@ -150,7 +153,7 @@ class Scene:
         for t in (getattr(desc, "textures", None) or []):
             rgb = _d(t["rgb"])
             ip = np.array([t.get("wrapU", 0), t.get("wrapV", 0), t.get("filter", 1)], np.int32)
-            fp = np.array([t.get("uscale", 1.0), t.get("vscale", 1.0), t.get("uoffset", 0.0), t.get("voffset", 0.0), t.get("scale", 1.0)], np.float64)
+            fp = np.array([t.get("uscale", 1.0), t.get("vscale", 1.0), t.get("uoffset", 0.0), t.get("voffset", 0.0), t.get("scale", 1.0), t.get("maxAnisotropy", 20.0)], np.float64)
             lib().gpo_scene_add_texture(self._h, rgb.shape[1], rgb.shape[0], _p(rgb), _p(ip), _p(fp))
         for mi, ti in enumerate(getattr(desc, "material_textures", None) or []):
             if ti >= 0:
@@ -181,6 +184,23 @@ class Scene:
     def texture_eval(self, texture, u, v):
         out = np.zeros(3, np.float64)
         lib().gpo_texture_eval(self._h, int(texture), float(u), float(v), _p(out))
+        return out
+
+    def texture_eval_filtered(self, texture, u, v, partials):
+        """The lookup of a hit with UV partials (dudx, dudy, dvdx, dvdy): trilinear / EWA over the MIP pyramid."""
+        out = np.zeros(3, np.float64)
+        lib().gpo_texture_eval_filtered(self._h, int(texture), C.c_double(u), C.c_double(v), _p(np.ascontiguousarray(partials, np.float64)), _p(out))
+        return out
+
+    def texture_pyramid(self, texture):
+        """The MIP pyramid of a trilinear / ewa texture: list of [h, w, 3] arrays, level 0 first."""
+        out = []
+        for l in range(lib().gpo_texture_levels(self._h, int(texture))):
+            wh = np.zeros(2, np.int32)
+            lib().gpo_texture_level(self._h, int(texture), l, _p(wh), None)
+            rgb = np.zeros((int(wh[1]), int(wh[0]), 3), np.float64)
+            lib().gpo_texture_level(self._h, int(texture), l, _p(wh), _p(rgb))
+            out.append(rgb)
         return out
 
     def invalid_puts(self):

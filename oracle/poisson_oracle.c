@@ -375,6 +375,26 @@ GDO_API void gdo_evaluate_metrics(const float *x, const float *dx, const float *
     free(b); free(e);
 }
 
+/* GBDPTIntegrator::prepareDataForSolver, src/integrators/gbdpt/gbdpt.cpp:264-280 (G-BDPT's reconstruction stage, BASELINE config 5):
+ * the developed Float (double) buffer scaled into the solver's fp32 input; with data2, every entry that has a partner at i + 3*offset
+ * becomes the mean of its own gradient and the negated gradient the partner recorded towards it ("merge inverse directions into one
+ * buffer").  Mixed float/double arithmetic exactly as the C++ expressions promote it. */
+GDO_API void gdo_gbdpt_prepare_data(float w, float *out, const double *data, int len, const double *data2, int offset)
+{
+    for (int i = 0; i < len; i++)
+        out[i] = w * (float)data[i];
+    if (data2 != NULL) {
+        int io;
+        for (int i = 0; i < len; i++) {
+            io = i + 3 * offset;
+            if (io >= 0 && io < len) {
+                out[i] *= 0.5;
+                out[i] -= 0.5 * w * (float)data2[io];
+            }
+        }
+    }
+}
+
 GDO_API void gdo_synth_inputs(int w, int h, unsigned seed, float *dx, float *dy, float *tp, float *direct)
 {
     const long n = (long)w * h;

@@ -53,6 +53,7 @@ def lib():
                                 C.c_int, C.c_int, _f32p, C.c_void_p]
         L.gdo_solve.restype = C.c_long
         L.gdo_evaluate_metrics.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p]
+        L.gdo_gbdpt_prepare_data.argtypes = [C.c_float, _f32p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.gdo_synth_inputs.argtypes = [C.c_int, C.c_int, C.c_uint, _f32p, _f32p, _f32p, C.c_void_p]
         _lib = L
     return _lib
@@ -163,3 +164,27 @@ def evaluate_metrics(x, dx, dy, tp, w, h, alpha):
     lib().gdo_evaluate_metrics(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(dx, np.float32), np.ascontiguousarray(dy, np.float32), tpp,
                                w, h, C.c_float(alpha), err, C.byref(l1), C.byref(l2))
     return err, float(l1.value), float(l2.value)
+
+
+def gbdpt_prepare_data(w, data, data2=None, offset=0):
+    """GBDPTIntegrator::prepareDataForSolver (gbdpt.cpp:264-280): data, data2 = developed double buffers (3*w*h), -> fp32 solver input."""
+    data = np.ascontiguousarray(data, np.float64).ravel()
+    out = np.zeros(data.size, np.float32)
+    d2 = None
+    if data2 is not None:
+        d2 = np.ascontiguousarray(data2, np.float64).ravel()
+        assert d2.size == data.size
+    lib().gdo_gbdpt_prepare_data(C.c_float(w), out, data.ctypes.data_as(C.c_void_p), data.size, None if d2 is None else d2.ctypes.data_as(C.c_void_p), offset)
+    return out
+
+
+def gbdpt_reconstruct(primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y, w, h, alpha=0.2):
+    """The second half of GBDPTIntegrator::render (gbdpt.cpp:178-247): the three prepareDataForSolver calls, then an L2D and an L1D
+    solve without a direct image -> (L2 image, L1 image), each 3*w*h fp32."""
+    imgf = gbdpt_prepare_data(1.0, primal)
+    dyf = gbdpt_prepare_data(1.0, grad_pos_y, grad_neg_y, w)
+    dxf = gbdpt_prepare_data(1.0, grad_pos_x, grad_neg_x, 1)
+    out = []
+    for name in ("L2D", "L1D"):
+        out.append(solve(preset(name, alpha), dxf, dyf, imgf, None, w, h))
+    return out[0], out[1]

@@ -713,7 +713,8 @@ def test_staged_pipeline_equals_the_single_kernel_and_the_oracle(G, name, builde
     S.close(); O.close()
 
 
-@pytest.mark.parametrize("flt,wrap", [(scenes.TEXFILTER_BILINEAR, scenes.TEXWRAP_REPEAT), (scenes.TEXFILTER_NEAREST, scenes.TEXWRAP_MIRROR), (scenes.TEXFILTER_BILINEAR, scenes.TEXWRAP_ZERO)])
+@pytest.mark.parametrize("flt,wrap", [(scenes.TEXFILTER_BILINEAR, scenes.TEXWRAP_REPEAT), (scenes.TEXFILTER_NEAREST, scenes.TEXWRAP_MIRROR), (scenes.TEXFILTER_BILINEAR, scenes.TEXWRAP_ZERO),
+                                      (scenes.TEXFILTER_EWA, scenes.TEXWRAP_REPEAT), (scenes.TEXFILTER_TRILINEAR, scenes.TEXWRAP_CLAMP)])
 def test_bitmap_textures_match_oracle(G, flt, wrap):
     """Texture coordinates in the hit record (skdtree.h:398-405) and `bitmap` textures on reflectance / specularReflectance (level-0
     nearest / bilinear lookups, wrap modes, uv scale and offset, energy-conservation scale): single samples and the film against the
@@ -788,10 +789,47 @@ def test_uv_tangents_orient_the_shading_frames(G, variant, textured):
     S.close(); O.close()
 
 
+@pytest.mark.parametrize("flt,wrap,uvscale,aniso,size", [(scenes.TEXFILTER_EWA, scenes.TEXWRAP_REPEAT, 9.0, 20.0, (37, 23)), (scenes.TEXFILTER_EWA, scenes.TEXWRAP_MIRROR, 25.0, 2.0, (64, 48)),
+                                                          (scenes.TEXFILTER_TRILINEAR, scenes.TEXWRAP_ZERO, 14.0, 20.0, (33, 65)), (scenes.TEXFILTER_EWA, scenes.TEXWRAP_ONE, 60.0, 8.0, (16, 12))])
+def test_mip_filtered_textures_match_oracle(G, flt, wrap, uvscale, aniso, size):
+    """filterType trilinear / ewa (the reference's default): the MIP pyramid (Lanczos-resampled levels, non-power-of-two sizes, every
+    wrap mode as boundary condition) and the filtered lookup at camera-ray hits -- UV partials from the ray differentials, ellipse,
+    anisotropy clamp, level selection, EWA over two levels / trilinear -- with textures fine enough that levels above 0 and
+    anisotropic footprints occur (the floor at a grazing angle).  Samples and the film against the oracle, both pipelines; and the
+    filtering must matter against the same scene with bilinear lookups."""
+    W, H, spp, md = 48, 36, 3, 5
+    sc = scenes.textured_cornell_box(W, H, filter=flt, wrap=wrap, uvscale=uvscale, maxAnisotropy=aniso, size=size)
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md)
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=md, spp=spp)
+    rng = np.random.default_rng(17)
+    for _ in range(60):
+        px, py, k = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, k), O.evaluate_point(ocfg, px, py, k)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-10, atol=1e-14), (px, py, k, key)
+    oacc, orays = O.render(ocfg)
+    for stages in (0, 2):
+        F = G.Film(S); F.set_pipeline(stages)
+        integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (stages, G.BUFFER_NAMES[b])
+        F.close()
+    plain = scenes.textured_cornell_box(W, H, filter=scenes.TEXFILTER_BILINEAR, wrap=wrap, uvscale=uvscale, size=size)
+    ref, _ = go.Scene(plain).render(ocfg)
+    assert not close(oacc[1], ref[1], 1e-4)
+    S.close(); O.close()
+
+
 def test_texture_arguments_are_checked(G):
     sc = scenes.textured_cornell_box(16, 12)
-    sc.textures[0]["filter"] = 2                                # ewa / trilinear are not carried: refused with a reason, not approximated
-    with pytest.raises(RuntimeError, match="nearest.*bilinear"):
+    sc.textures[0]["filter"] = 4
+    with pytest.raises(RuntimeError, match="Invalid filter type"):
+        G.Scene(sc)
+    sc = scenes.textured_cornell_box(16, 12, filter=scenes.TEXFILTER_EWA, maxAnisotropy=0.5)
+    with pytest.raises(RuntimeError, match="maxAnisotropy"):
         G.Scene(sc)
     sc = scenes.textured_cornell_box(16, 12)
     sc.material_textures[0] = 7

@@ -413,3 +413,68 @@ def test_textured_reflectance_reaches_the_film():
     plain2.materials[-1]["reflectance"] = (0.5, 0.5, 0.5)
     d, _ = go.Scene(plain2).render(cfg)
     assert np.allclose(b, d, rtol=1e-13, atol=1e-13) and not np.allclose(c[1], d[1])
+
+
+def test_mip_pyramid_and_filtered_lookup_known_answers():
+    """The MIP map of `trilinear` / `ewa` bitmap textures (oracle/mipmap_oracle.hpp): level sizes (non-power-of-two: (n + 1) / 2 down to
+    1x1, mipmap.h:183-190), a constant image stays constant through Lanczos resampling and through every filtered lookup, one level of
+    the resampler against the formulas of rfilter.h:122-183 written out with numpy, negative texels are clamped, lookups without
+    partials are level-0 bilinear, tiny footprints are too, and a huge footprint returns the coarsest texel."""
+    sc = scenes.textured_cornell_box(16, 12, filter=scenes.TEXFILTER_EWA, size=(37, 23))
+    img = np.asarray(sc.textures[0]["rgb"]).copy()
+    img[3, 5] = -0.5
+    sc.textures[0]["rgb"] = img
+    O = go.Scene(sc)
+    pyr = O.texture_pyramid(0)
+    assert [p.shape[:2] for p in pyr] == [(23, 37), (12, 19), (6, 10), (3, 5), (2, 3), (1, 2), (1, 1)]
+    assert pyr[0][3, 5].tolist() == [0.0, 0.0, 0.0] and all((p >= 0).all() and (p <= 1).all() for p in pyr[1:])
+    # level 1, x pass of row 0 by hand (repeat boundary): taps = ceil(2 * 2 * 37/19), weights = normalised lanczos2((start + j + .5 - centre) * 19/37)
+    src, dst = 37, 19
+    scale = src / dst; radius = 2 * scale; taps = int(np.ceil(radius * 2))
+    def lanczos2(x):
+        x = abs(x)
+        if x < 1e-7: return 1.0
+        if x > 2: return 0.0
+        return np.sin(np.pi * x) * np.sin(np.pi * x / 2) / (np.pi * x * (np.pi * x / 2))
+    xpass = np.zeros((23, dst, 3))
+    for i in range(dst):
+        centre = (i + 0.5) / dst * src
+        start = int(np.floor(centre - radius + 0.5))
+        w = np.array([lanczos2((start + j + 0.5 - centre) / scale) for j in range(taps)]); w = w / w.sum()
+        cols = [(start + j) % src for j in range(taps)]
+        xpass[:, i] = np.clip(np.einsum("j,yjc->yc", w, pyr[0][:, cols]), 0, 1)
+    src, dst = 23, 12
+    scale = src / dst; radius = 2 * scale; taps = int(np.ceil(radius * 2))
+    lvl1 = np.zeros((dst, 19, 3))
+    for i in range(dst):
+        centre = (i + 0.5) / dst * src
+        start = int(np.floor(centre - radius + 0.5))
+        w = np.array([lanczos2((start + j + 0.5 - centre) / scale) for j in range(taps)]); w = w / w.sum()
+        rows = [(start + j) % src for j in range(taps)]
+        lvl1[i] = np.clip(np.einsum("j,jxc->xc", w, xpass[rows]), 0, 1)
+    assert np.allclose(lvl1, pyr[1], rtol=0, atol=1e-14)
+    # lookups
+    b = O.texture_eval(0, 0.31, 0.62)
+    assert np.array_equal(O.texture_eval_filtered(0, 0.31, 0.62, [0, 0, 0, 0]), b)                   # no footprint -> trilinear branch -> level < 0 -> bilinear
+    assert np.array_equal(O.texture_eval_filtered(0, 0.31, 0.62, [1e-4, 0, 0, 1e-4]), b)             # footprint far below a texel
+    huge = O.texture_eval_filtered(0, 0.31, 0.62, [40.0, 0, 0, 40.0])
+    assert np.allclose(huge, pyr[-1][0, 0] * sc.textures[0]["scale"], rtol=1e-13)                    # beyond the pyramid: evalBox of the 1x1 level
+    mid = O.texture_eval_filtered(0, 0.31, 0.62, [0.2, 0.01, 0.02, 0.15])
+    assert np.isfinite(mid).all() and not np.allclose(mid, b) and not np.allclose(mid, huge)
+    const = scenes.textured_cornell_box(16, 12, filter=scenes.TEXFILTER_EWA, size=(37, 23))
+    const.textures[0]["rgb"] = np.full((23, 37, 3), 0.375)
+    C_ = go.Scene(const)
+    assert all(np.allclose(p, 0.375, rtol=0, atol=1e-15) for p in C_.texture_pyramid(0))
+    for part in ([0.2, 0.01, 0.02, 0.15], [3.0, 0, 0, 0.01], [0.01, 0, 0, 3.0], [0.05, 0.05, 0.05, 0.05]):
+        assert np.allclose(C_.texture_eval_filtered(0, 0.4, 0.7, part), 0.375, rtol=0, atol=1e-14), part
+    tri = scenes.textured_cornell_box(16, 12, filter=scenes.TEXFILTER_TRILINEAR, size=(37, 23))
+    T = go.Scene(tri)
+    lv = T.texture_pyramid(0)
+    # trilinear with an isotropic footprint of 2 texels: level = log2(2) = 1 exactly -> bilinear on level 1
+    d = 2.0 / 37
+    got = T.texture_eval_filtered(0, 0.31, 0.62, [d, 0, 0, 2.0 / 23])
+    u, v = 0.31 * 19 - 0.5, 0.62 * 12 - 0.5
+    x0, y0 = int(np.floor(u)), int(np.floor(v)); fx, fy = u - x0, v - y0
+    tx = lambda x, y: lv[1][y % 12, x % 19]
+    exp = tx(x0, y0) * (1 - fx) * (1 - fy) + tx(x0, y0 + 1) * (1 - fx) * fy + tx(x0 + 1, y0) * fx * (1 - fy) + tx(x0 + 1, y0 + 1) * fx * fy
+    assert np.allclose(got, exp * tri.textures[0]["scale"], rtol=1e-12)

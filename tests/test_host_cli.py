@@ -375,7 +375,7 @@ def write_png(path, img8):
 @pytest.mark.gpu
 def test_cli_bitmap_textures_equal_python_mirror(cli, tmp_path, gpu_required):
     """`<texture type="bitmap">` on a diffuse reflectance through the scene reader (PFM and 8-bit sRGB PNG files, OBJ `vt` coordinates with
-    flipTexCoords, filterType / wrapMode / uscale) == the Python mirror given the same texels and coordinates; `ewa` is refused with a reason."""
+    flipTexCoords, filterType / wrapMode / uscale) == the Python mirror given the same texels and coordinates; the default filterType is `ewa`."""
     import shutil
     import gradientdomain_mitsuba_amd.gpt as G
     shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
@@ -430,6 +430,15 @@ def test_cli_bitmap_textures_equal_python_mirror(cli, tmp_path, gpu_required):
         assert np.allclose(img, out[suffix], rtol=2e-6, atol=1e-7), suffix         # (pow() of the sRGB table: glibc here, numpy there)
     plain = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
     assert not np.allclose(plain["-throughput"], out["-throughput"], rtol=1e-2, atol=1e-3)
-    bad = str(tmp_path / "ewa.xml"); open(bad, "w").write(xml.replace('<string name="filterType" value="bilinear"/>', ""))
+    # without a filterType the reference's default applies: ewa (bitmap.cpp:213), with maxAnisotropy as given == the Python mirror again
+    ewa = str(tmp_path / "ewa.xml"); open(ewa, "w").write(xml.replace('<string name="filterType" value="bilinear"/>', '<float name="maxAnisotropy" value="4"/>'))
+    r = run(cli, "-o", dest + "e", "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", ewa)
+    assert r.returncode == 0, r.stderr
+    sc.textures[0] = scenes.bitmap_texture(rgb, wrap=scenes.TEXWRAP_MIRROR, filter=scenes.TEXFILTER_EWA, uscale=1.5, maxAnisotropy=4.0)
+    oute = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
+    for suffix in G.BUFFER_NAMES:
+        assert np.allclose(read_pfm(dest + "e" + suffix + ".pfm"), oute[suffix], rtol=2e-6, atol=1e-7), suffix
+    assert not np.allclose(oute["-throughput"], out["-throughput"], rtol=1e-3, atol=1e-5)
+    bad = str(tmp_path / "badf.xml"); open(bad, "w").write(xml.replace('value="bilinear"', 'value="cubic"'))
     r = run(cli, "-o", dest + "x", "-D", "width=16", "-D", "height=12", bad)
-    assert r.returncode == 1 and "ray differentials" in r.stderr and "bilinear" in r.stderr
+    assert r.returncode == 1 and "Invalid filter type" in r.stderr

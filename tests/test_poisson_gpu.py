@@ -356,3 +356,42 @@ def test_evaluate_metrics_matches_oracle(P):
     oe, oa, ob = po.evaluate_metrics(x, dx, dy, tp, w, h, 0.2)
     assert np.array_equal(e1, oe) and a1 == oa and b1 == ob and b1 < b0
     s.close()
+
+
+@pytest.mark.parametrize("w,h", [(7, 5), (64, 48), (1280, 720)])
+def test_gbdpt_prepare_data_is_bit_exact(P, w, h):
+    """GBDPTIntegrator::prepareDataForSolver (gbdpt.cpp:264-280) on the device against the oracle: every element, every promotion
+    (fp32 product, halving and subtraction through double), the offsets the integrator uses (0 / 1 / width) and odd ones."""
+    rng = np.random.default_rng(w * 131 + h)
+    n3 = 3 * w * h
+    a = rng.normal(0, 1, n3) * 10.0 ** rng.integers(-6, 4, n3); b = rng.normal(0, 1, n3) * 10.0 ** rng.integers(-6, 4, n3)
+    assert np.array_equal(P.gbdpt_prepare_data(1.0, a), po.gbdpt_prepare_data(1.0, a))
+    for wgt, off in ((1.0, w), (1.0, 1), (0.37, w), (1.0, -1), (2.5, 0), (1.0, w * h), (1.0, -w * h - 3)):
+        assert np.array_equal(P.gbdpt_prepare_data(wgt, a, b, off), po.gbdpt_prepare_data(wgt, a, b, off)), (wgt, off)
+    with pytest.raises(ValueError):
+        P.gbdpt_prepare_data(1.0, a, b[:-3], 1)
+
+
+def test_gbdpt_reconstruction_stage_1280x720_config5(P):
+    """The reconstruction stage of G-BDPT at BASELINE config 5's size (the second half of GBDPTIntegrator::render, gbdpt.cpp:178-247):
+    five developed double buffers -> merged fp32 gradients -> L2D and L1D without a direct image, against the oracle's restatement of the
+    same sequence.  The buffers are synthetic (the bidirectional sampler is not carried): a ground truth, its four directional
+    differences as the sampler's film would hold them (+x at the pixel, -x at the neighbour), noise on top."""
+    w, h = 1280, 720
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    gt = np.stack([0.5 + 0.4 * np.sin(0.02 * xx + c) * np.cos(0.015 * yy) for c in range(3)], -1)
+    px = np.zeros_like(gt); px[:, :-1] = gt[:, 1:] - gt[:, :-1]                 # gradient towards +x, stored at the pixel
+    nx = np.zeros_like(gt); nx[:, 1:] = gt[:, :-1] - gt[:, 1:]                  # gradient towards -x, stored at the pixel
+    py = np.zeros_like(gt); py[:-1] = gt[1:] - gt[:-1]
+    ny = np.zeros_like(gt); ny[1:] = gt[:-1] - gt[1:]
+    noise = lambda s: rng.normal(0, s, gt.shape)
+    bufs = [gt + noise(0.05), ny + noise(0.01), nx + noise(0.01), px + noise(0.01), py + noise(0.01)]
+    l2, l1 = P.gbdpt_reconstruct(*bufs, w, h, alpha=0.2)
+    o2, o1 = po.gbdpt_reconstruct(*bufs, w, h, alpha=0.2)
+    assert np.abs(l2 - o2).max() <= 5e-5 and np.abs(l1 - o1).max() <= 1e-3 and np.abs(l1 - o1).mean() <= 2e-5     # (the bars of the L2D / L1D full-size tests above)
+    primal = bufs[0].astype(np.float32).ravel()
+    err = lambda img: float(np.sqrt(np.mean((img - gt.ravel()) ** 2)))
+    assert err(l2) < 0.5 * err(primal) and err(l1) < 0.5 * err(primal)                # the stage does what it is for
+    only2, none1 = P.gbdpt_reconstruct(*bufs, w, h, alpha=0.2, l1=False)
+    assert none1 is None and np.array_equal(only2, l2)

@@ -196,3 +196,28 @@ def test_survey_stage_figures_reproduced():
     l1 = po.solve(po.preset("L1D"), dx, dy, tp, direct, 64, 48)
     assert ["%.9g" % v for v in l2[:3]] == ["0.501758039", "0.848977268", "0.851127267"]
     assert ["%.9g" % v for v in l1[:3]] == ["0.498723149", "0.842597842", "0.85677588"]
+
+
+def test_gbdpt_prepare_data_known_answers():
+    """GBDPTIntegrator::prepareDataForSolver (gbdpt.cpp:264-280) on a 2x2 image, by hand: out = w*float(data); entries with a partner at
+    i + 3*offset become 0.5*out - 0.5*w*float(partner) -- the last row (offset = width) / the last pixel (offset = 1, which also pairs
+    the end of a row with the start of the next, as the reference's flat index does) keep the plain value."""
+    data = np.arange(12, dtype=np.float64) + 0.25
+    d2 = 10.0 + np.arange(12, dtype=np.float64)
+    assert np.array_equal(po.gbdpt_prepare_data(2.0, data), (2.0 * data).astype(np.float32))
+    out = po.gbdpt_prepare_data(1.0, data, d2, 2)                 # +y with -y, width 2: pixels 0,1 pair with pixels 2,3
+    exp = data.astype(np.float32).copy()
+    exp[:6] = 0.5 * data[:6] - 0.5 * d2[6:]
+    assert np.array_equal(out, exp.astype(np.float32))
+    out = po.gbdpt_prepare_data(1.0, data, d2, 1)                 # +x with -x: pixel k pairs with pixel k + 1
+    exp = data.astype(np.float32).copy()
+    exp[:9] = 0.5 * data[:9] - 0.5 * d2[3:]
+    assert np.array_equal(out, exp.astype(np.float32))
+    out = po.gbdpt_prepare_data(1.0, data, d2, -1)                # a negative offset pairs with the previous pixel
+    exp = data.astype(np.float32).copy()
+    exp[3:] = 0.5 * data[3:] - 0.5 * d2[:9]
+    assert np.array_equal(out, exp.astype(np.float32))
+    # rounding: the value goes to fp32 BEFORE the halving and the subtraction runs in double and rounds once
+    x = np.array([1.0 + 2.0 ** -30] * 3 + [0.0] * 3); y = np.array([0.0] * 3 + [2.0 ** -26] * 3)
+    out = po.gbdpt_prepare_data(1.0, x, y, 1)
+    assert out[0] == np.float32(np.float64(np.float32(0.5)) - 0.5 * np.float64(np.float32(2.0 ** -26)))
