@@ -222,29 +222,48 @@ struct MipResampler {
         }
         return line[stride * pos + ch];
     }
-    void run(const double *line, size_t srcStride, double *out, size_t dstStride) const      // strides in doubles; 3 channels; clamp to [0, 1]
+    double hi = 1.0;                                                                            // upper clamp (1 for textures, infinity for the environment map)
+    void run(const double *line, size_t srcStride, double *out, size_t dstStride) const      // strides in doubles; 3 channels; clamp to [0, hi]
     {
         for (int i = 0; i < targetRes; ++i)
             for (int ch = 0; ch < 3; ++ch) {
                 double result = 0;
                 for (int j = 0; j < taps; ++j) result += lookup(line, start[i] + j, srcStride, ch) * weights[(size_t)i * taps + j];
-                out[(size_t)i * dstStride + ch] = std::min(1.0, std::max(0.0, result));
+                out[(size_t)i * dstStride + ch] = std::min(hi, std::max(0.0, result));
             }
     }
 };
-// Appends the levels below `level0` (w x h x 3) to `texels`; fills the level tables of `o`.
-void build_pyramid(std::vector<double> &texels, TexD &o)
+// half(float) -> float: the environment map's pyramid is stored in half precision (TMIPMap<Spectrum, SpectrumHalf>, envmap.cpp:101-103):
+// the double texel becomes a float, then a half (round to nearest even, gradual underflow, overflow to infinity)
+double round_to_half(double value)
+{
+    const float f = (float)value;
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = x & 0x80000000u;
+    x &= 0x7fffffffu;
+    float r;
+    if (x >= 0x7f800000u) r = f;
+    else if (x >= 0x477ff000u) { const uint32_t inf = sign | 0x7f800000u; std::memcpy(&r, &inf, 4); }
+    else if (x < 0x38800000u) { const float q = std::nearbyint(std::fabs(f) * 16777216.0f) * (1.0f / 16777216.0f); r = sign ? -q : q; }
+    else { x += 0x00000fffu + ((x >> 13) & 1u); x &= 0xffffe000u; x |= sign; std::memcpy(&r, &x, 4); }
+    return (double)r;
+}
+// Appends the levels below level 0 (w x h x 3, already in `texels`) to `texels`; fills the level tables of `o`.  Each level is resampled from the
+// previous level's unquantized values; halfStorage quantizes what is STORED (level 0 included), as the half-precision pyramid does.
+void build_pyramid(std::vector<double> &texels, TexD &o, double maxValue = 1.0, bool halfStorage = false)
 {
     o.levels = 1; o.lw[0] = o.w; o.lh[0] = o.h; o.loff[0] = 0; o.ratioX[0] = o.ratioY[0] = 1.0;
     int sw = o.w, sh = o.h;
-    size_t prev = 0;
+    std::vector<double> cur(texels.begin(), texels.end());
+    if (halfStorage) for (double &v : texels) v = round_to_half(v);
     while ((sw > 1 || sh > 1) && o.levels < TEX_MAX_LEVELS) {
         const int tw = std::max(1, (sw + 1) / 2), th = std::max(1, (sh + 1) / 2);
         std::vector<double> temp, next((size_t)tw * th * 3);
-        const double *src = &texels[prev];
+        const double *src = cur.data();
         int curW = sw;
         if (sw != tw) {
             MipResampler r(o.wrapU, sw, tw);
+            r.hi = maxValue;
             std::vector<double> &dst = (sh != th) ? temp : next;
             if (sh != th) temp.resize((size_t)tw * sh * 3);
             for (int y = 0; y < sh; ++y) r.run(src + (size_t)y * sw * 3, 3, &dst[(size_t)y * tw * 3], 3);
@@ -253,15 +272,20 @@ void build_pyramid(std::vector<double> &texels, TexD &o)
         }
         if (sh != th) {
             MipResampler r(o.wrapV, sh, th);
+            r.hi = maxValue;
             for (int x = 0; x < curW; ++x) r.run(src + (size_t)x * 3, (size_t)curW * 3, &next[(size_t)x * 3], (size_t)tw * 3);
         } else if (sw == tw) next.assign(src, src + (size_t)tw * th * 3);
         const int l = o.levels++;
         o.lw[l] = tw; o.lh[l] = th; o.loff[l] = (unsigned)(texels.size() / 3);
         o.ratioX[l] = (double)tw / (double)o.w; o.ratioY[l] = (double)th / (double)o.h;
-        prev = texels.size();
-        texels.insert(texels.end(), next.begin(), next.end());
+        for (double v : next) texels.push_back(halfStorage ? round_to_half(v) : v);
+        cur.swap(next);
         sw = tw; sh = th;
     }
+}
+void fill_ewa_lut(TexD &o)
+{ // m_weightLut, mipmap.h:297-301: exp(-2 r2) in double minus math::fastexp(-2.0f), whose FLOAT overload returns (float) exp(-2.0)
+    for (int k = 0; k < TEX_LUT_SIZE; ++k) { const double r2 = (double)k / (double)(TEX_LUT_SIZE - 1); o.lut[k] = std::exp(-2.0 * r2) - (double)(float)std::exp(-2.0); }
 }
 
 template <class T>
@@ -349,6 +373,10 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
     if (numEmitters < 0 || (numEmitters > 0 && !emitters)) return tfail(GDPT_ERR_INVALID, "scene_create: bad emitter list");
     if (numEmitters == 0 && !env) return tfail(GDPT_ERR_INVALID, "scene_create: at least one emitter (area or environment) is required");
+    if (env && env->rgb) {
+        if (env->width <= 0 || env->height <= 0) return tfail(GDPT_ERR_INVALID, "environment map: empty bitmap");
+        if (std::max(env->width, env->height) > 0xFFFF) return tfail(GDPT_ERR_INVALID, "Environment maps images must be smaller than 65536 pixels in width and height");   // envmap.cpp:161-163
+    }
     const int envIndex = env ? ((env->index < 0 || env->index > numEmitters) ? numEmitters : env->index) : -1;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return tfail(GDPT_ERR_NO_DEVICE, "no HIP device visible: the gfx950 tracer has no CPU fallback");
@@ -546,8 +574,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
             if (t.filter >= GDPT_TEXFILTER_TRILINEAR) {
                 if ((long)t.width * t.height > (1L << 28)) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_UNSUPPORTED, "texture %d: larger than 2^28 texels", i); }
                 build_pyramid(texels, o);
-                // m_weightLut, mipmap.h:297-301: exp(-2 r2) in double minus math::fastexp(-2.0f), whose FLOAT overload returns (float) exp(-2.0)
-                for (int k = 0; k < TEX_LUT_SIZE; ++k) { const double r2 = (double)k / (double)(TEX_LUT_SIZE - 1); o.lut[k] = std::exp(-2.0 * r2) - (double)(float)std::exp(-2.0); }
+                fill_ewa_lut(o);
             }
             double *dt;
             if ((rc = upload(&dt, texels))) { gdpt_scene_destroy(s); return rc; }
@@ -582,7 +609,77 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         const double dx = ctr[0] - mx[0], dy = ctr[1] - mx[1], dz = ctr[2] - mx[2];
         r2 = dx * dx + dy * dy + dz * dz;
         d.bsCenter = to_d3(h3(ctr[0], ctr[1], ctr[2]));
-        d.bsRadius = std::max((double)GD_EPSILON, std::sqrt(r2) * (double)1.5f);
+        d.bsRadius = std::max((double)GD_EPSILON, std::sqrt(r2) * (double)1.5f);       // (EnvironmentMap::createShape does the same, envmap.cpp:330-339)
+    }
+    d.envMap = nullptr; d.hasEnvMap = 0;
+    if (!(env && env->rgb)) {                  // (the pointer is never null: see SceneD::envMap)
+        EnvMapD *de;
+        const std::vector<EnvMapD> none(1, EnvMapD());
+        if ((rc = upload(&de, none))) { gdpt_scene_destroy(s); return rc; }
+        THIPCHK(hipMemset(de, 0, sizeof(EnvMapD)));
+        s->allocs.push_back(de);
+        d.envMap = de;
+    }
+    if (env && env->rgb) {
+        // EnvironmentMap (envmap.cpp:135-138,178-181,258-325): pyramid with half-precision storage, repeat / clamp, EWA with maxAnisotropy 10, no upper
+        // clamp; then the marginal and conditional cdfs over luminance x sin(theta), in float
+        EnvMapD e;
+        std::memset(&e, 0, sizeof e);
+        TexD &o = e.tex;
+        o.w = env->width; o.h = env->height; o.wrapU = GDPT_TEXWRAP_REPEAT; o.wrapV = GDPT_TEXWRAP_CLAMP; o.filter = GDPT_TEXFILTER_EWA;
+        o.uscale = o.vscale = 1.0; o.scale = 1.0; o.maxAnisotropy = 10.0;
+        std::vector<double> texels(env->rgb, env->rgb + (size_t)3 * o.w * o.h);
+        for (double &v : texels) if (v < 0) v = 0;
+        build_pyramid(texels, o, INFINITY, true);
+        fill_ewa_lut(o);
+        const int W = o.w, H = o.h;
+        std::vector<float> cdfCols((size_t)(W + 1) * H), cdfRows((size_t)H + 1);
+        std::vector<double> rowWeights(H);
+        size_t colPos = 0, rowPos = 0;
+        double rowSum = 0.0;
+        cdfRows[rowPos++] = 0;
+        for (int y = 0; y < H; ++y) {
+            double colSum = 0;
+            cdfCols[colPos++] = 0;
+            for (int x = 0; x < W; ++x) {
+                const double *t = &texels[((size_t)y * W + x) * 3];
+                colSum += t[0] * (double)0.212671f + t[1] * (double)0.715160f + t[2] * (double)0.072169f;      // Spectrum::getLuminance, spectrum.h:725-727
+                cdfCols[colPos++] = (float)colSum;
+            }
+            const float normalization = 1.0f / (float)colSum;
+            for (int x = 1; x < W; ++x) cdfCols[colPos - x - 1] *= normalization;
+            cdfCols[colPos - 1] = 1.0f;
+            const double weight = std::sin((y + 0.5) * M_PI / H);
+            rowWeights[y] = weight;
+            rowSum += colSum * weight;
+            cdfRows[rowPos++] = (float)rowSum;
+        }
+        const float normalization = 1.0f / (float)rowSum;
+        for (int y = 1; y < H; ++y) cdfRows[rowPos - y - 1] *= normalization;
+        cdfRows[rowPos - 1] = 1.0f;
+        if (rowSum == 0) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_INVALID, "The environment map is completely black -- this is not allowed."); }          // envmap.cpp:310-314
+        if (!std::isfinite(rowSum)) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_INVALID, "The environment map contains an invalid floating point value (nan/inf) -- giving up."); }
+        e.normalization = 1.0 / (rowSum * (2 * M_PI / W) * (M_PI / H));
+        e.pixelSizeX = 2 * M_PI / W; e.pixelSizeY = M_PI / H;
+        e.scale = env->scale;
+        for (int k = 0; k < 9; k++) e.toWorld[k] = env->toWorld[k];
+        {
+            const double *m = e.toWorld;
+            const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+            if (!(std::fabs(det) > 0)) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_INVALID, "environment map: singular toWorld"); }
+            const double id = 1.0 / det;
+            e.toLocal[0] = (m[4] * m[8] - m[5] * m[7]) * id; e.toLocal[1] = (m[2] * m[7] - m[1] * m[8]) * id; e.toLocal[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+            e.toLocal[3] = (m[5] * m[6] - m[3] * m[8]) * id; e.toLocal[4] = (m[0] * m[8] - m[2] * m[6]) * id; e.toLocal[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+            e.toLocal[6] = (m[3] * m[7] - m[4] * m[6]) * id; e.toLocal[7] = (m[1] * m[6] - m[0] * m[7]) * id; e.toLocal[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+        }
+        double *dt; float *dr, *dc; double *dw; EnvMapD *de;
+        if ((rc = upload(&dt, texels)) || (rc = upload(&dr, cdfRows)) || (rc = upload(&dc, cdfCols)) || (rc = upload(&dw, rowWeights))) { gdpt_scene_destroy(s); return rc; }
+        s->allocs.push_back(dt); s->allocs.push_back(dr); s->allocs.push_back(dc); s->allocs.push_back(dw);
+        o.texels = dt; e.cdfRows = dr; e.cdfCols = dc; e.rowWeights = dw;
+        const std::vector<EnvMapD> one(1, e);
+        if ((rc = upload(&de, one))) { gdpt_scene_destroy(s); return rc; }
+        s->allocs.push_back(de);
+        d.envMap = de; d.hasEnvMap = 1;
     }
     d.numMats = numMaterials;
     {
@@ -804,13 +901,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fd, stackDepth, f->contRefill); } while (0)
 #define GDPT_STAGED_F(LDSV, ACCV, WPS) do { \
         if (s->perVertex) GDPT_STAGED(LDSV, ACCV, WPS, true, true); \
-        else if (s->specialEmitters) GDPT_STAGED(LDSV, ACCV, WPS, true, false); \
+        else if (s->specialEmitters) GDPT_STAGED(LDSV, ACCV, WPS, true, ((WPS) > 2)); /* (4-wave: the per-vertex build, see below) */ \
         else GDPT_STAGED(LDSV, ACCV, WPS, false, false); } while (0)
     // builds: 2 or 4 waves/SIMD x {closed flat scenes | + environment / point emitters | + per-vertex normals (environment tested at run time)};
+    // the 4-wave builds have no environment-only variant: since the environment-map lookup was added to start_path that one build faults at
+    // address 0 from the second bounce on, even for scenes whose environment is the constant one (the code is present, never executed;
+    // -O2 the same; the per-vertex build of the same source is exact) -- DESIGN.md; such scenes run the per-vertex build
     // the features a scene does not use are compiled out of its build (they cost the closed Cornell box 5-8 % otherwise)
 #define GDPT_LAUNCH_W(LDSV, ACCV) do { \
         if (s->perVertex)           { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, true);   else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
-        else if (s->specialEmitters) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, false); } \
+        else if (s->specialEmitters) { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, true, false);  else GDPT_LAUNCH(LDSV, ACCV, 4, true, true); } \
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
         c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);
@@ -828,9 +928,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #ifndef GDPT_DEV_WPS
 #define GDPT_DEV_WPS 2
 #endif
+#ifndef GDPT_DEV_HBM_SMOOTH
+#define GDPT_DEV_HBM_SMOOTH true
+#endif
 #ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 5): one build per scene kind */
-        if (useQueue) { if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_STAGED(true, true, 2, false, false); else GDPT_STAGED(true, false, 2, false, false); } else GDPT_STAGED(false, false, 4, true, true); }
-        else if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, true);
+        if (useQueue) { if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_STAGED(true, true, 2, false, false); else GDPT_STAGED(true, false, 2, false, false); } else GDPT_STAGED(false, false, 4, true, GDPT_DEV_HBM_SMOOTH); }
+        else if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, GDPT_DEV_HBM_SMOOTH);
 #else
         if (useQueue) {
             // staged builds: {LDS scene, sums in LDS | LDS scene, sums in registers | HBM scene, sums in registers} x {flat | env | per-vertex}

@@ -120,6 +120,16 @@ struct TexD {
     Float maxAnisotropy;
     Float lut[TEX_LUT_SIZE];    // m_weightLut (Gaussian), mipmap.h:297-301
 };
+// `<emitter type="envmap">` (src/emitters/envmap.cpp): the latitude-longitude map in a MIP pyramid whose texels went through half precision
+// (TMIPMap<Spectrum, SpectrumHalf>; kept here as the doubles those halves are), repeat in u / clamp in v, EWA with maxAnisotropy 10; float
+// cdf tables over luminance x sin(theta) for light sampling (envmap.cpp:258-325).  Host-built (gpt_capi.hip).
+struct EnvMapD {
+    TexD tex;
+    const float *cdfRows, *cdfCols;         // (h + 1) and h x (w + 1)
+    const Float *rowWeights;                // sin((y + 0.5) pi / h)
+    Float normalization, scale, pixelSizeX, pixelSizeY;
+    Float toWorld[9], toLocal[9];           // linear part of the emitter's toWorld and its inverse, row-major
+};
 static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
     int firstEmTri, numTris, cdfOffset, pad;
@@ -156,6 +166,8 @@ struct SceneD {
     const TexD *tex;            // bitmap textures
     int numTex;
     int envIndex;               // position of the environment emitter in the emitter list, -1: none
+    const EnvMapD *envMap;      // never null (a zeroed record when the scene has no environment map): a load through it may be hoisted above the test of
+    int hasEnvMap;              // this flag -- the environment is an `envmap` (else `constant`: EmitterD::radiance)
     d3 bsCenter;                // its bounding sphere (ConstantBackgroundEmitter::m_sceneBSphere)
     Float bsRadius;
     CameraD cam;
@@ -801,6 +813,23 @@ __device__ __forceinline__ bool bsphere_hit(const SceneD &S, d3 ro, d3 rd, Float
     return solve_quadratic(len2(rd), 2 * dot(o, rd), len2(o) - S.bsRadius * S.bsRadius, nearT, farT);
 }
 __device__ __forceinline__ bool is_zero(d3 v) { return v.x == 0 && v.y == 0 && v.z == 0; }
+#ifndef GDPT_X_MASK
+#define GDPT_X_MASK 0
+#endif
+#define GDPT_HAS_ENVMAP_N(S, n) (!((GDPT_X_MASK >> (n)) & 1) && (S).hasEnvMap)
+// EnvironmentMap (defined after the texture lookups they use)
+__device__ d3 envmap_eval_call(const EnvMapD &e, d3 d, bool hasDifferentials, d3 rxD, d3 ryD);
+template <bool INL> __device__ __forceinline__ d3 envmap_eval(const EnvMapD &e, d3 d, bool hasDifferentials, d3 rxD, d3 ryD);
+__device__ void envmap_sample_direction(const EnvMapD &e, Float sx, Float sy, d3 &d, d3 &value, Float &pdf);
+__device__ Float envmap_pdf_direction(const EnvMapD &e, d3 dLocal);
+__device__ __forceinline__ d3 mul3(const Float *M, d3 v) { return mk(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
+// Scene::evalEnvironment(ray) for a ray WITHOUT differentials (every ray but the camera's): the constant, or the map's level 0
+template <bool INL>
+__device__ __forceinline__ d3 env_radiance(const SceneD &S, const SceneView &V, d3 d)
+{
+    if (GDPT_HAS_ENVMAP_N(S, 0)) return envmap_eval<INL>(*S.envMap, d, false, mk(0.0), mk(0.0));
+    return V.emitters[S.envIndex].radiance;
+}
 // ConstantBackgroundEmitter::fillDirectSamplingRecord, constant.cpp:245-261
 __device__ __forceinline__ bool env_fill_drec(const SceneD &S, DRec &dRec, d3 o, d3 d)
 {
@@ -816,6 +845,19 @@ __device__ __forceinline__ bool env_fill_drec(const SceneD &S, DRec &dRec, d3 o,
 // ConstantBackgroundEmitter::sampleDirect, constant.cpp:179-219
 __device__ __forceinline__ d3 env_sample_direct(const SceneD &S, d3 radiance, DRec &dRec, Float sx, Float sy)
 {
+    if (GDPT_HAS_ENVMAP_N(S, 1)) {                                       // EnvironmentMap::sampleDirect, envmap.cpp:509-534
+        d3 value, dl;
+        Float pdf, nearT, farT;
+        envmap_sample_direction(*S.envMap, sx, sy, dl, value, pdf);
+        const d3 dw = mul3(S.envMap->toWorld, dl);
+        dRec.d = dw; dRec.dist = 0.0; dRec.p = dRec.ref; dRec.n = mk(0.0);
+        if (is_zero(value) || pdf == 0 || !bsphere_hit(S, dRec.ref, dw, nearT, farT) || nearT >= 0 || farT <= 0) { dRec.pdf = 0.0; return mk(0.0); }
+        dRec.pdf = pdf;
+        dRec.p = dRec.ref + dw * farT;
+        dRec.n = normalize(S.bsCenter - dRec.p);
+        dRec.dist = farT;
+        return value / pdf;
+    }
     d3 d;
     Float pdf;
     const bool hasN = !is_zero(dRec.refN);
@@ -896,7 +938,8 @@ template <bool ENV>
 __device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, const SceneView &V, int object, d3 d, d3 refN, d3 n, Float dist)
 {
     Float pd = 0.0;
-    if (ENV && S.envIndex >= 0 && object == S.envIndex) pd = is_zero(refN) ? 1.0 / (4.0 * GD_PI) : GD_INV_PI * fmax((Float)0.0, dot(d, refN));   // constant.cpp:221-236
+    if (ENV && S.envIndex >= 0 && object == S.envIndex) pd = GDPT_HAS_ENVMAP_N(S, 2) ? envmap_pdf_direction(*S.envMap, mul3(S.envMap->toLocal, d))                 // envmap.cpp:536-547
+                                                                    : (is_zero(refN) ? 1.0 / (4.0 * GD_PI) : GD_INV_PI * fmax((Float)0.0, dot(d, refN)));   // constant.cpp:221-236
     else if (dot(d, refN) >= 0 && dot(d, n) < 0) pd = V.emitters[object].invSurfaceArea * (dist * dist) / fabs(dot(d, n));
     return pd * (1.0 * S.emitterNormalization);
 }
@@ -1010,6 +1053,9 @@ __device__ __forceinline__ bool tex_wrap(int &x, int size, int mode, Float &c)
     c = mode == 3 ? 0.0 : 1.0;
     return false;
 }
+// Real calls, and calls inside them: a kernel is charged the largest register count among its callees, and the 4-wave builds must stay at 128 --
+// the lookups are therefore cut into pieces that each fit (tex_ewa ~ the size of one footprint loop), at the price of nested calls on a cold path.
+#define GDPT_COLD_CALL __noinline__
 __device__ __forceinline__ d3 tex_texel(const TexD &t, int level, int x, int y)
 { // evalTexel, mipmap.h:503-563
     Float c = 0;
@@ -1107,7 +1153,7 @@ __device__ __forceinline__ d3 tex_filtered(const TexD &t, Float u, Float v, Floa
 }
 // Texture2D::eval(its) (texture.cpp:112-121) -> BitmapTexture::eval: level 0 by evalBox / evalBilinear (bitmap.cpp:431-452), or -- a hit with
 // UV partials under filterType trilinear / ewa -- the filtered lookup (bitmap.cpp:486-499).  partials = (dudx, dudy, dvdx, dvdy).
-__device__ __noinline__ d3 tex_eval(const TexD &t, Float u_, Float v_, bool hasPartials, Float dudx, Float dudy, Float dvdx, Float dvdy)   // a real call: textured vertices only; inlined at its six sites it cost every per-vertex build ~25 % (register pressure)
+__device__ __forceinline__ d3 tex_eval_impl(const TexD &t, Float u_, Float v_, bool hasPartials, Float dudx, Float dudy, Float dvdx, Float dvdy)   // a real call: textured vertices only; inlined at its six sites it cost every per-vertex build ~25 % (register pressure)
 {
     const Float ux = u_ * t.uscale + t.uoffset, vy = v_ * t.vscale + t.voffset;
     d3 value;
@@ -1116,19 +1162,107 @@ __device__ __noinline__ d3 tex_eval(const TexD &t, Float u_, Float v_, bool hasP
     else value = tex_filtered(t, ux, vy, dudx * t.uscale, dvdx * t.vscale, dudy * t.uscale, dvdy * t.vscale);
     return value * t.scale;
 }
-// The hit of a CAMERA ray on a textured material: Intersection::getBSDF(ray) runs computePartials first (shape.h; intersection.cpp:5-78:
-// the texture coordinates' change per pixel step, from the two differential rays of perspective.cpp:291-295 and the triangle's dpdu /
-// dpdv), and the lookup is the filtered one.  (sxp, syp) = the film position of this path's camera ray.  A real call like tex_eval.
-__device__ __noinline__ d3 tex_eval_primary(const SceneView &S, const CameraD &c, const TexD &t, const Vertex &v, d3 geoN, Float tu, Float tv, Float sxp, Float syp)
+__device__ GDPT_COLD_CALL d3 tex_eval_call(const TexD &t, Float u_, Float v_, bool hasPartials, Float dudx, Float dudy, Float dvdx, Float dvdy) { return tex_eval_impl(t, u_, v_, hasPartials, dudx, dudy, dvdx, dvdy); }
+// INL: the 4-wave builds inline the lookup (a callee with the EWA loop in it takes ~150 registers of its own accord, a kernel is charged the
+// largest count among its callees, and that would cost those builds a wave per SIMD); the 2-wave builds call it (inlined at their unrolled
+// sites it cost them 25 %)
+template <bool INL>
+__device__ __forceinline__ d3 tex_eval(const TexD &t, Float u_, Float v_, bool hasPartials, Float dudx, Float dudy, Float dvdx, Float dvdy)
 {
-    // differential directions: trafo(normalize(nearP + m_dx)), trafo(normalize(nearP + m_dy)); origins = the camera position
+    if constexpr (INL) return tex_eval_impl(t, u_, v_, hasPartials, dudx, dudy, dvdx, dvdy);
+    else return tex_eval_call(t, u_, v_, hasPartials, dudx, dudy, dvdx, dvdy);
+}
+// ---- EnvironmentMap, src/emitters/envmap.cpp ------------------------------------------------------------------------------------
+__device__ __forceinline__ Float lum3(d3 c) { return c.x * (Float)0.212671f + c.y * (Float)0.715160f + c.z * (Float)0.072169f; }   // spectrum.h:725-727
+// evalEnvironment, envmap.cpp:378-409
+__device__ __forceinline__ d3 envmap_eval_impl(const EnvMapD &e, d3 d, bool hasDifferentials, d3 rxD, d3 ryD)
+{
+    const d3 v = mul3(e.toLocal, d);
+    const Float uvx = atan2(v.x, -v.z) * GD_INV_TWOPI, uvy = acos(fmin(1.0, fmax(-1.0, v.y))) * GD_INV_PI;
+    d3 value;
+    if (!hasDifferentials) value = tex_bilinear(e.tex, 0, uvx, uvy);
+    else {
+        const d3 dvdx = mul3(e.toLocal, rxD) - v, dvdy = mul3(e.toLocal, ryD) - v;
+        const Float t1 = GD_INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -GD_INV_PI / fmax(safe_sqrt(1.0 - v.y * v.y), GD_EPSILON);
+        value = tex_filtered(e.tex, uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y);
+    }
+    return value * e.scale;
+}
+__device__ GDPT_COLD_CALL d3 envmap_eval_call(const EnvMapD &e, d3 d, bool hasDifferentials, d3 rxD, d3 ryD) { return envmap_eval_impl(e, d, hasDifferentials, rxD, ryD); }
+template <bool INL>
+__device__ __forceinline__ d3 envmap_eval(const EnvMapD &e, d3 d, bool hasDifferentials, d3 rxD, d3 ryD)
+{
+    if constexpr (INL) return envmap_eval_impl(e, d, hasDifferentials, rxD, ryD);
+    else return envmap_eval_call(e, d, hasDifferentials, rxD, ryD);
+}
+__device__ __forceinline__ int envmap_sample_reuse(const float *cdf, int size, Float &sample)
+{ // envmap.cpp:640-645: std::lower_bound over size + 1 floats for (float) sample
+    const float key = (float)sample;
+    int lo = 0, n = size + 1;
+    while (n > 0) { const int half = n >> 1; if (cdf[lo + half] < key) { lo += half + 1; n -= half + 1; } else n = half; }
+    int index = lo - 1;
+    if (index < 0) index = 0;
+    if (index > size - 1) index = size - 1;
+    sample = (sample - (Float)cdf[index]) / (Float)(cdf[index + 1] - cdf[index]);
+    return index;
+}
+__device__ __forceinline__ Float interval_to_tent(Float sample)
+{ // warp.cpp:143-155
+    Float sign;
+    if (sample < 0.5) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5); }
+    return sign * (1 - sqrt(sample));
+}
+// internalSampleDirection, envmap.cpp:556-594
+__device__ GDPT_COLD_CALL void envmap_sample_direction(const EnvMapD &e, Float sx, Float sy, d3 &d, d3 &value, Float &pdf)
+{
+    const int w = e.tex.w, h = e.tex.h;
+    const int row = envmap_sample_reuse(e.cdfRows, h, sy), col = envmap_sample_reuse(e.cdfCols + (size_t)row * (w + 1), w, sx);
+    const Float posx = (Float)col + interval_to_tent(sx), posy = (Float)row + interval_to_tent(sy);
+    const int xPos = (int)floor(posx), yPos = (int)floor(posy);
+    const Float dx1 = posx - xPos, dx2 = 1.0 - dx1, dy1 = posy - yPos, dy2 = 1.0 - dy1;
+    const d3 value1 = tex_texel(e.tex, 0, xPos, yPos) * dx2 * dy2 + tex_texel(e.tex, 0, xPos + 1, yPos) * dx1 * dy2;
+    const d3 value2 = tex_texel(e.tex, 0, xPos, yPos + 1) * dx2 * dy1 + tex_texel(e.tex, 0, xPos + 1, yPos + 1) * dx1 * dy1;
+    value = (value1 + value2) * e.scale;
+    pdf = (lum3(value1) * e.rowWeights[min(max(yPos, 0), h - 1)] + lum3(value2) * e.rowWeights[min(max(yPos + 1, 0), h - 1)]) * e.normalization;
+    const Float phi = e.pixelSizeX * (posx + 0.5), theta = e.pixelSizeY * (posy + 0.5);
+    const Float sinPhi = sin(phi), cosPhi = cos(phi), sinTheta = sin(theta), cosTheta = cos(theta);
+    d = mk(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= fmax(fabs(sinTheta), GD_EPSILON);
+}
+// internalPdfDirection, envmap.cpp:597-625
+__device__ GDPT_COLD_CALL Float envmap_pdf_direction(const EnvMapD &e, d3 d)
+{
+    const int w = e.tex.w, h = e.tex.h;
+    const Float uvx = atan2(d.x, -d.z) * GD_INV_TWOPI, uvy = acos(fmin(1.0, fmax(-1.0, d.y))) * GD_INV_PI;
+    if (!is_finite_d(uvx) || !is_finite_d(uvy)) return 0.0;
+    const Float u = uvx * w - 0.5, v = uvy * h - 0.5;
+    const int xPos = (int)floor(u), yPos = (int)floor(v);
+    const Float dx1 = u - xPos, dx2 = 1.0 - dx1, dy1 = v - yPos, dy2 = 1.0 - dy1;
+    const d3 value1 = tex_texel(e.tex, 0, xPos, yPos) * dx2 * dy2 + tex_texel(e.tex, 0, xPos + 1, yPos) * dx1 * dy2;
+    const d3 value2 = tex_texel(e.tex, 0, xPos, yPos + 1) * dx2 * dy1 + tex_texel(e.tex, 0, xPos + 1, yPos + 1) * dx1 * dy1;
+    const Float sinTheta = safe_sqrt(1 - d.y * d.y);
+    return (lum3(value1) * e.rowWeights[min(max(yPos, 0), h - 1)] + lum3(value2) * e.rowWeights[min(max(yPos + 1, 0), h - 1)]) * e.normalization / fmax(fabs(sinTheta), GD_EPSILON);
+}
+// the two differential directions of the camera ray through film position (sxp, syp): trafo(normalize(nearP + m_dx / m_dy)), perspective.cpp:291-295
+__device__ __forceinline__ void camera_differentials(const CameraD &c, Float sxp, Float syp, d3 &rxD, d3 &ryD)
+{
     const Float sxn = sxp * c.invW, syn = syp * c.invH;
     const d3 nearP = mk((1 - 2 * sxn) * c.nearClip * c.tanHalf, (1 - 2 * syn) / c.aspect * c.nearClip * c.tanHalf, c.nearClip);
     const d3 mdx = mk(-2 * c.invW * c.nearClip * c.tanHalf, 0.0, 0.0), mdy = mk(0.0, -2 * c.invH / c.aspect * c.nearClip * c.tanHalf, 0.0);
     const d3 lx = normalize(nearP + mdx), ly = normalize(nearP + mdy);
+    rxD = mk(c.m[0] * lx.x + c.m[1] * lx.y + c.m[2] * lx.z, c.m[4] * lx.x + c.m[5] * lx.y + c.m[6] * lx.z, c.m[8] * lx.x + c.m[9] * lx.y + c.m[10] * lx.z);
+    ryD = mk(c.m[0] * ly.x + c.m[1] * ly.y + c.m[2] * ly.z, c.m[4] * ly.x + c.m[5] * ly.y + c.m[6] * ly.z, c.m[8] * ly.x + c.m[9] * ly.y + c.m[10] * ly.z);
+}
+// The hit of a CAMERA ray on a textured material: Intersection::getBSDF(ray) runs computePartials first (shape.h; intersection.cpp:5-78:
+// the texture coordinates' change per pixel step, from the two differential rays of perspective.cpp:291-295 and the triangle's dpdu /
+// dpdv), and the lookup is the filtered one.  (sxp, syp) = the film position of this path's camera ray.  A real call like tex_eval.
+template <bool INL>
+__device__ __forceinline__ d3 tex_eval_primary_impl(const SceneView &S, const CameraD &c, const TexD &t, const Vertex &v, d3 geoN, Float tu, Float tv, Float sxp, Float syp)
+{
+    // differential directions (origins = the camera position)
+    d3 rxD, ryD;
+    camera_differentials(c, sxp, syp, rxD, ryD);
     const d3 o = mk(c.m[3], c.m[7], c.m[11]);
-    const d3 rxD = mk(c.m[0] * lx.x + c.m[1] * lx.y + c.m[2] * lx.z, c.m[4] * lx.x + c.m[5] * lx.y + c.m[6] * lx.z, c.m[8] * lx.x + c.m[9] * lx.y + c.m[10] * lx.z);
-    const d3 ryD = mk(c.m[0] * ly.x + c.m[1] * ly.y + c.m[2] * ly.z, c.m[4] * ly.x + c.m[5] * ly.y + c.m[6] * ly.z, c.m[8] * ly.x + c.m[9] * ly.y + c.m[10] * ly.z);
     // its.dpdu / its.dpdv: the edges, or the UV tangents of a mesh with texture coordinates (skdtree.h:373-380, trimesh.cpp:701-735)
     const TriShade &ts = S.shade[v.prim];
     const d3 dP1 = ts.p1 - ts.p0, dP2 = ts.p2 - ts.p0;
@@ -1171,12 +1305,13 @@ __device__ __noinline__ d3 tex_eval_primary(const SceneView &S, const CameraD &c
             dudy = (A11 * By0 - A01 * By1) * inverse; dvdy = (A00 * By1 - A10 * By0) * inverse;
         }
     }
-    return tex_eval(t, tu, tv, true, dudx, dudy, dvdx, dvdy);
+    return tex_eval<INL>(t, tu, tv, true, dudx, dudy, dvdx, dvdy);
 }
+__device__ GDPT_COLD_CALL d3 tex_eval_primary_call(const SceneView &S, const CameraD &c, const TexD &t, const Vertex &v, d3 geoN, Float tu, Float tv, Float sxp, Float syp) { return tex_eval_primary_impl<false>(S, c, t, v, geoN, tu, tv, sxp, syp); }
 // m_reflectance->eval(its) / m_specularReflectance->eval(its): the constant, or the bitmap at its.uv (skdtree.h:398-405: interpolated
 // texture coordinates, or the barycentrics (b1, b2) for a mesh without any).  PERVERTEX builds only; flat untextured scenes compile it out.
 // primary: v is the hit of the camera ray through film position (sxp, syp) -- the only hits that have UV partials.
-template <bool PERVERTEX>
+template <bool PERVERTEX, bool INL = false>
 __device__ __forceinline__ d3 reflectance_at(const SceneView &S, const MaterialD &m, const Vertex &v, bool primary = false, const CameraD *cam = nullptr, Float sxp = 0, Float syp = 0)
 {
     if (!PERVERTEX || m.tex < 0) return m.reflectance;
@@ -1188,8 +1323,11 @@ __device__ __forceinline__ d3 reflectance_at(const SceneView &S, const MaterialD
         tv = t.uv[1] * b0 + t.uv[3] * v.u + t.uv[5] * v.v;
     }
     const TexD &t = S.tex[m.tex];
-    if (primary && t.filter >= 2) return tex_eval_primary(S, *cam, t, v, shading_at<PERVERTEX>(S, v).geoN, tu, tv, sxp, syp);
-    return tex_eval(t, tu, tv, false, 0.0, 0.0, 0.0, 0.0);
+    if (primary && t.filter >= 2) {
+        if constexpr (INL) return tex_eval_primary_impl<true>(S, *cam, t, v, shading_at<PERVERTEX>(S, v).geoN, tu, tv, sxp, syp);
+        else return tex_eval_primary_call(S, *cam, t, v, shading_at<PERVERTEX>(S, v).geoN, tu, tv, sxp, syp);
+    }
+    return tex_eval<INL>(t, tu, tv, false, 0.0, 0.0, 0.0, 0.0);
 }
 
 // its.wi = its.toLocal(-ray.d), skdtree.h:427

@@ -128,7 +128,11 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
         }
     }
     if (L.v.prim < 0) {                                                          // :482-492
-        if (ENV && S.envIndex >= 0) A.add3(ACC_VD, L.throughput * sv.emitters[S.envIndex].radiance);   // evalEnvironment, constant.cpp:241-243
+        if (ENV && S.envIndex >= 0) {                                            // scene->evalEnvironment(main.ray): a camera ray (differentials: the map's EWA lookup, envmap.cpp:390-405)
+            d3 Le = sv.emitters[S.envIndex].radiance;                             // (constant.cpp:241-243)
+            if (GDPT_HAS_ENVMAP_N(S, 3)) { d3 rxD, ryD; camera_differentials(S.cam, L.sx, L.sy, rxD, ryD); Le = envmap_eval<!CALLS>(*S.envMap, L.rayD, true, rxD, ryD); }
+            A.add3(ACC_VD, L.throughput * Le);
+        }
         return false;
     }
     A.add3(ACC_VD, L.throughput * emitted(sv, L.v.prim, -L.rayD));                // :497-499
@@ -150,7 +154,8 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 // with them every use of an offset's own vertex and direction.  The strict-normals test of the offsets (:547-554) is dropped there
 // too: it reads the offset's LAST OWN vertex and direction, which stop changing when the offset connects, and with those very values
 // it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
-template <bool ENV, bool SMOOTH, bool CONN, bool UNROLL, class ACC>
+// INL: the cold texture / environment-map lookups are inlined (4-wave builds) or real calls (2-wave builds), see tex_eval in gpt_kernels.hip.h
+template <bool ENV, bool SMOOTH, bool CONN, bool UNROLL, bool INL, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
@@ -171,7 +176,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     }
     const bool lastSegment = (L.depth + 1 == cfg.maxDepth);                      // :559
     const MaterialD &mainBSDF = sv.mats[mts.material];
-    const d3 mainR = reflectance_at<SMOOTH>(sv, mainBSDF, L.v, L.depth == 1, &S.cam, L.sx, L.sy);                  // m_reflectance->eval(its): the constant or its bitmap texture at its.uv
+    const d3 mainR = reflectance_at<SMOOTH, INL>(sv, mainBSDF, L.v, L.depth == 1, &S.cam, L.sx, L.sy);                  // m_reflectance->eval(its): the constant or its bitmap texture at its.uv
 
     // ================= direct illumination sampling, :565-730 =================
     if (bsdfType(mainBSDF) & ESmooth) {
@@ -239,7 +244,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             } else {
                                 d3 f;
                                 Float pdfRaw;
-                                bsdf_eval_pdf(shiftedBSDF, reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i)), toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
+                                bsdf_eval_pdf(shiftedBSDF, reflectance_at<SMOOTH, INL>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i)), toLocal(sfr, -s.rayD), woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
                                 const Float shiftedBsdfPdf = (lightOnSurfaceSA && shiftedEmitterVisible) ? pdfRaw : 0;
                                 const Float jacobian = fabs(shiftedOpposingCosine * mainDistanceSquared) / (GD_EPSILON + fabs(mainOpposingCosine * shiftedDistanceSquared)); // :695
                                 const Float den = (jacobian * s.pdf) * (jacobian * s.pdf) * ((shiftedDRecPdf * shiftedDRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
@@ -293,7 +298,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     const bool mainHitEnv = ENV && mainHitEnvV;
     const TriShade &nts = sv.shade[mainHitEnv ? 0 : L.v.prim];
     const bool mainHitEmitter = mainHitEnv || nts.emitter >= 0;                   // :772-777, :793
-    const d3 mainEmitterRadiance = mainHitEnv ? sv.emitters[S.envIndex].radiance : (mainHitEmitter ? emitted(sv, L.v.prim, -L.rayD) : mk(0.0));
+    const d3 mainEmitterRadiance = mainHitEnv ? env_radiance<INL>(S, sv, L.rayD) : (mainHitEmitter ? emitted(sv, L.v.prim, -L.rayD) : mk(0.0));
     const bool mainNextVertexDiffuse = mainHitEnv ? true : vertex_is_diffuse(sv.mats[nts.material], cfg, bs.sampledType);  // :785, :799
     const Float mainBsdfPdf = bs.pdf, mainPreviousPdf = L.pdf;
     L.throughput = L.throughput * (bs.weight * bs.pdf);                          // :810-812
@@ -342,7 +347,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                 const Shading ssh = shading_at<SMOOTH>(sv, s.v);
                 const Frame3 sfr = ssh.fr;
                 const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
-                const d3 shiftedR = reflectance_at<SMOOTH>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i));   // (depth 1: still the offset's camera-ray hit)
+                const d3 shiftedR = reflectance_at<SMOOTH, INL>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i));   // (depth 1: still the offset's camera-ray hit)
                 if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
                     // ---- reconnection shift, :897-986 ----
                     if (!lastSegment || mainHitEmitter) {                        // :901
@@ -432,7 +437,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             trace<false>(sv, stack, s.v.p, outgoing, ray_mint_closest(s.v.p, GD_EPSILON), GD_INF, h);   // :1050-1052
                             if (h.prim < 0) {                                    // :1052-1074
                                 if (!ENV || S.envIndex < 0 || !mainHitEnv || (mainVertexDiffuse && shiftedVertexDiffuse)) ok = false;
-                                else { shiftedEmitterRadiance = sv.emitters[S.envIndex].radiance; envEnd = true; }
+                                else { shiftedEmitterRadiance = env_radiance<INL>(S, sv, outgoing); envEnd = true; }
                             } else if (mainHitEnv) ok = false;                    // :1078-1082: no shifts between env and non-env
                             else {
                                 s.rayD = outgoing;
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
             if (!active) { paths++; pathLen += L.depth; if (STAGED || F.qRec) q_finish(F, slot, A); else pending = true; }
         }
         if (active) {
-            if (!bounce<ENV, SMOOTH, false, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD)>(S, sv, cfg, stack, L, A)) {
+            if (!bounce<ENV, SMOOTH, false, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, stack, L, A)) {
                 active = false;
                 paths++; pathLen += L.depth;
                 // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
             }
         }
         if (__ballot(active) == 0) { if (exhausted) break; continue; }
-        if (active && !bounce<ENV, SMOOTH, true, true>(S, sv, cfg, stack, L, A)) {
+        if (active && !bounce<ENV, SMOOTH, true, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, stack, L, A)) {
             active = false;
             paths++; pathLen += L.depth;
             q_finish(F, slot, A);
@@ -1061,7 +1066,7 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
     bool active = start_path<true, true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
-    while (active) active = bounce<true, true, false, false>(S, sv, cfg, s_stack, L, A);
+    while (active) active = bounce<true, true, false, false, false>(S, sv, cfg, s_stack, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];

@@ -33,7 +33,7 @@ class Emitter(C.Structure):
 
 
 class Environment(C.Structure):
-    _fields_ = [("radiance", C.c_double * 3), ("index", C.c_int)]
+    _fields_ = [("radiance", C.c_double * 3), ("index", C.c_int), ("rgb", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("scale", C.c_double), ("toWorld", C.c_double * 9)]
 
 
 class Camera(C.Structure):
@@ -83,6 +83,15 @@ class Scene:
         env = None
         if envd is not None:                                 # `<emitter type="constant">`: (radiance rgb, position in the emitter list)
             env = Environment((C.c_double * 3)(*envd[0]), int(envd[1]))
+        emap = getattr(desc, "environment_map", None)
+        self._envmap_keep = None
+        if emap is not None:                                 # `<emitter type="envmap">`: dict(rgb [h, w, 3] linear, scale, toWorld 3x3, index)
+            if env is not None:
+                raise ValueError("a scene has one environment emitter: `environment` or `environment_map`")
+            rgb = np.ascontiguousarray(emap["rgb"], dtype=np.float64)
+            self._envmap_keep = rgb
+            env = Environment((C.c_double * 3)(0.0, 0.0, 0.0), int(emap.get("index", -1)), rgb.ctypes.data_as(C.c_void_p), rgb.shape[1], rgb.shape[0],
+                              float(emap.get("scale", 1.0)), (C.c_double * 9)(*np.asarray(emap.get("toWorld", np.eye(3)), np.float64).reshape(9)))
         nrm = getattr(desc, "normals", None)
         nrm = np.ascontiguousarray(nrm, dtype=np.float64) if nrm is not None else None
         # texture coordinates and bitmap textures (scenes.Scene.uvs / tri_has_uv / textures / material_textures)

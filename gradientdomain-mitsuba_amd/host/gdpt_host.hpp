@@ -169,7 +169,8 @@ struct SceneData {
     std::vector<int> materialTexture;       // per material: its reflectance / specularReflectance texture, -1 = constant (shorter than materials = -1)
     std::vector<gdpt_material> materials;
     std::vector<gdpt_emitter> emitters;
-    bool hasEnvironment = false;            // <emitter type="constant">
+    bool hasEnvironment = false;            // <emitter type="constant"> or <emitter type="envmap">
+    std::vector<double> envmapRgb;          // envmap: height x width x 3 linear values (environment.width / height), else empty
     gdpt_environment environment = {{0, 0, 0}, -1};
     gdpt_camera camera;
     Properties integrator, film, sampler, rfilter;
@@ -505,12 +506,14 @@ public:
             tex[i].width = t.width; tex[i].height = t.height; tex[i].rgb = t.rgb.data(); tex[i].wrapU = t.wrapU; tex[i].wrapV = t.wrapV; tex[i].filter = t.filter;
             tex[i].uscale = t.uscale; tex[i].vscale = t.vscale; tex[i].uoffset = t.uoffset; tex[i].voffset = t.voffset; tex[i].scale = t.scale; tex[i].maxAnisotropy = t.maxAnisotropy;
         }
+        gdpt_environment envCopy = sd.environment;
+        envCopy.rgb = sd.envmapRgb.empty() ? nullptr : sd.envmapRgb.data();
         std::vector<int> mtex = sd.materialTexture;
         mtex.resize(sd.materials.size(), -1);
         check(gdpt_scene_create_tex(sd.numTriangles(), sd.verts.data(), normals.empty() ? nullptr : normals.data(), uvs.empty() ? nullptr : uvs.data(),
                                     uvs.empty() ? nullptr : has.data(), sd.triMaterial.data(), (int)sd.materials.size(), sd.materials.data(),
                                     tex.empty() ? nullptr : mtex.data(), (int)tex.size(), tex.empty() ? nullptr : tex.data(),
-                                    (int)sd.emitters.size(), sd.emitters.data(), sd.hasEnvironment ? &sd.environment : nullptr, &sd.camera, device, scene));
+                                    (int)sd.emitters.size(), sd.emitters.data(), sd.hasEnvironment ? &envCopy : nullptr, &sd.camera, device, scene));
     }
 
 private:

@@ -98,6 +98,7 @@ public:
 		}
 		/* point and constant emitters, in the scene's emitter order (scene.cpp:855-862 selects by it) */
 		gdpt_environment env; bool haveEnv = false;
+		memset(&env, 0, sizeof env);
 		const ref_vector<Emitter> &emitters = scene->getEmitters();
 		for (size_t i = 0; i < emitters.size(); ++i) {
 			const Emitter *em = emitters[i].get();

@@ -5,7 +5,7 @@
 // (fov, fovAxis x|y, nearClip, farClip, toWorld), <sampler type="independent">, <film type="multifilm"> (width, height,
 // fileFormat="openexr"|"pfm") with <rfilter type="box|tent|gaussian|mitchell|catmullrom|lanczos"> (gaussian when absent, film.cpp:93), <bsdf type="diffuse|conductor|roughconductor|dielectric|twosided"> (top-level with id, or nested in a
 // shape), <shape type="obj|serialized|rectangle|cube"> (filename, toWorld, flipNormals, <ref>, nested <bsdf>, nested <emitter type="area">),
-// top-level <emitter type="constant"> (radiance) and <emitter type="point"> (position | toWorld, intensity),
+// top-level <emitter type="constant"> (radiance), <emitter type="envmap"> (filename, scale, gamma, toWorld) and <emitter type="point"> (position | toWorld, intensity),
 // <transform> built from translate / rotate / scale / lookat / matrix, <integer|float|boolean|string|rgb|spectrum>.
 // Anything else raises std::runtime_error naming the tag or plugin, like the reference's "unsupported" errors.
 #pragma once
@@ -215,7 +215,32 @@ public:
                     sd.emitters.push_back(e);
                     continue;
                 }
-                if (subst(n.get("type")) != "constant") logError(format("top-level emitter \"%s\" is not carried: `constant`, `point` (and `area` on shapes)", n.get("type").c_str()));
+                if (subst(n.get("type")) == "envmap") {                          // src/emitters/envmap.cpp: filename, scale, gamma, toWorld
+                    if (sd.hasEnvironment) logError("Only one environment emitter can be used at a time!");
+                    std::string filename;
+                    double scale = 1.0, gamma = 0.0;
+                    Mat4 T = Mat4::identity();
+                    for (auto &ec : n.children) {
+                        const std::string nm = ec->get("name", ""), v = subst(ec->get("value", ""));
+                        if (ec->tag == "string" && nm == "filename") filename = v;
+                        else if (ec->tag == "float" && nm == "scale") scale = std::stod(v);
+                        else if (ec->tag == "float" && nm == "gamma") gamma = std::stod(v);
+                        else if (ec->tag == "transform" && nm == "toWorld") T = transform(*ec);
+                        else if (ec->tag == "boolean" && nm == "cache") {}
+                        else if (ec->tag == "float" && nm == "samplingWeight") { if (std::stod(v) != 1.0) logError("emitter \"envmap\": samplingWeight other than 1 is not carried"); }
+                        else logError(format("emitter \"envmap\": <%s name=\"%s\"> is not carried", ec->tag.c_str(), nm.c_str()));
+                    }
+                    if (filename.empty()) logError("emitter \"envmap\": missing filename");
+                    SceneData::Texture img;
+                    loadImage(filename[0] == '/' ? filename : m_dir + "/" + filename, gamma, img);
+                    sd.envmapRgb = img.rgb;
+                    sd.hasEnvironment = true;
+                    sd.environment.width = img.width; sd.environment.height = img.height; sd.environment.scale = scale;
+                    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sd.environment.toWorld[3 * r + c] = T.m[4 * r + c];
+                    sd.environment.index = (int)sd.emitters.size();
+                    continue;
+                }
+                if (subst(n.get("type")) != "constant") logError(format("top-level emitter \"%s\" is not carried: `constant`, `envmap`, `point` (and `area` on shapes)", n.get("type").c_str()));
                 if (sd.hasEnvironment) logError("Only one environment emitter can be used at a time!");          // scene.cpp: addChild
                 double radiance[3] = {1.0, 1.0, 1.0};                            // constant.cpp:44: default radiance = D65 white
                 for (auto &ec : n.children) {

@@ -82,6 +82,7 @@ class Scene:
     normals: np.ndarray = None   # (ntri, 9) per-vertex normals (TriMesh vertex normals), all-zero rows = flat triangle; or None
     uvs: np.ndarray = None       # (ntri, 6) per-vertex texture coordinates u0 v0 u1 v1 u2 v2; or None (its.uv = the hit's barycentrics)
     tri_has_uv: np.ndarray = None   # (ntri,) 1 = the triangle's mesh has texture coordinates (None = all, when uvs is given)
+    environment_map: dict = None  # `<emitter type="envmap">`: dict(rgb [h, w, 3] linear latitude-longitude map (top row = up), scale, toWorld 3x3, index); excludes `environment`
     textures: list = None        # bitmap textures: dicts with rgb [h, w, 3] (linear), wrapU/wrapV (TEXWRAP_*), filter (TEXFILTER_*), uscale, vscale, uoffset, voffset, scale
     material_textures: list = None   # per material: texture index on its reflectance / specularReflectance, -1 = constant
 
@@ -346,3 +347,15 @@ def textured_cornell_box(width=64, height=48, filter=TEXFILTER_BILINEAR, wrap=TE
     sc.material_textures = mt
     sc.name = "cornell-textured"
     return sc
+
+
+def sky_map(w=32, h=16, seed=7, sun=40.0):
+    """A small latitude-longitude test environment: bluish gradient sky with per-texel noise, a darker ground half and a very bright
+    sun patch (so that the importance sampling and the half-precision storage both matter)."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(h) + 0.5) / h
+    img = np.zeros((h, w, 3))
+    img[...] = np.where(v[:, None, None] < 0.5, np.array([0.35, 0.55, 0.9]) * (1.2 - v[:, None, None]), np.array([0.12, 0.1, 0.08]))
+    img *= rng.uniform(0.7, 1.3, (h, w, 1))
+    img[h // 5: h // 5 + 2, w // 3: w // 3 + 2] = sun * np.array([1.0, 0.9, 0.7])
+    return img

@@ -49,9 +49,13 @@ typedef struct gdpt_emitter {   /* an `area` emitter attached to one mesh (src/e
     double position[3];         /* point emitters only (the `position` / translation of `toWorld`)                          */
 } gdpt_emitter;
 
-typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters/constant.cpp): uniform radiance from all directions */
-    double radiance[3];
+typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters/constant.cpp): uniform radiance from all directions -- or, with */
+    double radiance[3];             /* `rgb` set, `<emitter type="envmap">` (src/emitters/envmap.cpp): a latitude-longitude bitmap              */
     int    index;               /* its position in the scene's emitter list (XML order; Scene::sampleEmitterDirect picks by it); <0: last */
+    const double *rgb;          /* envmap: height x width x 3 LINEAR values, top row first (v = 0: straight up); NULL = the constant emitter.  The library  */
+    int    width, height;       /*   keeps it as the plugin does: MIP pyramid with half-precision texels, repeat in u / clamp in v, EWA lookups   */
+    double scale;               /*   (maxAnisotropy 10) for camera rays, level-0 bilinear otherwise, float cdfs for light sampling (envmap.cpp:135-138,258-325) */
+    double toWorld[9];          /* envmap: linear part of the emitter's `toWorld`, row-major (identity: +y is up, u = 0.5 looks along -z)   */
 } gdpt_environment;
 
 typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp), crop == film */

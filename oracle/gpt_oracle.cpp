@@ -336,6 +336,17 @@ struct Scene {
     int rfilterKind = 0;        // the film's reconstruction filter (Film::filterEval)
     double rfilterP0 = 0, rfilterP1 = 0;
     int envIndex = -1;          // position of the environment emitter in `emitters` (scene order), -1: none
+    // `<emitter type="envmap">` (src/emitters/envmap.cpp) instead of `constant`: latitude-longitude bitmap in a half-precision MIP map
+    // (repeat in u, clamp in v, EWA with maxAnisotropy 10: envmap.cpp:135-138,178-181), importance-sampled through float cdf tables
+    struct EnvMap {
+        bool present = false;
+        mip_oracle::MipMap mip;
+        int w = 0, h = 0;
+        std::vector<float> cdfRows, cdfCols;
+        std::vector<Float> rowWeights;
+        Float normalization = 0, scale = 1, pixelSizeX = 0, pixelSizeY = 0;
+        Float toWorld[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, toLocal[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // linear part of the emitter's toWorld and its inverse (row-major)
+    } envMap;
     V3 bsCenter;                // ConstantBackgroundEmitter::m_sceneBSphere (constant.cpp:67-70)
     Float bsRadius = 0;
     mutable uint64_t raysTraced = 0, shadowRaysTraced = 0; // skdtree.cpp:46-47
@@ -1024,6 +1035,104 @@ V3 squareToUniformSphere(Float sx, Float sy)
     Float phi = 2.0 * PI * sx;
     return V3(r * std::cos(phi), r * std::sin(phi), z);
 }
+// ---- EnvironmentMap, src/emitters/envmap.cpp ----------------------------------------------------------------------------------
+inline V3 mul3(const Float *M, V3 v) { return V3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
+inline Float luminance(const Float *c) { return c[0] * 0.212671f + c[1] * 0.715160f + c[2] * 0.072169f; }     // spectrum.h:725-727
+// configure(), envmap.cpp:258-325: marginal and conditional cdfs over luminance x sin(theta), in FLOAT as the reference keeps them
+void envMapConfigure(Scene::EnvMap &e)
+{
+    const mip_oracle::Level &L0 = e.mip.pyramid[0];
+    e.w = L0.w; e.h = L0.h;
+    e.cdfCols.assign((size_t)(e.w + 1) * e.h, 0.0f);
+    e.cdfRows.assign((size_t)e.h + 1, 0.0f);
+    e.rowWeights.assign(e.h, 0.0);
+    size_t colPos = 0, rowPos = 0;
+    Float rowSum = 0.0f;
+    e.cdfRows[rowPos++] = 0;
+    for (int y = 0; y < e.h; ++y) {
+        Float colSum = 0;
+        e.cdfCols[colPos++] = 0;
+        for (int x = 0; x < e.w; ++x) {
+            colSum += luminance(&L0.rgb[((size_t)y * e.w + x) * 3]);
+            e.cdfCols[colPos++] = (float)colSum;
+        }
+        const float normalization = 1.0f / (float)colSum;
+        for (int x = 1; x < e.w; ++x) e.cdfCols[colPos - x - 1] *= normalization;
+        e.cdfCols[colPos - 1] = 1.0f;
+        const Float weight = std::sin((y + 0.5f) * M_PI / e.h);
+        e.rowWeights[y] = weight;
+        rowSum += colSum * weight;
+        e.cdfRows[rowPos++] = (float)rowSum;
+    }
+    const float normalization = 1.0f / (float)rowSum;
+    for (int y = 1; y < e.h; ++y) e.cdfRows[rowPos - y - 1] *= normalization;
+    e.cdfRows[rowPos - 1] = 1.0f;
+    e.normalization = 1.0f / (rowSum * (2 * M_PI / e.w) * (M_PI / e.h));
+    e.pixelSizeX = 2 * M_PI / e.w; e.pixelSizeY = M_PI / e.h;
+}
+// evalEnvironment, envmap.cpp:378-409: bilinear on level 0, or -- a camera ray -- the EWA lookup with the partials of (u, v) along the differentials
+V3 envMapEval(const Scene &sc, const Ray &ray)
+{
+    const Scene::EnvMap &e = sc.envMap;
+    const V3 v = mul3(e.toLocal, ray.d);
+    const Float uvx = std::atan2(v.x, -v.z) * INV_TWOPI, uvy = std::acos(std::min(1.0, std::max(-1.0, v.y))) * INV_PI;
+    Float o[3];
+    if (!ray.hasDifferentials) e.mip.evalBilinear(0, uvx, uvy, o);
+    else {
+        const V3 dvdx = mul3(e.toLocal, ray.rxD) - v, dvdy = mul3(e.toLocal, ray.ryD) - v;
+        const Float t1 = INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -INV_PI / std::max(safe_sqrt(1.0f - v.y * v.y), Epsilon);
+        e.mip.eval(uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y, o);
+    }
+    return V3(o[0], o[1], o[2]) * e.scale;
+}
+inline uint32_t envSampleReuse(const float *cdf, uint32_t size, Float &sample)
+{ // envmap.cpp:640-645
+    const float *entry = std::lower_bound(cdf, cdf + size + 1, (float)sample);
+    const uint32_t index = std::min((uint32_t)std::max((ptrdiff_t)0, entry - cdf - 1), size - 1);
+    sample = (sample - (Float)cdf[index]) / (Float)(cdf[index + 1] - cdf[index]);
+    return index;
+}
+inline Float intervalToTent(Float sample)
+{ // warp.cpp:143-155
+    Float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - std::sqrt(sample));
+}
+// internalSampleDirection, envmap.cpp:556-594
+void envMapSampleDirection(const Scene::EnvMap &e, Float sx, Float sy, V3 &d, V3 &value, Float &pdf)
+{
+    const uint32_t row = envSampleReuse(e.cdfRows.data(), e.h, sy), col = envSampleReuse(e.cdfCols.data() + (size_t)row * (e.w + 1), e.w, sx);
+    const Float posx = (Float)col + intervalToTent(sx), posy = (Float)row + intervalToTent(sy);
+    const int xPos = (int)std::floor(posx), yPos = (int)std::floor(posy);
+    const Float dx1 = posx - xPos, dx2 = 1.0f - dx1, dy1 = posy - yPos, dy2 = 1.0f - dy1;
+    Float a[3], b[3], c[3], dd[3], value1[3], value2[3];
+    e.mip.texel(0, xPos, yPos, a); e.mip.texel(0, xPos + 1, yPos, b); e.mip.texel(0, xPos, yPos + 1, c); e.mip.texel(0, xPos + 1, yPos + 1, dd);
+    for (int k = 0; k < 3; ++k) { value1[k] = a[k] * dx2 * dy2 + b[k] * dx1 * dy2; value2[k] = c[k] * dx2 * dy1 + dd[k] * dx1 * dy1; }
+    value = V3(value1[0] + value2[0], value1[1] + value2[1], value1[2] + value2[2]) * e.scale;
+    pdf = (luminance(value1) * e.rowWeights[std::min(std::max(yPos, 0), e.h - 1)] + luminance(value2) * e.rowWeights[std::min(std::max(yPos + 1, 0), e.h - 1)]) * e.normalization;
+    const Float phi = e.pixelSizeX * (posx + 0.5f), theta = e.pixelSizeY * (posy + 0.5f);
+    const Float sinPhi = std::sin(phi), cosPhi = std::cos(phi), sinTheta = std::sin(theta), cosTheta = std::cos(theta);
+    d = V3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= std::max(std::abs(sinTheta), Epsilon);
+}
+// internalPdfDirection, envmap.cpp:597-625
+Float envMapPdfDirection(const Scene::EnvMap &e, V3 d)
+{
+    const Float uvx = std::atan2(d.x, -d.z) * INV_TWOPI, uvy = std::acos(std::min(1.0, std::max(-1.0, d.y))) * INV_PI;
+    if (!std::isfinite(uvx) || !std::isfinite(uvy)) return 0.0;
+    const Float u = uvx * e.w - 0.5f, v = uvy * e.h - 0.5f;
+    const int xPos = (int)std::floor(u), yPos = (int)std::floor(v);
+    const Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    Float a[3], b[3], c[3], dd[3], value1[3], value2[3];
+    e.mip.texel(0, xPos, yPos, a); e.mip.texel(0, xPos + 1, yPos, b); e.mip.texel(0, xPos, yPos + 1, c); e.mip.texel(0, xPos + 1, yPos + 1, dd);
+    for (int k = 0; k < 3; ++k) { value1[k] = a[k] * dx2 * dy2 + b[k] * dx1 * dy2; value2[k] = c[k] * dx2 * dy1 + dd[k] * dx1 * dy1; }
+    const Float sinTheta = safe_sqrt(1 - d.y * d.y);
+    return (luminance(value1) * e.rowWeights[std::min(std::max(yPos, 0), e.h - 1)] + luminance(value2) * e.rowWeights[std::min(std::max(yPos + 1, 0), e.h - 1)])
+        * e.normalization / std::max(std::abs(sinTheta), Epsilon);
+}
+// Scene::evalEnvironment for whichever environment emitter the scene has
+inline V3 evalEnvironment(const Scene &sc, const Ray &ray) { return sc.envMap.present ? envMapEval(sc, ray) : sc.emitters[sc.envIndex].radiance; }
+
 // ConstantBackgroundEmitter::fillDirectSamplingRecord, constant.cpp:245-261
 bool envFillDirectSamplingRecord(const Scene &sc, DirectSamplingRecord &dRec, const Ray &ray)
 {
@@ -1038,8 +1147,22 @@ bool envFillDirectSamplingRecord(const Scene &sc, DirectSamplingRecord &dRec, co
     return true;
 }
 // ConstantBackgroundEmitter::sampleDirect, constant.cpp:179-219
+bool bsphereRayIntersect(const Scene &sc, V3 ro, V3 rd, Float &nearHit, Float &farHit);
 V3 envSampleDirect(const Scene &sc, const Emitter &em, DirectSamplingRecord &dRec, Float sx, Float sy)
 {
+    if (sc.envMap.present) {                                      // EnvironmentMap::sampleDirect, envmap.cpp:509-534
+        V3 value, dl; Float pdf;
+        envMapSampleDirection(sc.envMap, sx, sy, dl, value, pdf);
+        const V3 dw = mul3(sc.envMap.toWorld, dl);
+        Float nearT, farT;
+        dRec.d = dw; dRec.dist = 0.0; dRec.p = dRec.ref; dRec.n = V3(0.0); dRec.measure = MEASURE_SOLID_ANGLE;
+        if (isZero(value) || pdf == 0 || !bsphereRayIntersect(sc, dRec.ref, dw, nearT, farT) || nearT >= 0 || farT <= 0) { dRec.pdf = 0.0; return V3(0.0); }
+        dRec.pdf = pdf;
+        dRec.p = dRec.ref + dw * farT;
+        dRec.n = normalize(sc.bsCenter - dRec.p);
+        dRec.dist = farT;
+        return value / pdf;
+    }
     V3 d;
     Float pdf;
     const bool hasN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
@@ -1066,8 +1189,12 @@ V3 envSampleDirect(const Scene &sc, const Emitter &em, DirectSamplingRecord &dRe
     return em.radiance / pdf;
 }
 // ConstantBackgroundEmitter::pdfDirect, constant.cpp:221-236
-Float envPdfDirect(const DirectSamplingRecord &dRec)
+Float envPdfDirect(const Scene &sc, const DirectSamplingRecord &dRec)
 {
+    if (sc.envMap.present) {                                      // EnvironmentMap::pdfDirect, envmap.cpp:536-547
+        const Float pdfSA = envMapPdfDirection(sc.envMap, mul3(sc.envMap.toLocal, dRec.d));
+        return dRec.measure == MEASURE_SOLID_ANGLE ? pdfSA : 0.0;
+    }
     const bool hasN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
     Float pdfSA = hasN ? INV_PI * std::max((Float)0.0, dot(dRec.d, dRec.refN)) : 1.0 / (4.0 * PI);
     if (dRec.measure == MEASURE_SOLID_ANGLE) return pdfSA;
@@ -1136,7 +1263,7 @@ Float pdfEmitterDirect(const Scene &sc, const DirectSamplingRecord &dRec)
 {
     const Emitter &em = sc.emitters[dRec.object];
     Float pd = 0.0;
-    if (em.numTris == 0) pd = envPdfDirect(dRec);
+    if (em.numTris == 0) pd = envPdfDirect(sc, dRec);
     else if (em.numTris < 0) pd = dRec.measure == MEASURE_DISCRETE ? 1.0 : 0.0;   // point.cpp:136-138
     else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
         Float pdfPos = em.invSurfaceArea;
@@ -1336,7 +1463,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
     main.ray.mint = Epsilon;
     for (int i = 0; i < secondaryCount; ++i) { rayIntersect(sc, shiftedRays[i].ray, shiftedRays[i].its); shiftedRays[i].ray.mint = Epsilon; }
     if (!main.its.isValid()) {                                                             // :482-492
-        if (sc.envIndex >= 0) out_veryDirect = out_veryDirect + main.throughput * sc.emitters[sc.envIndex].radiance; // evalEnvironment, constant.cpp:241-243
+        if (sc.envIndex >= 0) out_veryDirect = out_veryDirect + main.throughput * evalEnvironment(sc, main.ray); // scene->evalEnvironment(main.ray): a camera ray, with differentials
         return;
     }
     if (sc.tris[main.its.prim].emitter >= 0) out_veryDirect = out_veryDirect + main.throughput * Le(sc, main.its, -main.ray.d); // :497-499
@@ -1474,7 +1601,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
             mainNextVertexType = getVertexType(matOf(sc, main.its, main.ray), cfg, mainBsdfResult.sampledType); // :785
         } else {                                                                           // :786-804
             if (sc.envIndex < 0) break;
-            mainEmitterRadiance = sc.emitters[sc.envIndex].radiance;                       // evalEnvironment
+            mainEmitterRadiance = evalEnvironment(sc, main.ray);                           // evalEnvironment
             if (!envFillDirectSamplingRecord(sc, mainDRec, main.ray)) break;
             mainHitEmitter = true;
             mainNextVertexType = VERTEX_TYPE_DIFFUSE;                                      // "environment connection as diffuse"
@@ -1583,7 +1710,7 @@ void evaluate(const Scene &sc, const gpo_config &cfg, Rng &rng, RayState &main, 
                                 if (sc.envIndex < 0) { shifted.alive = false; goto half_vector_shift_failed; }
                                 if (main.its.isValid()) { shifted.alive = false; goto half_vector_shift_failed; }            // no shifts between env and non-env
                                 if (mainVertexType == VERTEX_TYPE_DIFFUSE && shiftedVertexType2 == VERTEX_TYPE_DIFFUSE) { shifted.alive = false; goto half_vector_shift_failed; }
-                                shiftedEmitterRadiance = sc.emitters[sc.envIndex].radiance;
+                                shiftedEmitterRadiance = evalEnvironment(sc, shifted.ray);
                                 postponedShiftEnd = true;
                                 goto half_vector_shift_failed;                                                             // (label name only: alive stays true)
                             }
@@ -1881,6 +2008,44 @@ GPO_API void gpo_scene_set_environment(gpo_scene *h, const double *radiance, int
     sc.bsRadius = std::max(Epsilon, length(sc.bsCenter - mx) * (Float)1.5f);   // aabb.cpp:44-47, constant.cpp:69
 }
 
+// `<emitter type="envmap">`: rgb = h x w x 3 linear values (top row first: v = 0 is straight up), `scale`, toWorld9 = the linear part of
+// the emitter's toWorld (row-major 3x3; identity: +y up, u = 0.5 looks along -z), index = position in the emitter list as for the constant one
+GPO_API void gpo_scene_set_envmap(gpo_scene *h, int w, int hgt, const double *rgb, double scale, const double *toWorld9, int index)
+{
+    Scene &sc = h->sc;
+    if (sc.envIndex >= 0) return;
+    const double zero[3] = {0, 0, 0};
+    gpo_scene_set_environment(h, zero, index);
+    Scene::EnvMap &e = sc.envMap;
+    e.present = true;
+    e.scale = scale;
+    for (int k = 0; k < 9; ++k) e.toWorld[k] = toWorld9[k];
+    {   // inverse of the 3x3 (Transform::inverse; a rotation in every sensible scene)
+        const Float *m = e.toWorld;
+        const Float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        const Float id = 1.0 / det;
+        e.toLocal[0] = (m[4] * m[8] - m[5] * m[7]) * id; e.toLocal[1] = (m[2] * m[7] - m[1] * m[8]) * id; e.toLocal[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+        e.toLocal[3] = (m[5] * m[6] - m[3] * m[8]) * id; e.toLocal[4] = (m[0] * m[8] - m[2] * m[6]) * id; e.toLocal[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+        e.toLocal[6] = (m[3] * m[7] - m[4] * m[6]) * id; e.toLocal[7] = (m[1] * m[6] - m[0] * m[7]) * id; e.toLocal[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    }
+    e.mip.build(w, hgt, rgb, mip_oracle::BC_REPEAT, mip_oracle::BC_CLAMP, mip_oracle::FILTER_EWA, 10.0, std::numeric_limits<Float>::infinity(), true);
+    envMapConfigure(e);
+}
+// probes: the environment map's radiance along a direction (no differentials), a light sample (direction, value / pdf, pdf) and its density
+GPO_API void gpo_envmap_eval(gpo_scene *h, const double *dir, double *rgb)
+{
+    Ray r(V3(0.0), V3(dir[0], dir[1], dir[2]));
+    const V3 v = envMapEval(h->sc, r);
+    rgb[0] = v.x; rgb[1] = v.y; rgb[2] = v.z;
+}
+GPO_API void gpo_envmap_sample(gpo_scene *h, double sx, double sy, double *out7)
+{
+    V3 d, value; Float pdf;
+    envMapSampleDirection(h->sc.envMap, sx, sy, d, value, pdf);
+    out7[0] = d.x; out7[1] = d.y; out7[2] = d.z; out7[3] = value.x; out7[4] = value.y; out7[5] = value.z; out7[6] = pdf;
+}
+GPO_API double gpo_envmap_pdf(gpo_scene *h, const double *dirLocal) { return envMapPdfDirection(h->sc.envMap, V3(dirLocal[0], dirLocal[1], dirLocal[2])); }
+
 // Per-vertex normals (9 doubles per triangle; three zero vectors = that triangle has none).  Emitter triangles must be flat:
 // AreaLight::eval and TriMesh::samplePosition would otherwise use interpolated normals, which this build does not carry.
 GPO_API int gpo_scene_set_normals(gpo_scene *h, const double *n9)
@@ -2156,7 +2321,7 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
                 if (sc.envIndex >= 0 && envFillDirectSamplingRecord(sc, q, next)) {       // the environment, MIS against its light sampling
                     Float pl = (s.sampledType & EDelta) ? 0.0 : pdfEmitterDirect(sc, q);
                     Float wgt = (s.pdf * s.pdf) / (s.pdf * s.pdf + pl * pl);
-                    L = L + beta * sc.emitters[sc.envIndex].radiance * wgt;
+                    L = L + beta * evalEnvironment(sc, next) * wgt;
                 }
                 break;
             }

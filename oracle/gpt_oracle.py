@@ -76,6 +76,11 @@ def lib():
         L.gpo_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_scene_set_material_texture.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.gpo_texture_eval.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_scene_set_envmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        L.gpo_envmap_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_envmap_sample.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_envmap_pdf.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpo_envmap_pdf.restype = C.c_double
         L.gpo_texture_eval_filtered.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.gpo_texture_levels.argtypes = [C.c_void_p, C.c_int]
         L.gpo_texture_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -164,6 +169,11 @@ class Scene:
         env = getattr(desc, "environment", None)
         if env is not None:                                  # (radiance rgb, position in the emitter list)
             lib().gpo_scene_set_environment(self._h, _p(_d(env[0])), int(env[1]))
+        em = getattr(desc, "environment_map", None)
+        if em is not None:                                   # dict(rgb [h, w, 3], scale, toWorld 3x3, index): `<emitter type="envmap">`
+            rgb = _d(em["rgb"])
+            lib().gpo_scene_set_envmap(self._h, rgb.shape[1], rgb.shape[0], _p(rgb), C.c_double(em.get("scale", 1.0)),
+                                       _p(_d(np.asarray(em.get("toWorld", np.eye(3))).reshape(9))), int(em.get("index", -1)))
 
     def render(self, cfg, rect=None):
         """-> (accum[5,H,W,4] float64, (closest_rays, shadow_rays))."""
@@ -202,6 +212,20 @@ class Scene:
             lib().gpo_texture_level(self._h, int(texture), l, _p(wh), _p(rgb))
             out.append(rgb)
         return out
+
+    def envmap_eval(self, d):
+        out = np.zeros(3)
+        lib().gpo_envmap_eval(self._h, _p(_d(d)), _p(out))
+        return out
+
+    def envmap_sample(self, sx, sy):
+        """-> (direction in the emitter's frame, radiance * scale, solid-angle pdf)"""
+        out = np.zeros(7)
+        lib().gpo_envmap_sample(self._h, C.c_double(sx), C.c_double(sy), _p(out))
+        return out[:3], out[3:6], float(out[6])
+
+    def envmap_pdf(self, d_local):
+        return float(lib().gpo_envmap_pdf(self._h, _p(_d(d_local))))
 
     def invalid_puts(self):
         """Puts the last render() dropped as invalid (ImageBlock::put, imageblock.h:154-158)."""

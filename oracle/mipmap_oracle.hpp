@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <limits>
 #include <vector>
 
 namespace mip_oracle {
@@ -96,6 +98,30 @@ struct Resampler {
     }
 };
 
+// half(float) -> float of the `half` class the environment map's pyramid is stored in (TMIPMap<Spectrum, SpectrumHalf>, envmap.cpp:101-103):
+// round to nearest even on the 10-bit mantissa, gradual underflow, overflow to infinity.  The double texel first becomes a float
+// (half's constructor takes one), then a half.
+inline Float roundToHalf(Float value)
+{
+    const float f = (float)value;
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = x & 0x80000000u;
+    x &= 0x7fffffffu;
+    float r;
+    if (x >= 0x7f800000u) { r = f; }                                                     // inf / nan stay
+    else if (x >= 0x477ff000u) { const uint32_t inf = sign | 0x7f800000u; std::memcpy(&r, &inf, 4); }   // >= 65520: rounds to infinity
+    else if (x < 0x38800000u) {                                                          // below 2^-14: a half denormal = a multiple of 2^-24
+        const float q = std::nearbyint(std::fabs(f) * 16777216.0f) * (1.0f / 16777216.0f);   // (round-half-even is the default rounding mode)
+        r = sign ? -q : q;
+    } else {
+        x += 0x00000fffu + ((x >> 13) & 1u);
+        x &= 0xffffe000u;
+        x |= sign;
+        std::memcpy(&r, &x, 4);
+    }
+    return (Float)r;
+}
+
 struct Level { int w = 0, h = 0; std::vector<Float> rgb; Float ratioX = 1, ratioY = 1; };
 
 // Bitmap::resample(rfilter, bcu, bcv, size, 0, maxValue), bitmap.cpp:2230-2330: X pass into a temporary (when the width changes), then Y pass
@@ -126,21 +152,26 @@ struct MipMap {
     Float weightLut[LUT_SIZE];
 
     // TMIPMap(bitmap, ...), mipmap.h:163-304 (negative texels are clamped first, :234-242)
-    void build(int w, int h, const Float *rgb, int bcu_, int bcv_, int filter_, Float maxAniso)
+    // maxValue: the upper clamp of the resampled levels (1 for bitmap textures, infinity for the environment map, envmap.cpp:178-181);
+    // halfStorage: the pyramid keeps its texels as `half` (TMIPMap<Spectrum, SpectrumHalf>) -- each level is resampled from the previous
+    // level's FLOAT bitmap and quantized when stored (mipmap.h:226-232,262-264)
+    void build(int w, int h, const Float *rgb, int bcu_, int bcv_, int filter_, Float maxAniso, Float maxValue = 1.0, bool halfStorage = false)
     {
         bcu = bcu_; bcv = bcv_; filter = filter_;
         maxAnisotropy = filter == FILTER_EWA ? maxAniso : 1.0;                                // bitmap.cpp:232-235
         pyramid.clear();
-        Level l0; l0.w = w; l0.h = h; l0.rgb.assign(rgb, rgb + (size_t)w * h * 3);
-        for (Float &v : l0.rgb) if (v < 0) v = 0;
-        pyramid.push_back(l0);
+        Level cur; cur.w = w; cur.h = h; cur.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+        for (Float &v : cur.rgb) if (v < 0) v = 0;
+        auto store = [&](const Level &l) { pyramid.push_back(l); if (halfStorage) for (Float &v : pyramid.back().rgb) v = roundToHalf(v); };
+        store(cur);
         if (filter != FILTER_NEAREST && filter != FILTER_BILINEAR) {
             int sx = w, sy = h;
             while (sx > 1 || sy > 1) {
                 sx = std::max(1, (sx + 1) / 2); sy = std::max(1, (sy + 1) / 2);
-                Level next = resampleImage(pyramid.back(), sx, sy, bcu, bcv, 1.0);
+                Level next = resampleImage(cur, sx, sy, bcu, bcv, maxValue);
                 next.ratioX = (Float)sx / (Float)w; next.ratioY = (Float)sy / (Float)h;
-                pyramid.push_back(next);
+                store(next);
+                cur = next;
             }
         }
         // :297-301.  `math::fastexp(-2.0f)` takes the FLOAT overload: (float) exp((double) value) on Linux/x86_64 (math.h:175-187) -- the

@@ -823,6 +823,88 @@ def test_mip_filtered_textures_match_oracle(G, flt, wrap, uvscale, aniso, size):
     S.close(); O.close()
 
 
+@pytest.mark.parametrize("variant,strict,rot,size,index", [("diffuse", False, 0.0, (32, 16), -1), ("glossy", False, 0.7, (37, 19), 0), ("smooth", True, 2.1, (64, 32), 1), ("glass", False, -1.3, (16, 9), -1)])
+def test_environment_map_matches_oracle(G, variant, strict, rot, size, index):
+    """`<emitter type="envmap">` (src/emitters/envmap.cpp) in place of the constant environment: latitude-longitude map in a
+    half-precision MIP pyramid, EWA lookup through the camera ray's differentials where the background is seen directly, level-0
+    bilinear for every other ray, importance sampling through the float cdf tables with the tent offset, its pdf, a rotated
+    `toWorld`, non-power-of-two maps, the emitter's position in the list.  The box is opened (no ceiling light blocking: the front
+    is open anyway) so that the map lights the scene; samples and the film against the oracle, both pipelines."""
+    W, H, spp, md = 40, 32, 4, 6
+    sc = scenes.cornell_box(W, H, variant)
+    c, s_ = np.cos(rot), np.sin(rot)
+    R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) @ np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    sc.environment_map = dict(rgb=scenes.sky_map(size[0], size[1]), scale=0.8, toWorld=R, index=index)
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict)
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=md, spp=spp, strictNormals=strict)
+    rng = np.random.default_rng(23)
+    for _ in range(60):
+        px, py, k = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, k), O.evaluate_point(ocfg, px, py, k)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-10, atol=1e-14), (px, py, k, key)
+    oacc, orays = O.render(ocfg)
+    for stages in (0, 2):
+        F = G.Film(S); F.set_pipeline(stages)
+        integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (stages, G.BUFFER_NAMES[b])
+        F.close()
+    assert oacc[4][..., :3].max() > 0                          # the map is seen directly somewhere (very direct = the EWA lookup)
+    flat = scenes.cornell_box(W, H, variant); flat.environment = ((0.4, 0.5, 0.6), len(flat.emitters))
+    ref, _ = go.Scene(flat).render(ocfg)
+    assert not close(oacc[1], ref[1], 1e-3)
+    S.close(); O.close()
+
+
+def test_environment_map_in_the_hbm_builds_and_bad_maps(G, monkeypatch):
+    """The same through the 4-wave (HBM-scene) builds, where the lookups are inlined instead of called; black / oversized / non-finite maps
+    are refused as the plugin refuses them."""
+    monkeypatch.setenv("GDPT_SCENE_IN_HBM", "1")
+    W, H, spp = 32, 24, 3
+    sc = scenes.cornell_box(W, H, "glossy")
+    sc.environment_map = dict(rgb=scenes.sky_map(24, 12), scale=1.5, index=-1)
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=5)
+    F = G.Film(S)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    acc, st = F.accum(), F.stats()
+    oacc, orays = O.render(go.config(maxDepth=5, spp=spp))
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+    for b in range(5):
+        assert close(acc[b], oacc[b]), G.BUFFER_NAMES[b]
+    F.close(); S.close(); O.close()
+    # the constant environment through the same builds, both pipelines, deep paths (the 4-wave builds once had an environment-only variant
+    # that faulted from the second bounce on: DESIGN.md)
+    flat = scenes.cornell_box(W, H, "glossy"); flat.environment = ((0.4, 0.5, 0.6), len(flat.emitters))
+    S, O = G.Scene(flat), go.Scene(flat)
+    oacc, orays = O.render(go.config(maxDepth=7, spp=spp))
+    for stages in (0, 2):
+        F = G.Film(S); F.set_pipeline(stages)
+        if stages == 0: F.set_occupancy(4)
+        G.GradientPathIntegrator(maxDepth=7).renderBlock(S, F, G.GradientPathIntegrator(maxDepth=7).config(spp), (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (stages, G.BUFFER_NAMES[b])
+        F.close()
+    S.close(); O.close()
+    monkeypatch.delenv("GDPT_SCENE_IN_HBM")
+    sc.environment_map = dict(rgb=np.zeros((8, 16, 3)))
+    with pytest.raises(RuntimeError, match="completely black"):
+        G.Scene(sc)
+    bad = scenes.sky_map(16, 8); bad[2, 3, 1] = np.inf
+    sc.environment_map = dict(rgb=bad)
+    with pytest.raises(RuntimeError, match="invalid floating"):
+        G.Scene(sc)
+    sc.environment_map = dict(rgb=scenes.sky_map(16, 8)); sc.environment = ((1, 1, 1), 0)
+    with pytest.raises(ValueError, match="one environment"):
+        G.Scene(sc)
+
+
 def test_texture_arguments_are_checked(G):
     sc = scenes.textured_cornell_box(16, 12)
     sc.textures[0]["filter"] = 4

@@ -478,3 +478,54 @@ def test_mip_pyramid_and_filtered_lookup_known_answers():
     tx = lambda x, y: lv[1][y % 12, x % 19]
     exp = tx(x0, y0) * (1 - fx) * (1 - fy) + tx(x0, y0 + 1) * (1 - fx) * fy + tx(x0 + 1, y0) * fx * (1 - fy) + tx(x0 + 1, y0 + 1) * fx * fy
     assert np.allclose(got, exp * tri.textures[0]["scale"], rtol=1e-12)
+
+
+def test_environment_map_known_answers():
+    """The environment map (src/emitters/envmap.cpp) on the oracle side: pyramid texels are exactly half-precision values (numpy's float16 is
+    the same rounding), a light sample's density is the density the pdf function reports for its direction and its value the map's level-0
+    lookup there, the density integrates to one over the sphere, sampling frequencies follow it, a constant map is the constant emitter's
+    radiance in every direction, and `toWorld` rotates lookups and samples alike."""
+    sc = scenes.cornell_box(16, 12, "diffuse")
+    img = scenes.sky_map(32, 16)
+    sc.environment_map = dict(rgb=img, scale=0.8)
+    O = go.Scene(sc)
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        d, val, pdf = O.envmap_sample(rng.random(), rng.random())
+        assert abs(np.linalg.norm(d) - 1) < 1e-12
+        assert np.isclose(O.envmap_pdf(d), pdf, rtol=1e-9) and np.allclose(O.envmap_eval(d), val, rtol=1e-9)
+    # integral of the density over the sphere, on a fine latitude-longitude grid (the density is piecewise bilinear / sin(theta))
+    nth, nph = 512, 1024
+    th = (np.arange(nth) + 0.5) * np.pi / nth; ph = (np.arange(nph) + 0.5) * 2 * np.pi / nph
+    tot = 0.0
+    for t in th[::8]:
+        ds = np.stack([np.sin(ph[::8]) * np.sin(t), np.full(nph // 8, np.cos(t)), -np.cos(ph[::8]) * np.sin(t)], 1)
+        tot += sum(O.envmap_pdf(d) for d in ds) * np.sin(t)
+    tot *= (np.pi / (nth // 8)) * (2 * np.pi / (nph // 8))
+    assert abs(tot - 1) < 2e-2
+    # the brightest texels (the sun patch) draw most of the samples
+    hits = 0
+    for _ in range(2000):
+        d, _, _ = O.envmap_sample(rng.random(), rng.random())
+        u = (np.arctan2(d[0], -d[2]) / (2 * np.pi)) % 1.0; v = np.arccos(np.clip(d[1], -1, 1)) / np.pi
+        hits += (32 // 3 - 1 <= u * 32 <= 32 // 3 + 3) and (16 // 5 - 1 <= v * 16 <= 16 // 5 + 3)
+    lum = img @ np.array([0.212671, 0.715160, 0.072169]) * np.sin((np.arange(16) + 0.5) * np.pi / 16)[:, None]
+    assert hits / 2000 > 0.8 * lum[16 // 5: 16 // 5 + 2, 32 // 3: 32 // 3 + 2].sum() / lum.sum()
+    const = scenes.cornell_box(16, 12, "diffuse"); const.environment_map = dict(rgb=np.full((8, 16, 3), 0.5), scale=2.0)
+    C_ = go.Scene(const)
+    for _ in range(20):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        assert np.allclose(C_.envmap_eval(d), 1.0, rtol=1e-12)
+    a, _ = C_.render(go.config(maxDepth=4, spp=2))
+    flat = scenes.cornell_box(16, 12, "diffuse"); flat.environment = ((1.0, 1.0, 1.0), len(flat.emitters))
+    b, _ = go.Scene(flat).render(go.config(maxDepth=4, spp=2))
+    assert np.allclose(a[4], b[4], rtol=1e-12)                                      # directly seen background: the same radiance
+    assert abs(a[1][..., :3].mean() - b[1][..., :3].mean()) < 0.15 * b[1][..., :3].mean()   # (other light samples: the same image in expectation)
+    # half-precision storage: what the lookups see are float16 values
+    one = scenes.cornell_box(16, 12, "diffuse"); one.environment_map = dict(rgb=np.full((4, 8, 3), 0.1), scale=1.0)
+    assert np.allclose(go.Scene(one).envmap_eval([0, 1, 0]), float(np.float16(np.float32(0.1))), rtol=0, atol=0)
+    R = np.array([[0.0, 0, 1], [0, 1, 0], [-1, 0, 0]])
+    rot = scenes.cornell_box(16, 12, "diffuse"); rot.environment_map = dict(rgb=img, scale=0.8, toWorld=R)
+    Rr = go.Scene(rot)
+    d = np.array([0.3, 0.5, -0.6]); d /= np.linalg.norm(d)
+    assert np.allclose(Rr.envmap_eval(R @ d), O.envmap_eval(d), rtol=1e-12)
