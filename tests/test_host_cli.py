@@ -159,7 +159,8 @@ def test_serialized_meshes(cli, tmp_path):
     ('<emitter type="constant"/><emitter type="constant"/>' + LIGHT, None, "Only one environment emitter"),
     (LIGHT, '<film type="hdrfilm"><rfilter type="box"/></film>', "without MultiFilm"),
     (LIGHT, '<film type="multifilm"><string name="fileFormat" value="pfm"/><rfilter type="sinc"/></film>', "rfilter \"sinc\" is not carried"),
-    ('<emitter type="envmap"/>' + LIGHT, None, "not carried"),
+    ('<emitter type="sunsky"/>' + LIGHT, None, "not carried"),
+    ('<emitter type="envmap"/>' + LIGHT, None, "missing filename"),
     ('<shape type="rectangle"><ref id="nope"/></shape>' + LIGHT, None, "not found"),
 ])
 def test_unsupported_input_is_an_error_with_a_reason(cli, tmp_path, body, film, needle):
