@@ -492,14 +492,16 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     for (int slot = 0, e = 0; slot < totalEmitters; slot++) {
         EmitterD &o = ems[slot];
         if (slot == envIndex) {                               // `constant` environment emitter: no triangles
-            o.firstEmTri = 0; o.numTris = 0; o.cdfOffset = 0; o.pad = 0;
+            std::memset(&o, 0, sizeof o);
+            o.firstEmTri = 0; o.numTris = 0; o.cdfOffset = 0;
             o.radiance = to_d3(h3(env->radiance[0], env->radiance[1], env->radiance[2]));
             o.invSurfaceArea = 0.0;
             o.position = to_d3(h3(0.0, 0.0, 0.0)); o.pad2 = 0.0;
             sceneCdf.push_back(sceneCdf.back() + 1.0);
             continue;
         }
-        o.firstEmTri = (int)emTris.size(); o.numTris = emitters[e].numTris; o.cdfOffset = (int)emCdf.size(); o.pad = 0;
+        std::memset(&o, 0, sizeof o);
+        o.firstEmTri = (int)emTris.size(); o.numTris = emitters[e].numTris; o.cdfOffset = (int)emCdf.size();
         o.radiance = to_d3(h3(emitters[e].radiance[0], emitters[e].radiance[1], emitters[e].radiance[2]));
         o.position = to_d3(h3(emitters[e].position[0], emitters[e].position[1], emitters[e].position[2])); o.pad2 = 0.0;
         if (o.numTris == -1) {                                // `point` emitter (src/emitters/point.cpp): sampled, never hit
@@ -522,6 +524,15 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         for (size_t i = 1; i < cdf.size(); i++) cdf[i] *= norm;
         cdf.back() = 1.0;
         o.invSurfaceArea = 1.0 / sum;
+        if (emitters[e].rectangle) {                          // a `rectangle` shape's light: Rectangle::samplePosition / getSurfaceArea, rectangle.cpp:119-121,200-206
+            if (o.numTris != 2) return tfail(GDPT_ERR_INVALID, "emitter %d: a rectangle light is the two triangles of Rectangle::createTriMesh", e);
+            const double *M = emitters[e].rectToWorld;
+            o.rectangle = 1;
+            for (int k = 0; k < 12; k++) o.rect[k] = M[k];
+            o.rectN = to_d3(h3(emitters[e].rectNormal[0], emitters[e].rectNormal[1], emitters[e].rectNormal[2]));
+            const H3 dpdu = h3(M[0] * 2.0, M[4] * 2.0, M[8] * 2.0), dpdv = h3(M[1] * 2.0, M[5] * 2.0, M[9] * 2.0);      // objectToWorld(Vector(2,0,0)), (0,2,0)
+            o.invSurfaceArea = 1.0 / (hlen(dpdu) * hlen(dpdv));
+        }
         emCdf.insert(emCdf.end(), cdf.begin(), cdf.end());
         sceneCdf.push_back(sceneCdf.back() + 1.0);
         e++;

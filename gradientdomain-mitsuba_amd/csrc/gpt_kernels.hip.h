@@ -132,11 +132,14 @@ struct EnvMapD {
 };
 static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
-    int firstEmTri, numTris, cdfOffset, pad;
+    int firstEmTri, numTris, cdfOffset, rectangle;     // rectangle: a `rectangle` shape's light -- sampled as Rectangle::samplePosition does
     d3 radiance;            // point: intensity
     Float invSurfaceArea;
     d3 position;            // point emitters only
     Float pad2;
+    Float rect[12];         // rectangle: rows of its 3x4 objectToWorld
+    d3 rectN;               // rectangle: its frame's normal
+    Float pad3;
 };
 struct EmTri { d3 p0, p1, p2; };
 static_assert(sizeof(EmitterD) % 16 == 0, "LDS staging copies 16-byte words");
@@ -909,6 +912,20 @@ __device__ d3 sample_emitter_direct(const SceneD &S, const SceneView &V, DRec &d
         dRec.d = dRec.d * invDist;
         dRec.n = mk(0.0);
         value = em.radiance * (invDist * invDist);
+    } else if (em.rectangle) {                                // Rectangle::samplePosition, rectangle.cpp:200-206, then Shape::sampleDirect (shape.cpp:102-116)
+        const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
+        dRec.p = mk(em.rect[0] * lx + em.rect[1] * ly + em.rect[2] * 0.0 + em.rect[3], em.rect[4] * lx + em.rect[5] * ly + em.rect[6] * 0.0 + em.rect[7],
+                    em.rect[8] * lx + em.rect[9] * ly + em.rect[10] * 0.0 + em.rect[11]);
+        dRec.n = em.rectN;
+        dRec.pdf = em.invSurfaceArea;
+        dRec.d = dRec.p - dRec.ref;
+        const Float distSquared = len2(dRec.d);
+        dRec.dist = sqrt(distSquared);
+        dRec.d = dRec.d / dRec.dist;
+        const Float dp = fabs(dot(dRec.d, dRec.n));
+        dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0;
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = em.radiance / dRec.pdf;
+        else { dRec.pdf = 0.0; value = mk(0.0); }
     } else {
         const Float *cdf = V.emCdf + em.cdfOffset;
         const int ti = cdf_sample(cdf, em.numTris, sy);

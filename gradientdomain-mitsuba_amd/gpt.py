@@ -29,7 +29,8 @@ class Texture(C.Structure):
 
 
 class Emitter(C.Structure):
-    _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3), ("position", C.c_double * 3)]
+    _fields_ = [("firstTri", C.c_int), ("numTris", C.c_int), ("radiance", C.c_double * 3), ("position", C.c_double * 3),
+                ("rectangle", C.c_int), ("rectToWorld", C.c_double * 12), ("rectNormal", C.c_double * 3)]
 
 
 class Environment(C.Structure):
@@ -75,6 +76,10 @@ class Scene:
                 ems[i].firstTri, ems[i].numTris, ems[i].position, ems[i].radiance = 0, -1, (C.c_double * 3)(*em[1]), (C.c_double * 3)(*em[2])
             else:
                 ems[i].firstTri, ems[i].numTris, ems[i].radiance = em[0], em[1], (C.c_double * 3)(*em[2])
+                if len(em) >= 5:                                 # the light of a `rectangle` shape: (firstTri, 2, radiance, toWorld 3x4, normal)
+                    ems[i].rectangle = 1
+                    ems[i].rectToWorld = (C.c_double * 12)(*np.asarray(em[3], np.float64).reshape(12))
+                    ems[i].rectNormal = (C.c_double * 3)(*em[4])
         cam = Camera()
         cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
         cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height

@@ -782,6 +782,17 @@ private:
             std::memset(&e, 0, sizeof e);
             e.firstTri = first; e.numTris = sd.numTriangles() - first;
             for (int k = 0; k < 3; ++k) e.radiance[k] = radiance[k];
+            if (type == "rectangle") {                           // light samples as Rectangle::samplePosition draws them (rectangle.cpp:80-85,100-107,200-206)
+                Mat4 M = T;
+                if (flipNormals) for (int r = 0; r < 4; ++r) M.m[4 * r + 2] = -M.m[4 * r + 2];      // m_objectToWorld * Transform::scale(Vector(1, 1, -1))
+                e.rectangle = 1;
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) e.rectToWorld[4 * r + c] = M.m[4 * r + c];
+                const double up[3] = {0, 0, 1};
+                double n[3];
+                M.normal(up, n);
+                const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                for (int k = 0; k < 3; ++k) e.rectNormal[k] = n[k] / len;
+            }
             sd.emitters.push_back(e);
         }
     }

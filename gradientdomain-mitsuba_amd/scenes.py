@@ -69,7 +69,8 @@ class Scene:
     verts: np.ndarray            # (ntri, 9) float64
     tri_material: np.ndarray     # (ntri,) int32
     materials: list
-    emitters: list               # [(firstTri, numTris, (r,g,b))] area lights and [("point", (x,y,z), (r,g,b) intensity)], in scene order
+    emitters: list               # [(firstTri, numTris, (r,g,b))] area lights, [(firstTri, 2, (r,g,b), toWorld 3x4, normal)] the light of a `rectangle` shape
+                                 # (sampled as the shape samples itself) and [("point", (x,y,z), (r,g,b) intensity)], in scene order
     to_world: np.ndarray         # 4x4 camera-to-world
     fov_x: float
     near: float = 1e-2

@@ -47,6 +47,9 @@ typedef struct gdpt_emitter {   /* an `area` emitter attached to one mesh (src/e
     int    firstTri, numTris;   /* area: that mesh's triangles, contiguous in the soup; point: numTris = -1                  */
     double radiance[3];         /* area: radiance; point: intensity                                                           */
     double position[3];         /* point emitters only (the `position` / translation of `toWorld`)                          */
+    int    rectangle;           /* 1: the mesh is a `rectangle` shape (src/shapes/rectangle.cpp) given as the two triangles of its createTriMesh():  */
+    double rectToWorld[12];     /*    light samples are drawn as the shape draws them, objectToWorld(2u - 1, 2v - 1, 0) (rectangle.cpp:200-206), with  */
+    double rectNormal[3];       /*    its frame's normal (normalize(objectToWorld(Normal(0,0,1)))) and pdf 1 / (|dpdu| |dpdv|); rows of the 3x4, incl. flipNormals */
 } gdpt_emitter;
 
 typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters/constant.cpp): uniform radiance from all directions -- or, with */

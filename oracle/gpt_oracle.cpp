@@ -258,6 +258,9 @@ struct Emitter {
     bool onSurface() const { return numTris >= 0; }   // Emitter::isOnSurface: area and constant set EOnSurface, point does not
     std::vector<Float> cdf; // DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h)
     Float invSurfaceArea;
+    bool rectangle = false; // the light of a `rectangle` shape (src/shapes/rectangle.cpp), hit as the two triangles of its createTriMesh() but
+    Float rect[12];         // SAMPLED as the shape samples itself: objectToWorld(2u - 1, 2v - 1, 0), its frame's normal, pdf 1 / (|dpdu| |dpdv|)
+    V3 rectN;
 };
 
 struct Distribution { // include/mitsuba/core/pmf.h
@@ -1222,6 +1225,13 @@ V3 sampleEmitterDirectVisible(const Scene &sc, DirectSamplingRecord &dRec, Float
         dRec.n = V3(0.0);
         value = em.radiance * (invDist * invDist);
     } else {
+    if (em.rectangle) {                                            // Rectangle::samplePosition, rectangle.cpp:200-206
+        const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
+        const Float *M = em.rect;                                  // Transform::operator()(Point), transform.h:108-124 (affine: w == 1)
+        dRec.p = V3(M[0] * lx + M[1] * ly + M[2] * 0.0 + M[3], M[4] * lx + M[5] * ly + M[6] * 0.0 + M[7], M[8] * lx + M[9] * ly + M[10] * 0.0 + M[11]);
+        dRec.n = em.rectN;
+        dRec.pdf = em.invSurfaceArea;
+    } else
     // TriMesh::samplePosition
     {
         const std::vector<Float> &cdf = em.cdf;
@@ -2006,6 +2016,21 @@ GPO_API void gpo_scene_set_environment(gpo_scene *h, const double *radiance, int
     mx = V3(std::max(mx.x, camPos.x), std::max(mx.y, camPos.y), std::max(mx.z, camPos.z));
     sc.bsCenter = (mx + mn) * 0.5;                                   // AABB::getCenter, aabb.h:132-134
     sc.bsRadius = std::max(Epsilon, length(sc.bsCenter - mx) * (Float)1.5f);   // aabb.cpp:44-47, constant.cpp:69
+}
+
+// Marks area emitter `index` (scene order, before any environment emitter is inserted) as the light of a `rectangle` shape: toWorld12 = rows of its
+// 3x4 objectToWorld (flipNormals folded in as the plugin does: toWorld * scale(1, 1, -1)), normal3 = its frame's normal
+GPO_API int gpo_scene_set_rectangle_emitter(gpo_scene *h, int index, const double *toWorld12, const double *normal3)
+{
+    Scene &sc = h->sc;
+    if (index < 0 || index >= (int)sc.emitters.size() || sc.emitters[index].numTris != 2) return -1;
+    Emitter &em = sc.emitters[index];
+    em.rectangle = true;
+    for (int k = 0; k < 12; ++k) em.rect[k] = toWorld12[k];
+    em.rectN = V3(normal3[0], normal3[1], normal3[2]);
+    const V3 dpdu(toWorld12[0] * 2.0, toWorld12[4] * 2.0, toWorld12[8] * 2.0), dpdv(toWorld12[1] * 2.0, toWorld12[5] * 2.0, toWorld12[9] * 2.0);   // rectangle.cpp:103-104
+    em.invSurfaceArea = 1.0 / (length(dpdu) * length(dpdv));       // :110,119-121
+    return 0;
 }
 
 // `<emitter type="envmap">`: rgb = h x w x 3 linear values (top row first: v = 0 is straight up), `scale`, toWorld9 = the linear part of

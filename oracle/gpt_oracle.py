@@ -76,6 +76,7 @@ def lib():
         L.gpo_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_scene_set_material_texture.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.gpo_texture_eval.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_scene_set_rectangle_emitter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.gpo_scene_set_envmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
         L.gpo_envmap_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_envmap_sample.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
@@ -146,6 +147,10 @@ class Scene:
         self.W, self.H = desc.width, desc.height
         self._h = lib().gpo_scene_create(verts.shape[0], _p(verts), _p(tm), len(desc.materials), C.byref(mats),
                                          len(desc.emitters), C.byref(ems), C.byref(cam))
+        for i, e in enumerate(desc.emitters):                # a `rectangle` shape's light: (firstTri, 2, radiance, toWorld 3x4, normal)
+            if len(e) >= 5 and not isinstance(e[0], str):
+                if lib().gpo_scene_set_rectangle_emitter(self._h, i, _p(_d(np.asarray(e[3]).reshape(12))), _p(_d(e[4]))) != 0:
+                    raise ValueError("a rectangle light is the two triangles of Rectangle::createTriMesh")
         nrm = getattr(desc, "normals", None)
         if nrm is not None:                                  # (ntri, 9) per-vertex normals, zero rows = flat triangle
             if lib().gpo_scene_set_normals(self._h, _p(_d(nrm))) != 0:

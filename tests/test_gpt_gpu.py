@@ -905,6 +905,60 @@ def test_environment_map_in_the_hbm_builds_and_bad_maps(G, monkeypatch):
         G.Scene(sc)
 
 
+def _with_rectangle_light(sc, corner, eu, ev, radiance=(18.0, 14.0, 9.0)):
+    """Appends a `rectangle` shape with an area emitter to a scene description: the two triangles of Rectangle::createTriMesh
+    (rectangle.cpp:158-193) and the emitter as (firstTri, 2, radiance, toWorld 3x4, normal).  objectToWorld maps (-1,-1,0) to `corner`."""
+    eu, ev, corner = np.asarray(eu, float), np.asarray(ev, float), np.asarray(corner, float)
+    c = corner + eu + ev                                             # image of the origin; columns: eu, ev, n, c
+    n = np.cross(eu, ev); n /= np.linalg.norm(n)
+    M = np.stack([eu, ev, n, c], 1)                                  # 3x4
+    P = lambda x, y: M @ np.array([x, y, 0.0, 1.0])
+    v = [P(-1, -1), P(1, -1), P(1, 1), P(-1, 1)]
+    tris = np.array([[v[0], v[1], v[2]], [v[2], v[3], v[0]]]).reshape(2, 9)
+    first = sc.ntri
+    sc.verts = np.concatenate([np.asarray(sc.verts, np.float64).reshape(-1, 9), tris])
+    sc.tri_material = np.concatenate([np.asarray(sc.tri_material, np.int32), np.zeros(2, np.int32)])
+    if getattr(sc, "normals", None) is not None:
+        sc.normals = np.concatenate([np.asarray(sc.normals), np.zeros((2, 9))])
+    sc.emitters = list(sc.emitters) + [(first, 2, tuple(radiance), M, tuple(n))]
+    return sc
+
+
+@pytest.mark.parametrize("variant,strict", [("diffuse", False), ("glossy", True)])
+def test_rectangle_light_is_sampled_as_the_shape_samples_itself(G, variant, strict):
+    """The light of a `rectangle` shape: hit as two triangles, SAMPLED as Rectangle::samplePosition does (objectToWorld(2u - 1, 2v - 1, 0),
+    the frame's normal, pdf 1 / (|dpdu| |dpdv|): rectangle.cpp:100-121,200-206) -- not through a triangle cdf.  A second, tilted and
+    non-square light next to the Cornell box's own mesh light; samples and the film against the oracle, both pipelines; and the
+    same two triangles declared as a plain mesh light give other samples (same distribution, another map from random numbers to points)."""
+    W, H, spp, md = 40, 32, 4, 6
+    base = scenes.cornell_box(W, H, variant)
+    sc = _with_rectangle_light(scenes.cornell_box(W, H, variant), (120.0, 300.0, 150.0), (45.0, 6.0, 0.0), (-3.0, 10.0, 60.0))
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict)
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=md, spp=spp, strictNormals=strict)
+    rng = np.random.default_rng(31)
+    for _ in range(60):
+        px, py, k = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, k), O.evaluate_point(ocfg, px, py, k)
+        for key in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[key], o[key], rtol=1e-10, atol=1e-14), (px, py, k, key)
+    oacc, orays = O.render(ocfg)
+    for stages in (0, 2):
+        F = G.Film(S); F.set_pipeline(stages)
+        integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (stages, G.BUFFER_NAMES[b])
+        F.close()
+    mesh = _with_rectangle_light(scenes.cornell_box(W, H, variant), (120.0, 300.0, 150.0), (45.0, 6.0, 0.0), (-3.0, 10.0, 60.0))
+    mesh.emitters = mesh.emitters[:-1] + [mesh.emitters[-1][:3]]
+    ref, _ = go.Scene(mesh).render(ocfg)
+    assert not close(oacc[1], ref[1], 1e-6)
+    assert abs(oacc[1][..., :3].mean() - ref[1][..., :3].mean()) < 0.1 * ref[1][..., :3].mean()        # (the same light in expectation)
+    S.close(); O.close()
+
+
 def test_texture_arguments_are_checked(G):
     sc = scenes.textured_cornell_box(16, 12)
     sc.textures[0]["filter"] = 4

@@ -468,3 +468,46 @@ def test_cli_envmap_emitter_equals_python_mirror(cli, tmp_path, gpu_required):
         assert np.allclose(read_pfm(dest + suffix + ".pfm"), out[suffix], rtol=2e-6, atol=1e-7), suffix
     plain = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
     assert not np.allclose(plain["-throughput"], out["-throughput"], rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_cli_rectangle_light_equals_python_mirror(cli, tmp_path, gpu_required):
+    """A `rectangle` shape with an area emitter through the scene reader (toWorld = scale, rotate, translate; once with flipNormals) ==
+    the Python mirror: the two triangles of Rectangle::createTriMesh, texture coordinates, and the emitter sampled as the shape samples itself."""
+    import shutil
+    import gradientdomain_mitsuba_amd.gpt as G
+    shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    for flipped in (False, True):
+        ang = 10.0 if not flipped else -170.0                      # rotation about x by ang + 90 degrees: the light faces down into the box either way
+        shape = ('<shape type="rectangle"><transform name="toWorld"><scale x="40" y="25"/><rotate x="1" angle="%g"/><translate x="200" y="420" z="250"/></transform>'
+                 '%s<emitter type="area"><rgb name="radiance" value="20, 15, 10"/></emitter></shape>') % (ang + 90.0, '<boolean name="flipNormals" value="true"/>' if flipped else "")
+        xml = open(XML).read().replace("</scene>", shape + "</scene>")
+        xr = str(tmp_path / ("rect%d.xml" % flipped)); open(xr, "w").write(xml)
+        dest = str(tmp_path / ("rect%d" % flipped))
+        r = run(cli, "-o", dest, "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xr)
+        assert r.returncode == 0, r.stderr
+        a = np.deg2rad(ang + 90.0)
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        L = Rx @ np.diag([40.0, 25.0, 1.0])
+        T = np.concatenate([L, np.array([[200.0], [420.0], [250.0]])], 1)          # 3x4 toWorld
+        M = T.copy()
+        if flipped: M[:, 2] = -M[:, 2]                                              # toWorld * scale(1, 1, -1)
+        n = np.linalg.inv(M[:, :3]).T @ np.array([0.0, 0.0, 1.0]); n /= np.linalg.norm(n)
+        P = lambda x, y: T @ np.array([x, y, 0.0, 1.0])
+        v = [P(-1, -1), P(1, -1), P(1, 1), P(-1, 1)]
+        order = [[0, 1, 2], [2, 3, 0]]
+        if flipped: order = [[0, 2, 1], [2, 0, 3]]                                   # the reader swaps the last two vertices of a flipped triangle
+        sc = scenes.cornell_box(40, 30)
+        first = sc.ntri
+        q = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        sc.verts = np.concatenate([np.asarray(sc.verts, np.float64).reshape(-1, 9), np.array([[v[i] for i in o] for o in order]).reshape(2, 9)])
+        gray = len(sc.materials); sc.materials = list(sc.materials) + [scenes.diffuse((0.5, 0.5, 0.5))]
+        sc.tri_material = np.concatenate([np.asarray(sc.tri_material, np.int32), np.full(2, gray, np.int32)])
+        uvs = np.zeros((first + 2, 6)); has = np.zeros(first + 2, np.uint8)
+        for t, o in enumerate(order):
+            uvs[first + t] = np.array([q[i] for i in o], float).reshape(6); has[first + t] = 1
+        sc.uvs, sc.tri_has_uv = uvs, has
+        sc.emitters = list(sc.emitters) + [(first, 2, (20.0, 15.0, 10.0), M, tuple(n))]
+        out = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
+        for suffix in G.BUFFER_NAMES:
+            assert np.allclose(read_pfm(dest + suffix + ".pfm"), out[suffix], rtol=2e-6, atol=1e-7), (flipped, suffix)
