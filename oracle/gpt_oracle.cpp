@@ -5,9 +5,10 @@
  * single-threaded, brute-force ray casting) of the reference's G-PT per-sample hot path:
  * GradientPathTracer::evaluatePoint/evaluate, the shift mappings, vertex classification, the 15-put
  * accumulation of GradientPathIntegrator::renderBlock, and the Mitsuba pieces those call for the
- * scene subset the build carries (triangle soups with optional per-vertex normals, area / point / constant
- * environment emitters, diffuse / conductor / roughconductor (Beckmann, GGX, Phong) / dielectric BSDFs and the
- * twosided adapter, perspective sensor, the six reconstruction filters).  GPO_TRACE_MAIN=1 in the environment
+ * scene subset the build carries (triangle soups with optional per-vertex normals and texture coordinates (UV tangents), area /
+ * rectangle / point emitters, the constant environment and the environment MAP (envmap.cpp), diffuse / conductor / roughconductor
+ * (Beckmann, GGX, Phong) / dielectric BSDFs and the twosided adapter, bitmap textures with all four filter types (mipmap_oracle.hpp),
+ * perspective sensor with ray differentials, the six reconstruction filters).  GPO_TRACE_MAIN=1 in the environment
  * makes evaluate() print its main path and light-sample decisions (tools/gpu_fuzz_locate.py).  Only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
@@ -196,12 +197,12 @@ struct Tri {
 
 // `<texture type="bitmap">` (src/textures/bitmap.cpp) as the G-PT path evaluates it.  Texture2D::eval (texture.cpp:112-121) scales and
 // offsets its.uv; with filterType nearest / bilinear both BitmapTexture::eval overloads end in MIPMap::evalBox / evalBilinear on
-// level 0 (bitmap.cpp:431-452, mipmap.h:566-596,628-633), ray differentials or not -- the two filter types carried here ("ewa" and
-// "trilinear" read the MIP pyramid through the primary ray's differentials: not carried).  Texels are Float (the MIP map converts the
+// level 0 (bitmap.cpp:431-452, mipmap.h:566-596,628-633), ray differentials or not; "trilinear" and "ewa" (the default) do the same except
+// at the hit of a camera ray, whose UV partials drive the filtered lookup of oracle/mipmap_oracle.hpp.  Texels are Float (the MIP map converts the
 // file to Bitmap::EFloat), wrap modes as evalTexel (mipmap.h:503-561).  `scale` is the factor of BSDF::ensureEnergyConservation
 // (bsdf.cpp: 0.99 / max when the texture exceeds 1), applied to the interpolated value as ScaleTexture does.
 struct Texture {
-    int w = 0, h = 0, wrapU = 0, wrapV = 0, filter = 1;      // wrap: 0 repeat, 1 clamp, 2 mirror, 3 zero, 4 one; filter: 0 nearest, 1 bilinear
+    int w = 0, h = 0, wrapU = 0, wrapV = 0, filter = 1;      // wrap: 0 repeat, 1 clamp, 2 mirror, 3 zero, 4 one; filter: 0 nearest, 1 bilinear, 2 trilinear, 3 ewa
     Float uscale = 1, vscale = 1, uoffset = 0, voffset = 0, scale = 1;
     std::vector<Float> rgb;                                   // [h][w][3], top row first
     static int modulo(int a, int b) { const int r = a % b; return r < 0 ? r + b : r; }        // math::modulo, math.h
