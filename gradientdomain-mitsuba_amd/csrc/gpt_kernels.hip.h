@@ -105,8 +105,8 @@ struct MaterialD {           // 112 B (a multiple of 16: tables are staged into 
 };
 struct TriUV { Float uv[6]; };   // 48 B: per-vertex texture coordinates (u0 v0 u1 v1 u2 v2) in leaf order (only scenes that have any)
 // `<texture type="bitmap">` as the G-PT path evaluates it (src/textures/bitmap.cpp:431-452 -> MIPMap::evalBox / evalBilinear on level 0,
-// mipmap.h:566-596; filterType nearest | bilinear -- "ewa"/"trilinear" read the MIP pyramid through ray differentials and are refused by
-// the host).  Texels are doubles (the reference's MIP map holds Float), [h][w][3], top row first, in HBM.
+// mipmap.h:566-596; with filterType "trilinear" / "ewa" the hit of a camera ray instead gets TMIPMap::eval over the pyramid, :628-712).
+// Texels are doubles (the reference's MIP map holds Float), [h][w][3], top row first, level after level, in HBM.
 constexpr int TEX_MAX_LEVELS = 16, TEX_LUT_SIZE = 64;     // (MTS_MIPMAP_LUT_SIZE, mipmap.h:37)
 struct TexD {
     int w, h, wrapU, wrapV;     // wrap: 0 repeat, 1 clamp, 2 mirror, 3 zero, 4 one (ReconstructionFilter::EBoundaryCondition as bitmap.cpp:324-338 names them)
