@@ -68,6 +68,23 @@ def make(seed):
     md = int(rng.choice([-1, 2, 3, 5, 8])); strict = bool(rng.random() < 0.3)
     return sc, W, H, spp, md, strict, variant, what
 
+def oracle_spread(sc, ocfg, px, py, k, key, o):
+    """How far the ORACLE's own value of one sample moves under few-ulp perturbations of the geometry: uniform and per-axis scalings, and --
+    since a hit on an edge two triangles share is not moved off it by a scaling -- 32 seeded perturbations of every coordinate independently
+    (+-4 ulp).  The rounding-noise floor of an ill-conditioned sample."""
+    sens = 0.0
+    v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
+    trials = [(ax, kk) for ax in (None, 0, 1, 2) for kk in (1, 2, 3, -1, -2, -3)] + [("each", t) for t in range(32)]
+    for ax, kk in trials:
+        v = v0.copy()
+        if ax is None: v *= 1 + kk * 2.0 ** -52
+        elif ax == "each": v *= 1 + np.random.default_rng(kk).integers(-4, 5, v.shape) * 2.0 ** -52
+        else: v[:, ax] *= 1 + kk * 2.0 ** -52
+        sc2 = copy.deepcopy(sc); sc2.verts = v.reshape(np.asarray(sc.verts).shape)
+        O2 = go.Scene(sc2); o2 = O2.evaluate_point(ocfg, px, py, k); O2.close()
+        sens = max(sens, float(np.abs(np.asarray(o2[key]) - np.asarray(o[key])).max()))
+    return sens
+
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -122,16 +139,7 @@ for seed in range(first, first + count):
                         for key in ("throughput", "gradients", "neighbours"):
                             diff = float(np.abs(np.asarray(g[key]) - np.asarray(o[key])).max())
                             if diff <= 1e-11 * (1 + float(np.abs(np.asarray(o[key])).max())): continue
-                            sens = 0.0
-                            v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
-                            for ax in (None, 0, 1, 2):
-                                for kk in (1, 2, 3, -1, -2, -3):
-                                    v = v0.copy()
-                                    if ax is None: v *= 1 + kk * 2.0 ** -52
-                                    else: v[:, ax] *= 1 + kk * 2.0 ** -52
-                                    sc2 = copy.deepcopy(sc); sc2.verts = v.reshape(np.asarray(sc.verts).shape)
-                                    O2 = go.Scene(sc2); o2 = O2.evaluate_point(ocfg, px, py, k); O2.close()
-                                    sens = max(sens, float(np.abs(np.asarray(o2[key]) - np.asarray(o[key])).max()))
+                            sens = oracle_spread(sc, ocfg, px, py, k, key, o)
                             if diff > 20 * sens:
                                 print("FILM MISMATCH seed", seed, variant, what, stages, G.BUFFER_NAMES[b], d, "sample", (px, py, k), key, diff, "oracle spread", sens); sys.exit(1)
                             explained = True

@@ -28,14 +28,5 @@ for (px, py) in cands:
         for key in ("veryDirect", "throughput", "gradients", "neighbours"):
             diff = float(np.abs(np.asarray(g[key]) - np.asarray(o[key])).max())
             if diff > 1e-12 * (1 + float(np.abs(np.asarray(o[key])).max())):
-                sens = 0.0
-                v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
-                for ax in (None, 0, 1, 2):
-                    for kk in (1, 2, 3, -1, -2, -3):
-                        v = v0.copy()
-                        if ax is None: v *= 1 + kk * 2.0 ** -52
-                        else: v[:, ax] *= 1 + kk * 2.0 ** -52
-                        sc2 = copy.deepcopy(sc); sc2.verts = v.reshape(np.asarray(sc.verts).shape)
-                        o2 = go.Scene(sc2).evaluate_point(ocfg, px, py, k)
-                        sens = max(sens, float(np.abs(np.asarray(o2[key]) - np.asarray(o[key])).max()))
+                sens = ff.oracle_spread(sc, ocfg, px, py, k, key, o)
                 print("  sample", (px, py, k), key, "HIP-oracle diff %.3e" % diff, "value scale %.3e" % float(np.abs(np.asarray(o[key])).max()), "oracle's own spread under ulp scalings %.3e" % sens)
