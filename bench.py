@@ -202,7 +202,20 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-4); 2 is the metric's configuration")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-height strips instead of rebalancing them after the warm-up pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the last step's reconstruction and the four gathered solver images to this .npz (tests)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: launch the N ranks here (one process per GPU, rendezvous on 127.0.0.1), exactly as
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` would; rank 0's JSON line is the output.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is what runs\n" % (a.gpus, os.environ["WORLD_SIZE"]))
     global W, H, PRESET, SCENE
     SCENE, W, H, spp_cfg, PRESET = CONFIGS[a.config]
     if a.spp == SPP:
@@ -240,9 +253,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last_out = [None]
+
     def step():
         """-> (rays of this rank, render kernel ms, solve seconds, halo bytes)"""
-        sr.render(a.spp)
+        last_out[0] = sr.render(a.spp)
         return sr.last["rays"], sr.last["render_ms"], sr.last["solve_s"], sr.last["halo_bytes"]
 
     for _ in range(a.warmup):
@@ -272,6 +287,9 @@ def main():
     else:
         rays = float(rays)
 
+    if rank == 0 and a.dump:
+        import numpy as np
+        np.savez(a.dump, final=last_out[0].cpu().numpy(), images=sr.last["images"].cpu().numpy(), strips=np.array(sr.strips))
     if rank == 0:
         mray = rays / wall / 1e6
         mpix_iter = W * H * iters * a.steps / solve_s / 1e6

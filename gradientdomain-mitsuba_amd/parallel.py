@@ -193,7 +193,8 @@ class StripRenderer:
     def render(self, spp, seed=5489):
         """One frame.  Rank 0 returns the reconstruction [H, W, 3] (device tensor; if the integrator does not reconstruct, the -final
         preview of gpt.cpp:1314-1322 = what gpt.GradientPathIntegrator.render()['-final'] holds in that mode) -- other ranks None.  self.last: rays, render_ms, solve_s, halo_bytes of this rank; on rank 0 also the four
-        gathered solver images under "images" ([4, H, W, 3]: throughput, dx, dy, direct)."""
+        gathered solver images under "images" ([4, H, W, 3]: throughput, dx, dy, direct; [5, H, W, 3] with the -final preview as a fifth
+        when the integrator does not reconstruct)."""
         film, integ = self.film, self.integ
         cfg = integ.config(spp, seed)
         tick = [time.perf_counter()]

@@ -1,0 +1,42 @@
+"""bench.py's own launcher: `python bench.py --gpus N` with no torchrun around it starts its N ranks itself (one process per GPU;
+here two ranks share the box's one device over gloo -- the functional run of the N > 1 path) and rank 0 prints ONE JSON line with
+n_gpus == N.  The frame of the two-strip run equals the one-rank frame (same samples; border sums to rounding).
+What is sharded: the reference's 32x32 blocks with their one-pixel border (gpt_proc.cpp:52-56,137-149)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(tmp_path, gpus, extra=()):
+    dump = str(tmp_path / ("dump%d.npz" % gpus))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--config", "1", "--spp", "2",
+           "--no-cpu-baseline", "--no-rebalance", "--backend", "gloo", "--dump", dump] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), np.load(dump)
+
+
+def test_bench_launches_its_own_ranks(gpu_required, tmp_path):
+    one, d1 = run_bench(tmp_path, 1)
+    two, d2 = run_bench(tmp_path, 2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["strip_rows"] == [256, 256] and one["config"]["strip_rows"] == [512]
+    assert two["rays_per_step"] == one["rays_per_step"]                       # same samples, same rays, whoever renders them
+    assert two["halo_bytes_per_rank"] > 0 and one["halo_bytes_per_rank"] == 0
+    assert two["metric"] == one["metric"] and two["unit"] == "Mray/s" and two["scaling"] == "strong"
+    # the four solver images: identical away from the strip border, equal to rounding of the fp64 border sums on it
+    assert np.allclose(d2["images"], d1["images"], rtol=0, atol=1e-6)
+    far = np.ones(512, bool); far[254:258] = False
+    assert np.array_equal(d2["images"][:, far], d1["images"][:, far])
+    assert np.abs(d2["final"] - d1["final"]).max() <= 5e-5
+    assert "roofline" in one and "roofline" in two

@@ -311,6 +311,39 @@ def test_whole_frame_at_configuration_size_matches_oracle(G, name, W, H, spp, md
     F.close(); S.close()
 
 
+def test_config1_cornell_512x512_frame_samples_and_l2_reconstruction(G):
+    """BASELINE config 1 (Cornell box, 512x512, 64 spp, L2 reconstruct): the whole frame against the oracle at 2 spp (every pixel of the
+    five buffers, both ray counters); the 64 spp frame through the integrator (render + develop + L2D) with its size-independent
+    properties, single samples spot-checked against the oracle at this geometry, and the L2D reconstruction of the HIP path's own
+    developed images against the oracle's solver."""
+    W = H = 512
+    sc = scenes.cornell_box(W, H, "diffuse")
+    S, O = G.Scene(sc), go.Scene(sc)
+    F = G.Film(S)
+    integ = G.GradientPathIntegrator(maxDepth=-1, reconstructL1=False, reconstructL2=True)
+    integ.renderBlock(S, F, integ.config(2), (0, 0, W, H))
+    acc = F.accum(); st = F.stats()
+    oacc, orays = O.render(go.config(maxDepth=-1, spp=2))
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays and st["paths"] == W * H * 2
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    F.close()
+    spp = 64
+    out = integ.render(S, spp)
+    assert integ.stats["paths"] == W * H * spp and all(np.isfinite(v).all() for v in out.values())
+    assert (out["-direct"] >= 0).all() and (out["-throughput"] >= -1e-6).all()
+    cfg, ocfg = integ.config(spp), go.config(maxDepth=-1, spp=spp)
+    rng = np.random.default_rng(21)
+    for _ in range(25):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g, o = S.evaluate_point(cfg, px, py, s), O.evaluate_point(ocfg, px, py, s)
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (px, py, s, k)
+    ref = po.solve(po.preset("L2D"), out["-dx"].ravel(), out["-dy"].ravel(), out["-throughput"].ravel(), out["-direct"].ravel(), W, H).reshape(H, W, 3)
+    assert np.abs(out["-final"] - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    S.close(); O.close()
+
+
 def test_atrium_hbm_bvh_film_matches_oracle(G):
     """Sponza-class stand-in (20k triangles): the BVH and triangle tables do not fit the LDS budget, so traversal reads
     node packets from HBM/L2 and the shading tables through the global path; diffuse + rough-conductor materials."""

@@ -309,16 +309,18 @@ def test_full_size_l1d_1280x720(P):
 
 
 def test_full_size_l1d_1920x1080_config3(P):
-    """BASELINE config 3 size (2.07 Mpixel, above the persistent kernel's range: the multi-kernel graphs run).  The oracle takes
-    minutes here, so: determinism, the fused path against the reference op sequence (itself checked against the oracle at the
-    smaller sizes), and the first IRLS iteration (== an L2 solve from x0 = throughput) against the oracle."""
+    """BASELINE config 3 size (2.07 Mpixel, above the persistent kernel's range: the multi-kernel graphs run) against the ORACLE's
+    L1D (the sequential restatement: ~30 s on one core for 20 x 50 iterations at this size), the bars of the 1280x720 L1D test;
+    plus determinism, the fused path against the reference op sequence, and the L2D solve against the oracle."""
     w, h = 1920, 1080
     dx, dy, tp, direct = po.synth_inputs(w, h)
     a, it = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 2)
     b, _ = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 2)
     assert it == 1000 and np.array_equal(a, b)
+    ref1 = po.solve(po.preset("L1D"), dx, dy, tp, direct, w, h)
+    assert np.abs(a - ref1).max() <= 1e-3 and np.abs(a - ref1).mean() <= 2e-5
     u, _ = run_solver(P, "L1D", dx, dy, tp, direct, w, h, 0)
-    assert np.abs(u - a).max() <= 1e-3 and np.abs(u - a).mean() <= 2e-5
+    assert np.abs(u - ref1).max() <= 1e-3 and np.abs(u - ref1).mean() <= 2e-5
     l2, _ = run_solver(P, "L2D", dx, dy, tp, direct, w, h, 2)
     ref = po.solve(po.preset("L2D"), dx, dy, tp, direct, w, h)
     assert np.abs(l2 - ref).max() <= 5e-5
