@@ -1,0 +1,1241 @@
+/*
+ * oracle/gbdpt_oracle.hpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Included by gpt_oracle.cpp inside its anonymous namespace (it uses
+ * that file's scene, ray casting, BSDF, emitter and sensor restatements).
+ *
+ * CPU restatement of the reference's G-BDPT per-sample hot path (BASELINE config 5):
+ *   GBDPTRenderer::process / evaluate / createShiftablePath / createShiftedLightPath / combine*Data
+ *                                                          src/integrators/gbdpt/gbdpt_proc.cpp:86-256,259-534,544-662
+ *   GBDPTWorkResult::putSample / putLightSample, GBDPTProcess::develop      gbdpt_wr.h:56-62, gbdpt_proc.cpp:694-706, multifilm.cpp:317-362
+ *   Path::alternatingRandomWalkFromPixel, miWeightBaseNoSweep_GBDPT, miWeightGradNoSweep_GBDPT, halfJacobian_GBDPT,
+ *   calcSpecularPDFChange, G, isConnectable_GBDPT          src/libbidir/path.cpp:26-454,548-631
+ *   PathVertex::sampleNext / sampleSensor / perturbDirection / eval / evalPdf / cast / update / connect /
+ *   getSamplePosition / updateSamplePosition               src/libbidir/vertex.cpp:35-384,488-679,781-1022,1115-1211,1298-1370
+ *   PathEdge::sampleNext / perturbDirection / connect / pathConnectAndCollapse / evalCached     src/libbidir/edge.cpp:27-131,169-287,442-574
+ *   ManifoldPerturbation::computeMuRec / getSpecularChainEndGBDPT / generateOffsetPathGBDPT / perturbDirection
+ *                                                          src/libbidir/mut_manifold.cpp:806-986,1230-1296
+ *   SpecularManifold::det / multiG / G (the cases without a specular vertex in the chain)         src/libbidir/manifold.cpp:759-775,871-906
+ *   PerspectiveCamera::importance / samplePosition / sampleDirection / pdfDirection / evalDirection / getSamplePosition
+ *                                                          src/sensors/perspective.cpp:190-247,300-410
+ *   AreaLight::samplePosition / evalPosition / pdfPosition / sampleDirection / evalDirection / pdfDirection   src/emitters/area.cpp:93-142
+ *   Scene::sampleEmitterPosition / pdfEmitterPosition      src/librender/scene.cpp:985-1006
+ *
+ * SCOPE (stage A/B): every surface vertex of a path must be CONNECTABLE in the sense of Path::isConnectable_GBDPT (path.cpp:30-47): a BSDF
+ * with a smooth component whose roughness is >= shiftThreshold -- diffuse and rough conductors, plain or two-sided, textured or not; area
+ * (triangle-mesh / rectangle) emitters; the perspective sensor; the box filter (the only one G-BDPT supports, gbdpt.cpp:70-71).  Then a
+ * specular chain never occurs: propagatePerturbation has nothing to propagate and manifoldWalk is not entered (mut_manifold.cpp:873,882),
+ * SpecularManifold::det returns 1 (manifold.cpp:774) and every generalized geometry term is a plain G.  A sample that meets a
+ * non-connectable surface vertex is counted in `unsupported` and contributes nothing; tests assert the count is zero.
+ *
+ * PARITY UNPINNED, like the rest of this oracle: nothing here was compared with output of the reference (it cannot be built in this image).
+ * Random numbers: the counter-based stream of gpt_oracle.cpp (one per pixel and sample), consumed in the reference's order.
+ */
+namespace gb {
+
+enum { ERadiance = 0, EImportance = 1 };                                                   // include/mitsuba/render/common.h:33-43
+enum { EInvalidMeasure = 0, ESolidAngle = 1, ELength = 2, EArea = 3, EDiscrete = 4 };      // common.h:56-67
+enum { EInvalid = 0, ESensorSupernode = 1, EEmitterSupernode = 2, ESensorSample = 4, EEmitterSample = 8, ESurfaceInteraction = 16,
+       ESupernode = 3 };                                                                   // include/mitsuba/bidir/vertex.h:67-87
+enum { EValueImp = 0x01, EValueRad = 0x02, ECosineImp = 0x04, ECosineRad = 0x08, EInverseSquareFalloff = 0x10, ETransmittance = 0x20,
+       EGeometricTerm = 0x04 | 0x08 | 0x10, EGeneralizedGeometricTerm = 0x04 | 0x08 | 0x10 | 0x20 };   // include/mitsuba/bidir/edge.h:171-185
+
+struct Config { int maxDepth, rrDepth, lightImage, spp; Float shiftThreshold; uint64_t seed; };
+
+struct PRec { V3 p, n; Float pdf = 0; int measure = 0; Float uvx = 0, uvy = 0; int object = -1; };   // PositionSamplingRecord, common.h:70-150
+
+struct Vertex {                                     // PathVertex, vertex.h
+    int type = EInvalid;
+    bool degenerate = false;
+    int measure = EInvalidMeasure;
+    int componentType = 0, sampledComponentIndex = 0;
+    V3 weight[2];
+    Float pdf[2] = {0, 0};
+    Float rrWeight = 0;
+    Intersection its;                               // ESurfaceInteraction
+    gpo_material mat;                               // its.getBSDF() with its texture resolved at its.uv (no ray differentials in libbidir)
+    PRec prec;                                      // sensor / emitter samples (the reference keeps both in one union: cast() overwrites)
+    bool isSupernode() const { return (type & ESupernode) != 0; }
+    bool isConnectable() const { return !degenerate && measure != EDiscrete; }             // vertex.h:750
+    bool isSurface() const { return type == ESurfaceInteraction; }
+    bool isOnSurface() const { return type == ESurfaceInteraction || type == EEmitterSample || type == ESensorSample; }   // vertex.h:592-596: area lights and the perspective sensor are EOnSurface
+    V3 position() const { return type == ESurfaceInteraction ? its.p : prec.p; }           // vertex.cpp:1213-1229
+    V3 shadingNormal() const { return type == ESurfaceInteraction ? its.sh.n : prec.n; }   // :1231-1243
+    V3 geometricNormal() const { return type == ESurfaceInteraction ? its.geoN : prec.n; } // :1245-1257
+};
+
+struct Edge {                                       // PathEdge, edge.h
+    V3 d;
+    Float length = 0;
+    V3 weight[2];
+    Float pdf[2] = {0, 0};
+};
+
+struct Path {                                       // Path, path.h: m_vertices / m_edges of POINTERS (base and offset paths share vertices)
+    std::vector<Vertex *> v;
+    std::vector<Edge *> e;
+    int length() const { return (int)e.size(); }
+    int vertexCount() const { return (int)v.size(); }
+    Vertex *vertexOrNull(int i) const { return (i < 0 || i >= (int)v.size()) ? nullptr : v[i]; }
+    Edge *edgeOrNull(int i) const { return (i < 0 || i >= (int)e.size()) ? nullptr : e[i]; }
+    void reverse() { std::reverse(v.begin(), v.end()); std::reverse(e.begin(), e.end()); }   // path.cpp:633-636
+    void clear() { v.clear(); e.clear(); }
+};
+
+struct Pool {                                       // MemoryPool: per sample, released wholesale
+    std::deque<Vertex> vs;
+    std::deque<Edge> es;
+    Vertex *allocVertex() { vs.emplace_back(); return &vs.back(); }
+    Edge *allocEdge() { es.emplace_back(); return &es.back(); }
+    Vertex *clone(const Vertex *o) { vs.push_back(*o); return &vs.back(); }
+};
+
+struct Ctx {
+    const Scene &sc;
+    Config cfg;
+    Float invLin[9];                                // linear part of the inverse camera transform (trafo.inverse() applied to a direction)
+    V3 camPos, camDir;
+    Float rectX, rectY, normalization;              // m_imageRect half extents and 1 / its area, perspective.cpp:167-173
+    uint64_t unsupported = 0;
+};
+
+inline void cameraSetup(Ctx &c)
+{
+    const double *M = c.sc.cam.toWorld;
+    const Float a = M[0], b = M[1], cc = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
+    const Float A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;                    // adjugate / determinant, a fixed operation order
+    const Float det = a * A + b * B + cc * C, r = 1.0 / det;
+    c.invLin[0] = A * r; c.invLin[1] = (cc * h - b * i) * r; c.invLin[2] = (b * f - cc * e) * r;
+    c.invLin[3] = B * r; c.invLin[4] = (a * i - cc * g) * r; c.invLin[5] = (cc * d - a * f) * r;
+    c.invLin[6] = C * r; c.invLin[7] = (b * g - a * h) * r; c.invLin[8] = (a * e - b * d) * r;
+    c.camPos = V3(M[3], M[7], M[11]);                                                      // trafo(Point(0))
+    c.camDir = V3(M[2], M[6], M[10]);                                                      // trafo(Vector(0, 0, 1)), perspective.cpp:303-305
+    c.rectX = c.sc.tanHalf; c.rectY = c.sc.tanHalf / c.sc.aspect;                           // sampleToCamera(0,0,0) / z and (1,1,0) / z written out (crop == film)
+    c.normalization = 1.0 / ((2 * c.rectX) * (2 * c.rectY));
+}
+inline V3 camToLocal(const Ctx &c, V3 d) { return mul3(c.invLin, d); }
+inline V3 camToWorld(const Ctx &c, V3 d)
+{
+    const double *M = c.sc.cam.toWorld;
+    return V3(M[0] * d.x + M[1] * d.y + M[2] * d.z, M[4] * d.x + M[5] * d.y + M[6] * d.z, M[8] * d.x + M[9] * d.y + M[10] * d.z);
+}
+
+// PerspectiveCameraImpl::importance, perspective.cpp:190-247
+inline Float importance(const Ctx &c, V3 d)
+{
+    const Float cosT = cosTheta(d);
+    if (cosT <= 0) return 0.0;
+    const Float invCosTheta = 1.0 / cosT;
+    const Float px = d.x * invCosTheta, py = d.y * invCosTheta;
+    if (!(px >= -c.rectX && px <= c.rectX && py >= -c.rectY && py <= c.rectY)) return 0.0;   // AABB2::contains
+    return c.normalization * invCosTheta * invCosTheta * invCosTheta;
+}
+// m_sampleToCamera(Point(sx, sy, 0)) normalised: the direction through a film position given in [0,1]^2 (perspective.cpp:150-156 written out)
+inline V3 sampleToCameraDir(const Ctx &c, Float sxn, Float syn)
+{
+    const gpo_camera &cam = c.sc.cam;
+    return normalize(V3((1 - 2 * sxn) * cam.nearClip * c.sc.tanHalf, (1 - 2 * syn) / c.sc.aspect * cam.nearClip * c.sc.tanHalf, cam.nearClip));
+}
+// PerspectiveCameraImpl::getSamplePosition, perspective.cpp:393-410 (m_cameraToSample written out: the inverse of the map above)
+inline bool sensorSamplePosition(const Ctx &c, V3 dWorld, Float &ox, Float &oy)
+{
+    const V3 local = camToLocal(c, dWorld);
+    if (local.z <= 0) return false;
+    const Float sx = 0.5 * (1 - local.x / (local.z * c.sc.tanHalf)), sy = 0.5 * (1 - local.y * c.sc.aspect / (local.z * c.sc.tanHalf));
+    if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return false;
+    ox = sx * c.sc.cam.width; oy = sy * c.sc.cam.height;
+    return true;
+}
+
+// ---- emitters ------------------------------------------------------------------------------------------------------------------------
+// Scene::sampleEmitterPosition (scene.cpp:985-1001) -> AreaLight::samplePosition (area.cpp:93-97) -> TriMesh / Rectangle::samplePosition
+inline V3 sampleEmitterPosition(const Ctx &c, PRec &pRec, Float sx, Float sy)
+{
+    const Scene &sc = c.sc;
+    Float emPdf;
+    const size_t index = sc.emitterPDF.sampleReuse(sx, emPdf);
+    const Emitter &em = sc.emitters[index];
+    if (em.rectangle) {                                                                    // rectangle.cpp:210-216
+        const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
+        const Float *M = em.rect;
+        pRec.p = V3(M[0] * lx + M[1] * ly + M[2] * 0.0 + M[3], M[4] * lx + M[5] * ly + M[6] * 0.0 + M[7], M[8] * lx + M[9] * ly + M[10] * 0.0 + M[11]);
+        pRec.n = em.rectN;
+        pRec.uvx = sx; pRec.uvy = sy;
+    } else {                                                                               // trimesh.cpp:412-423, triangle.cpp:24-59
+        const std::vector<Float> &cdf = em.cdf;
+        auto entry = std::lower_bound(cdf.begin(), cdf.end(), sy);
+        size_t ti = std::min(cdf.size() - 2, (size_t)std::max((std::ptrdiff_t)0, (std::ptrdiff_t)(entry - cdf.begin()) - 1));
+        while ((cdf[ti + 1] - cdf[ti]) == 0 && ti < cdf.size() - 1) ++ti;
+        sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
+        const Tri &tr = sc.tris[em.firstTri + ti];
+        const Float a = safe_sqrt(1.0 - sx);
+        const Float bx = 1 - a, by = a * sy;
+        const V3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
+        pRec.p = tr.p0 + (sideA * bx) + (sideB * by);
+        pRec.n = normalize(cross(sideA, sideB));
+        pRec.uvx = bx; pRec.uvy = by;
+    }
+    pRec.pdf = em.invSurfaceArea;
+    pRec.measure = EArea;
+    pRec.object = (int)index;
+    pRec.pdf *= emPdf;
+    const Float area = 1.0 / em.invSurfaceArea;
+    const V3 power = em.radiance * PI * area;                                              // m_power = m_radiance * M_PI * getSurfaceArea(), area.cpp:196
+    return power / emPdf;
+}
+inline Float pdfEmitterPosition(const Ctx &c, const PRec &pRec)                            // scene.cpp:1003-1006
+{
+    return c.sc.emitters[pRec.object].invSurfaceArea * (1.0 * c.sc.emitterPDF.normalization);
+}
+inline Float areaDirection(V3 d, V3 n, int measure)                                        // AreaLight::evalDirection / pdfDirection, area.cpp:124-142
+{
+    Float dp = dot(d, n);
+    if (measure != ESolidAngle || dp < 0) dp = 0.0;
+    return INV_PI * dp;
+}
+
+inline int bsdfMeasure(int m) { return m == EDiscrete ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE; }
+inline bool hasSmooth(const gpo_material &m) { return (bsdfType(m) & ESmooth) != 0; }
+
+// Path::isConnectable_GBDPT, path.cpp:30-47
+inline bool isConnectableGBDPT(const Vertex *va, Float threshold)
+{
+    if (!va->isConnectable()) return false;
+    if (va->type & (ESupernode | ESensorSample | EEmitterSample)) return true;
+    const Float roughness = getRoughness(va->mat);
+    if (roughness < threshold) return false;
+    return true;
+}
+
+struct Tracer {
+    Ctx &c;
+    Rng &rng;
+    Pool &pool;
+    Tracer(Ctx &c_, Rng &r_, Pool &p_) : c(c_), rng(r_), pool(p_) {}
+
+    // ---- PathEdge ----------------------------------------------------------------------------------------------------------------
+    void fillSurface(Vertex *succ) const
+    {
+        succ->type = ESurfaceInteraction;
+        Ray none;
+        succ->mat = matOf(c.sc, succ->its, none);
+        succ->degenerate = !(hasSmooth(succ->mat) || c.sc.tris[succ->its.prim].emitter >= 0);   // edge.cpp:44-45 (no sensor shapes)
+    }
+    // PathEdge::sampleNext, edge.cpp:27-71 (no media)
+    bool edgeSampleNext(Edge *e, const Ray &ray, Vertex *succ, int mode) const
+    {
+        if (!rayIntersect(c.sc, ray, succ->its)) return false;
+        fillSurface(succ);
+        e->length = succ->its.t;
+        if (e->length == 0) return false;
+        e->weight[ERadiance] = e->weight[EImportance] = V3(1.0);
+        e->pdf[ERadiance] = e->pdf[EImportance] = 1.0;
+        e->d = ray.d;
+        if (mode == ERadiance) e->d = -e->d;
+        return true;
+    }
+    // PathEdge::perturbDirection, edge.cpp:73-131 (no media: wantMedium is false, desiredType is not consulted otherwise)
+    bool edgePerturbDirection(Edge *e, const Ray &ray, Float dist, Vertex *succ, int mode) const
+    {
+        const bool surface = rayIntersect(c.sc, ray, succ->its);
+        if (dist <= 0) return false;
+        if (!surface) return false;
+        fillSurface(succ);
+        e->length = succ->its.t;
+        e->d = ray.d;
+        if (mode == ERadiance) e->d = -e->d;
+        if (e->length == 0) return false;
+        e->weight[ERadiance] = e->weight[EImportance] = V3(1.0);
+        e->pdf[ERadiance] = e->pdf[EImportance] = 1.0;
+        return true;
+    }
+    // PathEdge::connect, edge.cpp:221-287
+    bool edgeConnect(Edge *e, const Vertex *vs, const Vertex *vt) const
+    {
+        if (vs->type == EEmitterSupernode || vt->type == ESensorSupernode) {
+            const Float radianceTransport = vt->type == ESensorSupernode ? 1.0 : 0.0, importanceTransport = 1 - radianceTransport;
+            e->d = V3(0.0); e->length = 0.0;
+            e->pdf[ERadiance] = radianceTransport; e->pdf[EImportance] = importanceTransport;
+            e->weight[ERadiance] = V3(radianceTransport); e->weight[EImportance] = V3(importanceTransport);
+        } else {
+            const V3 vsp = vs->position(), vtp = vt->position();
+            e->d = vsp - vtp;
+            e->length = length(e->d);
+            e->d = e->d / e->length;
+            Ray ray(vtp, e->d, vt->isOnSurface() ? Epsilon : 0.0, e->length * (vs->isOnSurface() ? (1 - ShadowEpsilon) : 1.0));
+            if (rayIntersectShadow(c.sc, ray)) return false;
+            e->weight[ERadiance] = e->weight[EImportance] = V3(1.0);
+            e->pdf[ERadiance] = e->pdf[EImportance] = 1.0;
+        }
+        e->d = -e->d;
+        return true;
+    }
+    // PathEdge::pathConnectAndCollapse, edge.cpp:442-574 (no media, no ENull BSDFs: any surface in between is an occluder)
+    bool edgePathConnectAndCollapse(Edge *e, const Vertex *vs, const Vertex *vt, int &interactions) const
+    {
+        if (vs->type == EEmitterSupernode || vt->type == ESensorSupernode) {
+            const Float radianceTransport = vt->type == ESensorSupernode ? 1.0 : 0.0, importanceTransport = 1 - radianceTransport;
+            e->length = 0.0; e->d = V3(0.0);
+            e->pdf[ERadiance] = radianceTransport; e->pdf[EImportance] = importanceTransport;
+            e->weight[ERadiance] = V3(radianceTransport); e->weight[EImportance] = V3(importanceTransport);
+            interactions = 0;
+        } else {
+            const V3 vsp = vs->position(), vtp = vt->position();
+            e->d = vsp - vtp;
+            e->length = length(e->d);
+            interactions = 0;
+            if (e->length == 0) return false;
+            e->d = e->d / e->length;
+            const Float lengthFactor = vs->isOnSurface() ? (1 - ShadowEpsilon) : 1.0;
+            Ray ray(vtp, e->d, vt->isOnSurface() ? Epsilon : 0.0, e->length * lengthFactor);
+            e->weight[ERadiance] = e->weight[EImportance] = V3(1.0);
+            e->pdf[ERadiance] = e->pdf[EImportance] = 1.0;
+            Intersection its;
+            if (rayIntersect(c.sc, ray, its)) return false;
+        }
+        e->d = -e->d;
+        return true;
+    }
+    // PathEdge::evalCached, edge.cpp:169-219 (channel-wise; the callers here need a scalar for geometry terms, a spectrum otherwise)
+    V3 edgeEvalCached(const Edge *e, const Vertex *pred, const Vertex *succ, unsigned what) const
+    {
+        V3 result(1.0);
+        if (e->length == 0) {
+            if (what & EValueImp) result = result * (pred->weight[EImportance] * pred->pdf[EImportance]);
+            if (what & EValueRad) result = result * (succ->weight[ERadiance] * succ->pdf[ERadiance]);
+        } else {
+            if (what & EValueImp) {
+                Float tmp = pred->pdf[EImportance];
+                if (pred->isConnectable()) {
+                    tmp *= e->length * e->length;
+                    if (succ->isOnSurface()) tmp /= dot(succ->geometricNormal(), e->d);
+                    if (pred->isOnSurface() && !(what & ECosineImp)) tmp /= dot(pred->shadingNormal(), e->d);
+                }
+                result = result * (pred->weight[EImportance] * std::abs(tmp));
+            } else if ((what & ECosineImp) && pred->isOnSurface() && pred->isConnectable()) {
+                result = result * std::abs(dot(pred->shadingNormal(), e->d));
+            }
+            if (what & EValueRad) {
+                Float tmp = succ->pdf[ERadiance];
+                if (succ->isConnectable()) {
+                    tmp *= e->length * e->length;
+                    if (pred->isOnSurface()) tmp /= dot(pred->geometricNormal(), e->d);
+                    if (succ->isOnSurface() && !(what & ECosineRad)) tmp /= dot(succ->shadingNormal(), e->d);
+                }
+                result = result * (succ->weight[ERadiance] * std::abs(tmp));
+            } else if ((what & ECosineRad) && succ->isOnSurface() && succ->isConnectable()) {
+                result = result * std::abs(dot(succ->shadingNormal(), e->d));
+            }
+            if (what & EInverseSquareFalloff) result = result / (e->length * e->length);
+            if (what & ETransmittance) result = result * (e->weight[EImportance] * e->pdf[EImportance]);
+        }
+        return result;
+    }
+
+    // ---- PathVertex -----------------------------------------------------------------------------------------------------------------
+    // the ESurfaceInteraction branch shared by sampleNext and perturbDirection: the adjoint-BSDF factor for shading normals, vertex.cpp:213-221,611-619
+    static void adjoint(Vertex *v, int mode, V3 wiL, V3 woL, Float wiDotGeoN, Float woDotGeoN)
+    {
+        if (mode == EImportance) v->weight[EImportance] = v->weight[EImportance] * std::abs((cosTheta(wiL) * woDotGeoN) / (cosTheta(woL) * wiDotGeoN));
+        else v->weight[EImportance] = v->weight[EImportance] * std::abs((cosTheta(woL) * wiDotGeoN) / (cosTheta(wiL) * woDotGeoN));
+    }
+    void toArea(Vertex *v, int mode, const Vertex *pred, const Edge *predEdge, const Edge *succEdge, const Vertex *succ, V3 rayD) const
+    {                                                                                      // vertex.cpp:294-307,663-676
+        if (v->measure == ESolidAngle) {
+            v->measure = EArea;
+            v->pdf[mode] /= succEdge->length * succEdge->length;
+            if (succ->isOnSurface()) v->pdf[mode] *= std::abs(dot(rayD, succ->geometricNormal()));
+            if (predEdge->length != 0.0) {
+                v->pdf[1 - mode] /= predEdge->length * predEdge->length;
+                if (pred->isOnSurface()) v->pdf[1 - mode] *= std::abs(dot(predEdge->d, pred->geometricNormal()));
+            }
+        }
+    }
+    // PathVertex::sampleNext, vertex.cpp:35-310
+    bool sampleNext(Vertex *v, const Vertex *pred, const Edge *predEdge, Edge *succEdge, Vertex *succ, int mode, bool russianRoulette, V3 *throughput)
+    {
+        Ray ray;
+        *succEdge = Edge(); *succ = Vertex();
+        v->rrWeight = 1.0;
+        switch (v->type) {
+        case EEmitterSupernode: {
+            const Float sx = rng.next1D(), sy = rng.next1D();
+            const V3 result = sampleEmitterPosition(c, succ->prec, sx, sy);
+            if (isZero(result)) return false;
+            v->weight[EImportance] = result;
+            v->pdf[EImportance] = succ->prec.pdf;
+            v->measure = succ->prec.measure;
+            succ->type = EEmitterSample;
+            succ->degenerate = false;                                                      // area lights have no EDeltaDirection
+            succEdge->weight[EImportance] = V3(1.0);
+            succEdge->pdf[EImportance] = 1.0;
+            return true;
+        }
+        case EEmitterSample: {                                                             // :97-121, AreaLight::sampleDirection area.cpp:114-122
+            const Float sx = rng.next1D(), sy = rng.next1D();
+            const V3 local = squareToCosineHemisphere(sx, sy);
+            Frame fr; fr.n = v->prec.n; coordinateSystem(fr.n, fr.s, fr.t);
+            const V3 d = fr.toWorld(local);
+            const Float dpdf = INV_PI * cosTheta(local);                                   // squareToCosineHemispherePdf, warp.h
+            const V3 result(1.0);
+            v->weight[EImportance] = result;
+            v->weight[ERadiance] = result * dpdf * (1.0 / std::abs(dot(d, v->prec.n)));
+            v->pdf[EImportance] = dpdf;
+            v->pdf[ERadiance] = 1.0;
+            v->measure = ESolidAngle;
+            ray = Ray(v->prec.p, d);
+            break;
+        }
+        case ESurfaceInteraction: {                                                        // :149-231
+            const Intersection &its = v->its;
+            const V3 wi = normalize(pred->position() - its.p);
+            const V3 wiL = its.sh.toLocal(wi);
+            const Float sx = rng.next1D(), sy = rng.next1D();
+            const BSDFSample bs = bsdfSample(v->mat, wiL, sx, sy);
+            v->weight[mode] = bs.weight; v->pdf[mode] = bs.pdf;
+            if (isZero(v->weight[mode])) return false;
+            v->measure = (bs.sampledType & ESmooth) ? ESolidAngle : EDiscrete;             // BSDF::getMeasure, bsdf.h:313-324
+            v->componentType = bs.sampledType;
+            v->sampledComponentIndex = (bs.sampledType & EDeltaTransmission) ? 1 : 0;      // dielectric.cpp: component 1 is the transmission
+            const V3 wo = its.sh.toWorld(bs.wo);
+            const Float wiDotGeoN = dot(its.geoN, wi), woDotGeoN = dot(its.geoN, wo);
+            if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(bs.wo) <= 0) return false;
+            v->pdf[1 - mode] = bsdfPdf(v->mat, bs.wo, wiL, bsdfMeasure(v->measure));         // bRec.reverse()
+            if (v->pdf[1 - mode] <= RCPOVERFLOW) return false;
+            v->weight[1 - mode] = v->weight[mode] * (v->pdf[mode] / v->pdf[1 - mode]);      // no BSDF of the subset is ENonSymmetric
+            if (v->measure == ESolidAngle) v->weight[1 - mode] = v->weight[1 - mode] * std::abs(cosTheta(wiL) / cosTheta(bs.wo));   // (of the REVERSED record: wo = old wi)
+            adjoint(v, mode, wiL, bs.wo, wiDotGeoN, woDotGeoN);
+            ray = Ray(its.p, wo);
+            break;
+        }
+        default:
+            return false;                                                                  // (the sensor endpoints go through sampleSensor)
+        }
+        if (throughput) {
+            *throughput = *throughput * v->weight[mode];
+            if (russianRoulette) {
+                const Float q = std::min(maxc(*throughput), (Float)0.95f);
+                if (rng.next1D() > q) { v->measure = EInvalidMeasure; return false; }
+                v->rrWeight = 1.0 / q;
+                *throughput = *throughput * v->rrWeight;
+            }
+        }
+        if (!edgeSampleNext(succEdge, ray, succ, mode)) { v->measure = EInvalidMeasure; return false; }
+        toArea(v, mode, pred, predEdge, succEdge, succ, ray.d);
+        return true;
+    }
+    // PathVertex::sampleSensor, vertex.cpp:312-384 (perspective: the direction sample maps to pixels, no aperture sample)
+    int sampleSensor(Vertex *v0, int px, int py, Edge *e0, Vertex *v1, Edge *e1, Vertex *v2)
+    {
+        *e0 = Edge(); *v1 = Vertex();
+        const Float sx = rng.next1D(), sy = rng.next1D();
+        PRec &pRec = v1->prec;
+        pRec = PRec();
+        pRec.p = c.camPos; pRec.n = c.camDir; pRec.pdf = 1.0; pRec.measure = EDiscrete; pRec.object = -2;   // samplePosition, perspective.cpp:300-308
+        v0->weight[ERadiance] = V3(1.0);
+        v0->pdf[ERadiance] = pRec.pdf;
+        v0->measure = pRec.measure;
+        v0->rrWeight = 1.0;
+        v1->type = ESensorSample;
+        v1->degenerate = false;
+        e0->weight[ERadiance] = V3(1.0);
+        e0->pdf[ERadiance] = 1.0;
+        // sampleDirection, perspective.cpp:318-345
+        const Float spx = (px + sx) * (1.0 / c.sc.cam.width), spy = (py + sy) * (1.0 / c.sc.cam.height);
+        pRec.uvx = spx * c.sc.cam.width; pRec.uvy = spy * c.sc.cam.height;
+        const V3 dl = sampleToCameraDir(c, spx, spy);
+        const V3 d = camToWorld(c, dl);
+        const Float dpdf = c.normalization / (dl.z * dl.z * dl.z);
+        *e1 = Edge(); *v2 = Vertex();
+        v1->weight[EImportance] = V3(1.0) * dpdf * (1.0 / std::abs(dot(d, pRec.n)));
+        v1->weight[ERadiance] = V3(1.0);
+        v1->pdf[EImportance] = 1.0;
+        v1->pdf[ERadiance] = dpdf;
+        v1->rrWeight = 1.0;
+        v1->measure = ESolidAngle;
+        Ray ray(pRec.p, d);
+        if (!edgeSampleNext(e1, ray, v2, ERadiance)) { v1->measure = EInvalidMeasure; return 1; }
+        if (v1->measure == ESolidAngle) {
+            v1->measure = EArea;
+            v1->pdf[ERadiance] /= e1->length * e1->length;
+            if (v2->isOnSurface()) v1->pdf[ERadiance] *= std::abs(dot(ray.d, v2->geometricNormal()));
+        }
+        return 2;
+    }
+    // PathVertex::perturbDirection, vertex.cpp:488-679
+    bool perturbDirection(Vertex *v, const Vertex *pred, const Edge *predEdge, Edge *succEdge, Vertex *succ, V3 d, Float dist, int mode)
+    {
+        Ray ray(v->position(), d);
+        *succEdge = Edge(); *succ = Vertex();
+        succ->measure = EInvalidMeasure;
+        if (v->degenerate) return false;
+        switch (v->type) {
+        case ESensorSample: {                                                              // :526-547
+            const Float value = importance(c, camToLocal(c, d)), prob = value;             // evalDirection == pdfDirection, perspective.cpp:373-391
+            if (value == 0 || prob <= RCPOVERFLOW) return false;
+            v->weight[EImportance] = V3(value) * (1.0 / std::abs(dot(d, v->prec.n)));
+            v->weight[ERadiance] = V3(value) / prob;
+            v->pdf[EImportance] = 1.0;
+            v->pdf[ERadiance] = prob;
+            v->measure = ESolidAngle;
+            break;
+        }
+        case ESurfaceInteraction: {                                                        // :549-621
+            const Intersection &its = v->its;
+            const V3 wi = normalize(pred->position() - its.p), wo = d;
+            const V3 wiL = its.sh.toLocal(wi), woL = its.sh.toLocal(wo);
+            const V3 value = bsdfEval(v->mat, wiL, woL, MEASURE_SOLID_ANGLE);
+            const Float prob = bsdfPdf(v->mat, wiL, woL, MEASURE_SOLID_ANGLE);
+            if (isZero(value) || prob <= RCPOVERFLOW) return false;
+            v->weight[mode] = value / prob;
+            v->pdf[mode] = prob;
+            const Float wiDotGeoN = dot(its.geoN, wi), woDotGeoN = dot(its.geoN, wo);
+            if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(woL) <= 0) return false;
+            v->measure = ESolidAngle;
+            v->componentType = ESmooth;
+            v->pdf[1 - mode] = bsdfPdf(v->mat, woL, wiL, MEASURE_SOLID_ANGLE);
+            if (v->pdf[1 - mode] <= RCPOVERFLOW) return false;
+            v->weight[1 - mode] = v->weight[mode] * std::abs((v->pdf[mode] * cosTheta(wiL)) / (v->pdf[1 - mode] * cosTheta(woL)));   // (reversed record)
+            adjoint(v, mode, wiL, woL, wiDotGeoN, woDotGeoN);
+            break;
+        }
+        default:
+            return false;                                                                  // (an emitter sample is never perturbed on the G-BDPT path: mode is always ERadiance)
+        }
+        if (!edgePerturbDirection(succEdge, ray, dist, succ, mode)) { v->measure = EInvalidMeasure; return false; }
+        toArea(v, mode, pred, predEdge, succEdge, succ, ray.d);
+        return true;
+    }
+    // PathVertex::eval, vertex.cpp:781-913
+    V3 eval(const Vertex *v, const Vertex *pred, const Vertex *succ, int mode, int measure = EArea) const
+    {
+        switch (v->type) {
+        case EEmitterSupernode:
+            if (mode != EImportance || pred != nullptr || succ->type != EEmitterSample) return V3(0.0);
+            return c.sc.emitters[succ->prec.object].radiance * PI;                         // AreaLight::evalPosition, area.cpp:99-101
+        case ESensorSupernode:
+            if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return V3(0.0);
+            return V3(measure == EDiscrete ? 1.0 : 0.0);                                   // perspective.cpp:310-312
+        case EEmitterSample: {
+            V3 target;
+            if (mode == EImportance && pred->type == EEmitterSupernode) target = succ->position();
+            else if (mode == ERadiance && succ->type == EEmitterSupernode) target = pred->position();
+            else return V3(0.0);
+            const V3 wo = normalize(target - v->prec.p);
+            V3 result(areaDirection(wo, v->prec.n, measure == EArea ? ESolidAngle : measure));
+            const Float dp = std::abs(dot(v->prec.n, wo));
+            if (measure != EDiscrete && dp != 0) result = result / dp;
+            return result;
+        }
+        case ESensorSample: {
+            V3 target;
+            if (mode == ERadiance && pred->type == ESensorSupernode) target = succ->position();
+            else if (mode == EImportance && succ->type == ESensorSupernode) target = pred->position();
+            else return V3(0.0);
+            const V3 wo = normalize(target - v->prec.p);
+            V3 result((measure == EArea ? ESolidAngle : measure) != ESolidAngle ? 0.0 : importance(c, camToLocal(c, wo)));
+            const Float dp = std::abs(dot(v->prec.n, wo));
+            if (measure != EDiscrete && dp != 0) result = result / dp;
+            return result;
+        }
+        case ESurfaceInteraction: {
+            const Intersection &its = v->its;
+            const V3 wi = normalize(pred->position() - its.p), wo = normalize(succ->position() - its.p);
+            const V3 wiL = its.sh.toLocal(wi), woL = its.sh.toLocal(wo);
+            if (measure == EArea) measure = ESolidAngle;
+            V3 result = bsdfEval(v->mat, wiL, woL, bsdfMeasure(measure));
+            const Float wiDotGeoN = dot(its.geoN, wi), woDotGeoN = dot(its.geoN, wo);
+            if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(woL) <= 0) return V3(0.0);
+            if (mode == EImportance) result = result * std::abs((cosTheta(wiL) * woDotGeoN) / (cosTheta(woL) * wiDotGeoN));
+            if (measure != EDiscrete && cosTheta(woL) != 0) result = result / std::abs(cosTheta(woL));
+            return result;
+        }
+        }
+        return V3(0.0);
+    }
+    // PathVertex::evalPdf, vertex.cpp:915-1022
+    Float evalPdf(const Vertex *v, const Vertex *pred, const Vertex *succ, int mode, int measure = EArea) const
+    {
+        V3 wo(0.0);
+        Float dist = 0.0, result = 0.0;
+        switch (v->type) {
+        case EEmitterSupernode:
+            if (mode != EImportance || pred != nullptr || succ->type != EEmitterSample) return 0.0;
+            return pdfEmitterPosition(c, succ->prec);
+        case ESensorSupernode:
+            if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return 0.0;
+            return measure == EDiscrete ? 1.0 : 0.0;                                       // perspective.cpp:314-316
+        case EEmitterSample:
+            if (mode == ERadiance && succ->type == EEmitterSupernode) return 1.0;
+            else if (mode != EImportance || pred->type != EEmitterSupernode) return 0.0;
+            wo = succ->position() - v->prec.p;
+            dist = length(wo); wo = wo / dist;
+            result = areaDirection(wo, v->prec.n, measure == EArea ? ESolidAngle : measure);
+            break;
+        case ESensorSample:
+            if (mode == EImportance && succ->type == ESensorSupernode) return 1.0;
+            else if (mode != ERadiance || pred->type != ESensorSupernode) return 0.0;
+            wo = succ->position() - v->prec.p;
+            dist = length(wo); wo = wo / dist;
+            result = (measure == EArea ? ESolidAngle : measure) != ESolidAngle ? 0.0 : importance(c, camToLocal(c, wo));
+            break;
+        case ESurfaceInteraction: {
+            const Intersection &its = v->its;
+            wo = succ->position() - its.p;
+            dist = length(wo); wo = wo / dist;
+            const V3 wi = normalize(pred->position() - its.p);
+            const V3 wiL = its.sh.toLocal(wi), woL = its.sh.toLocal(wo);
+            result = bsdfPdf(v->mat, wiL, woL, bsdfMeasure(measure == EArea ? ESolidAngle : measure));
+            const Float wiDotGeoN = dot(its.geoN, wi), woDotGeoN = dot(its.geoN, wo);
+            if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(woL) <= 0) return 0.0;
+            break;
+        }
+        default:
+            return 0.0;
+        }
+        if (measure == EArea) {
+            result /= dist * dist;
+            if (succ->isOnSurface()) result *= std::abs(dot(wo, succ->geometricNormal()));
+        }
+        return result;
+    }
+    // PathVertex::cast, vertex.cpp:1115-1163 (no sensor shapes: a cast to ESensorSample of a surface vertex always fails)
+    bool cast(Vertex *v, int desired) const
+    {
+        if (desired == v->type) return true;
+        if (desired == EEmitterSample) {
+            if (v->type != ESurfaceInteraction) return false;
+            const int em = c.sc.tris[v->its.prim].emitter;
+            if (em < 0) return false;
+            v->type = desired;
+            PRec pRec;                                                                     // PositionSamplingRecord(its), records.inl:154-155
+            pRec.p = v->its.p; pRec.n = v->its.sh.n; pRec.measure = EArea; pRec.uvx = v->its.u; pRec.uvy = v->its.v;
+            pRec.object = em; pRec.pdf = 0.0;
+            v->prec = pRec;
+            v->measure = pRec.measure;
+            v->degenerate = false;
+            return true;
+        }
+        return false;
+    }
+    // PathVertex::update, vertex.cpp:1165-1211
+    bool update(Vertex *v, const Vertex *pred, const Vertex *succ, int mode, int measure) const
+    {
+        v->pdf[mode] = evalPdf(v, pred, succ, mode, measure);
+        v->pdf[1 - mode] = evalPdf(v, succ, pred, 1 - mode, measure);
+        v->weight[mode] = eval(v, pred, succ, mode, measure);
+        v->weight[1 - mode] = eval(v, succ, pred, 1 - mode, measure);
+        if (isZero(v->weight[mode]) || v->pdf[mode] <= RCPOVERFLOW) return false;
+        Float weightFwd = v->pdf[mode] <= RCPOVERFLOW ? 0.0 : 1 / v->pdf[mode], weightBkw = v->pdf[1 - mode] <= RCPOVERFLOW ? 0.0 : 1 / v->pdf[1 - mode];
+        v->measure = measure;
+        if (!v->isSupernode() && measure == EArea) {
+            if (!pred->isSupernode()) {
+                V3 d = pred->position() - v->position();
+                const Float invDistSqr = 1.0 / lengthSquared(d);
+                weightBkw *= invDistSqr;
+                d = d * std::sqrt(invDistSqr);
+                if (v->isOnSurface() && v->isConnectable()) weightBkw *= std::abs(dot(v->shadingNormal(), d));
+                if (pred->isOnSurface()) weightBkw *= std::abs(dot(pred->geometricNormal(), d));
+            }
+            if (!succ->isSupernode()) {
+                V3 d = succ->position() - v->position();
+                const Float invDistSqr = 1.0 / lengthSquared(d);
+                weightFwd *= invDistSqr;
+                d = d * std::sqrt(invDistSqr);
+                if (v->isOnSurface() && v->isConnectable()) weightFwd *= std::abs(dot(v->shadingNormal(), d));
+                if (succ->isOnSurface()) weightFwd *= std::abs(dot(succ->geometricNormal(), d));
+            }
+            if (v->isSurface()) v->componentType = ESmooth;
+        }
+        v->weight[mode] = v->weight[mode] * weightFwd;
+        v->weight[1 - mode] = v->weight[1 - mode] * weightBkw;
+        return true;
+    }
+    // PathVertex::connect with explicit measures, vertex.cpp:1348-1370
+    bool connect(const Vertex *pred, Vertex *vs, Edge *edge, Vertex *vt, const Vertex *succ, int vsMeasure, int vtMeasure) const
+    {
+        if (vs->type == EEmitterSupernode) { if (!cast(vt, EEmitterSample)) return false; }
+        else if (vt->type == ESensorSupernode) { if (!cast(vs, ESensorSample)) return false; }
+        if (!update(vs, pred, vt, EImportance, vsMeasure)) return false;
+        if (!update(vt, succ, vs, ERadiance, vtMeasure)) return false;
+        return edgeConnect(edge, vs, vt);
+    }
+    bool getSamplePosition(const Vertex *v, const Vertex *other, Float &ox, Float &oy) const   // vertex.cpp:1308-1316
+    {
+        return sensorSamplePosition(c, other->position() - v->position(), ox, oy);
+    }
+    bool updateSamplePosition(Vertex *v, const Vertex *other) const                        // :1298-1306
+    {
+        return sensorSamplePosition(c, other->position() - v->position(), v->prec.uvx, v->prec.uvy);
+    }
+
+    // ---- Path ------------------------------------------------------------------------------------------------------------------------
+    // Path::alternatingRandomWalkFromPixel, path.cpp:548-631
+    void alternatingRandomWalkFromPixel(Path &emitterPath, int nEmitterSteps, Path &sensorPath, int nSensorSteps, int px, int py, int rrStart)
+    {
+        Vertex *curVertexS = emitterPath.v[0], *curVertexT = sensorPath.v[0], *predVertexS = nullptr, *predVertexT = nullptr;
+        Edge *predEdgeS = nullptr, *predEdgeT = nullptr;
+        Vertex *v1 = pool.allocVertex(), *v2 = pool.allocVertex();
+        Edge *e0 = pool.allocEdge(), *e1 = pool.allocEdge();
+        int t = sampleSensor(curVertexT, px, py, e0, v1, e1, v2);
+        if (t >= 1) { sensorPath.e.push_back(e0); sensorPath.v.push_back(v1); }
+        if (t == 2) { sensorPath.e.push_back(e1); sensorPath.v.push_back(v2); predVertexT = v1; curVertexT = v2; predEdgeT = e1; }
+        else curVertexT = nullptr;
+        V3 throughputS(1.0), throughputT(1.0);
+        int s = 0;
+        do {
+            if (curVertexT && (t < nSensorSteps || nSensorSteps == -1)) {
+                Vertex *succVertexT = pool.allocVertex(); Edge *succEdgeT = pool.allocEdge();
+                if (sampleNext(curVertexT, predVertexT, predEdgeT, succEdgeT, succVertexT, ERadiance, rrStart != -1 && t >= rrStart, &throughputT)) {
+                    sensorPath.e.push_back(succEdgeT); sensorPath.v.push_back(succVertexT);
+                    predVertexT = curVertexT; curVertexT = succVertexT; predEdgeT = succEdgeT;
+                    t++;
+                } else curVertexT = nullptr;
+            } else curVertexT = nullptr;
+            if (curVertexS && (s < nEmitterSteps || nEmitterSteps == -1)) {
+                Vertex *succVertexS = pool.allocVertex(); Edge *succEdgeS = pool.allocEdge();
+                if (sampleNext(curVertexS, predVertexS, predEdgeS, succEdgeS, succVertexS, EImportance, rrStart != -1 && s >= rrStart, &throughputS)) {
+                    emitterPath.e.push_back(succEdgeS); emitterPath.v.push_back(succVertexS);
+                    predVertexS = curVertexS; curVertexS = succVertexS; predEdgeS = succEdgeS;
+                    s++;
+                } else curVertexS = nullptr;
+            } else curVertexS = nullptr;
+        } while (curVertexS || curVertexT);
+    }
+    // Path::G, path.cpp:424-454 (adjacent vertices; a longer chain would need the generalized term of a specular chain: out of scope)
+    Float pathG(const Path &p, int i, int j)
+    {
+        if (j != i + 1) { c.unsupported++; return 1.0; }
+        const Float cosI = std::abs(dot(p.e[i]->d, p.v[i]->shadingNormal())), cosJ = std::abs(dot(p.e[i]->d, p.v[j]->shadingNormal()));
+        const Float len = p.e[i]->length;
+        return cosI * cosJ / (len * len);
+    }
+    // SpecularManifold::G for adjacent vertices (manifold.cpp:900-906) and multiG (:871-898)
+    Float manifoldG(const Path &p, int a, int b)
+    {
+        if (std::abs(a - b) != 1) { c.unsupported++; return 1.0; }
+        if (a > b) std::swap(a, b);
+        return edgeEvalCached(p.e[a], p.v[a], p.v[b], EGeometricTerm).x;
+    }
+    Float multiG(const Path &p, int a, int b)
+    {
+        if (a == 0) ++a; else if (a == p.length()) --a;
+        if (b == 0) ++b; else if (b == p.length()) --b;
+        const int step = b > a ? 1 : -1;
+        while (!p.v[b]->isConnectable()) b -= step;
+        while (!p.v[a]->isConnectable()) a += step;
+        Float result = 1;
+        for (int i = a + step, start = a; i != b + step; i += step)
+            if (p.v[i]->isConnectable()) { result *= manifoldG(p, start, i); start = i; }
+        return result;
+    }
+    // SpecularManifold::det, manifold.cpp:759-775: a chain with at most one glossy vertex between a and c needs no derivative
+    Float manifoldDet(const Path &p, int a, int b, int cI)
+    {
+        const int k = p.length();
+        if (a == 0 || a == k) std::swap(a, cI);
+        const int step = b > a ? 1 : -1;
+        int nGlossy = 0, nSpecular = 0;
+        for (int i = a + step; i != cI; i += step) { if (p.v[i]->isConnectable()) ++nGlossy; else ++nSpecular; }
+        if (nGlossy <= 1) return 1.0;
+        c.unsupported++;
+        (void)nSpecular;
+        return 1.0;
+    }
+    // Path::halfJacobian_GBDPT, path.cpp:380-394
+    Float halfJacobian(const Path &p, int a, int b, int cI)
+    {
+        Float value = 1.0;
+        value /= p.v[a]->pdf[ERadiance];
+        value *= pathG(p, a - 1, a) / pathG(p, b, a);
+        value *= manifoldDet(p, a, b, cI);
+        return value;
+    }
+    // Path::calcSpecularPDFChange, path.cpp:403-421
+    Float calcSpecularPDFChange(const Path &p, int cI, bool lightpath = false)
+    {
+        Float value(1.0);
+        const int k = p.length() - 1;
+        cI = std::max(1, cI);
+        for (int i = cI + 1; i <= k; i++)
+            if (p.v[lightpath ? i - 1 : i]->isConnectable()) value *= pathG(p, i - 1, i);
+        if (value <= Float(0.0)) return 1.0;
+        return multiG(p, cI, k) / value;
+    }
+
+    struct MuRec { int l = 0, m = 0; int extra[5] = {0, 0, 0, 0, 0}; };
+    // ManifoldPerturbation::getSpecularChainEndGBDPT, mut_manifold.cpp:1230-1262
+    int getSpecularChainEnd(const Path &path, int pos, int step) const
+    {
+        while (true) {
+            if (pos < 0 || pos > path.length()) return -1;
+            const Vertex *vertex = path.v[pos];
+            if (!vertex->isSurface()) break;
+            const Float roughness = getRoughness(vertex->mat);
+            if (vertex->isConnectable() && roughness >= c.cfg.shiftThreshold) break;
+            pos += step;
+        }
+        return pos;
+    }
+    // ManifoldPerturbation::computeMuRec, mut_manifold.cpp:1264-1296
+    bool computeMuRec(const Path &source, MuRec &mu) const
+    {
+        const int k = source.length();
+        if (!source.v[k - 1]->isConnectable()) return false;
+        const int step = -1, a = k - 1;
+        int b, cI;
+        if ((b = getSpecularChainEnd(source, a + step, step)) == -1) return false;
+        if ((cI = getSpecularChainEnd(source, b + step, step)) == -1) return false;
+        mu.l = std::min(a, cI); mu.m = std::max(a, cI);
+        mu.extra[0] = a; mu.extra[1] = b; mu.extra[2] = cI; mu.extra[3] = step; mu.extra[4] = ERadiance;
+        return true;
+    }
+    // ManifoldPerturbation::perturbDirection, mut_manifold.cpp:938-986
+    bool mutPerturbDirection(const Path &source, Path &proposal, int step, int a, Float offX, Float offY)
+    {
+        const Vertex *succ_old = source.v[a + step];
+        (void)succ_old;
+        const Edge *succEdge_old = source.e[a - 1];
+        Vertex *pred = proposal.v[a - step], *vertex = proposal.v[a], *succ = proposal.v[a + step];
+        Edge *predEdge = proposal.e[a - 1 - step], *succEdge = proposal.e[a - 1];
+        const Float ppx = source.v[source.length() - 1]->prec.uvx + offX, ppy = source.v[source.length() - 1]->prec.uvy + offY;   // Path::getSamplePosition, path.h:540-542
+        // sensor->sampleRay(ray, proposalSamplePosition, (0.5, 0.5), 0), perspective.cpp:249-269
+        const V3 rd = camToWorld(c, sampleToCameraDir(c, ppx * (1.0 / c.sc.cam.width), ppy * (1.0 / c.sc.cam.height)));
+        const V3 ro = c.camPos;
+        // focusDistance = getFocusDistance() / absDot(worldTransform(0, 0, 1), ray.d); the default focus distance is the far clip (sensor.cpp:162)
+        const Float focusDistance = c.sc.cam.farClip / std::abs(dot(c.camDir, rd));
+        const V3 d = normalize((ro + rd * focusDistance) - source.v[a]->position());
+        return perturbDirection(vertex, pred, predEdge, succEdge, succ, d, succEdge_old->length, ERadiance);
+    }
+    // ManifoldPerturbation::generateOffsetPathGBDPT, mut_manifold.cpp:806-936, for chains without specular vertices
+    bool generateOffsetPath(const Path &source, Path &proposal, MuRec &mu, Float offX, Float offY, bool &couldConnectBehindB, bool lightPath)
+    {
+        const int k = source.length();
+        if (!source.v[k - 1]->isConnectable()) return false;
+        const int step = -1, a = k - 1;
+        int b, cI;
+        if ((b = getSpecularChainEnd(source, a + step, step)) == -1) return false;
+        if ((cI = getSpecularChainEnd(source, b + step, step)) == -1) return false;
+        const int l = std::min(a, cI), m = std::max(a, cI), q = std::min(b, b + step);
+        mu = MuRec();
+        mu.l = l; mu.m = m;
+        mu.extra[0] = a; mu.extra[1] = b; mu.extra[2] = cI; mu.extra[3] = step; mu.extra[4] = ERadiance;
+        if (a - b > 1 || b - cI > 1) { c.unsupported++; return false; }                     // a specular chain: propagatePerturbation / manifoldWalk (stage C)
+        proposal.clear();
+        for (int i = 0; i < l + 1; ++i) { proposal.v.push_back(source.v[i]); if (i + 1 < l + 1) proposal.e.push_back(source.e[i]); }   // append(source, 0, l + 1)
+        proposal.e.push_back(pool.allocEdge());
+        for (int i = l + 1; i < m; ++i) { proposal.v.push_back(pool.allocVertex()); proposal.e.push_back(pool.allocEdge()); }
+        for (int i = m; i < k + 1; ++i) { proposal.v.push_back(source.v[i]); if (i + 1 < k + 1) proposal.e.push_back(source.e[i]); }   // append(source, m, k + 1)
+        proposal.v[a] = pool.clone(proposal.v[a]);
+        proposal.v[cI] = pool.clone(proposal.v[cI]);
+        if (!mutPerturbDirection(source, proposal, step, a, offX, offY)) return false;
+        // propagatePerturbation: nothing between a and b
+        if (!proposal.v[b]->isConnectable()) return false;
+        couldConnectBehindB = connect(proposal.vertexOrNull(q - 1), proposal.v[q], proposal.e[q], proposal.v[q + 1], proposal.vertexOrNull(q + 2),
+                                      source.v[q]->isConnectable() ? EArea : EDiscrete, source.v[q + 1]->isConnectable() ? EArea : EDiscrete);
+        if (lightPath && !couldConnectBehindB) return false;
+        if (m >= k - 1) updateSamplePosition(proposal.v[k - 1], proposal.v[k - 2]);
+        for (int i = 0; i <= proposal.length(); i++) {
+            proposal.v[i]->rrWeight = source.v[i]->rrWeight;
+            proposal.v[i]->sampledComponentIndex = source.v[i]->sampledComponentIndex;
+            if (proposal.v[i]->type == ESurfaceInteraction && proposal.v[i]->componentType == 0) proposal.v[i]->componentType = source.v[i]->componentType;
+        }
+        return true;
+    }
+
+    // ---- MIS weights, path.cpp:49-378 ------------------------------------------------------------------------------------------------
+    struct MisArrays { std::vector<Float> pdfImp, pdfRad; };
+    void collectPdfs(const Path &emitterSubpath, const Edge *connectionEdge, const Path &sensorSubpath, int s, int t, std::vector<Float> &pdfImp, std::vector<Float> &pdfRad) const
+    {
+        const int k = s + t + 1, n = k + 1;
+        const Vertex *vsPred = emitterSubpath.vertexOrNull(s - 1), *vtPred = sensorSubpath.vertexOrNull(t - 1), *vs = emitterSubpath.v[s], *vt = sensorSubpath.v[t];
+        pdfImp.assign(n, 0.0); pdfRad.assign(n, 0.0);
+        int pos = 0;
+        pdfImp[pos++] = 1.0;
+        for (int i = 0; i < s; ++i) pdfImp[pos++] = emitterSubpath.v[i]->pdf[EImportance] * emitterSubpath.e[i]->pdf[EImportance];
+        pdfImp[pos++] = evalPdf(vs, vsPred, vt, EImportance, EArea) * connectionEdge->pdf[EImportance];
+        if (t > 0) {
+            pdfImp[pos++] = evalPdf(vt, vs, vtPred, EImportance, EArea) * sensorSubpath.e[t - 1]->pdf[EImportance];
+            for (int i = t - 1; i > 0; --i) pdfImp[pos++] = sensorSubpath.v[i]->pdf[EImportance] * sensorSubpath.e[i - 1]->pdf[EImportance];
+        }
+        pos = 0;
+        if (s > 0) {
+            for (int i = 0; i < s - 1; ++i) pdfRad[pos++] = emitterSubpath.v[i + 1]->pdf[ERadiance] * emitterSubpath.e[i]->pdf[ERadiance];
+            pdfRad[pos++] = evalPdf(vs, vt, vsPred, ERadiance, EArea) * emitterSubpath.e[s - 1]->pdf[ERadiance];
+        }
+        pdfRad[pos++] = evalPdf(vt, vtPred, vs, ERadiance, EArea) * connectionEdge->pdf[ERadiance];
+        for (int i = t; i > 0; --i) pdfRad[pos++] = sensorSubpath.v[i - 1]->pdf[ERadiance] * sensorSubpath.e[i - 1]->pdf[ERadiance];
+        pdfRad[pos++] = 1.0;
+    }
+    // the conversions of area densities next to a non-connectable vertex into projected solid angle, path.cpp:143-167,309-349
+    static void stripGeometry(const Path &emitterSubpath, const Path &sensorSubpath, int s, int k, const std::vector<char> &connectableStrict,
+                              std::vector<Float> &pdfImp, std::vector<Float> &pdfRad)
+    {
+        for (int i = 1; i <= k - 3; ++i) {
+            if (i == s || !(connectableStrict[i] && !connectableStrict[i + 1])) continue;
+            const Vertex *cur = i <= s ? emitterSubpath.v[i] : sensorSubpath.v[k - i];
+            const Vertex *succ = i + 1 <= s ? emitterSubpath.v[i + 1] : sensorSubpath.v[k - i - 1];
+            const Edge *edge = i < s ? emitterSubpath.e[i] : sensorSubpath.e[k - i - 1];
+            pdfImp[i + 1] *= edge->length * edge->length / std::abs((succ->isOnSurface() ? dot(edge->d, succ->geometricNormal()) : 1) * (cur->isOnSurface() ? dot(edge->d, cur->geometricNormal()) : 1));
+        }
+        for (int i = k - 1; i >= 3; --i) {
+            if (i - 1 == s || !(connectableStrict[i] && !connectableStrict[i - 1])) continue;
+            const Vertex *cur = i <= s ? emitterSubpath.v[i] : sensorSubpath.v[k - i];
+            const Vertex *succ = i - 1 <= s ? emitterSubpath.v[i - 1] : sensorSubpath.v[k - i + 1];
+            const Edge *edge = i <= s ? emitterSubpath.e[i - 1] : sensorSubpath.e[k - i];
+            pdfRad[i - 1] *= edge->length * edge->length / std::abs((succ->isOnSurface() ? dot(edge->d, succ->geometricNormal()) : 1) * (cur->isOnSurface() ? dot(edge->d, cur->geometricNormal()) : 1));
+        }
+    }
+    void classify(const Path &emitterSubpath, const Path &sensorSubpath, int s, int t, std::vector<char> &connectable, std::vector<char> &connectableStrict, std::vector<char> &isNull) const
+    {
+        connectable.clear(); connectableStrict.clear(); isNull.clear();
+        auto add = [&](const Vertex *v) {
+            const bool cn = isConnectableGBDPT(v, c.cfg.shiftThreshold);
+            connectable.push_back(cn); connectableStrict.push_back(v->isConnectable());
+            isNull.push_back(false);                                                       // isNullInteraction(): no ENull components in the subset
+        };
+        for (int i = 0; i <= s; ++i) add(emitterSubpath.v[i]);
+        for (int i = t; i >= 0; --i) add(sensorSubpath.v[i]);
+    }
+    // Path::miWeightBaseNoSweep_GBDPT, path.cpp:49-201
+    Float miWeightBase(const Path &emitterSubpath, const Edge *connectionEdge, const Path &sensorSubpath, int s, int t, bool lightImage, Float exponent, Float geomTermX) const
+    {
+        const int k = s + t + 1;
+        std::vector<char> connectable, connectableStrict, isNull;
+        classify(emitterSubpath, sensorSubpath, s, t, connectable, connectableStrict, isNull);
+        std::vector<Float> pdfImp, pdfRad;
+        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, pdfImp, pdfRad);
+        stripGeometry(emitterSubpath, sensorSubpath, s, k, connectableStrict, pdfImp, pdfRad);
+        double sum_p = 0.0, p_st = 0.0;
+        for (int p = 0; p < s + t + 1; ++p) {
+            double p_i = 1.0;
+            for (int i = 1; i < p + 1; ++i) p_i *= pdfImp[i];
+            for (int i = p + 1; i < s + t + 1; ++i) p_i *= pdfRad[i];
+            const int tPrime = k - p - 1;
+            const bool allowedToConnect = (connectable[p] || isNull[p]) && connectable[p + 1];
+            if (allowedToConnect && (lightImage || tPrime > 1)) sum_p += std::pow(p_i * geomTermX, exponent);
+            if (tPrime == t) p_st = std::pow(p_i * geomTermX, exponent);
+        }
+        return (Float)(p_st / sum_p);
+    }
+    // Path::miWeightGradNoSweep_GBDPT, path.cpp:204-378
+    Float miWeightGrad(const Path &emitterSubpath, const Edge *connectionEdge, const Path &sensorSubpath,
+                       const Path &offsetEmitterSubpath, const Edge *offsetConnectionEdge, const Path &offsetSensorSubpath,
+                       int s, int t, bool lightImage, Float jDet, Float exponent, Float geomTermX, Float geomTermY) const
+    {
+        const int k = s + t + 1;
+        std::vector<char> connectable, connectableStrict, isNull;
+        classify(emitterSubpath, sensorSubpath, s, t, connectable, connectableStrict, isNull);
+        std::vector<Float> pdfImp, pdfRad, offsetPdfImp, offsetPdfRad;
+        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, pdfImp, pdfRad);
+        collectPdfs(offsetEmitterSubpath, offsetConnectionEdge, offsetSensorSubpath, s, t, offsetPdfImp, offsetPdfRad);
+        stripGeometry(emitterSubpath, sensorSubpath, s, k, connectableStrict, pdfImp, pdfRad);
+        stripGeometry(offsetEmitterSubpath, offsetSensorSubpath, s, k, connectableStrict, offsetPdfImp, offsetPdfRad);   // (the base path's flags select the rows, :310,331)
+        double sum_p_i = 0.0, p_st = 0.0;
+        for (int p = 0; p < s + t + 1; ++p) {
+            double value = 1.0, oValue = 1.0;
+            for (int i = 1; i < p + 1; ++i) { value *= pdfImp[i]; oValue *= offsetPdfImp[i]; }
+            for (int i = p + 1; i < s + t + 1; ++i) { value *= pdfRad[i]; oValue *= offsetPdfRad[i]; }
+            const int tPrime = k - p - 1;
+            const bool allowedToConnect = (connectable[p] || isNull[p]) && connectable[p + 1];
+            if (allowedToConnect && (lightImage || tPrime > 1)) sum_p_i += std::pow(value * geomTermX, exponent) + std::pow(oValue * jDet * geomTermY, exponent);
+            if (tPrime == t) p_st = std::pow(value * geomTermX, exponent);
+        }
+        return (Float)(p_st / sum_p_i);
+    }
+
+    // ---- GBDPTRenderer ---------------------------------------------------------------------------------------------------------------
+    struct ShiftPathData {                                                                 // gbdpt_proc.cpp:29-42
+        std::vector<double> jacobianDet, genGeomTerm;
+        MuRec muRec;
+        bool couldConnectAfterB = false, success = false;
+        explicit ShiftPathData(int n) : jacobianDet(n + 3, 1.0), genGeomTerm(n + 3, 1.0) {}
+    };
+    // GBDPTRenderer::createShiftablePath, gbdpt_proc.cpp:600-662
+    bool createShiftablePath(Path &connectedPath, Path &emitterSubpath, Path &sensorSubpath, int s, int t, int &memPointer)
+    {
+        connectedPath.clear();
+        while (!isConnectableGBDPT(sensorSubpath.v[t], c.cfg.shiftThreshold)) { t--; sensorSubpath.v.pop_back(); sensorSubpath.e.pop_back(); }   // removeAndReleaseLastElement
+        if (sensorSubpath.v[t]->type == ESurfaceInteraction && c.sc.tris[sensorSubpath.v[t]->its.prim].emitter >= 0) s = 0;
+        for (memPointer = 0; memPointer < s; memPointer++) { connectedPath.v.push_back(emitterSubpath.v[memPointer]); connectedPath.e.push_back(emitterSubpath.e[memPointer]); }
+        connectedPath.v.push_back(pool.clone(emitterSubpath.v[memPointer]));
+        connectedPath.e.push_back(pool.allocEdge());
+        connectedPath.v.push_back(pool.clone(sensorSubpath.v[t]));
+        cast(connectedPath.v[memPointer + 1], EEmitterSample);
+        for (int i = t - 1; i >= 0; i--) { connectedPath.v.push_back(sensorSubpath.v[i]); connectedPath.e.push_back(sensorSubpath.e[i]); }
+        const bool pathSuccess = connect(connectedPath.vertexOrNull(memPointer - 1), connectedPath.v[memPointer], connectedPath.e[memPointer], connectedPath.v[memPointer + 1],
+                                         connectedPath.vertexOrNull(memPointer + 2),
+                                         connectedPath.v[memPointer]->isConnectable() ? EArea : EDiscrete, connectedPath.v[memPointer + 1]->isConnectable() ? EArea : EDiscrete);
+        if (t == 1) updateSamplePosition(connectedPath.v[connectedPath.vertexCount() - 2], connectedPath.v[connectedPath.vertexCount() - 3]);
+        return pathSuccess;
+    }
+    // GBDPTRenderer::createShiftedLightPath, gbdpt_proc.cpp:568-590
+    void createShiftedLightPath(Path &base, Path &offset, double &jacobian, bool &pathSuccess, V3 &offsetWeight, Float &offsetPdf, MuRec &mu, Float shX, Float shY, int s)
+    {
+        jacobian = 1.0;
+        bool couldConnectWithB = false;
+        pathSuccess = generateOffsetPath(base, offset, mu, shX, shY, couldConnectWithB, true);
+        if (pathSuccess) {
+            jacobian = halfJacobian(offset, mu.extra[0], mu.extra[1], mu.extra[2]) / halfJacobian(base, mu.extra[0], mu.extra[1], mu.extra[2]);
+            offsetPdf = 1.0;
+            offsetWeight = V3(1.0);
+            for (int i = 1; i <= s; ++i) {
+                offsetWeight = offsetWeight * offset.v[i - 1]->weight[EImportance] * offset.v[i - 1]->rrWeight * offset.e[i - 1]->weight[EImportance];
+                offsetPdf = offsetPdf * offset.v[i - 1]->pdf[EImportance] * offset.v[i - 1]->rrWeight * offset.e[i - 1]->pdf[EImportance];
+            }
+        }
+    }
+
+    struct Splat { Float x, y; int buffer; V3 value; };
+    struct SampleResult { V3 primal; V3 gradient[4]; Float posX = 0, posY = 0; std::vector<Splat> light; };
+
+    // GBDPTRenderer::evaluate, gbdpt_proc.cpp:259-534
+    void evaluate(SampleResult &wr, Path &emitterSubpath, std::vector<Path> &sensorSubpath, std::vector<ShiftPathData> &pathData, int vert_b)
+    {
+        static const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                // :265
+        const int neighbourCount = 4;
+        const Config &cfg = c.cfg;
+        const Float initialX = sensorSubpath[0].v[1]->prec.uvx, initialY = sensorSubpath[0].v[1]->prec.uvy;
+        wr.posX = initialX; wr.posY = initialY;
+        const int nE = emitterSubpath.vertexCount(), nS = sensorSubpath[0].vertexCount();
+        std::vector<V3> importanceWeights(nE);
+        std::vector<Float> importancePdf(nE);
+        std::vector<std::vector<V3>> radianceWeights(neighbourCount + 1, std::vector<V3>(nS));
+        std::vector<std::vector<Float>> radiancePdf(neighbourCount + 1, std::vector<Float>(nS, 0.0));
+        // combineImportanceData / combineRadianceData, :544-565
+        importanceWeights[0] = V3(1.0); importancePdf[0] = 1.0;
+        for (int i = 1; i < nE; ++i) {
+            importanceWeights[i] = importanceWeights[i - 1] * emitterSubpath.v[i - 1]->weight[EImportance] * emitterSubpath.v[i - 1]->rrWeight * emitterSubpath.e[i - 1]->weight[EImportance];
+            importancePdf[i] = importancePdf[i - 1] * emitterSubpath.v[i - 1]->pdf[EImportance] * emitterSubpath.v[i - 1]->rrWeight * emitterSubpath.e[i - 1]->pdf[EImportance];
+        }
+        for (int k = 0; k <= neighbourCount; k++) {
+            radianceWeights[k][0] = V3(1.0); radiancePdf[k][0] = 1.0;
+            for (int i = 1; i < nS; ++i)
+                if (pathData[k].success && i < sensorSubpath[k].vertexCount()) {
+                    radianceWeights[k][i] = radianceWeights[k][i - 1] * sensorSubpath[k].v[i - 1]->weight[ERadiance] * sensorSubpath[k].v[i - 1]->rrWeight * sensorSubpath[k].e[i - 1]->weight[ERadiance];
+                    radiancePdf[k][i] = radiancePdf[k][i - 1] * sensorSubpath[k].v[i - 1]->pdf[ERadiance] * sensorSubpath[k].v[i - 1]->rrWeight * sensorSubpath[k].e[i - 1]->pdf[ERadiance];
+                }
+        }
+        V3 primal(0.0), gradient[4];
+        Path offsetEmitterSubpath, connectedBasePath;
+        V3 geomTermBase, connectionPartsBase, offsetImportanceWeight;
+        Edge connectionEdge, connectionEdgeBase;
+        bool successConnectBase = false;
+        Float offsetImportancePdf = 0;
+        std::vector<V3> value(neighbourCount + 1);
+        std::vector<Float> miWeight(neighbourCount + 1), valuePdf(neighbourCount + 1);
+        std::vector<double> jacobianLP(neighbourCount), genGeomTermLP(neighbourCount + 1);
+        bool pathSuccess[5];
+
+        for (int s = nE - 1; s >= 0; --s) {
+            const int minT = std::max(2 - s, cfg.lightImage ? 1 : 2);
+            int maxT = nS - 1;
+            if (cfg.maxDepth != -1) maxT = std::min(maxT, cfg.maxDepth + 1 - s);
+            for (int t = maxT; t >= minT; --t) {
+                Float samplePosX = initialX, samplePosY = initialY;
+                if (t == 1) {
+                    if ((sensorSubpath[0].v[t]->type == ESensorSample && !getSamplePosition(sensorSubpath[0].v[t], emitterSubpath.v[s], samplePosX, samplePosY))
+                        || !isConnectableGBDPT(emitterSubpath.v[s], cfg.shiftThreshold))
+                        continue;
+                }
+                int memPointer = 0;
+                MuRec muRec;
+                for (int k = 0; k <= neighbourCount; k++) {
+                    miWeight[k] = 1.0 / (s + t + 1);
+                    pathSuccess[k] = pathData[k].success;
+                    value[k] = V3(0.0);
+                    valuePdf[k] = 0.0;
+                    const V3 *importanceWeightTmp = &importanceWeights[s], *radianceWeightTmp = &radianceWeights[t == 1 ? 0 : k][t];
+                    const Float *importancePdfTmp = &importancePdf[s], *radiancePdfTmp = &radiancePdf[t == 1 ? 0 : k][t];
+                    const Path *sensorSubpathTmp = &sensorSubpath[k], *emitterSubpathTmp = &emitterSubpath;
+                    if (t == 1 && k == 0) {
+                        pathSuccess[0] = createShiftablePath(connectedBasePath, emitterSubpath, sensorSubpath[0], s, 1, memPointer);
+                        computeMuRec(connectedBasePath, muRec);
+                        genGeomTermLP[0] = calcSpecularPDFChange(connectedBasePath, muRec.extra[2], true);
+                    }
+                    if (t == 1 && k > 0 && !isZero(value[0])) {
+                        if (!pathSuccess[0]) pathSuccess[k] = false;
+                        else {
+                            createShiftedLightPath(connectedBasePath, offsetEmitterSubpath, jacobianLP[k - 1], pathSuccess[k], offsetImportanceWeight, offsetImportancePdf, muRec,
+                                                   shifts[k - 1][0], shifts[k - 1][1], s);
+                            if (pathSuccess[k]) {
+                                genGeomTermLP[k] = calcSpecularPDFChange(offsetEmitterSubpath, muRec.extra[2], true);
+                                importanceWeightTmp = &offsetImportanceWeight;
+                                importancePdfTmp = &offsetImportancePdf;
+                                emitterSubpathTmp = &offsetEmitterSubpath;
+                            }
+                            sensorSubpathTmp = &sensorSubpath[0];
+                        }
+                    }
+                    V3 geomTerm(0.0);
+                    do {
+                        if (pathSuccess[k] && pathSuccess[0] && (k == 0 || (valuePdf[0] > 0 && !isZero(value[0])))) {
+                            if (!pathData[k].couldConnectAfterB && t > vert_b) break;
+                            Vertex *vsPred = emitterSubpathTmp->vertexOrNull(s - 1), *vtPred = sensorSubpathTmp->vertexOrNull(t - 1);
+                            Vertex *vs = emitterSubpathTmp->v[s], *vt = sensorSubpathTmp->v[t];
+                            const int remaining = cfg.maxDepth - s - t + 1;
+                            if (vs->type == EEmitterSupernode) {
+                                if (!cast(vt, EEmitterSample) || vt->degenerate) { valuePdf[k] = *radiancePdfTmp; break; }
+                                const V3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : eval(vs, vsPred, vt, EImportance) * eval(vt, vtPred, vs, ERadiance);
+                                if (k == 0) connectionPartsBase = connectionParts;
+                                value[k] = *radianceWeightTmp * connectionParts;
+                                valuePdf[k] = *radiancePdfTmp;
+                            } else if (vt->type == ESensorSupernode) {                      // (t >= 1 here: not reached)
+                                valuePdf[k] = *importancePdfTmp;
+                                break;
+                            } else {
+                                if (!isConnectableGBDPT(vs, cfg.shiftThreshold) || !isConnectableGBDPT(vt, cfg.shiftThreshold) || vs->type == 0 || vt->type == 0) {
+                                    valuePdf[k] = *importancePdfTmp * *radiancePdfTmp;
+                                    break;
+                                }
+                                const V3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : eval(vs, vsPred, vt, EImportance) * eval(vt, vtPred, vs, ERadiance);
+                                if (k == 0) connectionPartsBase = connectionParts;
+                                value[k] = *importanceWeightTmp * *radianceWeightTmp * connectionParts;
+                                valuePdf[k] = *importancePdfTmp * *radiancePdfTmp;
+                                vs->measure = vt->measure = EArea;
+                            }
+                            if (isZero(value[k]) || valuePdf[k] == 0) break;
+                            int interactions = remaining;
+                            const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edgePathConnectAndCollapse(&connectionEdge, vs, vt, interactions);
+                            if (k == 0) successConnectBase = successConnect;
+                            if (!successConnect) { value[k] = V3(0.0); break; }
+                            geomTerm = (k > 0 && t > vert_b) ? geomTermBase : edgeEvalCached(&connectionEdge, vs, vt, EGeneralizedGeometricTerm);
+                            value[k] = value[k] * geomTerm;
+                            valuePdf[k] *= (t < 2 ? genGeomTermLP[k] : pathData[k].genGeomTerm[t]);
+                            if (isZero(value[k]) || valuePdf[k] == 0) break;
+                            if (k == 0) {
+                                connectionEdgeBase = connectionEdge;
+                                geomTermBase = geomTerm;
+                                miWeight[0] = miWeightBase(emitterSubpath, &connectionEdgeBase, sensorSubpath[0], s, t, cfg.lightImage != 0, 2.0,
+                                                           (t < 2 ? genGeomTermLP[0] : pathData[0].genGeomTerm[t])) / valuePdf[0];
+                            } else {
+                                miWeight[k] = miWeightGrad(emitterSubpath, &connectionEdgeBase, sensorSubpath[0], *emitterSubpathTmp, &connectionEdge, *sensorSubpathTmp, s, t,
+                                                           cfg.lightImage != 0, (t < 2 ? jacobianLP[k - 1] : pathData[k].jacobianDet[t]), 1.0,
+                                                           (t < 2 ? genGeomTermLP[0] : pathData[0].genGeomTerm[t]), (t < 2 ? genGeomTermLP[k] : pathData[k].genGeomTerm[t])) / valuePdf[0];
+                            }
+                        }
+                    } while (false);
+                    if (isZero(value[k]) || isZero(value[0])) {
+                        value[k] = V3(0.0);
+                        miWeight[k] = miWeight[0];
+                        valuePdf[k] = valuePdf[0];
+                    }
+                }
+                if (isZero(value[0])) continue;
+                const V3 mainRad = value[0] * (valuePdf[0] * miWeight[0]);                   // Spectrum mainRad = valuePdf[0] * miWeight[0] * value[0]: (Float * Float) * Spectrum
+                if (t >= 2) primal = primal + mainRad;
+                else wr.light.push_back({samplePosX, samplePosY, 0, mainRad});
+                const V3 fx = value[0] * valuePdf[0];
+                for (int n = 0; n < neighbourCount; n++) {
+                    const V3 fy = value[n + 1] * valuePdf[n + 1] * (t < 2 ? jacobianLP[n] : pathData[n + 1].jacobianDet[t]);
+                    const V3 gradVal = (fy - fx) * (Float(2.0) * miWeight[n + 1]);           // Float(2.f) * miWeight * (fy - fx)
+                    if (t >= 2) gradient[n] = gradient[n] + gradVal;
+                    else wr.light.push_back({samplePosX, samplePosY, n + 1, gradVal});
+                }
+            }
+        }
+        wr.primal = primal;
+        for (int k = 0; k < neighbourCount; ++k) wr.gradient[k] = gradient[k];
+    }
+
+    // the body of GBDPTRenderer::process's sample loop, gbdpt_proc.cpp:152-252
+    void processSample(int px, int py, SampleResult &wr)
+    {
+        static const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                // :101
+        Config &cfg = c.cfg;
+        if (cfg.maxDepth == -1) cfg.maxDepth = 12;                                         // :103-106
+        int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth;
+        // the perspective sensor is degenerate (EDeltaPosition): no extra emitter step; area emitters can be hit: one more sensor step (:116-122)
+        if (sensorDepth != -1) ++sensorDepth;
+        const int neighborCount = 4;
+        std::vector<ShiftPathData> pathData(neighborCount + 1, ShiftPathData(sensorDepth + 3));
+        pathData[0].success = true;
+        pathData[0].couldConnectAfterB = true;
+        Path emitterSubpath;
+        std::vector<Path> sensorSubpath(neighborCount + 1);
+        emitterSubpath.v.push_back(pool.allocVertex());                                    // Path::initialize -> makeEndpoint, vertex.cpp:27-33
+        emitterSubpath.v[0]->type = EEmitterSupernode; emitterSubpath.v[0]->degenerate = false;
+        sensorSubpath[0].v.push_back(pool.allocVertex());
+        sensorSubpath[0].v[0]->type = ESensorSupernode; sensorSubpath[0].v[0]->degenerate = true;
+        alternatingRandomWalkFromPixel(emitterSubpath, emitterDepth, sensorSubpath[0], sensorDepth, px, py, cfg.rrDepth);
+        Path connectPath;
+        int ptx = 0;
+        createShiftablePath(connectPath, emitterSubpath, sensorSubpath[0], 1, sensorSubpath[0].vertexCount() - 1, ptx);
+        computeMuRec(connectPath, pathData[0].muRec);
+        for (int v = pathData[0].muRec.extra[0] - 1; v >= 0; v--) {
+            const int idx = connectPath.vertexCount() - 1 - v;
+            if (isConnectableGBDPT(connectPath.v[v], cfg.shiftThreshold) && v >= pathData[0].muRec.extra[2])
+                pathData[0].genGeomTerm.at(idx) = calcSpecularPDFChange(connectPath, v);
+            else
+                pathData[0].genGeomTerm.at(idx) = pathData[0].genGeomTerm.at(idx - 1);
+        }
+        for (int k = 0; k < neighborCount; k++) {
+            pathData[k + 1].success = pathData[0].muRec.extra[0] <= 2 ? false
+                : generateOffsetPath(connectPath, sensorSubpath[k + 1], pathData[k + 1].muRec, shifts[k][0], shifts[k][1], pathData[k + 1].couldConnectAfterB, false);
+            if (pathData[k + 1].success) {
+                for (int v = pathData[k + 1].muRec.extra[0] - 1; v >= 0; v--) {
+                    const int idx = connectPath.vertexCount() - 1 - v;
+                    if (isConnectableGBDPT(connectPath.v[v], cfg.shiftThreshold) && v >= pathData[k + 1].muRec.extra[2]) {
+                        const int a = pathData[k + 1].muRec.extra[0];
+                        const int b = v >= pathData[k + 1].muRec.extra[1] ? v : pathData[k + 1].muRec.extra[1];
+                        const int cI = v >= pathData[k + 1].muRec.extra[1] ? v - 1 : pathData[k + 1].muRec.extra[2];
+                        const double jx = halfJacobian(connectPath, a, b, cI), jy = halfJacobian(sensorSubpath[k + 1], a, b, cI);
+                        pathData[k + 1].jacobianDet.at(idx) = jy / jx;
+                        pathData[k + 1].genGeomTerm.at(idx) = calcSpecularPDFChange(sensorSubpath[k + 1], v);
+                    } else {
+                        pathData[k + 1].jacobianDet.at(idx) = pathData[k + 1].jacobianDet.at(idx - 1);
+                        pathData[k + 1].genGeomTerm.at(idx) = pathData[k + 1].genGeomTerm.at(idx - 1);
+                    }
+                }
+            }
+            sensorSubpath[k + 1].reverse();
+        }
+        const int v_b = connectPath.vertexCount() - 1 - pathData[0].muRec.extra[1];
+        evaluate(wr, emitterSubpath, sensorSubpath, pathData, v_b);
+    }
+};
+
+// GBDPTWorkResult (camera blocks: spectrum, alpha, weight; light images: spectrum) + GBDPTProcess::develop, for the box filter
+struct Film {
+    int W, H;
+    std::vector<double> block[5];    // [H][W][4]: R, G, B, weight
+    std::vector<double> light[5];    // [H][W][3]
+    unsigned long long invalidPuts = 0;
+    double filterRadius, filterScale, filterValues[32];
+    Film(int w, int h) : W(w), H(h)
+    {
+        for (auto &b : block) b.assign((size_t)w * h * 4, 0.0);
+        for (auto &b : light) b.assign((size_t)w * h * 3, 0.0);
+        filterRadius = 0.5 + (double)1e-5f;                                                 // box.cpp:38
+        double sum = 0;                                                                     // rfilter.cpp:37-55
+        for (int i = 0; i < 31; ++i) { filterValues[i] = 1.0; sum += 1.0; }
+        filterValues[31] = 0.0;
+        filterScale = 31 / filterRadius;
+        sum *= 2 * filterRadius / 31;
+        for (int i = 0; i < 31; ++i) filterValues[i] *= 1.0 / sum;
+    }
+    double evalDiscretized(double x) const { return filterValues[std::min((int)std::abs(x * filterScale), 31)]; }
+    // ImageBlock::put (imageblock.h:150-210) with negative values allowed (gbdpt_proc.cpp:175-179); channels = nch values + (alpha, weight) for the blocks
+    void put(std::vector<double> &buf, int stride, double px, double py, V3 spec, bool withWeight)
+    {
+        if (!std::isfinite(spec.x) || !std::isfinite(spec.y) || !std::isfinite(spec.z)) { invalidPuts++; return; }
+        const double posx = px - 0.5, posy = py - 0.5;
+        const int x0 = std::max((int)std::ceil(posx - filterRadius), 0), y0 = std::max((int)std::ceil(posy - filterRadius), 0);
+        const int x1 = std::min((int)std::floor(posx + filterRadius), W - 1), y1 = std::min((int)std::floor(posy + filterRadius), H - 1);
+        for (int y = y0; y <= y1; ++y) {
+            const double wy = evalDiscretized(y - posy);
+            for (int x = x0; x <= x1; ++x) {
+                const double w = evalDiscretized(x - posx) * wy;
+                double *dest = &buf[((size_t)y * W + x) * stride];
+                dest[0] += w * spec.x; dest[1] += w * spec.y; dest[2] += w * spec.z;
+                if (withWeight) dest[3] += w * 1.0;
+            }
+        }
+    }
+    void add(const Tracer::SampleResult &r)
+    {
+        put(block[0], 4, r.posX, r.posY, r.primal, true);                                   // putSample, gbdpt_proc.cpp:531-533
+        for (int k = 0; k < 4; ++k) put(block[k + 1], 4, r.posX, r.posY, r.gradient[k], true);
+        for (const auto &s : r.light) put(light[s.buffer], 3, s.x, s.y, s.value, false);    // putLightSample, :514,525
+    }
+};
+
+} // namespace gb

@@ -35,6 +35,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <limits>
 #include <vector>
 
@@ -1918,6 +1919,8 @@ void renderSerial(const Scene &sc, const gpo_config &cfg, int blockSize, uint64_
     }
 }
 
+#include "gbdpt_oracle.hpp"
+
 } // namespace
 
 // ================================================================================================================
@@ -2367,4 +2370,62 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
         sum = sum + L;
     }
     rgbOut[0] = sum.x / n; rgbOut[1] = sum.y / n; rgbOut[2] = sum.z / n;
+}
+
+// ---- G-BDPT (oracle/gbdpt_oracle.hpp) ---------------------------------------------------------------------------------------------
+extern "C" {
+typedef struct gpo_gbdpt_config { int maxDepth, rrDepth, lightImage, spp; double shiftThreshold; unsigned long long seed; } gpo_gbdpt_config;
+}
+static gb::Config gbConfig(const gpo_gbdpt_config *cfg)
+{
+    gb::Config c;
+    c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.lightImage = cfg->lightImage; c.spp = cfg->spp; c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    return c;
+}
+// one sample of GBDPTRenderer::process: out = primal(3), gradient[4](3 each), sample position(2); light splats as (x, y, buffer, r, g, b);
+// counters = closest-hit rays, shadow rays, unsupported events
+GPO_API void gpo_gbdpt_sample(gpo_scene *h, const gpo_gbdpt_config *cfg, int px, int py, int sampleIndex, double *out17, int maxLight, double *lightOut, int *nLight,
+                              unsigned long long *counters)
+{
+    gb::Ctx ctx{h->sc, gbConfig(cfg)};
+    gb::cameraSetup(ctx);
+    const uint64_t r0 = h->sc.raysTraced, s0 = h->sc.shadowRaysTraced;
+    Rng rng(cfg->seed, (uint64_t)py * h->sc.cam.width + px, (uint64_t)sampleIndex);
+    gb::Pool pool;
+    gb::Tracer tr(ctx, rng, pool);
+    gb::Tracer::SampleResult r;
+    tr.processSample(px, py, r);
+    out17[0] = r.primal.x; out17[1] = r.primal.y; out17[2] = r.primal.z;
+    for (int k = 0; k < 4; ++k) { out17[3 + 3 * k] = r.gradient[k].x; out17[4 + 3 * k] = r.gradient[k].y; out17[5 + 3 * k] = r.gradient[k].z; }
+    out17[15] = r.posX; out17[16] = r.posY;
+    *nLight = (int)r.light.size();
+    for (int i = 0; i < (int)r.light.size() && i < maxLight; ++i) {
+        double *o = lightOut + 6 * i;
+        o[0] = r.light[i].x; o[1] = r.light[i].y; o[2] = r.light[i].buffer; o[3] = r.light[i].value.x; o[4] = r.light[i].value.y; o[5] = r.light[i].value.z;
+    }
+    counters[0] = h->sc.raysTraced - r0; counters[1] = h->sc.shadowRaysTraced - s0; counters[2] = ctx.unsupported;
+}
+// GBDPTRenderer::process over the pixels of [x0,x1) x [y0,y1): the five camera blocks [5][H][W][4] and the five light images [5][H][W][3]
+GPO_API void gpo_gbdpt_render(gpo_scene *h, const gpo_gbdpt_config *cfg, int x0, int y0, int x1, int y1, double *block, double *light, unsigned long long *counters)
+{
+    gb::Ctx ctx{h->sc, gbConfig(cfg)};
+    gb::cameraSetup(ctx);
+    const uint64_t r0 = h->sc.raysTraced, s0 = h->sc.shadowRaysTraced;
+    const int W = h->sc.cam.width, H = h->sc.cam.height;
+    gb::Film film(W, H);
+    for (int py = y0; py < y1; ++py)
+        for (int px = x0; px < x1; ++px)
+            for (int j = 0; j < cfg->spp; ++j) {
+                Rng rng(cfg->seed, (uint64_t)py * W + px, (uint64_t)j);
+                gb::Pool pool;
+                gb::Tracer tr(ctx, rng, pool);
+                gb::Tracer::SampleResult r;
+                tr.processSample(px, py, r);
+                film.add(r);
+            }
+    for (int b = 0; b < 5; ++b) {
+        std::memcpy(block + (size_t)b * W * H * 4, film.block[b].data(), sizeof(double) * (size_t)W * H * 4);
+        std::memcpy(light + (size_t)b * W * H * 3, film.light[b].data(), sizeof(double) * (size_t)W * H * 3);
+    }
+    counters[0] = h->sc.raysTraced - r0; counters[1] = h->sc.shadowRaysTraced - s0; counters[2] = ctx.unsupported; counters[3] = film.invalidPuts;
 }

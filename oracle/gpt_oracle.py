@@ -33,6 +33,19 @@ class Config(C.Structure):
                 ("shiftThreshold", C.c_double), ("seed", C.c_ulonglong)]
 
 
+class GBDPTConfig(C.Structure):
+    _fields_ = [("maxDepth", C.c_int), ("rrDepth", C.c_int), ("lightImage", C.c_int), ("spp", C.c_int),
+                ("shiftThreshold", C.c_double), ("seed", C.c_ulonglong)]
+
+
+def gbdpt_config(maxDepth=-1, rrDepth=5, lightImage=True, spp=1, shiftThreshold=0.001, seed=5489):
+    """GBDPTConfiguration defaults of gbdpt.cpp:81-89 (maxDepth -1 renders as 12, gbdpt_proc.cpp:103-106)."""
+    return GBDPTConfig(maxDepth, rrDepth, int(lightImage), spp, shiftThreshold, seed)
+
+
+GBDPT_BUFFER_NAMES = ("-primal", "-gradientNegY", "-gradientNegX", "-gradientPosX", "-gradientPosY")     # block / light image i, gbdpt.cpp:163
+
+
 def config(maxDepth=-1, rrDepth=5, strictNormals=False, spp=1, shiftThreshold=0.001, seed=5489):
     """GradientPathTracerConfig defaults of gpt.cpp:1194-1201; seed 5489 echoes random.h:113."""
     return Config(maxDepth, rrDepth, int(strictNormals), spp, shiftThreshold, seed)
@@ -53,7 +66,7 @@ def material(m):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("gpt_oracle.cpp", "sfmt_random.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("gpt_oracle.cpp", "sfmt_random.hpp", "mipmap_oracle.hpp", "gbdpt_oracle.hpp")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -115,6 +128,8 @@ def lib():
         L.gpo_rng.restype = C.c_double
         L.gpo_rng.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_int]
         L.gpo_reference_pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.gpo_gbdpt_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_gbdpt_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -258,6 +273,27 @@ class Scene:
         lib().gpo_reference_pt(self._h, C.byref(cfg), px, py, n, _p(out))
         return out
 
+    def gbdpt_sample(self, cfg, px, py, sample, max_light=256):
+        """One sample of GBDPTRenderer::process (oracle/gbdpt_oracle.hpp) -> dict(primal[3], gradients[4,3] in the order (0,-1), (-1,0),
+        (1,0), (0,1), position[2], light = [n,6] rows (x, y, buffer, r, g, b) in evaluation order, raysTraced, shadowRaysTraced, unsupported)."""
+        out = np.zeros(17, np.float64)
+        light = np.zeros((max_light, 6), np.float64)
+        n = C.c_int(0)
+        cnt = np.zeros(3, np.uint64)
+        lib().gpo_gbdpt_sample(self._h, C.byref(cfg), px, py, sample, _p(out), max_light, _p(light), C.byref(n), _p(cnt))
+        assert n.value <= max_light
+        return dict(primal=out[0:3], gradients=out[3:15].reshape(4, 3), position=out[15:17], light=light[:n.value].copy(),
+                    raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]), unsupported=int(cnt[2]))
+
+    def gbdpt_render(self, cfg, rect=None):
+        """-> (block[5,H,W,4] camera blocks (rgb, weight), light[5,H,W,3] light images, dict of counters)."""
+        x0, y0, x1, y1 = rect if rect else (0, 0, self.W, self.H)
+        block = np.zeros((5, self.H, self.W, 4), np.float64)
+        light = np.zeros((5, self.H, self.W, 3), np.float64)
+        cnt = np.zeros(4, np.uint64)
+        lib().gpo_gbdpt_render(self._h, C.byref(cfg), x0, y0, x1, y1, _p(block), _p(light), _p(cnt))
+        return block, light, dict(raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]), unsupported=int(cnt[2]), invalidPuts=int(cnt[3]))
+
     def close(self):
         if self._h:
             lib().gpo_scene_destroy(self._h)
@@ -276,6 +312,18 @@ def develop(accum):
     out = np.zeros(a.shape[:-1] + (3,), np.float64)
     lib().gpo_develop(_p(a), int(np.prod(a.shape[:-1])), _p(out))
     return out
+
+
+def gbdpt_develop(block, light, spp):
+    """GBDPTProcess::develop (gbdpt_proc.cpp:694-706) + MultiFilm::developMulti: the camera block goes into the film storage as it is
+    (setBitmapMulti), the light image is added scaled by weight / sampleCount (addBitmapMulti, multifilm.cpp:351-361: a pixel without
+    any camera sample gets weight 1), develop divides by the weight (fmtconv.cpp: invWeight = w != 0 ? 1 / w : w).  -> rgb[5,H,W,3]"""
+    store = np.array(block, np.float64, copy=True)
+    w = store[..., 3]
+    w[w == 0] = 1.0
+    store[..., :3] += np.asarray(light, np.float64) * (w * (1.0 / spp))[..., None]
+    inv = np.where(w != 0, 1.0 / np.where(w != 0, w, 1.0), w)
+    return store[..., :3] * inv[..., None]
 
 
 def half_vector_shift(main_wi, main_wo, shifted_wi, main_eta=1.0, shifted_eta=1.0):
