@@ -1,0 +1,348 @@
+// gbdpt_capi.hip -- C-ABI (include/gdpt_tracer.h, "G-BDPT") over the gfx950 G-BDPT sampler of gbdpt_kernels.hip.h: what GBDPTRenderer::process
+// computes for a rectangle of pixels (src/integrators/gbdpt/gbdpt_proc.cpp:86-256), the five camera blocks and five light images of
+// GBDPTWorkResult (gbdpt_wr.{h,cpp}) merged as GBDPTProcess::processResult / develop do (gbdpt_proc.cpp:694-763, multifilm.cpp:317-362).
+// No CPU fallback: every value comes from the kernels below.
+#include "../../include/gdpt_tracer.h"
+#include "gbdpt_kernels.hip.h"
+#include "gpt_scene.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace gdpt_tr;
+using namespace gdpt_bd;
+
+extern "C" int gdpt_internal_fail(int code, const char *msg);
+
+namespace {
+
+int bfail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return gdpt_internal_fail(code, buf);
+}
+#define BHIPCHK(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return bfail(GDPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+__device__ __forceinline__ SceneView hbm_scene_view(const SceneD &S)
+{
+    SceneView sv;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf;
+    sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
+    return sv;
+}
+
+// ImageBlock::put (imageblock.h:150-210) with the box filter and negative values allowed (gbdpt_proc.cpp:175-179): a put with a non-finite
+// channel is dropped whole; the footprint [ceil(p - r), floor(p + r)] is one pixel except within 1e-5 of a pixel edge (box.cpp:38).
+// fp64 atomics: a light sample lands on any pixel, and the samples of one pixel are spread over lanes.
+__device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float py, d3 spec, bool withWeight, unsigned long long *invalid)
+{
+    if (!is_finite(spec.x) || !is_finite(spec.y) || !is_finite(spec.z)) { atomicAdd(invalid, 1ULL); return; }
+    const FilterD flt = box_filter();
+    const Float posx = px - 0.5, posy = py - 0.5;
+    const int x0 = max((int)ceil(posx - flt.radius), 0), y0 = max((int)ceil(posy - flt.radius), 0);
+    const int x1 = min((int)floor(posx + flt.radius), W - 1), y1 = min((int)floor(posy + flt.radius), H - 1);
+    for (int y = y0; y <= y1; ++y) {
+        const Float wy = eval_discretized(flt, y - posy);
+        for (int x = x0; x <= x1; ++x) {
+            const Float w = eval_discretized(flt, x - posx) * wy;
+            Float *dest = buf + ((size_t)y * W + x) * stride;
+            atomicAdd(dest + 0, w * spec.x); atomicAdd(dest + 1, w * spec.y); atomicAdd(dest + 2, w * spec.z);
+            if (withWeight) atomicAdd(dest + 3, w * 1.0);
+        }
+    }
+}
+
+// One lane = one (pixel, sample) of the launch: lanes of a wave take consecutive samples of one pixel first, then the next pixel of the tile row
+// (neighbouring paths start alike).  block: [5][H][W][4] (rgb, weight), light: [5][H][W][3].
+__global__ __launch_bounds__(TBLK) void k_gbdpt_render(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, Float *__restrict__ block, Float *__restrict__ light,
+                                                       unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    const int w = x1 - x0, h = y1 - y0;
+    const long long total = (long long)w * h * cfg.sCount;
+    const long long gid = (long long)blockIdx.x * TBLK + threadIdx.x;
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    if (gid < total) {
+        const int sIdx = (int)(gid % cfg.sCount);
+        const long long pix = gid / cfg.sCount;
+        const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
+        const int W = S.cam.width, H = S.cam.height;
+        c.rng.init(cfg.seed, (uint64_t)py * W + px, (uint64_t)(cfg.sBase + sIdx));
+        Sample sm;
+        SampleOut out;
+        process_sample(c, sm, px, py, out);
+        const size_t plane4 = (size_t)W * H * 4, plane3 = (size_t)W * H * 3;
+        film_put(block, 4, W, H, out.posX, out.posY, out.primal, true, stats + 3);                                  // putSample, gbdpt_proc.cpp:531-533
+        for (int k = 0; k < 4; k++) film_put(block + (k + 1) * plane4, 4, W, H, out.posX, out.posY, out.gradient[k], true, stats + 3);
+        for (int i = 0; i < out.nLight; i++) film_put(light + out.light[i].buffer * plane3, 3, W, H, out.light[i].x, out.light[i].y, out.light[i].value, false, stats + 3);   // putLightSample, :514,525
+    }
+    const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    const unsigned n = __builtin_amdgcn_wave_reduce_add_u32(gid < total ? 1u : 0u, 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); atomicAdd(stats + 2, (unsigned long long)n); }
+}
+
+// probe: one sample -> primal(3), gradients(12), position(2), light splats (x, y, buffer, r, g, b), counters
+__global__ __launch_bounds__(TBLK) void k_gbdpt_sample(SceneD S, BdCam cam, BdConfig cfg, int px, int py, int sample, Float *__restrict__ out17, int maxLight, Float *__restrict__ lightOut,
+                                                       int *__restrict__ nLight, unsigned long long *__restrict__ counters)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack; c.nClosest = c.nShadow = 0;
+    c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
+    Sample sm;
+    SampleOut out;
+    process_sample(c, sm, px, py, out);
+    out17[0] = out.primal.x; out17[1] = out.primal.y; out17[2] = out.primal.z;
+    for (int k = 0; k < 4; k++) { out17[3 + 3 * k] = out.gradient[k].x; out17[4 + 3 * k] = out.gradient[k].y; out17[5 + 3 * k] = out.gradient[k].z; }
+    out17[15] = out.posX; out17[16] = out.posY;
+    *nLight = out.nLight;
+    for (int i = 0; i < out.nLight && i < maxLight; i++) {
+        Float *o = lightOut + 6 * i;
+        o[0] = out.light[i].x; o[1] = out.light[i].y; o[2] = out.light[i].buffer; o[3] = out.light[i].value.x; o[4] = out.light[i].value.y; o[5] = out.light[i].value.z;
+    }
+    counters[0] = c.nClosest; counters[1] = c.nShadow;
+}
+
+// GBDPTProcess::develop (gbdpt_proc.cpp:694-706) + MultiFilm::developMulti: the camera block is the film storage (setBitmapMulti), the light
+// image is added scaled by weight / sampleCount (addBitmapMulti, multifilm.cpp:351-361: a pixel without camera samples gets weight 1), then
+// rgb * (1 / weight) (fmtconv.cpp: invWeight = w != 0 ? 1 / w : w).  out: [H][W][3] doubles.
+__global__ void k_gbdpt_develop(const Float *__restrict__ block, const Float *__restrict__ light, int npix, Float multiplier, Float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    Float wgt = block[4 * i + 3];
+    if (wgt == 0) wgt = 1;
+    const Float stored = wgt;
+    wgt *= multiplier;
+    const Float inv = stored != 0 ? 1.0 / stored : stored;
+    for (int k = 0; k < 3; k++) out[3 * i + k] = (block[4 * i + k] + light[3 * i + k] * wgt) * inv;
+}
+
+} // namespace
+
+struct gdpt_gbdpt_film {
+    gdpt_scene *scene = nullptr;
+    Float *block = nullptr, *light = nullptr;      // [5][H][W][4], [5][H][W][3]
+    unsigned long long *stats = nullptr;           // closest rays, shadow rays, samples, invalid puts
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float renderMs = 0.0f;
+    bool timed = false;
+    int W = 0, H = 0;
+};
+
+namespace {
+
+// the G-BDPT path of this library carries connectable vertices only (gbdpt_kernels.hip.h): refuse what would need the specular-chain
+// machinery (propagatePerturbation / manifoldWalk), and the emitters the bidirectional layer is not written for here
+int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
+{
+    if (cfg->maxDepth == 0 || cfg->maxDepth < -1) return bfail(GDPT_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // gbdpt.cpp:102-103
+    if (cfg->rrDepth <= 0) return bfail(GDPT_ERR_INVALID, "'rrDepth' must be set to a value greater than zero!");                                           // gbdpt.cpp:99-100
+    if (cfg->maxDepth > BD_MAX_DEPTH) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d (the reference's own cap for -1, gbdpt_proc.cpp:103-106)", BD_MAX_DEPTH);
+    if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
+    if (s->specialEmitters) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment and point emitters are not carried (area emitters only)");
+    for (size_t i = 0; i < s->hostMats.size(); i++) {
+        const MaterialD &m = s->hostMats[i];
+        if (m.type == 1 || m.type == 3) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: material %d is a Dirac BSDF (conductor / dielectric): specular chains (manifold walks) are not carried", (int)i);
+        if (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: material %d is rougher-than-mirror but below shiftThreshold: treated as specular by the reference, not carried", (int)i);
+    }
+    return GDPT_OK;
+}
+
+BdCam make_cam(const gdpt_scene *s)
+{
+    const CameraD &cd = s->d.cam;
+    BdCam cam;
+    const double a = cd.m[0], b = cd.m[1], cc = cd.m[2], d = cd.m[4], e = cd.m[5], f = cd.m[6], g = cd.m[8], h = cd.m[9], i = cd.m[10];
+    const double A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;                    // adjugate / determinant in a fixed operation order
+    const double det = a * A + b * B + cc * C, r = 1.0 / det;
+    cam.invLin[0] = A * r; cam.invLin[1] = (cc * h - b * i) * r; cam.invLin[2] = (b * f - cc * e) * r;
+    cam.invLin[3] = B * r; cam.invLin[4] = (a * i - cc * g) * r; cam.invLin[5] = (cc * d - a * f) * r;
+    cam.invLin[6] = C * r; cam.invLin[7] = (b * g - a * h) * r; cam.invLin[8] = (a * e - b * d) * r;
+    cam.pos.x = cd.m[3]; cam.pos.y = cd.m[7]; cam.pos.z = cd.m[11];
+    cam.dir.x = cd.m[2]; cam.dir.y = cd.m[6]; cam.dir.z = cd.m[10];
+    cam.rectX = cd.tanHalf; cam.rectY = cd.tanHalf / cd.aspect;
+    cam.normalization = 1.0 / ((2 * cam.rectX) * (2 * cam.rectY));
+    return cam;
+}
+
+BdConfig make_cfg(const gdpt_gbdpt_config *cfg)
+{
+    BdConfig c;
+    c.maxDepth = cfg->maxDepth == -1 ? BD_MAX_DEPTH : cfg->maxDepth;                        // gbdpt_proc.cpp:103-106
+    c.rrDepth = cfg->rrDepth; c.lightImage = cfg->lightImage ? 1 : 0; c.spp = cfg->spp;
+    c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    c.sBase = 0; c.sCount = cfg->spp;
+    return c;
+}
+
+} // namespace
+
+extern "C" {
+
+int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
+{
+    if (!s || !out) return bfail(GDPT_ERR_INVALID, "gbdpt_film_create: null argument");
+    BHIPCHK(hipSetDevice(s->device));
+    gdpt_gbdpt_film *f = new gdpt_gbdpt_film;
+    f->scene = s; f->W = s->d.cam.width; f->H = s->d.cam.height;
+    const size_t npix = (size_t)f->W * f->H;
+    BHIPCHK(hipMalloc((void **)&f->block, sizeof(Float) * 5 * npix * 4));
+    BHIPCHK(hipMalloc((void **)&f->light, sizeof(Float) * 5 * npix * 3));
+    BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 4));
+    BHIPCHK(hipStreamCreate(&f->stream));
+    BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1));
+    *out = f;
+    return gdpt_gbdpt_film_clear(f);
+}
+
+void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
+{
+    if (!f) return;
+    hipSetDevice(f->scene->device);
+    if (f->stream) hipStreamSynchronize(f->stream);
+    hipFree(f->block); hipFree(f->light); hipFree(f->stats);
+    if (f->e0) hipEventDestroy(f->e0);
+    if (f->e1) hipEventDestroy(f->e1);
+    if (f->stream) hipStreamDestroy(f->stream);
+    delete f;
+}
+
+int gdpt_gbdpt_film_clear(gdpt_gbdpt_film *f)
+{
+    if (!f) return bfail(GDPT_ERR_INVALID, "gbdpt_film_clear: null film");
+    BHIPCHK(hipSetDevice(f->scene->device));
+    const size_t npix = (size_t)f->W * f->H;
+    BHIPCHK(hipMemsetAsync(f->block, 0, sizeof(Float) * 5 * npix * 4, f->stream));
+    BHIPCHK(hipMemsetAsync(f->light, 0, sizeof(Float) * 5 * npix * 3, f->stream));
+    BHIPCHK(hipMemsetAsync(f->stats, 0, sizeof(unsigned long long) * 4, f->stream));
+    f->renderMs = 0.0f; f->timed = false;
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, int y0, int x1, int y1, gdpt_gbdpt_film *f)
+{
+    if (!s || !cfg || !f || f->scene != s) return bfail(GDPT_ERR_INVALID, "gbdpt_render_rect: null argument, or a film of another scene");
+    if (x0 < 0 || y0 < 0 || x1 > f->W || y1 > f->H || x0 >= x1 || y0 >= y1) return bfail(GDPT_ERR_INVALID, "gbdpt_render_rect: rectangle outside the film");
+    if (int rc = check_scope(s, cfg)) return rc;
+    BHIPCHK(hipSetDevice(s->device));
+    const BdCam cam = make_cam(s);
+    BdConfig c = make_cfg(cfg);
+    if (f->timed) { float ms = 0; BHIPCHK(hipEventSynchronize(f->e1)); BHIPCHK(hipEventElapsedTime(&ms, f->e0, f->e1)); f->renderMs += ms; f->timed = false; }
+    BHIPCHK(hipEventRecord(f->e0, f->stream));
+    // launches of at most 2^30 lanes: chunks of samples
+    const long long pixels = (long long)(x1 - x0) * (y1 - y0);
+    int chunk = (int)std::max(1LL, std::min((long long)c.spp, (1LL << 30) / pixels));
+    for (int sb = 0; sb < c.spp; sb += chunk) {
+        c.sBase = sb; c.sCount = std::min(chunk, c.spp - sb);
+        const long long total = pixels * c.sCount;
+        const unsigned grid = (unsigned)((total + TBLK - 1) / TBLK);
+        hipLaunchKernelGGL(k_gbdpt_render, dim3(grid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, f->block, f->light, f->stats);
+        BHIPCHK(hipGetLastError());
+    }
+    BHIPCHK(hipEventRecord(f->e1, f->stream));
+    f->timed = true;
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_film_sync(gdpt_gbdpt_film *f)
+{
+    if (!f) return bfail(GDPT_ERR_INVALID, "gbdpt_film_sync: null film");
+    BHIPCHK(hipSetDevice(f->scene->device));
+    BHIPCHK(hipStreamSynchronize(f->stream));
+    if (f->timed) { float ms = 0; BHIPCHK(hipEventElapsedTime(&ms, f->e0, f->e1)); f->renderMs += ms; f->timed = false; }
+    return GDPT_OK;
+}
+
+float gdpt_gbdpt_film_render_ms(gdpt_gbdpt_film *f)
+{
+    if (!f || gdpt_gbdpt_film_sync(f) != GDPT_OK) return -1.0f;
+    return f->renderMs;
+}
+
+int gdpt_gbdpt_film_accum(gdpt_gbdpt_film *f, double *block, double *light)
+{
+    if (!f || !block || !light) return bfail(GDPT_ERR_INVALID, "gbdpt_film_accum: null argument");
+    if (int rc = gdpt_gbdpt_film_sync(f)) return rc;
+    const size_t npix = (size_t)f->W * f->H;
+    BHIPCHK(hipMemcpy(block, f->block, sizeof(Float) * 5 * npix * 4, hipMemcpyDeviceToHost));
+    BHIPCHK(hipMemcpy(light, f->light, sizeof(Float) * 5 * npix * 3, hipMemcpyDeviceToHost));
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_film_develop_device(gdpt_gbdpt_film *f, int buffer, int spp, double *rgbDevice)
+{
+    if (!f || !rgbDevice || buffer < 0 || buffer > 4 || spp <= 0) return bfail(GDPT_ERR_INVALID, "gbdpt_film_develop: bad argument");
+    BHIPCHK(hipSetDevice(f->scene->device));
+    const int npix = f->W * f->H;
+    hipLaunchKernelGGL(k_gbdpt_develop, dim3((npix + 255) / 256), dim3(256), 0, f->stream, f->block + (size_t)buffer * npix * 4, f->light + (size_t)buffer * npix * 3, npix,
+                       (Float)(1.0 / spp), rgbDevice);
+    BHIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_film_develop(gdpt_gbdpt_film *f, int buffer, int spp, double *rgbHost)
+{
+    if (!f || !rgbHost) return bfail(GDPT_ERR_INVALID, "gbdpt_film_develop: null argument");
+    BHIPCHK(hipSetDevice(f->scene->device));
+    const size_t n = (size_t)f->W * f->H * 3;
+    double *d = nullptr;
+    BHIPCHK(hipMalloc((void **)&d, sizeof(double) * n));
+    int rc = gdpt_gbdpt_film_develop_device(f, buffer, spp, d);
+    if (rc == GDPT_OK) { hipError_t e = hipStreamSynchronize(f->stream); if (e == hipSuccess) e = hipMemcpy(rgbHost, d, sizeof(double) * n, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = bfail(GDPT_ERR_HIP, "gbdpt_film_develop: %s", hipGetErrorString(e)); }
+    hipFree(d);
+    return rc;
+}
+
+int gdpt_gbdpt_film_stats(gdpt_gbdpt_film *f, unsigned long long stats[4])
+{
+    if (!f || !stats) return bfail(GDPT_ERR_INVALID, "gbdpt_film_stats: null argument");
+    if (int rc = gdpt_gbdpt_film_sync(f)) return rc;
+    BHIPCHK(hipMemcpy(stats, f->stats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return GDPT_OK;
+}
+
+void *gdpt_gbdpt_film_stream(gdpt_gbdpt_film *f) { return f ? (void *)f->stream : nullptr; }
+
+int gdpt_gbdpt_evaluate_sample(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17], int maxLight, double *light6, int *nLight,
+                               unsigned long long counters[2])
+{
+    if (!s || !cfg || !out17 || !nLight || !counters || maxLight < 0 || (maxLight > 0 && !light6)) return bfail(GDPT_ERR_INVALID, "gbdpt_evaluate_sample: bad argument");
+    if (px < 0 || py < 0 || px >= s->d.cam.width || py >= s->d.cam.height) return bfail(GDPT_ERR_INVALID, "gbdpt_evaluate_sample: pixel outside the film");
+    if (int rc = check_scope(s, cfg)) return rc;
+    BHIPCHK(hipSetDevice(s->device));
+    const BdCam cam = make_cam(s);
+    const BdConfig c = make_cfg(cfg);
+    double *d = nullptr, *dl = nullptr;
+    int *dn = nullptr;
+    unsigned long long *dc = nullptr;
+    const int ml = std::max(maxLight, 1);
+    BHIPCHK(hipMalloc((void **)&d, sizeof(double) * 17));
+    BHIPCHK(hipMalloc((void **)&dl, sizeof(double) * 6 * ml));
+    BHIPCHK(hipMalloc((void **)&dn, sizeof(int)));
+    BHIPCHK(hipMalloc((void **)&dc, sizeof(unsigned long long) * 2));
+    hipLaunchKernelGGL(k_gbdpt_sample, dim3(1), dim3(TBLK), 0, 0, s->d, cam, c, px, py, sample, d, maxLight, dl, dn, dc);
+    BHIPCHK(hipGetLastError());
+    BHIPCHK(hipMemcpy(out17, d, sizeof(double) * 17, hipMemcpyDeviceToHost));
+    BHIPCHK(hipMemcpy(nLight, dn, sizeof(int), hipMemcpyDeviceToHost));
+    if (maxLight > 0) BHIPCHK(hipMemcpy(light6, dl, sizeof(double) * 6 * std::min(maxLight, std::max(*nLight, 0)), hipMemcpyDeviceToHost));
+    BHIPCHK(hipMemcpy(counters, dc, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost));
+    hipFree(d); hipFree(dl); hipFree(dn); hipFree(dc);
+    return GDPT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,868 @@
+// gbdpt_kernels.hip.h -- the G-BDPT sampler (BASELINE config 5) as a gfx950 kernel: one lane = one (pixel, sample).
+//
+// What the reference computes per sample (src/integrators/gbdpt/gbdpt_proc.cpp:152-252 GBDPTRenderer::process, :259-534 evaluate): an emitter
+// and a sensor subpath by an alternating random walk (src/libbidir/path.cpp:548-631), the four offset paths of the sensor subpath (pixel
+// shifts (0,-1) (-1,0) (1,0) (0,1); src/libbidir/mut_manifold.cpp:806-936 generateOffsetPathGBDPT), then every connection (s, t) of the two
+// subpaths for the base and the four offset paths with the MIS weights of path.cpp:49-378 (power 2 over the base strategies for the primal
+// value, balance over base + offset strategies for each gradient), light-tracing connections (t = 1) splatted into light images together with
+// their own four offset paths (gbdpt_proc.cpp:356-376,568-590).
+//
+// The reference walks heap-allocated PathVertex / PathEdge objects shared by pointer between base and offset paths.  Here a path is a pair
+// of fixed arrays of compact vertex records per lane (position, triangle + barycentrics, the two transport weights and densities, the edge
+// that arrived) and an offset path is three records (sensor sample, the shifted first vertex b', the re-connected vertex c') next to the
+// base arrays; `SV` below resolves an index of "the offset sensor subpath" to the right record.  All arithmetic is fp64, in the reference's
+// operation order (parity with oracle/gbdpt_oracle.hpp is held at 1e-10 per sample).
+//
+// SCOPE: every surface vertex connectable (Path::isConnectable_GBDPT, path.cpp:30-47): smooth BSDFs with roughness >= shiftThreshold.  The
+// C-ABI refuses other scenes (gbdpt_capi.hip); then no specular chain exists: propagatePerturbation / manifoldWalk are never entered,
+// SpecularManifold::det is 1 (manifold.cpp:774) and every generalized geometry term of calcSpecularPDFChange (path.cpp:403-421) is a
+// product of plain G terms divided by the same product, i.e. exactly 1.
+#pragma once
+#include "gpt_kernels.hip.h"
+
+namespace gdpt_bd {
+using namespace gdpt_tr;
+
+enum { ERadiance = 0, EImportance = 1 };                                                   // include/mitsuba/render/common.h:33-43
+enum { M_INVALID = 0, M_SOLID = 1, M_AREA = 3, M_DISCRETE = 4 };                           // EMeasure, common.h:56-67
+enum { T_INVALID = 0, T_SENSOR_SUPER = 1, T_EMITTER_SUPER = 2, T_SENSOR_SAMPLE = 4, T_EMITTER_SAMPLE = 8, T_SURFACE = 16 };   // vertex.h:67-87
+
+constexpr int BD_MAX_DEPTH = 12;                   // gbdpt_proc.cpp:103-106: maxDepth -1 renders as 12; the C-ABI takes 1..12
+constexpr int NSV = BD_MAX_DEPTH + 2;              // sensor subpath records: supernode, sensor sample, up to maxDepth surface vertices
+constexpr int NEV = BD_MAX_DEPTH + 1;              // emitter subpath records: supernode, emitter sample, up to maxDepth - 1 surface vertices
+constexpr int NMIS = NSV + NEV;                    // pdfImp / pdfRad entries of a full path
+constexpr int BD_MAX_LIGHT = 5 * BD_MAX_DEPTH;     // light-image splats of one sample (5 per emitter vertex)
+
+struct BdConfig {
+    int maxDepth, rrDepth, lightImage, spp;
+    Float shiftThreshold;
+    unsigned long long seed;
+    int sBase, sCount;                             // the samples [sBase, sBase + sCount) of every pixel are rendered by this launch
+};
+struct BdCam {                                     // perspective sensor quantities beyond CameraD (perspective.cpp:167-173,190-247)
+    Float invLin[9];                               // linear part of the inverse camera-to-world (trafo.inverse() applied to a direction)
+    d3 pos, dir;                                   // trafo(Point(0)), trafo(Vector(0, 0, 1))
+    Float rectX, rectY, normalization;             // m_imageRect half extents, 1 / its area
+};
+
+struct BV {                                        // PathVertex
+    int type, measure, degenerate, componentType;
+    int prim, object;                              // surface: leaf-order triangle; emitter samples (and surfaces on emitters after cast()): emitter index
+    Float u, v;                                    // surface: barycentrics; sensor sample: film position (pRec.uv)
+    d3 p, n;                                       // position; pRec.n of a sensor / emitter sample (a surface keeps its frames in the scene tables)
+    d3 w[2];                                       // weight[ERadiance], weight[EImportance]
+    Float pdf[2];
+    Float rr;                                      // rrWeight
+};
+struct BE { d3 d; Float length; Float tr[2]; };    // PathEdge: direction (along the light path), length, pdf[mode] == weight[mode] (1, or the 0/1 of a supernode edge)
+
+__device__ __forceinline__ bool bv_connectable(const BV &v) { return !v.degenerate && v.measure != M_DISCRETE; }   // vertex.h:750
+__device__ __forceinline__ bool bv_on_surface(const BV &v) { return v.type == T_SURFACE || v.type == T_EMITTER_SAMPLE || v.type == T_SENSOR_SAMPLE; }   // vertex.h:592-596
+__device__ __forceinline__ bool bv_super(const BV &v) { return (v.type & 3) != 0; }
+__device__ __forceinline__ void bv_clear(BV &v)
+{
+    v.type = T_INVALID; v.measure = M_INVALID; v.degenerate = 0; v.componentType = 0; v.prim = -1; v.object = -1; v.u = v.v = 0.0;
+    v.p = mk(0.0); v.n = mk(0.0); v.w[0] = v.w[1] = mk(0.0); v.pdf[0] = v.pdf[1] = 0.0; v.rr = 0.0;
+}
+__device__ __forceinline__ void be_clear(BE &e) { e.d = mk(0.0); e.length = 0.0; e.tr[0] = e.tr[1] = 0.0; }
+
+struct Surf { Frame3 fr; d3 geoN; MaterialD m; d3 R; };   // what its.getBSDF() / its.shFrame / its.geoFrame give at a surface vertex
+
+struct Ctx {
+    const SceneD *S;
+    SceneView V;
+    BdCam cam;
+    BdConfig cfg;
+    int *stack;
+    Rng rng;
+    unsigned nClosest, nShadow;
+};
+
+__device__ __forceinline__ Surf surf_of(const Ctx &c, const BV &v)
+{
+    Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+    const Shading sh = shading_at<true>(c.V, vx);
+    Surf s;
+    s.fr = sh.fr; s.geoN = sh.geoN;
+    s.m = c.V.mats[c.V.shade[v.prim].material];
+    s.R = reflectance_at<true, false>(c.V, s.m, vx);                                       // libbidir asks its.getBSDF() without a ray: no UV partials
+    return s;
+}
+__device__ __forceinline__ d3 bv_sh_normal(const Ctx &c, const BV &v)
+{
+    if (v.type != T_SURFACE) return v.n;
+    Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+    return shading_at<true>(c.V, vx).fr.n;
+}
+__device__ __forceinline__ d3 bv_geo_normal(const Ctx &c, const BV &v)
+{
+    if (v.type != T_SURFACE) return v.n;
+    Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+    return shading_at<true>(c.V, vx).geoN;
+}
+__device__ __forceinline__ Float mat_roughness(const MaterialD &m) { return m.type == 0 ? GD_INF : ((m.type == 1 || m.type == 3) ? 0.0 : 0.5 * (m.alphaU + m.alphaV)); }
+// Path::isConnectable_GBDPT, path.cpp:30-47
+__device__ __forceinline__ bool connectable_gbdpt(const Ctx &c, const BV &v)
+{
+    if (!bv_connectable(v)) return false;
+    if (v.type & (T_SENSOR_SUPER | T_EMITTER_SUPER | T_SENSOR_SAMPLE | T_EMITTER_SAMPLE)) return true;
+    return !(mat_roughness(c.V.mats[c.V.shade[v.prim].material]) < c.cfg.shiftThreshold);
+}
+
+// ---- sensor --------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ d3 cam_to_local(const Ctx &c, d3 d) { return mul3(c.cam.invLin, d); }
+__device__ __forceinline__ d3 cam_to_world(const Ctx &c, d3 d)
+{
+    const Float *M = c.S->cam.m;
+    return mk(M[0] * d.x + M[1] * d.y + M[2] * d.z, M[4] * d.x + M[5] * d.y + M[6] * d.z, M[8] * d.x + M[9] * d.y + M[10] * d.z);
+}
+// PerspectiveCameraImpl::importance, perspective.cpp:190-247
+__device__ __forceinline__ Float importance(const Ctx &c, d3 d)
+{
+    const Float cosT = d.z;
+    if (cosT <= 0) return 0.0;
+    const Float inv = 1.0 / cosT;
+    const Float px = d.x * inv, py = d.y * inv;
+    if (!(px >= -c.cam.rectX && px <= c.cam.rectX && py >= -c.cam.rectY && py <= c.cam.rectY)) return 0.0;
+    return c.cam.normalization * inv * inv * inv;
+}
+// normalize(m_sampleToCamera(Point(sx, sy, 0))), perspective.cpp:150-156 written out for crop == film
+__device__ __forceinline__ d3 sample_to_camera_dir(const Ctx &c, Float sxn, Float syn)
+{
+    const CameraD &cam = c.S->cam;
+    return normalize(mk((1 - 2 * sxn) * cam.nearClip * cam.tanHalf, (1 - 2 * syn) / cam.aspect * cam.nearClip * cam.tanHalf, cam.nearClip));
+}
+// PerspectiveCameraImpl::getSamplePosition, perspective.cpp:393-410
+__device__ __forceinline__ bool sensor_sample_position(const Ctx &c, d3 dWorld, Float &ox, Float &oy)
+{
+    const CameraD &cam = c.S->cam;
+    const d3 l = cam_to_local(c, dWorld);
+    if (l.z <= 0) return false;
+    const Float sx = 0.5 * (1 - l.x / (l.z * cam.tanHalf)), sy = 0.5 * (1 - l.y * cam.aspect / (l.z * cam.tanHalf));
+    if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return false;
+    ox = sx * cam.width; oy = sy * cam.height;
+    return true;
+}
+
+// ---- emitters ------------------------------------------------------------------------------------------------------------------------
+// Scene::sampleEmitterPosition (scene.cpp:985-1001) -> AreaLight::samplePosition (area.cpp:93-97) -> TriMesh / Rectangle::samplePosition
+__device__ __forceinline__ d3 sample_emitter_position(const Ctx &c, BV &succ, Float sx, Float sy, Float &pdfOut)
+{
+    const SceneView &V = c.V;
+    const int index = cdf_sample(V.emitterCdf, c.S->numEmitters, sx);
+    const Float emPdf = V.emitterCdf[index + 1] - V.emitterCdf[index];
+    sx = (sx - V.emitterCdf[index]) / (V.emitterCdf[index + 1] - V.emitterCdf[index]);
+    const EmitterD em = V.emitters[index];
+    if (em.rectangle) {
+        const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
+        succ.p = mk(em.rect[0] * lx + em.rect[1] * ly + em.rect[2] * 0.0 + em.rect[3], em.rect[4] * lx + em.rect[5] * ly + em.rect[6] * 0.0 + em.rect[7],
+                    em.rect[8] * lx + em.rect[9] * ly + em.rect[10] * 0.0 + em.rect[11]);
+        succ.n = em.rectN;
+        succ.u = sx; succ.v = sy;
+    } else {
+        const Float *cdf = V.emCdf + em.cdfOffset;
+        const int ti = cdf_sample(cdf, em.numTris, sy);
+        sy = (sy - cdf[ti]) / (cdf[ti + 1] - cdf[ti]);
+        const EmTri tr = V.emTris[em.firstEmTri + ti];
+        const Float a = safe_sqrt(1.0 - sx);
+        const Float bx = 1 - a, by = a * sy;
+        const d3 sideA = tr.p1 - tr.p0, sideB = tr.p2 - tr.p0;
+        succ.p = tr.p0 + (sideA * bx) + (sideB * by);
+        succ.n = normalize(cross(sideA, sideB));
+        succ.u = bx; succ.v = by;
+    }
+    Float pdf = em.invSurfaceArea;
+    succ.object = index;
+    pdf *= emPdf;
+    pdfOut = pdf;
+    const Float area = 1.0 / em.invSurfaceArea;
+    const d3 power = em.radiance * GD_PI * area;
+    return power / emPdf;
+}
+__device__ __forceinline__ Float pdf_emitter_position(const Ctx &c, int object) { return c.V.emitters[object].invSurfaceArea * (1.0 * c.S->emitterNormalization); }   // scene.cpp:1003-1006
+__device__ __forceinline__ Float area_direction(d3 d, d3 n, int measure)                    // AreaLight::evalDirection / pdfDirection, area.cpp:124-142
+{
+    Float dp = dot(d, n);
+    if (measure != M_SOLID || dp < 0) dp = 0.0;
+    return GD_INV_PI * dp;
+}
+__device__ __forceinline__ int bsdf_measure(int m) { return m == M_DISCRETE ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE; }
+
+// ---- rays ----------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool closest_hit(Ctx &c, d3 o, d3 d, Float mint, Float maxt, Hit &h)
+{
+    c.nClosest++;
+    return trace<false>(c.V, c.stack, o, d, ray_mint_closest(o, mint), maxt, h);
+}
+__device__ __forceinline__ bool any_hit(Ctx &c, d3 o, d3 d, Float mint, Float maxt)
+{
+    c.nShadow++;
+    Hit h;
+    return trace<true>(c.V, c.stack, o, d, ray_mint_shadow(o, mint), maxt, h);
+}
+__device__ __forceinline__ void fill_surface(const Ctx &c, const Hit &h, BV &succ)
+{
+    const TriShade &ts = c.V.shade[h.prim];
+    const d3 b = mk(1 - h.u - h.v, h.u, h.v);
+    succ.type = T_SURFACE;
+    succ.prim = h.prim; succ.u = h.u; succ.v = h.v;
+    succ.p = ts.p0 * b.x + ts.p1 * b.y + ts.p2 * b.z;
+    const MaterialD &m = c.V.mats[ts.material];
+    succ.degenerate = !((bsdfType(m) & ESmooth) || ts.emitter >= 0);                       // edge.cpp:44-45
+    succ.object = ts.emitter;
+}
+// PathEdge::sampleNext (edge.cpp:27-71) and PathEdge::perturbDirection (:73-131) without media: the ray's closest hit becomes the successor
+__device__ __forceinline__ bool edge_extend(Ctx &c, BE &e, d3 o, d3 d, BV &succ, int mode, bool perturb, Float dist)
+{
+    Hit h;
+    const bool surface = closest_hit(c, o, d, GD_EPSILON, GD_INF, h);
+    if (perturb && dist <= 0) return false;
+    if (!surface) return false;
+    fill_surface(c, h, succ);
+    e.length = h.t;
+    e.d = mode == ERadiance ? -d : d;
+    if (e.length == 0) return false;
+    e.tr[0] = e.tr[1] = 1.0;
+    return true;
+}
+// PathEdge::connect, edge.cpp:221-287
+__device__ __forceinline__ bool edge_connect(Ctx &c, BE &e, const BV &vs, const BV &vt)
+{
+    if (vs.type == T_EMITTER_SUPER || vt.type == T_SENSOR_SUPER) {
+        const Float rad = vt.type == T_SENSOR_SUPER ? 1.0 : 0.0;
+        e.d = mk(0.0); e.length = 0.0; e.tr[ERadiance] = rad; e.tr[EImportance] = 1 - rad;
+    } else {
+        e.d = vs.p - vt.p;
+        e.length = len(e.d);
+        e.d = e.d / e.length;
+        if (any_hit(c, vt.p, e.d, bv_on_surface(vt) ? GD_EPSILON : 0.0, e.length * (bv_on_surface(vs) ? (1 - GD_SHADOW_EPSILON) : 1.0))) return false;
+        e.tr[0] = e.tr[1] = 1.0;
+    }
+    e.d = -e.d;
+    return true;
+}
+// PathEdge::pathConnectAndCollapse, edge.cpp:442-574 (no media, no ENull BSDF: a surface in between is an occluder)
+__device__ __forceinline__ bool edge_path_connect(Ctx &c, BE &e, const BV &vs, const BV &vt)
+{
+    if (vs.type == T_EMITTER_SUPER || vt.type == T_SENSOR_SUPER) {
+        const Float rad = vt.type == T_SENSOR_SUPER ? 1.0 : 0.0;
+        e.length = 0.0; e.d = mk(0.0); e.tr[ERadiance] = rad; e.tr[EImportance] = 1 - rad;
+    } else {
+        e.d = vs.p - vt.p;
+        e.length = len(e.d);
+        if (e.length == 0) return false;
+        e.d = e.d / e.length;
+        e.tr[0] = e.tr[1] = 1.0;
+        Hit h;
+        if (closest_hit(c, vt.p, e.d, bv_on_surface(vt) ? GD_EPSILON : 0.0, e.length * (bv_on_surface(vs) ? (1 - GD_SHADOW_EPSILON) : 1.0), h)) return false;
+    }
+    e.d = -e.d;
+    return true;
+}
+// PathEdge::evalCached(pred, succ, EGeneralizedGeometricTerm), edge.cpp:169-219: cosines at connectable surface ends, inverse square, transmittance
+__device__ __forceinline__ Float edge_geometry_term(const Ctx &c, const BE &e, const BV &pred, const BV &succ)
+{
+    Float result = 1.0;
+    if (e.length == 0) return result;
+    if (bv_on_surface(pred) && bv_connectable(pred)) result *= fabs(dot(bv_sh_normal(c, pred), e.d));
+    if (bv_on_surface(succ) && bv_connectable(succ)) result *= fabs(dot(bv_sh_normal(c, succ), e.d));
+    result /= e.length * e.length;
+    result *= e.tr[EImportance] * e.tr[EImportance];                                        // weight[EImportance] * pdf[EImportance]
+    return result;
+}
+
+// ---- PathVertex ----------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adjoint(BV &v, int mode, d3 wiL, d3 woL, Float wiDotGeoN, Float woDotGeoN)   // vertex.cpp:213-221,611-619
+{
+    if (mode == EImportance) v.w[EImportance] = v.w[EImportance] * fabs((wiL.z * woDotGeoN) / (woL.z * wiDotGeoN));
+    else v.w[EImportance] = v.w[EImportance] * fabs((woL.z * wiDotGeoN) / (wiL.z * woDotGeoN));
+}
+__device__ __forceinline__ void to_area(const Ctx &c, BV &v, int mode, const BV &pred, const BE &predEdge, const BE &succEdge, const BV &succ, d3 rayD)
+{                                                                                          // vertex.cpp:294-307,663-676
+    if (v.measure != M_SOLID) return;
+    v.measure = M_AREA;
+    v.pdf[mode] /= succEdge.length * succEdge.length;
+    if (bv_on_surface(succ)) v.pdf[mode] *= fabs(dot(rayD, bv_geo_normal(c, succ)));
+    if (predEdge.length != 0.0) {
+        v.pdf[1 - mode] /= predEdge.length * predEdge.length;
+        if (bv_on_surface(pred)) v.pdf[1 - mode] *= fabs(dot(predEdge.d, bv_geo_normal(c, pred)));
+    }
+}
+// PathVertex::sampleNext, vertex.cpp:35-310 (the sensor endpoints go through sample_sensor)
+__device__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE *predEdge, BE &succEdge, BV &succ, int mode, bool russianRoulette, d3 &throughput)
+{
+    d3 ro, rd;
+    be_clear(succEdge); bv_clear(succ);
+    v.rr = 1.0;
+    if (v.type == T_EMITTER_SUPER) {
+        const Float sx = c.rng.next1D(), sy = c.rng.next1D();
+        Float ppdf;
+        const d3 result = sample_emitter_position(c, succ, sx, sy, ppdf);
+        if (is_zero(result)) return false;
+        v.w[EImportance] = result;
+        v.pdf[EImportance] = ppdf;
+        v.measure = M_AREA;
+        succ.type = T_EMITTER_SAMPLE;
+        succ.degenerate = 0;
+        succEdge.tr[EImportance] = 1.0;
+        return true;
+    } else if (v.type == T_EMITTER_SAMPLE) {                                               // AreaLight::sampleDirection, area.cpp:114-122
+        const Float sx = c.rng.next1D(), sy = c.rng.next1D();
+        const d3 local = squareToCosineHemisphere(sx, sy);
+        Frame3 fr; fr.n = v.n;
+        if (fabs(fr.n.x) > fabs(fr.n.y)) { const Float il = 1.0 / sqrt(fr.n.x * fr.n.x + fr.n.z * fr.n.z); fr.t = mk(fr.n.z * il, 0.0, -fr.n.x * il); }   // coordinateSystem, util.cpp:592-601
+        else { const Float il = 1.0 / sqrt(fr.n.y * fr.n.y + fr.n.z * fr.n.z); fr.t = mk(0.0, fr.n.z * il, -fr.n.y * il); }
+        fr.s = cross(fr.t, fr.n);
+        rd = toWorld(fr, local);
+        const Float dpdf = GD_INV_PI * local.z;
+        v.w[EImportance] = mk(1.0);
+        v.w[ERadiance] = mk(1.0) * dpdf * (1.0 / fabs(dot(rd, v.n)));
+        v.pdf[EImportance] = dpdf;
+        v.pdf[ERadiance] = 1.0;
+        v.measure = M_SOLID;
+        ro = v.p;
+    } else if (v.type == T_SURFACE) {
+        const Surf sf = surf_of(c, v);
+        const d3 wi = normalize(pred->p - v.p);
+        const d3 wiL = toLocal(sf.fr, wi);
+        const Float sx = c.rng.next1D(), sy = c.rng.next1D();
+        BSDFSample bs;
+        bsdf_sample(sf.m, sf.R, wiL, sx, sy, bs);
+        v.w[mode] = bs.weight; v.pdf[mode] = bs.pdf;
+        if (is_zero(v.w[mode])) return false;
+        v.measure = (bs.sampledType & ESmooth) ? M_SOLID : M_DISCRETE;
+        v.componentType = bs.sampledType;
+        const d3 wo = toWorld(sf.fr, bs.wo);
+        const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
+        if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * bs.wo.z <= 0) return false;
+        d3 fRev; Float pRev;
+        bsdf_eval_pdf(sf.m, sf.R, bs.wo, wiL, bsdf_measure(v.measure), fRev, pRev);          // bRec.reverse(); bsdf->pdf
+        v.pdf[1 - mode] = pRev;
+        if (v.pdf[1 - mode] <= 0x1p-1024) return false;
+        v.w[1 - mode] = v.w[mode] * (v.pdf[mode] / v.pdf[1 - mode]);
+        if (v.measure == M_SOLID) v.w[1 - mode] = v.w[1 - mode] * fabs(wiL.z / bs.wo.z);
+        adjoint(v, mode, wiL, bs.wo, wiDotGeoN, woDotGeoN);
+        ro = v.p; rd = wo;
+    } else return false;
+    throughput = throughput * v.w[mode];
+    if (russianRoulette) {
+        const Float q = fmin(maxc(throughput), (Float)0.95f);
+        if (c.rng.next1D() > q) { v.measure = M_INVALID; return false; }
+        v.rr = 1.0 / q;
+        throughput = throughput * v.rr;
+    }
+    if (!edge_extend(c, succEdge, ro, rd, succ, mode, false, 0.0)) { v.measure = M_INVALID; return false; }
+    to_area(c, v, mode, *pred, *predEdge, succEdge, succ, rd);
+    return true;
+}
+// PathVertex::sampleSensor, vertex.cpp:312-384 (perspective: the direction sample maps to pixels; no aperture sample)
+__device__ int sample_sensor(Ctx &c, BV &v0, int px, int py, BE &e0, BV &v1, BE &e1, BV &v2)
+{
+    be_clear(e0); bv_clear(v1);
+    const Float sx = c.rng.next1D(), sy = c.rng.next1D();
+    v1.p = c.cam.pos; v1.n = c.cam.dir; v1.object = -2;
+    v0.w[ERadiance] = mk(1.0); v0.pdf[ERadiance] = 1.0; v0.measure = M_DISCRETE; v0.rr = 1.0;
+    v1.type = T_SENSOR_SAMPLE; v1.degenerate = 0;
+    e0.tr[ERadiance] = 1.0;
+    const CameraD &cam = c.S->cam;
+    const Float spx = (px + sx) * cam.invW, spy = (py + sy) * cam.invH;
+    v1.u = spx * cam.width; v1.v = spy * cam.height;
+    const d3 dl = sample_to_camera_dir(c, spx, spy);
+    const d3 d = cam_to_world(c, dl);
+    const Float dpdf = c.cam.normalization / (dl.z * dl.z * dl.z);
+    be_clear(e1); bv_clear(v2);
+    v1.w[EImportance] = mk(1.0) * dpdf * (1.0 / fabs(dot(d, v1.n)));
+    v1.w[ERadiance] = mk(1.0);
+    v1.pdf[EImportance] = 1.0; v1.pdf[ERadiance] = dpdf;
+    v1.rr = 1.0;
+    v1.measure = M_SOLID;
+    if (!edge_extend(c, e1, v1.p, d, v2, ERadiance, false, 0.0)) { v1.measure = M_INVALID; return 1; }
+    v1.measure = M_AREA;
+    v1.pdf[ERadiance] /= e1.length * e1.length;
+    if (bv_on_surface(v2)) v1.pdf[ERadiance] *= fabs(dot(d, bv_geo_normal(c, v2)));
+    return 2;
+}
+// PathVertex::perturbDirection, vertex.cpp:488-679 (mode is always ERadiance on the G-BDPT path: the sensor sample is what gets perturbed;
+// the surface branch belongs to propagatePerturbation through glossy chains, which connectable-only scenes never enter)
+__device__ bool perturb_direction(Ctx &c, BV &v, const BV &pred, const BE &predEdge, BE &succEdge, BV &succ, d3 d, Float dist)
+{
+    be_clear(succEdge); bv_clear(succ);
+    if (v.degenerate) return false;
+    if (v.type != T_SENSOR_SAMPLE) return false;
+    const Float value = importance(c, cam_to_local(c, d)), prob = value;
+    if (value == 0 || prob <= 0x1p-1024) return false;
+    v.w[EImportance] = mk(value) * (1.0 / fabs(dot(d, v.n)));
+    v.w[ERadiance] = mk(value) / prob;
+    v.pdf[EImportance] = 1.0;
+    v.pdf[ERadiance] = prob;
+    v.measure = M_SOLID;
+    if (!edge_extend(c, succEdge, v.p, d, succ, ERadiance, true, dist)) { v.measure = M_INVALID; return false; }
+    to_area(c, v, ERadiance, pred, predEdge, succEdge, succ, d);
+    return true;
+}
+// PathVertex::eval, vertex.cpp:781-913
+__device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ, int mode, int measure = M_AREA)
+{
+    if (v.type == T_EMITTER_SUPER) {
+        if (mode != EImportance || pred != nullptr || succ->type != T_EMITTER_SAMPLE) return mk(0.0);
+        return c.V.emitters[succ->object].radiance * GD_PI;
+    } else if (v.type == T_SENSOR_SUPER) {
+        if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return mk(0.0);
+        return mk(measure == M_DISCRETE ? 1.0 : 0.0);
+    } else if (v.type == T_EMITTER_SAMPLE || v.type == T_SENSOR_SAMPLE) {
+        const bool emitter = v.type == T_EMITTER_SAMPLE;
+        const int fwd = emitter ? EImportance : ERadiance, superT = emitter ? T_EMITTER_SUPER : T_SENSOR_SUPER;
+        d3 target;
+        if (mode == fwd && pred->type == superT) target = succ->p;
+        else if (mode == 1 - fwd && succ->type == superT) target = pred->p;
+        else return mk(0.0);
+        const d3 wo = normalize(target - v.p);
+        const int dm = measure == M_AREA ? M_SOLID : measure;
+        d3 result = mk(emitter ? area_direction(wo, v.n, dm) : (dm != M_SOLID ? 0.0 : importance(c, cam_to_local(c, wo))));
+        const Float dp = fabs(dot(v.n, wo));
+        if (measure != M_DISCRETE && dp != 0) result = result / dp;
+        return result;
+    } else if (v.type == T_SURFACE) {
+        const Surf sf = surf_of(c, v);
+        const d3 wi = normalize(pred->p - v.p), wo = normalize(succ->p - v.p);
+        const d3 wiL = toLocal(sf.fr, wi), woL = toLocal(sf.fr, wo);
+        if (measure == M_AREA) measure = M_SOLID;
+        d3 result; Float pdfUnused;
+        bsdf_eval_pdf(sf.m, sf.R, wiL, woL, bsdf_measure(measure), result, pdfUnused);
+        const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
+        if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * woL.z <= 0) return mk(0.0);
+        if (mode == EImportance) result = result * fabs((wiL.z * woDotGeoN) / (woL.z * wiDotGeoN));
+        if (measure != M_DISCRETE && woL.z != 0) result = result / fabs(woL.z);
+        return result;
+    }
+    return mk(0.0);
+}
+// PathVertex::evalPdf, vertex.cpp:915-1022
+__device__ Float bv_eval_pdf(const Ctx &c, const BV &v, const BV *pred, const BV *succ, int mode, int measure = M_AREA)
+{
+    d3 wo = mk(0.0);
+    Float dist = 0.0, result = 0.0;
+    if (v.type == T_EMITTER_SUPER) {
+        if (mode != EImportance || pred != nullptr || succ->type != T_EMITTER_SAMPLE) return 0.0;
+        return pdf_emitter_position(c, succ->object);
+    } else if (v.type == T_SENSOR_SUPER) {
+        if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return 0.0;
+        return measure == M_DISCRETE ? 1.0 : 0.0;
+    } else if (v.type == T_EMITTER_SAMPLE) {
+        if (mode == ERadiance && succ->type == T_EMITTER_SUPER) return 1.0;
+        else if (mode != EImportance || pred->type != T_EMITTER_SUPER) return 0.0;
+        wo = succ->p - v.p;
+        dist = len(wo); wo = wo / dist;
+        result = area_direction(wo, v.n, measure == M_AREA ? M_SOLID : measure);
+    } else if (v.type == T_SENSOR_SAMPLE) {
+        if (mode == EImportance && succ->type == T_SENSOR_SUPER) return 1.0;
+        else if (mode != ERadiance || pred->type != T_SENSOR_SUPER) return 0.0;
+        wo = succ->p - v.p;
+        dist = len(wo); wo = wo / dist;
+        result = (measure == M_AREA ? M_SOLID : measure) != M_SOLID ? 0.0 : importance(c, cam_to_local(c, wo));
+    } else if (v.type == T_SURFACE) {
+        const Surf sf = surf_of(c, v);
+        wo = succ->p - v.p;
+        dist = len(wo); wo = wo / dist;
+        const d3 wi = normalize(pred->p - v.p);
+        const d3 wiL = toLocal(sf.fr, wi), woL = toLocal(sf.fr, wo);
+        d3 fUnused;
+        bsdf_eval_pdf(sf.m, sf.R, wiL, woL, bsdf_measure(measure == M_AREA ? M_SOLID : measure), fUnused, result);
+        const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
+        if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * woL.z <= 0) return 0.0;
+    } else return 0.0;
+    if (measure == M_AREA) {
+        result /= dist * dist;
+        if (bv_on_surface(*succ)) result *= fabs(dot(wo, bv_geo_normal(c, *succ)));
+    }
+    return result;
+}
+// PathVertex::cast to EEmitterSample, vertex.cpp:1115-1135 (PositionSamplingRecord(its): n = its.shFrame.n, records.inl:154-155)
+__device__ bool bv_cast_emitter(const Ctx &c, BV &v)
+{
+    if (v.type == T_EMITTER_SAMPLE) return true;
+    if (v.type != T_SURFACE) return false;
+    const int em = c.V.shade[v.prim].emitter;
+    if (em < 0) return false;
+    v.n = bv_sh_normal(c, v);
+    v.type = T_EMITTER_SAMPLE;
+    v.object = em;
+    v.measure = M_AREA;
+    v.degenerate = 0;
+    return true;
+}
+// PathVertex::update, vertex.cpp:1165-1211
+__device__ bool bv_update(const Ctx &c, BV &v, const BV *pred, const BV *succ, int mode, int measure)
+{
+    v.pdf[mode] = bv_eval_pdf(c, v, pred, succ, mode, measure);
+    v.pdf[1 - mode] = bv_eval_pdf(c, v, succ, pred, 1 - mode, measure);
+    v.w[mode] = bv_eval(c, v, pred, succ, mode, measure);
+    v.w[1 - mode] = bv_eval(c, v, succ, pred, 1 - mode, measure);
+    if (is_zero(v.w[mode]) || v.pdf[mode] <= 0x1p-1024) return false;
+    Float weightFwd = v.pdf[mode] <= 0x1p-1024 ? 0.0 : 1 / v.pdf[mode], weightBkw = v.pdf[1 - mode] <= 0x1p-1024 ? 0.0 : 1 / v.pdf[1 - mode];
+    v.measure = measure;
+    if (!bv_super(v) && measure == M_AREA) {
+        const d3 shN = bv_sh_normal(c, v);
+        if (!bv_super(*pred)) {
+            d3 d = pred->p - v.p;
+            const Float invDistSqr = 1.0 / len2(d);
+            weightBkw *= invDistSqr;
+            d = d * sqrt(invDistSqr);
+            if (bv_on_surface(v) && bv_connectable(v)) weightBkw *= fabs(dot(shN, d));
+            if (bv_on_surface(*pred)) weightBkw *= fabs(dot(bv_geo_normal(c, *pred), d));
+        }
+        if (!bv_super(*succ)) {
+            d3 d = succ->p - v.p;
+            const Float invDistSqr = 1.0 / len2(d);
+            weightFwd *= invDistSqr;
+            d = d * sqrt(invDistSqr);
+            if (bv_on_surface(v) && bv_connectable(v)) weightFwd *= fabs(dot(shN, d));
+            if (bv_on_surface(*succ)) weightFwd *= fabs(dot(bv_geo_normal(c, *succ), d));
+        }
+        if (v.type == T_SURFACE) v.componentType = ESmooth;
+    }
+    v.w[mode] = v.w[mode] * weightFwd;
+    v.w[1 - mode] = v.w[1 - mode] * weightBkw;
+    return true;
+}
+// PathVertex::connect with explicit measures, vertex.cpp:1348-1370 (no sensor shapes: a connection into the sensor supernode cannot occur here)
+__device__ bool bv_connect(Ctx &c, const BV *pred, BV &vs, BE &edge, BV &vt, const BV *succ, int vsMeasure, int vtMeasure)
+{
+    if (vs.type == T_EMITTER_SUPER) { if (!bv_cast_emitter(c, vt)) return false; }
+    else if (vt.type == T_SENSOR_SUPER) return false;
+    if (!bv_update(c, vs, pred, &vt, EImportance, vsMeasure)) return false;
+    if (!bv_update(c, vt, succ, &vs, ERadiance, vtMeasure)) return false;
+    return edge_connect(c, edge, vs, vt);
+}
+
+// ---- offset paths: ManifoldPerturbation::generateOffsetPathGBDPT, mut_manifold.cpp:806-936, for a chain a - b - c of adjacent vertices -------
+struct Offset {
+    BV a, b, c;                 // the perturbed sensor sample, the new first vertex, the clone of c re-connected to it
+    BE eab, ebc;                // proposal.edge(a - 1), proposal.edge(q)
+    int success, couldConnectAfterB;
+    Float jacobian;             // halfJacobian_GBDPT(offset) / halfJacobian_GBDPT(base), path.cpp:380-394 (G(a-1,a)/G(b,a) and det are 1 for this chain)
+};
+// source chain: srcC - srcB - srcA - S0 (towards the sensor), predC = the vertex before c (nullptr if c is the emitter supernode);
+// eSA = the edge between the sensor sample and the sensor supernode; distAB = source.edge(a - 1)->length
+__device__ bool generate_offset(Ctx &c, const BV &srcA, const BV &S0, const BE &eSA, const BV &srcB, const BV &srcC, const BV *predC, Float distAB,
+                                Float shX, Float shY, bool lightPath, Offset &o)
+{
+    o.success = 0; o.couldConnectAfterB = 0; o.jacobian = 1.0;
+    if (!bv_connectable(srcA)) return false;
+    o.a = srcA; o.c = srcC;                                                                // the deep copies of a and c, :863-864
+    // perturbDirection, mut_manifold.cpp:938-986
+    const CameraD &cam = c.S->cam;
+    const Float ppx = srcA.u + shX, ppy = srcA.v + shY;                                     // source.getSamplePosition() + offset
+    const d3 rd = cam_to_world(c, sample_to_camera_dir(c, ppx * cam.invW, ppy * cam.invH));  // sensor->sampleRay, perspective.cpp:249-269
+    const Float focusDistance = cam.farClip / fabs(dot(c.cam.dir, rd));                      // the default focus distance is the far clip, sensor.cpp:162
+    const d3 d = normalize((c.cam.pos + rd * focusDistance) - srcA.p);
+    if (!perturb_direction(c, o.a, S0, eSA, o.eab, o.b, d, distAB)) return false;
+    if (!bv_connectable(o.b)) return false;
+    o.couldConnectAfterB = bv_connect(c, predC, o.c, o.ebc, o.b, &o.a, bv_connectable(srcC) ? M_AREA : M_DISCRETE, bv_connectable(srcB) ? M_AREA : M_DISCRETE);
+    if (lightPath && !o.couldConnectAfterB) return false;
+    sensor_sample_position(c, o.b.p - o.a.p, o.a.u, o.a.v);                                 // updateSamplePosition, :912-913
+    o.a.rr = srcA.rr; o.b.rr = srcB.rr; o.c.rr = srcC.rr;                                   // :918-923
+    if (o.b.type == T_SURFACE && o.b.componentType == 0) o.b.componentType = srcB.componentType;
+    Float jy = 1.0; jy /= o.a.pdf[ERadiance];
+    Float jx = 1.0; jx /= srcA.pdf[ERadiance];
+    o.jacobian = jy / jx;
+    o.success = 1;
+    return true;
+}
+
+// ---- the sample --------------------------------------------------------------------------------------------------------------------------
+struct Sample {
+    BV X[NSV], Y[NEV];          // sensor / emitter subpath vertices
+    BE EX[NSV], EY[NEV];        // EX[i]: edge between X[i] and X[i+1]; EY likewise
+    int nX, nY;                 // vertex counts
+    BV XTc, Y1c;                // connectPath's clones: the last sensor vertex and the emitter vertex it is connected to (createShiftablePath, gbdpt_proc.cpp:600-662)
+    BE eConn;                   // the edge between them
+    int connS;                  // 1: connected to Y[1]; 0: the last sensor vertex lies on an emitter and is connected to the emitter supernode
+    Offset off[4];
+};
+
+// vertex i of "sensorSubpath[k]" (gbdpt_proc.cpp:224: the reversed proposal): base records except the three the shift replaced, and the
+// clone that createShiftablePath put at the connection end
+__device__ __forceinline__ const BV &SV(const Sample &sm, int k, int i)
+{
+    if (k == 0) return sm.X[i];
+    const Offset &o = sm.off[k - 1];
+    if (i == 1) return o.a;
+    if (i == 2) return o.b;
+    if (i == 3) return o.c;
+    if (i == sm.nX - 1) return sm.XTc;
+    return sm.X[i];
+}
+__device__ __forceinline__ const BE &SE(const Sample &sm, int k, int i)                     // edge between SV(k, i) and SV(k, i + 1)
+{
+    if (k == 0) return sm.EX[i];
+    const Offset &o = sm.off[k - 1];
+    if (i == 1) return o.eab;
+    if (i == 2) return o.ebc;
+    return sm.EX[i];
+}
+
+// the densities of Path::miWeight*NoSweep_GBDPT (path.cpp:99-132,264-307) for the path Y[0..s] + connection + SV(k, t..0), pdfImp / pdfRad[0..s+t+1]
+struct PathRef {
+    const Sample *sm; int k;             // sensor side: sensorSubpath[k]
+    const BV *ev; const BE *ee; int ne;  // emitter side: the base emitter subpath, or (light paths) a patched copy given by the overrides below
+    const BV *ovS, *ovSm1; const BE *ovEm1;   // overrides for emitter vertices s and s - 1 and edge s - 1 (offset light paths), or nullptr
+    const BV *ovT;                       // override for the sensor vertex t (the perturbed sensor sample of an offset light path), or nullptr
+};
+__device__ __forceinline__ const BV &PE(const PathRef &p, int i, int s) { if (p.ovS && i == s) return *p.ovS; if (p.ovSm1 && i == s - 1) return *p.ovSm1; return p.ev[i]; }
+__device__ __forceinline__ const BE &PEe(const PathRef &p, int i, int s) { if (p.ovEm1 && i == s - 1) return *p.ovEm1; return p.ee[i]; }
+__device__ __forceinline__ const BV &PS(const PathRef &p, int i, int t) { if (p.ovT && i == t) return *p.ovT; return SV(*p.sm, p.k, i); }
+
+__device__ void collect_pdfs(const Ctx &c, const PathRef &p, const BE &connectionEdge, int s, int t, Float *pdfImp, Float *pdfRad)
+{
+    const BV *vsPred = s > 0 ? &PE(p, s - 1, s) : nullptr, *vtPred = t > 0 ? &PS(p, t - 1, t) : nullptr;
+    const BV &vs = PE(p, s, s), &vt = PS(p, t, t);
+    int pos = 0;
+    pdfImp[pos++] = 1.0;
+    for (int i = 0; i < s; ++i) pdfImp[pos++] = PE(p, i, s).pdf[EImportance] * PEe(p, i, s).tr[EImportance];
+    pdfImp[pos++] = bv_eval_pdf(c, vs, vsPred, &vt, EImportance, M_AREA) * connectionEdge.tr[EImportance];
+    if (t > 0) {
+        pdfImp[pos++] = bv_eval_pdf(c, vt, &vs, vtPred, EImportance, M_AREA) * SE(*p.sm, p.k, t - 1).tr[EImportance];
+        for (int i = t - 1; i > 0; --i) pdfImp[pos++] = PS(p, i, t).pdf[EImportance] * SE(*p.sm, p.k, i - 1).tr[EImportance];
+    }
+    pos = 0;
+    if (s > 0) {
+        for (int i = 0; i < s - 1; ++i) pdfRad[pos++] = PE(p, i + 1, s).pdf[ERadiance] * PEe(p, i, s).tr[ERadiance];
+        pdfRad[pos++] = bv_eval_pdf(c, vs, &vt, vsPred, ERadiance, M_AREA) * PEe(p, s - 1, s).tr[ERadiance];
+    }
+    pdfRad[pos++] = bv_eval_pdf(c, vt, vtPred, &vs, ERadiance, M_AREA) * connectionEdge.tr[ERadiance];
+    for (int i = t; i > 0; --i) pdfRad[pos++] = PS(p, i - 1, t).pdf[ERadiance] * SE(*p.sm, p.k, i - 1).tr[ERadiance];
+    pdfRad[pos++] = 1.0;
+}
+// NOTE on path.cpp:143-167,309-349 (area densities next to a non-connectable vertex converted to projected solid angle): the loops run over
+// i in [1, k-3] / [3, k-1] and fire only where connectableStrict[i] && !connectableStrict[i +- 1]; with every surface vertex connectable
+// the only non-connectable vertex is the sensor supernode (index k), outside both ranges: nothing to convert.
+
+// Path::miWeightBaseNoSweep_GBDPT (path.cpp:49-201; exponent 2, geomTerm 1) and miWeightGradNoSweep_GBDPT (:204-378; exponent 1)
+__device__ Float mi_weight(const Ctx &c, const Sample &sm, const PathRef &base, const BE &baseEdge, const PathRef *offset, const BE *offsetEdge, int s, int t, Float jDet)
+{
+    Float pdfImp[NMIS + 1], pdfRad[NMIS + 1], oPdfImp[NMIS + 1], oPdfRad[NMIS + 1];
+    const int k = s + t + 1;
+    collect_pdfs(c, base, baseEdge, s, t, pdfImp, pdfRad);
+    if (offset) collect_pdfs(c, *offset, *offsetEdge, s, t, oPdfImp, oPdfRad);
+    const bool lightImage = c.cfg.lightImage != 0;
+    double sum = 0.0, p_st = 0.0;
+    for (int p = 0; p < s + t + 1; ++p) {
+        double value = 1.0, oValue = 1.0;
+        for (int i = 1; i < p + 1; ++i) { value *= pdfImp[i]; if (offset) oValue *= oPdfImp[i]; }
+        for (int i = p + 1; i < s + t + 1; ++i) { value *= pdfRad[i]; if (offset) oValue *= oPdfRad[i]; }
+        const int tPrime = k - p - 1;
+        // connectable[] of the BASE path (path.cpp:76-95,241-260): position p is emitter vertex p (p <= s) or sensor vertex k - p
+        const BV &vp = p <= s ? sm.Y[p] : sm.X[k - p], &vp1 = p + 1 <= s ? sm.Y[p + 1] : sm.X[k - p - 1];
+        const bool allowed = connectable_gbdpt(c, vp) && connectable_gbdpt(c, vp1);
+        if (allowed && (lightImage || tPrime > 1)) {
+            if (offset) sum += value * 1.0 + oValue * jDet * 1.0;                            // pow(x, 1.0) == x
+            else sum += (value * 1.0) * (value * 1.0);                                     // pow(x, 2.0) == x * x (correctly rounded either way)
+        }
+        if (tPrime == t) p_st = offset ? value * 1.0 : (value * 1.0) * (value * 1.0);
+    }
+    return (Float)(p_st / sum);
+}
+
+struct LightSplat { Float x, y; int buffer; d3 value; };
+struct SampleOut { d3 primal, gradient[4]; Float posX, posY; int nLight; LightSplat light[BD_MAX_LIGHT]; };
+
+// GBDPTRenderer::process (the sample loop body, gbdpt_proc.cpp:152-252) + evaluate (:259-534)
+__device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &out)
+{
+    const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                           // :101,265
+    const BdConfig &cfg = c.cfg;
+    const int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth + 1;                  // :110-122: degenerate (pinhole) sensor, hittable emitters
+    out.primal = mk(0.0); out.nLight = 0;
+    for (int k = 0; k < 4; k++) out.gradient[k] = mk(0.0);
+    // ---- Path::alternatingRandomWalkFromPixel, path.cpp:548-631 ----
+    bv_clear(sm.X[0]); sm.X[0].type = T_SENSOR_SUPER; sm.X[0].degenerate = 1;               // makeEndpoint, vertex.cpp:27-33
+    bv_clear(sm.Y[0]); sm.Y[0].type = T_EMITTER_SUPER; sm.Y[0].degenerate = 0;
+    sm.nX = 1; sm.nY = 1;
+    int t = sample_sensor(c, sm.X[0], px, py, sm.EX[0], sm.X[1], sm.EX[1], sm.X[2]);
+    sm.nX = 1 + t;
+    bool walkT = t == 2, walkS = true;
+    d3 thrS = mk(1.0), thrT = mk(1.0);
+    int s = 0;
+    do {
+        if (walkT && t < sensorDepth) {
+            if (sample_next(c, sm.X[t], &sm.X[t - 1], &sm.EX[t - 1], sm.EX[t], sm.X[t + 1], ERadiance, cfg.rrDepth != -1 && t >= cfg.rrDepth, thrT)) { t++; sm.nX++; }
+            else walkT = false;
+        } else walkT = false;
+        if (walkS && s < emitterDepth) {
+            if (sample_next(c, sm.Y[s], s > 0 ? &sm.Y[s - 1] : nullptr, s > 0 ? &sm.EY[s - 1] : nullptr, sm.EY[s], sm.Y[s + 1], EImportance, cfg.rrDepth != -1 && s >= cfg.rrDepth, thrS)) { s++; sm.nY++; }
+            else walkS = false;
+        } else walkS = false;
+    } while (walkS || walkT);
+    out.posX = sm.X[1].u; out.posY = sm.X[1].v;
+    if (sm.nY < 2) return;                                                                 // (no emitter could be sampled: a scene without power)
+
+    // ---- createShiftablePath(connectPath, emitterSubpath, sensorSubpath, 1, last), gbdpt_proc.cpp:600-662 ----
+    const int T = sm.nX - 1;
+    sm.connS = 1;
+    if (sm.X[T].type == T_SURFACE && c.V.shade[sm.X[T].prim].emitter >= 0) sm.connS = 0;
+    sm.Y1c = sm.Y[sm.connS];
+    sm.XTc = sm.X[T];
+    be_clear(sm.eConn);
+    bv_cast_emitter(c, sm.XTc);
+    bv_connect(c, sm.connS == 1 ? &sm.Y[0] : nullptr, sm.Y1c, sm.eConn, sm.XTc, T >= 1 ? &sm.X[T - 1] : nullptr, bv_connectable(sm.Y1c) ? M_AREA : M_DISCRETE, bv_connectable(sm.XTc) ? M_AREA : M_DISCRETE);
+    if (T == 1) sensor_sample_position(c, sm.Y1c.p - sm.XTc.p, sm.XTc.u, sm.XTc.v);          // (the clone's film position: never read again)
+    // connectPath = [Y0 (connS = 1), Y1c, XTc, X[T-1], ..., X[2], X[1], X[0]]: a = X[1], b = X[2] (or XTc if T == 2), c = X[3] (XTc if T == 3, Y1c if T == 2)
+    // muRec.extra[0] = a <= 2 (gbdpt_proc.cpp:200) <=> the connected path has at most four vertices: T + connS < 3
+    const bool shiftable = T + sm.connS >= 3 && T >= 2;
+    for (int k = 0; k < 4; k++) {
+        Offset &o = sm.off[k];
+        o.success = 0; o.couldConnectAfterB = 0; o.jacobian = 1.0;
+        if (!shiftable) continue;
+        const BV &srcB = T == 2 ? sm.XTc : sm.X[2];
+        const BV &srcC = T == 2 ? sm.Y1c : (T == 3 ? sm.XTc : sm.X[3]);
+        const BV *predC = T == 2 ? &sm.Y[0] : (T == 3 ? &sm.Y1c : (T == 4 ? &sm.XTc : &sm.X[4]));
+        generate_offset(c, sm.X[1], sm.X[0], sm.EX[0], srcB, srcC, predC, sm.EX[1].length, shifts[k][0], shifts[k][1], false, o);
+    }
+    const int vert_b = 2;                                                                  // connectPath.vertexCount() - 1 - extra[1]: b is sensor vertex 2
+
+    // ---- evaluate, gbdpt_proc.cpp:259-534 ----
+    const int nE = sm.nY, nS = sm.nX;
+    d3 impW[NEV]; Float impP[NEV];
+    d3 radW[5][NSV]; Float radP[5][NSV];
+    impW[0] = mk(1.0); impP[0] = 1.0;                                                      // combineImportanceData / combineRadianceData, :544-565
+    for (int i = 1; i < nE; ++i) {
+        impW[i] = impW[i - 1] * sm.Y[i - 1].w[EImportance] * sm.Y[i - 1].rr * sm.EY[i - 1].tr[EImportance];
+        impP[i] = impP[i - 1] * sm.Y[i - 1].pdf[EImportance] * sm.Y[i - 1].rr * sm.EY[i - 1].tr[EImportance];
+    }
+    for (int k = 0; k <= 4; k++) {
+        radW[k][0] = mk(1.0); radP[k][0] = 1.0;
+        for (int i = 1; i < nS; ++i) { radW[k][i] = mk(0.0); radP[k][i] = 0.0; }
+        if (k > 0 && !sm.off[k - 1].success) continue;
+        // sensorSubpath[k] has vertexCount = nS + connS + 1 >= nS entries for a successful shift
+        for (int i = 1; i < nS; ++i) {
+            const BV &pv = SV(sm, k, i - 1);
+            const BE &pe = SE(sm, k, i - 1);
+            radW[k][i] = radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
+            radP[k][i] = radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+        }
+    }
+    d3 primal = mk(0.0), gradient[4] = {mk(0.0), mk(0.0), mk(0.0), mk(0.0)};
+    d3 value[5]; Float miW[5], valuePdf[5];
+    for (s = nE - 1; s >= 0; --s) {
+        const int minT = max(2 - s, cfg.lightImage ? 1 : 2);
+        int maxT = nS - 1;
+        maxT = min(maxT, cfg.maxDepth + 1 - s);
+        for (t = maxT; t >= minT; --t) {
+            Float samplePosX = out.posX, samplePosY = out.posY;
+            if (t == 1) {
+                if (!sensor_sample_position(c, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) continue;
+            }
+            // light-tracing connections (t == 1): the base path Y[0..s-1], Ysc, S1c, X[0] and its four offsets (gbdpt_proc.cpp:356-376)
+            BV Ysc, S1c; BE eL;
+            bool pathSuccess0 = true;
+            if (t == 1) {                                                                  // createShiftablePath(connectedBasePath, emitter, sensor, s, 1)
+                Ysc = sm.Y[s]; S1c = sm.X[1]; be_clear(eL);
+                pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE);
+                sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
+            }
+            BE connEdge, connEdgeBase;
+            d3 connPartsBase = mk(0.0);
+            Float geomBase = 0.0;
+            bool successConnectBase = false;
+            Offset lo;                                                                     // the offset of a light path (transient)
+            BV vtBaseCast;                                                                 // s == 0: the base path's sensor vertex t as the emitter sample it was cast to
+            Float jacLP[4] = {1.0, 1.0, 1.0, 1.0};
+            for (int k = 0; k <= 4; k++) {
+                miW[k] = 1.0 / (s + t + 1);
+                bool ok = k == 0 ? true : (sm.off[k - 1].success != 0);
+                value[k] = mk(0.0); valuePdf[k] = 0.0;
+                d3 impWk = impW[s]; Float impPk = impP[s];
+                const d3 radWk = radW[t == 1 ? 0 : k][t]; const Float radPk = radP[t == 1 ? 0 : k][t];
+                bool lightOffset = false;
+                if (t == 1 && k == 0) ok = pathSuccess0;
+                if (t == 1 && k > 0 && !is_zero(value[0])) {
+                    if (!pathSuccess0) ok = false;
+                    else {                                                                 // createShiftedLightPath, :568-590
+                        ok = generate_offset(c, S1c, sm.X[0], sm.EX[0], Ysc, sm.Y[s - 1], s >= 2 ? &sm.Y[s - 2] : nullptr, eL.length,
+                                             shifts[k - 1][0], shifts[k - 1][1], true, lo);
+                        if (ok) {
+                            jacLP[k - 1] = lo.jacobian;
+                            impPk = 1.0; impWk = mk(1.0);
+                            for (int i = 1; i <= s; ++i) {                                 // the offset emitter subpath: Y[0..s-2], lo.c, lo.b
+                                const BV &pv = i - 1 == s - 1 ? lo.c : sm.Y[i - 1];
+                                const Float etr = i - 1 == s - 1 ? lo.ebc.tr[EImportance] : sm.EY[i - 1].tr[EImportance];
+                                impWk = impWk * pv.w[EImportance] * pv.rr * etr;
+                                impPk = impPk * pv.pdf[EImportance] * pv.rr * etr;
+                            }
+                            lightOffset = true;
+                        }
+                    }
+                }
+                Float geomTerm = 0.0;
+                do {
+                    if (!(ok && pathSuccess0 && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
+                    if (k > 0 && t != 1 && !sm.off[k - 1].couldConnectAfterB && t > vert_b) break;
+                    // the connection end points: emitter side vs (with its predecessor), sensor side vt (with its predecessor)
+                    const BV *vsPred, *vtPred; const BV *vsP;
+                    BV vtLocal;                                                            // s == 0: the sensor vertex is cast to an emitter sample (a copy: the cast of
+                    const BV *vtP;                                                         // the reference mutates the shared vertex, which no later evaluation reads)
+                    if (lightOffset) { vsP = &lo.b; vsPred = &lo.c; }
+                    else { vsP = &sm.Y[s]; vsPred = s > 0 ? &sm.Y[s - 1] : nullptr; }
+                    vtP = &SV(sm, t == 1 ? 0 : k, t); vtPred = &SV(sm, t == 1 ? 0 : k, t - 1);
+                    if (vsP->type == T_EMITTER_SUPER) {
+                        vtLocal = *vtP;
+                        if (!bv_cast_emitter(c, vtLocal) || vtLocal.degenerate) { valuePdf[k] = radPk; break; }
+                        vtP = &vtLocal;
+                        if (k == 0) vtBaseCast = vtLocal;
+                        const d3 connParts = (k > 0 && t > vert_b + 1) ? connPartsBase : bv_eval(c, *vsP, vsPred, vtP, EImportance) * bv_eval(c, *vtP, vtPred, vsP, ERadiance);
+                        if (k == 0) connPartsBase = connParts;
+                        value[k] = radWk * connParts;
+                        valuePdf[k] = radPk;
+                    } else {
+                        if (!connectable_gbdpt(c, *vsP) || !connectable_gbdpt(c, *vtP)) { valuePdf[k] = impPk * radPk; break; }
+                        const d3 connParts = (k > 0 && t > vert_b + 1) ? connPartsBase : bv_eval(c, *vsP, vsPred, vtP, EImportance) * bv_eval(c, *vtP, vtPred, vsP, ERadiance);
+                        if (k == 0) connPartsBase = connParts;
+                        value[k] = impWk * radWk * connParts;
+                        valuePdf[k] = impPk * radPk;
+                    }
+                    if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                    const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connEdge, *vsP, *vtP);
+                    if (k == 0) successConnectBase = successConnect;
+                    if (!successConnect) { value[k] = mk(0.0); break; }
+                    geomTerm = (k > 0 && t > vert_b) ? geomBase : edge_geometry_term(c, connEdge, *vsP, *vtP);
+                    value[k] = value[k] * geomTerm;
+                    valuePdf[k] *= 1.0;                                                    // genGeomTerm (calcSpecularPDFChange): 1 without specular chains
+                    if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                    PathRef base; base.sm = &sm; base.k = 0; base.ev = sm.Y; base.ee = sm.EY; base.ne = nE; base.ovS = base.ovSm1 = nullptr; base.ovEm1 = nullptr; base.ovT = nullptr;
+                    if (s == 0) base.ovT = &vtBaseCast;                                    // (the cast vertex: miWeight sees the emitter sample, gbdpt_proc.cpp:402)
+                    if (k == 0) {
+                        connEdgeBase = connEdge;
+                        geomBase = geomTerm;
+                        miW[0] = mi_weight(c, sm, base, connEdgeBase, nullptr, nullptr, s, t, 1.0) / valuePdf[0];
+                    } else {
+                        PathRef off = base;
+                        off.k = t == 1 ? 0 : k;
+                        if (lightOffset) { off.ovS = &lo.b; off.ovSm1 = &lo.c; off.ovEm1 = &lo.ebc; }
+                        if (s == 0) off.ovT = vtP;
+                        miW[k] = mi_weight(c, sm, base, connEdgeBase, &off, &connEdge, s, t, t < 2 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
+                    }
+                } while (false);
+#ifdef GDPT_BD_TRACE
+                printf("st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\n", s, t, k, (int)ok, value[k].x, value[k].y, value[k].z, valuePdf[k], miW[k], geomTerm, c.nClosest, c.nShadow);
+#endif
+                if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miW[k] = miW[0]; valuePdf[k] = valuePdf[0]; }
+            }
+            if (is_zero(value[0])) continue;
+            const d3 mainRad = value[0] * (valuePdf[0] * miW[0]);
+            if (t >= 2) primal = primal + mainRad;
+            else if (out.nLight < BD_MAX_LIGHT) { LightSplat &ls = out.light[out.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+            const d3 fx = value[0] * valuePdf[0];
+            for (int n = 0; n < 4; n++) {
+                const d3 fy = value[n + 1] * valuePdf[n + 1] * (t < 2 ? jacLP[n] : sm.off[n].jacobian);
+                const d3 gradVal = (fy - fx) * ((Float)2.0 * miW[n + 1]);
+                if (t >= 2) gradient[n] = gradient[n] + gradVal;
+                else if (out.nLight < BD_MAX_LIGHT) { LightSplat &ls = out.light[out.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
+            }
+        }
+    }
+    out.primal = primal;
+    for (int k = 0; k < 4; k++) out.gradient[k] = gradient[k];
+}
+
+} // namespace gdpt_bd

@@ -3,6 +3,7 @@
 // value is produced by the kernels of gpt_render.hip.h.
 #include "../../include/gdpt_tracer.h"
 #include "gpt_render.hip.h"
+#include "gpt_scene.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -300,17 +301,6 @@ int upload(T **dst, const std::vector<T> &v)
 
 } // namespace
 
-struct gdpt_scene {
-    SceneD d;
-    std::vector<void *> allocs;
-    int device = 0;
-    int bvhDepth = 0;
-    int numCUs = 256;
-    bool specialEmitters = false;   // an environment or point emitter: the ENV builds of the render kernel
-    bool perVertex = false;         // vertex normals or bitmap textures: the builds that keep a hit's barycentrics
-    size_t ldsSceneBytes = 0;
-};
-
 struct gdpt_film {
     gdpt_scene *scene = nullptr;
     FilmD d;
@@ -600,6 +590,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     s->perVertex = d.vn != nullptr || numTextures > 0;
     d.envIndex = envIndex;
     s->specialEmitters = env != nullptr || hasPoint;
+    s->hostMats = mats;
     if (env) {
         // ConstantBackgroundEmitter::createShape (constant.cpp:67-70): bounding sphere of Scene::getAABB() at that moment = the
         // kd-tree's AABB (enlarged by MTS_KD_AABB_EPSILON, gkdtree.h:1213-1219 -- the second line sees the moved min) + the

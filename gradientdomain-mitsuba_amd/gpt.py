@@ -227,8 +227,9 @@ class Film:
         return float(lib().gdpt_film_render_ms(self._h))
 
     def set_pipeline(self, stages, refill_lanes=0):
-        """Device staging of a render (2 = primary pass + general kernel + continuation kernel, the default; 1 = no primary pass;
-        0 = one kernel).  A tuning knob: results do not depend on it beyond rounding of the per-pixel sums."""
+        """Device staging of a render (0 = one kernel; any other value = the default pipeline: primary pass + general kernel +
+        continuation kernel -- the ABI treats 1 like 2, include/gdpt_tracer.h).  A tuning knob: results do not depend on it beyond
+        rounding of the per-pixel sums."""
         check(lib().gdpt_film_set_pipeline(self._h, int(stages), int(refill_lanes)))
 
     def set_occupancy(self, waves_per_simd):

@@ -200,6 +200,11 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
         back_m = b.material(conductor(**AL))
         tall_m = b.material(roughconductor(0.05, **AL, distribution=DISTR_GGX))
         short_m = white
+    elif variant == "rough":          # every BSDF smooth and rougher than shiftThreshold (G-BDPT's connectable-only scope): rough copper floor,
+        floor_m = b.material(roughconductor(0.1, **CU))                 # anisotropic rough aluminium back wall, GGX block, Phong-distribution short block
+        back_m = b.material(roughconductor(0.2, **AL, alphaV=0.05))
+        tall_m = b.material(roughconductor(0.05, **AL, distribution=DISTR_GGX))
+        short_m = b.material(twosided(roughconductor(0.3, **CU, distribution=DISTR_PHONG, sampleVisible=False)))
     elif variant == "nearspecular":   # roughness <= shiftThreshold (0.001): a glossy-sampled vertex that is classified GLOSSY
         floor_m = b.material(roughconductor(0.0008, **CU))
         back_m = b.material(roughconductor(0.2, **AL, alphaV=0.05))
@@ -294,6 +299,51 @@ def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):
     b.emitter(first, 2, (7.0, 6.5, 5.5))
     return b.finish(to_world=lookat((-17.0, 3.2, 0.6), (0.0, 4.5, 0.0), (0, 1, 0)), fov_x=70.0, near=0.1, far=200.0,
                     width=width, height=height, name="atrium")
+
+
+def veach_bidir(width=1280, height=720):
+    """Veach-bidir-class stand-in (BASELINE config 5; the original asset -- and its glass egg -- are not available offline): a closed room lit
+    almost entirely INDIRECTLY: an up-light inside a shade that only lets light reach the ceiling, and a wall sconce that faces the wall
+    behind it; a table with a smooth rough-aluminium sphere (interpolated normals), a diffuse sphere and a rough-copper block.  Every BSDF
+    is smooth with roughness far above shiftThreshold: the scope the G-BDPT sampler of this library carries (no specular chains)."""
+    b = _Builder()
+    wall = b.material(diffuse((0.72, 0.7, 0.66)))
+    floor_m = b.material(diffuse((0.45, 0.3, 0.18)))
+    wood = b.material(diffuse((0.5, 0.33, 0.2)))
+    shade = b.material(twosided(diffuse((0.8, 0.75, 0.6))))
+    alu = b.material(roughconductor(0.15, **AL, distribution=DISTR_GGX))
+    copper = b.material(roughconductor(0.1, **CU))
+    egg = b.material(diffuse((0.75, 0.75, 0.7)))
+    lightm = b.material(diffuse((0.5, 0.5, 0.5)))
+    room = (0.0, 1.5, 0.0)
+    X, Y, Z = 4.0, 3.0, 3.0
+    b.quad((-X, 0, -Z), (X, 0, -Z), (X, 0, Z), (-X, 0, Z), floor_m, room)
+    b.quad((-X, Y, -Z), (X, Y, -Z), (X, Y, Z), (-X, Y, Z), wall, room)
+    b.quad((-X, 0, Z), (X, 0, Z), (X, Y, Z), (-X, Y, Z), wall, room)
+    b.quad((-X, 0, -Z), (X, 0, -Z), (X, Y, -Z), (-X, Y, -Z), wall, room)
+    b.quad((-X, 0, -Z), (-X, 0, Z), (-X, Y, Z), (-X, Y, -Z), wall, room)
+    b.quad((X, 0, -Z), (X, 0, Z), (X, Y, Z), (X, Y, -Z), wall, room)
+    b.box([(-1.5, 1.0, -0.8), (-1.5, 1.0, 0.8), (1.5, 1.0, 0.8), (1.5, 1.0, -0.8)], 0.9, wood)              # table top
+    for (lx, lz) in ((-1.4, -0.7), (-1.4, 0.7), (1.4, -0.7), (1.4, 0.7)):                                     # legs
+        b.box([(lx - 0.05, 0.9, lz - 0.05), (lx - 0.05, 0.9, lz + 0.05), (lx + 0.05, 0.9, lz + 0.05), (lx + 0.05, 0.9, lz - 0.05)], 0.0, wood)
+    b.sphere((-0.6, 1.3, 0.1), 0.3, alu, level=2)
+    b.sphere((0.25, 1.2, -0.3), 0.2, egg, level=2)
+    b.box([(0.7, 1.35, 0.0), (0.7, 1.35, 0.4), (1.1, 1.35, 0.4), (1.1, 1.35, 0.0)], 1.0, copper)
+    # up-light: emitter facing up inside a four-sided shade (two-sided diffuse), open at the top only
+    cx, cy, cz, r, hgt = -2.6, 1.9, 0.8, 0.25, 0.5
+    for (a0, a1) in (((cx - r, cz - r), (cx + r, cz - r)), ((cx + r, cz - r), (cx + r, cz + r)), ((cx + r, cz + r), (cx - r, cz + r)), ((cx - r, cz + r), (cx - r, cz - r))):
+        b.quad((a0[0], cy - 0.05, a0[1]), (a1[0], cy - 0.05, a1[1]), (a1[0], cy + hgt, a1[1]), (a0[0], cy + hgt, a0[1]), shade, (cx, cy, cz))
+    b.quad((cx - r, cy - 0.05, cz - r), (cx + r, cy - 0.05, cz - r), (cx + r, cy - 0.05, cz + r), (cx - r, cy - 0.05, cz + r), shade, (cx, cy + 1, cz))
+    first = len(b.tris)
+    b.quad((cx - 0.15, cy, cz - 0.15), (cx + 0.15, cy, cz - 0.15), (cx + 0.15, cy, cz + 0.15), (cx - 0.15, cy, cz + 0.15), lightm, (cx, cy + 1, cz))
+    b.emitter(first, 2, (60.0, 52.0, 40.0))
+    # wall sconce: a small panel 10 cm in front of the right wall, emitting TOWARDS the wall; its back is a diffuse plate
+    first = len(b.tris)
+    b.quad((3.9, 1.6, -1.2), (3.9, 2.0, -1.2), (3.9, 2.0, -0.8), (3.9, 1.6, -0.8), lightm, (5.0, 1.8, -1.0))
+    b.emitter(first, 2, (40.0, 40.0, 46.0))
+    b.quad((3.88, 1.55, -1.25), (3.88, 2.05, -1.25), (3.88, 2.05, -0.75), (3.88, 1.55, -0.75), shade, (0.0, 1.8, -1.0))
+    return b.finish(to_world=lookat((0.4, 1.75, -2.75), (-0.1, 1.1, 0.1), (0, 1, 0)), fov_x=62.0, near=0.05, far=50.0,
+                    width=width, height=height, name="veach-bidir-class")
 
 
 def bitmap_texture(rgb, wrap=TEXWRAP_REPEAT, filter=TEXFILTER_BILINEAR, uscale=1.0, vscale=1.0, uoffset=0.0, voffset=0.0, wrapV=None, conserve=True, maxAnisotropy=20.0):

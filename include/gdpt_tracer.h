@@ -243,6 +243,45 @@ GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *ori
  * neighbourThroughputs[4](12), then closest-hit count, any-hit count, final depth. */
 GDPT_API int  gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int py, int sample, double out33[33]);
 
+/* ---- G-BDPT (BASELINE config 5): the per-block work of the reference's `gbdpt` integrator plugin ------------------------------------------
+ * What GBDPTRenderer::process -> evaluate compute for a rectangle of pixels (src/integrators/gbdpt/gbdpt_proc.cpp:86-256,259-534 over
+ * src/libbidir: Path::alternatingRandomWalkFromPixel, ManifoldPerturbation::generateOffsetPathGBDPT, Path::miWeight{Base,Grad}NoSweep_GBDPT),
+ * accumulated as GBDPTWorkResult / GBDPTProcess::processResult do (gbdpt_wr.h:56-62, gbdpt_proc.cpp:708-763): five camera blocks (rgb, weight)
+ * and five full-resolution light images, buffer order of the integrator's MultiFilm (gbdpt.cpp:163): 0 primal, 1 gradient towards (0,-1),
+ * 2 (-1,0), 3 (+1,0), 4 (0,+1).  Scope: scenes whose BSDFs are all connectable in the sense of Path::isConnectable_GBDPT (smooth, roughness >=
+ * shiftThreshold: diffuse and rough conductors, one- or two-sided, textured or not), area emitters, perspective sensor, box filter; others
+ * return GDPT_ERR_UNSUPPORTED (specular chains need the manifold walk, which is not carried).  Same counter-based random streams as the
+ * G-PT path, consumed in the reference's order. */
+typedef struct gdpt_gbdpt_config {
+    int    maxDepth;            /* -1 renders as 12 (gbdpt_proc.cpp:103-106); at most 12                                  */
+    int    rrDepth;             /* 5 (gbdpt.cpp:82)                                                                         */
+    int    lightImage;          /* 1 (gbdpt.cpp:83): connect emitter subpaths to the sensor (t = 1 strategies)             */
+    int    spp;
+    double shiftThreshold;      /* 0.001 (gbdpt.cpp:85)                                                                     */
+    unsigned long long seed;
+} gdpt_gbdpt_config;
+typedef struct gdpt_gbdpt_film gdpt_gbdpt_film;
+
+GDPT_API int   gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out);       /* GBDPTWorkResult for the whole crop window + GBDPTProcess::m_result */
+GDPT_API void  gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f);
+GDPT_API int   gdpt_gbdpt_film_clear(gdpt_gbdpt_film *f);
+/* GBDPTRenderer::process over the pixels [x0,x1) x [y0,y1), all cfg->spp samples each; asynchronous on the film's stream */
+GDPT_API int   gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, int y0, int x1, int y1, gdpt_gbdpt_film *f);
+GDPT_API int   gdpt_gbdpt_film_sync(gdpt_gbdpt_film *f);
+GDPT_API float gdpt_gbdpt_film_render_ms(gdpt_gbdpt_film *f);                      /* HIP-event time of the render kernels since the last clear */
+GDPT_API void *gdpt_gbdpt_film_stream(gdpt_gbdpt_film *f);
+/* raw sums: block[5][H][W][4] (r, g, b, weight), light[5][H][W][3]; HOST pointers */
+GDPT_API int   gdpt_gbdpt_film_accum(gdpt_gbdpt_film *f, double *block, double *light);
+/* GBDPTProcess::develop + MultiFilm::developMulti (gbdpt_proc.cpp:694-706, multifilm.cpp:317-362): (block + light * weight / spp) / weight
+ * as H x W x 3 doubles -- what GBDPTIntegrator::render reads back before prepareDataForSolver (gbdpt.cpp:199-207) */
+GDPT_API int   gdpt_gbdpt_film_develop_device(gdpt_gbdpt_film *f, int buffer, int spp, double *rgbDevice);
+GDPT_API int   gdpt_gbdpt_film_develop(gdpt_gbdpt_film *f, int buffer, int spp, double *rgbHost);
+GDPT_API int   gdpt_gbdpt_film_stats(gdpt_gbdpt_film *f, unsigned long long stats[4]);   /* closest-hit rays, shadow rays, samples, puts dropped as invalid */
+/* probe: ONE sample of GBDPTRenderer::process: out17 = primal(3), gradients(4 x 3), film position(2); its light-image splats as rows
+ * (x, y, buffer, r, g, b), at most maxLight of them (*nLight = how many there were); counters = closest-hit / shadow rays */
+GDPT_API int   gdpt_gbdpt_evaluate_sample(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17],
+                                          int maxLight, double *light6, int *nLight, unsigned long long counters[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1113,6 +1113,8 @@ struct Tracer {
                             }
                         }
                     } while (false);
+                    if (g_traceMain) std::fprintf(stderr, "st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %llu %llu\n", s, t, k, (int)pathSuccess[k], value[k].x, value[k].y, value[k].z, valuePdf[k], miWeight[k], geomTerm.x,
+                                                  (unsigned long long)c.sc.raysTraced, (unsigned long long)c.sc.shadowRaysTraced);
                     if (isZero(value[k]) || isZero(value[0])) {
                         value[k] = V3(0.0);
                         miWeight[k] = miWeight[0];

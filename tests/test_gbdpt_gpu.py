@@ -1,0 +1,179 @@
+"""GPU parity tests of the gfx950 G-BDPT sampler (csrc/gbdpt_kernels.hip.h), called through the C-ABI (include/gdpt_tracer.h, "G-BDPT").
+
+Checker: oracle/gbdpt_oracle.hpp (PARITY UNPINNED -- a line-cited fp64 restatement of GBDPTRenderer::process / evaluate over libbidir, see its
+header and DESIGN.md).  Both sides draw the same counter-based random numbers in the reference's order, so they build IDENTICAL subpaths,
+offset paths and connections; what differs is libm (ocml vs glibc), std::pow against x * x in the MIS weights, and the order of the fp64
+film sums (atomics).  Bar: single samples rtol 1e-9 (observed ~1e-14), films 1e-9 of the buffer scale per pixel, ray counts identical."""
+import numpy as np
+import pytest
+
+from gradientdomain_mitsuba_amd import scenes
+from oracle import gpt_oracle as go
+from oracle import poisson_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(gpu_required):
+    import gradientdomain_mitsuba_amd.gpt as G
+    return G
+
+
+@pytest.fixture(scope="module")
+def B(gpu_required):
+    import gradientdomain_mitsuba_amd.gbdpt as B
+    return B
+
+
+def builders():
+    return {"diffuse": lambda w, h: scenes.cornell_box(w, h, "diffuse"), "twosided": lambda w, h: scenes.cornell_box(w, h, "twosided"),
+            "rough": lambda w, h: scenes.cornell_box(w, h, "rough"), "smooth": lambda w, h: scenes.cornell_box(w, h, "smooth"),
+            "textured": lambda w, h: scenes.textured_cornell_box(w, h), "veach": lambda w, h: scenes.veach_bidir(w, h)}
+
+
+def compare_sample(g, o, what):
+    assert o["unsupported"] == 0, what
+    assert (g["raysTraced"], g["shadowRaysTraced"]) == (o["raysTraced"], o["shadowRaysTraced"]), what
+    assert np.allclose(g["position"], o["position"], rtol=1e-14, atol=0), what
+    scale = max(np.abs(o["primal"]).max(), np.abs(o["gradients"]).max(), 1e-300)
+    assert np.allclose(g["primal"], o["primal"], rtol=1e-9, atol=1e-12 * scale), (what, g["primal"], o["primal"])
+    assert np.allclose(g["gradients"], o["gradients"], rtol=1e-9, atol=1e-12 * scale), (what, g["gradients"], o["gradients"])
+    assert g["light"].shape == o["light"].shape, what
+    if len(o["light"]):
+        assert np.array_equal(g["light"][:, 2], o["light"][:, 2]), what
+        assert np.allclose(g["light"][:, :2], o["light"][:, :2], rtol=1e-12, atol=1e-9), what
+        ls = np.abs(o["light"][:, 3:]).max() + 1e-300
+        assert np.allclose(g["light"][:, 3:], o["light"][:, 3:], rtol=1e-9, atol=1e-12 * ls), what
+
+
+@pytest.mark.parametrize("name,md,li", [("diffuse", 5, True), ("diffuse", -1, True), ("diffuse", 3, False), ("twosided", 7, True), ("rough", 6, True),
+                                         ("rough", -1, False), ("smooth", 6, True), ("textured", 5, True), ("veach", -1, True), ("veach", 4, False)])
+def test_samples_match_oracle(G, B, name, md, li):
+    W, H = 40, 30
+    sc = builders()[name](W, H)
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=md, lightImage=li)
+    cfg, ocfg = integ.config(64), go.gbdpt_config(maxDepth=md, lightImage=li, spp=64)
+    rng = np.random.default_rng(17)
+    nonzero = lights = 0
+    for _ in range(60):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
+        g = integ.evaluate_sample(S, cfg, px, py, s)
+        o = O.gbdpt_sample(ocfg, px, py, s)
+        compare_sample(g, o, (name, md, li, px, py, s))
+        nonzero += bool(o["primal"].any()); lights += len(o["light"])
+    assert nonzero > 20 and (lights > 0) == li
+    S.close(); O.close()
+
+
+@pytest.mark.parametrize("name,W,H,spp,md,li", [("diffuse", 48, 36, 4, 6, True), ("rough", 40, 30, 3, -1, True), ("veach", 64, 36, 2, -1, True), ("twosided", 32, 24, 5, 5, False)])
+def test_film_matches_oracle(G, B, name, W, H, spp, md, li):
+    """The five camera blocks and five light images of a whole film (GBDPTWorkResult + processResult) against the oracle's, the developed
+    buffers (GBDPTProcess::develop) and the ray counters."""
+    sc = builders()[name](W, H)
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=md, lightImage=li)
+    F = B.Film(S)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    block, light = F.accum()
+    st = F.stats()
+    ob, ol, oc = O.gbdpt_render(go.gbdpt_config(maxDepth=md, lightImage=li, spp=spp))
+    assert oc["unsupported"] == 0 and st["invalidPuts"] == oc["invalidPuts"] == 0
+    assert (st["raysTraced"], st["shadowRaysTraced"], st["samples"]) == (oc["raysTraced"], oc["shadowRaysTraced"], W * H * spp)
+    for b in range(5):
+        assert np.abs(block[b] - ob[b]).max() <= 1e-9 * (np.abs(ob[b]).max() + 1e-300), (name, "block", b)
+        assert np.abs(light[b] - ol[b]).max() <= 1e-9 * (np.abs(ol[b]).max() + 1e-300), (name, "light", b)
+    dev = go.gbdpt_develop(ob, ol, spp)
+    for b in range(5):
+        d = F.develop(b, spp)
+        assert np.abs(d - dev[b]).max() <= 1e-9 * (np.abs(dev[b]).max() + 1e-300), (name, "develop", b)
+    # tiles rendered one after the other into the same film == the one-call film (sums to rounding: atomics)
+    F.clear()
+    for (x0, y0, x1, y1) in ((0, 0, W // 2, H), (W // 2, 0, W, H // 2), (W // 2, H // 2, W, H)):
+        integ.renderBlock(S, F, integ.config(spp), (x0, y0, x1, y1))
+    b2, l2 = F.accum()
+    assert np.allclose(b2, block, rtol=1e-12, atol=1e-12) and np.allclose(l2, light, rtol=1e-12, atol=1e-12) and F.stats() == st
+    F.close(); S.close(); O.close()
+
+
+def test_scope_and_property_errors(G, B):
+    from gradientdomain_mitsuba_amd._lib import GdptError
+    with pytest.raises(RuntimeError, match="two reconstructions"):
+        B.GBDPTIntegrator(reconstructL1=True, reconstructL2=True)
+    with pytest.raises(RuntimeError, match="reconstructAlpha"):
+        B.GBDPTIntegrator(reconstructAlpha=0.0)
+    with pytest.raises(RuntimeError, match="rrDepth"):
+        B.GBDPTIntegrator(rrDepth=0)
+    with pytest.raises(RuntimeError, match="maxDepth"):
+        B.GBDPTIntegrator(maxDepth=0)
+    assert B.GBDPTIntegrator().outNames() == ["-L1", "-gradientNegY", "-gradientNegX", "-gradientPosX", "-gradientPosY", "-L2", "-primal"]
+    assert B.GBDPTIntegrator(reconstructL1=False, reconstructL2=True).outNames()[0] == "-L2"
+    for variant, what in (("glossy", "Dirac"), ("nearspecular", "shiftThreshold")):       # a mirror; a roughness below the threshold
+        S = G.Scene(scenes.cornell_box(16, 12, variant))
+        F = B.Film(S)
+        integ = B.GBDPTIntegrator(maxDepth=4)
+        with pytest.raises(GdptError, match=what):
+            integ.renderBlock(S, F, integ.config(1), (0, 0, 16, 12))
+        F.close(); S.close()
+    S = G.Scene(scenes.cornell_box(16, 12, "diffuse", environment=(0.2, 0.2, 0.2)))
+    F = B.Film(S)
+    with pytest.raises(GdptError, match="environment"):
+        B.GBDPTIntegrator().renderBlock(S, F, B.GBDPTIntegrator().config(1), (0, 0, 16, 12))
+    with pytest.raises(GdptError):
+        B.GBDPTIntegrator(maxDepth=13).renderBlock(S, F, B.GBDPTIntegrator(maxDepth=13).config(1), (0, 0, 16, 12))
+    F.close(); S.close()
+
+
+def test_integrator_end_to_end_matches_oracle_pipeline(G, B):
+    """GBDPTIntegrator::render: sampler -> develop -> prepareDataForSolver -> L2D and L1D, against the same sequence on the oracle side."""
+    W, H, spp = 64, 48, 8
+    sc = scenes.cornell_box(W, H, "diffuse")
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=6)
+    out = integ.render(S, spp)
+    ob, ol, oc = O.gbdpt_render(go.gbdpt_config(maxDepth=6, spp=spp))
+    dev = go.gbdpt_develop(ob, ol, spp)
+    for i, name in enumerate(B.SAMPLER_BUFFERS):
+        assert np.abs(out[name] - dev[i]).max() <= 1e-9 * (np.abs(dev[i]).max() + 1e-300), name
+    o2, o1 = po.gbdpt_reconstruct(*[dev[i] for i in range(5)], W, H, alpha=0.2)
+    assert np.abs(out["-L2"].ravel() - o2).max() <= 5e-5 * max(1.0, np.abs(o2).max())
+    assert np.abs(out["-L1"].ravel() - o1).max() <= 5e-4 * max(1.0, np.abs(o1).max())
+    assert integ.stats["samples"] == W * H * spp and integ.stats["raysTraced"] == oc["raysTraced"]
+    S.close(); O.close()
+
+
+def test_gradient_domain_reconstruction_beats_the_primal_image(G, B):
+    """What G-BDPT is for (Manzi et al. 2015): at equal sample count the reconstructions are closer to the converged image than the primal."""
+    W, H, spp = 96, 54, 8
+    S = G.Scene(scenes.veach_bidir(W, H))
+    ref = B.GBDPTIntegrator(maxDepth=8).render(S, 64 * spp, seed=99, reconstruct=False)["-primal"]
+    out = B.GBDPTIntegrator(maxDepth=8).render(S, spp)
+    rel = lambda img: float(np.mean((img - ref) ** 2 / (ref ** 2 + 1e-3)))
+    e0, e1, e2 = rel(out["-primal"]), rel(out["-L1"]), rel(out["-L2"])
+    assert np.isfinite(out["-L1"]).all() and np.isfinite(out["-L2"]).all()
+    assert e1 < 0.7 * e0 and e2 < 0.8 * e0, (e0, e1, e2)
+    S.close()
+
+
+def test_config5_veach_1280x720_frame_matches_oracle(G, B):
+    """BASELINE config 5's resolution and scene class (Veach-bidir stand-in, G-BDPT, 1280x720) at 1 of its 128 spp: every pixel of the five
+    camera blocks and light images and both ray counters against the oracle; then samples of the 128 spp configuration spot-checked."""
+    W, H = 1280, 720
+    sc = scenes.veach_bidir(W, H)
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=-1)
+    F = B.Film(S)
+    integ.renderBlock(S, F, integ.config(1), (0, 0, W, H))
+    block, light = F.accum(); st = F.stats()
+    ob, ol, oc = O.gbdpt_render(go.gbdpt_config(maxDepth=-1, spp=1))
+    assert oc["unsupported"] == 0 and (st["raysTraced"], st["shadowRaysTraced"], st["samples"]) == (oc["raysTraced"], oc["shadowRaysTraced"], W * H)
+    for b in range(5):
+        assert np.abs(block[b] - ob[b]).max() <= 1e-9 * (np.abs(ob[b]).max() + 1e-300), ("block", b)
+        assert np.abs(light[b] - ol[b]).max() <= 1e-9 * (np.abs(ol[b]).max() + 1e-300), ("light", b)
+    cfg, ocfg = integ.config(128), go.gbdpt_config(maxDepth=-1, spp=128)
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 128))
+        compare_sample(integ.evaluate_sample(S, cfg, px, py, s), O.gbdpt_sample(ocfg, px, py, s), (px, py, s))
+    F.close(); S.close(); O.close()
