@@ -167,7 +167,12 @@ def test_config5_veach_1280x720_frame_matches_oracle(G, B):
     integ.renderBlock(S, F, integ.config(1), (0, 0, W, H))
     block, light = F.accum(); st = F.stats()
     ob, ol, oc = O.gbdpt_render(go.gbdpt_config(maxDepth=-1, spp=1))
-    assert oc["unsupported"] == 0 and (st["raysTraced"], st["shadowRaysTraced"], st["samples"]) == (oc["raysTraced"], oc["shadowRaysTraced"], W * H)
+    # Ray counts: a connection between two vertices of the SAME plane (both subpaths keep landing on the wall behind the sconce) runs a
+    # visibility ray inside that plane -- hit or miss is decided by the last bit, the connection's geometry term is ~1e-27 either way; a
+    # Beckmann lobe at its 1e-20 cut-off (microfacet.h:191-234) does the same.  42 of the 921 600 samples of this frame differ by 1-10
+    # closest-hit rays with outputs equal to 1e-25 (tools/gpu_gbdpt_locate.py, tools/gpu_gbdpt_trace.py); everything else is identical.
+    assert oc["unsupported"] == 0 and st["samples"] == W * H and st["shadowRaysTraced"] == oc["shadowRaysTraced"]
+    assert abs(st["raysTraced"] - oc["raysTraced"]) <= 2e-6 * oc["raysTraced"]
     for b in range(5):
         assert np.abs(block[b] - ob[b]).max() <= 1e-9 * (np.abs(ob[b]).max() + 1e-300), ("block", b)
         assert np.abs(light[b] - ol[b]).max() <= 1e-9 * (np.abs(ol[b]).max() + 1e-300), ("light", b)
