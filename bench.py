@@ -41,7 +41,8 @@ MAX_DEPTH = -1           # gpt.cpp:1194 default (unbounded; Russian roulette fro
 PRESET = "L2D"           # configs[1]: "L2 CG reconstruct"
 SCENE = "cornell"
 # BASELINE.json configs (1-based); the default run is configs[1] = --config 2.  The others are for the record, not bench lines.
-CONFIGS = {1: ("cornell", 512, 512, 64, "L2D"), 2: ("cornell", 1280, 720, 64, "L2D"), 3: ("atrium", 1920, 1080, 256, "L1D"), 4: ("atrium", 3840, 2160, 256, "L2D")}
+CONFIGS = {1: ("cornell", 512, 512, 64, "L2D"), 2: ("cornell", 1280, 720, 64, "L2D"), 3: ("atrium", 1920, 1080, 256, "L1D"), 4: ("atrium", 3840, 2160, 256, "L2D"),
+           5: ("veach", 1280, 720, 128, "L2D+L1D")}          # config 5: G-BDPT (bench_gbdpt below)
 BYTES_PER_PIX_ITER = {"L2D": 120.0, "L1D": 132.0}     # SURVEY.md 8(d), fp32, reference 3-op formulation
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0     # wave-instructions/s: 256 CUs x 4 SIMDs, one fp64 VALU wave-instruction per 4 cycles (MI355X_MICROARCH.md: 78.6 TFLOP/s fp64 vector)
@@ -192,6 +193,64 @@ def cpu_baseline(W, H, spp):
             "poisson_allcores_mpix_iter_s": round(W * H * 50 * reps / dpa / 1e6, 2), "poisson_allcores": _usable_cores()}
 
 
+def bench_gbdpt(a, rank, local, world, dev):
+    """BASELINE configs[4]: Veach-bidir-class scene, G-BDPT 128 spp, 1280x720 (for the record, like configs 1, 3, 4; the metric's own
+    configuration is --config 2).  A step = GBDPTIntegrator::render: the bidirectional sampler over every pixel (strips of rows per rank),
+    the reduction of the ranks' films onto rank 0, develop, prepareDataForSolver, the L2D and the L1D reconstruction."""
+    import torch
+    import torch.distributed as dist
+    from gradientdomain_mitsuba_amd import gbdpt, gpt, parallel, scenes
+    desc = scenes.veach_bidir(W, H)
+    scene = gpt.Scene(desc, device=local)
+    integ = gbdpt.GBDPTIntegrator(maxDepth=MAX_DEPTH)
+    sr = parallel.GBDPTStripRenderer(scene, integ, rank, world, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        sr.render(a.spp)
+    barrier()
+    t0 = time.perf_counter()
+    rays = samples = 0
+    render_ms = 0.0
+    solve = [0.0, 0.0]
+    phases = {}
+    for _ in range(a.steps):
+        sr.render(a.spp)
+        rays += sr.last["rays"]; samples += sr.last["samples"]; render_ms += sr.last["render_ms"]
+        solve[0] += sr.last["solve_s"][0]; solve[1] += sr.last["solve_s"][1]
+        for k, v in sr.last["phases_ms"].items():
+            phases[k] = phases.get(k, 0.0) + v
+    barrier()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall, render_ms, float(rays), float(samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = t.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        wall, render_ms, rays, samples = float(mx[0]), float(mx[1]), float(sm[2]), float(sm[3])
+    if rank == 0:
+        npx = W * H
+        out = {"metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp (G-BDPT)" % (W, H, a.spp),
+               "value": round(rays / wall / 1e6, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * wall / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "Veach-bidir-class room (build-authored, %d triangles, all BSDFs connectable), G-BDPT %d spp, %dx%d, fp64 sampler, L2D + L1D reconstruct (BASELINE configs[4])" % (desc.ntri, a.spp, W, H),
+                          "maxDepth": 12, "rrDepth": 5, "lightImage": True, "parallelism": "row strips of camera samples x%d + one film reduction onto rank 0" % world, "strip_rows": [s1 - s0 for (s0, s1) in sr.strips]},
+               "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / max(samples, 1.0), 2), "msample_s": round(samples / wall / 1e6, 3),
+               "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "phases_ms_per_step": {k: round(v / a.steps, 3) for k, v in phases.items()},
+               "reduce_bytes_per_rank": sr.last["reduce_bytes"],
+               "poisson": {"L2D": {"solve_ms_per_step": round(1e3 * solve[0] / a.steps, 4), "mpix_iter_s": round(npx * 50 * a.steps / solve[0] / 1e6, 1) if solve[0] > 0 else None},
+                           "L1D": {"solve_ms_per_step": round(1e3 * solve[1] / a.steps, 4), "mpix_iter_s": round(npx * 1000 * a.steps / solve[1] / 1e6, 1) if solve[1] > 0 else None}, "dtype": "f32"},
+               "roofline": None,
+               "roofline_note": "the G-BDPT sampler is one kernel at 1 wave/SIMD holding both subpaths, four offset paths and the MIS arrays in 17 KB of scratch per lane: latency-bound, no HBM or MFMA fraction applies (DESIGN.md, G-BDPT); the reconstructions are the persistent CG of --config 2"}
+        print(json.dumps(out))
+    sr.close(); scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +258,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-4); 2 is the metric's configuration")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-5); 2 is the metric's configuration, 5 = G-BDPT")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-height strips instead of rebalancing them after the warm-up pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the last step's reconstruction and the four gathered solver images to this .npz (tests)")
@@ -236,6 +295,8 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
+    if a.config == 5:
+        return bench_gbdpt(a, rank, local, world, dev)
     from gradientdomain_mitsuba_amd import gpt, parallel, scenes
     import gradientdomain_mitsuba_amd.poisson as P
 

@@ -65,6 +65,9 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
 
 // One lane = one (pixel, sample) of the launch: lanes of a wave take consecutive samples of one pixel first, then the next pixel of the tile row
 // (neighbouring paths start alike).  block: [5][H][W][4] (rgb, weight), light: [5][H][W][3].
+// Occupancy: process_sample and its callees are real functions (248-256 VGPRs + 82 AGPRs, 17 KB of scratch per lane for the two subpaths, the
+// four offsets and the MIS arrays): one wave per SIMD.  A kernel-level occupancy target does not reach callees, and inlining them into the
+// kernel crashes ROCm 7.2's backend (MachineCopyPropagation) -- DESIGN.md "G-BDPT": the next step is the wavefront form (connections as their own work items).
 __global__ __launch_bounds__(TBLK) void k_gbdpt_render(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, Float *__restrict__ block, Float *__restrict__ light,
                                                        unsigned long long *__restrict__ stats)
 {
@@ -313,6 +316,30 @@ int gdpt_gbdpt_film_stats(gdpt_gbdpt_film *f, unsigned long long stats[4])
     if (!f || !stats) return bfail(GDPT_ERR_INVALID, "gbdpt_film_stats: null argument");
     if (int rc = gdpt_gbdpt_film_sync(f)) return rc;
     BHIPCHK(hipMemcpy(stats, f->stats, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    return GDPT_OK;
+}
+
+// the raw sums as device-to-device copies, out of and into the film: what a multi-GPU host reduces between the films of its ranks (the light
+// image of a rank holds splats for EVERY pixel, gbdpt_wr.cpp:45-52 -- the reference merges whole work results by addition, :57-63)
+int gdpt_gbdpt_film_export_device(gdpt_gbdpt_film *f, double *blockDevice, double *lightDevice)
+{
+    if (!f || !blockDevice || !lightDevice) return bfail(GDPT_ERR_INVALID, "gbdpt_film_export_device: null argument");
+    BHIPCHK(hipSetDevice(f->scene->device));
+    const size_t npix = (size_t)f->W * f->H;
+    BHIPCHK(hipMemcpyAsync(blockDevice, f->block, sizeof(Float) * 5 * npix * 4, hipMemcpyDeviceToDevice, f->stream));
+    BHIPCHK(hipMemcpyAsync(lightDevice, f->light, sizeof(Float) * 5 * npix * 3, hipMemcpyDeviceToDevice, f->stream));
+    BHIPCHK(hipStreamSynchronize(f->stream));
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_film_import_device(gdpt_gbdpt_film *f, const double *blockDevice, const double *lightDevice)
+{
+    if (!f || !blockDevice || !lightDevice) return bfail(GDPT_ERR_INVALID, "gbdpt_film_import_device: null argument");
+    BHIPCHK(hipSetDevice(f->scene->device));
+    const size_t npix = (size_t)f->W * f->H;
+    BHIPCHK(hipMemcpyAsync(f->block, blockDevice, sizeof(Float) * 5 * npix * 4, hipMemcpyDeviceToDevice, f->stream));
+    BHIPCHK(hipMemcpyAsync(f->light, lightDevice, sizeof(Float) * 5 * npix * 3, hipMemcpyDeviceToDevice, f->stream));
+    BHIPCHK(hipStreamSynchronize(f->stream));
     return GDPT_OK;
 }
 

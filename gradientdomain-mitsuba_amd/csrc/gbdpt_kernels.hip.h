@@ -638,30 +638,51 @@ __device__ void collect_pdfs(const Ctx &c, const PathRef &p, const BE &connectio
 // i in [1, k-3] / [3, k-1] and fire only where connectableStrict[i] && !connectableStrict[i +- 1]; with every surface vertex connectable
 // the only non-connectable vertex is the sensor supernode (index k), outside both ranges: nothing to convert.
 
-// Path::miWeightBaseNoSweep_GBDPT (path.cpp:49-201; exponent 2, geomTerm 1) and miWeightGradNoSweep_GBDPT (:204-378; exponent 1)
-__device__ Float mi_weight(const Ctx &c, const Sample &sm, const PathRef &base, const BE &baseEdge, const PathRef *offset, const BE *offsetEdge, int s, int t, Float jDet)
+// Path::miWeightBaseNoSweep_GBDPT (path.cpp:49-201; exponent 2, geomTerm 1) and miWeightGradNoSweep_GBDPT (:204-378; exponent 1), restructured:
+// the reference rebuilds the base path's densities for each of the five paths of a connection and forms every strategy's density p_i by an
+// O(n) product (O(n^2) per weight).  Here the base path's p_i are computed ONCE per connection (k = 0) and kept for the four gradient
+// weights, and p_i = prefix(pdfImp)[i] * suffix(pdfRad)[i + 1] in O(n) -- same factors, another association of the products (a few ulp).
+struct MisBase { Float value[NMIS + 1]; unsigned allowed; int n; };
+__device__ __forceinline__ void strategy_densities(const Float *pdfImp, const Float *pdfRad, int n /* = s + t + 1 */, Float *value)
 {
-    Float pdfImp[NMIS + 1], pdfRad[NMIS + 1], oPdfImp[NMIS + 1], oPdfRad[NMIS + 1];
+    Float suffix[NMIS + 2];
+    suffix[n] = 1.0;
+    for (int i = n - 1; i >= 1; --i) suffix[i] = pdfRad[i] * suffix[i + 1];
+    Float prefix = 1.0;
+    for (int p = 0; p < n; ++p) {
+        if (p >= 1) prefix *= pdfImp[p];
+        value[p] = prefix * suffix[p + 1];
+    }
+}
+__device__ Float mi_weight_base(const Ctx &c, const Sample &sm, const PathRef &base, const BE &baseEdge, int s, int t, MisBase &mb)
+{
+    Float pdfImp[NMIS + 1], pdfRad[NMIS + 1];
     const int k = s + t + 1;
     collect_pdfs(c, base, baseEdge, s, t, pdfImp, pdfRad);
-    if (offset) collect_pdfs(c, *offset, *offsetEdge, s, t, oPdfImp, oPdfRad);
+    strategy_densities(pdfImp, pdfRad, k, mb.value);
+    mb.n = k; mb.allowed = 0;
     const bool lightImage = c.cfg.lightImage != 0;
     double sum = 0.0, p_st = 0.0;
-    for (int p = 0; p < s + t + 1; ++p) {
-        double value = 1.0, oValue = 1.0;
-        for (int i = 1; i < p + 1; ++i) { value *= pdfImp[i]; if (offset) oValue *= oPdfImp[i]; }
-        for (int i = p + 1; i < s + t + 1; ++i) { value *= pdfRad[i]; if (offset) oValue *= oPdfRad[i]; }
+    for (int p = 0; p < k; ++p) {
         const int tPrime = k - p - 1;
         // connectable[] of the BASE path (path.cpp:76-95,241-260): position p is emitter vertex p (p <= s) or sensor vertex k - p
         const BV &vp = p <= s ? sm.Y[p] : sm.X[k - p], &vp1 = p + 1 <= s ? sm.Y[p + 1] : sm.X[k - p - 1];
-        const bool allowed = connectable_gbdpt(c, vp) && connectable_gbdpt(c, vp1);
-        if (allowed && (lightImage || tPrime > 1)) {
-            if (offset) sum += value * 1.0 + oValue * jDet * 1.0;                            // pow(x, 1.0) == x
-            else sum += (value * 1.0) * (value * 1.0);                                     // pow(x, 2.0) == x * x (correctly rounded either way)
-        }
-        if (tPrime == t) p_st = offset ? value * 1.0 : (value * 1.0) * (value * 1.0);
+        const bool allowed = connectable_gbdpt(c, vp) && connectable_gbdpt(c, vp1) && (lightImage || tPrime > 1);
+        if (allowed) { mb.allowed |= 1u << p; sum += mb.value[p] * mb.value[p]; }           // pow(p_i * 1, 2.0)
+        if (tPrime == t) p_st = mb.value[p] * mb.value[p];
     }
     return (Float)(p_st / sum);
+}
+__device__ Float mi_weight_grad(const Ctx &c, const MisBase &mb, const PathRef &offset, const BE &offsetEdge, int s, int t, Float jDet)
+{
+    Float oPdfImp[NMIS + 1], oPdfRad[NMIS + 1], oValue[NMIS + 1];
+    const int k = s + t + 1;
+    collect_pdfs(c, offset, offsetEdge, s, t, oPdfImp, oPdfRad);
+    strategy_densities(oPdfImp, oPdfRad, k, oValue);
+    double sum = 0.0;
+    for (int p = 0; p < k; ++p)
+        if (mb.allowed & (1u << p)) sum += mb.value[p] * 1.0 + oValue[p] * jDet * 1.0;       // pow(x, 1.0) == x
+    return (Float)(mb.value[s] / sum);                                                      // tPrime == t <=> p == s
 }
 
 struct LightSplat { Float x, y; int buffer; d3 value; };
@@ -766,6 +787,7 @@ __device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &ou
             Float geomBase = 0.0;
             bool successConnectBase = false;
             Offset lo;                                                                     // the offset of a light path (transient)
+            MisBase misBase;                                                               // the base path's strategy densities of this connection (k = 0), reused by k = 1..4
             BV vtBaseCast;                                                                 // s == 0: the base path's sensor vertex t as the emitter sample it was cast to
             Float jacLP[4] = {1.0, 1.0, 1.0, 1.0};
             for (int k = 0; k <= 4; k++) {
@@ -834,13 +856,13 @@ __device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &ou
                     if (k == 0) {
                         connEdgeBase = connEdge;
                         geomBase = geomTerm;
-                        miW[0] = mi_weight(c, sm, base, connEdgeBase, nullptr, nullptr, s, t, 1.0) / valuePdf[0];
+                        miW[0] = mi_weight_base(c, sm, base, connEdgeBase, s, t, misBase) / valuePdf[0];
                     } else {
                         PathRef off = base;
                         off.k = t == 1 ? 0 : k;
                         if (lightOffset) { off.ovS = &lo.b; off.ovSm1 = &lo.c; off.ovEm1 = &lo.ebc; }
                         if (s == 0) off.ovT = vtP;
-                        miW[k] = mi_weight(c, sm, base, connEdgeBase, &off, &connEdge, s, t, t < 2 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
+                        miW[k] = mi_weight_grad(c, misBase, off, connEdge, s, t, t < 2 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
                     }
                 } while (false);
 #ifdef GDPT_BD_TRACE

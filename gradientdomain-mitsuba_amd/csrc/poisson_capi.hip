@@ -704,20 +704,12 @@ int gdpt_gbdpt_prepare_data(float w, float *out, const double *data, int len, co
     return rc;
 }
 
-int gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
-                           int width, int height, float alpha, int device, float *recL2, float *recL1)
+// the second half of GBDPTIntegrator::render on DEVICE buffers (five developed double images in, fp32 reconstructions out, host or device)
+static int gbdpt_reconstruct_core(double *const dev[5], int width, int height, float alpha, int device, float *recL2, float *recL1, bool outOnDevice, float *seconds2)
 {
-    if (!primal || !gradNegY || !gradNegX || !gradPosX || !gradPosY || width <= 0 || height <= 0)
-        return fail(GDPT_ERR_INVALID, "gbdpt_reconstruct: null buffer or empty image");
-    if (device >= 0) HIPCHK(hipSetDevice(device));
     const int len = 3 * width * height;
-    const double *host[5] = {primal, gradNegY, gradNegX, gradPosX, gradPosY};
-    double *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *in[3] = {nullptr, nullptr, nullptr};                  // imgf, dyf, dxf
     int rc = GDPT_OK;
-    for (int k = 0; k < 5 && !rc; k++)
-        if (hipMalloc(&dev[k], sizeof(double) * len) != hipSuccess || hipMemcpy(dev[k], host[k], sizeof(double) * len, hipMemcpyHostToDevice) != hipSuccess)
-            rc = fail(GDPT_ERR_HIP, "gbdpt_reconstruct: upload failed");
     for (int k = 0; k < 3 && !rc; k++) if (hipMalloc(&in[k], sizeof(float) * len) != hipSuccess) rc = fail(GDPT_ERR_HIP, "Out of memory!");
     if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[0], dev[0], len, nullptr, 0, nullptr);            // gbdpt.cpp:206
     if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[1], dev[4], len, dev[1], width, nullptr);          // :207  dy: grad[3] (+y) with grad[0] (-y)
@@ -726,6 +718,7 @@ int gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const d
     const char *presets[2] = {"L2D", "L1D"};                     // :213-218, both with m_reconstructAlpha
     float *outs[2] = {recL2, recL1};
     for (int k = 0; k < 2 && !rc; k++) {
+        if (seconds2) seconds2[k] = 0.0f;
         if (!outs[k]) continue;
         gdpt_poisson_params p;
         gdpt_poisson_params_defaults(&p);
@@ -737,12 +730,41 @@ int gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const d
         if (!rc) rc = gdpt_poisson_import_images_device(sv, in[2], in[1], in[0], nullptr, width, height);   // importImagesMTS(dx, dy, img, NULL), :229,243
         if (!rc) rc = gdpt_poisson_setup_backend(sv);
         if (!rc) rc = gdpt_poisson_solve_indirect(sv);
-        if (!rc) rc = gdpt_poisson_export_images(sv, outs[k]);
+        if (!rc) rc = outOnDevice ? gdpt_poisson_export_images_device(sv, outs[k]) : gdpt_poisson_export_images(sv, outs[k]);
+        if (!rc && outOnDevice) rc = gdpt_poisson_sync(sv);
+        if (!rc && seconds2) seconds2[k] = gdpt_poisson_last_solve_seconds(sv);
         gdpt_poisson_destroy(sv);
     }
-    for (double *d : dev) hipFree(d);
     for (float *f : in) hipFree(f);
     return rc;
+}
+
+int gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
+                           int width, int height, float alpha, int device, float *recL2, float *recL1)
+{
+    if (!primal || !gradNegY || !gradNegX || !gradPosX || !gradPosY || width <= 0 || height <= 0)
+        return fail(GDPT_ERR_INVALID, "gbdpt_reconstruct: null buffer or empty image");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    const int len = 3 * width * height;
+    const double *host[5] = {primal, gradNegY, gradNegX, gradPosX, gradPosY};
+    double *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = GDPT_OK;
+    for (int k = 0; k < 5 && !rc; k++)
+        if (hipMalloc(&dev[k], sizeof(double) * len) != hipSuccess || hipMemcpy(dev[k], host[k], sizeof(double) * len, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(GDPT_ERR_HIP, "gbdpt_reconstruct: upload failed");
+    if (!rc) rc = gbdpt_reconstruct_core(dev, width, height, alpha, device, recL2, recL1, false, nullptr);
+    for (double *d : dev) hipFree(d);
+    return rc;
+}
+
+int gdpt_gbdpt_reconstruct_device(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
+                                  int width, int height, float alpha, int device, float *recL2, float *recL1, float solveSeconds[2])
+{
+    if (!primal || !gradNegY || !gradNegX || !gradPosX || !gradPosY || width <= 0 || height <= 0)
+        return fail(GDPT_ERR_INVALID, "gbdpt_reconstruct_device: null buffer or empty image");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    double *dev[5] = {const_cast<double *>(primal), const_cast<double *>(gradNegY), const_cast<double *>(gradNegX), const_cast<double *>(gradPosX), const_cast<double *>(gradPosY)};
+    return gbdpt_reconstruct_core(dev, width, height, alpha, device, recL2, recL1, true, solveSeconds);
 }
 
 int gdpt_poisson_export_images(gdpt_poisson_solver *s, float *rec) { return export_common(s, rec, hipMemcpyDeviceToHost); }

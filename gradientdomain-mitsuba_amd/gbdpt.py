@@ -49,6 +49,21 @@ class Film:
         check(lib().gdpt_gbdpt_film_develop(self._h, int(buffer), int(spp), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def develop_device(self, buffer, spp, tensor):
+        """develop() into a contiguous float64 device tensor of H*W*3 values (asynchronous on the film's stream; sync() before reading)."""
+        import torch
+        if not (hasattr(tensor, "data_ptr") and tensor.is_cuda and tensor.is_contiguous() and tensor.dtype == torch.float64 and tensor.numel() >= 3 * self.width * self.height):
+            raise ValueError("develop_device: needs a contiguous float64 device tensor of at least H*W*3 elements")
+        check(lib().gdpt_gbdpt_film_develop_device(self._h, int(buffer), int(spp), C.c_void_p(tensor.data_ptr())))
+        return tensor
+
+    def export_device(self, block, light):
+        """The raw sums into two contiguous float64 device tensors ([5,H,W,4] and [5,H,W,3])."""
+        check(lib().gdpt_gbdpt_film_export_device(self._h, C.c_void_p(block.data_ptr()), C.c_void_p(light.data_ptr())))
+
+    def import_device(self, block, light):
+        check(lib().gdpt_gbdpt_film_import_device(self._h, C.c_void_p(block.data_ptr()), C.c_void_p(light.data_ptr())))
+
     def stats(self):
         s = (C.c_ulonglong * 4)()
         check(lib().gdpt_gbdpt_film_stats(self._h, s))
@@ -127,6 +142,33 @@ class GBDPTIntegrator:
             l2, l1 = _poisson.gbdpt_reconstruct(*[out[n] for n in SAMPLER_BUFFERS], scene.width, scene.height, alpha=self.reconstructAlpha)
             out["-L2"] = l2.reshape(scene.height, scene.width, 3)
             out["-L1"] = l1.reshape(scene.height, scene.width, 3)
+        if own:
+            film.close()
+        return out
+
+    def render_device(self, scene, spp, seed=5489, film=None, device=None):
+        """render() with everything resident in HBM: -> dict of device tensors ("-primal" ... float64 [H, W, 3]; "-L2", "-L1" float32) and
+        self.last = dict(render_ms, develop_ms, solve_s (L2D, L1D), rays)."""
+        import time
+        import torch
+        own = film is None
+        film = film or Film(scene)
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        cfg = self.config(spp, seed)
+        film.clear()
+        self.renderBlock(scene, film, cfg, (0, 0, scene.width, scene.height))
+        film.sync()
+        t0 = time.perf_counter()
+        bufs = [torch.empty((scene.height, scene.width, 3), dtype=torch.float64, device=dev) for _ in SAMPLER_BUFFERS]
+        for i, b in enumerate(bufs):
+            film.develop_device(i, spp, b)
+        film.sync()
+        t1 = time.perf_counter()
+        l2, l1, secs = _poisson.gbdpt_reconstruct_device(bufs, scene.width, scene.height, alpha=self.reconstructAlpha)
+        out = dict(zip(SAMPLER_BUFFERS, bufs))
+        out["-L2"], out["-L1"] = l2, l1
+        self.stats = film.stats()
+        self.last = dict(render_ms=film.render_ms(), develop_ms=1e3 * (t1 - t0), solve_s=secs, rays=self.stats["raysTraced"] + self.stats["shadowRaysTraced"])
         if own:
             film.close()
         return out

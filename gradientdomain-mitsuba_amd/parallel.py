@@ -242,3 +242,77 @@ class StripRenderer:
         if self.film is not None:
             self.film.close()
             self.film = None
+
+
+class GBDPTStripRenderer:
+    """GBDPTIntegrator::render (/root/reference/src/integrators/gbdpt/gbdpt.cpp:140-262) over the ranks of a process group.
+
+    The reference hands 32x32 blocks to workers; every worker's result carries camera blocks for its pixels AND five full-resolution light
+    images (light-tracing connections land on any pixel, gbdpt_wr.cpp:45-52), and results are merged by addition (GBDPTWorkResult::put,
+    :57-63).  Here: rank r renders the samples of a contiguous strip of rows into a film of its own (whole-image buffers), the films are SUMMED
+    onto rank 0 -- one reduction over RCCL (`dist.reduce`, 257 MB of fp64 sums at 1280x720: the path's one real exchange step; a one-pixel halo
+    would not do, a light sample of any rank can hit any pixel) -- and rank 0 develops and runs both reconstructions.
+
+    scene, integ: gpt.Scene / gbdpt.GBDPTIntegrator (or test doubles); film_factory(scene) defaults to gbdpt.Film."""
+
+    def __init__(self, scene, integ, rank, world, device, group=None, strips=None, film_factory=None, reconstruct=None):
+        self.scene, self.integ, self.rank, self.world, self.device, self.group = scene, integ, rank, world, device, group
+        self.width, self.height = scene.width, scene.height
+        if film_factory is None:
+            from . import gbdpt
+            film_factory = gbdpt.Film
+        if reconstruct is None:
+            from . import poisson
+
+            def reconstruct(bufs, w, h, alpha):
+                return poisson.gbdpt_reconstruct_device(bufs, w, h, alpha=alpha)
+        self._reconstruct = reconstruct
+        self.film = film_factory(scene)
+        self.strips = list(strips or row_strips(self.height, world))
+        self.y0, self.y1 = self.strips[rank]
+        self.block = torch.empty((5, self.height, self.width, 4), dtype=torch.float64, device=device)
+        self.light = torch.empty((5, self.height, self.width, 3), dtype=torch.float64, device=device)
+        self.last = {}
+
+    def render(self, spp, seed=5489):
+        """One frame.  Rank 0 returns dict("-primal" ... "-gradientPosY": float64 [H, W, 3], "-L2", "-L1": float32), other ranks None."""
+        film, integ = self.film, self.integ
+        cfg = integ.config(spp, seed)
+        t0 = time.perf_counter()
+        film.clear()
+        integ.renderBlock(self.scene, film, cfg, (0, self.y0, self.width, self.y1))
+        film.sync()
+        t1 = time.perf_counter()
+        reduce_bytes = 0
+        if self.world > 1:
+            film.export_device(self.block, self.light)
+            wb, wl = _wire(self.block), _wire(self.light)
+            dist.reduce(wb, 0, op=dist.ReduceOp.SUM, group=self.group)
+            dist.reduce(wl, 0, op=dist.ReduceOp.SUM, group=self.group)
+            reduce_bytes = (wb.numel() + wl.numel()) * 8
+            if self.rank == 0:
+                self.block.copy_(wb); self.light.copy_(wl)
+                _settle(self.block)
+                film.import_device(self.block, self.light)
+        t2 = time.perf_counter()
+        out = None
+        solve_s = (0.0, 0.0)
+        if self.rank == 0:
+            from .gbdpt import SAMPLER_BUFFERS
+            bufs = [torch.empty((self.height, self.width, 3), dtype=torch.float64, device=self.device) for _ in SAMPLER_BUFFERS]
+            for i, b in enumerate(bufs):
+                film.develop_device(i, spp, b)
+            film.sync()
+            l2, l1, solve_s = self._reconstruct(bufs, self.width, self.height, integ.reconstructAlpha)
+            out = dict(zip(SAMPLER_BUFFERS, bufs))
+            out["-L2"], out["-L1"] = l2, l1
+        t3 = time.perf_counter()
+        st = film.stats()
+        self.last = dict(phases_ms=dict(render=1e3 * (t1 - t0), reduce=1e3 * (t2 - t1), develop_reconstruct=1e3 * (t3 - t2)),
+                         rays=st["raysTraced"] + st["shadowRaysTraced"], samples=st["samples"], render_ms=film.render_ms(), solve_s=solve_s, reduce_bytes=reduce_bytes)
+        return out
+
+    def close(self):
+        if self.film is not None:
+            self.film.close()
+            self.film = None

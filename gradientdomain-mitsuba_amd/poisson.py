@@ -205,6 +205,23 @@ def gbdpt_reconstruct(primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y, wi
     return r2, r1
 
 
+def gbdpt_reconstruct_device(bufs, width, height, alpha=0.2, device=-1, l2=True, l1=True):
+    """gbdpt_reconstruct with every buffer on the device: `bufs` = five contiguous float64 device tensors of 3*width*height values (the
+    developed sampler buffers, MultiFilm order).  -> (L2 tensor or None, L1 tensor or None, (seconds of the L2D solve, of the L1D solve))."""
+    import torch
+    n3 = 3 * width * height
+    for b in bufs:
+        if not (b.is_cuda and b.is_contiguous() and b.dtype == torch.float64 and b.numel() == n3):
+            raise ValueError("gbdpt_reconstruct_device: five contiguous float64 device tensors of 3*width*height values")
+    r2 = torch.empty((height, width, 3), dtype=torch.float32, device=bufs[0].device) if l2 else None
+    r1 = torch.empty((height, width, 3), dtype=torch.float32, device=bufs[0].device) if l1 else None
+    torch.cuda.current_stream(bufs[0].device).synchronize()           # the library runs on its own streams
+    secs = (C.c_float * 2)()
+    check(lib().gdpt_gbdpt_reconstruct_device(*[C.c_void_p(b.data_ptr()) for b in bufs], width, height, C.c_float(alpha), device,
+                                              C.c_void_p(r2.data_ptr()) if l2 else None, C.c_void_p(r1.data_ptr()) if l1 else None, secs))
+    return r2, r1, (float(secs[0]), float(secs[1]))
+
+
 class Backend:
     """poisson::Backend virtuals (Backend.hpp:66-100) on device vectors (reference layouts).  Vectors are
     plain device addresses (ints); `upload`/`download` play Backend::write/read."""

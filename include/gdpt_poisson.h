@@ -127,6 +127,11 @@ GDPT_API int  gdpt_gbdpt_prepare_data_device(float w, float *out, const double *
 GDPT_API int  gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
                                      int width, int height, float alpha, int device, float *recL2, float *recL1);
 
+/* the same with every buffer on `device` (five developed double images in, fp32 reconstructions out; either output may be NULL);
+ * solveSeconds (may be NULL): the HIP-event spans of the L2D and the L1D solveIndirect.  The call returns with the results complete. */
+GDPT_API int  gdpt_gbdpt_reconstruct_device(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
+                                            int width, int height, float alpha, int device, float *recL2, float *recL1, float solveSeconds[2]);
+
 /* ---- (2) backend-op level ----------------------------------------------------------------- */
 /* Device-pointer forms of the `poisson::Backend` virtuals.  `stream` is a hipStream_t (NULL =
  * default stream).  Vectors use the reference layout; sizes in ELEMENTS as in Backend::Vector. */

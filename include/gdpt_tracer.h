@@ -276,6 +276,10 @@ GDPT_API int   gdpt_gbdpt_film_accum(gdpt_gbdpt_film *f, double *block, double *
  * as H x W x 3 doubles -- what GBDPTIntegrator::render reads back before prepareDataForSolver (gbdpt.cpp:199-207) */
 GDPT_API int   gdpt_gbdpt_film_develop_device(gdpt_gbdpt_film *f, int buffer, int spp, double *rgbDevice);
 GDPT_API int   gdpt_gbdpt_film_develop(gdpt_gbdpt_film *f, int buffer, int spp, double *rgbHost);
+/* the raw sums copied device-to-device out of / into the film (layouts of gdpt_gbdpt_film_accum; the call returns with the copy complete): a
+ * multi-GPU host adds the films of its ranks -- every rank's light images hold splats for the WHOLE image (GBDPTWorkResult::put, gbdpt_wr.cpp:57-63) */
+GDPT_API int   gdpt_gbdpt_film_export_device(gdpt_gbdpt_film *f, double *blockDevice, double *lightDevice);
+GDPT_API int   gdpt_gbdpt_film_import_device(gdpt_gbdpt_film *f, const double *blockDevice, const double *lightDevice);
 GDPT_API int   gdpt_gbdpt_film_stats(gdpt_gbdpt_film *f, unsigned long long stats[4]);   /* closest-hit rays, shadow rays, samples, puts dropped as invalid */
 /* probe: ONE sample of GBDPTRenderer::process: out17 = primal(3), gradients(4 x 3), film position(2); its light-image splats as rows
  * (x, y, buffer, r, g, b), at most maxLight of them (*nLight = how many there were); counters = closest-hit / shadow rays */

@@ -277,3 +277,102 @@ def test_strip_renderer_equals_one_rank(world, own_border, rebalance):
             assert halo == 8 * (NREC * W + 20 * W) * ((r > 0) + (r < world - 1))
     if rebalance:
         assert res[0][4] != parallel.row_strips(H, world) and res[0][4][0][1] > parallel.row_strips(H, world)[0][1]
+
+
+# ---- parallel.GBDPTStripRenderer over gloo with doubles of the G-BDPT film / integrator / reconstruction ------------------------------
+class _ToyBdFilm:
+    """Double of gbdpt.Film: camera blocks get a sample's value at its own pixel, light images get splats that land on pixels of OTHER
+    strips too (a light-tracing connection reaches any pixel) -- so only the sum over all ranks' films is the frame."""
+
+    def __init__(self, scene):
+        self.W, self.H = scene.width, scene.height
+        self.clear()
+
+    def clear(self):
+        self.block = np.zeros((5, self.H, self.W, 4)); self.light = np.zeros((5, self.H, self.W, 3)); self.n = 0
+
+    def render(self, spp, rect):
+        x0, y0, x1, y1 = rect
+        for y in range(y0, y1):
+            for x in range(x0, x1):
+                for b in range(5):
+                    self.block[b, y, x] += spp * np.array([x + 1, y + 2, b + 3, 1.0])
+                    ty, tx = (7 * y + 3 * x + b) % self.H, (5 * x + y) % self.W            # anywhere on the film
+                    self.light[b, ty, tx] += spp * np.array([1.0, x, y])
+                self.n += spp
+
+    def sync(self):
+        pass
+
+    def export_device(self, block, light):
+        block.copy_(torch.from_numpy(self.block)); light.copy_(torch.from_numpy(self.light))
+
+    def import_device(self, block, light):
+        self.block, self.light = block.numpy().copy(), light.numpy().copy()
+
+    def develop_device(self, b, spp, t):
+        w = self.block[b, ..., 3].copy(); w[w == 0] = 1.0
+        t.copy_(torch.from_numpy((self.block[b, ..., :3] + self.light[b] * (w / spp)[..., None]) / w[..., None]))
+
+    def stats(self):
+        return dict(raysTraced=3 * self.n, shadowRaysTraced=self.n, samples=self.n, invalidPuts=0)
+
+    def render_ms(self):
+        return 1.0
+
+    def close(self):
+        pass
+
+
+class _ToyBdIntegrator:
+    reconstructAlpha = 0.2
+
+    def config(self, spp, seed=5489):
+        return spp
+
+    def renderBlock(self, scene, film, cfg, rect):
+        film.render(cfg, rect)
+
+
+def _toy_bd_render(rank, world, W, H):
+    sr = parallel.GBDPTStripRenderer(_ToyScene(W, H), _ToyBdIntegrator(), rank, world, torch.device("cpu"), film_factory=_ToyBdFilm,
+                                     reconstruct=lambda bufs, w, h, alpha: ((bufs[0] + 2 * bufs[3] - bufs[2]).float(), (bufs[0] - bufs[4] + bufs[1]).float(), (1e-4, 2e-4)))
+    out = sr.render(3)
+    res = (None if out is None else {k: v.numpy().copy() for k, v in out.items()}, sr.last["rays"], sr.last["samples"], sr.last["reduce_bytes"], list(sr.strips))
+    sr.close()
+    return res
+
+
+def _bd_worker(rank, world, port, W, H, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _toy_bd_render(rank, world, W, H))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gbdpt_strip_renderer_equals_one_rank(world):
+    """G-BDPT over ranks: strips of camera samples + ONE reduction of the whole films onto rank 0 (light images reach every pixel) give the
+    one-rank frame exactly (integer-valued sums), developed buffers and both reconstructions."""
+    W, H = 9, 14
+    whole = _toy_bd_render(0, 1, W, H)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bd_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r][0] is None for r in range(1, world))
+    for k, v in whole[0].items():
+        assert np.array_equal(res[0][0][k], v), k
+    assert sum(res[r][2] for r in range(world)) == whole[2] == 3 * W * H and sum(res[r][1] for r in range(world)) == whole[1]
+    assert all(res[r][3] == 8 * 5 * W * H * 7 for r in range(world)) and whole[3] == 0
+    assert res[0][4] == parallel.row_strips(H, world)
