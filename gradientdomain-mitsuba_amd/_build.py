@@ -16,6 +16,9 @@ UNITS = {
     "gbdpt_capi.hip": ["gpt_kernels.hip.h", "gbdpt_kernels.hip.h", "gpt_scene.hip.h"],
     "device_capi.hip": [],
 }
+# per-unit flags: the G-BDPT connection kernel meets its 2-waves-per-SIMD target only when no callee parks spills in AGPRs (one AGPR in a callee
+# makes the kernel's unified register count 257)
+UNIT_FLAGS = {"gbdpt_capi.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 SOURCES = [os.path.join(CSRC, f) for f in UNITS]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", os.environ.get("GDPT_OPT", "-O3"), "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -27,7 +30,8 @@ STAMP = LIB + ".flags"          # the flags the library was built with: a develo
 
 def _flags_line():
     # (the checkout's own path is taken out: the same library is up to date wherever the tree is copied to)
-    return " ".join(FLAGS + os.environ.get("GDPT_EXTRA_FLAGS", "").split()).replace(ROOT, "$ROOT")
+    per_unit = sum(([u + ":"] + f for u, f in sorted(UNIT_FLAGS.items())), [])
+    return " ".join(FLAGS + os.environ.get("GDPT_EXTRA_FLAGS", "").split() + per_unit).replace(ROOT, "$ROOT")
 
 
 def _deps(unit):
@@ -68,7 +72,7 @@ def build(force=False, verbose=False):
     procs = []
     for unit in UNITS:                                   # the units compile side by side
         if force or _unit_stale(unit):
-            cmd = [hipcc] + FLAGS + extra + ["-c", "-o", _obj(unit), os.path.join(CSRC, unit)]
+            cmd = [hipcc] + FLAGS + UNIT_FLAGS.get(unit, []) + extra + ["-c", "-o", _obj(unit), os.path.join(CSRC, unit)]
             if verbose:
                 print(" ".join(cmd))
             procs.append((unit, subprocess.Popen(cmd)))

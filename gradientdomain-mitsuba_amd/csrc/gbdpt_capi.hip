@@ -63,37 +63,103 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
     }
 }
 
-// One lane = one (pixel, sample) of the launch: lanes of a wave take consecutive samples of one pixel first, then the next pixel of the tile row
-// (neighbouring paths start alike).  block: [5][H][W][4] (rgb, weight), light: [5][H][W][3].
-// Occupancy: process_sample and its callees are real functions (248-256 VGPRs + 82 AGPRs, 17 KB of scratch per lane for the two subpaths, the
-// four offsets and the MIS arrays): one wave per SIMD.  A kernel-level occupancy target does not reach callees, and inlining them into the
-// kernel crashes ROCm 7.2's backend (MachineCopyPropagation) -- DESIGN.md "G-BDPT": the next step is the wavefront form (connections as their own work items).
-__global__ __launch_bounds__(TBLK) void k_gbdpt_render(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, Float *__restrict__ block, Float *__restrict__ light,
-                                                       unsigned long long *__restrict__ stats)
+// ---- the frame in wavefront form ------------------------------------------------------------------------------------------------------
+// The reference evaluates a sample's connections in a serial double loop (gbdpt_proc.cpp:311-528).  One lane doing that holds both subpaths,
+// the four offset paths, the prefix products and the MIS arrays (17 KB) for the whole loop: 1 wave per SIMD, every access a scratch round
+// trip (2.0 Msample/s).  Here a chunk of samples goes through three launches joined by HBM records:
+//   k_bd_walk     one lane per sample: subpaths, connected base path, offset paths, prefix products -> a `Sample` record (11 KB) in HBM, the
+//                 sample's connections (s, t) appended to an item list, its film position;
+//   k_bd_connect  one lane per CONNECTION (on average ~25 per sample): reads the few vertices it needs from its sample's record (lanes of a
+//                 wave mostly share one record: the loads coalesce), evaluates the base path and the four offsets, adds primal / gradient
+//                 terms to the sample's 15 sums (fp64 atomics) or splats light-tracing terms into the light images;
+//   k_bd_put      one lane per sample: the five camera-block puts of its sums (GBDPTWorkResult::putSample, gbdpt_proc.cpp:531-533).
+// Same arithmetic per connection as the one-lane form (process_sample, kept as the probe); the sums of a sample are added in arrival order
+// instead of (s, t) order: rounding of the last bits only.
+constexpr int BD_ITEMS_PER_SAMPLE = 96;            // >= 90 = sum over s of the t-range at maxDepth 12 (pair_range)
+constexpr unsigned BD_CHUNK = 1u << 21;            // samples per chunk: 23 GB of records, 2.4 GB of item lists
+
+__global__ __launch_bounds__(TBLK) void k_bd_walk(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, long long first, unsigned count, Sample *__restrict__ recs,
+                                                  unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
-    const int w = x1 - x0, h = y1 - y0;
-    const long long total = (long long)w * h * cfg.sCount;
-    const long long gid = (long long)blockIdx.x * TBLK + threadIdx.x;
+    const unsigned lid = blockIdx.x * TBLK + threadIdx.x;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
-    if (gid < total) {
-        const int sIdx = (int)(gid % cfg.sCount);
-        const long long pix = gid / cfg.sCount;
+    if (lid < count) {
+        const int w = x1 - x0;
+        const long long gid = first + lid;
+        const int sIdx = (int)(gid % cfg.spp);                                             // consecutive lanes: consecutive samples of one pixel, then the next pixel
+        const long long pix = gid / cfg.spp;
         const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
-        const int W = S.cam.width, H = S.cam.height;
-        c.rng.init(cfg.seed, (uint64_t)py * W + px, (uint64_t)(cfg.sBase + sIdx));
-        Sample sm;
-        SampleOut out;
-        process_sample(c, sm, px, py, out);
-        const size_t plane4 = (size_t)W * H * 4, plane3 = (size_t)W * H * 3;
-        film_put(block, 4, W, H, out.posX, out.posY, out.primal, true, stats + 3);                                  // putSample, gbdpt_proc.cpp:531-533
-        for (int k = 0; k < 4; k++) film_put(block + (k + 1) * plane4, 4, W, H, out.posX, out.posY, out.gradient[k], true, stats + 3);
-        for (int i = 0; i < out.nLight; i++) film_put(light + out.light[i].buffer * plane3, 3, W, H, out.light[i].x, out.light[i].y, out.light[i].value, false, stats + 3);   // putLightSample, :514,525
+        c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sIdx);
+        Sample &sm = recs[lid];
+        walk_sample(c, sm, px, py);
+        for (int k = 0; k < 15; k++) acc[(size_t)lid * 15 + k] = 0.0;
+        unsigned n = 0;
+        for (int s = sm.nY - 1; s >= 0; --s) { int minT, maxT; pair_range(cfg, sm.nX, s, minT, maxT); if (maxT >= minT) n += (unsigned)(maxT - minT + 1); }
+        if (n) {
+            // three item lists, by the shape of the work: light-tracing connections (t == 1: a base connection + four offset paths, each with its
+            // own rays), connections inside or at the end of the shifted part (every path of the five evaluates its own BSDFs and densities),
+            // connections beyond it (the offsets share everything with the base path but seven densities) -- a wave runs ONE of the three codes
+            unsigned cnt[3] = {0, 0, 0};
+            for (int s = sm.nY - 1; s >= 0; --s) {
+                int minT, maxT;
+                pair_range(cfg, sm.nX, s, minT, maxT);
+                for (int t = maxT; t >= minT; --t) cnt[t == 1 ? 0 : (shares_connection(sm, t) ? 2 : 1)]++;
+            }
+            unsigned at[3];
+            for (int q = 0; q < 3; q++) at[q] = cnt[q] ? atomicAdd(itemCount + q, cnt[q]) : 0u;
+            for (int s = sm.nY - 1; s >= 0; --s) {
+                int minT, maxT;
+                pair_range(cfg, sm.nX, s, minT, maxT);
+                for (int t = maxT; t >= minT; --t) {
+                    const int q = t == 1 ? 0 : (shares_connection(sm, t) ? 2 : 1);
+                    items[(size_t)q * itemStride + at[q]++] = (lid << 10) | ((unsigned)s << 5) | (unsigned)t;
+                }
+            }
+        }
     }
     const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
-    const unsigned n = __builtin_amdgcn_wave_reduce_add_u32(gid < total ? 1u : 0u, 0);
+    const unsigned n = __builtin_amdgcn_wave_reduce_add_u32(lid < count ? 1u : 0u, 0);
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); atomicAdd(stats + 2, (unsigned long long)n); }
+}
+
+__global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ items, unsigned nItems,
+                                                     Float *__restrict__ acc, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    const unsigned i = blockIdx.x * TBLK + threadIdx.x;
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    if (i < nItems) {
+        const unsigned it = items[i];
+        const unsigned lid = it >> 10;
+        const int s = (int)((it >> 5) & 31u), t = (int)(it & 31u);
+        PairOut po;
+        if (connect_pair(c, recs[lid], s, t, po)) {
+            if (t >= 2) {
+                Float *a = acc + (size_t)lid * 15;
+                atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z);
+                for (int n = 0; n < 4; n++) { atomicAdd(a + 3 + 3 * n, po.gradient[n].x); atomicAdd(a + 4 + 3 * n, po.gradient[n].y); atomicAdd(a + 5 + 3 * n, po.gradient[n].z); }
+            } else {
+                const int W = S.cam.width, H = S.cam.height;
+                const size_t plane3 = (size_t)W * H * 3;
+                for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, W, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
+            }
+        }
+    }
+    const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
+}
+
+__global__ __launch_bounds__(TBLK) void k_bd_put(const Sample *__restrict__ recs, const Float *__restrict__ acc, unsigned count, int W, int H, Float *__restrict__ block, unsigned long long *__restrict__ stats)
+{
+    const unsigned lid = blockIdx.x * TBLK + threadIdx.x;
+    if (lid >= count) return;
+    const Float px = recs[lid].posX, py = recs[lid].posY;
+    const Float *a = acc + (size_t)lid * 15;
+    const size_t plane4 = (size_t)W * H * 4;
+    for (int k = 0; k < 5; k++) film_put(block + k * plane4, 4, W, H, px, py, mk(a[3 * k], a[3 * k + 1], a[3 * k + 2]), true, stats + 3);   // putSample, gbdpt_proc.cpp:531-533
 }
 
 // probe: one sample -> primal(3), gradients(12), position(2), light splats (x, y, buffer, r, g, b), counters
@@ -145,6 +211,11 @@ struct gdpt_gbdpt_film {
     float renderMs = 0.0f;
     bool timed = false;
     int W = 0, H = 0;
+    // workspace of the wavefront launches (allocated at the first render, sized for the largest chunk so far)
+    Sample *recs = nullptr;
+    unsigned *items = nullptr, *itemCount = nullptr;
+    Float *acc = nullptr;
+    unsigned capacity = 0;
 };
 
 namespace {
@@ -219,6 +290,7 @@ void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
     hipSetDevice(f->scene->device);
     if (f->stream) hipStreamSynchronize(f->stream);
     hipFree(f->block); hipFree(f->light); hipFree(f->stats);
+    hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
     if (f->e0) hipEventDestroy(f->e0);
     if (f->e1) hipEventDestroy(f->e1);
     if (f->stream) hipStreamDestroy(f->stream);
@@ -247,14 +319,31 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     BdConfig c = make_cfg(cfg);
     if (f->timed) { float ms = 0; BHIPCHK(hipEventSynchronize(f->e1)); BHIPCHK(hipEventElapsedTime(&ms, f->e0, f->e1)); f->renderMs += ms; f->timed = false; }
     BHIPCHK(hipEventRecord(f->e0, f->stream));
-    // launches of at most 2^30 lanes: chunks of samples
-    const long long pixels = (long long)(x1 - x0) * (y1 - y0);
-    int chunk = (int)std::max(1LL, std::min((long long)c.spp, (1LL << 30) / pixels));
-    for (int sb = 0; sb < c.spp; sb += chunk) {
-        c.sBase = sb; c.sCount = std::min(chunk, c.spp - sb);
-        const long long total = pixels * c.sCount;
-        const unsigned grid = (unsigned)((total + TBLK - 1) / TBLK);
-        hipLaunchKernelGGL(k_gbdpt_render, dim3(grid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, f->block, f->light, f->stats);
+    const long long pixels = (long long)(x1 - x0) * (y1 - y0), total = pixels * c.spp;
+    const unsigned chunk = (unsigned)std::min<long long>(total, BD_CHUNK);
+    if (chunk > f->capacity) {
+        hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
+        f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->capacity = 0;
+        if (hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) != hipSuccess || hipMalloc((void **)&f->items, sizeof(unsigned) * 3 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) != hipSuccess ||
+            hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 3) != hipSuccess || hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) != hipSuccess)
+            return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f GB)", chunk, (sizeof(Sample) + 4.0 * BD_ITEMS_PER_SAMPLE + 120.0) * chunk / 1e9);
+        f->capacity = chunk;
+    }
+    for (long long first = 0; first < total; first += chunk) {
+        const unsigned count = (unsigned)std::min<long long>(chunk, total - first);
+        const size_t itemStride = (size_t)f->capacity * BD_ITEMS_PER_SAMPLE;
+        BHIPCHK(hipMemsetAsync(f->itemCount, 0, sizeof(unsigned) * 3, f->stream));
+        hipLaunchKernelGGL(k_bd_walk, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats);
+        BHIPCHK(hipGetLastError());
+        unsigned nItems[3] = {0, 0, 0};
+        BHIPCHK(hipMemcpyAsync(nItems, f->itemCount, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, f->stream));
+        BHIPCHK(hipStreamSynchronize(f->stream));                                          // the sizes of the connection launches come from the walk
+        for (int q = 0; q < 3; q++) {
+            if (!nItems[q]) continue;
+            hipLaunchKernelGGL(k_bd_connect, dim3((nItems[q] + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->items + q * itemStride, nItems[q], f->acc, f->light, f->stats);
+            BHIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_bd_put, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, f->recs, f->acc, count, f->W, f->H, f->block, f->stats);
         BHIPCHK(hipGetLastError());
     }
     BHIPCHK(hipEventRecord(f->e1, f->stream));

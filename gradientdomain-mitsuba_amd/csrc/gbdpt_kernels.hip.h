@@ -579,6 +579,11 @@ struct Sample {
     BE eConn;                   // the edge between them
     int connS;                  // 1: connected to Y[1]; 0: the last sensor vertex lies on an emitter and is connected to the emitter supernode
     Offset off[4];
+    // combineImportanceData / combineRadianceData (gbdpt_proc.cpp:544-565): products of weights / densities along the emitter subpath and
+    // along the sensor subpath and each of its four offsets, up to vertex i
+    d3 impW[NEV]; Float impP[NEV];
+    d3 radW[5][NSV]; Float radP[5][NSV];
+    Float posX, posY;           // the sample's film position (sensorSubpath[0].vertex(1)->getSamplePosition())
 };
 
 // vertex i of "sensorSubpath[k]" (gbdpt_proc.cpp:224: the reversed proposal): base records except the three the shift replaced, and the
@@ -642,7 +647,7 @@ __device__ void collect_pdfs(const Ctx &c, const PathRef &p, const BE &connectio
 // the reference rebuilds the base path's densities for each of the five paths of a connection and forms every strategy's density p_i by an
 // O(n) product (O(n^2) per weight).  Here the base path's p_i are computed ONCE per connection (k = 0) and kept for the four gradient
 // weights, and p_i = prefix(pdfImp)[i] * suffix(pdfRad)[i + 1] in O(n) -- same factors, another association of the products (a few ulp).
-struct MisBase { Float value[NMIS + 1]; unsigned allowed; int n; };
+struct MisBase { Float value[NMIS + 1], pdfImp[NMIS + 1], pdfRad[NMIS + 1]; unsigned allowed; int n; };
 __device__ __forceinline__ void strategy_densities(const Float *pdfImp, const Float *pdfRad, int n /* = s + t + 1 */, Float *value)
 {
     Float suffix[NMIS + 2];
@@ -656,10 +661,9 @@ __device__ __forceinline__ void strategy_densities(const Float *pdfImp, const Fl
 }
 __device__ Float mi_weight_base(const Ctx &c, const Sample &sm, const PathRef &base, const BE &baseEdge, int s, int t, MisBase &mb)
 {
-    Float pdfImp[NMIS + 1], pdfRad[NMIS + 1];
     const int k = s + t + 1;
-    collect_pdfs(c, base, baseEdge, s, t, pdfImp, pdfRad);
-    strategy_densities(pdfImp, pdfRad, k, mb.value);
+    collect_pdfs(c, base, baseEdge, s, t, mb.pdfImp, mb.pdfRad);
+    strategy_densities(mb.pdfImp, mb.pdfRad, k, mb.value);
     mb.n = k; mb.allowed = 0;
     const bool lightImage = c.cfg.lightImage != 0;
     double sum = 0.0, p_st = 0.0;
@@ -684,18 +688,37 @@ __device__ Float mi_weight_grad(const Ctx &c, const MisBase &mb, const PathRef &
         if (mb.allowed & (1u << p)) sum += mb.value[p] * 1.0 + oValue[p] * jDet * 1.0;       // pow(x, 1.0) == x
     return (Float)(mb.value[s] / sum);                                                      // tPrime == t <=> p == s
 }
+// The gradient weight of a connection whose sensor vertex t lies beyond the shifted part of the offset path (5 <= t < the last sensor vertex):
+// the offset path shares vs, vt, their predecessors and the connection edge with the base path, so the four densities evaluated at the
+// connection are the base path's, and its arrays differ from the base path's in the entries of sensor vertices 0..3 only.  Those seven
+// entries are patched in place (and restored): same values as collect_pdfs on the offset path, a fraction of its loads and no BSDF call.
+__device__ __forceinline__ bool shares_connection(const Sample &sm, int t) { return t >= 5 && t < sm.nX - 1; }
+__device__ Float mi_weight_grad_shared(MisBase &mb, const Sample &sm, int k, int s, int t, Float jDet)
+{
+    Float oValue[NMIS + 1], saveI[3], saveR[4];
+    const int n = s + t + 1;
+    for (int i = 1; i <= 3; i++) { const int at = s + 2 + (t - i); saveI[i - 1] = mb.pdfImp[at]; mb.pdfImp[at] = SV(sm, k, i).pdf[EImportance] * SE(sm, k, i - 1).tr[EImportance]; }
+    for (int i = 1; i <= 4; i++) { const int at = s + 1 + (t - i); saveR[i - 1] = mb.pdfRad[at]; mb.pdfRad[at] = SV(sm, k, i - 1).pdf[ERadiance] * SE(sm, k, i - 1).tr[ERadiance]; }
+    strategy_densities(mb.pdfImp, mb.pdfRad, n, oValue);
+    for (int i = 1; i <= 3; i++) mb.pdfImp[s + 2 + (t - i)] = saveI[i - 1];
+    for (int i = 1; i <= 4; i++) mb.pdfRad[s + 1 + (t - i)] = saveR[i - 1];
+    double sum = 0.0;
+    for (int p = 0; p < n; ++p)
+        if (mb.allowed & (1u << p)) sum += mb.value[p] * 1.0 + oValue[p] * jDet * 1.0;
+    return (Float)(mb.value[s] / sum);
+}
 
 struct LightSplat { Float x, y; int buffer; d3 value; };
 struct SampleOut { d3 primal, gradient[4]; Float posX, posY; int nLight; LightSplat light[BD_MAX_LIGHT]; };
+struct PairOut { d3 primal, gradient[4]; int nLight; LightSplat light[5]; };   // one connection (s, t): t >= 2 adds to the sample's sums, t == 1 splats
 
-// GBDPTRenderer::process (the sample loop body, gbdpt_proc.cpp:152-252) + evaluate (:259-534)
-__device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &out)
+// First half of GBDPTRenderer::process (the sample loop body, gbdpt_proc.cpp:152-229): the two subpaths, the connected base path, its four
+// offset paths, the prefix products.  Everything the connections need is in `sm` afterwards (which may live in HBM: the wavefront form).
+__device__ void walk_sample(Ctx &c, Sample &sm, int px, int py)
 {
     const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                           // :101,265
     const BdConfig &cfg = c.cfg;
     const int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth + 1;                  // :110-122: degenerate (pinhole) sensor, hittable emitters
-    out.primal = mk(0.0); out.nLight = 0;
-    for (int k = 0; k < 4; k++) out.gradient[k] = mk(0.0);
     // ---- Path::alternatingRandomWalkFromPixel, path.cpp:548-631 ----
     bv_clear(sm.X[0]); sm.X[0].type = T_SENSOR_SUPER; sm.X[0].degenerate = 1;               // makeEndpoint, vertex.cpp:27-33
     bv_clear(sm.Y[0]); sm.Y[0].type = T_EMITTER_SUPER; sm.Y[0].degenerate = 0;
@@ -715,8 +738,9 @@ __device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &ou
             else walkS = false;
         } else walkS = false;
     } while (walkS || walkT);
-    out.posX = sm.X[1].u; out.posY = sm.X[1].v;
-    if (sm.nY < 2) return;                                                                 // (no emitter could be sampled: a scene without power)
+    sm.posX = sm.X[1].u; sm.posY = sm.X[1].v;
+    for (int k = 0; k < 4; k++) { sm.off[k].success = 0; sm.off[k].couldConnectAfterB = 0; sm.off[k].jacobian = 1.0; }
+    if (sm.nY < 2) { sm.nY = 0; return; }                                                   // (no emitter could be sampled: a scene without power; no connections)
 
     // ---- createShiftablePath(connectPath, emitterSubpath, sensorSubpath, 1, last), gbdpt_proc.cpp:600-662 ----
     const int T = sm.nX - 1;
@@ -732,159 +756,183 @@ __device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &ou
     // muRec.extra[0] = a <= 2 (gbdpt_proc.cpp:200) <=> the connected path has at most four vertices: T + connS < 3
     const bool shiftable = T + sm.connS >= 3 && T >= 2;
     for (int k = 0; k < 4; k++) {
-        Offset &o = sm.off[k];
-        o.success = 0; o.couldConnectAfterB = 0; o.jacobian = 1.0;
         if (!shiftable) continue;
         const BV &srcB = T == 2 ? sm.XTc : sm.X[2];
         const BV &srcC = T == 2 ? sm.Y1c : (T == 3 ? sm.XTc : sm.X[3]);
         const BV *predC = T == 2 ? &sm.Y[0] : (T == 3 ? &sm.Y1c : (T == 4 ? &sm.XTc : &sm.X[4]));
-        generate_offset(c, sm.X[1], sm.X[0], sm.EX[0], srcB, srcC, predC, sm.EX[1].length, shifts[k][0], shifts[k][1], false, o);
+        generate_offset(c, sm.X[1], sm.X[0], sm.EX[0], srcB, srcC, predC, sm.EX[1].length, shifts[k][0], shifts[k][1], false, sm.off[k]);
     }
-    const int vert_b = 2;                                                                  // connectPath.vertexCount() - 1 - extra[1]: b is sensor vertex 2
-
-    // ---- evaluate, gbdpt_proc.cpp:259-534 ----
+    // ---- combineImportanceData / combineRadianceData, gbdpt_proc.cpp:544-565 ----
     const int nE = sm.nY, nS = sm.nX;
-    d3 impW[NEV]; Float impP[NEV];
-    d3 radW[5][NSV]; Float radP[5][NSV];
-    impW[0] = mk(1.0); impP[0] = 1.0;                                                      // combineImportanceData / combineRadianceData, :544-565
+    sm.impW[0] = mk(1.0); sm.impP[0] = 1.0;
     for (int i = 1; i < nE; ++i) {
-        impW[i] = impW[i - 1] * sm.Y[i - 1].w[EImportance] * sm.Y[i - 1].rr * sm.EY[i - 1].tr[EImportance];
-        impP[i] = impP[i - 1] * sm.Y[i - 1].pdf[EImportance] * sm.Y[i - 1].rr * sm.EY[i - 1].tr[EImportance];
+        sm.impW[i] = sm.impW[i - 1] * sm.Y[i - 1].w[EImportance] * sm.Y[i - 1].rr * sm.EY[i - 1].tr[EImportance];
+        sm.impP[i] = sm.impP[i - 1] * sm.Y[i - 1].pdf[EImportance] * sm.Y[i - 1].rr * sm.EY[i - 1].tr[EImportance];
     }
     for (int k = 0; k <= 4; k++) {
-        radW[k][0] = mk(1.0); radP[k][0] = 1.0;
-        for (int i = 1; i < nS; ++i) { radW[k][i] = mk(0.0); radP[k][i] = 0.0; }
+        sm.radW[k][0] = mk(1.0); sm.radP[k][0] = 1.0;
+        for (int i = 1; i < nS; ++i) { sm.radW[k][i] = mk(0.0); sm.radP[k][i] = 0.0; }
         if (k > 0 && !sm.off[k - 1].success) continue;
         // sensorSubpath[k] has vertexCount = nS + connS + 1 >= nS entries for a successful shift
         for (int i = 1; i < nS; ++i) {
             const BV &pv = SV(sm, k, i - 1);
             const BE &pe = SE(sm, k, i - 1);
-            radW[k][i] = radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
-            radP[k][i] = radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+            sm.radW[k][i] = sm.radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
+            sm.radP[k][i] = sm.radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
         }
     }
-    d3 primal = mk(0.0), gradient[4] = {mk(0.0), mk(0.0), mk(0.0), mk(0.0)};
+}
+// the range of sensor vertices connected to emitter vertex s (gbdpt_proc.cpp:311-319)
+__device__ __forceinline__ void pair_range(const BdConfig &cfg, int nS, int s, int &minT, int &maxT)
+{
+    minT = max(2 - s, cfg.lightImage ? 1 : 2);
+    maxT = min(nS - 1, cfg.maxDepth + 1 - s);
+}
+
+// One connection (s, t) of GBDPTRenderer::evaluate (gbdpt_proc.cpp:319-527): the base path and its four offsets.  Reads `sm` only.
+// Returns false when the connection contributes nothing.
+__device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po)
+{
+    const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+    const int vert_b = 2;                                                                  // connectPath.vertexCount() - 1 - extra[1]: b is sensor vertex 2
+    const int nE = sm.nY;
     d3 value[5]; Float miW[5], valuePdf[5];
-    for (s = nE - 1; s >= 0; --s) {
-        const int minT = max(2 - s, cfg.lightImage ? 1 : 2);
-        int maxT = nS - 1;
-        maxT = min(maxT, cfg.maxDepth + 1 - s);
-        for (t = maxT; t >= minT; --t) {
-            Float samplePosX = out.posX, samplePosY = out.posY;
-            if (t == 1) {
-                if (!sensor_sample_position(c, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) continue;
-            }
-            // light-tracing connections (t == 1): the base path Y[0..s-1], Ysc, S1c, X[0] and its four offsets (gbdpt_proc.cpp:356-376)
-            BV Ysc, S1c; BE eL;
-            bool pathSuccess0 = true;
-            if (t == 1) {                                                                  // createShiftablePath(connectedBasePath, emitter, sensor, s, 1)
-                Ysc = sm.Y[s]; S1c = sm.X[1]; be_clear(eL);
-                pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE);
-                sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
-            }
-            BE connEdge, connEdgeBase;
-            d3 connPartsBase = mk(0.0);
-            Float geomBase = 0.0;
-            bool successConnectBase = false;
-            Offset lo;                                                                     // the offset of a light path (transient)
-            MisBase misBase;                                                               // the base path's strategy densities of this connection (k = 0), reused by k = 1..4
-            BV vtBaseCast;                                                                 // s == 0: the base path's sensor vertex t as the emitter sample it was cast to
-            Float jacLP[4] = {1.0, 1.0, 1.0, 1.0};
-            for (int k = 0; k <= 4; k++) {
-                miW[k] = 1.0 / (s + t + 1);
-                bool ok = k == 0 ? true : (sm.off[k - 1].success != 0);
-                value[k] = mk(0.0); valuePdf[k] = 0.0;
-                d3 impWk = impW[s]; Float impPk = impP[s];
-                const d3 radWk = radW[t == 1 ? 0 : k][t]; const Float radPk = radP[t == 1 ? 0 : k][t];
-                bool lightOffset = false;
-                if (t == 1 && k == 0) ok = pathSuccess0;
-                if (t == 1 && k > 0 && !is_zero(value[0])) {
-                    if (!pathSuccess0) ok = false;
-                    else {                                                                 // createShiftedLightPath, :568-590
-                        ok = generate_offset(c, S1c, sm.X[0], sm.EX[0], Ysc, sm.Y[s - 1], s >= 2 ? &sm.Y[s - 2] : nullptr, eL.length,
-                                             shifts[k - 1][0], shifts[k - 1][1], true, lo);
-                        if (ok) {
-                            jacLP[k - 1] = lo.jacobian;
-                            impPk = 1.0; impWk = mk(1.0);
-                            for (int i = 1; i <= s; ++i) {                                 // the offset emitter subpath: Y[0..s-2], lo.c, lo.b
-                                const BV &pv = i - 1 == s - 1 ? lo.c : sm.Y[i - 1];
-                                const Float etr = i - 1 == s - 1 ? lo.ebc.tr[EImportance] : sm.EY[i - 1].tr[EImportance];
-                                impWk = impWk * pv.w[EImportance] * pv.rr * etr;
-                                impPk = impPk * pv.pdf[EImportance] * pv.rr * etr;
-                            }
-                            lightOffset = true;
-                        }
+    po.nLight = 0;
+    Float samplePosX = sm.posX, samplePosY = sm.posY;
+    if (t == 1) {
+        if (!sensor_sample_position(c, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) return false;
+    }
+    // light-tracing connections (t == 1): the base path Y[0..s-1], Ysc, S1c, X[0] and its four offsets (gbdpt_proc.cpp:356-376)
+    BV Ysc, S1c; BE eL;
+    bool pathSuccess0 = true;
+    if (t == 1) {                                                                          // createShiftablePath(connectedBasePath, emitter, sensor, s, 1)
+        Ysc = sm.Y[s]; S1c = sm.X[1]; be_clear(eL);
+        pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE);
+        sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
+    }
+    BE connEdge, connEdgeBase;
+    d3 connPartsBase = mk(0.0);
+    Float geomBase = 0.0;
+    bool successConnectBase = false;
+    Offset lo;                                                                             // the offset of a light path (transient)
+    MisBase misBase;                                                                       // the base path's strategy densities of this connection (k = 0), reused by k = 1..4
+    BV vtBaseCast;                                                                         // s == 0: the base path's sensor vertex t as the emitter sample it was cast to
+    Float jacLP[4] = {1.0, 1.0, 1.0, 1.0};
+    for (int k = 0; k <= 4; k++) {
+        miW[k] = 1.0 / (s + t + 1);
+        bool ok = k == 0 ? true : (sm.off[k - 1].success != 0);
+        value[k] = mk(0.0); valuePdf[k] = 0.0;
+        d3 impWk = sm.impW[s]; Float impPk = sm.impP[s];
+        const d3 radWk = sm.radW[t == 1 ? 0 : k][t]; const Float radPk = sm.radP[t == 1 ? 0 : k][t];
+        bool lightOffset = false;
+        if (t == 1 && k == 0) ok = pathSuccess0;
+        if (t == 1 && k > 0 && !is_zero(value[0])) {
+            if (!pathSuccess0) ok = false;
+            else {                                                                         // createShiftedLightPath, :568-590
+                ok = generate_offset(c, S1c, sm.X[0], sm.EX[0], Ysc, sm.Y[s - 1], s >= 2 ? &sm.Y[s - 2] : nullptr, eL.length,
+                                     shifts[k - 1][0], shifts[k - 1][1], true, lo);
+                if (ok) {
+                    jacLP[k - 1] = lo.jacobian;
+                    impPk = 1.0; impWk = mk(1.0);
+                    for (int i = 1; i <= s; ++i) {                                         // the offset emitter subpath: Y[0..s-2], lo.c, lo.b
+                        const BV &pv = i - 1 == s - 1 ? lo.c : sm.Y[i - 1];
+                        const Float etr = i - 1 == s - 1 ? lo.ebc.tr[EImportance] : sm.EY[i - 1].tr[EImportance];
+                        impWk = impWk * pv.w[EImportance] * pv.rr * etr;
+                        impPk = impPk * pv.pdf[EImportance] * pv.rr * etr;
                     }
+                    lightOffset = true;
                 }
-                Float geomTerm = 0.0;
-                do {
-                    if (!(ok && pathSuccess0 && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
-                    if (k > 0 && t != 1 && !sm.off[k - 1].couldConnectAfterB && t > vert_b) break;
-                    // the connection end points: emitter side vs (with its predecessor), sensor side vt (with its predecessor)
-                    const BV *vsPred, *vtPred; const BV *vsP;
-                    BV vtLocal;                                                            // s == 0: the sensor vertex is cast to an emitter sample (a copy: the cast of
-                    const BV *vtP;                                                         // the reference mutates the shared vertex, which no later evaluation reads)
-                    if (lightOffset) { vsP = &lo.b; vsPred = &lo.c; }
-                    else { vsP = &sm.Y[s]; vsPred = s > 0 ? &sm.Y[s - 1] : nullptr; }
-                    vtP = &SV(sm, t == 1 ? 0 : k, t); vtPred = &SV(sm, t == 1 ? 0 : k, t - 1);
-                    if (vsP->type == T_EMITTER_SUPER) {
-                        vtLocal = *vtP;
-                        if (!bv_cast_emitter(c, vtLocal) || vtLocal.degenerate) { valuePdf[k] = radPk; break; }
-                        vtP = &vtLocal;
-                        if (k == 0) vtBaseCast = vtLocal;
-                        const d3 connParts = (k > 0 && t > vert_b + 1) ? connPartsBase : bv_eval(c, *vsP, vsPred, vtP, EImportance) * bv_eval(c, *vtP, vtPred, vsP, ERadiance);
-                        if (k == 0) connPartsBase = connParts;
-                        value[k] = radWk * connParts;
-                        valuePdf[k] = radPk;
-                    } else {
-                        if (!connectable_gbdpt(c, *vsP) || !connectable_gbdpt(c, *vtP)) { valuePdf[k] = impPk * radPk; break; }
-                        const d3 connParts = (k > 0 && t > vert_b + 1) ? connPartsBase : bv_eval(c, *vsP, vsPred, vtP, EImportance) * bv_eval(c, *vtP, vtPred, vsP, ERadiance);
-                        if (k == 0) connPartsBase = connParts;
-                        value[k] = impWk * radWk * connParts;
-                        valuePdf[k] = impPk * radPk;
-                    }
-                    if (is_zero(value[k]) || valuePdf[k] == 0) break;
-                    const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connEdge, *vsP, *vtP);
-                    if (k == 0) successConnectBase = successConnect;
-                    if (!successConnect) { value[k] = mk(0.0); break; }
-                    geomTerm = (k > 0 && t > vert_b) ? geomBase : edge_geometry_term(c, connEdge, *vsP, *vtP);
-                    value[k] = value[k] * geomTerm;
-                    valuePdf[k] *= 1.0;                                                    // genGeomTerm (calcSpecularPDFChange): 1 without specular chains
-                    if (is_zero(value[k]) || valuePdf[k] == 0) break;
-                    PathRef base; base.sm = &sm; base.k = 0; base.ev = sm.Y; base.ee = sm.EY; base.ne = nE; base.ovS = base.ovSm1 = nullptr; base.ovEm1 = nullptr; base.ovT = nullptr;
-                    if (s == 0) base.ovT = &vtBaseCast;                                    // (the cast vertex: miWeight sees the emitter sample, gbdpt_proc.cpp:402)
-                    if (k == 0) {
-                        connEdgeBase = connEdge;
-                        geomBase = geomTerm;
-                        miW[0] = mi_weight_base(c, sm, base, connEdgeBase, s, t, misBase) / valuePdf[0];
-                    } else {
-                        PathRef off = base;
-                        off.k = t == 1 ? 0 : k;
-                        if (lightOffset) { off.ovS = &lo.b; off.ovSm1 = &lo.c; off.ovEm1 = &lo.ebc; }
-                        if (s == 0) off.ovT = vtP;
-                        miW[k] = mi_weight_grad(c, misBase, off, connEdge, s, t, t < 2 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
-                    }
-                } while (false);
-#ifdef GDPT_BD_TRACE
-                printf("st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\n", s, t, k, (int)ok, value[k].x, value[k].y, value[k].z, valuePdf[k], miW[k], geomTerm, c.nClosest, c.nShadow);
-#endif
-                if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miW[k] = miW[0]; valuePdf[k] = valuePdf[0]; }
-            }
-            if (is_zero(value[0])) continue;
-            const d3 mainRad = value[0] * (valuePdf[0] * miW[0]);
-            if (t >= 2) primal = primal + mainRad;
-            else if (out.nLight < BD_MAX_LIGHT) { LightSplat &ls = out.light[out.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
-            const d3 fx = value[0] * valuePdf[0];
-            for (int n = 0; n < 4; n++) {
-                const d3 fy = value[n + 1] * valuePdf[n + 1] * (t < 2 ? jacLP[n] : sm.off[n].jacobian);
-                const d3 gradVal = (fy - fx) * ((Float)2.0 * miW[n + 1]);
-                if (t >= 2) gradient[n] = gradient[n] + gradVal;
-                else if (out.nLight < BD_MAX_LIGHT) { LightSplat &ls = out.light[out.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
             }
         }
+        Float geomTerm = 0.0;
+        do {
+            if (!(ok && pathSuccess0 && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
+            if (k > 0 && t != 1 && !sm.off[k - 1].couldConnectAfterB && t > vert_b) break;
+            // the connection end points: emitter side vs (with its predecessor), sensor side vt (with its predecessor)
+            const BV *vsPred, *vtPred; const BV *vsP;
+            BV vtLocal;                                                                    // s == 0: the sensor vertex is cast to an emitter sample (a copy: the cast of
+            const BV *vtP;                                                                 // the reference mutates the shared vertex, which no later evaluation reads)
+            if (lightOffset) { vsP = &lo.b; vsPred = &lo.c; }
+            else { vsP = &sm.Y[s]; vsPred = s > 0 ? &sm.Y[s - 1] : nullptr; }
+            vtP = &SV(sm, t == 1 ? 0 : k, t); vtPred = &SV(sm, t == 1 ? 0 : k, t - 1);
+            if (vsP->type == T_EMITTER_SUPER) {
+                vtLocal = *vtP;
+                if (!bv_cast_emitter(c, vtLocal) || vtLocal.degenerate) { valuePdf[k] = radPk; break; }
+                vtP = &vtLocal;
+                if (k == 0) vtBaseCast = vtLocal;
+                const d3 connParts = (k > 0 && t > vert_b + 1) ? connPartsBase : bv_eval(c, *vsP, vsPred, vtP, EImportance) * bv_eval(c, *vtP, vtPred, vsP, ERadiance);
+                if (k == 0) connPartsBase = connParts;
+                value[k] = radWk * connParts;
+                valuePdf[k] = radPk;
+            } else {
+                if (!connectable_gbdpt(c, *vsP) || !connectable_gbdpt(c, *vtP)) { valuePdf[k] = impPk * radPk; break; }
+                const d3 connParts = (k > 0 && t > vert_b + 1) ? connPartsBase : bv_eval(c, *vsP, vsPred, vtP, EImportance) * bv_eval(c, *vtP, vtPred, vsP, ERadiance);
+                if (k == 0) connPartsBase = connParts;
+                value[k] = impWk * radWk * connParts;
+                valuePdf[k] = impPk * radPk;
+            }
+            if (is_zero(value[k]) || valuePdf[k] == 0) break;
+            const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connEdge, *vsP, *vtP);
+            if (k == 0) successConnectBase = successConnect;
+            if (!successConnect) { value[k] = mk(0.0); break; }
+            geomTerm = (k > 0 && t > vert_b) ? geomBase : edge_geometry_term(c, connEdge, *vsP, *vtP);
+            value[k] = value[k] * geomTerm;
+            valuePdf[k] *= 1.0;                                                            // genGeomTerm (calcSpecularPDFChange): 1 without specular chains
+            if (is_zero(value[k]) || valuePdf[k] == 0) break;
+            PathRef base; base.sm = &sm; base.k = 0; base.ev = sm.Y; base.ee = sm.EY; base.ne = nE; base.ovS = base.ovSm1 = nullptr; base.ovEm1 = nullptr; base.ovT = nullptr;
+            if (s == 0) base.ovT = &vtBaseCast;                                            // (the cast vertex: miWeight sees the emitter sample, gbdpt_proc.cpp:402)
+            if (k == 0) {
+                connEdgeBase = connEdge;
+                geomBase = geomTerm;
+                miW[0] = mi_weight_base(c, sm, base, connEdgeBase, s, t, misBase) / valuePdf[0];
+            } else {
+                if (shares_connection(sm, t)) miW[k] = mi_weight_grad_shared(misBase, sm, k, s, t, sm.off[k - 1].jacobian) / valuePdf[0];
+                else {
+                    PathRef off = base;
+                    off.k = t == 1 ? 0 : k;
+                    if (lightOffset) { off.ovS = &lo.b; off.ovSm1 = &lo.c; off.ovEm1 = &lo.ebc; }
+                    if (s == 0) off.ovT = vtP;
+                    miW[k] = mi_weight_grad(c, misBase, off, connEdge, s, t, t < 2 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
+                }
+            }
+        } while (false);
+#ifdef GDPT_BD_TRACE
+        printf("st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\n", s, t, k, (int)ok, value[k].x, value[k].y, value[k].z, valuePdf[k], miW[k], geomTerm, c.nClosest, c.nShadow);
+#endif
+        if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miW[k] = miW[0]; valuePdf[k] = valuePdf[0]; }
     }
-    out.primal = primal;
-    for (int k = 0; k < 4; k++) out.gradient[k] = gradient[k];
+    if (is_zero(value[0])) return false;
+    const d3 mainRad = value[0] * (valuePdf[0] * miW[0]);
+    po.primal = mainRad;
+    if (t < 2) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+    const d3 fx = value[0] * valuePdf[0];
+    for (int n = 0; n < 4; n++) {
+        const d3 fy = value[n + 1] * valuePdf[n + 1] * (t < 2 ? jacLP[n] : sm.off[n].jacobian);
+        const d3 gradVal = (fy - fx) * ((Float)2.0 * miW[n + 1]);
+        po.gradient[n] = gradVal;
+        if (t < 2) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
+    }
+    return true;
+}
+
+// GBDPTRenderer::process + evaluate for one sample in ONE lane, connections in the reference's order (the probe entry; the frame kernels
+// run walk_sample and connect_pair as separate launches)
+__device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &out)
+{
+    out.primal = mk(0.0); out.nLight = 0;
+    for (int k = 0; k < 4; k++) out.gradient[k] = mk(0.0);
+    walk_sample(c, sm, px, py);
+    out.posX = sm.posX; out.posY = sm.posY;
+    PairOut po;
+    for (int s = sm.nY - 1; s >= 0; --s) {
+        int minT, maxT;
+        pair_range(c.cfg, sm.nX, s, minT, maxT);
+        for (int t = maxT; t >= minT; --t) {
+            if (!connect_pair(c, sm, s, t, po)) continue;
+            if (t >= 2) { out.primal = out.primal + po.primal; for (int n = 0; n < 4; n++) out.gradient[n] = out.gradient[n] + po.gradient[n]; }
+            for (int i = 0; i < po.nLight && out.nLight < BD_MAX_LIGHT; i++) out.light[out.nLight++] = po.light[i];
+        }
+    }
 }
 
 } // namespace gdpt_bd
