@@ -537,4 +537,73 @@ private:
     double m_shiftThreshold, m_reconstructAlpha;
 };
 
+/// GBDPTIntegrator (/root/reference/src/integrators/gbdpt/gbdpt.cpp:77-300): constructor :79-104, render :140-262.  The sampler is
+/// GBDPTProcess / GBDPTRenderer behind gdpt_gbdpt_render_rect; the film's seven buffers get the names of gbdpt.cpp:163; BOTH reconstructions
+/// are computed and written (the reconstructL1 / reconstructL2 properties only choose which one comes first, :87,235-251).
+class GBDPTIntegrator {
+public:
+    explicit GBDPTIntegrator(const Properties &props)
+    {
+        m_maxDepth = props.getInteger("maxDepth", -1);
+        m_rrDepth = props.getInteger("rrDepth", 5);
+        m_lightImage = props.getBoolean("lightImage", true);
+        m_shiftThreshold = props.getFloat("shiftThreshold", 0.001);
+        m_reconstructL1 = props.getBoolean("reconstructL1", true);
+        m_reconstructL2 = props.getBoolean("reconstructL2", false);
+        m_reconstructAlpha = props.getFloat("reconstructAlpha", 0.2);
+        if (m_reconstructL1 && m_reconstructL2)
+            logError("Disable 'reconstructL1' or 'reconstructL2': Cannot display two reconstructions at a time!");
+        if (m_reconstructAlpha <= 0.0)
+            logError("'reconstructAlpha' must be set to a value greater than zero!");
+        if (m_rrDepth <= 0)
+            logError("'rrDepth' must be set to a value greater than zero!");
+        if (m_maxDepth <= 0 && m_maxDepth != -1)
+            logError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
+    }
+
+    const Statistics &getStatistics() const { return m_stats; }
+
+    /// render (gbdpt.cpp:140-262)
+    bool render(const SceneData &sd, MultiFilm &film, int sampleCount, unsigned long long seed, std::string &log)
+    {
+        const std::vector<std::string> outNames = {(m_reconstructL1 ? "-L1" : "-L2"), "-gradientNegY", "-gradientNegX", "-gradientPosX", "-gradientPosY",
+                                                   (m_reconstructL1 ? "-L2" : "-L1"), "-primal"};                          // :163
+        if (!film.setBuffers(outNames)) logError("Cannot render image! G-BDPT has been called without MultiFilm.");
+        if (sd.rfilter.getPluginName() != "box" && !sd.rfilter.getPluginName().empty())
+            logError("G-BDPT supports no pixel filter beside the box filter (gbdpt.cpp:70-71)");
+        const int W = film.getWidth(), H = film.getHeight();
+        gdpt_scene *scene = nullptr;
+        gdpt_gbdpt_film *gf = nullptr;
+        GradientPathIntegrator::createScene(sd, -1, &scene);
+        struct Guard { gdpt_scene *&s; gdpt_gbdpt_film *&f; ~Guard() { gdpt_gbdpt_film_destroy(f); gdpt_scene_destroy(s); } } guard{scene, gf};
+        check(gdpt_gbdpt_film_create(scene, &gf));
+        gdpt_gbdpt_config cfg;
+        cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.lightImage = m_lightImage; cfg.spp = sampleCount; cfg.shiftThreshold = m_shiftThreshold; cfg.seed = seed;
+        log += format("Starting render job (%ix%i, %i %s, 1 MI355X) ..\n", W, H, sampleCount, sampleCount == 1 ? "sample" : "samples");
+        check(gdpt_gbdpt_render_rect(scene, &cfg, 0, 0, W, H, gf));
+        check(gdpt_gbdpt_film_sync(gf));
+        const size_t n3 = (size_t)3 * W * H;
+        std::vector<std::vector<double>> dev(5, std::vector<double>(n3));                     // film->developMulti of the primal and the four gradients, :199-202
+        for (int b = 0; b < 5; ++b) check(gdpt_gbdpt_film_develop(gf, b, sampleCount, dev[b].data()));
+        unsigned long long st[4];
+        check(gdpt_gbdpt_film_stats(gf, st));
+        m_stats.raysTraced = st[0]; m_stats.shadowRaysTraced = st[1]; m_stats.paths = st[2]; m_stats.pathLengthSum = 0;
+        const float ms = gdpt_gbdpt_film_render_ms(gf);
+        log += format("Render time: %.3f s, %llu rays + %llu shadow rays (%.1f Mray/s)\n", ms * 1e-3, st[0], st[1], (st[0] + st[1]) / (ms * 1e3));
+        std::vector<float> l2(n3), l1(n3);                                                     // prepareDataForSolver + both solves, :209-251
+        check(gdpt_gbdpt_reconstruct(dev[0].data(), dev[1].data(), dev[2].data(), dev[3].data(), dev[4].data(), W, H, (float)m_reconstructAlpha, -1, l2.data(), l1.data()));
+        film.buffer(0) = m_reconstructL1 ? l1 : l2;
+        film.buffer(5) = m_reconstructL1 ? l2 : l1;
+        for (int b = 1; b <= 4; ++b) for (size_t i = 0; i < n3; ++i) film.buffer(b)[i] = (float)dev[b][i];
+        for (size_t i = 0; i < n3; ++i) film.buffer(6)[i] = (float)dev[0][i];                  // setBitmapMulti(imgBaseBuff, 1, nNeighbours + 2), :255
+        return true;
+    }
+
+private:
+    Statistics m_stats;
+    int m_maxDepth, m_rrDepth;
+    bool m_lightImage, m_reconstructL1, m_reconstructL2;
+    double m_shiftThreshold, m_reconstructAlpha;
+};
+
 } // namespace gdpt

@@ -71,6 +71,17 @@ int main(int argc, char **argv)
         }
         struct stat stt;
         if (skipExisting && (stat((dest + "-final.pfm").c_str(), &stt) == 0 || stat((dest + "-final.exr").c_str(), &stt) == 0)) { if (!quiet) printf("Skipping %s (output exists)\n", scenePath.c_str()); return 0; }
+        if (sd.integrator.getPluginName() == "gbdpt") {                                  // <integrator type="gbdpt">: -L1 -gradient{NegY,NegX,PosX,PosY} -L2 -primal
+            if (skipExisting && (stat((dest + "-L1.pfm").c_str(), &stt) == 0 || stat((dest + "-L1.exr").c_str(), &stt) == 0)) { if (!quiet) printf("Skipping %s (output exists)\n", scenePath.c_str()); return 0; }
+            gdpt::GBDPTIntegrator bd(sd.integrator);
+            gdpt::MultiFilm film(sd.film);
+            film.setDestinationFile(dest);
+            std::string log;
+            bd.render(sd, film, spp, seed, log);
+            for (const std::string &p : film.develop(log, bd.getStatistics())) if (!quiet) printf("Writing image to \"%s\" ..\n", p.c_str());
+            if (!quiet) fputs(log.c_str(), stdout);
+            return 0;
+        }
         gdpt::GradientPathIntegrator integrator(sd.integrator);
         if (deviceList.empty() && numDevices > 1) {
             int visible = 0;

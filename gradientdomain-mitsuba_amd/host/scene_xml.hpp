@@ -190,7 +190,7 @@ public:
             const xml::Node &n = *c;
             if (n.tag == "default") { if (!params.count(n.get("name"))) params[n.get("name")] = subst(n.get("value")); }
             else if (n.tag == "integrator") {
-                if (subst(n.get("type")) != "gpt") logError(format("integrator \"%s\" is not carried: this build is the gpt hot path only", n.get("type").c_str()));
+                if (subst(n.get("type")) != "gpt" && subst(n.get("type")) != "gbdpt") logError(format("integrator \"%s\" is not carried: this build is the gpt / gbdpt hot path only", n.get("type").c_str()));
                 sd.integrator = props(n);
                 haveIntegrator = true;
             } else if (n.tag == "sensor") { sensor(n, sd); haveSensor = true; }

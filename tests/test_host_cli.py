@@ -511,3 +511,33 @@ def test_cli_rectangle_light_equals_python_mirror(cli, tmp_path, gpu_required):
         out = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
         for suffix in G.BUFFER_NAMES:
             assert np.allclose(read_pfm(dest + suffix + ".pfm"), out[suffix], rtol=2e-6, atol=1e-7), (flipped, suffix)
+
+
+@pytest.mark.gpu
+def test_cli_gbdpt_integrator_equals_python_mirror(cli, tmp_path, gpu_required):
+    """`<integrator type="gbdpt">` through the C++ host (GBDPTIntegrator::render, gbdpt.cpp:140-262: seven MultiFilm buffers, both
+    reconstructions) == the Python mirror over the same C-ABI; refused scopes carry their reason to the command line."""
+    import gradientdomain_mitsuba_amd.gpt as G
+    import gradientdomain_mitsuba_amd.gbdpt as B
+    xs = open(XML).read().replace('<integrator type="gpt">', '<integrator type="gbdpt">')
+    xb = str(tmp_path / "bd.xml"); open(xb, "w").write(xs)
+    import shutil; shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    dest = str(tmp_path / "bd")
+    r = run(cli, "-o", dest, "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=6", xb)
+    assert r.returncode == 0, r.stderr
+    integ = B.GBDPTIntegrator(maxDepth=6)
+    out = integ.render(G.Scene(scenes.cornell_box(40, 30)), 4)
+    names = integ.outNames()
+    assert names[0] == "-L1" and all(os.path.exists(dest + n + ".pfm") for n in names)
+    for n in names:
+        img = read_pfm(dest + n + ".pfm")
+        ref = out[n].astype(np.float32)
+        # (the sums of a pixel are fp64 atomics in free order: equal to rounding of the fp32 images and of the two solves fed by them)
+        assert img.shape == (30, 40, 3) and np.allclose(img, ref, rtol=2e-4, atol=2e-6), n
+    assert "Render time" in open(dest + "-log.txt").read()
+    bad = run(cli, "-o", dest + "x", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xb.replace("bd.xml", "bd.xml"), "-D", "maxDepth=13")
+    assert bad.returncode == 1 and "maxDepth" in bad.stderr
+    xm = str(tmp_path / "mirror.xml")
+    open(xm, "w").write(xs.replace("</scene>", '<shape type="rectangle"><transform name="toWorld"><scale value="50"/><translate x="270" y="200" z="300"/></transform><bsdf type="conductor"><rgb name="eta" value="1,1,1"/><rgb name="k" value="3,3,3"/></bsdf></shape></scene>'))
+    bad = run(cli, "-o", dest + "m", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xm)
+    assert bad.returncode == 1 and "Dirac" in bad.stderr
