@@ -224,8 +224,12 @@ public:
         m_height = props.getInteger("height", 576);
         m_fileFormat = props.getString("fileFormat", "openexr");                                    // multifilm.cpp:104
         m_componentFormat = props.getString("componentFormat", "float16");                          // multifilm.cpp:116-117
-        if (m_fileFormat != "pfm" && m_fileFormat != "openexr")
-            logError(format("MultiFilm: fileFormat \"%s\" is not carried (openexr, pfm)", m_fileFormat.c_str()));
+        m_attachLog = props.getBoolean("attachLog", true);                                           // multifilm.cpp:108
+        m_exrCompression = props.getString("exrCompression", "zip");                                // (not a reference property: OpenEXR's default ZIP, or "none" / "zips")
+        if (m_fileFormat != "pfm" && m_fileFormat != "openexr" && m_fileFormat != "rgbe")
+            logError("The \"fileFormat\" parameter must either be equal to \"openexr\", \"pfm\", or \"rgbe\"!");   // multifilm.cpp:126-127
+        if (m_exrCompression != "zip" && m_exrCompression != "zips" && m_exrCompression != "none")
+            logError(format("MultiFilm: exrCompression \"%s\" is not carried (zip, zips, none)", m_exrCompression.c_str()));
         if (m_componentFormat != "float16" && m_componentFormat != "float32")
             logError(format("MultiFilm: componentFormat \"%s\" is not carried (float16, float32)", m_componentFormat.c_str()));
         if (m_fileFormat == "pfm") m_componentFormat = "float32";                                   // multifilm.cpp:223-235: pfm forces float32
@@ -247,8 +251,15 @@ public:
         for (size_t i = 0; i < m_names.size(); ++i) {
             if (m_fileFormat == "openexr") {
                 const std::string path = m_dest + m_names[i] + ".exr";
-                if (!ExrWriter::write(path, m_images[i].data(), m_width, m_height, m_componentFormat == "float16", log))
+                const int comp = m_exrCompression == "zip" ? ExrWriter::ZIP_COMPRESSION : (m_exrCompression == "zips" ? ExrWriter::ZIPS_COMPRESSION : ExrWriter::NO_COMPRESSION);
+                if (!ExrWriter::write(path, m_images[i].data(), m_width, m_height, m_componentFormat == "float16", m_attachLog ? log : std::string(), comp))   // :481-484
                     logError(format("Cannot write \"%s\"", path.c_str()));
+                written.push_back(path);
+                continue;
+            }
+            if (m_fileFormat == "rgbe") {                                                          // multifilm.cpp:462-463
+                const std::string path = m_dest + m_names[i] + ".rgbe";
+                if (!ExrWriter::writeRGBE(path, m_images[i].data(), m_width, m_height)) logError(format("Cannot write \"%s\"", path.c_str()));
                 written.push_back(path);
                 continue;
             }
@@ -269,7 +280,8 @@ public:
 
 private:
     int m_width, m_height;
-    std::string m_fileFormat, m_componentFormat, m_dest;
+    std::string m_fileFormat, m_componentFormat, m_dest, m_exrCompression;
+    bool m_attachLog = true;
     std::vector<std::string> m_names;
     std::vector<std::vector<float>> m_images;
 };

@@ -34,7 +34,7 @@ int main(int argc, char **argv)
             else if (a == "--seed") seed = std::stoull(need("--seed"));
             else if (a == "--parse-only") parseOnly = true;
             else if (a == "--pfm2exr") {      // utility (and CPU-testable face of the EXR writer): --pfm2exr in.pfm out.exr [float16|float32]
-                const std::string in = need("--pfm2exr"), out = need("--pfm2exr"), fmt = (i + 1 < argc) ? argv[++i] : "float16";
+                const std::string in = need("--pfm2exr"), out = need("--pfm2exr"), fmt = (i + 1 < argc) ? argv[++i] : "float16", cmp = (i + 1 < argc) ? argv[++i] : "zip";
                 std::ifstream f(in, std::ios::binary);
                 std::string magic; int w = 0, h = 0; float scale = 0;
                 f >> magic >> w >> h >> scale;
@@ -42,7 +42,19 @@ int main(int argc, char **argv)
                 if (!f || magic != "PF" || scale >= 0 || w <= 0 || h <= 0) gdpt::logError("--pfm2exr: expected a little-endian colour PFM");
                 std::vector<float> img((size_t)3 * w * h);
                 for (int y = h - 1; y >= 0; --y) f.read(reinterpret_cast<char *>(&img[(size_t)3 * w * y]), sizeof(float) * 3 * w);
-                if (!gdpt::ExrWriter::write(out, img.data(), w, h, fmt == "float16")) gdpt::logError("cannot write " + out);
+                if (fmt == "rgbe") { if (!gdpt::ExrWriter::writeRGBE(out, img.data(), w, h)) gdpt::logError("cannot write " + out); return 0; }
+                const int comp = cmp == "zip" ? gdpt::ExrWriter::ZIP_COMPRESSION : (cmp == "zips" ? gdpt::ExrWriter::ZIPS_COMPRESSION : gdpt::ExrWriter::NO_COMPRESSION);
+                if (!gdpt::ExrWriter::write(out, img.data(), w, h, fmt == "float16", "", comp)) gdpt::logError("cannot write " + out);
+                return 0;
+            }
+            else if (a == "--tex2pfm") {      // utility (and CPU-testable face of the texture / environment-map READER): --tex2pfm in.{exr,png,ppm,pfm} out.pfm
+                const std::string in = need("--tex2pfm"), out = need("--tex2pfm");
+                gdpt::SceneData::Texture t;
+                loader.readBitmap(in, t, 1.0);
+                std::ofstream o(out, std::ios::binary);
+                o << "PF\n" << t.width << " " << t.height << "\n-1.0\n";
+                std::vector<float> row((size_t)3 * t.width);
+                for (int y = t.height - 1; y >= 0; --y) { for (int x = 0; x < 3 * t.width; ++x) row[x] = (float)t.rgb[(size_t)3 * t.width * y + x]; o.write(reinterpret_cast<const char *>(row.data()), sizeof(float) * row.size()); }
                 return 0;
             }
             else if (a == "-h" || a == "--help") { printf("usage: gdpt_mitsuba [-o dest] [-D key=val] [-p gpus] [--devices a,b,..] [-b n] [-x] [-q] [--seed n] [--parse-only] scene.xml\n"); return 0; }

@@ -529,6 +529,9 @@ private:
 
     // -> t.width, t.height, t.rgb (linear, top row first).  fileGamma: what the format implies (-1 sRGB for the 8-bit formats, 1 for floats);
     // `gamma` != 0 overrides it (bitmap.cpp:251-252).
+public:
+    void readBitmap(const std::string &path, SceneData::Texture &t, double gamma) { loadImage(path, gamma, t); }   // the texture / environment-map reader on its own (gdpt_mitsuba --tex2pfm)
+private:
     void loadImage(const std::string &path, double gamma, SceneData::Texture &t)
     {
         std::ifstream f(path, std::ios::binary);
@@ -622,29 +625,48 @@ private:
                 at += size;
             }
             ++at;
-            if (compression != 0 || w <= 0 || h <= 0 || channels.empty()) logError(path + ": only uncompressed scanline OpenEXR files are carried");
+            if ((compression != 0 && compression != 2 && compression != 3) || w <= 0 || h <= 0 || channels.empty())
+                logError(path + ": only uncompressed, ZIPS- and ZIP-compressed scanline OpenEXR files are carried (PIZ / PXR24 / B44 / DWA are not)");
             size_t rowBytes = 0;
             for (auto &c : channels) rowBytes += (size_t)w * (c.second == 1 ? 2 : 4);
             t.width = w; t.height = h; t.rgb.assign((size_t)3 * w * h, 0.0);
             auto half2d = [](unsigned short hv) { const int s = hv >> 15, e = (hv >> 10) & 31, m = hv & 1023; double v = e == 0 ? std::ldexp((double)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp((double)(m + 1024), e - 25)); return s ? -v : v; };
-            for (int y = 0; y < h; ++y) {
-                const size_t off = (size_t)(le32(at + 8 * (size_t)y)) | ((size_t)le32(at + 8 * (size_t)y + 4) << 32);
-                size_t p = off + 8;
-                for (auto &c : channels) {
-                    const int dst = c.first == "R" ? 0 : c.first == "G" ? 1 : c.first == "B" ? 2 : (c.first == "Y" ? 3 : -1);
-                    for (int x = 0; x < w; ++x) {
-                        double v;
-                        if (c.second == 1) { unsigned short hv; if (p + 2 > data.size()) logError(path + ": truncated"); std::memcpy(&hv, &data[p], 2); p += 2; v = half2d(hv); }
-                        else { float fv; if (p + 4 > data.size()) logError(path + ": truncated"); std::memcpy(&fv, &data[p], 4); p += 4; v = (double)fv; }
-                        if (gamma != 0 && gamma != 1) v = undoGamma(v, gamma);
-                        if (dst == 3) for (int k = 0; k < 3; ++k) t.rgb[((size_t)y * w + x) * 3 + k] = v;
-                        else if (dst >= 0) t.rgb[((size_t)y * w + x) * 3 + dst] = v;
-                    }
+            const int lines = compression == 3 ? 16 : 1, chunks = (h + lines - 1) / lines;
+            std::vector<unsigned char> raw, tmp;
+            for (int cidx = 0; cidx < chunks; ++cidx) {
+                const size_t off = (size_t)(le32(at + 8 * (size_t)cidx)) | ((size_t)le32(at + 8 * (size_t)cidx + 4) << 32);
+                const int y0 = (int)le32(off), y1 = std::min(h, y0 + lines);
+                const size_t sz = le32(off + 4), want = (size_t)(y1 - y0) * rowBytes;
+                if (y0 < 0 || y0 >= h || off + 8 + sz > data.size()) logError(path + ": truncated");
+                raw.assign(want, 0);
+                if (compression == 0 || sz == want) { if (sz != want) logError(path + ": truncated"); std::memcpy(raw.data(), &data[off + 8], want); }
+                else {                                                                                // ImfZip.cpp: zlib, undo the predictor, interleave the two halves
+                    tmp.assign(want, 0);
+                    uLongf outLen = (uLongf)want;
+                    if (uncompress(tmp.data(), &outLen, &data[off + 8], (uLong)sz) != Z_OK || outLen != want) logError(path + ": OpenEXR data is corrupt");
+                    for (size_t i = 1; i < want; ++i) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);
+                    const unsigned char *t1 = tmp.data(), *t2 = tmp.data() + (want + 1) / 2;
+                    for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? *t2++ : *t1++;
                 }
+                size_t p = 0;
+                for (int y = y0; y < y1; ++y)
+                    for (auto &c : channels) {
+                        const int dst = c.first == "R" ? 0 : c.first == "G" ? 1 : c.first == "B" ? 2 : (c.first == "Y" ? 3 : -1);
+                        for (int x = 0; x < w; ++x) {
+                            double v;
+                            if (c.second == 1) { unsigned short hv; std::memcpy(&hv, &raw[p], 2); p += 2; v = half2d(hv); }
+                            else { float fv; std::memcpy(&fv, &raw[p], 4); p += 4; v = (double)fv; }
+                            if (gamma != 0 && gamma != 1) v = undoGamma(v, gamma);
+                            if (dst == 3) for (int k = 0; k < 3; ++k) t.rgb[((size_t)y * w + x) * 3 + k] = v;
+                            else if (dst >= 0) t.rgb[((size_t)y * w + x) * 3 + dst] = v;
+                        }
+                    }
             }
             return;
         }
-        logError(format("texture \"%s\": the file format is not carried (PFM, PPM, 8-bit PNG, uncompressed OpenEXR)", path.c_str()));
+        if (data.size() >= 3 && data[0] == 0xff && data[1] == 0xd8 && data[2] == 0xff)
+            logError(format("texture \"%s\": JPEG files are not carried (convert to PNG / EXR)", path.c_str()));
+        logError(format("texture \"%s\": the file format is not carried (PFM, PPM, 8-bit PNG, uncompressed / ZIP OpenEXR)", path.c_str()));
     }
 
     /// lookupIOR (src/bsdfs/ior.h:40-80): a number, or one of the named media (float literals there, hence the casts)

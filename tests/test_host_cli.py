@@ -177,8 +177,10 @@ def test_cli_errors(cli, tmp_path):
 
 
 def read_exr(path):
-    """Minimal reader for the uncompressed scanline RGB OpenEXR files MultiFilm's default format produces here."""
+    """Minimal independent reader (numpy + zlib) for the scanline RGB OpenEXR files MultiFilm's default format produces here: uncompressed,
+    ZIPS (1 line per chunk) or ZIP (16 lines per chunk; OpenEXR's default and what the reference's Bitmap::writeOpenEXR writes)."""
     import struct
+    import zlib
     b = open(path, "rb").read()
     assert struct.unpack("<II", b[:8]) == (20000630, 2)
     i, attrs = 8, {}
@@ -188,7 +190,8 @@ def read_exr(path):
         (sz,) = struct.unpack("<i", b[i:i + 4]); i += 4
         attrs[name] = (typ, b[i:i + sz]); i += sz
     i += 1
-    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    comp = attrs["compression"][1][0]
+    assert comp in (0, 2, 3) and attrs["lineOrder"][1] == b"\0"
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
     ch, j, names, types = attrs["channels"][1], 0, [], []
@@ -197,13 +200,27 @@ def read_exr(path):
         types.append(struct.unpack("<i", ch[j:j + 4])[0]); j += 16
     assert names == ["B", "G", "R"] and len(set(types)) == 1
     dt = {1: "<f2", 2: "<f4"}[types[0]]
-    offs = struct.unpack("<%dQ" % h, b[i:i + 8 * h])
+    lines = 16 if comp == 3 else 1
+    chunks = (h + lines - 1) // lines
+    offs = struct.unpack("<%dQ" % chunks, b[i:i + 8 * chunks])
     img = np.zeros((h, w, 3), np.float32)
-    for y in range(h):
-        yy, sz = struct.unpack("<ii", b[offs[y]:offs[y] + 8])
-        assert yy == y and sz == w * 3 * np.dtype(dt).itemsize
-        line = np.frombuffer(b[offs[y] + 8:offs[y] + 8 + sz], dt).reshape(3, w)
-        img[y, :, 2], img[y, :, 1], img[y, :, 0] = line[0], line[1], line[2]
+    line_bytes = w * 3 * np.dtype(dt).itemsize
+    for c in range(chunks):
+        yy, sz = struct.unpack("<ii", b[offs[c]:offs[c] + 8])
+        n = min(lines, h - yy)
+        assert yy == c * lines
+        raw = b[offs[c] + 8:offs[c] + 8 + sz]
+        if comp != 0 and sz != n * line_bytes:                       # ImfZip: zlib -> undo the delta predictor -> interleave the two halves
+            t = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int64)
+            assert t.size == n * line_bytes
+            t[1:] -= 128
+            t = (np.cumsum(t) % 256).astype(np.uint8)
+            half = (t.size + 1) // 2
+            out = np.empty(t.size, np.uint8); out[0::2] = t[:half]; out[1::2] = t[half:]
+            raw = out.tobytes()
+        assert len(raw) == n * line_bytes
+        blk = np.frombuffer(raw, dt).reshape(n, 3, w)
+        img[yy:yy + n, :, 2], img[yy:yy + n, :, 1], img[yy:yy + n, :, 0] = blk[:, 0], blk[:, 1], blk[:, 2]
     return img, attrs
 
 
@@ -224,6 +241,44 @@ def test_exr_writer_round_trip(cli, tmp_path):
     imgh, _ = read_exr(str(tmp_path / "h.exr"))
     with np.errstate(over="ignore"):
         assert np.array_equal(imgh, a.astype(np.float16).astype(np.float32))                                    # round-to-nearest-even, like numpy
+    assert attrs["compression"][1] == b"\x03"                             # the default: ZIP, as OpenEXR's Header defaults (bitmap.cpp:3197)
+
+
+def test_exr_zip_writer_reader_and_rgbe(cli, tmp_path):
+    """ZIP / ZIPS / uncompressed scanline OpenEXR: written by the host's writer, read back by an independent numpy + zlib reader AND by the
+    host's texture / environment-map reader (`--tex2pfm`); ragged sizes (the last ZIP block shorter than 16 lines, odd byte counts), a
+    compressible and an incompressible image (a block that does not shrink is stored raw); the Radiance RGBE writer of fileFormat=rgbe."""
+    rng = np.random.default_rng(4)
+    for (h, w) in ((37, 21), (16, 5), (1, 1), (50, 64)):
+        smooth = np.stack([np.add.outer(np.arange(h), np.arange(w)) * 0.01 + c for c in range(3)], -1).astype(np.float32)
+        noisy = rng.standard_normal((h, w, 3)).astype(np.float32)
+        for name, a in (("smooth", smooth), ("noisy", noisy)):
+            write_pfm(str(tmp_path / "a.pfm"), a)
+            for fmt in ("float32", "float16"):
+                want = a if fmt == "float32" else a.astype(np.float16).astype(np.float32)
+                for cmp in ("zip", "zips", "none"):
+                    out = str(tmp_path / ("%s_%s_%s.exr" % (name, fmt, cmp)))
+                    assert run(cli, "--pfm2exr", str(tmp_path / "a.pfm"), out, fmt, cmp).returncode == 0
+                    img, attrs = read_exr(out)
+                    assert attrs["compression"][1][0] == {"zip": 3, "zips": 2, "none": 0}[cmp] and np.array_equal(img, want), (h, w, name, fmt, cmp)
+                    r = run(cli, "--tex2pfm", out, str(tmp_path / "back.pfm"))
+                    assert r.returncode == 0, r.stderr
+                    assert np.array_equal(read_pfm(str(tmp_path / "back.pfm")), want), (h, w, name, fmt, cmp)
+        if (h, w) == (50, 64):
+            assert os.path.getsize(str(tmp_path / "smooth_float32_zip.exr")) < 0.5 * os.path.getsize(str(tmp_path / "smooth_float32_none.exr"))
+    # RGBE: shared exponent, ~1 % relative accuracy on the largest channel
+    a = np.abs(rng.standard_normal((9, 14, 3))).astype(np.float32) * 5
+    write_pfm(str(tmp_path / "a.pfm"), a)
+    assert run(cli, "--pfm2exr", str(tmp_path / "a.pfm"), str(tmp_path / "a.rgbe"), "rgbe").returncode == 0
+    b = open(str(tmp_path / "a.rgbe"), "rb").read()
+    hdr_end = b.index(b"+X 14\n") + 6
+    assert b.startswith(b"#?RGBE\n") and b"-Y 9 +X 14" in b[:hdr_end]
+    px = np.frombuffer(b[hdr_end:], np.uint8).reshape(9, 14, 4).astype(np.float64)
+    dec = px[..., :3] * np.exp2(px[..., 3:4] - 136.0)
+    assert np.abs(dec - a).max() <= a.max(axis=-1, keepdims=True).max() / 100.0
+    bad = tmp_path / "x.jpg"; bad.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    r = run(cli, "--tex2pfm", str(bad), str(tmp_path / "back.pfm"))
+    assert r.returncode == 1 and "JPEG" in r.stderr
 
 
 def read_pfm(path):
@@ -431,6 +486,13 @@ def test_cli_bitmap_textures_equal_python_mirror(cli, tmp_path, gpu_required):
         assert np.allclose(img, out[suffix], rtol=2e-6, atol=1e-7), suffix         # (pow() of the sRGB table: glibc here, numpy there)
     plain = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
     assert not np.allclose(plain["-throughput"], out["-throughput"], rtol=1e-2, atol=1e-3)
+    # the same map as a ZIP-compressed float32 OpenEXR file (what real scene files ship) renders the same bytes as its PFM copy
+    assert run(cli, "--pfm2exr", str(tmp_path / "sky.pfm"), str(tmp_path / "sky.exr"), "float32", "zip").returncode == 0
+    xz = str(tmp_path / "envz.xml"); open(xz, "w").write(xml.replace("sky.pfm", "sky.exr"))
+    r = run(cli, "-o", dest + "z", "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xz)
+    assert r.returncode == 0, r.stderr
+    for suffix in G.BUFFER_NAMES:
+        assert np.array_equal(read_pfm(dest + "z" + suffix + ".pfm"), read_pfm(dest + suffix + ".pfm")), suffix
     # without a filterType the reference's default applies: ewa (bitmap.cpp:213), with maxAnisotropy as given == the Python mirror again
     ewa = str(tmp_path / "ewa.xml"); open(ewa, "w").write(xml.replace('<string name="filterType" value="bilinear"/>', '<float name="maxAnisotropy" value="4"/>'))
     r = run(cli, "-o", dest + "e", "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", ewa)
@@ -468,6 +530,13 @@ def test_cli_envmap_emitter_equals_python_mirror(cli, tmp_path, gpu_required):
         assert np.allclose(read_pfm(dest + suffix + ".pfm"), out[suffix], rtol=2e-6, atol=1e-7), suffix
     plain = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
     assert not np.allclose(plain["-throughput"], out["-throughput"], rtol=1e-2, atol=1e-3)
+    # the same map as a ZIP-compressed float32 OpenEXR file (what real scene files ship) renders the same bytes as its PFM copy
+    assert run(cli, "--pfm2exr", str(tmp_path / "sky.pfm"), str(tmp_path / "sky.exr"), "float32", "zip").returncode == 0
+    xz = str(tmp_path / "envz.xml"); open(xz, "w").write(xml.replace("sky.pfm", "sky.exr"))
+    r = run(cli, "-o", dest + "z", "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xz)
+    assert r.returncode == 0, r.stderr
+    for suffix in G.BUFFER_NAMES:
+        assert np.array_equal(read_pfm(dest + "z" + suffix + ".pfm"), read_pfm(dest + suffix + ".pfm")), suffix
 
 
 @pytest.mark.gpu
