@@ -486,13 +486,6 @@ def test_cli_bitmap_textures_equal_python_mirror(cli, tmp_path, gpu_required):
         assert np.allclose(img, out[suffix], rtol=2e-6, atol=1e-7), suffix         # (pow() of the sRGB table: glibc here, numpy there)
     plain = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
     assert not np.allclose(plain["-throughput"], out["-throughput"], rtol=1e-2, atol=1e-3)
-    # the same map as a ZIP-compressed float32 OpenEXR file (what real scene files ship) renders the same bytes as its PFM copy
-    assert run(cli, "--pfm2exr", str(tmp_path / "sky.pfm"), str(tmp_path / "sky.exr"), "float32", "zip").returncode == 0
-    xz = str(tmp_path / "envz.xml"); open(xz, "w").write(xml.replace("sky.pfm", "sky.exr"))
-    r = run(cli, "-o", dest + "z", "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xz)
-    assert r.returncode == 0, r.stderr
-    for suffix in G.BUFFER_NAMES:
-        assert np.array_equal(read_pfm(dest + "z" + suffix + ".pfm"), read_pfm(dest + suffix + ".pfm")), suffix
     # without a filterType the reference's default applies: ewa (bitmap.cpp:213), with maxAnisotropy as given == the Python mirror again
     ewa = str(tmp_path / "ewa.xml"); open(ewa, "w").write(xml.replace('<string name="filterType" value="bilinear"/>', '<float name="maxAnisotropy" value="4"/>'))
     r = run(cli, "-o", dest + "e", "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", ewa)
