@@ -1004,3 +1004,55 @@ def test_texture_arguments_are_checked(G):
     sc.material_textures[0] = 7
     with pytest.raises(RuntimeError, match="out of range"):
         G.Scene(sc)
+
+
+def _gate_scenes():
+    """One scene per feature set the render kernels are built for (flat | + environment | + per-vertex normals), each with the settings the two
+    unexplained -O3 findings of round 2 needed: strictNormals with near-specular / glossy lobes at maxDepth 4-8, a constant environment at maxDepth >= 3."""
+    return [("flat-nearspecular-strict", lambda: scenes.cornell_box(40, 30, "nearspecular"), dict(maxDepth=6, strictNormals=True)),
+            ("flat-glossy-strict", lambda: scenes.cornell_box(40, 30, "glossy"), dict(maxDepth=8, strictNormals=True)),
+            ("environment-strict", lambda: scenes.cornell_box(48, 30, "glossy", environment=(0.7, 0.9, 1.2)), dict(maxDepth=5, strictNormals=True)),
+            ("environment-deep", lambda: scenes.cornell_box(48, 30, "diffuse", environment=(0.7, 0.9, 1.2)), dict(maxDepth=4)),
+            ("pervertex-bent-strict", lambda: scenes.cornell_box(40, 30, "bent"), dict(maxDepth=7, strictNormals=True))]
+
+
+@pytest.mark.parametrize("name,builder,kw", _gate_scenes(), ids=[c[0] for c in _gate_scenes()])
+@pytest.mark.parametrize("hbm", [False, True], ids=["lds-scene", "hbm-scene"])
+def test_every_shipped_instantiation_agrees_with_the_general_kernel_and_the_oracle(G, monkeypatch, name, builder, kw, hbm):
+    """The regression gate ADVICE r2 asked for: EVERY instantiation of the render kernels the dispatcher can select for a scene -- staged
+    (k_render<STAGED> + k_continue) with the sums in LDS or in registers, the same with the GENERAL k_render in the staged pipeline
+    (GDPT_DEV_GENERAL_KERNEL), the single-kernel form built for 2 and for 4 waves per SIMD -- for the LDS-resident build and (GDPT_SCENE_IN_HBM:
+    small scenes through the HBM-scene builds, incl. the scratch-resident Lane of the 4-wave kernels) the HBM-resident one, against the oracle:
+    identical ray counts, films to 1e-9.  A silent wrong value of the kind found in round 2 (one 16-byte unit of an offset's throughput in one
+    instantiation, strictNormals + maxDepth >= 4 only) fails here."""
+    if hbm:
+        monkeypatch.setenv("GDPT_SCENE_IN_HBM", "1")
+    sc = builder()
+    W, H, spp = sc.width, sc.height, 4
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(**kw)
+    cfg = integ.config(spp)
+    oacc, orays = O.render(go.config(spp=spp, **kw))
+    variants = [("staged", dict(pipeline=2, occ=2), {}), ("staged-register-sums", dict(pipeline=2, occ=-2), {}),
+                ("staged-general-kernel", dict(pipeline=2, occ=2), {"GDPT_DEV_GENERAL_KERNEL": "1"}),
+                ("single-2-waves", dict(pipeline=0, occ=2), {}), ("single-2-waves-register-sums", dict(pipeline=0, occ=-2), {}),
+                ("single-4-waves", dict(pipeline=0, occ=4), {})]
+    ref = None
+    for vname, knobs, env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        F = G.Film(S)
+        F.set_pipeline(knobs["pipeline"]); F.set_occupancy(knobs["occ"])
+        integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        F.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays, (name, hbm, vname)
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (name, hbm, vname, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+        if ref is None:
+            ref = acc
+        else:
+            assert np.allclose(acc, ref, rtol=1e-12, atol=1e-12), (name, hbm, vname)
+    S.close(); O.close()
