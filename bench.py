@@ -426,6 +426,8 @@ def main():
             iter_bytes = 120.0 * npx
             iter_us = hb["kus"][3] + hb["kus"][1]
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "scope": "side measurement in this process at a synthetic HBM-resident size (%dx%d), NOT a kernel of the timed step: the step's own kernels are reported under tracer_issue (issue-bound) and persistent_cg (latency-bound) and have no HBM fraction" % (hb["w"], hb["h"]),
+                        "synthetic_size": True, "timed_step_roofline": None,
                         "traffic": _traffic_bytes(hc), "traffic_source": counters_file if hc else None,
                         "kernel": "kf_xp_Ax", "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
                         "what": "fused x_p + 5-point stencil of the screened-Poisson CG at %dx%d L2D (HBM-resident: 1.2 GB working set), algorithmic 72 B/px per launch / HIP-event launch duration, measured in this run" % (hb["w"], hb["h"]),

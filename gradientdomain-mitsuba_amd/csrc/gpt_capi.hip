@@ -257,7 +257,7 @@ void build_pyramid(std::vector<double> &texels, TexD &o, double maxValue = 1.0, 
     int sw = o.w, sh = o.h;
     std::vector<double> cur(texels.begin(), texels.end());
     if (halfStorage) for (double &v : texels) v = round_to_half(v);
-    while ((sw > 1 || sh > 1) && o.levels < TEX_MAX_LEVELS) {
+    while ((sw > 1 || sh > 1) && o.levels < TEX_MAX_LEVELS) {   // (a side of more than 32768 texels would need a 17th level: refused by the caller, pyramid_fits)
         const int tw = std::max(1, (sw + 1) / 2), th = std::max(1, (sh + 1) / 2);
         std::vector<double> temp, next((size_t)tw * th * 3);
         const double *src = cur.data();
@@ -574,6 +574,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
             o.maxAnisotropy = t.filter == GDPT_TEXFILTER_EWA ? t.maxAnisotropy : 1.0;         // bitmap.cpp:232-235
             if (t.filter >= GDPT_TEXFILTER_TRILINEAR) {
                 if ((long)t.width * t.height > (1L << 28)) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_UNSUPPORTED, "texture %d: larger than 2^28 texels", i); }
+                if (std::max(t.width, t.height) > (1 << (TEX_MAX_LEVELS - 1))) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_UNSUPPORTED, "texture %d: a side of more than %d texels needs more than %d MIP levels", i, 1 << (TEX_MAX_LEVELS - 1), TEX_MAX_LEVELS); }
                 build_pyramid(texels, o);
                 fill_ewa_lut(o);
             }
@@ -632,6 +633,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         o.uscale = o.vscale = 1.0; o.scale = 1.0; o.maxAnisotropy = 10.0;
         std::vector<double> texels(env->rgb, env->rgb + (size_t)3 * o.w * o.h);
         for (double &v : texels) if (v < 0) v = 0;
+        if (std::max(o.w, o.h) > (1 << (TEX_MAX_LEVELS - 1))) { gdpt_scene_destroy(s); return tfail(GDPT_ERR_UNSUPPORTED, "environment map: a side of more than %d texels needs more than %d MIP levels", 1 << (TEX_MAX_LEVELS - 1), TEX_MAX_LEVELS); }
         build_pyramid(texels, o, INFINITY, true);
         fill_ewa_lut(o);
         const int W = o.w, H = o.h;
@@ -857,26 +859,41 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // (GDPT_QUEUE_MB, default 24 GiB of the 288) and the chunks are made equal.
     const unsigned qPixels = (unsigned)tiles * TBLK;
     if (useQueue) {
+        // budget: GDPT_QUEUE_MB, else 24 GiB, never more than 40 % of what the device has free right now (+ what this film's queue already holds):
+        // several films on one GPU (strips wrapped onto a device, partitioned or smaller parts) each get a share instead of failing
         size_t budget = (size_t)24 << 30;
         if (const char *e = getenv("GDPT_QUEUE_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;
+        else {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, (size_t)(0.4 * (double)(freeB + f->qBytes))));
+        }
         const size_t perSample = (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int));
-        int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)0xffffffffu / qPixels));
-        maxChunk = std::min(maxChunk, chunk);
-        const int nChunks = (cfg->spp + maxChunk - 1) / maxChunk;
-        chunk = std::min(chunk, (cfg->spp + nChunks - 1) / nChunks);
-        const size_t need = (size_t)chunk * perSample;
-        if (f->qBytes < need) {
-            THIPCHK(hipStreamSynchronize(f->stream));
+        const int wantChunk = chunk;
+        for (int attempt = 0; ; attempt++) {
+            int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)0xffffffffu / qPixels));
+            maxChunk = std::min(maxChunk, wantChunk);
+            const int nChunks = (cfg->spp + maxChunk - 1) / maxChunk;
+            chunk = std::min(wantChunk, (cfg->spp + nChunks - 1) / nChunks);
+            const size_t need = (size_t)chunk * perSample;
+            if (f->qBytes >= need) break;
+            (void)hipStreamSynchronize(f->stream);
             if (f->d.qRec) hipFree(f->d.qRec);
             if (f->d.qList) hipFree(f->d.qList);
             if (f->d.pHit) hipFree(f->d.pHit);
             if (f->d.pPrim) hipFree(f->d.pPrim);
             f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr; f->qBytes = 0;
-            if (hipMalloc((void **)&f->d.qRec, (size_t)chunk * qPixels * NQ * sizeof(Float)) != hipSuccess ||
-                hipMalloc((void **)&f->d.qList, (size_t)chunk * qPixels * sizeof(unsigned)) != hipSuccess ||
-                hipMalloc((void **)&f->d.pHit, (size_t)chunk * qPixels * 15 * sizeof(Float)) != hipSuccess ||
-                hipMalloc((void **)&f->d.pPrim, (size_t)chunk * qPixels * 5 * sizeof(int)) != hipSuccess) return tfail(GDPT_ERR_HIP, "Out of memory!");
-            f->qBytes = need;
+            if (hipMalloc((void **)&f->d.qRec, (size_t)chunk * qPixels * NQ * sizeof(Float)) == hipSuccess &&
+                hipMalloc((void **)&f->d.qList, (size_t)chunk * qPixels * sizeof(unsigned)) == hipSuccess &&
+                hipMalloc((void **)&f->d.pHit, (size_t)chunk * qPixels * 15 * sizeof(Float)) == hipSuccess &&
+                hipMalloc((void **)&f->d.pPrim, (size_t)chunk * qPixels * 5 * sizeof(int)) == hipSuccess) { f->qBytes = need; break; }
+            (void)hipGetLastError();                                                       // the allocation failed: halve the chunk and try again
+            if (f->d.qRec) hipFree(f->d.qRec);
+            if (f->d.qList) hipFree(f->d.qList);
+            if (f->d.pHit) hipFree(f->d.pHit);
+            if (f->d.pPrim) hipFree(f->d.pPrim);
+            f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr;
+            if (chunk <= 1 || attempt > 24) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "Out of memory! (sample queue: %zu bytes for one sample per pixel)", perSample); }
+            budget = std::max<size_t>(perSample, need / 2);
         }
         if (!f->d.qCount) THIPCHK(hipMalloc((void **)&f->d.qCount, 2 * sizeof(unsigned)));
     }

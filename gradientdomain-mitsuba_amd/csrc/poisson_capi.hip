@@ -876,6 +876,60 @@ int gdpt_backend_calc_MIx(float *MIx, int w, int h, float alpha, const float *w2
     return GDPT_OK;
 }
 
+// Backend::tonemapSRGB (Backend.cpp:442-468): out[i] = ABGR_8888 of sRGB(in[i + idx * numPixels] * scale + bias); in: Vec3f per pixel
+int gdpt_backend_tonemap_srgb(unsigned *out, const float *in, int idx, int numPixels, float scale, float bias, void *stream)
+{
+    if (!out || !in || numPixels <= 0 || idx < 0) return fail(GDPT_ERR_INVALID, "tonemap_srgb: bad argument");
+    hipLaunchKernelGGL(kg_tonemap_srgb, dim3((numPixels + BLK - 1) / BLK), dim3(BLK), 0, (hipStream_t)stream, out, in + (size_t)idx * numPixels * 3, numPixels, scale, bias);
+    HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+// Backend::tonemapLinear (Backend.cpp:472-507): scale by the range of the `idx`-th block of numPixels * numComponents floats, |.|, pack.
+// `out` holds at least two words: the first two serve as the min / max cells of pass A before pass B overwrites them (as BackendCUDA.cu:647-653).
+int gdpt_backend_tonemap_linear(unsigned *out, const float *in, int idx, int numPixels, int numComponents, float scaleMin, float scaleMax, int hasNegative, void *stream)
+{
+    if (!out || !in || numPixels < 2 || numComponents < 1 || idx < 0) return fail(GDPT_ERR_INVALID, "tonemap_linear: bad argument");
+    const int total = numPixels * numComponents;
+    const float *src = in + (size_t)idx * total;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *cells = nullptr;                                                            // (separate cells: pass B reads them while it writes out[0..1])
+    HIPCHK(hipMallocAsync((void **)&cells, 2 * sizeof(unsigned), st));
+    const unsigned init[2] = {~0u, 0u};
+    HIPCHK(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kg_tonemap_minmax, dim3((total + BLK - 1) / BLK), dim3(BLK), 0, st, cells, src, total);
+    hipLaunchKernelGGL(kg_tonemap_linear, dim3((numPixels + BLK - 1) / BLK), dim3(BLK), 0, st, out, src, cells, numPixels, numComponents, scaleMin, scaleMax, hasNegative);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFreeAsync(cells, st));
+    return GDPT_OK;
+}
+// Backend::allocTimer / freeTimer / beginTimer / endTimer (Backend.hpp:95-98; BackendCUDA.cu: cudaEvent pairs): device time of the work between
+// begin and end on `stream`, in seconds -- a host clock around asynchronous launches would time the enqueue
+struct gdpt_backend_timer { hipEvent_t e0, e1; };
+gdpt_backend_timer *gdpt_backend_timer_alloc(void)
+{
+    if (ensure_device(-1)) return nullptr;
+    gdpt_backend_timer *t = new gdpt_backend_timer;
+    if (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) { delete t; fail(GDPT_ERR_HIP, "timer_alloc: hipEventCreate failed"); return nullptr; }
+    return t;
+}
+void gdpt_backend_timer_free(gdpt_backend_timer *t) { if (t) { hipEventDestroy(t->e0); hipEventDestroy(t->e1); delete t; } }
+int gdpt_backend_timer_begin(gdpt_backend_timer *t, void *stream)
+{
+    if (!t) return fail(GDPT_ERR_INVALID, "timer_begin: null timer");
+    HIPCHK(hipEventRecord(t->e0, (hipStream_t)stream));
+    return GDPT_OK;
+}
+int gdpt_backend_timer_end(gdpt_backend_timer *t, void *stream, float *seconds)
+{
+    if (!t || !seconds) return fail(GDPT_ERR_INVALID, "timer_end: null argument");
+    HIPCHK(hipEventRecord(t->e1, (hipStream_t)stream));
+    HIPCHK(hipEventSynchronize(t->e1));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, t->e0, t->e1));
+    *seconds = ms * 1e-3f;
+    return GDPT_OK;
+}
+
 void *gdpt_backend_alloc(size_t bytes)
 {
     void *p = nullptr;

@@ -650,4 +650,49 @@ __global__ __launch_bounds__(BLK) void kf_xp_Ax(float4 *__restrict__ Ax4, float4
     if (t == 0) part_pAp[blockIdx.x] = make_float4(acc[0], acc[1], acc[2], 0.0f);
 }
 
+// ---- Backend::tonemapSRGB / tonemapLinear (Backend.cpp:442-507; the CUDA backend's kernels: BackendCUDA.cu:564-660): the display path of
+// poisson::Solver (an ABGR_8888 image of the iterate after every solve, Solver.cpp:506) ------------------------------------------------
+__device__ __forceinline__ unsigned pack_abgr(float x, float y, float z)
+{
+    return 0xFF000000u | ((unsigned)(int)fminf(fmaxf(x * 255.0f + 0.5f, 0.0f), 255.0f) << 0) | ((unsigned)(int)fminf(fmaxf(y * 255.0f + 0.5f, 0.0f), 255.0f) << 8) |
+           ((unsigned)(int)fminf(fmaxf(z * 255.0f + 0.5f, 0.0f), 255.0f) << 16);
+}
+__global__ void kg_tonemap_srgb(unsigned *__restrict__ out, const float *__restrict__ in, int numPixels, float scale, float bias)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numPixels) return;
+    float c[3];
+    for (int k = 0; k < 3; k++) {
+        float t = in[3 * (size_t)i + k];
+        t = t * scale + bias;
+        c[k] = (t <= 0.0031308f) ? 12.92f * t : 1.055f * powf(t, 1.0f / 2.4f) - 0.055f;        // linear to sRGB
+    }
+    out[i] = pack_abgr(c[0], c[1], c[2]);
+}
+// pass A: min / max over all components (order-preserving integer keys, integer atomics); pass B: scale, bias, |.|, pack
+__global__ void kg_tonemap_minmax(unsigned *__restrict__ minmax, const float *__restrict__ in, int total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+    if (i < total) lo = hi = in[i];
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a ^= (unsigned)(((int)a >> 31) | 0x80000000u); b ^= (unsigned)(((int)b >> 31) | 0x80000000u);
+    a = __builtin_amdgcn_wave_reduce_umin(a, 0); b = __builtin_amdgcn_wave_reduce_umax(b, 0);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&minmax[0], a); atomicMax(&minmax[1], b); }
+}
+__global__ void kg_tonemap_linear(unsigned *__restrict__ out, const float *__restrict__ in, const unsigned *__restrict__ minmax, int numPixels, int numComponents, float scaleMin, float scaleMax, int hasNegative)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numPixels) return;
+    unsigned a = minmax[0], b = minmax[1];
+    a ^= (a & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu; b ^= (b & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu;
+    const float inMin = __uint_as_float(a), inMax = __uint_as_float(b);
+    const float FMIN = 1.175494351e-38f;
+    const float scale = fminf(fmaxf(hasNegative ? 0.5f / fmaxf(fmaxf(-inMin, inMax), FMIN) : 1.0f / fmaxf(inMax, FMIN), scaleMin), scaleMax);
+    const float bias = hasNegative ? 0.5f : 0.0f;
+    float c[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 3; k++) c[k] = (k < numComponents) ? fabsf(in[(size_t)i * numComponents + k] * scale + bias) : c[k - 1];
+    out[i] = pack_abgr(c[0], c[1], c[2]);
+}
+
 } // namespace gdpt

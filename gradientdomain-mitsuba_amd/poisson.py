@@ -295,6 +295,35 @@ class Backend:
     def calc_w2(self, w2, e, reg, numElems):
         check(self.L.gdpt_backend_calc_w2(self._f(w2), self._f(e), C.c_float(reg), numElems, self.stream))
 
+    def tonemapSRGB(self, out, x, idx, numPixels, scale, bias):
+        """Backend::tonemapSRGB (Backend.cpp:442-468): `out` = numPixels ABGR_8888 words (a device address from allocVector)."""
+        check(self.L.gdpt_backend_tonemap_srgb(C.c_void_p(out), self._f(x), int(idx), int(numPixels), C.c_float(scale), C.c_float(bias), self.stream))
+
+    def tonemapLinear(self, out, x, idx, numPixels, numComponents, scaleMin, scaleMax, hasNegative):
+        check(self.L.gdpt_backend_tonemap_linear(C.c_void_p(out), self._f(x), int(idx), int(numPixels), int(numComponents), C.c_float(scaleMin), C.c_float(scaleMax),
+                                                 int(bool(hasNegative)), self.stream))
+
+    def download_u32(self, p, n):
+        out = np.empty(n, np.uint32)
+        check(self.L.gdpt_backend_read(out.ctypes.data_as(C.c_void_p), C.c_void_p(p), n * 4, self.stream))
+        return out
+
+    def allocTimer(self):
+        self.L.gdpt_backend_timer_alloc.restype = C.c_void_p
+        return self.L.gdpt_backend_timer_alloc()
+
+    def freeTimer(self, t):
+        self.L.gdpt_backend_timer_free(C.c_void_p(t))
+
+    def beginTimer(self, t):
+        check(self.L.gdpt_backend_timer_begin(C.c_void_p(t), self.stream))
+
+    def endTimer(self, t):
+        """Seconds of device time between beginTimer and endTimer on the backend's stream (Backend.hpp:97-98)."""
+        s = C.c_float(0)
+        check(self.L.gdpt_backend_timer_end(C.c_void_p(t), self.stream, C.byref(s)))
+        return float(s.value)
+
     def close(self):
         for p in self._owned:
             self.L.gdpt_backend_free(C.c_void_p(p))

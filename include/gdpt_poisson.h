@@ -151,6 +151,15 @@ GDPT_API int   gdpt_backend_calc_r_rz(float *r, float *rz, const float *Ap, cons
 GDPT_API int   gdpt_backend_calc_x_p(float *x, float *p, const float *r, const float *rz, const float *rz2, const float *pAp, int numElems, void *stream); /* :319 */
 GDPT_API int   gdpt_backend_calc_w2(float *w2, const float *e, float reg, int numElems, void *stream);                           /* :354 */
 GDPT_API int   gdpt_backend_calc_MIx(float *MIx, int w, int h, float alpha, const float *w2, const float *x, void *stream);      /* :387 */
+/* Backend::tonemapSRGB / tonemapLinear (Backend.cpp:442-507, BackendCUDA.cu:564-660): ABGR_8888 display images of a device vector */
+GDPT_API int   gdpt_backend_tonemap_srgb(unsigned *out, const float *in, int idx, int numPixels, float scale, float bias, void *stream);
+GDPT_API int   gdpt_backend_tonemap_linear(unsigned *out, const float *in, int idx, int numPixels, int numComponents, float scaleMin, float scaleMax, int hasNegative, void *stream);
+/* Backend::allocTimer / freeTimer / beginTimer / endTimer (Backend.hpp:95-98): seconds of DEVICE time between begin and end on `stream` */
+typedef struct gdpt_backend_timer gdpt_backend_timer;
+GDPT_API gdpt_backend_timer *gdpt_backend_timer_alloc(void);
+GDPT_API void  gdpt_backend_timer_free(gdpt_backend_timer *t);
+GDPT_API int   gdpt_backend_timer_begin(gdpt_backend_timer *t, void *stream);
+GDPT_API int   gdpt_backend_timer_end(gdpt_backend_timer *t, void *stream, float *seconds);
 GDPT_API int   gdpt_backend_sync(void *stream);
 
 #ifdef __cplusplus

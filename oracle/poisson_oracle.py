@@ -188,3 +188,29 @@ def gbdpt_reconstruct(primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y, w,
     for name in ("L2D", "L1D"):
         out.append(solve(preset(name, alpha), dxf, dyf, imgf, None, w, h))
     return out[0], out[1]
+
+
+def tonemap_srgb(x, idx, num_pixels, scale, bias):
+    """Backend::tonemapSRGB (/root/reference/src/integrators/poisson_solver/Backend.cpp:442-468) in numpy fp32: ABGR_8888 words of
+    sRGB(in[i + idx * numPixels] * scale + bias).  Test infrastructure (checker of gdpt_backend_tonemap_srgb)."""
+    c = np.asarray(x, np.float32).reshape(-1, 3)[idx * num_pixels:(idx + 1) * num_pixels]
+    t = c * np.float32(scale) + np.float32(bias)
+    with np.errstate(invalid="ignore"):
+        s = np.where(t <= np.float32(0.0031308), np.float32(12.92) * t, np.float32(1.055) * np.power(np.maximum(t, 0), np.float32(1.0 / 2.4), dtype=np.float32) - np.float32(0.055)).astype(np.float32)
+    q = np.minimum(np.maximum(s * np.float32(255.0) + np.float32(0.5), np.float32(0.0)), np.float32(255.0)).astype(np.int64)
+    return (0xFF000000 | q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16)).astype(np.uint32)
+
+
+def tonemap_linear(x, idx, num_pixels, num_components, scale_min, scale_max, has_negative):
+    """Backend::tonemapLinear (Backend.cpp:472-507) in numpy fp32."""
+    total = num_pixels * num_components
+    v = np.asarray(x, np.float32).ravel()[idx * total:(idx + 1) * total]
+    in_min, in_max = np.float32(v.min()), np.float32(v.max())
+    fmin = np.float32(np.finfo(np.float32).tiny)
+    raw = (np.float32(0.5) / max(max(-in_min, in_max), fmin)) if has_negative else (np.float32(1.0) / max(in_max, fmin))
+    scale = np.float32(min(max(raw, np.float32(scale_min)), np.float32(scale_max)))
+    bias = np.float32(0.5 if has_negative else 0.0)
+    comp = np.abs(v.reshape(num_pixels, num_components) * scale + bias).astype(np.float32)
+    col = np.stack([comp[:, min(k, num_components - 1)] for k in range(3)], axis=1)
+    q = np.minimum(np.maximum(col * np.float32(255.0) + np.float32(0.5), np.float32(0.0)), np.float32(255.0)).astype(np.int64)
+    return (0xFF000000 | q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16)).astype(np.uint32)

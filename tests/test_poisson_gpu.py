@@ -397,3 +397,36 @@ def test_gbdpt_reconstruction_stage_1280x720_config5(P):
     assert err(l2) < 0.5 * err(primal) and err(l1) < 0.5 * err(primal)                # the stage does what it is for
     only2, none1 = P.gbdpt_reconstruct(*bufs, w, h, alpha=0.2, l1=False)
     assert none1 is None and np.array_equal(only2, l2)
+
+
+def test_tonemap_and_timer_backend_ops(P):
+    """Backend::tonemapSRGB / tonemapLinear (Backend.cpp:442-507) and the timer virtuals (Backend.hpp:95-98) at the backend-op level of the ABI:
+    what `BackendHIP` overrides so that poisson::Solver's display image and its logged execution time come from the device."""
+    rng = np.random.default_rng(9)
+    B = P.Backend()
+    for (n, comps) in ((1, 3), (2, 3), (777, 3), (64 * 48, 3), (500, 1), (123, 2)):
+        x = (rng.standard_normal((2, n, comps)) * np.array([0.3, 1.0, 4.0])[:comps]).astype(np.float32)
+        x[0, 0] = 0.0
+        dx = B.upload(x.ravel())
+        out = B.allocVector(max(n, 2), 4)
+        if comps == 3:
+            for idx, scale, bias in ((0, 1.0, 0.0), (1, 0.7, 0.1)):
+                B.tonemapSRGB(out, dx, idx, n, scale, bias)
+                got, ref = B.download_u32(out, n), po.tonemap_srgb(x, idx, n, scale, bias)
+                d = np.abs(((got[:, None] >> np.array([0, 8, 16])) & 255).astype(int) - ((ref[:, None] >> np.array([0, 8, 16])) & 255).astype(int))
+                assert (got >> 24 == 255).all() and d.max() <= 1 and (d == 0).mean() > 0.99          # powf: ocml vs numpy, last-bit rounding of a byte
+        if n >= 2:
+            for idx, neg in ((0, True), (1, False)):
+                B.tonemapLinear(out, dx, idx, n, comps, 0.0, 3.0e38, neg)
+                got, ref = B.download_u32(out, n), po.tonemap_linear(x, idx, n, comps, 0.0, 3.0e38, neg)
+                assert np.array_equal(got, ref), (n, comps, idx, neg)
+    t = B.allocTimer()
+    w, h = 1280, 720
+    a = B.upload(np.ones(3 * w * h, np.float32)); o = B.allocVector(9 * w * h, 4)
+    B.beginTimer(t)
+    for _ in range(20):
+        B.calc_Px(o, w, h, 0.2, a)
+    dt = B.endTimer(t)
+    assert 1e-5 < dt < 0.5                                                   # device seconds of 20 launches, not the microseconds their enqueue takes
+    B.freeTimer(t)
+    B.close()
