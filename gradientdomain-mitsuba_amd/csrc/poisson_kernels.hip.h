@@ -677,7 +677,7 @@ __global__ void kg_tonemap_minmax(unsigned *__restrict__ minmax, const float *__
     if (i < total) lo = hi = in[i];
     unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
     a ^= (unsigned)(((int)a >> 31) | 0x80000000u); b ^= (unsigned)(((int)b >> 31) | 0x80000000u);
-    a = __builtin_amdgcn_wave_reduce_umin(a, 0); b = __builtin_amdgcn_wave_reduce_umax(b, 0);
+    a = __builtin_amdgcn_wave_reduce_min_u32(a, 0); b = __builtin_amdgcn_wave_reduce_max_u32(b, 0);
     if ((threadIdx.x & 63) == 0) { atomicMin(&minmax[0], a); atomicMax(&minmax[1], b); }
 }
 __global__ void kg_tonemap_linear(unsigned *__restrict__ out, const float *__restrict__ in, const unsigned *__restrict__ minmax, int numPixels, int numComponents, float scaleMin, float scaleMax, int hasNegative)

@@ -1,0 +1,188 @@
+// tests/mitsuba_mock/mock_mitsuba.h -- COMPILE-ONLY HARNESS, written for this repository (no Mitsuba source is copied): the minimal declarations of
+// the Mitsuba 0.5 symbols that host/mitsuba_plugin/{gpt_hip.cpp,gbdpt_hip.cpp} use, with the signatures the reference's headers give them, so that
+// the drop-in sources at least parse, type-check and link against lib/libgdpt_hip.so in CI (tests/test_plugin_sources.py).  Nothing here
+// computes anything; it is not a Mitsuba build and pins no behaviour.  Signatures follow (paths relative to /root/reference/include/mitsuba):
+//   core/object.h, core/cobject.h (ConfigurableObject, MTS_EXPORT_PLUGIN), core/properties.h, core/logger.h (Log / SLog), core/spectrum.h,
+//   core/transform.h, core/bitmap.h, core/rfilter.h, core/sched.h, render/integrator.h (:61-118), render/scene.h, render/sensor.h,
+//   render/film.h (:62-79 the Multi* virtuals), render/trimesh.h, render/emitter.h, render/bsdf.h, render/texture.h, render/sampler.h.
+#pragma once
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define MTS_NAMESPACE_BEGIN namespace mitsuba {
+#define MTS_NAMESPACE_END }
+#define MTS_DECLARE_CLASS() virtual const Class *getClass() const;
+#define MTS_IMPLEMENT_CLASS_S(name, abstract, super) const Class *name::getClass() const { static Class c(#name); return &c; }
+#define MTS_EXPORT_PLUGIN(name, descr) extern "C" { void *CreateInstance(const Properties &props) { return new name(props); } const char *GetDescription() { return descr; } }
+
+MTS_NAMESPACE_BEGIN
+typedef double Float;                                   // the reference's DOUBLE_PRECISION build
+enum ELogLevel { EDebug, EInfo, EWarn, EError };
+inline void mockLog(ELogLevel lvl, const char *fmt, ...)
+{
+    char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (lvl == EError) throw std::runtime_error(buf);     // logger.cpp:147
+    fprintf(stderr, "%s\n", buf);
+}
+#define Log(level, ...) ::mitsuba::mockLog(level, __VA_ARGS__)
+#define SLog(level, ...) ::mitsuba::mockLog(level, __VA_ARGS__)
+
+class Class { public: explicit Class(const char *n) : m_name(n) {} const std::string &getName() const { return m_name; } private: std::string m_name; };
+class Object { public: virtual ~Object() {} virtual const Class *getClass() const = 0; void incRef() const {} void decRef() const {} };
+template <class T> class ref {
+public:
+    ref(T *p = nullptr) : m_p(p) {}
+    T *operator->() const { return m_p; }
+    T *get() const { return m_p; }
+    operator T *() const { return m_p; }
+private:
+    T *m_p;
+};
+template <class T> class ref_vector : public std::vector<ref<T> > {};
+
+struct Vector { Float x, y, z; Vector(Float a = 0, Float b = 0, Float c = 0) : x(a), y(b), z(c) {} };
+struct Point { Float x, y, z; Point(Float a = 0, Float b = 0, Float c = 0) : x(a), y(b), z(c) {} };
+inline Point operator+(Point p, Vector v) { return Point(p.x + v.x, p.y + v.y, p.z + v.z); }
+struct Normal { Float x, y, z; Normal(Float a = 0, Float b = 0, Float c = 0) : x(a), y(b), z(c) {} };
+struct Point2 { Float x, y; Point2(Float a = 0, Float b = 0) : x(a), y(b) {} };
+struct Vector2i { int x, y; Vector2i(int a = 0, int b = 0) : x(a), y(b) {} };
+struct Frame { Vector s, t; Normal n; Frame() {} explicit Frame(const Normal &nn) : n(nn) {} };
+struct Matrix4x4 { Float m[4][4]; Float operator()(int r, int c) const { return m[r][c]; } };
+class Transform { public: const Matrix4x4 &getMatrix() const { return m_m; } Point operator()(const Point &p) const { return p; } Vector operator()(const Vector &v) const { return v; } private: Matrix4x4 m_m; };
+class AnimatedTransform { public: const Transform &eval(Float) const { return m_t; } private: Transform m_t; };
+class Spectrum { public: Spectrum(Float v = 0) { c[0] = c[1] = c[2] = v; } void toLinearRGB(Float &r, Float &g, Float &b) const { r = c[0]; g = c[1]; b = c[2]; } Float c[3]; };
+struct Triangle { uint32_t idx[3]; };
+struct RayDifferential { RayDifferential(const Point &, const Vector &, Float) {} };
+
+class Properties {
+public:
+    explicit Properties(const std::string &plugin = "") : m_plugin(plugin) {}
+    const std::string &getPluginName() const { return m_plugin; }
+    bool hasProperty(const std::string &) const { return false; }
+    int getInteger(const std::string &, int def) const { return def; }
+    Float getFloat(const std::string &, Float def) const { return def; }
+    Float getFloat(const std::string &) const { return 0; }
+    bool getBoolean(const std::string &, bool def) const { return def; }
+    std::string getString(const std::string &, const std::string &def) const { return def; }
+    Spectrum getSpectrum(const std::string &, const Spectrum &def) const { return def; }
+    Spectrum getSpectrum(const std::string &) const { return Spectrum(); }
+private:
+    std::string m_plugin;
+};
+class Stream; class InstanceManager; class RenderQueue; class RenderJob;
+class ConfigurableObject : public Object {
+public:
+    ConfigurableObject() {}
+    explicit ConfigurableObject(const Properties &p) : m_properties(p) {}
+    const Properties &getProperties() const { return m_properties; }                    // cobject.h
+    virtual void serialize(Stream *, InstanceManager *) const {}
+protected:
+    Properties m_properties;
+};
+
+class Bitmap : public Object {
+public:
+    enum EPixelFormat { ELuminance, ERGB, ESpectrum };
+    enum EComponentFormat { EUInt8, EFloat16, EFloat32, EFloat64, EFloat = EFloat64 };
+    Bitmap(EPixelFormat, EComponentFormat, const Vector2i &size) : m_size(size), m_data((size_t)size.x * size.y * 3 * 8) {}
+    const Vector2i &getSize() const { return m_size; }
+    int getWidth() const { return m_size.x; }
+    int getHeight() const { return m_size.y; }
+    float *getFloat32Data() { return reinterpret_cast<float *>(m_data.data()); }
+    double *getFloat64Data() { return reinterpret_cast<double *>(m_data.data()); }
+    Float *getFloatData() { return reinterpret_cast<Float *>(m_data.data()); }
+    ref<Bitmap> convert(EPixelFormat pf, EComponentFormat cf, Float gamma = 1.0) const { (void)gamma; return new Bitmap(pf, cf, m_size); }   // bitmap.h convert(pixelFormat, componentFormat, gamma, ...)
+    const Class *getClass() const { static Class c("Bitmap"); return &c; }
+private:
+    Vector2i m_size; std::vector<char> m_data;
+};
+
+class ReconstructionFilter : public ConfigurableObject { public: Float getRadius() const { return 0.5; } const Class *getClass() const { static Class c("BoxFilter"); return &c; } };
+class Film : public ConfigurableObject {
+public:
+    const Vector2i &getCropSize() const { return m_size; }
+    const ReconstructionFilter *getReconstructionFilter() const { return &m_rf; }
+    virtual bool setBuffers(const std::vector<std::string> &) { return true; }                                   // film.h:62-79
+    virtual void setBitmapMulti(const Bitmap *, Float, int) {}
+    const Class *getClass() const { static Class c("MultiFilm"); return &c; }
+private:
+    Vector2i m_size; ReconstructionFilter m_rf;
+};
+class Sampler : public ConfigurableObject { public: size_t getSampleCount() const { return 4; } const Class *getClass() const { static Class c("IndependentSampler"); return &c; } };
+class Sensor : public ConfigurableObject {
+public:
+    Film *getFilm() { return &m_film; }
+    const AnimatedTransform *getWorldTransform() const { return &m_t; }
+    const Class *getClass() const { static Class c("PerspectiveCamera"); return &c; }
+private:
+    Film m_film; AnimatedTransform m_t;
+};
+class PerspectiveCamera : public Sensor { public: Float getXFov() const { return 40; } Float getNearClip() const { return 0.01; } Float getFarClip() const { return 1e4; } };
+
+struct Intersection { Frame shFrame, geoFrame; Point2 uv; };
+struct DirectSamplingRecord { DirectSamplingRecord(const Point &, Float) {} };
+class Texture : public ConfigurableObject {
+public:
+    virtual ref<Bitmap> getBitmap(const Vector2i &resolutionHint = Vector2i(-1, -1)) const { (void)resolutionHint; return new Bitmap(Bitmap::ERGB, Bitmap::EFloat64, Vector2i(1, 1)); }   // texture.h
+    virtual bool isConstant() const { return true; }
+    const Class *getClass() const { static Class c("ConstantSpectrumTexture"); return &c; }
+};
+class BSDF : public ConfigurableObject {
+public:
+    virtual Spectrum getDiffuseReflectance(const Intersection &) const { return Spectrum(0.5); }       // bsdf.h
+    virtual Spectrum getSpecularReflectance(const Intersection &) const { return Spectrum(1.0); }
+    const Class *getClass() const { static Class c("SmoothDiffuse"); return &c; }
+};
+class Emitter : public ConfigurableObject {
+public:
+    virtual Spectrum eval(const Intersection &, const Vector &) const { return Spectrum(1); }
+    virtual Spectrum evalEnvironment(const RayDifferential &) const { return Spectrum(1); }
+    virtual Spectrum sampleDirect(DirectSamplingRecord &, const Point2 &) const { return Spectrum(1); }
+    virtual ref<Bitmap> getBitmap(const Vector2i &sizeHint = Vector2i(-1, -1)) const { (void)sizeHint; return new Bitmap(Bitmap::ERGB, Bitmap::EFloat64, Vector2i(2, 1)); }   // emitter.h: the environment map's bitmap
+    const AnimatedTransform *getWorldTransform() const { return &m_t; }
+    const Class *getClass() const { static Class c("AreaLight"); return &c; }
+private:
+    AnimatedTransform m_t;
+};
+class Shape : public ConfigurableObject { public: const BSDF *getBSDF() const { return &m_bsdf; } bool isEmitter() const { return false; } const Emitter *getEmitter() const { return &m_em; } const Class *getClass() const { static Class c("Shape"); return &c; } protected: BSDF m_bsdf; Emitter m_em; };
+class TriMesh : public Shape {
+public:
+    const Point *getVertexPositions() const { return nullptr; }
+    const Normal *getVertexNormals() const { return nullptr; }
+    const Point2 *getVertexTexcoords() const { return nullptr; }
+    const Triangle *getTriangles() const { return nullptr; }
+    size_t getTriangleCount() const { return 0; }
+};
+class Scene : public ConfigurableObject {
+public:
+    Sensor *getSensor() { return &m_sensor; }
+    const std::vector<TriMesh *> &getMeshes() const { return m_meshes; }
+    const ref_vector<Emitter> &getEmitters() const { return m_emitters; }
+    const Class *getClass() const { static Class c("Scene"); return &c; }
+private:
+    PerspectiveCamera m_sensor; std::vector<TriMesh *> m_meshes; ref_vector<Emitter> m_emitters;
+};
+class Scheduler : public Object {
+public:
+    static Scheduler *getInstance() { static Scheduler s; return &s; }
+    ConfigurableObject *getResource(int, int = -1) { static Sampler smp; return &smp; }
+    const Class *getClass() const { static Class c("Scheduler"); return &c; }
+};
+class Integrator : public ConfigurableObject {                                            // render/integrator.h:61-118
+public:
+    explicit Integrator(const Properties &p) : ConfigurableObject(p) {}
+    Integrator(Stream *, InstanceManager *) {}
+    virtual bool preprocess(const Scene *, RenderQueue *, const RenderJob *, int, int, int) { return true; }
+    virtual bool render(Scene *, RenderQueue *, const RenderJob *, int, int, int) = 0;
+    virtual void cancel() = 0;
+    virtual void postprocess(const Scene *, RenderQueue *, const RenderJob *, int, int, int) {}
+    virtual void serialize(Stream *, InstanceManager *) const {}
+    virtual std::string toString() const { return "Integrator[]"; }
+};
+MTS_NAMESPACE_END
