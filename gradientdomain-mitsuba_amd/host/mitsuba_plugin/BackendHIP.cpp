@@ -34,3 +34,18 @@ void  BackendHIP::calc_r_rz(Vector* r, Vector* rz, Vector* Ap, Vector* rz2, Vect
 void  BackendHIP::calc_x_p(Vector* x, Vector* p, Vector* r, Vector* rz, Vector* rz2, Vector* pAp) { ok(gdpt_backend_calc_x_p(F(x), F(p), F(r), F(rz), F(rz2), F(pAp), x->numElems, 0)); }
 void  BackendHIP::calc_w2(Vector* w2, Vector* e, float reg) { ok(gdpt_backend_calc_w2(F(w2), F(e), reg, w2->numElems, 0)); }
 void  BackendHIP::calc_MIx(Vector* o, PoissonMatrix P, Vector* w2, Vector* x) { ok(gdpt_backend_calc_MIx(F(o), P.size.x, P.size.y, P.alpha, F(w2), F(x), 0)); }
+
+// Backend.cpp:442-507 (the display path of the solver's debug output, Solver.cpp:516-560), on the device: `in` holds a stack of images of out->numElems pixels each, `idx`
+// picks one; `out` gets one packed ABGR word per pixel.
+void  BackendHIP::tonemapSRGB(Vector* out, Vector* in, int idx, float scale, float bias) { ok(gdpt_backend_tonemap_srgb((unsigned*)out->ptr, F(in), idx, out->numElems, scale, bias, 0)); }
+void  BackendHIP::tonemapLinear(Vector* out, Vector* in, int idx, float scaleMin, float scaleMax, bool hasNegative)
+{
+    ok(gdpt_backend_tonemap_linear((unsigned*)out->ptr, F(in), idx, out->numElems, (int)(in->bytesPerElem / sizeof(float)), scaleMin, scaleMax, hasNegative ? 1 : 0, 0));
+}
+
+// BackendCUDA.cu:672-722: a pair of events; endTimer returns the seconds of DEVICE time between them (the base class measures host ticks)
+struct TimerHIP : public Backend::Timer { gdpt_backend_timer* t; };
+Backend::Timer* BackendHIP::allocTimer(void) { TimerHIP* t = new TimerHIP; t->beginTicks = 0; t->t = gdpt_backend_timer_alloc(); if (!t->t) fail("HIP backend: %s", gdpt_last_error()); return t; }
+void  BackendHIP::freeTimer(Timer* timer) { TimerHIP* t = (TimerHIP*)timer; if (t) gdpt_backend_timer_free(t->t); delete t; }
+void  BackendHIP::beginTimer(Timer* timer) { ok(gdpt_backend_timer_begin(((TimerHIP*)timer)->t, 0)); }
+float BackendHIP::endTimer(Timer* timer) { float s = 0.0f; ok(gdpt_backend_timer_end(((TimerHIP*)timer)->t, 0, &s)); return s; }

@@ -27,5 +27,11 @@ public:
     virtual void    calc_x_p(Vector* x, Vector* p, Vector* r, Vector* rz, Vector* rz2, Vector* pAp);
     virtual void    calc_w2(Vector* w2, Vector* e, float reg);
     virtual void    calc_MIx(Vector* MIx, PoissonMatrix P, Vector* w2, Vector* x);
+    virtual void    tonemapSRGB(Vector* out, Vector* in, int idx, float scale, float bias);
+    virtual void    tonemapLinear(Vector* out, Vector* in, int idx, float scaleMin, float scaleMax, bool hasNegative);
+    virtual Timer*  allocTimer(void);
+    virtual void    freeTimer(Timer* timer);
+    virtual void    beginTimer(Timer* timer);
+    virtual float   endTimer(Timer* timer);
 };
 }

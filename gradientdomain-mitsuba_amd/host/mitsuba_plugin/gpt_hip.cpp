@@ -5,15 +5,20 @@
 // cited inline).  It cannot be compiled in this repository's image (no boost / Xerces / OpenEXR), so it ships as a source for the
 // maintainer; every library call below is exercised by this repository's tests through the same C-ABI.
 //
-// What is carried is the scene subset of include/gdpt_tracer.h: triangle meshes; diffuse / conductor / roughconductor / dielectric
-// BSDFs (optionally `twosided`, optionally with a `bitmap` texture on the reflectance, filterType nearest | bilinear); area, point and
-// constant emitters; a perspective sensor; independent sampler semantics (counter-based streams); any of the six
-// reconstruction filters.  Anything else is refused by the library with a message -- never rendered approximately.
+// What is carried is the scene subset of include/gdpt_tracer.h, flattened by gdpt_mitsuba_scene.h: triangle meshes and `rectangle` shapes; diffuse /
+// conductor / roughconductor / dielectric BSDFs (optionally `twosided`, optionally with a `bitmap` texture on the reflectance); area, point,
+// constant and envmap emitters; a perspective sensor; independent sampler semantics (counter-based streams); any of the six
+// reconstruction filters.  Anything else is refused with a message -- never rendered approximately.  `devices` > 1 shards the frame over
+// the GPUs of the node in row strips (one thread per GPU, borders exchanged over xGMI), as host/gdpt_host.hpp does.
+// tests/test_plugin_sources.py compiles this file against compile-only mock headers (tests/mitsuba_mock) and links it with the library.
 #include <mitsuba/render/scene.h>
 #include <mitsuba/render/renderjob.h>
 #include <mitsuba/core/plugin.h>
 #include <mitsuba/core/bitmap.h>
+#include <thread>
 #include "gdpt_tracer.h"
+#include "gdpt_poisson.h"
+#include "gdpt_mitsuba_scene.h"
 
 MTS_NAMESPACE_BEGIN
 
@@ -55,103 +60,37 @@ public:
 		const Vector2i size = film->getCropSize();
 		const int W = size.x, H = size.y;
 
-		/* ---- flatten the scene (scene.h: getMeshes(); trimesh.h accessors) ---- */
-		std::vector<double> verts, normals, uvs;
-		std::vector<unsigned char> hasUV;
-		std::vector<int> triMat;
-		std::vector<gdpt_material> mats;
-		std::vector<int> matTex;
-		std::vector<gdpt_texture> texs;
-		std::vector<std::vector<double> > texels;
-		std::vector<gdpt_emitter> ems;
-		bool anyNormals = false, anyUV = false;
-		const std::vector<TriMesh *> &meshes = scene->getMeshes();
-		for (size_t m = 0; m < meshes.size(); ++m) {
-			const TriMesh *mesh = meshes[m];
-			const int first = (int) triMat.size();
-			const int mat = addMaterial(mesh->getBSDF(), mats, matTex, texs, texels);
-			const Point *P = mesh->getVertexPositions();
-			const Normal *N = mesh->getVertexNormals();
-			const Point2 *T = mesh->getVertexTexcoords();
-			const Triangle *tri = mesh->getTriangles();
-			for (size_t t = 0; t < mesh->getTriangleCount(); ++t) {
-				for (int k = 0; k < 3; ++k) {
-					const uint32_t i = tri[t].idx[k];
-					verts.push_back(P[i].x); verts.push_back(P[i].y); verts.push_back(P[i].z);
-					normals.push_back(N ? N[i].x : 0); normals.push_back(N ? N[i].y : 0); normals.push_back(N ? N[i].z : 0);
-					uvs.push_back(T ? T[i].x : 0); uvs.push_back(T ? T[i].y : 0);
-				}
-				hasUV.push_back(T ? 1 : 0);
-				triMat.push_back(mat);
-			}
-			anyNormals |= N != NULL; anyUV |= T != NULL;
-			if (mesh->isEmitter()) {
-				/* AreaLight::m_radiance (area.cpp:71): what eval() returns for a front-facing direction */
-				Intersection its; its.shFrame = its.geoFrame = Frame(Normal(0, 0, 1));
-				const Spectrum Le = mesh->getEmitter()->eval(its, Vector(0, 0, 1));
-				gdpt_emitter e; memset(&e, 0, sizeof e);
-				e.firstTri = first; e.numTris = (int) triMat.size() - first;
-				Float r, g, b; Le.toLinearRGB(r, g, b);
-				e.radiance[0] = r; e.radiance[1] = g; e.radiance[2] = b;
-				ems.push_back(e);
-			}
-		}
-		/* point and constant emitters, in the scene's emitter order (scene.cpp:855-862 selects by it) */
-		gdpt_environment env; bool haveEnv = false;
-		memset(&env, 0, sizeof env);
-		const ref_vector<Emitter> &emitters = scene->getEmitters();
-		for (size_t i = 0; i < emitters.size(); ++i) {
-			const Emitter *em = emitters[i].get();
-			const std::string cls = em->getClass()->getName();
-			if (cls == "ConstantBackgroundEmitter") {
-				const Spectrum Le = em->evalEnvironment(RayDifferential(Point(0.0f), Vector(0, 0, 1), 0));
-				Float r, g, b; Le.toLinearRGB(r, g, b);
-				env.radiance[0] = r; env.radiance[1] = g; env.radiance[2] = b; env.index = (int) i; haveEnv = true;
-			} else if (cls == "PointEmitter") {
-				gdpt_emitter e; memset(&e, 0, sizeof e);
-				e.numTris = -1;
-				const Point p = em->getWorldTransform()->eval(0)(Point(0.0f));
-				e.position[0] = p.x; e.position[1] = p.y; e.position[2] = p.z;
-				/* PointEmitter::m_intensity: sampleDirect returns intensity / dist^2 (point.cpp:120-134) */
-				DirectSamplingRecord dRec(p + Vector(0, 0, 1), 0);
-				const Spectrum I = em->sampleDirect(dRec, Point2(0.5f));
-				Float r, g, b; I.toLinearRGB(r, g, b);
-				e.radiance[0] = r; e.radiance[1] = g; e.radiance[2] = b;
-				ems.insert(ems.begin() + std::min(i, ems.size()), e);
-			} else if (cls != "AreaLight")
-				Log(EError, "gpt_hip: emitter \"%s\" is not carried (area, point, constant)", cls.c_str());
-		}
-		gdpt_camera cam;
-		{
-			const PerspectiveCamera *pc = static_cast<const PerspectiveCamera *>(sensor.get());
-			const Matrix4x4 &M = pc->getWorldTransform()->eval(0).getMatrix();
-			for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) cam.toWorld[4 * r + c] = M(r, c);
-			cam.fovX = pc->getXFov(); cam.nearClip = pc->getNearClip(); cam.farClip = pc->getFarClip();
-			cam.width = W; cam.height = H;
-		}
-		gdpt_scene *gs = NULL;
-		check(gdpt_scene_create_tex((int) triMat.size(), verts.data(), anyNormals ? normals.data() : NULL, anyUV ? uvs.data() : NULL,
-				anyUV ? hasUV.data() : NULL, triMat.data(), (int) mats.size(), mats.data(), texs.empty() ? NULL : matTex.data(),
-				(int) texs.size(), texs.empty() ? NULL : texs.data(), (int) ems.size(), ems.data(), haveEnv ? &env : NULL, &cam, -1, &gs));
-		check(gdpt_film_create(gs, 0, H, &m_film));
-		setFilter(film->getReconstructionFilter());
+		gdpt_plugin::FlatScene fs;
+		gdpt_plugin::flatten(scene, sensor.get(), size, fs);
+		int kind; double p0, p1;
+		gdpt_plugin::rfilterOf(film->getReconstructionFilter(), kind, p0, p1);
 
 		const Sampler *sampler = static_cast<const Sampler *>(Scheduler::getInstance()->getResource(samplerResID, 0));
 		gdpt_config cfg;
 		cfg.maxDepth = m_maxDepth; cfg.rrDepth = m_rrDepth; cfg.strictNormals = m_strictNormals;
 		cfg.spp = (int) sampler->getSampleCount(); cfg.shiftThreshold = m_shiftThreshold; cfg.seed = 5489ull;   /* random.h:113 */
-		Log(EInfo, "Starting render job (GPT::render on MI355X) (%ix%i, %i samples) ..", W, H, cfg.spp);
+		Log(EInfo, "Starting render job (GPT::render on %i MI355X) (%ix%i, %i samples) ..", m_devices, W, H, cfg.spp);
 
-		/* GPTBlockRenderer::process over the whole film in one call (blocks may also be handed over one by one) */
-		check(gdpt_render_rect(gs, &cfg, 0, 0, W, H, m_film));
-		check(gdpt_film_sync(m_film));
-		int cancelled = 0;
-		check(gdpt_film_cancelled(m_film, &cancelled));
-		if (cancelled) { release(gs); return false; }
-
-		/* developMulti + the float casts of gpt.cpp:1419-1442, on the device */
 		std::vector<float> img[5];
-		for (int b = 0; b < 5; ++b) { img[b].resize((size_t) 3 * W * H); check(gdpt_film_develop(m_film, b, img[b].data())); }
+		for (int b = 0; b < 5; ++b) img[b].resize((size_t) 3 * W * H);
+		if (m_devices > 1) {
+			if (!renderStrips(fs, cfg, kind, p0, p1, W, H, img)) return false;
+		} else {
+			/* GPTBlockRenderer::process over the whole film in one call (blocks may also be handed over one by one) */
+			gdpt_scene *gs = gdpt_plugin::upload(fs, -1);
+			check(gdpt_film_create(gs, 0, H, &m_film));
+			check(gdpt_film_set_rfilter(m_film, kind, p0, p1));
+			check(gdpt_render_rect(gs, &cfg, 0, 0, W, H, m_film));
+			check(gdpt_film_sync(m_film));
+			int cancelled = 0;
+			check(gdpt_film_cancelled(m_film, &cancelled));
+			if (!cancelled)
+				for (int b = 0; b < 5; ++b) check(gdpt_film_develop(m_film, b, img[b].data()));
+			release(gs);
+			if (cancelled) return false;
+		}
+
+		/* img[] = developMulti + the float casts of gpt.cpp:1419-1442, done on the device */
 		if (m_reconstructL1 || m_reconstructL2) {      /* gpt.cpp:1445-1462 */
 			gdpt_poisson_params p;
 			gdpt_poisson_params_defaults(&p);
@@ -171,7 +110,6 @@ public:
 			memcpy(bmp->getFloat32Data(), img[b].data(), sizeof(float) * img[b].size());
 			film->setBitmapMulti(bmp, 1, b);
 		}
-		release(gs);
 		return true;
 	}
 
@@ -185,38 +123,65 @@ private:
 	static void check(int rc) { if (rc != GDPT_OK) SLog(EError, "gpt_hip: %s", gdpt_last_error()); }
 	void release(gdpt_scene *gs) { gdpt_film_destroy(m_film); m_film = NULL; gdpt_scene_destroy(gs); }
 
-	void setFilter(const ReconstructionFilter *rf) {
-		const std::string cls = rf->getClass()->getName();
-		/* the filters' own parameters are private members; a maintainer passes them through (defaults shown) */
-		if (cls == "BoxFilter") return;
-		else if (cls == "TentFilter") check(gdpt_film_set_rfilter(m_film, GDPT_RFILTER_TENT, 0, 0));
-		else if (cls == "GaussianFilter") check(gdpt_film_set_rfilter(m_film, GDPT_RFILTER_GAUSSIAN, rf->getRadius() / 4, 0));   /* radius = 4 stddev, gaussian.cpp:38 */
-		else if (cls == "MitchellNetravaliFilter") check(gdpt_film_set_rfilter(m_film, GDPT_RFILTER_MITCHELL, 1.0 / 3.0, 1.0 / 3.0));
-		else if (cls == "CatmullRomFilter") check(gdpt_film_set_rfilter(m_film, GDPT_RFILTER_CATMULLROM, 0, 0));
-		else if (cls == "LanczosSincFilter") check(gdpt_film_set_rfilter(m_film, GDPT_RFILTER_LANCZOS, rf->getRadius(), 0));       /* radius = lobes, lanczos.cpp:35 */
-		else Log(EError, "gpt_hip: reconstruction filter \"%s\" is not carried", cls.c_str());
-	}
-
-	/* BSDF -> gdpt_material.  Mitsuba's BSDF classes keep eta / k / alpha private: the two conductors and the dielectric need the
-	   accessors `getEta()`, `getK()`, `getAlphaU()`, `getAlphaV()`, `getDistributionType()`, `getSampleVisible()` added next to their
-	   members (conductor.cpp, roughconductor.cpp, dielectric.cpp) -- one line each; diffuse works as is. */
-	int addMaterial(const BSDF *bsdf, std::vector<gdpt_material> &mats, std::vector<int> &matTex, std::vector<gdpt_texture> &texs, std::vector<std::vector<double> > &texels) {
-		gdpt_material m; memset(&m, 0, sizeof m);
-		m.sampleVisible = 1; m.alphaU = m.alphaV = 0.1;
-		std::string cls = bsdf->getClass()->getName();
-		if (cls == "TwoSidedBRDF") { m.twoSided = 1; bsdf = static_cast<const BSDF *>(bsdf->getSubObject(0)); cls = bsdf->getClass()->getName(); }   /* a maintainer exposes the nested BRDF */
-		Intersection its;
-		Float r, g, b;
-		if (cls == "SmoothDiffuse") {
-			m.type = GDPT_MAT_DIFFUSE;
-			bsdf->getDiffuseReflectance(its).toLinearRGB(r, g, b);
-			m.reflectance[0] = r; m.reflectance[1] = g; m.reflectance[2] = b;
-		} else
-			Log(EError, "gpt_hip: add the accessors named above to \"%s\" and fill eta / k / alpha here", cls.c_str());
-		/* a `bitmap` texture on the reflectance: Texture::getBitmap() gives level 0; wrap modes / filter type / uv transform need accessors too */
-		mats.push_back(m); matTex.push_back(-1);
-		(void) texs; (void) texels;
-		return (int) mats.size() - 1;
+	/* One thread and one strip film per GPU; border sums exchanged device to device (gdpt_film_pack_halo / unpack_halo over gdpt_device_copy =
+	   a peer DMA over xGMI), every strip develops its own rows.  The reference's counterpart is the block border merged by addition
+	   (gpt_proc.cpp:52-56,137-149).  Same strips and payloads as host/gdpt_host.hpp renderStrips and parallel.StripRenderer. */
+	bool renderStrips(const gdpt_plugin::FlatScene &fs, const gdpt_config &cfg, int kind, double p0, double p1, int W, int H, std::vector<float> img[5]) {
+		int have = 0;
+		check(gdpt_device_count(&have));
+		const int N = m_devices;
+		if (N > have || N > H) Log(EError, "gpt_hip: 'devices' = %i, but the node has %i GPUs and the image %i rows", N, have, H);
+		struct Strip { int y0, y1; gdpt_scene *scene; gdpt_film *film; void *out[2], *in[2]; std::string error; };
+		std::vector<Strip> strips(N);
+		for (int r = 0, y = 0; r < N; ++r) {
+			const int n = H / N + (r < H % N ? 1 : 0);
+			Strip &s = strips[r];
+			s.y0 = y; s.y1 = y + n; y += n; s.scene = NULL; s.film = NULL; s.out[0] = s.out[1] = s.in[0] = s.in[1] = NULL;
+		}
+		std::vector<std::thread> workers;
+		for (int r = 0; r < N; ++r)
+			workers.emplace_back([&, r]() {
+				Strip &s = strips[r];
+				try {
+					s.scene = gdpt_plugin::upload(fs, r);
+					check(gdpt_film_create(s.scene, s.y0, s.y1, &s.film));
+					check(gdpt_film_set_rfilter(s.film, kind, p0, p1));
+					check(gdpt_render_rect(s.scene, &cfg, 0, s.y0, W, s.y1, s.film));
+					check(gdpt_film_sync(s.film));
+				} catch (const std::exception &e) { s.error = e.what(); }
+			});
+		for (size_t i = 0; i < workers.size(); ++i) workers[i].join();
+		std::string error;
+		for (int r = 0; r < N; ++r) if (!strips[r].error.empty()) error = strips[r].error;
+		if (error.empty() && kind == GDPT_RFILTER_BOX) {     /* wider filters: every strip rendered the filter's reach itself */
+			size_t bytes = 0;
+			check(gdpt_film_halo_bytes(strips[0].film, &bytes));
+			for (int r = 0; r < N; ++r)
+				for (int which = 0; which < 2; ++which) {
+					if ((which == 0 && r == 0) || (which == 1 && r == N - 1)) continue;
+					check(gdpt_device_alloc(r, bytes, &strips[r].out[which]));
+					check(gdpt_device_alloc(r, bytes, &strips[r].in[which]));
+					check(gdpt_film_pack_halo(strips[r].film, which, strips[r].out[which]));       /* every strip packs before anyone unpacks */
+				}
+			for (int r = 0; r + 1 < N; ++r) {
+				check(gdpt_device_copy(r + 1, strips[r + 1].in[0], r, strips[r].out[1], bytes));
+				check(gdpt_device_copy(r, strips[r].in[1], r + 1, strips[r + 1].out[0], bytes));
+			}
+			for (int r = 0; r < N; ++r)
+				for (int which = 0; which < 2; ++which)
+					if (strips[r].in[which]) check(gdpt_film_unpack_halo(strips[r].film, which, strips[r].in[which]));
+		}
+		if (error.empty())
+			for (int r = 0; r < N; ++r)
+				for (int b = 0; b < 5; ++b)
+					check(gdpt_film_develop(strips[r].film, b, img[b].data() + (size_t) 3 * W * strips[r].y0));
+		for (int r = 0; r < N; ++r) {
+			for (int k = 0; k < 2; ++k) { gdpt_device_free(r, strips[r].out[k]); gdpt_device_free(r, strips[r].in[k]); }
+			gdpt_film_destroy(strips[r].film);
+			gdpt_scene_destroy(strips[r].scene);
+		}
+		if (!error.empty()) Log(EError, "%s", error.c_str());
+		return true;
 	}
 
 	gdpt_film *m_film;

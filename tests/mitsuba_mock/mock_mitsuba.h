@@ -50,19 +50,44 @@ struct Vector { Float x, y, z; Vector(Float a = 0, Float b = 0, Float c = 0) : x
 struct Point { Float x, y, z; Point(Float a = 0, Float b = 0, Float c = 0) : x(a), y(b), z(c) {} };
 inline Point operator+(Point p, Vector v) { return Point(p.x + v.x, p.y + v.y, p.z + v.z); }
 struct Normal { Float x, y, z; Normal(Float a = 0, Float b = 0, Float c = 0) : x(a), y(b), z(c) {} };
+inline Normal normalize(const Normal &n) { return n; }
 struct Point2 { Float x, y; Point2(Float a = 0, Float b = 0) : x(a), y(b) {} };
 struct Vector2i { int x, y; Vector2i(int a = 0, int b = 0) : x(a), y(b) {} };
 struct Frame { Vector s, t; Normal n; Frame() {} explicit Frame(const Normal &nn) : n(nn) {} };
 struct Matrix4x4 { Float m[4][4]; Float operator()(int r, int c) const { return m[r][c]; } };
-class Transform { public: const Matrix4x4 &getMatrix() const { return m_m; } Point operator()(const Point &p) const { return p; } Vector operator()(const Vector &v) const { return v; } private: Matrix4x4 m_m; };
+class Transform {
+public:
+    const Matrix4x4 &getMatrix() const { return m_m; }
+    Point operator()(const Point &p) const { return p; }
+    Vector operator()(const Vector &v) const { return v; }
+    Normal operator()(const Normal &n) const { return n; }
+    Transform operator*(const Transform &) const { return *this; }
+    static Transform scale(const Vector &) { return Transform(); }
+private:
+    Matrix4x4 m_m;
+};
 class AnimatedTransform { public: const Transform &eval(Float) const { return m_t; } private: Transform m_t; };
-class Spectrum { public: Spectrum(Float v = 0) { c[0] = c[1] = c[2] = v; } void toLinearRGB(Float &r, Float &g, Float &b) const { r = c[0]; g = c[1]; b = c[2]; } Float c[3]; };
+class InterpolatedSpectrum { public: explicit InterpolatedSpectrum(const std::string &) {} };          // core/spectrum.h
+class Spectrum {
+public:
+    Spectrum(Float v = 0) { c[0] = c[1] = c[2] = v; }
+    void toLinearRGB(Float &r, Float &g, Float &b) const { r = c[0]; g = c[1]; b = c[2]; }
+    void fromContinuousSpectrum(const InterpolatedSpectrum &) {}
+    Spectrum operator/(Float f) const { Spectrum s; for (int i = 0; i < 3; ++i) s.c[i] = c[i] / f; return s; }
+    static Spectrum getD65() { return Spectrum(1); }
+    Float c[3];
+};
+class FileResolver { public: std::string resolve(const std::string &p) const { return p; } void incRef() const {} };   // core/fresolver.h (returns fs::path there)
+class Thread { public: static Thread *getThread() { static Thread t; return &t; } FileResolver *getFileResolver() { return &m_fr; } private: FileResolver m_fr; };
 struct Triangle { uint32_t idx[3]; };
 struct RayDifferential { RayDifferential(const Point &, const Vector &, Float) {} };
 
 class Properties {
 public:
+    enum EPropertyType { EBoolean, EInteger, EFloat, EPoint, ETransform, EAnimatedTransform, ESpectrum, EString, EData };   // properties.h:52-62
     explicit Properties(const std::string &plugin = "") : m_plugin(plugin) {}
+    EPropertyType getType(const std::string &) const { return EFloat; }
+    Transform getTransform(const std::string &, const Transform &def) const { return def; }
     const std::string &getPluginName() const { return m_plugin; }
     bool hasProperty(const std::string &) const { return false; }
     int getInteger(const std::string &, int def) const { return def; }
@@ -131,12 +156,16 @@ class Texture : public ConfigurableObject {
 public:
     virtual ref<Bitmap> getBitmap(const Vector2i &resolutionHint = Vector2i(-1, -1)) const { (void)resolutionHint; return new Bitmap(Bitmap::ERGB, Bitmap::EFloat64, Vector2i(1, 1)); }   // texture.h
     virtual bool isConstant() const { return true; }
+    virtual const Texture *getNestedTexture() const { return nullptr; }                // ADDED accessor, not in Mitsuba 0.5
     const Class *getClass() const { static Class c("ConstantSpectrumTexture"); return &c; }
 };
 class BSDF : public ConfigurableObject {
 public:
     virtual Spectrum getDiffuseReflectance(const Intersection &) const { return Spectrum(0.5); }       // bsdf.h
     virtual Spectrum getSpecularReflectance(const Intersection &) const { return Spectrum(1.0); }
+    virtual Float getEta() const { return 1.0; }                                         // bsdf.h:451
+    virtual const BSDF *getNestedBRDF() const { return nullptr; }                       // ADDED accessor, not in Mitsuba 0.5
+    virtual const Texture *getReflectanceTexture() const { return nullptr; }            // ADDED accessor, not in Mitsuba 0.5
     const Class *getClass() const { static Class c("SmoothDiffuse"); return &c; }
 };
 class Emitter : public ConfigurableObject {
@@ -150,7 +179,17 @@ public:
 private:
     AnimatedTransform m_t;
 };
-class Shape : public ConfigurableObject { public: const BSDF *getBSDF() const { return &m_bsdf; } bool isEmitter() const { return false; } const Emitter *getEmitter() const { return &m_em; } const Class *getClass() const { static Class c("Shape"); return &c; } protected: BSDF m_bsdf; Emitter m_em; };
+class TriMesh;
+class Shape : public ConfigurableObject {
+public:
+    const BSDF *getBSDF() const { return &m_bsdf; }
+    bool isEmitter() const { return false; }
+    const Emitter *getEmitter() const { return &m_em; }
+    virtual ref<TriMesh> createTriMesh();                                               // shape.h:230
+    const Class *getClass() const { static Class c("Shape"); return &c; }
+protected:
+    BSDF m_bsdf; Emitter m_em;
+};
 class TriMesh : public Shape {
 public:
     const Point *getVertexPositions() const { return nullptr; }
@@ -159,14 +198,16 @@ public:
     const Triangle *getTriangles() const { return nullptr; }
     size_t getTriangleCount() const { return 0; }
 };
+inline ref<TriMesh> Shape::createTriMesh() { return nullptr; }
 class Scene : public ConfigurableObject {
 public:
     Sensor *getSensor() { return &m_sensor; }
     const std::vector<TriMesh *> &getMeshes() const { return m_meshes; }
+    const ref_vector<Shape> &getShapes() const { return m_shapes; }
     const ref_vector<Emitter> &getEmitters() const { return m_emitters; }
     const Class *getClass() const { static Class c("Scene"); return &c; }
 private:
-    PerspectiveCamera m_sensor; std::vector<TriMesh *> m_meshes; ref_vector<Emitter> m_emitters;
+    PerspectiveCamera m_sensor; std::vector<TriMesh *> m_meshes; ref_vector<Shape> m_shapes; ref_vector<Emitter> m_emitters;
 };
 class Scheduler : public Object {
 public:
