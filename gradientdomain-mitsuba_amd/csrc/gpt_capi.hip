@@ -323,6 +323,16 @@ struct gdpt_film {
     int lastSlices = 1;
 };
 
+static void material_to_device(const gdpt_material &m, int tex, MaterialD &o)
+{
+    o.type = m.type; o.distribution = m.distribution; o.sampleVisible = m.sampleVisible; o.twoSided = m.twoSided != 0;
+    o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));
+    o.eta = to_d3(h3(m.eta[0], m.eta[1], m.eta[2]));
+    o.k = to_d3(h3(m.k[0], m.k[1], m.k[2]));
+    o.alphaU = m.alphaU; o.alphaV = m.alphaV; o.pad2 = 0;
+    o.tex = tex < -1 ? -1 : tex;
+}
+
 extern "C" {
 
 int gdpt_scene_create(int numTris, const double *verts, const int *triMaterial, int numMaterials, const gdpt_material *materials,
@@ -463,14 +473,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
         if (m.type == 3 && m.twoSided) return tfail(GDPT_ERR_INVALID, "material %d: Only materials without a transmission component can be nested!", i);   // twosided.cpp:96-98
         if (m.type == 3 && !(m.eta[0] > 0)) return tfail(GDPT_ERR_INVALID, "material %d: The interior and exterior indices of refraction must be positive!", i);
         if (m.type == 2 && (m.distribution < 0 || m.distribution > 2)) return tfail(GDPT_ERR_INVALID, "material %d: Specified an invalid distribution, must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!", i);   // microfacet.h:113-115
-        MaterialD &o = mats[i];
-        o.type = m.type; o.distribution = m.distribution; o.sampleVisible = m.sampleVisible; o.twoSided = m.twoSided != 0;
-        o.reflectance = to_d3(h3(m.reflectance[0], m.reflectance[1], m.reflectance[2]));
-        o.eta = to_d3(h3(m.eta[0], m.eta[1], m.eta[2]));
-        o.k = to_d3(h3(m.k[0], m.k[1], m.k[2]));
-        o.alphaU = m.alphaU; o.alphaV = m.alphaV; o.pad2 = 0;
-        o.tex = materialTexture ? materialTexture[i] : -1;
-        if (o.tex < -1) o.tex = -1;
+        material_to_device(m, materialTexture ? materialTexture[i] : -1, mats[i]);
     }
 
     // emitters: DiscreteDistribution over triangle areas (trimesh.cpp:395-403, pmf.h:95-108), scene-level emitter pdf (scene.cpp:357-380)
@@ -1248,6 +1251,28 @@ int gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int
     THIPCHK(hipGetLastError());
     THIPCHK(hipMemcpy(out33, d, sizeof(double) * 33, hipMemcpyDeviceToHost));
     hipFree(d);
+    return GDPT_OK;
+}
+
+int gdpt_bsdf_probe(const gdpt_material *m, const double wi[3], int nSamples, const double *samples2, double *sampled8, int nDirs, const double *wo3, int measure, double *evalPdf4)
+{
+    if (!m || !wi || nSamples < 0 || nDirs < 0 || (nSamples && (!samples2 || !sampled8)) || (nDirs && (!wo3 || !evalPdf4))) return tfail(GDPT_ERR_INVALID, "bsdf_probe: bad argument");
+    if (m->type < 0 || m->type > 3) return tfail(GDPT_ERR_UNSUPPORTED, "bsdf_probe: BSDF type %d is not carried", m->type);
+    MaterialD md;
+    material_to_device(*m, -1, md);
+    double *dIn = nullptr, *dOut = nullptr;
+    const size_t nin = (size_t)2 * nSamples + (size_t)3 * nDirs, nout = (size_t)8 * nSamples + (size_t)4 * nDirs;
+    if (nin == 0) return GDPT_OK;
+    THIPCHK(hipMalloc((void **)&dIn, sizeof(double) * nin));
+    THIPCHK(hipMalloc((void **)&dOut, sizeof(double) * nout));
+    if (nSamples) THIPCHK(hipMemcpy(dIn, samples2, sizeof(double) * 2 * nSamples, hipMemcpyHostToDevice));
+    if (nDirs) THIPCHK(hipMemcpy(dIn + (size_t)2 * nSamples, wo3, sizeof(double) * 3 * nDirs, hipMemcpyHostToDevice));
+    const int n = nSamples + nDirs;
+    hipLaunchKernelGGL(k_bsdf_probe, dim3((n + TBLK - 1) / TBLK), dim3(TBLK), 0, 0, md, to_d3(h3(wi[0], wi[1], wi[2])), nSamples, nDirs, measure, dIn, dOut);
+    THIPCHK(hipGetLastError());
+    if (nSamples) THIPCHK(hipMemcpy(sampled8, dOut, sizeof(double) * 8 * nSamples, hipMemcpyDeviceToHost));
+    if (nDirs) THIPCHK(hipMemcpy(evalPdf4, dOut + (size_t)8 * nSamples, sizeof(double) * 4 * nDirs, hipMemcpyDeviceToHost));
+    hipFree(dIn); hipFree(dOut);
     return GDPT_OK;
 }
 

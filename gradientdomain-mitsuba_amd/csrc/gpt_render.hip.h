@@ -1075,4 +1075,23 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     *o++ = (Float)L.nClosest; *o++ = (Float)L.nShadow; *o++ = (Float)L.depth;
 }
 
+// probe: the device BSDF models on their own (tests: chi-square of sample() against pdf(), oracle parity per direction)
+__global__ __launch_bounds__(TBLK) void k_bsdf_probe(MaterialD m, d3 wi, int nSamples, int nDirs, int measure, const Float *__restrict__ in, Float *__restrict__ out)
+{
+    const int i = blockIdx.x * TBLK + threadIdx.x;
+    if (i < nSamples) {
+        BSDFSample r;
+        bsdf_sample(m, m.reflectance, wi, in[2 * i], in[2 * i + 1], r);
+        Float *o = out + (size_t)8 * i;
+        o[0] = r.wo.x; o[1] = r.wo.y; o[2] = r.wo.z; o[3] = r.weight.x; o[4] = r.weight.y; o[5] = r.weight.z; o[6] = r.pdf; o[7] = (Float)r.sampledType;
+    } else if (i < nSamples + nDirs) {
+        const int j = i - nSamples;
+        const Float *w = in + (size_t)2 * nSamples + (size_t)3 * j;
+        d3 f; Float pdf;
+        bsdf_eval_pdf(m, m.reflectance, wi, mk(w[0], w[1], w[2]), measure, f, pdf);
+        Float *o = out + (size_t)8 * nSamples + (size_t)4 * j;
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
+    }
+}
+
 } // namespace gdpt_tr

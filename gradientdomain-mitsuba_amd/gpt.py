@@ -61,6 +61,19 @@ def _material(m):
     return out
 
 
+def bsdf_probe(m, wi, samples=None, dirs=None, measure=0):
+    """gdpt_bsdf_probe: the device's BSDF::sample for each (sx, sy) row of `samples` -> (wo, weight, pdf, sampledType) arrays, and
+    BSDF::eval / pdf for each row of `dirs` -> (f, pdf) arrays.  A test probe (the models are otherwise reached through the render kernels)."""
+    mm = _material(m)
+    w = np.ascontiguousarray(wi, np.float64)
+    smp = np.ascontiguousarray(samples if samples is not None else np.zeros((0, 2)), np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(dirs if dirs is not None else np.zeros((0, 3)), np.float64).reshape(-1, 3)
+    out8 = np.zeros((len(smp), 8)); out4 = np.zeros((len(d), 4))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().gdpt_bsdf_probe(C.byref(mm), P(w), len(smp), P(smp), P(out8), len(d), P(d), measure, P(out4)))
+    return (out8[:, 0:3], out8[:, 3:6], out8[:, 6], out8[:, 7].astype(int)), (out4[:, 0:3], out4[:, 3])
+
+
 class Scene:
     """Device-resident scene (flat BVH + triangle records in HBM) built from a `scenes.Scene` description."""
 

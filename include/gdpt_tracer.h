@@ -243,6 +243,14 @@ GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *ori
  * neighbourThroughputs[4](12), then closest-hit count, any-hit count, final depth. */
 GDPT_API int  gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int py, int sample, double out33[33]);
 
+/* Probe for tests: the device's BSDF models on their own, for one material with its constant reflectance and one incident direction wi (local
+ * frame).  For each of nSamples pairs (sx, sy): the pdf-returning BSDF::sample (diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:
+ * 369-418, dielectric.cpp:277-305, twosided.cpp:148-168) -> sampled8 = wo(3), weight(3), pdf, sampledType.  For each of nDirs directions wo:
+ * BSDF::eval and BSDF::pdf in `measure` (0 solid angle, 1 discrete) -> evalPdf4 = f(3), pdf.  This is what the chi-square test of the reference's
+ * src/tests/test_chisquare.cpp checks a BSDF with, run on the HIP side. */
+GDPT_API int  gdpt_bsdf_probe(const gdpt_material *m, const double wi[3], int nSamples, const double *samples2, double *sampled8,
+                              int nDirs, const double *wo3, int measure, double *evalPdf4);
+
 /* ---- G-BDPT (BASELINE config 5): the per-block work of the reference's `gbdpt` integrator plugin ------------------------------------------
  * What GBDPTRenderer::process -> evaluate compute for a rectangle of pixels (src/integrators/gbdpt/gbdpt_proc.cpp:86-256,259-534 over
  * src/libbidir: Path::alternatingRandomWalkFromPixel, ManifoldPerturbation::generateOffsetPathGBDPT, Path::miWeight{Base,Grad}NoSweep_GBDPT),
