@@ -3,6 +3,9 @@
 // value is produced by the kernels of gpt_render.hip.h.
 #include "../../include/gdpt_tracer.h"
 #include "gpt_render.hip.h"
+#ifdef GDPT_WITH_SHIFT5     /* the one-path-per-lane shift stage: measured slower than k_render<STAGED>, kept as a development build */
+#include "gpt_shift5.hip.h"
+#endif
 #include "gpt_scene.hip.h"
 
 #include <algorithm>
@@ -907,6 +910,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     if (!usePrimary) { fd.pHit = nullptr; fd.pPrim = nullptr; }
     fd.qPixels = qPixels; fd.qCapacity = (unsigned)chunk * qPixels;
     const dim3 cgrid(s->numCUs * wps);
+#ifdef GDPT_WITH_SHIFT5
+    // the shift stage with one path per lane (gpt_shift5.hip.h) instead of k_render<STAGED>: GDPT_SHIFT5=1 in a -DGDPT_WITH_SHIFT5 build
+    const bool shift5 = useQueue && getenv("GDPT_SHIFT5") && atoi(getenv("GDPT_SHIFT5")) != 0;
+    const int shift5Regen = getenv("GDPT_SHIFT5_REGEN") ? std::max(1, std::min(12, atoi(getenv("GDPT_SHIFT5_REGEN")))) : 8;
+    const size_t lds5 = (size_t)stackDepth * TBLK * sizeof(int) + sizeof(Float) * MB_N * S5_K * (TBLK / 64) + sceneBytes;
+#define GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV) hipLaunchKernelGGL((k_shift5<LDSV, 4, ENVV, SMV>), dim3(s->numCUs * 16), block, lds5, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, stackDepth, shift5Regen)
+#else
+    const bool shift5 = false;
+#define GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV) do { } while (0)
+#endif
 #ifdef GDPT_DEV_TWO_BUILDS   /* investigation: GDPT_DEV_DUMP_QUEUE=<file> writes the sample queue as k_render left it (NQ x capacity doubles) */
 #define GDPT_DEV_DUMP_QUEUE() do { if (const char *qp = getenv("GDPT_DEV_DUMP_QUEUE")) { \
         (void)hipStreamSynchronize(f->stream); std::vector<double> hq((size_t)NQ * fd.qCapacity); \
@@ -917,7 +930,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #endif
 #define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
 #define GDPT_STAGED(LDSV, ACCV, WPS, ENVV, SMV) do { \
-        if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
+        if (shift5) GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV); \
+        else if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         GDPT_DEV_DUMP_QUEUE(); \
         hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fd, stackDepth, f->contRefill); } while (0)

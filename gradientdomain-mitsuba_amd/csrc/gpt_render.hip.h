@@ -559,7 +559,7 @@ __device__ __forceinline__ void finish_path(const FilmD &F, const FilterD &flt, 
 // sums (ACC_LDS only)][staged scene tables (LDS_SCENE only)]; sized by the host from the actual BVH depth and table bytes so that small
 // scenes leave room for more resident blocks per CU.
 template <bool LDS_SCENE, bool ACC_LDS>
-__device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, unsigned char *s_dyn, SceneView &sv, int *&stack, unsigned char *&s_acc)
+__device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, unsigned char *s_dyn, SceneView &sv, int *&stack, unsigned char *&s_acc, size_t extraBytes = 0 /* more room at s_acc (k_shift5's mailboxes) */)
 {
     int *s_stack = reinterpret_cast<int *>(s_dyn);
 #ifdef GDPT_LDS_POISON              /* investigation build: every dynamic-LDS word starts as a signalling pattern (a NaN as double, a huge
@@ -576,7 +576,7 @@ __device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, uns
     s_acc = s_scene + S.ldsBytes;
 #else
     s_acc = s_dyn + (size_t)stackDepth * TBLK * sizeof(int);
-    unsigned char *s_scene = s_acc + (ACC_LDS ? sizeof(Float) * ACC_N * TBLK : 0);
+    unsigned char *s_scene = s_acc + (ACC_LDS ? sizeof(Float) * ACC_N * TBLK : 0) + extraBytes;
 #endif
     if (LDS_SCENE) {
         // stage node packets, triangle records and the shading tables through LDS once per block (coalesced 16-byte copies);

@@ -148,6 +148,7 @@ struct gdpt_poisson_solver {
     unsigned *bar = nullptr;    // persistent CG: [1] sticky error flag
     unsigned long long *gat = nullptr;  // persistent CG: tagged partial tables (gather A, gather B)
     unsigned ptLaunch = 0;      // persistent CG: launch number (upper half of every tag)
+    bool ptWide = false;        // persistent CG: the 128-px wide tiles of kp_cg2
     int ptTilesX = 0, ptTilesY = 0, ptTH = 0;
     bool usedPersistent = false;
     hipGraphExec_t g0 = nullptr, gK = nullptr;
@@ -289,14 +290,20 @@ bool persistent_geometry(gdpt_poisson_solver *s)
     if (s->fusion < 2 || s->W % 4 != 0 || s->P.cgTolerance != 0.0f || s->P.verbose || s->P.cgPrecond || s->P.cgIterMax >= 0xffff) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
-    const int tilesX = cdiv(s->W, PT_W);
-    const int maxTY = cus / tilesX;
-    if (maxTY < 1) return false;
-    int TH = cdiv(s->H, maxTY);
-    if (TH < 8) TH = imin(8, s->H);
-    if (TH > PT_MAXH) return false;
-    s->ptTilesX = tilesX; s->ptTH = TH; s->ptTilesY = cdiv(s->H, TH);
-    return s->ptTilesX * s->ptTilesY <= imin(cus, PT_MAXG);
+    // 64-px wide tiles with 4 px per lane (kp_cg), else 128-px wide tiles with 8 px per lane and p in LDS only (kp_cg2: up to ~2 Mpixel)
+    for (int wide = 0; wide < 2; wide++) {
+        if (wide && getenv("GDPT_NO_WIDE_PERSISTENT")) break;
+        const int tw = wide ? P2_W : PT_W;
+        const int tilesX = cdiv(s->W, tw);
+        const int maxTY = cus / tilesX;
+        if (maxTY < 1) continue;
+        int TH = cdiv(s->H, maxTY);
+        if (TH < 8) TH = imin(8, s->H);
+        if (TH > PT_MAXH) continue;
+        s->ptTilesX = tilesX; s->ptTH = TH; s->ptTilesY = cdiv(s->H, TH); s->ptWide = wide != 0;
+        if (s->ptTilesX * s->ptTilesY <= imin(cus, PT_MAXG)) return true;
+    }
+    return false;
 }
 
 constexpr int PT_LAUNCH_REFUSED = -1000;     // internal: hipLaunchCooperativeKernel failed (never crosses the ABI)
@@ -309,14 +316,19 @@ int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
     { const char *e = getenv("GDPT_DEBUG_PERSISTENT_FAIL"); A.debugFail = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }   // test hooks: 1 = a gather times out, 2 = the launch is refused
     if (s->ptLaunch == 0 || s->ptLaunch == 0xffffu) {      // fresh tables, or the 16-bit launch number is about to wrap: forget all tags
         HIPCHK(hipMemsetAsync(s->gat, 0, sizeof(unsigned long long) * 6 * PT_MAXG, s->stream));
-        HIPCHK(hipMemsetAsync(s->halo, 0, sizeof(unsigned long long) * (size_t)PT_HALO * PT_MAXG, s->stream));
+        HIPCHK(hipMemsetAsync(s->halo, 0, sizeof(unsigned long long) * (size_t)P2_HALO * PT_MAXG, s->stream));
         s->ptLaunch = 0;
     }
     A.tagBase = (++s->ptLaunch) << 16;
     void *args[] = {&A};
     const dim3 grid(s->ptTilesX * s->ptTilesY), block(((16 * s->ptTH + 63) / 64) * 64);
-    const void *fn = unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>;
-    if (A.debugFail == 2 || hipLaunchCooperativeKernel(fn, grid, block, args, 0, s->stream) != hipSuccess) {
+    const void *fn = s->ptWide ? (unitw ? (const void *)kp_cg2<true> : (const void *)kp_cg2<false>) : (unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>);
+    const size_t shared = s->ptWide ? P2_SHARED_BYTES : 0;
+    if (s->ptWide) {
+        static bool raised[2] = {false, false};        // 111 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+        if (!raised[unitw ? 1 : 0]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared) != hipSuccess) { (void)hipGetLastError(); return PT_LAUNCH_REFUSED; } raised[unitw ? 1 : 0] = true; }
+    }
+    if (A.debugFail == 2 || hipLaunchCooperativeKernel(fn, grid, block, args, shared, s->stream) != hipSuccess) {
         (void)hipGetLastError();            // cooperative launch refused (unsupported, partitioned device, grid not co-resident): the caller falls back
         return PT_LAUNCH_REFUSED;
     }
@@ -455,7 +467,7 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
         HIPCHK(hipMalloc(&s->scal, sizeof(float) * 16));
         HIPCHK(hipMalloc(&s->regtab, sizeof(float) * (s->P.irlsIterMax + 1)));
         HIPCHK(hipMalloc(&s->counter, sizeof(int) * 4));
-        HIPCHK(hipMalloc(&s->halo, sizeof(unsigned long long) * (size_t)PT_HALO * PT_MAXG));
+        HIPCHK(hipMalloc(&s->halo, sizeof(unsigned long long) * (size_t)P2_HALO * PT_MAXG));      // (P2_HALO > PT_HALO: either kernel's records fit)
         HIPCHK(hipMalloc(&s->bar, sizeof(unsigned) * PT_BAR_WORDS));
         HIPCHK(hipMalloc(&s->gat, sizeof(unsigned long long) * 6 * PT_MAXG));
         // reg_k = regInit * regIter^(k-1), Solver.cpp:395 (host powf like the reference)

@@ -341,4 +341,221 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
     if (tile == 0 && t == 0) { A.s_rz[0] = rz[0]; A.s_rz[1] = rz[1]; A.s_rz[2] = rz[2]; }
 }
 
+// ---- the same for images of 1-2 Mpixel: 128-px wide tiles, 8 px per lane, p in LDS only -------------------------------------------------
+// 1920x1080 needs 8 100 px per CU.  A lane of kp_cg holds x, r, p, Ap and the IRLS weights of 4 px in ~125 registers; with 8 px that
+// would be 250.  kp_cg2 keeps what has to survive the two gathers in registers (x, r, Ap of two 4-px groups: 72 floats) and everything
+// else where it is cheap to fetch each iteration: p lives in the LDS image the stencil reads anyway (three planes of (TH+2) x 128 floats,
+// 101 KB; p = r + b p is a read-modify-write of a lane's own pixels there), the IRLS weights are re-read from L2 / MALL (25 MB per
+// iteration for the whole image, 98 KB per CU).  Tiles: 128 x TH, TH <= 64, one workgroup of 1024 threads per CU; lane (tx, ty) owns the
+// pixels [4 tx, 4 tx + 4) and [64 + 4 tx, 64 + 4 tx + 4) of row ty.  Gathers, tagged halo records, time-outs and the arithmetic per element
+// are kp_cg's.  1920x1080 = 15 x 17 tiles of 128 x 64 = 255 workgroups.
+constexpr int P2_W = 128;
+constexpr int P2_PLANE = (PT_MAXH + 2) * P2_W;
+constexpr int P2_COLL = 3 * P2_PLANE, P2_COLR = P2_COLL + 3 * PT_MAXH, P2_LDS = P2_COLR + 3 * PT_MAXH;
+constexpr int P2_HALO = (2 * P2_W + 2 * PT_MAXH) * 3;
+constexpr size_t P2_SHARED_BYTES = sizeof(float) * (P2_LDS + P2_HALO + 3 * PT_MAXG + 64) + 16;
+__device__ __forceinline__ int p2_plane(int c, int row, int x) { return c * P2_PLANE + row * P2_W + x; }
+
+template <bool UNITW>
+__global__ __launch_bounds__(1024) void kp_cg2(PersistArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float p2_dyn[];
+    float *lp = p2_dyn;                           // p of the tile with its ring
+    float *hs = lp + P2_LDS;
+    float *gsm = hs + P2_HALO;
+    float *sm = gsm + 3 * PT_MAXG;
+    int *s_failp = reinterpret_cast<int *>(sm + 64);
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, nwaves = (blockDim.x + 63) >> 6;
+    const int tile = blockIdx.x, tX = tile % A.tilesX, tY = tile / A.tilesX;
+    const int X0 = tX * P2_W, Y0 = tY * A.TH;
+    const int TWv = min(P2_W, A.W - X0), THv = min(A.TH, A.H - Y0);
+    const int y = Y0 + ty;
+    const int W = A.W, H = A.H, n = W * H;
+    const float alphaSqr = A.alpha * A.alpha;
+    const int G = A.tilesX * A.tilesY;
+    unsigned long long *myHalo = A.halo + (size_t)tile * P2_HALO;
+    const int lx[2] = {4 * tx, 64 + 4 * tx};                                     // the lane's two pixel groups, tile-local x
+    const bool valid[2] = {ty < THv && lx[0] < TWv, ty < THv && lx[1] < TWv};
+    const int gi[2] = {y * W + X0 + lx[0], y * W + X0 + lx[1]};
+
+    float xv[2][12], rv[2][12], Ap[2][12];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) { xv[g][k] = rv[g][k] = Ap[g][k] = 0.0f; }
+        if (valid[g]) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(A.x + 3 * (size_t)gi[g]), *r4 = reinterpret_cast<const float4 *>(A.r + 3 * (size_t)gi[g]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float4 a = x4[k], b = r4[k];
+                xv[g][4 * k] = a.x; xv[g][4 * k + 1] = a.y; xv[g][4 * k + 2] = a.z; xv[g][4 * k + 3] = a.w;
+                rv[g][4 * k] = b.x; rv[g][4 * k + 1] = b.y; rv[g][4 * k + 2] = b.z; rv[g][4 * k + 3] = b.w;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++)                                          // p := r (Solver.cpp:405)
+                *reinterpret_cast<float4 *>(&lp[p2_plane(c, ty + 1, lx[g])]) = make_float4(rv[g][c], rv[g][3 + c], rv[g][6 + c], rv[g][9 + c]);
+        }
+    }
+    const int ringN = (2 * TWv + 2 * THv) * 3;
+    for (int e = t; e < ringN; e += blockDim.x) {
+        const int c = e % 3, q = e / 3;
+        int gx, gy, slot;
+        if (q < TWv) { gx = X0 + q; gy = Y0 - 1; slot = p2_plane(c, 0, q); }
+        else if (q < 2 * TWv) { gx = X0 + (q - TWv); gy = Y0 + THv; slot = p2_plane(c, THv + 1, q - TWv); }
+        else if (q < 2 * TWv + THv) { gx = X0 - 1; gy = Y0 + (q - 2 * TWv); slot = P2_COLL + c * PT_MAXH + (q - 2 * TWv); }
+        else { gx = X0 + TWv; gy = Y0 + (q - 2 * TWv - THv); slot = P2_COLR + c * PT_MAXH + (q - 2 * TWv - THv); }
+        lp[slot] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? A.r[3 * ((size_t)gy * W + gx) + c] : 0.0f;
+    }
+    auto ring_source = [&](int e, int &nt, int &off, int &slot, int &c) -> bool {
+        c = e % 3;
+        const int q = e / 3;
+        bool have;
+        if (q < TWv) { have = tY > 0; nt = tile - A.tilesX; off = P2_W * 3 + q * 3 + c; slot = p2_plane(c, 0, q); }                                 // its bottom row
+        else if (q < 2 * TWv) { have = Y0 + THv < H; nt = tile + A.tilesX; off = (q - TWv) * 3 + c; slot = p2_plane(c, THv + 1, q - TWv); }        // its top row
+        else if (q < 2 * TWv + THv) { have = tX > 0; nt = tile - 1; off = 2 * P2_W * 3 + PT_MAXH * 3 + (q - 2 * TWv) * 3 + c; slot = P2_COLL + c * PT_MAXH + (q - 2 * TWv); }   // its right column
+        else { have = X0 + TWv < W; nt = tile + 1; off = 2 * P2_W * 3 + (q - 2 * TWv - THv) * 3 + c; slot = P2_COLR + c * PT_MAXH + (q - 2 * TWv - THv); }      // its left column
+        return have;
+    };
+    float rz[3];
+    rz[0] = A.s_rz[0]; rz[1] = A.s_rz[1]; rz[2] = A.s_rz[2];
+    bool ok = true;
+    if (t == 0) *s_failp = 0;
+    if (A.debugFail && tile == 0 && t == 0) __hip_atomic_store(A.bar + 1, 1u, PT_RLX_AGENT);
+    unsigned long long *gatA = A.gat, *gatB = A.gat + 3 * PT_MAXG;
+    unsigned *err = A.bar + 1;
+
+    for (int it = 0; it < A.iters && ok; it++) {
+        // ---- Ap = A p from the LDS image, partial p.Ap ----
+        pt_sync();
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int x = X0 + lx[g];
+            // the 17 weights the group's stencil needs, from L2 / MALL; fetched here, group by group: holding group 0's across the gathers (a prefetch
+            // during the wait for the ring) or both groups' at once spills, and cost 10 us per iteration when tried
+            const int i = gi[g];
+            float w0[4] = {1.0f, 1.0f, 1.0f, 1.0f}, w1[4] = {1.0f, 1.0f, 1.0f, 1.0f}, wv_[4] = {1.0f, 1.0f, 1.0f, 1.0f}, wu[4] = {1.0f, 1.0f, 1.0f, 1.0f}, w1l = 1.0f;
+            if (!UNITW && valid[g]) {
+                const float4 a = *reinterpret_cast<const float4 *>(A.w2 + i), b = *reinterpret_cast<const float4 *>(A.w2 + n + i), c = *reinterpret_cast<const float4 *>(A.w2 + 2 * n + i);
+                w0[0] = a.x; w0[1] = a.y; w0[2] = a.z; w0[3] = a.w;
+                w1[0] = b.x; w1[1] = b.y; w1[2] = b.z; w1[3] = b.w;
+                wv_[0] = c.x; wv_[1] = c.y; wv_[2] = c.z; wv_[3] = c.w;
+                w1l = (x != 0) ? A.w2[n + i - 1] : 0.0f;
+                if (y != 0) { const float4 d = *reinterpret_cast<const float4 *>(A.w2 + 2 * n + i - W); wu[0] = d.x; wu[1] = d.y; wu[2] = d.z; wu[3] = d.w; }
+                else { wu[0] = wu[1] = wu[2] = wu[3] = 0.0f; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float4 m4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), u4 = m4, d4 = m4;
+                if (valid[g]) {
+                    m4 = *reinterpret_cast<const float4 *>(&lp[p2_plane(c, ty + 1, lx[g])]);
+                    u4 = *reinterpret_cast<const float4 *>(&lp[p2_plane(c, ty, lx[g])]);
+                    d4 = *reinterpret_cast<const float4 *>(&lp[p2_plane(c, ty + 2, lx[g])]);
+                }
+                float lft = pt_from_left(m4.w), rgt = pt_from_right(m4.x);                    // all lanes take part
+                if (valid[g]) {
+                    if (tx == 0) lft = (g == 0) ? lp[P2_COLL + c * PT_MAXH + ty] : lp[p2_plane(c, ty + 1, 63)];
+                    if (lx[g] + 4 == TWv) rgt = lp[P2_COLR + c * PT_MAXH + ty];
+                    else if (tx == 15) rgt = lp[p2_plane(c, ty + 1, 64)];                      // (g == 0 here: the first pixel of the right half)
+                    const float pm[4] = {m4.x, m4.y, m4.z, m4.w}, up[4] = {u4.x, u4.y, u4.z, u4.w}, dn[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int xx = x + k;
+                        const float xi = pm[k];
+                        const float wl = (k == 0) ? w1l : w1[k - 1];
+                        const float xl = (k == 0) ? lft : pm[k - 1], xr = (k == 3) ? rgt : pm[k + 1];
+                        float a = w0[k] * xi * alphaSqr;                                   // Backend.cpp:228-233
+                        if (xx != 0)     a = a + wl * (xi - xl);
+                        if (xx != W - 1) a = a + w1[k] * (xi - xr);
+                        if (y != 0)      a = a + wu[k] * (xi - up[k]);
+                        if (y != H - 1)  a = a + wv_[k] * (xi - dn[k]);
+                        Ap[g][3 * k + c] = a;
+                        acc[c] += xi * a;
+                    }
+                }
+            }
+        }
+        pt_block_sum3(acc, sm, nwaves);
+        float pAp[3], a[3];
+        ok = pt_allgather_sum(gatA, A.tagBase + (unsigned)it + 1u, G, tile, acc, pAp, gsm, s_failp, err);
+        if (!ok) break;
+
+        // ---- a = rz / pAp ; x += p a ; r -= Ap a ; partial r.r ; publish the boundary of r ----
+#pragma unroll
+        for (int c = 0; c < 3; c++) a[c] = rz[c] / fmaxf(pAp[c], FLT_MIN);              // Backend.cpp:301
+        float acc2[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (valid[g]) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float4 m4 = *reinterpret_cast<const float4 *>(&lp[p2_plane(c, ty + 1, lx[g])]);
+                    const float pm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        xv[g][3 * k + c] = xv[g][3 * k + c] + pm[k] * a[c];             // Backend.cpp:343
+                        const float ri = rv[g][3 * k + c] - Ap[g][3 * k + c] * a[c];    // Backend.cpp:305-307
+                        rv[g][3 * k + c] = ri;
+                        acc2[c] += ri * ri;
+                    }
+                }
+                if (ty == 0) for (int k = 0; k < 12; k++) hs[lx[g] * 3 + k] = rv[g][k];
+                if (ty == THv - 1) for (int k = 0; k < 12; k++) hs[P2_W * 3 + lx[g] * 3 + k] = rv[g][k];
+                if (lx[g] == 0) for (int c = 0; c < 3; c++) hs[2 * P2_W * 3 + ty * 3 + c] = rv[g][c];
+                if (lx[g] + 4 == TWv) for (int c = 0; c < 3; c++) hs[2 * P2_W * 3 + PT_MAXH * 3 + ty * 3 + c] = rv[g][9 + c];
+            }
+        }
+        pt_block_sum3(acc2, sm, nwaves);
+        for (int e = t; e < P2_HALO; e += blockDim.x) pt_store(&myHalo[e], hs[e], A.tagBase + (unsigned)it + 1u);
+        float rzn[3], b[3];
+        ok = pt_allgather_sum(gatB, A.tagBase + (unsigned)it + 1u, G, tile, acc2, rzn, gsm, s_failp, err);
+        if (!ok) break;
+
+        // ---- b = rz_new / rz ; p = r + p b in the LDS image, for the tile and (redundantly) its ring ----
+#pragma unroll
+        for (int c = 0; c < 3; c++) { b[c] = rzn[c] / fmaxf(rz[c], FLT_MIN); rz[c] = rzn[c]; }   // Backend.cpp:336
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (valid[g]) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float4 *q = reinterpret_cast<float4 *>(&lp[p2_plane(c, ty + 1, lx[g])]);
+                    const float4 m4 = *q;
+                    *q = make_float4(rv[g][c] + m4.x * b[c], rv[g][3 + c] + m4.y * b[c], rv[g][6 + c] + m4.z * b[c], rv[g][9 + c] + m4.w * b[c]);   // Backend.cpp:344
+                }
+            }
+        }
+        for (int e = t; e < ringN; e += blockDim.x) {
+            int nt, off, slot, c;
+            if (ring_source(e, nt, off, slot, c)) {
+                unsigned long long *hp = &A.halo[(size_t)nt * P2_HALO + off];
+                const float rn = pt_wait(hp, __hip_atomic_load(hp, PT_RLX_AGENT), A.tagBase + (unsigned)it + 1u, s_failp, err);
+                lp[slot] = rn + lp[slot] * b[c];
+            }
+        }
+    }
+
+    // ---- write the iterate back ----
+    pt_sync();
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        if (valid[g]) {
+            float4 *x4 = reinterpret_cast<float4 *>(A.x + 3 * (size_t)gi[g]), *r4 = reinterpret_cast<float4 *>(A.r + 3 * (size_t)gi[g]), *p4 = reinterpret_cast<float4 *>(A.p + 3 * (size_t)gi[g]);
+            float pv[12];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float4 m4 = *reinterpret_cast<const float4 *>(&lp[p2_plane(c, ty + 1, lx[g])]);
+                pv[c] = m4.x; pv[3 + c] = m4.y; pv[6 + c] = m4.z; pv[9 + c] = m4.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                x4[k] = make_float4(xv[g][4 * k], xv[g][4 * k + 1], xv[g][4 * k + 2], xv[g][4 * k + 3]);
+                r4[k] = make_float4(rv[g][4 * k], rv[g][4 * k + 1], rv[g][4 * k + 2], rv[g][4 * k + 3]);
+                p4[k] = make_float4(pv[4 * k], pv[4 * k + 1], pv[4 * k + 2], pv[4 * k + 3]);
+            }
+        }
+    }
+    if (tile == 0 && t == 0) { A.s_rz[0] = rz[0]; A.s_rz[1] = rz[1]; A.s_rz[2] = rz[2]; }
+}
+
 } // namespace gdpt
