@@ -228,6 +228,7 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
     if (cfg->rrDepth <= 0) return bfail(GDPT_ERR_INVALID, "'rrDepth' must be set to a value greater than zero!");                                           // gbdpt.cpp:99-100
     if (cfg->maxDepth > BD_MAX_DEPTH) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d (the reference's own cap for -1, gbdpt_proc.cpp:103-106)", BD_MAX_DEPTH);
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
+    if (s->d.cam.thinlens) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: the thinlens sensor is not carried (perspective only)");
     if (s->specialEmitters) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment and point emitters are not carried (area emitters only)");
     for (size_t i = 0; i < s->hostMats.size(); i++) {
         const MaterialD &m = s->hostMats[i];

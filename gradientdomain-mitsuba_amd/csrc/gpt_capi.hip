@@ -374,6 +374,16 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
             if (materialTexture[i] >= numTextures) return tfail(GDPT_ERR_INVALID, "material %d: texture %d out of range", i, materialTexture[i]);
     if (!verts || !triMaterial || !materials || !camera || !out || numTris <= 0 || numMaterials <= 0)
         return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
+    if (camera->type != GDPT_SENSOR_PERSPECTIVE && camera->type != GDPT_SENSOR_THINLENS) return tfail(GDPT_ERR_UNSUPPORTED, "sensor type %d is not carried (perspective, thinlens)", camera->type);
+    if (camera->type == GDPT_SENSOR_THINLENS) {
+        if (!(camera->apertureRadius > 0)) return tfail(GDPT_ERR_INVALID, "thinlens: 'apertureRadius' must be positive (the plugin replaces 0 by Epsilon, thinlens.cpp:134-138: so does a host)");
+        if (!(camera->focusDistance > 0)) return tfail(GDPT_ERR_INVALID, "thinlens: 'focusDistance' must be positive");
+        // the lookups filtered by a camera ray's differentials (trilinear / ewa textures, the environment map seen directly) take their
+        // differential origins from the pinhole: refused with a lens rather than evaluated with the wrong footprint
+        for (int i = 0; i < numTextures; i++)
+            if (textures[i].filter >= GDPT_TEXFILTER_TRILINEAR) return tfail(GDPT_ERR_UNSUPPORTED, "thinlens sensor with a trilinear / ewa texture (texture %d) is not carried: use filterType nearest or bilinear", i);
+        if (env && env->rgb) return tfail(GDPT_ERR_UNSUPPORTED, "thinlens sensor with a bitmap environment map is not carried");
+    }
     if (numEmitters < 0 || (numEmitters > 0 && !emitters)) return tfail(GDPT_ERR_INVALID, "scene_create: bad emitter list");
     if (numEmitters == 0 && !env) return tfail(GDPT_ERR_INVALID, "scene_create: at least one emitter (area or environment) is required");
     if (env && env->rgb) {
@@ -709,6 +719,8 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     c.aspect = (double)camera->width / (double)camera->height;
     c.invW = 1.0 / camera->width; c.invH = 1.0 / camera->height;
     c.width = camera->width; c.height = camera->height;
+    c.thinlens = camera->type == GDPT_SENSOR_THINLENS ? 1 : 0; c.pad = 0;
+    c.apertureRadius = camera->apertureRadius; c.focusDistance = camera->focusDistance;
     { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) s->numCUs = cus; }
     *out = s;
     return GDPT_OK;

@@ -147,6 +147,8 @@ struct CameraD {
     Float m[12];            // rows of the 3x4 camera-to-world
     Float nearClip, farClip, tanHalf, aspect, invW, invH;
     int width, height;
+    int thinlens, pad;      // 1: `thinlens` sensor (thinlens.cpp): rays start on the aperture and pass through the focus point of their pixel
+    Float apertureRadius, focusDistance;
 };
 struct SceneD {
     const BvhNode *nodes;
@@ -962,15 +964,27 @@ __device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, const Scene
 }
 
 // ---- sensor: perspective.cpp:271-298 with the composite of :150-156 written out for crop == film ----------------
-__device__ __forceinline__ void camera_ray(const CameraD &c, Float px, Float py, d3 &o, d3 &d, Float &mint, Float &maxt)
+// apx, apy: the aperture sample (gpt.cpp:1262-1264), read by the thinlens sensor only (thinlens.cpp:324-361: a point of the aperture disk,
+// squareToUniformDiskConcentric * apertureRadius; the ray goes from there through the pixel's point on the focal plane)
+__device__ __forceinline__ void camera_ray(const CameraD &c, Float px, Float py, Float apx, Float apy, d3 &o, d3 &d, Float &mint, Float &maxt)
 {
     const Float sxn = px * c.invW, syn = py * c.invH;
     const d3 nearP = mk((1 - 2 * sxn) * c.nearClip * c.tanHalf, (1 - 2 * syn) / c.aspect * c.nearClip * c.tanHalf, c.nearClip);
-    const d3 dl = normalize(nearP);
+    d3 dl, ol = mk(0.0);
+    if (c.thinlens) {
+        const Float r1 = 2.0 * apx - 1.0, r2 = 2.0 * apy - 1.0;                    // warp.cpp:81-102
+        Float phi, r;
+        if (r1 == 0 && r2 == 0) { r = phi = 0; }
+        else if (r1 * r1 > r2 * r2) { r = r1; phi = (GD_PI / 4.0) * (r2 / r1); }
+        else { r = r2; phi = (GD_PI / 2.0) - (r1 / r2) * (GD_PI / 4.0); }
+        ol = mk(r * cos(phi) * c.apertureRadius, r * sin(phi) * c.apertureRadius, 0.0);
+        const Float fDist = c.focusDistance / nearP.z;
+        dl = normalize(nearP * fDist - ol);
+    } else dl = normalize(nearP);
     const Float invZ = 1.0 / dl.z;
     mint = c.nearClip * invZ;
     maxt = c.farClip * invZ;
-    o = mk(c.m[3], c.m[7], c.m[11]);
+    o = mk(c.m[0] * ol.x + c.m[1] * ol.y + c.m[2] * ol.z + c.m[3], c.m[4] * ol.x + c.m[5] * ol.y + c.m[6] * ol.z + c.m[7], c.m[8] * ol.x + c.m[9] * ol.y + c.m[10] * ol.z + c.m[11]);
     d = mk(c.m[0] * dl.x + c.m[1] * dl.y + c.m[2] * dl.z, c.m[4] * dl.x + c.m[5] * dl.y + c.m[6] * dl.z, c.m[8] * dl.x + c.m[9] * dl.y + c.m[10] * dl.z);
 }
 

@@ -86,6 +86,8 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     L.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
     L.sx = px + L.rng.next1D();                                                  // gpt.cpp:1261
     L.sy = py + L.rng.next1D();
+    Float apx = 0.5, apy = 0.5;
+    if (S.cam.thinlens) { apx = L.rng.next1D(); apy = L.rng.next1D(); }          // gpt.cpp:1262-1264 (needsApertureSample)
     L.throughput = mk(1.0); L.pdf = 1.0; L.eta = 1.0; L.depth = 1;
     A.zero();
     // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
@@ -106,7 +108,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
         d3 o, d;
         Float mint, maxt;
         const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);
-        camera_ray(S.cam, L.sx + ox, L.sy + oy, o, d, mint, maxt);
+        camera_ray(S.cam, L.sx + ox, L.sy + oy, apx, apy, o, d, mint, maxt);
         L.nClosest++;
         if constexpr (CALLS) hits[r] = trace_closest_call(sv, stack, o, d, ray_mint_closest(o, mint), maxt);
         else trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, hits[r]);
@@ -115,7 +117,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     for (int r = 0; r < 5; r++) {
         d3 o, d;
         Float mint, maxt;
-        camera_ray(S.cam, L.sx + (r ? shx[r - 1] : 0.0), L.sy + (r ? shy[r - 1] : 0.0), o, d, mint, maxt);
+        camera_ray(S.cam, L.sx + (r ? shx[r - 1] : 0.0), L.sy + (r ? shy[r - 1] : 0.0), apx, apy, o, d, mint, maxt);
         const Hit h = hits[r];
         if (r == 0) { fill_vertex(sv, h, d, L.v); L.rayO = o; L.rayD = d; }
         else {
@@ -786,13 +788,15 @@ __global__ __launch_bounds__(TBLK) void k_primary(SceneD S, ConfigD cfg, FilmD F
     Rng rng;
     rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)(cfg.sBase + sRel));
     const Float sx = px + rng.next1D(), sy = py + rng.next1D();                  // gpt.cpp:1261
+    Float apx = 0.5, apy = 0.5;
+    if (S.cam.thinlens) { apx = rng.next1D(); apy = rng.next1D(); }               // gpt.cpp:1262-1264
     const unsigned slot = (unsigned)sRel * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
 #pragma unroll 1
     for (int r = 0; r < 5; r++) {
         d3 o, d;
         Float mint, maxt;
         const Float ox = r == 1 ? 1.0 : (r == 3 ? -1.0 : 0.0), oy = r == 2 ? 1.0 : (r == 4 ? -1.0 : 0.0);     // gpt.cpp:410-415
-        camera_ray(S.cam, sx + ox, sy + oy, o, d, mint, maxt);
+        camera_ray(S.cam, sx + ox, sy + oy, apx, apy, o, d, mint, maxt);
         Hit h;
         trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, h);
         F.pHit[(size_t)(3 * r) * F.qCapacity + slot] = h.t;

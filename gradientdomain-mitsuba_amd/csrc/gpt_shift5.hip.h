@@ -151,9 +151,11 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_shift5(SceneD S, Confi
                         rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
                         sx = px + rng.next1D();                                              // gpt.cpp:1261
                         sy = py + rng.next1D();
+                        Float apx = 0.5, apy = 0.5;
+                        if (S.cam.thinlens) { apx = rng.next1D(); apy = rng.next1D(); }     // gpt.cpp:1262-1264
                         d3 o, d;
                         Float mint, maxt;
-                        camera_ray(S.cam, sx + (isBase ? 0.0 : offset_shift_x(oi)), sy + (isBase ? 0.0 : offset_shift_y(oi)), o, d, mint, maxt);
+                        camera_ray(S.cam, sx + (isBase ? 0.0 : offset_shift_x(oi)), sy + (isBase ? 0.0 : offset_shift_y(oi)), apx, apy, o, d, mint, maxt);
                         Hit h;
                         h.t = F.pHit[(size_t)(3 * role) * F.qCapacity + slot];
                         h.u = F.pHit[(size_t)(3 * role + 1) * F.qCapacity + slot];

@@ -39,7 +39,7 @@ class Environment(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("type", C.c_int), ("apertureRadius", C.c_double), ("focusDistance", C.c_double)]
 
 
 class Config(C.Structure):
@@ -96,6 +96,8 @@ class Scene:
         cam = Camera()
         cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
         cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height
+        if getattr(desc, "thinlens", None):                 # (apertureRadius, focusDistance) of a `thinlens` sensor
+            cam.type, cam.apertureRadius, cam.focusDistance = 1, float(desc.thinlens[0]), float(desc.thinlens[1])
         self._h = C.c_void_p()
         envd = getattr(desc, "environment", None)
         env = None

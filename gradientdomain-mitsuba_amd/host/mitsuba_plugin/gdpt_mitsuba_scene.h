@@ -233,13 +233,20 @@ inline void flatten(const Scene *scene, const Sensor *sensor, const Vector2i &si
 		} else if (cls != "AreaLight")
 			SLog(EError, "gdpt: emitter \"%s\" is not carried (area, point, constant, envmap)", cls.c_str());
 	}
-	if (sensor->getClass()->getName() != "PerspectiveCameraImpl" && sensor->getClass()->getName() != "PerspectiveCamera")
-		SLog(EError, "gdpt: sensor \"%s\" is not carried (perspective)", sensor->getClass()->getName().c_str());
+	const std::string scls = sensor->getClass()->getName();
+	if (scls != "PerspectiveCameraImpl" && scls != "PerspectiveCamera" && scls != "ThinLens")
+		SLog(EError, "gdpt: sensor \"%s\" is not carried (perspective, thinlens)", scls.c_str());
 	const PerspectiveCamera *pc = static_cast<const PerspectiveCamera *>(sensor);
 	const Matrix4x4 &M = pc->getWorldTransform()->eval(0).getMatrix();
 	for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) fs.cam.toWorld[4 * r + c] = M(r, c);
 	fs.cam.fovX = pc->getXFov(); fs.cam.nearClip = pc->getNearClip(); fs.cam.farClip = pc->getFarClip();
 	fs.cam.width = size.x; fs.cam.height = size.y;
+	if (scls == "ThinLens") {                                                              /* thinlens.cpp:236-244: both are plain properties */
+		fs.cam.type = GDPT_SENSOR_THINLENS;
+		fs.cam.apertureRadius = sensor->getProperties().getFloat("apertureRadius");
+		if (fs.cam.apertureRadius == 0) fs.cam.apertureRadius = Epsilon;                    /* :134-138 */
+		fs.cam.focusDistance = pc->getFocusDistance();                                      /* ProjectiveCamera::getFocusDistance, sensor.h */
+	}
 }
 
 inline void check(int rc) { if (rc != GDPT_OK) SLog(EError, "gdpt: %s", gdpt_last_error()); }

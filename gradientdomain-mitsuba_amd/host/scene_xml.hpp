@@ -355,7 +355,8 @@ private:
 
     void sensor(const xml::Node &n, SceneData &sd)
     {
-        if (subst(n.get("type")) != "perspective") logError(format("sensor \"%s\" is not carried: `perspective` only", n.get("type").c_str()));
+        const std::string stype = subst(n.get("type"));
+        if (stype != "perspective" && stype != "thinlens") logError(format("sensor \"%s\" is not carried: `perspective`, `thinlens`", n.get("type").c_str()));
         Properties p = props(n);
         Mat4 toWorld = Mat4::identity();
         bool haveFilm = false;
@@ -390,6 +391,12 @@ private:
         sd.camera.farClip = p.getFloat("farClip", 1e4);
         sd.camera.width = W;
         sd.camera.height = H;
+        if (stype == "thinlens") {                                       // thinlens.cpp:236-244, sensor.cpp (ProjectiveCamera: focusDistance, default farClip)
+            sd.camera.type = GDPT_SENSOR_THINLENS;
+            sd.camera.apertureRadius = p.getFloat("apertureRadius", 0.0);
+            if (sd.camera.apertureRadius == 0.0) sd.camera.apertureRadius = 1e-7;        // "Can't have a zero aperture radius -- setting to Epsilon", thinlens.cpp:134-138
+            sd.camera.focusDistance = p.getFloat("focusDistance", sd.camera.farClip);
+        }
     }
 
     int bsdf(const xml::Node &n, SceneData &sd)

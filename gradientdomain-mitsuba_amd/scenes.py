@@ -86,6 +86,7 @@ class Scene:
     environment_map: dict = None  # `<emitter type="envmap">`: dict(rgb [h, w, 3] linear latitude-longitude map (top row = up), scale, toWorld 3x3, index); excludes `environment`
     textures: list = None        # bitmap textures: dicts with rgb [h, w, 3] (linear), wrapU/wrapV (TEXWRAP_*), filter (TEXFILTER_*), uscale, vscale, uoffset, voffset, scale
     material_textures: list = None   # per material: texture index on its reflectance / specularReflectance, -1 = constant
+    thinlens: tuple = None       # (apertureRadius, focusDistance) of `<sensor type="thinlens">`; None = `perspective`
 
     @property
     def ntri(self):

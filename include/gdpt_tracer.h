@@ -66,7 +66,12 @@ typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective
     double fovX;                /* degrees (`fov`, fovAxis = x)                                    */
     double nearClip, farClip;
     int    width, height;       /* film size in pixels                                             */
+    int    type;                /* GDPT_SENSOR_PERSPECTIVE (0) | GDPT_SENSOR_THINLENS: `thinlens` (src/sensors/thinlens.cpp), the aperture sample of gpt.cpp:1262-1264 */
+    double apertureRadius;      /* thinlens `apertureRadius`                                        */
+    double focusDistance;       /* thinlens `focusDistance`                                         */
 } gdpt_camera;
+#define GDPT_SENSOR_PERSPECTIVE 0
+#define GDPT_SENSOR_THINLENS    1
 
 /* GradientPathTracerConfig (gpt.h:35-68) + sampler settings.  minDepth is forced to 1 (gpt.cpp:1369). */
 typedef struct gdpt_config {

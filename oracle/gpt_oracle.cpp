@@ -165,6 +165,8 @@ typedef struct gpo_camera {
     double fovX;        // degrees
     double nearClip, farClip;
     int width, height;
+    int type;           // 0 perspective, 1 thinlens (src/sensors/thinlens.cpp)
+    double apertureRadius, focusDistance;
 } gpo_camera;
 
 typedef struct gpo_config {
@@ -1302,23 +1304,34 @@ EnvShiftResult environmentShift(const Scene &sc, const Ray &mainRay, V3 shiftSou
 }
 
 // ---- sensor: PerspectiveCameraImpl::sampleRayDifferential, perspective.cpp:271-298 -----------------------
-void sampleRay(const Scene &sc, Float px, Float py, Ray &ray)
+// ... and ThinLensCamera::sampleRayDifferential, thinlens.cpp:324-361 (apx, apy = the aperture sample, ignored by the pinhole)
+void sampleRay(const Scene &sc, Float px, Float py, Ray &ray, Float apx = 0.5, Float apy = 0.5)
 {
     const gpo_camera &c = sc.cam;
     const Float sxn = px * (1.0 / c.width), syn = py * (1.0 / c.height);
     // m_sampleToCamera(Point(sx, sy, 0)) for the composite of perspective.cpp:150-156 with crop == film, written out:
     V3 nearP((1 - 2 * sxn) * c.nearClip * sc.tanHalf, (1 - 2 * syn) / sc.aspect * c.nearClip * sc.tanHalf, c.nearClip);
-    V3 d = normalize(nearP);
+    // m_dx = sampleToCamera(1/width, 0, 0) - sampleToCamera(0), m_dy likewise (perspective.cpp:160-163, thinlens.cpp:171-174), with the same written-out composite
+    const V3 mdx(-2 * (1.0 / c.width) * c.nearClip * sc.tanHalf, 0.0, 0.0), mdy(0.0, -2 * (1.0 / c.height) / sc.aspect * c.nearClip * sc.tanHalf, 0.0);
+    const double *M = c.toWorld;
+    V3 d, dx, dy, ol(0.0);
+    if (c.type == 1) {
+        Float tx, ty;
+        squareToUniformDiskConcentric(apx, apy, tx, ty);                    // thinlens.cpp:326-327
+        ol = V3(tx * c.apertureRadius, ty * c.apertureRadius, 0.0);         // apertureP
+        const Float fDist = c.focusDistance / nearP.z;                      // :340-343
+        const V3 focusP = nearP * fDist, focusPx = (nearP + mdx) * fDist, focusPy = (nearP + mdy) * fDist;
+        d = normalize(focusP - ol);
+        dx = normalize(focusPx - ol); dy = normalize(focusPy - ol);         // :356-357
+    } else {
+        d = normalize(nearP);
+        dx = normalize(nearP + mdx); dy = normalize(nearP + mdy);           // perspective.cpp:293-294
+    }
     Float invZ = 1.0 / d.z;
     ray.mint = c.nearClip * invZ;
     ray.maxt = c.farClip * invZ;
-    const double *M = c.toWorld;
-    ray.o = V3(M[3], M[7], M[11]);
+    ray.o = V3(M[0] * ol.x + M[1] * ol.y + M[2] * ol.z + M[3], M[4] * ol.x + M[5] * ol.y + M[6] * ol.z + M[7], M[8] * ol.x + M[9] * ol.y + M[10] * ol.z + M[11]);   // trafo.transformAffine(apertureP); rxOrigin = ryOrigin = o
     ray.d = V3(M[0] * d.x + M[1] * d.y + M[2] * d.z, M[4] * d.x + M[5] * d.y + M[6] * d.z, M[8] * d.x + M[9] * d.y + M[10] * d.z);
-    // rxDirection / ryDirection = trafo(normalize(nearP + m_dx / m_dy)), perspective.cpp:293-294; m_dx = sampleToCamera(1/width, 0, 0) -
-    // sampleToCamera(0), m_dy likewise (:160-163), with the same written-out composite
-    const V3 mdx(-2 * (1.0 / c.width) * c.nearClip * sc.tanHalf, 0.0, 0.0), mdy(0.0, -2 * (1.0 / c.height) / sc.aspect * c.nearClip * sc.tanHalf, 0.0);
-    const V3 dx = normalize(nearP + mdx), dy = normalize(nearP + mdy);
     ray.rxD = V3(M[0] * dx.x + M[1] * dx.y + M[2] * dx.z, M[4] * dx.x + M[5] * dx.y + M[6] * dx.z, M[8] * dx.x + M[9] * dx.y + M[10] * dx.z);
     ray.ryD = V3(M[0] * dy.x + M[1] * dy.y + M[2] * dy.z, M[4] * dy.x + M[5] * dy.y + M[6] * dy.z, M[8] * dy.x + M[9] * dy.y + M[10] * dy.z);
     ray.hasDifferentials = true;
@@ -1872,11 +1885,13 @@ void renderSample(const Scene &sc, const gpo_config &cfg, Rng &rng, int px, int 
 {
     static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};                 // gpt.cpp:410-415
     const double sx = px + rng.next1D(), sy = py + rng.next1D();               // :1261
+    double apx = 0.5, apy = 0.5;
+    if (sc.cam.type == 1) { apx = rng.next1D(); apy = rng.next1D(); }           // :1262-1264 (needsApertureSample); the time sample is never needed (no shutter)
     RayState mainRay;
-    sampleRay(sc, sx, sy, mainRay.ray);                                        // evaluatePoint, :397-436
+    sampleRay(sc, sx, sy, mainRay.ray, apx, apy);                              // evaluatePoint, :397-436: base and offsets share the aperture sample
     mainRay.throughput = V3(1.0);
     RayState shiftedRays[4];
-    for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], shiftedRays[i].ray); shiftedRays[i].throughput = V3(1.0); }
+    for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], shiftedRays[i].ray, apx, apy); shiftedRays[i].throughput = V3(1.0); }
     V3 veryDirect(0.0);
     evaluate(sc, cfg, rng, mainRay, shiftedRays, 4, veryDirect);
     const V3 T = mainRay.radiance;
@@ -2240,11 +2255,13 @@ GPO_API void gpo_evaluate_point(gpo_scene *h, const gpo_config *cfg, int px, int
     static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
     Rng rng(cfg->seed, (uint64_t)py * sc.cam.width + px, (uint64_t)sampleIndex);
     const double sx = px + rng.next1D(), sy = py + rng.next1D();
+    double apx = 0.5, apy = 0.5;
+    if (sc.cam.type == 1) { apx = rng.next1D(); apy = rng.next1D(); }
     RayState mainRay;
-    sampleRay(sc, sx, sy, mainRay.ray);
+    sampleRay(sc, sx, sy, mainRay.ray, apx, apy);
     mainRay.throughput = V3(1.0);
     RayState sh[4];
-    for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], sh[i].ray); sh[i].throughput = V3(1.0); }
+    for (int i = 0; i < 4; ++i) { sampleRay(sc, sx + shifts[i][0], sy + shifts[i][1], sh[i].ray, apx, apy); sh[i].throughput = V3(1.0); }
     V3 vd(0.0);
     evaluate(sc, *cfg, rng, mainRay, sh, 4, vd);
     double *o = out30;
@@ -2293,6 +2310,14 @@ GPO_API int gpo_intersect(gpo_scene *h, const double *o, const double *d, double
     out_t_p_wi[4] = its.wi.x; out_t_p_wi[5] = its.wi.y; out_t_p_wi[6] = its.wi.z;
     return its.prim;
 }
+GPO_API void gpo_camera_ray_ap(gpo_scene *h, double px, double py, double apx, double apy, double *out14)
+{   // with the aperture sample and the two differential directions: o(3), d(3), mint, maxt, rxD(3), ryD(3)
+    Ray r;
+    sampleRay(h->sc, px, py, r, apx, apy);
+    double *o = out14;
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.mint; o[7] = r.maxt;
+    o[8] = r.rxD.x; o[9] = r.rxD.y; o[10] = r.rxD.z; o[11] = r.ryD.x; o[12] = r.ryD.y; o[13] = r.ryD.z;
+}
 GPO_API void gpo_camera_ray(gpo_scene *h, double px, double py, double *out8)
 {
     Ray r;
@@ -2317,7 +2342,10 @@ GPO_API void gpo_reference_pt(gpo_scene *h, const gpo_config *cfg, int px, int p
     for (int j = 0; j < n; ++j) {
         Rng rng(cfg->seed ^ 0xABCDEF1234567ULL, (uint64_t)py * sc.cam.width + px, (uint64_t)j);
         Ray ray;
-        sampleRay(sc, px + rng.next1D(), py + rng.next1D(), ray);
+        const Float fx = px + rng.next1D(), fy = py + rng.next1D();
+        Float ax = 0.5, ay = 0.5;
+        if (sc.cam.type == 1) { ax = rng.next1D(); ay = rng.next1D(); }
+        sampleRay(sc, fx, fy, ray, ax, ay);
         Intersection its;
         if (!rayIntersect(sc, ray, its)) continue;
         V3 beta(1.0), L(0.0);

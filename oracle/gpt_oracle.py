@@ -25,7 +25,7 @@ class Emitter(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("type", C.c_int), ("apertureRadius", C.c_double), ("focusDistance", C.c_double)]
 
 
 class Config(C.Structure):
@@ -159,6 +159,8 @@ class Scene:
         cam = Camera()
         cam.toWorld = (C.c_double * 16)(*np.asarray(desc.to_world, np.float64).ravel())
         cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height
+        if getattr(desc, "thinlens", None):                 # (apertureRadius, focusDistance) of a `thinlens` sensor
+            cam.type, cam.apertureRadius, cam.focusDistance = 1, float(desc.thinlens[0]), float(desc.thinlens[1])
         self.W, self.H = desc.width, desc.height
         self._h = lib().gpo_scene_create(verts.shape[0], _p(verts), _p(tm), len(desc.materials), C.byref(mats),
                                          len(desc.emitters), C.byref(ems), C.byref(cam))
@@ -263,7 +265,12 @@ class Scene:
         prim = lib().gpo_intersect(self._h, _p(_d(o)), _p(_d(d)), _p(out))
         return prim, out[0], out[1:4], out[4:7]
 
-    def camera_ray(self, px, py):
+    def camera_ray(self, px, py, ap=None):
+        if ap is not None:                                      # with an aperture sample: also the differential directions
+            out = np.zeros(14)
+            lib().gpo_camera_ray_ap.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
+            lib().gpo_camera_ray_ap(self._h, px, py, ap[0], ap[1], _p(out))
+            return out[0:3], out[3:6], out[6], out[7], out[8:11], out[11:14]
         out = np.zeros(8)
         lib().gpo_camera_ray(self._h, px, py, _p(out))
         return out[0:3], out[3:6], out[6], out[7]

@@ -23,6 +23,7 @@
 
 MTS_NAMESPACE_BEGIN
 typedef double Float;                                   // the reference's DOUBLE_PRECISION build
+#define Epsilon 1e-7                                   // core/constants.h:25
 enum ELogLevel { EDebug, EInfo, EWarn, EError };
 inline void mockLog(ELogLevel lvl, const char *fmt, ...)
 {
@@ -148,7 +149,7 @@ public:
 private:
     Film m_film; AnimatedTransform m_t;
 };
-class PerspectiveCamera : public Sensor { public: Float getXFov() const { return 40; } Float getNearClip() const { return 0.01; } Float getFarClip() const { return 1e4; } };
+class PerspectiveCamera : public Sensor { public: Float getXFov() const { return 40; } Float getNearClip() const { return 0.01; } Float getFarClip() const { return 1e4; } Float getFocusDistance() const { return 1e4; } };
 
 struct Intersection { Frame shFrame, geoFrame; Point2 uv; };
 struct DirectSamplingRecord { DirectSamplingRecord(const Point &, Float) {} };

@@ -1056,3 +1056,61 @@ def test_every_shipped_instantiation_agrees_with_the_general_kernel_and_the_orac
         else:
             assert np.allclose(acc, ref, rtol=1e-12, atol=1e-12), (name, hbm, vname)
     S.close(); O.close()
+
+
+@pytest.mark.parametrize("variant,md,strict,lens", [("diffuse", -1, False, (25.0, 700.0)), ("glossy", 9, True, (40.0, 900.0)), ("glass", 10, False, (8.0, 1100.0)),
+                                                    ("bent", 6, True, (25.0, 820.0))])
+def test_thinlens_sensor_samples_and_films_match_oracle(G, variant, md, strict, lens):
+    """`<sensor type="thinlens">` (src/sensors/thinlens.cpp; the aperture sample of gpt.cpp:1262-1264, shared by the base ray and its four offsets):
+    single samples and whole films against the oracle, ray for ray, through the staged pipeline and the single kernel, for the LDS-resident and the
+    HBM-resident builds' feature sets (flat, per-vertex normals)."""
+    W, H = 40, 32
+    sc = scenes.cornell_box(W, H, variant); sc.thinlens = lens
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict)
+    rng = np.random.default_rng(29)
+    for _ in range(30):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
+        g = S.evaluate_point(integ.config(64), px, py, s)
+        o = O.evaluate_point(go.config(maxDepth=md, spp=64, strictNormals=strict), px, py, s)
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (variant, px, py, s, k)
+        assert (g["raysTraced"], g["shadowRaysTraced"]) == (o["raysTraced"], o["shadowRaysTraced"])
+    spp = 3
+    oacc, orays = O.render(go.config(maxDepth=md, spp=spp, strictNormals=strict))
+    for pipeline in (2, 0):
+        F = G.Film(S); F.set_pipeline(pipeline)
+        integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        F.close()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (pipeline, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    # a lens is not a pinhole: the film differs from the perspective render of the same scene
+    pin = scenes.cornell_box(W, H, variant)
+    pacc, _ = go.Scene(pin).render(go.config(maxDepth=md, spp=spp, strictNormals=strict))
+    assert not close(oacc[1], pacc[1], rel=1e-3)
+
+
+def test_thinlens_sensor_argument_checks_and_scope(G):
+    sc = scenes.cornell_box(16, 12, "diffuse"); sc.thinlens = (0.0, 500.0)
+    with pytest.raises(RuntimeError, match="apertureRadius"):
+        G.Scene(sc)
+    sc.thinlens = (10.0, 0.0)
+    with pytest.raises(RuntimeError, match="focusDistance"):
+        G.Scene(sc)
+    # lookups filtered by a camera ray's differentials take their footprint from the pinhole: refused with a lens, never evaluated with the wrong one
+    tx = scenes.textured_cornell_box(16, 12, filter=scenes.TEXFILTER_EWA); tx.thinlens = (10.0, 500.0)
+    with pytest.raises(RuntimeError, match="thinlens"):
+        G.Scene(tx)
+    tb = scenes.textured_cornell_box(16, 12, filter=scenes.TEXFILTER_BILINEAR); tb.thinlens = (10.0, 500.0)
+    S, O = G.Scene(tb), go.Scene(tb)
+    integ = G.GradientPathIntegrator(maxDepth=4)
+    g = S.evaluate_point(integ.config(8), 7, 6, 3); o = O.evaluate_point(go.config(maxDepth=4, spp=8), 7, 6, 3)
+    assert np.allclose(g["throughput"], o["throughput"], rtol=1e-10, atol=1e-14)
+    # G-BDPT samples the sensor itself (aperture position, importance): only the pinhole is carried there
+    import gradientdomain_mitsuba_amd.gbdpt as B
+    rough = scenes.cornell_box(16, 12, "rough"); rough.thinlens = (10.0, 500.0)
+    Sb = G.Scene(rough)
+    with pytest.raises(RuntimeError, match="thinlens"):
+        B.GBDPTIntegrator().render(Sb, 1)

@@ -529,3 +529,48 @@ def test_environment_map_known_answers():
     Rr = go.Scene(rot)
     d = np.array([0.3, 0.5, -0.6]); d /= np.linalg.norm(d)
     assert np.allclose(Rr.envmap_eval(R @ d), O.envmap_eval(d), rtol=1e-12)
+
+
+def test_thinlens_sensor_known_answers():
+    """`<sensor type="thinlens">` (src/sensors/thinlens.cpp:324-361) as restated in sampleRay: every ray of a pixel passes through the SAME point of
+    the focal plane whatever its aperture sample (that is what "in focus" means) and that point is where the pinhole ray of the pixel meets the plane
+    z = focusDistance of the camera frame; ray origins lie on the aperture disk (radius, camera plane z = 0); the centre of the aperture gives the
+    pinhole ray; the differential directions aim at the neighbouring pixels' focus points; and G-PT with a lens still converges to a plain path tracer
+    that draws its own lens samples."""
+    W, H = 40, 28
+    sc = scenes.cornell_box(W, H, "diffuse")
+    pin = go.Scene(sc)
+    fd, rad = 700.0, 25.0
+    sc2 = scenes.cornell_box(W, H, "diffuse"); sc2.thinlens = (rad, fd)
+    O = go.Scene(sc2)
+    M = np.asarray(sc.to_world, float)
+    rng = np.random.default_rng(3)
+    for px, py in ((20.3, 14.2), (3.7, 25.1), (38.9, 0.4)):
+        po_, pd_, pmint, pmaxt = pin.camera_ray(px, py)
+        dz = pd_ @ M[:3, 2]                                    # cosine to the optical axis
+        focus = po_ + pd_ * (fd / dz)
+        o0, d0, mint0, maxt0, rx0, ry0 = O.camera_ray(px, py, (0.5, 0.5))
+        assert np.allclose(o0, po_, atol=1e-12) and np.allclose(d0, pd_, atol=1e-14)                 # centre of the lens = the pinhole
+        assert np.isclose(mint0, pmint) and np.isclose(maxt0, pmaxt)
+        fx = pin.camera_ray(px + 1, py); fy = pin.camera_ray(px, py + 1)
+        for ap in rng.random((6, 2)):
+            o, d, mint, maxt, rxD, ryD = O.camera_ray(px, py, ap)
+            local = np.linalg.solve(M[:3, :3], o - M[:3, 3])
+            assert abs(local[2]) < 1e-9 and np.hypot(local[0], local[1]) <= rad * (1 + 1e-12)
+            t = ((focus - o) @ M[:3, 2]) / (d @ M[:3, 2])
+            assert np.allclose(o + d * t, focus, atol=1e-9)                                          # through the pixel's focus point
+            for dd, f in ((rxD, fx), (ryD, fy)):                                                     # differentials: towards the neighbours' focus points
+                fo, fdv = f[0], f[1]
+                nf = fo + fdv * (fd / (fdv @ M[:3, 2]))
+                tt = ((nf - o) @ M[:3, 2]) / (dd @ M[:3, 2])
+                assert np.allclose(o + dd * tt, nf, atol=1e-9)
+            assert np.isclose(mint * (d @ M[:3, 2]), sc.near) and np.isclose(maxt * (d @ M[:3, 2]), sc.far)
+    # the two extra random numbers are drawn after the film position (gpt.cpp:1261-1264): a lens sample changes the rays, not the pixel
+    cfg = go.config(maxDepth=4, spp=1)
+    a = pin.evaluate_point(cfg, 20, 14, 0); b = O.evaluate_point(cfg, 20, 14, 0)
+    assert not np.allclose(a["throughput"], b["throughput"])
+    px, py = 22, 13
+    ref = O.reference_pt(go.config(maxDepth=5, spp=1), px, py, 60000)
+    acc, _ = O.render(go.config(maxDepth=5, spp=4000), rect=(px - 1, py - 1, px + 2, py + 2))
+    thr = go.develop(acc)[1][py, px]
+    assert np.allclose(thr, ref, rtol=0.08), (thr, ref)

@@ -603,3 +603,31 @@ def test_cli_gbdpt_integrator_equals_python_mirror(cli, tmp_path, gpu_required):
     open(xm, "w").write(xs.replace("</scene>", '<shape type="rectangle"><transform name="toWorld"><scale value="50"/><translate x="270" y="200" z="300"/></transform><bsdf type="conductor"><rgb name="eta" value="1,1,1"/><rgb name="k" value="3,3,3"/></bsdf></shape></scene>'))
     bad = run(cli, "-o", dest + "m", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xm)
     assert bad.returncode == 1 and "Dirac" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cli_thinlens_sensor_equals_python_mirror(cli, tmp_path, gpu_required):
+    """`<sensor type="thinlens">` with apertureRadius / focusDistance through the scene reader == the Python mirror with the same lens; a zero aperture
+    radius becomes Epsilon as in thinlens.cpp:134-138 (and then renders what the pinhole renders, up to the two extra random numbers per sample)."""
+    import shutil
+    import gradientdomain_mitsuba_amd.gpt as G
+    shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    src = open(XML).read()
+    assert '<sensor type="perspective">' in src
+    xml = src.replace('<sensor type="perspective">', '<sensor type="thinlens"><float name="apertureRadius" value="30"/><float name="focusDistance" value="900"/>')
+    xl = str(tmp_path / "lens.xml"); open(xl, "w").write(xml)
+    dest = str(tmp_path / "lens")
+    r = run(cli, "-o", dest, "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xl)
+    assert r.returncode == 0, r.stderr
+    sc = scenes.cornell_box(40, 30); sc.thinlens = (30.0, 900.0)
+    out = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
+    for suffix in G.BUFFER_NAMES:
+        assert np.allclose(read_pfm(dest + suffix + ".pfm"), out[suffix], rtol=2e-6, atol=1e-7), suffix
+    pin = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
+    assert not np.allclose(out["-throughput"], pin["-throughput"], rtol=1e-3)
+    xz = str(tmp_path / "lens0.xml"); open(xz, "w").write(xml.replace('value="30"', 'value="0"'))
+    r = run(cli, "-o", str(tmp_path / "lens0"), "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xz)
+    assert r.returncode == 0, r.stderr
+    sc0 = scenes.cornell_box(40, 30); sc0.thinlens = (1e-7, 900.0)
+    out0 = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc0), 4)
+    assert np.allclose(read_pfm(str(tmp_path / "lens0") + "-throughput.pfm"), out0["-throughput"], rtol=2e-6, atol=1e-7)

@@ -1,8 +1,10 @@
-# Bench lines of BASELINE configs 1, 3 and 4 on one GPU (config 2 is the default bench line): gpurun -- 'TAG=r02b bash tools/bench_configs.sh'
+# Bench lines of BASELINE configs 1-5 on one GPU (config 2 with the CPU baseline = the default bench line): gpurun -- 'TAG=r02b bash tools/bench_configs.sh'
 cd $GRAFT_REPO_ROOT
 TAG=${TAG:-r02b}
 mkdir -p gpurun_out
 timeout 300 python bench.py --config 1 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config1.json 2> gpurun_out/${TAG}_bench_config1.err
 timeout 600 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config3.json 2> gpurun_out/${TAG}_bench_config3.err
 timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config4.json 2> gpurun_out/${TAG}_bench_config4.err
-for c in 1 3 4; do cut -c1-700 gpurun_out/${TAG}_bench_config$c.json; tail -2 gpurun_out/${TAG}_bench_config$c.err; done
+timeout 600 python bench.py > gpurun_out/${TAG}_bench_config2.json 2> gpurun_out/${TAG}_bench_config2.err
+timeout 900 python bench.py --config 5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${TAG}_bench_config5.json 2> gpurun_out/${TAG}_bench_config5.err
+for c in 1 2 3 4 5; do cut -c1-700 gpurun_out/${TAG}_bench_config$c.json; tail -2 gpurun_out/${TAG}_bench_config$c.err; done
