@@ -124,6 +124,7 @@ __global__ __launch_bounds__(TBLK) void k_bd_walk(SceneD S, BdCam cam, BdConfig 
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); atomicAdd(stats + 2, (unsigned long long)n); }
 }
 
+template <int CLS>
 __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ items, unsigned nItems,
                                                      Float *__restrict__ acc, Float *__restrict__ light, unsigned long long *__restrict__ stats)
 {
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
         const unsigned lid = it >> 10;
         const int s = (int)((it >> 5) & 31u), t = (int)(it & 31u);
         PairOut po;
-        if (connect_pair(c, recs[lid], s, t, po)) {
-            if (t >= 2) {
+        if (connect_pair<CLS>(c, recs[lid], s, t, po)) {
+            if (CLS != 0) {
                 Float *a = acc + (size_t)lid * 15;
                 atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z);
                 for (int n = 0; n < 4; n++) { atomicAdd(a + 3 + 3 * n, po.gradient[n].x); atomicAdd(a + 4 + 3 * n, po.gradient[n].y); atomicAdd(a + 5 + 3 * n, po.gradient[n].z); }
@@ -341,7 +342,11 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         BHIPCHK(hipStreamSynchronize(f->stream));                                          // the sizes of the connection launches come from the walk
         for (int q = 0; q < 3; q++) {
             if (!nItems[q]) continue;
-            hipLaunchKernelGGL(k_bd_connect, dim3((nItems[q] + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->items + q * itemStride, nItems[q], f->acc, f->light, f->stats);
+            const dim3 cgrid((nItems[q] + TBLK - 1) / TBLK);
+            const unsigned *list = f->items + q * itemStride;
+            if (q == 0) hipLaunchKernelGGL(k_bd_connect<0>, cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], f->acc, f->light, f->stats);
+            else if (q == 1) hipLaunchKernelGGL(k_bd_connect<1>, cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], f->acc, f->light, f->stats);
+            else hipLaunchKernelGGL(k_bd_connect<2>, cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], f->acc, f->light, f->stats);
             BHIPCHK(hipGetLastError());
         }
         hipLaunchKernelGGL(k_bd_put, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, f->recs, f->acc, count, f->W, f->H, f->block, f->stats);

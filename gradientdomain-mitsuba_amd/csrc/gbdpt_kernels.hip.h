@@ -618,94 +618,104 @@ __device__ __forceinline__ const BV &PE(const PathRef &p, int i, int s) { if (p.
 __device__ __forceinline__ const BE &PEe(const PathRef &p, int i, int s) { if (p.ovEm1 && i == s - 1) return *p.ovEm1; return p.ee[i]; }
 __device__ __forceinline__ const BV &PS(const PathRef &p, int i, int t) { if (p.ovT && i == t) return *p.ovT; return SV(*p.sm, p.k, i); }
 
-__device__ void collect_pdfs(const Ctx &c, const PathRef &p, const BE &connectionEdge, int s, int t, Float *pdfImp, Float *pdfRad)
+// The densities of the reference are two arrays pdfImp[0..n], pdfRad[0..n] (n = s + t + 1) per path; strategy p has the density
+// value[p] = pdfImp[1] .. pdfImp[p] * pdfRad[p + 1] .. pdfRad[n - 1].  The first wavefront form kept those arrays (and the prefix / suffix products)
+// per lane: 1.5 KB of dynamically indexed scratch per connection, written and read back -- the PMC pass of k_bd_connect showed 64 GB written and
+// 103 GB read PER LAUNCH, 7.6 KB per connection, 82 % of the wave cycles waiting.  Nothing needs the arrays: both weights are ratios of SUMS of
+// strategy densities, and a sum over p of (prefix product) x (suffix product) is a Horner recurrence over the entries in reverse order,
+//     R(p) = pdfRad[p + 1] R(p + 1),  G(p) = a_p R(p) + pdfImp[p + 1] G(p + 1),  G(n - 1) = a_(n-1), R(n - 1) = 1   =>   sum_p a_p value[p] = G(0)
+// (a_p = 1 for an allowed strategy), and the same with squared entries for the power heuristic.  The entries are read straight from the
+// sample's record as the recurrence walks the path; the four densities evaluated AT the connection are the only ones computed.
+struct ConnPdfs { Float impS, impT, radS, radT; };      // pdfImp[s + 1], pdfImp[s + 2], pdfRad[s - 1], pdfRad[s] (path.cpp:99-132,264-307)
+__device__ ConnPdfs conn_pdfs(const Ctx &c, const PathRef &p, const BE &connectionEdge, int s, int t)
 {
     const BV *vsPred = s > 0 ? &PE(p, s - 1, s) : nullptr, *vtPred = t > 0 ? &PS(p, t - 1, t) : nullptr;
     const BV &vs = PE(p, s, s), &vt = PS(p, t, t);
-    int pos = 0;
-    pdfImp[pos++] = 1.0;
-    for (int i = 0; i < s; ++i) pdfImp[pos++] = PE(p, i, s).pdf[EImportance] * PEe(p, i, s).tr[EImportance];
-    pdfImp[pos++] = bv_eval_pdf(c, vs, vsPred, &vt, EImportance, M_AREA) * connectionEdge.tr[EImportance];
-    if (t > 0) {
-        pdfImp[pos++] = bv_eval_pdf(c, vt, &vs, vtPred, EImportance, M_AREA) * SE(*p.sm, p.k, t - 1).tr[EImportance];
-        for (int i = t - 1; i > 0; --i) pdfImp[pos++] = PS(p, i, t).pdf[EImportance] * SE(*p.sm, p.k, i - 1).tr[EImportance];
-    }
-    pos = 0;
-    if (s > 0) {
-        for (int i = 0; i < s - 1; ++i) pdfRad[pos++] = PE(p, i + 1, s).pdf[ERadiance] * PEe(p, i, s).tr[ERadiance];
-        pdfRad[pos++] = bv_eval_pdf(c, vs, &vt, vsPred, ERadiance, M_AREA) * PEe(p, s - 1, s).tr[ERadiance];
-    }
-    pdfRad[pos++] = bv_eval_pdf(c, vt, vtPred, &vs, ERadiance, M_AREA) * connectionEdge.tr[ERadiance];
-    for (int i = t; i > 0; --i) pdfRad[pos++] = PS(p, i - 1, t).pdf[ERadiance] * SE(*p.sm, p.k, i - 1).tr[ERadiance];
-    pdfRad[pos++] = 1.0;
+    ConnPdfs cp;
+    cp.impS = bv_eval_pdf(c, vs, vsPred, &vt, EImportance, M_AREA) * connectionEdge.tr[EImportance];
+    cp.impT = t > 0 ? bv_eval_pdf(c, vt, &vs, vtPred, EImportance, M_AREA) * SE(*p.sm, p.k, t - 1).tr[EImportance] : 0.0;
+    cp.radS = s > 0 ? bv_eval_pdf(c, vs, &vt, vsPred, ERadiance, M_AREA) * PEe(p, s - 1, s).tr[ERadiance] : 0.0;
+    cp.radT = bv_eval_pdf(c, vt, vtPred, &vs, ERadiance, M_AREA) * connectionEdge.tr[ERadiance];
+    return cp;
+}
+// entry i (1 <= i <= n - 1) of the two arrays
+__device__ __forceinline__ Float mis_imp(const PathRef &p, const ConnPdfs &cp, int s, int t, int i)
+{
+    if (i <= s) return PE(p, i - 1, s).pdf[EImportance] * PEe(p, i - 1, s).tr[EImportance];
+    if (i == s + 1) return cp.impS;
+    if (i == s + 2) return cp.impT;
+    const int v = t + s + 2 - i;                                                            // sensor vertex t - 1 .. 1
+    return PS(p, v, t).pdf[EImportance] * SE(*p.sm, p.k, v - 1).tr[EImportance];
+}
+__device__ __forceinline__ Float mis_rad(const PathRef &p, const ConnPdfs &cp, int s, int t, int i)
+{
+    if (i <= s - 2) return PE(p, i + 1, s).pdf[ERadiance] * PEe(p, i, s).tr[ERadiance];
+    if (i == s - 1) return cp.radS;
+    if (i == s) return cp.radT;
+    const int v = t + s + 1 - i;                                                            // sensor vertex t .. 1
+    return PS(p, v - 1, t).pdf[ERadiance] * SE(*p.sm, p.k, v - 1).tr[ERadiance];
 }
 // NOTE on path.cpp:143-167,309-349 (area densities next to a non-connectable vertex converted to projected solid angle): the loops run over
 // i in [1, k-3] / [3, k-1] and fire only where connectableStrict[i] && !connectableStrict[i +- 1]; with every surface vertex connectable
 // the only non-connectable vertex is the sensor supernode (index k), outside both ranges: nothing to convert.
 
+// sum over the allowed strategies of value[p] (sum1) and of value[p]^2 (sum2, base path only), and value[s] = the density of the strategy in use
+template <bool SQUARES>
+__device__ __forceinline__ void mis_sums(const PathRef &p, const ConnPdfs &cp, int s, int t, unsigned allowed, Float &valueS, Float &sum1, Float &sum2)
+{
+    const int n = s + t + 1;
+    Float R = 1.0, G = (allowed >> (n - 1)) & 1u ? 1.0 : 0.0, R2 = 1.0, G2 = G, vS = 1.0;
+    for (int q = n - 2; q >= 0; --q) {
+        const int i = q + 1;
+        const Float im = mis_imp(p, cp, s, t, i), ra = mis_rad(p, cp, s, t, i);
+        vS *= i <= s ? im : ra;
+        R *= ra;
+        const bool a = (allowed >> q) & 1u;
+        G = (a ? R : 0.0) + im * G;
+        if (SQUARES) { R2 *= ra * ra; G2 = (a ? R2 : 0.0) + (im * im) * G2; }
+    }
+    valueS = vS; sum1 = G; sum2 = G2;
+}
+
 // Path::miWeightBaseNoSweep_GBDPT (path.cpp:49-201; exponent 2, geomTerm 1) and miWeightGradNoSweep_GBDPT (:204-378; exponent 1), restructured:
 // the reference rebuilds the base path's densities for each of the five paths of a connection and forms every strategy's density p_i by an
-// O(n) product (O(n^2) per weight).  Here the base path's p_i are computed ONCE per connection (k = 0) and kept for the four gradient
-// weights, and p_i = prefix(pdfImp)[i] * suffix(pdfRad)[i + 1] in O(n) -- same factors, another association of the products (a few ulp).
-struct MisBase { Float value[NMIS + 1], pdfImp[NMIS + 1], pdfRad[NMIS + 1]; unsigned allowed; int n; };
-__device__ __forceinline__ void strategy_densities(const Float *pdfImp, const Float *pdfRad, int n /* = s + t + 1 */, Float *value)
-{
-    Float suffix[NMIS + 2];
-    suffix[n] = 1.0;
-    for (int i = n - 1; i >= 1; --i) suffix[i] = pdfRad[i] * suffix[i + 1];
-    Float prefix = 1.0;
-    for (int p = 0; p < n; ++p) {
-        if (p >= 1) prefix *= pdfImp[p];
-        value[p] = prefix * suffix[p + 1];
-    }
-}
+// O(n) product (O(n^2) per weight).  Here each path's sums are one O(n) recurrence, the base path's are formed ONCE per connection and kept for
+// the four gradient weights (sum_p (b_p + j o_p) = sum_p b_p + j sum_p o_p) -- same factors, another association (a few ulp).
+struct MisBase { Float valueS, sum1; ConnPdfs cp; unsigned allowed; int n; };
 __device__ Float mi_weight_base(const Ctx &c, const Sample &sm, const PathRef &base, const BE &baseEdge, int s, int t, MisBase &mb)
 {
     const int k = s + t + 1;
-    collect_pdfs(c, base, baseEdge, s, t, mb.pdfImp, mb.pdfRad);
-    strategy_densities(mb.pdfImp, mb.pdfRad, k, mb.value);
     mb.n = k; mb.allowed = 0;
     const bool lightImage = c.cfg.lightImage != 0;
-    double sum = 0.0, p_st = 0.0;
     for (int p = 0; p < k; ++p) {
         const int tPrime = k - p - 1;
         // connectable[] of the BASE path (path.cpp:76-95,241-260): position p is emitter vertex p (p <= s) or sensor vertex k - p
         const BV &vp = p <= s ? sm.Y[p] : sm.X[k - p], &vp1 = p + 1 <= s ? sm.Y[p + 1] : sm.X[k - p - 1];
-        const bool allowed = connectable_gbdpt(c, vp) && connectable_gbdpt(c, vp1) && (lightImage || tPrime > 1);
-        if (allowed) { mb.allowed |= 1u << p; sum += mb.value[p] * mb.value[p]; }           // pow(p_i * 1, 2.0)
-        if (tPrime == t) p_st = mb.value[p] * mb.value[p];
+        if (connectable_gbdpt(c, vp) && connectable_gbdpt(c, vp1) && (lightImage || tPrime > 1)) mb.allowed |= 1u << p;
     }
-    return (Float)(p_st / sum);
+    mb.cp = conn_pdfs(c, base, baseEdge, s, t);
+    Float sum2;
+    mis_sums<true>(base, mb.cp, s, t, mb.allowed, mb.valueS, mb.sum1, sum2);
+    return (Float)((mb.valueS * mb.valueS) / sum2);                                         // pow(p_i * 1, 2.0); tPrime == t <=> p == s
 }
 __device__ Float mi_weight_grad(const Ctx &c, const MisBase &mb, const PathRef &offset, const BE &offsetEdge, int s, int t, Float jDet)
 {
-    Float oPdfImp[NMIS + 1], oPdfRad[NMIS + 1], oValue[NMIS + 1];
-    const int k = s + t + 1;
-    collect_pdfs(c, offset, offsetEdge, s, t, oPdfImp, oPdfRad);
-    strategy_densities(oPdfImp, oPdfRad, k, oValue);
-    double sum = 0.0;
-    for (int p = 0; p < k; ++p)
-        if (mb.allowed & (1u << p)) sum += mb.value[p] * 1.0 + oValue[p] * jDet * 1.0;       // pow(x, 1.0) == x
-    return (Float)(mb.value[s] / sum);                                                      // tPrime == t <=> p == s
+    const ConnPdfs cp = conn_pdfs(c, offset, offsetEdge, s, t);
+    Float oS, o1, o2;
+    mis_sums<false>(offset, cp, s, t, mb.allowed, oS, o1, o2);
+    return (Float)(mb.valueS / (mb.sum1 + o1 * jDet));                                       // pow(x, 1.0) == x
 }
 // The gradient weight of a connection whose sensor vertex t lies beyond the shifted part of the offset path (5 <= t < the last sensor vertex):
 // the offset path shares vs, vt, their predecessors and the connection edge with the base path, so the four densities evaluated at the
-// connection are the base path's, and its arrays differ from the base path's in the entries of sensor vertices 0..3 only.  Those seven
-// entries are patched in place (and restored): same values as collect_pdfs on the offset path, a fraction of its loads and no BSDF call.
+// connection are the base path's (no BSDF call) and only the entries of sensor vertices 0..3 differ, which the walk reads from the offset's record.
 __device__ __forceinline__ bool shares_connection(const Sample &sm, int t) { return t >= 5 && t < sm.nX - 1; }
-__device__ Float mi_weight_grad_shared(MisBase &mb, const Sample &sm, int k, int s, int t, Float jDet)
+__device__ Float mi_weight_grad_shared(const MisBase &mb, const PathRef &base, int k, int s, int t, Float jDet)
 {
-    Float oValue[NMIS + 1], saveI[3], saveR[4];
-    const int n = s + t + 1;
-    for (int i = 1; i <= 3; i++) { const int at = s + 2 + (t - i); saveI[i - 1] = mb.pdfImp[at]; mb.pdfImp[at] = SV(sm, k, i).pdf[EImportance] * SE(sm, k, i - 1).tr[EImportance]; }
-    for (int i = 1; i <= 4; i++) { const int at = s + 1 + (t - i); saveR[i - 1] = mb.pdfRad[at]; mb.pdfRad[at] = SV(sm, k, i - 1).pdf[ERadiance] * SE(sm, k, i - 1).tr[ERadiance]; }
-    strategy_densities(mb.pdfImp, mb.pdfRad, n, oValue);
-    for (int i = 1; i <= 3; i++) mb.pdfImp[s + 2 + (t - i)] = saveI[i - 1];
-    for (int i = 1; i <= 4; i++) mb.pdfRad[s + 1 + (t - i)] = saveR[i - 1];
-    double sum = 0.0;
-    for (int p = 0; p < n; ++p)
-        if (mb.allowed & (1u << p)) sum += mb.value[p] * 1.0 + oValue[p] * jDet * 1.0;
-    return (Float)(mb.value[s] / sum);
+    PathRef off = base;
+    off.k = k;
+    Float oS, o1, o2;
+    mis_sums<false>(off, mb.cp, s, t, mb.allowed, oS, o1, o2);
+    return (Float)(mb.valueS / (mb.sum1 + o1 * jDet));
 }
 
 struct LightSplat { Float x, y; int buffer; d3 value; };
@@ -791,21 +801,26 @@ __device__ __forceinline__ void pair_range(const BdConfig &cfg, int nS, int s, i
 
 // One connection (s, t) of GBDPTRenderer::evaluate (gbdpt_proc.cpp:319-527): the base path and its four offsets.  Reads `sm` only.
 // Returns false when the connection contributes nothing.
+// CLS: the item class the connection belongs to -- 0: light tracing (t == 1), 1: sensor vertex t inside or at the end of the shifted part, 2: beyond it
+// (shares_connection).  A compile-time class lets each build drop the other classes' locals (the cloned end vertices and the transient offset of a
+// light path are 1.2 KB of vertex records that live in scratch because they are passed by reference).
+template <int CLS>
 __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po)
 {
+    constexpr bool T1 = CLS == 0;
     const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
     const int vert_b = 2;                                                                  // connectPath.vertexCount() - 1 - extra[1]: b is sensor vertex 2
     const int nE = sm.nY;
     d3 value[5]; Float miW[5], valuePdf[5];
     po.nLight = 0;
     Float samplePosX = sm.posX, samplePosY = sm.posY;
-    if (t == 1) {
+    if (T1) {
         if (!sensor_sample_position(c, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) return false;
     }
     // light-tracing connections (t == 1): the base path Y[0..s-1], Ysc, S1c, X[0] and its four offsets (gbdpt_proc.cpp:356-376)
     BV Ysc, S1c; BE eL;
     bool pathSuccess0 = true;
-    if (t == 1) {                                                                          // createShiftablePath(connectedBasePath, emitter, sensor, s, 1)
+    if (T1) {                                                                          // createShiftablePath(connectedBasePath, emitter, sensor, s, 1)
         Ysc = sm.Y[s]; S1c = sm.X[1]; be_clear(eL);
         pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE);
         sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
@@ -823,10 +838,10 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
         bool ok = k == 0 ? true : (sm.off[k - 1].success != 0);
         value[k] = mk(0.0); valuePdf[k] = 0.0;
         d3 impWk = sm.impW[s]; Float impPk = sm.impP[s];
-        const d3 radWk = sm.radW[t == 1 ? 0 : k][t]; const Float radPk = sm.radP[t == 1 ? 0 : k][t];
+        const d3 radWk = sm.radW[T1 ? 0 : k][t]; const Float radPk = sm.radP[T1 ? 0 : k][t];
         bool lightOffset = false;
-        if (t == 1 && k == 0) ok = pathSuccess0;
-        if (t == 1 && k > 0 && !is_zero(value[0])) {
+        if (T1 && k == 0) ok = pathSuccess0;
+        if (T1 && k > 0 && !is_zero(value[0])) {
             if (!pathSuccess0) ok = false;
             else {                                                                         // createShiftedLightPath, :568-590
                 ok = generate_offset(c, S1c, sm.X[0], sm.EX[0], Ysc, sm.Y[s - 1], s >= 2 ? &sm.Y[s - 2] : nullptr, eL.length,
@@ -847,14 +862,14 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
         Float geomTerm = 0.0;
         do {
             if (!(ok && pathSuccess0 && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
-            if (k > 0 && t != 1 && !sm.off[k - 1].couldConnectAfterB && t > vert_b) break;
+            if (k > 0 && !T1 && !sm.off[k - 1].couldConnectAfterB && t > vert_b) break;
             // the connection end points: emitter side vs (with its predecessor), sensor side vt (with its predecessor)
             const BV *vsPred, *vtPred; const BV *vsP;
             BV vtLocal;                                                                    // s == 0: the sensor vertex is cast to an emitter sample (a copy: the cast of
             const BV *vtP;                                                                 // the reference mutates the shared vertex, which no later evaluation reads)
             if (lightOffset) { vsP = &lo.b; vsPred = &lo.c; }
             else { vsP = &sm.Y[s]; vsPred = s > 0 ? &sm.Y[s - 1] : nullptr; }
-            vtP = &SV(sm, t == 1 ? 0 : k, t); vtPred = &SV(sm, t == 1 ? 0 : k, t - 1);
+            vtP = &SV(sm, T1 ? 0 : k, t); vtPred = &SV(sm, T1 ? 0 : k, t - 1);
             if (vsP->type == T_EMITTER_SUPER) {
                 vtLocal = *vtP;
                 if (!bv_cast_emitter(c, vtLocal) || vtLocal.degenerate) { valuePdf[k] = radPk; break; }
@@ -886,13 +901,13 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
                 geomBase = geomTerm;
                 miW[0] = mi_weight_base(c, sm, base, connEdgeBase, s, t, misBase) / valuePdf[0];
             } else {
-                if (shares_connection(sm, t)) miW[k] = mi_weight_grad_shared(misBase, sm, k, s, t, sm.off[k - 1].jacobian) / valuePdf[0];
+                if (CLS == 2) miW[k] = mi_weight_grad_shared(misBase, base, k, s, t, sm.off[k - 1].jacobian) / valuePdf[0];
                 else {
                     PathRef off = base;
-                    off.k = t == 1 ? 0 : k;
+                    off.k = T1 ? 0 : k;
                     if (lightOffset) { off.ovS = &lo.b; off.ovSm1 = &lo.c; off.ovEm1 = &lo.ebc; }
                     if (s == 0) off.ovT = vtP;
-                    miW[k] = mi_weight_grad(c, misBase, off, connEdge, s, t, t < 2 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
+                    miW[k] = mi_weight_grad(c, misBase, off, connEdge, s, t, T1 ? jacLP[k - 1] : sm.off[k - 1].jacobian) / valuePdf[0];
                 }
             }
         } while (false);
@@ -904,13 +919,13 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
     if (is_zero(value[0])) return false;
     const d3 mainRad = value[0] * (valuePdf[0] * miW[0]);
     po.primal = mainRad;
-    if (t < 2) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+    if (T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
     const d3 fx = value[0] * valuePdf[0];
     for (int n = 0; n < 4; n++) {
-        const d3 fy = value[n + 1] * valuePdf[n + 1] * (t < 2 ? jacLP[n] : sm.off[n].jacobian);
+        const d3 fy = value[n + 1] * valuePdf[n + 1] * (T1 ? jacLP[n] : sm.off[n].jacobian);
         const d3 gradVal = (fy - fx) * ((Float)2.0 * miW[n + 1]);
         po.gradient[n] = gradVal;
-        if (t < 2) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
+        if (T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
     }
     return true;
 }
@@ -928,7 +943,7 @@ __device__ void process_sample(Ctx &c, Sample &sm, int px, int py, SampleOut &ou
         int minT, maxT;
         pair_range(c.cfg, sm.nX, s, minT, maxT);
         for (int t = maxT; t >= minT; --t) {
-            if (!connect_pair(c, sm, s, t, po)) continue;
+            if (!(t == 1 ? connect_pair<0>(c, sm, s, t, po) : (shares_connection(sm, t) ? connect_pair<2>(c, sm, s, t, po) : connect_pair<1>(c, sm, s, t, po)))) continue;
             if (t >= 2) { out.primal = out.primal + po.primal; for (int n = 0; n < 4; n++) out.gradient[n] = out.gradient[n] + po.gradient[n]; }
             for (int i = 0; i < po.nLight && out.nLight < BD_MAX_LIGHT; i++) out.light[out.nLight++] = po.light[i];
         }
