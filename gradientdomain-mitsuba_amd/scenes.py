@@ -186,6 +186,20 @@ def _random_material(rng):
     return m
 
 
+def _random_connectable_material(rng):
+    """One material from what the G-BDPT path carries: every vertex connectable (smooth, roughness well above any shiftThreshold in use)."""
+    if rng.random() < 0.4:
+        m = diffuse(tuple(float(v) for v in rng.uniform(0.05, 0.9, 3)))
+    else:
+        metal = {"eta": tuple(float(v) for v in rng.uniform(0.1, 2.5, 3)), "k": tuple(float(v) for v in rng.uniform(1.5, 7.0, 3))}
+        au = float(10.0 ** rng.uniform(-1.3, -0.3))
+        m = roughconductor(au, **metal, distribution=int(rng.choice([DISTR_GGX, DISTR_BECKMANN, DISTR_PHONG])),
+                           alphaV=float(au * rng.uniform(0.5, 2.0)) if rng.random() < 0.5 else None, sampleVisible=bool(rng.random() < 0.7))
+    if rng.random() < 0.3:
+        m = twosided(m)
+    return m
+
+
 def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=None, point_light=None):
     """The Cornell box (Cornell Program of Computer Graphics measurement data, 555-unit room), all triangle meshes:
     5 walls, short block, tall block, one area-light quad.  variant: "diffuse" (BASELINE configs 1-2) |
@@ -219,6 +233,9 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
     elif variant in ("smooth", "bent"):  # spheres with interpolated shading normals instead of the blocks ("bent": normals tilted up to 0.6 rad)
         tall_m = b.material(roughconductor(0.12, **AL, distribution=DISTR_GGX))
         short_m = white
+    elif variant == "random_connectable":   # fuzz for G-BDPT: the same four surfaces, connectable materials only
+        rng = np.random.default_rng(seed)
+        floor_m, back_m, tall_m, short_m = (b.material(_random_connectable_material(rng)) for _ in range(4))
     elif variant == "random":         # fuzz: floor, back wall and both blocks draw their materials from `seed`
         rng = np.random.default_rng(seed)
         floor_m, back_m, tall_m, short_m = (b.material(_random_material(rng)) for _ in range(4))

@@ -10,7 +10,7 @@
  * library the scene once and then asks for tiles.  See INTEGRATION.md for the binding.
  *
  * Scene subset carried: triangle soups without vertex normals/texcoords, `area` emitters on
- * meshes, `diffuse` / `conductor` / `roughconductor` BSDFs, `perspective` sensor, `box` rfilter, independent
+ * meshes, `diffuse` / `conductor` / `roughconductor` BSDFs, `perspective` (or `thinlens`) sensor, `box` rfilter, independent
  * sampling.  Arithmetic is fp64 like the reference's DOUBLE_PRECISION build.  Random numbers: one counter-based
  * stream per (seed, pixel, sample) -- a GPU cannot consume the reference's serial SFMT stream.
  *
@@ -61,7 +61,7 @@ typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters
     double toWorld[9];          /* envmap: linear part of the emitter's `toWorld`, row-major (identity: +y is up, u = 0.5 looks along -z)   */
 } gdpt_environment;
 
-typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp), crop == film */
+typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp) or `thinlens` (thinlens.cpp), crop == film */
     double toWorld[16];         /* row-major camera-to-world, Transform::lookAt convention         */
     double fovX;                /* degrees (`fov`, fovAxis = x)                                    */
     double nearClip, farClip;
