@@ -143,7 +143,7 @@ struct gdpt_poisson_solver {
     float alpha_eff = 0.0f;
     const float *dev_direct = nullptr; // device pointer of `direct` (borrowed or staged), or null
 
-    int fusion = 2;             // 0: reference op sequence; 1: x_p fused into the stencil; 2: persistent cooperative CG when the image fits, else 1
+    int fusion = 2;             // 0: reference op sequence; 1: x_p fused into the stencil; 2: persistent cooperative CG when the image fits, else 1; 3: 2 with the single-gather recurrence
     unsigned long long *halo = nullptr;   // persistent CG: per-tile boundary records (tagged floats)
     unsigned *bar = nullptr;    // persistent CG: [1] sticky error flag
     unsigned long long *gat = nullptr;  // persistent CG: tagged partial tables (gather A, gather B)
@@ -315,14 +315,16 @@ int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
     A.W = s->W; A.H = s->H; A.tilesX = s->ptTilesX; A.tilesY = s->ptTilesY; A.TH = s->ptTH; A.iters = cg; A.alpha = s->alpha_eff;
     { const char *e = getenv("GDPT_DEBUG_PERSISTENT_FAIL"); A.debugFail = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }   // test hooks: 1 = a gather times out, 2 = the launch is refused
     if (s->ptLaunch == 0 || s->ptLaunch == 0xffffu) {      // fresh tables, or the 16-bit launch number is about to wrap: forget all tags
-        HIPCHK(hipMemsetAsync(s->gat, 0, sizeof(unsigned long long) * 6 * PT_MAXG, s->stream));
+        HIPCHK(hipMemsetAsync(s->gat, 0, sizeof(unsigned long long) * 12 * PT_MAXG, s->stream));
         HIPCHK(hipMemsetAsync(s->halo, 0, sizeof(unsigned long long) * (size_t)P2_HALO * PT_MAXG, s->stream));
         s->ptLaunch = 0;
     }
     A.tagBase = (++s->ptLaunch) << 16;
     void *args[] = {&A};
     const dim3 grid(s->ptTilesX * s->ptTilesY), block(((16 * s->ptTH + 63) / 64) * 64);
-    const void *fn = s->ptWide ? (unitw ? (const void *)kp_cg2<true> : (const void *)kp_cg2<false>) : (unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>);
+    const bool single = s->fusion >= 3 && !s->ptWide;          // the single-gather recurrence exists for the 64-px kernel
+    const void *fn = s->ptWide ? (unitw ? (const void *)kp_cg2<true> : (const void *)kp_cg2<false>)
+                   : single ? (unitw ? (const void *)kp_cg<true, true> : (const void *)kp_cg<false, true>) : (unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>);
     const size_t shared = s->ptWide ? P2_SHARED_BYTES : 0;
     if (s->ptWide) {
         static bool raised[2] = {false, false};        // 111 KB of dynamic LDS: above the 64 KB a kernel gets without asking
@@ -469,7 +471,7 @@ int gdpt_poisson_setup_backend(gdpt_poisson_solver *s)
         HIPCHK(hipMalloc(&s->counter, sizeof(int) * 4));
         HIPCHK(hipMalloc(&s->halo, sizeof(unsigned long long) * (size_t)P2_HALO * PT_MAXG));      // (P2_HALO > PT_HALO: either kernel's records fit)
         HIPCHK(hipMalloc(&s->bar, sizeof(unsigned) * PT_BAR_WORDS));
-        HIPCHK(hipMalloc(&s->gat, sizeof(unsigned long long) * 6 * PT_MAXG));
+        HIPCHK(hipMalloc(&s->gat, sizeof(unsigned long long) * 12 * PT_MAXG));      // two gather tables; four (two per iteration parity) at fusion level 3
         // reg_k = regInit * regIter^(k-1), Solver.cpp:395 (host powf like the reference)
         std::vector<float> reg(s->P.irlsIterMax + 1, 0.0f);
         for (int k = 1; k < s->P.irlsIterMax; k++) reg[k] = s->P.irlsRegInit * powf(s->P.irlsRegIter, (float)(k - 1));
@@ -796,7 +798,7 @@ void *gdpt_poisson_stream(gdpt_poisson_solver *s) { return s ? (void *)s->stream
 int gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level)
 {
     if (!s) return fail(GDPT_ERR_INVALID, "null solver");
-    s->fusion = level < 0 ? 0 : (level > 2 ? 2 : level);
+    s->fusion = level < 0 ? 0 : (level > 3 ? 3 : level);
     return GDPT_OK;
 }
 

@@ -121,6 +121,29 @@ __device__ __forceinline__ bool pt_allgather_sum(unsigned long long *gat, unsign
     return *s_fail == 0;
 }
 
+// The same for two partials per workgroup at once (the single-gather CG, fusion level 3): tables gatG and gatD are published together and
+// polled together.  gsm: >= 6*G floats.
+__device__ __forceinline__ bool pt_allgather_sum6(unsigned long long *gatG, unsigned long long *gatD, unsigned tag, int G, int tile, const float (&g)[3], const float (&d)[3],
+                                                  float (&vg)[3], float (&vd)[3], float *gsm, int *s_fail, unsigned *err)
+{
+    const int t = threadIdx.x;
+    if (t < 3) pt_store(&gatG[tile * 3 + t], g[t], tag);
+    else if (t < 6) pt_store(&gatD[tile * 3 + (t - 3)], d[t - 3], tag);
+    for (int idx = t; idx < 6 * G; idx += blockDim.x) {
+        unsigned long long *w = idx < 3 * G ? &gatG[idx] : &gatD[idx - 3 * G];
+        gsm[idx] = pt_wait(w, __hip_atomic_load(w, PT_RLX_AGENT), tag, s_fail, err);
+    }
+    pt_sync();
+    const int ln = t & 63;
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = ln; i < G; i += 64)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { a[c] += gsm[3 * i + c]; a[3 + c] += gsm[3 * G + 3 * i + c]; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { vg[c] = pt_wave_sum(a[c]); vd[c] = pt_wave_sum(a[3 + c]); }
+    return *s_fail == 0;
+}
+
 // Sum a[0..2] over a block of up to 16 waves; every thread receives the totals.  sm: >= 64 floats.
 __device__ __forceinline__ void pt_block_sum3(float (&a)[3], float *sm, int nwaves)
 {
@@ -135,12 +158,18 @@ __device__ __forceinline__ void pt_block_sum3(float (&a)[3], float *sm, int nwav
     a[0] = t[0]; a[1] = t[1]; a[2] = t[2];
 }
 
-template <bool UNITW>
+// SINGLE (fusion level 3): the Chronopoulos-Gear form of the same iteration -- w = A r, gamma = r.r and delta = w.r in ONE gather, then
+//     beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old), z = w + beta z (= A p), p = r + beta p, x += alpha p, r -= alpha z
+// -- algebraically the recurrence of Solver.cpp:466-469 (alpha = r.r / p.Ap, beta = r'.r' / r.r) with p.Ap obtained from delta instead of a second
+// reduction; in floating point the iterates differ by rounding (tolerance in tests/test_poisson_gpu.py).  The stencil runs on r, the LDS
+// image holds r, and the ring is the neighbours' r as published.  The gather tables alternate by iteration parity: with one gather per iteration
+// a fast workgroup would otherwise overwrite a slot a slow one is still polling.
+template <bool UNITW, bool SINGLE = false>
 __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float lp[PT_LDS];                  // p of the tile with its ring
+    __shared__ __attribute__((aligned(16))) float lp[PT_LDS];                  // p (SINGLE: r) of the tile with its ring
     __shared__ float sm[64];
-    __shared__ float gsm[3 * PT_MAXG];
+    __shared__ float gsm[(SINGLE ? 6 : 3) * PT_MAXG];
     __shared__ float hs[PT_HALO];
     __shared__ int s_fail;
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4, nwaves = (blockDim.x + 63) >> 6;
@@ -226,6 +255,91 @@ __global__ __launch_bounds__(1024) void kp_cg(PersistArgs A)
 #else
 #define PT_TICK(k)
 #endif
+    if constexpr (SINGLE) {
+        float zv[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) zv[k] = 0.0f;
+        float gOld[3] = {1.0f, 1.0f, 1.0f}, aOld[3] = {1.0f, 1.0f, 1.0f};
+        for (int it = 0; it < A.iters && ok; it++) {
+            // ---- w = A r (tile of r staged in LDS), partials r.r and w.r ----
+            pt_sync();
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    *reinterpret_cast<float4 *>(&lp[pt_plane(c, ty + 1, 4 * tx)]) = make_float4(rv[c], rv[3 + c], rv[6 + c], rv[9 + c]);
+            }
+            float lft[3], rgt[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { lft[c] = pt_from_left(rv[9 + c]); rgt[c] = pt_from_right(rv[c]); }
+            pt_sync();
+            float wv[12], accG[3] = {0.0f, 0.0f, 0.0f}, accD[3] = {0.0f, 0.0f, 0.0f};
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float4 u4 = *reinterpret_cast<const float4 *>(&lp[pt_plane(c, ty, 4 * tx)]);
+                    const float4 d4 = *reinterpret_cast<const float4 *>(&lp[pt_plane(c, ty + 2, 4 * tx)]);
+                    const float up[4] = {u4.x, u4.y, u4.z, u4.w}, dn[4] = {d4.x, d4.y, d4.z, d4.w};
+                    if (tx == 0) lft[c] = lp[PT_COLL + c * PT_MAXH + ty];
+                    if (4 * tx + 4 == TWv) rgt[c] = lp[PT_COLR + c * PT_MAXH + ty];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int xx = x + k;
+                        const float xi = rv[3 * k + c];
+                        const float wl = (k == 0) ? w1l : w1[k - 1];
+                        const float xl = (k == 0) ? lft[c] : rv[3 * (k - 1) + c], xr = (k == 3) ? rgt[c] : rv[3 * (k + 1) + c];
+                        float a = w0[k] * xi * alphaSqr;                                   // Backend.cpp:228-233
+                        if (xx != 0)     a = a + wl * (xi - xl);
+                        if (xx != W - 1) a = a + w1[k] * (xi - xr);
+                        if (y != 0)      a = a + wu[k] * (xi - up[k]);
+                        if (y != H - 1)  a = a + wv_[k] * (xi - dn[k]);
+                        wv[3 * k + c] = a;
+                        accG[c] += xi * xi;
+                        accD[c] += xi * a;
+                    }
+                }
+            }
+            pt_block_sum3(accG, sm, nwaves);
+            pt_block_sum3(accD, sm, nwaves);
+            float gam[3], del[3], al[3], be[3];
+            unsigned long long *tg = A.gat + (size_t)(it & 1) * 6 * PT_MAXG;
+            ok = pt_allgather_sum6(tg, tg + 3 * PT_MAXG, A.tagBase + (unsigned)it + 1u, G, tile, accG, accD, gam, del, gsm, &s_fail, err);
+            if (!ok) break;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                be[c] = it == 0 ? 0.0f : gam[c] / fmaxf(gOld[c], FLT_MIN);
+                const float pAp = it == 0 ? del[c] : del[c] - be[c] * gam[c] / aOld[c];    // p.Ap = w.r - beta gamma / alpha_old
+                al[c] = gam[c] / fmaxf(pAp, FLT_MIN);
+                gOld[c] = gam[c]; aOld[c] = fmaxf(al[c], FLT_MIN);
+            }
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int q = 3 * k + c;
+                        zv[q] = wv[q] + zv[q] * be[c];
+                        pv[q] = it == 0 ? rv[q] : rv[q] + pv[q] * be[c];
+                        xv[q] = xv[q] + pv[q] * al[c];
+                        rv[q] = rv[q] - zv[q] * al[c];
+                    }
+                if (ty == 0) for (int k = 0; k < 12; k++) hs[(4 * tx) * 3 + k] = rv[k];
+                if (ty == THv - 1) for (int k = 0; k < 12; k++) hs[PT_W * 3 + (4 * tx) * 3 + k] = rv[k];
+                if (tx == 0) for (int c = 0; c < 3; c++) hs[2 * PT_W * 3 + ty * 3 + c] = rv[c];
+                if (4 * tx + 4 == TWv) for (int c = 0; c < 3; c++) hs[2 * PT_W * 3 + PT_MAXH * 3 + ty * 3 + c] = rv[9 + c];
+            }
+            pt_sync();
+            for (int e = t; e < PT_HALO; e += blockDim.x) pt_store(&myHalo[e], hs[e], A.tagBase + (unsigned)it + 1u);
+            // the ring of the next stencil: the neighbours' new r
+            for (int e = t; e < ringN; e += blockDim.x) {
+                int nt, off, slot, c;
+                if (ring_source(e, nt, off, slot, c)) {
+                    unsigned long long *hp = &A.halo[(size_t)nt * PT_HALO + off];
+                    lp[slot] = pt_wait(hp, __hip_atomic_load(hp, PT_RLX_AGENT), A.tagBase + (unsigned)it + 1u, &s_fail, err);
+                }
+            }
+            rz[0] = gam[0]; rz[1] = gam[1]; rz[2] = gam[2];
+        }
+    } else
     for (int it = 0; it < A.iters && ok; it++) {
         // ---- Ap = A p (tile staged in LDS), partial p.Ap ----
         pt_sync();

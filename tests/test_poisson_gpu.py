@@ -365,6 +365,21 @@ def test_wide_persistent_kernel_ragged_sizes(P, monkeypatch, w, h):
     assert np.array_equal(rec, g2)
 
 
+@pytest.mark.parametrize("w,h", [(64, 48), (260, 37), (512, 512)])
+@pytest.mark.parametrize("preset", ["L2D", "L1D"])
+def test_fusion_level_3_single_gather_recurrence(P, w, h, preset):
+    """Fusion level 3: the persistent CG with r.r and (A r).r in one grid-wide reduction (Chronopoulos-Gear; p.Ap = delta - beta gamma / alpha_old).
+    Algebraically the recurrence of Solver.cpp:466-469; in fp32 the iterates differ by rounding: the same bars against the oracle as the other levels
+    (L2D 5e-5, L1D 5e-4), bit-identical run to run.  (Measured no faster than level 2 -- the wait for the neighbours' ring takes the place of the
+    second gather on the critical path, DESIGN.md -- hence opt-in.)"""
+    dx, dy, tp, direct = po.synth_inputs(w, h)
+    a, it = run_solver(P, preset, dx, dy, tp, direct, w, h, 3)
+    b, _ = run_solver(P, preset, dx, dy, tp, direct, w, h, 3)
+    ref = po.solve(po.preset(preset), dx, dy, tp, direct, w, h)
+    assert it == po.preset(preset).irlsIterMax * po.preset(preset).cgIterMax and np.array_equal(a, b)
+    assert np.abs(a - ref).max() <= (5e-5 if preset == "L2D" else 5e-4)
+
+
 def test_full_size_l2d_3840x2160_config4(P):
     """BASELINE config 4 size (8.3 Mpixel; on 8 GPUs the strips are gathered and rank 0 solves this).  Linearity (exact for a
     power of two), determinism, fused vs reference op sequence, and the oracle itself (about 10 s)."""

@@ -42,6 +42,8 @@ for seed in range(first, first + count):
         sc = scenes.atrium(W, H, columns=int(rng.integers(4, 12)), segments=int(rng.integers(6, 16)))
     else:
         sc = scenes.cornell_box(W, H, kind, **kw)
+    if seed % 9 == 4:                                      # a thin lens instead of the pinhole (two more random numbers per sample, rays from the aperture)
+        sc.thinlens = (float(rng.uniform(2.0, 60.0)), float(rng.uniform(300.0, 1500.0))) if seed % 7 else (float(rng.uniform(0.01, 0.3)), float(rng.uniform(2.0, 30.0)))
     if seed % 11 == 3:                                     # a reconstruction filter wider than box (sample log + gather)
         sc.rfilter = scenes.RFILTER_DEFAULTS[1 + seed % 5]
     md = int(rng.choice([-1, 2, 3, 5, 9])); rr = int(rng.choice([1, 3, 5])); strict = bool(rng.random() < 0.35); thr = float(rng.choice([0.001, 0.02, 0.0]))

@@ -32,7 +32,7 @@ for seed in range(first, first + count):
             d = np.abs(np.asarray(g[key]) - np.asarray(o[key])).max()
             if d > 1e-9 * (scale if key != "position" else 1.0) + 1e-13:
                 print("MISMATCH sample: seed %d px %d py %d s %d %s\n%r\n%r" % (seed, px, py, s, key, g[key], o[key])); sys.exit(1)
-            if key != "position": worst = max(worst, d / scale)
+            if key != "position" and scale > 1e-6: worst = max(worst, d / scale)     # (relative to the sample's scale, for samples that carry light)
         gl, ol = np.asarray(g["light"]).reshape(-1, 6), np.asarray(o["light"]).reshape(-1, 6)
         if gl.shape != ol.shape or (len(ol) and (not np.array_equal(gl[:, 2], ol[:, 2]) or np.abs(gl[:, :2] - ol[:, :2]).max() > 1e-9 or
                                                  np.abs(gl[:, 3:] - ol[:, 3:]).max() > 1e-9 * max(np.abs(ol[:, 3:]).max(), 1e-300) + 1e-13)):
