@@ -78,7 +78,7 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
 constexpr int BD_ITEMS_PER_SAMPLE = 96;            // >= 90 = sum over s of the t-range at maxDepth 12 (pair_range)
 constexpr unsigned BD_CHUNK = 1u << 21;            // samples per chunk: 23 GB of records, 2.4 GB of item lists
 
-__global__ __launch_bounds__(TBLK) void k_bd_walk(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, long long first, unsigned count, Sample *__restrict__ recs,
+__global__ __launch_bounds__(TBLK, 2) void k_bd_walk(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, long long first, unsigned count, Sample *__restrict__ recs,
                                                   unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];

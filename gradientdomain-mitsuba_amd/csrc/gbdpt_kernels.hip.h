@@ -289,7 +289,7 @@ __device__ __forceinline__ void to_area(const Ctx &c, BV &v, int mode, const BV 
     }
 }
 // PathVertex::sampleNext, vertex.cpp:35-310 (the sensor endpoints go through sample_sensor)
-__device__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE *predEdge, BE &succEdge, BV &succ, int mode, bool russianRoulette, d3 &throughput)
+__device__ __noinline__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE *predEdge, BE &succEdge, BV &succ, int mode, bool russianRoulette, d3 &throughput)
 {
     d3 ro, rd;
     be_clear(succEdge); bv_clear(succ);
@@ -356,7 +356,7 @@ __device__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE *predEdge, B
     return true;
 }
 // PathVertex::sampleSensor, vertex.cpp:312-384 (perspective: the direction sample maps to pixels; no aperture sample)
-__device__ int sample_sensor(Ctx &c, BV &v0, int px, int py, BE &e0, BV &v1, BE &e1, BV &v2)
+__device__ __noinline__ int sample_sensor(Ctx &c, BV &v0, int px, int py, BE &e0, BV &v1, BE &e1, BV &v2)
 {
     be_clear(e0); bv_clear(v1);
     const Float sx = c.rng.next1D(), sy = c.rng.next1D();
@@ -724,9 +724,10 @@ struct PairOut { d3 primal, gradient[4]; int nLight; LightSplat light[5]; };   /
 
 // First half of GBDPTRenderer::process (the sample loop body, gbdpt_proc.cpp:152-229): the two subpaths, the connected base path, its four
 // offset paths, the prefix products.  Everything the connections need is in `sm` afterwards (which may live in HBM: the wavefront form).
-__device__ void walk_sample(Ctx &c, Sample &sm, int px, int py)
+// (two functions: as one, the allocator takes 256 VGPRs + 70 AGPRs for it and the walk kernel runs at one wave per SIMD; a register budget
+// cannot be attached to a device function, and inlining it into the kernel crashes the backend)
+__device__ __noinline__ bool walk_paths(Ctx &c, Sample &sm, int px, int py)
 {
-    const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                           // :101,265
     const BdConfig &cfg = c.cfg;
     const int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth + 1;                  // :110-122: degenerate (pinhole) sensor, hittable emitters
     // ---- Path::alternatingRandomWalkFromPixel, path.cpp:548-631 ----
@@ -750,8 +751,12 @@ __device__ void walk_sample(Ctx &c, Sample &sm, int px, int py)
     } while (walkS || walkT);
     sm.posX = sm.X[1].u; sm.posY = sm.X[1].v;
     for (int k = 0; k < 4; k++) { sm.off[k].success = 0; sm.off[k].couldConnectAfterB = 0; sm.off[k].jacobian = 1.0; }
-    if (sm.nY < 2) { sm.nY = 0; return; }                                                   // (no emitter could be sampled: a scene without power; no connections)
-
+    if (sm.nY < 2) { sm.nY = 0; return false; }                                             // (no emitter could be sampled: a scene without power; no connections)
+    return true;
+}
+__device__ __noinline__ void walk_shift(Ctx &c, Sample &sm)
+{
+    const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                           // :101,265
     // ---- createShiftablePath(connectPath, emitterSubpath, sensorSubpath, 1, last), gbdpt_proc.cpp:600-662 ----
     const int T = sm.nX - 1;
     sm.connS = 1;
@@ -792,6 +797,7 @@ __device__ void walk_sample(Ctx &c, Sample &sm, int px, int py)
         }
     }
 }
+__device__ __forceinline__ void walk_sample(Ctx &c, Sample &sm, int px, int py) { if (walk_paths(c, sm, px, py)) walk_shift(c, sm); }
 // the range of sensor vertices connected to emitter vertex s (gbdpt_proc.cpp:311-319)
 __device__ __forceinline__ void pair_range(const BdConfig &cfg, int nS, int s, int &minT, int &maxT)
 {
