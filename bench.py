@@ -370,7 +370,10 @@ def main():
         tracer_kernels = ("gdpt_tr::k_primary", "gdpt_tr::k_render", "gdpt_tr::k_continue", "gdpt_tr::k_fold_cont")
         res = _kernel_counters(counters, "gdpt_tr::k_resolve")          # once per step: the profile's step count
         per_step = {}
-        if res and res.get("calls") and world == 1:
+        # (the committed counters are those of the DEFAULT workload, config 2 at its own size and spp: another configuration's step has other
+        #  instruction counts, and pricing them with this run's duration once printed a "frac" of 1.29 for config 1)
+        profiled_workload = a.config == 2 and a.spp == SPP and (W, H) == (1280, 720)
+        if res and res.get("calls") and world == 1 and profiled_workload:
             for name, c in counters.items():
                 key = next((t for t in tracer_kernels if t in name), None)
                 if key and "SQ_INSTS_VALU" in c:
