@@ -467,7 +467,8 @@ constexpr int P2_W = 128;
 constexpr int P2_PLANE = (PT_MAXH + 2) * P2_W;
 constexpr int P2_COLL = 3 * P2_PLANE, P2_COLR = P2_COLL + 3 * PT_MAXH, P2_LDS = P2_COLR + 3 * PT_MAXH;
 constexpr int P2_HALO = (2 * P2_W + 2 * PT_MAXH) * 3;
-constexpr size_t P2_SHARED_BYTES = sizeof(float) * (P2_LDS + P2_HALO + 3 * PT_MAXG + 64) + 16;
+constexpr int P2_WV = (PT_MAXH + 1) * P2_W;       // LDS image of the vertical IRLS weights: row 0 = the image row above the tile, row r + 1 = tile row r
+constexpr size_t P2_SHARED_BYTES = sizeof(float) * (P2_LDS + P2_HALO + 3 * PT_MAXG + 64 + P2_WV) + 16;
 __device__ __forceinline__ int p2_plane(int c, int row, int x) { return c * P2_PLANE + row * P2_W + x; }
 
 template <bool UNITW>
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(1024) void kp_cg2(PersistArgs A)
     float *hs = lp + P2_LDS;
     float *gsm = hs + P2_HALO;
     float *sm = gsm + 3 * PT_MAXG;
-    int *s_failp = reinterpret_cast<int *>(sm + 64);
+    float *wvs = sm + 64;                         // (constant over the launch: read back by ds_read_b128 instead of two float4 loads from L2 per group and iteration)
+    int *s_failp = reinterpret_cast<int *>(wvs + P2_WV);
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4, nwaves = (blockDim.x + 63) >> 6;
     const int tile = blockIdx.x, tX = tile % A.tilesX, tY = tile / A.tilesX;
     const int X0 = tX * P2_W, Y0 = tY * A.TH;
@@ -509,6 +511,14 @@ __global__ __launch_bounds__(1024) void kp_cg2(PersistArgs A)
             for (int c = 0; c < 3; c++)                                          // p := r (Solver.cpp:405)
                 *reinterpret_cast<float4 *>(&lp[p2_plane(c, ty + 1, lx[g])]) = make_float4(rv[g][c], rv[g][3 + c], rv[g][6 + c], rv[g][9 + c]);
         }
+    }
+    if (!UNITW) {
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+            if (valid[g]) {
+                *reinterpret_cast<float4 *>(&wvs[(ty + 1) * P2_W + lx[g]]) = *reinterpret_cast<const float4 *>(A.w2 + 2 * n + gi[g]);
+                if (ty == 0) *reinterpret_cast<float4 *>(&wvs[lx[g]]) = y != 0 ? *reinterpret_cast<const float4 *>(A.w2 + 2 * n + gi[g] - W) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
     }
     const int ringN = (2 * TWv + 2 * THv) * 3;
     for (int e = t; e < ringN; e += blockDim.x) {
@@ -545,18 +555,18 @@ __global__ __launch_bounds__(1024) void kp_cg2(PersistArgs A)
 #pragma unroll
         for (int g = 0; g < 2; g++) {
             const int x = X0 + lx[g];
-            // the 17 weights the group's stencil needs, from L2 / MALL; fetched here, group by group: holding group 0's across the gathers (a prefetch
+            // the 17 weights the group's stencil needs: w0, w1 and the left neighbour's w1 from L2 / MALL, the two vertical ones from their LDS image; fetched here, group by group: holding group 0's across the gathers (a prefetch
             // during the wait for the ring) or both groups' at once spills, and cost 10 us per iteration when tried
             const int i = gi[g];
             float w0[4] = {1.0f, 1.0f, 1.0f, 1.0f}, w1[4] = {1.0f, 1.0f, 1.0f, 1.0f}, wv_[4] = {1.0f, 1.0f, 1.0f, 1.0f}, wu[4] = {1.0f, 1.0f, 1.0f, 1.0f}, w1l = 1.0f;
             if (!UNITW && valid[g]) {
-                const float4 a = *reinterpret_cast<const float4 *>(A.w2 + i), b = *reinterpret_cast<const float4 *>(A.w2 + n + i), c = *reinterpret_cast<const float4 *>(A.w2 + 2 * n + i);
+                const float4 a = *reinterpret_cast<const float4 *>(A.w2 + i), b = *reinterpret_cast<const float4 *>(A.w2 + n + i);
+                const float4 c = *reinterpret_cast<const float4 *>(&wvs[(ty + 1) * P2_W + lx[g]]), d = *reinterpret_cast<const float4 *>(&wvs[ty * P2_W + lx[g]]);
                 w0[0] = a.x; w0[1] = a.y; w0[2] = a.z; w0[3] = a.w;
                 w1[0] = b.x; w1[1] = b.y; w1[2] = b.z; w1[3] = b.w;
                 wv_[0] = c.x; wv_[1] = c.y; wv_[2] = c.z; wv_[3] = c.w;
                 w1l = (x != 0) ? A.w2[n + i - 1] : 0.0f;
-                if (y != 0) { const float4 d = *reinterpret_cast<const float4 *>(A.w2 + 2 * n + i - W); wu[0] = d.x; wu[1] = d.y; wu[2] = d.z; wu[3] = d.w; }
-                else { wu[0] = wu[1] = wu[2] = wu[3] = 0.0f; }
+                wu[0] = d.x; wu[1] = d.y; wu[2] = d.z; wu[3] = d.w;                      // (zeros in the image's first row)
             }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
