@@ -335,6 +335,19 @@ __global__ __launch_bounds__(BLK) void kg_setup(float *__restrict__ b, float *__
 // t starts at colour (t + j) % 3: in the lane's ROTATED colour frame (rot = t % 3) the colour of
 // component k of load j is the compile-time constant (j + k) % 3, so no per-element selects.
 
+// streaming stores (and loads): the CG vectors of an HBM-resident image are written once and read by the NEXT kernel, 100 MB later -- kept out of
+// L2 / MALL they do not evict the rows the neighbouring tile is about to re-read (kf_xp_Ax at 3840x2160: 140 -> 117 us)
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4 *dst, float4 v)
+{
+    v4f_nt w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt *>(dst));
+}
+__device__ __forceinline__ float4 nt_load4(const float4 *src)
+{
+    const v4f_nt w = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(src));
+    return make_float4(w.x, w.y, w.z, w.w);
+}
 constexpr int FLAT_TILE = 3 * BLK; // float4 per block-iteration
 
 __device__ __forceinline__ void rotate3(const float (&a)[3], int rot, float (&aR)[3])
@@ -449,7 +462,7 @@ struct Tile { int x0, y0; };
 
 // Stencil of one lane's 4 px x RGB from the staged tile; returns p.Ap contributions in acc.
 // Association order == Backend.cpp:228-233.
-template <bool UNITW>
+template <bool UNITW, bool NT = false>
 __device__ __forceinline__ void stencil_lane(const float *__restrict__ tile, int row, int lane, int x0, int y0, int W, int H,
                                              const float *__restrict__ w2, float alphaSqr, float4 *__restrict__ Ax4, float (&acc)[3])
 {
@@ -511,9 +524,15 @@ __device__ __forceinline__ void stencil_lane(const float *__restrict__ tile, int
         }
     }
     float4 *o = Ax4 + (3 * (size_t)i) / 4;
-    o[0] = make_float4(out[0], out[1], out[2], out[3]);
-    o[1] = make_float4(out[4], out[5], out[6], out[7]);
-    o[2] = make_float4(out[8], out[9], out[10], out[11]);
+    if (NT) {       // (kf_xp_Ax: Ap is read next by kf_r_rz, a whole image later)
+        nt_store4(&o[0], make_float4(out[0], out[1], out[2], out[3]));
+        nt_store4(&o[1], make_float4(out[4], out[5], out[6], out[7]));
+        nt_store4(&o[2], make_float4(out[8], out[9], out[10], out[11]));
+    } else {
+        o[0] = make_float4(out[0], out[1], out[2], out[3]);
+        o[1] = make_float4(out[4], out[5], out[6], out[7]);
+        o[2] = make_float4(out[8], out[9], out[10], out[11]);
+    }
 }
 
 // Backend::calc_Ax_xAx (Backend.cpp:209-242), LDS-tiled.
@@ -631,20 +650,20 @@ __global__ __launch_bounds__(BLK) void kf_xp_Ax(float4 *__restrict__ Ax4, float4
             pn.w = rv[m].w + pv[m].w * bR[(m + 3) % 3];
             *reinterpret_cast<float4 *>(tile + rr * RS + 4 + 4 * q) = pn;
             if (own[m]) {
-                p_new4[gi[m]] = pn;
+                nt_store4(&p_new4[gi[m]], pn);
                 float4 xo;
                 xo.x = xv[m].x + pv[m].x * aR[(m + 0) % 3];
                 xo.y = xv[m].y + pv[m].y * aR[(m + 1) % 3];
                 xo.z = xv[m].z + pv[m].z * aR[(m + 2) % 3];
                 xo.w = xv[m].w + pv[m].w * aR[(m + 3) % 3];
-                x4[gi[m]] = xo;
+                nt_store4(&x4[gi[m]], xo);
             }
         }
         if (hslot >= 0) tile[hslot] = hr + hp * sel3(hc, b[0], b[1], b[2]);
         __syncthreads();
 #pragma unroll
         for (int row = 0; row < TH_; row += BLK / 64)
-            stencil_lane<UNITW>(tile, row + wv, ln, x0, y0, W, H, w2, alphaSqr, Ax4, acc);
+            stencil_lane<UNITW, true>(tile, row + wv, ln, x0, y0, W, H, w2, alphaSqr, Ax4, acc);
     }
     block_sum3(acc, sm);
     if (t == 0) part_pAp[blockIdx.x] = make_float4(acc[0], acc[1], acc[2], 0.0f);
