@@ -20,6 +20,10 @@ namespace gdpt_tr {
 #else
 #define GDPT_UNROLL_OFFSETS(WPS) ((WPS) <= 2)
 #endif
+// queue records are written once and read a whole chunk of samples later (14 GB per 32-sample chunk at 1280x720): streaming stores keep them
+// from evicting what the render kernels do re-use from L2 (their scratch, the scene tables of the HBM-resident builds)
+__device__ __forceinline__ void qst(Float *p, Float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ Float qld(const Float *p) { return __builtin_nontemporal_load(p); }
 // pixel shift of offset path i (gpt.cpp:410-415: right, down, left, up)
 __device__ __forceinline__ Float offset_shift_x(int i) { return i == 0 ? 1.0 : (i == 2 ? -1.0 : 0.0); }
 __device__ __forceinline__ Float offset_shift_y(int i) { return i == 1 ? 1.0 : (i == 3 ? -1.0 : 0.0); }
@@ -96,10 +100,10 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     if (traced) {
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            hits[r].t = F->pHit[(size_t)(3 * r) * F->qCapacity + slot];
-            hits[r].u = F->pHit[(size_t)(3 * r + 1) * F->qCapacity + slot];
-            hits[r].v = F->pHit[(size_t)(3 * r + 2) * F->qCapacity + slot];
-            hits[r].prim = F->pPrim[(size_t)r * F->qCapacity + slot];
+            hits[r].t = qld(&F->pHit[(size_t)(3 * r) * F->qCapacity + slot]);
+            hits[r].u = qld(&F->pHit[(size_t)(3 * r + 1) * F->qCapacity + slot]);
+            hits[r].v = qld(&F->pHit[(size_t)(3 * r + 2) * F->qCapacity + slot]);
+            hits[r].prim = __builtin_nontemporal_load(&F->pPrim[(size_t)r * F->qCapacity + slot]);
         }
         L.nClosest += 5;
     }
@@ -626,46 +630,46 @@ __device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lan
 {
     Float *q = F.qRec + slot;
     const size_t st = F.qCapacity;
-    q[0 * st] = L.throughput.x; q[1 * st] = L.throughput.y; q[2 * st] = L.throughput.z;
-    q[3 * st] = L.pdf; q[4 * st] = L.eta;
-    q[5 * st] = L.v.p.x; q[6 * st] = L.v.p.y; q[7 * st] = L.v.p.z;
-    q[8 * st] = L.rayD.x; q[9 * st] = L.rayD.y; q[10 * st] = L.rayD.z;
-    q[11 * st] = L.v.u; q[12 * st] = L.v.v;
-    q[13 * st] = __longlong_as_double((long long)(((unsigned long long)(unsigned)L.depth << 32) | (unsigned)L.v.prim));
-    q[14 * st] = __longlong_as_double((long long)L.rng.s);
+    qst(&q[0 * st], L.throughput.x); qst(&q[1 * st], L.throughput.y); qst(&q[2 * st], L.throughput.z);
+    qst(&q[3 * st], L.pdf); qst(&q[4 * st], L.eta);
+    qst(&q[5 * st], L.v.p.x); qst(&q[6 * st], L.v.p.y); qst(&q[7 * st], L.v.p.z);
+    qst(&q[8 * st], L.rayD.x); qst(&q[9 * st], L.rayD.y); qst(&q[10 * st], L.rayD.z);
+    qst(&q[11 * st], L.v.u); qst(&q[12 * st], L.v.v);
+    qst(&q[13 * st], __longlong_as_double((long long)(((unsigned long long)(unsigned)L.depth << 32) | (unsigned)L.v.prim)));
+    qst(&q[14 * st], __longlong_as_double((long long)L.rng.s));
     unsigned alive = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const Offset &o = L.off[i];
-        q[(15 + 4 * i) * st] = o.throughput.x; q[(16 + 4 * i) * st] = o.throughput.y; q[(17 + 4 * i) * st] = o.throughput.z; q[(18 + 4 * i) * st] = o.pdf;
+        qst(&q[(15 + 4 * i) * st], o.throughput.x); qst(&q[(16 + 4 * i) * st], o.throughput.y); qst(&q[(17 + 4 * i) * st], o.throughput.z); qst(&q[(18 + 4 * i) * st], o.pdf);
         alive |= (o.alive ? 1u : 0u) << i;
     }
-    q[31 * st] = __longlong_as_double((long long)alive);
+    qst(&q[31 * st], __longlong_as_double((long long)alive));
 #pragma unroll
-    for (int k = 0; k < ACC_N; k++) q[(32 + k) * st] = A.get(k);
+    for (int k = 0; k < ACC_N; k++) qst(&q[(32 + k) * st], A.get(k));
 }
 template <class ACC>
 __device__ __forceinline__ void q_load(const FilmD &F, unsigned slot, Lane &L, ACC &A)
 {
     const Float *q = F.qRec + slot;
     const size_t st = F.qCapacity;
-    L.throughput = mk(q[0 * st], q[1 * st], q[2 * st]);
-    L.pdf = q[3 * st]; L.eta = q[4 * st];
-    L.v.p = mk(q[5 * st], q[6 * st], q[7 * st]);
-    L.rayD = mk(q[8 * st], q[9 * st], q[10 * st]);
-    L.v.u = q[11 * st]; L.v.v = q[12 * st];
-    const unsigned long long pk = (unsigned long long)__double_as_longlong(q[13 * st]);
+    L.throughput = mk(qld(&q[0 * st]), qld(&q[1 * st]), qld(&q[2 * st]));
+    L.pdf = qld(&q[3 * st]); L.eta = qld(&q[4 * st]);
+    L.v.p = mk(qld(&q[5 * st]), qld(&q[6 * st]), qld(&q[7 * st]));
+    L.rayD = mk(qld(&q[8 * st]), qld(&q[9 * st]), qld(&q[10 * st]));
+    L.v.u = qld(&q[11 * st]); L.v.v = qld(&q[12 * st]);
+    const unsigned long long pk = (unsigned long long)__double_as_longlong(qld(&q[13 * st]));
     L.v.prim = (int)(unsigned)(pk & 0xffffffffu); L.depth = (int)(unsigned)(pk >> 32);
-    L.rng.s = (uint64_t)__double_as_longlong(q[14 * st]);
-    const unsigned alive = (unsigned)__double_as_longlong(q[31 * st]);
+    L.rng.s = (uint64_t)__double_as_longlong(qld(&q[14 * st]));
+    const unsigned alive = (unsigned)__double_as_longlong(qld(&q[31 * st]));
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         Offset &o = L.off[i];
-        o.throughput = mk(q[(15 + 4 * i) * st], q[(16 + 4 * i) * st], q[(17 + 4 * i) * st]); o.pdf = q[(18 + 4 * i) * st];
+        o.throughput = mk(qld(&q[(15 + 4 * i) * st]), qld(&q[(16 + 4 * i) * st]), qld(&q[(17 + 4 * i) * st])); o.pdf = qld(&q[(18 + 4 * i) * st]);
         o.alive = (alive >> i) & 1; o.status = RAY_CONNECTED;
     }
 #pragma unroll
-    for (int k = 0; k < ACC_N; k++) A.set(k, q[(32 + k) * st]);
+    for (int k = 0; k < ACC_N; k++) A.set(k, qld(&q[(32 + k) * st]));
 }
 // a sample that ended in the render kernel: its sums go to its slot like a continued one's (k_fold_cont adds them to the pixel)
 template <class ACC>
@@ -674,8 +678,8 @@ __device__ __forceinline__ void q_finish(const FilmD &F, unsigned slot, const AC
     Float *q = F.qRec + slot;
     const size_t st = F.qCapacity;
 #pragma unroll
-    for (int k = 0; k < ACC_N; k++) q[(32 + k) * st] = A.get(k);
-    q[13 * st] = __longlong_as_double((long long)Q_DONE);
+    for (int k = 0; k < ACC_N; k++) qst(&q[(32 + k) * st], A.get(k));
+    qst(&q[13 * st], __longlong_as_double((long long)Q_DONE));
 }
 __device__ __forceinline__ bool all_connected(const Lane &L)
 {
@@ -799,10 +803,10 @@ __global__ __launch_bounds__(TBLK) void k_primary(SceneD S, ConfigD cfg, FilmD F
         camera_ray(S.cam, sx + ox, sy + oy, apx, apy, o, d, mint, maxt);
         Hit h;
         trace<false>(sv, stack, o, d, ray_mint_closest(o, mint), maxt, h);
-        F.pHit[(size_t)(3 * r) * F.qCapacity + slot] = h.t;
-        F.pHit[(size_t)(3 * r + 1) * F.qCapacity + slot] = h.u;
-        F.pHit[(size_t)(3 * r + 2) * F.qCapacity + slot] = h.v;
-        F.pPrim[(size_t)r * F.qCapacity + slot] = h.prim;
+        qst(&F.pHit[(size_t)(3 * r) * F.qCapacity + slot], h.t);
+        qst(&F.pHit[(size_t)(3 * r + 1) * F.qCapacity + slot], h.u);
+        qst(&F.pHit[(size_t)(3 * r + 2) * F.qCapacity + slot], h.v);
+        __builtin_nontemporal_store(h.prim, &F.pPrim[(size_t)r * F.qCapacity + slot]);
     }
 }
 
@@ -874,10 +878,10 @@ __global__ __launch_bounds__(TBLK) void k_fold_cont(SceneD S, ConfigD cfg, FilmD
     for (int s = 0; s < cfg.sCount; s++) {
         const unsigned slot = (unsigned)s * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
         const Float *q = F.qRec + slot;
-        if ((unsigned long long)__double_as_longlong(q[13 * st]) != Q_DONE) continue;         // (a cancelled frame: the sample was never started)
+        if ((unsigned long long)__double_as_longlong(qld(&q[13 * st])) != Q_DONE) continue;         // (a cancelled frame: the sample was never started)
         Acc<false> A;
 #pragma unroll
-        for (int k = 0; k < ACC_N; k++) A.a[k] = q[(32 + k) * st];
+        for (int k = 0; k < ACC_N; k++) A.a[k] = qld(&q[(32 + k) * st]);
         Rng rng;
         rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)(cfg.sBase + s));
         const Float sx = px + rng.next1D(), sy = py + rng.next1D();              // the sample's position, as start_path drew it (gpt.cpp:1261)
