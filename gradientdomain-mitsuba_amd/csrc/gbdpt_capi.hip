@@ -17,7 +17,7 @@ using namespace gdpt_bd;
 
 extern "C" int gdpt_internal_fail(int code, const char *msg);
 
-namespace {
+namespace gdpt_bdk {        // (named: rocprofv3 prints kernels of an anonymous namespace without their names)
 
 int bfail(int code, const char *fmt, ...)
 {
@@ -201,7 +201,8 @@ __global__ void k_gbdpt_develop(const Float *__restrict__ block, const Float *__
     for (int k = 0; k < 3; k++) out[3 * i + k] = (block[4 * i + k] + light[3 * i + k] * wgt) * inv;
 }
 
-} // namespace
+} // namespace gdpt_bdk
+using namespace gdpt_bdk;
 
 struct gdpt_gbdpt_film {
     gdpt_scene *scene = nullptr;
