@@ -810,10 +810,16 @@ __device__ __forceinline__ void pair_range(const BdConfig &cfg, int nS, int s, i
 // CLS: the item class the connection belongs to -- 0: light tracing (t == 1), 1: sensor vertex t inside or at the end of the shifted part, 2: beyond it
 // (shares_connection).  A compile-time class lets each build drop the other classes' locals (the cloned end vertices and the transient offset of a
 // light path are 1.2 KB of vertex records that live in scratch because they are passed by reference).
-template <int CLS>
+// PHASE: 0 = the whole connection (the probe entry); 1 = the base path only: returns whether it carries anything and its primal term -- most
+// connections end here (blocked, back-facing, zero throughput), and a wave in which one lane goes on to the four offsets while the others wait ran
+// at 17 % lane utilisation; 2 = the offsets of a connection that survived phase 1: the base path is evaluated again for the state the offsets
+// share with it (its rays are not counted twice), the gradients are the output.  Phases 1 and 2 run as two launches with the survivors compacted
+// in between.
+template <int CLS, int PHASE = 0>
 __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po)
 {
     constexpr bool T1 = CLS == 0;
+    const unsigned nClosest0 = c.nClosest, nShadow0 = c.nShadow;
     const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
     const int vert_b = 2;                                                                  // connectPath.vertexCount() - 1 - extra[1]: b is sensor vertex 2
     const int nE = sm.nY;
@@ -839,7 +845,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
     MisBase misBase;                                                                       // the base path's strategy densities of this connection (k = 0), reused by k = 1..4
     BV vtBaseCast;                                                                         // s == 0: the base path's sensor vertex t as the emitter sample it was cast to
     Float jacLP[4] = {1.0, 1.0, 1.0, 1.0};
-    for (int k = 0; k <= 4; k++) {
+    for (int k = 0; k <= (PHASE == 1 ? 0 : 4); k++) {
         miW[k] = 1.0 / (s + t + 1);
         bool ok = k == 0 ? true : (sm.off[k - 1].success != 0);
         value[k] = mk(0.0); valuePdf[k] = 0.0;
@@ -921,11 +927,13 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
         printf("st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\n", s, t, k, (int)ok, value[k].x, value[k].y, value[k].z, valuePdf[k], miW[k], geomTerm, c.nClosest, c.nShadow);
 #endif
         if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miW[k] = miW[0]; valuePdf[k] = valuePdf[0]; }
+        if (PHASE == 2 && k == 0) { c.nClosest = nClosest0; c.nShadow = nShadow0; }        // (counted by phase 1)
     }
     if (is_zero(value[0])) return false;
     const d3 mainRad = value[0] * (valuePdf[0] * miW[0]);
     po.primal = mainRad;
-    if (T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+    if (PHASE != 2 && T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+    if (PHASE == 1) return true;
     const d3 fx = value[0] * valuePdf[0];
     for (int n = 0; n < 4; n++) {
         const d3 fy = value[n + 1] * valuePdf[n + 1] * (T1 ? jacLP[n] : sm.off[n].jacobian);
