@@ -124,46 +124,50 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_walk(SceneD S, BdCam cam, BdConf
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); atomicAdd(stats + 2, (unsigned long long)n); }
 }
 
-// PHASE 1: one lane per connection of the class's item list: the base path; adds its primal term and appends the connections that carry
-// anything to the survivor list (one atomic per wave).  PHASE 2: one lane per survivor: the four offsets, the gradient terms.
+// Three launches per class, each over the survivors of the one before (lists compacted with one atomic per wave):
+//   PHASE 3  every connection of the class's item list: the part of the base path that needs no visibility ray of the connection;
+//   PHASE 1  the base path: visibility, geometry term, MIS weight; adds the primal term;
+//   PHASE 2  the four offsets of the connections whose base path carries anything: the gradient terms.
 template <int CLS, int PHASE>
-__global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ items, unsigned nItems,
-                                                     unsigned *__restrict__ survivors, unsigned *__restrict__ nSurvivors, Float *__restrict__ acc, Float *__restrict__ light,
-                                                     unsigned long long *__restrict__ stats)
+__global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ in, unsigned nIn,
+                                                     const unsigned *__restrict__ nInDev, unsigned *__restrict__ out, unsigned *__restrict__ nOut, Float *__restrict__ acc,
+                                                     Float *__restrict__ light, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned i = blockIdx.x * TBLK + threadIdx.x;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
-    const unsigned n = PHASE == 2 ? __hip_atomic_load(nSurvivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nItems;
-    if (PHASE == 2 && blockIdx.x * TBLK >= n) return;                                       // (the grid is sized for the item list: its tail has nothing to do)
+    const unsigned n = nInDev ? __hip_atomic_load(nInDev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nIn;
+    if (blockIdx.x * TBLK >= n) return;                                                     // (the grid is sized for the item list: its tail has nothing to do)
     bool keep = false;
     unsigned it = 0;
     if (i < n) {
-        it = PHASE == 2 ? survivors[i] : items[i];
+        it = in[i];
         const unsigned lid = it >> 10;
         const int s = (int)((it >> 5) & 31u), t = (int)(it & 31u);
         PairOut po;
         if (connect_pair<CLS, PHASE>(c, recs[lid], s, t, po)) {
             keep = true;
-            const int W = S.cam.width, H = S.cam.height;
-            const size_t plane3 = (size_t)W * H * 3;
-            if (CLS != 0) {
-                Float *a = acc + (size_t)lid * 15;
-                if (PHASE == 1) { atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z); }
-                else for (int g = 0; g < 4; g++) { atomicAdd(a + 3 + 3 * g, po.gradient[g].x); atomicAdd(a + 4 + 3 * g, po.gradient[g].y); atomicAdd(a + 5 + 3 * g, po.gradient[g].z); }
-            } else
-                for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, W, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
+            if (PHASE != 3) {
+                const int W = S.cam.width, H = S.cam.height;
+                const size_t plane3 = (size_t)W * H * 3;
+                if (CLS != 0) {
+                    Float *a = acc + (size_t)lid * 15;
+                    if (PHASE == 1) { atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z); }
+                    else for (int g = 0; g < 4; g++) { atomicAdd(a + 3 + 3 * g, po.gradient[g].x); atomicAdd(a + 4 + 3 * g, po.gradient[g].y); atomicAdd(a + 5 + 3 * g, po.gradient[g].z); }
+                } else
+                    for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, W, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
+            }
         }
     }
-    if (PHASE == 1) {
+    if (PHASE != 2) {
         const unsigned long long mask = __ballot(keep);
         if (mask) {
             const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)mask) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(nSurvivors, (unsigned)__popcll(mask));
+            if (lane == leader) base = atomicAdd(nOut, (unsigned)__popcll(mask));
             base = __shfl(base, leader);
-            if (keep) survivors[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = it;
+            if (keep) out[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = it;
         }
     }
     const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
@@ -344,15 +348,15 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (chunk > f->capacity) {
         hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
         f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->capacity = 0;
-        if (hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) != hipSuccess || hipMalloc((void **)&f->items, sizeof(unsigned) * 6 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) != hipSuccess ||      // three item lists + three survivor lists
-            hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 6) != hipSuccess || hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) != hipSuccess)
-            return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f GB)", chunk, (sizeof(Sample) + 8.0 * BD_ITEMS_PER_SAMPLE + 120.0) * chunk / 1e9);
+        if (hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) != hipSuccess || hipMalloc((void **)&f->items, sizeof(unsigned) * 9 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) != hipSuccess ||      // three item lists + two survivor lists each
+            hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 9) != hipSuccess || hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) != hipSuccess)
+            return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f GB)", chunk, (sizeof(Sample) + 12.0 * BD_ITEMS_PER_SAMPLE + 120.0) * chunk / 1e9);
         f->capacity = chunk;
     }
     for (long long first = 0; first < total; first += chunk) {
         const unsigned count = (unsigned)std::min<long long>(chunk, total - first);
         const size_t itemStride = (size_t)f->capacity * BD_ITEMS_PER_SAMPLE;
-        BHIPCHK(hipMemsetAsync(f->itemCount, 0, sizeof(unsigned) * 6, f->stream));
+        BHIPCHK(hipMemsetAsync(f->itemCount, 0, sizeof(unsigned) * 9, f->stream));
         hipLaunchKernelGGL(k_bd_walk, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats);
         BHIPCHK(hipGetLastError());
         unsigned nItems[3] = {0, 0, 0};
@@ -362,11 +366,15 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
             if (!nItems[q]) continue;
             const dim3 cgrid((nItems[q] + TBLK - 1) / TBLK);
             const unsigned *list = f->items + q * itemStride;
-            unsigned *surv = f->items + (3 + q) * itemStride, *nSurv = f->itemCount + 3 + q;
+            unsigned *listA = f->items + (3 + q) * itemStride, *nA = f->itemCount + 3 + q, *listB = f->items + (6 + q) * itemStride, *nB = f->itemCount + 6 + q;
 #define BD_CONNECT(CLSV) do { \
-                hipLaunchKernelGGL((k_bd_connect<CLSV, 1>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], surv, nSurv, f->acc, f->light, f->stats); \
-                hipLaunchKernelGGL((k_bd_connect<CLSV, 2>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], surv, nSurv, f->acc, f->light, f->stats); } while (0)
-            if (q == 0) BD_CONNECT(0); else if (q == 1) BD_CONNECT(1); else BD_CONNECT(2);
+                hipLaunchKernelGGL((k_bd_connect<CLSV, 3>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], (const unsigned *)nullptr, listA, nA, f->acc, f->light, f->stats); \
+                hipLaunchKernelGGL((k_bd_connect<CLSV, 1>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)listA, nItems[q], (const unsigned *)nA, listB, nB, f->acc, f->light, f->stats); \
+                hipLaunchKernelGGL((k_bd_connect<CLSV, 2>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)listB, nItems[q], (const unsigned *)nB, (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->light, f->stats); } while (0)
+            if (q == 0) {        // light tracing: two launches (base path, offsets of the survivors)
+                hipLaunchKernelGGL((k_bd_connect<0, 1>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], (const unsigned *)nullptr, listB, nB, f->acc, f->light, f->stats);
+                hipLaunchKernelGGL((k_bd_connect<0, 2>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)listB, nItems[q], (const unsigned *)nB, (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->light, f->stats);
+            } else if (q == 1) BD_CONNECT(1); else BD_CONNECT(2);
 #undef BD_CONNECT
             BHIPCHK(hipGetLastError());
         }

@@ -810,7 +810,8 @@ __device__ __forceinline__ void pair_range(const BdConfig &cfg, int nS, int s, i
 // CLS: the item class the connection belongs to -- 0: light tracing (t == 1), 1: sensor vertex t inside or at the end of the shifted part, 2: beyond it
 // (shares_connection).  A compile-time class lets each build drop the other classes' locals (the cloned end vertices and the transient offset of a
 // light path are 1.2 KB of vertex records that live in scratch because they are passed by reference).
-// PHASE: 0 = the whole connection (the probe entry); 1 = the base path only: returns whether it carries anything and its primal term -- most
+// PHASE: 0 = the whole connection (the probe entry); 3 = the part of the base path that needs no visibility ray of the connection (end points
+// connectable, facing each other, non-zero throughput; for light tracing: the sensor connection): a filter in front of phase 1; 1 = the base path only: returns whether it carries anything and its primal term -- most
 // connections end here (blocked, back-facing, zero throughput), and a wave in which one lane goes on to the four offsets while the others wait ran
 // at 17 % lane utilisation; 2 = the offsets of a connection that survived phase 1: the base path is evaluated again for the state the offsets
 // share with it (its rays are not counted twice), the gradients are the output.  Phases 1 and 2 run as two launches with the survivors compacted
@@ -837,6 +838,8 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
         pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE);
         sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
     }
+    if (PHASE == 1 && !T1) { c.nClosest = nClosest0; c.nShadow = nShadow0; }               // (the rays up to here were counted by phase 3; light tracing has no phase 3:
+                                                                                           //  its filter IS a visibility ray -- the sensor connection -- and a launch of its own for it cost more than it saved)
     BE connEdge, connEdgeBase;
     d3 connPartsBase = mk(0.0);
     Float geomBase = 0.0;
@@ -845,7 +848,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
     MisBase misBase;                                                                       // the base path's strategy densities of this connection (k = 0), reused by k = 1..4
     BV vtBaseCast;                                                                         // s == 0: the base path's sensor vertex t as the emitter sample it was cast to
     Float jacLP[4] = {1.0, 1.0, 1.0, 1.0};
-    for (int k = 0; k <= (PHASE == 1 ? 0 : 4); k++) {
+    for (int k = 0; k <= ((PHASE == 1 || PHASE == 3) ? 0 : 4); k++) {
         miW[k] = 1.0 / (s + t + 1);
         bool ok = k == 0 ? true : (sm.off[k - 1].success != 0);
         value[k] = mk(0.0); valuePdf[k] = 0.0;
@@ -899,6 +902,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
                 valuePdf[k] = impPk * radPk;
             }
             if (is_zero(value[k]) || valuePdf[k] == 0) break;
+            if (PHASE == 3) return true;                                                    // (k == 0: both end points face each other and carry throughput -- worth a visibility ray)
             const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connEdge, *vsP, *vtP);
             if (k == 0) successConnectBase = successConnect;
             if (!successConnect) { value[k] = mk(0.0); break; }
@@ -929,7 +933,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
         if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miW[k] = miW[0]; valuePdf[k] = valuePdf[0]; }
         if (PHASE == 2 && k == 0) { c.nClosest = nClosest0; c.nShadow = nShadow0; }        // (counted by phase 1)
     }
-    if (is_zero(value[0])) return false;
+    if (PHASE == 3 || is_zero(value[0])) return false;
     const d3 mainRad = value[0] * (valuePdf[0] * miW[0]);
     po.primal = mainRad;
     if (PHASE != 2 && T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
