@@ -244,7 +244,7 @@ def bench_gbdpt(a, rank, local, world, dev):
                "poisson": {"L2D": {"solve_ms_per_step": round(1e3 * solve[0] / a.steps, 4), "mpix_iter_s": round(npx * 50 * a.steps / solve[0] / 1e6, 1) if solve[0] > 0 else None},
                            "L1D": {"solve_ms_per_step": round(1e3 * solve[1] / a.steps, 4), "mpix_iter_s": round(npx * 1000 * a.steps / solve[1] / 1e6, 1) if solve[1] > 0 else None}, "dtype": "f32"},
                "roofline": None,
-               "roofline_note": "the G-BDPT sampler runs as walk / connect / put launches joined by 11 KB sample records in HBM (DESIGN.md, G-BDPT); the connection kernels (70 % of a frame; one build per item class and phase -- base path for every connection, offsets for the survivors --, MIS weights as recurrences over the record) are latency-bound at 2 waves/SIMD on dependent record and scene-table loads plus fp64 BSDF evaluations -- counter traffic ~0.9 TB/s, a ninth of the HBM peak: no HBM or MFMA fraction applies; the reconstructions are the persistent CG of --config 2"}
+               "roofline_note": "the G-BDPT sampler runs as walk / connect / put launches joined by 11 KB sample records in HBM (DESIGN.md, G-BDPT); the connection kernels (70 % of a frame; one build per item class and phase -- a ray-free filter, the base path, the offsets, each on the survivors of the one before --, MIS weights as recurrences over the record) are latency-bound at 2 waves/SIMD on dependent record and scene-table loads plus fp64 BSDF evaluations -- counter traffic ~0.9 TB/s, a ninth of the HBM peak: no HBM or MFMA fraction applies; the reconstructions are the persistent CG of --config 2"}
         print(json.dumps(out))
     sr.close(); scene.close()
     if world > 1:
