@@ -78,22 +78,78 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
 constexpr int BD_ITEMS_PER_SAMPLE = 96;            // >= 90 = sum over s of the t-range at maxDepth 12 (pair_range)
 constexpr unsigned BD_CHUNK = 1u << 21;            // samples per chunk: 23 GB of records, 2.4 GB of item lists
 
-__global__ __launch_bounds__(TBLK, 2) void k_bd_walk(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, long long first, unsigned count, Sample *__restrict__ recs,
-                                                  unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats)
+// The two subpaths of every sample (Path::alternatingRandomWalkFromPixel, path.cpp:548-631) with PERSISTENT lanes: the subpaths of a sample have between
+// 3 and 25 vertices (Russian roulette), and with one sample per lane a wave took as long as its longest pair (40 % lane utilisation).  Here a
+// lane walks through its share of the chunk's samples in ONE flat loop -- every iteration either starts the next sample (sample_sensor) or advances
+// the current one by one step of each subpath (sample_next), exactly the body of walk_paths' loop -- so the lanes of a wave are at different
+// samples but in the same code.  Which lane walks which sample does not matter: a sample's random numbers are its own, its record is recs[lid].
+__global__ __launch_bounds__(TBLK, 2) void k_bd_paths(SceneD S, BdCam cam, BdConfig cfg, int x0, int y0, int x1, int y1, long long first, unsigned count, Sample *__restrict__ recs,
+                                                   unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned total = gridDim.x * TBLK;
+    unsigned next = blockIdx.x * TBLK + threadIdx.x, lid = 0, done = 0;
+    const int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth + 1;                  // gbdpt_proc.cpp:110-122: degenerate (pinhole) sensor, hittable emitters
+    bool have = false, walkT = false, walkS = false;
+    int s = 0, t = 0;
+    d3 thrS = mk(1.0), thrT = mk(1.0);
+    while (true) {
+        if (!have) {
+            if (next >= count) break;
+            lid = next; next += total;
+            const int w = x1 - x0;
+            const long long gid = first + lid;
+            const int sIdx = (int)(gid % cfg.spp);
+            const long long pix = gid / cfg.spp;
+            const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
+            c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sIdx);
+            Sample &sm = recs[lid];
+            bv_clear(sm.X[0]); sm.X[0].type = T_SENSOR_SUPER; sm.X[0].degenerate = 1;       // makeEndpoint, vertex.cpp:27-33
+            bv_clear(sm.Y[0]); sm.Y[0].type = T_EMITTER_SUPER; sm.Y[0].degenerate = 0;
+            sm.nX = 1; sm.nY = 1;
+            t = sample_sensor(c, sm.X[0], px, py, sm.EX[0], sm.X[1], sm.EX[1], sm.X[2]);
+            sm.nX = 1 + t;
+            walkT = t == 2; walkS = true;
+            thrS = mk(1.0); thrT = mk(1.0);
+            s = 0;
+            have = true;
+        } else {
+            Sample &sm = recs[lid];
+            if (walkT && t < sensorDepth) {
+                if (sample_next(c, sm.X[t], &sm.X[t - 1], &sm.EX[t - 1], sm.EX[t], sm.X[t + 1], ERadiance, cfg.rrDepth != -1 && t >= cfg.rrDepth, thrT)) { t++; sm.nX++; }
+                else walkT = false;
+            } else walkT = false;
+            if (walkS && s < emitterDepth) {
+                if (sample_next(c, sm.Y[s], s > 0 ? &sm.Y[s - 1] : nullptr, s > 0 ? &sm.EY[s - 1] : nullptr, sm.EY[s], sm.Y[s + 1], EImportance, cfg.rrDepth != -1 && s >= cfg.rrDepth, thrS)) { s++; sm.nY++; }
+                else walkS = false;
+            } else walkS = false;
+            if (!(walkS || walkT)) {
+                sm.posX = sm.X[1].u; sm.posY = sm.X[1].v;
+                for (int k = 0; k < 4; k++) { sm.off[k].success = 0; sm.off[k].couldConnectAfterB = 0; sm.off[k].jacobian = 1.0; }
+                if (sm.nY < 2) sm.nY = 0;                                                    // (no emitter could be sampled: a scene without power; no connections)
+                have = false; done++;
+            }
+        }
+    }
+    const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    const unsigned n = __builtin_amdgcn_wave_reduce_add_u32(done, 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); atomicAdd(stats + 2, (unsigned long long)n); }
+}
+
+// One lane per sample: the connected base path and its four offset paths, the prefix products (walk_shift), the sample's connections appended to
+// the three item lists.
+__global__ __launch_bounds__(TBLK, 2) void k_bd_shift(SceneD S, BdCam cam, BdConfig cfg, unsigned count, Sample *__restrict__ recs,
+                                                   unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned lid = blockIdx.x * TBLK + threadIdx.x;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
     if (lid < count) {
-        const int w = x1 - x0;
-        const long long gid = first + lid;
-        const int sIdx = (int)(gid % cfg.spp);                                             // consecutive lanes: consecutive samples of one pixel, then the next pixel
-        const long long pix = gid / cfg.spp;
-        const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
-        c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sIdx);
         Sample &sm = recs[lid];
-        walk_sample(c, sm, px, py);
+        if (sm.nY >= 2) walk_shift(c, sm);
         for (int k = 0; k < 15; k++) acc[(size_t)lid * 15 + k] = 0.0;
         unsigned n = 0;
         for (int s = sm.nY - 1; s >= 0; --s) { int minT, maxT; pair_range(cfg, sm.nX, s, minT, maxT); if (maxT >= minT) n += (unsigned)(maxT - minT + 1); }
@@ -120,8 +176,7 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_walk(SceneD S, BdCam cam, BdConf
         }
     }
     const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
-    const unsigned n = __builtin_amdgcn_wave_reduce_add_u32(lid < count ? 1u : 0u, 0);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); atomicAdd(stats + 2, (unsigned long long)n); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
 }
 
 // Three launches per class, each over the survivors of the one before (lists compacted with one atomic per wave):
@@ -357,7 +412,9 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         const unsigned count = (unsigned)std::min<long long>(chunk, total - first);
         const size_t itemStride = (size_t)f->capacity * BD_ITEMS_PER_SAMPLE;
         BHIPCHK(hipMemsetAsync(f->itemCount, 0, sizeof(unsigned) * 9, f->stream));
-        hipLaunchKernelGGL(k_bd_walk, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats);
+        const unsigned pgrid = std::min<unsigned>((count + TBLK - 1) / TBLK, (unsigned)s->numCUs * 2u);      // persistent: the grid that is resident at 2 waves per SIMD
+        hipLaunchKernelGGL(k_bd_paths, dim3(pgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->stats);
+        hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats);
         BHIPCHK(hipGetLastError());
         unsigned nItems[3] = {0, 0, 0};
         BHIPCHK(hipMemcpyAsync(nItems, f->itemCount, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, f->stream));
