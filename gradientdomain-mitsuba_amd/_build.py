@@ -90,6 +90,51 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# The optimisation fence (tests/test_opt_fence_gpu.py): the SAME library with the tracer unit compiled at -O1.  Both miscompiles
+# met so far were -O3-only (tools/repro/README.md); every film and ray count of the -O3 product is held against this build on the GPU.
+FENCE_OPT = "-O1"
+FENCE_LIB = os.path.join(PKG, "lib", "libgdpt_hip_O1.so")
+FENCE_UNIT = "gpt_capi.hip"
+
+
+def fence_stale():
+    if not os.path.exists(FENCE_LIB):
+        return True
+    t = os.path.getmtime(FENCE_LIB)
+    return any(os.path.getmtime(d) > t for d in _deps(FENCE_UNIT))
+
+
+def build_fence(force=False, verbose=False):
+    """lib/libgdpt_hip_O1.so: gpt_capi.hip at -O1 (6 min of hipcc, started BEFORE the product build so that the two run side by side),
+    linked with the other units' product objects."""
+    if not force and not fence_stale():
+        return FENCE_LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [FENCE_OPT if f == FLAGS[1] else f for f in FLAGS]
+    o1 = os.path.join(OBJDIR, "gpt_capi_O1.o")
+    jobs = []
+    if force or not os.path.exists(o1) or any(os.path.getmtime(d) > os.path.getmtime(o1) for d in _deps(FENCE_UNIT)):
+        jobs.append([hipcc] + flags + ["-c", "-o", o1, os.path.join(CSRC, FENCE_UNIT)])
+    others = [u for u in UNITS if u != FENCE_UNIT]
+    if not stale():                                      # a tree that arrived with the product library but without lib/obj/
+        jobs += [[hipcc] + FLAGS + UNIT_FLAGS.get(u, []) + ["-c", "-o", _obj(u), os.path.join(CSRC, u)] for u in others if not os.path.exists(_obj(u))]
+    procs = []
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd))
+    build(verbose=verbose)
+    for cmd, p in zip(jobs, procs):
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", FENCE_LIB, o1] + [_obj(u) for u in others]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return FENCE_LIB
+
+
 HOST_BIN = os.path.join(PKG, "bin", "gdpt_mitsuba")
 
 

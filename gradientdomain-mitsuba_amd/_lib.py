@@ -15,10 +15,11 @@ class GdptError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_build.LIB):
+        path = os.environ.get("GDPT_LIB") or _build.LIB          # GDPT_LIB: another BUILD of the same HIP sources (the -O1 fence, _build.FENCE_LIB)
+        if not os.path.exists(path):
             raise GdptError("HIP library %s is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
-                            "(no CPU fallback exists)" % _build.LIB)
-        _lib = C.CDLL(_build.LIB)
+                            "(no CPU fallback exists)" % path)
+        _lib = C.CDLL(path)
         _lib.gdpt_last_error.restype = C.c_char_p
     return _lib
 
