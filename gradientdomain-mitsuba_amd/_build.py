@@ -90,33 +90,38 @@ def build(force=False, verbose=False):
     return LIB
 
 
-# The optimisation fence (tests/test_opt_fence_gpu.py): the SAME library with the tracer unit compiled at -O1.  Both miscompiles
-# met so far were -O3-only (tools/repro/README.md); every film and ray count of the -O3 product is held against this build on the GPU.
+# The optimisation fence (tests/test_opt_fence_gpu.py): the SAME library with the two tracer units compiled at -O1.  Both
+# miscompiles met so far were -O3-only (tools/repro/README.md); films and ray counts of the -O3 product are held against this build on the GPU.
 FENCE_OPT = "-O1"
 FENCE_LIB = os.path.join(PKG, "lib", "libgdpt_hip_O1.so")
-FENCE_UNIT = "gpt_capi.hip"
+FENCE_UNITS = ("gpt_capi.hip", "gbdpt_capi.hip")
+
+
+def _fence_obj(unit):
+    return os.path.join(OBJDIR, unit.replace(".hip", "_O1.o"))
 
 
 def fence_stale():
     if not os.path.exists(FENCE_LIB):
         return True
     t = os.path.getmtime(FENCE_LIB)
-    return any(os.path.getmtime(d) > t for d in _deps(FENCE_UNIT))
+    return any(os.path.getmtime(d) > t for u in FENCE_UNITS for d in _deps(u))
 
 
 def build_fence(force=False, verbose=False):
-    """lib/libgdpt_hip_O1.so: gpt_capi.hip at -O1 (6 min of hipcc, started BEFORE the product build so that the two run side by side),
-    linked with the other units' product objects."""
+    """lib/libgdpt_hip_O1.so: gpt_capi.hip (6 min of hipcc) and gbdpt_capi.hip at -O1, started BEFORE the product build so that they run
+    side by side with it, linked with the other units' product objects."""
     if not force and not fence_stale():
         return FENCE_LIB
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = [FENCE_OPT if f == FLAGS[1] else f for f in FLAGS]
-    o1 = os.path.join(OBJDIR, "gpt_capi_O1.o")
     jobs = []
-    if force or not os.path.exists(o1) or any(os.path.getmtime(d) > os.path.getmtime(o1) for d in _deps(FENCE_UNIT)):
-        jobs.append([hipcc] + flags + ["-c", "-o", o1, os.path.join(CSRC, FENCE_UNIT)])
-    others = [u for u in UNITS if u != FENCE_UNIT]
+    for u in FENCE_UNITS:
+        o = _fence_obj(u)
+        if force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in _deps(u)):
+            jobs.append([hipcc] + flags + UNIT_FLAGS.get(u, []) + ["-c", "-o", o, os.path.join(CSRC, u)])
+    others = [u for u in UNITS if u not in FENCE_UNITS]
     if not stale():                                      # a tree that arrived with the product library but without lib/obj/
         jobs += [[hipcc] + FLAGS + UNIT_FLAGS.get(u, []) + ["-c", "-o", _obj(u), os.path.join(CSRC, u)] for u in others if not os.path.exists(_obj(u))]
     procs = []
@@ -128,7 +133,7 @@ def build_fence(force=False, verbose=False):
     for cmd, p in zip(jobs, procs):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", FENCE_LIB, o1] + [_obj(u) for u in others]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", FENCE_LIB] + [_fence_obj(u) for u in FENCE_UNITS] + [_obj(u) for u in others]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

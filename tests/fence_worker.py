@@ -3,14 +3,16 @@ library the environment selects (GDPT_LIB: the -O1 build; unset: the -O3 product
 scenes follow tools/gpu_fuzz_campaign.py's recipe: fuzzed Cornell boxes (random materials; a constant environment, a latitude-longitude map
 or none; vertex normals, point lights, thin lenses), every seventh seed the atrium, strictNormals on a third of the seeds; every seed
 through the HBM-scene builds (GDPT_SCENE_IN_HBM), every fourth also through the LDS-scene builds; the staged pipeline and the single kernel
-built for 4 waves per SIMD (the one that keeps its Lane in scratch)."""
+built for 4 waves per SIMD (the one that keeps its Lane in scratch).  Every third seed also one G-BDPT film (tools/gpu_gbdpt_fuzz.py's recipe:
+connectable Cornell boxes or the Veach-bidir stand-in, random maxDepth / rrDepth / lightImage) through the wavefront kernels: camera blocks,
+light image, both ray counters."""
 import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 
-from gradientdomain_mitsuba_amd import gpt as G, scenes
+from gradientdomain_mitsuba_amd import gpt as G, gbdpt as B, scenes
 
 VARIANTS = (("staged", 2, 2), ("single4", 0, 4))
 
@@ -60,6 +62,20 @@ def main(first, count, out):
                 res[key + "/strict"] = np.array([int(kw["strictNormals"])])
                 F.close()
             S.close()
+        if seed % 3 == 0:
+            os.environ.pop("GDPT_SCENE_IN_HBM", None)
+            rng = np.random.default_rng(seed + 7)
+            W, H = int(rng.integers(12, 36)), int(rng.integers(8, 28))
+            sc = scenes.veach_bidir(W, H) if seed % 5 == 0 else scenes.cornell_box(W, H, "random_connectable", seed=seed)
+            integ = B.GBDPTIntegrator(maxDepth=int(rng.choice([-1, 1, 2, 3, 5, 8, 12])), rrDepth=int(rng.choice([1, 3, 5])), lightImage=bool(rng.random() < 0.7))
+            S = G.Scene(sc); F = B.Film(S)
+            integ.renderBlock(S, F, integ.config(int(rng.integers(1, 4)), 5489 + seed), (0, 0, W, H)); F.sync()
+            blk, lgt = F.accum(); st = F.stats()
+            key = "%d/0/gbdpt" % seed
+            res[key + "/film"] = np.concatenate([np.asarray(blk, np.float64).reshape(-1), np.asarray(lgt, np.float64).reshape(-1)])[None]
+            res[key + "/rays"] = np.array([st["raysTraced"], st["shadowRaysTraced"]], np.int64)
+            res[key + "/strict"] = np.array([0])
+            F.close(); S.close()
     np.savez(out, **res)
 
 

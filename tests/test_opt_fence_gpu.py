@@ -1,4 +1,4 @@
-"""The optimisation fence of VERDICT r2 #5: the tracer unit compiled at -O1 (lib/libgdpt_hip_O1.so, `_build.build_fence`) against the -O3
+"""The optimisation fence of VERDICT r2 #5: the two tracer units (G-PT, G-BDPT) compiled at -O1 (lib/libgdpt_hip_O1.so, `_build.build_fence`) against the -O3
 product, same sources, same flags otherwise.  Both miscompiles met so far (tools/repro/README.md: one 16-byte unit of an offset's
 throughput wrong in one k_render instantiation; a 4-wave variant faulting at address 0) were -O3-only and neither announced itself: this
 test renders 600 fuzz seeds (tests/fence_worker.py) through both libraries, each in its own process, and asks for identical ray counts and
@@ -38,6 +38,7 @@ def test_O1_and_O3_builds_of_the_tracer_render_the_same_films(tmp_path):
     assert sorted(o1.files) == sorted(o3.files)
     films = [k for k in o3.files if k.endswith("/film")]
     assert len(films) >= 2 * COUNT
+    assert sum(k.endswith("/gbdpt/film") for k in films) >= COUNT // 3
     strict = sum(int(o3[k[:-5] + "/strict"][0]) for k in films)
     assert strict >= len(films) // 5
     identical, worst = 0, 0.0
