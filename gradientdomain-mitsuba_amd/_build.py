@@ -105,7 +105,7 @@ def fence_stale():
     if not os.path.exists(FENCE_LIB):
         return True
     t = os.path.getmtime(FENCE_LIB)
-    return any(os.path.getmtime(d) > t for u in FENCE_UNITS for d in _deps(u))
+    return any(os.path.getmtime(d) > t for u in UNITS for d in _deps(u))        # (the other units' product objects are linked in)
 
 
 def build_fence(force=False, verbose=False):
