@@ -101,8 +101,24 @@ def _fence_obj(unit):
     return os.path.join(OBJDIR, unit.replace(".hip", "_O1.o"))
 
 
+def fence_source_hash():
+    """Contents of every source the fence library is made of (+ its optimisation level): what tests/test_opt_fence_gpu.py compares with the
+    stamp written at build time -- file times do not survive every way a tree gets copied to a GPU box, contents do."""
+    import hashlib
+    h = hashlib.sha256(FENCE_OPT.encode())
+    for d in sorted({d for u in UNITS for d in _deps(u)}):
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def fence_stamp():
+    p = FENCE_LIB + ".flags"
+    return open(p).read().strip() if os.path.exists(p) else None
+
+
 def fence_stale():
-    if not os.path.exists(FENCE_LIB):
+    if not os.path.exists(FENCE_LIB) or fence_stamp() != fence_source_hash():
         return True
     t = os.path.getmtime(FENCE_LIB)
     return any(os.path.getmtime(d) > t for u in UNITS for d in _deps(u))        # (the other units' product objects are linked in)
@@ -137,6 +153,8 @@ def build_fence(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(FENCE_LIB + ".flags", "w") as f:
+        f.write(fence_source_hash() + "\n")
     return FENCE_LIB
 
 
