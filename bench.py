@@ -9,11 +9,20 @@ random numbers are the counter-based streams both the HIP path and the oracle us
                      reference counts in raysTraced + shadowRaysTraced, skdtree.cpp:46-47) / wall time of the step
                      (render + halo exchange + develop + gather + reconstruct), all ranks, max over ranks.
   poisson          = Poisson-CG Mpix-iter/s of the reconstruction inside the same steps (HIP-event span of solveIndirect).
-  roofline         = the HBM-resident Poisson CG kernel against the 8 TB/s HBM peak (the graded kernel): the fused
+  roofline         = the TIMED STEP's dominant kernels, the staged render (k_primary + k_render + k_continue + k_fold_cont, 98.8 % of a step):
+                     not an HBM workload (the scene sits in LDS / L2), so its ceiling is VALU issue: wave-instructions of those
+                     kernels per step (committed PMC pass of THIS binary, profiles/*_counters.json, keyed by a hash of csrc/) / their launch
+                     duration by HIP events, measured live in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles; `traffic` = their FETCH_SIZE x 2
+                     + WRITE_SIZE per step.  Without a matching counter file (sources changed, another configuration) the block falls back
+                     to the live byte figure below, so that it is never null.
+  tracer_bytes     = SURVEY 8d-B's algorithmic bytes per ray (ray record + hit record + nodes visited x 64 B + triangles tested x 80 B,
+                     counted live on the device tree for 65 536 surface-born rays) x this run's rays/s against the 8 TB/s HBM peak, with
+                     the survey's caveat: the traversal is latency- and divergence-bound and is served from LDS / L2, not HBM.
+  roofline_hbm_case= the HBM-resident Poisson CG kernel against the 8 TB/s HBM peak (metric A's graded kernel): the fused
                      x_p + stencil kernel `kf_xp_Ax` at 3840x2160 (working set 1.2 GB, beyond the 256 MB Infinity Cache), algorithmic
                      bytes per launch (72 B/px) / launch duration by HIP events on the solver's stream, measured live in this run;
-                     `traffic` = FETCH_SIZE x 2 + WRITE_SIZE per launch from the committed PMC pass of THIS binary (profiles/*_counters.json,
-                     keyed by a hash of csrc/; null when the sources changed since).  frac <= 1 by construction.
+                     `traffic` = FETCH_SIZE x 2 + WRITE_SIZE per launch from the committed PMC pass.  A side measurement at a synthetic
+                     size, NOT a kernel of the timed step (whose own solve is the persistent CG below).  frac <= 1 by construction.
   persistent_cg    = the cooperative CG kernel that runs the metric's own 1280x720 solve: NOT an HBM workload (the iterate lives in
                      VGPRs, counter traffic is 25x below the algorithmic bytes), so it is reported as latency-bound with its
                      per-iteration phase budget, never as an HBM fraction.
@@ -60,11 +69,11 @@ def _source_hash():
     return h.hexdigest()[:16]
 
 
-def _profiled_counters():
+def _profiled_counters(suffix="_counters.json"):
     """-> (dict kernel-name-prefix -> counters, file name) of the newest committed counter file whose source hash matches, else ({}, None)."""
     import glob
     sh = _source_hash()
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
@@ -121,6 +130,33 @@ def poisson_hbm_roofline(P, dev, preset="L2D"):
     iters = prm.irlsIterMax * prm.cgIterMax
     return dict(w=w, h=h, preset=preset, solve_ms=1e3 * solve_s, mpix_iter_s=w * h * iters / solve_s / 1e6, kus=kus, persistent_us=pus)
 
+
+
+def tracer_bytes_block(scene, desc, rays_per_s, closest_frac):
+    """algorithmic bytes per ray of the traversal, counted live on the device BVH (gdpt_scene_trace_stats) for 65 536 rays born on
+    the scene's surfaces (area-weighted point, uniform direction: what a path's bounces produce), weighted by this run's closest-hit / any-hit mix."""
+    import numpy as np
+    v = np.asarray(desc.verts, np.float64).reshape(-1, 3, 3)
+    rng = np.random.default_rng(1)
+    n = 1 << 16
+    e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    area = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+    tri = rng.choice(len(v), size=n, p=area / area.sum())
+    u, w = rng.random(n), rng.random(n)
+    f = u + w > 1; u[f], w[f] = 1 - u[f], 1 - w[f]
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = v[tri, 0] + u[:, None] * e1[tri] + w[:, None] * e2[tri] + 1e-6 * d
+    st = scene.trace_stats(o, d)
+    NODE_B, TRI_B, RAY_B, HIT_B = 64.0, 80.0, 56.0, 28.0       # BvhNode, TriIsect (fp64 TriAccel), ray record (o, d, maxt in fp64), hit record (t, u, v, prim)
+    b_closest = RAY_B + HIT_B + st["nodes_closest"] * NODE_B + st["tris_closest"] * TRI_B
+    b_any = RAY_B + 4.0 + st["nodes_any"] * NODE_B + st["tris_any"] * TRI_B
+    bpr = closest_frac * b_closest + (1.0 - closest_frac) * b_any
+    ach = bpr * rays_per_s / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_ray": round(bpr, 1), "bytes_per_closest_ray": round(b_closest, 1), "bytes_per_shadow_ray": round(b_any, 1), "closest_hit_share_of_rays": round(closest_frac, 4),
+            "nodes_visited": {"closest": round(st["nodes_closest"], 2), "any": round(st["nodes_any"], 2)}, "tris_tested": {"closest": round(st["tris_closest"], 2), "any": round(st["tris_any"], 2)},
+            "what": "SURVEY 8d-B: (ray record + hit record + nodes_visited x 64 B + tris_tested x 80 B, counted live by gdpt_scene_trace_stats on 65 536 surface-born rays) x this run's rays/s / 8 TB/s",
+            "caveat": "not an HBM-roofline workload: the tables are served from LDS (small scenes) or L2 / Infinity Cache, the traversal is latency- and divergence-bound; path-state traffic is not in the figure"}
 
 
 def _usable_cores():
@@ -214,13 +250,13 @@ def bench_gbdpt(a, rank, local, world, dev):
         sr.render(a.spp)
     barrier()
     t0 = time.perf_counter()
-    rays = samples = 0
+    rays = samples = closest = 0
     render_ms = 0.0
     solve = [0.0, 0.0]
     phases = {}
     for _ in range(a.steps):
         sr.render(a.spp)
-        rays += sr.last["rays"]; samples += sr.last["samples"]; render_ms += sr.last["render_ms"]
+        rays += sr.last["rays"]; samples += sr.last["samples"]; render_ms += sr.last["render_ms"]; closest += sr.last["closest_rays"]
         solve[0] += sr.last["solve_s"][0]; solve[1] += sr.last["solve_s"][1]
         for k, v in sr.last["phases_ms"].items():
             phases[k] = phases.get(k, 0.0) + v
@@ -233,6 +269,36 @@ def bench_gbdpt(a, rank, local, world, dev):
         wall, render_ms, rays, samples = float(mx[0]), float(mx[1]), float(sm[2]), float(sm[3])
     if rank == 0:
         npx = W * H
+        # the ceiling figures of this line: SURVEY 8d-B's bytes per ray (live), and -- when a PMC pass of this binary's G-BDPT kernels is
+        # committed (profiles/*_counters_gbdpt.json, tools/prof_gbdpt.sh) -- the issue-slot view of the sampler: its wave-instructions PER SAMPLE
+        # from that pass x this run's samples/s against the fp64 VALU issue peak, with lane utilisation and waiting share per kernel
+        launch_s = render_ms * 1e-3 / a.steps
+        tracer_bytes = tracer_bytes_block(scene, desc, rays / launch_s / a.steps, closest / float(max(1, sr.last["rays"] * a.steps)) if world == 1 else 0.5)
+        counters, counters_file = _profiled_counters("_counters_gbdpt.json")
+        issue = None
+        bd = {k: v for k, v in counters.items() if "gdpt_bd::k_bd_" in k and "SQ_INSTS_VALU" in v}
+        put = next((v for k, v in bd.items() if "k_bd_put" in k), None)
+        if bd and put and put.get("grid_x") and world == 1:
+            # k_bd_put runs once per chunk with one thread per sample: its launches x grid = the samples of the profiled run
+            prof_samples = sum(v.get("calls", 0) * v.get("grid_x", 0) for k, v in bd.items() if "k_bd_put" in k)
+            tot = {f: sum(v.get("calls", 0) * v.get(f, 0.0) for v in bd.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE")}
+            per_sample = tot["SQ_INSTS_VALU"] / prof_samples
+            ach = per_sample * samples / (render_ms * 1e-3)
+            issue = {"bound": "valu-issue", "achieved": round(ach / 1e9, 1), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instr/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
+                     "traffic": round((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / prof_samples * samples / a.steps),
+                     "traffic_what": "FETCH_SIZE x 2 + WRITE_SIZE of the sampler's kernels per sample of the profiled run x this run's samples per step, bytes",
+                     "kernel": "k_bd_paths + k_bd_shift + k_bd_connect<*> + k_bd_put", "launch_ms_live": round(1e3 * launch_s, 3),
+                     "valu_wave_instr_per_sample": round(per_sample, 1), "profiled_samples": prof_samples,
+                     "lane_utilisation": round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if tot["SQ_ACTIVE_INST_VALU"] else None,
+                     "wait_any_frac_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4) if tot["SQ_WAVE_CYCLES"] else None,
+                     "per_kernel": {k.split("gdpt_bd::")[1].split("@")[0]: {"calls": v.get("calls"), "avg_us": v.get("avg_us"), "vgpr": v.get("vgpr"),
+                                                                           "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 3) if v.get("SQ_ACTIVE_INST_VALU") else None,
+                                                                           "wait_any_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAVE_CYCLES") else None}
+                                    for k, v in bd.items()},
+                     "counters_file": counters_file,
+                     "what": "the sampler's kernels: VALU wave-instructions per sample (committed PMC pass of this binary at the same scene and maxDepth) x this run's samples/s, against 1024 SIMDs x 2.4 GHz / 4 cycles"}
+        roofline = issue if issue else dict(tracer_bytes, kernel="k_bd_paths + k_bd_shift + k_bd_connect<*> (traversal part)", counters_file=None,
+                                            note="no committed PMC pass of the G-BDPT kernels matches this binary: the live byte figure of SURVEY 8d-B stands in for the issue-slot view")
         out = {"metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp (G-BDPT)" % (W, H, a.spp),
                "value": round(rays / wall / 1e6, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * wall / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -243,7 +309,7 @@ def bench_gbdpt(a, rank, local, world, dev):
                "reduce_bytes_per_rank": sr.last["reduce_bytes"],
                "poisson": {"L2D": {"solve_ms_per_step": round(1e3 * solve[0] / a.steps, 4), "mpix_iter_s": round(npx * 50 * a.steps / solve[0] / 1e6, 1) if solve[0] > 0 else None},
                            "L1D": {"solve_ms_per_step": round(1e3 * solve[1] / a.steps, 4), "mpix_iter_s": round(npx * 1000 * a.steps / solve[1] / 1e6, 1) if solve[1] > 0 else None}, "dtype": "f32"},
-               "roofline": None,
+               "roofline": roofline, "tracer_bytes": tracer_bytes,
                "roofline_note": "the G-BDPT sampler runs as walk / connect / put launches joined by 11 KB sample records in HBM (DESIGN.md, G-BDPT); the connection kernels (70 % of a frame; one build per item class and phase -- a ray-free filter, the base path, the offsets, each on the survivors of the one before --, MIS weights as recurrences over the record) are latency-bound at 2 waves/SIMD on dependent record and scene-table loads plus fp64 BSDF evaluations -- counter traffic ~0.9 TB/s, a ninth of the HBM peak: no HBM or MFMA fraction applies; the reconstructions are the persistent CG of --config 2"}
         print(json.dumps(out))
     sr.close(); scene.close()
@@ -405,6 +471,8 @@ def main():
                                                 for k, v in per_step.items()}})
         else:
             tracer_issue.update({"achieved": None, "frac": None})
+        closest_frac = st_["raysTraced"] / float(max(1, st_["raysTraced"] + st_["shadowRaysTraced"]))
+        tracer_bytes = tracer_bytes_block(scene, desc, rays / world / launch_s * world, closest_frac)
         # --- the persistent CG kernel that runs THIS configuration's solve: latency-bound, never an HBM fraction
         persistent = None
         if pus > 0.0:
@@ -419,7 +487,7 @@ def main():
                 persistent["counter_traffic_gbs"] = round(persistent["counter_traffic_bytes"] / (pus * 1e-6) / 1e9, 1)
         # --- the graded HBM roofline: the same CG on an HBM-resident image (3840x2160), measured live
         hb = poisson_hbm_roofline(P, dev, "L2D") if world == 1 else None
-        roofline = None
+        hbm_case = None
         if hb is not None:
             npx = hb["w"] * hb["h"]
             kb = 72.0 * npx                                    # kf_xp_Ax<unit w>: R r, p, x + W x, p, Ap = 72 B/px (x_p 60 + stencil's p read / Ap write counted once)
@@ -428,9 +496,9 @@ def main():
             hc = _kernel_counters(counters, "void gdpt::kf_xp_Ax", pick="max_grid")
             iter_bytes = 120.0 * npx
             iter_us = hb["kus"][3] + hb["kus"][1]
-            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            hbm_case = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "scope": "side measurement in this process at a synthetic HBM-resident size (%dx%d), NOT a kernel of the timed step: the step's own kernels are reported under tracer_issue (issue-bound) and persistent_cg (latency-bound) and have no HBM fraction" % (hb["w"], hb["h"]),
-                        "synthetic_size": True, "timed_step_roofline": None,
+                        "synthetic_size": True,
                         "traffic": _traffic_bytes(hc), "traffic_source": counters_file if hc else None,
                         "kernel": "kf_xp_Ax", "kernel_avg_us": round(kavg, 2), "kernel_bytes": kb,
                         "what": "fused x_p + 5-point stencil of the screened-Poisson CG at %dx%d L2D (HBM-resident: 1.2 GB working set), algorithmic 72 B/px per launch / HIP-event launch duration, measured in this run" % (hb["w"], hb["h"]),
@@ -439,6 +507,21 @@ def main():
                                       "what": "one CG iteration = kf_xp_Ax + kf_r_rz against SURVEY 8d's 120 B/pix-iter"},
                         "solve": {"ms": round(hb["solve_ms"], 3), "mpix_iter_s": round(hb["mpix_iter_s"], 1),
                                   "achieved": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9, 1), "frac": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)}}
+        # --- `roofline`: the timed step's dominant kernels.  With the committed counters of this binary: the staged render against the VALU issue
+        # peak (what bounds it); otherwise the live byte figure of SURVEY 8d-B, so that every configuration's line carries a recomputable fraction
+        if tracer_issue.get("frac") is not None:
+            roofline = {"bound": "valu-issue", "achieved": tracer_issue["achieved"], "peak": tracer_issue["peak"], "unit": tracer_issue["unit"], "frac": tracer_issue["frac"],
+                        "traffic": round(tracer_issue["fabric_traffic_gb_per_step"] * 1e9), "traffic_what": "FETCH_SIZE x 2 + WRITE_SIZE of the step's render kernels, bytes per step (scratch + sample queue; algorithmic film bytes %.2f GB)" % (31 * 8 * 2 * W * H / 1e9),
+                        "kernel": "k_primary + k_render + k_continue + k_fold_cont", "share_of_step": round(launch_s / (wall / a.steps), 4),
+                        "launch_ms_live": round(1e3 * launch_s, 3), "valu_wave_instr_per_step": round(tracer_issue["achieved"] * 1e9 * launch_s),
+                        "lane_utilisation": tracer_issue.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": tracer_issue.get("wait_any_frac_of_wave_cycles"),
+                        "per_kernel": tracer_issue.get("per_kernel"), "counters_file": tracer_issue.get("counters_file"),
+                        "what": "the timed step's render kernels: VALU wave-instructions per step (committed PMC pass of this binary) / their launch duration by HIP events in THIS run, against 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction; MFMA is not used (no dense contraction) and the scene is not HBM-resident, so neither the hbm nor the mfma ceiling applies to them"}
+        else:
+            roofline = dict(tracer_bytes)
+            roofline["kernel"] = "k_primary + k_render + k_continue + k_fold_cont (traversal part)"
+            roofline["counters_file"] = None
+            roofline["note"] = "no committed PMC pass matches this binary / configuration: the live byte figure of SURVEY 8d-B stands in for the issue-slot view"
         out = {
             "metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp" % (W, H, a.spp),
             "value": round(mray, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -457,6 +540,8 @@ def main():
                         "reference_cpu_mpix_iter_s": {"L2D": 65.8, "L1D": 80.8, "what": "BASELINE.md section 2: the reference's own solver, 1 thread, survey-stage shimmed build (supplementary)"}},
             "persistent_cg": persistent,
             "roofline": roofline,
+            "tracer_bytes": tracer_bytes,
+            "roofline_hbm_case": hbm_case,
         }
         if not a.no_cpu_baseline and a.config == 2 and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)

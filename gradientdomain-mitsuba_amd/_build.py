@@ -12,7 +12,8 @@ INC = [os.path.join(ROOT, "include", f) for f in ("gdpt_poisson.h", "gdpt_tracer
 # (the tracer unit is 4 of the 4.5 minutes of hipcc)
 UNITS = {
     "poisson_capi.hip": ["poisson_kernels.hip.h", "poisson_persistent.hip.h"],
-    "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_shift5.hip.h", "gpt_scene.hip.h"],
+    "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_shift5.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"],
+    "gpt_wave_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"],
     "gbdpt_capi.hip": ["gpt_kernels.hip.h", "gbdpt_kernels.hip.h", "gpt_scene.hip.h"],
     "device_capi.hip": [],
 }
@@ -94,7 +95,7 @@ def build(force=False, verbose=False):
 # miscompiles met so far were -O3-only (tools/repro/README.md); films and ray counts of the -O3 product are held against this build on the GPU.
 FENCE_OPT = "-O1"
 FENCE_LIB = os.path.join(PKG, "lib", "libgdpt_hip_O1.so")
-FENCE_UNITS = ("gpt_capi.hip", "gbdpt_capi.hip")
+FENCE_UNITS = ("gpt_capi.hip", "gpt_wave_capi.hip", "gbdpt_capi.hip")
 
 
 def _fence_obj(unit):
@@ -105,7 +106,8 @@ def fence_source_hash():
     """Contents of every source the fence library is made of (+ its optimisation level): what tests/test_opt_fence_gpu.py compares with the
     stamp written at build time -- file times do not survive every way a tree gets copied to a GPU box, contents do."""
     import hashlib
-    h = hashlib.sha256(FENCE_OPT.encode())
+    # (the development flags are part of the configuration: a product built with GDPT_EXTRA_FLAGS is only ever held against a fence built with the same)
+    h = hashlib.sha256((FENCE_OPT + " " + os.environ.get("GDPT_EXTRA_FLAGS", "")).encode())
     for d in sorted({d for u in UNITS for d in _deps(u)}):
         h.update(os.path.basename(d).encode())
         h.update(open(d, "rb").read())
@@ -131,7 +133,7 @@ def build_fence(force=False, verbose=False):
         return FENCE_LIB
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = [FENCE_OPT if f == FLAGS[1] else f for f in FLAGS]
+    flags = [FENCE_OPT if f == FLAGS[1] else f for f in FLAGS] + os.environ.get("GDPT_EXTRA_FLAGS", "").split()
     jobs = []
     for u in FENCE_UNITS:
         o = _fence_obj(u)
@@ -139,7 +141,7 @@ def build_fence(force=False, verbose=False):
             jobs.append([hipcc] + flags + UNIT_FLAGS.get(u, []) + ["-c", "-o", o, os.path.join(CSRC, u)])
     others = [u for u in UNITS if u not in FENCE_UNITS]
     if not stale():                                      # a tree that arrived with the product library but without lib/obj/
-        jobs += [[hipcc] + FLAGS + UNIT_FLAGS.get(u, []) + ["-c", "-o", _obj(u), os.path.join(CSRC, u)] for u in others if not os.path.exists(_obj(u))]
+        jobs += [[hipcc] + FLAGS + UNIT_FLAGS.get(u, []) + os.environ.get("GDPT_EXTRA_FLAGS", "").split() + ["-c", "-o", _obj(u), os.path.join(CSRC, u)] for u in others if not os.path.exists(_obj(u))]
     procs = []
     for cmd in jobs:
         if verbose:

@@ -76,7 +76,7 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
 // Same arithmetic per connection as the one-lane form (process_sample, kept as the probe); the sums of a sample are added in arrival order
 // instead of (s, t) order: rounding of the last bits only.
 constexpr int BD_ITEMS_PER_SAMPLE = 96;            // >= 90 = sum over s of the t-range at maxDepth 12 (pair_range)
-constexpr unsigned BD_CHUNK = 1u << 21;            // samples per chunk: 23 GB of records, 2.4 GB of item lists
+constexpr unsigned BD_CHUNK = 1u << 21;            // most samples per chunk: 23 GB of records, 7.2 GB of item lists (nine lists of 96 x 4 B per sample), 0.25 GB of sums
 
 // The two subpaths of every sample (Path::alternatingRandomWalkFromPixel, path.cpp:548-631) with PERSISTENT lanes: the subpaths of a sample have between
 // 3 and 25 vertices (Russian roulette), and with one sample per lane a wave took as long as its longest pair (40 % lane utilisation).  Here a
@@ -399,15 +399,36 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (f->timed) { float ms = 0; BHIPCHK(hipEventSynchronize(f->e1)); BHIPCHK(hipEventElapsedTime(&ms, f->e0, f->e1)); f->renderMs += ms; f->timed = false; }
     BHIPCHK(hipEventRecord(f->e0, f->stream));
     const long long pixels = (long long)(x1 - x0) * (y1 - y0), total = pixels * c.spp;
-    const unsigned chunk = (unsigned)std::min<long long>(total, BD_CHUNK);
-    if (chunk > f->capacity) {
-        hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
-        f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->capacity = 0;
-        if (hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) != hipSuccess || hipMalloc((void **)&f->items, sizeof(unsigned) * 9 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) != hipSuccess ||      // three item lists + two survivor lists each
-            hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 9) != hipSuccess || hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) != hipSuccess)
-            return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f GB)", chunk, (sizeof(Sample) + 12.0 * BD_ITEMS_PER_SAMPLE + 120.0) * chunk / 1e9);
-        f->capacity = chunk;
+    // The chunk: at most BD_CHUNK samples, at most what fits 40 % of the memory the device has free right now (+ what this film already holds) --
+    // several films on one GPU (strips wrapped onto a device, a G-PT film resident beside this one) or a partitioned / smaller part each get a
+    // share instead of failing -- halved again while the allocation itself fails.  GDPT_BD_CHUNK forces a size (tests of the chunk loop).
+    const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15;      // record + three item lists with two survivor lists each + sums
+    unsigned chunk = (unsigned)std::min<long long>(total, BD_CHUNK);
+    if (const char *e = getenv("GDPT_BD_CHUNK")) chunk = (unsigned)std::max<long long>(1, std::min<long long>(chunk, atoll(e)));
+    else {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const size_t budget = std::max<size_t>((size_t)64 << 20, (size_t)(0.4 * (double)(freeB + (size_t)f->capacity * perSample)));
+            chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(chunk, budget / perSample));
+        }
     }
+    if (chunk > f->capacity || (getenv("GDPT_BD_CHUNK") && chunk != f->capacity)) {
+        BHIPCHK(hipStreamSynchronize(f->stream));
+        for (;;) {
+            hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
+            f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->capacity = 0;
+            if (hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) == hipSuccess && hipMalloc((void **)&f->items, sizeof(unsigned) * 9 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) == hipSuccess &&
+                hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 9) == hipSuccess && hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) == hipSuccess) break;
+            (void)hipGetLastError();
+            if (chunk <= 1024) {
+                hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
+                f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr;
+                return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f MB)", chunk, (double)perSample * chunk / 1e6);
+            }
+            chunk /= 2;
+        }
+        f->capacity = chunk;
+    } else chunk = std::min<unsigned>(chunk, f->capacity);
     for (long long first = 0; first < total; first += chunk) {
         const unsigned count = (unsigned)std::min<long long>(chunk, total - first);
         const size_t itemStride = (size_t)f->capacity * BD_ITEMS_PER_SAMPLE;

@@ -7,6 +7,7 @@
 #include "gpt_shift5.hip.h"
 #endif
 #include "gpt_scene.hip.h"
+#include "gpt_wavefront.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -323,6 +324,8 @@ struct gdpt_film {
     int contRefill = 32;        // idle lanes of a wave of k_continue before they take new records together (measured: 4..48 within 4 %, 32-48 best)
     size_t qBytes = 0;          // allocation behind d.qRec
     bool primaryPass = true;    // trace the primary rays in their own kernel (k_primary)
+    int wfIters = 0;            // > 0: the first `wfIters` bounces of the continuation phase run in wavefront form (gpt_wavefront.hip.h), k_continue takes the rest
+    WfQueues *wf = nullptr;     // its queues (allocated with the sample queue)
     int lastSlices = 1;
 };
 
@@ -779,6 +782,7 @@ void gdpt_film_destroy(gdpt_film *f)
     if (f->d.qRec) hipFree(f->d.qRec);
     if (f->d.qList) hipFree(f->d.qList);
     if (f->d.qCount) hipFree(f->d.qCount);
+    wf_destroy(f->wf);
     if (f->d.pHit) hipFree(f->d.pHit);
     if (f->d.pPrim) hipFree(f->d.pPrim);
     if (f->d.spill) hipFree(f->d.spill);
@@ -835,6 +839,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     lds += sceneBytes;
     // staged pipeline (k_primary -> k_render<STAGED> -> k_continue -> k_fold_cont) or everything in the round-1 kernel
     const bool useQueue = f->continuation && !getenv("GDPT_NO_CONTINUATION");
+    const int wfIters = useQueue ? std::min(f->wfIters, wf_max_iters()) : 0;
+    if (wfIters > 0 && !f->wf) f->wf = wf_create();
     // the render kernel is built for 2 and for 4 resident waves per SIMD; the staged kernels exist for the measured optimum of the scene's
     // residency only (LDS-resident scene: 2, HBM-resident: 4) -- gdpt_film_set_occupancy applies to the single-kernel form
     const int wps = useQueue ? (s->d.ldsScene ? 2 : 4) : (f->wavesPerSimd <= 2 ? 2 : 4);
@@ -885,31 +891,34 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, (size_t)(0.4 * (double)(freeB + f->qBytes))));
         }
-        const size_t perSample = (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int));
+        const size_t perSample = (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int) + (wfIters > 0 ? wf_bytes_per_slot() : 0));
         const int wantChunk = chunk;
         for (int attempt = 0; ; attempt++) {
-            int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)0xffffffffu / qPixels));
+            int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)(wfIters > 0 ? 0x0fffffffu : 0xffffffffu) / qPixels));   // (a ray's id keeps its slot in 28 bits)
             maxChunk = std::min(maxChunk, wantChunk);
             const int nChunks = (cfg->spp + maxChunk - 1) / maxChunk;
             chunk = std::min(wantChunk, (cfg->spp + nChunks - 1) / nChunks);
             const size_t need = (size_t)chunk * perSample;
-            if (f->qBytes >= need) break;
+            if (f->qBytes >= need && (wfIters == 0 || wf_slots(f->wf) >= (size_t)chunk * qPixels)) break;
             (void)hipStreamSynchronize(f->stream);
             if (f->d.qRec) hipFree(f->d.qRec);
             if (f->d.qList) hipFree(f->d.qList);
             if (f->d.pHit) hipFree(f->d.pHit);
             if (f->d.pPrim) hipFree(f->d.pPrim);
             f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr; f->qBytes = 0;
+            if (f->wf) wf_release(f->wf);
             if (hipMalloc((void **)&f->d.qRec, (size_t)chunk * qPixels * NQ * sizeof(Float)) == hipSuccess &&
                 hipMalloc((void **)&f->d.qList, (size_t)chunk * qPixels * sizeof(unsigned)) == hipSuccess &&
                 hipMalloc((void **)&f->d.pHit, (size_t)chunk * qPixels * 15 * sizeof(Float)) == hipSuccess &&
-                hipMalloc((void **)&f->d.pPrim, (size_t)chunk * qPixels * 5 * sizeof(int)) == hipSuccess) { f->qBytes = need; break; }
+                hipMalloc((void **)&f->d.pPrim, (size_t)chunk * qPixels * 5 * sizeof(int)) == hipSuccess &&
+                (wfIters == 0 || wf_reserve(f->wf, (size_t)chunk * qPixels))) { f->qBytes = need; break; }
             (void)hipGetLastError();                                                       // the allocation failed: halve the chunk and try again
             if (f->d.qRec) hipFree(f->d.qRec);
             if (f->d.qList) hipFree(f->d.qList);
             if (f->d.pHit) hipFree(f->d.pHit);
             if (f->d.pPrim) hipFree(f->d.pPrim);
             f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr;
+            if (f->wf) wf_release(f->wf);
             if (chunk <= 1 || attempt > 24) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "Out of memory! (sample queue: %zu bytes for one sample per pixel)", perSample); }
             budget = std::max<size_t>(perSample, need / 2);
         }
@@ -921,6 +930,9 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     if (!useQueue) fd.qRec = nullptr;
     if (!usePrimary) { fd.pHit = nullptr; fd.pPrim = nullptr; }
     fd.qPixels = qPixels; fd.qCapacity = (unsigned)chunk * qPixels;
+    // wavefront continuation: k_render<STAGED> hands its samples to list 0 of the wavefront queues; k_continue takes over the list that is left
+    // after `wfIters` traced bounces (with its own cursor next to that list's count)
+    FilmD fdc = fd;
     const dim3 cgrid(s->numCUs * wps);
 #ifdef GDPT_WITH_SHIFT5
     // the shift stage with one path per lane (gpt_shift5.hip.h) instead of k_render<STAGED>: GDPT_SHIFT5=1 in a -DGDPT_WITH_SHIFT5 build
@@ -946,7 +958,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         GDPT_DEV_DUMP_QUEUE(); \
-        hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fd, stackDepth, f->contRefill); } while (0)
+        if (wfIters > 0 && wf_continue(s, f->stream, c, fd, f->wf, wfIters, stackDepth, sceneBytes) != 0) return tfail(GDPT_ERR_HIP, "wavefront launch failed"); \
+        hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
 #define GDPT_STAGED_F(LDSV, ACCV, WPS) do { \
         if (s->perVertex) GDPT_STAGED(LDSV, ACCV, WPS, true, true); \
         else if (s->specialEmitters) GDPT_STAGED(LDSV, ACCV, WPS, true, ((WPS) > 2)); /* (4-wave: the per-vertex build, see below) */ \
@@ -965,7 +978,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (useQueue) {
             // (the "finished" mark of every slot of the chunk and the two queue counters)
             THIPCHK(hipMemsetAsync(fd.qRec + (size_t)13 * fd.qCapacity, 0, sizeof(Float) * (size_t)c.sCount * qPixels, f->stream));
-            THIPCHK(hipMemsetAsync(fd.qCount, 0, 2 * sizeof(unsigned), f->stream));
+            if (wfIters > 0) { if (wf_begin_chunk(f->wf, f->stream, wfIters, fd, fdc) != 0) return tfail(GDPT_ERR_HIP, "wavefront queues: bad chunk"); }
+            else THIPCHK(hipMemsetAsync(fd.qCount, 0, 2 * sizeof(unsigned), f->stream));
         }
         if (usePrimary) {
             const size_t plds = (size_t)stackDepth * TBLK * sizeof(int) + sceneBytes;
@@ -1214,9 +1228,11 @@ int gdpt_film_set_regeneration(gdpt_film *f, int idleLanes)
 
 int gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes)
 {
-    if (!f || stages < 0 || stages > 2 || refillLanes < 0 || refillLanes > 64) return tfail(GDPT_ERR_INVALID, "pipeline: stages 0..2, refill threshold 1..64 idle lanes (0 = keep)");
+    if (!f || stages < 0 || stages > 3 || refillLanes < 0 || refillLanes > 64) return tfail(GDPT_ERR_INVALID, "pipeline: stages 0..3, refill threshold 1..64 idle lanes (0 = keep)");
     f->continuation = stages >= 1;       // (1 and 2 are the same since the staged kernels are their own builds)
     f->primaryPass = stages >= 1;
+    // 3: the continuation phase starts in wavefront form (GDPT_WF_ITERS traced bounces, default 6), k_continue runs what is left
+    f->wfIters = stages >= 3 ? (getenv("GDPT_WF_ITERS") ? std::max(0, atoi(getenv("GDPT_WF_ITERS"))) : 6) : 0;
     if (refillLanes > 0) f->contRefill = refillLanes;
     return GDPT_OK;
 }

@@ -64,18 +64,42 @@ struct Lane {
     unsigned nClosest, nShadow;
 };
 
-__device__ __forceinline__ bool cast_shadow(const SceneView &sv, int *stack, Lane &L, d3 o, d3 d, Float maxt)
-{
-    Hit h;
-    L.nShadow++;
-    return trace<true>(sv, stack, o, d, ray_mint_shadow(o, GD_EPSILON), maxt, h);
-}
-
-// testVisibility, gpt.cpp:84-93: unnormalised direction, maxt = 1 - ShadowEpsilon
-__device__ __forceinline__ bool test_visibility(const SceneView &sv, int *stack, Lane &L, d3 p1, d3 p2)
-{
-    return !cast_shadow(sv, stack, L, p1, p2 - p1, 1.0 - GD_SHADOW_EPSILON);
-}
+// ---- how a bounce gets its rays traced ------------------------------------------------------------------------------------------------
+// bounce() asks for every ray of evaluate()'s main loop through a tracer object; the ray sites of one bounce are numbered:
+//   0      the base path's emitter sample (shadow ray)              gpt.cpp:572 (sampleEmitterDirect's visibility test)
+//   1 + i  offset i's own emitter sample (shadow ray)               gpt.cpp:676
+//   5      the base path's extension (closest hit)                  gpt.cpp:768-777
+//   6 + i  offset i's ray: the reconnection's visibility test (shadow ray, :84-93,96-114) or the half-vector shift's extension (closest hit, :1050)
+// Sites 0-5 depend on the state at the top of the bounce only ("level 1"); sites 6-9 also on the hit of site 5 ("level 2").
+// MODE 0: the ray is traced in place (the megakernels).  The wavefront pipeline (gpt_wavefront.hip.h) runs the SAME source three ways:
+// MODE 1 writes the level-1 rays to a queue and stops; MODE 2 replays the bounce with their results and writes the level-2 rays; MODE 3
+// replays it with all results and is the only one that keeps what it computed -- one source, so the arithmetic is identical by construction.
+enum { SITE_NEE = 0, SITE_NEE_OFF = 1, SITE_EXT = 5, SITE_OFF = 6, N_SITES = 10 };
+struct InlineTracer {
+    static constexpr int MODE = 0;
+    const SceneView &sv;
+    int *stack;
+    __device__ __forceinline__ bool occluded(int, Lane &L, d3 o, d3 d, Float maxt) const
+    {
+        Hit h;
+        L.nShadow++;
+        return trace<true>(sv, stack, o, d, ray_mint_shadow(o, GD_EPSILON), maxt, h);
+    }
+    __device__ __forceinline__ void closest(int, Lane &L, d3 o, d3 d, Hit &h) const
+    {
+        L.nClosest++;
+        trace<false>(sv, stack, o, d, ray_mint_closest(o, GD_EPSILON), GD_INF, h);
+    }
+    // the offsets' states: here the Lane's own (a wavefront pass may keep them in the sample's record instead and fetch each one where it is used).
+    // MODIFIES: the body changes the offset (the BSDF-sampling part of a bounce; the emitter-sampling part only reads it)
+    template <bool UNROLL, bool MODIFIES, class BODY>
+    __device__ __forceinline__ void each_offset(Lane &L, BODY &&body) const { for_offsets<UNROLL>(L.off, body); }
+    __device__ __forceinline__ void scale_offset_pdfs(Lane &L, Float q) const
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) L.off[i].pdf *= q;
+    }
+};
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
@@ -161,8 +185,8 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 // too: it reads the offset's LAST OWN vertex and direction, which stop changing when the offset connects, and with those very values
 // it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
 // INL: the cold texture / environment-map lookups are inlined (4-wave builds) or real calls (2-wave builds), see tex_eval in gpt_kernels.hip.h
-template <bool ENV, bool SMOOTH, bool CONN, bool UNROLL, bool INL, class ACC>
-__device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, int *stack, Lane &L, ACC &A)
+template <bool ENV, bool SMOOTH, bool CONN, bool UNROLL, bool INL, class TR, class ACC>
+__device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, TR &tr, Lane &L, ACC &A)
 {
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
     const TriShade &mts = sv.shade[L.v.prim];
@@ -185,12 +209,13 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     const d3 mainR = reflectance_at<SMOOTH, INL>(sv, mainBSDF, L.v, L.depth == 1, &S.cam, L.sx, L.sy);                  // m_reflectance->eval(its): the constant or its bitmap texture at its.uv
 
     // ================= direct illumination sampling, :565-730 =================
-    if (bsdfType(mainBSDF) & ESmooth) {
+    if constexpr (TR::MODE == 2) { if (bsdfType(mainBSDF) & ESmooth) { L.rng.next1D(); L.rng.next1D(); } }   // (level 2 only needs the stream to advance, :572)
+    else if (bsdfType(mainBSDF) & ESmooth) {
         DRec dRec;
         dRec.ref = L.v.p; dRec.refN = (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n;       // records.inl:160-164 (no refN behind a back-sided BSDF)
         const Float lsx = L.rng.next1D(), lsy = L.rng.next1D();                  // :572
         d3 value = sample_emitter_direct<ENV>(S, sv, dRec, lsx, lsy);
-        const bool mainEmitterVisible = !cast_shadow(sv, stack, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
+        const bool mainEmitterVisible = !tr.occluded(SITE_NEE, L, dRec.ref, dRec.d, dRec.dist * (1 - GD_SHADOW_EPSILON)); // scene.cpp:869-876
         if (!mainEmitterVisible) value = mk(0.0);
         const d3 mainEmitterRadiance = value * dRec.pdf;                         // :575
         const d3 mainWoL = toLocal(mfr, dRec.d);
@@ -205,7 +230,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const Float mainWeightDenominator = (L.pdf * L.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
         const d3 mainContributionAll = L.throughput * (mainBSDFValue * mainEmitterRadiance);
         if (!cfg.strictNormals || dot(mGeoN, dRec.d) * mainWoL.z > 0) {         // :607
-            for_offsets<UNROLL>(L.off, [&](auto ic, Offset &s) __attribute__((always_inline)) {
+            tr.template each_offset<UNROLL, false>(L, [&](auto ic, Offset &s) __attribute__((always_inline)) {
                 const int i = ic;
                 d3 shiftedContribution = mk(0.0);
                 Float weight = 0;
@@ -237,7 +262,8 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             DRec sRec;
                             sRec.ref = s.v.p; sRec.refN = (shiftedBSDF.twoSided || shiftedBSDF.type == 3) ? mk(0.0) : sfr.n;
                             d3 sv_ = sample_emitter_direct<ENV>(S, sv, sRec, lsx, lsy);
-                            const bool shiftedEmitterVisible = !cast_shadow(sv, stack, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
+                            const bool shiftedEmitterVisible = !tr.occluded(SITE_NEE_OFF + i, L, sRec.ref, sRec.d, sRec.dist * (1 - GD_SHADOW_EPSILON));
+                            if constexpr (TR::MODE == 1) return;
                             if (!shiftedEmitterVisible) sv_ = mk(0.0);
                             const d3 shiftedEmitterRadiance = sv_ * sRec.pdf;
                             const Float shiftedDRecPdf = sRec.pdf;
@@ -288,8 +314,8 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     DRec envRec;                                                                  // mainDRec of an environment hit (:790-797)
     {
         Hit h;
-        L.nClosest++;
-        trace<false>(sv, stack, L.rayO, L.rayD, ray_mint_closest(L.rayO, GD_EPSILON), GD_INF, h);
+        tr.closest(SITE_EXT, L, L.rayO, L.rayD, h);
+        if constexpr (TR::MODE == 1) return true;                                // (the level-1 rays of this bounce are out)
         if (h.prim < 0) {                                                        // :786-804
             if (!ENV || S.envIndex < 0) return false;
             envRec.ref = prevP; envRec.refN = (mainBSDF.twoSided || mainBSDF.type == 3) ? mk(0.0) : mfr.n;
@@ -319,7 +345,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
     const int measure = (bs.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
 
-    for_offsets<UNROLL>(L.off, [&](auto ic, Offset &s) __attribute__((always_inline)) {      // :830
+    tr.template each_offset<UNROLL, true>(L, [&](auto ic, Offset &s) __attribute__((always_inline)) {      // :830
         const int i = ic;
         d3 shiftedContribution = mk(0.0);
         Float weight = 0;
@@ -363,8 +389,9 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             DRec er;
                             er.dist = 0.0;
                             env_fill_drec(S, er, s.v.p, L.rayD);
-                            visible = !cast_shadow(sv, stack, L, s.v.p, L.rayD, (1.0 - GD_SHADOW_EPSILON) * er.dist);
-                        } else visible = test_visibility(sv, stack, L, s.v.p, L.v.p);
+                            visible = !tr.occluded(SITE_OFF + i, L, s.v.p, L.rayD, (1.0 - GD_SHADOW_EPSILON) * er.dist);
+                        } else visible = !tr.occluded(SITE_OFF + i, L, s.v.p, L.v.p - s.v.p, 1.0 - GD_SHADOW_EPSILON);     // testVisibility, gpt.cpp:84-93: unnormalised direction, maxt = 1 - ShadowEpsilon
+                        if constexpr (TR::MODE == 2) return;
                         if (!visible) { s.alive = 0; }
                         else if (mainHitEnv) {
                             // reconnection at infinity: J = 1, wo = the base direction (:364-366); radiance and light pdf of the base (:972-976)
@@ -439,8 +466,8 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                         else if (cfg.strictNormals && dot(outgoing, ssh.geoN) * tsOut.z <= 0) ok = false;
                         else {
                             Hit h;
-                            L.nClosest++;
-                            trace<false>(sv, stack, s.v.p, outgoing, ray_mint_closest(s.v.p, GD_EPSILON), GD_INF, h);   // :1050-1052
+                            tr.closest(SITE_OFF + i, L, s.v.p, outgoing, h);                                            // :1050-1052
+                            if constexpr (TR::MODE == 2) return;
                             if (h.prim < 0) {                                    // :1052-1074
                                 if (!ENV || S.envIndex < 0 || !mainHitEnv || (mainVertexDiffuse && shiftedVertexDiffuse)) ok = false;
                                 else { shiftedEmitterRadiance = env_radiance<INL>(S, sv, outgoing); envEnd = true; }
@@ -477,14 +504,14 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         add_offset_sums(A, i, mc * weight, shiftedContribution * weight, (shiftedContribution - mc) * weight);   // :1140-1146
         if (postponedShiftEnd) s.alive = 0;
     });
+    if constexpr (TR::MODE == 2) return true;                                    // (the level-2 rays of this bounce are out)
 
     if (mainHitEnv) return false;                                                // :1155-1157
     if (L.depth++ >= cfg.rrDepth) {                                              // :1159-1174
         const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
         if (L.rng.next1D() >= q) return false;
         L.pdf *= q;
-#pragma unroll
-        for (int i = 0; i < 4; i++) L.off[i].pdf *= q;
+        tr.scale_offset_pdfs(L, q);
     }
     return true;
 }
@@ -625,8 +652,7 @@ __device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, uns
 //   0-2 throughput | 3 pdf | 4 eta | 5-7 v.p | 8-10 rayD | 11-12 v.u, v.v | 13 prim (low 32 bits), depth (high) -- all ones once finished |
 //   14 rng state | 15+4i..18+4i offset i: throughput, pdf | 31 alive mask | 32-61 the sample's 30 sums so far (finished: its final sums)
 constexpr unsigned long long Q_DONE = ~0ULL;
-template <class ACC>
-__device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lane &L, const ACC &A)
+__device__ __forceinline__ void q_store_main(const FilmD &F, unsigned slot, const Lane &L)
 {
     Float *q = F.qRec + slot;
     const size_t st = F.qCapacity;
@@ -637,6 +663,13 @@ __device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lan
     qst(&q[11 * st], L.v.u); qst(&q[12 * st], L.v.v);
     qst(&q[13 * st], __longlong_as_double((long long)(((unsigned long long)(unsigned)L.depth << 32) | (unsigned)L.v.prim)));
     qst(&q[14 * st], __longlong_as_double((long long)L.rng.s));
+}
+template <class ACC>
+__device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lane &L, const ACC &A)
+{
+    q_store_main(F, slot, L);
+    Float *q = F.qRec + slot;
+    const size_t st = F.qCapacity;
     unsigned alive = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -648,8 +681,7 @@ __device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lan
 #pragma unroll
     for (int k = 0; k < ACC_N; k++) qst(&q[(32 + k) * st], A.get(k));
 }
-template <class ACC>
-__device__ __forceinline__ void q_load(const FilmD &F, unsigned slot, Lane &L, ACC &A)
+__device__ __forceinline__ void q_load_main(const FilmD &F, unsigned slot, Lane &L)          // the base path's part of a record
 {
     const Float *q = F.qRec + slot;
     const size_t st = F.qCapacity;
@@ -661,6 +693,12 @@ __device__ __forceinline__ void q_load(const FilmD &F, unsigned slot, Lane &L, A
     const unsigned long long pk = (unsigned long long)__double_as_longlong(qld(&q[13 * st]));
     L.v.prim = (int)(unsigned)(pk & 0xffffffffu); L.depth = (int)(unsigned)(pk >> 32);
     L.rng.s = (uint64_t)__double_as_longlong(qld(&q[14 * st]));
+}
+__device__ __forceinline__ void q_load_lane(const FilmD &F, unsigned slot, Lane &L)          // the path's part of a record: base path and offsets
+{
+    q_load_main(F, slot, L);
+    const Float *q = F.qRec + slot;
+    const size_t st = F.qCapacity;
     const unsigned alive = (unsigned)__double_as_longlong(qld(&q[31 * st]));
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -668,6 +706,13 @@ __device__ __forceinline__ void q_load(const FilmD &F, unsigned slot, Lane &L, A
         o.throughput = mk(qld(&q[(15 + 4 * i) * st]), qld(&q[(16 + 4 * i) * st]), qld(&q[(17 + 4 * i) * st])); o.pdf = qld(&q[(18 + 4 * i) * st]);
         o.alive = (alive >> i) & 1; o.status = RAY_CONNECTED;
     }
+}
+template <class ACC>
+__device__ __forceinline__ void q_load(const FilmD &F, unsigned slot, Lane &L, ACC &A)
+{
+    q_load_lane(F, slot, L);
+    const Float *q = F.qRec + slot;
+    const size_t st = F.qCapacity;
 #pragma unroll
     for (int k = 0; k < ACC_N; k++) A.set(k, qld(&q[(32 + k) * st]));
 }
@@ -742,7 +787,8 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
             if (!active) { paths++; pathLen += L.depth; if (STAGED || F.qRec) q_finish(F, slot, A); else pending = true; }
         }
         if (active) {
-            if (!bounce<ENV, SMOOTH, false, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, stack, L, A)) {
+            const InlineTracer tr = {sv, stack};
+            if (!bounce<ENV, SMOOTH, false, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
                 active = false;
                 paths++; pathLen += L.depth;
                 // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
@@ -845,7 +891,8 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
             }
         }
         if (__ballot(active) == 0) { if (exhausted) break; continue; }
-        if (active && !bounce<ENV, SMOOTH, true, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, stack, L, A)) {
+        const InlineTracer tr = {sv, stack};
+        if (active && !bounce<ENV, SMOOTH, true, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
             active = false;
             paths++; pathLen += L.depth;
             q_finish(F, slot, A);
@@ -861,6 +908,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
     }
 }
 
+#ifndef GDPT_RENDER_DEVICE_FUNCTIONS_ONLY      /* (gpt_wave_capi.hip takes the device functions and kernel templates above; the plain kernels below belong to gpt_capi.hip) */
 // finish_path for the samples of a chunk, all of which left their final sums in their queue slots (from the render kernel or from
 // k_continue): one thread per pixel of the launch adds them in sample order -- a fixed association, so a render is reproducible bit for
 // bit -- in registers, and touches the pixel's record once.  Reads are coalesced ([component][slot], consecutive lanes = consecutive slots).
@@ -1074,7 +1122,8 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     L.nClosest = L.nShadow = 0;
     Acc<false> A;
     bool active = start_path<true, true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
-    while (active) active = bounce<true, true, false, false, false>(S, sv, cfg, s_stack, L, A);
+    const InlineTracer tr = {sv, s_stack};
+    while (active) active = bounce<true, true, false, false, false>(S, sv, cfg, tr, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];
@@ -1101,5 +1150,7 @@ __global__ __launch_bounds__(TBLK) void k_bsdf_probe(MaterialD m, d3 wi, int nSa
         o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
     }
 }
+
+#endif // GDPT_RENDER_DEVICE_FUNCTIONS_ONLY
 
 } // namespace gdpt_tr

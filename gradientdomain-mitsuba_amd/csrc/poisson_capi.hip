@@ -327,8 +327,15 @@ int enqueue_cg_persistent(gdpt_poisson_solver *s, bool unitw, int cg)
                    : single ? (unitw ? (const void *)kp_cg<true, true> : (const void *)kp_cg<false, true>) : (unitw ? (const void *)kp_cg<true> : (const void *)kp_cg<false>);
     const size_t shared = s->ptWide ? P2_SHARED_BYTES : 0;
     if (s->ptWide) {
-        static bool raised[2] = {false, false};        // 111 KB of dynamic LDS: above the 64 KB a kernel gets without asking
-        if (!raised[unitw ? 1 : 0]) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared) != hipSuccess) { (void)hipGetLastError(); return PT_LAUNCH_REFUSED; } raised[unitw ? 1 : 0] = true; }
+        // 141 KB of dynamic LDS (P2_SHARED_BYTES = 144 144 B): above the 64 KB a kernel gets without asking.  The attribute is PER DEVICE, so the
+        // "already raised" note is kept per (device, variant): a process that creates solvers on two GPUs raises it on both
+        static std::mutex raisedMutex;
+        static std::map<std::pair<int, int>, bool> raised;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(raisedMutex);
+        bool &done = raised[std::make_pair(dev, unitw ? 1 : 0)];
+        if (!done) { if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared) != hipSuccess) { (void)hipGetLastError(); return PT_LAUNCH_REFUSED; } done = true; }
     }
     if (A.debugFail == 2 || hipLaunchCooperativeKernel(fn, grid, block, args, shared, s->stream) != hipSuccess) {
         (void)hipGetLastError();            // cooperative launch refused (unsupported, partitioned device, grid not co-resident): the caller falls back
@@ -718,13 +725,55 @@ int gdpt_gbdpt_prepare_data(float w, float *out, const double *data, int len, co
     return rc;
 }
 
-// the second half of GBDPTIntegrator::render on DEVICE buffers (five developed double images in, fp32 reconstructions out, host or device)
+// The second half of GBDPTIntegrator::render on DEVICE buffers (five developed double images in, fp32 reconstructions out, host or device).
+// The integrator has no handle of its own at this level, so the library keeps what a frame needs from one call to the next: per (device, size,
+// alpha) the three fp32 input images and one solver per preset.  Creating and destroying them per frame (round 3) put three hipMallocs and the
+// COLD first cooperative launch of a fresh solver inside every frame's reported solve: 6.8 ms for config 5's L2D where config 2's identical
+// 1280x720 solve takes 0.65 ms.  gdpt_gbdpt_reconstruct_release() drops the cache.
+namespace {
+struct GbdptRecon {
+    int device = -1, width = 0, height = 0;
+    float alpha = 0.0f;
+    float *in[3] = {nullptr, nullptr, nullptr};                  // imgf, dyf, dxf
+    gdpt_poisson_solver *sv[2] = {nullptr, nullptr};             // L2D, L1D (created on first use)
+    unsigned long long stamp = 0;
+    void drop()
+    {
+        for (auto &p : sv) { if (p) gdpt_poisson_destroy(p); p = nullptr; }
+        for (auto &f : in) { if (f) hipFree(f); f = nullptr; }
+        width = height = 0; device = -1;
+    }
+};
+std::mutex g_reconMutex;
+std::vector<GbdptRecon> g_recon;
+unsigned long long g_reconClock = 0;
+constexpr size_t GBDPT_RECON_CACHE = 8;                          // (device, size) pairs kept: strips of a multi-GPU host, a few film sizes
+}
+
 static int gbdpt_reconstruct_core(double *const dev[5], int width, int height, float alpha, int device, float *recL2, float *recL1, bool outOnDevice, float *seconds2)
 {
+    std::lock_guard<std::mutex> lock(g_reconMutex);
+    int cur = device;
+    if (cur < 0 && hipGetDevice(&cur) != hipSuccess) return fail(GDPT_ERR_HIP, "gbdpt_reconstruct: no current device");
     const int len = 3 * width * height;
-    float *in[3] = {nullptr, nullptr, nullptr};                  // imgf, dyf, dxf
+    GbdptRecon *R = nullptr;
+    for (auto &e : g_recon) if (e.device == cur && e.width == width && e.height == height && e.alpha == alpha) R = &e;
     int rc = GDPT_OK;
-    for (int k = 0; k < 3 && !rc; k++) if (hipMalloc(&in[k], sizeof(float) * len) != hipSuccess) rc = fail(GDPT_ERR_HIP, "Out of memory!");
+    if (!R) {
+        if (g_recon.size() >= GBDPT_RECON_CACHE) {               // evict the entry used longest ago
+            size_t old = 0;
+            for (size_t i = 1; i < g_recon.size(); i++) if (g_recon[i].stamp < g_recon[old].stamp) old = i;
+            const int back = cur;
+            (void)hipSetDevice(g_recon[old].device); g_recon[old].drop(); (void)hipSetDevice(back);
+            g_recon.erase(g_recon.begin() + (long)old);
+        }
+        g_recon.emplace_back();
+        R = &g_recon.back();
+        R->device = cur; R->width = width; R->height = height; R->alpha = alpha;
+        for (int k = 0; k < 3 && !rc; k++) if (hipMalloc(&R->in[k], sizeof(float) * len) != hipSuccess) rc = fail(GDPT_ERR_HIP, "Out of memory!");
+    }
+    R->stamp = ++g_reconClock;
+    float **in = R->in;
     if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[0], dev[0], len, nullptr, 0, nullptr);            // gbdpt.cpp:206
     if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[1], dev[4], len, dev[1], width, nullptr);          // :207  dy: grad[3] (+y) with grad[0] (-y)
     if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[2], dev[3], len, dev[2], 1, nullptr);              // :208  dx: grad[2] (+x) with grad[1] (-x)
@@ -734,23 +783,38 @@ static int gbdpt_reconstruct_core(double *const dev[5], int width, int height, f
     for (int k = 0; k < 2 && !rc; k++) {
         if (seconds2) seconds2[k] = 0.0f;
         if (!outs[k]) continue;
-        gdpt_poisson_params p;
-        gdpt_poisson_params_defaults(&p);
-        gdpt_poisson_params_preset(&p, presets[k]);
-        p.alpha = alpha;
-        p.device = device;
-        gdpt_poisson_solver *sv = nullptr;
-        rc = gdpt_poisson_create(&p, &sv);
+        if (!R->sv[k]) {
+            gdpt_poisson_params p;
+            gdpt_poisson_params_defaults(&p);
+            gdpt_poisson_params_preset(&p, presets[k]);
+            p.alpha = alpha;
+            p.device = device;
+            rc = gdpt_poisson_create(&p, &R->sv[k]);
+        }
+        gdpt_poisson_solver *sv = R->sv[k];
         if (!rc) rc = gdpt_poisson_import_images_device(sv, in[2], in[1], in[0], nullptr, width, height);   // importImagesMTS(dx, dy, img, NULL), :229,243
         if (!rc) rc = gdpt_poisson_setup_backend(sv);
         if (!rc) rc = gdpt_poisson_solve_indirect(sv);
         if (!rc) rc = outOnDevice ? gdpt_poisson_export_images_device(sv, outs[k]) : gdpt_poisson_export_images(sv, outs[k]);
         if (!rc && outOnDevice) rc = gdpt_poisson_sync(sv);
         if (!rc && seconds2) seconds2[k] = gdpt_poisson_last_solve_seconds(sv);
-        gdpt_poisson_destroy(sv);
     }
-    for (float *f : in) hipFree(f);
+    if (rc) {                                                    // a failed frame leaves nothing half-built behind
+        R->drop();
+        g_recon.erase(g_recon.begin() + (R - g_recon.data()));
+    }
     return rc;
+}
+
+int gdpt_gbdpt_reconstruct_release(void)
+{
+    std::lock_guard<std::mutex> lock(g_reconMutex);
+    int back = 0;
+    const bool have = hipGetDevice(&back) == hipSuccess;
+    for (auto &e : g_recon) { (void)hipSetDevice(e.device); e.drop(); }
+    g_recon.clear();
+    if (have) (void)hipSetDevice(back);
+    return GDPT_OK;
 }
 
 int gdpt_gbdpt_reconstruct(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,

@@ -243,8 +243,8 @@ class Film:
 
     def set_pipeline(self, stages, refill_lanes=0):
         """Device staging of a render (0 = one kernel; any other value = the default pipeline: primary pass + general kernel +
-        continuation kernel -- the ABI treats 1 like 2, include/gdpt_tracer.h).  A tuning knob: results do not depend on it beyond
-        rounding of the per-pixel sums."""
+        continuation kernel -- the ABI treats 1 like 2, include/gdpt_tracer.h; 3 = the continuation phase starts in wavefront form, an
+        opt-in experiment that is bit-identical to 2 and slower).  A tuning knob: results do not depend on it beyond rounding of the per-pixel sums."""
         check(lib().gdpt_film_set_pipeline(self._h, int(stages), int(refill_lanes)))
 
     def set_occupancy(self, waves_per_simd):

@@ -27,6 +27,8 @@ public:
 		m_reconstructL1 = props.getBoolean("reconstructL1", true);
 		m_reconstructL2 = props.getBoolean("reconstructL2", false);
 		m_reconstructAlpha = (Float) props.getFloat("reconstructAlpha", Float(0.2));
+		if (m_reconstructL1 && m_reconstructL2)
+			Log(EError, "Disable 'reconstructL1' or 'reconstructL2': Cannot display two reconstructions at a time!");   /* gbdpt.cpp:91-92 */
 		if (m_reconstructAlpha <= 0.0f)
 			Log(EError, "'reconstructAlpha' must be set to a value greater than zero!");
 		if (m_rrDepth <= 0)

@@ -10,11 +10,26 @@
 // constant and envmap emitters; a perspective sensor; independent sampler semantics (counter-based streams); any of the six
 // reconstruction filters.  Anything else is refused with a message -- never rendered approximately.  `devices` > 1 shards the frame over
 // the GPUs of the node in row strips (one thread per GPU, borders exchanged over xGMI), as host/gdpt_host.hpp does.
+//
+// Two shapes of render() (property `blocked`, default true on one device):
+//  * the reference's own: a BlockedRenderProcess (GPTRenderProcessHIP / GPTBlockRendererHIP / GPTWorkResultHIP below = gpt_proc.{h,cpp} and
+//    gpt_wr.{h,cpp}) -- Mitsuba's scheduler hands out RectangularWorkUnits in its spiral, a work unit is rendered by gdpt_render_rect into a
+//    device film of the block's rows plus one row above and below, comes back as five ImageBlocks with a one-pixel border and is merged by
+//    MultiFilm::putMulti exactly as gpt_proc.cpp:137-149 does -- so `-b blocksize`, the progress bar, the GUI's block preview and per-block
+//    cancellation work as with `gpt`.  A GPU wants LARGE blocks (a 32 x 32 block is 1 024 lanes on a 131 072-lane device): use `-b 256` or more.
+//  * the whole frame in one gdpt_render_rect call (`blocked` = false, and always with `devices` > 1): no per-block traffic, no block preview.
+// To make this plugin THE `gpt` of a build, compile it as src/integrators/gpt/ (SConscript: plugins += env.SharedLibrary('gpt', ['gpt_hip.cpp'])):
+// the XML's <integrator type="gpt"> then loads it; the properties are the reference's.
 // tests/test_plugin_sources.py compiles this file against compile-only mock headers (tests/mitsuba_mock) and links it with the library.
 #include <mitsuba/render/scene.h>
 #include <mitsuba/render/renderjob.h>
+#include <mitsuba/render/renderproc.h>
+#include <mitsuba/render/rectwu.h>
+#include <mitsuba/render/imageblock.h>
 #include <mitsuba/core/plugin.h>
 #include <mitsuba/core/bitmap.h>
+#include <mitsuba/core/statistics.h>
+#include <mitsuba/core/lock.h>
 #include <thread>
 #include "gdpt_tracer.h"
 #include "gdpt_poisson.h"
@@ -22,9 +37,88 @@
 
 MTS_NAMESPACE_BEGIN
 
-class GradientPathIntegratorHIP : public Integrator {
+/* ==================================================================== */
+/*   GPTWorkResult (gpt_wr.h:36-97, gpt_wr.cpp:31-86): five ImageBlocks   */
+/* ==================================================================== */
+class GPTWorkResultHIP : public WorkResult {
 public:
-	GradientPathIntegratorHIP(const Properties &props) : Integrator(props), m_film(NULL) {
+	enum { BUFFER_COUNT = 5 };     /* 0: preview / final, 1: throughput, 2: dx, 3: dy, 4: very direct */
+	GPTWorkResultHIP(const ReconstructionFilter *rfilter, Vector2i blockSize, int extraBorder) {
+		for (int i = 0; i < BUFFER_COUNT; ++i) {
+			m_block[i] = new ImageBlock(Bitmap::ESpectrumAlphaWeight, blockSize, rfilter, -1, true, extraBorder);
+			m_block[i]->setOffset(Point2i(0, 0));
+			m_block[i]->setSize(blockSize);
+		}
+		m_block[2]->setAllowNegativeValues(true);
+		m_block[3]->setAllowNegativeValues(true);
+	}
+	void clear() { for (int i = 0; i < BUFFER_COUNT; ++i) m_block[i]->clear(); }
+	void load(Stream *stream) { for (int i = 0; i < BUFFER_COUNT; ++i) m_block[i]->load(stream); }
+	void save(Stream *stream) const { for (int i = 0; i < BUFFER_COUNT; ++i) m_block[i]->save(stream); }
+	ImageBlock *getImageBlock(int buffer) { return m_block[buffer].get(); }
+	const ImageBlock *getImageBlock(int buffer) const { return m_block[buffer].get(); }
+	void setSize(const Vector2i &size) { for (int i = 0; i < BUFFER_COUNT; ++i) m_block[i]->setSize(size); }
+	void setOffset(const Point2i &offset) { for (int i = 0; i < BUFFER_COUNT; ++i) m_block[i]->setOffset(offset); }
+	std::string toString() const { return m_block[0]->toString(); }
+	MTS_DECLARE_CLASS()
+private:
+	ref<ImageBlock> m_block[BUFFER_COUNT];
+};
+
+class GradientPathIntegratorHIP;
+
+/* ==================================================================== */
+/*   GPTBlockRenderer (gpt_proc.cpp:47-128): renders work units           */
+/* ==================================================================== */
+class GPTBlockRendererHIP : public WorkProcessor {
+public:
+	GPTBlockRendererHIP(int blockSize) : m_integrator(NULL), m_sensor(NULL), m_film(NULL), m_filmY0(-1), m_filmY1(-1), m_blockSize(blockSize) { }
+	GPTBlockRendererHIP(Stream *stream, InstanceManager *manager) : WorkProcessor(stream, manager), m_integrator(NULL), m_sensor(NULL), m_film(NULL), m_filmY0(-1), m_filmY1(-1) {
+		m_blockSize = stream->readInt();
+	}
+	ref<WorkUnit> createWorkUnit() const { return new RectangularWorkUnit(); }
+	ref<WorkResult> createWorkResult() const;
+	void prepare();
+	void process(const WorkUnit *workUnit, WorkResult *workResult, const bool &stop);
+	void serialize(Stream *stream, InstanceManager *) const { stream->writeInt(m_blockSize); }
+	ref<WorkProcessor> clone() const { return new GPTBlockRendererHIP(m_blockSize); }
+	MTS_DECLARE_CLASS()
+protected:
+	virtual ~GPTBlockRendererHIP();
+private:
+	GradientPathIntegratorHIP *m_integrator;
+	Sensor *m_sensor;
+	gdpt_film *m_film;              /* the device film of the current band of rows: reused while consecutive work units share their rows */
+	int m_filmY0, m_filmY1;
+	int m_blockSize;
+	std::vector<double> m_accum;
+};
+
+/* ==================================================================== */
+/*   GPTRenderProcess (gpt_proc.h:41-64, gpt_proc.cpp:131-149)            */
+/* ==================================================================== */
+class GPTRenderProcessHIP : public BlockedRenderProcess {
+public:
+	GPTRenderProcessHIP(const RenderJob *parent, RenderQueue *queue, int blockSize) : BlockedRenderProcess(parent, queue, blockSize) { }
+	ref<WorkProcessor> createWorkProcessor() const { return new GPTBlockRendererHIP(m_blockSize); }
+	void processResult(const WorkResult *result, bool cancelled) {
+		const GPTWorkResultHIP *block = static_cast<const GPTWorkResultHIP *>(result);
+		UniqueLock lock(m_resultMutex);
+		for (int i = 0; i < 5; ++i)
+			m_film->putMulti(block->getImageBlock(i), i);
+		m_progress->update(++m_resultCount);
+		lock.unlock();
+		m_queue->signalWorkEnd(m_parent, block->getImageBlock(0), cancelled);
+	}
+	MTS_DECLARE_CLASS()
+protected:
+	virtual ~GPTRenderProcessHIP() { }
+};
+
+class GradientPathIntegratorHIP : public Integrator {
+	friend class GPTBlockRendererHIP;
+public:
+	GradientPathIntegratorHIP(const Properties &props) : Integrator(props), m_film(NULL), m_blockScene(NULL), m_process(NULL) {
 		/* the properties and checks of gpt.cpp:1194-1213 */
 		m_maxDepth = props.getInteger("maxDepth", -1);
 		m_rrDepth = props.getInteger("rrDepth", 5);
@@ -34,6 +128,7 @@ public:
 		m_reconstructL2 = props.getBoolean("reconstructL2", false);
 		m_reconstructAlpha = (Float) props.getFloat("reconstructAlpha", Float(0.2));
 		m_devices = props.getInteger("devices", 1);      /* not a reference property: GPUs to shard the frame over (row strips) */
+		m_blocked = props.getBoolean("blocked", true);   /* not a reference property: false = the whole frame in one launch instead of a BlockedRenderProcess */
 		if (m_reconstructL1 && m_reconstructL2)
 			Log(EError, "Disable 'reconstructL1' or 'reconstructL2': Cannot display two reconstructions at a time!");
 		if (m_reconstructAlpha <= 0.0f)
@@ -42,7 +137,7 @@ public:
 			Log(EError, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
 	}
 
-	GradientPathIntegratorHIP(Stream *stream, InstanceManager *manager) : Integrator(stream, manager), m_film(NULL) {
+	GradientPathIntegratorHIP(Stream *stream, InstanceManager *manager) : Integrator(stream, manager), m_film(NULL), m_blockScene(NULL), m_process(NULL) {
 		Log(EError, "gpt_hip: network rendering is not carried (the GPU path renders on the node that owns the GPUs)");
 	}
 
@@ -75,6 +170,36 @@ public:
 		for (int b = 0; b < 5; ++b) img[b].resize((size_t) 3 * W * H);
 		if (m_devices > 1) {
 			if (!renderStrips(fs, cfg, kind, p0, p1, W, H, img)) return false;
+		} else if (m_blocked && kind == GDPT_RFILTER_BOX) {
+			/* gpt.cpp:1396-1414: "This is a sampling-based integrator - parallelize": the scheduler's workers each drive the GPU through a
+			   GPTBlockRendererHIP; the blocks' borders are merged by addition in MultiFilm::putMulti (gpt_proc.cpp:137-149) */
+			ref<Scheduler> sched = Scheduler::getInstance();
+			m_blockScene = gdpt_plugin::upload(fs, -1);
+			m_blockCfg = cfg;
+			ref<BlockedRenderProcess> proc = new GPTRenderProcessHIP(job, queue, (int) scene->getBlockSize());
+			int integratorResID = sched->registerResource(this);
+			proc->bindResource("integrator", integratorResID);
+			proc->bindResource("scene", sceneResID);
+			proc->bindResource("sensor", sensorResID);
+			proc->bindResource("sampler", samplerResID);
+			scene->bindUsedResources(proc);
+			bindUsedResources(proc);
+			sched->schedule(proc);
+			m_process = proc;
+			sched->wait(proc);
+			sched->unregisterResource(integratorResID);
+			m_process = NULL;
+			const bool ok = proc->getReturnStatus() == ParallelProcess::ESuccess;
+			gdpt_scene_destroy(m_blockScene);
+			m_blockScene = NULL;
+			if (!ok) return false;
+			/* gpt.cpp:1419-1442: develop the five buffers of the MultiFilm and cast them to float */
+			for (int b = 0; b < 5; ++b) {
+				ref<Bitmap> bmp = new Bitmap(Bitmap::ESpectrum, Bitmap::EFloat, size);
+				film->developMulti(Point2i(0, 0), size, Point2i(0, 0), bmp, b);
+				const Float *src = bmp->getFloatData();
+				for (size_t i = 0; i < img[b].size(); ++i) img[b][i] = (float) src[i];
+			}
 		} else {
 			/* GPTBlockRenderer::process over the whole film in one call (blocks may also be handed over one by one) */
 			gdpt_scene *gs = gdpt_plugin::upload(fs, -1);
@@ -113,14 +238,18 @@ public:
 		return true;
 	}
 
-	void cancel() { if (m_film) gdpt_film_cancel(m_film); }     /* Integrator::cancel, integrator.h:88 */
+	/* Integrator::cancel, integrator.h:88; gpt.cpp:1482-1485 for the process */
+	void cancel() {
+		if (m_film) gdpt_film_cancel(m_film);
+		if (m_process) Scheduler::getInstance()->cancel(m_process);
+	}
 	void postprocess(const Scene *, RenderQueue *, const RenderJob *, int, int, int) {}
 	void serialize(Stream *stream, InstanceManager *manager) const { Integrator::serialize(stream, manager); }
 	std::string toString() const { return "GradientPathIntegratorHIP[]"; }
 
 	MTS_DECLARE_CLASS()
-private:
 	static void check(int rc) { if (rc != GDPT_OK) SLog(EError, "gpt_hip: %s", gdpt_last_error()); }
+private:
 	void release(gdpt_scene *gs) { gdpt_film_destroy(m_film); m_film = NULL; gdpt_scene_destroy(gs); }
 
 	/* One thread and one strip film per GPU; border sums exchanged device to device (gdpt_film_pack_halo / unpack_halo over gdpt_device_copy =
@@ -185,11 +314,72 @@ private:
 	}
 
 	gdpt_film *m_film;
+	gdpt_scene *m_blockScene;       /* blocked shape: the device scene the workers' GPTBlockRendererHIP render from */
+	gdpt_config m_blockCfg;
+	ParallelProcess *m_process;
 	int m_maxDepth, m_rrDepth, m_devices;
-	bool m_strictNormals, m_reconstructL1, m_reconstructL2;
+	bool m_strictNormals, m_reconstructL1, m_reconstructL2, m_blocked;
 	Float m_shiftThreshold, m_reconstructAlpha;
 };
 
+/* ---- GPTBlockRendererHIP: needs the integrator's members ---- */
+ref<WorkResult> GPTBlockRendererHIP::createWorkResult() const {
+	return new GPTWorkResultHIP(m_sensor ? m_sensor->getFilm()->getReconstructionFilter() : NULL, Vector2i(m_blockSize, m_blockSize), 1);    /* gpt_proc.cpp:52-56: extraBorder = 1 */
+}
+
+void GPTBlockRendererHIP::prepare() {      /* gpt_proc.cpp:58-72: the resources the process bound */
+	m_sensor = static_cast<Sensor *>(getResource("sensor"));
+	m_integrator = static_cast<GradientPathIntegratorHIP *>(getResource("integrator"));
+}
+
+GPTBlockRendererHIP::~GPTBlockRendererHIP() { if (m_film) gdpt_film_destroy(m_film); }
+
+/* gpt_proc.cpp:74-91 with renderBlock replaced by gdpt_render_rect: the unit's pixels are sampled on the device, the 15 puts of every sample
+   (gpt.cpp:1314-1352) land in the unit's rectangle grown by one pixel, which is what comes back in the five ImageBlocks */
+void GPTBlockRendererHIP::process(const WorkUnit *workUnit, WorkResult *workResult, const bool &stop) {
+	const RectangularWorkUnit *rect = static_cast<const RectangularWorkUnit *>(workUnit);
+	GPTWorkResultHIP *block = static_cast<GPTWorkResultHIP *>(workResult);
+	block->setOffset(rect->getOffset());
+	block->setSize(rect->getSize());
+	block->clear();
+	if (stop) return;
+	const Vector2i crop = m_sensor->getFilm()->getCropSize();
+	const int W = crop.x, H = crop.y;
+	const int x0 = rect->getOffset().x, y0 = rect->getOffset().y, x1 = x0 + rect->getSize().x, y1 = y0 + rect->getSize().y;
+	const int fy0 = std::max(0, y0 - 1), fy1 = std::min(H, y1 + 1);          /* the film owns the border rows too: their sums come back resolved */
+	if (!m_film || fy0 != m_filmY0 || fy1 != m_filmY1) {
+		if (m_film) gdpt_film_destroy(m_film);
+		m_film = NULL;
+		GradientPathIntegratorHIP::check(gdpt_film_create(m_integrator->m_blockScene, fy0, fy1, &m_film));
+		m_filmY0 = fy0; m_filmY1 = fy1;
+		m_accum.resize((size_t) 5 * (fy1 - fy0) * W * 4);
+	} else GradientPathIntegratorHIP::check(gdpt_film_clear(m_film));
+	GradientPathIntegratorHIP::check(gdpt_render_rect(m_integrator->m_blockScene, &m_integrator->m_blockCfg, x0, y0, x1, y1, m_film));
+	GradientPathIntegratorHIP::check(gdpt_film_sync(m_film));
+	if (stop) return;                        /* (the scheduler drops the result of a cancelled unit) */
+	GradientPathIntegratorHIP::check(gdpt_film_accum(m_film, m_accum.data()));
+	/* accum[5][rows][W][4] = (R, G, B, weight) -> the block's bitmap: SPECTRUM_SAMPLES + 2 channels per pixel (spectrum, alpha, weight;
+	   GPTWorkResult::put, gpt_wr.h:57-65, writes alpha = 1 per put, which MultiFilm's develop never reads: it is set to the weight here) */
+	const int rows = fy1 - fy0;
+	for (int b = 0; b < 5; ++b) {
+		ImageBlock *ib = block->getImageBlock(b);
+		Bitmap *bmp = ib->getBitmap();
+		const int border = ib->getBorderSize(), bw = bmp->getWidth(), ch = bmp->getChannelCount();
+		Float *dst = bmp->getFloatData();
+		for (int yy = std::max(fy0, y0 - border); yy < std::min(fy1, y1 + border); ++yy)
+			for (int xx = std::max(0, x0 - border); xx < std::min(W, x1 + border); ++xx) {
+				const double *a = &m_accum[((((size_t) b * rows) + (yy - fy0)) * W + xx) * 4];
+				Float *d = dst + ((size_t) (yy - y0 + border) * bw + (xx - x0 + border)) * ch;
+				for (int c = 0; c < ch - 2; ++c) d[c] = (Float) a[c < 3 ? c : 2];
+				d[ch - 2] = (Float) a[3];
+				d[ch - 1] = (Float) a[3];
+			}
+	}
+}
+
+MTS_IMPLEMENT_CLASS(GPTWorkResultHIP, false, WorkResult)
+MTS_IMPLEMENT_CLASS_S(GPTBlockRendererHIP, false, WorkProcessor)
+MTS_IMPLEMENT_CLASS(GPTRenderProcessHIP, false, BlockedRenderProcess)
 MTS_IMPLEMENT_CLASS_S(GradientPathIntegratorHIP, false, Integrator)
 MTS_EXPORT_PLUGIN(GradientPathIntegratorHIP, "Gradient-domain path tracer on MI355X (libgdpt_hip)");
 MTS_NAMESPACE_END

@@ -619,7 +619,7 @@ private:
         if (data.size() >= 4 && data[0] == 0x76 && data[1] == 0x2f && data[2] == 0x31 && data[3] == 0x01) {
             // OpenEXR, the subset this build writes itself (uncompressed scanlines, half or float channels B G R in file order)
             size_t at = 8;
-            int w = 0, h = 0, compression = -1;
+            int w = 0, h = 0, minY = 0, compression = -1;
             std::vector<std::pair<std::string, int>> channels;                                        // name, pixel type (1 half, 2 float)
             auto cstr = [&]() { std::string r; while (at < data.size() && data[at]) r += (char)data[at++]; ++at; return r; };
             auto le32 = [&](size_t o) { if (o + 4 > data.size()) logError(path + ": truncated"); unsigned v; std::memcpy(&v, &data[o], 4); return v; };
@@ -628,7 +628,7 @@ private:
                 const unsigned size = le32(at); at += 4;
                 if (name == "channels") { size_t p = at; while (data[p]) { std::string cn; while (data[p]) cn += (char)data[p++]; ++p; const int pt = (int)le32(p); p += 16; channels.emplace_back(cn, pt); } }
                 else if (name == "compression") compression = data[at];
-                else if (name == "dataWindow") { w = (int)le32(at + 8) - (int)le32(at) + 1; h = (int)le32(at + 12) - (int)le32(at + 4) + 1; }
+                else if (name == "dataWindow") { w = (int)le32(at + 8) - (int)le32(at) + 1; h = (int)le32(at + 12) - (int)le32(at + 4) + 1; minY = (int)le32(at + 4); }
                 at += size;
             }
             ++at;
@@ -642,7 +642,7 @@ private:
             std::vector<unsigned char> raw, tmp;
             for (int cidx = 0; cidx < chunks; ++cidx) {
                 const size_t off = (size_t)(le32(at + 8 * (size_t)cidx)) | ((size_t)le32(at + 8 * (size_t)cidx + 4) << 32);
-                const int y0 = (int)le32(off), y1 = std::min(h, y0 + lines);
+                const int y0 = (int)le32(off) - minY, y1 = std::min(h, y0 + lines);      // (a chunk stores its y in dataWindow coordinates: cropped renders start above 0)
                 const size_t sz = le32(off + 4), want = (size_t)(y1 - y0) * rowBytes;
                 if (y0 < 0 || y0 >= h || off + 8 + sz > data.size()) logError(path + ": truncated");
                 raw.assign(want, 0);

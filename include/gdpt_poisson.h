@@ -135,6 +135,10 @@ GDPT_API int  gdpt_gbdpt_reconstruct(const double *primal, const double *gradNeg
 GDPT_API int  gdpt_gbdpt_reconstruct_device(const double *primal, const double *gradNegY, const double *gradNegX, const double *gradPosX, const double *gradPosY,
                                             int width, int height, float alpha, int device, float *recL2, float *recL1, float solveSeconds[2]);
 
+/* Both calls keep, per (device, size, alpha), the three fp32 solver inputs and one solver per preset from one frame to the next (an
+ * integrator renders many frames of one size); this frees them (all devices). */
+GDPT_API int  gdpt_gbdpt_reconstruct_release(void);
+
 /* ---- (2) backend-op level ----------------------------------------------------------------- */
 /* Device-pointer forms of the `poisson::Backend` virtuals.  `stream` is a hipStream_t (NULL =
  * default stream).  Vectors use the reference layout; sizes in ELEMENTS as in Backend::Vector. */

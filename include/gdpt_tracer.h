@@ -198,6 +198,9 @@ GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
  * stages = 0: everything in k_render (the round-1 form; gdpt_film_set_occupancy chooses its build); 1 is accepted and means 2.  Samples,
  * random numbers, ray counts and the order in which a pixel's samples are summed do not depend on the setting; results agree to
  * rounding of the per-pixel sums.
+ * stages = 3 (round 4, opt-in, measured SLOWER than 2 -- DESIGN.md): the first GDPT_WF_ITERS (default 6) bounces of the continuation phase run
+ * in wavefront form (csrc/gpt_wavefront.hip.h: rays through HBM queues to traversal-only kernels, shading passes that replay the one bounce()
+ * around them), k_continue takes what is left; films, ray counts and statistics are bit-identical to stages = 2.
  * refillLanes: idle lanes of a wave of k_continue before they take new records together (0 = keep the current value, default 32).
  * Environment: GDPT_NO_CONTINUATION and GDPT_QUEUE_MB (memory budget of the sample queue, default
  * 24576) override at render time (GDPT_NO_CONTINUATION set = stages 0). */

@@ -1,0 +1,1 @@
+#include "../../mock_mitsuba.h"

@@ -4,8 +4,12 @@
 // computes anything; it is not a Mitsuba build and pins no behaviour.  Signatures follow (paths relative to /root/reference/include/mitsuba):
 //   core/object.h, core/cobject.h (ConfigurableObject, MTS_EXPORT_PLUGIN), core/properties.h, core/logger.h (Log / SLog), core/spectrum.h,
 //   core/transform.h, core/bitmap.h, core/rfilter.h, core/sched.h, render/integrator.h (:61-118), render/scene.h, render/sensor.h,
-//   render/film.h (:62-79 the Multi* virtuals), render/trimesh.h, render/emitter.h, render/bsdf.h, render/texture.h, render/sampler.h.
+//   render/film.h (:62-79 the Multi* virtuals), render/trimesh.h, render/emitter.h, render/bsdf.h, render/texture.h, render/sampler.h;
+//   for the block-process shape of gpt_hip.cpp: core/sched.h (:43-177 WorkUnit / WorkResult / WorkProcessor, :216-330 ParallelProcess, :362-463),
+//   core/lock.h, core/statistics.h (:293-299), render/rectwu.h, render/imageblock.h (:59-106), render/imageproc.h, render/renderproc.h (:38-93),
+//   render/renderqueue.h (:102).
 #pragma once
+#include <algorithm>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
@@ -19,6 +23,7 @@
 #define MTS_NAMESPACE_END }
 #define MTS_DECLARE_CLASS() virtual const Class *getClass() const;
 #define MTS_IMPLEMENT_CLASS_S(name, abstract, super) const Class *name::getClass() const { static Class c(#name); return &c; }
+#define MTS_IMPLEMENT_CLASS(name, abstract, super) MTS_IMPLEMENT_CLASS_S(name, abstract, super)
 #define MTS_EXPORT_PLUGIN(name, descr) extern "C" { void *CreateInstance(const Properties &props) { return new name(props); } const char *GetDescription() { return descr; } }
 
 MTS_NAMESPACE_BEGIN
@@ -54,6 +59,7 @@ struct Normal { Float x, y, z; Normal(Float a = 0, Float b = 0, Float c = 0) : x
 inline Normal normalize(const Normal &n) { return n; }
 struct Point2 { Float x, y; Point2(Float a = 0, Float b = 0) : x(a), y(b) {} };
 struct Vector2i { int x, y; Vector2i(int a = 0, int b = 0) : x(a), y(b) {} };
+struct Point2i { int x, y; Point2i(int a = 0, int b = 0) : x(a), y(b) {} };
 struct Frame { Vector s, t; Normal n; Frame() {} explicit Frame(const Normal &nn) : n(nn) {} };
 struct Matrix4x4 { Float m[4][4]; Float operator()(int r, int c) const { return m[r][c]; } };
 class Transform {
@@ -101,22 +107,30 @@ public:
 private:
     std::string m_plugin;
 };
-class Stream; class InstanceManager; class RenderQueue; class RenderJob;
-class ConfigurableObject : public Object {
+class InstanceManager; class RenderJob; class ParallelProcess;
+class Stream { public: int readInt() { return 0; } void writeInt(int) {} bool readBool() { return false; } void writeBool(bool) {} };   // core/stream.h
+class SerializableObject : public Object {                                             // core/serialization.h
+public:
+    SerializableObject() {}
+    SerializableObject(Stream *, InstanceManager *) {}
+    virtual void serialize(Stream *, InstanceManager *) const {}
+};
+class ConfigurableObject : public SerializableObject {
 public:
     ConfigurableObject() {}
     explicit ConfigurableObject(const Properties &p) : m_properties(p) {}
     const Properties &getProperties() const { return m_properties; }                    // cobject.h
-    virtual void serialize(Stream *, InstanceManager *) const {}
 protected:
     Properties m_properties;
 };
 
 class Bitmap : public Object {
 public:
-    enum EPixelFormat { ELuminance, ERGB, ESpectrum };
+    enum EPixelFormat { ELuminance, ERGB, ESpectrum, ESpectrumAlphaWeight };
     enum EComponentFormat { EUInt8, EFloat16, EFloat32, EFloat64, EFloat = EFloat64 };
-    Bitmap(EPixelFormat, EComponentFormat, const Vector2i &size) : m_size(size), m_data((size_t)size.x * size.y * 3 * 8) {}
+    Bitmap(EPixelFormat, EComponentFormat, const Vector2i &size) : m_size(size), m_data((size_t)size.x * size.y * 5 * 8) {}
+    int getChannelCount() const { return 5; }
+    void clear() { std::fill(m_data.begin(), m_data.end(), 0); }
     const Vector2i &getSize() const { return m_size; }
     int getWidth() const { return m_size.x; }
     int getHeight() const { return m_size.y; }
@@ -130,12 +144,36 @@ private:
 };
 
 class ReconstructionFilter : public ConfigurableObject { public: Float getRadius() const { return 0.5; } const Class *getClass() const { static Class c("BoxFilter"); return &c; } };
+class ImageBlock : public Object {                                                       // render/imageblock.h:59-106 (this fork's extraBorder argument)
+public:
+    ImageBlock(Bitmap::EPixelFormat fmt, const Vector2i &size, const ReconstructionFilter *filter = nullptr, int channels = -1, bool warn = true, int extraBorder = 0)
+        : m_size(size), m_border(extraBorder), m_bitmap(new Bitmap(fmt, Bitmap::EFloat, Vector2i(size.x + 2 * extraBorder, size.y + 2 * extraBorder))) { (void)filter; (void)channels; (void)warn; }
+    void setAllowNegativeValues(bool) {}
+    void setOffset(const Point2i &o) { m_offset = o; }
+    const Point2i &getOffset() const { return m_offset; }
+    void setSize(const Vector2i &s) { m_size = s; }
+    const Vector2i &getSize() const { return m_size; }
+    int getBorderSize() const { return m_border; }
+    Bitmap *getBitmap() { return m_bitmap; }
+    const Bitmap *getBitmap() const { return m_bitmap.get(); }
+    void clear() { m_bitmap->clear(); }
+    void load(Stream *) {}
+    void save(Stream *) const {}
+    std::string toString() const { return "ImageBlock[]"; }
+    const Class *getClass() const { static Class c("ImageBlock"); return &c; }
+private:
+    Point2i m_offset; Vector2i m_size; int m_border; ref<Bitmap> m_bitmap;
+};
 class Film : public ConfigurableObject {
 public:
     const Vector2i &getCropSize() const { return m_size; }
     const ReconstructionFilter *getReconstructionFilter() const { return &m_rf; }
-    virtual bool setBuffers(const std::vector<std::string> &) { return true; }                                   // film.h:62-79
+    virtual void clear() {}
+    virtual bool setBuffers(std::vector<std::string> &) { return true; }                                          // film.h:62-79: the five multi-buffer virtuals
     virtual void setBitmapMulti(const Bitmap *, Float, int) {}
+    virtual void addBitmapMulti(const Bitmap *, Float, int) {}
+    virtual bool developMulti(const Point2i &, const Vector2i &, const Point2i &, Bitmap *, int) const { return true; }
+    virtual void putMulti(const ImageBlock *, int) {}
     const Class *getClass() const { static Class c("MultiFilm"); return &c; }
 private:
     Vector2i m_size; ReconstructionFilter m_rf;
@@ -203,6 +241,8 @@ inline ref<TriMesh> Shape::createTriMesh() { return nullptr; }
 class Scene : public ConfigurableObject {
 public:
     Sensor *getSensor() { return &m_sensor; }
+    uint32_t getBlockSize() const { return 32; }                                         // scene.h:1128
+    void bindUsedResources(ParallelProcess *) const {}                                  // scene.h:1134
     const std::vector<TriMesh *> &getMeshes() const { return m_meshes; }
     const ref_vector<Shape> &getShapes() const { return m_shapes; }
     const ref_vector<Emitter> &getEmitters() const { return m_emitters; }
@@ -210,10 +250,63 @@ public:
 private:
     PerspectiveCamera m_sensor; std::vector<TriMesh *> m_meshes; ref_vector<Shape> m_shapes; ref_vector<Emitter> m_emitters;
 };
+// ---- core/sched.h, core/lock.h, core/statistics.h, render/{rectwu,imageproc,renderproc,renderqueue}.h: the block scheduler's surface ----
+class Mutex : public Object { public: const Class *getClass() const { static Class c("Mutex"); return &c; } };
+class UniqueLock { public: explicit UniqueLock(Mutex *) {} void unlock() {} };
+class ProgressReporter { public: ProgressReporter(const std::string &, long long, const void *) {} void update(long long) {} };
+class RenderQueue : public Object { public: void signalWorkEnd(const RenderJob *, const ImageBlock *, bool) {} const Class *getClass() const { static Class c("RenderQueue"); return &c; } };
+class WorkUnit : public Object { public: virtual void set(const WorkUnit *) = 0; virtual void load(Stream *) = 0; virtual void save(Stream *) const = 0; virtual std::string toString() const = 0; };
+class WorkResult : public Object { public: virtual void load(Stream *) = 0; virtual void save(Stream *) const = 0; virtual std::string toString() const = 0; };
+class RectangularWorkUnit : public WorkUnit {
+public:
+    void set(const WorkUnit *) {} void load(Stream *) {} void save(Stream *) const {} std::string toString() const { return "RectangularWorkUnit[]"; }
+    const Point2i &getOffset() const { return m_offset; }
+    const Vector2i &getSize() const { return m_size; }
+    const Class *getClass() const { static Class c("RectangularWorkUnit"); return &c; }
+private:
+    Point2i m_offset; Vector2i m_size;
+};
+class WorkProcessor : public SerializableObject {
+public:
+    virtual ref<WorkUnit> createWorkUnit() const = 0;
+    virtual ref<WorkResult> createWorkResult() const = 0;
+    virtual ref<WorkProcessor> clone() const = 0;
+    virtual void prepare() = 0;
+    virtual void process(const WorkUnit *workUnit, WorkResult *workResult, const bool &stop) = 0;
+protected:
+    WorkProcessor() {}
+    WorkProcessor(Stream *s, InstanceManager *m) : SerializableObject(s, m) {}
+    SerializableObject *getResource(const std::string &) { return nullptr; }
+};
+class ParallelProcess : public Object {
+public:
+    enum EStatus { EUnknown, EPause, ESuccess, EFailure };
+    EStatus getReturnStatus() const { return ESuccess; }
+    virtual ref<WorkProcessor> createWorkProcessor() const = 0;
+    virtual void processResult(const WorkResult *result, bool cancelled) = 0;
+    virtual void bindResource(const std::string &, int) {}
+};
+class BlockedImageProcess : public ParallelProcess { protected: int m_blockSize; };
+class BlockedRenderProcess : public BlockedImageProcess {
+public:
+    BlockedRenderProcess(const RenderJob *parent, RenderQueue *queue, int blockSize)
+        : m_queue(queue), m_film(nullptr), m_parent(parent), m_resultCount(0), m_resultMutex(new Mutex()), m_progress(new ProgressReporter("Rendering", 1, parent)),
+          m_borderSize(0), m_pixelFormat(Bitmap::ESpectrumAlphaWeight), m_channelCount(-1), m_warnInvalid(false) { m_blockSize = blockSize; }
+    void bindResource(const std::string &, int) {}
+protected:
+    ref<RenderQueue> m_queue; ref<Film> m_film; const RenderJob *m_parent; int m_resultCount; ref<Mutex> m_resultMutex; ProgressReporter *m_progress;
+    int m_borderSize; Bitmap::EPixelFormat m_pixelFormat; int m_channelCount; bool m_warnInvalid;
+};
 class Scheduler : public Object {
 public:
     static Scheduler *getInstance() { static Scheduler s; return &s; }
     ConfigurableObject *getResource(int, int = -1) { static Sampler smp; return &smp; }
+    int registerResource(SerializableObject *) { return 0; }
+    bool unregisterResource(int) { return true; }
+    bool schedule(ParallelProcess *) { return true; }
+    bool wait(const ParallelProcess *) { return true; }
+    bool cancel(ParallelProcess *) { return true; }
+    size_t getCoreCount() const { return 1; }
     const Class *getClass() const { static Class c("Scheduler"); return &c; }
 };
 class Integrator : public ConfigurableObject {                                            // render/integrator.h:61-118
@@ -226,5 +319,6 @@ public:
     virtual void postprocess(const Scene *, RenderQueue *, const RenderJob *, int, int, int) {}
     virtual void serialize(Stream *, InstanceManager *) const {}
     virtual std::string toString() const { return "Integrator[]"; }
+    void bindUsedResources(ParallelProcess *) const {}                                 // cobject.h
 };
 MTS_NAMESPACE_END

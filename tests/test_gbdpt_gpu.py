@@ -97,6 +97,37 @@ def test_film_matches_oracle(G, B, name, W, H, spp, md, li):
     F.close(); S.close(); O.close()
 
 
+def test_small_workspace_chunks_give_the_same_film(G, B):
+    """gdpt_gbdpt_render_rect walks a rectangle's samples in chunks of its workspace (sized from the memory the device has free; the `first +=
+    chunk` loop).  Forced down to chunks that cut through pixels (GDPT_BD_CHUNK = 777 and 5000 samples of 48 x 36 x 4 = 6912): the same samples,
+    ray counts identical, film equal to the one-chunk film to the rounding of the fp64 atomic splats, and to the oracle."""
+    import os
+    W, H, spp = 48, 36, 4
+    sc = scenes.cornell_box(W, H, "rough")
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=6, lightImage=True)
+    F = B.Film(S)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    block, light = F.accum(); st = F.stats()
+    F.close()
+    ob, ol, oc = O.gbdpt_render(go.gbdpt_config(maxDepth=6, lightImage=True, spp=spp))
+    for forced in ("777", "5000"):
+        os.environ["GDPT_BD_CHUNK"] = forced
+        try:
+            F = B.Film(S)
+            integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+            b2, l2 = F.accum(); st2 = F.stats()
+            F.close()
+        finally:
+            del os.environ["GDPT_BD_CHUNK"]
+        assert st2 == st and (st2["raysTraced"], st2["shadowRaysTraced"]) == (oc["raysTraced"], oc["shadowRaysTraced"]), forced
+        assert np.allclose(b2, block, rtol=1e-12, atol=1e-12) and np.allclose(l2, light, rtol=1e-12, atol=1e-12), forced
+        for b in range(5):
+            assert np.abs(b2[b] - ob[b]).max() <= 1e-9 * (np.abs(ob[b]).max() + 1e-300), (forced, "block", b)
+            assert np.abs(l2[b] - ol[b]).max() <= 1e-9 * (np.abs(ol[b]).max() + 1e-300), (forced, "light", b)
+    S.close(); O.close()
+
+
 def test_scope_and_property_errors(G, B):
     from gradientdomain_mitsuba_amd._lib import GdptError
     with pytest.raises(RuntimeError, match="two reconstructions"):

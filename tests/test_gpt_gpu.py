@@ -746,6 +746,49 @@ def test_staged_pipeline_equals_the_single_kernel_and_the_oracle(G, name, builde
     S.close(); O.close()
 
 
+@pytest.mark.parametrize("name,builder,kw", _pipeline_cases(), ids=[c[0] for c in _pipeline_cases()])
+def test_wavefront_continuation_is_bit_identical_to_the_staged_pipeline(G, name, builder, kw):
+    """gdpt_film_set_pipeline(3): the continuation phase in wavefront form (csrc/gpt_wavefront.hip.h: ray queues, traversal-only kernels,
+    shading passes that replay bounce() with the traced results) against the staged pipeline: the replay runs the same source, so films,
+    ray counts and path statistics must be IDENTICAL, bit for bit -- for 1 traced bounce, for the default, and for more bounces than any
+    path has (k_continue left with nothing); through the LDS-scene and the HBM-scene builds; with several queue chunks per launch."""
+    import os
+    sc = builder()
+    W, H, spp = sc.width, sc.height, 5
+    integ = G.GradientPathIntegrator(**kw)
+    cfg = integ.config(spp)
+    for hbm in (False, True):
+        if hbm:
+            os.environ["GDPT_SCENE_IN_HBM"] = "1"
+        try:
+            S = G.Scene(sc)
+            F = G.Film(S); F.set_pipeline(2)
+            integ.renderBlock(S, F, cfg, (0, 0, W, H))
+            ref = (F.accum(), F.stats(), F.invalid_puts())
+            F.close()
+            for iters, queue_mb in ((1, None), (6, None), (40, None), (3, "1")):
+                os.environ["GDPT_WF_ITERS"] = str(iters)
+                if queue_mb:
+                    os.environ["GDPT_QUEUE_MB"] = queue_mb
+                try:
+                    F = G.Film(S); F.set_pipeline(3)
+                    integ.renderBlock(S, F, cfg, (0, 0, W, H))
+                    got = (F.accum(), F.stats(), F.invalid_puts())
+                    F.close()
+                finally:
+                    os.environ.pop("GDPT_WF_ITERS", None); os.environ.pop("GDPT_QUEUE_MB", None)
+                assert got[1] == ref[1] and got[2] == ref[2], (hbm, iters)
+                if name == "gaussian-film" or queue_mb:      # (the log's gather / filter-edge samples of other chunkings: fp64 atomics in another order)
+                    for b in range(5):
+                        assert close(got[0][b], ref[0][b], 1e-12), (hbm, iters, G.BUFFER_NAMES[b])
+                else:
+                    for b in range(5):
+                        assert np.array_equal(got[0][b], ref[0][b]), (hbm, iters, G.BUFFER_NAMES[b])
+            S.close()
+        finally:
+            os.environ.pop("GDPT_SCENE_IN_HBM", None)
+
+
 @pytest.mark.parametrize("flt,wrap", [(scenes.TEXFILTER_BILINEAR, scenes.TEXWRAP_REPEAT), (scenes.TEXFILTER_NEAREST, scenes.TEXWRAP_MIRROR), (scenes.TEXFILTER_BILINEAR, scenes.TEXWRAP_ZERO),
                                       (scenes.TEXFILTER_EWA, scenes.TEXWRAP_REPEAT), (scenes.TEXFILTER_TRILINEAR, scenes.TEXWRAP_CLAMP)])
 def test_bitmap_textures_match_oracle(G, flt, wrap):

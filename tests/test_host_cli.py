@@ -281,6 +281,39 @@ def test_exr_zip_writer_reader_and_rgbe(cli, tmp_path):
     assert r.returncode == 1 and "JPEG" in r.stderr
 
 
+def test_exr_reader_takes_the_data_window_origin(cli, tmp_path):
+    """A scanline chunk stores its y in dataWindow coordinates: a cropped render (dataWindow.min != 0: common for textures and environment
+    maps cut out of a larger frame) must decode into rows 0..h-1, not be rejected as truncated.  The file is this build's own, with its
+    data / display windows and every chunk's y moved by (+11, +7) in place."""
+    import struct
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((37, 21, 3)).astype(np.float32)
+    write_pfm(str(tmp_path / "a.pfm"), a)
+    for cmp in ("zip", "zips", "none"):
+        out = str(tmp_path / ("w_%s.exr" % cmp))
+        assert run(cli, "--pfm2exr", str(tmp_path / "a.pfm"), out, "float32", cmp).returncode == 0
+        b = bytearray(open(out, "rb").read())
+        i = 8
+        while b[i] != 0:
+            e = b.index(b"\0", i); name = bytes(b[i:e]).decode(); i = e + 1
+            e = b.index(b"\0", i); i = e + 1
+            (sz,) = struct.unpack("<i", b[i:i + 4]); i += 4
+            if name in ("dataWindow", "displayWindow"):
+                x0, y0, x1, y1 = struct.unpack("<4i", b[i:i + 16])
+                b[i:i + 16] = struct.pack("<4i", x0 + 11, y0 + 7, x1 + 11, y1 + 7)
+            i += sz
+        i += 1
+        lines = 16 if cmp == "zip" else 1
+        chunks = (37 + lines - 1) // lines
+        for off in struct.unpack("<%dQ" % chunks, b[i:i + 8 * chunks]):
+            (yy,) = struct.unpack("<i", b[off:off + 4])
+            b[off:off + 4] = struct.pack("<i", yy + 7)
+        open(out, "wb").write(bytes(b))
+        r = run(cli, "--tex2pfm", out, str(tmp_path / "back.pfm"))
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(read_pfm(str(tmp_path / "back.pfm")), a), cmp
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"

@@ -9,6 +9,9 @@ desc = scenes.atrium(W, H) if name == "atrium" else scenes.cornell_box(W, H, "di
 scene = gpt.Scene(desc, device=0)
 integ = gpt.GradientPathIntegrator(maxDepth=-1 if name != "glossy" else 12)
 film = gpt.Film(scene)
+import os
+if os.environ.get("WF_PIPE"):
+    film.set_pipeline(int(os.environ["WF_PIPE"]))          # (3: wavefront continuation, GDPT_WF_ITERS traced bounces)
 for rep in range(3):
     film.clear(); integ.renderBlock(scene, film, integ.config(spp), (0, 0, W, H)); film.sync()
     st = film.stats()

@@ -1,0 +1,11 @@
+# SQ + L2 counters of a command, per kernel: gpurun -- 'PMC_GREP=k_wf bash tools/pmc_l2.sh python tools/gpu_one_render.py atrium 8'
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_tmp; rm -rf $OUT; mkdir -p $OUT
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY -d $OUT/a -o r -- "$@" > $OUT/stdout.log 2> $OUT/err.log
+timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA -d $OUT/b -o r -- "$@" >> $OUT/stdout.log 2>> $OUT/err.log
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum -d $OUT/c -o r -- "$@" >> $OUT/stdout.log 2>> $OUT/err.log
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/d -o r -- "$@" >> $OUT/stdout.log 2>> $OUT/err.log
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/e -o r -- "$@" >> $OUT/stdout.log 2>> $OUT/err.log
+tail -3 $OUT/stdout.log; grep -i "error\|invalid" $OUT/err.log | head -5
+python tools/rocpd_summary.py pmc $(find $OUT -name "*.db") | grep -E "${PMC_GREP:-k_wf}" | sort
+find $OUT -name "*.db" -delete
