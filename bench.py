@@ -407,10 +407,22 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     t = torch.tensor([wall, render_ms, float(rays), solve_s], dtype=torch.float64, device=dev)
+    ranks_line = None
     if world > 1:
+        # per rank: render-kernel ms and the host phases of a step -- who is the slowest, how uneven the strips are, how much of a step is not render
+        mine = torch.tensor([render_ms / a.steps] + [phase_ms.get(k, 0.0) / a.steps for k in ("render", "halo", "develop", "gather", "reconstruct")], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = [[float(v) for v in r.tolist()] for r in allr]
+        rk = [p[0] for p in per]
+        slow = max(range(world), key=lambda r: rk[r])
+        ranks_line = {"render_kernel_ms": [round(v, 3) for v in rk], "slowest_rank": slow, "imbalance_max_over_mean": round(max(rk) / (sum(rk) / world), 4),
+                      "phases_ms_by_rank": {k: [round(p[1 + i], 3) for p in per] for i, k in enumerate(("render", "halo", "develop", "gather", "reconstruct"))},
+                      "what": "render_kernel_ms: HIP-event span of a rank's render kernels per step; phases: host wall time per step, each phase ends synchronised (gather on rank 0 includes waiting for the slowest strip)"}
         mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = t.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         wall, render_ms, solve_s, rays = float(mx[0]), float(mx[1]), float(mx[3]), float(sm[2])
+        ranks_line["step_fraction_outside_render"] = round(1.0 - (render_ms / a.steps) / (1e3 * wall / a.steps), 4)
     else:
         rays = float(rays)
 
@@ -472,7 +484,7 @@ def main():
         else:
             tracer_issue.update({"achieved": None, "frac": None})
         closest_frac = st_["raysTraced"] / float(max(1, st_["raysTraced"] + st_["shadowRaysTraced"]))
-        tracer_bytes = tracer_bytes_block(scene, desc, rays / world / launch_s * world, closest_frac)
+        tracer_bytes = tracer_bytes_block(scene, desc, rays / a.steps / launch_s, closest_frac)
         # --- the persistent CG kernel that runs THIS configuration's solve: latency-bound, never an HBM fraction
         persistent = None
         if pus > 0.0:
@@ -543,6 +555,8 @@ def main():
             "tracer_bytes": tracer_bytes,
             "roofline_hbm_case": hbm_case,
         }
+        if ranks_line:
+            out["ranks"] = ranks_line
         if not a.no_cpu_baseline and a.config == 2 and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, H, a.spp)
         print(json.dumps(out))

@@ -13,18 +13,24 @@
  *   PathEdge::sampleNext / perturbDirection / connect / pathConnectAndCollapse / evalCached     src/libbidir/edge.cpp:27-131,169-287,442-574
  *   ManifoldPerturbation::computeMuRec / getSpecularChainEndGBDPT / generateOffsetPathGBDPT / perturbDirection
  *                                                          src/libbidir/mut_manifold.cpp:806-986,1230-1296
- *   SpecularManifold::det / multiG / G (the cases without a specular vertex in the chain)         src/libbidir/manifold.cpp:759-775,871-906
+ *   ManifoldPerturbation::propagatePerturbation / manifoldWalk (stage C, round 4)                 src/libbidir/mut_manifold.cpp:989-1227
+ *   PathVertex::propagatePerturbation                                                           src/libbidir/vertex.cpp:681-790
+ *   SpecularManifold::init / computeTangents / project / move / update / det / multiG / G       src/libbidir/manifold.cpp:59-951
  *   PerspectiveCamera::importance / samplePosition / sampleDirection / pdfDirection / evalDirection / getSamplePosition
  *                                                          src/sensors/perspective.cpp:190-247,300-410
  *   AreaLight::samplePosition / evalPosition / pdfPosition / sampleDirection / evalDirection / pdfDirection   src/emitters/area.cpp:93-142
  *   Scene::sampleEmitterPosition / pdfEmitterPosition      src/librender/scene.cpp:985-1006
  *
- * SCOPE (stage A/B): every surface vertex of a path must be CONNECTABLE in the sense of Path::isConnectable_GBDPT (path.cpp:30-47): a BSDF
- * with a smooth component whose roughness is >= shiftThreshold -- diffuse and rough conductors, plain or two-sided, textured or not; area
- * (triangle-mesh / rectangle) emitters; the perspective sensor; the box filter (the only one G-BDPT supports, gbdpt.cpp:70-71).  Then a
- * specular chain never occurs: propagatePerturbation has nothing to propagate and manifoldWalk is not entered (mut_manifold.cpp:873,882),
- * SpecularManifold::det returns 1 (manifold.cpp:774) and every generalized geometry term is a plain G.  A sample that meets a
- * non-connectable surface vertex is counted in `unsupported` and contributes nothing; tests assert the count is zero.
+ * SCOPE: surface interactions only (no media), area (triangle-mesh / rectangle) emitters, the perspective sensor, the box filter (the only one
+ * G-BDPT supports, gbdpt.cpp:70-71); BSDFs diffuse / roughconductor (plain or two-sided, textured or not) and -- stage C -- conductor, dielectric
+ * and rough conductors below shiftThreshold: paths with SPECULAR CHAINS.  Their offset paths follow the reference's three mechanisms: the chain
+ * between the sensor a and the first connectable vertex b is re-created vertex by vertex (a specular vertex takes its delta component again, a
+ * glossy one keeps its half vector), the chain between b and the next connectable vertex c follows b by a Newton walk on the specular manifold
+ * (reversibility-checked; a failed walk falls back to the unshifted chain), and Jacobians / MIS weights carry SpecularManifold's generalized
+ * geometry terms and determinants.  Not carried: media, directional endpoints (EPinnedDirection), index-matched ENull transmission; the one
+ * place the reference calls Eigen (the inverse and determinant of the mixed glossy / specular system of SpecularManifold::det) is restated as
+ * Gauss-Jordan / LU with partial pivoting.  A BSDF is identified by its material index where the reference compares BSDF pointers.
+ * `unsupported` counts what falls outside (a chain through a non-surface vertex); tests assert it is zero.
  *
  * PARITY UNPINNED, like the rest of this oracle: nothing here was compared with output of the reference (it cannot be built in this image).
  * Random numbers: the counter-based stream of gpt_oracle.cpp (one per pixel and sample), consumed in the reference's order.
@@ -95,6 +101,9 @@ struct Ctx {
     V3 camPos, camDir;
     Float rectX, rectY, normalization;              // m_imageRect half extents and 1 / its area, perspective.cpp:167-173
     uint64_t unsupported = 0;
+    // specular-chain statistics of the offset paths (the reference's statsUsedManifold / statsMWSuccess / statsUsedPropagation counters,
+    // mut_manifold.cpp:33-75): manifold walks entered, walks that converged reversibly, chain vertices re-created by propagatePerturbation
+    uint64_t walks = 0, walksOk = 0, propagated = 0;
 };
 
 inline void cameraSetup(Ctx &c)
@@ -389,7 +398,7 @@ struct Tracer {
             const V3 wi = normalize(pred->position() - its.p);
             const V3 wiL = its.sh.toLocal(wi);
             const Float sx = rng.next1D(), sy = rng.next1D();
-            const BSDFSample bs = bsdfSample(v->mat, wiL, sx, sy);
+            const BSDFSample bs = bsdfSample(v->mat, wiL, sx, sy, mode == EImportance);
             v->weight[mode] = bs.weight; v->pdf[mode] = bs.pdf;
             if (isZero(v->weight[mode])) return false;
             v->measure = (bs.sampledType & ESmooth) ? ESolidAngle : EDiscrete;             // BSDF::getMeasure, bsdf.h:313-324
@@ -400,9 +409,12 @@ struct Tracer {
             if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(bs.wo) <= 0) return false;
             v->pdf[1 - mode] = bsdfPdf(v->mat, bs.wo, wiL, bsdfMeasure(v->measure));         // bRec.reverse()
             if (v->pdf[1 - mode] <= RCPOVERFLOW) return false;
-            v->weight[1 - mode] = v->weight[mode] * (v->pdf[mode] / v->pdf[1 - mode]);      // no BSDF of the subset is ENonSymmetric
-            if (v->measure == ESolidAngle) v->weight[1 - mode] = v->weight[1 - mode] * std::abs(cosTheta(wiL) / cosTheta(bs.wo));   // (of the REVERSED record: wo = old wi)
+            if (v->mat.type != MAT_DIELECTRIC) {                                             // (dielectric.cpp:87-98 is the one ENonSymmetric BSDF of the subset)
+                v->weight[1 - mode] = v->weight[mode] * (v->pdf[mode] / v->pdf[1 - mode]);
+                if (v->measure == ESolidAngle) v->weight[1 - mode] = v->weight[1 - mode] * std::abs(cosTheta(wiL) / cosTheta(bs.wo));   // (of the REVERSED record: wo = old wi)
+            } else v->weight[1 - mode] = bsdfEval(v->mat, bs.wo, wiL, bsdfMeasure(v->measure), (1 - mode) == EImportance) / v->pdf[1 - mode];   // bRec.reverse() flips the mode too
             adjoint(v, mode, wiL, bs.wo, wiDotGeoN, woDotGeoN);
+            if (throughput && mode == ERadiance && bs.eta != 1) *throughput = *throughput * (bs.eta * bs.eta);   // "for BDPT & russian roulette, track radiance * eta^2", :225-227
             ray = Ray(its.p, wo);
             break;
         }
@@ -541,7 +553,7 @@ struct Tracer {
             const V3 wi = normalize(pred->position() - its.p), wo = normalize(succ->position() - its.p);
             const V3 wiL = its.sh.toLocal(wi), woL = its.sh.toLocal(wo);
             if (measure == EArea) measure = ESolidAngle;
-            V3 result = bsdfEval(v->mat, wiL, woL, bsdfMeasure(measure));
+            V3 result = bsdfEval(v->mat, wiL, woL, bsdfMeasure(measure), mode == EImportance);
             const Float wiDotGeoN = dot(its.geoN, wi), woDotGeoN = dot(its.geoN, wo);
             if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(woL) <= 0) return V3(0.0);
             if (mode == EImportance) result = result * std::abs((cosTheta(wiL) * woDotGeoN) / (cosTheta(woL) * wiDotGeoN));
@@ -700,20 +712,382 @@ struct Tracer {
             } else curVertexS = nullptr;
         } while (curVertexS || curVertexT);
     }
-    // Path::G, path.cpp:424-454 (adjacent vertices; a longer chain would need the generalized term of a specular chain: out of scope)
+
+    // PathVertex::propagatePerturbation, vertex.cpp:681-790: re-creates a SPECULAR vertex of a perturbed chain -- the delta component named by
+    // componentType is taken deterministically (the sample (0.5, 0.5) is never consulted by a one-component request) and its ray traced to `dist`
+    bool propagatePerturbation(Vertex *v, const Vertex *pred, const Edge *predEdge, Edge *succEdge, Vertex *succ, int componentType, Float dist, int mode)
+    {
+        const Intersection &its = v->its;
+        if (!(bsdfType(v->mat) & EDelta)) return false;
+        *succEdge = Edge(); *succ = Vertex();
+        const V3 wi = normalize(pred->position() - its.p);
+        const V3 wiL = its.sh.toLocal(wi);
+        const BSDFSample bs = bsdfSample(v->mat, wiL, 0.5, 0.5, mode == EImportance, componentType);
+        if (isZero(bs.weight)) return false;
+        const V3 wo = its.sh.toWorld(bs.wo);
+        const Float wiDotGeoN = dot(its.geoN, wi), woDotGeoN = dot(its.geoN, wo);
+        if (wiDotGeoN * cosTheta(wiL) <= 0 || woDotGeoN * cosTheta(bs.wo) <= 0) return false;
+        const Float prob = bsdfPdf(v->mat, wiL, bs.wo, MEASURE_DISCRETE);                   // bRec.typeMask = BSDF::EAll
+        if (prob <= RCPOVERFLOW) return false;
+        v->weight[mode] = bsdfEval(v->mat, wiL, bs.wo, MEASURE_DISCRETE, mode == EImportance) / prob;
+        v->pdf[mode] = prob;
+        v->measure = EDiscrete;
+        v->componentType = componentType;
+        if (isZero(v->weight[mode]) || prob <= RCPOVERFLOW) return false;
+        v->pdf[1 - mode] = bsdfPdf(v->mat, bs.wo, wiL, MEASURE_DISCRETE);
+        if (v->pdf[1 - mode] <= RCPOVERFLOW) return false;
+        if (v->mat.type != MAT_DIELECTRIC) v->weight[1 - mode] = v->weight[mode];
+        else v->weight[1 - mode] = bsdfEval(v->mat, bs.wo, wiL, MEASURE_DISCRETE, (1 - mode) == EImportance) / v->pdf[1 - mode];
+        adjoint(v, mode, wiL, bs.wo, wiDotGeoN, woDotGeoN);
+        (void)predEdge;
+        Ray ray(its.p, wo);
+        if (!edgePerturbDirection(succEdge, ray, dist, succ, mode)) { v->measure = EInvalidMeasure; return false; }
+        return true;
+    }
+
+    // ---- SpecularManifold, src/libbidir/manifold.cpp (surface interactions and position-pinned endpoints: no media, no directional endpoints) ----
+    struct M2 {                                     // Matrix2x2, core/matrix.h:455-530
+        Float m[2][2];
+        M2() { m[0][0] = m[0][1] = m[1][0] = m[1][1] = 0; }
+        M2(Float a, Float b, Float cc, Float d) { m[0][0] = a; m[0][1] = b; m[1][0] = cc; m[1][1] = d; }
+        void setZero() { m[0][0] = m[0][1] = m[1][0] = m[1][1] = 0; }
+        void setIdentity() { m[0][0] = m[1][1] = 1; m[0][1] = m[1][0] = 0; }
+        Float det() const { return m[0][0] * m[1][1] - m[0][1] * m[1][0]; }
+        bool invert(M2 &t) const
+        {
+            const Float d = m[0][0] * m[1][1] - m[0][1] * m[1][0];
+            if (std::abs(d) <= RCPOVERFLOW) return false;
+            const Float invDet = 1 / d;
+            t.m[0][0] = m[1][1] * invDet; t.m[0][1] = -m[0][1] * invDet; t.m[1][1] = m[0][0] * invDet; t.m[1][0] = -m[1][0] * invDet;
+            return true;
+        }
+        M2 operator*(const M2 &o) const
+        {
+            M2 r;
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { Float sum = 0; for (int k = 0; k < 2; ++k) sum += m[i][k] * o.m[k][j]; r.m[i][j] = sum; }   // Matrix::operator*, matrix.h
+            return r;
+        }
+        M2 operator-(const M2 &o) const { return M2(m[0][0] - o.m[0][0], m[0][1] - o.m[0][1], m[1][0] - o.m[1][0], m[1][1] - o.m[1][1]); }
+        M2 operator-() const { return M2(-m[0][0], -m[0][1], -m[1][0], -m[1][1]); }
+    };
+    enum { EPinnedPosition = 0, EReflection = 2, ERefraction = 3, EMovable = 5 };             // manifold.h:88-95
+    struct SimpleVertex {                           // manifold.h:98-134
+        bool degenerate = false;
+        int type = EPinnedPosition;
+        V3 p, dpdu, dpdv, n, gn, dndu, dndv, m;
+        Float eta = 1.0;
+        int object = -1;                            // the BSDF: here the material index
+        M2 a, b, c, u, Tp;
+        SimpleVertex() {}
+        SimpleVertex(int t, V3 pos) : type(t), p(pos), dpdu(0.0), dpdv(0.0), n(0.0), gn(0.0), dndu(0.0), dndv(0.0), m(0.0) {}
+        V3 map(Float uu, Float vv) const { const Float tx = Tp.m[0][0] * uu + Tp.m[0][1] * vv, ty = Tp.m[1][0] * uu + Tp.m[1][1] * vv; return dpdu * tx + dpdv * ty; }
+    };
+    std::vector<SimpleVertex> mVerts, mProposal;
+    int mIterations = 0;
+    // TriMesh::getNormalDerivative, trimesh.cpp:745-822 (shadingFrame = true)
+    void normalDerivative(const Intersection &its, V3 &dndu, V3 &dndv) const
+    {
+        const Tri &tr = c.sc.tris[its.prim];
+        dndu = dndv = V3(0.0);
+        if (!tr.hasNormals) return;
+        const V3 rel = its.p - tr.p0, du = tr.p1 - tr.p0, dv = tr.p2 - tr.p0;
+        const Float b1 = dot(du, rel), b2 = dot(dv, rel), a11 = dot(du, du), a12 = dot(du, dv), a22 = dot(dv, dv);
+        Float det = a11 * a22 - a12 * a12;
+        if (det == 0) return;
+        Float invDet = 1.0 / det;
+        const Float u = (a22 * b1 - a12 * b2) * invDet, v = (-a12 * b1 + a11 * b2) * invDet, w = 1 - u - v;
+        V3 N = tr.n1 * u + tr.n2 * v + tr.n0 * w;
+        const Float il = 1.0 / length(N); N = N * il;
+        dndu = (tr.n1 - tr.n0) * il; dndu = dndu - N * dot(N, dndu);
+        dndv = (tr.n2 - tr.n0) * il; dndv = dndv - N * dot(N, dndv);
+        if (tr.hasUV) {
+            const Float d1x = tr.uv[2] - tr.uv[0], d1y = tr.uv[3] - tr.uv[1], d2x = tr.uv[4] - tr.uv[0], d2y = tr.uv[5] - tr.uv[1];
+            det = d1x * d2y - d1y * d2x;
+            if (det == 0) { dndu = dndv = V3(0.0); return; }
+            invDet = 1.0 / det;
+            const V3 du_ = (dndu * d2y - dndv * d1y) * invDet, dv_ = (dndv * d1x - dndu * d2x) * invDet;
+            dndu = du_; dndv = dv_;
+        }
+    }
+    // the surface part of SimpleVertex from an intersection: position, normals, an orthonormal parameterization at p (manifold.cpp:101-122,480-507)
+    void manifoldSurface(SimpleVertex &v, const Intersection &its) const
+    {
+        v.p = its.p; v.gn = its.geoN; v.n = its.sh.n; v.dpdu = its.dpdu; v.dpdv = its.dpdv;
+        normalDerivative(its, v.dndu, v.dndv);
+        Float invLen = 1 / length(v.dpdu);
+        v.dpdu = v.dpdu * invLen; v.dndu = v.dndu * invLen;
+        const Float dp = dot(v.dpdu, v.dpdv);
+        const V3 dpdv = v.dpdv - v.dpdu * dp, dndv = v.dndv - v.dndu * dp;
+        invLen = 1 / length(dpdv);
+        v.dpdv = dpdv * invLen; v.dndv = dndv * invLen;
+    }
+    // SpecularManifold::init, manifold.cpp:59-170
+    bool manifoldInit(const Path &path, int start, int end)
+    {
+        const int step = start < end ? 1 : -1;
+        if (path.v[start]->isSupernode()) start += step;
+        if (path.v[end]->isSupernode()) end -= step;
+        const Vertex *vs = path.v[start], *ve = path.v[end];
+        mVerts.clear();
+        mVerts.push_back(SimpleVertex(EPinnedPosition, vs->position()));   // (area lights and the perspective sensor: no EDeltaDirection endpoint)
+        for (int i = start + step; i != end; i += step) {
+            const Vertex *pred = path.v[i - step], *vertex = path.v[i], *succ = path.v[i + step];
+            SimpleVertex v(EPinnedPosition, V3(0.0));
+            if (!vertex->isSurface()) return false;
+            manifoldSurface(v, vertex->its);
+            v.object = c.sc.tris[vertex->its.prim].material;
+            v.degenerate = !vertex->isConnectable();
+            const V3 wPred = pred->position() - v.p, wSucc = succ->position() - v.p;
+            if (dot(v.gn, wPred) * dot(v.gn, wSucc) < 0) { v.type = ERefraction; v.eta = getEta(vertex->mat); }
+            else { v.type = EReflection; v.eta = 1.0; }
+            mVerts.push_back(v);
+        }
+        mVerts.push_back(SimpleVertex(EMovable, ve->position()));
+        return true;
+    }
+    // SpecularManifold::computeTangents, manifold.cpp:172-400
+    bool manifoldTangents()
+    {
+        const int n = (int)mVerts.size() - 1;
+        mVerts[0].Tp.setZero();
+        mVerts[mVerts.size() - 1].Tp.setIdentity();
+        if (mVerts.size() == 2) return true;
+        for (int i = 0; i < n; ++i) {
+            SimpleVertex *v = &mVerts[i];
+            V3 wo = v[1].p - v[0].p;
+            Float ilo = length(wo);
+            if (ilo == 0) return false;
+            ilo = 1 / ilo; wo = wo * ilo;
+            if (v[0].type == EPinnedPosition) { v[0].a.setZero(); v[0].b.setIdentity(); v[0].c.setZero(); continue; }
+            V3 wi = v[-1].p - v[0].p;
+            Float ili = length(wi);
+            if (ili == 0) return false;
+            ili = 1 / ili; wi = wi * ili;
+            if (v[0].type != EReflection && v[0].type != ERefraction) return false;
+            Float eta = v[0].eta;
+            const bool normalizeH = !(v[0].type == ERefraction && eta == 1);
+            V3 H;
+            Float ilh;
+            if (normalizeH) {
+                if (dot(wi, v[0].gn) < 0) eta = 1 / eta;
+                H = wi + wo * eta;
+                ilh = 1 / length(H);
+                H = H * ilh;
+            } else { H = wi + wo; ilh = 1.0; }
+            const Float dot_H_n = dot(v[0].n, H), dot_H_dndu = dot(v[0].dndu, H), dot_H_dndv = dot(v[0].dndv, H), dot_u_n = dot(v[0].dpdu, v[0].n), dot_v_n = dot(v[0].dpdv, v[0].n);
+            V3 s_ = v[0].dpdu - v[0].n * dot_u_n, t_ = v[0].dpdv - v[0].n * dot_v_n;
+            ilo *= eta * ilh; ili *= ilh;
+            V3 dH_du = (v[-1].dpdu - wi * dot(wi, v[-1].dpdu)) * ili, dH_dv = (v[-1].dpdv - wi * dot(wi, v[-1].dpdv)) * ili;
+            if (normalizeH) { dH_du = dH_du - H * dot(dH_du, H); dH_dv = dH_dv - H * dot(dH_dv, H); }
+            v[0].a = M2(dot(dH_du, s_), dot(dH_dv, s_), dot(dH_du, t_), dot(dH_dv, t_));
+            dH_du = -v[0].dpdu * (ili + ilo) + wi * (dot(wi, v[0].dpdu) * ili) + wo * (dot(wo, v[0].dpdu) * ilo);
+            dH_dv = -v[0].dpdv * (ili + ilo) + wi * (dot(wi, v[0].dpdv) * ili) + wo * (dot(wo, v[0].dpdv) * ilo);
+            if (normalizeH) { dH_du = dH_du - H * dot(dH_du, H); dH_dv = dH_dv - H * dot(dH_dv, H); }
+            v[0].b = M2(dot(dH_du, s_) - dot(v[0].dpdu, v[0].dndu) * dot_H_n - dot_u_n * dot_H_dndu,
+                        dot(dH_dv, s_) - dot(v[0].dpdu, v[0].dndv) * dot_H_n - dot_u_n * dot_H_dndv,
+                        dot(dH_du, t_) - dot(v[0].dpdv, v[0].dndu) * dot_H_n - dot_v_n * dot_H_dndu,
+                        dot(dH_dv, t_) - dot(v[0].dpdv, v[0].dndv) * dot_H_n - dot_v_n * dot_H_dndv);
+            dH_du = (v[1].dpdu - wo * dot(wo, v[1].dpdu)) * ilo;
+            dH_dv = (v[1].dpdv - wo * dot(wo, v[1].dpdv)) * ilo;
+            if (normalizeH) { dH_du = dH_du - H * dot(dH_du, H); dH_dv = dH_dv - H * dot(dH_dv, H); }
+            v[0].c = M2(dot(dH_du, s_), dot(dH_dv, s_), dot(dH_du, t_), dot(dH_dv, t_));
+            s_ = normalize(s_);
+            t_ = cross(v[0].n, s_);
+            v[0].m = V3(dot(s_, H), dot(t_, H), dot(v[0].n, H));
+            if (dot(H, v[0].gn) < 0) v[0].m = -v[0].m;
+        }
+        M2 Li;
+        if (!mVerts[0].b.invert(Li)) return false;
+        for (int i = 0; i < n - 1; ++i) {
+            mVerts[i].u = Li * mVerts[i].c;
+            const M2 temp = mVerts[i + 1].b - mVerts[i + 1].a * mVerts[i].u;
+            if (!temp.invert(Li)) return false;
+        }
+        mVerts[n - 1].Tp = -(Li * mVerts[n - 1].c);
+        for (int i = n - 2; i >= 0; --i) mVerts[i].Tp = -(mVerts[i].u * mVerts[i + 1].Tp);
+        return true;
+    }
+    static V3 reflectAbout(V3 wi, V3 n) { return n * (2 * dot(wi, n)) - wi; }                // util.cpp:763-765
+    static V3 refractAbout(V3 wi, V3 n, Float eta)                                           // util.cpp:774-792
+    {
+        if (eta == 1) return -wi;
+        const Float cosThetaI = dot(wi, n);
+        if (cosThetaI > 0) eta = 1 / eta;
+        const Float cosThetaTSqr = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
+        if (cosThetaTSqr <= 0.0) return V3(0.0);
+        return n * (cosThetaI * eta - (cosThetaI < 0 ? -1.0 : (cosThetaI > 0 ? 1.0 : 0.0)) * std::sqrt(cosThetaTSqr)) - wi * eta;
+    }
+    // SpecularManifold::project, manifold.cpp:402-510
+    bool manifoldProject(V3 d)
+    {
+        const SimpleVertex &last = mVerts[mVerts.size() - 1];
+        const Float du = dot(d, last.dpdu), dv = dot(d, last.dpdv);
+        Ray ray;
+        Intersection its;
+        mProposal.clear();
+        for (size_t i = 0; i < mVerts.size(); ++i) {
+            mProposal.push_back(mVerts[i]);
+            SimpleVertex &vertex = mProposal[i];
+            if (i == 0) {
+                const V3 p0 = mVerts[0].p + mVerts[0].map(du, dv), p1 = mVerts[1].p + mVerts[1].map(du, dv);
+                ray = Ray(p0, normalize(p1 - p0));
+                vertex.p = ray.o;
+                continue;
+            } else if (vertex.type == EMovable) {
+                const Float dp = dot(ray.d, vertex.n);
+                if (std::abs(dp) < Epsilon) return false;
+                const Float t = dot(vertex.p - ray.o, vertex.n) / dp;
+                vertex.p = ray.o + ray.d * t;
+                break;
+            } else if (vertex.type == EReflection || vertex.type == ERefraction) {
+                if (!rayIntersect(c.sc, ray, its)) return false;
+                const V3 n = its.sh.n;
+                V3 s_ = its.dpdu;
+                s_ = normalize(s_ - n * dot(n, s_));
+                const V3 t_ = cross(n, s_);
+                const V3 m = s_ * vertex.m.x + t_ * vertex.m.y + n * vertex.m.z;
+                V3 out;
+                if (vertex.type == EReflection) out = reflectAbout(-ray.d, m);
+                else {
+                    Ray none;
+                    out = refractAbout(-ray.d, m, getEta(matOf(c.sc, its, none)));
+                    if (isZero(out)) return false;
+                }
+                ray = Ray(its.p, out);
+            } else return false;
+            if (vertex.object != c.sc.tris[its.prim].material) return false;
+            manifoldSurface(vertex, its);
+        }
+        return true;
+    }
+    // SpecularManifold::move, manifold.cpp:512-635
+    bool manifoldMove(V3 target, V3 n)
+    {
+        SimpleVertex &last = mVerts[mVerts.size() - 1];
+        if (mVerts.size() == 2 && mVerts[0].type == EPinnedPosition) return true;
+        const Float invScale = 1.0 / std::max(std::max(std::abs(target.x), std::abs(target.y)), std::abs(target.z));
+        Float stepSize = 1;
+        coordinateSystem(n, last.dpdu, last.dpdv);
+        last.n = n;
+        mIterations = 0;
+        while (mIterations < 20) {                                                           // MTS_MANIFOLD_MAX_ITERATIONS, manifold.h:27
+            const V3 rel = target - mVerts[mVerts.size() - 1].p;
+            Float dist = length(rel), newDist;
+            if (dist * invScale < Epsilon) {                                                 // MTS_MANIFOLD_EPSILON
+                dist = length(mVerts[mVerts.size() - 1].p - mVerts[mVerts.size() - 2].p);
+                if (dist * invScale < Epsilon) return false;
+                return true;
+            }
+            mIterations++;
+            if (!manifoldTangents()) return false;
+            bool failure = false;
+            if (!manifoldProject(rel * stepSize)) failure = true;
+            else {
+                newDist = length(target - mProposal[mProposal.size() - 1].p);
+                if (newDist > dist) failure = true;
+            }
+            if (!failure) {
+                mProposal.swap(mVerts);
+                stepSize = std::min((Float)1.0, stepSize * 2.0);
+                continue;
+            }
+            stepSize /= 2.0;
+        }
+        return false;
+    }
+    // SpecularManifold::update, manifold.cpp:637-757 (start > end: the walk runs from c towards b, mode = ERadiance)
+    bool manifoldUpdate(Path &path, int start, int end)
+    {
+        const int step = start < end ? 1 : -1, mode = start < end ? EImportance : ERadiance;
+        const int last = (int)mVerts.size() - 2;
+        for (int j = 0, i = start; j < last; ++j, i += step) {
+            const SimpleVertex &v = mVerts[j], &vn = mVerts[j + 1];
+            Vertex *pred = path.vertexOrNull(i - step), *vertex = path.v[i], *succ = path.v[i + step];
+            const int predEdgeIdx = (mode == EImportance) ? i - step : i - step - 1;
+            Edge *predEdge = path.edgeOrNull(predEdgeIdx), *succEdge = path.e[predEdgeIdx + step];
+            V3 d = vn.p - v.p;
+            const Float len = length(d);
+            d = d / len;
+            if (!v.degenerate) {
+                if (!perturbDirection(vertex, pred, predEdge, succEdge, succ, d, len, mode)) return false;
+            } else {
+                const int compType = v.type == ERefraction ? EDeltaTransmission : EDeltaReflection;   // (no index-matched ENull components in the subset)
+                if (!propagatePerturbation(vertex, pred, predEdge, succEdge, succ, compType, len, mode)) return false;
+            }
+            const Float relerr = length(vn.p - succ->position()) / std::max(std::max(std::abs(vn.p.x), std::abs(vn.p.y)), std::abs(vn.p.z));
+            if (relerr > (Float)1e-3f) return false;
+        }
+        return true;
+    }
+    // dense inverse-with-determinant of the small system of SpecularManifold::det's mixed case (the reference calls Eigen's inverse() /
+    // determinant() -- partial-pivot LU; restated as Gauss-Jordan with partial pivoting: the same matrix, another rounding)
+    static bool denseInverse(std::vector<Float> &A, int n, std::vector<Float> &Ai)
+    {
+        Ai.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) Ai[(size_t)i * n + i] = 1.0;
+        for (int col = 0; col < n; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < n; ++r) if (std::abs(A[(size_t)r * n + col]) > std::abs(A[(size_t)piv * n + col])) piv = r;
+            if (A[(size_t)piv * n + col] == 0) return false;
+            if (piv != col) for (int k = 0; k < n; ++k) { std::swap(A[(size_t)piv * n + k], A[(size_t)col * n + k]); std::swap(Ai[(size_t)piv * n + k], Ai[(size_t)col * n + k]); }
+            const Float inv = 1.0 / A[(size_t)col * n + col];
+            for (int k = 0; k < n; ++k) { A[(size_t)col * n + k] *= inv; Ai[(size_t)col * n + k] *= inv; }
+            for (int r = 0; r < n; ++r) {
+                if (r == col) continue;
+                const Float f = A[(size_t)r * n + col];
+                if (f == 0) continue;
+                for (int k = 0; k < n; ++k) { A[(size_t)r * n + k] -= f * A[(size_t)col * n + k]; Ai[(size_t)r * n + k] -= f * Ai[(size_t)col * n + k]; }
+            }
+        }
+        return true;
+    }
+    static Float denseDet(std::vector<Float> A, int n)
+    {
+        Float det = 1.0;
+        for (int col = 0; col < n; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < n; ++r) if (std::abs(A[(size_t)r * n + col]) > std::abs(A[(size_t)piv * n + col])) piv = r;
+            if (A[(size_t)piv * n + col] == 0) return 0.0;
+            if (piv != col) { for (int k = 0; k < n; ++k) std::swap(A[(size_t)piv * n + k], A[(size_t)col * n + k]); det = -det; }
+            det *= A[(size_t)col * n + col];
+            for (int r = col + 1; r < n; ++r) {
+                const Float f = A[(size_t)r * n + col] / A[(size_t)col * n + col];
+                if (f == 0) continue;
+                for (int k = col; k < n; ++k) A[(size_t)r * n + k] -= f * A[(size_t)col * n + k];
+            }
+        }
+        return det;
+    }
+    // Path::G, path.cpp:424-454: the plain geometry term of an edge, the generalized one of SpecularManifold::G across a specular chain
     Float pathG(const Path &p, int i, int j)
     {
-        if (j != i + 1) { c.unsupported++; return 1.0; }
+        if (i >= j) return 1.0;
+        if (j != i + 1) return manifoldG(p, i, j);
         const Float cosI = std::abs(dot(p.e[i]->d, p.v[i]->shadingNormal())), cosJ = std::abs(dot(p.e[i]->d, p.v[j]->shadingNormal()));
         const Float len = p.e[i]->length;
         return cosI * cosJ / (len * len);
     }
-    // SpecularManifold::G for adjacent vertices (manifold.cpp:900-906) and multiG (:871-898)
+    // SpecularManifold::G (manifold.cpp:900-951) and multiG (:871-898)
     Float manifoldG(const Path &p, int a, int b)
     {
-        if (std::abs(a - b) != 1) { c.unsupported++; return 1.0; }
-        if (a > b) std::swap(a, b);
-        return edgeEvalCached(p.e[a], p.v[a], p.v[b], EGeometricTerm).x;
+        if (std::abs(a - b) == 1) {
+            if (a > b) std::swap(a, b);
+            return edgeEvalCached(p.e[a], p.v[a], p.v[b], EGeometricTerm).x;
+        }
+        const int step = b > a ? 1 : -1;
+        if (!manifoldInit(p, a, b)) { c.unsupported++; return 0.0; }
+        SimpleVertex &last = mVerts[mVerts.size() - 1];
+        const Vertex *vb = p.v[b];
+        if (!vb->isOnSurface()) last.n = p.e[a < b ? (b - 1) : b]->d;
+        else last.n = vb->shadingNormal();
+        coordinateSystem(last.n, last.dpdu, last.dpdv);
+        if (!manifoldTangents()) return 0.0;                                                 // "non-manifold configuration"
+        const V3 d = mVerts[1].p - mVerts[0].p;
+        const Float lengthSqr = lengthSquared(d), invLength = 1 / std::sqrt(lengthSqr);
+        Float result = length(cross(mVerts[1].map(1, 0), mVerts[1].map(0, 1))) / lengthSqr;
+        if (p.v[a]->isOnSurface()) result *= std::abs(dot(d, p.v[a]->shadingNormal())) * invLength;
+        if (p.v[a + step]->isOnSurface()) result *= std::abs(dot(d, p.v[a + step]->shadingNormal())) * invLength;
+        return result;
     }
     Float multiG(const Path &p, int a, int b)
     {
@@ -736,9 +1110,39 @@ struct Tracer {
         int nGlossy = 0, nSpecular = 0;
         for (int i = a + step; i != cI; i += step) { if (p.v[i]->isConnectable()) ++nGlossy; else ++nSpecular; }
         if (nGlossy <= 1) return 1.0;
-        c.unsupported++;
-        (void)nSpecular;
-        return 1.0;
+        if (!manifoldInit(p, a, cI)) { c.unsupported++; return 0.0; }
+        const int b_idx = std::abs(b - a);
+        SimpleVertex &vb = mVerts[b_idx];
+        vb.n = p.v[b]->shadingNormal();
+        coordinateSystem(vb.n, vb.dpdu, vb.dpdv);
+        if (!manifoldTangents()) return 0.0;
+        mVerts[b_idx].a.setZero(); mVerts[b_idx].b.setIdentity(); mVerts[b_idx].c.setZero();
+        if (nSpecular == 0) {                                                                // glossy vertices only: the block tridiagonal determinant, manifold.cpp:800-822
+            M2 Di, D = mVerts[1].b;
+            Float det = D.det();
+            for (size_t i = 2; i < mVerts.size() - 1; ++i) {
+                if (!D.invert(Di)) return 0.0;
+                D = mVerts[i].b - mVerts[i].a * Di * mVerts[i - 1].c;
+                det *= D.det();
+            }
+            return std::abs(1 / det);
+        }
+        const int nv = nGlossy + nSpecular, N = 2 * nv;                                      // glossy and specular vertices, :823-867
+        std::vector<Float> A((size_t)N * N, 0.0), Ai;
+        for (int j = 0; j < nv; ++j) {
+            const int i = j;
+            auto put = [&](int cj, const M2 &mm) { A[(size_t)(2 * i) * N + 2 * cj] = mm.m[0][0]; A[(size_t)(2 * i) * N + 2 * cj + 1] = mm.m[0][1]; A[(size_t)(2 * i + 1) * N + 2 * cj] = mm.m[1][0]; A[(size_t)(2 * i + 1) * N + 2 * cj + 1] = mm.m[1][1]; };
+            if (j - 1 >= 0) put(j - 1, mVerts[j + 1].a);
+            put(j, mVerts[j + 1].b);
+            if (j + 1 < nv) put(j + 1, mVerts[j + 1].c);
+        }
+        if (!denseInverse(A, N, Ai)) return 0.0;
+        for (int i = 0; i < nv; ++i) {
+            if (!mVerts[i + 1].degenerate) continue;
+            for (int k = 0; k < N; ++k) { Ai[(size_t)(2 * i) * N + k] = 0; Ai[(size_t)(2 * i + 1) * N + k] = 0; Ai[(size_t)k * N + 2 * i] = 0; Ai[(size_t)k * N + 2 * i + 1] = 0; }
+            Ai[(size_t)(2 * i) * N + 2 * i] = 1; Ai[(size_t)(2 * i + 1) * N + 2 * i + 1] = 1;
+        }
+        return std::abs(denseDet(Ai, N));
     }
     // Path::halfJacobian_GBDPT, path.cpp:380-394
     Float halfJacobian(const Path &p, int a, int b, int cI)
@@ -805,7 +1209,72 @@ struct Tracer {
         const V3 d = normalize((ro + rd * focusDistance) - source.v[a]->position());
         return perturbDirection(vertex, pred, predEdge, succEdge, succ, d, succEdge_old->length, ERadiance);
     }
-    // ManifoldPerturbation::generateOffsetPathGBDPT, mut_manifold.cpp:806-936, for chains without specular vertices
+    // ManifoldPerturbation::propagatePerturbation, mut_manifold.cpp:989-1149 (surface interactions; mode = ERadiance, step = -1): the vertices
+    // between a and b follow the perturbed first segment deterministically -- a glossy one keeps its half vector, a specular one its component
+    bool mutPropagatePerturbation(const Path &source, Path &proposal, int step, int a, int b, int mode)
+    {
+        for (int i = a + step; i != b; i += step) {
+            const Vertex *pred_old = source.v[i - step], *vertex_old = source.v[i], *succ_old = source.v[i + step];
+            const Edge *succEdge_old = source.e[mode == EImportance ? i : i - 1];
+            Vertex *pred = proposal.v[i - step], *vertex = proposal.v[i], *succ = proposal.v[i + step];
+            Edge *predEdge = proposal.e[mode == EImportance ? i - step : i - 1 - step], *succEdge = proposal.e[mode == EImportance ? i : i - 1];
+            if (!vertex_old->isSurface()) return false;
+            c.propagated++;
+            const Intersection &its_old = vertex_old->its, &its_new = vertex->its;
+            const V3 wi_old = its_old.sh.toLocal(normalize(pred_old->position() - its_old.p)), wo_old = its_old.sh.toLocal(normalize(succ_old->position() - its_old.p));
+            const bool reflection = cosTheta(wi_old) * cosTheta(wo_old) > 0;
+            const Float eta = getEta(vertex_old->mat);
+            const V3 wi_world = normalize(pred->position() - vertex->position());
+            V3 wo_world(0.0);
+            if (c.sc.tris[its_old.prim].material != c.sc.tris[its_new.prim].material) return false;      // its_old.getBSDF() != its_new.getBSDF()
+            if (vertex_old->isConnectable()) {
+                V3 m(0.0);
+                if (reflection) m = normalize(wi_old + wo_old);
+                else if (eta != 1) m = normalize(wi_old.z < 0 ? (wi_old * eta + wo_old) : (wi_old + wo_old * eta));
+                m = its_new.sh.toWorld(m.z > 0 ? m : -m);
+                if (reflection) wo_world = reflectAbout(wi_world, m);
+                else if (eta != 1) { wo_world = refractAbout(wi_world, m, eta); if (isZero(wo_world)) return false; }
+                else wo_world = -wi_world;
+                if (!perturbDirection(vertex, pred, predEdge, succEdge, succ, wo_world, succEdge_old->length, mode)) return false;
+            } else {
+                const int component = reflection ? EDeltaReflection : EDeltaTransmission;
+                if (!propagatePerturbation(vertex, pred, predEdge, succEdge, succ, component, succEdge_old->length, mode)) return false;
+            }
+        }
+        return true;
+    }
+    // ManifoldPerturbation::manifoldWalk, mut_manifold.cpp:1151-1227: the specular chain between b and c follows b's displacement by a Newton walk
+    // on the specular manifold (pinned at c), checked for reversibility
+    bool mutManifoldWalk(const Path &source, Path &proposal, int step, int b, int cI)
+    {
+        (void)step;
+        const Vertex *vb_old = source.v[b], *vb_new = proposal.v[b];
+        V3 n1 = vb_old->geometricNormal(), n2 = vb_new->geometricNormal();
+        V3 rel = vb_new->position() - vb_old->position();
+        Float len = length(rel);
+        if (len == 0) return false;
+        rel = rel / len;
+        if (dot(n1, n2) < 0) n1 = -n1;
+        V3 n = n1 + n2;
+        n = n - rel * dot(rel, n);
+        len = length(n);
+        if (len == 0) return false;
+        n = n / len;
+        c.walks++;
+        if (!manifoldInit(source, cI, b)) return false;
+        const V3 p0 = mVerts[1].p;
+        if (!manifoldMove(vb_new->position(), n)) return false;
+        if (!manifoldUpdate(proposal, cI, b)) return false;
+        if (!manifoldMove(vb_old->position(), n)) return false;
+        const V3 p1 = mVerts[1].p;
+        const V3 ctr = (c.sc.aabbMin + c.sc.aabbMax) * 0.5;
+        const Float radius = length(c.sc.aabbMax - ctr);                                     // m_scene->getBSphere().radius, aabb.h
+        const Float relerr = length(p0 - p1) / radius;
+        if (relerr > 10.0 * Epsilon) return false;
+        c.walksOk++;
+        return true;
+    }
+    // ManifoldPerturbation::generateOffsetPathGBDPT, mut_manifold.cpp:806-936
     bool generateOffsetPath(const Path &source, Path &proposal, MuRec &mu, Float offX, Float offY, bool &couldConnectBehindB, bool lightPath)
     {
         const int k = source.length();
@@ -818,7 +1287,6 @@ struct Tracer {
         mu = MuRec();
         mu.l = l; mu.m = m;
         mu.extra[0] = a; mu.extra[1] = b; mu.extra[2] = cI; mu.extra[3] = step; mu.extra[4] = ERadiance;
-        if (a - b > 1 || b - cI > 1) { c.unsupported++; return false; }                     // a specular chain: propagatePerturbation / manifoldWalk (stage C)
         proposal.clear();
         for (int i = 0; i < l + 1; ++i) { proposal.v.push_back(source.v[i]); if (i + 1 < l + 1) proposal.e.push_back(source.e[i]); }   // append(source, 0, l + 1)
         proposal.e.push_back(pool.allocEdge());
@@ -827,8 +1295,16 @@ struct Tracer {
         proposal.v[a] = pool.clone(proposal.v[a]);
         proposal.v[cI] = pool.clone(proposal.v[cI]);
         if (!mutPerturbDirection(source, proposal, step, a, offX, offY)) return false;
-        // propagatePerturbation: nothing between a and b
+        if (!mutPropagatePerturbation(source, proposal, step, a, b, ERadiance)) return false;
         if (!proposal.v[b]->isConnectable()) return false;
+        if (std::abs(b - cI) > 1) {                                                          // :882-896
+            const bool walkSuccess = mutManifoldWalk(source, proposal, step, b, cI);
+            if (!walkSuccess && lightPath) return false;
+            if (!walkSuccess) {              // "change state of proposal to as if no MW should have been done in the first place"
+                for (int i = b + step; i != cI; i += step) proposal.v[i] = pool.clone(source.v[i]);
+                mu.extra[2] = b + step;
+            }
+        }
         couldConnectBehindB = connect(proposal.vertexOrNull(q - 1), proposal.v[q], proposal.e[q], proposal.v[q + 1], proposal.vertexOrNull(q + 2),
                                       source.v[q]->isConnectable() ? EArea : EDiscrete, source.v[q + 1]->isConnectable() ? EArea : EDiscrete);
         if (lightPath && !couldConnectBehindB) return false;
@@ -1139,6 +1615,42 @@ struct Tracer {
     }
 
     // the body of GBDPTRenderer::process's sample loop, gbdpt_proc.cpp:152-252
+    // Known-answer probe of the manifold (tests/test_gbdpt_oracle.py): the sensor subpath of one sample; for its first chain "connectable
+    // vertex i, ONE non-connectable vertex, connectable vertex i + 2": out = found, the three positions, the end's shading normal, the
+    // generalized geometry term G(i, i + 2), the plain terms of its two edges, then -- pinned at i, end moved by `delta` within the end's tangent
+    // plane -- the walk's iteration count, its success, and the positions the chain vertex and the end arrive at.
+    void manifoldProbe(int px, int py, const Float delta[3], Float out[32])
+    {
+        for (int k = 0; k < 32; ++k) out[k] = 0.0;
+        Config &cfg = c.cfg;
+        if (cfg.maxDepth == -1) cfg.maxDepth = 12;
+        Path emitterSubpath, sensorSubpath;
+        emitterSubpath.v.push_back(pool.allocVertex());
+        emitterSubpath.v[0]->type = EEmitterSupernode; emitterSubpath.v[0]->degenerate = false;
+        sensorSubpath.v.push_back(pool.allocVertex());
+        sensorSubpath.v[0]->type = ESensorSupernode; sensorSubpath.v[0]->degenerate = true;
+        alternatingRandomWalkFromPixel(emitterSubpath, 0, sensorSubpath, cfg.maxDepth + 1, px, py, -1);
+        const Path &p = sensorSubpath;
+        for (int i = 1; i + 2 < p.vertexCount(); ++i) {
+            if (!p.v[i]->isConnectable() || p.v[i + 1]->isConnectable() || !p.v[i + 2]->isConnectable() || !p.v[i + 1]->isSurface() || !p.v[i + 2]->isSurface()) continue;
+            out[0] = 1.0;
+            const V3 pa = p.v[i]->position(), pm = p.v[i + 1]->position(), pb = p.v[i + 2]->position(), nb = p.v[i + 2]->shadingNormal(), na = p.v[i]->shadingNormal(), nm = p.v[i + 1]->shadingNormal();
+            out[1] = pa.x; out[2] = pa.y; out[3] = pa.z; out[4] = pm.x; out[5] = pm.y; out[6] = pm.z; out[7] = pb.x; out[8] = pb.y; out[9] = pb.z;
+            out[10] = nb.x; out[11] = nb.y; out[12] = nb.z;
+            out[13] = manifoldG(p, i, i + 2);
+            out[14] = pathG(p, i, i + 1); out[15] = pathG(p, i + 1, i + 2);
+            out[26] = na.x; out[27] = na.y; out[28] = na.z; out[29] = nm.x; out[30] = nm.y; out[31] = nm.z;
+            if (!manifoldInit(p, i, i + 2)) return;
+            const V3 target = pb + V3(delta[0], delta[1], delta[2]);
+            const bool ok = manifoldMove(target, nb);
+            out[16] = mIterations; out[17] = ok ? 1.0 : 0.0;
+            out[18] = mVerts[1].p.x; out[19] = mVerts[1].p.y; out[20] = mVerts[1].p.z;
+            out[21] = mVerts[2].p.x; out[22] = mVerts[2].p.y; out[23] = mVerts[2].p.z;
+            out[24] = (Float)(p.v[i + 1]->mat.type); out[25] = (Float)i;
+            return;
+        }
+    }
+
     void processSample(int px, int py, SampleResult &wr)
     {
         static const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                // :101

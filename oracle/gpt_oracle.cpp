@@ -849,18 +849,20 @@ inline V3 dielectricRefract(const gpo_material &m, V3 wi, Float cosThetaT)
     return V3(scale * wi.x, scale * wi.y, cosThetaT);
 }
 
-V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure)
+// `importance`: bRec.mode == EImportance (libbidir's light subpaths; G-PT only ever transports radiance); `typeMask`: bRec.typeMask restricted
+// to one of the delta components (PathVertex::propagatePerturbation, vertex.cpp:696-700) -- both default to what G-PT asks for
+V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure, bool importance = false, int typeMask = EDelta | ESmooth)
 {
-    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:227-252 (mode == ERadiance)
+    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:227-252
         Float cosThetaT;
         Float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, m.eta[0]);
         if (measure != MEASURE_DISCRETE) return V3(0.0);
         if (cosTheta(wi) * cosTheta(wo) >= 0) {
-            if (std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return V3(0.0);
+            if (!(typeMask & EDeltaReflection) || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return V3(0.0);
             return rgb(m.reflectance) * F;
         }
-        if (std::abs(dot(dielectricRefract(m, wi, cosThetaT), wo) - 1) > DeltaEpsilon) return V3(0.0);
-        Float factor = cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0];
+        if (!(typeMask & EDeltaTransmission) || std::abs(dot(dielectricRefract(m, wi, cosThetaT), wo) - 1) > DeltaEpsilon) return V3(0.0);
+        Float factor = importance ? 1.0 : (cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0]);
         return rgb(m.k) * factor * factor * (1 - F);
     }
     switch (m.type) {
@@ -868,7 +870,7 @@ V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure)
         if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0);
         return rgb(m.reflectance) * (INV_PI * cosTheta(wo));
     case MAT_CONDUCTOR: // conductor.cpp:223-239
-        if (measure != MEASURE_DISCRETE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0 || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return V3(0.0);
+        if (!(typeMask & EDeltaReflection) || measure != MEASURE_DISCRETE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0 || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return V3(0.0);
         return rgb(m.reflectance) * fresnelConductorExact(cosTheta(wi), rgb(m.eta), rgb(m.k));
     default: { // roughconductor.cpp:257-293
         if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0);
@@ -884,25 +886,26 @@ V3 bsdfEvalOne(const gpo_material &m, V3 wi, V3 wo, int measure)
     }
 }
 
-Float bsdfPdfOne(const gpo_material &m, V3 wi, V3 wo, int measure)
+Float bsdfPdfOne(const gpo_material &m, V3 wi, V3 wo, int measure, int typeMask = EDelta | ESmooth)
 {
     if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:254-275
         Float cosThetaT;
         Float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, m.eta[0]);
         if (measure != MEASURE_DISCRETE) return 0.0;
+        const bool sampleReflection = (typeMask & EDeltaReflection) != 0, sampleTransmission = (typeMask & EDeltaTransmission) != 0;
         if (cosTheta(wi) * cosTheta(wo) >= 0) {
-            if (std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return 0.0;
-            return F;
+            if (!sampleReflection || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return 0.0;
+            return sampleTransmission ? F : 1.0;
         }
-        if (std::abs(dot(dielectricRefract(m, wi, cosThetaT), wo) - 1) > DeltaEpsilon) return 0.0;
-        return 1 - F;
+        if (!sampleTransmission || std::abs(dot(dielectricRefract(m, wi, cosThetaT), wo) - 1) > DeltaEpsilon) return 0.0;
+        return sampleReflection ? 1 - F : 1.0;
     }
     switch (m.type) {
     case MAT_DIFFUSE: // diffuse.cpp:120-127
         if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0;
         return INV_PI * cosTheta(wo);
     case MAT_CONDUCTOR: // conductor.cpp:241-254
-        if (measure != MEASURE_DISCRETE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0 || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return 0.0;
+        if (!(typeMask & EDeltaReflection) || measure != MEASURE_DISCRETE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0 || std::abs(dot(V3(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon) return 0.0;
         return 1.0;
     default: { // roughconductor.cpp:295-319
         if (measure != MEASURE_SOLID_ANGLE || cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0;
@@ -915,13 +918,25 @@ Float bsdfPdfOne(const gpo_material &m, V3 wi, V3 wo, int measure)
 }
 
 // The pdf-returning BSDF::sample overloads: diffuse.cpp:141-151, conductor.cpp:256-273, roughconductor.cpp:369-418
-BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy)
+BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy, bool importance = false, int typeMask = EDelta | ESmooth)
 {
     BSDFSample r;
     r.wo = V3(0.0); r.eta = 1.0; r.sampledType = 0; r.weight = V3(0.0); r.pdf = 0.0; // gpt.cpp:450-454: result.pdf starts at 0
-    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:277-305 (both components requested)
+    if (m.type == MAT_DIELECTRIC) { // dielectric.cpp:277-331
         Float cosThetaT;
         Float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, m.eta[0]);
+        const bool sampleReflection = (typeMask & EDeltaReflection) != 0, sampleTransmission = (typeMask & EDeltaTransmission) != 0;
+        if (!(sampleReflection && sampleTransmission)) {      // one component only (:307-331): it is taken with probability 1 and carries its Fresnel factor
+            if (sampleReflection) {
+                r.sampledType = EDeltaReflection; r.wo = V3(-wi.x, -wi.y, wi.z); r.eta = 1.0; r.pdf = 1.0;
+                r.weight = rgb(m.reflectance) * F;
+            } else if (sampleTransmission) {
+                r.sampledType = EDeltaTransmission; r.wo = dielectricRefract(m, wi, cosThetaT); r.eta = cosThetaT < 0 ? m.eta[0] : 1 / m.eta[0]; r.pdf = 1.0;
+                Float factor = importance ? 1.0 : (cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0]);
+                r.weight = rgb(m.k) * (factor * factor * (1 - F));
+            }
+            return r;
+        }
         if (sx <= F) {
             r.sampledType = EDeltaReflection;
             r.wo = V3(-wi.x, -wi.y, wi.z);
@@ -933,7 +948,7 @@ BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy)
             r.wo = dielectricRefract(m, wi, cosThetaT);
             r.eta = cosThetaT < 0 ? m.eta[0] : 1 / m.eta[0];
             r.pdf = 1 - F;
-            Float factor = cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0];
+            Float factor = importance ? 1.0 : (cosThetaT < 0 ? 1 / m.eta[0] : m.eta[0]);
             r.weight = rgb(m.k) * (factor * factor);
         }
         return r;
@@ -947,7 +962,7 @@ BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy)
         r.weight = rgb(m.reflectance);
         return r;
     case MAT_CONDUCTOR:
-        if (cosTheta(wi) <= 0) return r;
+        if (cosTheta(wi) <= 0 || !(typeMask & EDeltaReflection)) return r;
         r.sampledType = EDeltaReflection;
         r.wo = V3(-wi.x, -wi.y, wi.z);
         r.pdf = 1;
@@ -976,23 +991,23 @@ BSDFSample bsdfSampleOne(const gpo_material &m, V3 wi, Float sx, Float sy)
 }
 
 // TwoSided (src/bsdfs/twosided.cpp:100-168) around the one-sided models, nestedBRDF[1] == nestedBRDF[0]
-V3 bsdfEval(const gpo_material &m, V3 wi, V3 wo, int measure)
+V3 bsdfEval(const gpo_material &m, V3 wi, V3 wo, int measure, bool importance = false, int typeMask = EDelta | ESmooth)
 {
-    if (!m.twoSided || cosTheta(wi) > 0) return bsdfEvalOne(m, wi, wo, measure);
+    if (!m.twoSided || cosTheta(wi) > 0) return bsdfEvalOne(m, wi, wo, measure, importance, typeMask);
     wi.z *= -1; wo.z *= -1;
-    return bsdfEvalOne(m, wi, wo, measure);
+    return bsdfEvalOne(m, wi, wo, measure, importance, typeMask);
 }
-Float bsdfPdf(const gpo_material &m, V3 wi, V3 wo, int measure)
+Float bsdfPdf(const gpo_material &m, V3 wi, V3 wo, int measure, int typeMask = EDelta | ESmooth)
 {
-    if (!m.twoSided || wi.z > 0) return bsdfPdfOne(m, wi, wo, measure);
+    if (!m.twoSided || wi.z > 0) return bsdfPdfOne(m, wi, wo, measure, typeMask);
     wi.z *= -1; wo.z *= -1;
-    return bsdfPdfOne(m, wi, wo, measure);
+    return bsdfPdfOne(m, wi, wo, measure, typeMask);
 }
-BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy)
+BSDFSample bsdfSample(const gpo_material &m, V3 wi, Float sx, Float sy, bool importance = false, int typeMask = EDelta | ESmooth)
 {
     bool flipped = false;
     if (m.twoSided && cosTheta(wi) < 0) { wi.z *= -1; flipped = true; }
-    BSDFSample r = bsdfSampleOne(m, wi, sx, sy);
+    BSDFSample r = bsdfSampleOne(m, wi, sx, sy, importance, typeMask);
     if (flipped && !isZero(r.weight) && r.pdf != 0) r.wo.z *= -1;
     return r;
 }
@@ -2411,7 +2426,7 @@ static gb::Config gbConfig(const gpo_gbdpt_config *cfg)
     return c;
 }
 // one sample of GBDPTRenderer::process: out = primal(3), gradient[4](3 each), sample position(2); light splats as (x, y, buffer, r, g, b);
-// counters = closest-hit rays, shadow rays, unsupported events
+// counters = closest-hit rays, shadow rays, unsupported events (gpo_gbdpt_render: + invalid puts, manifold walks entered / converged, propagated chain vertices)
 GPO_API void gpo_gbdpt_sample(gpo_scene *h, const gpo_gbdpt_config *cfg, int px, int py, int sampleIndex, double *out17, int maxLight, double *lightOut, int *nLight,
                               unsigned long long *counters)
 {
@@ -2432,6 +2447,16 @@ GPO_API void gpo_gbdpt_sample(gpo_scene *h, const gpo_gbdpt_config *cfg, int px,
         o[0] = r.light[i].x; o[1] = r.light[i].y; o[2] = r.light[i].buffer; o[3] = r.light[i].value.x; o[4] = r.light[i].value.y; o[5] = r.light[i].value.z;
     }
     counters[0] = h->sc.raysTraced - r0; counters[1] = h->sc.shadowRaysTraced - s0; counters[2] = ctx.unsupported;
+}
+// known-answer probe of the specular manifold on the sensor subpath of one sample (gb::Tracer::manifoldProbe)
+GPO_API void gpo_manifold_probe(gpo_scene *h, const gpo_gbdpt_config *cfg, int px, int py, int sampleIndex, const double *delta3, double *out32)
+{
+    gb::Ctx ctx{h->sc, gbConfig(cfg)};
+    gb::cameraSetup(ctx);
+    Rng rng(cfg->seed, (uint64_t)py * h->sc.cam.width + px, (uint64_t)sampleIndex);
+    gb::Pool pool;
+    gb::Tracer tr(ctx, rng, pool);
+    tr.manifoldProbe(px, py, delta3, out32);
 }
 // GBDPTRenderer::process over the pixels of [x0,x1) x [y0,y1): the five camera blocks [5][H][W][4] and the five light images [5][H][W][3]
 GPO_API void gpo_gbdpt_render(gpo_scene *h, const gpo_gbdpt_config *cfg, int x0, int y0, int x1, int y1, double *block, double *light, unsigned long long *counters)
@@ -2456,4 +2481,5 @@ GPO_API void gpo_gbdpt_render(gpo_scene *h, const gpo_gbdpt_config *cfg, int x0,
         std::memcpy(light + (size_t)b * W * H * 3, film.light[b].data(), sizeof(double) * (size_t)W * H * 3);
     }
     counters[0] = h->sc.raysTraced - r0; counters[1] = h->sc.shadowRaysTraced - s0; counters[2] = ctx.unsupported; counters[3] = film.invalidPuts;
+    counters[4] = ctx.walks; counters[5] = ctx.walksOk; counters[6] = ctx.propagated;
 }

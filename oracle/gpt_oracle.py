@@ -292,14 +292,29 @@ class Scene:
         return dict(primal=out[0:3], gradients=out[3:15].reshape(4, 3), position=out[15:17], light=light[:n.value].copy(),
                     raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]), unsupported=int(cnt[2]))
 
+    def manifold_probe(self, cfg, px, py, sample, delta=(0.0, 0.0, 0.0)):
+        """Known-answer probe of the specular manifold (oracle/gbdpt_oracle.hpp manifoldProbe) on the sensor subpath of one sample: None if it
+        has no chain "connectable, one specular vertex, connectable"; else dict(a, m, b = positions, na, nm, nb = shading normals, G = the
+        generalized geometry term across the chain, Gam, Gmb = the plain terms of its edges, iterations / converged / m_moved / b_moved of a
+        manifold walk that moves b by `delta`, material type of the chain vertex, index of a)."""
+        out = np.zeros(32, np.float64)
+        d = np.asarray(delta, np.float64)
+        lib().gpo_manifold_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib().gpo_manifold_probe(self._h, C.byref(cfg), px, py, sample, _p(d), _p(out))
+        if out[0] == 0:
+            return None
+        return dict(a=out[1:4].copy(), m=out[4:7].copy(), b=out[7:10].copy(), nb=out[10:13].copy(), G=out[13], Gam=out[14], Gmb=out[15], iterations=int(out[16]),
+                    converged=bool(out[17]), m_moved=out[18:21].copy(), b_moved=out[21:24].copy(), material=int(out[24]), index=int(out[25]), na=out[26:29].copy(), nm=out[29:32].copy())
+
     def gbdpt_render(self, cfg, rect=None):
         """-> (block[5,H,W,4] camera blocks (rgb, weight), light[5,H,W,3] light images, dict of counters)."""
         x0, y0, x1, y1 = rect if rect else (0, 0, self.W, self.H)
         block = np.zeros((5, self.H, self.W, 4), np.float64)
         light = np.zeros((5, self.H, self.W, 3), np.float64)
-        cnt = np.zeros(4, np.uint64)
+        cnt = np.zeros(7, np.uint64)
         lib().gpo_gbdpt_render(self._h, C.byref(cfg), x0, y0, x1, y1, _p(block), _p(light), _p(cnt))
-        return block, light, dict(raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]), unsupported=int(cnt[2]), invalidPuts=int(cnt[3]))
+        return block, light, dict(raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]), unsupported=int(cnt[2]), invalidPuts=int(cnt[3]),
+                                  manifoldWalks=int(cnt[4]), manifoldWalksConverged=int(cnt[5]), propagatedVertices=int(cnt[6]))
 
     def close(self):
         if self._h:

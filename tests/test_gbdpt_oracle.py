@@ -1,6 +1,6 @@
 """CPU tests of oracle/gbdpt_oracle.hpp, the restatement of the reference's G-BDPT sampler (GBDPTRenderer::process / evaluate over libbidir,
-src/integrators/gbdpt/gbdpt_proc.cpp:86-662, src/libbidir/{path,vertex,edge,mut_manifold,manifold}.cpp) for paths whose surface vertices are
-all connectable.  PARITY UNPINNED (the reference cannot be built here): what holds the restatement is
+src/integrators/gbdpt/gbdpt_proc.cpp:86-662, src/libbidir/{path,vertex,edge,mut_manifold,manifold}.cpp), including -- round 4 -- paths with
+specular chains (propagatePerturbation, the manifold walk, generalized geometry terms).  PARITY UNPINNED (the reference cannot be built here): what holds the restatement is
   * closed forms: a directly seen emitter (the only strategy of maxDepth 1 without the light image) returns exactly its radiance; the
     "T0" gradient of an unshiftable path is -2 w f (gbdpt_proc.cpp:494-499,517-521);
   * the estimator's expectation: the primal image converges to -throughput + -direct of the G-PT oracle (an independent restatement of
@@ -116,10 +116,71 @@ def test_samples_are_reproducible_and_depend_on_the_seed():
     assert a["unsupported"] == 0 and a["raysTraced"] > 0
 
 
-def test_scope_counter_flags_specular_chains():
-    """Stage A/B carries connectable vertices only: a scene with a perfect mirror makes samples meet non-connectable vertices, which the
-    oracle COUNTS instead of guessing (the product refuses such scenes for G-BDPT)."""
-    sc = scenes.cornell_box(16, 12, "glossy")                          # mirror back wall
+@pytest.mark.parametrize("variant", ["glass", "glossy", "nearspecular"])
+def test_specular_chains_estimator_expectation(variant):
+    """Stage C (round 4): offset paths through SPECULAR CHAINS -- ManifoldPerturbation::propagatePerturbation on the camera side, the manifold
+    walk of SpecularManifold::{init, computeTangents, project, move, update} between b and c, the generalized geometry terms and determinants
+    of SpecularManifold::{G, multiG, det} in the Jacobians and MIS weights (mut_manifold.cpp:989-1227, manifold.cpp:59-951, path.cpp:380-454).
+    Scenes: a solid glass block + an aluminium mirror block ("glass": refraction chains, a non-symmetric BSDF), a mirror back wall ("glossy"),
+    a rough conductor BELOW shiftThreshold ("nearspecular": glossy vertices inside a chain, perturbed with their half vector kept).
+    What holds it: the primal image still converges to the G-PT oracle's path tracer and the merged gradients to its finite differences --
+    a wrong Jacobian, determinant or generalized G biases exactly these -- and the walks are really taken (thousands per frame, most converge)."""
+    W, H, spp, md = 20, 15, 256, 5
+    sc = scenes.cornell_box(W, H, variant)
     O = go.Scene(sc)
-    _b, _l, c = O.gbdpt_render(go.gbdpt_config(maxDepth=6, spp=4))
-    assert c["unsupported"] > 0
+    acc, _ = O.render(go.config(maxDepth=md, spp=4 * spp))
+    dev = go.develop(acc)
+    pt = dev[1] + dev[4]
+    fdx, fdy = pt[:, 1:] - pt[:, :-1], pt[1:] - pt[:-1]
+    scale = np.abs(fdx).mean() + np.abs(fdy).mean()
+    for li in (True, False):
+        b, l, c = O.gbdpt_render(go.gbdpt_config(maxDepth=md, spp=spp, lightImage=li))
+        assert c["unsupported"] == 0 and c["invalidPuts"] == 0
+        assert c["manifoldWalks"] > 1000 and c["manifoldWalksConverged"] > 0.5 * c["manifoldWalks"] and c["propagatedVertices"] > 100, c
+        img = go.gbdpt_develop(b, l, spp)
+        assert abs(img[0].mean() - pt.mean()) <= 0.03 * pt.mean(), (variant, li, img[0].mean(), pt.mean())
+        h, w = pt.shape[:2]
+        for ys in (slice(0, h // 2), slice(h // 2, h)):
+            for xs in (slice(0, w // 2), slice(w // 2, w)):
+                assert abs(img[0][ys, xs].mean() - pt[ys, xs].mean()) <= 0.08 * pt[ys, xs].mean(), (variant, li)
+        gx, gy = merged_gradients(img)
+        ex, ey = np.abs(gx[:, :-1] - fdx).mean(), np.abs(gy[:-1] - fdy).mean()
+        assert ex + ey <= 0.3 * scale, (variant, li, ex, ey, scale)
+        assert abs((gx[:, :-1] - fdx).mean()) <= 0.03 * scale and abs((gy[:-1] - fdy).mean()) <= 0.03 * scale, (variant, li)
+    O.close()
+
+
+def test_planar_mirror_known_answers_of_the_manifold():
+    """Closed forms for a chain "diffuse a -- planar mirror m -- diffuse b" (the aluminium back wall of the "glossy" box):
+      * SpecularManifold::G(a, b) (computeTangents + the tangent map of vertex 1, manifold.cpp:900-951) is the PLAIN geometry term between a
+        and the mirror image b' of b: |cos_a| |cos_b'| / |a - b'|^2 (the mirror patch a sees subtends the solid angle of the image of b's patch);
+      * SpecularManifold::move: the constraint is linear for a planar mirror, so the Newton walk lands on the exact chain vertex -- the
+        intersection of the segment a -> b' with the mirror plane -- at its FIRST step (the second iteration only finds it has arrived)."""
+    sc = scenes.cornell_box(32, 24, "glossy")
+    O = go.Scene(sc)
+    cfg = go.gbdpt_config(maxDepth=6, spp=4)
+    seen = 0
+    for py in range(0, 24, 2):
+        for px in range(0, 32, 2):
+            r = O.manifold_probe(cfg, px, py, 0)
+            if r is None or r["material"] != 1:          # (conductor)
+                continue
+            nm = r["nm"]
+            b_img = r["b"] - 2 * np.dot(r["b"] - r["m"], nm) * nm
+            d = b_img - r["a"]; dist = np.linalg.norm(d); d /= dist
+            nb_img = r["nb"] - 2 * np.dot(r["nb"], nm) * nm
+            closed = abs(np.dot(d, r["na"])) * abs(np.dot(d, nb_img)) / dist ** 2
+            assert np.isclose(r["G"], closed, rtol=1e-7), (px, py, r["G"], closed)
+            t = np.cross(r["nb"], [0.3, 0.5, 0.8]); t /= np.linalg.norm(t)
+            delta = 3.0 * t                                # b moves 3 units (of a 550-unit box) within its tangent plane
+            w = O.manifold_probe(cfg, px, py, 0, delta)
+            bt = r["b"] + delta
+            bimg = bt - 2 * np.dot(bt - r["m"], nm) * nm
+            dd = bimg - r["a"]
+            mexp = r["a"] + (np.dot(r["m"] - r["a"], nm) / np.dot(dd, nm)) * dd
+            if 0 < mexp[0] < 550 and 0 < mexp[1] < 540:  # (the exact vertex is still on the wall)
+                assert w["converged"] and w["iterations"] <= 2, (px, py, w)
+                assert np.abs(w["m_moved"] - mexp).max() <= 1e-4 and np.abs(w["b_moved"] - bt).max() <= 1e-4, (px, py, w["m_moved"], mexp)
+                seen += 1
+    assert seen >= 20
+    O.close()
