@@ -3,7 +3,7 @@
 // GBDPTWorkResult (gbdpt_wr.{h,cpp}) merged as GBDPTProcess::processResult / develop do (gbdpt_proc.cpp:694-763, multifilm.cpp:317-362).
 // No CPU fallback: every value comes from the kernels below.
 #include "../../include/gdpt_tracer.h"
-#include "gbdpt_kernels.hip.h"
+#include "gbdpt_general.hip.h"
 #include "gpt_scene.hip.h"
 
 #include <algorithm>
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_paths(SceneD S, BdCam cam, BdCon
 // One lane per sample: the connected base path and its four offset paths, the prefix products (walk_shift), the sample's connections appended to
 // the three item lists.
 __global__ __launch_bounds__(TBLK, 2) void k_bd_shift(SceneD S, BdCam cam, BdConfig cfg, unsigned count, Sample *__restrict__ recs,
-                                                   unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats)
+                                                   unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats,
+                                                   unsigned *__restrict__ genList, unsigned *__restrict__ genCount)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned lid = blockIdx.x * TBLK + threadIdx.x;
@@ -149,9 +150,14 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_shift(SceneD S, BdCam cam, BdCon
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
     if (lid < count) {
         Sample &sm = recs[lid];
-        if (sm.nY >= 2) walk_shift(c, sm);
+        // a sample that met a specular vertex (conductor, dielectric, a rough conductor below shiftThreshold) goes to the general form
+        // (gbdpt_general.hip.h, k_bd_general): no offsets, no connections here
+        const bool general = sm.nY >= 2 && sample_needs_general(c, sm);
+        if (general) genList[atomicAdd(genCount, 1u)] = lid;
+        if (sm.nY >= 2 && !general) walk_shift(c, sm);
         for (int k = 0; k < 15; k++) acc[(size_t)lid * 15 + k] = 0.0;
         unsigned n = 0;
+        if (!general)
         for (int s = sm.nY - 1; s >= 0; --s) { int minT, maxT; pair_range(cfg, sm.nX, s, minT, maxT); if (maxT >= minT) n += (unsigned)(maxT - minT + 1); }
         if (n) {
             // three item lists, by the shape of the work: light-tracing connections (t == 1: a base connection + four offset paths, each with its
@@ -229,6 +235,37 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
 }
 
+// The general form of a sample (specular chains; gbdpt_general.hip.h): one lane per listed sample, from the connected base path to its last
+// connection, in a workspace of its own.  Persistent lanes (a workspace is ~56 KB: the launch has as many lanes as there are workspaces).
+__global__ __launch_bounds__(64, 1) void k_bd_general(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, const unsigned *__restrict__ genCount,
+                                                     GWork *__restrict__ work, Float *__restrict__ acc, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];      // (the traversal stack is laid out [level][TBLK]: a 64-lane block uses the first 64 columns of every level)
+    const unsigned lane = blockIdx.x * 64 + threadIdx.x, lanes = gridDim.x * 64;
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned n = __hip_atomic_load(genCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned overflow = 0, done = 0;
+    GWork &W = work[lane];
+    for (unsigned i = lane; i < n; i += lanes) {
+        const unsigned lid = genList[i];
+        GTr g(c, W);
+        g.loadSubpaths(recs[lid]);
+        SampleOut out;
+        g.processSample(out);
+        overflow += W.overflow; done++;
+        Float *a = acc + (size_t)lid * 15;
+        a[0] = out.primal.x; a[1] = out.primal.y; a[2] = out.primal.z;
+        for (int k = 0; k < 4; k++) { a[3 + 3 * k] = out.gradient[k].x; a[4 + 3 * k] = out.gradient[k].y; a[5 + 3 * k] = out.gradient[k].z; }
+        const int Wd = S.cam.width, H = S.cam.height;
+        const size_t plane3 = (size_t)Wd * H * 3;
+        for (int k = 0; k < out.nLight; k++) film_put(light + out.light[k].buffer * plane3, 3, Wd, H, out.light[k].x, out.light[k].y, out.light[k].value, false, stats + 3);
+    }
+    atomicAdd(stats + 0, (unsigned long long)c.nClosest); atomicAdd(stats + 1, (unsigned long long)c.nShadow);
+    if (done) atomicAdd(stats + 4, (unsigned long long)done);
+    if (overflow) atomicAdd(stats + 5, (unsigned long long)overflow);
+}
+
 __global__ __launch_bounds__(TBLK) void k_bd_put(const Sample *__restrict__ recs, const Float *__restrict__ acc, unsigned count, int W, int H, Float *__restrict__ block, unsigned long long *__restrict__ stats)
 {
     const unsigned lid = blockIdx.x * TBLK + threadIdx.x;
@@ -241,7 +278,7 @@ __global__ __launch_bounds__(TBLK) void k_bd_put(const Sample *__restrict__ recs
 
 // probe: one sample -> primal(3), gradients(12), position(2), light splats (x, y, buffer, r, g, b), counters
 __global__ __launch_bounds__(TBLK) void k_gbdpt_sample(SceneD S, BdCam cam, BdConfig cfg, int px, int py, int sample, Float *__restrict__ out17, int maxLight, Float *__restrict__ lightOut,
-                                                       int *__restrict__ nLight, unsigned long long *__restrict__ counters)
+                                                       int *__restrict__ nLight, unsigned long long *__restrict__ counters, GWork *__restrict__ work)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -250,7 +287,19 @@ __global__ __launch_bounds__(TBLK) void k_gbdpt_sample(SceneD S, BdCam cam, BdCo
     c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
     Sample sm;
     SampleOut out;
-    process_sample(c, sm, px, py, out);
+    if (work) {                                     // (the host passes a workspace: the sample may need the general form)
+        if (walk_paths(c, sm, px, py) && sample_needs_general(c, sm)) {
+            GTr g(c, *work);
+            g.loadSubpaths(sm);
+            g.processSample(out);
+            counters[2] = 1; counters[3] = work->overflow;
+        } else {
+            c.nClosest = c.nShadow = 0;
+            c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
+            process_sample(c, sm, px, py, out);
+            counters[2] = 0; counters[3] = 0;
+        }
+    } else process_sample(c, sm, px, py, out);
     out17[0] = out.primal.x; out17[1] = out.primal.y; out17[2] = out.primal.z;
     for (int k = 0; k < 4; k++) { out17[3 + 3 * k] = out.gradient[k].x; out17[4 + 3 * k] = out.gradient[k].y; out17[5 + 3 * k] = out.gradient[k].z; }
     out17[15] = out.posX; out17[16] = out.posY;
@@ -294,6 +343,11 @@ struct gdpt_gbdpt_film {
     unsigned *items = nullptr, *itemCount = nullptr;
     Float *acc = nullptr;
     unsigned capacity = 0;
+    // the general form (specular chains): the samples that need it, and one workspace per persistent lane of k_bd_general
+    unsigned *genList = nullptr, *genCount = nullptr;
+    GWork *work = nullptr;
+    unsigned workLanes = 0;
+    double sceneRadius = 0.0;
 };
 
 namespace {
@@ -308,11 +362,7 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
     if (s->d.cam.thinlens) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: the thinlens sensor is not carried (perspective only)");
     if (s->specialEmitters) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment and point emitters are not carried (area emitters only)");
-    for (size_t i = 0; i < s->hostMats.size(); i++) {
-        const MaterialD &m = s->hostMats[i];
-        if (m.type == 1 || m.type == 3) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: material %d is a Dirac BSDF (conductor / dielectric): specular chains (manifold walks) are not carried", (int)i);
-        if (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: material %d is rougher-than-mirror but below shiftThreshold: treated as specular by the reference, not carried", (int)i);
-    }
+    // (round 4: Dirac BSDFs and rough conductors below shiftThreshold are carried -- samples that meet one run the general form, gbdpt_general.hip.h)
     return GDPT_OK;
 }
 
@@ -333,9 +383,33 @@ BdCam make_cam(const gdpt_scene *s)
     return cam;
 }
 
-BdConfig make_cfg(const gdpt_gbdpt_config *cfg)
+// m_scene->getBSphere().radius: the bounding sphere of the kd-tree's bounds, which GenericKDTree::buildInternal enlarges by MTS_KD_AABB_EPSILON
+// (gkdtree.h:50,1213-1219; the second line sees the already-moved minimum, as there); the vertices are the fp64 ones of the shading table
+int scene_radius(const gdpt_scene *s, double *radius)
+{
+    std::vector<TriShade> sh((size_t)s->d.numTris);
+    BHIPCHK(hipMemcpy(sh.data(), s->d.shade, sizeof(TriShade) * sh.size(), hipMemcpyDeviceToHost));
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (const TriShade &t : sh)
+        for (const d3 &p : {t.p0, t.p1, t.p2}) {
+            mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
+            mx[0] = std::max(mx[0], p.x); mx[1] = std::max(mx[1], p.y); mx[2] = std::max(mx[2], p.z);
+        }
+    const double eps = (double)1e-3f;
+    for (int a = 0; a < 3; a++) mn[a] = mn[a] - ((mx[a] - mn[a]) * eps + eps);
+    for (int a = 0; a < 3; a++) mx[a] = mx[a] + ((mx[a] - mn[a]) * eps + eps);
+    double r2 = 0.0;
+    double d[3];
+    for (int a = 0; a < 3; a++) { const double ctr = (mn[a] + mx[a]) * 0.5; d[a] = mx[a] - ctr; }
+    r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    *radius = std::sqrt(r2);
+    return GDPT_OK;
+}
+
+BdConfig make_cfg(const gdpt_gbdpt_config *cfg, double sceneRadius)
 {
     BdConfig c;
+    c.sceneRadius = sceneRadius;
     c.maxDepth = cfg->maxDepth == -1 ? BD_MAX_DEPTH : cfg->maxDepth;                        // gbdpt_proc.cpp:103-106
     c.rrDepth = cfg->rrDepth; c.lightImage = cfg->lightImage ? 1 : 0; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
@@ -356,7 +430,9 @@ int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
     const size_t npix = (size_t)f->W * f->H;
     BHIPCHK(hipMalloc((void **)&f->block, sizeof(Float) * 5 * npix * 4));
     BHIPCHK(hipMalloc((void **)&f->light, sizeof(Float) * 5 * npix * 3));
-    BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 4));
+    BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 8));           // [0..3] the public counters; [4] samples run in the general form, [5] workspace overflows
+    BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned)));
+    if (int rc = scene_radius(s, &f->sceneRadius)) { delete f; return rc; }
     BHIPCHK(hipStreamCreate(&f->stream));
     BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1));
     *out = f;
@@ -370,6 +446,7 @@ void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
     if (f->stream) hipStreamSynchronize(f->stream);
     hipFree(f->block); hipFree(f->light); hipFree(f->stats);
     hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
+    hipFree(f->genList); hipFree(f->genCount); hipFree(f->work);
     if (f->e0) hipEventDestroy(f->e0);
     if (f->e1) hipEventDestroy(f->e1);
     if (f->stream) hipStreamDestroy(f->stream);
@@ -383,7 +460,7 @@ int gdpt_gbdpt_film_clear(gdpt_gbdpt_film *f)
     const size_t npix = (size_t)f->W * f->H;
     BHIPCHK(hipMemsetAsync(f->block, 0, sizeof(Float) * 5 * npix * 4, f->stream));
     BHIPCHK(hipMemsetAsync(f->light, 0, sizeof(Float) * 5 * npix * 3, f->stream));
-    BHIPCHK(hipMemsetAsync(f->stats, 0, sizeof(unsigned long long) * 4, f->stream));
+    BHIPCHK(hipMemsetAsync(f->stats, 0, sizeof(unsigned long long) * 8, f->stream));
     f->renderMs = 0.0f; f->timed = false;
     return GDPT_OK;
 }
@@ -395,14 +472,23 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (int rc = check_scope(s, cfg)) return rc;
     BHIPCHK(hipSetDevice(s->device));
     const BdCam cam = make_cam(s);
-    BdConfig c = make_cfg(cfg);
+    BdConfig c = make_cfg(cfg, f->sceneRadius);
     if (f->timed) { float ms = 0; BHIPCHK(hipEventSynchronize(f->e1)); BHIPCHK(hipEventElapsedTime(&ms, f->e0, f->e1)); f->renderMs += ms; f->timed = false; }
     BHIPCHK(hipEventRecord(f->e0, f->stream));
     const long long pixels = (long long)(x1 - x0) * (y1 - y0), total = pixels * c.spp;
     // The chunk: at most BD_CHUNK samples, at most what fits 40 % of the memory the device has free right now (+ what this film already holds) --
     // several films on one GPU (strips wrapped onto a device, a G-PT film resident beside this one) or a partitioned / smaller part each get a
     // share instead of failing -- halved again while the allocation itself fails.  GDPT_BD_CHUNK forces a size (tests of the chunk loop).
-    const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15;      // record + three item lists with two survivor lists each + sums
+    const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15 + sizeof(unsigned);   // record + three item lists with two survivor lists each + sums + general-list entry
+    // the general form's workspaces (only scenes that can produce a specular vertex need them): one per persistent lane, at most 1 GB
+    bool specularScene = false;
+    for (const MaterialD &m : s->hostMats) if (m.type == 1 || m.type == 3 || (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold)) specularScene = true;
+    if (specularScene && !f->work) {
+        unsigned lanes = (unsigned)std::min<size_t>((size_t)s->numCUs * 64, ((size_t)1 << 30) / sizeof(GWork));
+        lanes = std::max(64u, lanes / 64 * 64);
+        if (hipMalloc((void **)&f->work, sizeof(GWork) * (size_t)lanes) != hipSuccess) { (void)hipGetLastError(); return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT general-form workspaces: %.1f MB)", sizeof(GWork) * (double)lanes / 1e6); }
+        f->workLanes = lanes;
+    }
     unsigned chunk = (unsigned)std::min<long long>(total, BD_CHUNK);
     if (const char *e = getenv("GDPT_BD_CHUNK")) chunk = (unsigned)std::max<long long>(1, std::min<long long>(chunk, atoll(e)));
     else {
@@ -415,14 +501,15 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (chunk > f->capacity || (getenv("GDPT_BD_CHUNK") && chunk != f->capacity)) {
         BHIPCHK(hipStreamSynchronize(f->stream));
         for (;;) {
-            hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
-            f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->capacity = 0;
-            if (hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) == hipSuccess && hipMalloc((void **)&f->items, sizeof(unsigned) * 9 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) == hipSuccess &&
+            hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc); hipFree(f->genList);
+            f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->genList = nullptr; f->capacity = 0;
+            if (hipMalloc((void **)&f->genList, sizeof(unsigned) * (size_t)chunk) == hipSuccess &&
+                hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) == hipSuccess && hipMalloc((void **)&f->items, sizeof(unsigned) * 9 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) == hipSuccess &&
                 hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 9) == hipSuccess && hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) == hipSuccess) break;
             (void)hipGetLastError();
             if (chunk <= 1024) {
-                hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
-                f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr;
+                hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc); hipFree(f->genList);
+                f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->genList = nullptr;
                 return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f MB)", chunk, (double)perSample * chunk / 1e6);
             }
             chunk /= 2;
@@ -433,9 +520,11 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         const unsigned count = (unsigned)std::min<long long>(chunk, total - first);
         const size_t itemStride = (size_t)f->capacity * BD_ITEMS_PER_SAMPLE;
         BHIPCHK(hipMemsetAsync(f->itemCount, 0, sizeof(unsigned) * 9, f->stream));
+        BHIPCHK(hipMemsetAsync(f->genCount, 0, sizeof(unsigned), f->stream));
         const unsigned pgrid = std::min<unsigned>((count + TBLK - 1) / TBLK, (unsigned)s->numCUs * 2u);      // persistent: the grid that is resident at 2 waves per SIMD
         hipLaunchKernelGGL(k_bd_paths, dim3(pgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->stats);
-        hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats);
+        hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats, f->genList, f->genCount);
+        if (f->work) hipLaunchKernelGGL(k_bd_general, dim3(f->workLanes / 64), dim3(64), 0, f->stream, s->d, cam, c, f->recs, f->genList, f->genCount, f->work, f->acc, f->light, f->stats);
         BHIPCHK(hipGetLastError());
         unsigned nItems[3] = {0, 0, 0};
         BHIPCHK(hipMemcpyAsync(nItems, f->itemCount, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, f->stream));
@@ -547,30 +636,53 @@ int gdpt_gbdpt_film_import_device(gdpt_gbdpt_film *f, const double *blockDevice,
 
 void *gdpt_gbdpt_film_stream(gdpt_gbdpt_film *f) { return f ? (void *)f->stream : nullptr; }
 
-int gdpt_gbdpt_evaluate_sample(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17], int maxLight, double *light6, int *nLight,
-                               unsigned long long counters[2])
+int gdpt_gbdpt_evaluate_sample2(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17], int maxLight, double *light6, int *nLight,
+                                unsigned long long counters[4])
 {
     if (!s || !cfg || !out17 || !nLight || !counters || maxLight < 0 || (maxLight > 0 && !light6)) return bfail(GDPT_ERR_INVALID, "gbdpt_evaluate_sample: bad argument");
     if (px < 0 || py < 0 || px >= s->d.cam.width || py >= s->d.cam.height) return bfail(GDPT_ERR_INVALID, "gbdpt_evaluate_sample: pixel outside the film");
     if (int rc = check_scope(s, cfg)) return rc;
     BHIPCHK(hipSetDevice(s->device));
     const BdCam cam = make_cam(s);
-    const BdConfig c = make_cfg(cfg);
+    double radius = 0.0;
+    if (int rc = scene_radius(s, &radius)) return rc;
+    const BdConfig c = make_cfg(cfg, radius);
     double *d = nullptr, *dl = nullptr;
     int *dn = nullptr;
     unsigned long long *dc = nullptr;
+    GWork *work = nullptr;
     const int ml = std::max(maxLight, 1);
     BHIPCHK(hipMalloc((void **)&d, sizeof(double) * 17));
     BHIPCHK(hipMalloc((void **)&dl, sizeof(double) * 6 * ml));
     BHIPCHK(hipMalloc((void **)&dn, sizeof(int)));
-    BHIPCHK(hipMalloc((void **)&dc, sizeof(unsigned long long) * 2));
-    hipLaunchKernelGGL(k_gbdpt_sample, dim3(1), dim3(TBLK), 0, 0, s->d, cam, c, px, py, sample, d, maxLight, dl, dn, dc);
+    BHIPCHK(hipMalloc((void **)&dc, sizeof(unsigned long long) * 4));
+    BHIPCHK(hipMalloc((void **)&work, sizeof(GWork)));
+    BHIPCHK(hipMemset(dc, 0, sizeof(unsigned long long) * 4));
+    hipLaunchKernelGGL(k_gbdpt_sample, dim3(1), dim3(TBLK), 0, 0, s->d, cam, c, px, py, sample, d, maxLight, dl, dn, dc, work);
     BHIPCHK(hipGetLastError());
     BHIPCHK(hipMemcpy(out17, d, sizeof(double) * 17, hipMemcpyDeviceToHost));
     BHIPCHK(hipMemcpy(nLight, dn, sizeof(int), hipMemcpyDeviceToHost));
     if (maxLight > 0) BHIPCHK(hipMemcpy(light6, dl, sizeof(double) * 6 * std::min(maxLight, std::max(*nLight, 0)), hipMemcpyDeviceToHost));
-    BHIPCHK(hipMemcpy(counters, dc, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost));
-    hipFree(d); hipFree(dl); hipFree(dn); hipFree(dc);
+    BHIPCHK(hipMemcpy(counters, dc, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+    hipFree(d); hipFree(dl); hipFree(dn); hipFree(dc); hipFree(work);
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_evaluate_sample(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17], int maxLight, double *light6, int *nLight,
+                               unsigned long long counters[2])
+{
+    unsigned long long c4[4] = {0, 0, 0, 0};
+    if (!counters) return bfail(GDPT_ERR_INVALID, "gbdpt_evaluate_sample: bad argument");
+    const int rc = gdpt_gbdpt_evaluate_sample2(s, cfg, px, py, sample, out17, maxLight, light6, nLight, c4);
+    counters[0] = c4[0]; counters[1] = c4[1];
+    return rc;
+}
+
+int gdpt_gbdpt_film_chain_stats(gdpt_gbdpt_film *f, unsigned long long stats[2])
+{
+    if (!f || !stats) return bfail(GDPT_ERR_INVALID, "gbdpt_film_chain_stats: null argument");
+    if (int rc = gdpt_gbdpt_film_sync(f)) return rc;
+    BHIPCHK(hipMemcpy(stats, f->stats + 4, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost));
     return GDPT_OK;
 }
 

@@ -1,0 +1,1112 @@
+// gbdpt_general.hip.h -- the GENERAL form of the G-BDPT sample (round 4: stage C of SURVEY.md 8f-1): paths with SPECULAR CHAINS.
+//
+// gbdpt_kernels.hip.h carries the samples whose surface vertices are all connectable (Path::isConnectable_GBDPT): an offset path is three
+// records, every generalized geometry term is 1, the MIS sums are recurrences.  A sample that meets a perfectly specular BSDF (conductor,
+// dielectric) or a rough conductor below shiftThreshold needs what that form leaves out:
+//   * ManifoldPerturbation::propagatePerturbation (mut_manifold.cpp:989-1149): the chain between the sensor and the first connectable vertex b
+//     is re-created vertex by vertex (PathVertex::propagatePerturbation / perturbDirection, vertex.cpp:488-790);
+//   * ManifoldPerturbation::manifoldWalk (:1151-1227) over SpecularManifold::{init, computeTangents, project, move, update}
+//     (manifold.cpp:59-757): the chain between b and the next connectable vertex c follows b by a Newton walk on the specular manifold;
+//   * SpecularManifold::{G, multiG, det} (manifold.cpp:759-951) in Path::{G, halfJacobian_GBDPT, calcSpecularPDFChange} (path.cpp:380-454), and the
+//     conversion of area densities next to non-connectable vertices in the MIS weights (path.cpp:143-167,309-349).
+// Offset paths then replace a variable number of vertices, so this form keeps the reference's own shape: paths are lists of indices into a pool
+// of vertex / edge records (the reference's paths share PathVertex objects by pointer, and evaluate() mutates shared vertices -- cast(), the
+// measure of connected end points -- which index lists reproduce for free), one lane runs one sample from the connected base path to its last
+// connection.  The pool, the manifold's vertices and the MIS arrays live in a per-lane workspace in HBM (~56 KB): this is the SLOW path, there
+// for completeness; samples without a specular vertex never enter it.  The two subpaths come from the same walk (k_bd_paths) as the fast form's.
+//
+// One restatement in two places: this file follows oracle/gbdpt_oracle.hpp function by function (that file cites the reference line by line and
+// is held by closed forms and by the estimator's expectation, tests/test_gbdpt_oracle.py); parity of the two is held per sample at 1e-9
+// (tests/test_gbdpt_gpu.py).  Chains of more than GM_MAX - 2 vertices are not shifted (both sides).
+#pragma once
+#include "gbdpt_kernels.hip.h"
+
+namespace gdpt_bd {
+
+constexpr int GP_LEN = 32;                         // vertices of a path (the connected path: <= NEV + NSV)
+constexpr int GV_POOL = 176, GE_POOL = 176;        // vertex / edge records of one sample: both subpaths, the clones of createShiftablePath, four offset paths, one light path and its offset
+constexpr int GM_MAX = 12;                         // vertices of a specular manifold: two end points + a chain of up to 10 (longer chains are not shifted)
+
+struct GPath {                                     // Path: m_vertices / m_edges as indices into the pool
+    short v[GP_LEN], e[GP_LEN];
+    int nv, ne;
+    __device__ __forceinline__ int length() const { return ne; }
+    __device__ __forceinline__ void clear() { nv = ne = 0; }
+    __device__ __forceinline__ void pushV(int i) { if (nv < GP_LEN) v[nv] = (short)i; nv++; }
+    __device__ __forceinline__ void pushE(int i) { if (ne < GP_LEN) e[ne] = (short)i; ne++; }
+    __device__ __forceinline__ void reverse()
+    {
+        for (int i = 0, j = nv - 1; i < j; i++, j--) { const short t = v[i]; v[i] = v[j]; v[j] = t; }
+        for (int i = 0, j = ne - 1; i < j; i++, j--) { const short t = e[i]; e[i] = e[j]; e[j] = t; }
+    }
+};
+struct M2 {                                        // Matrix2x2, core/matrix.h:455-530
+    Float m[2][2];
+    __device__ __forceinline__ void setZero() { m[0][0] = m[0][1] = m[1][0] = m[1][1] = 0; }
+    __device__ __forceinline__ void setIdentity() { m[0][0] = m[1][1] = 1; m[0][1] = m[1][0] = 0; }
+    __device__ __forceinline__ Float det() const { return m[0][0] * m[1][1] - m[0][1] * m[1][0]; }
+    __device__ __forceinline__ bool invert(M2 &t) const
+    {
+        const Float d = m[0][0] * m[1][1] - m[0][1] * m[1][0];
+        if (fabs(d) <= 0x1p-1024) return false;
+        const Float invDet = 1 / d;
+        t.m[0][0] = m[1][1] * invDet; t.m[0][1] = -m[0][1] * invDet; t.m[1][1] = m[0][0] * invDet; t.m[1][0] = -m[1][0] * invDet;
+        return true;
+    }
+};
+__device__ __forceinline__ M2 m2(Float a, Float b, Float c, Float d) { M2 r; r.m[0][0] = a; r.m[0][1] = b; r.m[1][0] = c; r.m[1][1] = d; return r; }
+__device__ __forceinline__ M2 m2mul(const M2 &a, const M2 &b)
+{
+    M2 r;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { Float sum = 0; for (int k = 0; k < 2; ++k) sum += a.m[i][k] * b.m[k][j]; r.m[i][j] = sum; }
+    return r;
+}
+__device__ __forceinline__ M2 m2sub(const M2 &a, const M2 &b) { return m2(a.m[0][0] - b.m[0][0], a.m[0][1] - b.m[0][1], a.m[1][0] - b.m[1][0], a.m[1][1] - b.m[1][1]); }
+__device__ __forceinline__ M2 m2neg(const M2 &a) { return m2(-a.m[0][0], -a.m[0][1], -a.m[1][0], -a.m[1][1]); }
+enum { MV_PINNED = 0, MV_REFLECTION = 2, MV_REFRACTION = 3, MV_MOVABLE = 5 };                // manifold.h:88-95
+struct MV {                                        // SpecularManifold::SimpleVertex, manifold.h:98-134
+    int degenerate, type, object, pad;
+    d3 p, dpdu, dpdv, n, gn, dndu, dndv, m;
+    Float eta;
+    M2 a, b, c, u, Tp;
+    __device__ __forceinline__ d3 map(Float uu, Float vv) const { const Float tx = Tp.m[0][0] * uu + Tp.m[0][1] * vv, ty = Tp.m[1][0] * uu + Tp.m[1][1] * vv; return dpdu * tx + dpdv * ty; }
+};
+__device__ __forceinline__ void mv_init(MV &v, int type, d3 p)
+{
+    v.degenerate = 0; v.type = type; v.object = -1; v.pad = 0; v.p = p;
+    v.dpdu = v.dpdv = v.n = v.gn = v.dndu = v.dndv = v.m = mk(0.0); v.eta = 1.0;
+    v.a.setZero(); v.b.setZero(); v.c.setZero(); v.u.setZero(); v.Tp.setZero();
+}
+struct MuRec { int l, m; int extra[5]; };
+
+struct GWork {                                     // per-lane workspace (HBM)
+    BV v[GV_POOL]; BE e[GE_POOL];
+    int nv, ne;
+    MV mv[GM_MAX], mp[GM_MAX];
+    int nm, nmp, mIterations, pad;
+    Float pdfImp[GP_LEN + 2], pdfRad[GP_LEN + 2], oPdfImp[GP_LEN + 2], oPdfRad[GP_LEN + 2];
+    char connectable[GP_LEN + 2], connectableStrict[GP_LEN + 2];
+    d3 impW[NEV + 1]; Float impP[NEV + 1];
+    d3 radW[5][NSV + 1]; Float radP[5][NSV + 1];
+    Float jacobianDet[5][NSV + 4], genGeomTerm[5][NSV + 4];
+    Float A[4 * GM_MAX * GM_MAX], Ai[4 * GM_MAX * GM_MAX];           // the dense system of SpecularManifold::det's mixed case: 2 (GM_MAX - 2) squared, twice
+    GPath emitter, sensor[5], connect, offsetEmitter, connectedBase;
+    MuRec mu[5];
+    int success[5], couldConnectAfterB[5];
+    unsigned overflow;                             // a pool or a list ran out (the sample's result is then void: counted, asserted zero by the tests)
+};
+
+// its.dpdu / its.dpdv of a triangle hit (skdtree.h:373-380, trimesh.cpp:683-735): the edges, or the UV tangents of a mesh with texture coordinates
+__device__ void tri_partials(const Ctx &c, int prim, d3 &dpdu, d3 &dpdv)
+{
+    const TriShade &ts = c.V.shade[prim];
+    const d3 dP1 = ts.p1 - ts.p0, dP2 = ts.p2 - ts.p0;
+    dpdu = dP1; dpdv = dP2;
+    if (c.V.uv && c.V.hasUV[prim]) {
+        const TriUV t = c.V.uv[prim];
+        const Float du1 = t.uv[2] - t.uv[0], dv1 = t.uv[3] - t.uv[1], du2 = t.uv[4] - t.uv[0], dv2 = t.uv[5] - t.uv[1];
+        const Float determinant = du1 * dv2 - dv1 * du2;
+        if (determinant == 0) {                    // trimesh.cpp:708-714: a degenerate parameterization falls back to a frame about the face normal
+            const d3 n = normalize(cross(dP1, dP2));
+            if (fabs(n.x) > fabs(n.y)) { const Float il = 1.0 / sqrt(n.x * n.x + n.z * n.z); dpdv = mk(n.z * il, 0.0, -n.x * il); }
+            else { const Float il = 1.0 / sqrt(n.y * n.y + n.z * n.z); dpdv = mk(0.0, n.z * il, -n.y * il); }
+            dpdu = cross(dpdv, n);
+        } else {
+            const Float invDet = 1.0 / determinant;
+            dpdu = (dP1 * dv2 - dP2 * dv1) * invDet;
+            dpdv = (dP2 * du1 - dP1 * du2) * invDet;
+        }
+    }
+}
+
+struct GTr {
+    Ctx &c;
+    GWork &W;
+    __device__ GTr(Ctx &c_, GWork &w_) : c(c_), W(w_) {}
+
+    // ---- pool ----
+    __device__ int allocV() { if (W.nv >= GV_POOL) { W.overflow++; return GV_POOL - 1; } bv_clear(W.v[W.nv]); return W.nv++; }
+    __device__ int allocE() { if (W.ne >= GE_POOL) { W.overflow++; return GE_POOL - 1; } be_clear(W.e[W.ne]); return W.ne++; }
+    __device__ int cloneV(int i) { const int j = allocV(); W.v[j] = W.v[i]; return j; }
+    __device__ BV &V_(const GPath &p, int i) { return W.v[p.v[i]]; }
+    __device__ BE &E_(const GPath &p, int i) { return W.e[p.e[i]]; }
+    __device__ BV *VN(const GPath &p, int i) { return (i < 0 || i >= p.nv) ? nullptr : &W.v[p.v[i]]; }
+    __device__ BE *EN(const GPath &p, int i) { return (i < 0 || i >= p.ne) ? nullptr : &W.e[p.e[i]]; }
+
+    // ---- PathVertex with transport modes (the fast form's helpers are radiance-only where the BSDF is symmetric) ----
+    __device__ d3 gEval(const BV &v, const BV *pred, const BV *succ, int mode, int measure = M_AREA)
+    {
+        if (v.type != T_SURFACE) return bv_eval(c, v, pred, succ, mode, measure);
+        const Surf sf = surf_of(c, v);
+        const d3 wi = normalize(pred->p - v.p), wo = normalize(succ->p - v.p);
+        const d3 wiL = toLocal(sf.fr, wi), woL = toLocal(sf.fr, wo);
+        if (measure == M_AREA) measure = M_SOLID;
+        d3 result; Float pdfUnused;
+        bd_eval_pdf(sf.m, sf.R, wiL, woL, bsdf_measure(measure), mode == EImportance, BD_ALL, result, pdfUnused);
+        const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
+        if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * woL.z <= 0) return mk(0.0);
+        if (mode == EImportance) result = result * fabs((wiL.z * woDotGeoN) / (woL.z * wiDotGeoN));
+        if (measure != M_DISCRETE && woL.z != 0) result = result / fabs(woL.z);
+        return result;
+    }
+    // PathVertex::update, vertex.cpp:1165-1211
+    __device__ bool gUpdate(BV &v, const BV *pred, const BV *succ, int mode, int measure)
+    {
+        v.pdf[mode] = bv_eval_pdf(c, v, pred, succ, mode, measure);
+        v.pdf[1 - mode] = bv_eval_pdf(c, v, succ, pred, 1 - mode, measure);
+        v.w[mode] = gEval(v, pred, succ, mode, measure);
+        v.w[1 - mode] = gEval(v, succ, pred, 1 - mode, measure);
+        if (is_zero(v.w[mode]) || v.pdf[mode] <= 0x1p-1024) return false;
+        Float weightFwd = v.pdf[mode] <= 0x1p-1024 ? 0.0 : 1 / v.pdf[mode], weightBkw = v.pdf[1 - mode] <= 0x1p-1024 ? 0.0 : 1 / v.pdf[1 - mode];
+        v.measure = measure;
+        if (!bv_super(v) && measure == M_AREA) {
+            const d3 shN = bv_sh_normal(c, v);
+            if (!bv_super(*pred)) {
+                d3 d = pred->p - v.p;
+                const Float invDistSqr = 1.0 / len2(d);
+                weightBkw *= invDistSqr;
+                d = d * sqrt(invDistSqr);
+                if (bv_on_surface(v) && bv_connectable(v)) weightBkw *= fabs(dot(shN, d));
+                if (bv_on_surface(*pred)) weightBkw *= fabs(dot(bv_geo_normal(c, *pred), d));
+            }
+            if (!bv_super(*succ)) {
+                d3 d = succ->p - v.p;
+                const Float invDistSqr = 1.0 / len2(d);
+                weightFwd *= invDistSqr;
+                d = d * sqrt(invDistSqr);
+                if (bv_on_surface(v) && bv_connectable(v)) weightFwd *= fabs(dot(shN, d));
+                if (bv_on_surface(*succ)) weightFwd *= fabs(dot(bv_geo_normal(c, *succ), d));
+            }
+            if (v.type == T_SURFACE) v.componentType = ESmooth;
+        }
+        v.w[mode] = v.w[mode] * weightFwd;
+        v.w[1 - mode] = v.w[1 - mode] * weightBkw;
+        return true;
+    }
+    // PathVertex::connect with explicit measures, vertex.cpp:1348-1370
+    __device__ bool gConnect(const BV *pred, BV &vs, BE &edge, BV &vt, const BV *succ, int vsMeasure, int vtMeasure)
+    {
+        if (vs.type == T_EMITTER_SUPER) { if (!bv_cast_emitter(c, vt)) return false; }
+        else if (vt.type == T_SENSOR_SUPER) return false;                                    // (no sensor shapes)
+        if (!gUpdate(vs, pred, &vt, EImportance, vsMeasure)) return false;
+        if (!gUpdate(vt, succ, &vs, ERadiance, vtMeasure)) return false;
+        return edge_connect(c, edge, vs, vt);
+    }
+    // PathVertex::perturbDirection, vertex.cpp:488-679: the sensor sample, or a glossy surface vertex of a chain
+    __device__ bool gPerturbDirection(BV &v, const BV *pred, const BE *predEdge, BE &succEdge, BV &succ, d3 d, Float dist, int mode)
+    {
+        be_clear(succEdge); bv_clear(succ);
+        if (v.degenerate) return false;
+        if (v.type == T_SENSOR_SAMPLE) {
+            const Float value = importance(c, cam_to_local(c, d)), prob = value;
+            if (value == 0 || prob <= 0x1p-1024) return false;
+            v.w[EImportance] = mk(value) * (1.0 / fabs(dot(d, v.n)));
+            v.w[ERadiance] = mk(value) / prob;
+            v.pdf[EImportance] = 1.0; v.pdf[ERadiance] = prob;
+            v.measure = M_SOLID;
+        } else if (v.type == T_SURFACE) {
+            const Surf sf = surf_of(c, v);
+            const d3 wi = normalize(pred->p - v.p), wo = d;
+            const d3 wiL = toLocal(sf.fr, wi), woL = toLocal(sf.fr, wo);
+            d3 value; Float prob;
+            bd_eval_pdf(sf.m, sf.R, wiL, woL, MEASURE_SOLID_ANGLE, mode == EImportance, BD_ALL, value, prob);
+            if (is_zero(value) || prob <= 0x1p-1024) return false;
+            v.w[mode] = value / prob;
+            v.pdf[mode] = prob;
+            const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
+            if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * woL.z <= 0) return false;
+            v.measure = M_SOLID;
+            v.componentType = ESmooth;
+            d3 fRev; Float pRev;
+            bd_eval_pdf(sf.m, sf.R, woL, wiL, MEASURE_SOLID_ANGLE, (1 - mode) == EImportance, BD_ALL, fRev, pRev);
+            v.pdf[1 - mode] = pRev;
+            if (v.pdf[1 - mode] <= 0x1p-1024) return false;
+            v.w[1 - mode] = v.w[mode] * fabs((v.pdf[mode] * wiL.z) / (v.pdf[1 - mode] * woL.z));
+            adjoint(v, mode, wiL, woL, wiDotGeoN, woDotGeoN);
+        } else return false;
+        if (!edge_extend(c, succEdge, v.p, d, succ, mode, true, dist)) { v.measure = M_INVALID; return false; }
+        to_area(c, v, mode, *pred, *predEdge, succEdge, succ, d);
+        return true;
+    }
+    // PathVertex::propagatePerturbation, vertex.cpp:681-790
+    __device__ bool gPropagatePerturbation(BV &v, const BV *pred, BE &succEdge, BV &succ, int componentType, Float dist, int mode)
+    {
+        const Surf sf = surf_of(c, v);
+        if (!(bsdfType(sf.m) & EDelta)) return false;
+        be_clear(succEdge); bv_clear(succ);
+        const d3 wi = normalize(pred->p - v.p);
+        const d3 wiL = toLocal(sf.fr, wi);
+        BSDFSample bs;
+        bd_sample(sf.m, sf.R, wiL, 0.5, 0.5, mode == EImportance, componentType, bs);
+        if (is_zero(bs.weight)) return false;
+        const d3 wo = toWorld(sf.fr, bs.wo);
+        const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
+        if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * bs.wo.z <= 0) return false;
+        d3 f; Float prob;
+        bd_eval_pdf(sf.m, sf.R, wiL, bs.wo, MEASURE_DISCRETE, mode == EImportance, BD_ALL, f, prob);
+        if (prob <= 0x1p-1024) return false;
+        v.w[mode] = f / prob;
+        v.pdf[mode] = prob;
+        v.measure = M_DISCRETE;
+        v.componentType = componentType;
+        if (is_zero(v.w[mode])) return false;
+        d3 fRev; Float pRev;
+        bd_eval_pdf(sf.m, sf.R, bs.wo, wiL, MEASURE_DISCRETE, (1 - mode) == EImportance, BD_ALL, fRev, pRev);
+        v.pdf[1 - mode] = pRev;
+        if (v.pdf[1 - mode] <= 0x1p-1024) return false;
+        if (sf.m.type != 3) v.w[1 - mode] = v.w[mode];
+        else v.w[1 - mode] = fRev / v.pdf[1 - mode];
+        adjoint(v, mode, wiL, bs.wo, wiDotGeoN, woDotGeoN);
+        if (!edge_extend(c, succEdge, v.p, wo, succ, mode, true, dist)) { v.measure = M_INVALID; return false; }
+        return true;
+    }
+    // PathEdge::evalCached, edge.cpp:169-219 (scalar: every caller here asks for geometry terms)
+    __device__ Float gEdgeEvalCached(const BE &e, const BV &pred, const BV &succ, unsigned what)
+    {
+        enum { EValueImp = 0x01, EValueRad = 0x02, ECosineImp = 0x04, ECosineRad = 0x08, EInverseSquareFalloff = 0x10, ETransmittance = 0x20 };
+        Float result = 1.0;
+        if (e.length == 0) return result;                                                    // (no EValue* request here)
+        if ((what & ECosineImp) && bv_on_surface(pred) && bv_connectable(pred)) result *= fabs(dot(bv_sh_normal(c, pred), e.d));
+        if ((what & ECosineRad) && bv_on_surface(succ) && bv_connectable(succ)) result *= fabs(dot(bv_sh_normal(c, succ), e.d));
+        if (what & EInverseSquareFalloff) result /= e.length * e.length;
+        if (what & ETransmittance) result *= e.tr[EImportance] * e.tr[EImportance];
+        return result;
+    }
+
+    // ---- SpecularManifold, manifold.cpp ----
+    __device__ void normalDerivative(const BV &v, d3 &dndu, d3 &dndv)                        // TriMesh::getNormalDerivative, trimesh.cpp:745-822
+    {
+        const TriShade &ts = c.V.shade[v.prim];
+        dndu = dndv = mk(0.0);
+        if (!(c.V.vn && ts.smooth)) return;
+        const TriNormals vn = c.V.vn[v.prim];
+        const d3 rel = v.p - ts.p0, du = ts.p1 - ts.p0, dv = ts.p2 - ts.p0;
+        const Float b1 = dot(du, rel), b2 = dot(dv, rel), a11 = dot(du, du), a12 = dot(du, dv), a22 = dot(dv, dv);
+        Float det = a11 * a22 - a12 * a12;
+        if (det == 0) return;
+        Float invDet = 1.0 / det;
+        const Float u = (a22 * b1 - a12 * b2) * invDet, vv = (-a12 * b1 + a11 * b2) * invDet, w = 1 - u - vv;
+        d3 N = vn.n1 * u + vn.n2 * vv + vn.n0 * w;
+        const Float il = 1.0 / len(N); N = N * il;
+        dndu = (vn.n1 - vn.n0) * il; dndu = dndu - N * dot(N, dndu);
+        dndv = (vn.n2 - vn.n0) * il; dndv = dndv - N * dot(N, dndv);
+        if (c.V.uv && c.V.hasUV[v.prim]) {
+            const TriUV t = c.V.uv[v.prim];
+            const Float d1x = t.uv[2] - t.uv[0], d1y = t.uv[3] - t.uv[1], d2x = t.uv[4] - t.uv[0], d2y = t.uv[5] - t.uv[1];
+            det = d1x * d2y - d1y * d2x;
+            if (det == 0) { dndu = dndv = mk(0.0); return; }
+            invDet = 1.0 / det;
+            const d3 du_ = (dndu * d2y - dndv * d1y) * invDet, dv_ = (dndv * d1x - dndu * d2x) * invDet;
+            dndu = du_; dndv = dv_;
+        }
+    }
+    __device__ void manifoldSurface(MV &m, const BV &v)                                       // manifold.cpp:101-122,480-507
+    {
+        Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+        const Shading sh = shading_at<true>(c.V, vx);
+        m.p = v.p; m.gn = sh.geoN; m.n = sh.fr.n;
+        tri_partials(c, v.prim, m.dpdu, m.dpdv);
+        normalDerivative(v, m.dndu, m.dndv);
+        Float invLen = 1 / len(m.dpdu);
+        m.dpdu = m.dpdu * invLen; m.dndu = m.dndu * invLen;
+        const Float dp = dot(m.dpdu, m.dpdv);
+        const d3 dpdv = m.dpdv - m.dpdu * dp, dndv = m.dndv - m.dndu * dp;
+        invLen = 1 / len(dpdv);
+        m.dpdv = dpdv * invLen; m.dndv = dndv * invLen;
+    }
+    __device__ bool manifoldInit(const GPath &path, int start, int end)                      // manifold.cpp:59-170
+    {
+        const int step = start < end ? 1 : -1;
+        if (bv_super(V_(path, start))) start += step;
+        if (bv_super(V_(path, end))) end -= step;
+        W.nm = 0;
+        if ((end - start) * step + 1 > GM_MAX) return false;
+        mv_init(W.mv[W.nm++], MV_PINNED, V_(path, start).p);
+        for (int i = start + step; i != end; i += step) {
+            const BV &pred = V_(path, i - step), &vertex = V_(path, i), &succ = V_(path, i + step);
+            MV &m = W.mv[W.nm++];
+            mv_init(m, MV_PINNED, mk(0.0));
+            if (vertex.type != T_SURFACE) return false;
+            manifoldSurface(m, vertex);
+            m.object = c.V.shade[vertex.prim].material;
+            m.degenerate = !bv_connectable(vertex);
+            const d3 wPred = pred.p - m.p, wSucc = succ.p - m.p;
+            if (dot(m.gn, wPred) * dot(m.gn, wSucc) < 0) { m.type = MV_REFRACTION; m.eta = bsdf_eta(c.V.mats[m.object]); }
+            else { m.type = MV_REFLECTION; m.eta = 1.0; }
+        }
+        mv_init(W.mv[W.nm++], MV_MOVABLE, V_(path, end).p);
+        return true;
+    }
+    __device__ bool manifoldTangents()                                                       // manifold.cpp:172-400
+    {
+        const int n = W.nm - 1;
+        W.mv[0].Tp.setZero();
+        W.mv[W.nm - 1].Tp.setIdentity();
+        if (W.nm == 2) return true;
+        for (int i = 0; i < n; ++i) {
+            MV *v = &W.mv[i];
+            d3 wo = v[1].p - v[0].p;
+            Float ilo = len(wo);
+            if (ilo == 0) return false;
+            ilo = 1 / ilo; wo = wo * ilo;
+            if (v[0].type == MV_PINNED) { v[0].a.setZero(); v[0].b.setIdentity(); v[0].c.setZero(); continue; }
+            d3 wi = v[-1].p - v[0].p;
+            Float ili = len(wi);
+            if (ili == 0) return false;
+            ili = 1 / ili; wi = wi * ili;
+            if (v[0].type != MV_REFLECTION && v[0].type != MV_REFRACTION) return false;
+            Float eta = v[0].eta;
+            const bool normalizeH = !(v[0].type == MV_REFRACTION && eta == 1);
+            d3 H;
+            Float ilh;
+            if (normalizeH) {
+                if (dot(wi, v[0].gn) < 0) eta = 1 / eta;
+                H = wi + wo * eta;
+                ilh = 1 / len(H);
+                H = H * ilh;
+            } else { H = wi + wo; ilh = 1.0; }
+            const Float dot_H_n = dot(v[0].n, H), dot_H_dndu = dot(v[0].dndu, H), dot_H_dndv = dot(v[0].dndv, H), dot_u_n = dot(v[0].dpdu, v[0].n), dot_v_n = dot(v[0].dpdv, v[0].n);
+            d3 s_ = v[0].dpdu - v[0].n * dot_u_n, t_ = v[0].dpdv - v[0].n * dot_v_n;
+            ilo *= eta * ilh; ili *= ilh;
+            d3 dH_du = (v[-1].dpdu - wi * dot(wi, v[-1].dpdu)) * ili, dH_dv = (v[-1].dpdv - wi * dot(wi, v[-1].dpdv)) * ili;
+            if (normalizeH) { dH_du = dH_du - H * dot(dH_du, H); dH_dv = dH_dv - H * dot(dH_dv, H); }
+            v[0].a = m2(dot(dH_du, s_), dot(dH_dv, s_), dot(dH_du, t_), dot(dH_dv, t_));
+            dH_du = -v[0].dpdu * (ili + ilo) + wi * (dot(wi, v[0].dpdu) * ili) + wo * (dot(wo, v[0].dpdu) * ilo);
+            dH_dv = -v[0].dpdv * (ili + ilo) + wi * (dot(wi, v[0].dpdv) * ili) + wo * (dot(wo, v[0].dpdv) * ilo);
+            if (normalizeH) { dH_du = dH_du - H * dot(dH_du, H); dH_dv = dH_dv - H * dot(dH_dv, H); }
+            v[0].b = m2(dot(dH_du, s_) - dot(v[0].dpdu, v[0].dndu) * dot_H_n - dot_u_n * dot_H_dndu,
+                        dot(dH_dv, s_) - dot(v[0].dpdu, v[0].dndv) * dot_H_n - dot_u_n * dot_H_dndv,
+                        dot(dH_du, t_) - dot(v[0].dpdv, v[0].dndu) * dot_H_n - dot_v_n * dot_H_dndu,
+                        dot(dH_dv, t_) - dot(v[0].dpdv, v[0].dndv) * dot_H_n - dot_v_n * dot_H_dndv);
+            dH_du = (v[1].dpdu - wo * dot(wo, v[1].dpdu)) * ilo;
+            dH_dv = (v[1].dpdv - wo * dot(wo, v[1].dpdv)) * ilo;
+            if (normalizeH) { dH_du = dH_du - H * dot(dH_du, H); dH_dv = dH_dv - H * dot(dH_dv, H); }
+            v[0].c = m2(dot(dH_du, s_), dot(dH_dv, s_), dot(dH_du, t_), dot(dH_dv, t_));
+            s_ = normalize(s_);
+            t_ = cross(v[0].n, s_);
+            v[0].m = mk(dot(s_, H), dot(t_, H), dot(v[0].n, H));
+            if (dot(H, v[0].gn) < 0) v[0].m = -v[0].m;
+        }
+        M2 Li;
+        if (!W.mv[0].b.invert(Li)) return false;
+        for (int i = 0; i < n - 1; ++i) {
+            W.mv[i].u = m2mul(Li, W.mv[i].c);
+            const M2 temp = m2sub(W.mv[i + 1].b, m2mul(W.mv[i + 1].a, W.mv[i].u));
+            if (!temp.invert(Li)) return false;
+        }
+        W.mv[n - 1].Tp = m2neg(m2mul(Li, W.mv[n - 1].c));
+        for (int i = n - 2; i >= 0; --i) W.mv[i].Tp = m2neg(m2mul(W.mv[i].u, W.mv[i + 1].Tp));
+        return true;
+    }
+    __device__ static d3 reflectAbout(d3 wi, d3 n) { return n * (2 * dot(wi, n)) - wi; }      // util.cpp:763-765
+    __device__ static d3 refractAbout(d3 wi, d3 n, Float eta)                                 // util.cpp:774-792
+    {
+        if (eta == 1) return -wi;
+        const Float cosThetaI = dot(wi, n);
+        if (cosThetaI > 0) eta = 1 / eta;
+        const Float cosThetaTSqr = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
+        if (cosThetaTSqr <= 0.0) return mk(0.0);
+        return n * (cosThetaI * eta - (cosThetaI < 0 ? -1.0 : (cosThetaI > 0 ? 1.0 : 0.0)) * sqrt(cosThetaTSqr)) - wi * eta;
+    }
+    __device__ bool manifoldProject(d3 d)                                                    // manifold.cpp:402-510
+    {
+        const MV &last = W.mv[W.nm - 1];
+        const Float du = dot(d, last.dpdu), dv = dot(d, last.dpdv);
+        d3 ro = mk(0.0), rd = mk(0.0);
+        W.nmp = 0;
+        for (int i = 0; i < W.nm; ++i) {
+            W.mp[W.nmp++] = W.mv[i];
+            MV &vertex = W.mp[i];
+            if (i == 0) {
+                const d3 p0 = W.mv[0].p + W.mv[0].map(du, dv), p1 = W.mv[1].p + W.mv[1].map(du, dv);
+                ro = p0; rd = normalize(p1 - p0);
+                vertex.p = ro;
+                continue;
+            } else if (vertex.type == MV_MOVABLE) {
+                const Float dp = dot(rd, vertex.n);
+                if (fabs(dp) < GD_EPSILON) return false;
+                const Float t = dot(vertex.p - ro, vertex.n) / dp;
+                vertex.p = ro + rd * t;
+                break;
+            } else if (vertex.type == MV_REFLECTION || vertex.type == MV_REFRACTION) {
+                Hit h;
+                if (!closest_hit(c, ro, rd, GD_EPSILON, GD_INF, h)) return false;
+                BV hv; bv_clear(hv);
+                fill_surface(c, h, hv);
+                Vertex vx; vx.p = hv.p; vx.prim = hv.prim; vx.u = hv.u; vx.v = hv.v;
+                const d3 n = shading_at<true>(c.V, vx).fr.n;
+                d3 s_, dpdvUnused;
+                tri_partials(c, hv.prim, s_, dpdvUnused);
+                s_ = normalize(s_ - n * dot(n, s_));
+                const d3 t_ = cross(n, s_);
+                const d3 m = s_ * vertex.m.x + t_ * vertex.m.y + n * vertex.m.z;
+                d3 out;
+                if (vertex.type == MV_REFLECTION) out = reflectAbout(-rd, m);
+                else { out = refractAbout(-rd, m, bsdf_eta(c.V.mats[c.V.shade[hv.prim].material])); if (is_zero(out)) return false; }
+                ro = hv.p; rd = out;
+                if (vertex.object != c.V.shade[hv.prim].material) return false;
+                manifoldSurface(vertex, hv);
+            } else return false;
+        }
+        return true;
+    }
+    __device__ bool manifoldMove(d3 target, d3 n)                                            // manifold.cpp:512-635
+    {
+        MV &last = W.mv[W.nm - 1];
+        if (W.nm == 2 && W.mv[0].type == MV_PINNED) return true;
+        const Float invScale = 1.0 / fmax(fmax(fabs(target.x), fabs(target.y)), fabs(target.z));
+        Float stepSize = 1;
+        if (fabs(n.x) > fabs(n.y)) { const Float il = 1.0 / sqrt(n.x * n.x + n.z * n.z); last.dpdv = mk(n.z * il, 0.0, -n.x * il); }   // coordinateSystem(n, dpdu, dpdv), util.cpp:592-601
+        else { const Float il = 1.0 / sqrt(n.y * n.y + n.z * n.z); last.dpdv = mk(0.0, n.z * il, -n.y * il); }
+        last.dpdu = cross(last.dpdv, n);
+        last.n = n;
+        W.mIterations = 0;
+        while (W.mIterations < 20) {
+            const d3 rel = target - W.mv[W.nm - 1].p;
+            Float dist = len(rel), newDist;
+            if (dist * invScale < GD_EPSILON) {
+                dist = len(W.mv[W.nm - 1].p - W.mv[W.nm - 2].p);
+                if (dist * invScale < GD_EPSILON) return false;
+                return true;
+            }
+            W.mIterations++;
+            if (!manifoldTangents()) return false;
+            bool failure = false;
+            if (!manifoldProject(rel * stepSize)) failure = true;
+            else {
+                newDist = len(target - W.mp[W.nmp - 1].p);
+                if (newDist > dist) failure = true;
+            }
+            if (!failure) {
+                for (int i = 0; i < W.nmp; i++) W.mv[i] = W.mp[i];                             // m_proposal.swap(m_vertices): the old vertices are never read again
+                W.nm = W.nmp;
+                stepSize = fmin((Float)1.0, stepSize * 2.0);
+                continue;
+            }
+            stepSize /= 2.0;
+        }
+        return false;
+    }
+    __device__ bool manifoldUpdate(GPath &path, int start, int end)                          // manifold.cpp:637-757
+    {
+        const int step = start < end ? 1 : -1, mode = start < end ? EImportance : ERadiance;
+        const int last = W.nm - 2;
+        for (int j = 0, i = start; j < last; ++j, i += step) {
+            const MV &v = W.mv[j], &vn = W.mv[j + 1];
+            BV *pred = VN(path, i - step); BV &vertex = V_(path, i), &succ = V_(path, i + step);
+            const int predEdgeIdx = (mode == EImportance) ? i - step : i - step - 1;
+            BE *predEdge = EN(path, predEdgeIdx); BE &succEdge = E_(path, predEdgeIdx + step);
+            d3 d = vn.p - v.p;
+            const Float length = len(d);
+            d = d / length;
+            if (!v.degenerate) { if (!gPerturbDirection(vertex, pred, predEdge, succEdge, succ, d, length, mode)) return false; }
+            else if (!gPropagatePerturbation(vertex, pred, succEdge, succ, v.type == MV_REFRACTION ? EDeltaTransmission : EDeltaReflection, length, mode)) return false;
+            const Float relerr = len(vn.p - succ.p) / fmax(fmax(fabs(vn.p.x), fabs(vn.p.y)), fabs(vn.p.z));
+            if (relerr > (Float)1e-3f) return false;
+        }
+        return true;
+    }
+    // the dense inverse and determinant of SpecularManifold::det's mixed case (Gauss-Jordan / LU with partial pivoting, as the oracle)
+    __device__ bool denseInverse(int n)
+    {
+        Float *A = W.A, *Ai = W.Ai;
+        for (int i = 0; i < n * n; ++i) Ai[i] = 0.0;
+        for (int i = 0; i < n; ++i) Ai[i * n + i] = 1.0;
+        for (int col = 0; col < n; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < n; ++r) if (fabs(A[r * n + col]) > fabs(A[piv * n + col])) piv = r;
+            if (A[piv * n + col] == 0) return false;
+            if (piv != col) for (int k = 0; k < n; ++k) { Float t = A[piv * n + k]; A[piv * n + k] = A[col * n + k]; A[col * n + k] = t; t = Ai[piv * n + k]; Ai[piv * n + k] = Ai[col * n + k]; Ai[col * n + k] = t; }
+            const Float inv = 1.0 / A[col * n + col];
+            for (int k = 0; k < n; ++k) { A[col * n + k] *= inv; Ai[col * n + k] *= inv; }
+            for (int r = 0; r < n; ++r) {
+                if (r == col) continue;
+                const Float f = A[r * n + col];
+                if (f == 0) continue;
+                for (int k = 0; k < n; ++k) { A[r * n + k] -= f * A[col * n + k]; Ai[r * n + k] -= f * Ai[col * n + k]; }
+            }
+        }
+        return true;
+    }
+    __device__ Float denseDet(int n)                                                         // of W.Ai, destroyed
+    {
+        Float *A = W.Ai;
+        Float det = 1.0;
+        for (int col = 0; col < n; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < n; ++r) if (fabs(A[r * n + col]) > fabs(A[piv * n + col])) piv = r;
+            if (A[piv * n + col] == 0) return 0.0;
+            if (piv != col) { for (int k = 0; k < n; ++k) { const Float t = A[piv * n + k]; A[piv * n + k] = A[col * n + k]; A[col * n + k] = t; } det = -det; }
+            det *= A[col * n + col];
+            for (int r = col + 1; r < n; ++r) {
+                const Float f = A[r * n + col] / A[col * n + col];
+                if (f == 0) continue;
+                for (int k = col; k < n; ++k) A[r * n + k] -= f * A[col * n + k];
+            }
+        }
+        return det;
+    }
+
+    // ---- Path: geometry terms, Jacobians (path.cpp:380-454; manifold.cpp:759-951) ----
+    __device__ Float manifoldG(const GPath &p, int a, int b)
+    {
+        if (abs(a - b) == 1) {
+            if (a > b) { const int t = a; a = b; b = t; }
+            return gEdgeEvalCached(E_(p, a), V_(p, a), V_(p, b), 0x04 | 0x08 | 0x10);        // EGeometricTerm
+        }
+        const int step = b > a ? 1 : -1;
+        if (!manifoldInit(p, a, b)) return 0.0;
+        MV &last = W.mv[W.nm - 1];
+        const BV &vb = V_(p, b);
+        last.n = bv_on_surface(vb) ? bv_sh_normal(c, vb) : E_(p, a < b ? (b - 1) : b).d;
+        if (fabs(last.n.x) > fabs(last.n.y)) { const Float il = 1.0 / sqrt(last.n.x * last.n.x + last.n.z * last.n.z); last.dpdv = mk(last.n.z * il, 0.0, -last.n.x * il); }
+        else { const Float il = 1.0 / sqrt(last.n.y * last.n.y + last.n.z * last.n.z); last.dpdv = mk(0.0, last.n.z * il, -last.n.y * il); }
+        last.dpdu = cross(last.dpdv, last.n);
+        if (!manifoldTangents()) return 0.0;
+        const d3 d = W.mv[1].p - W.mv[0].p;
+        const Float lengthSqr = len2(d), invLength = 1 / sqrt(lengthSqr);
+        Float result = len(cross(W.mv[1].map(1, 0), W.mv[1].map(0, 1))) / lengthSqr;
+        if (bv_on_surface(V_(p, a))) result *= fabs(dot(d, bv_sh_normal(c, V_(p, a)))) * invLength;
+        if (bv_on_surface(V_(p, a + step))) result *= fabs(dot(d, bv_sh_normal(c, V_(p, a + step)))) * invLength;
+        return result;
+    }
+    __device__ Float pathG(const GPath &p, int i, int j)
+    {
+        if (i >= j) return 1.0;
+        if (j != i + 1) return manifoldG(p, i, j);
+        const BE &e = E_(p, i);
+        const Float cosI = fabs(dot(e.d, bv_sh_normal(c, V_(p, i)))), cosJ = fabs(dot(e.d, bv_sh_normal(c, V_(p, j))));
+        return cosI * cosJ / (e.length * e.length);
+    }
+    __device__ Float multiG(const GPath &p, int a, int b)
+    {
+        if (a == 0) ++a; else if (a == p.length()) --a;
+        if (b == 0) ++b; else if (b == p.length()) --b;
+        const int step = b > a ? 1 : -1;
+        while (!bv_connectable(V_(p, b))) b -= step;
+        while (!bv_connectable(V_(p, a))) a += step;
+        Float result = 1;
+        for (int i = a + step, start = a; i != b + step; i += step)
+            if (bv_connectable(V_(p, i))) { result *= manifoldG(p, start, i); start = i; }
+        return result;
+    }
+    __device__ Float manifoldDet(const GPath &p, int a, int b, int cI)
+    {
+        const int k = p.length();
+        if (a == 0 || a == k) { const int t = a; a = cI; cI = t; }
+        const int step = b > a ? 1 : -1;
+        int nGlossy = 0, nSpecular = 0;
+        for (int i = a + step; i != cI; i += step) { if (bv_connectable(V_(p, i))) ++nGlossy; else ++nSpecular; }
+        if (nGlossy <= 1) return 1.0;
+        if (!manifoldInit(p, a, cI)) return 0.0;
+        const int b_idx = abs(b - a);
+        MV &vb = W.mv[b_idx];
+        vb.n = bv_sh_normal(c, V_(p, b));
+        if (fabs(vb.n.x) > fabs(vb.n.y)) { const Float il = 1.0 / sqrt(vb.n.x * vb.n.x + vb.n.z * vb.n.z); vb.dpdv = mk(vb.n.z * il, 0.0, -vb.n.x * il); }
+        else { const Float il = 1.0 / sqrt(vb.n.y * vb.n.y + vb.n.z * vb.n.z); vb.dpdv = mk(0.0, vb.n.z * il, -vb.n.y * il); }
+        vb.dpdu = cross(vb.dpdv, vb.n);
+        if (!manifoldTangents()) return 0.0;
+        W.mv[b_idx].a.setZero(); W.mv[b_idx].b.setIdentity(); W.mv[b_idx].c.setZero();
+        if (nSpecular == 0) {
+            M2 Di, D = W.mv[1].b;
+            Float det = D.det();
+            for (int i = 2; i < W.nm - 1; ++i) {
+                if (!D.invert(Di)) return 0.0;
+                D = m2sub(W.mv[i].b, m2mul(m2mul(W.mv[i].a, Di), W.mv[i - 1].c));
+                det *= D.det();
+            }
+            return fabs(1 / det);
+        }
+        const int nv = nGlossy + nSpecular, N = 2 * nv;
+        for (int i = 0; i < N * N; ++i) W.A[i] = 0.0;
+        for (int j = 0; j < nv; ++j) {
+            const int i = j;
+            for (int q = -1; q <= 1; ++q) {
+                const int cj = j + q;
+                if (cj < 0 || cj >= nv) continue;
+                const M2 &mm = q < 0 ? W.mv[j + 1].a : (q == 0 ? W.mv[j + 1].b : W.mv[j + 1].c);
+                W.A[(2 * i) * N + 2 * cj] = mm.m[0][0]; W.A[(2 * i) * N + 2 * cj + 1] = mm.m[0][1]; W.A[(2 * i + 1) * N + 2 * cj] = mm.m[1][0]; W.A[(2 * i + 1) * N + 2 * cj + 1] = mm.m[1][1];
+            }
+        }
+        if (!denseInverse(N)) return 0.0;
+        for (int i = 0; i < nv; ++i) {
+            if (!W.mv[i + 1].degenerate) continue;
+            for (int q = 0; q < N; ++q) { W.Ai[(2 * i) * N + q] = 0; W.Ai[(2 * i + 1) * N + q] = 0; W.Ai[q * N + 2 * i] = 0; W.Ai[q * N + 2 * i + 1] = 0; }
+            W.Ai[(2 * i) * N + 2 * i] = 1; W.Ai[(2 * i + 1) * N + 2 * i + 1] = 1;
+        }
+        return fabs(denseDet(N));
+    }
+    __device__ Float halfJacobian(const GPath &p, int a, int b, int cI)                      // path.cpp:380-394
+    {
+        Float value = 1.0;
+        value /= V_(p, a).pdf[ERadiance];
+        value *= pathG(p, a - 1, a) / pathG(p, b, a);
+        value *= manifoldDet(p, a, b, cI);
+        return value;
+    }
+    __device__ Float calcSpecularPDFChange(const GPath &p, int cI, bool lightpath = false)   // path.cpp:403-421
+    {
+        Float value = 1.0;
+        const int k = p.length() - 1;
+        cI = max(1, cI);
+        for (int i = cI + 1; i <= k; i++)
+            if (bv_connectable(V_(p, lightpath ? i - 1 : i))) value *= pathG(p, i - 1, i);
+        if (value <= (Float)0.0) return 1.0;
+        return multiG(p, cI, k) / value;
+    }
+
+    // ---- ManifoldPerturbation, mut_manifold.cpp ----
+    __device__ int getSpecularChainEnd(const GPath &path, int pos, int step)                 // :1230-1262
+    {
+        while (true) {
+            if (pos < 0 || pos > path.length()) return -1;
+            const BV &vertex = V_(path, pos);
+            if (vertex.type != T_SURFACE) break;
+            const Float roughness = mat_roughness(c.V.mats[c.V.shade[vertex.prim].material]);
+            if (bv_connectable(vertex) && roughness >= c.cfg.shiftThreshold) break;
+            pos += step;
+        }
+        return pos;
+    }
+    __device__ bool computeMuRec(const GPath &source, MuRec &mu)                             // :1264-1296
+    {
+        const int k = source.length();
+        mu.l = mu.m = 0; for (int i = 0; i < 5; i++) mu.extra[i] = 0;
+        if (!bv_connectable(V_(source, k - 1))) return false;
+        const int step = -1, a = k - 1;
+        int b, cI;
+        if ((b = getSpecularChainEnd(source, a + step, step)) == -1) return false;
+        if ((cI = getSpecularChainEnd(source, b + step, step)) == -1) return false;
+        mu.l = min(a, cI); mu.m = max(a, cI);
+        mu.extra[0] = a; mu.extra[1] = b; mu.extra[2] = cI; mu.extra[3] = step; mu.extra[4] = ERadiance;
+        return true;
+    }
+    __device__ bool mutPerturbDirection(const GPath &source, GPath &proposal, int step, int a, Float offX, Float offY)   // :938-986
+    {
+        const BE &succEdge_old = E_(source, a - 1);
+        BV &pred = V_(proposal, a - step), &vertex = V_(proposal, a), &succ = V_(proposal, a + step);
+        BE &predEdge = E_(proposal, a - 1 - step), &succEdge = E_(proposal, a - 1);
+        const CameraD &cam = c.S->cam;
+        const BV &sensor = V_(source, source.length() - 1);
+        const Float ppx = sensor.u + offX, ppy = sensor.v + offY;
+        const d3 rd = cam_to_world(c, sample_to_camera_dir(c, ppx * cam.invW, ppy * cam.invH));
+        const Float focusDistance = cam.farClip / fabs(dot(c.cam.dir, rd));
+        const d3 d = normalize((c.cam.pos + rd * focusDistance) - V_(source, a).p);
+        return gPerturbDirection(vertex, &pred, &predEdge, succEdge, succ, d, succEdge_old.length, ERadiance);
+    }
+    __device__ bool mutPropagatePerturbation(const GPath &source, GPath &proposal, int step, int a, int b, int mode)   // :989-1149
+    {
+        for (int i = a + step; i != b; i += step) {
+            const BV &pred_old = V_(source, i - step), &vertex_old = V_(source, i), &succ_old = V_(source, i + step);
+            const BE &succEdge_old = E_(source, mode == EImportance ? i : i - 1);
+            BV &pred = V_(proposal, i - step), &vertex = V_(proposal, i), &succ = V_(proposal, i + step);
+            BE &predEdge = E_(proposal, mode == EImportance ? i - step : i - 1 - step), &succEdge = E_(proposal, mode == EImportance ? i : i - 1);
+            if (vertex_old.type != T_SURFACE) return false;
+            const Surf so = surf_of(c, vertex_old), sn = surf_of(c, vertex);
+            const d3 wi_old = toLocal(so.fr, normalize(pred_old.p - vertex_old.p)), wo_old = toLocal(so.fr, normalize(succ_old.p - vertex_old.p));
+            const bool reflection = wi_old.z * wo_old.z > 0;
+            const Float eta = bsdf_eta(so.m);
+            const d3 wi_world = normalize(pred.p - vertex.p);
+            d3 wo_world = mk(0.0);
+            if (c.V.shade[vertex_old.prim].material != c.V.shade[vertex.prim].material) return false;
+            if (bv_connectable(vertex_old)) {
+                d3 m = mk(0.0);
+                if (reflection) m = normalize(wi_old + wo_old);
+                else if (eta != 1) m = normalize(wi_old.z < 0 ? (wi_old * eta + wo_old) : (wi_old + wo_old * eta));
+                m = toWorld(sn.fr, m.z > 0 ? m : -m);
+                if (reflection) wo_world = reflectAbout(wi_world, m);
+                else if (eta != 1) { wo_world = refractAbout(wi_world, m, eta); if (is_zero(wo_world)) return false; }
+                else wo_world = -wi_world;
+                if (!gPerturbDirection(vertex, &pred, &predEdge, succEdge, succ, wo_world, succEdge_old.length, mode)) return false;
+            } else {
+                if (!gPropagatePerturbation(vertex, &pred, succEdge, succ, reflection ? EDeltaReflection : EDeltaTransmission, succEdge_old.length, mode)) return false;
+            }
+        }
+        return true;
+    }
+    __device__ bool mutManifoldWalk(const GPath &source, GPath &proposal, int b, int cI)     // :1151-1227
+    {
+        const BV &vb_old = V_(source, b), &vb_new = V_(proposal, b);
+        d3 n1 = bv_geo_normal(c, vb_old), n2 = bv_geo_normal(c, vb_new);
+        d3 rel = vb_new.p - vb_old.p;
+        Float l = len(rel);
+        if (l == 0) return false;
+        rel = rel / l;
+        if (dot(n1, n2) < 0) n1 = -n1;
+        d3 n = n1 + n2;
+        n = n - rel * dot(rel, n);
+        l = len(n);
+        if (l == 0) return false;
+        n = n / l;
+        if (!manifoldInit(source, cI, b)) return false;
+        const d3 p0 = W.mv[1].p;
+        if (!manifoldMove(vb_new.p, n)) return false;
+        if (!manifoldUpdate(proposal, cI, b)) return false;
+        if (!manifoldMove(vb_old.p, n)) return false;
+        const d3 p1 = W.mv[1].p;
+        const Float relerr = len(p0 - p1) / c.cfg.sceneRadius;
+        if (relerr > 10.0 * GD_EPSILON) return false;
+        return true;
+    }
+    __device__ bool generateOffsetPath(const GPath &source, GPath &proposal, MuRec &mu, Float offX, Float offY, int &couldConnectBehindB, bool lightPath)   // :806-936
+    {
+        const int k = source.length();
+        couldConnectBehindB = 0;
+        if (!bv_connectable(V_(source, k - 1))) return false;
+        const int step = -1, a = k - 1;
+        int b, cI;
+        if ((b = getSpecularChainEnd(source, a + step, step)) == -1) return false;
+        if ((cI = getSpecularChainEnd(source, b + step, step)) == -1) return false;
+        const int l = min(a, cI), m = max(a, cI), q = min(b, b + step);
+        mu.l = l; mu.m = m;
+        mu.extra[0] = a; mu.extra[1] = b; mu.extra[2] = cI; mu.extra[3] = step; mu.extra[4] = ERadiance;
+        proposal.clear();
+        for (int i = 0; i < l + 1; ++i) { proposal.pushV(source.v[i]); if (i + 1 < l + 1) proposal.pushE(source.e[i]); }
+        proposal.pushE(allocE());
+        for (int i = l + 1; i < m; ++i) { proposal.pushV(allocV()); proposal.pushE(allocE()); }
+        for (int i = m; i < k + 1; ++i) { proposal.pushV(source.v[i]); if (i + 1 < k + 1) proposal.pushE(source.e[i]); }
+        proposal.v[a] = (short)cloneV(proposal.v[a]);
+        proposal.v[cI] = (short)cloneV(proposal.v[cI]);
+        if (!mutPerturbDirection(source, proposal, step, a, offX, offY)) return false;
+        if (!mutPropagatePerturbation(source, proposal, step, a, b, ERadiance)) return false;
+        if (!bv_connectable(V_(proposal, b))) return false;
+        if (abs(b - cI) > 1) {
+            const bool walkSuccess = mutManifoldWalk(source, proposal, b, cI);
+            if (!walkSuccess && lightPath) return false;
+            if (!walkSuccess) {
+                for (int i = b + step; i != cI; i += step) proposal.v[i] = (short)cloneV(source.v[i]);
+                mu.extra[2] = b + step;
+            }
+        }
+        couldConnectBehindB = gConnect(VN(proposal, q - 1), V_(proposal, q), E_(proposal, q), V_(proposal, q + 1), VN(proposal, q + 2),
+                                       bv_connectable(V_(source, q)) ? M_AREA : M_DISCRETE, bv_connectable(V_(source, q + 1)) ? M_AREA : M_DISCRETE) ? 1 : 0;
+        if (lightPath && !couldConnectBehindB) return false;
+        if (m >= k - 1) { BV &s1 = V_(proposal, k - 1); sensor_sample_position(c, V_(proposal, k - 2).p - s1.p, s1.u, s1.v); }
+        for (int i = 0; i <= proposal.length(); i++) {
+            BV &pv = V_(proposal, i); const BV &sv = V_(source, i);
+            pv.rr = sv.rr;
+            if (pv.type == T_SURFACE && pv.componentType == 0) pv.componentType = sv.componentType;
+        }
+        return true;
+    }
+
+    // ---- MIS weights, path.cpp:49-378 ----
+    __device__ void collectPdfs(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, Float *pdfImp, Float *pdfRad)
+    {
+        const int k = s + t + 1, n = k + 1;
+        const BV *vsPred = VN(emitterSubpath, s - 1), *vtPred = VN(sensorSubpath, t - 1); const BV &vs = V_(emitterSubpath, s), &vt = V_(sensorSubpath, t);
+        for (int i = 0; i < n; i++) { pdfImp[i] = 0.0; pdfRad[i] = 0.0; }
+        int pos = 0;
+        pdfImp[pos++] = 1.0;
+        for (int i = 0; i < s; ++i) pdfImp[pos++] = V_(emitterSubpath, i).pdf[EImportance] * E_(emitterSubpath, i).tr[EImportance];
+        pdfImp[pos++] = bv_eval_pdf(c, vs, vsPred, &vt, EImportance, M_AREA) * connectionEdge.tr[EImportance];
+        if (t > 0) {
+            pdfImp[pos++] = bv_eval_pdf(c, vt, &vs, vtPred, EImportance, M_AREA) * E_(sensorSubpath, t - 1).tr[EImportance];
+            for (int i = t - 1; i > 0; --i) pdfImp[pos++] = V_(sensorSubpath, i).pdf[EImportance] * E_(sensorSubpath, i - 1).tr[EImportance];
+        }
+        pos = 0;
+        if (s > 0) {
+            for (int i = 0; i < s - 1; ++i) pdfRad[pos++] = V_(emitterSubpath, i + 1).pdf[ERadiance] * E_(emitterSubpath, i).tr[ERadiance];
+            pdfRad[pos++] = bv_eval_pdf(c, vs, &vt, vsPred, ERadiance, M_AREA) * E_(emitterSubpath, s - 1).tr[ERadiance];
+        }
+        pdfRad[pos++] = bv_eval_pdf(c, vt, vtPred, &vs, ERadiance, M_AREA) * connectionEdge.tr[ERadiance];
+        for (int i = t; i > 0; --i) pdfRad[pos++] = V_(sensorSubpath, i - 1).pdf[ERadiance] * E_(sensorSubpath, i - 1).tr[ERadiance];
+        pdfRad[pos++] = 1.0;
+    }
+    __device__ void stripGeometry(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int k, Float *pdfImp, Float *pdfRad)   // path.cpp:143-167,309-349
+    {
+        const char *cs = W.connectableStrict;
+        for (int i = 1; i <= k - 3; ++i) {
+            if (i == s || !(cs[i] && !cs[i + 1])) continue;
+            const BV &cur = i <= s ? V_(emitterSubpath, i) : V_(sensorSubpath, k - i);
+            const BV &succ = i + 1 <= s ? V_(emitterSubpath, i + 1) : V_(sensorSubpath, k - i - 1);
+            const BE &edge = i < s ? E_(emitterSubpath, i) : E_(sensorSubpath, k - i - 1);
+            pdfImp[i + 1] *= edge.length * edge.length / fabs((bv_on_surface(succ) ? dot(edge.d, bv_geo_normal(c, succ)) : 1) * (bv_on_surface(cur) ? dot(edge.d, bv_geo_normal(c, cur)) : 1));
+        }
+        for (int i = k - 1; i >= 3; --i) {
+            if (i - 1 == s || !(cs[i] && !cs[i - 1])) continue;
+            const BV &cur = i <= s ? V_(emitterSubpath, i) : V_(sensorSubpath, k - i);
+            const BV &succ = i - 1 <= s ? V_(emitterSubpath, i - 1) : V_(sensorSubpath, k - i + 1);
+            const BE &edge = i <= s ? E_(emitterSubpath, i - 1) : E_(sensorSubpath, k - i);
+            pdfRad[i - 1] *= edge.length * edge.length / fabs((bv_on_surface(succ) ? dot(edge.d, bv_geo_normal(c, succ)) : 1) * (bv_on_surface(cur) ? dot(edge.d, bv_geo_normal(c, cur)) : 1));
+        }
+    }
+    __device__ void classify(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int t)
+    {
+        int n = 0;
+        for (int i = 0; i <= s; ++i) { const BV &v = V_(emitterSubpath, i); W.connectable[n] = connectable_gbdpt(c, v); W.connectableStrict[n] = bv_connectable(v); n++; }
+        for (int i = t; i >= 0; --i) { const BV &v = V_(sensorSubpath, i); W.connectable[n] = connectable_gbdpt(c, v); W.connectableStrict[n] = bv_connectable(v); n++; }
+    }
+    __device__ Float miWeightBase(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, bool lightImage, Float geomTermX)
+    {
+        const int k = s + t + 1;
+        classify(emitterSubpath, sensorSubpath, s, t);
+        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, W.pdfImp, W.pdfRad);
+        stripGeometry(emitterSubpath, sensorSubpath, s, k, W.pdfImp, W.pdfRad);
+        double sum_p = 0.0, p_st = 0.0;
+        for (int p = 0; p < s + t + 1; ++p) {
+            double p_i = 1.0;
+            for (int i = 1; i < p + 1; ++i) p_i *= W.pdfImp[i];
+            for (int i = p + 1; i < s + t + 1; ++i) p_i *= W.pdfRad[i];
+            const int tPrime = k - p - 1;
+            const bool allowedToConnect = W.connectable[p] && W.connectable[p + 1];
+            const double v2 = (p_i * geomTermX) * (p_i * geomTermX);                         // std::pow(x, 2.0)
+            if (allowedToConnect && (lightImage || tPrime > 1)) sum_p += v2;
+            if (tPrime == t) p_st = v2;
+        }
+        return (Float)(p_st / sum_p);
+    }
+    __device__ Float miWeightGrad(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath,
+                                  const GPath &offsetEmitterSubpath, const BE &offsetConnectionEdge, const GPath &offsetSensorSubpath,
+                                  int s, int t, bool lightImage, Float jDet, Float geomTermX, Float geomTermY)
+    {
+        const int k = s + t + 1;
+        classify(emitterSubpath, sensorSubpath, s, t);
+        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, W.pdfImp, W.pdfRad);
+        collectPdfs(offsetEmitterSubpath, offsetConnectionEdge, offsetSensorSubpath, s, t, W.oPdfImp, W.oPdfRad);
+        stripGeometry(emitterSubpath, sensorSubpath, s, k, W.pdfImp, W.pdfRad);
+        stripGeometry(offsetEmitterSubpath, offsetSensorSubpath, s, k, W.oPdfImp, W.oPdfRad);
+        double sum_p_i = 0.0, p_st = 0.0;
+        for (int p = 0; p < s + t + 1; ++p) {
+            double value = 1.0, oValue = 1.0;
+            for (int i = 1; i < p + 1; ++i) { value *= W.pdfImp[i]; oValue *= W.oPdfImp[i]; }
+            for (int i = p + 1; i < s + t + 1; ++i) { value *= W.pdfRad[i]; oValue *= W.oPdfRad[i]; }
+            const int tPrime = k - p - 1;
+            const bool allowedToConnect = W.connectable[p] && W.connectable[p + 1];
+            if (allowedToConnect && (lightImage || tPrime > 1)) sum_p_i += value * geomTermX + oValue * jDet * geomTermY;   // std::pow(x, 1.0)
+            if (tPrime == t) p_st = value * geomTermX;
+        }
+        return (Float)(p_st / sum_p_i);
+    }
+
+    // ---- GBDPTRenderer, gbdpt_proc.cpp ----
+    __device__ bool createShiftablePath(GPath &connectedPath, GPath &emitterSubpath, GPath &sensorSubpath, int s, int t, int &memPointer)   // :600-662
+    {
+        connectedPath.clear();
+        while (!connectable_gbdpt(c, V_(sensorSubpath, t))) { t--; sensorSubpath.nv--; sensorSubpath.ne--; }
+        if (V_(sensorSubpath, t).type == T_SURFACE && c.V.shade[V_(sensorSubpath, t).prim].emitter >= 0) s = 0;
+        for (memPointer = 0; memPointer < s; memPointer++) { connectedPath.pushV(emitterSubpath.v[memPointer]); connectedPath.pushE(emitterSubpath.e[memPointer]); }
+        connectedPath.pushV(cloneV(emitterSubpath.v[memPointer]));
+        connectedPath.pushE(allocE());
+        connectedPath.pushV(cloneV(sensorSubpath.v[t]));
+        bv_cast_emitter(c, V_(connectedPath, memPointer + 1));
+        for (int i = t - 1; i >= 0; i--) { connectedPath.pushV(sensorSubpath.v[i]); connectedPath.pushE(sensorSubpath.e[i]); }
+        const bool pathSuccess = gConnect(VN(connectedPath, memPointer - 1), V_(connectedPath, memPointer), E_(connectedPath, memPointer), V_(connectedPath, memPointer + 1),
+                                          VN(connectedPath, memPointer + 2),
+                                          bv_connectable(V_(connectedPath, memPointer)) ? M_AREA : M_DISCRETE, bv_connectable(V_(connectedPath, memPointer + 1)) ? M_AREA : M_DISCRETE);
+        if (t == 1) { BV &s1 = V_(connectedPath, connectedPath.nv - 2); sensor_sample_position(c, V_(connectedPath, connectedPath.nv - 3).p - s1.p, s1.u, s1.v); }
+        return pathSuccess;
+    }
+
+    // GBDPTRenderer::process (from the connected base path on, :186-252) + evaluate (:259-534).  The two subpaths are W.emitter / W.sensor[0].
+    __device__ void processSample(SampleOut &wr)
+    {
+        const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+        const BdConfig &cfg = c.cfg;
+        GPath &emitterSubpath = W.emitter;
+        for (int k = 0; k < 5; k++) {
+            W.success[k] = 0; W.couldConnectAfterB[k] = 0;
+            for (int i = 0; i < NSV + 4; i++) { W.jacobianDet[k][i] = 1.0; W.genGeomTerm[k][i] = 1.0; }
+            W.mu[k].l = W.mu[k].m = 0; for (int i = 0; i < 5; i++) W.mu[k].extra[i] = 0;
+        }
+        W.success[0] = 1; W.couldConnectAfterB[0] = 1;
+        GPath &connectPath = W.connect;
+        int ptx = 0;
+        createShiftablePath(connectPath, emitterSubpath, W.sensor[0], 1, W.sensor[0].nv - 1, ptx);
+        computeMuRec(connectPath, W.mu[0]);
+        for (int v = W.mu[0].extra[0] - 1; v >= 0; v--) {
+            const int idx = connectPath.nv - 1 - v;
+            if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[0].extra[2]) W.genGeomTerm[0][idx] = calcSpecularPDFChange(connectPath, v);
+            else W.genGeomTerm[0][idx] = W.genGeomTerm[0][idx - 1];
+        }
+        for (int k = 0; k < 4; k++) {
+            GPath &off = W.sensor[k + 1];
+            off.clear();
+            W.success[k + 1] = W.mu[0].extra[0] <= 2 ? 0 : (generateOffsetPath(connectPath, off, W.mu[k + 1], shifts[k][0], shifts[k][1], W.couldConnectAfterB[k + 1], false) ? 1 : 0);
+            if (W.success[k + 1]) {
+                for (int v = W.mu[k + 1].extra[0] - 1; v >= 0; v--) {
+                    const int idx = connectPath.nv - 1 - v;
+                    if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[k + 1].extra[2]) {
+                        const int a = W.mu[k + 1].extra[0];
+                        const int b = v >= W.mu[k + 1].extra[1] ? v : W.mu[k + 1].extra[1];
+                        const int cI = v >= W.mu[k + 1].extra[1] ? v - 1 : W.mu[k + 1].extra[2];
+                        const double jx = halfJacobian(connectPath, a, b, cI), jy = halfJacobian(off, a, b, cI);
+                        W.jacobianDet[k + 1][idx] = jy / jx;
+                        W.genGeomTerm[k + 1][idx] = calcSpecularPDFChange(off, v);
+                    } else {
+                        W.jacobianDet[k + 1][idx] = W.jacobianDet[k + 1][idx - 1];
+                        W.genGeomTerm[k + 1][idx] = W.genGeomTerm[k + 1][idx - 1];
+                    }
+                }
+            }
+            off.reverse();
+        }
+        const int vert_b = connectPath.nv - 1 - W.mu[0].extra[1];
+        evaluate(wr, vert_b);
+    }
+
+    __device__ void evaluate(SampleOut &wr, int vert_b)
+    {
+        const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+        const BdConfig &cfg = c.cfg;
+        GPath &emitterSubpath = W.emitter;
+        const Float initialX = V_(W.sensor[0], 1).u, initialY = V_(W.sensor[0], 1).v;
+        wr.posX = initialX; wr.posY = initialY;
+        wr.nLight = 0;
+        const int nE = emitterSubpath.nv, nS = W.sensor[0].nv;
+        W.impW[0] = mk(1.0); W.impP[0] = 1.0;
+        for (int i = 1; i < nE; ++i) {
+            const BV &pv = V_(emitterSubpath, i - 1); const BE &pe = E_(emitterSubpath, i - 1);
+            W.impW[i] = W.impW[i - 1] * pv.w[EImportance] * pv.rr * pe.tr[EImportance];
+            W.impP[i] = W.impP[i - 1] * pv.pdf[EImportance] * pv.rr * pe.tr[EImportance];
+        }
+        for (int k = 0; k <= 4; k++) {
+            W.radW[k][0] = mk(1.0); W.radP[k][0] = 1.0;
+            for (int i = 1; i < nS; ++i) {
+                W.radW[k][i] = mk(0.0); W.radP[k][i] = 0.0;
+                if (W.success[k] && i < W.sensor[k].nv) {
+                    const BV &pv = V_(W.sensor[k], i - 1); const BE &pe = E_(W.sensor[k], i - 1);
+                    W.radW[k][i] = W.radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
+                    W.radP[k][i] = W.radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+                }
+            }
+        }
+        d3 primal = mk(0.0), gradient[4] = {mk(0.0), mk(0.0), mk(0.0), mk(0.0)};
+        GPath &offsetEmitterSubpath = W.offsetEmitter, &connectedBasePath = W.connectedBase;
+        Float geomTermBase = 0.0; d3 connectionPartsBase = mk(0.0), offsetImportanceWeight = mk(0.0);
+        BE connectionEdge, connectionEdgeBase;
+        be_clear(connectionEdge); be_clear(connectionEdgeBase);
+        bool successConnectBase = false;
+        Float offsetImportancePdf = 0;
+        d3 value[5]; Float miWeight[5], valuePdf[5];
+        double jacobianLP[4] = {1.0, 1.0, 1.0, 1.0}, genGeomTermLP[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
+        bool pathSuccess[5];
+        for (int s = nE - 1; s >= 0; --s) {
+            const int minT = max(2 - s, cfg.lightImage ? 1 : 2);
+            const int maxT = min(nS - 1, cfg.maxDepth + 1 - s);
+            for (int t = maxT; t >= minT; --t) {
+                Float samplePosX = initialX, samplePosY = initialY;
+                if (t == 1) {
+                    const BV &v1 = V_(W.sensor[0], 1);
+                    if ((v1.type == T_SENSOR_SAMPLE && !sensor_sample_position(c, V_(emitterSubpath, s).p - v1.p, samplePosX, samplePosY)) || !connectable_gbdpt(c, V_(emitterSubpath, s))) continue;
+                }
+                const int markV = W.nv, markE = W.ne;                                        // (the light path's clones and offsets live until the end of this connection)
+                int memPointer = 0;
+                MuRec muRec; muRec.l = muRec.m = 0; for (int i = 0; i < 5; i++) muRec.extra[i] = 0;
+                for (int k = 0; k <= 4; k++) {
+                    miWeight[k] = 1.0 / (s + t + 1);
+                    pathSuccess[k] = W.success[k] != 0;
+                    value[k] = mk(0.0);
+                    valuePdf[k] = 0.0;
+                    d3 importanceWeightTmp = W.impW[s], radianceWeightTmp = W.radW[t == 1 ? 0 : k][t];
+                    Float importancePdfTmp = W.impP[s], radiancePdfTmp = W.radP[t == 1 ? 0 : k][t];
+                    const GPath *sensorSubpathTmp = &W.sensor[k], *emitterSubpathTmp = &emitterSubpath;
+                    if (t == 1 && k == 0) {
+                        pathSuccess[0] = createShiftablePath(connectedBasePath, emitterSubpath, W.sensor[0], s, 1, memPointer);
+                        computeMuRec(connectedBasePath, muRec);
+                        genGeomTermLP[0] = calcSpecularPDFChange(connectedBasePath, muRec.extra[2], true);
+                    }
+                    if (t == 1 && k > 0 && !is_zero(value[0])) {
+                        if (!pathSuccess[0]) pathSuccess[k] = false;
+                        else {
+                            // createShiftedLightPath, :568-590
+                            jacobianLP[k - 1] = 1.0;
+                            int couldConnectWithB = 0;
+                            pathSuccess[k] = generateOffsetPath(connectedBasePath, offsetEmitterSubpath, muRec, shifts[k - 1][0], shifts[k - 1][1], couldConnectWithB, true);
+                            if (pathSuccess[k]) {
+                                jacobianLP[k - 1] = halfJacobian(offsetEmitterSubpath, muRec.extra[0], muRec.extra[1], muRec.extra[2]) / halfJacobian(connectedBasePath, muRec.extra[0], muRec.extra[1], muRec.extra[2]);
+                                offsetImportancePdf = 1.0;
+                                offsetImportanceWeight = mk(1.0);
+                                for (int i = 1; i <= s; ++i) {
+                                    const BV &pv = V_(offsetEmitterSubpath, i - 1); const BE &pe = E_(offsetEmitterSubpath, i - 1);
+                                    offsetImportanceWeight = offsetImportanceWeight * pv.w[EImportance] * pv.rr * pe.tr[EImportance];
+                                    offsetImportancePdf = offsetImportancePdf * pv.pdf[EImportance] * pv.rr * pe.tr[EImportance];
+                                }
+                                genGeomTermLP[k] = calcSpecularPDFChange(offsetEmitterSubpath, muRec.extra[2], true);
+                                importanceWeightTmp = offsetImportanceWeight;
+                                importancePdfTmp = offsetImportancePdf;
+                                emitterSubpathTmp = &offsetEmitterSubpath;
+                            }
+                            sensorSubpathTmp = &W.sensor[0];
+                        }
+                    }
+                    Float geomTerm = 0.0;
+                    do {
+                        if (!(pathSuccess[k] && pathSuccess[0] && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
+                        if (!W.couldConnectAfterB[k] && t > vert_b) break;
+                        BV *vsPred = VN(*emitterSubpathTmp, s - 1), *vtPred = VN(*sensorSubpathTmp, t - 1);
+                        BV &vs = W.v[emitterSubpathTmp->v[s]], &vt = W.v[sensorSubpathTmp->v[t]];
+                        if (vs.type == T_EMITTER_SUPER) {
+                            if (!bv_cast_emitter(c, vt) || vt.degenerate) { valuePdf[k] = radiancePdfTmp; break; }
+                            const d3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : gEval(vs, vsPred, &vt, EImportance) * gEval(vt, vtPred, &vs, ERadiance);
+                            if (k == 0) connectionPartsBase = connectionParts;
+                            value[k] = radianceWeightTmp * connectionParts;
+                            valuePdf[k] = radiancePdfTmp;
+                        } else if (vt.type == T_SENSOR_SUPER) { valuePdf[k] = importancePdfTmp; break; }
+                        else {
+                            if (!connectable_gbdpt(c, vs) || !connectable_gbdpt(c, vt) || vs.type == 0 || vt.type == 0) { valuePdf[k] = importancePdfTmp * radiancePdfTmp; break; }
+                            const d3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : gEval(vs, vsPred, &vt, EImportance) * gEval(vt, vtPred, &vs, ERadiance);
+                            if (k == 0) connectionPartsBase = connectionParts;
+                            value[k] = importanceWeightTmp * radianceWeightTmp * connectionParts;
+                            valuePdf[k] = importancePdfTmp * radiancePdfTmp;
+                            vs.measure = vt.measure = M_AREA;
+                        }
+                        if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                        const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connectionEdge, vs, vt);
+                        if (k == 0) successConnectBase = successConnect;
+                        if (!successConnect) { value[k] = mk(0.0); break; }
+                        geomTerm = (k > 0 && t > vert_b) ? geomTermBase : gEdgeEvalCached(connectionEdge, vs, vt, 0x04 | 0x08 | 0x10 | 0x20);
+                        value[k] = value[k] * geomTerm;
+                        valuePdf[k] *= (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t]);
+                        if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                        if (k == 0) {
+                            connectionEdgeBase = connectionEdge;
+                            geomTermBase = geomTerm;
+                            miWeight[0] = miWeightBase(emitterSubpath, connectionEdgeBase, W.sensor[0], s, t, cfg.lightImage != 0, (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t])) / valuePdf[0];
+                        } else {
+                            miWeight[k] = miWeightGrad(emitterSubpath, connectionEdgeBase, W.sensor[0], *emitterSubpathTmp, connectionEdge, *sensorSubpathTmp, s, t, cfg.lightImage != 0,
+                                                       (t < 2 ? jacobianLP[k - 1] : W.jacobianDet[k][t]), (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t]), (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t])) / valuePdf[0];
+                        }
+                    } while (false);
+#ifdef GDPT_BD_TRACE
+                    printf("G st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\\n", s, t, k, (int)pathSuccess[k], value[k].x, value[k].y, value[k].z, valuePdf[k], miWeight[k], geomTerm, c.nClosest, c.nShadow);
+#endif
+                    if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miWeight[k] = miWeight[0]; valuePdf[k] = valuePdf[0]; }
+                }
+                W.nv = markV; W.ne = markE;
+                if (is_zero(value[0])) continue;
+                const d3 mainRad = value[0] * (valuePdf[0] * miWeight[0]);
+                if (t >= 2) primal = primal + mainRad;
+                else if (wr.nLight < BD_MAX_LIGHT) { LightSplat &ls = wr.light[wr.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+                const d3 fx = value[0] * valuePdf[0];
+                for (int n = 0; n < 4; n++) {
+                    const d3 fy = value[n + 1] * valuePdf[n + 1] * (Float)(t < 2 ? jacobianLP[n] : W.jacobianDet[n + 1][t]);
+                    const d3 gradVal = (fy - fx) * ((Float)2.0 * miWeight[n + 1]);
+                    if (t >= 2) gradient[n] = gradient[n] + gradVal;
+                    else if (wr.nLight < BD_MAX_LIGHT) { LightSplat &ls = wr.light[wr.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
+                }
+            }
+        }
+        wr.primal = primal;
+        for (int k = 0; k < 4; ++k) wr.gradient[k] = gradient[k];
+    }
+
+    // the two subpaths of a walked sample -> pool records and index lists
+    __device__ void loadSubpaths(const Sample &sm)
+    {
+        W.nv = W.ne = 0; W.overflow = 0;
+        W.emitter.clear(); W.sensor[0].clear();
+        for (int i = 0; i < sm.nY; i++) { const int j = allocV(); W.v[j] = sm.Y[i]; W.emitter.pushV(j); if (i + 1 < sm.nY) { const int e = allocE(); W.e[e] = sm.EY[i]; W.emitter.pushE(e); } }
+        for (int i = 0; i < sm.nX; i++) { const int j = allocV(); W.v[j] = sm.X[i]; W.sensor[0].pushV(j); if (i + 1 < sm.nX) { const int e = allocE(); W.e[e] = sm.EX[i]; W.sensor[0].pushE(e); } }
+    }
+};
+
+// does the sample need the general form?  (a surface vertex of either subpath that is not connectable in the sense of Path::isConnectable_GBDPT)
+__device__ bool sample_needs_general(const Ctx &c, const Sample &sm)
+{
+    for (int i = 2; i < sm.nX; i++) if (sm.X[i].type == T_SURFACE && !connectable_gbdpt(c, sm.X[i])) return true;
+    for (int i = 2; i < sm.nY; i++) if (sm.Y[i].type == T_SURFACE && !connectable_gbdpt(c, sm.Y[i])) return true;
+    return false;
+}
+
+} // namespace gdpt_bd

@@ -38,6 +38,7 @@ struct BdConfig {
     Float shiftThreshold;
     unsigned long long seed;
     int sBase, sCount;                             // the samples [sBase, sBase + sCount) of every pixel are rendered by this launch
+    Float sceneRadius;                             // m_scene->getBSphere().radius (the kd-tree's enlarged bounds): the yardstick of the manifold walk's reversibility test
 };
 struct BdCam {                                     // perspective sensor quantities beyond CameraD (perspective.cpp:167-173,190-247)
     Float invLin[9];                               // linear part of the inverse camera-to-world (trafo.inverse() applied to a direction)
@@ -271,6 +272,49 @@ __device__ __forceinline__ Float edge_geometry_term(const Ctx &c, const BE &e, c
     return result;
 }
 
+// ---- BSDFs as libbidir asks for them: transport mode (dielectric.cpp:248-250,296-298: radiance is scaled when it crosses the interface,
+// importance is not) and a component mask (PathVertex::propagatePerturbation takes ONE delta component, vertex.cpp:696-700) -----------------
+__device__ void bd_eval_pdf(const MaterialD &m, d3 R, d3 wi, d3 wo, int measure, bool importance, int typeMask, d3 &f, Float &pdf)
+{
+    if (m.type == 3) {
+        f = mk(0.0); pdf = 0.0;
+        Float cosThetaT;
+        const Float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta.x);
+        if (measure != MEASURE_DISCRETE) return;
+        const bool sampleReflection = (typeMask & EDeltaReflection) != 0, sampleTransmission = (typeMask & EDeltaTransmission) != 0;
+        if (wi.z * wo.z >= 0) {
+            if (!sampleReflection || fabs(dot(mk(-wi.x, -wi.y, wi.z), wo) - 1) > GD_DELTA_EPSILON) return;
+            f = R * F; pdf = sampleTransmission ? F : 1.0;
+        } else {
+            if (!sampleTransmission || fabs(dot(dielectric_refract(m, wi, cosThetaT), wo) - 1) > GD_DELTA_EPSILON) return;
+            const Float factor = importance ? 1.0 : (cosThetaT < 0 ? 1 / m.eta.x : m.eta.x);
+            f = m.k * factor * factor * (1 - F); pdf = sampleReflection ? 1 - F : 1.0;
+        }
+        return;
+    }
+    if (m.type == 1 && !(typeMask & EDeltaReflection)) { f = mk(0.0); pdf = 0.0; return; }
+    bsdf_eval_pdf(m, R, wi, wo, measure, f, pdf);
+}
+__device__ void bd_sample(const MaterialD &m, d3 R, d3 wi, Float sx, Float sy, bool importance, int typeMask, BSDFSample &r)
+{
+    if (m.type == 3) {
+        r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.eta = 1.0; r.sampledType = 0;
+        Float cosThetaT;
+        const Float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta.x);
+        const bool sampleReflection = (typeMask & EDeltaReflection) != 0, sampleTransmission = (typeMask & EDeltaTransmission) != 0;
+        const Float factor = importance ? 1.0 : (cosThetaT < 0 ? 1 / m.eta.x : m.eta.x);
+        if (sampleReflection && sampleTransmission) {
+            if (sx <= F) { r.sampledType = EDeltaReflection; r.wo = mk(-wi.x, -wi.y, wi.z); r.pdf = F; r.weight = R; }
+            else { r.sampledType = EDeltaTransmission; r.wo = dielectric_refract(m, wi, cosThetaT); r.eta = cosThetaT < 0 ? m.eta.x : 1 / m.eta.x; r.pdf = 1 - F; r.weight = m.k * (factor * factor); }
+        } else if (sampleReflection) { r.sampledType = EDeltaReflection; r.wo = mk(-wi.x, -wi.y, wi.z); r.pdf = 1.0; r.weight = R * F; }
+        else if (sampleTransmission) { r.sampledType = EDeltaTransmission; r.wo = dielectric_refract(m, wi, cosThetaT); r.eta = cosThetaT < 0 ? m.eta.x : 1 / m.eta.x; r.pdf = 1.0; r.weight = m.k * (factor * factor * (1 - F)); }
+        return;
+    }
+    if (m.type == 1 && !(typeMask & EDeltaReflection)) { r.wo = mk(0.0); r.weight = mk(0.0); r.pdf = 0.0; r.eta = 1.0; r.sampledType = 0; return; }
+    bsdf_sample(m, R, wi, sx, sy, r);
+}
+constexpr int BD_ALL = EDelta | ESmooth;
+
 // ---- PathVertex ----------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void adjoint(BV &v, int mode, d3 wiL, d3 woL, Float wiDotGeoN, Float woDotGeoN)   // vertex.cpp:213-221,611-619
 {
@@ -327,7 +371,7 @@ __device__ __noinline__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE
         const d3 wiL = toLocal(sf.fr, wi);
         const Float sx = c.rng.next1D(), sy = c.rng.next1D();
         BSDFSample bs;
-        bsdf_sample(sf.m, sf.R, wiL, sx, sy, bs);
+        bd_sample(sf.m, sf.R, wiL, sx, sy, mode == EImportance, BD_ALL, bs);
         v.w[mode] = bs.weight; v.pdf[mode] = bs.pdf;
         if (is_zero(v.w[mode])) return false;
         v.measure = (bs.sampledType & ESmooth) ? M_SOLID : M_DISCRETE;
@@ -336,12 +380,15 @@ __device__ __noinline__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE
         const Float wiDotGeoN = dot(sf.geoN, wi), woDotGeoN = dot(sf.geoN, wo);
         if (wiDotGeoN * wiL.z <= 0 || woDotGeoN * bs.wo.z <= 0) return false;
         d3 fRev; Float pRev;
-        bsdf_eval_pdf(sf.m, sf.R, bs.wo, wiL, bsdf_measure(v.measure), fRev, pRev);          // bRec.reverse(); bsdf->pdf
+        bd_eval_pdf(sf.m, sf.R, bs.wo, wiL, bsdf_measure(v.measure), (1 - mode) == EImportance, BD_ALL, fRev, pRev);   // bRec.reverse() (flips the mode too); bsdf->pdf
         v.pdf[1 - mode] = pRev;
         if (v.pdf[1 - mode] <= 0x1p-1024) return false;
-        v.w[1 - mode] = v.w[mode] * (v.pdf[mode] / v.pdf[1 - mode]);
-        if (v.measure == M_SOLID) v.w[1 - mode] = v.w[1 - mode] * fabs(wiL.z / bs.wo.z);
+        if (sf.m.type != 3) {                                                              // (the dielectric is the one ENonSymmetric BSDF of the subset, dielectric.cpp:87-98)
+            v.w[1 - mode] = v.w[mode] * (v.pdf[mode] / v.pdf[1 - mode]);
+            if (v.measure == M_SOLID) v.w[1 - mode] = v.w[1 - mode] * fabs(wiL.z / bs.wo.z);
+        } else v.w[1 - mode] = fRev / v.pdf[1 - mode];
         adjoint(v, mode, wiL, bs.wo, wiDotGeoN, woDotGeoN);
+        if (mode == ERadiance && bs.eta != 1) throughput = throughput * (bs.eta * bs.eta);     // "for BDPT & russian roulette, track radiance * eta^2", vertex.cpp:225-227
         ro = v.p; rd = wo;
     } else return false;
     throughput = throughput * v.w[mode];

@@ -69,6 +69,12 @@ class Film:
         check(lib().gdpt_gbdpt_film_stats(self._h, s))
         return dict(raysTraced=int(s[0]), shadowRaysTraced=int(s[1]), samples=int(s[2]), invalidPuts=int(s[3]))
 
+    def chain_stats(self):
+        """Samples since the last clear that ran in the general form (specular chains), and how often that form's workspace ran out (0)."""
+        s = (C.c_ulonglong * 2)()
+        check(lib().gdpt_gbdpt_film_chain_stats(self._h, s))
+        return dict(generalSamples=int(s[0]), overflows=int(s[1]))
+
     def render_ms(self):
         lib().gdpt_gbdpt_film_render_ms.restype = C.c_float
         return float(lib().gdpt_gbdpt_film_render_ms(self._h))
@@ -119,11 +125,12 @@ class GBDPTIntegrator:
         out = np.zeros(17, np.float64)
         light = np.zeros((max_light, 6), np.float64)
         n = C.c_int(0)
-        cnt = (C.c_ulonglong * 2)()
-        check(lib().gdpt_gbdpt_evaluate_sample(scene._h, C.byref(cfg), px, py, sample, out.ctypes.data_as(C.c_void_p), max_light,
-                                               light.ctypes.data_as(C.c_void_p), C.byref(n), cnt))
+        cnt = (C.c_ulonglong * 4)()
+        check(lib().gdpt_gbdpt_evaluate_sample2(scene._h, C.byref(cfg), px, py, sample, out.ctypes.data_as(C.c_void_p), max_light,
+                                                light.ctypes.data_as(C.c_void_p), C.byref(n), cnt))
+        # general: the sample met a specular vertex and ran in the general form (manifold walks); overflow: its workspace ran out (must be 0)
         return dict(primal=out[0:3], gradients=out[3:15].reshape(4, 3), position=out[15:17], light=light[:min(n.value, max_light)].copy(),
-                    raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]))
+                    raysTraced=int(cnt[0]), shadowRaysTraced=int(cnt[1]), general=bool(cnt[2]), overflow=int(cnt[3]))
 
     def render(self, scene, spp, seed=5489, film=None, reconstruct=True):
         """GBDPTIntegrator::render (gbdpt.cpp:140-262).  Returns {suffix: image [H, W, 3]}: the five sampler buffers as developed doubles,

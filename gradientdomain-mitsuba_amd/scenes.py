@@ -319,11 +319,14 @@ def atrium(width=1920, height=1080, columns=24, segments=48, seed=7):
                     width=width, height=height, name="atrium")
 
 
-def veach_bidir(width=1280, height=720):
-    """Veach-bidir-class stand-in (BASELINE config 5; the original asset -- and its glass egg -- are not available offline): a closed room lit
-    almost entirely INDIRECTLY: an up-light inside a shade that only lets light reach the ceiling, and a wall sconce that faces the wall
-    behind it; a table with a smooth rough-aluminium sphere (interpolated normals), a diffuse sphere and a rough-copper block.  Every BSDF
-    is smooth with roughness far above shiftThreshold: the scope the G-BDPT sampler of this library carries (no specular chains)."""
+def veach_bidir(width=1280, height=720, specular=False):
+    """Veach-bidir-class stand-in (BASELINE config 5; the original asset is not available offline): a closed room lit almost entirely
+    INDIRECTLY: an up-light inside a shade that only lets light reach the ceiling, and a wall sconce that faces the wall behind it; a table
+    with a smooth rough-aluminium sphere (interpolated normals), an egg-sized sphere and a rough-copper block.
+    specular=False (rounds 1-3): every BSDF smooth with roughness far above shiftThreshold, the egg diffuse -- no specular chains.
+    specular=True (round 4, what the scene's name stands for): the egg is solid GLASS (bk7, interpolated normals), a framed MIRROR hangs on the
+    back wall and the block is polished copper (a perfect conductor): caustics under the egg, the room seen in the mirror -- the paths that need
+    G-BDPT's manifold walks."""
     b = _Builder()
     wall = b.material(diffuse((0.72, 0.7, 0.66)))
     floor_m = b.material(diffuse((0.45, 0.3, 0.18)))
@@ -331,7 +334,10 @@ def veach_bidir(width=1280, height=720):
     shade = b.material(twosided(diffuse((0.8, 0.75, 0.6))))
     alu = b.material(roughconductor(0.15, **AL, distribution=DISTR_GGX))
     copper = b.material(roughconductor(0.1, **CU))
-    egg = b.material(diffuse((0.75, 0.75, 0.7)))
+    egg = b.material(dielectric() if specular else diffuse((0.75, 0.75, 0.7)))
+    if specular:
+        copper = b.material(conductor(**CU))
+        mirror = b.material(conductor(**AL))
     lightm = b.material(diffuse((0.5, 0.5, 0.5)))
     room = (0.0, 1.5, 0.0)
     X, Y, Z = 4.0, 3.0, 3.0
@@ -347,6 +353,8 @@ def veach_bidir(width=1280, height=720):
     b.sphere((-0.6, 1.3, 0.1), 0.3, alu, level=2)
     b.sphere((0.25, 1.2, -0.3), 0.2, egg, level=2)
     b.box([(0.7, 1.35, 0.0), (0.7, 1.35, 0.4), (1.1, 1.35, 0.4), (1.1, 1.35, 0.0)], 1.0, copper)
+    if specular:                                   # a mirror on the wall the camera faces, 2 cm in front of it
+        b.quad((-2.2, 0.9, Z - 0.02), (0.6, 0.9, Z - 0.02), (0.6, 2.4, Z - 0.02), (-2.2, 2.4, Z - 0.02), mirror, room)
     # up-light: emitter facing up inside a four-sided shade (two-sided diffuse), open at the top only
     cx, cy, cz, r, hgt = -2.6, 1.9, 0.8, 0.25, 0.5
     for (a0, a1) in (((cx - r, cz - r), (cx + r, cz - r)), ((cx + r, cz - r), (cx + r, cz + r)), ((cx + r, cz + r), (cx - r, cz + r)), ((cx - r, cz + r), (cx - r, cz - r))):

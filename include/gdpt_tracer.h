@@ -301,6 +301,13 @@ GDPT_API int   gdpt_gbdpt_film_stats(gdpt_gbdpt_film *f, unsigned long long stat
  * (x, y, buffer, r, g, b), at most maxLight of them (*nLight = how many there were); counters = closest-hit / shadow rays */
 GDPT_API int   gdpt_gbdpt_evaluate_sample(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17],
                                           int maxLight, double *light6, int *nLight, unsigned long long counters[2]);
+/* the same with counters[4] = closest-hit rays, shadow rays, 1 if the sample ran in the general form (it met a specular vertex: conductor,
+ * dielectric, a rough conductor below shiftThreshold -- offset paths by propagatePerturbation + manifoldWalk, mut_manifold.cpp:989-1227), and the
+ * number of times that form's per-sample workspace ran out (0: the result is complete) */
+GDPT_API int   gdpt_gbdpt_evaluate_sample2(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int px, int py, int sample, double out17[17],
+                                           int maxLight, double *light6, int *nLight, unsigned long long counters[4]);
+/* since the last clear: stats[0] samples that ran in the general form (specular chains), stats[1] workspace overflows among them (0 = none) */
+GDPT_API int   gdpt_gbdpt_film_chain_stats(gdpt_gbdpt_film *f, unsigned long long stats[2]);
 
 #ifdef __cplusplus
 }
