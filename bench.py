@@ -236,7 +236,9 @@ def bench_gbdpt(a, rank, local, world, dev):
     import torch
     import torch.distributed as dist
     from gradientdomain_mitsuba_amd import gbdpt, gpt, parallel, scenes
-    desc = scenes.veach_bidir(W, H)
+    # the scene class the configuration names: a glass egg, a mirror and polished copper in the indirectly lit room (round 4: paths with specular
+    # chains run the general form of the sampler, manifold walks and all); --bd-connectable renders rounds 1-3's stand-in (every BSDF connectable)
+    desc = scenes.veach_bidir(W, H, specular=not a.bd_connectable)
     scene = gpt.Scene(desc, device=local)
     integ = gbdpt.GBDPTIntegrator(maxDepth=MAX_DEPTH)
     sr = parallel.GBDPTStripRenderer(scene, integ, rank, world, dev)
@@ -250,12 +252,14 @@ def bench_gbdpt(a, rank, local, world, dev):
         sr.render(a.spp)
     barrier()
     t0 = time.perf_counter()
-    rays = samples = closest = 0
+    rays = samples = closest = general = 0
     render_ms = 0.0
     solve = [0.0, 0.0]
     phases = {}
     for _ in range(a.steps):
         sr.render(a.spp)
+        general += sr.last["chain"]["generalSamples"]
+        assert sr.last["chain"]["overflows"] == 0
         rays += sr.last["rays"]; samples += sr.last["samples"]; render_ms += sr.last["render_ms"]; closest += sr.last["closest_rays"]
         solve[0] += sr.last["solve_s"][0]; solve[1] += sr.last["solve_s"][1]
         for k, v in sr.last["phases_ms"].items():
@@ -302,7 +306,9 @@ def bench_gbdpt(a, rank, local, world, dev):
         out = {"metric": "shift-mapped Mray/s + Poisson-CG Mpix-iter/s, %dx%dx%dspp (G-BDPT)" % (W, H, a.spp),
                "value": round(rays / wall / 1e6, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * wall / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "Veach-bidir-class room (build-authored, %d triangles, all BSDFs connectable), G-BDPT %d spp, %dx%d, fp64 sampler, L2D + L1D reconstruct (BASELINE configs[4])" % (desc.ntri, a.spp, W, H),
+               "config": {"workload": "Veach-bidir-class room (build-authored, %d triangles, %s), G-BDPT %d spp, %dx%d, fp64 sampler, L2D + L1D reconstruct (BASELINE configs[4])" % (
+                              desc.ntri, "all BSDFs connectable: rounds 1-3's stand-in" if a.bd_connectable else "glass egg + mirror + polished copper: specular chains, manifold walks", a.spp, W, H),
+                          "general_form_sample_share": round(general / max(samples, 1.0), 4) if world == 1 else None,
                           "maxDepth": 12, "rrDepth": 5, "lightImage": True, "parallelism": "row strips of camera samples x%d + one film reduction onto rank 0" % world, "strip_rows": [s1 - s0 for (s0, s1) in sr.strips]},
                "rays_per_step": round(rays / a.steps), "rays_per_sample": round(rays / max(samples, 1.0), 2), "msample_s": round(samples / wall / 1e6, 3),
                "render_kernel_ms_per_step": round(render_ms / a.steps, 3), "phases_ms_per_step": {k: round(v / a.steps, 3) for k, v in phases.items()},
@@ -325,6 +331,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-5); 2 is the metric's configuration, 5 = G-BDPT")
+    ap.add_argument("--bd-connectable", action="store_true", help="--config 5: the connectable-only stand-in scene of rounds 1-3 instead of the specular one")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-height strips instead of rebalancing them after the warm-up pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the last step's reconstruction and the four gathered solver images to this .npz (tests)")

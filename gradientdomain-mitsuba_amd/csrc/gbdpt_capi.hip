@@ -236,18 +236,22 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
 }
 
 // The general form of a sample (specular chains; gbdpt_general.hip.h): one lane per listed sample, from the connected base path to its last
-// connection, in a workspace of its own.  Persistent lanes (a workspace is ~56 KB: the launch has as many lanes as there are workspaces).
-__global__ __launch_bounds__(64, 1) void k_bd_general(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, const unsigned *__restrict__ genCount,
+// connection, in a workspace of its own.  Persistent lanes (a workspace is ~56 KB: the launch has as many lanes as there are workspaces:
+// two 256-thread blocks per CU = the 2 waves per SIMD its ~216 registers allow; with ONE wave per CU the first version took 957 ms for the
+// 568 k general samples of a 2 spp frame of the specular Veach scene).
+__global__ __launch_bounds__(TBLK, 2) void k_bd_general(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, const unsigned *__restrict__ genCount,
                                                      GWork *__restrict__ work, Float *__restrict__ acc, Float *__restrict__ light, unsigned long long *__restrict__ stats)
 {
-    __shared__ int s_stack[STACK_DEPTH * TBLK];      // (the traversal stack is laid out [level][TBLK]: a 64-lane block uses the first 64 columns of every level)
-    const unsigned lane = blockIdx.x * 64 + threadIdx.x, lanes = gridDim.x * 64;
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    const unsigned lane = blockIdx.x * TBLK + threadIdx.x, lanes = gridDim.x * TBLK;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
     const unsigned n = __hip_atomic_load(genCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned overflow = 0, done = 0;
     GWork &W = work[lane];
-    for (unsigned i = lane; i < n; i += lanes) {
+    (void)lanes;
+    // (samples differ by orders of magnitude in work -- connections, manifold walks: a lane takes the next sample of the list when it is done)
+    for (unsigned i = atomicAdd(const_cast<unsigned *>(genCount) + 1, 1u); i < n; i = atomicAdd(const_cast<unsigned *>(genCount) + 1, 1u)) {
         const unsigned lid = genList[i];
         GTr g(c, W);
         g.loadSubpaths(recs[lid]);
@@ -261,9 +265,13 @@ __global__ __launch_bounds__(64, 1) void k_bd_general(SceneD S, BdCam cam, BdCon
         const size_t plane3 = (size_t)Wd * H * 3;
         for (int k = 0; k < out.nLight; k++) film_put(light + out.light[k].buffer * plane3, 3, Wd, H, out.light[k].x, out.light[k].y, out.light[k].value, false, stats + 3);
     }
-    atomicAdd(stats + 0, (unsigned long long)c.nClosest); atomicAdd(stats + 1, (unsigned long long)c.nShadow);
-    if (done) atomicAdd(stats + 4, (unsigned long long)done);
-    if (overflow) atomicAdd(stats + 5, (unsigned long long)overflow);
+    const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    const unsigned r2 = __builtin_amdgcn_wave_reduce_add_u32(done, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1);
+        if (r2) atomicAdd(stats + 4, (unsigned long long)r2);
+        if (r3) atomicAdd(stats + 5, (unsigned long long)r3);
+    }
 }
 
 __global__ __launch_bounds__(TBLK) void k_bd_put(const Sample *__restrict__ recs, const Float *__restrict__ acc, unsigned count, int W, int H, Float *__restrict__ block, unsigned long long *__restrict__ stats)
@@ -431,7 +439,7 @@ int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
     BHIPCHK(hipMalloc((void **)&f->block, sizeof(Float) * 5 * npix * 4));
     BHIPCHK(hipMalloc((void **)&f->light, sizeof(Float) * 5 * npix * 3));
     BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 8));           // [0..3] the public counters; [4] samples run in the general form, [5] workspace overflows
-    BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned)));
+    BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned) * 2));               // entries of the general list, k_bd_general's cursor
     if (int rc = scene_radius(s, &f->sceneRadius)) { delete f; return rc; }
     BHIPCHK(hipStreamCreate(&f->stream));
     BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1));
@@ -484,8 +492,12 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     bool specularScene = false;
     for (const MaterialD &m : s->hostMats) if (m.type == 1 || m.type == 3 || (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold)) specularScene = true;
     if (specularScene && !f->work) {
-        unsigned lanes = (unsigned)std::min<size_t>((size_t)s->numCUs * 64, ((size_t)1 << 30) / sizeof(GWork));
-        lanes = std::max(64u, lanes / 64 * 64);
+        // two resident 256-thread blocks per CU (7.3 GB on 256 CUs), at most a fifth of what the device has free
+        size_t freeB = 0, totalB = 0;
+        size_t budget = (size_t)8 << 30;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 5);
+        unsigned lanes = (unsigned)std::min<size_t>((size_t)s->numCUs * 2 * TBLK, budget / sizeof(GWork));
+        lanes = std::max((unsigned)TBLK, lanes / TBLK * TBLK);
         if (hipMalloc((void **)&f->work, sizeof(GWork) * (size_t)lanes) != hipSuccess) { (void)hipGetLastError(); return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT general-form workspaces: %.1f MB)", sizeof(GWork) * (double)lanes / 1e6); }
         f->workLanes = lanes;
     }
@@ -520,11 +532,11 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         const unsigned count = (unsigned)std::min<long long>(chunk, total - first);
         const size_t itemStride = (size_t)f->capacity * BD_ITEMS_PER_SAMPLE;
         BHIPCHK(hipMemsetAsync(f->itemCount, 0, sizeof(unsigned) * 9, f->stream));
-        BHIPCHK(hipMemsetAsync(f->genCount, 0, sizeof(unsigned), f->stream));
+        BHIPCHK(hipMemsetAsync(f->genCount, 0, sizeof(unsigned) * 2, f->stream));
         const unsigned pgrid = std::min<unsigned>((count + TBLK - 1) / TBLK, (unsigned)s->numCUs * 2u);      // persistent: the grid that is resident at 2 waves per SIMD
         hipLaunchKernelGGL(k_bd_paths, dim3(pgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->stats);
         hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats, f->genList, f->genCount);
-        if (f->work) hipLaunchKernelGGL(k_bd_general, dim3(f->workLanes / 64), dim3(64), 0, f->stream, s->d, cam, c, f->recs, f->genList, f->genCount, f->work, f->acc, f->light, f->stats);
+        if (f->work) hipLaunchKernelGGL(k_bd_general, dim3(f->workLanes / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->genList, f->genCount, f->work, f->acc, f->light, f->stats);
         BHIPCHK(hipGetLastError());
         unsigned nItems[3] = {0, 0, 0};
         BHIPCHK(hipMemcpyAsync(nItems, f->itemCount, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, f->stream));

@@ -5,7 +5,9 @@ C-ABI of include/gdpt_tracer.h ("G-BDPT") and include/gdpt_poisson.h.
 (/root/reference/src/integrators/gbdpt/gbdpt.cpp:79-104) and `render()` walks the steps of GBDPTIntegrator::render (:140-262): the MultiFilm
 buffers `-L1|-L2, -gradientNegY, -gradientNegX, -gradientPosX, -gradientPosY, -L2|-L1, -primal` (:163), the sampling job
 (GBDPTProcess / GBDPTRenderer, gbdpt_proc.cpp), develop, prepareDataForSolver, BOTH reconstructions (L2D and L1D, :215-251).
-Scope of the sampler: scenes whose BSDFs are all connectable (include/gdpt_tracer.h); all arithmetic runs in lib/libgdpt_hip.so."""
+Scope of the sampler: surface scenes with area emitters, a perspective sensor and the box filter; BSDFs diffuse / roughconductor (the fast form)
+and -- round 4 -- conductor, dielectric and rough conductors below shiftThreshold: samples that meet such a SPECULAR vertex run the general form
+(offset paths by propagatePerturbation and manifold walks, include/gdpt_tracer.h); all arithmetic runs in lib/libgdpt_hip.so."""
 import ctypes as C
 
 import numpy as np

@@ -309,7 +309,8 @@ class GBDPTStripRenderer:
         t3 = time.perf_counter()
         st = film.stats()
         self.last = dict(phases_ms=dict(render=1e3 * (t1 - t0), reduce=1e3 * (t2 - t1), develop_reconstruct=1e3 * (t3 - t2)),
-                         rays=st["raysTraced"] + st["shadowRaysTraced"], closest_rays=st["raysTraced"], samples=st["samples"], render_ms=film.render_ms(), solve_s=solve_s, reduce_bytes=reduce_bytes)
+                         rays=st["raysTraced"] + st["shadowRaysTraced"], closest_rays=st["raysTraced"], samples=st["samples"], render_ms=film.render_ms(), solve_s=solve_s, reduce_bytes=reduce_bytes,
+                         chain=film.chain_stats() if hasattr(film, "chain_stats") else dict(generalSamples=0, overflows=0))
         return out
 
     def close(self):
