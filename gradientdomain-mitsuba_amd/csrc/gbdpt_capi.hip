@@ -105,6 +105,7 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_paths(SceneD S, BdCam cam, BdCon
             const long long pix = gid / cfg.spp;
             const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
             c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sIdx);
+            if (S.cam.needsTime) (void)c.rng.next1D();                  // gbdpt_proc.cpp:156-157: the time sample comes first
             Sample &sm = recs[lid];
             bv_clear(sm.X[0]); sm.X[0].type = T_SENSOR_SUPER; sm.X[0].degenerate = 1;       // makeEndpoint, vertex.cpp:27-33
             bv_clear(sm.Y[0]); sm.Y[0].type = T_EMITTER_SUPER; sm.Y[0].degenerate = 0;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(TBLK) void k_gbdpt_sample(SceneD S, BdCam cam, BdCo
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack; c.nClosest = c.nShadow = 0;
     c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
+    if (S.cam.needsTime) (void)c.rng.next1D();                          // gbdpt_proc.cpp:156-157
     Sample sm;
     SampleOut out;
     if (work) {                                     // (the host passes a workspace: the sample may need the general form)
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(TBLK) void k_gbdpt_sample(SceneD S, BdCam cam, BdCo
         } else {
             c.nClosest = c.nShadow = 0;
             c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
+            if (S.cam.needsTime) (void)c.rng.next1D();
             process_sample(c, sm, px, py, out);
             counters[2] = 0; counters[3] = 0;
         }

@@ -378,6 +378,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     if (!verts || !triMaterial || !materials || !camera || !out || numTris <= 0 || numMaterials <= 0)
         return tfail(GDPT_ERR_INVALID, "scene_create: null or empty input");
     if (camera->type != GDPT_SENSOR_PERSPECTIVE && camera->type != GDPT_SENSOR_THINLENS) return tfail(GDPT_ERR_UNSUPPORTED, "sensor type %d is not carried (perspective, thinlens)", camera->type);
+    if (!(camera->shutterClose >= camera->shutterOpen)) return tfail(GDPT_ERR_INVALID, "Shutter opening time must be less than or equal to the shutter closing time!");   // sensor.cpp:33-35
     if (camera->type == GDPT_SENSOR_THINLENS) {
         if (!(camera->apertureRadius > 0)) return tfail(GDPT_ERR_INVALID, "thinlens: 'apertureRadius' must be positive (the plugin replaces 0 by Epsilon, thinlens.cpp:134-138: so does a host)");
         if (!(camera->focusDistance > 0)) return tfail(GDPT_ERR_INVALID, "thinlens: 'focusDistance' must be positive");
@@ -722,7 +723,8 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     c.aspect = (double)camera->width / (double)camera->height;
     c.invW = 1.0 / camera->width; c.invH = 1.0 / camera->height;
     c.width = camera->width; c.height = camera->height;
-    c.thinlens = camera->type == GDPT_SENSOR_THINLENS ? 1 : 0; c.pad = 0;
+    c.thinlens = camera->type == GDPT_SENSOR_THINLENS ? 1 : 0;
+    c.needsTime = camera->shutterClose > camera->shutterOpen ? 1 : 0;           // sensor.cpp:30-37: an interval of zero length is EDeltaTime
     c.apertureRadius = camera->apertureRadius; c.focusDistance = camera->focusDistance;
     { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) s->numCUs = cus; }
     *out = s;

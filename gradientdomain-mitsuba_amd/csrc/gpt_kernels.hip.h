@@ -147,7 +147,7 @@ struct CameraD {
     Float m[12];            // rows of the 3x4 camera-to-world
     Float nearClip, farClip, tanHalf, aspect, invW, invH;
     int width, height;
-    int thinlens, pad;      // 1: `thinlens` sensor (thinlens.cpp): rays start on the aperture and pass through the focus point of their pixel
+    int thinlens, needsTime;// needsTime: shutterClose > shutterOpen -- a sample draws its time sample (Sensor::needsTimeSample, sensor.h:290).  thinlens 1: `thinlens` sensor (thinlens.cpp): rays start on the aperture and pass through the focus point of their pixel
     Float apertureRadius, focusDistance;
 };
 struct SceneD {

@@ -116,6 +116,7 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
     L.sy = py + L.rng.next1D();
     Float apx = 0.5, apy = 0.5;
     if (S.cam.thinlens) { apx = L.rng.next1D(); apy = L.rng.next1D(); }          // gpt.cpp:1262-1264 (needsApertureSample)
+    if (S.cam.needsTime) (void)L.rng.next1D();                                   // gpt.cpp:1265-1267 (needsTimeSample): ray.time of static transforms
     L.throughput = mk(1.0); L.pdf = 1.0; L.eta = 1.0; L.depth = 1;
     A.zero();
     // five primary rays: traversal in ONE rolled loop (one copy of the traversal code), results parked in a small array
@@ -840,6 +841,7 @@ __global__ __launch_bounds__(TBLK) void k_primary(SceneD S, ConfigD cfg, FilmD F
     const Float sx = px + rng.next1D(), sy = py + rng.next1D();                  // gpt.cpp:1261
     Float apx = 0.5, apy = 0.5;
     if (S.cam.thinlens) { apx = rng.next1D(); apy = rng.next1D(); }               // gpt.cpp:1262-1264
+    // (the time sample of gpt.cpp:1265-1267 comes after these draws and is not needed here: k_primary only traces the five primary rays)
     const unsigned slot = (unsigned)sRel * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
 #pragma unroll 1
     for (int r = 0; r < 5; r++) {

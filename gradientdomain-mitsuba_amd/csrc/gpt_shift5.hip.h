@@ -153,6 +153,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_shift5(SceneD S, Confi
                         sy = py + rng.next1D();
                         Float apx = 0.5, apy = 0.5;
                         if (S.cam.thinlens) { apx = rng.next1D(); apy = rng.next1D(); }     // gpt.cpp:1262-1264
+                        if (S.cam.needsTime) (void)rng.next1D();                             // gpt.cpp:1265-1267
                         d3 o, d;
                         Float mint, maxt;
                         camera_ray(S.cam, sx + (isBase ? 0.0 : offset_shift_x(oi)), sy + (isBase ? 0.0 : offset_shift_y(oi)), apx, apy, o, d, mint, maxt);

@@ -39,7 +39,8 @@ class Environment(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
-                ("width", C.c_int), ("height", C.c_int), ("type", C.c_int), ("apertureRadius", C.c_double), ("focusDistance", C.c_double)]
+                ("width", C.c_int), ("height", C.c_int), ("type", C.c_int), ("apertureRadius", C.c_double), ("focusDistance", C.c_double),
+                ("shutterOpen", C.c_double), ("shutterClose", C.c_double)]
 
 
 class Config(C.Structure):
@@ -98,6 +99,8 @@ class Scene:
         cam.fovX, cam.nearClip, cam.farClip, cam.width, cam.height = desc.fov_x, desc.near, desc.far, desc.width, desc.height
         if getattr(desc, "thinlens", None):                 # (apertureRadius, focusDistance) of a `thinlens` sensor
             cam.type, cam.apertureRadius, cam.focusDistance = 1, float(desc.thinlens[0]), float(desc.thinlens[1])
+        if getattr(desc, "shutter", None):                  # (shutterOpen, shutterClose) of the sensor: an interval of positive length draws a time sample
+            cam.shutterOpen, cam.shutterClose = float(desc.shutter[0]), float(desc.shutter[1])
         self._h = C.c_void_p()
         envd = getattr(desc, "environment", None)
         env = None

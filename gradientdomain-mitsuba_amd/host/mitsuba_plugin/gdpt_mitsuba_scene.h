@@ -241,6 +241,8 @@ inline void flatten(const Scene *scene, const Sensor *sensor, const Vector2i &si
 	for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) fs.cam.toWorld[4 * r + c] = M(r, c);
 	fs.cam.fovX = pc->getXFov(); fs.cam.nearClip = pc->getNearClip(); fs.cam.farClip = pc->getFarClip();
 	fs.cam.width = size.x; fs.cam.height = size.y;
+	fs.cam.shutterOpen = sensor->getShutterOpen();                                         /* sensor.h:275-281; an interval of positive length <=> needsTimeSample() */
+	fs.cam.shutterClose = sensor->getShutterOpen() + sensor->getShutterOpenTime();
 	if (scls == "ThinLens") {                                                              /* thinlens.cpp:236-244: both are plain properties */
 		fs.cam.type = GDPT_SENSOR_THINLENS;
 		fs.cam.apertureRadius = sensor->getProperties().getFloat("apertureRadius");

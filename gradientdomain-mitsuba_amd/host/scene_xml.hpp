@@ -391,6 +391,9 @@ private:
         sd.camera.farClip = p.getFloat("farClip", 1e4);
         sd.camera.width = W;
         sd.camera.height = H;
+        sd.camera.shutterOpen = p.getFloat("shutterOpen", 0.0);            // Sensor::Sensor, sensor.cpp:28-30
+        sd.camera.shutterClose = p.getFloat("shutterClose", 0.0);
+        if (sd.camera.shutterClose < sd.camera.shutterOpen) logError("Shutter opening time must be less than or equal to the shutter closing time!");   // sensor.cpp:33-35
         if (stype == "thinlens") {                                       // thinlens.cpp:236-244, sensor.cpp (ProjectiveCamera: focusDistance, default farClip)
             sd.camera.type = GDPT_SENSOR_THINLENS;
             sd.camera.apertureRadius = p.getFloat("apertureRadius", 0.0);

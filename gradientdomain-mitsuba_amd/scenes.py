@@ -87,6 +87,7 @@ class Scene:
     textures: list = None        # bitmap textures: dicts with rgb [h, w, 3] (linear), wrapU/wrapV (TEXWRAP_*), filter (TEXFILTER_*), uscale, vscale, uoffset, voffset, scale
     material_textures: list = None   # per material: texture index on its reflectance / specularReflectance, -1 = constant
     thinlens: tuple = None       # (apertureRadius, focusDistance) of `<sensor type="thinlens">`; None = `perspective`
+    shutter: tuple = None        # (shutterOpen, shutterClose) of the sensor (sensor.cpp:26-38); None = (0, 0): no time sample
 
     @property
     def ntri(self):

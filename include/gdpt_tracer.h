@@ -69,6 +69,9 @@ typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective
     int    type;                /* GDPT_SENSOR_PERSPECTIVE (0) | GDPT_SENSOR_THINLENS: `thinlens` (src/sensors/thinlens.cpp), the aperture sample of gpt.cpp:1262-1264 */
     double apertureRadius;      /* thinlens `apertureRadius`                                        */
     double focusDistance;       /* thinlens `focusDistance`                                         */
+    double shutterOpen;         /* `shutterOpen` / `shutterClose` (Sensor::Sensor, sensor.cpp:26-38): with shutterClose > shutterOpen every sample draws  */
+    double shutterClose;        /*   its time sample (gpt.cpp:1265-1267, gbdpt_proc.cpp:156-157); both 0 = no shutter.  Transforms are static: the time    */
+                                /*   of a ray moves nothing, the draw keeps the sample's random stream where the reference's is                           */
 } gdpt_camera;
 #define GDPT_SENSOR_PERSPECTIVE 0
 #define GDPT_SENSOR_THINLENS    1

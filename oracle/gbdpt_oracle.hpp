@@ -1623,6 +1623,7 @@ struct Tracer {
     {
         for (int k = 0; k < 32; ++k) out[k] = 0.0;
         Config &cfg = c.cfg;
+        if (c.sc.cam.shutterClose > c.sc.cam.shutterOpen) (void)rng.next1D();
         if (cfg.maxDepth == -1) cfg.maxDepth = 12;
         Path emitterSubpath, sensorSubpath;
         emitterSubpath.v.push_back(pool.allocVertex());
@@ -1655,6 +1656,7 @@ struct Tracer {
     {
         static const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                // :101
         Config &cfg = c.cfg;
+        if (c.sc.cam.shutterClose > c.sc.cam.shutterOpen) (void)rng.next1D();               // :156-157 (needsTimeSample; the subpaths' `time` moves nothing: static transforms)
         if (cfg.maxDepth == -1) cfg.maxDepth = 12;                                         // :103-106
         int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth;
         // the perspective sensor is degenerate (EDeltaPosition): no extra emitter step; area emitters can be hit: one more sensor step (:116-122)

@@ -167,6 +167,7 @@ typedef struct gpo_camera {
     int width, height;
     int type;           // 0 perspective, 1 thinlens (src/sensors/thinlens.cpp)
     double apertureRadius, focusDistance;
+    double shutterOpen, shutterClose;   // Sensor::Sensor, sensor.cpp:26-38: shutterClose > shutterOpen <=> needsTimeSample() (sensor.h:290)
 } gpo_camera;
 
 typedef struct gpo_config {
@@ -1901,7 +1902,9 @@ void renderSample(const Scene &sc, const gpo_config &cfg, Rng &rng, int px, int 
     static const double shifts[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};                 // gpt.cpp:410-415
     const double sx = px + rng.next1D(), sy = py + rng.next1D();               // :1261
     double apx = 0.5, apy = 0.5;
-    if (sc.cam.type == 1) { apx = rng.next1D(); apy = rng.next1D(); }           // :1262-1264 (needsApertureSample); the time sample is never needed (no shutter)
+    if (sc.cam.type == 1) { apx = rng.next1D(); apy = rng.next1D(); }           // :1262-1264 (needsApertureSample)
+    if (sc.cam.shutterClose > sc.cam.shutterOpen) (void)rng.next1D();          // :1265-1267 (needsTimeSample): timeSample -> ray.time = sampleTime(.), sensor.h:202;
+                                                                               // every transform here is static (m_worldTransform->eval(time) is one matrix), so the draw is all it does
     RayState mainRay;
     sampleRay(sc, sx, sy, mainRay.ray, apx, apy);                              // evaluatePoint, :397-436: base and offsets share the aperture sample
     mainRay.throughput = V3(1.0);
@@ -2272,6 +2275,7 @@ GPO_API void gpo_evaluate_point(gpo_scene *h, const gpo_config *cfg, int px, int
     const double sx = px + rng.next1D(), sy = py + rng.next1D();
     double apx = 0.5, apy = 0.5;
     if (sc.cam.type == 1) { apx = rng.next1D(); apy = rng.next1D(); }
+    if (sc.cam.shutterClose > sc.cam.shutterOpen) (void)rng.next1D();
     RayState mainRay;
     sampleRay(sc, sx, sy, mainRay.ray, apx, apy);
     mainRay.throughput = V3(1.0);

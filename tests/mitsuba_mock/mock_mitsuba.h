@@ -183,6 +183,8 @@ class Sensor : public ConfigurableObject {
 public:
     Film *getFilm() { return &m_film; }
     const AnimatedTransform *getWorldTransform() const { return &m_t; }
+    Float getShutterOpen() const { return 0; }              // sensor.h:275
+    Float getShutterOpenTime() const { return 0; }          // sensor.h:281
     const Class *getClass() const { static Class c("PerspectiveCamera"); return &c; }
 private:
     Film m_film; AnimatedTransform m_t;
