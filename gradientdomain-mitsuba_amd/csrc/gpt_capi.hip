@@ -10,6 +10,7 @@
 #include "gpt_wavefront.hip.h"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -87,10 +88,13 @@ inline double half_area(const Box &b)
     return (dx < 0) ? 0.0 : dx * dy + dy * dz + dz * dx;
 }
 
+struct Node2 { Box b[2]; uint32_t child[2]; };       // the binary SAH tree the builder makes first
 struct Builder {
     const std::vector<Box> &tb;
     std::vector<int> order;
-    std::vector<BvhNode> nodes;
+    std::vector<Node2> nodes2;
+    std::vector<BvhNode> nodes;                      // the device tree: four children per node (fold())
+    int stackNeed = 0;                               // most entries the traversal's stack can hold at once on this tree
     int maxDepth = 0;
     explicit Builder(const std::vector<Box> &b) : tb(b), order(b.size()) { for (size_t i = 0; i < b.size(); i++) order[i] = (int)i; }
 
@@ -165,19 +169,54 @@ struct Builder {
             nl = (int)(mid - b0);
             if (nl == 0 || nl == count) nl = count / 2;
         }
-        const int me = (int)nodes.size();
-        nodes.push_back(BvhNode());
+        const int me = (int)nodes2.size();
+        nodes2.push_back(Node2());
         const uint32_t l = build(first, nl, depth + 1), r = build(first + nl, count - nl, depth + 1);
-        const Box bl = bounds_of(first, nl), br = bounds_of(first + nl, count - nl);
-        BvhNode &n = nodes[me];
-        for (int i = 0; i < 3; i++) {
-            n.b[0][i] = (f2){round_down(bl.lo[i]), round_up(bl.hi[i])};
-            n.b[1][i] = (f2){round_down(br.lo[i]), round_up(br.hi[i])};
-        }
-        n.child[0] = l; n.child[1] = r; n.pad[0] = n.pad[1] = 0;
+        Node2 &n = nodes2[me];
+        n.b[0] = bounds_of(first, nl); n.b[1] = bounds_of(first + nl, count - nl);
+        n.child[0] = l; n.child[1] = r;
         return (uint32_t)me;
     }
     bool tooDeep = false;
+
+    // The device tree: a node takes the two children of a binary node and then, while it has room, replaces the inner child with the largest
+    // box by that child's own two (in place, so children stay in the binary tree's left-to-right order): up to four children, leaves unchanged
+    // (same triangles, same leaf order).  Returns the reference of the folded subtree and, in `need`, the most stack entries a traversal of it
+    // can hold: with k children entered, k - 1 - j wait while the j-th visited is walked; the worst order walks the neediest first.
+    uint32_t fold(uint32_t ref2, int &need)
+    {
+        need = 0;
+        if (ref2 & BVH_LEAF) return ref2;
+        struct Slot { Box b; uint32_t ref; };
+        std::vector<Slot> ch;
+        ch.push_back({nodes2[ref2].b[0], nodes2[ref2].child[0]});
+        ch.push_back({nodes2[ref2].b[1], nodes2[ref2].child[1]});
+        while (ch.size() < 4) {
+            int best = -1;
+            for (int i = 0; i < (int)ch.size(); i++)
+                if (!(ch[i].ref & BVH_LEAF) && (best < 0 || half_area(ch[i].b) > half_area(ch[best].b))) best = i;
+            if (best < 0) break;
+            const Node2 &o = nodes2[ch[best].ref];
+            const Slot a = {o.b[0], o.child[0]}, b = {o.b[1], o.child[1]};
+            ch[best] = a;
+            ch.insert(ch.begin() + best + 1, b);
+        }
+        const int me = (int)nodes.size();
+        nodes.push_back(BvhNode());
+        uint32_t refs[4];
+        std::vector<int> needs;
+        for (size_t i = 0; i < ch.size(); i++) { int nd; refs[i] = fold(ch[i].ref, nd); needs.push_back(nd); }
+        BvhNode &n = nodes[me];
+        std::memset(&n, 0, sizeof n);
+        for (int i = 0; i < 4; i++) {
+            if (i >= (int)ch.size()) { n.child[i] = BVH_NONE; continue; }
+            for (int a = 0; a < 3; a++) n.b[i][a] = (f2){round_down(ch[i].b.lo[a]), round_up(ch[i].b.hi[a])};
+            n.child[i] = refs[i];
+        }
+        std::sort(needs.begin(), needs.end(), std::greater<int>());
+        for (int j = 0; j < (int)needs.size(); j++) need = std::max(need, (int)needs.size() - 1 - j + needs[j]);
+        return (uint32_t)me;
+    }
 };
 
 // ---- MIP pyramid of a `trilinear` / `ewa` bitmap texture (host side; the lookups are in gpt_kernels.hip.h) ---------------------------
@@ -411,8 +450,8 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     if ((long)numTris >= (1L << 28)) return tfail(GDPT_ERR_UNSUPPORTED, "more than 2^28 triangles");
     Builder bld(tb);
     if (const char *e = getenv("GDPT_BVH_LEAF")) bld.leafMax = std::max(1, std::min(8, atoi(e)));   // experiment knob (tools/gpu_leaf_sweep.py)
-    const uint32_t rootRef = bld.build(0, numTris, 0);
-    if (bld.tooDeep) return tfail(GDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (%d levels) on degenerate geometry", STACK_DEPTH);
+    const uint32_t rootRef = bld.fold(bld.build(0, numTris, 0), bld.stackNeed);
+    if (bld.tooDeep || bld.stackNeed >= STACK_DEPTH) return tfail(GDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (%d entries) on degenerate geometry", STACK_DEPTH);
     if (bld.nodes.empty()) bld.nodes.push_back(BvhNode());        // a scene of one leaf: keep the table non-empty
 
     std::vector<int> emitterOf(numTris, -1);
@@ -552,7 +591,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     sceneCdf.back() = 1.0;
 
     gdpt_scene *s = new gdpt_scene;
-    s->bvhDepth = bld.maxDepth;
+    s->bvhDepth = bld.stackNeed;                     // (what the launches size the LDS stack by: entries, not levels)
     hipGetDevice(&s->device);
     SceneD &d = s->d;
     std::memset(&d, 0, sizeof d);

@@ -253,18 +253,8 @@ __global__ __launch_bounds__(TBLK) void k_wf_trace(SceneD S, WfD Q, int it, int 
             if (__ballot(inner) == 0) break;
             if ((int)__popcll(__ballot((ref & BVH_LEAF) != 0 && ref < WF_FIN)) >= leafMin) break;
             if (inner) {
-                const BvhNode n = sv.nodes[ref];
-                float tl, tr;
-                const bool hl = box_test(n.b[0], R, tl);
-                const bool hr = box_test(n.b[1], R, tr);
-                if (hl && hr) {
-                    const bool leftFirst = tl <= tr;
-                    if (sp < STACK_DEPTH) { stack[sp * TBLK] = (int)(leftFirst ? n.child[1] : n.child[0]); sp++; }
-                    ref = leftFirst ? n.child[0] : n.child[1];
-                } else if (hl) ref = n.child[0];
-                else if (hr) ref = n.child[1];
-                else if (sp == 0) ref = WF_FIN;
-                else { sp--; ref = (uint32_t)stack[sp * TBLK]; }
+                ref = node_step(sv.nodes[ref], R, stack, sp);
+                if (ref == BVH_NONE) ref = WF_FIN;
             }
         }
         // leaves: the lanes that hold one test its triangles together

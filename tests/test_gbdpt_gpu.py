@@ -113,6 +113,35 @@ def test_film_matches_oracle(G, B, name, W, H, spp, md, li):
     F.close(); S.close(); O.close()
 
 
+def test_shutter_interval_draws_the_time_sample_first(G, B):
+    """gbdpt_proc.cpp:156-157: with needsTimeSample() the time sample is the FIRST draw of a sample (before the random walks); the subpaths' time moves
+    nothing (static transforms).  Samples and a film against the oracle, with the general form in play (glass)."""
+    W, H = 40, 30
+    sc = scenes.cornell_box(W, H, "glass"); sc.shutter = (0.0, 0.02)
+    S, O = G.Scene(sc), go.Scene(sc)
+    S0 = G.Scene(scenes.cornell_box(W, H, "glass"))
+    integ = B.GBDPTIntegrator(maxDepth=7)
+    cfg, ocfg = integ.config(64), go.gbdpt_config(maxDepth=7, lightImage=True, spp=64)
+    rng = np.random.default_rng(5)
+    moved = 0
+    for _ in range(40):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
+        g = integ.evaluate_sample(S, cfg, px, py, s)
+        compare_sample(g, O.gbdpt_sample(ocfg, px, py, s), ("shutter", px, py, s))
+        moved += not np.allclose(g["position"], integ.evaluate_sample(S0, cfg, px, py, s)["position"])
+    assert moved == 40                                   # the film position is drawn behind the time sample: another one for every sample
+    F = B.Film(S)
+    integ.renderBlock(S, F, integ.config(2), (0, 0, W, H))
+    block, light = F.accum()
+    ob, ol, oc = O.gbdpt_render(go.gbdpt_config(maxDepth=7, lightImage=True, spp=2))
+    st = F.stats()
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == (oc["raysTraced"], oc["shadowRaysTraced"])
+    for b in range(5):
+        assert np.abs(block[b] - ob[b]).max() <= 1e-9 * (np.abs(ob[b]).max() + 1e-300)
+        assert np.abs(light[b] - ol[b]).max() <= 1e-9 * (np.abs(ol[b]).max() + 1e-300)
+    F.close(); S.close(); S0.close(); O.close()
+
+
 def test_small_workspace_chunks_give_the_same_film(G, B):
     """gdpt_gbdpt_render_rect walks a rectangle's samples in chunks of its workspace (sized from the memory the device has free; the `first +=
     chunk` loop).  Forced down to chunks that cut through pixels (GDPT_BD_CHUNK = 777 and 5000 samples of 48 x 36 x 4 = 6912): the same samples,

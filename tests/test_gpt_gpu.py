@@ -1135,6 +1135,47 @@ def test_thinlens_sensor_samples_and_films_match_oracle(G, variant, md, strict, 
     assert not close(oacc[1], pacc[1], rel=1e-3)
 
 
+@pytest.mark.parametrize("variant,md,lens", [("diffuse", 7, None), ("glossy", -1, (30.0, 800.0))])
+def test_shutter_interval_draws_the_time_sample(G, variant, md, lens):
+    """`shutterOpen` / `shutterClose` on the sensor (Sensor::Sensor, sensor.cpp:26-38): an interval of positive length makes needsTimeSample() true and every
+    sample draws its time sample after the film position and the aperture sample (gpt.cpp:1261-1267).  Transforms are static, so the time moves nothing --
+    the draw shifts the rest of the sample's random stream, and the device must shift with the oracle: single samples and films ray for ray, in the staged
+    pipeline and the single kernel; an interval of zero length (EDeltaTime) draws nothing; a negative one is refused with the reference's message."""
+    W, H = 40, 32
+    def build(shutter):
+        sc = scenes.cornell_box(W, H, variant); sc.thinlens = lens; sc.shutter = shutter
+        return sc
+    S, O = G.Scene(build((0.0, 1.0 / 30))), go.Scene(build((0.0, 1.0 / 30)))
+    S0, Sz = G.Scene(build(None)), G.Scene(build((0.25, 0.25)))
+    integ = G.GradientPathIntegrator(maxDepth=md)
+    rng = np.random.default_rng(41)
+    moved = 0
+    for _ in range(30):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
+        g = S.evaluate_point(integ.config(64), px, py, s)
+        o = O.evaluate_point(go.config(maxDepth=md, spp=64), px, py, s)
+        g0, gz = S0.evaluate_point(integ.config(64), px, py, s), Sz.evaluate_point(integ.config(64), px, py, s)
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (variant, px, py, s, k)
+            assert np.array_equal(g0[k], gz[k]), (variant, px, py, s, k)
+        assert (g["raysTraced"], g["shadowRaysTraced"]) == (o["raysTraced"], o["shadowRaysTraced"])
+        moved += not np.allclose(g["throughput"], g0["throughput"])
+    assert moved > 15                                   # the stream behind the draw is another one
+    spp = 3
+    oacc, orays = O.render(go.config(maxDepth=md, spp=spp))
+    for pipeline in (2, 0):
+        F = G.Film(S); F.set_pipeline(pipeline)
+        integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        F.close()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (pipeline, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    with pytest.raises(RuntimeError, match="Shutter opening time"):
+        G.Scene(build((1.0, 0.5)))
+    for x in (S, S0, Sz, O): x.close()
+
+
 def test_thinlens_sensor_argument_checks_and_scope(G):
     sc = scenes.cornell_box(16, 12, "diffuse"); sc.thinlens = (0.0, 500.0)
     with pytest.raises(RuntimeError, match="apertureRadius"):

@@ -531,6 +531,37 @@ def test_environment_map_known_answers():
     assert np.allclose(Rr.envmap_eval(R @ d), O.envmap_eval(d), rtol=1e-12)
 
 
+def test_shutter_time_sample_of_the_restatement():
+    """Sensor::needsTimeSample (sensor.h:290) <=> shutterClose > shutterOpen (sensor.cpp:30-37).  Then renderBlock draws the time sample after the film
+    position and the aperture sample (gpt.cpp:1261-1267) and G-BDPT draws it first (gbdpt_proc.cpp:156-157).  With static transforms the time changes no
+    ray: (1) an interval of zero length is the no-shutter sampler bit for bit; (2) with an interval the film position of a G-PT sample stays (drawn
+    before), the path behind it changes; a G-BDPT sample's film position changes (drawn after); (3) the estimators still converge to the same image."""
+    W, H = 32, 24
+    def build(shutter, variant="diffuse"):
+        sc = scenes.cornell_box(W, H, variant); sc.shutter = shutter
+        return sc
+    O0, Oz, O1 = go.Scene(build(None)), go.Scene(build((0.5, 0.5))), go.Scene(build((0.0, 0.04)))
+    cfg = go.config(maxDepth=5, spp=8)
+    bcfg = go.gbdpt_config(maxDepth=5, lightImage=True, spp=8)
+    changed = 0
+    for (px, py, s) in ((3, 4, 0), (20, 11, 5), (31, 23, 7), (16, 2, 3), (9, 17, 1)):
+        a, z, b = (o.evaluate_point(cfg, px, py, s) for o in (O0, Oz, O1))
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.array_equal(a[k], z[k])
+        changed += not np.allclose(a["throughput"], b["throughput"])
+        ga, gz, gb = (o.gbdpt_sample(bcfg, px, py, s) for o in (O0, Oz, O1))
+        assert np.array_equal(ga["position"], gz["position"]) and np.array_equal(ga["primal"], gz["primal"])
+        assert not np.array_equal(ga["position"], gb["position"])
+    assert changed >= 4
+    # the same image in expectation: a 3x3 block at 3000 spp each way
+    px, py = 15, 12
+    rect = (px - 1, py - 1, px + 2, py + 2)
+    t0 = go.develop(O0.render(go.config(maxDepth=5, spp=3000, seed=3), rect=rect)[0])[1][py - 1:py + 2, px - 1:px + 2]
+    t1 = go.develop(O1.render(go.config(maxDepth=5, spp=3000, seed=3), rect=rect)[0])[1][py - 1:py + 2, px - 1:px + 2]
+    assert not np.array_equal(t0, t1) and np.allclose(t0.mean(axis=(0, 1)), t1.mean(axis=(0, 1)), rtol=0.03)
+    for o in (O0, Oz, O1): o.close()
+
+
 def test_thinlens_sensor_known_answers():
     """`<sensor type="thinlens">` (src/sensors/thinlens.cpp:324-361) as restated in sampleRay: every ray of a pixel passes through the SAME point of
     the focal plane whatever its aperture sample (that is what "in focus" means) and that point is where the pinhole ray of the pixel meets the plane

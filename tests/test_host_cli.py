@@ -666,3 +666,27 @@ def test_cli_thinlens_sensor_equals_python_mirror(cli, tmp_path, gpu_required):
     sc0 = scenes.cornell_box(40, 30); sc0.thinlens = (1e-7, 900.0)
     out0 = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc0), 4)
     assert np.allclose(read_pfm(str(tmp_path / "lens0") + "-throughput.pfm"), out0["-throughput"], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_cli_shutter_interval_equals_python_mirror(cli, tmp_path, gpu_required):
+    """`shutterOpen` / `shutterClose` on the sensor through the scene reader (Sensor::Sensor, sensor.cpp:26-38) == the Python mirror with the same interval
+    (every sample draws its time sample, gpt.cpp:1265-1267); a closing time before the opening time ends with the reference's message."""
+    import shutil
+    import gradientdomain_mitsuba_amd.gpt as G
+    shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    src = open(XML).read()
+    xml = src.replace('<sensor type="perspective">', '<sensor type="perspective"><float name="shutterOpen" value="0.25"/><float name="shutterClose" value="0.5"/>')
+    xs = str(tmp_path / "shutter.xml"); open(xs, "w").write(xml)
+    dest = str(tmp_path / "shutter")
+    r = run(cli, "-o", dest, "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xs)
+    assert r.returncode == 0, r.stderr
+    sc = scenes.cornell_box(40, 30); sc.shutter = (0.25, 0.5)
+    out = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
+    for suffix in G.BUFFER_NAMES:
+        assert np.allclose(read_pfm(dest + suffix + ".pfm"), out[suffix], rtol=2e-6, atol=1e-7), suffix
+    still = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(40, 30)), 4)
+    assert not np.allclose(out["-throughput"], still["-throughput"], rtol=1e-3)
+    xb = str(tmp_path / "shutter_bad.xml"); open(xb, "w").write(xml.replace('value="0.5"', 'value="0.125"'))
+    bad = run(cli, "-o", dest + "b", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xb)
+    assert bad.returncode == 1 and "Shutter opening time" in bad.stderr
