@@ -93,8 +93,11 @@ struct Builder {
     const std::vector<Box> &tb;
     std::vector<int> order;
     std::vector<Node2> nodes2;
-    std::vector<BvhNode> nodes;                      // the device tree: four children per node (fold())
+    std::vector<BvhNode> nodes;                      // the device tree: four children per node (fold()), fp32 boxes ...
+    std::vector<BvhNodeQ> qnodes;                    // ... or 8-bit boxes on the node's grid (the layout of scenes that stay in HBM)
+    bool quant = false;
     int stackNeed = 0;                               // most entries the traversal's stack can hold at once on this tree
+    double maxPlane = 0.0;                           // largest |coordinate| of a decoded box plane (the slab test's error-bound scale)
     int maxDepth = 0;
     explicit Builder(const std::vector<Box> &b) : tb(b), order(b.size()) { for (size_t i = 0; i < b.size(); i++) order[i] = (int)i; }
 
@@ -201,20 +204,50 @@ struct Builder {
             ch[best] = a;
             ch.insert(ch.begin() + best + 1, b);
         }
-        const int me = (int)nodes.size();
-        nodes.push_back(BvhNode());
+        const int me = (int)(quant ? qnodes.size() : nodes.size());
+        if (quant) qnodes.push_back(BvhNodeQ()); else nodes.push_back(BvhNode());
         uint32_t refs[4];
         std::vector<int> needs;
         for (size_t i = 0; i < ch.size(); i++) { int nd; refs[i] = fold(ch[i].ref, nd); needs.push_back(nd); }
-        BvhNode &n = nodes[me];
-        std::memset(&n, 0, sizeof n);
-        for (int i = 0; i < 4; i++) {
-            if (i >= (int)ch.size()) { n.child[i] = BVH_NONE; continue; }
-            for (int a = 0; a < 3; a++) n.b[i][a] = (f2){round_down(ch[i].b.lo[a]), round_up(ch[i].b.hi[a])};
-            n.child[i] = refs[i];
-        }
         std::sort(needs.begin(), needs.end(), std::greater<int>());
         for (int j = 0; j < (int)needs.size(); j++) need = std::max(need, (int)needs.size() - 1 - j + needs[j]);
+        if (!quant) {
+            BvhNode &n = nodes[me];
+            std::memset(&n, 0, sizeof n);
+            for (int i = 0; i < 4; i++) {
+                if (i >= (int)ch.size()) { n.child[i] = BVH_NONE; continue; }
+                for (int a = 0; a < 3; a++) {
+                    n.b[i][a] = (f2){round_down(ch[i].b.lo[a]), round_up(ch[i].b.hi[a])};
+                    maxPlane = std::max(maxPlane, (double)std::max(std::fabs(n.b[i][a].x), std::fabs(n.b[i][a].y)));
+                }
+                n.child[i] = refs[i];
+            }
+            return (uint32_t)me;
+        }
+        BvhNodeQ &n = qnodes[me];
+        std::memset(&n, 0, sizeof n);
+        // the node's grid: origin = its box's lower corner rounded down to fp32, scale = the power of two with 255 * scale >= extent; a child's planes
+        // are the grid planes just outside its box (org + q * scale is exact in double: checked, not assumed)
+        Box nb = empty_box();
+        for (const Slot &s : ch) grow(nb, s.b);
+        for (int a = 0; a < 3; a++) {
+            const float org = round_down(nb.lo[a]);
+            const double ext = nb.hi[a] - (double)org;
+            int e;
+            std::frexp(std::max(ext / 255.0, std::max(std::fabs((double)org), 1.0) * 0x1p-40), &e);           // value = m * 2^e, m in [0.5, 1): 2^e >= value
+            const double sc = std::ldexp(1.0, e);
+            n.org[a] = org; n.scale[a] = (float)sc;
+            for (size_t i = 0; i < ch.size(); i++) {
+                long ql = (long)std::floor((ch[i].b.lo[a] - (double)org) / sc), qh = (long)std::ceil((ch[i].b.hi[a] - (double)org) / sc);
+                ql = std::min(255L, std::max(0L, ql)); qh = std::min(255L, std::max(0L, qh));
+                while (ql > 0 && (double)org + (double)ql * sc > ch[i].b.lo[a]) ql--;
+                while (qh < 255 && (double)org + (double)qh * sc < ch[i].b.hi[a]) qh++;
+                if ((double)org + (double)ql * sc > ch[i].b.lo[a] || (double)org + (double)qh * sc < ch[i].b.hi[a]) tooDeep = true;   // (cannot happen: 255 * scale >= extent)
+                n.qlo[a] |= (uint32_t)ql << (8 * i); n.qhi[a] |= (uint32_t)qh << (8 * i);
+                maxPlane = std::max(maxPlane, std::max(std::fabs((double)org + (double)ql * sc), std::fabs((double)org + (double)qh * sc)));
+            }
+        }
+        for (int i = 0; i < 4; i++) n.child[i] = i < (int)ch.size() ? refs[i] : BVH_NONE;
         return (uint32_t)me;
     }
 };
@@ -450,7 +483,8 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     if ((long)numTris >= (1L << 28)) return tfail(GDPT_ERR_UNSUPPORTED, "more than 2^28 triangles");
     Builder bld(tb);
     if (const char *e = getenv("GDPT_BVH_LEAF")) bld.leafMax = std::max(1, std::min(8, atoi(e)));   // experiment knob (tools/gpu_leaf_sweep.py)
-    const uint32_t rootRef = bld.fold(bld.build(0, numTris, 0), bld.stackNeed);
+    const uint32_t root2 = bld.build(0, numTris, 0);
+    uint32_t rootRef = bld.fold(root2, bld.stackNeed);
     if (bld.tooDeep || bld.stackNeed >= STACK_DEPTH) return tfail(GDPT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack (%d entries) on degenerate geometry", STACK_DEPTH);
     if (bld.nodes.empty()) bld.nodes.push_back(BvhNode());        // a scene of one leaf: keep the table non-empty
 
@@ -595,18 +629,33 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     hipGetDevice(&s->device);
     SceneD &d = s->d;
     std::memset(&d, 0, sizeof d);
+    // Where the tables will live decides the nodes' layout: the scene is staged into LDS (block_setup, gpt_render.hip.h) when its tables fit -- then
+    // fp32 boxes --, otherwise it stays in HBM and the tree is folded again with 8-bit boxes (same children in the same order: same stack need).
+    size_t ldsTot = 0;
+    {
+        const size_t parts[8] = {bld.nodes.size() * sizeof(BvhNode), (size_t)numTris * sizeof(TriIsect), (size_t)numTris * sizeof(TriShade), (size_t)numMaterials * sizeof(MaterialD),
+                                 (size_t)totalEmitters * sizeof(EmitterD), emTris.size() * sizeof(EmTri), emCdf.size() * sizeof(double), ((size_t)totalEmitters + 1) * sizeof(double)};
+        for (size_t b : parts) ldsTot += (b + 15) & ~(size_t)15;                 // block_setup's layout: every table starts on a 16-byte word
+    }
+    const bool ldsResident = ldsTot <= (size_t)LDS_SCENE_BYTES && !getenv("GDPT_SCENE_IN_HBM");     // (GDPT_SCENE_IN_HBM: test knob -- small scenes through the HBM-scene builds)
+    if (!ldsResident && !(rootRef & BVH_LEAF)) {
+        bld.quant = true; bld.maxPlane = 0.0;
+        int need;
+        rootRef = bld.fold(root2, need);
+        if (bld.tooDeep) { return tfail(GDPT_ERR_UNSUPPORTED, "BVH: a box does not fit its node's grid"); }
+    }
     BvhNode *dn; TriIsect *di; TriShade *ds; MaterialD *dm; EmitterD *de; EmTri *det; double *dc, *dsc;
     int rc;
-    if ((rc = upload(&dn, bld.nodes)) || (rc = upload(&di, isect)) || (rc = upload(&ds, shade)) || (rc = upload(&dm, mats)) ||
+    if ((rc = bld.quant ? upload((BvhNodeQ **)&dn, bld.qnodes) : upload(&dn, bld.nodes)) || (rc = upload(&di, isect)) || (rc = upload(&ds, shade)) || (rc = upload(&dm, mats)) ||
         (rc = upload(&de, ems)) || (rc = upload(&det, emTris)) || (rc = upload(&dc, emCdf)) || (rc = upload(&dsc, sceneCdf))) { delete s; return rc; }
     s->allocs = {dn, di, ds, dm, de, det, dc, dsc};
     d.nodes = dn; d.isect = di; d.shade = ds; d.mats = dm; d.emitters = de; d.emTris = det; d.emCdf = dc; d.emitterCdf = dsc;
     d.numEmTris = (int)emTris.size(); d.numEmCdf = (int)emCdf.size();
     d.emitterNormalization = sceneNorm;
-    d.numNodes = (int)bld.nodes.size(); d.numTris = numTris; d.numEmitters = totalEmitters;
-    d.rootRef = rootRef;
+    d.numNodes = (int)(bld.quant ? bld.qnodes.size() : bld.nodes.size()); d.numTris = numTris; d.numEmitters = totalEmitters;
+    d.rootRef = rootRef; d.quantNodes = bld.quant ? 1 : 0;
     {   // error-bound scale of the fp32 slab test: the largest |coordinate| any node bound can hold
-        double m = 0.0;
+        double m = bld.maxPlane;
         for (int i = 0; i < numTris; i++) for (int a = 0; a < 3; a++) m = std::max(m, std::max(std::fabs(tb[i].lo[a]), std::fabs(tb[i].hi[a])));
         d.boundM = round_up(m);
     }
@@ -746,13 +795,9 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     }
     d.numMats = numMaterials;
     {
-        const size_t parts[8] = {(size_t)d.numNodes * sizeof(BvhNode), (size_t)numTris * sizeof(TriIsect), (size_t)numTris * sizeof(TriShade), (size_t)numMaterials * sizeof(MaterialD),
-                                 (size_t)totalEmitters * sizeof(EmitterD), emTris.size() * sizeof(EmTri), emCdf.size() * sizeof(double), ((size_t)totalEmitters + 1) * sizeof(double)};
-        size_t tot = 0;
-        for (size_t b : parts) tot += (b + 15) & ~(size_t)15;                 // block_setup's layout: every table starts on a 16-byte word
-        s->ldsSceneBytes = tot;
-        d.ldsScene = (tot <= (size_t)LDS_SCENE_BYTES && !getenv("GDPT_SCENE_IN_HBM")) ? 1 : 0;     // (GDPT_SCENE_IN_HBM: test knob -- small scenes through the HBM-scene builds)
-        d.ldsBytes = d.ldsScene ? (int)tot : 0;
+        s->ldsSceneBytes = ldsTot;
+        d.ldsScene = ldsResident ? 1 : 0;
+        d.ldsBytes = d.ldsScene ? (int)ldsTot : 0;
     }
     CameraD &c = d.cam;
     for (int r = 0; r < 3; r++)

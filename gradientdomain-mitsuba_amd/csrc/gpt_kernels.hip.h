@@ -79,10 +79,18 @@ __device__ __forceinline__ bool is_finite_d(Float v) { return (v - v) == 0; }
 // record and a leaf never costs a node fetch.  Reference: top bit set = leaf, (first triangle << 3) | (count - 1); else the
 // index of an inner node.
 typedef float f2 __attribute__((ext_vector_type(2)));
-struct BvhNode {                // 128 B, one L2 line: a node of FOUR children (the binary SAH tree with every second level folded into its parent, gpt_capi.hip).
+// A node has FOUR children (the binary SAH tree with every second level folded into its parent, gpt_capi.hip), in one of two layouts the scene
+// picks by where its tables live:
+struct BvhNode {                // 128 B -- scenes staged into LDS (SceneD::quantNodes == 0): fp32 boxes, the cheapest test; LDS bytes cost little
     f2 b[4][3];                 // per child and axis: (lo, hi) -- one packed-FMA operand of the slab test
     uint32_t child[4];          // BVH_NONE: no such child (its box is never looked at)
     uint32_t pad[4];
+};
+struct BvhNodeQ {               // 64 B -- scenes in HBM (quantNodes == 1): boxes as 8-bit offsets on the node's own grid, plane = org + q * scale exactly
+    float org[3];               // (scale is a power of two), lower planes rounded down and upper planes up on the host.  Half the tree's footprint in an L2
+    float scale[3];             // that the render kernels' scratch traffic washes through (atrium frame 72.4 -> 67.0 ms), for ~30 more VALU operations per
+    uint32_t child[4];          // node -- which the LDS-resident scenes, bound by issue, pay for and get nothing back (Cornell 61.2 -> 65.2 ms: hence two layouts)
+    uint32_t qlo[3], qhi[3];    // per axis: byte i = child i's lower / upper plane
 };
 constexpr uint32_t BVH_LEAF = 0x80000000u;
 constexpr uint32_t BVH_NONE = 0xffffffffu;      // (also what a finished traversal holds: a leaf's first triangle is < 2^28, so no leaf reference looks like this)
@@ -131,7 +139,7 @@ struct EnvMapD {
     Float normalization, scale, pixelSizeX, pixelSizeY;
     Float toWorld[9], toLocal[9];           // linear part of the emitter's toWorld and its inverse, row-major
 };
-static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
+static_assert(sizeof(BvhNode) == 128 && sizeof(BvhNodeQ) == 64 && sizeof(TriIsect) % 16 == 0 && sizeof(TriShade) % 16 == 0 && sizeof(MaterialD) % 16 == 0 && sizeof(TriNormals) % 16 == 0, "LDS staging copies 16-byte words");
 struct EmitterD {           // numTris == 0: the environment emitter (`constant`, src/emitters/constant.cpp); -1: `point` (point.cpp)
     int firstEmTri, numTris, cdfOffset, rectangle;     // rectangle: a `rectangle` shape's light -- sampled as Rectangle::samplePosition does
     d3 radiance;            // point: intensity
@@ -166,6 +174,7 @@ struct SceneD {
     int ldsBytes;               // bytes of the staged tables (16-byte words per table), 0 if the scene is not LDS-resident
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds
+    int quantNodes;             // `nodes` holds BvhNodeQ records (scenes that are not LDS-resident)
     const TriNormals *vn;       // per-vertex normals in leaf order, nullptr if the scene has none
     const TriUV *uv;            // per-vertex texture coordinates in leaf order, nullptr if the scene has none
     const unsigned char *hasUV; // per triangle: 1 = its mesh has texture coordinates (else its.uv = the barycentrics, skdtree.h:403-405)
@@ -257,6 +266,7 @@ struct SceneView {
     const TexD *tex;
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds (error bound of the fp32 slab test)
+    int quant;                  // nodes are BvhNodeQ records (uniform; a compile-time 0 in the kernels that stage the scene into LDS)
 };
 
 // TriAccel::rayIntersect, triaccel.h:96-158
@@ -317,13 +327,24 @@ __device__ __forceinline__ bool box_test(const f2 (&b)[3], const RayF &R, float 
     tn = n;
     return n <= f;
 }
+// A child box of a BvhNodeQ: plane = org + q * scale, so its slab parameter t = plane * rdf - a = q * (scale * rdf) + (org * rdf - a): per node and axis one
+// product (exact: scale is a power of two) and one packed FMA give (sr, c), per child and axis ONE packed FMA t = q * sr + c as before.  Roundings: rdf,
+// o * rdf, the sum inside a, c and t: each at most 2^-24 of a term bounded by (M + |o|) |rdf| -- five of them against the E = 8 x 2^-24 (M + |o|) |rdf| the
+// ray's offsets carry.  M covers |org| and every decoded plane (host: boundM).
+__device__ __forceinline__ bool box_test(f2 qx, f2 qy, f2 qz, f2 sx, f2 sy, f2 sz, f2 cx, f2 cy, f2 cz, const RayF &R, float &tn)
+{
+    const f2 tx = __builtin_elementwise_fma(qx, sx, cx), ty = __builtin_elementwise_fma(qy, sy, cy), tz = __builtin_elementwise_fma(qz, sz, cz);
+    const float n = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), R.mint));
+    const float f = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), R.maxt));
+    tn = n;
+    return n <= f;
+}
 
 // One inner node of the traversal: the four slab tests, the children the ray enters sorted by entry parameter (a five-comparator network on
 // (key, child) pairs; the key of a child the ray misses -- or that is not there -- is all ones, so it sorts behind every hit), the far ones
-// pushed far-to-near, the nearest returned; BVH_NONE when nothing is entered and the stack is empty.  A node is one 128-byte line and ends two
-// levels of the binary tree: half the dependent round trips per ray of the 64-byte binary node (the traversal waits on exactly those), for ~1.4x
-// the arithmetic per ray.  The ORDER in which nodes are visited only decides how much is culled: closest hits are the minimum over all triangles whose
-// boxes the ray enters, any-hit is an OR.
+// pushed far-to-near, the nearest returned; BVH_NONE when nothing is entered and the stack is empty.  A node ends two levels of the binary tree: half
+// the dependent round trips per ray.  The ORDER in which nodes are visited only decides how much is culled: closest hits are the minimum over all
+// triangles whose boxes the ray enters, any-hit is an OR.
 __device__ __forceinline__ void sort2(uint32_t &ka, uint32_t &ca, uint32_t &kb, uint32_t &cb)
 {
     const bool s = kb < ka;
@@ -331,16 +352,8 @@ __device__ __forceinline__ void sort2(uint32_t &ka, uint32_t &ca, uint32_t &kb, 
     kb = s ? ka : kb; cb = s ? ca : cb;
     ka = k; ca = c;
 }
-__device__ __forceinline__ uint32_t node_step(const BvhNode &n, const RayF &R, int *stack, int &sp)
+__device__ __forceinline__ uint32_t node_sorted(uint32_t (&k)[4], uint32_t (&c)[4], int *stack, int &sp)
 {
-    uint32_t k[4], c[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float tn;
-        const bool h = box_test(n.b[i], R, tn) && n.child[i] != BVH_NONE;
-        k[i] = h ? __float_as_uint(tn) : BVH_NONE;
-        c[i] = n.child[i];
-    }
     sort2(k[0], c[0], k[1], c[1]); sort2(k[2], c[2], k[3], c[3]);
     sort2(k[0], c[0], k[2], c[2]); sort2(k[1], c[1], k[3], c[3]);
     sort2(k[1], c[1], k[2], c[2]);
@@ -353,6 +366,43 @@ __device__ __forceinline__ uint32_t node_step(const BvhNode &n, const RayF &R, i
     if (k[2] != BVH_NONE && sp < STACK_DEPTH) { stack[sp * TBLK] = (int)c[2]; sp++; }
     if (k[1] != BVH_NONE && sp < STACK_DEPTH) { stack[sp * TBLK] = (int)c[1]; sp++; }
     return c[0];
+}
+__device__ __forceinline__ uint32_t node_step(const BvhNode &n, const RayF &R, int *stack, int &sp)
+{
+    uint32_t k[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float tn;
+        const bool h = box_test(n.b[i], R, tn) && n.child[i] != BVH_NONE;
+        k[i] = h ? __float_as_uint(tn) : BVH_NONE;
+        c[i] = n.child[i];
+    }
+    return node_sorted(k, c, stack, sp);
+}
+__device__ __forceinline__ uint32_t node_step(const BvhNodeQ &n, const RayF &R, int *stack, int &sp)
+{
+    uint32_t k[4], c[4];
+    const float srx = n.scale[0] * R.rx.x, sry = n.scale[1] * R.ry.x, srz = n.scale[2] * R.rz.x;
+    const f2 sx = (f2){srx, srx}, sy = (f2){sry, sry}, sz = (f2){srz, srz};
+    const f2 cx = __builtin_elementwise_fma((f2){n.org[0], n.org[0]}, R.rx, R.ax), cy = __builtin_elementwise_fma((f2){n.org[1], n.org[1]}, R.ry, R.ay),
+             cz = __builtin_elementwise_fma((f2){n.org[2], n.org[2]}, R.rz, R.az);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float tn;
+        const f2 qx = (f2){(float)((n.qlo[0] >> (8 * i)) & 255u), (float)((n.qhi[0] >> (8 * i)) & 255u)};      // (v_cvt_f32_ubyte<i>)
+        const f2 qy = (f2){(float)((n.qlo[1] >> (8 * i)) & 255u), (float)((n.qhi[1] >> (8 * i)) & 255u)};
+        const f2 qz = (f2){(float)((n.qlo[2] >> (8 * i)) & 255u), (float)((n.qhi[2] >> (8 * i)) & 255u)};
+        const bool h = box_test(qx, qy, qz, sx, sy, sz, cx, cy, cz, R, tn) && n.child[i] != BVH_NONE;
+        k[i] = h ? __float_as_uint(tn) : BVH_NONE;
+        c[i] = n.child[i];
+    }
+    return node_sorted(k, c, stack, sp);
+}
+// the step on whichever layout the scene's nodes have (a uniform branch; the LDS-scene kernels hold quant == 0 at compile time)
+__device__ __forceinline__ uint32_t node_step(const SceneView &sv, uint32_t ref, const RayF &R, int *stack, int &sp)
+{
+    if (sv.quant) return node_step(reinterpret_cast<const BvhNodeQ *>(sv.nodes)[ref], R, stack, sp);
+    return node_step(sv.nodes[ref], R, stack, sp);
 }
 
 // ShapeKDTree::rayIntersect (closest, skdtree.cpp:112-142) / rayIntersect(ray) (shadow, :207-226) on the BVH.
@@ -374,7 +424,7 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
     while (true) {
         while (!(ref & BVH_LEAF)) {
             if (COUNT) tc->nodes++;
-            ref = node_step(sv.nodes[ref], R, stack, sp);
+            ref = node_step(sv, ref, R, stack, sp);
         }
         if (ref == DONE) break;
         const uint32_t first = (ref & ~BVH_LEAF) >> 3, cnt = (ref & 7u) + 1u;
@@ -403,17 +453,17 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
 // 1280x720x32 Cornell pass.  Inside bounce(), where ~150 registers of path state are live, inlining is the faster form.
 // Arguments of a real call travel in VGPRs: only the four fields of the scene view the traversal reads are passed, which keeps the
 // callee within the 128 registers of the 4-wave builds (with the whole view it needs 132 and costs them a wave per SIMD).
-__device__ __noinline__ Hit trace_closest_fn(const BvhNode *nodes, const TriIsect *isect, uint32_t rootRef, float boundM, int *stack, d3 o, d3 d, Float mint, Float maxt)
+__device__ __noinline__ Hit trace_closest_fn(const BvhNode *nodes, const TriIsect *isect, uint32_t rootRef, float boundM, int quant, int *stack, d3 o, d3 d, Float mint, Float maxt)
 {
     SceneView sv;
-    sv.nodes = nodes; sv.isect = isect; sv.rootRef = rootRef; sv.boundM = boundM;
+    sv.nodes = nodes; sv.isect = isect; sv.rootRef = rootRef; sv.boundM = boundM; sv.quant = quant;
     Hit h;
     trace<false>(sv, stack, o, d, mint, maxt, h);
     return h;
 }
 __device__ __forceinline__ Hit trace_closest_call(const SceneView &sv, int *stack, d3 o, d3 d, Float mint, Float maxt)
 {
-    return trace_closest_fn(sv.nodes, sv.isect, sv.rootRef, sv.boundM, stack, o, d, mint, maxt);
+    return trace_closest_fn(sv.nodes, sv.isect, sv.rootRef, sv.boundM, sv.quant, stack, o, d, mint, maxt);
 }
 
 __device__ __forceinline__ Float ray_mint_closest(d3 o, Float mint)

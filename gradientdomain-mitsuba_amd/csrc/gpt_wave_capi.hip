@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TBLK) void k_wf_trace(SceneD S, WfD Q, int it, int 
             if (__ballot(inner) == 0) break;
             if ((int)__popcll(__ballot((ref & BVH_LEAF) != 0 && ref < WF_FIN)) >= leafMin) break;
             if (inner) {
-                ref = node_step(sv.nodes[ref], R, stack, sp);
+                ref = node_step(sv, ref, R, stack, sp);
                 if (ref == BVH_NONE) ref = WF_FIN;
             }
         }
