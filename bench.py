@@ -280,7 +280,7 @@ def bench_gbdpt(a, rank, local, world, dev):
         tracer_bytes = tracer_bytes_block(scene, desc, rays / launch_s / a.steps, closest / float(max(1, sr.last["rays"] * a.steps)) if world == 1 else 0.5)
         counters, counters_file = _profiled_counters("_counters_gbdpt.json")
         issue = None
-        bd = {k: v for k, v in counters.items() if "gdpt_bd::k_bd_" in k and "SQ_INSTS_VALU" in v}
+        bd = {k: v for k, v in counters.items() if "gdpt_bdk::k_bd_" in k and "SQ_INSTS_VALU" in v}
         put = next((v for k, v in bd.items() if "k_bd_put" in k), None)
         if bd and put and put.get("grid_x") and world == 1:
             # k_bd_put runs once per chunk with one thread per sample: its launches x grid = the samples of the profiled run
@@ -295,7 +295,7 @@ def bench_gbdpt(a, rank, local, world, dev):
                      "valu_wave_instr_per_sample": round(per_sample, 1), "profiled_samples": prof_samples,
                      "lane_utilisation": round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if tot["SQ_ACTIVE_INST_VALU"] else None,
                      "wait_any_frac_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4) if tot["SQ_WAVE_CYCLES"] else None,
-                     "per_kernel": {k.split("gdpt_bd::")[1].split("@")[0]: {"calls": v.get("calls"), "avg_us": v.get("avg_us"), "vgpr": v.get("vgpr"),
+                     "per_kernel": {k.split("gdpt_bdk::")[1].split("@")[0]: {"calls": v.get("calls"), "avg_us": v.get("avg_us"), "vgpr": v.get("vgpr"),
                                                                            "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 3) if v.get("SQ_ACTIVE_INST_VALU") else None,
                                                                            "wait_any_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAVE_CYCLES") else None}
                                     for k, v in bd.items()},
@@ -524,6 +524,9 @@ def main():
                         "iteration": {"kernels_us": {"kf_xp_Ax": round(hb["kus"][3], 2), "kf_r_rz": round(hb["kus"][1], 2)}, "bytes": iter_bytes,
                                       "achieved": round(iter_bytes / (iter_us * 1e-6) / 1e9, 1), "frac": round(iter_bytes / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                       "what": "one CG iteration = kf_xp_Ax + kf_r_rz against SURVEY 8d's 120 B/pix-iter"},
+                        "stream_yardstick": {"us": 95.0, "tb_s": 6.29, "frac_of_it": round(95.0 / kavg, 3) if hb["w"] == 3840 and hb["h"] == 2160 else None,
+                                             "source": "profiles/r04_stream_ceiling.txt (tools/stream_ceiling.hip)",
+                                             "what": "a bare streaming kernel with this kernel's access mix (3 coalesced reads + 3 non-temporal writes of 99.5 MB arrays, no stencil, no reuse) on the same GPU: what 72 B/px can be moved in at all; 0.79 of the 8 TB/s figure"},
                         "solve": {"ms": round(hb["solve_ms"], 3), "mpix_iter_s": round(hb["mpix_iter_s"], 1),
                                   "achieved": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9, 1), "frac": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)}}
         # --- `roofline`: the timed step's dominant kernels.  With the committed counters of this binary: the staged render against the VALU issue

@@ -12,8 +12,9 @@ INC = [os.path.join(ROOT, "include", f) for f in ("gdpt_poisson.h", "gdpt_tracer
 # (the tracer unit is 4 of the 4.5 minutes of hipcc)
 UNITS = {
     "poisson_capi.hip": ["poisson_kernels.hip.h", "poisson_persistent.hip.h"],
-    "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_shift5.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"],
+    "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_shift5.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h", "gpt_serial.hip.h"],
     "gpt_wave_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"],
+    "gpt_serial_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_serial.hip.h"],
     "gbdpt_capi.hip": ["gpt_kernels.hip.h", "gbdpt_kernels.hip.h", "gpt_scene.hip.h"],
     "device_capi.hip": [],
 }

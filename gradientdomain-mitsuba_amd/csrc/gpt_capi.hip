@@ -8,6 +8,7 @@
 #endif
 #include "gpt_scene.hip.h"
 #include "gpt_wavefront.hip.h"
+#include "gpt_serial.hip.h"
 
 #include <algorithm>
 #include <functional>
@@ -1100,6 +1101,34 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #undef GDPT_STAGED
     if (slices > 1 && !f->d.fValues && !useQueue) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
     THIPCHK(hipGetLastError());
+    THIPCHK(hipEventRecord(e1, f->stream));
+    f->events.push_back(std::make_pair(e0, e1));
+    f->resolved = false;
+    return GDPT_OK;
+}
+
+int gdpt_render_serial(gdpt_scene *s, const gdpt_config *cfg, gdpt_film *f, int blockSize, unsigned long long parentSeed, unsigned long long *draws)
+{
+    if (!s || !cfg || !f || f->scene != s) return tfail(GDPT_ERR_INVALID, "render_serial: null argument or film of another scene");
+    if (cfg->spp <= 0) return tfail(GDPT_ERR_INVALID, "spp must be positive");
+    if (cfg->maxDepth <= 0 && cfg->maxDepth != -1) return tfail(GDPT_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); // gpt.cpp:1212
+    if (blockSize <= 0 || blockSize > 255) return tfail(GDPT_ERR_INVALID, "render_serial: block size must be 1..255 (the block's curve has byte coordinates, sfcurve.h:37)");
+    if (f->d.y0 != 0 || f->d.y1 != f->d.H) return tfail(GDPT_ERR_UNSUPPORTED, "render_serial: the film must hold the whole image (a strip has no serial order)");
+    if (f->d.fValues) return tfail(GDPT_ERR_UNSUPPORTED, "render_serial: box reconstruction filter only");
+    if (s->bvhDepth >= STACK_DEPTH) return tfail(GDPT_ERR_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", s->bvhDepth);
+    THIPCHK(hipSetDevice(s->device));
+    ConfigD c;
+    c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
+    c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
+    c.regenMin = 1; c.sBase = 0; c.sCount = cfg->spp;
+    FilmD fd = f->d;                    // (no queue, no primary-hit records: the single-kernel pipeline's film)
+    fd.qRec = nullptr; fd.pHit = nullptr; fd.pPrim = nullptr;
+    hipEvent_t e0, e1;
+    THIPCHK(hipEventCreate(&e0));
+    THIPCHK(hipEventCreate(&e1));
+    THIPCHK(hipEventRecord(e0, f->stream));
+    const int rc = serial_render(s, f->stream, c, fd, blockSize, parentSeed, draws);
+    if (rc != 0) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "render_serial: %s", hipGetErrorString((hipError_t)rc)); }
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
     f->resolved = false;

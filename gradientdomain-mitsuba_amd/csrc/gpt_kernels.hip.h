@@ -227,6 +227,27 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
+#ifdef GDPT_SERIAL_STREAM
+// gpt_serial_capi.hip's build of the sampler: every draw comes from ONE SFMT-19937 stream, as `mitsuba -p 1` consumes it (IndependentSampler::next1D,
+// independent.cpp:94-96 -> Random::nextFloat, random.cpp:616-626).  The 624 state words and the read index (word 624) sit in LDS; the lane that runs the
+// serial film owns them.  init() is what a per-sample stream needs and a serial one must not have: the position carries over from sample to sample.
+struct Rng {
+    uint32_t *w;
+    __device__ __forceinline__ void init(uint64_t, uint64_t, uint64_t) {}
+    __device__ __forceinline__ uint64_t position() const { return 0; }             // (a sample never leaves its lane in the serial form: nothing to carry in a queue record)
+    __device__ __forceinline__ void set_position(uint64_t) {}
+    __device__ void regenerate();
+    __device__ __forceinline__ Float next1D()
+    {
+        if (w[624] >= 624u) { regenerate(); w[624] = 0; }
+        const uint32_t i = w[624];
+        const uint64_t u = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);          // State::gen_rand64, random.cpp:285-293
+        w[624] = i + 2;
+        w[625]++;                                                                   // draws so far (returned to the host: tests hold it against the oracle's count)
+        return __longlong_as_double((long long)((u >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+    }
+};
+#else
 struct Rng {
     uint64_t s;
     __device__ __forceinline__ void init(uint64_t seed, uint64_t pixel, uint64_t sample)
@@ -234,12 +255,15 @@ struct Rng {
         s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
         s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
     }
+    __device__ __forceinline__ uint64_t position() const { return s; }             // what a queue record carries of the stream
+    __device__ __forceinline__ void set_position(uint64_t p) { s = p; }
     __device__ __forceinline__ Float next1D()
     {
         s += 0x9E3779B97F4A7C15ULL;
         return __longlong_as_double((long long)((mix64(s) >> 12) | 0x3FF0000000000000ULL)) - 1.0;
     }
 };
+#endif
 
 // ---- frames -------------------------------------------------------------------------------------------
 struct Frame3 { d3 s, t, n; };

@@ -663,7 +663,7 @@ __device__ __forceinline__ void q_store_main(const FilmD &F, unsigned slot, cons
     qst(&q[8 * st], L.rayD.x); qst(&q[9 * st], L.rayD.y); qst(&q[10 * st], L.rayD.z);
     qst(&q[11 * st], L.v.u); qst(&q[12 * st], L.v.v);
     qst(&q[13 * st], __longlong_as_double((long long)(((unsigned long long)(unsigned)L.depth << 32) | (unsigned)L.v.prim)));
-    qst(&q[14 * st], __longlong_as_double((long long)L.rng.s));
+    qst(&q[14 * st], __longlong_as_double((long long)L.rng.position()));
 }
 template <class ACC>
 __device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lane &L, const ACC &A)
@@ -693,7 +693,7 @@ __device__ __forceinline__ void q_load_main(const FilmD &F, unsigned slot, Lane 
     L.v.u = qld(&q[11 * st]); L.v.v = qld(&q[12 * st]);
     const unsigned long long pk = (unsigned long long)__double_as_longlong(qld(&q[13 * st]));
     L.v.prim = (int)(unsigned)(pk & 0xffffffffu); L.depth = (int)(unsigned)(pk >> 32);
-    L.rng.s = (uint64_t)__double_as_longlong(qld(&q[14 * st]));
+    L.rng.set_position((uint64_t)__double_as_longlong(qld(&q[14 * st])));
 }
 __device__ __forceinline__ void q_load_lane(const FilmD &F, unsigned slot, Lane &L)          // the path's part of a record: base path and offsets
 {

@@ -317,6 +317,14 @@ class GradientPathIntegrator:
         x0, y0, x1, y1 = rect
         check(lib().gdpt_render_rect(scene._h, C.byref(cfg), x0, y0, x1, y1, film._h))
 
+    def renderSerial(self, scene, film, cfg, blockSize=32, parentSeed=5489):
+        """The film as ONE worker of the reference samples it (`mitsuba -p 1`): spiral blocks, Hilbert order inside a block, every random number from one
+        SFMT-19937 stream seeded as the worker's cloned sampler is (gdpt_render_serial).  One lane, synchronous: a validation path.  -> random numbers drawn."""
+        draws = C.c_ulonglong(0)
+        lib().gdpt_render_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_ulonglong, C.c_void_p]
+        check(lib().gdpt_render_serial(scene._h, C.byref(cfg), film._h, int(blockSize), int(parentSeed), C.byref(draws)))
+        return int(draws.value)
+
     def render(self, scene, spp, seed=5489, film=None):
         """GradientPathIntegrator::render (gpt.cpp:1358-1480).  Returns {suffix: float32 [H,W,3]}."""
         own = film is None
@@ -335,6 +343,23 @@ class GradientPathIntegrator:
         if own:
             film.close()
         return out
+
+
+def serial_random(seed, n, cloned=False):
+    """n successive Random::nextULong outputs of Mitsuba's SFMT-19937 `Random(seed)` -- cloned: of a Random seeded from that one, as a worker's sampler is
+    (host code of the library: no device needed)."""
+    out = np.zeros(n, np.uint64)
+    lib().gdpt_serial_random.argtypes = [C.c_ulonglong, C.c_int, C.c_int, C.c_void_p]
+    check(lib().gdpt_serial_random(int(seed), int(bool(cloned)), int(n), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def serial_pixel_order(width, height, blockSize=32):
+    """The pixels of a film in the order one worker of the reference renders them: [(x, y)] (host code of the library)."""
+    xy = np.zeros((width * height, 2), np.int32)
+    lib().gdpt_serial_pixel_order.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    check(lib().gdpt_serial_pixel_order(int(width), int(height), int(blockSize), xy.ctypes.data_as(C.c_void_p)))
+    return xy
 
 
 def write_pfm(path, rgb):

@@ -12,7 +12,8 @@
  * Scene subset carried: triangle soups without vertex normals/texcoords, `area` emitters on
  * meshes, `diffuse` / `conductor` / `roughconductor` BSDFs, `perspective` (or `thinlens`) sensor, `box` rfilter, independent
  * sampling.  Arithmetic is fp64 like the reference's DOUBLE_PRECISION build.  Random numbers: one counter-based
- * stream per (seed, pixel, sample) -- a GPU cannot consume the reference's serial SFMT stream.
+ * stream per (seed, pixel, sample) -- a GPU cannot consume the reference's serial SFMT stream at speed; gdpt_render_serial
+ * below is the same sampler fed by that stream in a one-worker render's order, on one lane: the validation path.
  *
  * Plain C; status codes and gdpt_last_error() as in gdpt_poisson.h.  No CPU fallback.
  */
@@ -153,6 +154,19 @@ GDPT_API int  gdpt_film_clear(gdpt_film *f);
  * film (GPTBlockRenderer::process + processResult).  Asynchronous on the film's stream; gdpt_film_sync waits. */
 GDPT_API int  gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int x1, int y1, gdpt_film *f);
 GDPT_API int  gdpt_film_sync(gdpt_film *f);
+/* The film as `mitsuba -p 1` samples it: ONE lane renders every pixel of the (whole-image, box-filter) film with cfg->spp samples each, in the order a
+ * single worker does -- BlockedImageProcess's spiral of blockSize x blockSize blocks (imageproc.cpp:28-78; Scene::getBlockSize(), 32), Hilbert order inside
+ * a block (gpt_proc.cpp:84-87, sfcurve.h:34-107), samples in index order (gpt.cpp:1245-1268) -- drawing every random number from ONE SFMT-19937 stream:
+ * the clone of the scene's IndependentSampler, seeded by init_by_array from 312 draws of a parent Random(parentSeed) (renderjob.cpp:59-66,
+ * independent.cpp:71-80, random.cpp:400-467,519-524; parentSeed 5489 = random.h:113).  cfg->seed is not used.  ADDS into the film like gdpt_render_rect;
+ * synchronous; minutes per megasample -- a validation path (tests hold it against the oracle's render_serial), never the product's renderer.
+ * draws (may be NULL): random numbers consumed. */
+GDPT_API int  gdpt_render_serial(gdpt_scene *s, const gdpt_config *cfg, gdpt_film *f, int blockSize, unsigned long long parentSeed, unsigned long long *draws);
+/* Host-only probes of the two integer pieces of that path (no device needed; the CPU suite pins them): n successive 64-bit outputs (Random::nextULong,
+ * random.cpp:285-293) of Random(seed) -- or, with cloned != 0, of a Random seeded from a parent Random(seed) as a worker's sampler is --; and the pixel order
+ * of a width x height film, xy = 2 ints per pixel. */
+GDPT_API int  gdpt_serial_random(unsigned long long seed, int cloned, int n, unsigned long long *out);
+GDPT_API int  gdpt_serial_pixel_order(int width, int height, int blockSize, int *xy);
 /* Integrator::cancel (include/mitsuba/render/integrator.h:88; the `stop` flag polled per pixel and sample, gpt.cpp:1246,1254): may be
  * called from another thread while a gdpt_render_rect is running.  Waves stop starting samples, running base paths finish, the film
  * keeps what was accumulated (with a filter wider than box: the chunks gathered so far) and later gdpt_render_rect calls into this

@@ -1176,6 +1176,39 @@ def test_shutter_interval_draws_the_time_sample(G, variant, md, lens):
     for x in (S, S0, Sz, O): x.close()
 
 
+@pytest.mark.parametrize("variant,W,H,spp,md,bs,seed,lens,shutter", [("diffuse", 48, 40, 2, 6, 32, 5489, None, None), ("glossy", 40, 33, 2, -1, 16, 5489, (30.0, 800.0), (0.0, 0.1)),
+                                                                   ("glass", 36, 36, 3, 9, 32, 77, None, None), ("bent", 70, 20, 1, 5, 32, 5489, None, None)])
+def test_serial_render_consumes_the_reference_stream_in_the_reference_order(G, variant, W, H, spp, md, bs, seed, lens, shutter):
+    """gdpt_render_serial: the HIP sampler fed by ONE SFMT-19937 stream (the product's generator: pinned to the reference test's own table in
+    tests/test_serial_host.py) in the order a one-worker run of the reference visits the film -- SURVEY 8a rows 19 (IndependentSampler + SFMT) and 30 (spiral
+    blocks + Hilbert order) on the device.  Every draw of every sample has to sit where the oracle's render_serial has it, or everything behind it is
+    another image: films to fp64 rounding of the sums (the device adds per pixel record, the oracle per put), ray counts exactly."""
+    sc = scenes.cornell_box(W, H, variant); sc.thinlens = lens; sc.shutter = shutter
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md)
+    F = G.Film(S)
+    draws = integ.renderSerial(S, F, integ.config(spp), blockSize=bs, parentSeed=seed)
+    acc, st = F.accum(), F.stats()
+    oacc, orays = O.render_serial(go.config(maxDepth=md, spp=spp), block_size=bs, parent_seed=seed)
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+    for b in range(5):
+        assert close(acc[b], oacc[b]), (G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    assert draws >= (2 + (2 if lens else 0) + (1 if shutter else 0)) * W * H * spp
+    # not the per-sample streams' film, and another parent seed is another film
+    F.clear()
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H)); F.sync()
+    assert not close(F.accum()[1], oacc[1], rel=1e-3)
+    F.clear()
+    integ.renderSerial(S, F, integ.config(spp), blockSize=bs, parentSeed=seed + 1)
+    assert not close(F.accum()[1], oacc[1], rel=1e-3)
+    F.close()
+    # scope: whole-image films with the box filter
+    F2 = G.Film(S, 0, H // 2)
+    with pytest.raises(RuntimeError, match="whole image"):
+        integ.renderSerial(S, F2, integ.config(1))
+    F2.close(); S.close(); O.close()
+
+
 def test_thinlens_sensor_argument_checks_and_scope(G):
     sc = scenes.cornell_box(16, 12, "diffuse"); sc.thinlens = (0.0, 500.0)
     with pytest.raises(RuntimeError, match="apertureRadius"):

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=${TAG:-r04a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_gbdpt
 rm -rf $OUT; mkdir -p $OUT
-B="python tools/gpu_gbdpt_perf.py ${GBDPT_SPP:-2} veach"
+B="python tools/gpu_gbdpt_perf.py ${GBDPT_SPP:-2} ${GBDPT_SCENE:-veach_specular}"      # (config 5's scene since round 4: with the glass egg, the mirror and the polished copper)
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o r1 -- $B > $OUT/stdout.log 2> $OUT/kt.err
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r1 -- $B > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r1 -- $B > /dev/null 2> $OUT/pmc_write.err

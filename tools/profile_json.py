@@ -42,7 +42,7 @@ def main():
             k["scratch_bytes_per_lane"] = r[5]
             k["agpr"] = r[6]
     # keep the file small: kernels that matter to the bench line
-    keep = ("gdpt_tr::k_render", "gdpt::kp_cg", "gdpt::kf_", "gdpt_tr::k_resolve", "gdpt_tr::k_develop", "gdpt_tr::k_gather", "gdpt_tr::k_bounce", "gdpt_tr::k_", "gdpt_bd::k_")
+    keep = ("gdpt_tr::k_render", "gdpt::kp_cg", "gdpt::kf_", "gdpt_tr::k_resolve", "gdpt_tr::k_develop", "gdpt_tr::k_gather", "gdpt_tr::k_bounce", "gdpt_tr::k_", "gdpt_bdk::k_")
     kernels = {k: v for k, v in kernels.items() if any(s in k for s in keep)}
     json.dump(dict(tag=tag, source_hash=bench._source_hash(), units={"FETCH_SIZE": "KiB", "WRITE_SIZE": "KiB", "avg_us": "us"},
                    command="tools/prof_r02.sh (rocprofv3 --kernel-trace --stats | --pmc ..., separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline",
