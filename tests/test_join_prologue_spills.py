@@ -39,3 +39,27 @@ def test_no_shipped_kernel_spills_in_a_join_prologue(unit):
         pytest.skip("lib/obj/ is not in this tree (the objects stay where the library was built)")
     found = S.scan(obj, quiet=True)
     assert found == [], "spill stores ahead of an exec restore in %s:\n%s" % (unit, "\n".join("%s  branch %#x  %s" % f for f in found))
+
+
+def test_else_branch_copies_into_a_spill_slot_are_not_a_join_prologue():
+    """A two-sided `if` whose value goes through a spill slot: the THEN lanes store before the flip to the ELSE lanes (s_andn2_saveexec), the ELSE lanes
+    store in their own short branch, then exec is restored.  The branch over the THEN part lands on the flip, a few instructions ahead of an
+    `s_or_b64 exec`: looks like the bad pattern, is correct code (met in round 4's build of k_render<1,0,2,1,0,1>).  The same stores with the flip taken
+    out -- a store under the `if`'s mask at the head of the real join -- must still be reported."""
+    def text(flip):
+        body = ["0000000000000000 <k>:",
+                "\tv_mov_b32_e32 v28, v1                                       // 000000000000: 00000000",
+                "\ts_and_saveexec_b64 s[6:7], s[0:1]                          // 000000000004: 00000000",
+                "\ts_cbranch_execz 2                                          // 000000000008: 00000000",
+                "\tv_mov_b32_e32 v54, v2                                      // 00000000000C: 00000000",
+                "\tscratch_store_dword off, v54, off offset:916               // 000000000010: 00000000",
+                ("\ts_andn2_saveexec_b64 s[6:7], s[10:11]                     // 000000000014: 00000000" if flip else
+                 "\ts_nop 0                                                   // 000000000014: 00000000"),
+                "\ts_nop 0                                                    // 000000000018: 00000000",
+                "\tscratch_store_dword off, v28, off offset:916               // 00000000001C: 00000000",
+                "\ts_or_b64 exec, exec, s[6:7]                                // 000000000020: 00000000",
+                "\ts_endpgm                                                   // 000000000024: 00000000"]
+        return body
+    assert S.scan_text(text(True), quiet=True) == []
+    bad = S.scan_text(text(False), quiet=True)
+    assert [(a, s) for _, a, s in bad] == [(0x8, "scratch_store_dword off, v28, off offset:916")]

@@ -57,6 +57,11 @@ def scan_text(txt, want="", quiet=False):
             if j is None: continue
             end = next((q for q in range(j, min(j + 8, len(ins))) if ins[q][1].startswith("s_or_b64") and ins[q][2].startswith("exec, exec")), None)
             if end is None or op != "s_cbranch_execz": continue          # (only a block whose prologue does end in an exec restore is a join)
+            # ... and whose prologue runs under the `if`'s mask all the way: a target that first flips to the ELSE lanes (s_andn2_saveexec / s_or_saveexec)
+            # and then runs a short else-branch is no join -- stores in there are the else lanes' own copies into the slot, the then lanes made theirs
+            # before the flip (met in round 4: k_render<1,0,2,1,0,1>, a two-sided phi through a spill slot; correct code)
+            if any(ins[q][1].startswith(("s_andn2_saveexec", "s_or_saveexec", "s_and_saveexec", "s_xor_saveexec", "s_cbranch", "s_branch")) or
+                   (ins[q][1].startswith(("s_mov_b64", "s_and_b64", "s_andn2_b64", "s_xor_b64")) and ins[q][2].startswith("exec")) for q in range(j, end)): continue
             k = j
             while k < end:
                 if ins[k][1].startswith("scratch_store") and ", off" in ins[k][2]:
