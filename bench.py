@@ -15,7 +15,7 @@ random numbers are the counter-based streams both the HIP path and the oracle us
                      duration by HIP events, measured live in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles; `traffic` = their FETCH_SIZE x 2
                      + WRITE_SIZE per step.  Without a matching counter file (sources changed, another configuration) the block falls back
                      to the live byte figure below, so that it is never null.
-  tracer_bytes     = SURVEY 8d-B's algorithmic bytes per ray (ray record + hit record + nodes visited x 64 B + triangles tested x 80 B,
+  tracer_bytes     = SURVEY 8d-B's algorithmic bytes per ray (ray record + hit record + nodes visited x 128 | 64 B (the scene's node layout) + triangles tested x 80 B,
                      counted live on the device tree for 65 536 surface-born rays) x this run's rays/s against the 8 TB/s HBM peak, with
                      the survey's caveat: the traversal is latency- and divergence-bound and is served from LDS / L2, not HBM.
   roofline_hbm_case= the HBM-resident Poisson CG kernel against the 8 TB/s HBM peak (metric A's graded kernel): the fused
@@ -147,7 +147,8 @@ def tracer_bytes_block(scene, desc, rays_per_s, closest_frac):
     d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     o = v[tri, 0] + u[:, None] * e1[tri] + w[:, None] * e2[tri] + 1e-6 * d
     st = scene.trace_stats(o, d)
-    NODE_B, TRI_B, RAY_B, HIT_B = 64.0, 80.0, 56.0, 28.0       # BvhNode (4 children, 8-bit boxes), TriIsect (fp64 TriAccel), ray record (o, d, maxt in fp64), hit record (t, u, v, prim)
+    lay = scene.layout()
+    NODE_B, TRI_B, RAY_B, HIT_B = float(lay["node_bytes"]), 80.0, 56.0, 28.0       # BvhNode / BvhNodeQ (four children; fp32 boxes when the scene is LDS-resident, 8-bit boxes in HBM), TriIsect (fp64 TriAccel), ray record (o, d, maxt in fp64), hit record (t, u, v, prim)
     b_closest = RAY_B + HIT_B + st["nodes_closest"] * NODE_B + st["tris_closest"] * TRI_B
     b_any = RAY_B + 4.0 + st["nodes_any"] * NODE_B + st["tris_any"] * TRI_B
     bpr = closest_frac * b_closest + (1.0 - closest_frac) * b_any
@@ -155,7 +156,8 @@ def tracer_bytes_block(scene, desc, rays_per_s, closest_frac):
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_ray": round(bpr, 1), "bytes_per_closest_ray": round(b_closest, 1), "bytes_per_shadow_ray": round(b_any, 1), "closest_hit_share_of_rays": round(closest_frac, 4),
             "nodes_visited": {"closest": round(st["nodes_closest"], 2), "any": round(st["nodes_any"], 2)}, "tris_tested": {"closest": round(st["tris_closest"], 2), "any": round(st["tris_any"], 2)},
-            "what": "SURVEY 8d-B: (ray record + hit record + nodes_visited x 64 B + tris_tested x 80 B, counted live by gdpt_scene_trace_stats on 65 536 surface-born rays) x this run's rays/s / 8 TB/s",
+            "node_bytes": lay["node_bytes"], "scene_lds_resident": lay["lds_resident"],
+            "what": "SURVEY 8d-B: (ray record + hit record + nodes_visited x node_bytes + tris_tested x 80 B, counted live by gdpt_scene_trace_stats on 65 536 surface-born rays) x this run's rays/s / 8 TB/s",
             "caveat": "not an HBM-roofline workload: the tables are served from LDS (small scenes) or L2 / Infinity Cache, the traversal is latency- and divergence-bound; path-state traffic is not in the figure"}
 
 

@@ -655,6 +655,7 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     d.emitterNormalization = sceneNorm;
     d.numNodes = (int)(bld.quant ? bld.qnodes.size() : bld.nodes.size()); d.numTris = numTris; d.numEmitters = totalEmitters;
     d.rootRef = rootRef; d.quantNodes = bld.quant ? 1 : 0;
+
     {   // error-bound scale of the fp32 slab test: the largest |coordinate| any node bound can hold
         double m = bld.maxPlane;
         for (int i = 0; i < numTris; i++) for (int a = 0; a < 3; a++) m = std::max(m, std::max(std::fabs(tb[i].lo[a]), std::fabs(tb[i].hi[a])));
@@ -1104,6 +1105,14 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
     f->resolved = false;
+    return GDPT_OK;
+}
+
+int gdpt_scene_layout(gdpt_scene *s, long long out[6])
+{
+    if (!s || !out) return tfail(GDPT_ERR_INVALID, "scene_layout: null argument");
+    out[0] = s->d.numNodes; out[1] = s->d.quantNodes ? (long long)sizeof(BvhNodeQ) : (long long)sizeof(BvhNode); out[2] = s->d.ldsScene;
+    out[3] = s->bvhDepth; out[4] = (long long)s->ldsSceneBytes; out[5] = s->d.ldsScene ? 0 : 1;
     return GDPT_OK;
 }
 

@@ -291,6 +291,8 @@ struct SceneView {
     uint32_t rootRef;
     float boundM;               // largest |coordinate| of the node bounds (error bound of the fp32 slab test)
     int quant;                  // nodes are BvhNodeQ records (uniform; a compile-time 0 in the kernels that stage the scene into LDS)
+    int leafExit;               // trace() leaves its inner-node loop once half of the wave's lanes on their way hold a leaf: a compile-time 1 in every kernel that reads
+                                // the tables from HBM, 0 in the kernels that stage the scene into LDS
 };
 
 // TriAccel::rayIntersect, triaccel.h:96-158
@@ -440,17 +442,36 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
     hit.t = GD_INF;
     if (!(maxt > mint)) return false;
     RayF R = ray_f(o, d, mint, maxt, sv.boundM);
-    // "while-while" form: every lane first walks inner nodes until it holds a leaf (or is done), then the wave tests its
-    // leaves together -- the two codes run with fuller exec masks than one loop that alternates per lane.
     constexpr uint32_t DONE = BVH_NONE;
     int sp = 0;
     uint32_t ref = sv.rootRef;
     while (true) {
-        while (!(ref & BVH_LEAF)) {
-            if (COUNT) tc->nodes++;
-            ref = node_step(sv, ref, R, stack, sp);
+        // inner nodes: every lane walks down to ITS next leaf ("while-while": the node code and the triangle code each run with fuller exec masks than one
+        // loop that alternates per lane) -- or, in the kernels that read the tables from HBM (leafExit), only until half of the lanes still on their way hold a
+        // leaf: a lane needs ~2 steps from one leaf to its next, the slowest of 64 several times that, and the lanes already at a leaf would wait for it with
+        // their triangle records' latency still ahead of them.  Leaving early only changes WHEN a lane's leaf is tested, not what the lane visits or in which
+        // order (a lane that still holds an inner node passes the leaf part).  Atrium frame 70.3 -> 64 ms (threshold sweep: 2/8 66.0, 3/8 64.4, 4/8 and 5/8 63.8),
+        // traversal-only kernel 1.25 -> 1.04 ms per 4.2 M rays; the LDS-resident box loses 1-4 % with it (a leaf costs it a few cycles of LDS latency, the
+        // extra passes through the loop more): those kernels keep the plain loop.
+        if (sv.leafExit) {
+            while (true) {
+                const bool inner = !(ref & BVH_LEAF);
+                const unsigned long long innerMask = __ballot(inner);
+                if (innerMask == 0) break;
+                if ((int)__popcll(__ballot(!inner && ref != DONE)) >= (int)__popcll(innerMask)) break;
+                if (inner) {
+                    if (COUNT) tc->nodes++;
+                    ref = node_step(sv, ref, R, stack, sp);
+                }
+            }
+        } else {
+            while (!(ref & BVH_LEAF)) {
+                if (COUNT) tc->nodes++;
+                ref = node_step(sv, ref, R, stack, sp);
+            }
         }
         if (ref == DONE) break;
+        if (!(ref & BVH_LEAF)) continue;
         const uint32_t first = (ref & ~BVH_LEAF) >> 3, cnt = (ref & 7u) + 1u;
         if (COUNT) tc->tris += cnt;
         for (uint32_t i = 0; i < cnt; i++) {
@@ -477,17 +498,17 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
 // 1280x720x32 Cornell pass.  Inside bounce(), where ~150 registers of path state are live, inlining is the faster form.
 // Arguments of a real call travel in VGPRs: only the four fields of the scene view the traversal reads are passed, which keeps the
 // callee within the 128 registers of the 4-wave builds (with the whole view it needs 132 and costs them a wave per SIMD).
-__device__ __noinline__ Hit trace_closest_fn(const BvhNode *nodes, const TriIsect *isect, uint32_t rootRef, float boundM, int quant, int *stack, d3 o, d3 d, Float mint, Float maxt)
+__device__ __noinline__ Hit trace_closest_fn(const BvhNode *nodes, const TriIsect *isect, uint32_t rootRef, float boundM, int quant, int leafExit, int *stack, d3 o, d3 d, Float mint, Float maxt)
 {
     SceneView sv;
-    sv.nodes = nodes; sv.isect = isect; sv.rootRef = rootRef; sv.boundM = boundM; sv.quant = quant;
+    sv.nodes = nodes; sv.isect = isect; sv.rootRef = rootRef; sv.boundM = boundM; sv.quant = quant; sv.leafExit = leafExit;
     Hit h;
     trace<false>(sv, stack, o, d, mint, maxt, h);
     return h;
 }
 __device__ __forceinline__ Hit trace_closest_call(const SceneView &sv, int *stack, d3 o, d3 d, Float mint, Float maxt)
 {
-    return trace_closest_fn(sv.nodes, sv.isect, sv.rootRef, sv.boundM, sv.quant, stack, o, d, mint, maxt);
+    return trace_closest_fn(sv.nodes, sv.isect, sv.rootRef, sv.boundM, sv.quant, sv.leafExit, stack, o, d, mint, maxt);
 }
 
 __device__ __forceinline__ Float ray_mint_closest(d3 o, Float mint)

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(TBLK) void k_render_serial(SceneD S, ConfigD cfg, F
     for (int i = 0; i < SF_WORDS; i++) s_rng[i] = state[i];
     s_rng[SF_WORDS] = SF_WORDS; s_rng[SF_WORDS + 1] = 0;
     SceneView sv;
-    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.quant = S.quantNodes; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.quant = S.quantNodes; sv.leafExit = 1; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
     const FilterD flt = box_filter();
     Lane L;
     L.rng.w = s_rng;

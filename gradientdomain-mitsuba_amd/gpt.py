@@ -152,6 +152,13 @@ class Scene:
         check(lib().gdpt_scene_intersect(self._h, n, od.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p)))
         return prim, tp[:, 0], tp[:, 1:4]
 
+    def layout(self):
+        """-> dict(nodes, node_bytes (128: fp32 boxes, LDS-resident scene; 64: 8-bit boxes, scene in HBM), lds_resident, stack_entries, table_bytes, leaf_exit)"""
+        out = (C.c_longlong * 6)()
+        lib().gdpt_scene_layout.argtypes = [C.c_void_p, C.c_void_p]
+        check(lib().gdpt_scene_layout(self._h, out))
+        return dict(nodes=int(out[0]), node_bytes=int(out[1]), lds_resident=bool(out[2]), stack_entries=int(out[3]), table_bytes=int(out[4]), leaf_exit=int(out[5]))
+
     def trace_stats(self, origins, dirs):
         """-> dict of mean inner nodes fetched / triangles tested per ray, closest-hit and any-hit (SURVEY 8d-B bytes per ray)."""
         od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))

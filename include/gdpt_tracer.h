@@ -261,6 +261,10 @@ GDPT_API int  gdpt_film_set_regeneration(gdpt_film *f, int idleLanes);
 /* Probe for the roofline note of SURVEY 8(d)-B: traversal statistics of numRays rays (origin, direction; unbounded), traced once as
  * closest-hit and once as any-hit queries: sums[0..3] = inner nodes fetched / triangles tested (closest), the same (any-hit). */
 GDPT_API int  gdpt_scene_trace_stats(gdpt_scene *s, int numRays, const double *originsDirs6, unsigned long long sums[4]);
+/* What the scene looks like on the device: out[0] = inner nodes of the BVH (four children each), out[1] = bytes per node (128: fp32 boxes, scenes staged
+ * into LDS; 64: 8-bit boxes, scenes in HBM), out[2] = 1 if the tables are staged into LDS by the render kernels, out[3] = traversal stack entries the tree can
+ * need, out[4] = bytes of the staged tables, out[5] = 1 if the render kernels read the tables from HBM (their traversal leaves its inner-node loop early, gpt_kernels.hip.h trace()). */
+GDPT_API int  gdpt_scene_layout(gdpt_scene *s, long long out[6]);
 /* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */
 GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *tp4);
 

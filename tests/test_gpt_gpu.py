@@ -27,6 +27,29 @@ def close(a, b, rel=REL):
     return np.abs(a - b).max() <= rel * scale
 
 
+def test_node_layout_follows_residency_and_both_layouts_find_the_same_hits(G, monkeypatch):
+    """Scenes staged into LDS get 128-byte nodes with fp32 boxes, scenes in HBM 64-byte nodes with 8-bit boxes on the node's grid and the early exit from
+    the inner-node loop ("BVH nodes"); both are conservative, so a ray meets the same triangle at the same distance, bit for bit, either way."""
+    box = scenes.cornell_box(32, 32, "glossy")
+    c = G.Scene(box); lc = c.layout()
+    assert lc["lds_resident"] and lc["node_bytes"] == 128 and lc["leaf_exit"] == 0 and 0 < lc["table_bytes"] <= 40 * 1024
+    a = G.Scene(scenes.atrium(64, 36)); la = a.layout()
+    assert not la["lds_resident"] and la["node_bytes"] == 64 and la["leaf_exit"] == 1 and la["nodes"] > 10000 and 4 < la["stack_entries"] < 40
+    a.close()
+    monkeypatch.setenv("GDPT_SCENE_IN_HBM", "1")
+    h = G.Scene(box); lh = h.layout()
+    monkeypatch.delenv("GDPT_SCENE_IN_HBM")
+    assert not lh["lds_resident"] and lh["node_bytes"] == 64 and lh["nodes"] == lc["nodes"] and lh["stack_entries"] == lc["stack_entries"]
+    rng = np.random.default_rng(2)
+    n = 20000
+    o = rng.uniform(50, 500, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pc, tc, _ = c.intersect(o, d); ph, th, _ = h.intersect(o, d)
+    assert (pc >= 0).mean() > 0.5 and np.array_equal(pc, ph) and np.array_equal(tc, th)
+    sc, sh = c.trace_stats(o, d), h.trace_stats(o, d)
+    assert sh["nodes_closest"] <= 1.15 * sc["nodes_closest"] and sh["tris_closest"] <= 1.15 * sc["tris_closest"]       # looser boxes: a few visits more, not many
+    c.close(); h.close()
+
+
 @pytest.mark.parametrize("builder", [lambda: scenes.cornell_box(64, 64, "glossy"), lambda: scenes.atrium(64, 36, columns=8, segments=12)])
 def test_bvh_closest_hit_matches_brute_force(G, builder):
     sc = builder()
