@@ -66,6 +66,11 @@ def _source_hash():
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "gradientdomain-mitsuba_amd", "csrc", "*"))):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    try:                                                                       # ... and of the flags they are compiled with (per-unit flags change kernels too)
+        import importlib
+        h.update(importlib.import_module("gradientdomain_mitsuba_amd._build")._flags_line().encode())
+    except Exception:
+        pass
     return h.hexdigest()[:16]
 
 

@@ -20,7 +20,10 @@ UNITS = {
 }
 # per-unit flags: the G-BDPT connection kernel meets its 2-waves-per-SIMD target only when no callee parks spills in AGPRs (one AGPR in a callee
 # makes the kernel's unified register count 257)
-UNIT_FLAGS = {"gbdpt_capi.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
+# -amdgpu-function-calls=0 (every device function inlined into its kernel): a callee is compiled without its kernel's occupancy target and may take AGPRs of its own --
+# k_bd_general (the general form of a G-BDPT sample, ~1 000 lines of callees) came out at 256 + 118 registers = ONE wave per SIMD; inlined it is 256 + 0 and two waves:
+# 400 -> 342 ms per 568 k general samples (round 4).  The unit takes 5 minutes instead of 40 s (beside gpt_capi.hip's 7).
+UNIT_FLAGS = {"gbdpt_capi.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-mllvm", "-amdgpu-function-calls=0"]}
 SOURCES = [os.path.join(CSRC, f) for f in UNITS]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", os.environ.get("GDPT_OPT", "-O3"), "-std=c++17", "-ffp-contract=off", "-fPIC",
