@@ -15,7 +15,7 @@ UNITS = {
     "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_shift5.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h", "gpt_serial.hip.h"],
     "gpt_wave_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"],
     "gpt_serial_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_serial.hip.h"],
-    "gbdpt_capi.hip": ["gpt_kernels.hip.h", "gbdpt_kernels.hip.h", "gpt_scene.hip.h"],
+    "gbdpt_capi.hip": ["gpt_kernels.hip.h", "gbdpt_kernels.hip.h", "gbdpt_general.hip.h", "gpt_scene.hip.h"],
     "device_capi.hip": [],
 }
 # per-unit flags: the G-BDPT connection kernel meets its 2-waves-per-SIMD target only when no callee parks spills in AGPRs (one AGPR in a callee

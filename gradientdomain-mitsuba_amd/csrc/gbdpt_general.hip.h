@@ -17,7 +17,7 @@
 //
 // One restatement in two places: this file follows oracle/gbdpt_oracle.hpp function by function (that file cites the reference line by line and
 // is held by closed forms and by the estimator's expectation, tests/test_gbdpt_oracle.py); parity of the two is held per sample at 1e-9
-// (tests/test_gbdpt_gpu.py).  Chains of more than GM_MAX - 2 vertices are not shifted (both sides).
+// (tests/test_gbdpt_gpu.py).
 #pragma once
 #include "gbdpt_kernels.hip.h"
 
@@ -25,7 +25,8 @@ namespace gdpt_bd {
 
 constexpr int GP_LEN = 32;                         // vertices of a path (the connected path: <= NEV + NSV)
 constexpr int GV_POOL = 176, GE_POOL = 176;        // vertex / edge records of one sample: both subpaths, the clones of createShiftablePath, four offset paths, one light path and its offset
-constexpr int GM_MAX = 12;                         // vertices of a specular manifold: two end points + a chain of up to 10 (longer chains are not shifted)
+constexpr int GM_MAX = 16;                         // vertices of a specular manifold: a path has at most BD_MAX_DEPTH + 3 = 15 vertices, so no chain is ever too long for it
+                                                   // (12 until the fuzz of round 4: a 9-vertex chain between two long subpaths left both half-Jacobians 0 and their ratio NaN)
 
 struct GPath {                                     // Path: m_vertices / m_edges as indices into the pool
     short v[GP_LEN], e[GP_LEN];
@@ -875,7 +876,14 @@ struct GTr {
             const bool allowedToConnect = W.connectable[p] && W.connectable[p + 1];
             if (allowedToConnect && (lightImage || tPrime > 1)) sum_p_i += value * geomTermX + oValue * jDet * geomTermY;   // std::pow(x, 1.0)
             if (tPrime == t) p_st = value * geomTermX;
+#ifdef GDPT_BD_TRACE
+            printf("G   miWeightGrad p %d value %.17g oValue %.17g allowed %d sum %.17g\n", p, value, oValue, (int)allowedToConnect, sum_p_i);
+#endif
         }
+#ifdef GDPT_BD_TRACE
+        printf("G   miWeightGrad s %d t %d jDet %.17g geomX %.17g geomY %.17g p_st %.17g sum %.17g\n", s, t, jDet, geomTermX, geomTermY, p_st, sum_p_i);
+        for (int i = 0; i <= k; i++) printf("G   pdf[%d] imp %.17g rad %.17g oImp %.17g oRad %.17g cs %d\n", i, W.pdfImp[i], W.pdfRad[i], W.oPdfImp[i], W.oPdfRad[i], (int)W.connectableStrict[i]);
+#endif
         return (Float)(p_st / sum_p_i);
     }
 

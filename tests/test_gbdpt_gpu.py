@@ -260,15 +260,19 @@ def test_config5_veach_1280x720_frame_matches_oracle(G, B):
     F.close(); S.close(); O.close()
 
 
-@pytest.mark.parametrize("seed", [9001, 9002, 9003, 9004, 9006, 9007])
-def test_fuzzed_connectable_scenes_match_oracle(G, B, seed):
+@pytest.mark.parametrize("seed,variant", [(9001, "random_connectable"), (9002, "random_connectable"), (9003, "random_connectable"), (9004, "random_connectable"),
+                                          (9006, "random_connectable"), (9007, "random_connectable"),
+                                          # round 4: materials from everything the path carries (smooth conductors, dielectrics, rough conductors on both sides of
+                                          # shiftThreshold): samples with specular chains -- the general form (GBDPT_FUZZ_SPECULAR=1 tools/gpu_gbdpt_fuzz.py)
+                                          (740001, "random"), (740002, "random"), (740003, "random"), (740004, "random"), (740006, "random"), (740007, "random")])
+def test_fuzzed_connectable_scenes_match_oracle(G, B, seed, variant):
     """A few seeds of tools/gpu_gbdpt_fuzz.py (which ran 34 000 of them on the round-3 binary: 816 000 single samples and 34 000 films, no difference
     beyond 1.2e-12 of a sample's scale): the four free surfaces of the box draw connectable materials from the seed (diffuse, rough conductors of
     all three distributions, anisotropic, one- or two-sided), random depth / Russian-roulette depth / light image; single samples through the probe
     entry and one film through the wavefront kernels."""
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(12, 36)), int(rng.integers(8, 28))
-    sc = scenes.cornell_box(W, H, "random_connectable", seed=seed)
+    sc = scenes.cornell_box(W, H, variant, seed=seed)
     md = int(rng.choice([-1, 1, 2, 3, 5, 8, 12])); rr = int(rng.choice([1, 3, 5])); li = bool(rng.random() < 0.7)
     spp = int(rng.integers(1, 4))
     S, O = G.Scene(sc), go.Scene(sc)

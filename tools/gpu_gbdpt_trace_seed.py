@@ -8,7 +8,7 @@ from oracle import gpt_oracle as go
 seed, px, py, smp = (int(v) for v in sys.argv[1:5])
 rng = np.random.default_rng(seed)
 W, H = int(rng.integers(12, 36)), int(rng.integers(8, 28))
-sc = scenes.veach_bidir(W, H) if seed % 5 == 0 else scenes.cornell_box(W, H, "random_connectable", seed=seed)
+sc = (scenes.veach_bidir(W, H, specular=True) if seed % 5 == 0 else scenes.cornell_box(W, H, "random", seed=seed)) if os.environ.get("GBDPT_FUZZ_SPECULAR") else (scenes.veach_bidir(W, H) if seed % 5 == 0 else scenes.cornell_box(W, H, "random_connectable", seed=seed))
 md = int(rng.choice([-1, 1, 2, 3, 5, 8, 12])); rr = int(rng.choice([1, 3, 5])); li = bool(rng.random() < 0.7)
 spp = int(rng.integers(1, 4))
 S = G.Scene(sc); O = go.Scene(sc)
