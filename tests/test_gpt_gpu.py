@@ -1232,6 +1232,41 @@ def test_serial_render_consumes_the_reference_stream_in_the_reference_order(G, v
     F2.close(); S.close(); O.close()
 
 
+def _serial_block(seed):
+    return (8, 16, 32)[seed % 3]
+
+
+@pytest.mark.parametrize("seed", [3, 6, 11, 12, 14, 17, 22, 31])
+def test_serial_render_on_fuzzed_scenes(G, seed):
+    """gdpt_render_serial on the scenes of tools/gpu_fuzz_campaign.py (random materials incl. glass and near-specular lobes; every third seed an environment, seeds
+    = 1 mod 5 vertex normals, = 2 mod 5 a point light, multiples of 7 the atrium, = 4 mod 9 a thin lens; random depth, roulette depth, strict normals, threshold):
+    the serial stream has no per-sample reset, so ONE draw out of place anywhere in the sampler's features shifts every later sample of the film."""
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(17, 44)), int(rng.integers(9, 34))
+    kind = "random"
+    kw = dict(seed=seed, environment=(0.5, 0.7, 0.9) if seed % 3 == 0 else None)
+    if seed % 5 == 1:
+        kind = "smooth" if seed % 2 else "bent"; kw = dict(environment=kw["environment"])
+    if seed % 5 == 2:
+        kw["point_light"] = ((float(rng.uniform(100, 450)), float(rng.uniform(200, 500)), float(rng.uniform(100, 450))), (4e4, 3e4, 2e4), bool(seed % 2))
+    sc = scenes.atrium(W, H, columns=int(rng.integers(4, 12)), segments=int(rng.integers(6, 16))) if seed % 7 == 0 else scenes.cornell_box(W, H, kind, **kw)
+    if seed % 9 == 4:
+        sc.thinlens = (float(rng.uniform(2.0, 60.0)), float(rng.uniform(300.0, 1500.0)))
+    md = int(rng.choice([-1, 2, 3, 5, 9])); rr = int(rng.choice([1, 3, 5])); strict = bool(rng.random() < 0.35); thr = float(rng.choice([0.001, 0.02, 0.0]))
+    spp = int(rng.integers(1, 4))
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, rrDepth=rr, strictNormals=strict, shiftThreshold=thr)
+    F = G.Film(S)
+    integ.renderSerial(S, F, integ.config(spp), blockSize=_serial_block(seed))
+    acc, st = F.accum(), F.stats()
+    F.close()
+    oacc, orays = O.render_serial(go.config(maxDepth=md, rrDepth=rr, strictNormals=strict, spp=spp, shiftThreshold=thr), block_size=_serial_block(seed))
+    assert (st["raysTraced"], st["shadowRaysTraced"]) == orays, seed
+    for b in range(5):
+        assert close(acc[b], oacc[b], rel=1e-9), (seed, G.BUFFER_NAMES[b], np.abs(acc[b] - oacc[b]).max())
+    S.close(); O.close()
+
+
 def test_thinlens_sensor_argument_checks_and_scope(G):
     sc = scenes.cornell_box(16, 12, "diffuse"); sc.thinlens = (0.0, 500.0)
     with pytest.raises(RuntimeError, match="apertureRadius"):
