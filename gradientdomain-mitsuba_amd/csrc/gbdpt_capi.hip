@@ -497,7 +497,7 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (specularScene && !f->work) {
         // two resident 256-thread blocks per CU (7.3 GB on 256 CUs), at most a fifth of what the device has free
         size_t freeB = 0, totalB = 0;
-        size_t budget = (size_t)8 << 30;
+        size_t budget = (size_t)10 << 30;             // (two 256-thread blocks per CU x 256 CUs = 131 072 workspaces of ~65 KB: 8.5 GB of the 288)
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 5);
         unsigned lanes = (unsigned)std::min<size_t>((size_t)s->numCUs * 2 * TBLK, budget / sizeof(GWork));
         lanes = std::max((unsigned)TBLK, lanes / TBLK * TBLK);

@@ -90,7 +90,7 @@ struct GWork {                                     // per-lane workspace (HBM)
     d3 impW[NEV + 1]; Float impP[NEV + 1];
     d3 radW[5][NSV + 1]; Float radP[5][NSV + 1];
     Float jacobianDet[5][NSV + 4], genGeomTerm[5][NSV + 4];
-    Float A[4 * GM_MAX * GM_MAX], Ai[4 * GM_MAX * GM_MAX];           // the dense system of SpecularManifold::det's mixed case: 2 (GM_MAX - 2) squared, twice
+    Float A[4 * (GM_MAX - 2) * (GM_MAX - 2)], Ai[4 * (GM_MAX - 2) * (GM_MAX - 2)];   // the dense system of SpecularManifold::det's mixed case: (2 (GM_MAX - 2)) squared, twice
     GPath emitter, sensor[5], connect, offsetEmitter, connectedBase;
     MuRec mu[5];
     int success[5], couldConnectAfterB[5];
