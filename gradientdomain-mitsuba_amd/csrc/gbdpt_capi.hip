@@ -236,41 +236,108 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
 }
 
-// The general form of a sample (specular chains; gbdpt_general.hip.h): one lane per listed sample, from the connected base path to its last
-// connection, in a workspace of its own.  Persistent lanes (a workspace is ~56 KB: the launch has as many lanes as there are workspaces:
-// two 256-thread blocks per CU = the 2 waves per SIMD its ~216 registers allow; with ONE wave per CU the first version took 957 ms for the
-// 568 k general samples of a 2 spp frame of the specular Veach scene).
-__global__ __launch_bounds__(TBLK, 2) void k_bd_general(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, const unsigned *__restrict__ genCount,
-                                                     GWork *__restrict__ work, Float *__restrict__ acc, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+// The general form of a sample (specular chains; gbdpt_general.hip.h) in three launches per pass over <= gsCap listed samples (round 5; round 4 ran a
+// sample from its connected base path to its last connection in ONE lane with a 56 KB workspace: 80 % of a config-5 frame at 10 % lane utilisation):
+//   k_bdg_shift    one lane per sample (persistent lanes, a manifold scratch each): the connected base path, its four offset paths with their walks,
+//                  Jacobians and generalized geometry terms, the prefix products -> the sample's GSamp record, read-only from here on; appends the
+//                  sample's connections to two item lists;
+//   k_bdg_connect  one lane per connection (s, t >= 2), ~25 per sample: reads the sample's record (lanes of a wave mostly share one), keeps its MIS arrays
+//                  private, allocates nothing; adds to the sample's 15 sums;
+//   k_bdg_light    one lane per light-tracing connection (s, 1): the only ones that build paths of their own (clones + four offset paths with manifold
+//                  walks) -- in the lane's transient pool (persistent lanes); splats into the light images.
+constexpr int GD_ITEMS = BD_ITEMS_PER_SAMPLE, GD_LIGHT = 16;       // connection items (t >= 2) / light items (<= NEV) per general sample
+__global__ __launch_bounds__(TBLK, 2) void k_bdg_shift(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, unsigned first, unsigned count,
+                                                    GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, unsigned *__restrict__ gItems, unsigned *__restrict__ gLight,
+                                                    unsigned *__restrict__ gCount, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
-    const unsigned lane = blockIdx.x * TBLK + threadIdx.x, lanes = gridDim.x * TBLK;
+    const unsigned lane = blockIdx.x * TBLK + threadIdx.x;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
-    const unsigned n = __hip_atomic_load(genCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned overflow = 0, done = 0;
-    GWork &W = work[lane];
-    (void)lanes;
-    // (samples differ by orders of magnitude in work -- connections, manifold walks: a lane takes the next sample of the list when it is done)
-    for (unsigned i = atomicAdd(const_cast<unsigned *>(genCount) + 1, 1u); i < n; i = atomicAdd(const_cast<unsigned *>(genCount) + 1, 1u)) {
-        const unsigned lid = genList[i];
-        GTr g(c, W);
+    // (samples differ by an order of magnitude in work -- chain lengths, manifold walks: a lane takes the next sample of the pass when it is done)
+    for (unsigned i = atomicAdd(gCount + 2, 1u); i < count; i = atomicAdd(gCount + 2, 1u)) {
+        const unsigned lid = genList[first + i];
+        GSamp &W = gsamp[i];
+        GTr g(c, W, &scratch[lane], nullptr);
         g.loadSubpaths(recs[lid]);
-        SampleOut out;
-        g.processSample(out);
-        overflow += W.overflow; done++;
-        Float *a = acc + (size_t)lid * 15;
-        a[0] = out.primal.x; a[1] = out.primal.y; a[2] = out.primal.z;
-        for (int k = 0; k < 4; k++) { a[3 + 3 * k] = out.gradient[k].x; a[4 + 3 * k] = out.gradient[k].y; a[5 + 3 * k] = out.gradient[k].z; }
-        const int Wd = S.cam.width, H = S.cam.height;
-        const size_t plane3 = (size_t)Wd * H * 3;
-        for (int k = 0; k < out.nLight; k++) film_put(light + out.light[k].buffer * plane3, 3, Wd, H, out.light[k].x, out.light[k].y, out.light[k].value, false, stats + 3);
+        g.prepare();
+        W.lid = lid;
+        done++;
+        if (g.overflow) { overflow += g.overflow; continue; }                                // (a pool ran out: the sample is void -- no connections, counted; asserted zero by tests and bench)
+        unsigned nC = 0, nL = 0;
+        for (int s = W.emitter.nv - 1; s >= 0; --s) {
+            int minT, maxT;
+            g.pairRange(s, minT, maxT);
+            if (maxT < minT) continue;
+            if (minT == 1) { nL++; minT = 2; }
+            if (maxT >= minT) nC += (unsigned)(maxT - minT + 1);
+        }
+        unsigned atC = nC ? atomicAdd(gCount + 0, nC) : 0u, atL = nL ? atomicAdd(gCount + 1, nL) : 0u;
+        for (int s = W.emitter.nv - 1; s >= 0; --s) {
+            int minT, maxT;
+            g.pairRange(s, minT, maxT);
+            for (int t = maxT; t >= minT; --t) {
+                const unsigned it = (i << 10) | ((unsigned)s << 5) | (unsigned)t;
+                if (t == 1) gLight[atL++] = it; else gItems[atC++] = it;
+            }
+        }
     }
     const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
     const unsigned r2 = __builtin_amdgcn_wave_reduce_add_u32(done, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1);
         if (r2) atomicAdd(stats + 4, (unsigned long long)r2);
+        if (r3) atomicAdd(stats + 5, (unsigned long long)r3);
+    }
+}
+
+__global__ __launch_bounds__(TBLK, 2) void k_bdg_connect(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, const unsigned *__restrict__ gItems, const unsigned *__restrict__ gCount,
+                                                      Float *__restrict__ acc, unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned n = __hip_atomic_load(gCount + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GMis mis;
+    for (unsigned i = blockIdx.x * TBLK + threadIdx.x; i < n; i += gridDim.x * TBLK) {
+        const unsigned it = gItems[i];
+        GSamp &W = gsamp[it >> 10];
+        GTrT<false> g(c, W, nullptr, &mis);
+        PairOut po;
+        if (!g.connectPair<false>((int)((it >> 5) & 31u), (int)(it & 31u), po)) continue;
+        Float *a = acc + (size_t)W.lid * 15;
+        atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z);
+        for (int k = 0; k < 4; k++) { atomicAdd(a + 3 + 3 * k, po.gradient[k].x); atomicAdd(a + 4 + 3 * k, po.gradient[k].y); atomicAdd(a + 5 + 3 * k, po.gradient[k].z); }
+    }
+    const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1); }
+}
+
+__global__ __launch_bounds__(TBLK, 2) void k_bdg_light(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, const unsigned *__restrict__ gLight,
+                                                    unsigned *__restrict__ gCount, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    const unsigned lane = blockIdx.x * TBLK + threadIdx.x;
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned n = __hip_atomic_load(gCount + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int Wd = S.cam.width, H = S.cam.height;
+    const size_t plane3 = (size_t)Wd * H * 3;
+    unsigned overflow = 0;
+    GMis mis;
+    for (unsigned i = atomicAdd(gCount + 3, 1u); i < n; i = atomicAdd(gCount + 3, 1u)) {
+        const unsigned it = gLight[i];
+        GTr g(c, gsamp[it >> 10], &scratch[lane], &mis);
+        PairOut po;
+        const bool ok = g.connectPair<true>((int)((it >> 5) & 31u), 1, po);
+        if (g.overflow) { overflow += g.overflow; continue; }
+        if (!ok) continue;
+        for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, Wd, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
+    }
+    const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1);
         if (r3) atomicAdd(stats + 5, (unsigned long long)r3);
     }
 }
@@ -302,7 +369,7 @@ __global__ __launch_bounds__(TBLK) void k_gbdpt_sample(SceneD S, BdCam cam, BdCo
             GTr g(c, *work);
             g.loadSubpaths(sm);
             g.processSample(out);
-            counters[2] = 1; counters[3] = work->overflow;
+            counters[2] = 1; counters[3] = g.overflow;
         } else {
             c.nClosest = c.nShadow = 0;
             c.rng.init(cfg.seed, (uint64_t)py * S.cam.width + px, (uint64_t)sample);
@@ -354,10 +421,13 @@ struct gdpt_gbdpt_film {
     unsigned *items = nullptr, *itemCount = nullptr;
     Float *acc = nullptr;
     unsigned capacity = 0;
-    // the general form (specular chains): the samples that need it, and one workspace per persistent lane of k_bd_general
+    // the general form (specular chains): the samples that need it; one record per sample of a pass (k_bdg_shift writes it, the connection kernels
+    // read it), one scratch per persistent lane of k_bdg_shift / k_bdg_light, the two item lists of a pass and their counters / cursors
     unsigned *genList = nullptr, *genCount = nullptr;
-    GWork *work = nullptr;
-    unsigned workLanes = 0;
+    GSamp *gsamp = nullptr;
+    GScratch *gscratch = nullptr;
+    unsigned *gItems = nullptr, *gLight = nullptr, *gCount = nullptr;
+    unsigned gsCap = 0, gLanes = 0;
     double sceneRadius = 0.0;
 };
 
@@ -394,29 +464,6 @@ BdCam make_cam(const gdpt_scene *s)
     return cam;
 }
 
-// m_scene->getBSphere().radius: the bounding sphere of the kd-tree's bounds, which GenericKDTree::buildInternal enlarges by MTS_KD_AABB_EPSILON
-// (gkdtree.h:50,1213-1219; the second line sees the already-moved minimum, as there); the vertices are the fp64 ones of the shading table
-int scene_radius(const gdpt_scene *s, double *radius)
-{
-    std::vector<TriShade> sh((size_t)s->d.numTris);
-    BHIPCHK(hipMemcpy(sh.data(), s->d.shade, sizeof(TriShade) * sh.size(), hipMemcpyDeviceToHost));
-    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-    for (const TriShade &t : sh)
-        for (const d3 &p : {t.p0, t.p1, t.p2}) {
-            mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
-            mx[0] = std::max(mx[0], p.x); mx[1] = std::max(mx[1], p.y); mx[2] = std::max(mx[2], p.z);
-        }
-    const double eps = (double)1e-3f;
-    for (int a = 0; a < 3; a++) mn[a] = mn[a] - ((mx[a] - mn[a]) * eps + eps);
-    for (int a = 0; a < 3; a++) mx[a] = mx[a] + ((mx[a] - mn[a]) * eps + eps);
-    double r2 = 0.0;
-    double d[3];
-    for (int a = 0; a < 3; a++) { const double ctr = (mn[a] + mx[a]) * 0.5; d[a] = mx[a] - ctr; }
-    r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    *radius = std::sqrt(r2);
-    return GDPT_OK;
-}
-
 BdConfig make_cfg(const gdpt_gbdpt_config *cfg, double sceneRadius)
 {
     BdConfig c;
@@ -442,8 +489,9 @@ int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
     BHIPCHK(hipMalloc((void **)&f->block, sizeof(Float) * 5 * npix * 4));
     BHIPCHK(hipMalloc((void **)&f->light, sizeof(Float) * 5 * npix * 3));
     BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 8));           // [0..3] the public counters; [4] samples run in the general form, [5] workspace overflows
-    BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned) * 2));               // entries of the general list, k_bd_general's cursor
-    if (int rc = scene_radius(s, &f->sceneRadius)) { delete f; return rc; }
+    BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned) * 2));               // entries of the general list
+    BHIPCHK(hipMalloc((void **)&f->gCount, sizeof(unsigned) * 4));                 // of a pass: connection items, light items, k_bdg_shift's cursor, k_bdg_light's cursor
+    f->sceneRadius = s->bsphereRadius;              // m_scene->getBSphere().radius (gpt_capi.hip: kd-tree bounds + sensor + emitters, scene.cpp:386-413)
     BHIPCHK(hipStreamCreate(&f->stream));
     BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1));
     *out = f;
@@ -457,7 +505,7 @@ void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
     if (f->stream) hipStreamSynchronize(f->stream);
     hipFree(f->block); hipFree(f->light); hipFree(f->stats);
     hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
-    hipFree(f->genList); hipFree(f->genCount); hipFree(f->work);
+    hipFree(f->genList); hipFree(f->genCount); hipFree(f->gsamp); hipFree(f->gscratch); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gCount);
     if (f->e0) hipEventDestroy(f->e0);
     if (f->e1) hipEventDestroy(f->e1);
     if (f->stream) hipStreamDestroy(f->stream);
@@ -491,18 +539,29 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     // several films on one GPU (strips wrapped onto a device, a G-PT film resident beside this one) or a partitioned / smaller part each get a
     // share instead of failing -- halved again while the allocation itself fails.  GDPT_BD_CHUNK forces a size (tests of the chunk loop).
     const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15 + sizeof(unsigned);   // record + three item lists with two survivor lists each + sums + general-list entry
-    // the general form's workspaces (only scenes that can produce a specular vertex need them): one per persistent lane, at most 1 GB
+    // the general form's memory (only scenes that can produce a specular vertex need it): a scratch per persistent lane (two 256-thread blocks per CU:
+    // 131 072 x 35 KB = 4.6 GB on 256 CUs) and the records + item lists of a pass (4 samples per lane: 524 288 x 36 KB = 19 GB of the 288) -- at most a
+    // quarter of what the device has free, halved until it fits
     bool specularScene = false;
     for (const MaterialD &m : s->hostMats) if (m.type == 1 || m.type == 3 || (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold)) specularScene = true;
-    if (specularScene && !f->work) {
-        // two resident 256-thread blocks per CU (7.3 GB on 256 CUs), at most a fifth of what the device has free
+    if (specularScene && !f->gsamp) {
         size_t freeB = 0, totalB = 0;
-        size_t budget = (size_t)10 << 30;             // (two 256-thread blocks per CU x 256 CUs = 131 072 workspaces of ~65 KB: 8.5 GB of the 288)
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 5);
-        unsigned lanes = (unsigned)std::min<size_t>((size_t)s->numCUs * 2 * TBLK, budget / sizeof(GWork));
-        lanes = std::max((unsigned)TBLK, lanes / TBLK * TBLK);
-        if (hipMalloc((void **)&f->work, sizeof(GWork) * (size_t)lanes) != hipSuccess) { (void)hipGetLastError(); return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT general-form workspaces: %.1f MB)", sizeof(GWork) * (double)lanes / 1e6); }
-        f->workLanes = lanes;
+        size_t budget = (size_t)32 << 30;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 4);
+        unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 4 * lanes;
+        if (const char *e = getenv("GDPT_BD_GENERAL_PASS")) cap = (unsigned)std::max<long long>(1, atoll(e));      // (tests of the pass loop)
+        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (GD_ITEMS + GD_LIGHT);
+        for (;;) {
+            while ((size_t)lanes * sizeof(GScratch) + (size_t)cap * perSampleG > budget && (lanes > TBLK || cap > TBLK)) { if (cap > lanes) cap /= 2; else lanes = std::max<unsigned>(TBLK, lanes / 2 / TBLK * TBLK); }
+            if (hipMalloc((void **)&f->gscratch, sizeof(GScratch) * (size_t)lanes) == hipSuccess && hipMalloc((void **)&f->gsamp, sizeof(GSamp) * (size_t)cap) == hipSuccess &&
+                hipMalloc((void **)&f->gItems, sizeof(unsigned) * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * GD_LIGHT * (size_t)cap) == hipSuccess) break;
+            (void)hipGetLastError();
+            hipFree(f->gscratch); hipFree(f->gsamp); hipFree(f->gItems); hipFree(f->gLight);
+            f->gscratch = nullptr; f->gsamp = nullptr; f->gItems = nullptr; f->gLight = nullptr;
+            if (budget <= ((size_t)64 << 20)) return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT general-form records: %.1f MB)", ((double)lanes * sizeof(GScratch) + (double)cap * perSampleG) / 1e6);
+            budget /= 2;
+        }
+        f->gLanes = lanes; f->gsCap = cap;
     }
     unsigned chunk = (unsigned)std::min<long long>(total, BD_CHUNK);
     if (const char *e = getenv("GDPT_BD_CHUNK")) chunk = (unsigned)std::max<long long>(1, std::min<long long>(chunk, atoll(e)));
@@ -539,11 +598,22 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         const unsigned pgrid = std::min<unsigned>((count + TBLK - 1) / TBLK, (unsigned)s->numCUs * 2u);      // persistent: the grid that is resident at 2 waves per SIMD
         hipLaunchKernelGGL(k_bd_paths, dim3(pgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->stats);
         hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats, f->genList, f->genCount);
-        if (f->work) hipLaunchKernelGGL(k_bd_general, dim3(f->workLanes / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->genList, f->genCount, f->work, f->acc, f->light, f->stats);
         BHIPCHK(hipGetLastError());
-        unsigned nItems[3] = {0, 0, 0};
+        unsigned nItems[3] = {0, 0, 0}, nGen = 0;
         BHIPCHK(hipMemcpyAsync(nItems, f->itemCount, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, f->stream));
+        BHIPCHK(hipMemcpyAsync(&nGen, f->genCount, sizeof(unsigned), hipMemcpyDeviceToHost, f->stream));
         BHIPCHK(hipStreamSynchronize(f->stream));                                          // the sizes of the connection launches come from the walk
+        if (nGen && !f->gsamp) return bfail(GDPT_ERR_HIP, "G-BDPT: a sample needs the general form in a scene without a specular material");
+        for (unsigned gFirst = 0; gFirst < nGen; gFirst += f->gsCap) {                     // the general form, a pass of <= gsCap samples at a time
+            const unsigned gN = std::min(f->gsCap, nGen - gFirst);
+            BHIPCHK(hipMemsetAsync(f->gCount, 0, sizeof(unsigned) * 4, f->stream));
+            const unsigned lgrid = std::min((gN + TBLK - 1) / TBLK, f->gLanes / TBLK);
+            hipLaunchKernelGGL(k_bdg_shift, dim3(lgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->genList, gFirst, gN, f->gsamp, f->gscratch, f->gItems, f->gLight, f->gCount, f->stats);
+            const unsigned cgridG = (unsigned)std::min<size_t>(((size_t)gN * 24 + TBLK - 1) / TBLK, (size_t)s->numCUs * 16);   // (grid-stride over the list, whose length only the device knows)
+            hipLaunchKernelGGL(k_bdg_connect, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gItems, f->gCount, f->acc, f->stats);
+            hipLaunchKernelGGL(k_bdg_light, dim3(std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK)), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, f->gLight, f->gCount, f->light, f->stats);
+            BHIPCHK(hipGetLastError());
+        }
         for (int q = 0; q < 3; q++) {
             if (!nItems[q]) continue;
             const dim3 cgrid((nItems[q] + TBLK - 1) / TBLK);
@@ -659,27 +729,24 @@ int gdpt_gbdpt_evaluate_sample2(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int
     if (int rc = check_scope(s, cfg)) return rc;
     BHIPCHK(hipSetDevice(s->device));
     const BdCam cam = make_cam(s);
-    double radius = 0.0;
-    if (int rc = scene_radius(s, &radius)) return rc;
-    const BdConfig c = make_cfg(cfg, radius);
-    double *d = nullptr, *dl = nullptr;
-    int *dn = nullptr;
-    unsigned long long *dc = nullptr;
-    GWork *work = nullptr;
+    const BdConfig c = make_cfg(cfg, s->bsphereRadius);
+    struct Bufs {                                  // (freed on every return path)
+        double *d = nullptr, *dl = nullptr; int *dn = nullptr; unsigned long long *dc = nullptr; GWork *work = nullptr;
+        ~Bufs() { hipFree(d); hipFree(dl); hipFree(dn); hipFree(dc); hipFree(work); }
+    } b;
     const int ml = std::max(maxLight, 1);
-    BHIPCHK(hipMalloc((void **)&d, sizeof(double) * 17));
-    BHIPCHK(hipMalloc((void **)&dl, sizeof(double) * 6 * ml));
-    BHIPCHK(hipMalloc((void **)&dn, sizeof(int)));
-    BHIPCHK(hipMalloc((void **)&dc, sizeof(unsigned long long) * 4));
-    BHIPCHK(hipMalloc((void **)&work, sizeof(GWork)));
-    BHIPCHK(hipMemset(dc, 0, sizeof(unsigned long long) * 4));
-    hipLaunchKernelGGL(k_gbdpt_sample, dim3(1), dim3(TBLK), 0, 0, s->d, cam, c, px, py, sample, d, maxLight, dl, dn, dc, work);
+    BHIPCHK(hipMalloc((void **)&b.d, sizeof(double) * 17));
+    BHIPCHK(hipMalloc((void **)&b.dl, sizeof(double) * 6 * ml));
+    BHIPCHK(hipMalloc((void **)&b.dn, sizeof(int)));
+    BHIPCHK(hipMalloc((void **)&b.dc, sizeof(unsigned long long) * 4));
+    BHIPCHK(hipMalloc((void **)&b.work, sizeof(GWork)));
+    BHIPCHK(hipMemset(b.dc, 0, sizeof(unsigned long long) * 4));
+    hipLaunchKernelGGL(k_gbdpt_sample, dim3(1), dim3(TBLK), 0, 0, s->d, cam, c, px, py, sample, b.d, maxLight, b.dl, b.dn, b.dc, b.work);
     BHIPCHK(hipGetLastError());
-    BHIPCHK(hipMemcpy(out17, d, sizeof(double) * 17, hipMemcpyDeviceToHost));
-    BHIPCHK(hipMemcpy(nLight, dn, sizeof(int), hipMemcpyDeviceToHost));
-    if (maxLight > 0) BHIPCHK(hipMemcpy(light6, dl, sizeof(double) * 6 * std::min(maxLight, std::max(*nLight, 0)), hipMemcpyDeviceToHost));
-    BHIPCHK(hipMemcpy(counters, dc, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
-    hipFree(d); hipFree(dl); hipFree(dn); hipFree(dc); hipFree(work);
+    BHIPCHK(hipMemcpy(out17, b.d, sizeof(double) * 17, hipMemcpyDeviceToHost));
+    BHIPCHK(hipMemcpy(nLight, b.dn, sizeof(int), hipMemcpyDeviceToHost));
+    if (maxLight > 0) BHIPCHK(hipMemcpy(light6, b.dl, sizeof(double) * 6 * std::min(maxLight, std::max(*nLight, 0)), hipMemcpyDeviceToHost));
+    BHIPCHK(hipMemcpy(counters, b.dc, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
     return GDPT_OK;
 }
 

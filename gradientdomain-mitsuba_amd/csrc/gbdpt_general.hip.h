@@ -12,8 +12,11 @@
 // Offset paths then replace a variable number of vertices, so this form keeps the reference's own shape: paths are lists of indices into a pool
 // of vertex / edge records (the reference's paths share PathVertex objects by pointer, and evaluate() mutates shared vertices -- cast(), the
 // measure of connected end points -- which index lists reproduce for free), one lane runs one sample from the connected base path to its last
-// connection.  The pool, the manifold's vertices and the MIS arrays live in a per-lane workspace in HBM (~56 KB): this is the SLOW path, there
-// for completeness; samples without a specular vertex never enter it.  The two subpaths come from the same walk (k_bd_paths) as the fast form's.
+// connection -- in the probe entry.  The frame kernels (gbdpt_capi.hip, round 5) run the stages of a sample as separate launches over the
+// sample's record in HBM: the shift stage (one lane per sample: connected base path, four offset paths, Jacobians; GTr::prepare), the connections
+// (one lane per (s, t): GTr::connectPair<false>), the light-tracing connections (one lane per (s, 1), the only ones that allocate and walk
+// manifolds: connectPair<true>).  Samples without a specular vertex never enter any of it.  The two subpaths come from the same walk
+// (k_bd_paths) as the fast form's.
 //
 // One restatement in two places: this file follows oracle/gbdpt_oracle.hpp function by function (that file cites the reference line by line and
 // is held by closed forms and by the estimator's expectation, tests/test_gbdpt_oracle.py); parity of the two is held per sample at 1e-9
@@ -24,7 +27,7 @@
 namespace gdpt_bd {
 
 constexpr int GP_LEN = 32;                         // vertices of a path (the connected path: <= NEV + NSV)
-constexpr int GV_POOL = 176, GE_POOL = 176;        // vertex / edge records of one sample: both subpaths, the clones of createShiftablePath, four offset paths, one light path and its offset
+constexpr int GV_POOL = 144, GE_POOL = 144;        // vertex / edge records of one sample: both subpaths (<= 27), the clones of createShiftablePath (2), four offset paths (<= 28 each: 15 new + 13 re-cloned after a failed walk)
 constexpr int GM_MAX = 16;                         // vertices of a specular manifold: a path has at most BD_MAX_DEPTH + 3 = 15 vertices, so no chain is ever too long for it
                                                    // (12 until the fuzz of round 4: a 9-vertex chain between two long subpaths left both half-Jacobians 0 and their ratio NaN)
 
@@ -80,22 +83,39 @@ __device__ __forceinline__ void mv_init(MV &v, int type, d3 p)
 }
 struct MuRec { int l, m; int extra[5]; };
 
-struct GWork {                                     // per-lane workspace (HBM)
+// What a sample's stages share, in three pieces (round 5: round 4 kept all of it in ONE 56 KB per-lane workspace and ran a sample from its connected
+// base path to its last connection in one lane -- 10 % lane utilisation, 385 GB of fabric traffic per launch):
+//   GSamp     the SAMPLE's state, in HBM, written once by the shift stage (k_bdg_shift) and read-only afterwards: the pool of vertex / edge records,
+//             the paths as index lists, the per-offset Jacobians and generalized geometry terms, the prefix products -- what every connection reads;
+//   GScratch  what a LANE needs while it runs manifold code or builds a light path: the manifold's two vertex lists, the dense system, a small
+//             transient pool (indices >= GV_POOL) -- only the shift stage and the light-tracing connections have one (persistent lanes);
+//   GMis      the strategy densities of one connection: private to a lane (registers / scratch of the connection kernels).
+constexpr int GL_POOL = 48;                        // transient records of ONE light-tracing connection: two clones + one offset path at a time (<= 15 new + 13 re-cloned vertices)
+struct GSamp {
     BV v[GV_POOL]; BE e[GE_POOL];
     int nv, ne;
-    MV mv[GM_MAX], mp[GM_MAX];
-    int nm, nmp, mIterations, pad;
-    Float pdfImp[GP_LEN + 2], pdfRad[GP_LEN + 2], oPdfImp[GP_LEN + 2], oPdfRad[GP_LEN + 2];
-    char connectable[GP_LEN + 2], connectableStrict[GP_LEN + 2];
-    d3 impW[NEV + 1]; Float impP[NEV + 1];
-    d3 radW[5][NSV + 1]; Float radP[5][NSV + 1];
-    Float jacobianDet[5][NSV + 4], genGeomTerm[5][NSV + 4];
-    Float A[4 * (GM_MAX - 2) * (GM_MAX - 2)], Ai[4 * (GM_MAX - 2) * (GM_MAX - 2)];   // the dense system of SpecularManifold::det's mixed case: (2 (GM_MAX - 2)) squared, twice
-    GPath emitter, sensor[5], connect, offsetEmitter, connectedBase;
+    GPath emitter, sensor[5], connect;
     MuRec mu[5];
     int success[5], couldConnectAfterB[5];
-    unsigned overflow;                             // a pool or a list ran out (the sample's result is then void: counted, asserted zero by the tests)
+    Float jacobianDet[5][NSV + 4], genGeomTerm[5][NSV + 4];
+    d3 impW[NEV + 1]; Float impP[NEV + 1];
+    d3 radW[5][NSV + 1]; Float radP[5][NSV + 1];
+    int vert_b;                                    // connectPath.vertexCount() - 1 - muRec.extra[1]: the sensor-side index of b
+    unsigned lid;                                  // the sample's record in the chunk
 };
+struct GScratch {
+    MV mv[GM_MAX], mp[GM_MAX];
+    int nm, nmp, mIterations, pad;
+    Float A[4 * (GM_MAX - 2) * (GM_MAX - 2)], Ai[4 * (GM_MAX - 2) * (GM_MAX - 2)];   // the dense system of SpecularManifold::det's mixed case: (2 (GM_MAX - 2)) squared, twice
+    BV lv[GL_POOL]; BE le[GL_POOL];
+    int nlv, nle;
+    GPath offsetEmitter, connectedBase;
+};
+struct GMis {
+    Float pdfImp[GP_LEN + 2], pdfRad[GP_LEN + 2], oPdfImp[GP_LEN + 2], oPdfRad[GP_LEN + 2];
+    char connectable[GP_LEN + 2], connectableStrict[GP_LEN + 2];
+};
+struct GWork { GSamp s; GScratch x; GMis m; };    // all three for one lane: the probe entry (one sample, start to end, in one lane)
 
 // its.dpdu / its.dpdv of a triangle hit (skdtree.h:373-380, trimesh.cpp:683-735): the edges, or the UV tangents of a mesh with texture coordinates
 __device__ void tri_partials(const Ctx &c, int prim, d3 &dpdu, d3 &dpdv)
@@ -120,19 +140,36 @@ __device__ void tri_partials(const Ctx &c, int prim, d3 &dpdu, d3 &dpdv)
     }
 }
 
-struct GTr {
+// HAS_X: the lane has a GScratch (manifold code, transient pool).  The connection kernel for t >= 2 builds GTrT<false>: every pool index is the sample's.
+template <bool HAS_X>
+struct GTrT {
     Ctx &c;
-    GWork &W;
-    __device__ GTr(Ctx &c_, GWork &w_) : c(c_), W(w_) {}
+    GSamp &W;
+    GScratch *X;                                   // nullptr in the connection kernel for t >= 2: nothing there allocates or touches a manifold
+    GMis *M;
+    bool localAlloc = false;                       // allocations go to the lane's transient pool (a light-tracing connection), not to the sample's
+    unsigned overflow = 0;                         // a pool or a list ran out (the sample's result is then void: counted, asserted zero by the tests)
+    __device__ GTrT(Ctx &c_, GSamp &w_, GScratch *x_, GMis *m_) : c(c_), W(w_), X(x_), M(m_) {}
+    __device__ GTrT(Ctx &c_, GWork &w_) : c(c_), W(w_.s), X(&w_.x), M(&w_.m) {}
 
-    // ---- pool ----
-    __device__ int allocV() { if (W.nv >= GV_POOL) { W.overflow++; return GV_POOL - 1; } bv_clear(W.v[W.nv]); return W.nv++; }
-    __device__ int allocE() { if (W.ne >= GE_POOL) { W.overflow++; return GE_POOL - 1; } be_clear(W.e[W.ne]); return W.ne++; }
-    __device__ int cloneV(int i) { const int j = allocV(); W.v[j] = W.v[i]; return j; }
-    __device__ BV &V_(const GPath &p, int i) { return W.v[p.v[i]]; }
-    __device__ BE &E_(const GPath &p, int i) { return W.e[p.e[i]]; }
-    __device__ BV *VN(const GPath &p, int i) { return (i < 0 || i >= p.nv) ? nullptr : &W.v[p.v[i]]; }
-    __device__ BE *EN(const GPath &p, int i) { return (i < 0 || i >= p.ne) ? nullptr : &W.e[p.e[i]]; }
+    // ---- pool: indices < GV_POOL are the sample's records, the others the lane's transient ones ----
+    __device__ int allocV()
+    {
+        if (HAS_X && localAlloc) { if (X->nlv >= GL_POOL) { overflow++; return GV_POOL + GL_POOL - 1; } bv_clear(X->lv[X->nlv]); return GV_POOL + X->nlv++; }
+        if (W.nv >= GV_POOL) { overflow++; return GV_POOL - 1; } bv_clear(W.v[W.nv]); return W.nv++;
+    }
+    __device__ int allocE()
+    {
+        if (HAS_X && localAlloc) { if (X->nle >= GL_POOL) { overflow++; return GE_POOL + GL_POOL - 1; } be_clear(X->le[X->nle]); return GE_POOL + X->nle++; }
+        if (W.ne >= GE_POOL) { overflow++; return GE_POOL - 1; } be_clear(W.e[W.ne]); return W.ne++;
+    }
+    __device__ __forceinline__ BV &PV(int i) { if (!HAS_X) return W.v[i]; return i < GV_POOL ? W.v[i] : X->lv[i - GV_POOL]; }
+    __device__ __forceinline__ BE &PE_(int i) { if (!HAS_X) return W.e[i]; return i < GE_POOL ? W.e[i] : X->le[i - GE_POOL]; }
+    __device__ int cloneV(int i) { const int j = allocV(); PV(j) = PV(i); return j; }
+    __device__ BV &V_(const GPath &p, int i) { return PV(p.v[i]); }
+    __device__ BE &E_(const GPath &p, int i) { return PE_(p.e[i]); }
+    __device__ BV *VN(const GPath &p, int i) { return (i < 0 || i >= p.nv) ? nullptr : &PV(p.v[i]); }
+    __device__ BE *EN(const GPath &p, int i) { return (i < 0 || i >= p.ne) ? nullptr : &PE_(p.e[i]); }
 
     // ---- PathVertex with transport modes (the fast form's helpers are radiance-only where the BSDF is symmetric) ----
     __device__ d3 gEval(const BV &v, const BV *pred, const BV *succ, int mode, int measure = M_AREA)
@@ -320,12 +357,12 @@ struct GTr {
         const int step = start < end ? 1 : -1;
         if (bv_super(V_(path, start))) start += step;
         if (bv_super(V_(path, end))) end -= step;
-        W.nm = 0;
+        X->nm = 0;
         if ((end - start) * step + 1 > GM_MAX) return false;
-        mv_init(W.mv[W.nm++], MV_PINNED, V_(path, start).p);
+        mv_init(X->mv[X->nm++], MV_PINNED, V_(path, start).p);
         for (int i = start + step; i != end; i += step) {
             const BV &pred = V_(path, i - step), &vertex = V_(path, i), &succ = V_(path, i + step);
-            MV &m = W.mv[W.nm++];
+            MV &m = X->mv[X->nm++];
             mv_init(m, MV_PINNED, mk(0.0));
             if (vertex.type != T_SURFACE) return false;
             manifoldSurface(m, vertex);
@@ -335,17 +372,17 @@ struct GTr {
             if (dot(m.gn, wPred) * dot(m.gn, wSucc) < 0) { m.type = MV_REFRACTION; m.eta = bsdf_eta(c.V.mats[m.object]); }
             else { m.type = MV_REFLECTION; m.eta = 1.0; }
         }
-        mv_init(W.mv[W.nm++], MV_MOVABLE, V_(path, end).p);
+        mv_init(X->mv[X->nm++], MV_MOVABLE, V_(path, end).p);
         return true;
     }
     __device__ bool manifoldTangents()                                                       // manifold.cpp:172-400
     {
-        const int n = W.nm - 1;
-        W.mv[0].Tp.setZero();
-        W.mv[W.nm - 1].Tp.setIdentity();
-        if (W.nm == 2) return true;
+        const int n = X->nm - 1;
+        X->mv[0].Tp.setZero();
+        X->mv[X->nm - 1].Tp.setIdentity();
+        if (X->nm == 2) return true;
         for (int i = 0; i < n; ++i) {
-            MV *v = &W.mv[i];
+            MV *v = &X->mv[i];
             d3 wo = v[1].p - v[0].p;
             Float ilo = len(wo);
             if (ilo == 0) return false;
@@ -389,14 +426,14 @@ struct GTr {
             if (dot(H, v[0].gn) < 0) v[0].m = -v[0].m;
         }
         M2 Li;
-        if (!W.mv[0].b.invert(Li)) return false;
+        if (!X->mv[0].b.invert(Li)) return false;
         for (int i = 0; i < n - 1; ++i) {
-            W.mv[i].u = m2mul(Li, W.mv[i].c);
-            const M2 temp = m2sub(W.mv[i + 1].b, m2mul(W.mv[i + 1].a, W.mv[i].u));
+            X->mv[i].u = m2mul(Li, X->mv[i].c);
+            const M2 temp = m2sub(X->mv[i + 1].b, m2mul(X->mv[i + 1].a, X->mv[i].u));
             if (!temp.invert(Li)) return false;
         }
-        W.mv[n - 1].Tp = m2neg(m2mul(Li, W.mv[n - 1].c));
-        for (int i = n - 2; i >= 0; --i) W.mv[i].Tp = m2neg(m2mul(W.mv[i].u, W.mv[i + 1].Tp));
+        X->mv[n - 1].Tp = m2neg(m2mul(Li, X->mv[n - 1].c));
+        for (int i = n - 2; i >= 0; --i) X->mv[i].Tp = m2neg(m2mul(X->mv[i].u, X->mv[i + 1].Tp));
         return true;
     }
     __device__ static d3 reflectAbout(d3 wi, d3 n) { return n * (2 * dot(wi, n)) - wi; }      // util.cpp:763-765
@@ -411,15 +448,15 @@ struct GTr {
     }
     __device__ bool manifoldProject(d3 d)                                                    // manifold.cpp:402-510
     {
-        const MV &last = W.mv[W.nm - 1];
+        const MV &last = X->mv[X->nm - 1];
         const Float du = dot(d, last.dpdu), dv = dot(d, last.dpdv);
         d3 ro = mk(0.0), rd = mk(0.0);
-        W.nmp = 0;
-        for (int i = 0; i < W.nm; ++i) {
-            W.mp[W.nmp++] = W.mv[i];
-            MV &vertex = W.mp[i];
+        X->nmp = 0;
+        for (int i = 0; i < X->nm; ++i) {
+            X->mp[X->nmp++] = X->mv[i];
+            MV &vertex = X->mp[i];
             if (i == 0) {
-                const d3 p0 = W.mv[0].p + W.mv[0].map(du, dv), p1 = W.mv[1].p + W.mv[1].map(du, dv);
+                const d3 p0 = X->mv[0].p + X->mv[0].map(du, dv), p1 = X->mv[1].p + X->mv[1].map(du, dv);
                 ro = p0; rd = normalize(p1 - p0);
                 vertex.p = ro;
                 continue;
@@ -453,34 +490,34 @@ struct GTr {
     }
     __device__ bool manifoldMove(d3 target, d3 n)                                            // manifold.cpp:512-635
     {
-        MV &last = W.mv[W.nm - 1];
-        if (W.nm == 2 && W.mv[0].type == MV_PINNED) return true;
+        MV &last = X->mv[X->nm - 1];
+        if (X->nm == 2 && X->mv[0].type == MV_PINNED) return true;
         const Float invScale = 1.0 / fmax(fmax(fabs(target.x), fabs(target.y)), fabs(target.z));
         Float stepSize = 1;
         if (fabs(n.x) > fabs(n.y)) { const Float il = 1.0 / sqrt(n.x * n.x + n.z * n.z); last.dpdv = mk(n.z * il, 0.0, -n.x * il); }   // coordinateSystem(n, dpdu, dpdv), util.cpp:592-601
         else { const Float il = 1.0 / sqrt(n.y * n.y + n.z * n.z); last.dpdv = mk(0.0, n.z * il, -n.y * il); }
         last.dpdu = cross(last.dpdv, n);
         last.n = n;
-        W.mIterations = 0;
-        while (W.mIterations < 20) {
-            const d3 rel = target - W.mv[W.nm - 1].p;
+        X->mIterations = 0;
+        while (X->mIterations < 20) {
+            const d3 rel = target - X->mv[X->nm - 1].p;
             Float dist = len(rel), newDist;
             if (dist * invScale < GD_EPSILON) {
-                dist = len(W.mv[W.nm - 1].p - W.mv[W.nm - 2].p);
+                dist = len(X->mv[X->nm - 1].p - X->mv[X->nm - 2].p);
                 if (dist * invScale < GD_EPSILON) return false;
                 return true;
             }
-            W.mIterations++;
+            X->mIterations++;
             if (!manifoldTangents()) return false;
             bool failure = false;
             if (!manifoldProject(rel * stepSize)) failure = true;
             else {
-                newDist = len(target - W.mp[W.nmp - 1].p);
+                newDist = len(target - X->mp[X->nmp - 1].p);
                 if (newDist > dist) failure = true;
             }
             if (!failure) {
-                for (int i = 0; i < W.nmp; i++) W.mv[i] = W.mp[i];                             // m_proposal.swap(m_vertices): the old vertices are never read again
-                W.nm = W.nmp;
+                for (int i = 0; i < X->nmp; i++) X->mv[i] = X->mp[i];                             // m_proposal.swap(m_vertices): the old vertices are never read again
+                X->nm = X->nmp;
                 stepSize = fmin((Float)1.0, stepSize * 2.0);
                 continue;
             }
@@ -491,9 +528,9 @@ struct GTr {
     __device__ bool manifoldUpdate(GPath &path, int start, int end)                          // manifold.cpp:637-757
     {
         const int step = start < end ? 1 : -1, mode = start < end ? EImportance : ERadiance;
-        const int last = W.nm - 2;
+        const int last = X->nm - 2;
         for (int j = 0, i = start; j < last; ++j, i += step) {
-            const MV &v = W.mv[j], &vn = W.mv[j + 1];
+            const MV &v = X->mv[j], &vn = X->mv[j + 1];
             BV *pred = VN(path, i - step); BV &vertex = V_(path, i), &succ = V_(path, i + step);
             const int predEdgeIdx = (mode == EImportance) ? i - step : i - step - 1;
             BE *predEdge = EN(path, predEdgeIdx); BE &succEdge = E_(path, predEdgeIdx + step);
@@ -510,7 +547,7 @@ struct GTr {
     // the dense inverse and determinant of SpecularManifold::det's mixed case (Gauss-Jordan / LU with partial pivoting, as the oracle)
     __device__ bool denseInverse(int n)
     {
-        Float *A = W.A, *Ai = W.Ai;
+        Float *A = X->A, *Ai = X->Ai;
         for (int i = 0; i < n * n; ++i) Ai[i] = 0.0;
         for (int i = 0; i < n; ++i) Ai[i * n + i] = 1.0;
         for (int col = 0; col < n; ++col) {
@@ -529,9 +566,9 @@ struct GTr {
         }
         return true;
     }
-    __device__ Float denseDet(int n)                                                         // of W.Ai, destroyed
+    __device__ Float denseDet(int n)                                                         // of X->Ai, destroyed
     {
-        Float *A = W.Ai;
+        Float *A = X->Ai;
         Float det = 1.0;
         for (int col = 0; col < n; ++col) {
             int piv = col;
@@ -557,16 +594,16 @@ struct GTr {
         }
         const int step = b > a ? 1 : -1;
         if (!manifoldInit(p, a, b)) return 0.0;
-        MV &last = W.mv[W.nm - 1];
+        MV &last = X->mv[X->nm - 1];
         const BV &vb = V_(p, b);
         last.n = bv_on_surface(vb) ? bv_sh_normal(c, vb) : E_(p, a < b ? (b - 1) : b).d;
         if (fabs(last.n.x) > fabs(last.n.y)) { const Float il = 1.0 / sqrt(last.n.x * last.n.x + last.n.z * last.n.z); last.dpdv = mk(last.n.z * il, 0.0, -last.n.x * il); }
         else { const Float il = 1.0 / sqrt(last.n.y * last.n.y + last.n.z * last.n.z); last.dpdv = mk(0.0, last.n.z * il, -last.n.y * il); }
         last.dpdu = cross(last.dpdv, last.n);
         if (!manifoldTangents()) return 0.0;
-        const d3 d = W.mv[1].p - W.mv[0].p;
+        const d3 d = X->mv[1].p - X->mv[0].p;
         const Float lengthSqr = len2(d), invLength = 1 / sqrt(lengthSqr);
-        Float result = len(cross(W.mv[1].map(1, 0), W.mv[1].map(0, 1))) / lengthSqr;
+        Float result = len(cross(X->mv[1].map(1, 0), X->mv[1].map(0, 1))) / lengthSqr;
         if (bv_on_surface(V_(p, a))) result *= fabs(dot(d, bv_sh_normal(c, V_(p, a)))) * invLength;
         if (bv_on_surface(V_(p, a + step))) result *= fabs(dot(d, bv_sh_normal(c, V_(p, a + step)))) * invLength;
         return result;
@@ -601,39 +638,39 @@ struct GTr {
         if (nGlossy <= 1) return 1.0;
         if (!manifoldInit(p, a, cI)) return 0.0;
         const int b_idx = abs(b - a);
-        MV &vb = W.mv[b_idx];
+        MV &vb = X->mv[b_idx];
         vb.n = bv_sh_normal(c, V_(p, b));
         if (fabs(vb.n.x) > fabs(vb.n.y)) { const Float il = 1.0 / sqrt(vb.n.x * vb.n.x + vb.n.z * vb.n.z); vb.dpdv = mk(vb.n.z * il, 0.0, -vb.n.x * il); }
         else { const Float il = 1.0 / sqrt(vb.n.y * vb.n.y + vb.n.z * vb.n.z); vb.dpdv = mk(0.0, vb.n.z * il, -vb.n.y * il); }
         vb.dpdu = cross(vb.dpdv, vb.n);
         if (!manifoldTangents()) return 0.0;
-        W.mv[b_idx].a.setZero(); W.mv[b_idx].b.setIdentity(); W.mv[b_idx].c.setZero();
+        X->mv[b_idx].a.setZero(); X->mv[b_idx].b.setIdentity(); X->mv[b_idx].c.setZero();
         if (nSpecular == 0) {
-            M2 Di, D = W.mv[1].b;
+            M2 Di, D = X->mv[1].b;
             Float det = D.det();
-            for (int i = 2; i < W.nm - 1; ++i) {
+            for (int i = 2; i < X->nm - 1; ++i) {
                 if (!D.invert(Di)) return 0.0;
-                D = m2sub(W.mv[i].b, m2mul(m2mul(W.mv[i].a, Di), W.mv[i - 1].c));
+                D = m2sub(X->mv[i].b, m2mul(m2mul(X->mv[i].a, Di), X->mv[i - 1].c));
                 det *= D.det();
             }
             return fabs(1 / det);
         }
         const int nv = nGlossy + nSpecular, N = 2 * nv;
-        for (int i = 0; i < N * N; ++i) W.A[i] = 0.0;
+        for (int i = 0; i < N * N; ++i) X->A[i] = 0.0;
         for (int j = 0; j < nv; ++j) {
             const int i = j;
             for (int q = -1; q <= 1; ++q) {
                 const int cj = j + q;
                 if (cj < 0 || cj >= nv) continue;
-                const M2 &mm = q < 0 ? W.mv[j + 1].a : (q == 0 ? W.mv[j + 1].b : W.mv[j + 1].c);
-                W.A[(2 * i) * N + 2 * cj] = mm.m[0][0]; W.A[(2 * i) * N + 2 * cj + 1] = mm.m[0][1]; W.A[(2 * i + 1) * N + 2 * cj] = mm.m[1][0]; W.A[(2 * i + 1) * N + 2 * cj + 1] = mm.m[1][1];
+                const M2 &mm = q < 0 ? X->mv[j + 1].a : (q == 0 ? X->mv[j + 1].b : X->mv[j + 1].c);
+                X->A[(2 * i) * N + 2 * cj] = mm.m[0][0]; X->A[(2 * i) * N + 2 * cj + 1] = mm.m[0][1]; X->A[(2 * i + 1) * N + 2 * cj] = mm.m[1][0]; X->A[(2 * i + 1) * N + 2 * cj + 1] = mm.m[1][1];
             }
         }
         if (!denseInverse(N)) return 0.0;
         for (int i = 0; i < nv; ++i) {
-            if (!W.mv[i + 1].degenerate) continue;
-            for (int q = 0; q < N; ++q) { W.Ai[(2 * i) * N + q] = 0; W.Ai[(2 * i + 1) * N + q] = 0; W.Ai[q * N + 2 * i] = 0; W.Ai[q * N + 2 * i + 1] = 0; }
-            W.Ai[(2 * i) * N + 2 * i] = 1; W.Ai[(2 * i + 1) * N + 2 * i + 1] = 1;
+            if (!X->mv[i + 1].degenerate) continue;
+            for (int q = 0; q < N; ++q) { X->Ai[(2 * i) * N + q] = 0; X->Ai[(2 * i + 1) * N + q] = 0; X->Ai[q * N + 2 * i] = 0; X->Ai[q * N + 2 * i + 1] = 0; }
+            X->Ai[(2 * i) * N + 2 * i] = 1; X->Ai[(2 * i + 1) * N + 2 * i + 1] = 1;
         }
         return fabs(denseDet(N));
     }
@@ -740,11 +777,11 @@ struct GTr {
         if (l == 0) return false;
         n = n / l;
         if (!manifoldInit(source, cI, b)) return false;
-        const d3 p0 = W.mv[1].p;
+        const d3 p0 = X->mv[1].p;
         if (!manifoldMove(vb_new.p, n)) return false;
         if (!manifoldUpdate(proposal, cI, b)) return false;
         if (!manifoldMove(vb_old.p, n)) return false;
-        const d3 p1 = W.mv[1].p;
+        const d3 p1 = X->mv[1].p;
         const Float relerr = len(p0 - p1) / c.cfg.sceneRadius;
         if (relerr > 10.0 * GD_EPSILON) return false;
         return true;
@@ -784,6 +821,7 @@ struct GTr {
         if (lightPath && !couldConnectBehindB) return false;
         if (m >= k - 1) { BV &s1 = V_(proposal, k - 1); sensor_sample_position(c, V_(proposal, k - 2).p - s1.p, s1.u, s1.v); }
         for (int i = 0; i <= proposal.length(); i++) {
+            if (proposal.v[i] == source.v[i]) continue;                                  // (a shared record: rr and componentType are its own already -- and other lanes may be reading it)
             BV &pv = V_(proposal, i); const BV &sv = V_(source, i);
             pv.rr = sv.rr;
             if (pv.type == T_SURFACE && pv.componentType == 0) pv.componentType = sv.componentType;
@@ -792,10 +830,11 @@ struct GTr {
     }
 
     // ---- MIS weights, path.cpp:49-378 ----
-    __device__ void collectPdfs(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, Float *pdfImp, Float *pdfRad)
+    // (ovT: the sensor-side end point as the emitter sample a connection to the emitter supernode casts it to -- a lane-local copy, see connectPair)
+    __device__ void collectPdfs(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, Float *pdfImp, Float *pdfRad, const BV *ovT)
     {
         const int k = s + t + 1, n = k + 1;
-        const BV *vsPred = VN(emitterSubpath, s - 1), *vtPred = VN(sensorSubpath, t - 1); const BV &vs = V_(emitterSubpath, s), &vt = V_(sensorSubpath, t);
+        const BV *vsPred = VN(emitterSubpath, s - 1), *vtPred = VN(sensorSubpath, t - 1); const BV &vs = V_(emitterSubpath, s), &vt = ovT ? *ovT : V_(sensorSubpath, t);
         for (int i = 0; i < n; i++) { pdfImp[i] = 0.0; pdfRad[i] = 0.0; }
         int pos = 0;
         pdfImp[pos++] = 1.0;
@@ -814,43 +853,44 @@ struct GTr {
         for (int i = t; i > 0; --i) pdfRad[pos++] = V_(sensorSubpath, i - 1).pdf[ERadiance] * E_(sensorSubpath, i - 1).tr[ERadiance];
         pdfRad[pos++] = 1.0;
     }
-    __device__ void stripGeometry(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int k, Float *pdfImp, Float *pdfRad)   // path.cpp:143-167,309-349
+    __device__ void stripGeometry(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int k, Float *pdfImp, Float *pdfRad, const BV *ovT)   // path.cpp:143-167,309-349
     {
-        const char *cs = W.connectableStrict;
+        const char *cs = M->connectableStrict;
+        const int t = k - s - 1;
         for (int i = 1; i <= k - 3; ++i) {
             if (i == s || !(cs[i] && !cs[i + 1])) continue;
-            const BV &cur = i <= s ? V_(emitterSubpath, i) : V_(sensorSubpath, k - i);
-            const BV &succ = i + 1 <= s ? V_(emitterSubpath, i + 1) : V_(sensorSubpath, k - i - 1);
+            const BV &cur = i <= s ? V_(emitterSubpath, i) : ((ovT && k - i == t) ? *ovT : V_(sensorSubpath, k - i));
+            const BV &succ = i + 1 <= s ? V_(emitterSubpath, i + 1) : ((ovT && k - i - 1 == t) ? *ovT : V_(sensorSubpath, k - i - 1));
             const BE &edge = i < s ? E_(emitterSubpath, i) : E_(sensorSubpath, k - i - 1);
             pdfImp[i + 1] *= edge.length * edge.length / fabs((bv_on_surface(succ) ? dot(edge.d, bv_geo_normal(c, succ)) : 1) * (bv_on_surface(cur) ? dot(edge.d, bv_geo_normal(c, cur)) : 1));
         }
         for (int i = k - 1; i >= 3; --i) {
             if (i - 1 == s || !(cs[i] && !cs[i - 1])) continue;
-            const BV &cur = i <= s ? V_(emitterSubpath, i) : V_(sensorSubpath, k - i);
-            const BV &succ = i - 1 <= s ? V_(emitterSubpath, i - 1) : V_(sensorSubpath, k - i + 1);
+            const BV &cur = i <= s ? V_(emitterSubpath, i) : ((ovT && k - i == t) ? *ovT : V_(sensorSubpath, k - i));
+            const BV &succ = i - 1 <= s ? V_(emitterSubpath, i - 1) : ((ovT && k - i + 1 == t) ? *ovT : V_(sensorSubpath, k - i + 1));
             const BE &edge = i <= s ? E_(emitterSubpath, i - 1) : E_(sensorSubpath, k - i);
             pdfRad[i - 1] *= edge.length * edge.length / fabs((bv_on_surface(succ) ? dot(edge.d, bv_geo_normal(c, succ)) : 1) * (bv_on_surface(cur) ? dot(edge.d, bv_geo_normal(c, cur)) : 1));
         }
     }
-    __device__ void classify(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int t)
+    __device__ void classify(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int t, const BV *ovT)
     {
         int n = 0;
-        for (int i = 0; i <= s; ++i) { const BV &v = V_(emitterSubpath, i); W.connectable[n] = connectable_gbdpt(c, v); W.connectableStrict[n] = bv_connectable(v); n++; }
-        for (int i = t; i >= 0; --i) { const BV &v = V_(sensorSubpath, i); W.connectable[n] = connectable_gbdpt(c, v); W.connectableStrict[n] = bv_connectable(v); n++; }
+        for (int i = 0; i <= s; ++i) { const BV &v = V_(emitterSubpath, i); M->connectable[n] = connectable_gbdpt(c, v); M->connectableStrict[n] = bv_connectable(v); n++; }
+        for (int i = t; i >= 0; --i) { const BV &v = (ovT && i == t) ? *ovT : V_(sensorSubpath, i); M->connectable[n] = connectable_gbdpt(c, v); M->connectableStrict[n] = bv_connectable(v); n++; }
     }
-    __device__ Float miWeightBase(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, bool lightImage, Float geomTermX)
+    __device__ Float miWeightBase(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, bool lightImage, Float geomTermX, const BV *ovT)
     {
         const int k = s + t + 1;
-        classify(emitterSubpath, sensorSubpath, s, t);
-        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, W.pdfImp, W.pdfRad);
-        stripGeometry(emitterSubpath, sensorSubpath, s, k, W.pdfImp, W.pdfRad);
+        classify(emitterSubpath, sensorSubpath, s, t, ovT);
+        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, M->pdfImp, M->pdfRad, ovT);
+        stripGeometry(emitterSubpath, sensorSubpath, s, k, M->pdfImp, M->pdfRad, ovT);
         double sum_p = 0.0, p_st = 0.0;
         for (int p = 0; p < s + t + 1; ++p) {
             double p_i = 1.0;
-            for (int i = 1; i < p + 1; ++i) p_i *= W.pdfImp[i];
-            for (int i = p + 1; i < s + t + 1; ++i) p_i *= W.pdfRad[i];
+            for (int i = 1; i < p + 1; ++i) p_i *= M->pdfImp[i];
+            for (int i = p + 1; i < s + t + 1; ++i) p_i *= M->pdfRad[i];
             const int tPrime = k - p - 1;
-            const bool allowedToConnect = W.connectable[p] && W.connectable[p + 1];
+            const bool allowedToConnect = M->connectable[p] && M->connectable[p + 1];
             const double v2 = (p_i * geomTermX) * (p_i * geomTermX);                         // std::pow(x, 2.0)
             if (allowedToConnect && (lightImage || tPrime > 1)) sum_p += v2;
             if (tPrime == t) p_st = v2;
@@ -859,21 +899,21 @@ struct GTr {
     }
     __device__ Float miWeightGrad(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath,
                                   const GPath &offsetEmitterSubpath, const BE &offsetConnectionEdge, const GPath &offsetSensorSubpath,
-                                  int s, int t, bool lightImage, Float jDet, Float geomTermX, Float geomTermY)
+                                  int s, int t, bool lightImage, Float jDet, Float geomTermX, Float geomTermY, const BV *ovT, const BV *oOvT)
     {
         const int k = s + t + 1;
-        classify(emitterSubpath, sensorSubpath, s, t);
-        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, W.pdfImp, W.pdfRad);
-        collectPdfs(offsetEmitterSubpath, offsetConnectionEdge, offsetSensorSubpath, s, t, W.oPdfImp, W.oPdfRad);
-        stripGeometry(emitterSubpath, sensorSubpath, s, k, W.pdfImp, W.pdfRad);
-        stripGeometry(offsetEmitterSubpath, offsetSensorSubpath, s, k, W.oPdfImp, W.oPdfRad);
+        classify(emitterSubpath, sensorSubpath, s, t, ovT);
+        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, M->pdfImp, M->pdfRad, ovT);
+        collectPdfs(offsetEmitterSubpath, offsetConnectionEdge, offsetSensorSubpath, s, t, M->oPdfImp, M->oPdfRad, oOvT);
+        stripGeometry(emitterSubpath, sensorSubpath, s, k, M->pdfImp, M->pdfRad, ovT);
+        stripGeometry(offsetEmitterSubpath, offsetSensorSubpath, s, k, M->oPdfImp, M->oPdfRad, oOvT);
         double sum_p_i = 0.0, p_st = 0.0;
         for (int p = 0; p < s + t + 1; ++p) {
             double value = 1.0, oValue = 1.0;
-            for (int i = 1; i < p + 1; ++i) { value *= W.pdfImp[i]; oValue *= W.oPdfImp[i]; }
-            for (int i = p + 1; i < s + t + 1; ++i) { value *= W.pdfRad[i]; oValue *= W.oPdfRad[i]; }
+            for (int i = 1; i < p + 1; ++i) { value *= M->pdfImp[i]; oValue *= M->oPdfImp[i]; }
+            for (int i = p + 1; i < s + t + 1; ++i) { value *= M->pdfRad[i]; oValue *= M->oPdfRad[i]; }
             const int tPrime = k - p - 1;
-            const bool allowedToConnect = W.connectable[p] && W.connectable[p + 1];
+            const bool allowedToConnect = M->connectable[p] && M->connectable[p + 1];
             if (allowedToConnect && (lightImage || tPrime > 1)) sum_p_i += value * geomTermX + oValue * jDet * geomTermY;   // std::pow(x, 1.0)
             if (tPrime == t) p_st = value * geomTermX;
 #ifdef GDPT_BD_TRACE
@@ -882,7 +922,7 @@ struct GTr {
         }
 #ifdef GDPT_BD_TRACE
         printf("G   miWeightGrad s %d t %d jDet %.17g geomX %.17g geomY %.17g p_st %.17g sum %.17g\n", s, t, jDet, geomTermX, geomTermY, p_st, sum_p_i);
-        for (int i = 0; i <= k; i++) printf("G   pdf[%d] imp %.17g rad %.17g oImp %.17g oRad %.17g cs %d\n", i, W.pdfImp[i], W.pdfRad[i], W.oPdfImp[i], W.oPdfRad[i], (int)W.connectableStrict[i]);
+        for (int i = 0; i <= k; i++) printf("G   pdf[%d] imp %.17g rad %.17g oImp %.17g oRad %.17g cs %d\n", i, M->pdfImp[i], M->pdfRad[i], M->oPdfImp[i], M->oPdfRad[i], (int)M->connectableStrict[i]);
 #endif
         return (Float)(p_st / sum_p_i);
     }
@@ -906,11 +946,12 @@ struct GTr {
         return pathSuccess;
     }
 
-    // GBDPTRenderer::process (from the connected base path on, :186-252) + evaluate (:259-534).  The two subpaths are W.emitter / W.sensor[0].
-    __device__ void processSample(SampleOut &wr)
+    // GBDPTRenderer::process from the connected base path on (gbdpt_proc.cpp:186-229): createShiftablePath, the four offset paths with their
+    // Jacobians and generalized geometry terms, the prefix products of combineImportanceData / combineRadianceData (:544-565).  Everything a
+    // connection reads is in W afterwards, and W is not written again.  The two subpaths are W.emitter / W.sensor[0] (loadSubpaths).
+    __device__ void prepare()
     {
         const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
-        const BdConfig &cfg = c.cfg;
         GPath &emitterSubpath = W.emitter;
         for (int k = 0; k < 5; k++) {
             W.success[k] = 0; W.couldConnectAfterB[k] = 0;
@@ -949,18 +990,7 @@ struct GTr {
             }
             off.reverse();
         }
-        const int vert_b = connectPath.nv - 1 - W.mu[0].extra[1];
-        evaluate(wr, vert_b);
-    }
-
-    __device__ void evaluate(SampleOut &wr, int vert_b)
-    {
-        const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
-        const BdConfig &cfg = c.cfg;
-        GPath &emitterSubpath = W.emitter;
-        const Float initialX = V_(W.sensor[0], 1).u, initialY = V_(W.sensor[0], 1).v;
-        wr.posX = initialX; wr.posY = initialY;
-        wr.nLight = 0;
+        W.vert_b = connectPath.nv - 1 - W.mu[0].extra[1];
         const int nE = emitterSubpath.nv, nS = W.sensor[0].nv;
         W.impW[0] = mk(1.0); W.impP[0] = 1.0;
         for (int i = 1; i < nE; ++i) {
@@ -979,8 +1009,35 @@ struct GTr {
                 }
             }
         }
-        d3 primal = mk(0.0), gradient[4] = {mk(0.0), mk(0.0), mk(0.0), mk(0.0)};
-        GPath &offsetEmitterSubpath = W.offsetEmitter, &connectedBasePath = W.connectedBase;
+    }
+    // the connections of emitter vertex s (gbdpt_proc.cpp:311-319; the sensor subpath may have lost trailing non-connectable vertices in createShiftablePath)
+    __device__ __forceinline__ void pairRange(int s, int &minT, int &maxT) const
+    {
+        minT = max(2 - s, c.cfg.lightImage ? 1 : 2);
+        maxT = min(W.sensor[0].nv - 1, c.cfg.maxDepth + 1 - s);
+    }
+
+    // ONE connection (s, t) of GBDPTRenderer::evaluate (gbdpt_proc.cpp:319-527): the base path and its four offsets.  Reads W, writes nothing
+    // of it: the reference casts the sensor-side end point to an emitter sample IN PLACE at s = 0 (:402) and sets the measure of connected end points
+    // (:439) on vertices the five paths share -- no later connection reads either (vertex t is not on the path of a smaller t, s = 0 is the last s;
+    // a measure that is not EDiscrete stays so), so a connection works on a local copy of the cast vertex and leaves the measures alone, and
+    // connections may run side by side in any order.  T1: a light-tracing connection (t == 1): its own shiftable path, four offset paths with
+    // their own manifold walks, all in the lane's transient pool (X); t >= 2 needs no X.  Returns false when the connection contributes nothing.
+    template <bool T1>
+    __device__ bool connectPair(int s, int t, PairOut &po)
+    {
+        const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+        const BdConfig &cfg = c.cfg;
+        GPath &emitterSubpath = W.emitter;
+        const int vert_b = W.vert_b;
+        po.nLight = 0;
+        Float samplePosX = V_(W.sensor[0], 1).u, samplePosY = V_(W.sensor[0], 1).v;
+        if constexpr (T1) {
+            const BV &v1 = V_(W.sensor[0], 1);
+            if ((v1.type == T_SENSOR_SAMPLE && !sensor_sample_position(c, V_(emitterSubpath, s).p - v1.p, samplePosX, samplePosY)) || !connectable_gbdpt(c, V_(emitterSubpath, s))) return false;
+            X->nlv = X->nle = 0;
+            localAlloc = true;
+        }
         Float geomTermBase = 0.0; d3 connectionPartsBase = mk(0.0), offsetImportanceWeight = mk(0.0);
         BE connectionEdge, connectionEdgeBase;
         be_clear(connectionEdge); be_clear(connectionEdgeBase);
@@ -989,125 +1046,143 @@ struct GTr {
         d3 value[5]; Float miWeight[5], valuePdf[5];
         double jacobianLP[4] = {1.0, 1.0, 1.0, 1.0}, genGeomTermLP[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
         bool pathSuccess[5];
-        for (int s = nE - 1; s >= 0; --s) {
-            const int minT = max(2 - s, cfg.lightImage ? 1 : 2);
-            const int maxT = min(nS - 1, cfg.maxDepth + 1 - s);
-            for (int t = maxT; t >= minT; --t) {
-                Float samplePosX = initialX, samplePosY = initialY;
-                if (t == 1) {
-                    const BV &v1 = V_(W.sensor[0], 1);
-                    if ((v1.type == T_SENSOR_SAMPLE && !sensor_sample_position(c, V_(emitterSubpath, s).p - v1.p, samplePosX, samplePosY)) || !connectable_gbdpt(c, V_(emitterSubpath, s))) continue;
-                }
-                const int markV = W.nv, markE = W.ne;                                        // (the light path's clones and offsets live until the end of this connection)
-                int memPointer = 0;
-                MuRec muRec; muRec.l = muRec.m = 0; for (int i = 0; i < 5; i++) muRec.extra[i] = 0;
-                for (int k = 0; k <= 4; k++) {
-                    miWeight[k] = 1.0 / (s + t + 1);
-                    pathSuccess[k] = W.success[k] != 0;
-                    value[k] = mk(0.0);
-                    valuePdf[k] = 0.0;
-                    d3 importanceWeightTmp = W.impW[s], radianceWeightTmp = W.radW[t == 1 ? 0 : k][t];
-                    Float importancePdfTmp = W.impP[s], radiancePdfTmp = W.radP[t == 1 ? 0 : k][t];
-                    const GPath *sensorSubpathTmp = &W.sensor[k], *emitterSubpathTmp = &emitterSubpath;
-                    if (t == 1 && k == 0) {
-                        pathSuccess[0] = createShiftablePath(connectedBasePath, emitterSubpath, W.sensor[0], s, 1, memPointer);
-                        computeMuRec(connectedBasePath, muRec);
-                        genGeomTermLP[0] = calcSpecularPDFChange(connectedBasePath, muRec.extra[2], true);
+        int memPointer = 0;
+        MuRec muRec; muRec.l = muRec.m = 0; for (int i = 0; i < 5; i++) muRec.extra[i] = 0;
+        BV vtBaseCast, vtCast;                                                               // s == 0: the sensor-side end point as the emitter sample it is cast to (base path / path k)
+        int markV = 0, markE = 0;
+        for (int k = 0; k <= 4; k++) {
+            miWeight[k] = 1.0 / (s + t + 1);
+            pathSuccess[k] = W.success[k] != 0;
+            value[k] = mk(0.0);
+            valuePdf[k] = 0.0;
+            d3 importanceWeightTmp = W.impW[s], radianceWeightTmp = W.radW[T1 ? 0 : k][t];
+            Float importancePdfTmp = W.impP[s], radiancePdfTmp = W.radP[T1 ? 0 : k][t];
+            const GPath *sensorSubpathTmp = &W.sensor[k], *emitterSubpathTmp = &emitterSubpath;
+            if constexpr (T1) if (k == 0) {
+                pathSuccess[0] = createShiftablePath(X->connectedBase, emitterSubpath, W.sensor[0], s, 1, memPointer);
+                computeMuRec(X->connectedBase, muRec);
+                genGeomTermLP[0] = calcSpecularPDFChange(X->connectedBase, muRec.extra[2], true);
+                markV = X->nlv; markE = X->nle;
+            }
+            if constexpr (T1) if (k > 0 && !is_zero(value[0])) {
+                if (!pathSuccess[0]) pathSuccess[k] = false;
+                else {
+                    // createShiftedLightPath, :568-590 (the records of the previous offset are dead: its values are in value / valuePdf / miWeight)
+                    X->nlv = markV; X->nle = markE;
+                    jacobianLP[k - 1] = 1.0;
+                    int couldConnectWithB = 0;
+                    pathSuccess[k] = generateOffsetPath(X->connectedBase, X->offsetEmitter, muRec, shifts[k - 1][0], shifts[k - 1][1], couldConnectWithB, true);
+                    if (pathSuccess[k]) {
+                        jacobianLP[k - 1] = halfJacobian(X->offsetEmitter, muRec.extra[0], muRec.extra[1], muRec.extra[2]) / halfJacobian(X->connectedBase, muRec.extra[0], muRec.extra[1], muRec.extra[2]);
+                        offsetImportancePdf = 1.0;
+                        offsetImportanceWeight = mk(1.0);
+                        for (int i = 1; i <= s; ++i) {
+                            const BV &pv = V_(X->offsetEmitter, i - 1); const BE &pe = E_(X->offsetEmitter, i - 1);
+                            offsetImportanceWeight = offsetImportanceWeight * pv.w[EImportance] * pv.rr * pe.tr[EImportance];
+                            offsetImportancePdf = offsetImportancePdf * pv.pdf[EImportance] * pv.rr * pe.tr[EImportance];
+                        }
+                        genGeomTermLP[k] = calcSpecularPDFChange(X->offsetEmitter, muRec.extra[2], true);
+                        importanceWeightTmp = offsetImportanceWeight;
+                        importancePdfTmp = offsetImportancePdf;
+                        emitterSubpathTmp = &X->offsetEmitter;
                     }
-                    if (t == 1 && k > 0 && !is_zero(value[0])) {
-                        if (!pathSuccess[0]) pathSuccess[k] = false;
-                        else {
-                            // createShiftedLightPath, :568-590
-                            jacobianLP[k - 1] = 1.0;
-                            int couldConnectWithB = 0;
-                            pathSuccess[k] = generateOffsetPath(connectedBasePath, offsetEmitterSubpath, muRec, shifts[k - 1][0], shifts[k - 1][1], couldConnectWithB, true);
-                            if (pathSuccess[k]) {
-                                jacobianLP[k - 1] = halfJacobian(offsetEmitterSubpath, muRec.extra[0], muRec.extra[1], muRec.extra[2]) / halfJacobian(connectedBasePath, muRec.extra[0], muRec.extra[1], muRec.extra[2]);
-                                offsetImportancePdf = 1.0;
-                                offsetImportanceWeight = mk(1.0);
-                                for (int i = 1; i <= s; ++i) {
-                                    const BV &pv = V_(offsetEmitterSubpath, i - 1); const BE &pe = E_(offsetEmitterSubpath, i - 1);
-                                    offsetImportanceWeight = offsetImportanceWeight * pv.w[EImportance] * pv.rr * pe.tr[EImportance];
-                                    offsetImportancePdf = offsetImportancePdf * pv.pdf[EImportance] * pv.rr * pe.tr[EImportance];
-                                }
-                                genGeomTermLP[k] = calcSpecularPDFChange(offsetEmitterSubpath, muRec.extra[2], true);
-                                importanceWeightTmp = offsetImportanceWeight;
-                                importancePdfTmp = offsetImportancePdf;
-                                emitterSubpathTmp = &offsetEmitterSubpath;
-                            }
-                            sensorSubpathTmp = &W.sensor[0];
-                        }
-                    }
-                    Float geomTerm = 0.0;
-                    do {
-                        if (!(pathSuccess[k] && pathSuccess[0] && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
-                        if (!W.couldConnectAfterB[k] && t > vert_b) break;
-                        BV *vsPred = VN(*emitterSubpathTmp, s - 1), *vtPred = VN(*sensorSubpathTmp, t - 1);
-                        BV &vs = W.v[emitterSubpathTmp->v[s]], &vt = W.v[sensorSubpathTmp->v[t]];
-                        if (vs.type == T_EMITTER_SUPER) {
-                            if (!bv_cast_emitter(c, vt) || vt.degenerate) { valuePdf[k] = radiancePdfTmp; break; }
-                            const d3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : gEval(vs, vsPred, &vt, EImportance) * gEval(vt, vtPred, &vs, ERadiance);
-                            if (k == 0) connectionPartsBase = connectionParts;
-                            value[k] = radianceWeightTmp * connectionParts;
-                            valuePdf[k] = radiancePdfTmp;
-                        } else if (vt.type == T_SENSOR_SUPER) { valuePdf[k] = importancePdfTmp; break; }
-                        else {
-                            if (!connectable_gbdpt(c, vs) || !connectable_gbdpt(c, vt) || vs.type == 0 || vt.type == 0) { valuePdf[k] = importancePdfTmp * radiancePdfTmp; break; }
-                            const d3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : gEval(vs, vsPred, &vt, EImportance) * gEval(vt, vtPred, &vs, ERadiance);
-                            if (k == 0) connectionPartsBase = connectionParts;
-                            value[k] = importanceWeightTmp * radianceWeightTmp * connectionParts;
-                            valuePdf[k] = importancePdfTmp * radiancePdfTmp;
-                            vs.measure = vt.measure = M_AREA;
-                        }
-                        if (is_zero(value[k]) || valuePdf[k] == 0) break;
-                        const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connectionEdge, vs, vt);
-                        if (k == 0) successConnectBase = successConnect;
-                        if (!successConnect) { value[k] = mk(0.0); break; }
-                        geomTerm = (k > 0 && t > vert_b) ? geomTermBase : gEdgeEvalCached(connectionEdge, vs, vt, 0x04 | 0x08 | 0x10 | 0x20);
-                        value[k] = value[k] * geomTerm;
-                        valuePdf[k] *= (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t]);
-                        if (is_zero(value[k]) || valuePdf[k] == 0) break;
-                        if (k == 0) {
-                            connectionEdgeBase = connectionEdge;
-                            geomTermBase = geomTerm;
-                            miWeight[0] = miWeightBase(emitterSubpath, connectionEdgeBase, W.sensor[0], s, t, cfg.lightImage != 0, (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t])) / valuePdf[0];
-                        } else {
-                            miWeight[k] = miWeightGrad(emitterSubpath, connectionEdgeBase, W.sensor[0], *emitterSubpathTmp, connectionEdge, *sensorSubpathTmp, s, t, cfg.lightImage != 0,
-                                                       (t < 2 ? jacobianLP[k - 1] : W.jacobianDet[k][t]), (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t]), (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t])) / valuePdf[0];
-                        }
-                    } while (false);
-#ifdef GDPT_BD_TRACE
-                    printf("G st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\\n", s, t, k, (int)pathSuccess[k], value[k].x, value[k].y, value[k].z, valuePdf[k], miWeight[k], geomTerm, c.nClosest, c.nShadow);
-#endif
-                    if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miWeight[k] = miWeight[0]; valuePdf[k] = valuePdf[0]; }
-                }
-                W.nv = markV; W.ne = markE;
-                if (is_zero(value[0])) continue;
-                const d3 mainRad = value[0] * (valuePdf[0] * miWeight[0]);
-                if (t >= 2) primal = primal + mainRad;
-                else if (wr.nLight < BD_MAX_LIGHT) { LightSplat &ls = wr.light[wr.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
-                const d3 fx = value[0] * valuePdf[0];
-                for (int n = 0; n < 4; n++) {
-                    const d3 fy = value[n + 1] * valuePdf[n + 1] * (Float)(t < 2 ? jacobianLP[n] : W.jacobianDet[n + 1][t]);
-                    const d3 gradVal = (fy - fx) * ((Float)2.0 * miWeight[n + 1]);
-                    if (t >= 2) gradient[n] = gradient[n] + gradVal;
-                    else if (wr.nLight < BD_MAX_LIGHT) { LightSplat &ls = wr.light[wr.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
+                    sensorSubpathTmp = &W.sensor[0];
                 }
             }
+            Float geomTerm = 0.0;
+            do {
+                if (!(pathSuccess[k] && pathSuccess[0] && (k == 0 || (valuePdf[0] > 0 && !is_zero(value[0]))))) break;
+                if (!W.couldConnectAfterB[k] && t > vert_b) break;
+                const BV *vsPred = VN(*emitterSubpathTmp, s - 1), *vtPred = VN(*sensorSubpathTmp, t - 1);
+                const BV &vs = PV(emitterSubpathTmp->v[s]);
+                const BV *vtP = &PV(sensorSubpathTmp->v[t]);
+                if (vs.type == T_EMITTER_SUPER) {
+                    vtCast = *vtP;
+                    if (!bv_cast_emitter(c, vtCast) || vtCast.degenerate) { valuePdf[k] = radiancePdfTmp; break; }
+                    vtP = &vtCast;
+                    if (k == 0) vtBaseCast = vtCast;
+                    const d3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : gEval(vs, vsPred, vtP, EImportance) * gEval(*vtP, vtPred, &vs, ERadiance);
+                    if (k == 0) connectionPartsBase = connectionParts;
+                    value[k] = radianceWeightTmp * connectionParts;
+                    valuePdf[k] = radiancePdfTmp;
+                } else if (vtP->type == T_SENSOR_SUPER) { valuePdf[k] = importancePdfTmp; break; }
+                else {
+                    if (!connectable_gbdpt(c, vs) || !connectable_gbdpt(c, *vtP) || vs.type == 0 || vtP->type == 0) { valuePdf[k] = importancePdfTmp * radiancePdfTmp; break; }
+                    const d3 connectionParts = (k > 0 && t > vert_b + 1) ? connectionPartsBase : gEval(vs, vsPred, vtP, EImportance) * gEval(*vtP, vtPred, &vs, ERadiance);
+                    if (k == 0) connectionPartsBase = connectionParts;
+                    value[k] = importanceWeightTmp * radianceWeightTmp * connectionParts;
+                    valuePdf[k] = importancePdfTmp * radiancePdfTmp;
+                }
+                if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connectionEdge, vs, *vtP);
+                if (k == 0) successConnectBase = successConnect;
+                if (!successConnect) { value[k] = mk(0.0); break; }
+                geomTerm = (k > 0 && t > vert_b) ? geomTermBase : gEdgeEvalCached(connectionEdge, vs, *vtP, 0x04 | 0x08 | 0x10 | 0x20);
+                value[k] = value[k] * geomTerm;
+                valuePdf[k] *= (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t]);
+                if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                const BV *ovBase = vs.type == T_EMITTER_SUPER ? &vtBaseCast : nullptr;      // (the cast vertex: miWeight sees the emitter sample, gbdpt_proc.cpp:402)
+                if (k == 0) {
+                    connectionEdgeBase = connectionEdge;
+                    geomTermBase = geomTerm;
+                    miWeight[0] = miWeightBase(emitterSubpath, connectionEdgeBase, W.sensor[0], s, t, cfg.lightImage != 0, (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t]), ovBase) / valuePdf[0];
+                } else {
+                    miWeight[k] = miWeightGrad(emitterSubpath, connectionEdgeBase, W.sensor[0], *emitterSubpathTmp, connectionEdge, *sensorSubpathTmp, s, t, cfg.lightImage != 0,
+                                               (t < 2 ? jacobianLP[k - 1] : W.jacobianDet[k][t]), (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t]), (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t]),
+                                               ovBase, vs.type == T_EMITTER_SUPER ? vtP : nullptr) / valuePdf[0];
+                }
+            } while (false);
+#ifdef GDPT_BD_TRACE
+            printf("G st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\n", s, t, k, (int)pathSuccess[k], value[k].x, value[k].y, value[k].z, valuePdf[k], miWeight[k], geomTerm, c.nClosest, c.nShadow);
+#endif
+            if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miWeight[k] = miWeight[0]; valuePdf[k] = valuePdf[0]; }
         }
-        wr.primal = primal;
-        for (int k = 0; k < 4; ++k) wr.gradient[k] = gradient[k];
+        if constexpr (T1) localAlloc = false;
+        if (is_zero(value[0])) return false;
+        const d3 mainRad = value[0] * (valuePdf[0] * miWeight[0]);
+        po.primal = mainRad;
+        if (T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+        const d3 fx = value[0] * valuePdf[0];
+        for (int n = 0; n < 4; n++) {
+            const d3 fy = value[n + 1] * valuePdf[n + 1] * (Float)(t < 2 ? jacobianLP[n] : W.jacobianDet[n + 1][t]);
+            const d3 gradVal = (fy - fx) * ((Float)2.0 * miWeight[n + 1]);
+            po.gradient[n] = gradVal;
+            if (T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = n + 1; ls.value = gradVal; }
+        }
+        return true;
     }
+
+    // GBDPTRenderer::evaluate (:259-534) in ONE lane, connections in the reference's order: the probe entry (the frame kernels run prepare and
+    // connectPair as separate launches: k_bdg_shift, k_bdg_connect, k_bdg_light)
+    __device__ void evaluate(SampleOut &wr)
+    {
+        wr.posX = V_(W.sensor[0], 1).u; wr.posY = V_(W.sensor[0], 1).v;
+        wr.nLight = 0;
+        wr.primal = mk(0.0);
+        for (int k = 0; k < 4; ++k) wr.gradient[k] = mk(0.0);
+        PairOut po;
+        for (int s = W.emitter.nv - 1; s >= 0; --s) {
+            int minT, maxT;
+            pairRange(s, minT, maxT);
+            for (int t = maxT; t >= minT; --t) {
+                if (!(t == 1 ? connectPair<true>(s, t, po) : connectPair<false>(s, t, po))) continue;
+                if (t >= 2) { wr.primal = wr.primal + po.primal; for (int n = 0; n < 4; n++) wr.gradient[n] = wr.gradient[n] + po.gradient[n]; }
+                for (int i = 0; i < po.nLight && wr.nLight < BD_MAX_LIGHT; i++) wr.light[wr.nLight++] = po.light[i];
+            }
+        }
+    }
+    __device__ void processSample(SampleOut &wr) { prepare(); evaluate(wr); }
 
     // the two subpaths of a walked sample -> pool records and index lists
     __device__ void loadSubpaths(const Sample &sm)
     {
-        W.nv = W.ne = 0; W.overflow = 0;
+        W.nv = W.ne = 0; overflow = 0;
         W.emitter.clear(); W.sensor[0].clear();
         for (int i = 0; i < sm.nY; i++) { const int j = allocV(); W.v[j] = sm.Y[i]; W.emitter.pushV(j); if (i + 1 < sm.nY) { const int e = allocE(); W.e[e] = sm.EY[i]; W.emitter.pushE(e); } }
         for (int i = 0; i < sm.nX; i++) { const int j = allocV(); W.v[j] = sm.X[i]; W.sensor[0].pushV(j); if (i + 1 < sm.nX) { const int e = allocE(); W.e[e] = sm.EX[i]; W.sensor[0].pushE(e); } }
     }
 };
+using GTr = GTrT<true>;
 
 // does the sample need the general form?  (a surface vertex of either subpath that is not connectable in the sense of Path::isConnectable_GBDPT)
 __device__ bool sample_needs_general(const Ctx &c, const Sample &sm)

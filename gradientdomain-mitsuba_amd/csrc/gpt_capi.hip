@@ -702,27 +702,44 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     d.envIndex = envIndex;
     s->specialEmitters = env != nullptr || hasPoint;
     s->hostMats = mats;
-    if (env) {
-        // ConstantBackgroundEmitter::createShape (constant.cpp:67-70): bounding sphere of Scene::getAABB() at that moment = the
-        // kd-tree's AABB (enlarged by MTS_KD_AABB_EPSILON, gkdtree.h:1213-1219 -- the second line sees the moved min) + the
-        // sensor's position (scene.cpp:386-395), radius x 1.5f
+    {
+        // Scene::initializeBidirectional (scene.cpp:386-413): m_aabb = the kd-tree's AABB (enlarged by MTS_KD_AABB_EPSILON, gkdtree.h:1213-1219 --
+        // the second line sees the moved min) expanded by the sensor's AABB (perspective: the camera position, perspective.cpp:444-446; thinlens: the
+        // spatial bounds of the aperture box (-r,-r,0)..(r,r,0), thinlens.cpp:516-520), then by every emitter's AABB (area: its shape's bounds, inside
+        // already; point: its position, point.cpp:153-155; constant / envmap: the centre of m_sceneBSphere, constant.cpp:234-240 -- inside by construction).
         double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int i = 0; i < numTris; i++)
             for (int v = 0; v < 3; v++)
                 for (int a = 0; a < 3; a++) { const double c = verts[9 * i + 3 * v + a]; mn[a] = std::min(mn[a], c); mx[a] = std::max(mx[a], c); }
         const double eps = (double)1e-3f;
-        double ctr[3], r2 = 0.0;
+        const double *M = camera->toWorld;
         for (int a = 0; a < 3; a++) {
             mn[a] = mn[a] - ((mx[a] - mn[a]) * eps + eps);
             mx[a] = mx[a] + ((mx[a] - mn[a]) * eps + eps);
-            const double cam = camera->toWorld[4 * a + 3];
-            mn[a] = std::min(mn[a], cam); mx[a] = std::max(mx[a], cam);
-            ctr[a] = (mx[a] + mn[a]) * 0.5;
+            if (camera->type == GDPT_SENSOR_THINLENS) {
+                const double r = camera->apertureRadius;
+                for (int j = 0; j < 4; j++) {
+                    const double c = M[4 * a + 0] * ((j & 1) ? r : -r) + M[4 * a + 1] * ((j & 2) ? r : -r) + M[4 * a + 3];
+                    mn[a] = std::min(mn[a], c); mx[a] = std::max(mx[a], c);
+                }
+            } else { mn[a] = std::min(mn[a], M[4 * a + 3]); mx[a] = std::max(mx[a], M[4 * a + 3]); }
         }
-        const double dx = ctr[0] - mx[0], dy = ctr[1] - mx[1], dz = ctr[2] - mx[2];
-        r2 = dx * dx + dy * dy + dz * dz;
-        d.bsCenter = to_d3(h3(ctr[0], ctr[1], ctr[2]));
-        d.bsRadius = std::max((double)GD_EPSILON, std::sqrt(r2) * (double)1.5f);       // (EnvironmentMap::createShape does the same, envmap.cpp:330-339)
+        if (env) {
+            // ConstantBackgroundEmitter::createShape (constant.cpp:67-70): the bounding sphere of Scene::getAABB() at that moment (kd-tree + sensor:
+            // the emitters' boxes are merged after the loop that calls createShape), radius x 1.5f
+            double ctr[3];
+            for (int a = 0; a < 3; a++) ctr[a] = (mx[a] + mn[a]) * 0.5;
+            const double dx = ctr[0] - mx[0], dy = ctr[1] - mx[1], dz = ctr[2] - mx[2];
+            d.bsCenter = to_d3(h3(ctr[0], ctr[1], ctr[2]));
+            d.bsRadius = std::max((double)GD_EPSILON, std::sqrt(dx * dx + dy * dy + dz * dz) * (double)1.5f);       // (EnvironmentMap::createShape does the same, envmap.cpp:330-339)
+        }
+        for (int e = 0; e < numEmitters; e++)
+            if (emitters[e].numTris < 0)
+                for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], emitters[e].position[a]); mx[a] = std::max(mx[a], emitters[e].position[a]); }
+        // Scene::getBSphere().radius (scene.h:972-975, aabb.cpp:44-47): the yardstick of ManifoldPerturbation::manifoldWalk's reversibility test
+        double r2 = 0.0;
+        for (int a = 0; a < 3; a++) { const double c = (mx[a] + mn[a]) * 0.5; r2 += (c - mx[a]) * (c - mx[a]); }
+        s->bsphereRadius = std::sqrt(r2);
     }
     d.envMap = nullptr; d.hasEnvMap = 0;
     if (!(env && env->rgb)) {                  // (the pointer is never null: see SceneD::envMap)
@@ -819,6 +836,13 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
 
 int gdpt_scene_device(const gdpt_scene *s) { return s ? s->device : -1; }
 
+int gdpt_scene_bsphere_radius(const gdpt_scene *s, double *radius)
+{
+    if (!s || !radius) return tfail(GDPT_ERR_INVALID, "scene_bsphere_radius: null argument");
+    *radius = s->bsphereRadius;
+    return GDPT_OK;
+}
+
 void gdpt_scene_destroy(gdpt_scene *s)
 {
     if (!s) return;
@@ -910,10 +934,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
     c.regenMin = f->regenMin;
+    // A reconstruction filter wider than box.  The whole film: a STRIP -- the launch covers the film's rows plus the filter's reach (the log's rows), so
+    // that the strip needs nothing from its neighbours.  A sub-rectangle: a BLOCK (GPTBlockRenderer::process's unit, gpt_proc.cpp:74-91) -- the samples of
+    // its pixels only, put within the filter's reach around it as GPTWorkResult's bordered blocks take them (gpt_wr.cpp:31-44); blocks add up to the film.
+    int gsx0 = x0, gsy0 = y0, gsx1 = x1, gsy1 = y1;         // the pixels whose samples are logged; the receiving pixels follow from them
     if (f->d.fValues) {
-        // a reconstruction filter wider than box: the launch covers the film's rows plus the filter's reach (the log's rows)
-        if (x0 != 0 || x1 != f->d.W || y0 != f->d.y0 || y1 != f->d.y1) return tfail(GDPT_ERR_UNSUPPORTED, "with a reconstruction filter wider than box the rectangle must be the whole film");
-        y0 = f->d.logY0; y1 = f->d.logY0 + f->d.logRows;
+        if (x0 == 0 && x1 == f->d.W && y0 == f->d.y0 && y1 == f->d.y1) { y0 = f->d.logY0; y1 = f->d.logY0 + f->d.logRows; gsy0 = y0; gsy1 = y1; }
     }
     const int tilesX = (x1 - x0 + 15) / 16, tilesY = (y1 - y0 + 15) / 16;
     hipEvent_t e0, e1;
@@ -1093,8 +1119,11 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else                      { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #endif
         if (useQueue) hipLaunchKernelGGL(k_fold_cont, dim3(tiles), block, 0, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX);
-        if (f->d.fValues)
-            hipLaunchKernelGGL(k_gather_log, dim3((f->d.W + 15) / 16, (f->d.y1 - f->d.y0 + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount);
+        if (f->d.fValues) {
+            const int reach = (int)std::ceil(f->d.fRadius) + 1;
+            const int ox0 = std::max(0, gsx0 - reach), ox1 = std::min(f->d.W, gsx1 + reach), oy0 = std::max(f->d.y0, gsy0 - reach), oy1 = std::min(f->d.y1, gsy1 + reach);
+            hipLaunchKernelGGL(k_gather_log, dim3((ox1 - ox0 + 15) / 16, (oy1 - oy0 + 15) / 16), dim3(TBLK), 0, f->stream, f->d, c.sCount, gsx0, gsy0, gsx1, gsy1, ox0, oy0, ox1, oy1);
+        }
     }
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
@@ -1217,6 +1246,21 @@ int gdpt_film_accum(gdpt_film *f, double *accum)
     int rc = ensure_resolved(f);
     if (rc) return rc;
     THIPCHK(hipMemcpyAsync(accum, f->accum, sizeof(Float) * 5 * (size_t)(f->d.y1 - f->d.y0) * f->d.W * 4, hipMemcpyDeviceToHost, f->stream));
+    THIPCHK(hipStreamSynchronize(f->stream));
+    return GDPT_OK;
+}
+
+int gdpt_film_accum_rect(gdpt_film *f, int x0, int y0, int x1, int y1, double *accum)
+{
+    if (!f || !accum) return tfail(GDPT_ERR_INVALID, "film_accum_rect: null argument");
+    if (x0 < 0 || x1 > f->d.W || x0 >= x1 || y0 < f->d.y0 || y1 > f->d.y1 || y0 >= y1) return tfail(GDPT_ERR_INVALID, "film_accum_rect: rectangle outside the film rows");
+    (void)hipSetDevice(f->scene->device);
+    int rc = ensure_resolved(f);
+    if (rc) return rc;
+    const size_t rows = (size_t)(f->d.y1 - f->d.y0), pitch = sizeof(Float) * 4 * (size_t)f->d.W, width = sizeof(Float) * 4 * (size_t)(x1 - x0);
+    for (int b = 0; b < 5; b++)
+        THIPCHK(hipMemcpy2DAsync(accum + (size_t)b * (y1 - y0) * (x1 - x0) * 4, width, f->accum + ((size_t)b * rows + (size_t)(y0 - f->d.y0)) * f->d.W * 4 + (size_t)x0 * 4, pitch, width,
+                                 (size_t)(y1 - y0), hipMemcpyDeviceToHost, f->stream));
     THIPCHK(hipStreamSynchronize(f->stream));
     return GDPT_OK;
 }

@@ -949,11 +949,14 @@ __global__ __launch_bounds__(TBLK) void k_fold_cont(SceneD S, ConfigD cfg, FilmD
 // shift of the neighbour puts), reads each sample's position, forms the weights of the five put positions from the discretised
 // filter (ImageBlock::put, imageblock.h:150-199: w = wx * wy; beyond the radius the table gives 0) and adds into its own 5 x 4
 // sums in (row, column, sample) order -- no atomics, reproducible.  Adjacent threads read adjacent log entries.
-__global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
+// [sx0, sx1) x [sy0, sy1): the pixels whose samples this chunk logged -- the film's rows and their reach (a whole strip), or a block of the film (round 5:
+// gdpt_render_rect on a sub-rectangle, GPTBlockRenderer's unit: the block's samples land within the filter's reach AROUND the block, gpt_wr.cpp:31-44,
+// and blocks add up); the receiving pixels [ox0, ..) x [oy0, ..) are the film's pixels within reach of those.
+__global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count, int sx0, int sy0, int sx1, int sy1, int ox0, int oy0, int ox1, int oy1)
 {
     enum { RIGHT = 0, BOTTOM = 1, LEFT = 2, TOP = 3 };
-    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = F.y0 + blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= F.W || y >= F.y1) return;
+    const int x = ox0 + blockIdx.x * 16 + (threadIdx.x & 15), y = oy0 + blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= ox1 || y >= oy1) return;
     if (__hip_atomic_load(F.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;      // a cancelled chunk is incomplete: dropped
     const int R = (int)ceil(F.fRadius) + 1;                 // (the host sizes logY0 / logRows with the same reach)
     const size_t plane = (size_t)F.logRows * F.W, comp = (size_t)F.logChunk * plane;
@@ -961,8 +964,8 @@ __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count)
     Float o[5][4];
     unsigned invalid = 0;
     for (int b = 0; b < 5; b++) for (int k = 0; k < 4; k++) o[b][k] = 0.0;
-    for (int yy = max(F.logY0, y - R); yy <= min(F.logY0 + F.logRows - 1, y + R); yy++)
-        for (int xx = max(0, x - R); xx <= min(F.W - 1, x + R); xx++)
+    for (int yy = max(sy0, y - R); yy <= min(sy1 - 1, y + R); yy++)
+        for (int xx = max(sx0, x - R); xx <= min(sx1 - 1, x + R); xx++)
             for (int c = 0; c < count; c++) {
                 const size_t at = (size_t)c * plane + (size_t)(yy - F.logY0) * F.W + xx;
                 const Float sx = F.log[(size_t)30 * comp + at], sy = F.log[(size_t)31 * comp + at];

@@ -13,5 +13,6 @@ struct gdpt_scene {
     bool specialEmitters = false;   // an environment or point emitter: the ENV builds of the render kernel
     bool perVertex = false;         // vertex normals or bitmap textures: the builds that keep a hit's barycentrics
     size_t ldsSceneBytes = 0;
+    double bsphereRadius = 0.0;     // Scene::getBSphere().radius after Scene::initializeBidirectional (kd-tree bounds + sensor + emitters, scene.cpp:386-413)
     std::vector<gdpt_tr::MaterialD> hostMats;   // the material table as uploaded (G-BDPT checks its scope against it)
 };

@@ -152,6 +152,13 @@ class Scene:
         check(lib().gdpt_scene_intersect(self._h, n, od.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p)))
         return prim, tp[:, 0], tp[:, 1:4]
 
+    def bsphere_radius(self):
+        """Scene::getBSphere().radius after Scene::initializeBidirectional (scene.cpp:386-413): kd-tree bounds + sensor + emitters."""
+        r = C.c_double(0.0)
+        lib().gdpt_scene_bsphere_radius.argtypes = [C.c_void_p, C.c_void_p]
+        check(lib().gdpt_scene_bsphere_radius(self._h, C.byref(r)))
+        return float(r.value)
+
     def layout(self):
         """-> dict(nodes, node_bytes (128: fp32 boxes, LDS-resident scene; 64: 8-bit boxes, scene in HBM), lds_resident, stack_entries, table_bytes, leaf_exit)"""
         out = (C.c_longlong * 6)()
@@ -205,6 +212,13 @@ class Film:
     def accum(self):
         out = np.empty((5, self.rows, self.width, 4), np.float64)
         check(lib().gdpt_film_accum(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def accum_rect(self, x0, y0, x1, y1):
+        """The five accumulation buffers over the pixels [x0,x1) x [y0,y1) of the film only: [5, y1 - y0, x1 - x0, 4] -- a block with its border."""
+        out = np.empty((5, y1 - y0, x1 - x0, 4), np.float64)
+        lib().gdpt_film_accum_rect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        check(lib().gdpt_film_accum_rect(self._h, int(x0), int(y0), int(x1), int(y1), out.ctypes.data_as(C.c_void_p)))
         return out
 
     def develop(self, buffer):

@@ -128,7 +128,10 @@ public:
 		m_reconstructL2 = props.getBoolean("reconstructL2", false);
 		m_reconstructAlpha = (Float) props.getFloat("reconstructAlpha", Float(0.2));
 		m_devices = props.getInteger("devices", 1);      /* not a reference property: GPUs to shard the frame over (row strips) */
-		m_blocked = props.getBoolean("blocked", true);   /* not a reference property: false = the whole frame in one launch instead of a BlockedRenderProcess */
+		/* not a reference property.  false (default): the whole frame in one gdpt_render_rect -- what fills a 131 072-lane GPU.  true: the reference's
+		   own shape, a BlockedRenderProcess whose workers hand blocks to the GPU (mitsuba -b, progress, per-unit cancel, border merge by putMulti); a
+		   32x32 unit is 1 024 lanes, so units of at least 256x256 pixels are asked for whatever Scene::getBlockSize() says (see render()) */
+		m_blocked = props.getBoolean("blocked", false);
 		if (m_reconstructL1 && m_reconstructL2)
 			Log(EError, "Disable 'reconstructL1' or 'reconstructL2': Cannot display two reconstructions at a time!");
 		if (m_reconstructAlpha <= 0.0f)
@@ -154,6 +157,9 @@ public:
 		}
 		const Vector2i size = film->getCropSize();
 		const int W = size.x, H = size.y;
+		/* the C-ABI's camera has crop == film (include/gdpt_tracer.h, gdpt_camera): a crop window would move every pixel's ray */
+		if (film->getSize().x != W || film->getSize().y != H || film->getCropOffset().x != 0 || film->getCropOffset().y != 0)
+			Log(EError, "gpt_hip: a film with a crop window is not carried (crop %ix%i at (%i, %i) of %ix%i)", W, H, film->getCropOffset().x, film->getCropOffset().y, film->getSize().x, film->getSize().y);
 
 		gdpt_plugin::FlatScene fs;
 		gdpt_plugin::flatten(scene, sensor.get(), size, fs);
@@ -170,13 +176,14 @@ public:
 		for (int b = 0; b < 5; ++b) img[b].resize((size_t) 3 * W * H);
 		if (m_devices > 1) {
 			if (!renderStrips(fs, cfg, kind, p0, p1, W, H, img)) return false;
-		} else if (m_blocked && kind == GDPT_RFILTER_BOX) {
+		} else if (m_blocked) {
 			/* gpt.cpp:1396-1414: "This is a sampling-based integrator - parallelize": the scheduler's workers each drive the GPU through a
 			   GPTBlockRendererHIP; the blocks' borders are merged by addition in MultiFilm::putMulti (gpt_proc.cpp:137-149) */
 			ref<Scheduler> sched = Scheduler::getInstance();
 			m_blockScene = gdpt_plugin::upload(fs, -1);
 			m_blockCfg = cfg;
-			ref<BlockedRenderProcess> proc = new GPTRenderProcessHIP(job, queue, (int) scene->getBlockSize());
+			m_blockFilter[0] = kind; m_blockFilterP[0] = p0; m_blockFilterP[1] = p1;
+			ref<BlockedRenderProcess> proc = new GPTRenderProcessHIP(job, queue, std::max((int) scene->getBlockSize(), 256));
 			int integratorResID = sched->registerResource(this);
 			proc->bindResource("integrator", integratorResID);
 			proc->bindResource("scene", sceneResID);
@@ -316,6 +323,8 @@ private:
 	gdpt_film *m_film;
 	gdpt_scene *m_blockScene;       /* blocked shape: the device scene the workers' GPTBlockRendererHIP render from */
 	gdpt_config m_blockCfg;
+	int m_blockFilter[1];           /* the film's reconstruction filter, as gdpt_film_set_rfilter takes it */
+	double m_blockFilterP[2];
 	ParallelProcess *m_process;
 	int m_maxDepth, m_rrDepth, m_devices;
 	bool m_strictNormals, m_reconstructL1, m_reconstructL2, m_blocked;
@@ -334,8 +343,11 @@ void GPTBlockRendererHIP::prepare() {      /* gpt_proc.cpp:58-72: the resources 
 
 GPTBlockRendererHIP::~GPTBlockRendererHIP() { if (m_film) gdpt_film_destroy(m_film); }
 
-/* gpt_proc.cpp:74-91 with renderBlock replaced by gdpt_render_rect: the unit's pixels are sampled on the device, the 15 puts of every sample
-   (gpt.cpp:1314-1352) land in the unit's rectangle grown by one pixel, which is what comes back in the five ImageBlocks */
+/* gpt_proc.cpp:74-91 with renderBlock replaced by gdpt_render_rect: the unit's pixels are sampled on the device; the 15 puts of every sample
+   (gpt.cpp:1314-1352) land in the unit's rectangle grown by the blocks' border -- the filter's reach + the extra pixel of the neighbour puts
+   (gpt_proc.cpp:52-56, imageblock.cpp:23-38) --, which is what comes back in the five ImageBlocks.  With a filter wider than box the C-ABI renders
+   a sub-rectangle as exactly such a block (include/gdpt_tracer.h, gdpt_film_set_rfilter).  Unit offsets are relative to the crop window
+   (BlockedRenderProcess::bindResource, renderproc.cpp:158-181); the C-ABI's camera has crop == film, which flatten() checks. */
 void GPTBlockRendererHIP::process(const WorkUnit *workUnit, WorkResult *workResult, const bool &stop) {
 	const RectangularWorkUnit *rect = static_cast<const RectangularWorkUnit *>(workUnit);
 	GPTWorkResultHIP *block = static_cast<GPTWorkResultHIP *>(workResult);
@@ -345,31 +357,38 @@ void GPTBlockRendererHIP::process(const WorkUnit *workUnit, WorkResult *workResu
 	if (stop) return;
 	const Vector2i crop = m_sensor->getFilm()->getCropSize();
 	const int W = crop.x, H = crop.y;
-	const int x0 = rect->getOffset().x, y0 = rect->getOffset().y, x1 = x0 + rect->getSize().x, y1 = y0 + rect->getSize().y;
-	const int fy0 = std::max(0, y0 - 1), fy1 = std::min(H, y1 + 1);          /* the film owns the border rows too: their sums come back resolved */
+	/* (a film with high-quality edges hands out units that reach beyond the crop window, renderproc.cpp:166-171: their outside part has no pixels here) */
+	const int ux0 = rect->getOffset().x, uy0 = rect->getOffset().y;
+	const int x0 = std::max(0, ux0), y0 = std::max(0, uy0), x1 = std::min(W, ux0 + rect->getSize().x), y1 = std::min(H, uy0 + rect->getSize().y);
+	if (x0 >= x1 || y0 >= y1) return;
+	const int border = block->getImageBlock(0)->getBorderSize();
+	const int fy0 = std::max(0, y0 - border), fy1 = std::min(H, y1 + border);          /* the film owns the border rows too: their sums come back resolved */
+	const int fx0 = std::max(0, x0 - border), fx1 = std::min(W, x1 + border);
 	if (!m_film || fy0 != m_filmY0 || fy1 != m_filmY1) {
 		if (m_film) gdpt_film_destroy(m_film);
 		m_film = NULL;
 		GradientPathIntegratorHIP::check(gdpt_film_create(m_integrator->m_blockScene, fy0, fy1, &m_film));
+		GradientPathIntegratorHIP::check(gdpt_film_set_rfilter(m_film, m_integrator->m_blockFilter[0], m_integrator->m_blockFilterP[0], m_integrator->m_blockFilterP[1]));
 		m_filmY0 = fy0; m_filmY1 = fy1;
-		m_accum.resize((size_t) 5 * (fy1 - fy0) * W * 4);
 	} else GradientPathIntegratorHIP::check(gdpt_film_clear(m_film));
 	GradientPathIntegratorHIP::check(gdpt_render_rect(m_integrator->m_blockScene, &m_integrator->m_blockCfg, x0, y0, x1, y1, m_film));
 	GradientPathIntegratorHIP::check(gdpt_film_sync(m_film));
 	if (stop) return;                        /* (the scheduler drops the result of a cancelled unit) */
-	GradientPathIntegratorHIP::check(gdpt_film_accum(m_film, m_accum.data()));
-	/* accum[5][rows][W][4] = (R, G, B, weight) -> the block's bitmap: SPECTRUM_SAMPLES + 2 channels per pixel (spectrum, alpha, weight;
-	   GPTWorkResult::put, gpt_wr.h:57-65, writes alpha = 1 per put, which MultiFilm's develop never reads: it is set to the weight here) */
-	const int rows = fy1 - fy0;
+	/* only the block and its border travel back: accum[5][rows][cols][4] = (R, G, B, weight) */
+	const int rows = fy1 - fy0, cols = fx1 - fx0;
+	m_accum.resize((size_t) 5 * rows * cols * 4);
+	GradientPathIntegratorHIP::check(gdpt_film_accum_rect(m_film, fx0, fy0, fx1, fy1, m_accum.data()));
+	/* -> the block's bitmap: SPECTRUM_SAMPLES + 2 channels per pixel (spectrum, alpha, weight; GPTWorkResult::put, gpt_wr.h:57-65, writes alpha = 1
+	   per put, which MultiFilm's develop never reads: it is set to the weight here) */
 	for (int b = 0; b < 5; ++b) {
 		ImageBlock *ib = block->getImageBlock(b);
 		Bitmap *bmp = ib->getBitmap();
-		const int border = ib->getBorderSize(), bw = bmp->getWidth(), ch = bmp->getChannelCount();
+		const int bw = bmp->getWidth(), ch = bmp->getChannelCount();
 		Float *dst = bmp->getFloatData();
-		for (int yy = std::max(fy0, y0 - border); yy < std::min(fy1, y1 + border); ++yy)
-			for (int xx = std::max(0, x0 - border); xx < std::min(W, x1 + border); ++xx) {
-				const double *a = &m_accum[((((size_t) b * rows) + (yy - fy0)) * W + xx) * 4];
-				Float *d = dst + ((size_t) (yy - y0 + border) * bw + (xx - x0 + border)) * ch;
+		for (int yy = fy0; yy < fy1; ++yy)
+			for (int xx = fx0; xx < fx1; ++xx) {
+				const double *a = &m_accum[((((size_t) b * rows) + (yy - fy0)) * cols + (xx - fx0)) * 4];
+				Float *d = dst + ((size_t) (yy - uy0 + border) * bw + (xx - ux0 + border)) * ch;
 				for (int c = 0; c < ch - 2; ++c) d[c] = (Float) a[c < 3 ? c : 2];
 				d[ch - 2] = (Float) a[3];
 				d[ch - 1] = (Float) a[3];

@@ -228,6 +228,13 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
     elif variant == "glass":          # the tall block is solid bk7 glass, the short one an aluminium mirror: refraction branch of the half-vector shift
         tall_m = b.material(dielectric())
         short_m = b.material(conductor(**AL))
+    elif variant == "slab":           # "glass" with an EXACT rectangular glass block (the measured tall block's opposite faces are parallel to 1e-4 only): a slab
+        tall_m = b.material(dielectric())
+        short_m = white
+    elif variant == "mirrors":        # two mirrors facing each other at an angle: the back wall and the tall block (chains with two specular vertices)
+        back_m = b.material(conductor(**AL))
+        tall_m = b.material(conductor(**AL))
+        short_m = white
     elif variant == "twosided":       # two-sided walls and a free-standing two-sided GGX panel lit and seen from both faces
         white = b.material(twosided(diffuse((0.725, 0.71, 0.68))))
         floor_m = back_m = tall_m = short_m = white
@@ -253,7 +260,12 @@ def cornell_box(width=512, height=512, variant="diffuse", seed=0, environment=No
         b.sphere((368, 150, 351), 150.0, tall_m, level=1, bend=0.6 if variant == "bent" else 0.0, seed=2)
     else:
         b.box([(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)], 0.0, short_m)         # short block
-        b.box([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 0.0, tall_m)        # tall block
+        if variant == "slab":          # 200 x 60 footprint about (368, 351), turned by atan(3/4): corners are exact in binary floating point to the last bit or two
+            cx, cz, ux, uz = 368.0, 351.0, 0.8, 0.6
+            corner = lambda su, sv: (cx + su * 100 * ux - sv * 30 * uz, 330, cz + su * 100 * uz + sv * 30 * ux)
+            b.box([corner(1, -1), corner(-1, -1), corner(-1, 1), corner(1, 1)], 0.0, tall_m)
+        else:
+            b.box([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 0.0, tall_m)        # tall block
     if variant == "twosided":
         panel = b.material(twosided(roughconductor(0.15, **AL, distribution=DISTR_GGX)))
         b.quad((60, 20, 150), (200, 20, 60), (200, 300, 60), (60, 300, 150), panel, room)

@@ -187,6 +187,9 @@ GDPT_API int  gdpt_film_unpack_halo(gdpt_film *f, int which, const void *devBuf)
  * the box filter would have (gpt.cpp:1314-1352, imageblock.h:150-199): accum[5][rows][width][4] doubles (R,G,B,weight)
  * on the HOST, rows = y1 - y0. */
 GDPT_API int  gdpt_film_accum(gdpt_film *f, double *accum);
+/* The same for the pixels [x0,x1) x [y0,y1) of the film only: accum[5][y1 - y0][x1 - x0][4] -- what a block-wise host copies back per work unit
+ * (GPTBlockRenderer::process's five ImageBlocks with their border, src/integrators/gpt/gpt_proc.cpp:74-91, gpt_wr.cpp:31-44). */
+GDPT_API int  gdpt_film_accum_rect(gdpt_film *f, int x0, int y0, int x1, int y1, double *accum);
 /* MultiFilm::developMulti (multifilm.cpp:366-416; weight division fmtconv.cpp:955-1058) of one buffer to fp32 RGB
  * (the std::transform casts of gpt.cpp:1439-1442) into a DEVICE buffer of 3*rows*width floats -- the solver's input. */
 GDPT_API int  gdpt_film_develop_device(gdpt_film *f, int buffer, float *rgbDevice);
@@ -235,12 +238,19 @@ GDPT_API int  gdpt_device_copy(int dstDevice, void *dst, int srcDevice, const vo
 GDPT_API int  gdpt_device_download(int device, void *host, const void *dev, size_t bytes);
 /* The device a scene (and every film created on it) lives on. */
 GDPT_API int  gdpt_scene_device(const gdpt_scene *s);
+/* Scene::getBSphere().radius (include/mitsuba/render/scene.h:972-975) of the box Scene::initializeBidirectional builds (src/librender/scene.cpp:386-413):
+ * the kd-tree's bounds (enlarged by MTS_KD_AABB_EPSILON) + the sensor's AABB + every emitter's AABB -- what ManifoldPerturbation::manifoldWalk
+ * measures its reversibility error against (src/libbidir/mut_manifold.cpp:1219). */
+GDPT_API int  gdpt_scene_bsphere_radius(const gdpt_scene *s, double *radius);
 /* The film's reconstruction filter (`<rfilter type=...>`, src/rfilters/<type>.cpp, discretised as rfilter.cpp:37-55): GDPT_RFILTER_BOX
  * (default: every put covers one pixel, the per-pixel-sums fast path), TENT, GAUSSIAN (p0 = stddev, 0.5), MITCHELL (p0 = B, p1 = C,
  * 1/3 each), CATMULLROM, LANCZOS (p0 = lobes, 3).  The wider filters log every sample and gather the puts per receiving pixel
- * (no atomics; 1.3-2.3x the box render time) and take whole-film rectangles only.  A film over a strip of rows then renders the
- * rows within the filter's reach (ceil(radius) + 1 above and below, clipped to the image) as well, so that its own rows come
- * out bit-identical to the same rows of a whole-image film and strips need no exchange (gdpt_film_stats counts those rays too).
+ * (no atomics; 1.3-2.3x the box render time).  A rectangle that is the WHOLE film renders a strip: a film over a strip of rows then
+ * renders the rows within the filter's reach (ceil(radius) + 1 above and below, clipped to the image) as well, so that its own rows come
+ * out bit-identical to the same rows of a whole-image film and strips need no exchange (gdpt_film_stats counts those rays too).  A
+ * SUB-rectangle renders a block as GPTBlockRenderer::process does (src/integrators/gpt/gpt_proc.cpp:74-91): the samples of its pixels
+ * only, put within the filter's reach AROUND the rectangle (GPTWorkResult's bordered ImageBlocks, gpt_wr.cpp:31-44, clipped to the film's
+ * rows); the blocks of a film add up to the whole-film render (to the rounding of the sums' order).
  * Call before rendering. */
 #define GDPT_RFILTER_BOX        0
 #define GDPT_RFILTER_TENT       1

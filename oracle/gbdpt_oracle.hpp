@@ -1267,8 +1267,8 @@ struct Tracer {
         if (!manifoldUpdate(proposal, cI, b)) return false;
         if (!manifoldMove(vb_old->position(), n)) return false;
         const V3 p1 = mVerts[1].p;
-        const V3 ctr = (c.sc.aabbMin + c.sc.aabbMax) * 0.5;
-        const Float radius = length(c.sc.aabbMax - ctr);                                     // m_scene->getBSphere().radius, aabb.h
+        const Float radius = sceneBSphereRadius(c.sc);                                       // m_scene->getBSphere().radius: the box of Scene::initializeBidirectional
+                                                                                             // (kd-tree bounds + sensor + emitters, scene.cpp:386-413; gbdpt_proc.cpp:80 calls it)
         const Float relerr = length(p0 - p1) / radius;
         if (relerr > 10.0 * Epsilon) return false;
         c.walksOk++;
@@ -1648,6 +1648,44 @@ struct Tracer {
             out[18] = mVerts[1].p.x; out[19] = mVerts[1].p.y; out[20] = mVerts[1].p.z;
             out[21] = mVerts[2].p.x; out[22] = mVerts[2].p.y; out[23] = mVerts[2].p.z;
             out[24] = (Float)(p.v[i + 1]->mat.type); out[25] = (Float)i;
+            return;
+        }
+    }
+
+    // The same for a chain with TWO non-connectable vertices: "connectable vertex i, specular i + 1, specular i + 2, connectable i + 3" of the sensor
+    // subpath (two facing mirrors; both faces of a glass slab).  out: [0] found, [1..12] the four positions, [13..24] their shading normals,
+    // [25] SpecularManifold::G(i, i + 3), [26] multiG(i, i + 3) (-1 when i + 3 is the path's last vertex), [27] [28] the material types of the chain vertices, [29] eta of the first;
+    // then -- pinned at i, the end moved by `delta` -- [30] iterations, [31] success, [32..40] where the chain vertices and the end arrive.
+    void manifoldProbe2(int px, int py, const Float delta[3], Float out[48])
+    {
+        for (int k = 0; k < 48; ++k) out[k] = 0.0;
+        Config &cfg = c.cfg;
+        if (c.sc.cam.shutterClose > c.sc.cam.shutterOpen) (void)rng.next1D();
+        if (cfg.maxDepth == -1) cfg.maxDepth = 12;
+        Path emitterSubpath, sensorSubpath;
+        emitterSubpath.v.push_back(pool.allocVertex());
+        emitterSubpath.v[0]->type = EEmitterSupernode; emitterSubpath.v[0]->degenerate = false;
+        sensorSubpath.v.push_back(pool.allocVertex());
+        sensorSubpath.v[0]->type = ESensorSupernode; sensorSubpath.v[0]->degenerate = true;
+        alternatingRandomWalkFromPixel(emitterSubpath, 0, sensorSubpath, cfg.maxDepth + 1, px, py, -1);
+        const Path &p = sensorSubpath;
+        for (int i = 1; i + 3 < p.vertexCount(); ++i) {
+            if (!p.v[i]->isConnectable() || p.v[i + 1]->isConnectable() || p.v[i + 2]->isConnectable() || !p.v[i + 3]->isConnectable()) continue;
+            if (!p.v[i]->isSurface() || !p.v[i + 1]->isSurface() || !p.v[i + 2]->isSurface() || !p.v[i + 3]->isSurface()) continue;
+            out[0] = 1.0;
+            for (int q = 0; q < 4; ++q) {
+                const V3 pp = p.v[i + q]->position(), nn = p.v[i + q]->shadingNormal();
+                out[1 + 3 * q] = pp.x; out[2 + 3 * q] = pp.y; out[3 + 3 * q] = pp.z;
+                out[13 + 3 * q] = nn.x; out[14 + 3 * q] = nn.y; out[15 + 3 * q] = nn.z;
+            }
+            out[25] = manifoldG(p, i, i + 3);
+            out[26] = i + 3 < p.length() ? multiG(p, i, i + 3) : -1.0;                         // (multiG steps back from the path's last vertex: it takes it for a supernode, path.cpp:423-454)
+            out[27] = (Float)(p.v[i + 1]->mat.type); out[28] = (Float)(p.v[i + 2]->mat.type); out[29] = p.v[i + 1]->mat.eta[0];
+            if (!manifoldInit(p, i, i + 3)) return;
+            const V3 target = p.v[i + 3]->position() + V3(delta[0], delta[1], delta[2]);
+            const bool ok = manifoldMove(target, p.v[i + 3]->shadingNormal());
+            out[30] = mIterations; out[31] = ok ? 1.0 : 0.0;
+            for (int q = 0; q < 3; ++q) { out[32 + 3 * q] = mVerts[1 + q].p.x; out[33 + 3 * q] = mVerts[1 + q].p.y; out[34 + 3 * q] = mVerts[1 + q].p.z; }
             return;
         }
     }

@@ -1952,6 +1952,50 @@ void renderSerial(const Scene &sc, const gpo_config &cfg, int blockSize, uint64_
     }
 }
 
+// Scene::getAABB() AFTER Scene::initializeBidirectional (scene.cpp:386-413): the kd-tree's (enlarged) bounds, expanded by the sensor's AABB
+// (perspective: the camera position, perspective.cpp:444-446 -> AnimatedTransform::getTranslationBounds, track.cpp:79-83; thinlens: the
+// spatial bounds of the aperture box (-r,-r,0)..(r,r,0), thinlens.cpp:516-520 -> track.cpp:123-129) and by every emitter's AABB (area: its
+// shape's bounds, inside the kd-tree's already, area.cpp:204-206; point: its position, point.cpp:153-155; constant / envmap: the centre of
+// m_sceneBSphere, constant.cpp:234-240).  Scene::getBSphere() (scene.h:972-975) is AABB::getBSphere of THIS box (aabb.cpp:44-47) -- the
+// yardstick of ManifoldPerturbation::manifoldWalk's reversibility test (mut_manifold.cpp:1219).
+static void sensorBounds(const Scene &sc, V3 &mn, V3 &mx)              // m_aabb after `m_aabb.expandBy(m_sensor->getAABB())`, scene.cpp:386-395
+{
+    mn = sc.aabbMin; mx = sc.aabbMax;
+    auto expand = [&](V3 p) {
+        mn = V3(std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z));
+        mx = V3(std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z));
+    };
+    const double *M = sc.cam.toWorld;
+    if (sc.cam.type == 1) {
+        const Float r = sc.cam.apertureRadius;
+        for (int j = 0; j < 4; ++j) {                                  // the box is flat in z: four distinct corners
+            const Float x = (j & 1) ? r : -r, y = (j & 2) ? r : -r;
+            expand(V3(M[0] * x + M[1] * y + M[3], M[4] * x + M[5] * y + M[7], M[8] * x + M[9] * y + M[11]));
+        }
+    } else expand(V3(M[3], M[7], M[11]));
+}
+static void sceneBounds(const Scene &sc, V3 &mn, V3 &mx)
+{
+    sensorBounds(sc, mn, mx);
+    const V3 sceneMn = mn, sceneMx = mx;                               // (m_aabb when the environment emitter's createShape reads it, scene.cpp:398-407)
+    for (size_t e = 0; e < sc.emitters.size(); ++e) {
+        const Emitter &em = sc.emitters[e];
+        V3 p;
+        if (em.numTris < 0) p = em.position;
+        else if (em.numTris == 0) p = (sceneMx + sceneMn) * 0.5;       // AABB(m_sceneBSphere.center): inside the box by construction
+        else continue;
+        mn = V3(std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z));
+        mx = V3(std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z));
+    }
+}
+static Float sceneBSphereRadius(const Scene &sc)
+{
+    V3 mn, mx;
+    sceneBounds(sc, mn, mx);
+    const V3 ctr = (mx + mn) * 0.5;                                    // AABB::getCenter, aabb.h:132-134
+    return length(ctr - mx);                                          // aabb.cpp:44-47
+}
+
 #include "gbdpt_oracle.hpp"
 
 } // namespace
@@ -2047,10 +2091,8 @@ GPO_API void gpo_scene_set_environment(gpo_scene *h, const double *radiance, int
     sc.emitterPDF = Distribution();
     for (size_t i = 0; i < sc.emitters.size(); ++i) sc.emitterPDF.append(1.0);
     sc.emitterPDF.normalize();
-    V3 mn = sc.aabbMin, mx = sc.aabbMax;
-    const V3 camPos(sc.cam.toWorld[3], sc.cam.toWorld[7], sc.cam.toWorld[11]);
-    mn = V3(std::min(mn.x, camPos.x), std::min(mn.y, camPos.y), std::min(mn.z, camPos.z));
-    mx = V3(std::max(mx.x, camPos.x), std::max(mx.y, camPos.y), std::max(mx.z, camPos.z));
+    V3 mn, mx;
+    sensorBounds(sc, mn, mx);                                        // Scene::getAABB() when createShape reads it: kd-tree + sensor (scene.cpp:386-407)
     sc.bsCenter = (mx + mn) * 0.5;                                   // AABB::getCenter, aabb.h:132-134
     sc.bsRadius = std::max(Epsilon, length(sc.bsCenter - mx) * (Float)1.5f);   // aabb.cpp:44-47, constant.cpp:69
 }
@@ -2430,6 +2472,9 @@ static gb::Config gbConfig(const gpo_gbdpt_config *cfg)
     return c;
 }
 // one sample of GBDPTRenderer::process: out = primal(3), gradient[4](3 each), sample position(2); light splats as (x, y, buffer, r, g, b);
+// Scene::getBSphere().radius after Scene::initializeBidirectional (scene.cpp:386-413, aabb.cpp:44-47)
+GPO_API double gpo_scene_bsphere_radius(gpo_scene *h) { return sceneBSphereRadius(h->sc); }
+
 // counters = closest-hit rays, shadow rays, unsupported events (gpo_gbdpt_render: + invalid puts, manifold walks entered / converged, propagated chain vertices)
 GPO_API void gpo_gbdpt_sample(gpo_scene *h, const gpo_gbdpt_config *cfg, int px, int py, int sampleIndex, double *out17, int maxLight, double *lightOut, int *nLight,
                               unsigned long long *counters)
@@ -2461,6 +2506,15 @@ GPO_API void gpo_manifold_probe(gpo_scene *h, const gpo_gbdpt_config *cfg, int p
     gb::Pool pool;
     gb::Tracer tr(ctx, rng, pool);
     tr.manifoldProbe(px, py, delta3, out32);
+}
+GPO_API void gpo_manifold_probe2(gpo_scene *h, const gpo_gbdpt_config *cfg, int px, int py, int sampleIndex, const double *delta3, double *out48)
+{
+    gb::Ctx ctx{h->sc, gbConfig(cfg)};
+    gb::cameraSetup(ctx);
+    Rng rng(cfg->seed, (uint64_t)py * h->sc.cam.width + px, (uint64_t)sampleIndex);
+    gb::Pool pool;
+    gb::Tracer tr(ctx, rng, pool);
+    tr.manifoldProbe2(px, py, delta3, out48);
 }
 // GBDPTRenderer::process over the pixels of [x0,x1) x [y0,y1): the five camera blocks [5][H][W][4] and the five light images [5][H][W][3]
 GPO_API void gpo_gbdpt_render(gpo_scene *h, const gpo_gbdpt_config *cfg, int x0, int y0, int x1, int y1, double *block, double *light, unsigned long long *counters)

@@ -309,6 +309,26 @@ class Scene:
         return dict(a=out[1:4].copy(), m=out[4:7].copy(), b=out[7:10].copy(), nb=out[10:13].copy(), G=out[13], Gam=out[14], Gmb=out[15], iterations=int(out[16]),
                     converged=bool(out[17]), m_moved=out[18:21].copy(), b_moved=out[21:24].copy(), material=int(out[24]), index=int(out[25]), na=out[26:29].copy(), nm=out[29:32].copy())
 
+    def manifold_probe2(self, cfg, px, py, sample, delta=(0.0, 0.0, 0.0)):
+        """The probe for a chain with TWO specular vertices (manifoldProbe2): None, or dict(p = [4,3] positions of a, m1, m2, b, n = [4,3] shading
+        normals, G = SpecularManifold::G(a, b), multiG, materials = (type of m1, type of m2), eta of m1, iterations / converged / moved = [3,3]
+        positions of m1, m2, b after a manifold walk that moves b by `delta`)."""
+        out = np.zeros(48, np.float64)
+        d = np.asarray(delta, np.float64)
+        lib().gpo_manifold_probe2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib().gpo_manifold_probe2(self._h, C.byref(cfg), px, py, sample, _p(d), _p(out))
+        if out[0] == 0:
+            return None
+        return dict(p=out[1:13].reshape(4, 3).copy(), n=out[13:25].reshape(4, 3).copy(), G=out[25], multiG=out[26], materials=(int(out[27]), int(out[28])), eta=out[29],
+                    iterations=int(out[30]), converged=bool(out[31]), moved=out[32:41].reshape(3, 3).copy())
+
+    def bsphere_radius(self):
+        """Scene::getBSphere().radius after Scene::initializeBidirectional: kd-tree bounds (enlarged) + sensor + emitters (scene.cpp:386-413) --
+        the yardstick of manifoldWalk's reversibility test (mut_manifold.cpp:1219)."""
+        lib().gpo_scene_bsphere_radius.restype = C.c_double
+        lib().gpo_scene_bsphere_radius.argtypes = [C.c_void_p]
+        return float(lib().gpo_scene_bsphere_radius(self._h))
+
     def gbdpt_render(self, cfg, rect=None):
         """-> (block[5,H,W,4] camera blocks (rgb, weight), light[5,H,W,3] light images, dict of counters)."""
         x0, y0, x1, y1 = rect if rect else (0, 0, self.W, self.H)

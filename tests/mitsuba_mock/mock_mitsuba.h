@@ -166,7 +166,9 @@ private:
 };
 class Film : public ConfigurableObject {
 public:
+    const Vector2i &getSize() const { return m_size; }                                                           // film.h:35-42
     const Vector2i &getCropSize() const { return m_size; }
+    const Point2i &getCropOffset() const { return m_cropOffset; }
     const ReconstructionFilter *getReconstructionFilter() const { return &m_rf; }
     virtual void clear() {}
     virtual bool setBuffers(std::vector<std::string> &) { return true; }                                          // film.h:62-79: the five multi-buffer virtuals
@@ -176,7 +178,7 @@ public:
     virtual void putMulti(const ImageBlock *, int) {}
     const Class *getClass() const { static Class c("MultiFilm"); return &c; }
 private:
-    Vector2i m_size; ReconstructionFilter m_rf;
+    Vector2i m_size; Point2i m_cropOffset; ReconstructionFilter m_rf;
 };
 class Sampler : public ConfigurableObject { public: size_t getSampleCount() const { return 4; } const Class *getClass() const { static Class c("IndependentSampler"); return &c; } };
 class Sensor : public ConfigurableObject {

@@ -170,11 +170,36 @@ def test_reconstruction_filters_match_oracle(G, kind):
         Fs = G.Film(S, y0, y1)
         integ.renderBlock(S, Fs, integ.config(spp), (0, y0, W, y1))
         parts.append(Fs.accum())
-        with pytest.raises(GdptError, match="whole film"):
-            integ.renderBlock(S, Fs, integ.config(spp), (0, y0, W // 2, y1))
         Fs.close()
     assert np.array_equal(np.concatenate(parts, axis=1), acc)
-    F.close(); S.close()
+    # blocks (round 5): a sub-rectangle renders the samples of ITS pixels and puts them within the filter's reach around it, as GPTBlockRenderer's unit
+    # does into GPTWorkResult's bordered blocks (gpt_proc.cpp:52-56,74-91; gpt_wr.cpp:31-44) -- four ragged tiles into one film add up to the one-call
+    # film (the sums of a pixel arrive tile by tile: their order, hence the last bits, differ), same rays; so do tiles rendered into films of their
+    # own, copied back with their border (gdpt_film_accum_rect) and merged by addition as MultiFilm::putMulti merges them (gpt_proc.cpp:137-149)
+    Ft = G.Film(S)
+    tiles = [(0, 0, 17, 11), (17, 0, W, 11), (0, 11, 17, H), (17, 11, W, H)]
+    for t in tiles:
+        integ.renderBlock(S, Ft, integ.config(spp), t)
+    acct = Ft.accum(); stt = Ft.stats()
+    assert stt == st
+    for b in range(5):
+        assert np.abs(acct[b] - acc[b]).max() <= 1e-12 * np.abs(acc[b]).max(), (kind, "tiles", G.BUFFER_NAMES[b])
+    reach = 4                                                 # ceil(radius) + 1 of the widest of the five (lanczos, 3 lobes); the others reach less
+    merged = np.zeros_like(acc)
+    for (x0, y0, x1, y1) in tiles:
+        fy0, fy1 = max(0, y0 - reach), min(H, y1 + reach)
+        Fb = G.Film(S, fy0, fy1)
+        integ.renderBlock(S, Fb, integ.config(spp), (x0, y0, x1, y1))
+        bx0, bx1 = max(0, x0 - reach), min(W, x1 + reach)
+        part = Fb.accum_rect(bx0, fy0, bx1, fy1)
+        assert np.array_equal(part, Fb.accum()[:, :, bx0:bx1])
+        outside = Fb.accum().copy(); outside[:, :, bx0:bx1] = 0
+        assert not outside.any()                              # nothing lands beyond the reach
+        merged[:, fy0:fy1, bx0:bx1] += part
+        Fb.close()
+    for b in range(5):
+        assert np.abs(merged[b] - acc[b]).max() <= 1e-12 * np.abs(acc[b]).max(), (kind, "blocks", G.BUFFER_NAMES[b])
+    Ft.close(); F.close(); S.close()
 
 
 def test_filter_strips_over_several_log_chunks(G):
