@@ -287,7 +287,7 @@ def bench_gbdpt(a, rank, local, world, dev):
         tracer_bytes = tracer_bytes_block(scene, desc, rays / launch_s / a.steps, closest / float(max(1, sr.last["rays"] * a.steps)) if world == 1 else 0.5)
         counters, counters_file = _profiled_counters("_counters_gbdpt.json")
         issue = None
-        bd = {k: v for k, v in counters.items() if "gdpt_bdk::k_bd_" in k and "SQ_INSTS_VALU" in v}
+        bd = {k: v for k, v in counters.items() if "gdpt_bdk::k_bd" in k and "SQ_INSTS_VALU" in v}         # k_bd_* (every vertex connectable) and k_bdg_* (the general form)
         put = next((v for k, v in bd.items() if "k_bd_put" in k), None)
         if bd and put and put.get("grid_x") and world == 1:
             # k_bd_put runs once per chunk with one thread per sample: its launches x grid = the samples of the profiled run
@@ -298,7 +298,7 @@ def bench_gbdpt(a, rank, local, world, dev):
             issue = {"bound": "valu-issue", "achieved": round(ach / 1e9, 1), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instr/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
                      "traffic": round((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / prof_samples * samples / a.steps),
                      "traffic_what": "FETCH_SIZE x 2 + WRITE_SIZE of the sampler's kernels per sample of the profiled run x this run's samples per step, bytes",
-                     "kernel": "k_bd_paths + k_bd_shift + k_bd_connect<*> + k_bd_put", "launch_ms_live": round(1e3 * launch_s, 3),
+                     "kernel": "k_bd_paths + k_bd_shift + k_bd_connect<*> + k_bdg_shift + k_bdg_offset + k_bdg_connect<*> + k_bdg_light<*> + k_bd_put", "launch_ms_live": round(1e3 * launch_s, 3),
                      "valu_wave_instr_per_sample": round(per_sample, 1), "profiled_samples": prof_samples,
                      "lane_utilisation": round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if tot["SQ_ACTIVE_INST_VALU"] else None,
                      "wait_any_frac_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4) if tot["SQ_WAVE_CYCLES"] else None,

@@ -10,10 +10,12 @@ CSRC = os.path.join(PKG, "csrc")
 INC = [os.path.join(ROOT, "include", f) for f in ("gdpt_poisson.h", "gdpt_tracer.h")]
 # translation units of the library and what each is made of: one object per unit, rebuilt only when its own sources changed
 # (the tracer unit is 4 of the 4.5 minutes of hipcc)
+# GDPT_WITH_WAVEFRONT=1: a development build that carries the wavefront continuation (gdpt_film_set_pipeline(3), gpt_wave_capi.hip: built, bit-identical to
+# the staged pipeline, measured slower -- DESIGN.md); the product library and the GPU suite do not pay for it.
+WITH_WAVEFRONT = os.environ.get("GDPT_WITH_WAVEFRONT", "") not in ("", "0")
 UNITS = {
     "poisson_capi.hip": ["poisson_kernels.hip.h", "poisson_persistent.hip.h"],
-    "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_shift5.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h", "gpt_serial.hip.h"],
-    "gpt_wave_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"],
+    "gpt_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h", "gpt_serial.hip.h"],
     "gpt_serial_capi.hip": ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_serial.hip.h"],
     "gbdpt_capi.hip": ["gpt_kernels.hip.h", "gbdpt_kernels.hip.h", "gbdpt_general.hip.h", "gpt_scene.hip.h"],
     "device_capi.hip": [],
@@ -24,10 +26,12 @@ UNITS = {
 # k_bd_general (the general form of a G-BDPT sample, ~1 000 lines of callees) came out at 256 + 118 registers = ONE wave per SIMD; inlined it is 256 + 0 and two waves:
 # 400 -> 342 ms per 568 k general samples (round 4).  The unit takes 5 minutes instead of 40 s (beside gpt_capi.hip's 7).
 UNIT_FLAGS = {"gbdpt_capi.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-mllvm", "-amdgpu-function-calls=0"]}
+if WITH_WAVEFRONT:
+    UNITS["gpt_wave_capi.hip"] = ["gpt_kernels.hip.h", "gpt_render.hip.h", "gpt_scene.hip.h", "gpt_wavefront.hip.h"]
 SOURCES = [os.path.join(CSRC, f) for f in UNITS]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", os.environ.get("GDPT_OPT", "-O3"), "-std=c++17", "-ffp-contract=off", "-fPIC",
-         "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
+         "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")] + (["-DGDPT_WITH_WAVEFRONT"] if WITH_WAVEFRONT else [])
 
 
 STAMP = LIB + ".flags"          # the flags the library was built with: a development build (GDPT_EXTRA_FLAGS) never passes for the product
@@ -99,7 +103,7 @@ def build(force=False, verbose=False):
 # miscompiles met so far were -O3-only (tools/repro/README.md); films and ray counts of the -O3 product are held against this build on the GPU.
 FENCE_OPT = "-O1"
 FENCE_LIB = os.path.join(PKG, "lib", "libgdpt_hip_O1.so")
-FENCE_UNITS = ("gpt_capi.hip", "gpt_wave_capi.hip", "gbdpt_capi.hip")
+FENCE_UNITS = ("gpt_capi.hip", "gbdpt_capi.hip") + (("gpt_wave_capi.hip",) if WITH_WAVEFRONT else ())
 
 
 def _fence_obj(unit):

@@ -236,35 +236,42 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
 }
 
-// The general form of a sample (specular chains; gbdpt_general.hip.h) in three launches per pass over <= gsCap listed samples (round 5; round 4 ran a
+// The general form of a sample (specular chains; gbdpt_general.hip.h) in staged launches per pass over <= gsCap listed samples (round 5; round 4 ran a
 // sample from its connected base path to its last connection in ONE lane with a 56 KB workspace: 80 % of a config-5 frame at 10 % lane utilisation):
-//   k_bdg_shift    one lane per sample (persistent lanes, a manifold scratch each): the connected base path, its four offset paths with their walks,
-//                  Jacobians and generalized geometry terms, the prefix products -> the sample's GSamp record, read-only from here on; appends the
-//                  sample's connections to two item lists;
-//   k_bdg_connect  one lane per connection (s, t >= 2), ~25 per sample: reads the sample's record (lanes of a wave mostly share one), keeps its MIS arrays
-//                  private, allocates nothing; adds to the sample's 15 sums;
+//   k_bdg_shift    one lane per sample (persistent lanes, a manifold scratch each): the connected base path, its generalized geometry terms, the prefix
+//                  products, the flag masks -> the sample's GSamp record; appends the sample's connections and its four offset paths to item lists;
+//   k_bdg_offset   one lane per (sample, offset path), twice: the offset paths that enter a manifold walk and those that do not -- perturbation,
+//                  propagation, walk, re-connection, Jacobians, generalized geometry terms, prefix products -> the record, read-only from here on;
+//   k_bdg_connect  one lane per connection (s, t >= 2), ~25 per sample: reads the sample's record (lanes of a wave mostly share one), forms its MIS sums
+//                  as recurrences over it, allocates nothing; adds to the sample's 15 sums;
 //   k_bdg_light    one lane per light-tracing connection (s, 1): the only ones that build paths of their own (clones + four offset paths with manifold
 //                  walks) -- in the lane's transient pool (persistent lanes); splats into the light images.
 constexpr int GD_ITEMS = BD_ITEMS_PER_SAMPLE, GD_LIGHT = 16;       // connection items (t >= 2) / light items (<= NEV) per general sample
+// gCount (16 counters of a pass): [0] connection items, [1] light items, [2] k_bdg_shift's cursor, [3] k_bdg_light<1>'s, [4] survivors of connection phase 3,
+// [5] of phase 1, [6] surviving light items, [7] k_bdg_light<2>'s cursor, [8] [9] offset-path items without / with a manifold walk, [10] [11] their cursors.
 __global__ __launch_bounds__(TBLK, 2) void k_bdg_shift(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, unsigned first, unsigned count,
-                                                    GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, unsigned *__restrict__ gItems, unsigned *__restrict__ gLight,
-                                                    unsigned *__restrict__ gCount, unsigned long long *__restrict__ stats)
+                                                    GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, unsigned *__restrict__ gItems, unsigned *__restrict__ gLight, unsigned *__restrict__ gOff,
+                                                    size_t offStride, unsigned *__restrict__ gCount, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned lane = blockIdx.x * TBLK + threadIdx.x;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
     unsigned overflow = 0, done = 0;
-    // (samples differ by an order of magnitude in work -- chain lengths, manifold walks: a lane takes the next sample of the pass when it is done)
     for (unsigned i = atomicAdd(gCount + 2, 1u); i < count; i = atomicAdd(gCount + 2, 1u)) {
         const unsigned lid = genList[first + i];
         GSamp &W = gsamp[i];
-        GTr g(c, W, &scratch[lane], nullptr);
+        GTr g(c, W, &scratch[lane]);
         g.loadSubpaths(recs[lid]);
-        g.prepare();
+        g.prepareBase();
         W.lid = lid;
         done++;
-        if (g.overflow) { overflow += g.overflow; continue; }                                // (a pool ran out: the sample is void -- no connections, counted; asserted zero by tests and bench)
+        if (g.overflow) { overflow += g.overflow; W.voidSample = 1; continue; }              // (a pool ran out: the sample is void -- no connections, counted; asserted zero by tests and bench)
+        if (g.hasOffsets()) {                                                              // its four offset paths: one lane each (k_bdg_offset), lists by "enters a manifold walk"
+            const int q = g.offsetsWalk() ? 1 : 0;
+            const unsigned at = atomicAdd(gCount + 8 + q, 4u);
+            for (unsigned k = 0; k < 4; k++) gOff[(size_t)q * offStride + at + k] = (i << 2) | k;
+        }
         unsigned nC = 0, nL = 0;
         for (int s = W.emitter.nv - 1; s >= 0; --s) {
             int minT, maxT;
@@ -292,47 +299,100 @@ __global__ __launch_bounds__(TBLK, 2) void k_bdg_shift(SceneD S, BdCam cam, BdCo
     }
 }
 
-__global__ __launch_bounds__(TBLK, 2) void k_bdg_connect(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, const unsigned *__restrict__ gItems, const unsigned *__restrict__ gCount,
-                                                      Float *__restrict__ acc, unsigned long long *__restrict__ stats)
-{
-    __shared__ int s_stack[STACK_DEPTH * TBLK];
-    Ctx c;
-    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
-    const unsigned n = __hip_atomic_load(gCount + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    GMis mis;
-    for (unsigned i = blockIdx.x * TBLK + threadIdx.x; i < n; i += gridDim.x * TBLK) {
-        const unsigned it = gItems[i];
-        GSamp &W = gsamp[it >> 10];
-        GTrT<false> g(c, W, nullptr, &mis);
-        PairOut po;
-        if (!g.connectPair<false>((int)((it >> 5) & 31u), (int)(it & 31u), po)) continue;
-        Float *a = acc + (size_t)W.lid * 15;
-        atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z);
-        for (int k = 0; k < 4; k++) { atomicAdd(a + 3 + 3 * k, po.gradient[k].x); atomicAdd(a + 4 + 3 * k, po.gradient[k].y); atomicAdd(a + 5 + 3 * k, po.gradient[k].z); }
-    }
-    const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1); }
-}
-
-__global__ __launch_bounds__(TBLK, 2) void k_bdg_light(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, const unsigned *__restrict__ gLight,
-                                                    unsigned *__restrict__ gCount, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+// One lane per (sample, offset path): ManifoldPerturbation::generateOffsetPathGBDPT, the path's half-Jacobians and generalized geometry terms, its prefix
+// products (GTr::prepareOffset) -- into the sample's record, each lane its own slots and its own slice of the pool.  Two launches: the offset paths whose
+// chain b..c holds specular vertices (a manifold walk, <= 2 x 20 Newton steps with re-traced chains) and the others, so that a wave runs one of the two.
+__global__ __launch_bounds__(TBLK, 2) void k_bdg_offset(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, const unsigned *__restrict__ in,
+                                                     const unsigned *__restrict__ nIn, unsigned *__restrict__ cursor, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned lane = blockIdx.x * TBLK + threadIdx.x;
     Ctx c;
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
-    const unsigned n = __hip_atomic_load(gCount + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned n = __hip_atomic_load(nIn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned overflow = 0;
+    // (a wave takes 64 consecutive items = the four offset paths of 16 samples: the lanes of a sample share its base path)
+    for (unsigned base = 0; ; ) {
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, 64u);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const unsigned i = base + (threadIdx.x & 63);
+        if (i < n) {
+            const unsigned it = in[i];
+            GSamp &W = gsamp[it >> 2];
+            GTr g(c, W, &scratch[lane]);
+            g.setRegion((int)(it & 3u));
+            g.prepareOffset((int)(it & 3u));
+            if (g.overflow) { overflow += g.overflow; W.voidSample = 1; }
+        }
+    }
+    const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1);
+        if (r3) atomicAdd(stats + 5, (unsigned long long)r3);
+    }
+}
+
+// Three launches, each over the survivors of the one before (lists compacted with one atomic per wave), as k_bd_connect's: PHASE 3 the ray-free part of
+// the base path, PHASE 1 the base path (visibility, MIS weight; adds the primal term), PHASE 2 the four offsets (the gradient terms).
+template <int PHASE>
+__global__ __launch_bounds__(TBLK, 2) void k_bdg_connect(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, const unsigned *__restrict__ in, const unsigned *__restrict__ nIn,
+                                                      unsigned *__restrict__ out, unsigned *__restrict__ nOut, Float *__restrict__ acc, unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned n = __hip_atomic_load(nIn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned i = blockIdx.x * TBLK + threadIdx.x; i < n; i += gridDim.x * TBLK) {
+        const unsigned it = in[i];
+        GSamp &W = gsamp[it >> 10];
+        GTrT<false> g(c, W, nullptr);
+        PairOut po;
+        const bool keep = !W.voidSample && g.connectPair<false, PHASE>((int)((it >> 5) & 31u), (int)(it & 31u), po);
+        if (keep && PHASE != 3) {
+            Float *a = acc + (size_t)W.lid * 15;
+            if (PHASE == 1) { atomicAdd(a + 0, po.primal.x); atomicAdd(a + 1, po.primal.y); atomicAdd(a + 2, po.primal.z); }
+            else for (int k = 0; k < 4; k++) { atomicAdd(a + 3 + 3 * k, po.gradient[k].x); atomicAdd(a + 4 + 3 * k, po.gradient[k].y); atomicAdd(a + 5 + 3 * k, po.gradient[k].z); }
+        }
+        if (PHASE != 2) {
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+                const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(nOut, (unsigned)__popcll(mask));
+                base = __shfl(base, leader);
+                if (keep) out[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = it;
+            }
+        }
+    }
+    const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1); }
+}
+
+// PHASE 1: the base path of every light-tracing connection (its own shiftable path: clones, the sensor connection's visibility ray, MIS weight); splats the
+// primal term, lists the connections that carry anything ([6] of gCount).  PHASE 2: their four offset paths (perturbed sensor direction, propagation, manifold
+// walk, re-connection), the base path built again for what they share with it (its rays not counted twice); splats the gradient terms.
+template <int PHASE>
+__global__ __launch_bounds__(TBLK, 2) void k_bdg_light(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, const unsigned *__restrict__ in, const unsigned *__restrict__ nIn,
+                                                    unsigned *__restrict__ cursor, unsigned *__restrict__ out, unsigned *__restrict__ nOut, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    const unsigned lane = blockIdx.x * TBLK + threadIdx.x;
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned n = __hip_atomic_load(nIn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int Wd = S.cam.width, H = S.cam.height;
     const size_t plane3 = (size_t)Wd * H * 3;
     unsigned overflow = 0;
-    GMis mis;
-    for (unsigned i = atomicAdd(gCount + 3, 1u); i < n; i = atomicAdd(gCount + 3, 1u)) {
-        const unsigned it = gLight[i];
-        GTr g(c, gsamp[it >> 10], &scratch[lane], &mis);
+    for (unsigned i = atomicAdd(cursor, 1u); i < n; i = atomicAdd(cursor, 1u)) {
+        const unsigned it = in[i];
+        GTr g(c, gsamp[it >> 10], &scratch[lane]);
         PairOut po;
-        const bool ok = g.connectPair<true>((int)((it >> 5) & 31u), 1, po);
+        if (gsamp[it >> 10].voidSample) continue;
+        const bool ok = g.connectPair<true, PHASE>((int)((it >> 5) & 31u), 1, po);
         if (g.overflow) { overflow += g.overflow; continue; }
         if (!ok) continue;
+        if (PHASE == 1) out[atomicAdd(nOut, 1u)] = it;
         for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, Wd, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
     }
     const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
@@ -426,7 +486,7 @@ struct gdpt_gbdpt_film {
     unsigned *genList = nullptr, *genCount = nullptr;
     GSamp *gsamp = nullptr;
     GScratch *gscratch = nullptr;
-    unsigned *gItems = nullptr, *gLight = nullptr, *gCount = nullptr;
+    unsigned *gItems = nullptr, *gLight = nullptr, *gOff = nullptr, *gCount = nullptr;
     unsigned gsCap = 0, gLanes = 0;
     double sceneRadius = 0.0;
 };
@@ -490,7 +550,7 @@ int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
     BHIPCHK(hipMalloc((void **)&f->light, sizeof(Float) * 5 * npix * 3));
     BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 8));           // [0..3] the public counters; [4] samples run in the general form, [5] workspace overflows
     BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned) * 2));               // entries of the general list
-    BHIPCHK(hipMalloc((void **)&f->gCount, sizeof(unsigned) * 4));                 // of a pass: connection items, light items, k_bdg_shift's cursor, k_bdg_light's cursor
+    BHIPCHK(hipMalloc((void **)&f->gCount, sizeof(unsigned) * 16));                // the counters and cursors of a pass (k_bdg_shift)
     f->sceneRadius = s->bsphereRadius;              // m_scene->getBSphere().radius (gpt_capi.hip: kd-tree bounds + sensor + emitters, scene.cpp:386-413)
     BHIPCHK(hipStreamCreate(&f->stream));
     BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1));
@@ -505,7 +565,7 @@ void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
     if (f->stream) hipStreamSynchronize(f->stream);
     hipFree(f->block); hipFree(f->light); hipFree(f->stats);
     hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
-    hipFree(f->genList); hipFree(f->genCount); hipFree(f->gsamp); hipFree(f->gscratch); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gCount);
+    hipFree(f->genList); hipFree(f->genCount); hipFree(f->gsamp); hipFree(f->gscratch); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff); hipFree(f->gCount);
     if (f->e0) hipEventDestroy(f->e0);
     if (f->e1) hipEventDestroy(f->e1);
     if (f->stream) hipStreamDestroy(f->stream);
@@ -550,14 +610,15 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 4);
         unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 4 * lanes;
         if (const char *e = getenv("GDPT_BD_GENERAL_PASS")) cap = (unsigned)std::max<long long>(1, atoll(e));      // (tests of the pass loop)
-        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (GD_ITEMS + GD_LIGHT);
+        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 2 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
         for (;;) {
             while ((size_t)lanes * sizeof(GScratch) + (size_t)cap * perSampleG > budget && (lanes > TBLK || cap > TBLK)) { if (cap > lanes) cap /= 2; else lanes = std::max<unsigned>(TBLK, lanes / 2 / TBLK * TBLK); }
             if (hipMalloc((void **)&f->gscratch, sizeof(GScratch) * (size_t)lanes) == hipSuccess && hipMalloc((void **)&f->gsamp, sizeof(GSamp) * (size_t)cap) == hipSuccess &&
-                hipMalloc((void **)&f->gItems, sizeof(unsigned) * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * GD_LIGHT * (size_t)cap) == hipSuccess) break;
+                hipMalloc((void **)&f->gItems, sizeof(unsigned) * 3 * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * 2 * GD_LIGHT * (size_t)cap) == hipSuccess &&
+                hipMalloc((void **)&f->gOff, sizeof(unsigned) * 8 * (size_t)cap) == hipSuccess) break;
             (void)hipGetLastError();
-            hipFree(f->gscratch); hipFree(f->gsamp); hipFree(f->gItems); hipFree(f->gLight);
-            f->gscratch = nullptr; f->gsamp = nullptr; f->gItems = nullptr; f->gLight = nullptr;
+            hipFree(f->gscratch); hipFree(f->gsamp); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff);
+            f->gscratch = nullptr; f->gsamp = nullptr; f->gItems = nullptr; f->gLight = nullptr; f->gOff = nullptr;
             if (budget <= ((size_t)64 << 20)) return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT general-form records: %.1f MB)", ((double)lanes * sizeof(GScratch) + (double)cap * perSampleG) / 1e6);
             budget /= 2;
         }
@@ -606,12 +667,22 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         if (nGen && !f->gsamp) return bfail(GDPT_ERR_HIP, "G-BDPT: a sample needs the general form in a scene without a specular material");
         for (unsigned gFirst = 0; gFirst < nGen; gFirst += f->gsCap) {                     // the general form, a pass of <= gsCap samples at a time
             const unsigned gN = std::min(f->gsCap, nGen - gFirst);
-            BHIPCHK(hipMemsetAsync(f->gCount, 0, sizeof(unsigned) * 4, f->stream));
+            BHIPCHK(hipMemsetAsync(f->gCount, 0, sizeof(unsigned) * 16, f->stream));
             const unsigned lgrid = std::min((gN + TBLK - 1) / TBLK, f->gLanes / TBLK);
-            hipLaunchKernelGGL(k_bdg_shift, dim3(lgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->genList, gFirst, gN, f->gsamp, f->gscratch, f->gItems, f->gLight, f->gCount, f->stats);
+            const size_t offStride = (size_t)4 * f->gsCap;
+            hipLaunchKernelGGL(k_bdg_shift, dim3(lgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->genList, gFirst, gN, f->gsamp, f->gscratch, f->gItems, f->gLight, f->gOff, offStride, f->gCount, f->stats);
+            const dim3 ogrid((unsigned)std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK));
+            for (int q = 0; q < 2; q++)
+                hipLaunchKernelGGL(k_bdg_offset, ogrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)(f->gOff + q * offStride), (const unsigned *)(f->gCount + 8 + q), f->gCount + 10 + q, f->stats);
             const unsigned cgridG = (unsigned)std::min<size_t>(((size_t)gN * 24 + TBLK - 1) / TBLK, (size_t)s->numCUs * 16);   // (grid-stride over the list, whose length only the device knows)
-            hipLaunchKernelGGL(k_bdg_connect, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gItems, f->gCount, f->acc, f->stats);
-            hipLaunchKernelGGL(k_bdg_light, dim3(std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK)), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, f->gLight, f->gCount, f->light, f->stats);
+            unsigned *listA = f->gItems + (size_t)GD_ITEMS * f->gsCap, *listB = listA + (size_t)GD_ITEMS * f->gsCap;
+            hipLaunchKernelGGL(k_bdg_connect<3>, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, (const unsigned *)f->gItems, (const unsigned *)(f->gCount + 0), listA, f->gCount + 4, f->acc, f->stats);
+            hipLaunchKernelGGL(k_bdg_connect<1>, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, (const unsigned *)listA, (const unsigned *)(f->gCount + 4), listB, f->gCount + 5, f->acc, f->stats);
+            hipLaunchKernelGGL(k_bdg_connect<2>, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, (const unsigned *)listB, (const unsigned *)(f->gCount + 5), (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->stats);
+            const dim3 lgridL((unsigned)std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK));
+            unsigned *lightB = f->gLight + (size_t)GD_LIGHT * f->gsCap;
+            hipLaunchKernelGGL(k_bdg_light<1>, lgridL, dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)f->gLight, (const unsigned *)(f->gCount + 1), f->gCount + 3, lightB, f->gCount + 6, f->light, f->stats);
+            hipLaunchKernelGGL(k_bdg_light<2>, lgridL, dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightB, (const unsigned *)(f->gCount + 6), f->gCount + 7, (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
             BHIPCHK(hipGetLastError());
         }
         for (int q = 0; q < 3; q++) {

@@ -28,6 +28,7 @@ namespace gdpt_bd {
 
 constexpr int GP_LEN = 32;                         // vertices of a path (the connected path: <= NEV + NSV)
 constexpr int GV_POOL = 144, GE_POOL = 144;        // vertex / edge records of one sample: both subpaths (<= 27), the clones of createShiftablePath (2), four offset paths (<= 28 each: 15 new + 13 re-cloned after a failed walk)
+constexpr int GV_REGION = 28;                      // records of ONE offset path: <= 15 new + 13 re-cloned after a failed walk (GV_POOL >= 29 + 4 x 28)
 constexpr int GM_MAX = 16;                         // vertices of a specular manifold: a path has at most BD_MAX_DEPTH + 3 = 15 vertices, so no chain is ever too long for it
                                                    // (12 until the fuzz of round 4: a 9-vertex chain between two long subpaths left both half-Jacobians 0 and their ratio NaN)
 
@@ -89,11 +90,12 @@ struct MuRec { int l, m; int extra[5]; };
 //             the paths as index lists, the per-offset Jacobians and generalized geometry terms, the prefix products -- what every connection reads;
 //   GScratch  what a LANE needs while it runs manifold code or builds a light path: the manifold's two vertex lists, the dense system, a small
 //             transient pool (indices >= GV_POOL) -- only the shift stage and the light-tracing connections have one (persistent lanes);
-//   GMis      the strategy densities of one connection: private to a lane (registers / scratch of the connection kernels).
 constexpr int GL_POOL = 48;                        // transient records of ONE light-tracing connection: two clones + one offset path at a time (<= 15 new + 13 re-cloned vertices)
 struct GSamp {
     BV v[GV_POOL]; BE e[GE_POOL];
     int nv, ne;
+    int nvBase, neBase;                            // records in use after the base stage (both subpaths + the clones of createShiftablePath): offset path k takes [nvBase + 28 k, + 28)
+    int voidSample;                                // a pool ran out while the sample's paths were built: its connections are skipped (counted; asserted zero by tests and bench)
     GPath emitter, sensor[5], connect;
     MuRec mu[5];
     int success[5], couldConnectAfterB[5];
@@ -101,6 +103,7 @@ struct GSamp {
     d3 impW[NEV + 1]; Float impP[NEV + 1];
     d3 radW[5][NSV + 1]; Float radP[5][NSV + 1];
     int vert_b;                                    // connectPath.vertexCount() - 1 - muRec.extra[1]: the sensor-side index of b
+    unsigned connE, strictE, connS, strictS;       // bit i: vertex i of the emitter subpath / of sensor[0] is connectable in the sense of Path::isConnectable_GBDPT / of PathVertex::isConnectable
     unsigned lid;                                  // the sample's record in the chunk
 };
 struct GScratch {
@@ -111,11 +114,7 @@ struct GScratch {
     int nlv, nle;
     GPath offsetEmitter, connectedBase;
 };
-struct GMis {
-    Float pdfImp[GP_LEN + 2], pdfRad[GP_LEN + 2], oPdfImp[GP_LEN + 2], oPdfRad[GP_LEN + 2];
-    char connectable[GP_LEN + 2], connectableStrict[GP_LEN + 2];
-};
-struct GWork { GSamp s; GScratch x; GMis m; };    // all three for one lane: the probe entry (one sample, start to end, in one lane)
+struct GWork { GSamp s; GScratch x; };            // both for one lane: the probe entry (one sample, start to end, in one lane)
 
 // its.dpdu / its.dpdv of a triangle hit (skdtree.h:373-380, trimesh.cpp:683-735): the edges, or the UV tangents of a mesh with texture coordinates
 __device__ void tri_partials(const Ctx &c, int prim, d3 &dpdu, d3 &dpdv)
@@ -146,21 +145,25 @@ struct GTrT {
     Ctx &c;
     GSamp &W;
     GScratch *X;                                   // nullptr in the connection kernel for t >= 2: nothing there allocates or touches a manifold
-    GMis *M;
     bool localAlloc = false;                       // allocations go to the lane's transient pool (a light-tracing connection), not to the sample's
     unsigned overflow = 0;                         // a pool or a list ran out (the sample's result is then void: counted, asserted zero by the tests)
-    __device__ GTrT(Ctx &c_, GSamp &w_, GScratch *x_, GMis *m_) : c(c_), W(w_), X(x_), M(m_) {}
-    __device__ GTrT(Ctx &c_, GWork &w_) : c(c_), W(w_.s), X(&w_.x), M(&w_.m) {}
+    __device__ GTrT(Ctx &c_, GSamp &w_, GScratch *x_) : c(c_), W(w_), X(x_) {}
+    __device__ GTrT(Ctx &c_, GWork &w_) : c(c_), W(w_.s), X(&w_.x) {}
 
     // ---- pool: indices < GV_POOL are the sample's records, the others the lane's transient ones ----
+    // (region: the lane builds ONE offset path of a sample while other lanes build the others -- each in its own slice of the sample's pool)
+    int regV = -1, regV1 = 0, regE = 0, regE1 = 0;
+    __device__ void setRegion(int k) { regV = W.nvBase + k * GV_REGION; regV1 = regV + GV_REGION; regE = W.neBase + k * GV_REGION; regE1 = regE + GV_REGION; }
     __device__ int allocV()
     {
         if (HAS_X && localAlloc) { if (X->nlv >= GL_POOL) { overflow++; return GV_POOL + GL_POOL - 1; } bv_clear(X->lv[X->nlv]); return GV_POOL + X->nlv++; }
+        if (regV >= 0) { if (regV >= regV1 || regV >= GV_POOL) { overflow++; return GV_POOL - 1; } bv_clear(W.v[regV]); return regV++; }
         if (W.nv >= GV_POOL) { overflow++; return GV_POOL - 1; } bv_clear(W.v[W.nv]); return W.nv++;
     }
     __device__ int allocE()
     {
         if (HAS_X && localAlloc) { if (X->nle >= GL_POOL) { overflow++; return GE_POOL + GL_POOL - 1; } be_clear(X->le[X->nle]); return GE_POOL + X->nle++; }
+        if (regV >= 0) { if (regE >= regE1 || regE >= GE_POOL) { overflow++; return GE_POOL - 1; } be_clear(W.e[regE]); return regE++; }
         if (W.ne >= GE_POOL) { overflow++; return GE_POOL - 1; } be_clear(W.e[W.ne]); return W.ne++;
     }
     __device__ __forceinline__ BV &PV(int i) { if (!HAS_X) return W.v[i]; return i < GV_POOL ? W.v[i] : X->lv[i - GV_POOL]; }
@@ -830,101 +833,121 @@ struct GTrT {
     }
 
     // ---- MIS weights, path.cpp:49-378 ----
+    // The reference fills pdfImp / pdfRad[0..k] per path (Path::miWeight*NoSweep_GBDPT: collect, :99-132,264-307; convert the area densities next
+    // to a non-connectable vertex to projected solid angle, :143-167,309-349) and forms every strategy's density by an O(k) product: O(k^2) per
+    // weight, five paths per connection, the base path's arrays rebuilt for each of the four gradient weights.  Round 4 kept those arrays in the
+    // lane's workspace.  Here (round 5), as in the fast form (gbdpt_kernels.hip.h, mis_sums): both weights are ratios of SUMS of strategy densities
+    //     value[p] = pdfImp[1] .. pdfImp[p] * pdfRad[p + 1] .. pdfRad[k - 1],
+    // and such a sum is a Horner recurrence over the entries in reverse order, R(p) = pdfRad[p + 1] R(p + 1), G(p) = a_p R(p) + pdfImp[p + 1] G(p + 1)
+    // (a_p = 1 for an allowed strategy; squared entries for the power heuristic).  An entry is read from the sample's record when the recurrence
+    // reaches it, with its conversion factor where the path has a specular vertex next to it; the connectable flags of the base path are two bit
+    // masks per subpath made once per sample (GSamp::flags); the base path's sums are formed ONCE per connection and serve the four gradient
+    // weights (sum_p (b_p gX + j gY o_p) = gX sum_p b_p + j gY sum_p o_p).  Same factors, another association: a few ulp.
+    struct GConn { Float impS, impT, radS, radT; };       // pdfImp[s + 1], pdfImp[s + 2], pdfRad[s - 1], pdfRad[s]: the four densities evaluated AT the connection
+    struct GMisBase { Float valueS, sum1, sum2; unsigned allowed, strict; GConn cp; };
     // (ovT: the sensor-side end point as the emitter sample a connection to the emitter supernode casts it to -- a lane-local copy, see connectPair)
-    __device__ void collectPdfs(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, Float *pdfImp, Float *pdfRad, const BV *ovT)
+    __device__ GConn connPdfs(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, const BV *ovT)
     {
-        const int k = s + t + 1, n = k + 1;
         const BV *vsPred = VN(emitterSubpath, s - 1), *vtPred = VN(sensorSubpath, t - 1); const BV &vs = V_(emitterSubpath, s), &vt = ovT ? *ovT : V_(sensorSubpath, t);
-        for (int i = 0; i < n; i++) { pdfImp[i] = 0.0; pdfRad[i] = 0.0; }
-        int pos = 0;
-        pdfImp[pos++] = 1.0;
-        for (int i = 0; i < s; ++i) pdfImp[pos++] = V_(emitterSubpath, i).pdf[EImportance] * E_(emitterSubpath, i).tr[EImportance];
-        pdfImp[pos++] = bv_eval_pdf(c, vs, vsPred, &vt, EImportance, M_AREA) * connectionEdge.tr[EImportance];
-        if (t > 0) {
-            pdfImp[pos++] = bv_eval_pdf(c, vt, &vs, vtPred, EImportance, M_AREA) * E_(sensorSubpath, t - 1).tr[EImportance];
-            for (int i = t - 1; i > 0; --i) pdfImp[pos++] = V_(sensorSubpath, i).pdf[EImportance] * E_(sensorSubpath, i - 1).tr[EImportance];
-        }
-        pos = 0;
-        if (s > 0) {
-            for (int i = 0; i < s - 1; ++i) pdfRad[pos++] = V_(emitterSubpath, i + 1).pdf[ERadiance] * E_(emitterSubpath, i).tr[ERadiance];
-            pdfRad[pos++] = bv_eval_pdf(c, vs, &vt, vsPred, ERadiance, M_AREA) * E_(emitterSubpath, s - 1).tr[ERadiance];
-        }
-        pdfRad[pos++] = bv_eval_pdf(c, vt, vtPred, &vs, ERadiance, M_AREA) * connectionEdge.tr[ERadiance];
-        for (int i = t; i > 0; --i) pdfRad[pos++] = V_(sensorSubpath, i - 1).pdf[ERadiance] * E_(sensorSubpath, i - 1).tr[ERadiance];
-        pdfRad[pos++] = 1.0;
+        GConn cp;
+        cp.impS = bv_eval_pdf(c, vs, vsPred, &vt, EImportance, M_AREA) * connectionEdge.tr[EImportance];
+        cp.impT = t > 0 ? bv_eval_pdf(c, vt, &vs, vtPred, EImportance, M_AREA) * E_(sensorSubpath, t - 1).tr[EImportance] : 0.0;
+        cp.radS = s > 0 ? bv_eval_pdf(c, vs, &vt, vsPred, ERadiance, M_AREA) * E_(emitterSubpath, s - 1).tr[ERadiance] : 0.0;
+        cp.radT = bv_eval_pdf(c, vt, vtPred, &vs, ERadiance, M_AREA) * connectionEdge.tr[ERadiance];
+        return cp;
     }
-    __device__ void stripGeometry(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int k, Float *pdfImp, Float *pdfRad, const BV *ovT)   // path.cpp:143-167,309-349
+    // path vertex i (0..k) of "emitter subpath [0..s] + sensor subpath [t..0]"
+    __device__ __forceinline__ const BV &pathV(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int k, int i, const BV *ovT)
     {
-        const char *cs = M->connectableStrict;
-        const int t = k - s - 1;
-        for (int i = 1; i <= k - 3; ++i) {
-            if (i == s || !(cs[i] && !cs[i + 1])) continue;
-            const BV &cur = i <= s ? V_(emitterSubpath, i) : ((ovT && k - i == t) ? *ovT : V_(sensorSubpath, k - i));
-            const BV &succ = i + 1 <= s ? V_(emitterSubpath, i + 1) : ((ovT && k - i - 1 == t) ? *ovT : V_(sensorSubpath, k - i - 1));
-            const BE &edge = i < s ? E_(emitterSubpath, i) : E_(sensorSubpath, k - i - 1);
-            pdfImp[i + 1] *= edge.length * edge.length / fabs((bv_on_surface(succ) ? dot(edge.d, bv_geo_normal(c, succ)) : 1) * (bv_on_surface(cur) ? dot(edge.d, bv_geo_normal(c, cur)) : 1));
-        }
-        for (int i = k - 1; i >= 3; --i) {
-            if (i - 1 == s || !(cs[i] && !cs[i - 1])) continue;
-            const BV &cur = i <= s ? V_(emitterSubpath, i) : ((ovT && k - i == t) ? *ovT : V_(sensorSubpath, k - i));
-            const BV &succ = i - 1 <= s ? V_(emitterSubpath, i - 1) : ((ovT && k - i + 1 == t) ? *ovT : V_(sensorSubpath, k - i + 1));
-            const BE &edge = i <= s ? E_(emitterSubpath, i - 1) : E_(sensorSubpath, k - i);
-            pdfRad[i - 1] *= edge.length * edge.length / fabs((bv_on_surface(succ) ? dot(edge.d, bv_geo_normal(c, succ)) : 1) * (bv_on_surface(cur) ? dot(edge.d, bv_geo_normal(c, cur)) : 1));
-        }
+        if (i <= s) return V_(emitterSubpath, i);
+        return (ovT && k - i == k - s - 1 /* = t */) ? *ovT : V_(sensorSubpath, k - i);
     }
-    __device__ void classify(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int t, const BV *ovT)
+    // the factor that turns the area density across path edge (e, e + 1), e != s, into a projected-solid-angle one (path.cpp:158-166,340-348)
+    __device__ Float edgeFactor(const GPath &emitterSubpath, const GPath &sensorSubpath, int s, int k, int e, const BV *ovT)
     {
-        int n = 0;
-        for (int i = 0; i <= s; ++i) { const BV &v = V_(emitterSubpath, i); M->connectable[n] = connectable_gbdpt(c, v); M->connectableStrict[n] = bv_connectable(v); n++; }
-        for (int i = t; i >= 0; --i) { const BV &v = (ovT && i == t) ? *ovT : V_(sensorSubpath, i); M->connectable[n] = connectable_gbdpt(c, v); M->connectableStrict[n] = bv_connectable(v); n++; }
+        const BV &va = pathV(emitterSubpath, sensorSubpath, s, k, e, ovT), &vb = pathV(emitterSubpath, sensorSubpath, s, k, e + 1, ovT);
+        const BE &edge = e < s ? E_(emitterSubpath, e) : E_(sensorSubpath, k - e - 1);
+        return edge.length * edge.length / fabs((bv_on_surface(vb) ? dot(edge.d, bv_geo_normal(c, vb)) : 1) * (bv_on_surface(va) ? dot(edge.d, bv_geo_normal(c, va)) : 1));
     }
-    __device__ Float miWeightBase(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, bool lightImage, Float geomTermX, const BV *ovT)
+    // entry i (1 <= i <= k - 1) of pdfImp / pdfRad after the conversion loops; strict = connectableStrict[] of the BASE path as a bit mask
+    __device__ __forceinline__ Float misImp(const GPath &emitterSubpath, const GPath &sensorSubpath, const GConn &cp, unsigned strict, int s, int t, int i, const BV *ovT)
     {
         const int k = s + t + 1;
-        classify(emitterSubpath, sensorSubpath, s, t, ovT);
-        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, M->pdfImp, M->pdfRad, ovT);
-        stripGeometry(emitterSubpath, sensorSubpath, s, k, M->pdfImp, M->pdfRad, ovT);
-        double sum_p = 0.0, p_st = 0.0;
-        for (int p = 0; p < s + t + 1; ++p) {
-            double p_i = 1.0;
-            for (int i = 1; i < p + 1; ++i) p_i *= M->pdfImp[i];
-            for (int i = p + 1; i < s + t + 1; ++i) p_i *= M->pdfRad[i];
-            const int tPrime = k - p - 1;
-            const bool allowedToConnect = M->connectable[p] && M->connectable[p + 1];
-            const double v2 = (p_i * geomTermX) * (p_i * geomTermX);                         // std::pow(x, 2.0)
-            if (allowedToConnect && (lightImage || tPrime > 1)) sum_p += v2;
-            if (tPrime == t) p_st = v2;
-        }
-        return (Float)(p_st / sum_p);
+        Float v;
+        if (i <= s) v = V_(emitterSubpath, i - 1).pdf[EImportance] * E_(emitterSubpath, i - 1).tr[EImportance];
+        else if (i == s + 1) v = cp.impS;
+        else if (i == s + 2) v = cp.impT;
+        else { const int q = t + s + 2 - i; v = V_(sensorSubpath, q).pdf[EImportance] * E_(sensorSubpath, q - 1).tr[EImportance]; }       // sensor vertex t - 1 .. 1
+        // pdfImp[j + 1] of the loop j = 1 .. k - 3, j != s, where connectableStrict[j] && !connectableStrict[j + 1]
+        const int j = i - 1;
+        if (j >= 1 && j <= k - 3 && j != s && ((strict >> j) & 1u) && !((strict >> (j + 1)) & 1u)) v *= edgeFactor(emitterSubpath, sensorSubpath, s, k, j, ovT);
+        return v;
     }
-    __device__ Float miWeightGrad(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath,
-                                  const GPath &offsetEmitterSubpath, const BE &offsetConnectionEdge, const GPath &offsetSensorSubpath,
-                                  int s, int t, bool lightImage, Float jDet, Float geomTermX, Float geomTermY, const BV *ovT, const BV *oOvT)
+    __device__ __forceinline__ Float misRad(const GPath &emitterSubpath, const GPath &sensorSubpath, const GConn &cp, unsigned strict, int s, int t, int i, const BV *ovT)
     {
         const int k = s + t + 1;
-        classify(emitterSubpath, sensorSubpath, s, t, ovT);
-        collectPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, M->pdfImp, M->pdfRad, ovT);
-        collectPdfs(offsetEmitterSubpath, offsetConnectionEdge, offsetSensorSubpath, s, t, M->oPdfImp, M->oPdfRad, oOvT);
-        stripGeometry(emitterSubpath, sensorSubpath, s, k, M->pdfImp, M->pdfRad, ovT);
-        stripGeometry(offsetEmitterSubpath, offsetSensorSubpath, s, k, M->oPdfImp, M->oPdfRad, oOvT);
-        double sum_p_i = 0.0, p_st = 0.0;
-        for (int p = 0; p < s + t + 1; ++p) {
-            double value = 1.0, oValue = 1.0;
-            for (int i = 1; i < p + 1; ++i) { value *= M->pdfImp[i]; oValue *= M->oPdfImp[i]; }
-            for (int i = p + 1; i < s + t + 1; ++i) { value *= M->pdfRad[i]; oValue *= M->oPdfRad[i]; }
-            const int tPrime = k - p - 1;
-            const bool allowedToConnect = M->connectable[p] && M->connectable[p + 1];
-            if (allowedToConnect && (lightImage || tPrime > 1)) sum_p_i += value * geomTermX + oValue * jDet * geomTermY;   // std::pow(x, 1.0)
-            if (tPrime == t) p_st = value * geomTermX;
-#ifdef GDPT_BD_TRACE
-            printf("G   miWeightGrad p %d value %.17g oValue %.17g allowed %d sum %.17g\n", p, value, oValue, (int)allowedToConnect, sum_p_i);
-#endif
+        Float v;
+        if (i <= s - 2) v = V_(emitterSubpath, i + 1).pdf[ERadiance] * E_(emitterSubpath, i).tr[ERadiance];
+        else if (i == s - 1) v = cp.radS;
+        else if (i == s) v = cp.radT;
+        else { const int q = t + s + 1 - i; v = V_(sensorSubpath, q - 1).pdf[ERadiance] * E_(sensorSubpath, q - 1).tr[ERadiance]; }         // sensor vertex t .. 1
+        // pdfRad[j - 1] of the loop j = k - 1 .. 3, j - 1 != s, where connectableStrict[j] && !connectableStrict[j - 1]
+        const int j = i + 1;
+        if (j >= 3 && j <= k - 1 && i != s && ((strict >> j) & 1u) && !((strict >> i) & 1u)) v *= edgeFactor(emitterSubpath, sensorSubpath, s, k, i, ovT);
+        return v;
+    }
+    template <bool SQUARES>
+    __device__ void misSums(const GPath &emitterSubpath, const GPath &sensorSubpath, const GConn &cp, unsigned allowed, unsigned strict, int s, int t, const BV *ovT, Float &valueS, Float &sum1, Float &sum2)
+    {
+        const int n = s + t + 1;
+        Float R = 1.0, G = (allowed >> (n - 1)) & 1u ? 1.0 : 0.0, R2 = 1.0, G2 = G, vS = 1.0;
+        for (int q = n - 2; q >= 0; --q) {
+            const int i = q + 1;
+            const Float im = misImp(emitterSubpath, sensorSubpath, cp, strict, s, t, i, ovT), ra = misRad(emitterSubpath, sensorSubpath, cp, strict, s, t, i, ovT);
+            vS *= i <= s ? im : ra;
+            R *= ra;
+            const bool a = (allowed >> q) & 1u;
+            G = (a ? R : 0.0) + im * G;
+            if (SQUARES) { R2 *= ra * ra; G2 = (a ? R2 : 0.0) + (im * im) * G2; }
         }
-#ifdef GDPT_BD_TRACE
-        printf("G   miWeightGrad s %d t %d jDet %.17g geomX %.17g geomY %.17g p_st %.17g sum %.17g\n", s, t, jDet, geomTermX, geomTermY, p_st, sum_p_i);
-        for (int i = 0; i <= k; i++) printf("G   pdf[%d] imp %.17g rad %.17g oImp %.17g oRad %.17g cs %d\n", i, M->pdfImp[i], M->pdfRad[i], M->oPdfImp[i], M->oPdfRad[i], (int)M->connectableStrict[i]);
-#endif
-        return (Float)(p_st / sum_p_i);
+        valueS = vS; sum1 = G; sum2 = G2;
+    }
+    // the two flag masks of the base path "emitter [0..s] + sensor[0] [t..0]" (path.cpp:76-95,241-260) from the sample's per-subpath masks
+    __device__ void pathFlags(int s, int t, const BV *ovT, unsigned &conn, unsigned &strict)
+    {
+        const int k = s + t + 1;
+        conn = W.connE & ((2u << s) - 1u); strict = W.strictE & ((2u << s) - 1u);
+        for (int p = s + 1; p <= k; ++p) {
+            const int q = k - p;
+            bool cg, cs;
+            if (ovT && q == t) { cg = connectable_gbdpt(c, *ovT); cs = bv_connectable(*ovT); }
+            else { cg = (W.connS >> q) & 1u; cs = (W.strictS >> q) & 1u; }
+            conn |= (cg ? 1u : 0u) << p; strict |= (cs ? 1u : 0u) << p;
+        }
+    }
+    // Path::miWeightBaseNoSweep_GBDPT (path.cpp:49-201): (p_st geomTermX)^2 / sum over the allowed strategies of (p_i geomTermX)^2 -- geomTermX cancels
+    __device__ Float miWeightBase(const GPath &emitterSubpath, const BE &connectionEdge, const GPath &sensorSubpath, int s, int t, bool lightImage, const BV *ovT, GMisBase &mb)
+    {
+        const int k = s + t + 1;
+        unsigned conn;
+        pathFlags(s, t, ovT, conn, mb.strict);
+        mb.allowed = conn & (conn >> 1);                                                     // connectable[p] && connectable[p + 1]
+        if (!lightImage) mb.allowed &= k >= 2 ? ((1u << (k - 2)) - 1u) : 0u;                 // tPrime = k - p - 1 > 1
+        mb.allowed &= (1u << k) - 1u;
+        mb.cp = connPdfs(emitterSubpath, connectionEdge, sensorSubpath, s, t, ovT);
+        misSums<true>(emitterSubpath, sensorSubpath, mb.cp, mb.allowed, mb.strict, s, t, ovT, mb.valueS, mb.sum1, mb.sum2);
+        return (Float)((mb.valueS * mb.valueS) / mb.sum2);
+    }
+    // Path::miWeightGradNoSweep_GBDPT (path.cpp:204-378): p_st geomTermX / sum over the allowed strategies of (value_i geomTermX + oValue_i jDet geomTermY);
+    // sharedEnds: the offset path's end points, their predecessors and the connection edge ARE the base path's records (a connection beyond the
+    // shifted part): its four connection densities are the base path's, no BSDF is evaluated
+    __device__ Float miWeightGrad(const GMisBase &mb, const GPath &offsetEmitterSubpath, const BE &offsetConnectionEdge, const GPath &offsetSensorSubpath,
+                                  int s, int t, Float jDet, Float geomTermX, Float geomTermY, const BV *oOvT, bool sharedEnds)
+    {
+        const GConn cp = sharedEnds ? mb.cp : connPdfs(offsetEmitterSubpath, offsetConnectionEdge, offsetSensorSubpath, s, t, oOvT);
+        Float oS, o1, o2;
+        misSums<false>(offsetEmitterSubpath, offsetSensorSubpath, cp, mb.allowed, mb.strict, s, t, oOvT, oS, o1, o2);
+        return (Float)((mb.valueS * geomTermX) / (mb.sum1 * geomTermX + o1 * jDet * geomTermY));
     }
 
     // ---- GBDPTRenderer, gbdpt_proc.cpp ----
@@ -949,9 +972,10 @@ struct GTrT {
     // GBDPTRenderer::process from the connected base path on (gbdpt_proc.cpp:186-229): createShiftablePath, the four offset paths with their
     // Jacobians and generalized geometry terms, the prefix products of combineImportanceData / combineRadianceData (:544-565).  Everything a
     // connection reads is in W afterwards, and W is not written again.  The two subpaths are W.emitter / W.sensor[0] (loadSubpaths).
-    __device__ void prepare()
+    // Two stages, so that the frame kernels can run them on different lanes: prepareBase (one lane per sample) and prepareOffset(k) (one lane per
+    // sample AND offset path: the four offset paths of a sample depend on its connected base path only, each writes its own slots and pool slice).
+    __device__ void prepareBase()
     {
-        const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
         GPath &emitterSubpath = W.emitter;
         for (int k = 0; k < 5; k++) {
             W.success[k] = 0; W.couldConnectAfterB[k] = 0;
@@ -959,6 +983,7 @@ struct GTrT {
             W.mu[k].l = W.mu[k].m = 0; for (int i = 0; i < 5; i++) W.mu[k].extra[i] = 0;
         }
         W.success[0] = 1; W.couldConnectAfterB[0] = 1;
+        W.voidSample = 0;
         GPath &connectPath = W.connect;
         int ptx = 0;
         createShiftablePath(connectPath, emitterSubpath, W.sensor[0], 1, W.sensor[0].nv - 1, ptx);
@@ -968,47 +993,66 @@ struct GTrT {
             if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[0].extra[2]) W.genGeomTerm[0][idx] = calcSpecularPDFChange(connectPath, v);
             else W.genGeomTerm[0][idx] = W.genGeomTerm[0][idx - 1];
         }
-        for (int k = 0; k < 4; k++) {
-            GPath &off = W.sensor[k + 1];
-            off.clear();
-            W.success[k + 1] = W.mu[0].extra[0] <= 2 ? 0 : (generateOffsetPath(connectPath, off, W.mu[k + 1], shifts[k][0], shifts[k][1], W.couldConnectAfterB[k + 1], false) ? 1 : 0);
-            if (W.success[k + 1]) {
-                for (int v = W.mu[k + 1].extra[0] - 1; v >= 0; v--) {
-                    const int idx = connectPath.nv - 1 - v;
-                    if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[k + 1].extra[2]) {
-                        const int a = W.mu[k + 1].extra[0];
-                        const int b = v >= W.mu[k + 1].extra[1] ? v : W.mu[k + 1].extra[1];
-                        const int cI = v >= W.mu[k + 1].extra[1] ? v - 1 : W.mu[k + 1].extra[2];
-                        const double jx = halfJacobian(connectPath, a, b, cI), jy = halfJacobian(off, a, b, cI);
-                        W.jacobianDet[k + 1][idx] = jy / jx;
-                        W.genGeomTerm[k + 1][idx] = calcSpecularPDFChange(off, v);
-                    } else {
-                        W.jacobianDet[k + 1][idx] = W.jacobianDet[k + 1][idx - 1];
-                        W.genGeomTerm[k + 1][idx] = W.genGeomTerm[k + 1][idx - 1];
-                    }
-                }
-            }
-            off.reverse();
-        }
+        W.nvBase = W.nv; W.neBase = W.ne;
         W.vert_b = connectPath.nv - 1 - W.mu[0].extra[1];
         const int nE = emitterSubpath.nv, nS = W.sensor[0].nv;
+        W.connE = W.strictE = W.connS = W.strictS = 0u;
+        for (int i = 0; i < nE; ++i) { const BV &v = V_(emitterSubpath, i); W.connE |= (connectable_gbdpt(c, v) ? 1u : 0u) << i; W.strictE |= (bv_connectable(v) ? 1u : 0u) << i; }
+        for (int i = 0; i < nS; ++i) { const BV &v = V_(W.sensor[0], i); W.connS |= (connectable_gbdpt(c, v) ? 1u : 0u) << i; W.strictS |= (bv_connectable(v) ? 1u : 0u) << i; }
         W.impW[0] = mk(1.0); W.impP[0] = 1.0;
         for (int i = 1; i < nE; ++i) {
             const BV &pv = V_(emitterSubpath, i - 1); const BE &pe = E_(emitterSubpath, i - 1);
             W.impW[i] = W.impW[i - 1] * pv.w[EImportance] * pv.rr * pe.tr[EImportance];
             W.impP[i] = W.impP[i - 1] * pv.pdf[EImportance] * pv.rr * pe.tr[EImportance];
         }
-        for (int k = 0; k <= 4; k++) {
-            W.radW[k][0] = mk(1.0); W.radP[k][0] = 1.0;
-            for (int i = 1; i < nS; ++i) {
-                W.radW[k][i] = mk(0.0); W.radP[k][i] = 0.0;
-                if (W.success[k] && i < W.sensor[k].nv) {
-                    const BV &pv = V_(W.sensor[k], i - 1); const BE &pe = E_(W.sensor[k], i - 1);
-                    W.radW[k][i] = W.radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
-                    W.radP[k][i] = W.radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+        for (int k = 0; k <= 4; k++) { W.radW[k][0] = mk(1.0); W.radP[k][0] = 1.0; for (int i = 1; i < nS; ++i) { W.radW[k][i] = mk(0.0); W.radP[k][i] = 0.0; } }
+        for (int k = 1; k <= 4; k++) W.sensor[k].clear();
+        radianceProducts(0);
+    }
+    __device__ void radianceProducts(int k)
+    {
+        const int nS = W.sensor[0].nv;
+        for (int i = 1; i < nS; ++i) {
+            W.radW[k][i] = mk(0.0); W.radP[k][i] = 0.0;
+            if (W.success[k] && i < W.sensor[k].nv) {
+                const BV &pv = V_(W.sensor[k], i - 1); const BE &pe = E_(W.sensor[k], i - 1);
+                W.radW[k][i] = W.radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
+                W.radP[k][i] = W.radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+            }
+        }
+    }
+    __device__ bool hasOffsets() const { return W.mu[0].extra[0] > 2; }                      // gbdpt_proc.cpp:200
+    __device__ bool offsetsWalk() const { return abs(W.mu[0].extra[1] - W.mu[0].extra[2]) > 1; }   // (b and c are not adjacent: generateOffsetPath enters manifoldWalk, mut_manifold.cpp:882)
+    __device__ void prepareOffset(int k)                                                     // k = 0..3: the offset path sensor[k + 1]
+    {
+        const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+        GPath &connectPath = W.connect;
+        GPath &off = W.sensor[k + 1];
+        off.clear();
+        W.success[k + 1] = !hasOffsets() ? 0 : (generateOffsetPath(connectPath, off, W.mu[k + 1], shifts[k][0], shifts[k][1], W.couldConnectAfterB[k + 1], false) ? 1 : 0);
+        if (W.success[k + 1]) {
+            for (int v = W.mu[k + 1].extra[0] - 1; v >= 0; v--) {
+                const int idx = connectPath.nv - 1 - v;
+                if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[k + 1].extra[2]) {
+                    const int a = W.mu[k + 1].extra[0];
+                    const int b = v >= W.mu[k + 1].extra[1] ? v : W.mu[k + 1].extra[1];
+                    const int cI = v >= W.mu[k + 1].extra[1] ? v - 1 : W.mu[k + 1].extra[2];
+                    const double jx = halfJacobian(connectPath, a, b, cI), jy = halfJacobian(off, a, b, cI);
+                    W.jacobianDet[k + 1][idx] = jy / jx;
+                    W.genGeomTerm[k + 1][idx] = calcSpecularPDFChange(off, v);
+                } else {
+                    W.jacobianDet[k + 1][idx] = W.jacobianDet[k + 1][idx - 1];
+                    W.genGeomTerm[k + 1][idx] = W.genGeomTerm[k + 1][idx - 1];
                 }
             }
         }
+        off.reverse();
+        radianceProducts(k + 1);
+    }
+    __device__ void prepare()
+    {
+        prepareBase();
+        for (int k = 0; k < 4; k++) prepareOffset(k);
     }
     // the connections of emitter vertex s (gbdpt_proc.cpp:311-319; the sensor subpath may have lost trailing non-connectable vertices in createShiftablePath)
     __device__ __forceinline__ void pairRange(int s, int &minT, int &maxT) const
@@ -1023,9 +1067,15 @@ struct GTrT {
     // a measure that is not EDiscrete stays so), so a connection works on a local copy of the cast vertex and leaves the measures alone, and
     // connections may run side by side in any order.  T1: a light-tracing connection (t == 1): its own shiftable path, four offset paths with
     // their own manifold walks, all in the lane's transient pool (X); t >= 2 needs no X.  Returns false when the connection contributes nothing.
-    template <bool T1>
+    // PHASE (as the fast form's connect_pair; light tracing has phases 1 and 2 only -- its filter IS a visibility ray, the sensor connection): 0 = the whole connection (the probe entry); 3 = the part of the base path that
+    // needs no visibility ray (end points connectable, facing each other, throughput): a filter in front of 1 = the base path only: visibility,
+    // geometry term, MIS weight -> whether it carries anything and its primal term (most connections end here, and a wave in which one lane goes
+    // on to the four offsets while the others wait runs at a fifth of its lanes); 2 = the four offsets of a survivor of phase 1: the base path is
+    // evaluated again for the state the offsets share with it (its ray is not counted twice), the gradients are the output.
+    template <bool T1, int PHASE = 0>
     __device__ bool connectPair(int s, int t, PairOut &po)
     {
+        const unsigned nClosest0 = c.nClosest, nShadow0 = c.nShadow;
         const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
         const BdConfig &cfg = c.cfg;
         GPath &emitterSubpath = W.emitter;
@@ -1048,9 +1098,10 @@ struct GTrT {
         bool pathSuccess[5];
         int memPointer = 0;
         MuRec muRec; muRec.l = muRec.m = 0; for (int i = 0; i < 5; i++) muRec.extra[i] = 0;
+        GMisBase misBase;                                                                    // the base path's strategy sums of this connection (k = 0), reused by k = 1..4
         BV vtBaseCast, vtCast;                                                               // s == 0: the sensor-side end point as the emitter sample it is cast to (base path / path k)
         int markV = 0, markE = 0;
-        for (int k = 0; k <= 4; k++) {
+        for (int k = 0; k <= ((PHASE == 1 || PHASE == 3) ? 0 : 4); k++) {
             miWeight[k] = 1.0 / (s + t + 1);
             pathSuccess[k] = W.success[k] != 0;
             value[k] = mk(0.0);
@@ -1114,6 +1165,7 @@ struct GTrT {
                     valuePdf[k] = importancePdfTmp * radiancePdfTmp;
                 }
                 if (is_zero(value[k]) || valuePdf[k] == 0) break;
+                if (PHASE == 3) return true;                                                // (k == 0: both end points face each other and carry throughput -- worth a visibility ray)
                 const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connectionEdge, vs, *vtP);
                 if (k == 0) successConnectBase = successConnect;
                 if (!successConnect) { value[k] = mk(0.0); break; }
@@ -1125,23 +1177,27 @@ struct GTrT {
                 if (k == 0) {
                     connectionEdgeBase = connectionEdge;
                     geomTermBase = geomTerm;
-                    miWeight[0] = miWeightBase(emitterSubpath, connectionEdgeBase, W.sensor[0], s, t, cfg.lightImage != 0, (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t]), ovBase) / valuePdf[0];
+                    miWeight[0] = miWeightBase(emitterSubpath, connectionEdgeBase, W.sensor[0], s, t, cfg.lightImage != 0, ovBase, misBase) / valuePdf[0];
                 } else {
-                    miWeight[k] = miWeightGrad(emitterSubpath, connectionEdgeBase, W.sensor[0], *emitterSubpathTmp, connectionEdge, *sensorSubpathTmp, s, t, cfg.lightImage != 0,
+                    // (a path k whose end points, their predecessors and -- t > vert_b -- connection edge are the base path's own records)
+                    const bool sharedEnds = !T1 && t > vert_b && t >= 1 && sensorSubpathTmp->v[t] == W.sensor[0].v[t] && sensorSubpathTmp->v[t - 1] == W.sensor[0].v[t - 1];
+                    miWeight[k] = miWeightGrad(misBase, *emitterSubpathTmp, connectionEdge, *sensorSubpathTmp, s, t,
                                                (t < 2 ? jacobianLP[k - 1] : W.jacobianDet[k][t]), (t < 2 ? genGeomTermLP[0] : W.genGeomTerm[0][t]), (t < 2 ? genGeomTermLP[k] : W.genGeomTerm[k][t]),
-                                               ovBase, vs.type == T_EMITTER_SUPER ? vtP : nullptr) / valuePdf[0];
+                                               vs.type == T_EMITTER_SUPER ? vtP : nullptr, sharedEnds) / valuePdf[0];
                 }
             } while (false);
 #ifdef GDPT_BD_TRACE
             printf("G st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %u %u\n", s, t, k, (int)pathSuccess[k], value[k].x, value[k].y, value[k].z, valuePdf[k], miWeight[k], geomTerm, c.nClosest, c.nShadow);
 #endif
             if (is_zero(value[k]) || is_zero(value[0])) { value[k] = mk(0.0); miWeight[k] = miWeight[0]; valuePdf[k] = valuePdf[0]; }
+            if (PHASE == 2 && k == 0) { c.nClosest = nClosest0; c.nShadow = nShadow0; }     // (counted by phase 1)
         }
         if constexpr (T1) localAlloc = false;
-        if (is_zero(value[0])) return false;
+        if (PHASE == 3 || is_zero(value[0])) return false;
         const d3 mainRad = value[0] * (valuePdf[0] * miWeight[0]);
         po.primal = mainRad;
-        if (T1) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+        if (T1 && PHASE != 2) { LightSplat &ls = po.light[po.nLight++]; ls.x = samplePosX; ls.y = samplePosY; ls.buffer = 0; ls.value = mainRad; }
+        if (PHASE == 1) return true;
         const d3 fx = value[0] * valuePdf[0];
         for (int n = 0; n < 4; n++) {
             const d3 fy = value[n + 1] * valuePdf[n + 1] * (Float)(t < 2 ? jacobianLP[n] : W.jacobianDet[n + 1][t]);

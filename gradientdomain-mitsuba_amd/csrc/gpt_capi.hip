@@ -3,8 +3,8 @@
 // value is produced by the kernels of gpt_render.hip.h.
 #include "../../include/gdpt_tracer.h"
 #include "gpt_render.hip.h"
-#ifdef GDPT_WITH_SHIFT5     /* the one-path-per-lane shift stage: measured slower than k_render<STAGED>, kept as a development build */
-#include "gpt_shift5.hip.h"
+#ifdef GDPT_WITH_SHIFT5     /* the one-path-per-lane shift stage: measured slower than k_render<STAGED>: a development build, its source under tools/dev/ */
+#include "../../tools/dev/gpt_shift5.hip.h"
 #endif
 #include "gpt_scene.hip.h"
 #include "gpt_wavefront.hip.h"
@@ -21,6 +21,23 @@
 #include <cstdlib>
 
 using namespace gdpt_tr;
+
+#ifndef GDPT_WITH_WAVEFRONT
+// The wavefront continuation (gpt_wave_capi.hip: gdpt_film_set_pipeline(3)) is built, bit-identical to the staged pipeline and measured SLOWER (DESIGN.md,
+// "Wavefront continuation"): it is a development build (GDPT_WITH_WAVEFRONT=1), not part of the product library.  Without its unit the launcher's
+// interface is this: no queues, no iterations.
+namespace gdpt_tr {
+WfQueues *wf_create() { return nullptr; }
+void wf_destroy(WfQueues *) {}
+size_t wf_bytes_per_slot() { return 0; }
+bool wf_reserve(WfQueues *, size_t) { return false; }
+void wf_release(WfQueues *) {}
+size_t wf_slots(const WfQueues *) { return 0; }
+int wf_max_iters() { return 0; }
+int wf_begin_chunk(WfQueues *, hipStream_t, int, FilmD &, FilmD &) { return -1; }
+int wf_continue(const gdpt_scene *, hipStream_t, const ConfigD &, const FilmD &, WfQueues *, int, int, int) { return -1; }
+}
+#endif
 
 extern "C" int gdpt_internal_fail(int code, const char *msg);   // shares the thread-local error string of poisson_capi.hip
 
@@ -1397,6 +1414,9 @@ int gdpt_film_set_regeneration(gdpt_film *f, int idleLanes)
 int gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes)
 {
     if (!f || stages < 0 || stages > 3 || refillLanes < 0 || refillLanes > 64) return tfail(GDPT_ERR_INVALID, "pipeline: stages 0..3, refill threshold 1..64 idle lanes (0 = keep)");
+#ifndef GDPT_WITH_WAVEFRONT
+    if (stages == 3) return tfail(GDPT_ERR_UNSUPPORTED, "pipeline 3 (wavefront continuation) is a development build: GDPT_WITH_WAVEFRONT=1 (measured slower than the staged pipeline, DESIGN.md)");
+#endif
     f->continuation = stages >= 1;       // (1 and 2 are the same since the staged kernels are their own builds)
     f->primaryPass = stages >= 1;
     // 3: the continuation phase starts in wavefront form (GDPT_WF_ITERS traced bounces, default 6), k_continue runs what is left

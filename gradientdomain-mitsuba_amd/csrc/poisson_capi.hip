@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <list>
 #include <vector>
 #include <cstdlib>
 #include <map>
@@ -737,6 +738,8 @@ struct GbdptRecon {
     float *in[3] = {nullptr, nullptr, nullptr};                  // imgf, dyf, dxf
     gdpt_poisson_solver *sv[2] = {nullptr, nullptr};             // L2D, L1D (created on first use)
     unsigned long long stamp = 0;
+    int users = 0;                                               // frames in flight on this entry (under g_reconMutex): an entry in use is never evicted
+    std::mutex work;                                             // one frame at a time PER ENTRY: hosts that drive several GPUs from several threads solve side by side
     void drop()
     {
         for (auto &p : sv) { if (p) gdpt_poisson_destroy(p); p = nullptr; }
@@ -744,65 +747,70 @@ struct GbdptRecon {
         width = height = 0; device = -1;
     }
 };
-std::mutex g_reconMutex;
-std::vector<GbdptRecon> g_recon;
+std::mutex g_reconMutex;                                         // guards the list, not the solves
+std::list<GbdptRecon> g_recon;
 unsigned long long g_reconClock = 0;
 constexpr size_t GBDPT_RECON_CACHE = 8;                          // (device, size) pairs kept: strips of a multi-GPU host, a few film sizes
 }
 
 static int gbdpt_reconstruct_core(double *const dev[5], int width, int height, float alpha, int device, float *recL2, float *recL1, bool outOnDevice, float *seconds2)
 {
-    std::lock_guard<std::mutex> lock(g_reconMutex);
     int cur = device;
     if (cur < 0 && hipGetDevice(&cur) != hipSuccess) return fail(GDPT_ERR_HIP, "gbdpt_reconstruct: no current device");
     const int len = 3 * width * height;
     GbdptRecon *R = nullptr;
-    for (auto &e : g_recon) if (e.device == cur && e.width == width && e.height == height && e.alpha == alpha) R = &e;
+    {
+        std::lock_guard<std::mutex> lock(g_reconMutex);
+        for (auto &e : g_recon) if (e.device == cur && e.width == width && e.height == height && e.alpha == alpha) R = &e;
+        if (!R) {
+            if (g_recon.size() >= GBDPT_RECON_CACHE) {           // evict the idle entry used longest ago (the callers have made `cur` the current device)
+                auto old = g_recon.end();
+                for (auto it = g_recon.begin(); it != g_recon.end(); ++it) if (it->users == 0 && (old == g_recon.end() || it->stamp < old->stamp)) old = it;
+                if (old != g_recon.end()) { (void)hipSetDevice(old->device); old->drop(); (void)hipSetDevice(cur); g_recon.erase(old); }
+            }
+            g_recon.emplace_back();
+            R = &g_recon.back();
+            R->device = cur; R->width = width; R->height = height; R->alpha = alpha;
+        }
+        R->stamp = ++g_reconClock;
+        R->users++;
+    }
     int rc = GDPT_OK;
-    if (!R) {
-        if (g_recon.size() >= GBDPT_RECON_CACHE) {               // evict the entry used longest ago
-            size_t old = 0;
-            for (size_t i = 1; i < g_recon.size(); i++) if (g_recon[i].stamp < g_recon[old].stamp) old = i;
-            const int back = cur;
-            (void)hipSetDevice(g_recon[old].device); g_recon[old].drop(); (void)hipSetDevice(back);
-            g_recon.erase(g_recon.begin() + (long)old);
+    {
+        std::lock_guard<std::mutex> frame(R->work);
+        for (int k = 0; k < 3 && !rc; k++) if (!R->in[k] && hipMalloc(&R->in[k], sizeof(float) * len) != hipSuccess) rc = fail(GDPT_ERR_HIP, "Out of memory!");
+        float **in = R->in;
+        if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[0], dev[0], len, nullptr, 0, nullptr);            // gbdpt.cpp:206
+        if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[1], dev[4], len, dev[1], width, nullptr);          // :207  dy: grad[3] (+y) with grad[0] (-y)
+        if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[2], dev[3], len, dev[2], 1, nullptr);              // :208  dx: grad[2] (+x) with grad[1] (-x)
+        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(GDPT_ERR_HIP, "gbdpt_reconstruct: prepare failed");
+        const char *presets[2] = {"L2D", "L1D"};                     // :213-218, both with m_reconstructAlpha
+        float *outs[2] = {recL2, recL1};
+        for (int k = 0; k < 2 && !rc; k++) {
+            if (seconds2) seconds2[k] = 0.0f;
+            if (!outs[k]) continue;
+            if (!R->sv[k]) {
+                gdpt_poisson_params p;
+                gdpt_poisson_params_defaults(&p);
+                gdpt_poisson_params_preset(&p, presets[k]);
+                p.alpha = alpha;
+                p.device = device;
+                rc = gdpt_poisson_create(&p, &R->sv[k]);
+            }
+            gdpt_poisson_solver *sv = R->sv[k];
+            if (!rc) rc = gdpt_poisson_import_images_device(sv, in[2], in[1], in[0], nullptr, width, height);   // importImagesMTS(dx, dy, img, NULL), :229,243
+            if (!rc) rc = gdpt_poisson_setup_backend(sv);
+            if (!rc) rc = gdpt_poisson_solve_indirect(sv);
+            if (!rc) rc = outOnDevice ? gdpt_poisson_export_images_device(sv, outs[k]) : gdpt_poisson_export_images(sv, outs[k]);
+            if (!rc && outOnDevice) rc = gdpt_poisson_sync(sv);
+            if (!rc && seconds2) seconds2[k] = gdpt_poisson_last_solve_seconds(sv);
         }
-        g_recon.emplace_back();
-        R = &g_recon.back();
-        R->device = cur; R->width = width; R->height = height; R->alpha = alpha;
-        for (int k = 0; k < 3 && !rc; k++) if (hipMalloc(&R->in[k], sizeof(float) * len) != hipSuccess) rc = fail(GDPT_ERR_HIP, "Out of memory!");
+        if (rc) R->drop();                                       // a failed frame leaves nothing half-built behind (the empty entry goes when nobody uses it)
     }
-    R->stamp = ++g_reconClock;
-    float **in = R->in;
-    if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[0], dev[0], len, nullptr, 0, nullptr);            // gbdpt.cpp:206
-    if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[1], dev[4], len, dev[1], width, nullptr);          // :207  dy: grad[3] (+y) with grad[0] (-y)
-    if (!rc) rc = gdpt_gbdpt_prepare_data_device(1.0f, in[2], dev[3], len, dev[2], 1, nullptr);              // :208  dx: grad[2] (+x) with grad[1] (-x)
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(GDPT_ERR_HIP, "gbdpt_reconstruct: prepare failed");
-    const char *presets[2] = {"L2D", "L1D"};                     // :213-218, both with m_reconstructAlpha
-    float *outs[2] = {recL2, recL1};
-    for (int k = 0; k < 2 && !rc; k++) {
-        if (seconds2) seconds2[k] = 0.0f;
-        if (!outs[k]) continue;
-        if (!R->sv[k]) {
-            gdpt_poisson_params p;
-            gdpt_poisson_params_defaults(&p);
-            gdpt_poisson_params_preset(&p, presets[k]);
-            p.alpha = alpha;
-            p.device = device;
-            rc = gdpt_poisson_create(&p, &R->sv[k]);
-        }
-        gdpt_poisson_solver *sv = R->sv[k];
-        if (!rc) rc = gdpt_poisson_import_images_device(sv, in[2], in[1], in[0], nullptr, width, height);   // importImagesMTS(dx, dy, img, NULL), :229,243
-        if (!rc) rc = gdpt_poisson_setup_backend(sv);
-        if (!rc) rc = gdpt_poisson_solve_indirect(sv);
-        if (!rc) rc = outOnDevice ? gdpt_poisson_export_images_device(sv, outs[k]) : gdpt_poisson_export_images(sv, outs[k]);
-        if (!rc && outOnDevice) rc = gdpt_poisson_sync(sv);
-        if (!rc && seconds2) seconds2[k] = gdpt_poisson_last_solve_seconds(sv);
-    }
-    if (rc) {                                                    // a failed frame leaves nothing half-built behind
-        R->drop();
-        g_recon.erase(g_recon.begin() + (R - g_recon.data()));
-    }
+    std::lock_guard<std::mutex> lock(g_reconMutex);
+    R->users--;
+    if (rc && R->users == 0)
+        for (auto it = g_recon.begin(); it != g_recon.end(); ++it) if (&*it == R) { g_recon.erase(it); break; }
     return rc;
 }
 
@@ -811,8 +819,8 @@ int gdpt_gbdpt_reconstruct_release(void)
     std::lock_guard<std::mutex> lock(g_reconMutex);
     int back = 0;
     const bool have = hipGetDevice(&back) == hipSuccess;
-    for (auto &e : g_recon) { (void)hipSetDevice(e.device); e.drop(); }
-    g_recon.clear();
+    for (auto it = g_recon.begin(); it != g_recon.end();)      // (an entry with a frame in flight on another thread stays)
+        if (it->users == 0) { if (it->device >= 0) (void)hipSetDevice(it->device); it->drop(); it = g_recon.erase(it); } else ++it;
     if (have) (void)hipSetDevice(back);
     return GDPT_OK;
 }

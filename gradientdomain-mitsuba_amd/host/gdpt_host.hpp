@@ -573,6 +573,7 @@ public:
             logError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
     }
 
+    ~GBDPTIntegrator() { gdpt_gbdpt_reconstruct_release(); }     // (the library keeps a frame size's solvers between render() calls of this integrator)
     const Statistics &getStatistics() const { return m_stats; }
 
     /// render (gbdpt.cpp:140-262)

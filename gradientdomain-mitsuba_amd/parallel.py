@@ -94,16 +94,25 @@ def exchange_halos(film, rank, world, device, group=None):
     return sent
 
 
-def gather_rows(strip, strips, width, rank, world, group=None):
-    """Gather per-rank strips to rank 0 (None elsewhere).  strip: [rows_r, width, 3] -> [H, width, 3], or a stack of images
-    [k, rows_r, width, 3] -> [k, H, width, 3] (one message per rank for all k images instead of k)."""
+def gather_post(shape_lead, dtype, device, strips, width, rank, world, group=None):
+    """Rank 0 posts the receives of a gather (one message per rank) and returns (parts, requests) for gather_finish; other ranks get None.
+    On a communicator of its own (StripRenderer.gather_group) this may happen BEFORE rank 0 renders: between one pair of ranks RCCL matches
+    point-to-point messages in posting order, so on the halo's communicator an early gather receive from rank 1 would take rank 1's halo."""
+    if world == 1 or rank != 0:
+        return None
+    parts = [_wire(torch.empty(tuple(shape_lead) + (y1 - y0, width, 3), dtype=dtype, device=device)) for (y0, y1) in strips]
+    reqs = dist.batch_isend_irecv([dist.P2POp(dist.irecv, parts[r], r, group=group) for r in range(1, world)])
+    return parts, reqs
+
+
+def gather_finish(strip, posted, rank, world, group=None):
+    """Completes a gather: rank 0 waits for the posted receives and returns the assembled rows, the others send their strip (None)."""
     if world == 1:
         return strip
     stacked = strip.dim() == 4
-    lead = (strip.shape[0],) if stacked else ()
     if rank == 0:
-        parts = [_wire(torch.empty(lead + (y1 - y0, width, 3), dtype=strip.dtype, device=strip.device)) for (y0, y1) in strips]
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, parts[r], r, group=group) for r in range(1, world)]):
+        parts, reqs = posted
+        for q in reqs:
             q.wait()
         parts[0] = strip
         full = torch.cat([p.to(strip.device) for p in parts], dim=1 if stacked else 0)
@@ -113,6 +122,15 @@ def gather_rows(strip, strips, width, rank, world, group=None):
         q.wait()
     _settle(strip)          # the library reuses the strip buffer on its own stream next step
     return None
+
+
+def gather_rows(strip, strips, width, rank, world, group=None):
+    """Gather per-rank strips to rank 0 (None elsewhere).  strip: [rows_r, width, 3] -> [H, width, 3], or a stack of images
+    [k, rows_r, width, 3] -> [k, H, width, 3] (one message per rank for all k images instead of k)."""
+    if world == 1:
+        return strip
+    lead = (strip.shape[0],) if strip.dim() == 4 else ()
+    return gather_finish(strip, gather_post(lead, strip.dtype, strip.device, strips, width, rank, world, group), rank, world, group)
 
 
 class StripRenderer:
@@ -143,6 +161,10 @@ class StripRenderer:
         self.preset = "L1D" if getattr(integ, "reconstructL1", False) else ("L2D" if getattr(integ, "reconstructL2", False) else None)
         self.solver = solver_factory(self.preset, integ.reconstructAlpha) if (rank == 0 and self.preset) else None
         self.film = None
+        # the gather has a communicator of its own: rank 0 posts its receives BEFORE it renders (they complete while it is still busy with its own strip
+        # instead of being set up after it), which on the halo's communicator would collide with the halo messages (gather_post)
+        self.gather_group = dist.new_group(ranks=list(range(world))) if (world > 1 and dist.is_initialized() and group is None) else group
+        self.early_gather = world > 1 and self.gather_group is not group          # (a caller's own group: no second communicator, the receives are posted after the halo exchange)
         self.set_strips(strips or row_strips(self.height, world))
         self.last = {}
         self._open_links()
@@ -161,7 +183,7 @@ class StripRenderer:
                 ops.append(dist.P2POp(dist.irecv, keep[-1], peer, group=self.group))
         for q in dist.batch_isend_irecv(ops):
             q.wait()
-        gather_rows(one.view(1, 1, 1).expand(1, 1, 3).contiguous(), [(r, r + 1) for r in range(self.world)], 1, self.rank, self.world, self.group)
+        gather_rows(one.view(1, 1, 1).expand(1, 1, 3).contiguous(), [(r, r + 1) for r in range(self.world)], 1, self.rank, self.world, self.gather_group)
 
     def set_strips(self, strips):
         """(Re)partition the image; every rank must pass the same list."""
@@ -205,6 +227,8 @@ class StripRenderer:
             phases[name] = 1e3 * (now - tick[0])
             tick[0] = now
         film.clear()
+        post = lambda: gather_post((self.strip_imgs.shape[0],), self.strip_imgs.dtype, self.device, self.strips, self.width, self.rank, self.world, self.gather_group)
+        posted = post() if self.early_gather else None
         integ.renderBlock(self.scene, film, cfg, (0, self.y0, self.width, self.y1))       # GPTBlockRenderer::process over the strip
         film.sync()
         lap("render")
@@ -215,7 +239,7 @@ class StripRenderer:
         for i, b in enumerate((1, 2, 3, 4) if self.preset else (1, 2, 3, 4, 0)):          # BUFFER_THROUGHPUT, DX, DY, VERY_DIRECT (, BUFFER_FINAL)
             film.develop_device(b, self.strip_imgs[i])                                     # developMulti + float cast, gpt.cpp:1419-1442
         lap("develop")
-        full = gather_rows(self.strip_imgs, self.strips, self.width, self.rank, self.world, self.group)
+        full = gather_finish(self.strip_imgs, posted if self.early_gather else post(), self.rank, self.world, self.gather_group)
         lap("gather")
         solve_s = 0.0
         out = None
@@ -250,7 +274,7 @@ class GBDPTStripRenderer:
     The reference hands 32x32 blocks to workers; every worker's result carries camera blocks for its pixels AND five full-resolution light
     images (light-tracing connections land on any pixel, gbdpt_wr.cpp:45-52), and results are merged by addition (GBDPTWorkResult::put,
     :57-63).  Here: rank r renders the samples of a contiguous strip of rows into a film of its own (whole-image buffers), the films are SUMMED
-    onto rank 0 -- one reduction over RCCL (`dist.reduce`, 257 MB of fp64 sums at 1280x720: the path's one real exchange step; a one-pixel halo
+    onto rank 0 -- ONE reduction over RCCL (`dist.reduce` of a single buffer, 258 MB of fp64 sums at 1280x720: the path's one real exchange step; a one-pixel halo
     would not do, a light sample of any rank can hit any pixel) -- and rank 0 develops and runs both reconstructions.
 
     scene, integ: gpt.Scene / gbdpt.GBDPTIntegrator (or test doubles); film_factory(scene) defaults to gbdpt.Film."""
@@ -270,8 +294,11 @@ class GBDPTStripRenderer:
         self.film = film_factory(scene)
         self.strips = list(strips or row_strips(self.height, world))
         self.y0, self.y1 = self.strips[rank]
-        self.block = torch.empty((5, self.height, self.width, 4), dtype=torch.float64, device=device)
-        self.light = torch.empty((5, self.height, self.width, 3), dtype=torch.float64, device=device)
+        # the camera blocks and the light images of a film in ONE buffer: one reduction per frame (a collective's set-up costs more than 100 MB more payload)
+        n4, n3 = 5 * self.height * self.width * 4, 5 * self.height * self.width * 3
+        self.sums = torch.empty(n4 + n3, dtype=torch.float64, device=device)
+        self.block = self.sums[:n4].view(5, self.height, self.width, 4)
+        self.light = self.sums[n4:].view(5, self.height, self.width, 3)
         self.last = {}
 
     def render(self, spp, seed=5489):
@@ -286,13 +313,13 @@ class GBDPTStripRenderer:
         reduce_bytes = 0
         if self.world > 1:
             film.export_device(self.block, self.light)
-            wb, wl = _wire(self.block), _wire(self.light)
-            dist.reduce(wb, 0, op=dist.ReduceOp.SUM, group=self.group)
-            dist.reduce(wl, 0, op=dist.ReduceOp.SUM, group=self.group)
-            reduce_bytes = (wb.numel() + wl.numel()) * 8
+            ws = _wire(self.sums)
+            dist.reduce(ws, 0, op=dist.ReduceOp.SUM, group=self.group)
+            reduce_bytes = ws.numel() * 8
             if self.rank == 0:
-                self.block.copy_(wb); self.light.copy_(wl)
-                _settle(self.block)
+                if ws is not self.sums:
+                    self.sums.copy_(ws)
+                _settle(self.sums)
                 film.import_device(self.block, self.light)
         t2 = time.perf_counter()
         out = None

@@ -188,6 +188,23 @@ def gbdpt_prepare_data(w, data, data2=None, offset=0):
     return out
 
 
+_release_registered = False
+
+
+def _register_release():
+    """The library keeps the three input images and a solver per preset between G-BDPT frames (gdpt_gbdpt_reconstruct_release drops them): released when
+    the interpreter exits -- or whenever the host calls gbdpt_reconstruct_release() (a film size that will not come again)."""
+    global _release_registered
+    if not _release_registered:
+        import atexit
+        atexit.register(gbdpt_reconstruct_release)
+        _release_registered = True
+
+
+def gbdpt_reconstruct_release():
+    check(lib().gdpt_gbdpt_reconstruct_release())
+
+
 def gbdpt_reconstruct(primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y, width, height, alpha=0.2, device=-1, l2=True, l1=True):
     """The second half of GBDPTIntegrator::render (gbdpt.cpp:178-247) on the device: the three prepareDataForSolver calls, then the
     L2D and the L1D solve without a direct image.  Buffers in the order of the integrator's MultiFilm ("-primal", "-gradientNegY",
@@ -200,6 +217,7 @@ def gbdpt_reconstruct(primal, grad_neg_y, grad_neg_x, grad_pos_x, grad_pos_y, wi
     r2 = np.zeros(n3, np.float32) if l2 else None
     r1 = np.zeros(n3, np.float32) if l1 else None
     dp = C.POINTER(C.c_double)
+    _register_release()
     check(lib().gdpt_gbdpt_reconstruct(*[b.ctypes.data_as(dp) for b in bufs], width, height, C.c_float(alpha), device,
                                        None if r2 is None else r2.ctypes.data_as(_fp), None if r1 is None else r1.ctypes.data_as(_fp)))
     return r2, r1
@@ -217,6 +235,7 @@ def gbdpt_reconstruct_device(bufs, width, height, alpha=0.2, device=-1, l2=True,
     r1 = torch.empty((height, width, 3), dtype=torch.float32, device=bufs[0].device) if l1 else None
     torch.cuda.current_stream(bufs[0].device).synchronize()           # the library runs on its own streams
     secs = (C.c_float * 2)()
+    _register_release()
     check(lib().gdpt_gbdpt_reconstruct_device(*[C.c_void_p(b.data_ptr()) for b in bufs], width, height, C.c_float(alpha), device,
                                               C.c_void_p(r2.data_ptr()) if l2 else None, C.c_void_p(r1.data_ptr()) if l1 else None, secs))
     return r2, r1, (float(secs[0]), float(secs[1]))

@@ -801,8 +801,18 @@ def test_wavefront_continuation_is_bit_identical_to_the_staged_pipeline(G, name,
     ray counts and path statistics must be IDENTICAL, bit for bit -- for 1 traced bounce, for the default, and for more bounces than any
     path has (k_continue left with nothing); through the LDS-scene and the HBM-scene builds; with several queue chunks per launch."""
     import os
+    from gradientdomain_mitsuba_amd import _build
+    from gradientdomain_mitsuba_amd._lib import GdptError
     sc = builder()
     W, H, spp = sc.width, sc.height, 5
+    if not _build.WITH_WAVEFRONT:
+        # round 5: the wavefront unit is a development build (GDPT_WITH_WAVEFRONT=1 python -c "import __graft_entry__ as g; g.build()"): measured slower than
+        # the staged pipeline, so the product library and this suite do not pay for it; the product says so instead of running something else
+        S = G.Scene(sc); F = G.Film(S)
+        with pytest.raises(GdptError, match="development build"):
+            F.set_pipeline(3)
+        F.close(); S.close()
+        pytest.skip("product build: pipeline 3 lives in the GDPT_WITH_WAVEFRONT=1 development build (tools/gpu_wf_check.py holds it bit-identical there)")
     integ = G.GradientPathIntegrator(**kw)
     cfg = integ.config(spp)
     for hbm in (False, True):

@@ -12,7 +12,7 @@
 // sum of a sample is accumulated by its base lane from the four offsets' weights in offset order, so a sample's sums are bit-identical to
 // k_render<STAGED>'s and k_continue / k_fold_cont take over unchanged.
 #pragma once
-#include "gpt_render.hip.h"
+#include "../../gradientdomain-mitsuba_amd/csrc/gpt_render.hip.h"
 
 namespace gdpt_tr {
 
