@@ -101,6 +101,21 @@ def _kernel_counters(kernels, prefix, pick=None, **match):
     return c[0]
 
 
+def _valu_busy(tot, profiled_s):
+    """The fraction of the kernels' cycles in which a SIMD's VALU was executing: SQ_ACTIVE_INST_VALU (quad-cycles a wave spends in VALU instructions,
+    MI355X_MICROARCH.md) x 4 / (1024 SIMDs x elapsed cycles), the gfx94x VALUBusy formula rocprofv3 falls back to on gfx950.  Elapsed cycles = GRBM_GUI_ACTIVE of
+    the same PMC pass (the chip's real clock under the profiler, not a nominal 2.4 GHz); rocprofv3 reports it summed over the 8 XCDs -- told apart from a
+    per-device figure by comparing it with the kernels' duration.  Unlike `frac` (instructions against an all-fp64 issue rate: an upper bound, fp32 and
+    integer instructions issue faster) this is a measured busy fraction.  {} when the counter file has no GRBM_GUI_ACTIVE."""
+    cyc = tot.get("GRBM_GUI_ACTIVE", 0.0)
+    if not cyc or not tot.get("SQ_ACTIVE_INST_VALU") or profiled_s <= 0:
+        return {}
+    xcds = 8.0 if cyc / (profiled_s * 2.4e9) > 3.0 else 1.0
+    busy = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc / xcds)
+    return {"valu_busy": round(busy, 4), "effective_clock_ghz_profiled": round(cyc / xcds / profiled_s / 1e9, 3),
+            "valu_busy_what": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / %d XCDs) of the committed PMC pass: the measured share of SIMD cycles spent executing VALU instructions" % int(xcds)}
+
+
 def _traffic_bytes(c):
     """FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both KiB per launch -> bytes."""
     if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
@@ -130,10 +145,11 @@ def poisson_hbm_roofline(P, dev, preset="L2D"):
         sv.setupBackend(); sv.solveIndirect(); t.append(sv.lastSolveSeconds)
     kus = sv.profileKernels(30)
     pus = sv.profilePersistent(2)
+    stream_us = sv.profileStream(10)                    # the yardstick: kf_xp_Ax's access mix and nothing else, here and now
     sv.close()
     solve_s = sorted(t)[1]
     iters = prm.irlsIterMax * prm.cgIterMax
-    return dict(w=w, h=h, preset=preset, solve_ms=1e3 * solve_s, mpix_iter_s=w * h * iters / solve_s / 1e6, kus=kus, persistent_us=pus)
+    return dict(w=w, h=h, preset=preset, solve_ms=1e3 * solve_s, mpix_iter_s=w * h * iters / solve_s / 1e6, kus=kus, persistent_us=pus, stream_us=stream_us)
 
 
 
@@ -158,7 +174,10 @@ def tracer_bytes_block(scene, desc, rays_per_s, closest_frac):
     b_any = RAY_B + 4.0 + st["nodes_any"] * NODE_B + st["tris_any"] * TRI_B
     bpr = closest_frac * b_closest + (1.0 - closest_frac) * b_any
     ach = bpr * rays_per_s / 1e9
-    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+    lds = bool(lay["lds_resident"])
+    # (a scene that sits in LDS moves none of these bytes over HBM: the figure is then bytes per ray and a rate, with no ceiling attached)
+    return {"bound": "none (scene tables in LDS: not an HBM workload)" if lds else "hbm", "achieved": round(ach, 1), "peak": None if lds else HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None if lds else round(ach / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_ray": round(bpr, 1), "bytes_per_closest_ray": round(b_closest, 1), "bytes_per_shadow_ray": round(b_any, 1), "closest_hit_share_of_rays": round(closest_frac, 4),
             "nodes_visited": {"closest": round(st["nodes_closest"], 2), "any": round(st["nodes_any"], 2)}, "tris_tested": {"closest": round(st["tris_closest"], 2), "any": round(st["tris_any"], 2)},
             "node_bytes": lay["node_bytes"], "scene_lds_resident": lay["lds_resident"],
@@ -292,7 +311,8 @@ def bench_gbdpt(a, rank, local, world, dev):
         if bd and put and put.get("grid_x") and world == 1:
             # k_bd_put runs once per chunk with one thread per sample: its launches x grid = the samples of the profiled run
             prof_samples = sum(v.get("calls", 0) * v.get("grid_x", 0) for k, v in bd.items() if "k_bd_put" in k)
-            tot = {f: sum(v.get("calls", 0) * v.get(f, 0.0) for v in bd.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE")}
+            tot = {f: sum(v.get("calls", 0) * v.get(f, 0.0) for v in bd.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")}
+            busy = _valu_busy(tot, sum(v.get("calls", 0) * v.get("avg_us", 0.0) for v in bd.values()) * 1e-6)
             per_sample = tot["SQ_INSTS_VALU"] / prof_samples
             ach = per_sample * samples / (render_ms * 1e-3)
             issue = {"bound": "valu-issue", "achieved": round(ach / 1e9, 1), "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instr/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
@@ -306,7 +326,7 @@ def bench_gbdpt(a, rank, local, world, dev):
                                                                            "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 3) if v.get("SQ_ACTIVE_INST_VALU") else None,
                                                                            "wait_any_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAVE_CYCLES") else None}
                                     for k, v in bd.items()},
-                     "counters_file": counters_file,
+                     "counters_file": counters_file, **busy,
                      "what": "the sampler's kernels: VALU wave-instructions per sample (committed PMC pass of this binary at the same scene and maxDepth) x this run's samples/s, against 1024 SIMDs x 2.4 GHz / 4 cycles"}
         roofline = issue if issue else dict(tracer_bytes, kernel="k_bd_paths + k_bd_shift + k_bd_connect<*> (traversal part)", counters_file=None,
                                             note="no committed PMC pass of the G-BDPT kernels matches this binary: the live byte figure of SURVEY 8d-B stands in for the issue-slot view")
@@ -473,7 +493,7 @@ def main():
                     acc = per_step.setdefault(key, {"launches_per_step": 0.0, "avg_ms": 0.0})
                     acc["launches_per_step"] += n
                     acc["avg_ms"] += n * c.get("avg_us", 0.0) * 1e-3
-                    for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE"):
+                    for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
                         if f in c:
                             acc[f] = acc.get(f, 0.0) + n * c[f]
         tracer_issue = {"bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
@@ -481,8 +501,9 @@ def main():
                         "kernels": "k_primary + k_render + k_continue + k_fold_cont (the staged render of one step)", "render_ms_per_step": round(1e3 * launch_s, 3),
                         "counters_file": counters_file if per_step else None}
         if per_step:
-            tot = {f: sum(k.get(f, 0.0) for k in per_step.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE")}
+            tot = {f: sum(k.get(f, 0.0) for k in per_step.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")}
             valu = tot["SQ_INSTS_VALU"]
+            tracer_issue.update(_valu_busy(tot, sum(k["avg_ms"] for k in per_step.values()) * 1e-3))
             tracer_issue.update({"achieved": round(valu / launch_s / 1e9, 1), "frac": round(valu / launch_s / VALU_ISSUE_PEAK, 4),
                                  "valu_wave_instr_per_ray": round(valu / rays_per_launch, 2),
                                  "lane_utilisation": round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if tot["SQ_ACTIVE_INST_VALU"] else None,
@@ -531,9 +552,10 @@ def main():
                         "iteration": {"kernels_us": {"kf_xp_Ax": round(hb["kus"][3], 2), "kf_r_rz": round(hb["kus"][1], 2)}, "bytes": iter_bytes,
                                       "achieved": round(iter_bytes / (iter_us * 1e-6) / 1e9, 1), "frac": round(iter_bytes / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                       "what": "one CG iteration = kf_xp_Ax + kf_r_rz against SURVEY 8d's 120 B/pix-iter"},
-                        "stream_yardstick": {"us": 95.0, "tb_s": 6.29, "frac_of_it": round(95.0 / kavg, 3) if hb["w"] == 3840 and hb["h"] == 2160 else None,
-                                             "source": "profiles/r04_stream_ceiling.txt (tools/stream_ceiling.hip)",
-                                             "what": "a bare streaming kernel with this kernel's access mix (3 coalesced reads + 3 non-temporal writes of 99.5 MB arrays, no stencil, no reuse) on the same GPU: what 72 B/px can be moved in at all; 0.79 of the 8 TB/s figure"},
+                        "stream_yardstick": {"us": round(hb["stream_us"], 2), "tb_s": round(kb / (hb["stream_us"] * 1e-6) / 1e12, 3), "frac_of_peak": round(kb / (hb["stream_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "frac_of_it": round(hb["stream_us"] / kavg, 3),
+                                             "source": "gdpt_poisson_profile_stream: measured in this run, on this solver's own vectors (best of 10 launches by HIP events)",
+                                             "what": "a bare streaming kernel with this kernel's access mix (3 coalesced 16-byte reads + 3 non-temporal 16-byte writes per float4 element, no stencil, no reuse): what 72 B/px can be moved in at all on this device; frac_of_it = the yardstick's time / kf_xp_Ax's"},
                         "solve": {"ms": round(hb["solve_ms"], 3), "mpix_iter_s": round(hb["mpix_iter_s"], 1),
                                   "achieved": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9, 1), "frac": round(120.0 * hb["mpix_iter_s"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4)}}
         # --- `roofline`: the timed step's dominant kernels.  With the committed counters of this binary: the staged render against the VALU issue
@@ -544,6 +566,8 @@ def main():
                         "kernel": "k_primary + k_render + k_continue + k_fold_cont", "share_of_step": round(launch_s / (wall / a.steps), 4),
                         "launch_ms_live": round(1e3 * launch_s, 3), "valu_wave_instr_per_step": round(tracer_issue["achieved"] * 1e9 * launch_s),
                         "lane_utilisation": tracer_issue.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": tracer_issue.get("wait_any_frac_of_wave_cycles"),
+                        "valu_busy": tracer_issue.get("valu_busy"), "valu_busy_what": tracer_issue.get("valu_busy_what"), "effective_clock_ghz_profiled": tracer_issue.get("effective_clock_ghz_profiled"),
+                        "frac_what": "an UPPER bound on issue use (every VALU instruction priced at the fp64 rate of 4 cycles; fp32 / integer ones issue in 2): valu_busy is the measured busy fraction",
                         "per_kernel": tracer_issue.get("per_kernel"), "counters_file": tracer_issue.get("counters_file"),
                         "what": "the timed step's render kernels: VALU wave-instructions per step (committed PMC pass of this binary) / their launch duration by HIP events in THIS run, against 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction; MFMA is not used (no dense contraction) and the scene is not HBM-resident, so neither the hbm nor the mfma ceiling applies to them"}
         else:

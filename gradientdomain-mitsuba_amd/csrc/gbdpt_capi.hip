@@ -322,7 +322,14 @@ __global__ __launch_bounds__(TBLK, 2) void k_bdg_offset(SceneD S, BdCam cam, BdC
             GSamp &W = gsamp[it >> 2];
             GTr g(c, W, &scratch[lane]);
             g.setRegion((int)(it & 3u));
+#ifdef GDPT_BD_PROFILE
+            const unsigned long long tAll = clock64();
+#endif
             g.prepareOffset((int)(it & 3u));
+#ifdef GDPT_BD_PROFILE
+            g.prof[5] = clock64() - tAll;
+            for (int q = 0; q < 6; q++) atomicAdd(stats + 8 + q, g.prof[q]);
+#endif
             if (g.overflow) { overflow += g.overflow; W.voidSample = 1; }
         }
     }
@@ -384,15 +391,28 @@ __global__ __launch_bounds__(TBLK, 2) void k_bdg_light(SceneD S, BdCam cam, BdCo
     const int Wd = S.cam.width, H = S.cam.height;
     const size_t plane3 = (size_t)Wd * H * 3;
     unsigned overflow = 0;
-    for (unsigned i = atomicAdd(cursor, 1u); i < n; i = atomicAdd(cursor, 1u)) {
+    // (PHASE 2: a wave takes 64 consecutive items = the four offset paths of 16 connections, so that the lanes of a connection stay side by side)
+    unsigned wbase = 0;
+    for (unsigned i = 0; ; ) {
+        if (PHASE == 2) {
+            if ((threadIdx.x & 63) == 0) wbase = atomicAdd(cursor, 64u);
+            wbase = __shfl(wbase, 0);
+            if (wbase >= n) break;
+            i = wbase + (threadIdx.x & 63);
+            if (i >= n) continue;
+        } else { i = atomicAdd(cursor, 1u); if (i >= n) break; }
+        // an item: PHASE 1 (sample << 10) | (s << 5) | 1; PHASE 2 (sample << 7) | (s << 2) | (offset - 1): one lane per offset path of a surviving connection
         const unsigned it = in[i];
-        GTr g(c, gsamp[it >> 10], &scratch[lane]);
+        const unsigned smp = PHASE == 1 ? it >> 10 : it >> 7;
+        const int es = PHASE == 1 ? (int)((it >> 5) & 31u) : (int)((it >> 2) & 31u);
+        GTr g(c, gsamp[smp], &scratch[lane]);
         PairOut po;
-        if (gsamp[it >> 10].voidSample) continue;
-        const bool ok = g.connectPair<true, PHASE>((int)((it >> 5) & 31u), 1, po);
+        if (gsamp[smp].voidSample) continue;
+        if (PHASE == 2) g.lightK = (int)(it & 3u) + 1;
+        const bool ok = g.connectPair<true, PHASE>(es, 1, po);
         if (g.overflow) { overflow += g.overflow; continue; }
         if (!ok) continue;
-        if (PHASE == 1) out[atomicAdd(nOut, 1u)] = it;
+        if (PHASE == 1) { const unsigned at = atomicAdd(nOut, 4u); for (unsigned k = 0; k < 4; k++) out[at + k] = (smp << 7) | ((unsigned)es << 2) | k; }
         for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, Wd, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
     }
     const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
@@ -471,8 +491,8 @@ struct gdpt_gbdpt_film {
     gdpt_scene *scene = nullptr;
     Float *block = nullptr, *light = nullptr;      // [5][H][W][4], [5][H][W][3]
     unsigned long long *stats = nullptr;           // closest rays, shadow rays, samples, invalid puts
-    hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t stream = nullptr, gstream = nullptr;   // gstream: the general form's launches of a chunk run beside the fast form's (they share nothing but atomics)
+    hipEvent_t e0 = nullptr, e1 = nullptr, eG = nullptr;
     float renderMs = 0.0f;
     bool timed = false;
     int W = 0, H = 0;
@@ -548,12 +568,12 @@ int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
     const size_t npix = (size_t)f->W * f->H;
     BHIPCHK(hipMalloc((void **)&f->block, sizeof(Float) * 5 * npix * 4));
     BHIPCHK(hipMalloc((void **)&f->light, sizeof(Float) * 5 * npix * 3));
-    BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 8));           // [0..3] the public counters; [4] samples run in the general form, [5] workspace overflows
+    BHIPCHK(hipMalloc((void **)&f->stats, sizeof(unsigned long long) * 16));           // [0..3] the public counters; [4] samples run in the general form, [5] workspace overflows
     BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned) * 2));               // entries of the general list
     BHIPCHK(hipMalloc((void **)&f->gCount, sizeof(unsigned) * 16));                // the counters and cursors of a pass (k_bdg_shift)
     f->sceneRadius = s->bsphereRadius;              // m_scene->getBSphere().radius (gpt_capi.hip: kd-tree bounds + sensor + emitters, scene.cpp:386-413)
-    BHIPCHK(hipStreamCreate(&f->stream));
-    BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1));
+    BHIPCHK(hipStreamCreate(&f->stream)); BHIPCHK(hipStreamCreate(&f->gstream));
+    BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1)); BHIPCHK(hipEventCreateWithFlags(&f->eG, hipEventDisableTiming));
     *out = f;
     return gdpt_gbdpt_film_clear(f);
 }
@@ -563,6 +583,8 @@ void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
     if (!f) return;
     hipSetDevice(f->scene->device);
     if (f->stream) hipStreamSynchronize(f->stream);
+    if (f->gstream) { hipStreamSynchronize(f->gstream); hipStreamDestroy(f->gstream); }
+    if (f->eG) hipEventDestroy(f->eG);
     hipFree(f->block); hipFree(f->light); hipFree(f->stats);
     hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
     hipFree(f->genList); hipFree(f->genCount); hipFree(f->gsamp); hipFree(f->gscratch); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff); hipFree(f->gCount);
@@ -579,7 +601,7 @@ int gdpt_gbdpt_film_clear(gdpt_gbdpt_film *f)
     const size_t npix = (size_t)f->W * f->H;
     BHIPCHK(hipMemsetAsync(f->block, 0, sizeof(Float) * 5 * npix * 4, f->stream));
     BHIPCHK(hipMemsetAsync(f->light, 0, sizeof(Float) * 5 * npix * 3, f->stream));
-    BHIPCHK(hipMemsetAsync(f->stats, 0, sizeof(unsigned long long) * 8, f->stream));
+    BHIPCHK(hipMemsetAsync(f->stats, 0, sizeof(unsigned long long) * 16, f->stream));
     f->renderMs = 0.0f; f->timed = false;
     return GDPT_OK;
 }
@@ -610,11 +632,11 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 4);
         unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 4 * lanes;
         if (const char *e = getenv("GDPT_BD_GENERAL_PASS")) cap = (unsigned)std::max<long long>(1, atoll(e));      // (tests of the pass loop)
-        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 2 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
+        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 5 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
         for (;;) {
             while ((size_t)lanes * sizeof(GScratch) + (size_t)cap * perSampleG > budget && (lanes > TBLK || cap > TBLK)) { if (cap > lanes) cap /= 2; else lanes = std::max<unsigned>(TBLK, lanes / 2 / TBLK * TBLK); }
             if (hipMalloc((void **)&f->gscratch, sizeof(GScratch) * (size_t)lanes) == hipSuccess && hipMalloc((void **)&f->gsamp, sizeof(GSamp) * (size_t)cap) == hipSuccess &&
-                hipMalloc((void **)&f->gItems, sizeof(unsigned) * 3 * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * 2 * GD_LIGHT * (size_t)cap) == hipSuccess &&
+                hipMalloc((void **)&f->gItems, sizeof(unsigned) * 3 * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * 5 * GD_LIGHT * (size_t)cap) == hipSuccess &&
                 hipMalloc((void **)&f->gOff, sizeof(unsigned) * 8 * (size_t)cap) == hipSuccess) break;
             (void)hipGetLastError();
             hipFree(f->gscratch); hipFree(f->gsamp); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff);
@@ -665,26 +687,32 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         BHIPCHK(hipMemcpyAsync(&nGen, f->genCount, sizeof(unsigned), hipMemcpyDeviceToHost, f->stream));
         BHIPCHK(hipStreamSynchronize(f->stream));                                          // the sizes of the connection launches come from the walk
         if (nGen && !f->gsamp) return bfail(GDPT_ERR_HIP, "G-BDPT: a sample needs the general form in a scene without a specular material");
+        // The general form of this chunk's listed samples on a stream of its own, BESIDE the fast form's connection launches below: the two share the
+        // chunk's read-only records and otherwise only atomics (sums of disjoint samples, the light images, the counters).  Its kernels are persistent
+        // lanes with long tails (a manifold walk is 10-100x an offset path without one); the fast form's dense launches fill the CUs those tails leave
+        // idle.  GDPT_BD_NO_OVERLAP=1: one stream (the A/B switch of the measurement in DESIGN.md).
+        hipStream_t gs = getenv("GDPT_BD_NO_OVERLAP") ? f->stream : f->gstream;
         for (unsigned gFirst = 0; gFirst < nGen; gFirst += f->gsCap) {                     // the general form, a pass of <= gsCap samples at a time
             const unsigned gN = std::min(f->gsCap, nGen - gFirst);
-            BHIPCHK(hipMemsetAsync(f->gCount, 0, sizeof(unsigned) * 16, f->stream));
+            BHIPCHK(hipMemsetAsync(f->gCount, 0, sizeof(unsigned) * 16, gs));
             const unsigned lgrid = std::min((gN + TBLK - 1) / TBLK, f->gLanes / TBLK);
             const size_t offStride = (size_t)4 * f->gsCap;
-            hipLaunchKernelGGL(k_bdg_shift, dim3(lgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, f->genList, gFirst, gN, f->gsamp, f->gscratch, f->gItems, f->gLight, f->gOff, offStride, f->gCount, f->stats);
+            hipLaunchKernelGGL(k_bdg_shift, dim3(lgrid), dim3(TBLK), 0, gs, s->d, cam, c, f->recs, f->genList, gFirst, gN, f->gsamp, f->gscratch, f->gItems, f->gLight, f->gOff, offStride, f->gCount, f->stats);
             const dim3 ogrid((unsigned)std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK));
             for (int q = 0; q < 2; q++)
-                hipLaunchKernelGGL(k_bdg_offset, ogrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)(f->gOff + q * offStride), (const unsigned *)(f->gCount + 8 + q), f->gCount + 10 + q, f->stats);
+                hipLaunchKernelGGL(k_bdg_offset, ogrid, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)(f->gOff + q * offStride), (const unsigned *)(f->gCount + 8 + q), f->gCount + 10 + q, f->stats);
             const unsigned cgridG = (unsigned)std::min<size_t>(((size_t)gN * 24 + TBLK - 1) / TBLK, (size_t)s->numCUs * 16);   // (grid-stride over the list, whose length only the device knows)
             unsigned *listA = f->gItems + (size_t)GD_ITEMS * f->gsCap, *listB = listA + (size_t)GD_ITEMS * f->gsCap;
-            hipLaunchKernelGGL(k_bdg_connect<3>, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, (const unsigned *)f->gItems, (const unsigned *)(f->gCount + 0), listA, f->gCount + 4, f->acc, f->stats);
-            hipLaunchKernelGGL(k_bdg_connect<1>, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, (const unsigned *)listA, (const unsigned *)(f->gCount + 4), listB, f->gCount + 5, f->acc, f->stats);
-            hipLaunchKernelGGL(k_bdg_connect<2>, dim3(cgridG), dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, (const unsigned *)listB, (const unsigned *)(f->gCount + 5), (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->stats);
+            hipLaunchKernelGGL(k_bdg_connect<3>, dim3(cgridG), dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, (const unsigned *)f->gItems, (const unsigned *)(f->gCount + 0), listA, f->gCount + 4, f->acc, f->stats);
+            hipLaunchKernelGGL(k_bdg_connect<1>, dim3(cgridG), dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, (const unsigned *)listA, (const unsigned *)(f->gCount + 4), listB, f->gCount + 5, f->acc, f->stats);
+            hipLaunchKernelGGL(k_bdg_connect<2>, dim3(cgridG), dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, (const unsigned *)listB, (const unsigned *)(f->gCount + 5), (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->stats);
             const dim3 lgridL((unsigned)std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK));
             unsigned *lightB = f->gLight + (size_t)GD_LIGHT * f->gsCap;
-            hipLaunchKernelGGL(k_bdg_light<1>, lgridL, dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)f->gLight, (const unsigned *)(f->gCount + 1), f->gCount + 3, lightB, f->gCount + 6, f->light, f->stats);
-            hipLaunchKernelGGL(k_bdg_light<2>, lgridL, dim3(TBLK), 0, f->stream, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightB, (const unsigned *)(f->gCount + 6), f->gCount + 7, (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
+            hipLaunchKernelGGL(k_bdg_light<1>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)f->gLight, (const unsigned *)(f->gCount + 1), f->gCount + 3, lightB, f->gCount + 6, f->light, f->stats);
+            hipLaunchKernelGGL(k_bdg_light<2>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightB, (const unsigned *)(f->gCount + 6), f->gCount + 7, (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
             BHIPCHK(hipGetLastError());
         }
+        if (nGen && gs != f->stream) { BHIPCHK(hipEventRecord(f->eG, gs)); }
         for (int q = 0; q < 3; q++) {
             if (!nItems[q]) continue;
             const dim3 cgrid((nItems[q] + TBLK - 1) / TBLK);
@@ -701,6 +729,7 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
 #undef BD_CONNECT
             BHIPCHK(hipGetLastError());
         }
+        if (nGen && gs != f->stream) BHIPCHK(hipStreamWaitEvent(f->stream, f->eG, 0));        // the sums of the general samples are complete
         hipLaunchKernelGGL(k_bd_put, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, f->recs, f->acc, count, f->W, f->H, f->block, f->stats);
         BHIPCHK(hipGetLastError());
     }
@@ -830,6 +859,17 @@ int gdpt_gbdpt_evaluate_sample(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int 
     counters[0] = c4[0]; counters[1] = c4[1];
     return rc;
 }
+
+#ifdef GDPT_BD_PROFILE
+// development (-DGDPT_BD_PROFILE, tools/gpu_gbdpt_profile.py): lane clocks of k_bdg_offset by section -- generateOffsetPath, of which the manifold walk,
+// half-Jacobians, calcSpecularPDFChange, prefix products, all of prepareOffset
+__attribute__((visibility("default"))) int gdpt_gbdpt_film_profile(gdpt_gbdpt_film *f, unsigned long long out[6])
+{
+    if (int rc = gdpt_gbdpt_film_sync(f)) return rc;
+    BHIPCHK(hipMemcpy(out, f->stats + 8, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost));
+    return GDPT_OK;
+}
+#endif
 
 int gdpt_gbdpt_film_chain_stats(gdpt_gbdpt_film *f, unsigned long long stats[2])
 {

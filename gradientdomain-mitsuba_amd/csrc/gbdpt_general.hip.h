@@ -146,6 +146,13 @@ struct GTrT {
     GSamp &W;
     GScratch *X;                                   // nullptr in the connection kernel for t >= 2: nothing there allocates or touches a manifold
     bool localAlloc = false;                       // allocations go to the lane's transient pool (a light-tracing connection), not to the sample's
+#ifdef GDPT_BD_PROFILE   /* development: lane clocks per section of prepareOffset (tools/gpu_gbdpt_profile.py) */
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+#define GPROF(i, stmt) do { const unsigned long long t0_ = clock64(); stmt; prof[i] += clock64() - t0_; } while (0)
+#else
+#define GPROF(i, stmt) do { stmt; } while (0)
+#endif
+    int lightK = 0;                                // connectPair<true, 2>: 1..4 = build this one of the light path's four offset paths only (0: all four)
     unsigned overflow = 0;                         // a pool or a list ran out (the sample's result is then void: counted, asserted zero by the tests)
     __device__ GTrT(Ctx &c_, GSamp &w_, GScratch *x_) : c(c_), W(w_), X(x_) {}
     __device__ GTrT(Ctx &c_, GWork &w_) : c(c_), W(w_.s), X(&w_.x) {}
@@ -619,7 +626,11 @@ struct GTrT {
         const Float cosI = fabs(dot(e.d, bv_sh_normal(c, V_(p, i)))), cosJ = fabs(dot(e.d, bv_sh_normal(c, V_(p, j))));
         return cosI * cosJ / (e.length * e.length);
     }
-    __device__ Float multiG(const GPath &p, int a, int b)
+    // The geometry terms of ONE path, each computed once: calcSpecularPDFChange is asked for every connectable vertex v of a path in turn, and its
+    // products over [v, k] share every factor with the call before (the plain terms of the edges: two shading-frame lookups each; the chains' generalized
+    // terms: a manifold each).  The products themselves are formed as before, factor by factor in the same order -- same values, bit for bit.
+    struct GCache { unsigned haveE = 0, haveS = 0; Float e[GP_LEN], s[GP_LEN]; };
+    __device__ Float multiG(const GPath &p, int a, int b, GCache *gc = nullptr)
     {
         if (a == 0) ++a; else if (a == p.length()) --a;
         if (b == 0) ++b; else if (b == p.length()) --b;
@@ -628,7 +639,14 @@ struct GTrT {
         while (!bv_connectable(V_(p, a))) a += step;
         Float result = 1;
         for (int i = a + step, start = a; i != b + step; i += step)
-            if (bv_connectable(V_(p, i))) { result *= manifoldG(p, start, i); start = i; }
+            if (bv_connectable(V_(p, i))) {
+                Float g;
+                if (gc && step > 0) {                                                        // (a segment is named by where it starts: its end is the next connectable vertex)
+                    if (!((gc->haveS >> start) & 1u)) { gc->s[start] = manifoldG(p, start, i); gc->haveS |= 1u << start; }
+                    g = gc->s[start];
+                } else g = manifoldG(p, start, i);
+                result *= g; start = i;
+            }
         return result;
     }
     __device__ Float manifoldDet(const GPath &p, int a, int b, int cI)
@@ -685,15 +703,22 @@ struct GTrT {
         value *= manifoldDet(p, a, b, cI);
         return value;
     }
-    __device__ Float calcSpecularPDFChange(const GPath &p, int cI, bool lightpath = false)   // path.cpp:403-421
+    __device__ Float calcSpecularPDFChange(const GPath &p, int cI, bool lightpath = false, GCache *gc = nullptr)   // path.cpp:403-421
     {
         Float value = 1.0;
         const int k = p.length() - 1;
         cI = max(1, cI);
         for (int i = cI + 1; i <= k; i++)
-            if (bv_connectable(V_(p, lightpath ? i - 1 : i))) value *= pathG(p, i - 1, i);
+            if (bv_connectable(V_(p, lightpath ? i - 1 : i))) {
+                Float g;
+                if (gc) {
+                    if (!((gc->haveE >> i) & 1u)) { gc->e[i] = pathG(p, i - 1, i); gc->haveE |= 1u << i; }
+                    g = gc->e[i];
+                } else g = pathG(p, i - 1, i);
+                value *= g;
+            }
         if (value <= (Float)0.0) return 1.0;
-        return multiG(p, cI, k) / value;
+        return multiG(p, cI, k, gc) / value;
     }
 
     // ---- ManifoldPerturbation, mut_manifold.cpp ----
@@ -812,7 +837,8 @@ struct GTrT {
         if (!mutPropagatePerturbation(source, proposal, step, a, b, ERadiance)) return false;
         if (!bv_connectable(V_(proposal, b))) return false;
         if (abs(b - cI) > 1) {
-            const bool walkSuccess = mutManifoldWalk(source, proposal, b, cI);
+            bool walkSuccess;
+            GPROF(1, walkSuccess = mutManifoldWalk(source, proposal, b, cI));
             if (!walkSuccess && lightPath) return false;
             if (!walkSuccess) {
                 for (int i = b + step; i != cI; i += step) proposal.v[i] = (short)cloneV(source.v[i]);
@@ -988,9 +1014,10 @@ struct GTrT {
         int ptx = 0;
         createShiftablePath(connectPath, emitterSubpath, W.sensor[0], 1, W.sensor[0].nv - 1, ptx);
         computeMuRec(connectPath, W.mu[0]);
+        GCache gc;
         for (int v = W.mu[0].extra[0] - 1; v >= 0; v--) {
             const int idx = connectPath.nv - 1 - v;
-            if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[0].extra[2]) W.genGeomTerm[0][idx] = calcSpecularPDFChange(connectPath, v);
+            if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[0].extra[2]) W.genGeomTerm[0][idx] = calcSpecularPDFChange(connectPath, v, false, &gc);
             else W.genGeomTerm[0][idx] = W.genGeomTerm[0][idx - 1];
         }
         W.nvBase = W.nv; W.neBase = W.ne;
@@ -1029,17 +1056,26 @@ struct GTrT {
         GPath &connectPath = W.connect;
         GPath &off = W.sensor[k + 1];
         off.clear();
-        W.success[k + 1] = !hasOffsets() ? 0 : (generateOffsetPath(connectPath, off, W.mu[k + 1], shifts[k][0], shifts[k][1], W.couldConnectAfterB[k + 1], false) ? 1 : 0);
+        GPROF(0, W.success[k + 1] = !hasOffsets() ? 0 : (generateOffsetPath(connectPath, off, W.mu[k + 1], shifts[k][0], shifts[k][1], W.couldConnectAfterB[k + 1], false) ? 1 : 0));
         if (W.success[k + 1]) {
+            int lastB = -1, lastC = -1;
+            double lastJ = 1.0;
+            GCache gc;
             for (int v = W.mu[k + 1].extra[0] - 1; v >= 0; v--) {
                 const int idx = connectPath.nv - 1 - v;
                 if (connectable_gbdpt(c, V_(connectPath, v)) && v >= W.mu[k + 1].extra[2]) {
                     const int a = W.mu[k + 1].extra[0];
                     const int b = v >= W.mu[k + 1].extra[1] ? v : W.mu[k + 1].extra[1];
                     const int cI = v >= W.mu[k + 1].extra[1] ? v - 1 : W.mu[k + 1].extra[2];
-                    const double jx = halfJacobian(connectPath, a, b, cI), jy = halfJacobian(off, a, b, cI);
-                    W.jacobianDet[k + 1][idx] = jy / jx;
-                    W.genGeomTerm[k + 1][idx] = calcSpecularPDFChange(off, v);
+                    // (below b the triple (a, b, c) no longer changes with v: the same two half-Jacobians -- 22 % of this stage's clocks when they were
+                    //  computed for every v; same inputs, same quotient, bit for bit)
+                    if (b != lastB || cI != lastC) {
+                        double jx, jy;
+                        GPROF(2, jx = halfJacobian(connectPath, a, b, cI); jy = halfJacobian(off, a, b, cI));
+                        lastJ = jy / jx; lastB = b; lastC = cI;
+                    }
+                    W.jacobianDet[k + 1][idx] = lastJ;
+                    GPROF(3, W.genGeomTerm[k + 1][idx] = calcSpecularPDFChange(off, v, false, &gc));
                 } else {
                     W.jacobianDet[k + 1][idx] = W.jacobianDet[k + 1][idx - 1];
                     W.genGeomTerm[k + 1][idx] = W.genGeomTerm[k + 1][idx - 1];
@@ -1047,7 +1083,7 @@ struct GTrT {
             }
         }
         off.reverse();
-        radianceProducts(k + 1);
+        GPROF(4, radianceProducts(k + 1));
     }
     __device__ void prepare()
     {
@@ -1102,6 +1138,7 @@ struct GTrT {
         BV vtBaseCast, vtCast;                                                               // s == 0: the sensor-side end point as the emitter sample it is cast to (base path / path k)
         int markV = 0, markE = 0;
         for (int k = 0; k <= ((PHASE == 1 || PHASE == 3) ? 0 : 4); k++) {
+            if (T1 && PHASE == 2 && lightK && k != 0 && k != lightK) continue;              // (this lane builds ONE of the light path's four offsets; the other lanes the others)
             miWeight[k] = 1.0 / (s + t + 1);
             pathSuccess[k] = W.success[k] != 0;
             value[k] = mk(0.0);
@@ -1200,6 +1237,7 @@ struct GTrT {
         if (PHASE == 1) return true;
         const d3 fx = value[0] * valuePdf[0];
         for (int n = 0; n < 4; n++) {
+            if (T1 && PHASE == 2 && lightK && n + 1 != lightK) continue;
             const d3 fy = value[n + 1] * valuePdf[n + 1] * (Float)(t < 2 ? jacobianLP[n] : W.jacobianDet[n + 1][t]);
             const d3 gradVal = (fy - fx) * ((Float)2.0 * miWeight[n + 1]);
             po.gradient[n] = gradVal;

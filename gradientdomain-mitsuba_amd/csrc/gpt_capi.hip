@@ -1130,6 +1130,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #else
         if (useQueue) {
             // staged builds: {LDS scene, sums in LDS | LDS scene, sums in registers | HBM scene, sums in registers} x {flat | env | per-vertex}
+            if (s->d.ldsScene && accLds && !s->perVertex && !s->specialEmitters && f->wavesPerSimd == 1) {
+                // (round 5 experiment, gdpt_film_set_occupancy(1): the first-bounce stage with the whole register file of a SIMD for ONE wave -- 512 registers,
+                //  no spilled path state -- against the default's two waves x 256 + 1.3 KB of scratch per lane; k_continue keeps its two waves.  DESIGN.md)
+                hipLaunchKernelGGL((k_render<true, true, 1, false, false, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes);
+                hipLaunchKernelGGL((k_continue<true, true, 2, false, false>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill);
+            } else
             if (s->d.ldsScene) { if (accLds) GDPT_STAGED_F(true, true, 2); else GDPT_STAGED_F(true, false, 2); }
             else GDPT_STAGED_F(false, false, 4);
         } else if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }

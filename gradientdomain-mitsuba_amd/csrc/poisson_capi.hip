@@ -73,7 +73,7 @@ struct Lattice {
     long n() const { return (long)W * H; }
     int tilesX() const { return cdiv(W, TW); }
     int tiles() const { return tilesX() * cdiv(H, TH); }
-    int tilesF() const { return tilesX() * cdiv(H, TH_F); }     // tiles of the fused x_p+stencil kernel
+    int tilesF(int th = TH_F) const { return tilesX() * cdiv(H, th); }     // tiles of the fused x_p+stencil kernel (th rows each)
 };
 
 // Ap = A p and block partials of p.Ap; returns the number of partials written.
@@ -260,23 +260,47 @@ void enqueue_cg_precond(gdpt_poisson_solver *s, bool unitw, int cg, bool first)
     }
 }
 
+// The fused x_p + stencil kernel in the variant GDPT_XPAX=rows,blocks names (tile rows 4 | 8 | 12, resident blocks per CU asked of the register allocator:
+// 1 = its own choice); default = the product's 8 rows.  Returns the grid (= the number of p.Ap partials written).
+struct XpAxVariant { int th, minb; };
+static XpAxVariant xpax_variant()
+{
+    static XpAxVariant v = [] {
+        XpAxVariant r = {TH_F, 1};
+        if (const char *e = getenv("GDPT_XPAX")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) { r.th = a; r.minb = b; } }
+        return r;
+    }();
+    return v;
+}
+static int launch_xp_Ax(hipStream_t st, const Lattice &L, bool unitw, float *Ap, float4 *part_pAp, const float *w2, float *x, const float *po, float *pn, const float *r,
+                        const float *s_rz2, const float *s_pAp, const float4 *part_rz, int G_in, float *s_rz_out)
+{
+    const XpAxVariant v = xpax_variant();
+    const int tiles = L.tilesF(v.th), Gt = imin(tiles, MAXP);
+#define XPAX(U, TH_V, MB) hipLaunchKernelGGL((kf_xp_Ax<U, TH_V, MB>), dim3(Gt), dim3(BLK), 0, st, (float4 *)Ap, part_pAp, w2, (float4 *)x, po, (float4 *)pn, r, s_rz2, s_pAp, part_rz, G_in, s_rz_out, L.W, L.H, L.alpha, L.tilesX(), tiles)
+#define XPAX_U(TH_V, MB) do { if (unitw) XPAX(true, TH_V, MB); else XPAX(false, TH_V, MB); } while (0)
+    if (v.th == 4 && v.minb == 1) XPAX_U(4, 1);
+    else if (v.th == 4 && v.minb == 3) XPAX_U(4, 3);
+    else if (v.th == 4 && v.minb == 4) XPAX_U(4, 4);
+    else if (v.th == 8 && v.minb == 3) XPAX_U(8, 3);
+    else if (v.th == 12 && v.minb == 1) XPAX_U(12, 1);
+    else XPAX_U(TH_F, 1);
+#undef XPAX_U
+#undef XPAX
+    return Gt;
+}
+
 // `cg` iterations with x_p(k) fused into the stencil of iteration k+1: 2*cg + 1 kernels.
 void enqueue_cg_fused(gdpt_poisson_solver *s, bool unitw, int cg)
 {
     const Lattice L = s->lat();
     const long n3 = 3 * L.n();
     hipStream_t st = s->stream;
-    const int Gt = imin(L.tilesF(), MAXP);
     int Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
     int Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
     for (int k = 1; k < cg; k++) {
         float *po = s->p[(k - 1) & 1], *pn = s->p[k & 1];
-        if (unitw)
-            hipLaunchKernelGGL((kf_xp_Ax<true, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
-                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
-        else
-            hipLaunchKernelGGL((kf_xp_Ax<false, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, po, (float4 *)pn, s->r,
-                               s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
+        const int Gt = launch_xp_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->x, po, pn, s->r, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
         Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Gt, s->s_pAp(), s->s_rz_old());
     }
     launch_x_p(st, n3, s->x, s->p[(cg - 1) & 1], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
@@ -901,12 +925,7 @@ int gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4])
                 if (which == 0) Ga = launch_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->p[0]);
                 if (which == 1) Gr = launch_r_rz(st, n3, s->r, s->part_rz, s->Ap, s->s_rz_next(), nullptr, s->part_pAp, Ga, s->s_pAp(), s->s_rz_old());
                 if (which == 2) launch_x_p(st, n3, s->x, s->p[0], s->r, nullptr, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
-                if (which == 3) {
-                    if (unitw) hipLaunchKernelGGL((kf_xp_Ax<true, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
-                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
-                    else       hipLaunchKernelGGL((kf_xp_Ax<false, TH_F>), dim3(Gt), dim3(BLK), 0, st, (float4 *)s->Ap, s->part_pAp, s->w2, (float4 *)s->x, s->p[k & 1], (float4 *)s->p[(k + 1) & 1], s->r,
-                                                  s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next(), L.W, L.H, L.alpha, L.tilesX(), L.tilesF());
-                }
+                if (which == 3) launch_xp_Ax(st, L, unitw, s->Ap, s->part_pAp, s->w2, s->x, s->p[k & 1], s->p[(k + 1) & 1], s->r, s->s_rz_old(), s->s_pAp(), s->part_rz, Gr, s->s_rz_next());
             }
             HIPCHK(hipEventRecord(s->ev1, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -916,6 +935,28 @@ int gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, float us[4])
         }
     }
     HIPCHK(hipGetLastError());
+    return GDPT_OK;
+}
+
+// Bench hook: the yardstick beside kf_xp_Ax's HBM fraction, measured in the SAME process on the same device -- a bare streaming kernel with that kernel's access
+// mix (three coalesced 16-byte reads from three arrays, three non-temporal 16-byte writes to three others, no stencil, no reuse) over the handle's own CG
+// vectors (x, r, p[0] in; Ap, p[1], rec out: the solver's buffers, clobbered -- call setup_backend again before the next solve).  us = best of `reps` launches.
+int gdpt_poisson_profile_stream(gdpt_poisson_solver *s, int reps, float *us)
+{
+    if (!s || !s->ready || reps < 1 || !us) return fail(GDPT_ERR_INVALID, "profile_stream needs a set-up solver");
+    const size_t n4 = (size_t)3 * s->W * s->H / 4;
+    hipStream_t st = s->stream;
+    float best = 1e30f;
+    for (int k = 0; k < reps + 2; k++) {          // (two warm-up launches)
+        HIPCHK(hipEventRecord(s->ev0, st));
+        hipLaunchKernelGGL(kg_stream33, dim3(1024), dim3(BLK), 0, st, (const float4 *)s->x, (const float4 *)s->r, (const float4 *)s->p[0], (float4 *)s->Ap, (float4 *)s->p[1], (float4 *)s->rec, n4);
+        HIPCHK(hipEventRecord(s->ev1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        if (k >= 2 && ms < best) best = ms;
+    }
+    *us = best * 1000.0f;
     return GDPT_OK;
 }
 

@@ -575,8 +575,10 @@ __global__ __launch_bounds__(BLK) void kf_Ax(float4 *__restrict__ Ax4, float4 *_
 // neighbouring block may still be reading p_old for its ring) and update x += p_old*a.
 // TH_ = tile rows (ring overhead (TH_+2)/TH_ on the r,p reads); the first tile's loads are issued BEFORE
 // the block reduces the previous kernel's partials, so that fixed latency hides under the HBM/MALL fetch.
-template <bool UNITW, int TH_>
-__global__ __launch_bounds__(BLK) void kf_xp_Ax(float4 *__restrict__ Ax4, float4 *__restrict__ part_pAp, const float *__restrict__ w2,
+// MINB: resident blocks per CU the register allocator is asked to leave room for (1 = its own choice).  Round 5's occupancy sweep at 3840x2160 (DESIGN.md,
+// "kf_xp_Ax: occupancy sweep"; GDPT_XPAX=rows,blocks selects a variant, tools/gpu_xpax_sweep.py times them).
+template <bool UNITW, int TH_, int MINB = 1>
+__global__ __launch_bounds__(BLK, MINB) void kf_xp_Ax(float4 *__restrict__ Ax4, float4 *__restrict__ part_pAp, const float *__restrict__ w2,
                                                 float4 *__restrict__ x4, const float *__restrict__ p_old, float4 *__restrict__ p_new4,
                                                 const float *__restrict__ r, const float *__restrict__ s_rz2, const float *__restrict__ s_pAp,
                                                 const float4 *__restrict__ part_rz, int G_in, float *s_rz_out,
@@ -667,6 +669,21 @@ __global__ __launch_bounds__(BLK) void kf_xp_Ax(float4 *__restrict__ Ax4, float4
     }
     block_sum3(acc, sm);
     if (t == 0) part_pAp[blockIdx.x] = make_float4(acc[0], acc[1], acc[2], 0.0f);
+}
+
+// The yardstick of kf_xp_Ax's HBM fraction (gdpt_poisson_profile_stream): its access mix and nothing else -- per float4 element three coalesced loads from three
+// arrays, three non-temporal stores to three others.
+__global__ __launch_bounds__(BLK) void kg_stream33(const float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
+                                                   float4 *__restrict__ o0, float4 *__restrict__ o1, float4 *__restrict__ o2, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        const float4 va = a[i], vb = b[i], vc = c[i];
+        float4 v;
+        v.x = va.x + vb.x + vc.x; v.y = va.y + vb.y + vc.y; v.z = va.z + vb.z + vc.z; v.w = va.w + vb.w + vc.w;
+        nt_store4(&o0[i], v);
+        v.x += 1.0f; nt_store4(&o1[i], v);
+        v.x += 1.0f; nt_store4(&o2[i], v);
+    }
 }
 
 // ---- Backend::tonemapSRGB / tonemapLinear (Backend.cpp:442-507; the CUDA backend's kernels: BackendCUDA.cu:564-660): the display path of

@@ -126,6 +126,13 @@ class Solver:
         check(lib().gdpt_poisson_profile_kernels(self._h, int(reps), us))
         return [float(v) for v in us]
 
+    def profileStream(self, reps=10):
+        """Bench hook: microseconds (best of reps) of a bare streaming kernel with kf_xp_Ax's access mix over this solver's own vectors: the
+        yardstick of that kernel's HBM fraction, measured in this process on this device.  Clobbers the iterate."""
+        us = C.c_float(0.0)
+        check(lib().gdpt_poisson_profile_stream(self._h, int(reps), C.byref(us)))
+        return float(us.value)
+
     def profilePersistent(self, reps=20):
         """Bench hook: mean microseconds of one launch of the persistent CG kernel (cgIterMax iterations); 0 if not used."""
         us = C.c_float(0.0)

@@ -115,6 +115,10 @@ GDPT_API int  gdpt_poisson_profile_kernels(gdpt_poisson_solver *s, int reps, flo
 /* Same for the persistent CG kernel of fusion level 2: mean duration in microseconds of ONE launch (= cgIterMax CG
  * iterations), 0 when the handle's geometry does not use it.  Clobbers the iterate like profile_kernels. */
 GDPT_API int  gdpt_poisson_profile_persistent(gdpt_poisson_solver *s, int reps, float *us);
+/* Bench hook: a bare streaming kernel with kf_xp_Ax's access mix (3 coalesced 16-byte reads + 3 non-temporal 16-byte writes per float4 element, no stencil,
+ * no reuse) over the handle's own CG vectors: what 72 B/px can be moved in at all on this device, measured in the same process as the kernel it is the
+ * yardstick of (best of `reps` launches, microseconds).  Clobbers the iterate: call setup_backend again before the next solve. */
+GDPT_API int  gdpt_poisson_profile_stream(gdpt_poisson_solver *s, int reps, float *us);
 
 /* --- G-BDPT's reconstruction stage (BASELINE config 5; the sampler of that integrator is not part of this library) ------------------
  * GBDPTIntegrator::prepareDataForSolver, src/integrators/gbdpt/gbdpt.cpp:264-280: out[i] = w * float(data[i]); with data2, every

@@ -89,5 +89,6 @@ def test_bench_eight_ranks_of_config4_on_one_device(gpu_required, tmp_path):
     for a, b in strips[:-1]:
         border[int(b) - 2:int(b) + 2] = True
     assert np.array_equal(d8["images"][:, ~border], d1["images"][:, ~border])
-    assert np.allclose(d8["images"], d1["images"], rtol=0, atol=1e-5)
+    for k in range(4):                                                          # (on the border rows: fp32 images of fp64 sums added in another order)
+        assert np.abs(d8["images"][k] - d1["images"][k]).max() <= 1e-5 * max(1.0, float(np.abs(d1["images"][k]).max())), k
     assert np.abs(d8["final"] - d1["final"]).max() <= 1e-3 * max(1.0, float(np.abs(d1["final"]).max()))

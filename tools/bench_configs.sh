@@ -6,5 +6,5 @@ timeout 300 python bench.py --config 1 --steps 5 --warmup 1 --no-cpu-baseline > 
 timeout 600 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config3.json 2> gpurun_out/${TAG}_bench_config3.err
 timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config4.json 2> gpurun_out/${TAG}_bench_config4.err
 timeout 600 python bench.py > gpurun_out/${TAG}_bench_config2.json 2> gpurun_out/${TAG}_bench_config2.err
-timeout 900 python bench.py --config 5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${TAG}_bench_config5.json 2> gpurun_out/${TAG}_bench_config5.err
+timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config5.json 2> gpurun_out/${TAG}_bench_config5.err
 for c in 1 2 3 4 5; do cut -c1-700 gpurun_out/${TAG}_bench_config$c.json; tail -2 gpurun_out/${TAG}_bench_config$c.err; done

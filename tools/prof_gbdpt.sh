@@ -10,7 +10,7 @@ B="python tools/gpu_gbdpt_perf.py ${GBDPT_SPP:-2} ${GBDPT_SCENE:-veach_specular}
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o r1 -- $B > $OUT/stdout.log 2> $OUT/kt.err
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r1 -- $B > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r1 -- $B > /dev/null 2> $OUT/pmc_write.err
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY -d $OUT/pmc_sq1 -o r1 -- $B > /dev/null 2> $OUT/pmc_sq1.err
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sq1 -o r1 -- $B > /dev/null 2> $OUT/pmc_sq1.err
 python tools/rocpd_summary.py stats $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.csv
 python tools/rocpd_summary.py pmc $(find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 -name "*.db") > $OUT/pmc.csv
 python tools/profile_json.py ${TAG}_gbdpt $OUT/counters_gbdpt.json $(find $OUT/kt -name "*.db" | head -1) $(find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 -name "*.db")
