@@ -75,7 +75,7 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
 //   k_bd_put      one lane per sample: the five camera-block puts of its sums (GBDPTWorkResult::putSample, gbdpt_proc.cpp:531-533).
 // Same arithmetic per connection as the one-lane form (process_sample, kept as the probe); the sums of a sample are added in arrival order
 // instead of (s, t) order: rounding of the last bits only.
-constexpr int BD_ITEMS_PER_SAMPLE = 96;            // >= 90 = sum over s of the t-range at maxDepth 12 (pair_range)
+constexpr int BD_ITEMS_PER_SAMPLE = 2 * BD_MAX_DEPTH + (BD_MAX_DEPTH - 1) * BD_MAX_DEPTH / 2 + 2;   // >= the sum over s of the t-range at maxDepth d (pair_range): 2 d + (d - 1) d / 2 (90 at 12, 230 at 20)
 constexpr unsigned BD_CHUNK = 1u << 21;            // most samples per chunk: 23 GB of records, 7.2 GB of item lists (nine lists of 96 x 4 B per sample), 0.25 GB of sums
 
 // The two subpaths of every sample (Path::alternatingRandomWalkFromPixel, path.cpp:548-631) with PERSISTENT lanes: the subpaths of a sample have between
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
 //                  as recurrences over it, allocates nothing; adds to the sample's 15 sums;
 //   k_bdg_light    one lane per light-tracing connection (s, 1): the only ones that build paths of their own (clones + four offset paths with manifold
 //                  walks) -- in the lane's transient pool (persistent lanes); splats into the light images.
-constexpr int GD_ITEMS = BD_ITEMS_PER_SAMPLE, GD_LIGHT = 16;       // connection items (t >= 2) / light items (<= NEV) per general sample
+constexpr int GD_ITEMS = BD_ITEMS_PER_SAMPLE, GD_LIGHT = NEV + 3;       // connection items (t >= 2) / light items (<= NEV) per general sample
 // gCount (16 counters of a pass): [0] connection items, [1] light items, [2] k_bdg_shift's cursor, [3] k_bdg_light<1>'s, [4] survivors of connection phase 3,
 // [5] of phase 1, [6] surviving light items, [7] k_bdg_light<2>'s cursor, [8] [9] offset-path items without / with a manifold walk, [10] [11] their cursors.
 __global__ __launch_bounds__(TBLK, 2) void k_bdg_shift(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, unsigned first, unsigned count,
@@ -519,7 +519,7 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
 {
     if (cfg->maxDepth == 0 || cfg->maxDepth < -1) return bfail(GDPT_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // gbdpt.cpp:102-103
     if (cfg->rrDepth <= 0) return bfail(GDPT_ERR_INVALID, "'rrDepth' must be set to a value greater than zero!");                                           // gbdpt.cpp:99-100
-    if (cfg->maxDepth > BD_MAX_DEPTH) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d (the reference's own cap for -1, gbdpt_proc.cpp:103-106)", BD_MAX_DEPTH);
+    if (cfg->maxDepth > BD_MAX_DEPTH) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d (a sample's record holds both subpaths; -1 renders as 12, gbdpt_proc.cpp:103-106)", BD_MAX_DEPTH);
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
     if (s->d.cam.thinlens) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: the thinlens sensor is not carried (perspective only)");
     if (s->specialEmitters) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment and point emitters are not carried (area emitters only)");
@@ -548,7 +548,7 @@ BdConfig make_cfg(const gdpt_gbdpt_config *cfg, double sceneRadius)
 {
     BdConfig c;
     c.sceneRadius = sceneRadius;
-    c.maxDepth = cfg->maxDepth == -1 ? BD_MAX_DEPTH : cfg->maxDepth;                        // gbdpt_proc.cpp:103-106
+    c.maxDepth = cfg->maxDepth == -1 ? BD_DEFAULT_DEPTH : cfg->maxDepth;                    // gbdpt_proc.cpp:103-106
     c.rrDepth = cfg->rrDepth; c.lightImage = cfg->lightImage ? 1 : 0; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
     c.sBase = 0; c.sCount = cfg->spp;
@@ -622,15 +622,16 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     // share instead of failing -- halved again while the allocation itself fails.  GDPT_BD_CHUNK forces a size (tests of the chunk loop).
     const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15 + sizeof(unsigned);   // record + three item lists with two survivor lists each + sums + general-list entry
     // the general form's memory (only scenes that can produce a specular vertex need it): a scratch per persistent lane (two 256-thread blocks per CU:
-    // 131 072 x 35 KB = 4.6 GB on 256 CUs) and the records + item lists of a pass (4 samples per lane: 524 288 x 36 KB = 19 GB of the 288) -- at most a
-    // quarter of what the device has free, halved until it fits
+    // 131 072 x 60 KB = 7.9 GB on 256 CUs) and the records + item lists of a pass (8 samples per lane: 1 048 576 x 55 KB = 58 GB of the 288: a chunk of
+    // 2 M samples of the specular Veach scene lists 650 k -- one pass; with half of that it was a full pass and a quarter-full one, and every pass pays the
+    // tails of its persistent kernels) -- at most a third of what the device has free, halved until it fits
     bool specularScene = false;
     for (const MaterialD &m : s->hostMats) if (m.type == 1 || m.type == 3 || (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold)) specularScene = true;
     if (specularScene && !f->gsamp) {
         size_t freeB = 0, totalB = 0;
-        size_t budget = (size_t)32 << 30;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 4);
-        unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 4 * lanes;
+        size_t budget = (size_t)96 << 30;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 3);
+        unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 8 * lanes;
         if (const char *e = getenv("GDPT_BD_GENERAL_PASS")) cap = (unsigned)std::max<long long>(1, atoll(e));      // (tests of the pass loop)
         const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 5 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
         for (;;) {
@@ -692,8 +693,9 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         // lanes with long tails (a manifold walk is 10-100x an offset path without one); the fast form's dense launches fill the CUs those tails leave
         // idle.  GDPT_BD_NO_OVERLAP=1: one stream (the A/B switch of the measurement in DESIGN.md).
         hipStream_t gs = getenv("GDPT_BD_NO_OVERLAP") ? f->stream : f->gstream;
-        for (unsigned gFirst = 0; gFirst < nGen; gFirst += f->gsCap) {                     // the general form, a pass of <= gsCap samples at a time
-            const unsigned gN = std::min(f->gsCap, nGen - gFirst);
+        const unsigned gPasses = nGen ? (nGen + f->gsCap - 1) / f->gsCap : 0u, gPer = gPasses ? (nGen + gPasses - 1) / gPasses : 0u;   // passes of equal size
+        for (unsigned gFirst = 0; gFirst < nGen; gFirst += gPer) {                        // the general form, a pass of <= gsCap samples at a time
+            const unsigned gN = std::min(gPer, nGen - gFirst);
             BHIPCHK(hipMemsetAsync(f->gCount, 0, sizeof(unsigned) * 16, gs));
             const unsigned lgrid = std::min((gN + TBLK - 1) / TBLK, f->gLanes / TBLK);
             const size_t offStride = (size_t)4 * f->gsCap;

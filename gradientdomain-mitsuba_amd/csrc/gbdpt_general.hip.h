@@ -26,10 +26,10 @@
 
 namespace gdpt_bd {
 
-constexpr int GP_LEN = 32;                         // vertices of a path (the connected path: <= NEV + NSV)
-constexpr int GV_POOL = 144, GE_POOL = 144;        // vertex / edge records of one sample: both subpaths (<= 27), the clones of createShiftablePath (2), four offset paths (<= 28 each: 15 new + 13 re-cloned after a failed walk)
-constexpr int GV_REGION = 28;                      // records of ONE offset path: <= 15 new + 13 re-cloned after a failed walk (GV_POOL >= 29 + 4 x 28)
-constexpr int GM_MAX = 16;                         // vertices of a specular manifold: a path has at most BD_MAX_DEPTH + 3 = 15 vertices, so no chain is ever too long for it
+constexpr int GP_LEN = 32;                         // vertices of a path (the connected path: <= BD_MAX_DEPTH + 4)
+constexpr int GV_REGION = 2 * BD_MAX_DEPTH + 4;    // records of ONE offset path: <= BD_MAX_DEPTH + 3 new + <= BD_MAX_DEPTH + 1 re-cloned after a failed walk
+constexpr int GV_POOL = NSV + NEV + 2 + 4 * GV_REGION, GE_POOL = GV_POOL;   // vertex / edge records of one sample: both subpaths, the clones of createShiftablePath (2), four offset paths
+constexpr int GM_MAX = BD_MAX_DEPTH + 4;           // vertices of a specular manifold: a path has at most BD_MAX_DEPTH + 3 vertices, so no chain is ever too long for it
                                                    // (12 until the fuzz of round 4: a 9-vertex chain between two long subpaths left both half-Jacobians 0 and their ratio NaN)
 
 struct GPath {                                     // Path: m_vertices / m_edges as indices into the pool
@@ -90,7 +90,7 @@ struct MuRec { int l, m; int extra[5]; };
 //             the paths as index lists, the per-offset Jacobians and generalized geometry terms, the prefix products -- what every connection reads;
 //   GScratch  what a LANE needs while it runs manifold code or builds a light path: the manifold's two vertex lists, the dense system, a small
 //             transient pool (indices >= GV_POOL) -- only the shift stage and the light-tracing connections have one (persistent lanes);
-constexpr int GL_POOL = 48;                        // transient records of ONE light-tracing connection: two clones + one offset path at a time (<= 15 new + 13 re-cloned vertices)
+constexpr int GL_POOL = GV_REGION + 4;             // transient records of ONE light-tracing connection: two clones + one offset path at a time
 struct GSamp {
     BV v[GV_POOL]; BE e[GE_POOL];
     int nv, ne;

@@ -27,11 +27,17 @@ enum { ERadiance = 0, EImportance = 1 };                                        
 enum { M_INVALID = 0, M_SOLID = 1, M_AREA = 3, M_DISCRETE = 4 };                           // EMeasure, common.h:56-67
 enum { T_INVALID = 0, T_SENSOR_SUPER = 1, T_EMITTER_SUPER = 2, T_SENSOR_SAMPLE = 4, T_EMITTER_SAMPLE = 8, T_SURFACE = 16 };   // vertex.h:67-87
 
-constexpr int BD_MAX_DEPTH = 12;                   // gbdpt_proc.cpp:103-106: maxDepth -1 renders as 12; the C-ABI takes 1..12
+constexpr int BD_DEFAULT_DEPTH = 12;               // gbdpt_proc.cpp:103-106: maxDepth -1 renders as 12
+#ifndef GDPT_BD_MAX_DEPTH          /* (a development build may size the records for another cap: -DGDPT_BD_MAX_DEPTH=12 is round 4's, tools/build_depth12_lib.sh) */
+#define GDPT_BD_MAX_DEPTH 20
+#endif
+constexpr int BD_MAX_DEPTH = GDPT_BD_MAX_DEPTH;                   // the deepest maxDepth the records are sized for (round 5: 12 until then; the reference takes any positive value,
+                                                   // gbdpt.cpp:102-103 -- a record holds whole subpaths, so a cap there has to be; the C-ABI refuses beyond it and says so)
 constexpr int NSV = BD_MAX_DEPTH + 2;              // sensor subpath records: supernode, sensor sample, up to maxDepth surface vertices
 constexpr int NEV = BD_MAX_DEPTH + 1;              // emitter subpath records: supernode, emitter sample, up to maxDepth - 1 surface vertices
 constexpr int NMIS = NSV + NEV;                    // pdfImp / pdfRad entries of a full path
 constexpr int BD_MAX_LIGHT = 5 * BD_MAX_DEPTH;     // light-image splats of one sample (5 per emitter vertex)
+static_assert(BD_MAX_DEPTH + 4 <= 32, "strategy masks are 32-bit words, items pack s and t in 5 bits each");
 
 struct BdConfig {
     int maxDepth, rrDepth, lightImage, spp;

@@ -34,6 +34,7 @@ bool wf_reserve(WfQueues *, size_t) { return false; }
 void wf_release(WfQueues *) {}
 size_t wf_slots(const WfQueues *) { return 0; }
 int wf_max_iters() { return 0; }
+bool wf_failed(const WfQueues *) { return false; }
 int wf_begin_chunk(WfQueues *, hipStream_t, int, FilmD &, FilmD &) { return -1; }
 int wf_continue(const gdpt_scene *, hipStream_t, const ConfigD &, const FilmD &, WfQueues *, int, int, int) { return -1; }
 }
@@ -1089,7 +1090,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         GDPT_DEV_DUMP_QUEUE(); \
-        if (wfIters > 0 && wf_continue(s, f->stream, c, fd, f->wf, wfIters, stackDepth, sceneBytes) != 0) return tfail(GDPT_ERR_HIP, "wavefront launch failed"); \
+        if (wfIters > 0 && wf_continue(s, f->stream, c, fd, f->wf, wfIters, stackDepth, sceneBytes) != 0) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "wavefront launch failed"); } \
         hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
 #define GDPT_STAGED_F(LDSV, ACCV, WPS) do { \
         if (s->perVertex) GDPT_STAGED(LDSV, ACCV, WPS, true, true); \
@@ -1109,7 +1110,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (useQueue) {
             // (the "finished" mark of every slot of the chunk and the two queue counters)
             THIPCHK(hipMemsetAsync(fd.qRec + (size_t)13 * fd.qCapacity, 0, sizeof(Float) * (size_t)c.sCount * qPixels, f->stream));
-            if (wfIters > 0) { if (wf_begin_chunk(f->wf, f->stream, wfIters, fd, fdc) != 0) return tfail(GDPT_ERR_HIP, "wavefront queues: bad chunk"); }
+            if (wfIters > 0) { if (wf_begin_chunk(f->wf, f->stream, wfIters, fd, fdc) != 0) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "wavefront queues: bad chunk"); } }
             else THIPCHK(hipMemsetAsync(fd.qCount, 0, 2 * sizeof(unsigned), f->stream));
         }
         if (usePrimary) {
@@ -1220,6 +1221,7 @@ int gdpt_film_sync(gdpt_film *f)
     if (!f) return tfail(GDPT_ERR_INVALID, "null film");
     (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     THIPCHK(hipStreamSynchronize(f->stream));
+    if (f->wf && wf_failed(f->wf)) return tfail(GDPT_ERR_HIP, "wavefront pipeline: a ray found its queue full -- the films rendered through it are void");
     return GDPT_OK;
 }
 

@@ -477,7 +477,10 @@ __device__ __forceinline__ bool trace(const SceneView &sv, int *stack /* [STACK_
         for (uint32_t i = 0; i < cnt; i++) {
             Float u, v, t;
             // the whole 80-byte record in one go: read field by field as the test proceeds (k, then the plane, then the edge terms) it is
-            // three dependent LDS / L2 round trips per triangle, and the traversal is bound by exactly that latency chain, not by bandwidth
+            // three dependent LDS / L2 round trips per triangle, and the traversal is bound by exactly that latency chain, not by bandwidth.
+            // (Round 5 measured fetching the leaf's SECOND record before the first test -- a leaf holds one or two triangles -- in the kernels that read
+            //  the tables from HBM: bit-identical hits, atrium frame 61.9 -> 65.1 ms: the 20 extra registers cost the 128-register builds more in spills
+            //  than the overlapped round trip returns.  Not kept.)
             const TriIsect ta = sv.isect[first + i];
             if (tri_test(ta, o, d, mint, maxt, u, v, t)) {
                 if (ANY) return true;

@@ -28,6 +28,7 @@ struct WfD {
     // takes the last list over -- k_continue -- its cursor at [2 it + 1]); behind them per iteration the ray counts of the two queues and the
     // tracing waves' cursors into them
     unsigned *counters;
+    unsigned *err;              // [WF_COUNTERS] of the same allocation, zeroed when the queues are (re)allocated, never per chunk: a ray that found its queue full (wf_failed)
 };
 __host__ __device__ __forceinline__ constexpr unsigned wf_list_count(int it) { return 2u * (unsigned)it; }
 __host__ __device__ __forceinline__ constexpr unsigned wf_ray_count(int it, int kind) { return 2u * (WF_MAX_ITERS + 1) + 4u * (unsigned)it + (unsigned)kind; }
@@ -52,6 +53,11 @@ void wf_destroy(WfQueues *q) { if (q) { wf_release(q); delete q; } }
 size_t wf_bytes_per_slot() { return 2 * (7 * sizeof(Float) + sizeof(unsigned)) + WF_SITES * sizeof(int) + 15 * sizeof(Float) + 2 * sizeof(unsigned); }
 size_t wf_slots(const WfQueues *q) { return q->slots; }
 int wf_max_iters() { return WF_MAX_ITERS - 1; }
+bool wf_failed(const WfQueues *q)                      // (the caller has synchronised the stream)
+{
+    unsigned e = 0;
+    return q && q->d.err && (hipMemcpy(&e, q->d.err, sizeof e, hipMemcpyDeviceToHost) != hipSuccess || e != 0);
+}
 bool wf_reserve(WfQueues *q, size_t cap)
 {
     wf_release(q);
@@ -63,7 +69,8 @@ bool wf_reserve(WfQueues *q, size_t cap)
              hipMalloc((void **)&w.list[k], cap * sizeof(unsigned)) == hipSuccess;
     }
     ok = ok && hipMalloc((void **)&w.resI, cap * WF_SITES * sizeof(int)) == hipSuccess && hipMalloc((void **)&w.resH, cap * 15 * sizeof(Float)) == hipSuccess &&
-         hipMalloc((void **)&w.counters, WF_COUNTERS * sizeof(unsigned)) == hipSuccess;
+         hipMalloc((void **)&w.counters, (WF_COUNTERS + 1) * sizeof(unsigned)) == hipSuccess;
+    if (ok) { w.err = w.counters + WF_COUNTERS; ok = hipMemset(w.err, 0, sizeof(unsigned)) == hipSuccess; }
     if (!ok) { (void)hipGetLastError(); wf_release(q); return false; }
     q->slots = cap;
     return true;
@@ -157,7 +164,9 @@ struct WfTracer {
         if (lane == leader) base = atomicAdd(&rayCount[kind], (unsigned)__popcll(mask));
         base = __shfl(base, leader);
         const unsigned at = base + (unsigned)__popcll(mask & ((1ULL << lane) - 1ULL));
-        if (at < Q.rayCap[kind]) {      // (never false: the queues are sized for every site of every slot)
+        if (at >= Q.rayCap[kind]) atomicOr(Q.err, 1u);   // (the queues are sized for every site of every slot: should that ever not hold, the replay would read a
+                                                        //  stale result -- the render is failed instead, wf_failed / gdpt_film_sync)
+        if (at < Q.rayCap[kind]) {
             Float *r = Q.ray[kind] + at;
             const size_t st = Q.rayCap[kind];
             qst(&r[0], o.x); qst(&r[st], o.y); qst(&r[2 * st], o.z);

@@ -32,6 +32,7 @@ bool wf_reserve(WfQueues *q, size_t slots);         // (re)allocates for `slots`
 void wf_release(WfQueues *q);                       // frees the device memory, keeps the handle
 size_t wf_slots(const WfQueues *q);                 // slots the queues are allocated for
 int wf_max_iters();                                 // most traced bounces wf_continue takes
+bool wf_failed(const WfQueues *q);                  // a ray found its queue full since the queues were allocated (call after synchronising): the films rendered since are void
 // Start of a chunk: zeroes the chunk's counters (asynchronous on `stream`) and points the descriptors at the sample lists: fdRender (the
 // kernel that hands samples over: k_render<STAGED>) appends to the first list, fdContinue (the kernel that takes over what is left after
 // `iters` traced bounces: k_continue) reads the last one.  Both descriptors must already hold the chunk's queue geometry (qCapacity).

@@ -303,7 +303,7 @@ GDPT_API int  gdpt_bsdf_probe(const gdpt_material *m, const double wi[3], int nS
  * det} -- complete, parity-held, and ~25x slower per sample (one lane per sample, its paths in an HBM workspace).  Environment / point emitters
  * and the thinlens sensor return GDPT_ERR_UNSUPPORTED.  Same counter-based random streams as the G-PT path, consumed in the reference's order. */
 typedef struct gdpt_gbdpt_config {
-    int    maxDepth;            /* -1 renders as 12 (gbdpt_proc.cpp:103-106); at most 12                                  */
+    int    maxDepth;            /* -1 renders as 12 (gbdpt_proc.cpp:103-106); at most 20 (a sample record holds whole subpaths) */
     int    rrDepth;             /* 5 (gbdpt.cpp:82)                                                                         */
     int    lightImage;          /* 1 (gbdpt.cpp:83): connect emitter subpaths to the sensor (t = 1 strategies)             */
     int    spp;

@@ -630,7 +630,7 @@ def test_cli_gbdpt_integrator_equals_python_mirror(cli, tmp_path, gpu_required):
         # (the sums of a pixel are fp64 atomics in free order: equal to rounding of the fp32 images and of the two solves fed by them)
         assert img.shape == (30, 40, 3) and np.allclose(img, ref, rtol=2e-4, atol=2e-6), n
     assert "Render time" in open(dest + "-log.txt").read()
-    bad = run(cli, "-o", dest + "x", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xb.replace("bd.xml", "bd.xml"), "-D", "maxDepth=13")
+    bad = run(cli, "-o", dest + "x", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xb.replace("bd.xml", "bd.xml"), "-D", "maxDepth=21")       # (the records hold subpaths of up to 20 + 2 vertices since round 5: 12 until then)
     assert bad.returncode == 1 and "maxDepth" in bad.stderr
     xm = str(tmp_path / "mirror.xml")
     open(xm, "w").write(xs.replace("</scene>", '<shape type="rectangle"><transform name="toWorld"><scale value="50"/><translate x="270" y="200" z="300"/></transform><bsdf type="conductor"><rgb name="eta" value="1,1,1"/><rgb name="k" value="3,3,3"/></bsdf></shape></scene>'))
