@@ -248,7 +248,8 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
 //                  walks) -- in the lane's transient pool (persistent lanes); splats into the light images.
 constexpr int GD_ITEMS = BD_ITEMS_PER_SAMPLE, GD_LIGHT = NEV + 3;       // connection items (t >= 2) / light items (<= NEV) per general sample
 // gCount (16 counters of a pass): [0] connection items, [1] light items, [2] k_bdg_shift's cursor, [3] k_bdg_light<1>'s, [4] survivors of connection phase 3,
-// [5] of phase 1, [6] surviving light items, [7] k_bdg_light<2>'s cursor, [8] [9] offset-path items without / with a manifold walk, [10] [11] their cursors.
+// [5] of phase 1, [6] [14] light offset-path items without / with a manifold walk, [7] [15] k_bdg_light<2>'s cursors into them, [8] [9] offset-path items without / with a
+// manifold walk, [10] [11] their cursors, [12] light items that passed the ray-free test, [13] k_bdg_light<1>'s cursor.
 __global__ __launch_bounds__(TBLK, 2) void k_bdg_shift(SceneD S, BdCam cam, BdConfig cfg, const Sample *__restrict__ recs, const unsigned *__restrict__ genList, unsigned first, unsigned count,
                                                     GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, unsigned *__restrict__ gItems, unsigned *__restrict__ gLight, unsigned *__restrict__ gOff,
                                                     size_t offStride, unsigned *__restrict__ gCount, unsigned long long *__restrict__ stats)
@@ -376,12 +377,15 @@ __global__ __launch_bounds__(TBLK, 2) void k_bdg_connect(SceneD S, BdCam cam, Bd
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)r0); atomicAdd(stats + 1, (unsigned long long)r1); }
 }
 
-// PHASE 1: the base path of every light-tracing connection (its own shiftable path: clones, the sensor connection's visibility ray, MIS weight); splats the
-// primal term, lists the connections that carry anything ([6] of gCount).  PHASE 2: their four offset paths (perturbed sensor direction, propagation, manifold
-// walk, re-connection), the base path built again for what they share with it (its rays not counted twice); splats the gradient terms.
+// PHASE 3: every light-tracing connection's ray-free test (the emitter vertex is connectable and inside the sensor's frustum: most are not) -> survivors.
+// PHASE 1: the base path of a survivor (its own shiftable path: clones, the sensor connection's visibility ray, MIS weight); splats the primal term, lists
+// the connections that carry anything, four items each -- one per offset path -- in one of two lists: offset paths that will walk a manifold, and the others.
+// PHASE 2 (once per list, so that a wave runs one of the two): ONE offset path of a connection per lane (perturbed sensor direction, propagation, manifold walk,
+// re-connection), the base path built again for what the offset shares with it (its rays not counted twice); splats the offset's gradient term.
 template <int PHASE>
 __global__ __launch_bounds__(TBLK, 2) void k_bdg_light(SceneD S, BdCam cam, BdConfig cfg, GSamp *__restrict__ gsamp, GScratch *__restrict__ scratch, const unsigned *__restrict__ in, const unsigned *__restrict__ nIn,
-                                                    unsigned *__restrict__ cursor, unsigned *__restrict__ out, unsigned *__restrict__ nOut, Float *__restrict__ light, unsigned long long *__restrict__ stats)
+                                                    unsigned *__restrict__ cursor, unsigned *__restrict__ out, unsigned *__restrict__ nOut, unsigned *__restrict__ outWalk, unsigned *__restrict__ nOutWalk,
+                                                    Float *__restrict__ light, unsigned long long *__restrict__ stats)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned lane = blockIdx.x * TBLK + threadIdx.x;
@@ -391,29 +395,51 @@ __global__ __launch_bounds__(TBLK, 2) void k_bdg_light(SceneD S, BdCam cam, BdCo
     const int Wd = S.cam.width, H = S.cam.height;
     const size_t plane3 = (size_t)Wd * H * 3;
     unsigned overflow = 0;
-    // (PHASE 2: a wave takes 64 consecutive items = the four offset paths of 16 connections, so that the lanes of a connection stay side by side)
+    // (PHASE 2 and 3: a wave takes 64 consecutive items -- in phase 2 the four offset paths of 16 connections, so that the lanes of a connection stay side by side;
+    //  PHASE 1: a lane takes the next connection when it is done with its own: their work differs by whether the visibility ray is reached at all)
     unsigned wbase = 0;
     for (unsigned i = 0; ; ) {
-        if (PHASE == 2) {
+        if (PHASE != 1) {
             if ((threadIdx.x & 63) == 0) wbase = atomicAdd(cursor, 64u);
             wbase = __shfl(wbase, 0);
             if (wbase >= n) break;
             i = wbase + (threadIdx.x & 63);
-            if (i >= n) continue;
         } else { i = atomicAdd(cursor, 1u); if (i >= n) break; }
-        // an item: PHASE 1 (sample << 10) | (s << 5) | 1; PHASE 2 (sample << 7) | (s << 2) | (offset - 1): one lane per offset path of a surviving connection
-        const unsigned it = in[i];
-        const unsigned smp = PHASE == 1 ? it >> 10 : it >> 7;
-        const int es = PHASE == 1 ? (int)((it >> 5) & 31u) : (int)((it >> 2) & 31u);
-        GTr g(c, gsamp[smp], &scratch[lane]);
-        PairOut po;
-        if (gsamp[smp].voidSample) continue;
-        if (PHASE == 2) g.lightK = (int)(it & 3u) + 1;
-        const bool ok = g.connectPair<true, PHASE>(es, 1, po);
-        if (g.overflow) { overflow += g.overflow; continue; }
-        if (!ok) continue;
-        if (PHASE == 1) { const unsigned at = atomicAdd(nOut, 4u); for (unsigned k = 0; k < 4; k++) out[at + k] = (smp << 7) | ((unsigned)es << 2) | k; }
-        for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, Wd, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
+        bool keep = false;
+        unsigned it = 0;
+        if (i < n) {
+            // an item: PHASE 3 / 1 (sample << 10) | (s << 5) | 1; PHASE 2 (sample << 7) | (s << 2) | (offset - 1)
+            it = in[i];
+            const unsigned smp = PHASE != 2 ? it >> 10 : it >> 7;
+            const int es = PHASE != 2 ? (int)((it >> 5) & 31u) : (int)((it >> 2) & 31u);
+            if (!gsamp[smp].voidSample) {
+                GTr g(c, gsamp[smp], &scratch[lane]);
+                PairOut po;
+                if (PHASE == 2) g.lightK = (int)(it & 3u) + 1;
+                const bool ok = g.connectPair<true, PHASE>(es, 1, po);
+                if (g.overflow) overflow += g.overflow;
+                else if (ok) {
+                    keep = true;
+                    if (PHASE == 1) {
+                        unsigned *o = g.lightWalks ? outWalk : out;
+                        const unsigned at = atomicAdd(g.lightWalks ? nOutWalk : nOut, 4u);
+                        for (unsigned k = 0; k < 4; k++) o[at + k] = (smp << 7) | ((unsigned)es << 2) | k;
+                    }
+                    if (PHASE != 3)
+                        for (int k = 0; k < po.nLight; k++) film_put(light + po.light[k].buffer * plane3, 3, Wd, H, po.light[k].x, po.light[k].y, po.light[k].value, false, stats + 3);   // putLightSample, :514,525
+                }
+            }
+        }
+        if (PHASE == 3) {
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+                const int ln = threadIdx.x & 63, leader = __ffsll((unsigned long long)mask) - 1;
+                unsigned base = 0;
+                if (ln == leader) base = atomicAdd(nOut, (unsigned)__popcll(mask));
+                base = __shfl(base, leader);
+                if (keep) out[base + __popcll(mask & ((1ULL << ln) - 1ULL))] = it;
+            }
+        }
     }
     const unsigned r0 = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), r1 = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0), r3 = __builtin_amdgcn_wave_reduce_add_u32(overflow, 0);
     if ((threadIdx.x & 63) == 0) {
@@ -633,11 +659,11 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 3);
         unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 8 * lanes;
         if (const char *e = getenv("GDPT_BD_GENERAL_PASS")) cap = (unsigned)std::max<long long>(1, atoll(e));      // (tests of the pass loop)
-        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 5 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
+        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 10 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
         for (;;) {
             while ((size_t)lanes * sizeof(GScratch) + (size_t)cap * perSampleG > budget && (lanes > TBLK || cap > TBLK)) { if (cap > lanes) cap /= 2; else lanes = std::max<unsigned>(TBLK, lanes / 2 / TBLK * TBLK); }
             if (hipMalloc((void **)&f->gscratch, sizeof(GScratch) * (size_t)lanes) == hipSuccess && hipMalloc((void **)&f->gsamp, sizeof(GSamp) * (size_t)cap) == hipSuccess &&
-                hipMalloc((void **)&f->gItems, sizeof(unsigned) * 3 * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * 5 * GD_LIGHT * (size_t)cap) == hipSuccess &&
+                hipMalloc((void **)&f->gItems, sizeof(unsigned) * 3 * GD_ITEMS * (size_t)cap) == hipSuccess && hipMalloc((void **)&f->gLight, sizeof(unsigned) * 10 * GD_LIGHT * (size_t)cap) == hipSuccess &&
                 hipMalloc((void **)&f->gOff, sizeof(unsigned) * 8 * (size_t)cap) == hipSuccess) break;
             (void)hipGetLastError();
             hipFree(f->gscratch); hipFree(f->gsamp); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff);
@@ -709,9 +735,16 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
             hipLaunchKernelGGL(k_bdg_connect<1>, dim3(cgridG), dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, (const unsigned *)listA, (const unsigned *)(f->gCount + 4), listB, f->gCount + 5, f->acc, f->stats);
             hipLaunchKernelGGL(k_bdg_connect<2>, dim3(cgridG), dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, (const unsigned *)listB, (const unsigned *)(f->gCount + 5), (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->stats);
             const dim3 lgridL((unsigned)std::min(((size_t)gN * 4 + TBLK - 1) / TBLK, (size_t)f->gLanes / TBLK));
-            unsigned *lightB = f->gLight + (size_t)GD_LIGHT * f->gsCap;
-            hipLaunchKernelGGL(k_bdg_light<1>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)f->gLight, (const unsigned *)(f->gCount + 1), f->gCount + 3, lightB, f->gCount + 6, f->light, f->stats);
-            hipLaunchKernelGGL(k_bdg_light<2>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightB, (const unsigned *)(f->gCount + 6), f->gCount + 7, (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
+            // light lists: [0] every light-tracing connection, [1] the survivors of the ray-free test, [2] / [3] offset-path items without / with a manifold walk (x 4)
+            unsigned *lightF = f->gLight + (size_t)GD_LIGHT * f->gsCap, *lightB = lightF + (size_t)GD_LIGHT * f->gsCap, *lightW = lightB + (size_t)4 * GD_LIGHT * f->gsCap;
+            hipLaunchKernelGGL(k_bdg_light<3>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)f->gLight, (const unsigned *)(f->gCount + 1), f->gCount + 3, lightF, f->gCount + 12,
+                               (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
+            hipLaunchKernelGGL(k_bdg_light<1>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightF, (const unsigned *)(f->gCount + 12), f->gCount + 13, lightB, f->gCount + 6,
+                               lightW, f->gCount + 14, f->light, f->stats);
+            hipLaunchKernelGGL(k_bdg_light<2>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightB, (const unsigned *)(f->gCount + 6), f->gCount + 7, (unsigned *)nullptr, (unsigned *)nullptr,
+                               (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
+            hipLaunchKernelGGL(k_bdg_light<2>, lgridL, dim3(TBLK), 0, gs, s->d, cam, c, f->gsamp, f->gscratch, (const unsigned *)lightW, (const unsigned *)(f->gCount + 14), f->gCount + 15, (unsigned *)nullptr, (unsigned *)nullptr,
+                               (unsigned *)nullptr, (unsigned *)nullptr, f->light, f->stats);
             BHIPCHK(hipGetLastError());
         }
         if (nGen && gs != f->stream) { BHIPCHK(hipEventRecord(f->eG, gs)); }
@@ -724,9 +757,7 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
                 hipLaunchKernelGGL((k_bd_connect<CLSV, 3>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], (const unsigned *)nullptr, listA, nA, f->acc, f->light, f->stats); \
                 hipLaunchKernelGGL((k_bd_connect<CLSV, 1>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)listA, nItems[q], (const unsigned *)nA, listB, nB, f->acc, f->light, f->stats); \
                 hipLaunchKernelGGL((k_bd_connect<CLSV, 2>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)listB, nItems[q], (const unsigned *)nB, (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->light, f->stats); } while (0)
-            if (q == 0) {        // light tracing: two launches (base path, offsets of the survivors)
-                hipLaunchKernelGGL((k_bd_connect<0, 1>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, list, nItems[q], (const unsigned *)nullptr, listB, nB, f->acc, f->light, f->stats);
-                hipLaunchKernelGGL((k_bd_connect<0, 2>), cgrid, dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)listB, nItems[q], (const unsigned *)nB, (unsigned *)nullptr, (unsigned *)nullptr, f->acc, f->light, f->stats);
+            if (q == 0) { BD_CONNECT(0);      // light tracing: its phase 3 is the test whether the sensor sees the emitter vertex at all
             } else if (q == 1) BD_CONNECT(1); else BD_CONNECT(2);
 #undef BD_CONNECT
             BHIPCHK(hipGetLastError());

@@ -152,6 +152,7 @@ struct GTrT {
 #else
 #define GPROF(i, stmt) do { stmt; } while (0)
 #endif
+    bool lightWalks = false;                       // connectPair<true, *>: the light path's offset paths will walk a manifold (set with its base path)
     int lightK = 0;                                // connectPair<true, 2>: 1..4 = build this one of the light path's four offset paths only (0: all four)
     unsigned overflow = 0;                         // a pool or a list ran out (the sample's result is then void: counted, asserted zero by the tests)
     __device__ GTrT(Ctx &c_, GSamp &w_, GScratch *x_) : c(c_), W(w_), X(x_) {}
@@ -1103,7 +1104,7 @@ struct GTrT {
     // a measure that is not EDiscrete stays so), so a connection works on a local copy of the cast vertex and leaves the measures alone, and
     // connections may run side by side in any order.  T1: a light-tracing connection (t == 1): its own shiftable path, four offset paths with
     // their own manifold walks, all in the lane's transient pool (X); t >= 2 needs no X.  Returns false when the connection contributes nothing.
-    // PHASE (as the fast form's connect_pair; light tracing has phases 1 and 2 only -- its filter IS a visibility ray, the sensor connection): 0 = the whole connection (the probe entry); 3 = the part of the base path that
+    // PHASE (as the fast form's connect_pair; light tracing's phase 3 is the test whether the sensor sees the emitter vertex at all): 0 = the whole connection (the probe entry); 3 = the part of the base path that
     // needs no visibility ray (end points connectable, facing each other, throughput): a filter in front of 1 = the base path only: visibility,
     // geometry term, MIS weight -> whether it carries anything and its primal term (most connections end here, and a wave in which one lane goes
     // on to the four offsets while the others wait runs at a fifth of its lanes); 2 = the four offsets of a survivor of phase 1: the base path is
@@ -1121,6 +1122,7 @@ struct GTrT {
         if constexpr (T1) {
             const BV &v1 = V_(W.sensor[0], 1);
             if ((v1.type == T_SENSOR_SAMPLE && !sensor_sample_position(c, V_(emitterSubpath, s).p - v1.p, samplePosX, samplePosY)) || !connectable_gbdpt(c, V_(emitterSubpath, s))) return false;
+            if (PHASE == 3) return true;                                                    // (light tracing's ray-free filter: the emitter vertex is connectable and the sensor sees it)
             X->nlv = X->nle = 0;
             localAlloc = true;
         }
@@ -1149,6 +1151,7 @@ struct GTrT {
             if constexpr (T1) if (k == 0) {
                 pathSuccess[0] = createShiftablePath(X->connectedBase, emitterSubpath, W.sensor[0], s, 1, memPointer);
                 computeMuRec(X->connectedBase, muRec);
+                lightWalks = abs(muRec.extra[1] - muRec.extra[2]) > 1;                       // (its offset paths enter a manifold walk: b and c are not adjacent, mut_manifold.cpp:882)
                 genGeomTermLP[0] = calcSpecularPDFChange(X->connectedBase, muRec.extra[2], true);
                 markV = X->nlv; markE = X->nle;
             }

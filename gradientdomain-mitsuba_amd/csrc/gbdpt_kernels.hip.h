@@ -882,6 +882,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
     Float samplePosX = sm.posX, samplePosY = sm.posY;
     if (T1) {
         if (!sensor_sample_position(c, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) return false;
+        if (PHASE == 3) return true;             // (light tracing's ray-free filter, round 5: most emitter vertices lie outside the sensor's frustum -- its base-path launch ran at 9 % lane utilisation)
     }
     // light-tracing connections (t == 1): the base path Y[0..s-1], Ysc, S1c, X[0] and its four offsets (gbdpt_proc.cpp:356-376)
     BV Ysc, S1c; BE eL;

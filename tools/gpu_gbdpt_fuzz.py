@@ -42,7 +42,7 @@ for seed in range(first, first + count):
         sc = scenes.veach_bidir(W, H, specular=True) if seed % 5 == 0 else scenes.cornell_box(W, H, "random", seed=seed)
     else:
         sc = scenes.veach_bidir(W, H) if seed % 5 == 0 else scenes.cornell_box(W, H, "random_connectable", seed=seed)
-    md = int(rng.choice([-1, 1, 2, 3, 5, 8, 12])); rr = int(rng.choice([1, 3, 5])); li = bool(rng.random() < 0.7)
+    md = int(rng.choice([-1, 1, 2, 3, 5, 8, 12, 16, 20])); rr = int(rng.choice([1, 3, 5])); li = bool(rng.random() < 0.7)
     spp = int(rng.integers(1, 4))
     S = G.Scene(sc); O = go.Scene(sc)
     integ = B.GBDPTIntegrator(maxDepth=md, rrDepth=rr, lightImage=li)
