@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_paths(SceneD S, BdCam cam, BdCon
 // the three item lists.
 __global__ __launch_bounds__(TBLK, 2) void k_bd_shift(SceneD S, BdCam cam, BdConfig cfg, unsigned count, Sample *__restrict__ recs,
                                                    unsigned *__restrict__ items, size_t itemStride, unsigned *__restrict__ itemCount, Float *__restrict__ acc, unsigned long long *__restrict__ stats,
-                                                   unsigned *__restrict__ genList, unsigned *__restrict__ genCount)
+                                                   unsigned *__restrict__ genList, unsigned *__restrict__ genCount, unsigned *__restrict__ offList)
 {
     __shared__ int s_stack[STACK_DEPTH * TBLK];
     const unsigned lid = blockIdx.x * TBLK + threadIdx.x;
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_shift(SceneD S, BdCam cam, BdCon
         // (gbdpt_general.hip.h, k_bd_general): no offsets, no connections here
         const bool general = sm.nY >= 2 && sample_needs_general(c, sm);
         if (general) genList[atomicAdd(genCount, 1u)] = lid;
-        if (sm.nY >= 2 && !general) walk_shift(c, sm);
+        // (round 5: the four offset paths of the sample go to k_bd_offs, one lane each: genCount[1] counts them)
+        if (sm.nY >= 2 && !general && walk_shift_base(c, sm)) { const unsigned at = atomicAdd(genCount + 1, 4u); for (unsigned k = 0; k < 4; k++) offList[at + k] = (lid << 2) | k; }
         for (int k = 0; k < 15; k++) acc[(size_t)lid * 15 + k] = 0.0;
         unsigned n = 0;
         if (!general)
@@ -181,6 +182,23 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_shift(SceneD S, BdCam cam, BdCon
                 }
             }
         }
+    }
+    const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
+}
+
+// One lane per (sample, offset path) of the fast form: generateOffsetPathGBDPT for a chain a - b - c of adjacent vertices (perturbed sensor direction, the new
+// first vertex, its re-connection) and the offset path's prefix products -- four lanes per sample instead of one lane running the four in turn.
+__global__ __launch_bounds__(TBLK, 2) void k_bd_offs(SceneD S, BdCam cam, BdConfig cfg, Sample *__restrict__ recs, const unsigned *__restrict__ offList, const unsigned *__restrict__ nOff,
+                                                  unsigned long long *__restrict__ stats)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    Ctx c;
+    c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
+    const unsigned n = __hip_atomic_load(nOff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned i = blockIdx.x * TBLK + threadIdx.x; i < n; i += gridDim.x * TBLK) {
+        const unsigned it = offList[i];
+        walk_shift_offset(c, recs[it >> 2], (int)(it & 3u));
     }
     const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
     if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
@@ -529,11 +547,11 @@ struct gdpt_gbdpt_film {
     unsigned capacity = 0;
     // the general form (specular chains): the samples that need it; one record per sample of a pass (k_bdg_shift writes it, the connection kernels
     // read it), one scratch per persistent lane of k_bdg_shift / k_bdg_light, the two item lists of a pass and their counters / cursors
-    unsigned *genList = nullptr, *genCount = nullptr;
+    unsigned *genList = nullptr, *genCount = nullptr, *offList = nullptr;     // genCount: [0] entries of the general list, [1] of the fast form's offset-path list
     GSamp *gsamp = nullptr;
     GScratch *gscratch = nullptr;
     unsigned *gItems = nullptr, *gLight = nullptr, *gOff = nullptr, *gCount = nullptr;
-    unsigned gsCap = 0, gLanes = 0;
+    unsigned gsCap = 0, gLanes = 0, gsWant = 0;     // records of a pass, persistent lanes with a scratch, and the call size they were allocated for
     double sceneRadius = 0.0;
 };
 
@@ -613,7 +631,7 @@ void gdpt_gbdpt_film_destroy(gdpt_gbdpt_film *f)
     if (f->eG) hipEventDestroy(f->eG);
     hipFree(f->block); hipFree(f->light); hipFree(f->stats);
     hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc);
-    hipFree(f->genList); hipFree(f->genCount); hipFree(f->gsamp); hipFree(f->gscratch); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff); hipFree(f->gCount);
+    hipFree(f->genList); hipFree(f->offList); hipFree(f->genCount); hipFree(f->gsamp); hipFree(f->gscratch); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff); hipFree(f->gCount);
     if (f->e0) hipEventDestroy(f->e0);
     if (f->e1) hipEventDestroy(f->e1);
     if (f->stream) hipStreamDestroy(f->stream);
@@ -646,20 +664,27 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     // The chunk: at most BD_CHUNK samples, at most what fits 40 % of the memory the device has free right now (+ what this film already holds) --
     // several films on one GPU (strips wrapped onto a device, a G-PT film resident beside this one) or a partitioned / smaller part each get a
     // share instead of failing -- halved again while the allocation itself fails.  GDPT_BD_CHUNK forces a size (tests of the chunk loop).
-    const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15 + sizeof(unsigned);   // record + three item lists with two survivor lists each + sums + general-list entry
+    const size_t perSample = sizeof(Sample) + sizeof(unsigned) * 9 * BD_ITEMS_PER_SAMPLE + sizeof(Float) * 15 + 5 * sizeof(unsigned);   // record + three item lists with two survivor lists each + sums + general-list entry + four offset-path items
     // the general form's memory (only scenes that can produce a specular vertex need it): a scratch per persistent lane (two 256-thread blocks per CU:
     // 131 072 x 60 KB = 7.9 GB on 256 CUs) and the records + item lists of a pass (8 samples per lane: 1 048 576 x 55 KB = 58 GB of the 288: a chunk of
     // 2 M samples of the specular Veach scene lists 650 k -- one pass; with half of that it was a full pass and a quarter-full one, and every pass pays the
     // tails of its persistent kernels) -- at most a third of what the device has free, halved until it fits
     bool specularScene = false;
     for (const MaterialD &m : s->hostMats) if (m.type == 1 || m.type == 3 || (m.type == 2 && 0.5 * (m.alphaU + m.alphaV) < cfg->shiftThreshold)) specularScene = true;
-    if (specularScene && !f->gsamp) {
+    // ... and never more than THIS call can use: a chunk lists at most its own samples (a 24 x 18 film must not take 65 GB -- sixteen fuzz processes on one GPU
+    // found that out), a lane of the persistent kernels has at most four items per listed sample to fetch.  A later, larger call re-allocates.
+    const unsigned wantCap = (unsigned)std::min<long long>((long long)8 * s->numCUs * 2 * TBLK, std::max<long long>(1, std::min<long long>(total, BD_CHUNK)));
+    const unsigned wantLanes = (unsigned)std::min<long long>((long long)s->numCUs * 2 * TBLK, ((long long)4 * wantCap + TBLK - 1) / TBLK * TBLK);
+    if (specularScene && (!f->gsamp || (f->gsWant < wantCap && !getenv("GDPT_BD_GENERAL_PASS")))) {
+        BHIPCHK(hipStreamSynchronize(f->stream)); BHIPCHK(hipStreamSynchronize(f->gstream));
+        hipFree(f->gscratch); hipFree(f->gsamp); hipFree(f->gItems); hipFree(f->gLight); hipFree(f->gOff);
+        f->gscratch = nullptr; f->gsamp = nullptr; f->gItems = nullptr; f->gLight = nullptr; f->gOff = nullptr;
         size_t freeB = 0, totalB = 0;
         size_t budget = (size_t)96 << 30;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, freeB / 3);
-        unsigned lanes = (unsigned)s->numCUs * 2 * TBLK, cap = 8 * lanes;
+        unsigned lanes = wantLanes, cap = wantCap;
         if (const char *e = getenv("GDPT_BD_GENERAL_PASS")) cap = (unsigned)std::max<long long>(1, atoll(e));      // (tests of the pass loop)
-        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 10 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light list with its survivor list + the two offset-path lists
+        const size_t perSampleG = sizeof(GSamp) + sizeof(unsigned) * (3 * GD_ITEMS + 10 * GD_LIGHT + 8);  // record + the connection list with its two survivor lists + the light lists + the two offset-path lists
         for (;;) {
             while ((size_t)lanes * sizeof(GScratch) + (size_t)cap * perSampleG > budget && (lanes > TBLK || cap > TBLK)) { if (cap > lanes) cap /= 2; else lanes = std::max<unsigned>(TBLK, lanes / 2 / TBLK * TBLK); }
             if (hipMalloc((void **)&f->gscratch, sizeof(GScratch) * (size_t)lanes) == hipSuccess && hipMalloc((void **)&f->gsamp, sizeof(GSamp) * (size_t)cap) == hipSuccess &&
@@ -671,7 +696,7 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
             if (budget <= ((size_t)64 << 20)) return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT general-form records: %.1f MB)", ((double)lanes * sizeof(GScratch) + (double)cap * perSampleG) / 1e6);
             budget /= 2;
         }
-        f->gLanes = lanes; f->gsCap = cap;
+        f->gLanes = lanes; f->gsCap = cap; f->gsWant = wantCap;
     }
     unsigned chunk = (unsigned)std::min<long long>(total, BD_CHUNK);
     if (const char *e = getenv("GDPT_BD_CHUNK")) chunk = (unsigned)std::max<long long>(1, std::min<long long>(chunk, atoll(e)));
@@ -685,15 +710,15 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (chunk > f->capacity || (getenv("GDPT_BD_CHUNK") && chunk != f->capacity)) {
         BHIPCHK(hipStreamSynchronize(f->stream));
         for (;;) {
-            hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc); hipFree(f->genList);
-            f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->genList = nullptr; f->capacity = 0;
-            if (hipMalloc((void **)&f->genList, sizeof(unsigned) * (size_t)chunk) == hipSuccess &&
+            hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc); hipFree(f->genList); hipFree(f->offList);
+            f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->genList = nullptr; f->offList = nullptr; f->capacity = 0;
+            if (hipMalloc((void **)&f->genList, sizeof(unsigned) * (size_t)chunk) == hipSuccess && hipMalloc((void **)&f->offList, sizeof(unsigned) * 4 * (size_t)chunk) == hipSuccess &&
                 hipMalloc((void **)&f->recs, sizeof(Sample) * (size_t)chunk) == hipSuccess && hipMalloc((void **)&f->items, sizeof(unsigned) * 9 * (size_t)chunk * BD_ITEMS_PER_SAMPLE) == hipSuccess &&
                 hipMalloc((void **)&f->itemCount, sizeof(unsigned) * 9) == hipSuccess && hipMalloc((void **)&f->acc, sizeof(Float) * 15 * (size_t)chunk) == hipSuccess) break;
             (void)hipGetLastError();
             if (chunk <= 1024) {
-                hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc); hipFree(f->genList);
-                f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->genList = nullptr;
+                hipFree(f->recs); hipFree(f->items); hipFree(f->itemCount); hipFree(f->acc); hipFree(f->genList); hipFree(f->offList);
+                f->recs = nullptr; f->items = nullptr; f->itemCount = nullptr; f->acc = nullptr; f->genList = nullptr; f->offList = nullptr;
                 return bfail(GDPT_ERR_HIP, "Out of memory! (G-BDPT workspace for %u samples: %.1f MB)", chunk, (double)perSample * chunk / 1e6);
             }
             chunk /= 2;
@@ -707,7 +732,8 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
         BHIPCHK(hipMemsetAsync(f->genCount, 0, sizeof(unsigned) * 2, f->stream));
         const unsigned pgrid = std::min<unsigned>((count + TBLK - 1) / TBLK, (unsigned)s->numCUs * 2u);      // persistent: the grid that is resident at 2 waves per SIMD
         hipLaunchKernelGGL(k_bd_paths, dim3(pgrid), dim3(TBLK), 0, f->stream, s->d, cam, c, x0, y0, x1, y1, first, count, f->recs, f->stats);
-        hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats, f->genList, f->genCount);
+        hipLaunchKernelGGL(k_bd_shift, dim3((count + TBLK - 1) / TBLK), dim3(TBLK), 0, f->stream, s->d, cam, c, count, f->recs, f->items, itemStride, f->itemCount, f->acc, f->stats, f->genList, f->genCount, f->offList);
+        hipLaunchKernelGGL(k_bd_offs, dim3(std::min<unsigned>((4 * count + TBLK - 1) / TBLK, (unsigned)s->numCUs * 32u)), dim3(TBLK), 0, f->stream, s->d, cam, c, f->recs, (const unsigned *)f->offList, (const unsigned *)(f->genCount + 1), f->stats);
         BHIPCHK(hipGetLastError());
         unsigned nItems[3] = {0, 0, 0}, nGen = 0;
         BHIPCHK(hipMemcpyAsync(nItems, f->itemCount, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, f->stream));

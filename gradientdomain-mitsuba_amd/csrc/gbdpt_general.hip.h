@@ -233,13 +233,13 @@ struct GTrT {
         return true;
     }
     // PathVertex::connect with explicit measures, vertex.cpp:1348-1370
-    __device__ bool gConnect(const BV *pred, BV &vs, BE &edge, BV &vt, const BV *succ, int vsMeasure, int vtMeasure)
+    __device__ bool gConnect(const BV *pred, BV &vs, BE &edge, BV &vt, const BV *succ, int vsMeasure, int vtMeasure, bool knownVisible = false)
     {
         if (vs.type == T_EMITTER_SUPER) { if (!bv_cast_emitter(c, vt)) return false; }
         else if (vt.type == T_SENSOR_SUPER) return false;                                    // (no sensor shapes)
         if (!gUpdate(vs, pred, &vt, EImportance, vsMeasure)) return false;
         if (!gUpdate(vt, succ, &vs, ERadiance, vtMeasure)) return false;
-        return edge_connect(c, edge, vs, vt);
+        return edge_connect(c, edge, vs, vt, knownVisible);
     }
     // PathVertex::perturbDirection, vertex.cpp:488-679: the sensor sample, or a glossy surface vertex of a chain
     __device__ bool gPerturbDirection(BV &v, const BV *pred, const BE *predEdge, BE &succEdge, BV &succ, d3 d, Float dist, int mode)
@@ -978,7 +978,7 @@ struct GTrT {
     }
 
     // ---- GBDPTRenderer, gbdpt_proc.cpp ----
-    __device__ bool createShiftablePath(GPath &connectedPath, GPath &emitterSubpath, GPath &sensorSubpath, int s, int t, int &memPointer)   // :600-662
+    __device__ bool createShiftablePath(GPath &connectedPath, GPath &emitterSubpath, GPath &sensorSubpath, int s, int t, int &memPointer, bool knownVisible = false)   // :600-662
     {
         connectedPath.clear();
         while (!connectable_gbdpt(c, V_(sensorSubpath, t))) { t--; sensorSubpath.nv--; sensorSubpath.ne--; }
@@ -991,7 +991,7 @@ struct GTrT {
         for (int i = t - 1; i >= 0; i--) { connectedPath.pushV(sensorSubpath.v[i]); connectedPath.pushE(sensorSubpath.e[i]); }
         const bool pathSuccess = gConnect(VN(connectedPath, memPointer - 1), V_(connectedPath, memPointer), E_(connectedPath, memPointer), V_(connectedPath, memPointer + 1),
                                           VN(connectedPath, memPointer + 2),
-                                          bv_connectable(V_(connectedPath, memPointer)) ? M_AREA : M_DISCRETE, bv_connectable(V_(connectedPath, memPointer + 1)) ? M_AREA : M_DISCRETE);
+                                          bv_connectable(V_(connectedPath, memPointer)) ? M_AREA : M_DISCRETE, bv_connectable(V_(connectedPath, memPointer + 1)) ? M_AREA : M_DISCRETE, knownVisible);
         if (t == 1) { BV &s1 = V_(connectedPath, connectedPath.nv - 2); sensor_sample_position(c, V_(connectedPath, connectedPath.nv - 3).p - s1.p, s1.u, s1.v); }
         return pathSuccess;
     }
@@ -1149,7 +1149,8 @@ struct GTrT {
             Float importancePdfTmp = W.impP[s], radiancePdfTmp = W.radP[T1 ? 0 : k][t];
             const GPath *sensorSubpathTmp = &W.sensor[k], *emitterSubpathTmp = &emitterSubpath;
             if constexpr (T1) if (k == 0) {
-                pathSuccess[0] = createShiftablePath(X->connectedBase, emitterSubpath, W.sensor[0], s, 1, memPointer);
+                // (phase 2 runs on the survivors of phase 1: the base path's sensor connection and -- below -- its connection edge were traced there and found free)
+                pathSuccess[0] = createShiftablePath(X->connectedBase, emitterSubpath, W.sensor[0], s, 1, memPointer, PHASE == 2);
                 computeMuRec(X->connectedBase, muRec);
                 lightWalks = abs(muRec.extra[1] - muRec.extra[2]) > 1;                       // (its offset paths enter a manifold walk: b and c are not adjacent, mut_manifold.cpp:882)
                 genGeomTermLP[0] = calcSpecularPDFChange(X->connectedBase, muRec.extra[2], true);
@@ -1206,7 +1207,7 @@ struct GTrT {
                 }
                 if (is_zero(value[k]) || valuePdf[k] == 0) break;
                 if (PHASE == 3) return true;                                                // (k == 0: both end points face each other and carry throughput -- worth a visibility ray)
-                const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connectionEdge, vs, *vtP);
+                const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connectionEdge, vs, *vtP, PHASE == 2 && k == 0);
                 if (k == 0) successConnectBase = successConnect;
                 if (!successConnect) { value[k] = mk(0.0); break; }
                 geomTerm = (k > 0 && t > vert_b) ? geomTermBase : gEdgeEvalCached(connectionEdge, vs, *vtP, 0x04 | 0x08 | 0x10 | 0x20);

@@ -233,7 +233,9 @@ __device__ __forceinline__ bool edge_extend(Ctx &c, BE &e, d3 o, d3 d, BV &succ,
     return true;
 }
 // PathEdge::connect, edge.cpp:221-287
-__device__ __forceinline__ bool edge_connect(Ctx &c, BE &e, const BV &vs, const BV &vt)
+// (knownVisible: the caller has traced this very segment in an earlier launch and found it free -- phase 2 of a connection builds its base path again for the
+//  state the offsets share with it; the ray is neither traced nor counted a second time)
+__device__ __forceinline__ bool edge_connect(Ctx &c, BE &e, const BV &vs, const BV &vt, bool knownVisible = false)
 {
     if (vs.type == T_EMITTER_SUPER || vt.type == T_SENSOR_SUPER) {
         const Float rad = vt.type == T_SENSOR_SUPER ? 1.0 : 0.0;
@@ -242,14 +244,14 @@ __device__ __forceinline__ bool edge_connect(Ctx &c, BE &e, const BV &vs, const 
         e.d = vs.p - vt.p;
         e.length = len(e.d);
         e.d = e.d / e.length;
-        if (any_hit(c, vt.p, e.d, bv_on_surface(vt) ? GD_EPSILON : 0.0, e.length * (bv_on_surface(vs) ? (1 - GD_SHADOW_EPSILON) : 1.0))) return false;
+        if (!knownVisible && any_hit(c, vt.p, e.d, bv_on_surface(vt) ? GD_EPSILON : 0.0, e.length * (bv_on_surface(vs) ? (1 - GD_SHADOW_EPSILON) : 1.0))) return false;
         e.tr[0] = e.tr[1] = 1.0;
     }
     e.d = -e.d;
     return true;
 }
 // PathEdge::pathConnectAndCollapse, edge.cpp:442-574 (no media, no ENull BSDF: a surface in between is an occluder)
-__device__ __forceinline__ bool edge_path_connect(Ctx &c, BE &e, const BV &vs, const BV &vt)
+__device__ __forceinline__ bool edge_path_connect(Ctx &c, BE &e, const BV &vs, const BV &vt, bool knownVisible = false)
 {
     if (vs.type == T_EMITTER_SUPER || vt.type == T_SENSOR_SUPER) {
         const Float rad = vt.type == T_SENSOR_SUPER ? 1.0 : 0.0;
@@ -261,7 +263,7 @@ __device__ __forceinline__ bool edge_path_connect(Ctx &c, BE &e, const BV &vs, c
         e.d = e.d / e.length;
         e.tr[0] = e.tr[1] = 1.0;
         Hit h;
-        if (closest_hit(c, vt.p, e.d, bv_on_surface(vt) ? GD_EPSILON : 0.0, e.length * (bv_on_surface(vs) ? (1 - GD_SHADOW_EPSILON) : 1.0), h)) return false;
+        if (!knownVisible && closest_hit(c, vt.p, e.d, bv_on_surface(vt) ? GD_EPSILON : 0.0, e.length * (bv_on_surface(vs) ? (1 - GD_SHADOW_EPSILON) : 1.0), h)) return false;
     }
     e.d = -e.d;
     return true;
@@ -579,13 +581,13 @@ __device__ bool bv_update(const Ctx &c, BV &v, const BV *pred, const BV *succ, i
     return true;
 }
 // PathVertex::connect with explicit measures, vertex.cpp:1348-1370 (no sensor shapes: a connection into the sensor supernode cannot occur here)
-__device__ bool bv_connect(Ctx &c, const BV *pred, BV &vs, BE &edge, BV &vt, const BV *succ, int vsMeasure, int vtMeasure)
+__device__ bool bv_connect(Ctx &c, const BV *pred, BV &vs, BE &edge, BV &vt, const BV *succ, int vsMeasure, int vtMeasure, bool knownVisible = false)
 {
     if (vs.type == T_EMITTER_SUPER) { if (!bv_cast_emitter(c, vt)) return false; }
     else if (vt.type == T_SENSOR_SUPER) return false;
     if (!bv_update(c, vs, pred, &vt, EImportance, vsMeasure)) return false;
     if (!bv_update(c, vt, succ, &vs, ERadiance, vtMeasure)) return false;
-    return edge_connect(c, edge, vs, vt);
+    return edge_connect(c, edge, vs, vt, knownVisible);
 }
 
 // ---- offset paths: ManifoldPerturbation::generateOffsetPathGBDPT, mut_manifold.cpp:806-936, for a chain a - b - c of adjacent vertices -------
@@ -807,9 +809,11 @@ __device__ __noinline__ bool walk_paths(Ctx &c, Sample &sm, int px, int py)
     if (sm.nY < 2) { sm.nY = 0; return false; }                                             // (no emitter could be sampled: a scene without power; no connections)
     return true;
 }
-__device__ __noinline__ void walk_shift(Ctx &c, Sample &sm)
+// walk_shift in two stages, so that the frame kernels can run them on different lanes (round 5): the base stage (one lane per sample: the connected base
+// path, the emitter side's prefix products, the base path's own) and ONE offset path (one lane per sample and offset: the four depend on the connected base
+// path only, and each writes its own record and products).  Returns whether the sample has offset paths at all.
+__device__ __noinline__ bool walk_shift_base(Ctx &c, Sample &sm)
 {
-    const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                           // :101,265
     // ---- createShiftablePath(connectPath, emitterSubpath, sensorSubpath, 1, last), gbdpt_proc.cpp:600-662 ----
     const int T = sm.nX - 1;
     sm.connS = 1;
@@ -820,16 +824,6 @@ __device__ __noinline__ void walk_shift(Ctx &c, Sample &sm)
     bv_cast_emitter(c, sm.XTc);
     bv_connect(c, sm.connS == 1 ? &sm.Y[0] : nullptr, sm.Y1c, sm.eConn, sm.XTc, T >= 1 ? &sm.X[T - 1] : nullptr, bv_connectable(sm.Y1c) ? M_AREA : M_DISCRETE, bv_connectable(sm.XTc) ? M_AREA : M_DISCRETE);
     if (T == 1) sensor_sample_position(c, sm.Y1c.p - sm.XTc.p, sm.XTc.u, sm.XTc.v);          // (the clone's film position: never read again)
-    // connectPath = [Y0 (connS = 1), Y1c, XTc, X[T-1], ..., X[2], X[1], X[0]]: a = X[1], b = X[2] (or XTc if T == 2), c = X[3] (XTc if T == 3, Y1c if T == 2)
-    // muRec.extra[0] = a <= 2 (gbdpt_proc.cpp:200) <=> the connected path has at most four vertices: T + connS < 3
-    const bool shiftable = T + sm.connS >= 3 && T >= 2;
-    for (int k = 0; k < 4; k++) {
-        if (!shiftable) continue;
-        const BV &srcB = T == 2 ? sm.XTc : sm.X[2];
-        const BV &srcC = T == 2 ? sm.Y1c : (T == 3 ? sm.XTc : sm.X[3]);
-        const BV *predC = T == 2 ? &sm.Y[0] : (T == 3 ? &sm.Y1c : (T == 4 ? &sm.XTc : &sm.X[4]));
-        generate_offset(c, sm.X[1], sm.X[0], sm.EX[0], srcB, srcC, predC, sm.EX[1].length, shifts[k][0], shifts[k][1], false, sm.off[k]);
-    }
     // ---- combineImportanceData / combineRadianceData, gbdpt_proc.cpp:544-565 ----
     const int nE = sm.nY, nS = sm.nX;
     sm.impW[0] = mk(1.0); sm.impP[0] = 1.0;
@@ -840,15 +834,38 @@ __device__ __noinline__ void walk_shift(Ctx &c, Sample &sm)
     for (int k = 0; k <= 4; k++) {
         sm.radW[k][0] = mk(1.0); sm.radP[k][0] = 1.0;
         for (int i = 1; i < nS; ++i) { sm.radW[k][i] = mk(0.0); sm.radP[k][i] = 0.0; }
-        if (k > 0 && !sm.off[k - 1].success) continue;
-        // sensorSubpath[k] has vertexCount = nS + connS + 1 >= nS entries for a successful shift
-        for (int i = 1; i < nS; ++i) {
-            const BV &pv = SV(sm, k, i - 1);
-            const BE &pe = SE(sm, k, i - 1);
-            sm.radW[k][i] = sm.radW[k][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
-            sm.radP[k][i] = sm.radP[k][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
-        }
     }
+    for (int i = 1; i < nS; ++i) {
+        const BV &pv = SV(sm, 0, i - 1);
+        const BE &pe = SE(sm, 0, i - 1);
+        sm.radW[0][i] = sm.radW[0][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
+        sm.radP[0][i] = sm.radP[0][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+    }
+    // connectPath = [Y0 (connS = 1), Y1c, XTc, X[T-1], ..., X[2], X[1], X[0]]: a = X[1], b = X[2] (or XTc if T == 2), c = X[3] (XTc if T == 3, Y1c if T == 2)
+    // muRec.extra[0] = a <= 2 (gbdpt_proc.cpp:200) <=> the connected path has at most four vertices: T + connS < 3
+    return T + sm.connS >= 3 && T >= 2;
+}
+__device__ __noinline__ void walk_shift_offset(Ctx &c, Sample &sm, int k)                   // k = 0..3: sm.off[k], radW / radP[k + 1]
+{
+    const Float shifts[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};                           // :101,265
+    const int T = sm.nX - 1, nS = sm.nX;
+    const BV &srcB = T == 2 ? sm.XTc : sm.X[2];
+    const BV &srcC = T == 2 ? sm.Y1c : (T == 3 ? sm.XTc : sm.X[3]);
+    const BV *predC = T == 2 ? &sm.Y[0] : (T == 3 ? &sm.Y1c : (T == 4 ? &sm.XTc : &sm.X[4]));
+    generate_offset(c, sm.X[1], sm.X[0], sm.EX[0], srcB, srcC, predC, sm.EX[1].length, shifts[k][0], shifts[k][1], false, sm.off[k]);
+    if (!sm.off[k].success) return;
+    // sensorSubpath[k + 1] has vertexCount = nS + connS + 1 >= nS entries for a successful shift
+    for (int i = 1; i < nS; ++i) {
+        const BV &pv = SV(sm, k + 1, i - 1);
+        const BE &pe = SE(sm, k + 1, i - 1);
+        sm.radW[k + 1][i] = sm.radW[k + 1][i - 1] * pv.w[ERadiance] * pv.rr * pe.tr[ERadiance];
+        sm.radP[k + 1][i] = sm.radP[k + 1][i - 1] * pv.pdf[ERadiance] * pv.rr * pe.tr[ERadiance];
+    }
+}
+__device__ __noinline__ void walk_shift(Ctx &c, Sample &sm)
+{
+    if (walk_shift_base(c, sm))
+        for (int k = 0; k < 4; k++) walk_shift_offset(c, sm, k);
 }
 __device__ __forceinline__ void walk_sample(Ctx &c, Sample &sm, int px, int py) { if (walk_paths(c, sm, px, py)) walk_shift(c, sm); }
 // the range of sensor vertices connected to emitter vertex s (gbdpt_proc.cpp:311-319)
@@ -889,7 +906,8 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
     bool pathSuccess0 = true;
     if (T1) {                                                                          // createShiftablePath(connectedBasePath, emitter, sensor, s, 1)
         Ysc = sm.Y[s]; S1c = sm.X[1]; be_clear(eL);
-        pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE);
+        // (phase 2 runs on the survivors of phase 1: their base path's sensor connection and -- below -- connection edge were traced there and found free)
+        pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE, PHASE == 2);
         sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
     }
     if (PHASE == 1 && !T1) { c.nClosest = nClosest0; c.nShadow = nShadow0; }               // (the rays up to here were counted by phase 3; light tracing has no phase 3:
@@ -957,7 +975,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
             }
             if (is_zero(value[k]) || valuePdf[k] == 0) break;
             if (PHASE == 3) return true;                                                    // (k == 0: both end points face each other and carry throughput -- worth a visibility ray)
-            const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connEdge, *vsP, *vtP);
+            const bool successConnect = (k > 0 && t > vert_b) ? successConnectBase : edge_path_connect(c, connEdge, *vsP, *vtP, PHASE == 2 && k == 0);
             if (k == 0) successConnectBase = successConnect;
             if (!successConnect) { value[k] = mk(0.0); break; }
             geomTerm = (k > 0 && t > vert_b) ? geomBase : edge_geometry_term(c, connEdge, *vsP, *vtP);
