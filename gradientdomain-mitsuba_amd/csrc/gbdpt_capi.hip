@@ -91,7 +91,7 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_paths(SceneD S, BdCam cam, BdCon
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
     const unsigned total = gridDim.x * TBLK;
     unsigned next = blockIdx.x * TBLK + threadIdx.x, lid = 0, done = 0;
-    const int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth + 1;                  // gbdpt_proc.cpp:110-122: degenerate (pinhole) sensor, hittable emitters
+    const int emitterDepth = cfg.maxDepth + (S.cam.thinlens ? 1 : 0), sensorDepth = cfg.maxDepth + 1;   // gbdpt_proc.cpp:110-122: one more emitter step unless the sensor is a point (pinhole); hittable emitters
     bool have = false, walkT = false, walkS = false;
     int s = 0, t = 0;
     d3 thrS = mk(1.0), thrT = mk(1.0);
@@ -565,7 +565,8 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
     if (cfg->rrDepth <= 0) return bfail(GDPT_ERR_INVALID, "'rrDepth' must be set to a value greater than zero!");                                           // gbdpt.cpp:99-100
     if (cfg->maxDepth > BD_MAX_DEPTH) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d (a sample's record holds both subpaths; -1 renders as 12, gbdpt_proc.cpp:103-106)", BD_MAX_DEPTH);
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
-    if (s->d.cam.thinlens) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: the thinlens sensor is not carried (perspective only)");
+    if (s->d.cam.thinlens && (cfg->maxDepth < 0 ? BD_DEFAULT_DEPTH : cfg->maxDepth) > BD_MAX_DEPTH - 1)   // (the extra emitter step of a non-degenerate sensor, gbdpt_proc.cpp:117-118, needs one more record)
+        return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d with the thinlens sensor", BD_MAX_DEPTH - 1);
     if (s->specialEmitters) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment and point emitters are not carried (area emitters only)");
     // (round 4: Dirac BSDFs and rough conductors below shiftThreshold are carried -- samples that meet one run the general form, gbdpt_general.hip.h)
     return GDPT_OK;
@@ -585,6 +586,7 @@ BdCam make_cam(const gdpt_scene *s)
     cam.dir.x = cd.m[2]; cam.dir.y = cd.m[6]; cam.dir.z = cd.m[10];
     cam.rectX = cd.tanHalf; cam.rectY = cd.tanHalf / cd.aspect;
     cam.normalization = 1.0 / ((2 * cam.rectX) * (2 * cam.rectY));
+    cam.aperturePdf = cd.thinlens ? 1 / (GD_PI * cd.apertureRadius * cd.apertureRadius) : 0.0;
     return cam;
 }
 

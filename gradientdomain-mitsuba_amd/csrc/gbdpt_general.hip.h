@@ -247,7 +247,7 @@ struct GTrT {
         be_clear(succEdge); bv_clear(succ);
         if (v.degenerate) return false;
         if (v.type == T_SENSOR_SAMPLE) {
-            const Float value = importance(c, cam_to_local(c, d)), prob = value;
+            const Float value = sensor_direction(c, v.p, d), prob = value;
             if (value == 0 || prob <= 0x1p-1024) return false;
             v.w[EImportance] = mk(value) * (1.0 / fabs(dot(d, v.n)));
             v.w[ERadiance] = mk(value) / prob;
@@ -756,8 +756,8 @@ struct GTrT {
         const CameraD &cam = c.S->cam;
         const BV &sensor = V_(source, source.length() - 1);
         const Float ppx = sensor.u + offX, ppy = sensor.v + offY;
-        const d3 rd = cam_to_world(c, sample_to_camera_dir(c, ppx * cam.invW, ppy * cam.invH));
-        const Float focusDistance = cam.farClip / fabs(dot(c.cam.dir, rd));
+        const d3 rd = cam_to_world(c, centre_ray_dir(c, ppx * cam.invW, ppy * cam.invH));
+        const Float focusDistance = focus_distance(cam) / fabs(dot(c.cam.dir, rd));
         const d3 d = normalize((c.cam.pos + rd * focusDistance) - V_(source, a).p);
         return gPerturbDirection(vertex, &pred, &predEdge, succEdge, succ, d, succEdge_old.length, ERadiance);
     }
@@ -849,7 +849,7 @@ struct GTrT {
         couldConnectBehindB = gConnect(VN(proposal, q - 1), V_(proposal, q), E_(proposal, q), V_(proposal, q + 1), VN(proposal, q + 2),
                                        bv_connectable(V_(source, q)) ? M_AREA : M_DISCRETE, bv_connectable(V_(source, q + 1)) ? M_AREA : M_DISCRETE) ? 1 : 0;
         if (lightPath && !couldConnectBehindB) return false;
-        if (m >= k - 1) { BV &s1 = V_(proposal, k - 1); sensor_sample_position(c, V_(proposal, k - 2).p - s1.p, s1.u, s1.v); }
+        if (m >= k - 1) { BV &s1 = V_(proposal, k - 1); sensor_sample_position(c, s1.p, V_(proposal, k - 2).p - s1.p, s1.u, s1.v); }
         for (int i = 0; i <= proposal.length(); i++) {
             if (proposal.v[i] == source.v[i]) continue;                                  // (a shared record: rr and componentType are its own already -- and other lanes may be reading it)
             BV &pv = V_(proposal, i); const BV &sv = V_(source, i);
@@ -992,7 +992,7 @@ struct GTrT {
         const bool pathSuccess = gConnect(VN(connectedPath, memPointer - 1), V_(connectedPath, memPointer), E_(connectedPath, memPointer), V_(connectedPath, memPointer + 1),
                                           VN(connectedPath, memPointer + 2),
                                           bv_connectable(V_(connectedPath, memPointer)) ? M_AREA : M_DISCRETE, bv_connectable(V_(connectedPath, memPointer + 1)) ? M_AREA : M_DISCRETE, knownVisible);
-        if (t == 1) { BV &s1 = V_(connectedPath, connectedPath.nv - 2); sensor_sample_position(c, V_(connectedPath, connectedPath.nv - 3).p - s1.p, s1.u, s1.v); }
+        if (t == 1) { BV &s1 = V_(connectedPath, connectedPath.nv - 2); sensor_sample_position(c, s1.p, V_(connectedPath, connectedPath.nv - 3).p - s1.p, s1.u, s1.v); }
         return pathSuccess;
     }
 
@@ -1121,7 +1121,7 @@ struct GTrT {
         Float samplePosX = V_(W.sensor[0], 1).u, samplePosY = V_(W.sensor[0], 1).v;
         if constexpr (T1) {
             const BV &v1 = V_(W.sensor[0], 1);
-            if ((v1.type == T_SENSOR_SAMPLE && !sensor_sample_position(c, V_(emitterSubpath, s).p - v1.p, samplePosX, samplePosY)) || !connectable_gbdpt(c, V_(emitterSubpath, s))) return false;
+            if ((v1.type == T_SENSOR_SAMPLE && !sensor_sample_position(c, v1.p, V_(emitterSubpath, s).p - v1.p, samplePosX, samplePosY)) || !connectable_gbdpt(c, V_(emitterSubpath, s))) return false;
             if (PHASE == 3) return true;                                                    // (light tracing's ray-free filter: the emitter vertex is connectable and the sensor sees it)
             X->nlv = X->nle = 0;
             localAlloc = true;

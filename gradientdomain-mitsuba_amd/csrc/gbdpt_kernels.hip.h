@@ -50,6 +50,7 @@ struct BdCam {                                     // perspective sensor quantit
     Float invLin[9];                               // linear part of the inverse camera-to-world (trafo.inverse() applied to a direction)
     d3 pos, dir;                                   // trafo(Point(0)), trafo(Vector(0, 0, 1))
     Float rectX, rectY, normalization;             // m_imageRect half extents, 1 / its area
+    Float aperturePdf;                             // `thinlens` sensor (CameraD::thinlens): 1 / (pi r^2), thinlens.cpp:213 (0 for the pinhole)
 };
 
 struct BV {                                        // PathVertex
@@ -133,18 +134,60 @@ __device__ __forceinline__ Float importance(const Ctx &c, d3 d)
     if (!(px >= -c.cam.rectX && px <= c.cam.rectX && py >= -c.cam.rectY && py <= c.cam.rectY)) return 0.0;
     return c.cam.normalization * inv * inv * inv;
 }
+// m_cameraToSample(P).xy for crop == film: the film position, in [0,1]^2, that the camera-space point P projects to
+__device__ __forceinline__ void camera_to_sample(const CameraD &cam, d3 P, Float &sx, Float &sy)
+{
+    sx = 0.5 * (1 - P.x / (P.z * cam.tanHalf)); sy = 0.5 * (1 - P.y * cam.aspect / (P.z * cam.tanHalf));
+}
+__device__ __forceinline__ d3 cam_to_local_point(const Ctx &c, d3 p) { return mul3(c.cam.invLin, p - c.cam.pos); }   // trafo.inverse().transformAffine(p)
+// ThinLensCamera::importance, thinlens.cpp:231-291: p a point of the aperture, d the direction from it (camera space); the pixel is the one whose focus-plane
+// point the ray passes through
+__device__ __forceinline__ Float importance_lens(const Ctx &c, d3 p, d3 d)
+{
+    const Float cosT = d.z;
+    if (cosT <= 0) return 0.0;
+    const Float inv = 1.0 / cosT;
+    Float sx, sy;
+    camera_to_sample(c.S->cam, p + d * (c.S->cam.focusDistance * inv), sx, sy);
+    if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return 0.0;
+    return c.cam.normalization * inv * inv * inv;
+}
+// Sensor::evalDirection == pdfDirection of a sensor sample at world position p towards world direction d (perspective.cpp:373-391, thinlens.cpp:420-437)
+__device__ __forceinline__ Float sensor_direction(const Ctx &c, d3 p, d3 d)
+{
+    return c.S->cam.thinlens ? importance_lens(c, cam_to_local_point(c, p), cam_to_local(c, d)) : importance(c, cam_to_local(c, d));
+}
 // normalize(m_sampleToCamera(Point(sx, sy, 0))), perspective.cpp:150-156 written out for crop == film
 __device__ __forceinline__ d3 sample_to_camera_dir(const Ctx &c, Float sxn, Float syn)
 {
     const CameraD &cam = c.S->cam;
     return normalize(mk((1 - 2 * sxn) * cam.nearClip * cam.tanHalf, (1 - 2 * syn) / cam.aspect * cam.nearClip * cam.tanHalf, cam.nearClip));
 }
-// PerspectiveCameraImpl::getSamplePosition, perspective.cpp:393-410
-__device__ __forceinline__ bool sensor_sample_position(const Ctx &c, d3 dWorld, Float &ox, Float &oy)
+// the direction of sensor->sampleRay(ray, film position, aperture sample (0.5, 0.5)) in camera space: perspective.cpp:249-269; thinlens.cpp:293-322, whose
+// aperture point is then the lens centre: normalize(focusP - 0)
+__device__ __forceinline__ d3 centre_ray_dir(const Ctx &c, Float sxn, Float syn)
+{
+    const CameraD &cam = c.S->cam;
+    if (!cam.thinlens) return sample_to_camera_dir(c, sxn, syn);
+    const d3 nearP = mk((1 - 2 * sxn) * cam.nearClip * cam.tanHalf, (1 - 2 * syn) / cam.aspect * cam.nearClip * cam.tanHalf, cam.nearClip);
+    return normalize(nearP * (cam.focusDistance / nearP.z));
+}
+// getFocusDistance(): the `focusDistance` of a thinlens sensor; a pinhole's default is the far clip, sensor.cpp:162
+__device__ __forceinline__ Float focus_distance(const CameraD &cam) { return cam.thinlens ? cam.focusDistance : cam.farClip; }
+// PerspectiveCameraImpl::getSamplePosition, perspective.cpp:393-410; ThinLensCamera::getSamplePosition, thinlens.cpp:536-557 (pWorld: the sensor sample's
+// point of the aperture; the pinhole does not read it)
+__device__ __forceinline__ bool sensor_sample_position(const Ctx &c, d3 pWorld, d3 dWorld, Float &ox, Float &oy)
 {
     const CameraD &cam = c.S->cam;
     const d3 l = cam_to_local(c, dWorld);
     if (l.z <= 0) return false;
+    if (cam.thinlens) {
+        Float sx, sy;
+        camera_to_sample(cam, cam_to_local_point(c, pWorld) + l * (cam.focusDistance / l.z), sx, sy);
+        if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return false;
+        ox = sx * cam.width; oy = sy * cam.height;
+        return true;
+    }
     const Float sx = 0.5 * (1 - l.x / (l.z * cam.tanHalf)), sy = 0.5 * (1 - l.y * cam.aspect / (l.z * cam.tanHalf));
     if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return false;
     ox = sx * cam.width; oy = sy * cam.height;
@@ -417,12 +460,31 @@ __device__ __noinline__ int sample_sensor(Ctx &c, BV &v0, int px, int py, BE &e0
     const Float sx = c.rng.next1D(), sy = c.rng.next1D();
     v1.p = c.cam.pos; v1.n = c.cam.dir; v1.object = -2;
     v0.w[ERadiance] = mk(1.0); v0.pdf[ERadiance] = 1.0; v0.measure = M_DISCRETE; v0.rr = 1.0;
+    const CameraD &cam = c.S->cam;
+    if (cam.thinlens) {                                                                    // the aperture sample (:324-325) and ThinLensCamera::samplePosition, thinlens.cpp:363-376
+        const Float ax = c.rng.next1D(), ay = c.rng.next1D();
+        const Float r1 = 2.0 * ax - 1.0, r2 = 2.0 * ay - 1.0;                              // squareToUniformDiskConcentric, warp.cpp:81-102
+        Float phi, r;
+        if (r1 == 0 && r2 == 0) { r = phi = 0; }
+        else if (r1 * r1 > r2 * r2) { r = r1; phi = (GD_PI / 4.0) * (r2 / r1); }
+        else { r = r2; phi = (GD_PI / 2.0) - (r1 / r2) * (GD_PI / 4.0); }
+        const d3 ol = mk(r * cos(phi) * cam.apertureRadius, r * sin(phi) * cam.apertureRadius, 0.0);
+        v1.p = mk(cam.m[0] * ol.x + cam.m[1] * ol.y + cam.m[2] * ol.z + cam.m[3], cam.m[4] * ol.x + cam.m[5] * ol.y + cam.m[6] * ol.z + cam.m[7],
+                  cam.m[8] * ol.x + cam.m[9] * ol.y + cam.m[10] * ol.z + cam.m[11]);
+        v0.pdf[ERadiance] = c.cam.aperturePdf; v0.measure = M_AREA;
+    }
     v1.type = T_SENSOR_SAMPLE; v1.degenerate = 0;
     e0.tr[ERadiance] = 1.0;
-    const CameraD &cam = c.S->cam;
     const Float spx = (px + sx) * cam.invW, spy = (py + sy) * cam.invH;
     v1.u = spx * cam.width; v1.v = spy * cam.height;
-    const d3 dl = sample_to_camera_dir(c, spx, spy);
+    d3 dl = sample_to_camera_dir(c, spx, spy);
+    if (cam.thinlens) {                                                                    // ThinLensCamera::sampleDirection, thinlens.cpp:386-418: through the pixel's point of the focus plane
+        d3 nearP = mk((1 - 2 * spx) * cam.nearClip * cam.tanHalf, (1 - 2 * spy) / cam.aspect * cam.nearClip * cam.tanHalf, cam.nearClip);
+        nearP.x = nearP.x * (cam.focusDistance / nearP.z);
+        nearP.y = nearP.y * (cam.focusDistance / nearP.z);
+        nearP.z = cam.focusDistance;
+        dl = normalize(nearP - cam_to_local_point(c, v1.p));
+    }
     const d3 d = cam_to_world(c, dl);
     const Float dpdf = c.cam.normalization / (dl.z * dl.z * dl.z);
     be_clear(e1); bv_clear(v2);
@@ -444,7 +506,7 @@ __device__ bool perturb_direction(Ctx &c, BV &v, const BV &pred, const BE &predE
     be_clear(succEdge); bv_clear(succ);
     if (v.degenerate) return false;
     if (v.type != T_SENSOR_SAMPLE) return false;
-    const Float value = importance(c, cam_to_local(c, d)), prob = value;
+    const Float value = sensor_direction(c, v.p, d), prob = value;
     if (value == 0 || prob <= 0x1p-1024) return false;
     v.w[EImportance] = mk(value) * (1.0 / fabs(dot(d, v.n)));
     v.w[ERadiance] = mk(value) / prob;
@@ -463,6 +525,7 @@ __device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ,
         return c.V.emitters[succ->object].radiance * GD_PI;
     } else if (v.type == T_SENSOR_SUPER) {
         if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return mk(0.0);
+        if (c.S->cam.thinlens) return mk(measure == M_AREA ? c.cam.aperturePdf : 0.0);     // thinlens.cpp:378-380
         return mk(measure == M_DISCRETE ? 1.0 : 0.0);
     } else if (v.type == T_EMITTER_SAMPLE || v.type == T_SENSOR_SAMPLE) {
         const bool emitter = v.type == T_EMITTER_SAMPLE;
@@ -473,7 +536,7 @@ __device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ,
         else return mk(0.0);
         const d3 wo = normalize(target - v.p);
         const int dm = measure == M_AREA ? M_SOLID : measure;
-        d3 result = mk(emitter ? area_direction(wo, v.n, dm) : (dm != M_SOLID ? 0.0 : importance(c, cam_to_local(c, wo))));
+        d3 result = mk(emitter ? area_direction(wo, v.n, dm) : (dm != M_SOLID ? 0.0 : sensor_direction(c, v.p, wo)));
         const Float dp = fabs(dot(v.n, wo));
         if (measure != M_DISCRETE && dp != 0) result = result / dp;
         return result;
@@ -502,6 +565,7 @@ __device__ Float bv_eval_pdf(const Ctx &c, const BV &v, const BV *pred, const BV
         return pdf_emitter_position(c, succ->object);
     } else if (v.type == T_SENSOR_SUPER) {
         if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return 0.0;
+        if (c.S->cam.thinlens) return measure == M_AREA ? c.cam.aperturePdf : 0.0;         // thinlens.cpp:382-384
         return measure == M_DISCRETE ? 1.0 : 0.0;
     } else if (v.type == T_EMITTER_SAMPLE) {
         if (mode == ERadiance && succ->type == T_EMITTER_SUPER) return 1.0;
@@ -514,7 +578,7 @@ __device__ Float bv_eval_pdf(const Ctx &c, const BV &v, const BV *pred, const BV
         else if (mode != ERadiance || pred->type != T_SENSOR_SUPER) return 0.0;
         wo = succ->p - v.p;
         dist = len(wo); wo = wo / dist;
-        result = (measure == M_AREA ? M_SOLID : measure) != M_SOLID ? 0.0 : importance(c, cam_to_local(c, wo));
+        result = (measure == M_AREA ? M_SOLID : measure) != M_SOLID ? 0.0 : sensor_direction(c, v.p, wo);
     } else if (v.type == T_SURFACE) {
         const Surf sf = surf_of(c, v);
         wo = succ->p - v.p;
@@ -608,14 +672,14 @@ __device__ bool generate_offset(Ctx &c, const BV &srcA, const BV &S0, const BE &
     // perturbDirection, mut_manifold.cpp:938-986
     const CameraD &cam = c.S->cam;
     const Float ppx = srcA.u + shX, ppy = srcA.v + shY;                                     // source.getSamplePosition() + offset
-    const d3 rd = cam_to_world(c, sample_to_camera_dir(c, ppx * cam.invW, ppy * cam.invH));  // sensor->sampleRay, perspective.cpp:249-269
-    const Float focusDistance = cam.farClip / fabs(dot(c.cam.dir, rd));                      // the default focus distance is the far clip, sensor.cpp:162
+    const d3 rd = cam_to_world(c, centre_ray_dir(c, ppx * cam.invW, ppy * cam.invH));        // sensor->sampleRay, perspective.cpp:249-269
+    const Float focusDistance = focus_distance(cam) / fabs(dot(c.cam.dir, rd));
     const d3 d = normalize((c.cam.pos + rd * focusDistance) - srcA.p);
     if (!perturb_direction(c, o.a, S0, eSA, o.eab, o.b, d, distAB)) return false;
     if (!bv_connectable(o.b)) return false;
     o.couldConnectAfterB = bv_connect(c, predC, o.c, o.ebc, o.b, &o.a, bv_connectable(srcC) ? M_AREA : M_DISCRETE, bv_connectable(srcB) ? M_AREA : M_DISCRETE);
     if (lightPath && !o.couldConnectAfterB) return false;
-    sensor_sample_position(c, o.b.p - o.a.p, o.a.u, o.a.v);                                 // updateSamplePosition, :912-913
+    sensor_sample_position(c, o.a.p, o.b.p - o.a.p, o.a.u, o.a.v);                                 // updateSamplePosition, :912-913
     o.a.rr = srcA.rr; o.b.rr = srcB.rr; o.c.rr = srcC.rr;                                   // :918-923
     if (o.b.type == T_SURFACE && o.b.componentType == 0) o.b.componentType = srcB.componentType;
     Float jy = 1.0; jy /= o.a.pdf[ERadiance];
@@ -784,7 +848,7 @@ struct PairOut { d3 primal, gradient[4]; int nLight; LightSplat light[5]; };   /
 __device__ __noinline__ bool walk_paths(Ctx &c, Sample &sm, int px, int py)
 {
     const BdConfig &cfg = c.cfg;
-    const int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth + 1;                  // :110-122: degenerate (pinhole) sensor, hittable emitters
+    const int emitterDepth = cfg.maxDepth + (c.S->cam.thinlens ? 1 : 0), sensorDepth = cfg.maxDepth + 1;   // :110-122: one more emitter step unless the sensor is a point (pinhole), hittable emitters
     // ---- Path::alternatingRandomWalkFromPixel, path.cpp:548-631 ----
     bv_clear(sm.X[0]); sm.X[0].type = T_SENSOR_SUPER; sm.X[0].degenerate = 1;               // makeEndpoint, vertex.cpp:27-33
     bv_clear(sm.Y[0]); sm.Y[0].type = T_EMITTER_SUPER; sm.Y[0].degenerate = 0;
@@ -823,7 +887,7 @@ __device__ __noinline__ bool walk_shift_base(Ctx &c, Sample &sm)
     be_clear(sm.eConn);
     bv_cast_emitter(c, sm.XTc);
     bv_connect(c, sm.connS == 1 ? &sm.Y[0] : nullptr, sm.Y1c, sm.eConn, sm.XTc, T >= 1 ? &sm.X[T - 1] : nullptr, bv_connectable(sm.Y1c) ? M_AREA : M_DISCRETE, bv_connectable(sm.XTc) ? M_AREA : M_DISCRETE);
-    if (T == 1) sensor_sample_position(c, sm.Y1c.p - sm.XTc.p, sm.XTc.u, sm.XTc.v);          // (the clone's film position: never read again)
+    if (T == 1) sensor_sample_position(c, sm.XTc.p, sm.Y1c.p - sm.XTc.p, sm.XTc.u, sm.XTc.v);          // (the clone's film position: never read again)
     // ---- combineImportanceData / combineRadianceData, gbdpt_proc.cpp:544-565 ----
     const int nE = sm.nY, nS = sm.nX;
     sm.impW[0] = mk(1.0); sm.impP[0] = 1.0;
@@ -898,7 +962,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
     po.nLight = 0;
     Float samplePosX = sm.posX, samplePosY = sm.posY;
     if (T1) {
-        if (!sensor_sample_position(c, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) return false;
+        if (!sensor_sample_position(c, sm.X[1].p, sm.Y[s].p - sm.X[1].p, samplePosX, samplePosY) || !connectable_gbdpt(c, sm.Y[s])) return false;
         if (PHASE == 3) return true;             // (light tracing's ray-free filter, round 5: most emitter vertices lie outside the sensor's frustum -- its base-path launch ran at 9 % lane utilisation)
     }
     // light-tracing connections (t == 1): the base path Y[0..s-1], Ysc, S1c, X[0] and its four offsets (gbdpt_proc.cpp:356-376)
@@ -908,7 +972,7 @@ __device__ bool connect_pair(Ctx &c, const Sample &sm, int s, int t, PairOut &po
         Ysc = sm.Y[s]; S1c = sm.X[1]; be_clear(eL);
         // (phase 2 runs on the survivors of phase 1: their base path's sensor connection and -- below -- connection edge were traced there and found free)
         pathSuccess0 = bv_connect(c, &sm.Y[s - 1], Ysc, eL, S1c, &sm.X[0], bv_connectable(Ysc) ? M_AREA : M_DISCRETE, bv_connectable(S1c) ? M_AREA : M_DISCRETE, PHASE == 2);
-        sensor_sample_position(c, Ysc.p - S1c.p, S1c.u, S1c.v);
+        sensor_sample_position(c, S1c.p, Ysc.p - S1c.p, S1c.u, S1c.v);
     }
     if (PHASE == 1 && !T1) { c.nClosest = nClosest0; c.nShadow = nShadow0; }               // (the rays up to here were counted by phase 3; light tracing has no phase 3:
                                                                                            //  its filter IS a visibility ray -- the sensor connection -- and a launch of its own for it cost more than it saved)

@@ -295,15 +295,15 @@ GDPT_API int  gdpt_bsdf_probe(const gdpt_material *m, const double wi[3], int nS
  * src/libbidir: Path::alternatingRandomWalkFromPixel, ManifoldPerturbation::generateOffsetPathGBDPT, Path::miWeight{Base,Grad}NoSweep_GBDPT),
  * accumulated as GBDPTWorkResult / GBDPTProcess::processResult do (gbdpt_wr.h:56-62, gbdpt_proc.cpp:708-763): five camera blocks (rgb, weight)
  * and five full-resolution light images, buffer order of the integrator's MultiFilm (gbdpt.cpp:163): 0 primal, 1 gradient towards (0,-1),
- * 2 (-1,0), 3 (+1,0), 4 (0,+1).  Scope: surface scenes, area emitters, perspective sensor, box filter; BSDFs diffuse and rough conductors
+ * 2 (-1,0), 3 (+1,0), 4 (0,+1).  Scope: surface scenes, area emitters, perspective or thinlens sensor, box filter; BSDFs diffuse and rough conductors
  * (one- or two-sided, textured or not) and -- round 4 -- conductor, dielectric and rough conductors below shiftThreshold.  A sample whose
  * surface vertices are all connectable in the sense of Path::isConnectable_GBDPT runs the fast wavefront form; a sample that meets a
  * SPECULAR vertex runs the general form (csrc/gbdpt_general.hip.h): offset paths by ManifoldPerturbation::propagatePerturbation and
  * manifoldWalk (mut_manifold.cpp:989-1227, SpecularManifold manifold.cpp:59-757), Jacobians and MIS weights with SpecularManifold::{G, multiG,
- * det} -- complete, parity-held, and ~25x slower per sample (one lane per sample, its paths in an HBM workspace).  Environment / point emitters
- * and the thinlens sensor return GDPT_ERR_UNSUPPORTED.  Same counter-based random streams as the G-PT path, consumed in the reference's order. */
+ * det} -- as staged launches over per-sample records in HBM (round 5: DESIGN.md "the general form as staged launches").  Environment / point
+ * emitters return GDPT_ERR_UNSUPPORTED.  Same counter-based random streams as the G-PT path, consumed in the reference's order. */
 typedef struct gdpt_gbdpt_config {
-    int    maxDepth;            /* -1 renders as 12 (gbdpt_proc.cpp:103-106); at most 20 (a sample record holds whole subpaths) */
+    int    maxDepth;            /* -1 renders as 12 (gbdpt_proc.cpp:103-106); at most 20 (a sample record holds whole subpaths; 19 with the thinlens sensor) */
     int    rrDepth;             /* 5 (gbdpt.cpp:82)                                                                         */
     int    lightImage;          /* 1 (gbdpt.cpp:83): connect emitter subpaths to the sensor (t = 1 strategies)             */
     int    spp;

@@ -100,6 +100,8 @@ struct Ctx {
     Float invLin[9];                                // linear part of the inverse camera transform (trafo.inverse() applied to a direction)
     V3 camPos, camDir;
     Float rectX, rectY, normalization;              // m_imageRect half extents and 1 / its area, perspective.cpp:167-173
+    bool thinlens = false;                          // `thinlens` sensor (thinlens.cpp): the position sample is a point of the aperture disk (EArea), not a delta
+    Float aperturePdf = 0;                          // 1 / (pi r^2), thinlens.cpp:213
     uint64_t unsupported = 0;
     // specular-chain statistics of the offset paths (the reference's statsUsedManifold / statsMWSuccess / statsUsedPropagation counters,
     // mut_manifold.cpp:33-75): manifold walks entered, walks that converged reversibly, chain vertices re-created by propagatePerturbation
@@ -119,8 +121,11 @@ inline void cameraSetup(Ctx &c)
     c.camDir = V3(M[2], M[6], M[10]);                                                      // trafo(Vector(0, 0, 1)), perspective.cpp:303-305
     c.rectX = c.sc.tanHalf; c.rectY = c.sc.tanHalf / c.sc.aspect;                           // sampleToCamera(0,0,0) / z and (1,1,0) / z written out (crop == film)
     c.normalization = 1.0 / ((2 * c.rectX) * (2 * c.rectY));
+    c.thinlens = c.sc.cam.type == 1;
+    if (c.thinlens) c.aperturePdf = 1 / (PI * c.sc.cam.apertureRadius * c.sc.cam.apertureRadius);
 }
 inline V3 camToLocal(const Ctx &c, V3 d) { return mul3(c.invLin, d); }
+inline V3 camToLocalPoint(const Ctx &c, V3 p) { return mul3(c.invLin, p - c.camPos); }      // trafo.inverse().transformAffine(p)
 inline V3 camToWorld(const Ctx &c, V3 d)
 {
     const double *M = c.sc.cam.toWorld;
@@ -137,6 +142,29 @@ inline Float importance(const Ctx &c, V3 d)
     if (!(px >= -c.rectX && px <= c.rectX && py >= -c.rectY && py <= c.rectY)) return 0.0;   // AABB2::contains
     return c.normalization * invCosTheta * invCosTheta * invCosTheta;
 }
+// m_cameraToSample(P).xy for crop == film (the inverse of sampleToCameraDir's map): the film position, in [0,1]^2, that the camera-space point P projects to
+inline void cameraToSample(const Ctx &c, V3 P, Float &sx, Float &sy)
+{
+    sx = 0.5 * (1 - P.x / (P.z * c.sc.tanHalf)); sy = 0.5 * (1 - P.y * c.sc.aspect / (P.z * c.sc.tanHalf));
+}
+// ThinLensCamera::importance, thinlens.cpp:231-291: p a point of the aperture, d the direction from it (both in camera space); the pixel is the one whose
+// focus-plane point the ray passes through
+inline Float importanceLens(const Ctx &c, V3 p, V3 d, Float *ox = nullptr, Float *oy = nullptr)
+{
+    const Float cosT = cosTheta(d);
+    if (cosT <= 0) return 0.0;
+    const Float invCosTheta = 1.0 / cosT;
+    Float sx, sy;
+    cameraToSample(c, p + d * (c.sc.cam.focusDistance * invCosTheta), sx, sy);
+    if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return 0.0;
+    if (ox) { *ox = sx * c.sc.cam.width; *oy = sy * c.sc.cam.height; }
+    return c.normalization * invCosTheta * invCosTheta * invCosTheta;
+}
+// Sensor::evalDirection == pdfDirection of a sensor sample at world position p towards world direction d (perspective.cpp:373-391, thinlens.cpp:420-437)
+inline Float sensorDirection(const Ctx &c, V3 p, V3 d)
+{
+    return c.thinlens ? importanceLens(c, camToLocalPoint(c, p), camToLocal(c, d)) : importance(c, camToLocal(c, d));
+}
 // m_sampleToCamera(Point(sx, sy, 0)) normalised: the direction through a film position given in [0,1]^2 (perspective.cpp:150-156 written out)
 inline V3 sampleToCameraDir(const Ctx &c, Float sxn, Float syn)
 {
@@ -144,10 +172,19 @@ inline V3 sampleToCameraDir(const Ctx &c, Float sxn, Float syn)
     return normalize(V3((1 - 2 * sxn) * cam.nearClip * c.sc.tanHalf, (1 - 2 * syn) / c.sc.aspect * cam.nearClip * c.sc.tanHalf, cam.nearClip));
 }
 // PerspectiveCameraImpl::getSamplePosition, perspective.cpp:393-410 (m_cameraToSample written out: the inverse of the map above)
-inline bool sensorSamplePosition(const Ctx &c, V3 dWorld, Float &ox, Float &oy)
+// ... and ThinLensCamera::getSamplePosition, thinlens.cpp:536-557 (pWorld: the sensor sample's point of the aperture; the pinhole does not read it)
+inline bool sensorSamplePosition(const Ctx &c, V3 pWorld, V3 dWorld, Float &ox, Float &oy)
 {
     const V3 local = camToLocal(c, dWorld);
     if (local.z <= 0) return false;
+    if (c.thinlens) {
+        const V3 localP = camToLocalPoint(c, pWorld);
+        Float sx, sy;
+        cameraToSample(c, localP + local * (c.sc.cam.focusDistance / local.z), sx, sy);
+        if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return false;
+        ox = sx * c.sc.cam.width; oy = sy * c.sc.cam.height;
+        return true;
+    }
     const Float sx = 0.5 * (1 - local.x / (local.z * c.sc.tanHalf)), sy = 0.5 * (1 - local.y * c.sc.aspect / (local.z * c.sc.tanHalf));
     if (sx < 0 || sx > 1 || sy < 0 || sy > 1) return false;
     ox = sx * c.sc.cam.width; oy = sy * c.sc.cam.height;
@@ -442,6 +479,17 @@ struct Tracer {
         PRec &pRec = v1->prec;
         pRec = PRec();
         pRec.p = c.camPos; pRec.n = c.camDir; pRec.pdf = 1.0; pRec.measure = EDiscrete; pRec.object = -2;   // samplePosition, perspective.cpp:300-308
+        V3 apertureP(0.0);
+        if (c.thinlens) {                                                                  // the aperture sample (:324-325) and ThinLensCamera::samplePosition, thinlens.cpp:363-376
+            const Float ax = rng.next1D(), ay = rng.next1D();
+            Float tx, ty;
+            squareToUniformDiskConcentric(ax, ay, tx, ty);
+            apertureP = V3(tx * c.sc.cam.apertureRadius, ty * c.sc.cam.apertureRadius, 0.0);
+            const double *M = c.sc.cam.toWorld;
+            pRec.p = V3(M[0] * apertureP.x + M[1] * apertureP.y + M[2] * apertureP.z + M[3], M[4] * apertureP.x + M[5] * apertureP.y + M[6] * apertureP.z + M[7],
+                        M[8] * apertureP.x + M[9] * apertureP.y + M[10] * apertureP.z + M[11]);
+            pRec.pdf = c.aperturePdf; pRec.measure = EArea;
+        }
         v0->weight[ERadiance] = V3(1.0);
         v0->pdf[ERadiance] = pRec.pdf;
         v0->measure = pRec.measure;
@@ -453,7 +501,15 @@ struct Tracer {
         // sampleDirection, perspective.cpp:318-345
         const Float spx = (px + sx) * (1.0 / c.sc.cam.width), spy = (py + sy) * (1.0 / c.sc.cam.height);
         pRec.uvx = spx * c.sc.cam.width; pRec.uvy = spy * c.sc.cam.height;
-        const V3 dl = sampleToCameraDir(c, spx, spy);
+        V3 dl = sampleToCameraDir(c, spx, spy);
+        if (c.thinlens) {                                                                  // ThinLensCamera::sampleDirection, thinlens.cpp:386-418: through the pixel's point of the focus plane
+            const gpo_camera &cam = c.sc.cam;
+            V3 nearP((1 - 2 * spx) * cam.nearClip * c.sc.tanHalf, (1 - 2 * spy) / c.sc.aspect * cam.nearClip * c.sc.tanHalf, cam.nearClip);
+            nearP.x = nearP.x * (cam.focusDistance / nearP.z);
+            nearP.y = nearP.y * (cam.focusDistance / nearP.z);
+            nearP.z = cam.focusDistance;
+            dl = normalize(nearP - camToLocalPoint(c, pRec.p));                            // (apertureP = trafo.inverse().transformAffine(pRec.p): the round trip of the reference)
+        }
         const V3 d = camToWorld(c, dl);
         const Float dpdf = c.normalization / (dl.z * dl.z * dl.z);
         *e1 = Edge(); *v2 = Vertex();
@@ -481,7 +537,7 @@ struct Tracer {
         if (v->degenerate) return false;
         switch (v->type) {
         case ESensorSample: {                                                              // :526-547
-            const Float value = importance(c, camToLocal(c, d)), prob = value;             // evalDirection == pdfDirection, perspective.cpp:373-391
+            const Float value = sensorDirection(c, v->prec.p, d), prob = value;             // evalDirection == pdfDirection, perspective.cpp:373-391
             if (value == 0 || prob <= RCPOVERFLOW) return false;
             v->weight[EImportance] = V3(value) * (1.0 / std::abs(dot(d, v->prec.n)));
             v->weight[ERadiance] = V3(value) / prob;
@@ -525,6 +581,7 @@ struct Tracer {
             return c.sc.emitters[succ->prec.object].radiance * PI;                         // AreaLight::evalPosition, area.cpp:99-101
         case ESensorSupernode:
             if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return V3(0.0);
+            if (c.thinlens) return V3(measure == EArea ? c.aperturePdf : 0.0);             // thinlens.cpp:378-380
             return V3(measure == EDiscrete ? 1.0 : 0.0);                                   // perspective.cpp:310-312
         case EEmitterSample: {
             V3 target;
@@ -543,7 +600,7 @@ struct Tracer {
             else if (mode == EImportance && succ->type == ESensorSupernode) target = pred->position();
             else return V3(0.0);
             const V3 wo = normalize(target - v->prec.p);
-            V3 result((measure == EArea ? ESolidAngle : measure) != ESolidAngle ? 0.0 : importance(c, camToLocal(c, wo)));
+            V3 result((measure == EArea ? ESolidAngle : measure) != ESolidAngle ? 0.0 : sensorDirection(c, v->prec.p, wo));
             const Float dp = std::abs(dot(v->prec.n, wo));
             if (measure != EDiscrete && dp != 0) result = result / dp;
             return result;
@@ -574,6 +631,7 @@ struct Tracer {
             return pdfEmitterPosition(c, succ->prec);
         case ESensorSupernode:
             if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return 0.0;
+            if (c.thinlens) return measure == EArea ? c.aperturePdf : 0.0;                 // thinlens.cpp:382-384
             return measure == EDiscrete ? 1.0 : 0.0;                                       // perspective.cpp:314-316
         case EEmitterSample:
             if (mode == ERadiance && succ->type == EEmitterSupernode) return 1.0;
@@ -587,7 +645,7 @@ struct Tracer {
             else if (mode != ERadiance || pred->type != ESensorSupernode) return 0.0;
             wo = succ->position() - v->prec.p;
             dist = length(wo); wo = wo / dist;
-            result = (measure == EArea ? ESolidAngle : measure) != ESolidAngle ? 0.0 : importance(c, camToLocal(c, wo));
+            result = (measure == EArea ? ESolidAngle : measure) != ESolidAngle ? 0.0 : sensorDirection(c, v->prec.p, wo);
             break;
         case ESurfaceInteraction: {
             const Intersection &its = v->its;
@@ -672,11 +730,11 @@ struct Tracer {
     }
     bool getSamplePosition(const Vertex *v, const Vertex *other, Float &ox, Float &oy) const   // vertex.cpp:1308-1316
     {
-        return sensorSamplePosition(c, other->position() - v->position(), ox, oy);
+        return sensorSamplePosition(c, v->position(), other->position() - v->position(), ox, oy);
     }
     bool updateSamplePosition(Vertex *v, const Vertex *other) const                        // :1298-1306
     {
-        return sensorSamplePosition(c, other->position() - v->position(), v->prec.uvx, v->prec.uvy);
+        return sensorSamplePosition(c, v->position(), other->position() - v->position(), v->prec.uvx, v->prec.uvy);
     }
 
     // ---- Path ------------------------------------------------------------------------------------------------------------------------
@@ -1202,10 +1260,16 @@ struct Tracer {
         Edge *predEdge = proposal.e[a - 1 - step], *succEdge = proposal.e[a - 1];
         const Float ppx = source.v[source.length() - 1]->prec.uvx + offX, ppy = source.v[source.length() - 1]->prec.uvy + offY;   // Path::getSamplePosition, path.h:540-542
         // sensor->sampleRay(ray, proposalSamplePosition, (0.5, 0.5), 0), perspective.cpp:249-269
-        const V3 rd = camToWorld(c, sampleToCameraDir(c, ppx * (1.0 / c.sc.cam.width), ppy * (1.0 / c.sc.cam.height)));
+        V3 dl = sampleToCameraDir(c, ppx * (1.0 / c.sc.cam.width), ppy * (1.0 / c.sc.cam.height));
+        if (c.thinlens) {                                                                  // ThinLensCamera::sampleRay with the aperture's centre, thinlens.cpp:293-322: normalize(focusP - 0)
+            const gpo_camera &cam = c.sc.cam;
+            const V3 nearP((1 - 2 * ppx * (1.0 / cam.width)) * cam.nearClip * c.sc.tanHalf, (1 - 2 * ppy * (1.0 / cam.height)) / c.sc.aspect * cam.nearClip * c.sc.tanHalf, cam.nearClip);
+            dl = normalize(nearP * (cam.focusDistance / nearP.z));
+        }
+        const V3 rd = camToWorld(c, dl);
         const V3 ro = c.camPos;
         // focusDistance = getFocusDistance() / absDot(worldTransform(0, 0, 1), ray.d); the default focus distance is the far clip (sensor.cpp:162)
-        const Float focusDistance = c.sc.cam.farClip / std::abs(dot(c.camDir, rd));
+        const Float focusDistance = (c.thinlens ? c.sc.cam.focusDistance : c.sc.cam.farClip) / std::abs(dot(c.camDir, rd));
         const V3 d = normalize((ro + rd * focusDistance) - source.v[a]->position());
         return perturbDirection(vertex, pred, predEdge, succEdge, succ, d, succEdge_old->length, ERadiance);
     }
@@ -1698,6 +1762,7 @@ struct Tracer {
         if (cfg.maxDepth == -1) cfg.maxDepth = 12;                                         // :103-106
         int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth;
         // the perspective sensor is degenerate (EDeltaPosition): no extra emitter step; area emitters can be hit: one more sensor step (:116-122)
+        if (c.thinlens && emitterDepth != -1) ++emitterDepth;                              // "go one extra step if the sensor can be intersected": not EDeltaPosition, :117-118
         if (sensorDepth != -1) ++sensorDepth;
         const int neighborCount = 4;
         std::vector<ShiftPathData> pathData(neighborCount + 1, ShiftPathData(sensorDepth + 3));
