@@ -91,7 +91,7 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_paths(SceneD S, BdCam cam, BdCon
     c.S = &S; c.V = hbm_scene_view(S); c.cam = cam; c.cfg = cfg; c.stack = s_stack + threadIdx.x; c.nClosest = c.nShadow = 0;
     const unsigned total = gridDim.x * TBLK;
     unsigned next = blockIdx.x * TBLK + threadIdx.x, lid = 0, done = 0;
-    const int emitterDepth = cfg.maxDepth + (S.cam.thinlens ? 1 : 0), sensorDepth = cfg.maxDepth + 1;   // gbdpt_proc.cpp:110-122: one more emitter step unless the sensor is a point (pinhole); hittable emitters
+    const int emitterDepth = cfg.maxDepth + (S.cam.thinlens ? 1 : 0), sensorDepth = cfg.maxDepth + (cfg.hittableEmitters ? 1 : 0);   // gbdpt_proc.cpp:110-122: one more emitter step unless the sensor is a point (pinhole); one more sensor step if an emitter can be hit
     bool have = false, walkT = false, walkS = false;
     int s = 0, t = 0;
     d3 thrS = mk(1.0), thrT = mk(1.0);
@@ -567,7 +567,7 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
     if (s->d.cam.thinlens && (cfg->maxDepth < 0 ? BD_DEFAULT_DEPTH : cfg->maxDepth) > BD_MAX_DEPTH - 1)   // (the extra emitter step of a non-degenerate sensor, gbdpt_proc.cpp:117-118, needs one more record)
         return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d with the thinlens sensor", BD_MAX_DEPTH - 1);
-    if (s->specialEmitters) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment and point emitters are not carried (area emitters only)");
+    if (s->d.envIndex >= 0) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment emitters are not carried (area and point emitters only)");
     // (round 4: Dirac BSDFs and rough conductors below shiftThreshold are carried -- samples that meet one run the general form, gbdpt_general.hip.h)
     return GDPT_OK;
 }
@@ -590,10 +590,11 @@ BdCam make_cam(const gdpt_scene *s)
     return cam;
 }
 
-BdConfig make_cfg(const gdpt_gbdpt_config *cfg, double sceneRadius)
+BdConfig make_cfg(const gdpt_gbdpt_config *cfg, double sceneRadius, bool hittableEmitters)
 {
     BdConfig c;
     c.sceneRadius = sceneRadius;
+    c.hittableEmitters = hittableEmitters ? 1 : 0;
     c.maxDepth = cfg->maxDepth == -1 ? BD_DEFAULT_DEPTH : cfg->maxDepth;                    // gbdpt_proc.cpp:103-106
     c.rrDepth = cfg->rrDepth; c.lightImage = cfg->lightImage ? 1 : 0; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
@@ -659,7 +660,7 @@ int gdpt_gbdpt_render_rect(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int x0, 
     if (int rc = check_scope(s, cfg)) return rc;
     BHIPCHK(hipSetDevice(s->device));
     const BdCam cam = make_cam(s);
-    BdConfig c = make_cfg(cfg, f->sceneRadius);
+    BdConfig c = make_cfg(cfg, f->sceneRadius, s->hittableEmitters);
     if (f->timed) { float ms = 0; BHIPCHK(hipEventSynchronize(f->e1)); BHIPCHK(hipEventElapsedTime(&ms, f->e0, f->e1)); f->renderMs += ms; f->timed = false; }
     BHIPCHK(hipEventRecord(f->e0, f->stream));
     const long long pixels = (long long)(x1 - x0) * (y1 - y0), total = pixels * c.spp;
@@ -890,7 +891,7 @@ int gdpt_gbdpt_evaluate_sample2(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int
     if (int rc = check_scope(s, cfg)) return rc;
     BHIPCHK(hipSetDevice(s->device));
     const BdCam cam = make_cam(s);
-    const BdConfig c = make_cfg(cfg, s->bsphereRadius);
+    const BdConfig c = make_cfg(cfg, s->bsphereRadius, s->hittableEmitters);
     struct Bufs {                                  // (freed on every return path)
         double *d = nullptr, *dl = nullptr; int *dn = nullptr; unsigned long long *dc = nullptr; GWork *work = nullptr;
         ~Bufs() { hipFree(d); hipFree(dl); hipFree(dn); hipFree(dc); hipFree(work); }

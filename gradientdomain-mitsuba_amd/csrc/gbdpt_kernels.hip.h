@@ -44,6 +44,7 @@ struct BdConfig {
     Float shiftThreshold;
     unsigned long long seed;
     int sBase, sCount;                             // the samples [sBase, sBase + sCount) of every pixel are rendered by this launch
+    int hittableEmitters;                          // !Scene::hasDegenerateEmitters (scene.cpp:388,410-411): some emitter is not a point -- the sensor subpath takes one more step, gbdpt_proc.cpp:120-122
     Float sceneRadius;                             // m_scene->getBSphere().radius (the kd-tree's enlarged bounds): the yardstick of the manifold walk's reversibility test
 };
 struct BdCam {                                     // perspective sensor quantities beyond CameraD (perspective.cpp:167-173,190-247)
@@ -65,7 +66,10 @@ struct BV {                                        // PathVertex
 struct BE { d3 d; Float length; Float tr[2]; };    // PathEdge: direction (along the light path), length, pdf[mode] == weight[mode] (1, or the 0/1 of a supernode edge)
 
 __device__ __forceinline__ bool bv_connectable(const BV &v) { return !v.degenerate && v.measure != M_DISCRETE; }   // vertex.h:750
-__device__ __forceinline__ bool bv_on_surface(const BV &v) { return v.type == T_SURFACE || v.type == T_EMITTER_SAMPLE || v.type == T_SENSOR_SAMPLE; }   // vertex.h:592-596
+// vertex.h:592-596: a surface vertex, or an endpoint sample whose sensor / emitter is EOnSurface -- area lights and both perspective sensors are, a `point`
+// emitter is not (point.cpp:56): its samples carry prim == BV_OFF_SURFACE
+constexpr int BV_OFF_SURFACE = -2;
+__device__ __forceinline__ bool bv_on_surface(const BV &v) { return v.type == T_SURFACE || ((v.type == T_EMITTER_SAMPLE || v.type == T_SENSOR_SAMPLE) && v.prim != BV_OFF_SURFACE); }
 __device__ __forceinline__ bool bv_super(const BV &v) { return (v.type & 3) != 0; }
 __device__ __forceinline__ void bv_clear(BV &v)
 {
@@ -203,6 +207,13 @@ __device__ __forceinline__ d3 sample_emitter_position(const Ctx &c, BV &succ, Fl
     const Float emPdf = V.emitterCdf[index + 1] - V.emitterCdf[index];
     sx = (sx - V.emitterCdf[index]) / (V.emitterCdf[index + 1] - V.emitterCdf[index]);
     const EmitterD em = V.emitters[index];
+    if (em.numTris < 0) {                                                                  // PointEmitter::samplePosition, point.cpp:79-87
+        succ.p = em.position; succ.n = mk(0.0); succ.object = index; succ.prim = BV_OFF_SURFACE;
+        Float pdf = 1.0;
+        pdf *= emPdf;
+        pdfOut = pdf;
+        return (em.radiance * (4 * GD_PI)) / emPdf;
+    }
     if (em.rectangle) {
         const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
         succ.p = mk(em.rect[0] * lx + em.rect[1] * ly + em.rect[2] * 0.0 + em.rect[3], em.rect[4] * lx + em.rect[5] * ly + em.rect[6] * 0.0 + em.rect[7],
@@ -229,12 +240,23 @@ __device__ __forceinline__ d3 sample_emitter_position(const Ctx &c, BV &succ, Fl
     const d3 power = em.radiance * GD_PI * area;
     return power / emPdf;
 }
-__device__ __forceinline__ Float pdf_emitter_position(const Ctx &c, int object) { return c.V.emitters[object].invSurfaceArea * (1.0 * c.S->emitterNormalization); }   // scene.cpp:1003-1006
+__device__ __forceinline__ Float pdf_emitter_position(const Ctx &c, int object, int measure)   // scene.cpp:1003-1006 (pRec.measure = measure, vertex.cpp:925-927)
+{
+    if (c.V.emitters[object].numTris < 0) return (measure == M_DISCRETE ? 1.0 : 0.0) * (1.0 * c.S->emitterNormalization);   // point.cpp:93-95
+    return c.V.emitters[object].invSurfaceArea * (1.0 * c.S->emitterNormalization);
+}
 __device__ __forceinline__ Float area_direction(d3 d, d3 n, int measure)                    // AreaLight::evalDirection / pdfDirection, area.cpp:124-142
 {
     Float dp = dot(d, n);
     if (measure != M_SOLID || dp < 0) dp = 0.0;
     return GD_INV_PI * dp;
+}
+// Emitter::evalDirection == pdfDirection of an emitter sample: AreaLight (above) or PointEmitter, point.cpp:107-115
+#define GD_INV_FOURPI 0.07957747154594766788
+__device__ __forceinline__ Float emitter_direction(const Ctx &c, const BV &v, d3 d, int measure)
+{
+    if (v.prim == BV_OFF_SURFACE) return measure == M_SOLID ? GD_INV_FOURPI : 0.0;
+    return area_direction(d, v.n, measure);
 }
 __device__ __forceinline__ int bsdf_measure(int m) { return m == M_DISCRETE ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE; }
 
@@ -396,13 +418,23 @@ __device__ __noinline__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE
         if (is_zero(result)) return false;
         v.w[EImportance] = result;
         v.pdf[EImportance] = ppdf;
-        v.measure = M_AREA;
+        v.measure = succ.prim == BV_OFF_SURFACE ? M_DISCRETE : M_AREA;
         succ.type = T_EMITTER_SAMPLE;
         succ.degenerate = 0;
         succEdge.tr[EImportance] = 1.0;
         return true;
     } else if (v.type == T_EMITTER_SAMPLE) {                                               // AreaLight::sampleDirection, area.cpp:114-122
         const Float sx = c.rng.next1D(), sy = c.rng.next1D();
+        if (v.prim == BV_OFF_SURFACE) {                                                    // PointEmitter::sampleDirection, point.cpp:97-105: not EOnSurface, no cosine
+            const Float z = 1.0 - 2.0 * sy, r = safe_sqrt(1.0 - z * z);                     // warp::squareToUniformSphere, warp.cpp:25-31
+            rd = mk(r * cos(2.0 * GD_PI * sx), r * sin(2.0 * GD_PI * sx), z);
+            v.w[EImportance] = mk(1.0);
+            v.w[ERadiance] = mk(1.0) * GD_INV_FOURPI;
+            v.pdf[EImportance] = GD_INV_FOURPI;
+            v.pdf[ERadiance] = 1.0;
+            v.measure = M_SOLID;
+            ro = v.p;
+        } else {
         const d3 local = squareToCosineHemisphere(sx, sy);
         Frame3 fr; fr.n = v.n;
         if (fabs(fr.n.x) > fabs(fr.n.y)) { const Float il = 1.0 / sqrt(fr.n.x * fr.n.x + fr.n.z * fr.n.z); fr.t = mk(fr.n.z * il, 0.0, -fr.n.x * il); }   // coordinateSystem, util.cpp:592-601
@@ -416,6 +448,7 @@ __device__ __noinline__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE
         v.pdf[ERadiance] = 1.0;
         v.measure = M_SOLID;
         ro = v.p;
+        }
     } else if (v.type == T_SURFACE) {
         const Surf sf = surf_of(c, v);
         const d3 wi = normalize(pred->p - v.p);
@@ -522,6 +555,7 @@ __device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ,
 {
     if (v.type == T_EMITTER_SUPER) {
         if (mode != EImportance || pred != nullptr || succ->type != T_EMITTER_SAMPLE) return mk(0.0);
+        if (succ->prim == BV_OFF_SURFACE) return measure == M_DISCRETE ? c.V.emitters[succ->object].radiance * (4 * GD_PI) : mk(0.0);   // PointEmitter::evalPosition, point.cpp:89-91
         return c.V.emitters[succ->object].radiance * GD_PI;
     } else if (v.type == T_SENSOR_SUPER) {
         if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return mk(0.0);
@@ -536,7 +570,7 @@ __device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ,
         else return mk(0.0);
         const d3 wo = normalize(target - v.p);
         const int dm = measure == M_AREA ? M_SOLID : measure;
-        d3 result = mk(emitter ? area_direction(wo, v.n, dm) : (dm != M_SOLID ? 0.0 : sensor_direction(c, v.p, wo)));
+        d3 result = mk(emitter ? emitter_direction(c, v, wo, dm) : (dm != M_SOLID ? 0.0 : sensor_direction(c, v.p, wo)));
         const Float dp = fabs(dot(v.n, wo));
         if (measure != M_DISCRETE && dp != 0) result = result / dp;
         return result;
@@ -562,7 +596,7 @@ __device__ Float bv_eval_pdf(const Ctx &c, const BV &v, const BV *pred, const BV
     Float dist = 0.0, result = 0.0;
     if (v.type == T_EMITTER_SUPER) {
         if (mode != EImportance || pred != nullptr || succ->type != T_EMITTER_SAMPLE) return 0.0;
-        return pdf_emitter_position(c, succ->object);
+        return pdf_emitter_position(c, succ->object, measure);
     } else if (v.type == T_SENSOR_SUPER) {
         if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return 0.0;
         if (c.S->cam.thinlens) return measure == M_AREA ? c.cam.aperturePdf : 0.0;         // thinlens.cpp:382-384
@@ -572,7 +606,7 @@ __device__ Float bv_eval_pdf(const Ctx &c, const BV &v, const BV *pred, const BV
         else if (mode != EImportance || pred->type != T_EMITTER_SUPER) return 0.0;
         wo = succ->p - v.p;
         dist = len(wo); wo = wo / dist;
-        result = area_direction(wo, v.n, measure == M_AREA ? M_SOLID : measure);
+        result = emitter_direction(c, v, wo, measure == M_AREA ? M_SOLID : measure);
     } else if (v.type == T_SENSOR_SAMPLE) {
         if (mode == EImportance && succ->type == T_SENSOR_SUPER) return 1.0;
         else if (mode != ERadiance || pred->type != T_SENSOR_SUPER) return 0.0;
@@ -848,7 +882,7 @@ struct PairOut { d3 primal, gradient[4]; int nLight; LightSplat light[5]; };   /
 __device__ __noinline__ bool walk_paths(Ctx &c, Sample &sm, int px, int py)
 {
     const BdConfig &cfg = c.cfg;
-    const int emitterDepth = cfg.maxDepth + (c.S->cam.thinlens ? 1 : 0), sensorDepth = cfg.maxDepth + 1;   // :110-122: one more emitter step unless the sensor is a point (pinhole), hittable emitters
+    const int emitterDepth = cfg.maxDepth + (c.S->cam.thinlens ? 1 : 0), sensorDepth = cfg.maxDepth + (cfg.hittableEmitters ? 1 : 0);   // :110-122: one more emitter step unless the sensor is a point (pinhole), one more sensor step if an emitter can be hit
     // ---- Path::alternatingRandomWalkFromPixel, path.cpp:548-631 ----
     bv_clear(sm.X[0]); sm.X[0].type = T_SENSOR_SUPER; sm.X[0].degenerate = 1;               // makeEndpoint, vertex.cpp:27-33
     bv_clear(sm.Y[0]); sm.Y[0].type = T_EMITTER_SUPER; sm.Y[0].degenerate = 0;

@@ -719,6 +719,8 @@ int gdpt_scene_create_tex(int numTris, const double *verts, const double *normal
     s->perVertex = d.vn != nullptr || numTextures > 0;
     d.envIndex = envIndex;
     s->specialEmitters = env != nullptr || hasPoint;
+    s->hittableEmitters = false;                              // !Scene::hasDegenerateEmitters, scene.cpp:388,410-411: an emitter that is not EDeltaPosition (area, environment)
+    for (const EmitterD &o : ems) if (o.numTris >= 0) s->hittableEmitters = true;
     s->hostMats = mats;
     {
         // Scene::initializeBidirectional (scene.cpp:386-413): m_aabb = the kd-tree's AABB (enlarged by MTS_KD_AABB_EPSILON, gkdtree.h:1213-1219 --

@@ -11,6 +11,7 @@ struct gdpt_scene {
     int bvhDepth = 0;
     int numCUs = 256;
     bool specialEmitters = false;   // an environment or point emitter: the ENV builds of the render kernel
+    bool hittableEmitters = true;   // some emitter is not a point (G-BDPT: the sensor subpath's extra step, gbdpt_proc.cpp:120-122)
     bool perVertex = false;         // vertex normals or bitmap textures: the builds that keep a hit's barycentrics
     size_t ldsSceneBytes = 0;
     double bsphereRadius = 0.0;     // Scene::getBSphere().radius after Scene::initializeBidirectional (kd-tree bounds + sensor + emitters, scene.cpp:386-413)

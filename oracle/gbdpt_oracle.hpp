@@ -44,9 +44,11 @@ enum { EInvalid = 0, ESensorSupernode = 1, EEmitterSupernode = 2, ESensorSample 
 enum { EValueImp = 0x01, EValueRad = 0x02, ECosineImp = 0x04, ECosineRad = 0x08, EInverseSquareFalloff = 0x10, ETransmittance = 0x20,
        EGeometricTerm = 0x04 | 0x08 | 0x10, EGeneralizedGeometricTerm = 0x04 | 0x08 | 0x10 | 0x20 };   // include/mitsuba/bidir/edge.h:171-185
 
+const Float INV_FOURPI = 0.07957747154594766788;
 struct Config { int maxDepth, rrDepth, lightImage, spp; Float shiftThreshold; uint64_t seed; };
 
-struct PRec { V3 p, n; Float pdf = 0; int measure = 0; Float uvx = 0, uvy = 0; int object = -1; };   // PositionSamplingRecord, common.h:70-150
+struct PRec { V3 p, n; Float pdf = 0; int measure = 0; Float uvx = 0, uvy = 0; int object = -1;       // PositionSamplingRecord, common.h:70-150
+              bool onSurface = true; };        // object->getType() & EOnSurface: area lights and both perspective sensors; a `point` emitter is not (point.cpp:56)
 
 struct Vertex {                                     // PathVertex, vertex.h
     int type = EInvalid;
@@ -62,7 +64,7 @@ struct Vertex {                                     // PathVertex, vertex.h
     bool isSupernode() const { return (type & ESupernode) != 0; }
     bool isConnectable() const { return !degenerate && measure != EDiscrete; }             // vertex.h:750
     bool isSurface() const { return type == ESurfaceInteraction; }
-    bool isOnSurface() const { return type == ESurfaceInteraction || type == EEmitterSample || type == ESensorSample; }   // vertex.h:592-596: area lights and the perspective sensor are EOnSurface
+    bool isOnSurface() const { return type == ESurfaceInteraction || ((type == EEmitterSample || type == ESensorSample) && prec.onSurface); }   // vertex.h:592-596
     V3 position() const { return type == ESurfaceInteraction ? its.p : prec.p; }           // vertex.cpp:1213-1229
     V3 shadingNormal() const { return type == ESurfaceInteraction ? its.sh.n : prec.n; }   // :1231-1243
     V3 geometricNormal() const { return type == ESurfaceInteraction ? its.geoN : prec.n; } // :1245-1257
@@ -199,6 +201,11 @@ inline V3 sampleEmitterPosition(const Ctx &c, PRec &pRec, Float sx, Float sy)
     Float emPdf;
     const size_t index = sc.emitterPDF.sampleReuse(sx, emPdf);
     const Emitter &em = sc.emitters[index];
+    if (em.numTris < 0) {                                                                  // PointEmitter::samplePosition, point.cpp:79-87
+        pRec.p = em.position; pRec.n = V3(0.0); pRec.pdf = 1.0; pRec.measure = EDiscrete; pRec.object = (int)index; pRec.onSurface = false;
+        pRec.pdf *= emPdf;
+        return (em.radiance * (4 * PI)) / emPdf;
+    }
     if (em.rectangle) {                                                                    // rectangle.cpp:210-216
         const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
         const Float *M = em.rect;
@@ -227,9 +234,17 @@ inline V3 sampleEmitterPosition(const Ctx &c, PRec &pRec, Float sx, Float sy)
     const V3 power = em.radiance * PI * area;                                              // m_power = m_radiance * M_PI * getSurfaceArea(), area.cpp:196
     return power / emPdf;
 }
-inline Float pdfEmitterPosition(const Ctx &c, const PRec &pRec)                            // scene.cpp:1003-1006
+inline Float pdfEmitterPosition(const Ctx &c, const PRec &pRec, int measure)               // scene.cpp:1003-1006 (pRec.measure = measure, vertex.cpp:925-927)
 {
+    if (c.sc.emitters[pRec.object].numTris < 0) return (measure == EDiscrete ? 1.0 : 0.0) * (1.0 * c.sc.emitterPDF.normalization);   // point.cpp:93-95
     return c.sc.emitters[pRec.object].invSurfaceArea * (1.0 * c.sc.emitterPDF.normalization);
+}
+// Emitter::evalDirection == pdfDirection of an emitter sample: AreaLight (below), PointEmitter::evalDirection / pdfDirection, point.cpp:107-115
+inline Float areaDirection(V3 d, V3 n, int measure);
+inline Float emitterDirection(const Ctx &c, const PRec &pRec, V3 d, int measure)
+{
+    if (c.sc.emitters[pRec.object].numTris < 0) return measure == ESolidAngle ? INV_FOURPI : 0.0;
+    return areaDirection(d, pRec.n, measure);
 }
 inline Float areaDirection(V3 d, V3 n, int measure)                                        // AreaLight::evalDirection / pdfDirection, area.cpp:124-142
 {
@@ -410,13 +425,26 @@ struct Tracer {
             v->pdf[EImportance] = succ->prec.pdf;
             v->measure = succ->prec.measure;
             succ->type = EEmitterSample;
-            succ->degenerate = false;                                                      // area lights have no EDeltaDirection
+            succ->degenerate = false;                                                      // neither area nor point lights have EDeltaDirection
             succEdge->weight[EImportance] = V3(1.0);
             succEdge->pdf[EImportance] = 1.0;
             return true;
         }
         case EEmitterSample: {                                                             // :97-121, AreaLight::sampleDirection area.cpp:114-122
             const Float sx = rng.next1D(), sy = rng.next1D();
+            if (c.sc.emitters[v->prec.object].numTris < 0) {                               // PointEmitter::sampleDirection, point.cpp:97-105: not EOnSurface, no cosine
+                const Float z = 1.0 - 2.0 * sy, r = safe_sqrt(1.0 - z * z);                 // warp::squareToUniformSphere, warp.cpp:25-31
+                const Float sinPhi = std::sin(2.0 * PI * sx), cosPhi = std::cos(2.0 * PI * sx);
+                const V3 d(r * cosPhi, r * sinPhi, z);
+                const V3 result(1.0);
+                v->weight[EImportance] = result;
+                v->weight[ERadiance] = result * INV_FOURPI;
+                v->pdf[EImportance] = INV_FOURPI;
+                v->pdf[ERadiance] = 1.0;
+                v->measure = ESolidAngle;
+                ray = Ray(v->prec.p, d);
+                break;
+            }
             const V3 local = squareToCosineHemisphere(sx, sy);
             Frame fr; fr.n = v->prec.n; coordinateSystem(fr.n, fr.s, fr.t);
             const V3 d = fr.toWorld(local);
@@ -578,6 +606,8 @@ struct Tracer {
         switch (v->type) {
         case EEmitterSupernode:
             if (mode != EImportance || pred != nullptr || succ->type != EEmitterSample) return V3(0.0);
+            if (c.sc.emitters[succ->prec.object].numTris < 0)                              // PointEmitter::evalPosition, point.cpp:89-91
+                return measure == EDiscrete ? c.sc.emitters[succ->prec.object].radiance * (4 * PI) : V3(0.0);
             return c.sc.emitters[succ->prec.object].radiance * PI;                         // AreaLight::evalPosition, area.cpp:99-101
         case ESensorSupernode:
             if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return V3(0.0);
@@ -589,7 +619,7 @@ struct Tracer {
             else if (mode == ERadiance && succ->type == EEmitterSupernode) target = pred->position();
             else return V3(0.0);
             const V3 wo = normalize(target - v->prec.p);
-            V3 result(areaDirection(wo, v->prec.n, measure == EArea ? ESolidAngle : measure));
+            V3 result(emitterDirection(c, v->prec, wo, measure == EArea ? ESolidAngle : measure));
             const Float dp = std::abs(dot(v->prec.n, wo));
             if (measure != EDiscrete && dp != 0) result = result / dp;
             return result;
@@ -628,7 +658,7 @@ struct Tracer {
         switch (v->type) {
         case EEmitterSupernode:
             if (mode != EImportance || pred != nullptr || succ->type != EEmitterSample) return 0.0;
-            return pdfEmitterPosition(c, succ->prec);
+            return pdfEmitterPosition(c, succ->prec, measure);
         case ESensorSupernode:
             if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return 0.0;
             if (c.thinlens) return measure == EArea ? c.aperturePdf : 0.0;                 // thinlens.cpp:382-384
@@ -638,7 +668,7 @@ struct Tracer {
             else if (mode != EImportance || pred->type != EEmitterSupernode) return 0.0;
             wo = succ->position() - v->prec.p;
             dist = length(wo); wo = wo / dist;
-            result = areaDirection(wo, v->prec.n, measure == EArea ? ESolidAngle : measure);
+            result = emitterDirection(c, v->prec, wo, measure == EArea ? ESolidAngle : measure);
             break;
         case ESensorSample:
             if (mode == EImportance && succ->type == ESensorSupernode) return 1.0;
@@ -1763,7 +1793,9 @@ struct Tracer {
         int emitterDepth = cfg.maxDepth, sensorDepth = cfg.maxDepth;
         // the perspective sensor is degenerate (EDeltaPosition): no extra emitter step; area emitters can be hit: one more sensor step (:116-122)
         if (c.thinlens && emitterDepth != -1) ++emitterDepth;                              // "go one extra step if the sensor can be intersected": not EDeltaPosition, :117-118
-        if (sensorDepth != -1) ++sensorDepth;
+        bool degenerateEmitters = true;                                                    // Scene::hasDegenerateEmitters, scene.cpp:388,410-411: every emitter is EDeltaPosition
+        for (const Emitter &em : c.sc.emitters) if (em.numTris >= 0) degenerateEmitters = false;
+        if (!degenerateEmitters && sensorDepth != -1) ++sensorDepth;
         const int neighborCount = 4;
         std::vector<ShiftPathData> pathData(neighborCount + 1, ShiftPathData(sensorDepth + 3));
         pathData[0].success = true;

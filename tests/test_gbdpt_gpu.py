@@ -152,6 +152,47 @@ def test_thinlens_sensor_samples_and_films_match_oracle(G, B, name, md, li, lens
     F.close(); S.close(); O.close()
 
 
+@pytest.mark.parametrize("name,md,li,mode", [("diffuse", 5, True, "both"), ("diffuse", -1, False, "first"), ("rough", 6, True, "only"), ("glass", 7, True, "both"),
+                                              ("glossy", -1, True, "only"), ("twosided", 4, True, "only")])
+def test_point_emitters_samples_and_films_match_oracle(G, B, name, md, li, mode):
+    """`point` emitters under G-BDPT (round 5; refused until then): a position sample with a discrete measure (the emitter end of a path is not connectable, so no
+    strategy ever 'hits' the light: point.cpp:79-95), directions uniform over the sphere without a cosine (not EOnSurface: point.cpp:97-115, vertex.h:592-596), and
+    -- when EVERY emitter is a point -- no extra sensor step (Scene::hasDegenerateEmitters, gbdpt_proc.cpp:120-122).  Beside, before, and instead of the area light."""
+    W, H = 40, 30
+    sc = builders()[name](W, H)
+    pl = ("point", (278.0, 400.0, 279.5), (4e4, 3e4, 2e4))
+    sc.emitters = {"both": sc.emitters + [pl], "first": [pl] + sc.emitters, "only": [pl, ("point", (120.0, 90.0, 140.0), (1e4, 2e4, 3e4))]}[mode]
+    S, O = G.Scene(sc), go.Scene(sc)
+    integ = B.GBDPTIntegrator(maxDepth=md, lightImage=li)
+    cfg, ocfg = integ.config(64), go.gbdpt_config(maxDepth=md, lightImage=li, spp=64)
+    rng = np.random.default_rng(29)
+    nonzero = 0
+    for _ in range(60):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
+        g = integ.evaluate_sample(S, cfg, px, py, s)
+        o = O.gbdpt_sample(ocfg, px, py, s)
+        compare_sample(g, o, (name, md, li, mode, px, py, s))
+        assert g["overflow"] == 0
+        nonzero += bool(o["primal"].any())
+    assert nonzero > 20
+    spp = 2
+    F = B.Film(S)
+    integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+    blk, light = F.accum()
+    st = F.stats()
+    oblk, olight, ocnt = O.gbdpt_render(go.gbdpt_config(maxDepth=md, lightImage=li, spp=spp))
+    assert ocnt["unsupported"] == 0 and F.chain_stats()["overflows"] == 0
+    # (ray counts: a sample whose weight underflows to exactly 0 on one side and to 1e-31 on the other traces its four offset paths on one side only -- two of the
+    #  2400 samples of the two-point-lights film, located with tools/gpu_gbdpt_point_locate.py; outputs equal.  The fuzz tool counts these as "ray-count knife edges")
+    assert abs(st["raysTraced"] - ocnt["raysTraced"]) <= 1e-3 * ocnt["raysTraced"] and abs(st["shadowRaysTraced"] - ocnt["shadowRaysTraced"]) <= 1e-3 * ocnt["shadowRaysTraced"]
+    if mode != "only" and name not in ("glass", "glossy"):
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == (ocnt["raysTraced"], ocnt["shadowRaysTraced"])
+    for a, b in ((blk, oblk), (light, olight)):
+        scale = np.abs(b).max() + 1e-300
+        assert np.abs(a - b).max() <= 1e-9 * scale, (name, np.abs(a - b).max() / scale)
+    F.close(); S.close(); O.close()
+
+
 def test_shutter_interval_draws_the_time_sample_first(G, B):
     """gbdpt_proc.cpp:156-157: with needsTimeSample() the time sample is the FIRST draw of a sample (before the random walks); the subpaths' time moves
     nothing (static transforms).  Samples and a film against the oracle, with the general form in play (glass)."""

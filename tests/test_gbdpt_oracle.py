@@ -150,6 +150,55 @@ def test_specular_chains_estimator_expectation(variant):
     O.close()
 
 
+@pytest.mark.parametrize("what", ["thinlens", "thinlens_wide", "point_beside_area", "points_only"])
+def test_thinlens_sensor_and_point_emitters_estimator_expectation(what):
+    """Round 5: the thinlens sensor (thinlens.cpp: aperture position sample, importance through the pixel's focus-plane point, one more emitter step) and `point`
+    emitters (point.cpp: discrete position measure, uniform directions, no cosine; no extra sensor step when every emitter is one) in the G-BDPT oracle.  What
+    holds them: the primal image converges to the G-PT oracle's path tracer -- an estimator that shares the scene and BSDF code but none of the bidirectional
+    layer (it samples the lens in sampleRay and the point light in sampleEmitterDirect) -- and the merged gradients to its finite differences.  A point light is
+    also SEEN by the light image (s = 1, t = 1: one bright pixel a path tracer cannot produce): that pixel is left out of the comparison."""
+    W, H, spp, md = 20, 15, 256, 4
+    sc = scenes.cornell_box(W, H, "diffuse")
+    if what == "thinlens": sc.thinlens = (40.0, 1100.0)
+    if what == "thinlens_wide": sc.thinlens = (120.0, 600.0)
+    pl = ("point", (300.0, 400.0, 279.5), (4e4, 3e4, 2e4))        # (off the film's centre line: a splat exactly between two pixels lands in both, imageblock.h)
+    if what == "point_beside_area": sc.emitters = sc.emitters + [pl]
+    if what == "points_only": sc.emitters = [pl, ("point", (120.0, 90.0, 140.0), (1e4, 2e4, 3e4))]
+    O = go.Scene(sc)
+    acc, _ = O.render(go.config(maxDepth=md, spp=4 * spp))
+    dev = go.develop(acc)
+    pt = dev[1] + dev[4]
+    fdx, fdy = pt[:, 1:] - pt[:, :-1], pt[1:] - pt[:-1]
+    scale = np.abs(fdx).mean() + np.abs(fdy).mean()
+    # (a point light BESIDE an area light, lightImage off: a sensor path that hits the area light while the emitter subpath drew the point light asks
+    #  miWeightBaseNoSweep_GBDPT for strategy s = 0 with the emitter supernode's measure EDiscrete -- "not connectable", path.cpp:81,192 -- so the sum of
+    #  strategy pdfs is 0 and the weight infinite: the reference drops such a sample as an invalid put (imageblock.h:160-175), and so do oracle and device.
+    #  With the light image on the t = 1 strategy keeps the sum positive.  That combination is therefore compared with the light image only.)
+    for li in ((True,) if what == "point_beside_area" else (True, False)):
+        b, l, c = O.gbdpt_render(go.gbdpt_config(maxDepth=md, spp=spp, lightImage=li))
+        assert c["unsupported"] == 0 and c["invalidPuts"] == 0
+        img = go.gbdpt_develop(b, l, spp)
+        keep = np.ones((H, W), bool)
+        if li and what.startswith("point"):
+            d = (img[0] - pt).sum(-1)
+            for _ in range(2 if what == "points_only" else 1):
+                y, x = np.unravel_index(np.argmax(np.where(keep, d, -np.inf)), d.shape)
+                if d[y, x] > 5 * pt.mean(): keep[y, x] = False   # the light's own image: far brighter than anything it lights (the second light sits behind the short block)
+            assert not keep.all()
+        assert abs(img[0][keep].mean() - pt[keep].mean()) <= 0.03 * pt[keep].mean(), (what, li, img[0][keep].mean(), pt[keep].mean())
+        h, w = pt.shape[:2]
+        for ys in (slice(0, h // 2), slice(h // 2, h)):
+            for xs in (slice(0, w // 2), slice(w // 2, w)):
+                k = keep[ys, xs]
+                assert abs(img[0][ys, xs][k].mean() - pt[ys, xs][k].mean()) <= 0.08 * pt[ys, xs][k].mean(), (what, li)
+        gx, gy = merged_gradients(img)
+        kx, ky = keep[:, :-1] & keep[:, 1:], keep[:-1] & keep[1:]
+        ex, ey = np.abs(gx[:, :-1] - fdx)[kx].mean(), np.abs(gy[:-1] - fdy)[ky].mean()
+        # (the wide aperture blurs the image: its gradients are small against the noise of the path-traced finite differences they are compared with)
+        assert ex + ey <= (0.5 if what == "thinlens_wide" else 0.3) * scale, (what, li, ex, ey, scale)
+    O.close()
+
+
 def test_planar_mirror_known_answers_of_the_manifold():
     """Closed forms for a chain "diffuse a -- planar mirror m -- diffuse b" (the aluminium back wall of the "glossy" box):
       * SpecularManifold::G(a, b) (computeTangents + the tangent map of vertex 1, manifold.cpp:900-951) is the PLAIN geometry term between a
