@@ -718,6 +718,10 @@ __device__ bool generate_offset(Ctx &c, const BV &srcA, const BV &S0, const BE &
     if (o.b.type == T_SURFACE && o.b.componentType == 0) o.b.componentType = srcB.componentType;
     Float jy = 1.0; jy /= o.a.pdf[ERadiance];
     Float jx = 1.0; jx /= srcA.pdf[ERadiance];
+    // (b of a light path with s = 1 is the emitter sample.  A `point` emitter's sample has the shading normal 0 (point.cpp:82), so Path::G(a - 1, a) == G(b, a) == 0
+    //  and the reference's quotient is 0 / 0: it warns "Invalid Path::halfJacobian" and carries the NaN into the gradient, which the film then drops as an invalid
+    //  put.  Only reached when the shifted ray happens to end on an AREA light, so that the offset path connects at all.)
+    if (srcB.type == T_EMITTER_SAMPLE && srcB.prim == BV_OFF_SURFACE) jx *= __builtin_nan("");
     o.jacobian = jy / jx;
     o.success = 1;
     return true;

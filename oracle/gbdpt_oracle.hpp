@@ -1683,6 +1683,7 @@ struct Tracer {
                             }
                         }
                     } while (false);
+                    if (g_traceMain && t < 2 && k > 0) std::fprintf(stderr, "   light path: jacobian %.17g genGeomTerm %.17g (base %.17g)\n", jacobianLP[k - 1], genGeomTermLP[k], genGeomTermLP[0]);
                     if (g_traceMain) std::fprintf(stderr, "st %d %d k %d ok %d value %.17g %.17g %.17g pdf %.17g miW %.17g geom %.17g rays %llu %llu\n", s, t, k, (int)pathSuccess[k], value[k].x, value[k].y, value[k].z, valuePdf[k], miWeight[k], geomTerm.x,
                                                   (unsigned long long)c.sc.raysTraced, (unsigned long long)c.sc.shadowRaysTraced);
                     if (isZero(value[k]) || isZero(value[0])) {

@@ -40,15 +40,17 @@ def compare_sample(g, o, what):
     assert o["unsupported"] == 0, what
     assert (g["raysTraced"], g["shadowRaysTraced"]) == (o["raysTraced"], o["shadowRaysTraced"]), what
     assert np.allclose(g["position"], o["position"], rtol=1e-14, atol=0), what
-    scale = max(np.abs(o["primal"]).max(), np.abs(o["gradients"]).max(), 1e-300)
-    assert np.allclose(g["primal"], o["primal"], rtol=1e-9, atol=1e-12 * scale), (what, g["primal"], o["primal"])
-    assert np.allclose(g["gradients"], o["gradients"], rtol=1e-9, atol=1e-12 * scale), (what, g["gradients"], o["gradients"])
+    # (a value the reference's own arithmetic makes NaN or infinite -- DESIGN.md "G-BDPT: endpoints" -- has to be NaN or infinite on both sides)
+    fin = lambda a: np.nan_to_num(np.asarray(a, float), nan=0.0, posinf=0.0, neginf=0.0)
+    scale = max(np.abs(fin(o["primal"])).max(), np.abs(fin(o["gradients"])).max(), 1e-300)
+    assert np.allclose(g["primal"], o["primal"], rtol=1e-9, atol=1e-12 * scale, equal_nan=True), (what, g["primal"], o["primal"])
+    assert np.allclose(g["gradients"], o["gradients"], rtol=1e-9, atol=1e-12 * scale, equal_nan=True), (what, g["gradients"], o["gradients"])
     assert g["light"].shape == o["light"].shape, what
     if len(o["light"]):
         assert np.array_equal(g["light"][:, 2], o["light"][:, 2]), what
         assert np.allclose(g["light"][:, :2], o["light"][:, :2], rtol=1e-12, atol=1e-9), what
-        ls = np.abs(o["light"][:, 3:]).max() + 1e-300
-        assert np.allclose(g["light"][:, 3:], o["light"][:, 3:], rtol=1e-9, atol=1e-12 * ls), what
+        ls = np.abs(fin(o["light"][:, 3:])).max() + 1e-300
+        assert np.allclose(g["light"][:, 3:], o["light"][:, 3:], rtol=1e-9, atol=1e-12 * ls, equal_nan=True), what
 
 
 @pytest.mark.parametrize("name,md,li", [("diffuse", 5, True), ("diffuse", -1, True), ("diffuse", 3, False), ("twosided", 7, True), ("rough", 6, True),
@@ -153,7 +155,7 @@ def test_thinlens_sensor_samples_and_films_match_oracle(G, B, name, md, li, lens
 
 
 @pytest.mark.parametrize("name,md,li,mode", [("diffuse", 5, True, "both"), ("diffuse", -1, False, "first"), ("rough", 6, True, "only"), ("glass", 7, True, "both"),
-                                              ("glossy", -1, True, "only"), ("twosided", 4, True, "only")])
+                                              ("glossy", -1, True, "only"), ("twosided", 4, True, "only"), ("diffuse", 5, True, "nan"), ("rough", 4, True, "nan_lens")])
 def test_point_emitters_samples_and_films_match_oracle(G, B, name, md, li, mode):
     """`point` emitters under G-BDPT (round 5; refused until then): a position sample with a discrete measure (the emitter end of a path is not connectable, so no
     strategy ever 'hits' the light: point.cpp:79-95), directions uniform over the sphere without a cosine (not EOnSurface: point.cpp:97-115, vertex.h:592-596), and
@@ -161,12 +163,18 @@ def test_point_emitters_samples_and_films_match_oracle(G, B, name, md, li, mode)
     W, H = 40, 30
     sc = builders()[name](W, H)
     pl = ("point", (278.0, 400.0, 279.5), (4e4, 3e4, 2e4))
-    sc.emitters = {"both": sc.emitters + [pl], "first": [pl] + sc.emitters, "only": [pl, ("point", (120.0, 90.0, 140.0), (1e4, 2e4, 3e4))]}[mode]
+    # "nan": a point light just below the area light.  The light image sees it (s = 1, t = 1), and the ray of that splat's upward shift ends ON the area light, so the
+    # offset path connects -- and the reference's half-Jacobian of the base path is G / G with the point sample's zero normal: 0 / 0 (DESIGN.md "G-BDPT: endpoints").
+    # The NaN must come out of both sides, and the film must drop the same puts.
+    under = ("point", (298.0, 535.0, 280.0), (4e4, 3e4, 2e4))
+    sc.emitters = {"both": sc.emitters + [pl], "first": [pl] + sc.emitters, "only": [pl, ("point", (120.0, 90.0, 140.0), (1e4, 2e4, 3e4))],
+                   "nan": sc.emitters + [under], "nan_lens": [under] + sc.emitters}[mode]
+    if mode == "nan_lens": sc.thinlens = (30.0, 1080.0)
     S, O = G.Scene(sc), go.Scene(sc)
     integ = B.GBDPTIntegrator(maxDepth=md, lightImage=li)
     cfg, ocfg = integ.config(64), go.gbdpt_config(maxDepth=md, lightImage=li, spp=64)
     rng = np.random.default_rng(29)
-    nonzero = 0
+    nonzero = nans = 0
     for _ in range(60):
         px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
         g = integ.evaluate_sample(S, cfg, px, py, s)
@@ -174,7 +182,8 @@ def test_point_emitters_samples_and_films_match_oracle(G, B, name, md, li, mode)
         compare_sample(g, o, (name, md, li, mode, px, py, s))
         assert g["overflow"] == 0
         nonzero += bool(o["primal"].any())
-    assert nonzero > 20
+        nans += bool(len(o["light"]) and np.isnan(o["light"]).any())
+    assert nonzero > 20 and (nans > 5) == mode.startswith("nan"), (nonzero, nans)
     spp = 2
     F = B.Film(S)
     integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
@@ -182,6 +191,7 @@ def test_point_emitters_samples_and_films_match_oracle(G, B, name, md, li, mode)
     st = F.stats()
     oblk, olight, ocnt = O.gbdpt_render(go.gbdpt_config(maxDepth=md, lightImage=li, spp=spp))
     assert ocnt["unsupported"] == 0 and F.chain_stats()["overflows"] == 0
+    assert st["invalidPuts"] == ocnt["invalidPuts"] and (ocnt["invalidPuts"] > 100) == mode.startswith("nan"), (st["invalidPuts"], ocnt["invalidPuts"])
     # (ray counts: a sample whose weight underflows to exactly 0 on one side and to 1e-31 on the other traces its four offset paths on one side only -- two of the
     #  2400 samples of the two-point-lights film, located with tools/gpu_gbdpt_point_locate.py; outputs equal.  The fuzz tool counts these as "ray-count knife edges")
     assert abs(st["raysTraced"] - ocnt["raysTraced"]) <= 1e-3 * ocnt["raysTraced"] and abs(st["shadowRaysTraced"] - ocnt["shadowRaysTraced"]) <= 1e-3 * ocnt["shadowRaysTraced"]

@@ -4,7 +4,8 @@ anisotropic, one- or two-sided), or (every fifth) the Veach-bidir stand-in; rand
 probe entry (primal, four gradients, film position, every light splat, both ray counters) and one small whole film through the wavefront kernels
 (camera blocks, light images, ray counters).  Prints the first mismatch and exits non-zero, or a summary.
 GBDPT_FUZZ_SPECULAR=1: the free surfaces draw from EVERY material (smooth conductors, dielectrics, rough conductors on both sides of shiftThreshold) and the
-Veach-class room comes with its glass egg and mirror: samples with specular chains, i.e. the general form (csrc/gbdpt_general.hip.h)."""
+Veach-class room comes with its glass egg and mirror: samples with specular chains, i.e. the general form (csrc/gbdpt_general.hip.h).
+GBDPT_FUZZ_ENDPOINTS=1: half of the seeds get a thinlens sensor, most Cornell seeds one or two point emitters beside, before or instead of the area light."""
 import sys, time
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -43,6 +44,16 @@ for seed in range(first, first + count):
     else:
         sc = scenes.veach_bidir(W, H) if seed % 5 == 0 else scenes.cornell_box(W, H, "random_connectable", seed=seed)
     md = int(rng.choice([-1, 1, 2, 3, 5, 8, 12, 16, 20])); rr = int(rng.choice([1, 3, 5])); li = bool(rng.random() < 0.7)
+    if os.environ.get("GBDPT_FUZZ_ENDPOINTS"):      # round 5: the endpoints G-BDPT refused until then -- a thinlens sensor, point emitters beside / before / instead of the area light
+        r2 = np.random.default_rng(1000003 * seed + 17)
+        cornell = seed % 5 != 0
+        if r2.random() < 0.5:
+            sc.thinlens = (float(r2.uniform(2.0, 60.0)), float(r2.uniform(300.0, 1500.0))) if cornell else (float(r2.uniform(0.05, 0.5)), float(r2.uniform(5.0, 15.0)))
+            md = min(md, 19)
+        if cornell and r2.random() < 0.6:
+            pls = [("point", tuple(float(v) for v in r2.uniform(40.0, 510.0, 3)), tuple(float(v) for v in r2.uniform(2e3, 5e4, 3))) for _ in range(int(r2.integers(1, 3)))]
+            mode = int(r2.integers(0, 3))
+            sc.emitters = sc.emitters + pls if mode == 0 else (pls + sc.emitters if mode == 1 else pls)
     spp = int(rng.integers(1, 4))
     S = G.Scene(sc); O = go.Scene(sc)
     integ = B.GBDPTIntegrator(maxDepth=md, rrDepth=rr, lightImage=li)
@@ -55,9 +66,13 @@ for seed in range(first, first + count):
         gl, ol = np.asarray(g["light"]).reshape(-1, 6), np.asarray(o["light"]).reshape(-1, 6)
         bad = None
         for key in ("primal", "gradients", "position"):
-            d = np.abs(np.asarray(g[key]) - np.asarray(o[key])).max()
+            if not np.array_equal(np.isfinite(np.asarray(g[key])), np.isfinite(np.asarray(o[key]))): bad = bad or key      # (an invalid value on one side only)
+            d = np.nanmax(np.abs(np.nan_to_num(np.asarray(g[key]), nan=0.0, posinf=0.0, neginf=0.0) - np.nan_to_num(np.asarray(o[key]), nan=0.0, posinf=0.0, neginf=0.0)))
             if d > 1e-9 * (scale if key != "position" else 1.0) + 1e-13: bad = bad or key
             elif key != "position" and scale > 1e-6: worst = max(worst, d / scale)     # (relative to the sample's scale, for samples that carry light)
+        if gl.shape == ol.shape and len(ol):
+            if not np.array_equal(np.isfinite(gl), np.isfinite(ol)): bad = bad or "light splats"
+            gl, ol = np.nan_to_num(gl, nan=0.0, posinf=0.0, neginf=0.0), np.nan_to_num(ol, nan=0.0, posinf=0.0, neginf=0.0)
         if gl.shape != ol.shape or (len(ol) and (not np.array_equal(gl[:, 2], ol[:, 2]) or np.abs(gl[:, :2] - ol[:, :2]).max() > 1e-9 or
                                                  np.abs(gl[:, 3:] - ol[:, 3:]).max() > 1e-9 * max(np.abs(ol[:, 3:]).max(), 1e-300) + 1e-13)):
             bad = bad or "light splats"
