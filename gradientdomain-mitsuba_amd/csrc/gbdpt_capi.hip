@@ -567,7 +567,6 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
     if (s->d.cam.thinlens && (cfg->maxDepth < 0 ? BD_DEFAULT_DEPTH : cfg->maxDepth) > BD_MAX_DEPTH - 1)   // (the extra emitter step of a non-degenerate sensor, gbdpt_proc.cpp:117-118, needs one more record)
         return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d with the thinlens sensor", BD_MAX_DEPTH - 1);
-    if (s->d.envIndex >= 0) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: environment emitters are not carried (area and point emitters only)");
     // (round 4: Dirac BSDFs and rough conductors below shiftThreshold are carried -- samples that meet one run the general form, gbdpt_general.hip.h)
     return GDPT_OK;
 }
@@ -903,12 +902,18 @@ int gdpt_gbdpt_evaluate_sample2(gdpt_scene *s, const gdpt_gbdpt_config *cfg, int
     BHIPCHK(hipMalloc((void **)&b.dc, sizeof(unsigned long long) * 4));
     BHIPCHK(hipMalloc((void **)&b.work, sizeof(GWork)));
     BHIPCHK(hipMemset(b.dc, 0, sizeof(unsigned long long) * 4));
+#ifdef GDPT_BD_CHECK_PRIM
+    { int z[4] = {0, 0, 0, 0}; BHIPCHK(hipMemset(b.work, 0x7f, sizeof(GWork))); BHIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_bdPrimTrap), z, sizeof z)); }
+#endif
     hipLaunchKernelGGL(k_gbdpt_sample, dim3(1), dim3(TBLK), 0, 0, s->d, cam, c, px, py, sample, b.d, maxLight, b.dl, b.dn, b.dc, b.work);
     BHIPCHK(hipGetLastError());
     BHIPCHK(hipMemcpy(out17, b.d, sizeof(double) * 17, hipMemcpyDeviceToHost));
     BHIPCHK(hipMemcpy(nLight, b.dn, sizeof(int), hipMemcpyDeviceToHost));
     if (maxLight > 0) BHIPCHK(hipMemcpy(light6, b.dl, sizeof(double) * 6 * std::min(maxLight, std::max(*nLight, 0)), hipMemcpyDeviceToHost));
     BHIPCHK(hipMemcpy(counters, b.dc, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost));
+#ifdef GDPT_BD_CHECK_PRIM
+    { int z[4]; BHIPCHK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bdPrimTrap), sizeof z)); if (z[2]) fprintf(stderr, "G-BDPT prim trap: pixel (%d, %d) sample %d: %d loads outside the tables, first at site %d (len*1000 + line) with prim %d\n", px, py, sample, z[2], z[0], z[1]); }
+#endif
     return GDPT_OK;
 }
 

@@ -119,6 +119,7 @@ struct GWork { GSamp s; GScratch x; };            // both for one lane: the prob
 // its.dpdu / its.dpdv of a triangle hit (skdtree.h:373-380, trimesh.cpp:683-735): the edges, or the UV tangents of a mesh with texture coordinates
 __device__ void tri_partials(const Ctx &c, int prim, d3 &dpdu, d3 &dpdv)
 {
+    prim = BD_PRIM(c, prim, "tri_partials");
     const TriShade &ts = c.V.shade[prim];
     const d3 dP1 = ts.p1 - ts.p0, dP2 = ts.p2 - ts.p0;
     dpdu = dP1; dpdv = dP2;
@@ -325,10 +326,11 @@ struct GTrT {
     // ---- SpecularManifold, manifold.cpp ----
     __device__ void normalDerivative(const BV &v, d3 &dndu, d3 &dndv)                        // TriMesh::getNormalDerivative, trimesh.cpp:745-822
     {
-        const TriShade &ts = c.V.shade[v.prim];
+        const int prim = BD_PRIM(c, v.prim, "normalDerivative");
+        const TriShade &ts = c.V.shade[prim];
         dndu = dndv = mk(0.0);
         if (!(c.V.vn && ts.smooth)) return;
-        const TriNormals vn = c.V.vn[v.prim];
+        const TriNormals vn = c.V.vn[prim];
         const d3 rel = v.p - ts.p0, du = ts.p1 - ts.p0, dv = ts.p2 - ts.p0;
         const Float b1 = dot(du, rel), b2 = dot(dv, rel), a11 = dot(du, du), a12 = dot(du, dv), a22 = dot(dv, dv);
         Float det = a11 * a22 - a12 * a12;
@@ -339,8 +341,8 @@ struct GTrT {
         const Float il = 1.0 / len(N); N = N * il;
         dndu = (vn.n1 - vn.n0) * il; dndu = dndu - N * dot(N, dndu);
         dndv = (vn.n2 - vn.n0) * il; dndv = dndv - N * dot(N, dndv);
-        if (c.V.uv && c.V.hasUV[v.prim]) {
-            const TriUV t = c.V.uv[v.prim];
+        if (c.V.uv && c.V.hasUV[prim]) {
+            const TriUV t = c.V.uv[prim];
             const Float d1x = t.uv[2] - t.uv[0], d1y = t.uv[3] - t.uv[1], d2x = t.uv[4] - t.uv[0], d2y = t.uv[5] - t.uv[1];
             det = d1x * d2y - d1y * d2x;
             if (det == 0) { dndu = dndv = mk(0.0); return; }
@@ -351,7 +353,7 @@ struct GTrT {
     }
     __device__ void manifoldSurface(MV &m, const BV &v)                                       // manifold.cpp:101-122,480-507
     {
-        Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+        Vertex vx; vx.p = v.p; vx.prim = BD_PRIM(c, v.prim, "manifoldSurface"); vx.u = v.u; vx.v = v.v;
         const Shading sh = shading_at<true>(c.V, vx);
         m.p = v.p; m.gn = sh.geoN; m.n = sh.fr.n;
         tri_partials(c, v.prim, m.dpdu, m.dpdv);
@@ -377,7 +379,7 @@ struct GTrT {
             mv_init(m, MV_PINNED, mk(0.0));
             if (vertex.type != T_SURFACE) return false;
             manifoldSurface(m, vertex);
-            m.object = c.V.shade[vertex.prim].material;
+            m.object = c.V.shade[BD_PRIM(c, vertex.prim, "manifoldInit")].material;
             m.degenerate = !bv_connectable(vertex);
             const d3 wPred = pred.p - m.p, wSucc = succ.p - m.p;
             if (dot(m.gn, wPred) * dot(m.gn, wSucc) < 0) { m.type = MV_REFRACTION; m.eta = bsdf_eta(c.V.mats[m.object]); }
@@ -729,7 +731,7 @@ struct GTrT {
             if (pos < 0 || pos > path.length()) return -1;
             const BV &vertex = V_(path, pos);
             if (vertex.type != T_SURFACE) break;
-            const Float roughness = mat_roughness(c.V.mats[c.V.shade[vertex.prim].material]);
+            const Float roughness = vertex.prim == BV_ENV_PRIM ? GD_INF : mat_roughness(c.V.mats[c.V.shade[max(vertex.prim, 0)].material]);   // (the environment's sphere: a black diffuse BSDF)
             if (bv_connectable(vertex) && roughness >= c.cfg.shiftThreshold) break;
             pos += step;
         }
@@ -775,7 +777,7 @@ struct GTrT {
             const Float eta = bsdf_eta(so.m);
             const d3 wi_world = normalize(pred.p - vertex.p);
             d3 wo_world = mk(0.0);
-            if (c.V.shade[vertex_old.prim].material != c.V.shade[vertex.prim].material) return false;
+            if (prim_material(c, vertex_old.prim) != prim_material(c, vertex.prim)) return false;
             if (bv_connectable(vertex_old)) {
                 d3 m = mk(0.0);
                 if (reflection) m = normalize(wi_old + wo_old);
@@ -982,7 +984,7 @@ struct GTrT {
     {
         connectedPath.clear();
         while (!connectable_gbdpt(c, V_(sensorSubpath, t))) { t--; sensorSubpath.nv--; sensorSubpath.ne--; }
-        if (V_(sensorSubpath, t).type == T_SURFACE && c.V.shade[V_(sensorSubpath, t).prim].emitter >= 0) s = 0;
+        if (V_(sensorSubpath, t).type == T_SURFACE && prim_emitter(c, V_(sensorSubpath, t).prim) >= 0) s = 0;
         for (memPointer = 0; memPointer < s; memPointer++) { connectedPath.pushV(emitterSubpath.v[memPointer]); connectedPath.pushE(emitterSubpath.e[memPointer]); }
         connectedPath.pushV(cloneV(emitterSubpath.v[memPointer]));
         connectedPath.pushE(allocE());

@@ -69,6 +69,31 @@ __device__ __forceinline__ bool bv_connectable(const BV &v) { return !v.degenera
 // vertex.h:592-596: a surface vertex, or an endpoint sample whose sensor / emitter is EOnSurface -- area lights and both perspective sensors are, a `point`
 // emitter is not (point.cpp:56): its samples carry prim == BV_OFF_SURFACE
 constexpr int BV_OFF_SURFACE = -2;
+// The constant environment emitter as libbidir sees it: a SHAPE (Scene::initializeBidirectional, scene.cpp:397-408; ConstantBackgroundEmitter::createShape,
+// constant.cpp:67-93): a `sphere` of m_sceneBSphere with flipped normals, the emitter as its child and an all-absorbing diffuse BSDF (Shape::configure).
+// Scene::rayIntersectAll tests it after the kd-tree, so a ray that leaves the geometry ends in a SURFACE vertex on that sphere -- connectable (a smooth BSDF), black,
+// castable to an emitter sample.  Such a vertex carries prim == BV_ENV_PRIM and its (inward) normal in BV::n, which triangle vertices leave unused.
+constexpr int BV_ENV_PRIM = -3;
+// development aid (-DGDPT_BD_CHECK_PRIM): every table load indexed by a vertex's `prim` records an index outside the triangle tables in g_bdPrimTrap (site, prim,
+// count) and goes on with triangle 0, so the kernel completes and the host can say where (gdpt_gbdpt_evaluate_sample2 prints it and fills its workspace with 0x7f
+// bytes first, so a read of a vertex nobody wrote shows up whatever the allocation held before)
+#ifdef GDPT_BD_CHECK_PRIM
+__device__ int g_bdPrimTrap[4];
+__device__ __forceinline__ int bd_prim_trap(int prim, int numTris, int site)
+{
+    if ((unsigned)prim < (unsigned)numTris) return prim;
+    if (atomicAdd(&g_bdPrimTrap[2], 1) == 0) { g_bdPrimTrap[0] = site; g_bdPrimTrap[1] = prim; }
+    return 0;
+}
+#define BD_PRIM(c, prim, where) bd_prim_trap((int)(prim), (c).S->numTris, (int)sizeof(where) * 1000 + __LINE__)
+#else
+// The product: every such index is CLAMPED into the tables.  A vertex that is not a triangle hit (prim -1 of an endpoint sample, BV_OFF_SURFACE, BV_ENV_PRIM, or a
+// record nobody wrote yet) never has its table entry USED -- the trap build above shows that, on workspaces filled with 0x7f bytes -- but the load itself may be issued
+// ahead of the test that discards it: the product build of round 5's environment cases faulted in k_gbdpt_sample on a TriNormals load (rocgdb), only after other tests
+// had left their bytes in the allocation, and not once in the build that clamps.  Two integer instructions per table access beside fp64 shading.
+__device__ __forceinline__ int bd_prim_clamp(int prim, int numTris) { return min(max(prim, 0), numTris - 1); }
+#define BD_PRIM(c, prim, where) bd_prim_clamp((int)(prim), (c).S->numTris)
+#endif
 __device__ __forceinline__ bool bv_on_surface(const BV &v) { return v.type == T_SURFACE || ((v.type == T_EMITTER_SAMPLE || v.type == T_SENSOR_SAMPLE) && v.prim != BV_OFF_SURFACE); }
 __device__ __forceinline__ bool bv_super(const BV &v) { return (v.type & 3) != 0; }
 __device__ __forceinline__ void bv_clear(BV &v)
@@ -92,24 +117,37 @@ struct Ctx {
 
 __device__ __forceinline__ Surf surf_of(const Ctx &c, const BV &v)
 {
-    Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+    if (v.prim == BV_ENV_PRIM) {                                                           // (sphere.cpp:248-251 sets shFrame.n only; nothing that survives the black BSDF reads s and t: Frame(n) stands in)
+        Surf s;
+        s.fr.n = v.n;
+        if (fabs(v.n.x) > fabs(v.n.y)) { const Float il = 1.0 / sqrt(v.n.x * v.n.x + v.n.z * v.n.z); s.fr.t = mk(v.n.z * il, 0.0, -v.n.x * il); }
+        else { const Float il = 1.0 / sqrt(v.n.y * v.n.y + v.n.z * v.n.z); s.fr.t = mk(0.0, v.n.z * il, -v.n.y * il); }
+        s.fr.s = cross(s.fr.t, s.fr.n);
+        s.geoN = v.n;
+        s.m = c.V.mats[0]; s.m.type = 0; s.m.twoSided = 0; s.m.reflectance = mk(0.0); s.m.tex = -1;   // Shape::configure: "light source & no BSDF -> an all-absorbing BSDF" (diffuse, reflectance 0)
+        s.R = mk(0.0);
+        return s;
+    }
+    // (max(prim, 0): the table loads below go through C++ references, which the compiler may hoist above the test of prim -- a load from shade[-3] then reads
+    //  whatever lies in front of the table, or faults when nothing does: seen as a memory violation in scenes whose tables happened to start an allocation)
+    Vertex vx; vx.p = v.p; vx.prim = max(BD_PRIM(c, v.prim, "surf_of"), 0); vx.u = v.u; vx.v = v.v;
     const Shading sh = shading_at<true>(c.V, vx);
     Surf s;
     s.fr = sh.fr; s.geoN = sh.geoN;
-    s.m = c.V.mats[c.V.shade[v.prim].material];
+    s.m = c.V.mats[c.V.shade[vx.prim].material];
     s.R = reflectance_at<true, false>(c.V, s.m, vx);                                       // libbidir asks its.getBSDF() without a ray: no UV partials
     return s;
 }
 __device__ __forceinline__ d3 bv_sh_normal(const Ctx &c, const BV &v)
 {
-    if (v.type != T_SURFACE) return v.n;
-    Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+    if (v.type != T_SURFACE || v.prim == BV_ENV_PRIM) return v.n;
+    Vertex vx; vx.p = v.p; vx.prim = max(BD_PRIM(c, v.prim, "bv_sh_normal"), 0); vx.u = v.u; vx.v = v.v;
     return shading_at<true>(c.V, vx).fr.n;
 }
 __device__ __forceinline__ d3 bv_geo_normal(const Ctx &c, const BV &v)
 {
-    if (v.type != T_SURFACE) return v.n;
-    Vertex vx; vx.p = v.p; vx.prim = v.prim; vx.u = v.u; vx.v = v.v;
+    if (v.type != T_SURFACE || v.prim == BV_ENV_PRIM) return v.n;
+    Vertex vx; vx.p = v.p; vx.prim = max(BD_PRIM(c, v.prim, "bv_geo_normal"), 0); vx.u = v.u; vx.v = v.v;
     return shading_at<true>(c.V, vx).geoN;
 }
 __device__ __forceinline__ Float mat_roughness(const MaterialD &m) { return m.type == 0 ? GD_INF : ((m.type == 1 || m.type == 3) ? 0.0 : 0.5 * (m.alphaU + m.alphaV)); }
@@ -118,8 +156,12 @@ __device__ __forceinline__ bool connectable_gbdpt(const Ctx &c, const BV &v)
 {
     if (!bv_connectable(v)) return false;
     if (v.type & (T_SENSOR_SUPER | T_EMITTER_SUPER | T_SENSOR_SAMPLE | T_EMITTER_SAMPLE)) return true;
-    return !(mat_roughness(c.V.mats[c.V.shade[v.prim].material]) < c.cfg.shiftThreshold);
+    if (v.prim == BV_ENV_PRIM) return true;                                                // (diffuse: roughness infinite)
+    return !(mat_roughness(c.V.mats[c.V.shade[max(BD_PRIM(c, v.prim, "connectable_gbdpt"), 0)].material]) < c.cfg.shiftThreshold);
 }
+
+__device__ __forceinline__ int prim_emitter(const Ctx &c, int prim) { return prim == BV_ENV_PRIM ? c.S->envIndex : c.V.shade[max(BD_PRIM(c, prim, "prim_emitter"), 0)].emitter; }
+__device__ __forceinline__ int prim_material(const Ctx &c, int prim) { return prim == BV_ENV_PRIM ? -1 : c.V.shade[max(BD_PRIM(c, prim, "prim_material"), 0)].material; }
 
 // ---- sensor --------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ d3 cam_to_local(const Ctx &c, d3 d) { return mul3(c.cam.invLin, d); }
@@ -199,6 +241,19 @@ __device__ __forceinline__ bool sensor_sample_position(const Ctx &c, d3 pWorld, 
 }
 
 // ---- emitters ------------------------------------------------------------------------------------------------------------------------
+// `envmap` as libbidir's endpoint (round 5): positions as the constant environment has them (uniform on the sphere of createShape, envmap.cpp:331-343,412-430), directions
+// from the map itself -- sampleDirection / pdfDirection / evalDirection (envmap.cpp:455-498) importance-sample, price and look up a direction of the map whatever the
+// position (envmap.cpp:432-454 calls it a compromise).  m_power = surfaceArea * m_scale / m_normalization (envmap.cpp:326-328)
+__device__ __forceinline__ Float envmap_power(const Ctx &c) { const Float surfaceArea = 4 * GD_PI * c.S->bsRadius * c.S->bsRadius; return surfaceArea * c.S->envMap->scale / c.S->envMap->normalization; }
+__device__ __forceinline__ bool is_envmap(const Ctx &c, int object) { return c.S->hasEnvMap && object == c.S->envIndex; }
+// EnvironmentMap::evalDirection, envmap.cpp:482-498: bilinear on level 0 along -d (map space), times m_normalization (not m_scale); the measure is not consulted
+__device__ __noinline__ d3 envmap_eval_direction(const Ctx &c, d3 d)
+{
+    const EnvMapD &e = *c.S->envMap;
+    const d3 v = -mul3(e.toLocal, d);
+    const Float uvx = atan2(v.x, -v.z) * GD_INV_TWOPI, uvy = acos(fmin(1.0, fmax(-1.0, v.y))) * GD_INV_PI;
+    return tex_bilinear(e.tex, 0, uvx, uvy) * e.normalization;
+}
 // Scene::sampleEmitterPosition (scene.cpp:985-1001) -> AreaLight::samplePosition (area.cpp:93-97) -> TriMesh / Rectangle::samplePosition
 __device__ __forceinline__ d3 sample_emitter_position(const Ctx &c, BV &succ, Float sx, Float sy, Float &pdfOut)
 {
@@ -207,6 +262,18 @@ __device__ __forceinline__ d3 sample_emitter_position(const Ctx &c, BV &succ, Fl
     const Float emPdf = V.emitterCdf[index + 1] - V.emitterCdf[index];
     sx = (sx - V.emitterCdf[index]) / (V.emitterCdf[index + 1] - V.emitterCdf[index]);
     const EmitterD em = V.emitters[index];
+    if (em.numTris == 0) {                                                                 // ConstantBackgroundEmitter::samplePosition, constant.cpp:110-120
+        const Float z = 1.0 - 2.0 * sy, r = safe_sqrt(1.0 - z * z), phi = 2.0 * GD_PI * sx;  // warp::squareToUniformSphere, warp.cpp:25-31
+        const d3 d = mk(r * cos(phi), r * sin(phi), z);
+        const Float R = c.S->bsRadius;
+        succ.p = c.S->bsCenter + d * R; succ.n = -d; succ.object = index;
+        Float pdf = 1 / (4 * GD_PI * R * R);
+        pdf *= emPdf;
+        pdfOut = pdf;
+        const Float surfaceArea = 4 * GD_PI * R * R;
+        if (c.S->hasEnvMap) return mk(envmap_power(c)) / emPdf;                              // EnvironmentMap::samplePosition, envmap.cpp:412-422: the same sphere, Spectrum(m_power)
+        return (em.radiance * surfaceArea * GD_PI) / emPdf;                                 // m_power, constant.cpp:100
+    }
     if (em.numTris < 0) {                                                                  // PointEmitter::samplePosition, point.cpp:79-87
         succ.p = em.position; succ.n = mk(0.0); succ.object = index; succ.prim = BV_OFF_SURFACE;
         Float pdf = 1.0;
@@ -243,6 +310,7 @@ __device__ __forceinline__ d3 sample_emitter_position(const Ctx &c, BV &succ, Fl
 __device__ __forceinline__ Float pdf_emitter_position(const Ctx &c, int object, int measure)   // scene.cpp:1003-1006 (pRec.measure = measure, vertex.cpp:925-927)
 {
     if (c.V.emitters[object].numTris < 0) return (measure == M_DISCRETE ? 1.0 : 0.0) * (1.0 * c.S->emitterNormalization);   // point.cpp:93-95
+    if (c.V.emitters[object].numTris == 0) return (1 / (4 * GD_PI * c.S->bsRadius * c.S->bsRadius)) * (1.0 * c.S->emitterNormalization);   // constant.cpp:126-128
     return c.V.emitters[object].invSurfaceArea * (1.0 * c.S->emitterNormalization);
 }
 __device__ __forceinline__ Float area_direction(d3 d, d3 n, int measure)                    // AreaLight::evalDirection / pdfDirection, area.cpp:124-142
@@ -256,7 +324,14 @@ __device__ __forceinline__ Float area_direction(d3 d, d3 n, int measure)        
 __device__ __forceinline__ Float emitter_direction(const Ctx &c, const BV &v, d3 d, int measure)
 {
     if (v.prim == BV_OFF_SURFACE) return measure == M_SOLID ? GD_INV_FOURPI : 0.0;
+    if (is_envmap(c, v.object)) return envmap_pdf_direction(*c.S->envMap, -mul3(c.S->envMap->toLocal, d));   // EnvironmentMap::pdfDirection, envmap.cpp:476-480 (no measure test)
     return area_direction(d, v.n, measure);
+}
+// Emitter::evalDirection as a spectrum: the envmap's is coloured (envmap.cpp:482-498), every other emitter's equals its pdfDirection
+__device__ __forceinline__ d3 emitter_eval_direction(const Ctx &c, const BV &v, d3 d, int measure)
+{
+    if (is_envmap(c, v.object)) return envmap_eval_direction(c, d);
+    return mk(emitter_direction(c, v, d, measure));
 }
 __device__ __forceinline__ int bsdf_measure(int m) { return m == M_DISCRETE ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE; }
 
@@ -287,10 +362,29 @@ __device__ __forceinline__ void fill_surface(const Ctx &c, const Hit &h, BV &suc
 __device__ __forceinline__ bool edge_extend(Ctx &c, BE &e, d3 o, d3 d, BV &succ, int mode, bool perturb, Float dist)
 {
     Hit h;
-    const bool surface = closest_hit(c, o, d, GD_EPSILON, GD_INF, h);
+    bool surface = closest_hit(c, o, d, GD_EPSILON, GD_INF, h);
     if (perturb && dist <= 0) return false;
+    bool envHit = false;
+    if (!surface && c.S->envIndex >= 0) {                                                   // Scene::rayIntersectAll, scene.cpp:736-760: the special shapes after the kd-tree; Sphere::rayIntersect, sphere.cpp:163-187
+        const Float mint = ray_mint_closest(o, GD_EPSILON);                                // (the sphere encloses the geometry: it only ever answers when the kd-tree found nothing)
+        const d3 oc = o - c.S->bsCenter;
+        Float nearT, farT;
+        if (solve_quadratic(len2(d), 2 * dot(oc, d), len2(oc) - c.S->bsRadius * c.S->bsRadius, nearT, farT) && nearT <= GD_INF && farT >= mint) {
+            if (nearT < mint) { if (!(farT > GD_INF)) { h.t = farT; envHit = true; } }
+            else { h.t = nearT; envHit = true; }
+        }
+        surface = envHit;
+    }
     if (!surface) return false;
+    if (envHit) h.prim = 0;                                                                // (fill_surface's table loads may be hoisted above the branch below: they must be in bounds either way)
     fill_surface(c, h, succ);
+    if (envHit) {                                                                          // Sphere::fillIntersectionRecord, sphere.cpp:209-255 (flipped normals); edge.cpp:44-45
+        bv_clear(succ);
+        succ.type = T_SURFACE; succ.prim = BV_ENV_PRIM;
+        succ.p = o + d * h.t;
+        succ.n = -normalize(succ.p - c.S->bsCenter);
+        succ.degenerate = 0; succ.object = c.S->envIndex;
+    }
     e.length = h.t;
     e.d = mode == ERadiance ? -d : d;
     if (e.length == 0) return false;
@@ -434,6 +528,19 @@ __device__ __noinline__ bool sample_next(Ctx &c, BV &v, const BV *pred, const BE
             v.pdf[ERadiance] = 1.0;
             v.measure = M_SOLID;
             ro = v.p;
+        } else if (is_envmap(c, v.object)) {                                               // EnvironmentMap::sampleDirection, envmap.cpp:455-474
+            d3 value, dl; Float dpdf;
+            envmap_sample_direction(*c.S->envMap, sx, sy, dl, value, dpdf);
+            rd = mul3(c.S->envMap->toWorld, -dl);
+            if (is_zero(value) || dpdf == 0) return false;                                  // ("be wary of roundoff errors": Spectrum(0) -> sampleNext fails, vertex.cpp:106-107)
+            const d3 result = (value * c.S->envMap->normalization) / (dpdf * c.S->envMap->scale);
+            if (is_zero(result)) return false;
+            v.w[EImportance] = result;
+            v.w[ERadiance] = result * dpdf * (1.0 / fabs(dot(rd, v.n)));                      // (EOnSurface, envmap.cpp:107)
+            v.pdf[EImportance] = dpdf;
+            v.pdf[ERadiance] = 1.0;
+            v.measure = M_SOLID;
+            ro = v.p;
         } else {
         const d3 local = squareToCosineHemisphere(sx, sy);
         Frame3 fr; fr.n = v.n;
@@ -556,6 +663,7 @@ __device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ,
     if (v.type == T_EMITTER_SUPER) {
         if (mode != EImportance || pred != nullptr || succ->type != T_EMITTER_SAMPLE) return mk(0.0);
         if (succ->prim == BV_OFF_SURFACE) return measure == M_DISCRETE ? c.V.emitters[succ->object].radiance * (4 * GD_PI) : mk(0.0);   // PointEmitter::evalPosition, point.cpp:89-91
+        if (is_envmap(c, succ->object)) return mk(envmap_power(c) * (1 / (4 * GD_PI * c.S->bsRadius * c.S->bsRadius)));   // EnvironmentMap::evalPosition, envmap.cpp:424-426
         return c.V.emitters[succ->object].radiance * GD_PI;
     } else if (v.type == T_SENSOR_SUPER) {
         if (mode != ERadiance || pred != nullptr || succ->type != T_SENSOR_SAMPLE) return mk(0.0);
@@ -570,7 +678,7 @@ __device__ d3 bv_eval(const Ctx &c, const BV &v, const BV *pred, const BV *succ,
         else return mk(0.0);
         const d3 wo = normalize(target - v.p);
         const int dm = measure == M_AREA ? M_SOLID : measure;
-        d3 result = mk(emitter ? emitter_direction(c, v, wo, dm) : (dm != M_SOLID ? 0.0 : sensor_direction(c, v.p, wo)));
+        d3 result = emitter ? emitter_eval_direction(c, v, wo, dm) : mk(dm != M_SOLID ? 0.0 : sensor_direction(c, v.p, wo));
         const Float dp = fabs(dot(v.n, wo));
         if (measure != M_DISCRETE && dp != 0) result = result / dp;
         return result;
@@ -635,7 +743,7 @@ __device__ bool bv_cast_emitter(const Ctx &c, BV &v)
 {
     if (v.type == T_EMITTER_SAMPLE) return true;
     if (v.type != T_SURFACE) return false;
-    const int em = c.V.shade[v.prim].emitter;
+    const int em = prim_emitter(c, v.prim);
     if (em < 0) return false;
     v.n = bv_sh_normal(c, v);
     v.type = T_EMITTER_SAMPLE;
@@ -919,7 +1027,7 @@ __device__ __noinline__ bool walk_shift_base(Ctx &c, Sample &sm)
     // ---- createShiftablePath(connectPath, emitterSubpath, sensorSubpath, 1, last), gbdpt_proc.cpp:600-662 ----
     const int T = sm.nX - 1;
     sm.connS = 1;
-    if (sm.X[T].type == T_SURFACE && c.V.shade[sm.X[T].prim].emitter >= 0) sm.connS = 0;
+    if (sm.X[T].type == T_SURFACE && prim_emitter(c, sm.X[T].prim) >= 0) sm.connS = 0;
     sm.Y1c = sm.Y[sm.connS];
     sm.XTc = sm.X[T];
     be_clear(sm.eConn);

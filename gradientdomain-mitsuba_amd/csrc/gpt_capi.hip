@@ -885,11 +885,11 @@ int gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out)
     d.fValues = nullptr; d.fRadius = 0.0; d.fScale = 0.0;       // box filter
     d.log = nullptr; d.logChunk = 0; d.logY0 = 0; d.logRows = 0;
     d.qRec = nullptr; d.qList = nullptr; d.qCount = nullptr; d.qCapacity = 0; d.qPixels = 0; d.pHit = nullptr; d.pPrim = nullptr;
-    d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2;
+    d.W = W; d.H = H; d.y0 = y0; d.y1 = y1; d.recRows = (y1 - y0) + 2; d.spillRows = (y1 - y0) + 4;
     d.recStride = (size_t)d.recRows * W;
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return tfail(GDPT_ERR_HIP, "stream creation failed"); }
     if (hipMalloc((void **)&d.rec, sizeof(Float) * NREC * d.recStride) != hipSuccess ||
-        hipMalloc((void **)&d.spill, sizeof(Float) * 5 * d.recStride * 4) != hipSuccess ||
+        hipMalloc((void **)&d.spill, sizeof(Float) * 5 * (size_t)d.spillRows * W * 4) != hipSuccess ||
         hipMalloc((void **)&d.stats, sizeof(unsigned long long) * 5) != hipSuccess ||
         hipMalloc((void **)&f->cancelFlag, sizeof(int)) != hipSuccess || hipStreamCreateWithFlags(&f->cancelStream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&f->accum, sizeof(Float) * 5 * (size_t)(y1 - y0) * W * 4) != hipSuccess) {
@@ -932,7 +932,7 @@ int gdpt_film_clear(gdpt_film *f)
     (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
     FilmD &d = f->d;
     THIPCHK(hipMemsetAsync(d.rec, 0, sizeof(Float) * NREC * d.recStride, f->stream));
-    THIPCHK(hipMemsetAsync(d.spill, 0, sizeof(Float) * 5 * d.recStride * 4, f->stream));
+    THIPCHK(hipMemsetAsync(d.spill, 0, sizeof(Float) * 5 * (size_t)d.spillRows * d.W * 4, f->stream));
     THIPCHK(hipMemsetAsync(d.stats, 0, sizeof(unsigned long long) * 5, f->stream));
     THIPCHK(hipMemsetAsync(f->cancelFlag, 0, sizeof(int), f->stream));             // a new frame is not cancelled
     THIPCHK(hipStreamSynchronize(f->stream));
@@ -1241,7 +1241,7 @@ int gdpt_film_halo_bytes(gdpt_film *f, size_t *bytes)
 {
     if (!f || !bytes) return tfail(GDPT_ERR_INVALID, "null argument");
     (void)hipSetDevice(f->scene->device);          // (a host may drive several devices from one thread)
-    *bytes = sizeof(Float) * ((size_t)NREC * f->d.W + (size_t)5 * f->d.W * 4);
+    *bytes = sizeof(Float) * ((size_t)NREC * f->d.W + (size_t)2 * 5 * f->d.W * 4);      // a boundary row's records + the spill of the two halo rows beyond it
     return GDPT_OK;
 }
 

@@ -197,7 +197,9 @@ struct ConfigD {
 struct FilmD {
     Float *rec;                 // [NREC][recRows][W] per-pixel sample sums; row index = y - (y0 - 1)
     Float *recExtra;            // [slices-1][NREC][recRows][W]: the sums of sample slices 1.. of a launch, folded into rec after it
-    Float *spill;               // [5][recRows][W][4] exact generic puts (R,G,B,weight)
+    Float *spill;               // [5][spillRows][W][4] exact generic puts (R,G,B,weight); row index = y - (y0 - 2): TWO rows beyond the strip on either side -- a sample
+                                // within 1e-5 of a pixel edge lands in both pixels (the box filter's radius is 0.5 + 1e-5, box.cpp:38), so its neighbour puts reach two
+                                // rows from its own: the border of the reference's blocks is rfilter border 1 + extraBorder 1 (gpt_wr.cpp:31-44)
     const Float *fValues;       // nullptr: box filter (the fast path below); else the 32-entry table of ReconstructionFilter::configure
     Float fRadius, fScale;      // of that table (rfilter.cpp:37-55)
     Float *log;                 // wider filters: sample log [32][logChunk][logRows][W] (30 sums, sx, sy of every sample of a chunk), gathered by k_gather_log
@@ -216,7 +218,7 @@ struct FilmD {
     int *pPrim;
     unsigned long long *stats;  // [5]: closest rays, shadow rays, paths, path length sum, puts dropped as invalid
     const int *cancel;          // device flag set by gdpt_film_cancel: waves stop starting samples (Integrator::cancel, the `stop` flag of gpt.cpp:1246,1254)
-    int W, H, y0, y1, recRows;
+    int W, H, y0, y1, recRows, spillRows;
     size_t recStride;           // recRows * W
 };
 
@@ -1571,11 +1573,11 @@ __device__ void spill_put(const FilmD &F, const FilterD &flt, Float px, Float py
     if (x1 > F.W - 1) x1 = F.W - 1;
     if (y1 > F.H - 1) y1 = F.H - 1;
     for (int y = y0; y <= y1; ++y) {
-        if (y < F.y0 - 1 || y > F.y1) continue;               // outside this film's rows + halo: another strip's sample
+        if (y < F.y0 - 2 || y > F.y1 + 1) continue;           // outside this film's rows + its two-row halo: another strip's sample
         const Float wy = evalD(y - posy);
         for (int x = x0; x <= x1; ++x) {
             const Float w = evalD(x - posx) * wy;
-            Float *dest = F.spill + (((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4;
+            Float *dest = F.spill + (((size_t)b * F.spillRows + (y - (F.y0 - 2))) * F.W + x) * 4;
             atomicAdd(dest + 0, w * spec.x);
             atomicAdd(dest + 1, w * spec.y);
             atomicAdd(dest + 2, w * spec.z);

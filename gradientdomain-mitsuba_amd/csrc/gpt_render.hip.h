@@ -990,7 +990,7 @@ __global__ __launch_bounds__(TBLK) void k_gather_log(FilmD F, int count, int sx0
                 put(4, w0, vd, 1.0);
             }
     for (int b = 0; b < 5; b++)
-        for (int k = 0; k < 4; k++) F.spill[(((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4 + k] += o[b][k];
+        for (int k = 0; k < 4; k++) F.spill[(((size_t)b * F.spillRows + (y - (F.y0 - 2))) * F.W + x) * 4 + k] += o[b][k];
     if (invalid) atomicAdd(&F.stats[4], (unsigned long long)invalid);
 }
 
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(TBLK) void k_resolve(FilmD F, Float *__restrict__ o
         o[4][3] = w * cnt;
         for (int b = 0; b < 5; b++)
             for (int k = 0; k < 4; k++) {
-                const size_t si = (((size_t)b * F.recRows + (y - (F.y0 - 1))) * F.W + x) * 4 + k;
+                const size_t si = (((size_t)b * F.spillRows + (y - (F.y0 - 2))) * F.W + x) * 4 + k;
                 out[(((size_t)b * rows + (y - F.y0)) * F.W + x) * 4 + k] = o[b][k] + F.spill[si];
             }
     }
@@ -1054,24 +1054,31 @@ __global__ __launch_bounds__(TBLK) void k_develop(const Float *__restrict__ accu
     }
 }
 
-// halo exchange payload: [NREC][W] records of an owned boundary row, then [5][W][4] spill of the halo row beyond it
+// halo exchange payload: [NREC][W] records of an owned boundary row, then [2][5][W][4]: the spill of the two halo rows beyond it (near, far)
 __global__ __launch_bounds__(TBLK) void k_pack_halo(FilmD F, int which, Float *__restrict__ buf)
 {
-    const int ownRow = which == 0 ? F.y0 : F.y1 - 1, haloRow = which == 0 ? F.y0 - 1 : F.y1;
+    const int ownRow = which == 0 ? F.y0 : F.y1 - 1, step = which == 0 ? -1 : 1;       // the halo rows: ownRow + step (near), ownRow + 2 * step (far)
     const int n1 = NREC * F.W, n2 = 5 * F.W * 4;
-    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n1 + n2; i += gridDim.x * TBLK) {
+    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n1 + 2 * n2; i += gridDim.x * TBLK) {
         if (i < n1) { const int k = i / F.W, x = i % F.W; buf[i] = F.rec[(size_t)k * F.recStride + (size_t)(ownRow - (F.y0 - 1)) * F.W + x]; }
-        else { const int j = i - n1, b = j / (F.W * 4), r = j % (F.W * 4); buf[i] = F.spill[((size_t)b * F.recRows + (haloRow - (F.y0 - 1))) * F.W * 4 + r]; }
+        else {
+            const int far = (i - n1) / n2, j = (i - n1) % n2, b = j / (F.W * 4), r = j % (F.W * 4);
+            buf[i] = F.spill[((size_t)b * F.spillRows + (ownRow + (1 + far) * step - (F.y0 - 2))) * F.W * 4 + r];
+        }
     }
 }
-// receive from the neighbour on side `which`: its boundary-row records become my halo row; its spill of my boundary row is added
+// receive from the neighbour on side `which`: its boundary-row records become my halo row; its spill of my boundary row and of the row inside it is added
 __global__ __launch_bounds__(TBLK) void k_unpack_halo(FilmD F, int which, const Float *__restrict__ buf)
 {
-    const int ownRow = which == 0 ? F.y0 : F.y1 - 1, haloRow = which == 0 ? F.y0 - 1 : F.y1;
+    const int ownRow = which == 0 ? F.y0 : F.y1 - 1, haloRow = which == 0 ? F.y0 - 1 : F.y1, step = which == 0 ? 1 : -1;   // the neighbour's near row is my boundary row, its far row the one inside it
     const int n1 = NREC * F.W, n2 = 5 * F.W * 4;
-    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n1 + n2; i += gridDim.x * TBLK) {
+    for (int i = blockIdx.x * TBLK + threadIdx.x; i < n1 + 2 * n2; i += gridDim.x * TBLK) {
         if (i < n1) { const int k = i / F.W, x = i % F.W; F.rec[(size_t)k * F.recStride + (size_t)(haloRow - (F.y0 - 1)) * F.W + x] = buf[i]; }
-        else { const int j = i - n1, b = j / (F.W * 4), r = j % (F.W * 4); F.spill[((size_t)b * F.recRows + (ownRow - (F.y0 - 1))) * F.W * 4 + r] += buf[i]; }
+        else {
+            const int far = (i - n1) / n2, j = (i - n1) % n2, b = j / (F.W * 4), r = j % (F.W * 4);
+            const int row = ownRow + far * step;
+            if (row >= F.y0 && row < F.y1) F.spill[((size_t)b * F.spillRows + (row - (F.y0 - 2))) * F.W * 4 + r] += buf[i];     // (a one-row strip has no row inside its boundary row)
+        }
     }
 }
 

@@ -138,7 +138,8 @@ class StripRenderer:
     every rank renders its strip (GPTBlockRenderer::process), strips settle their borders, the four developed solver images
     travel to rank 0 as one message per rank, and rank 0 reconstructs (`poisson::Solver`).
 
-    Borders: with the box filter a sample touches only its own pixel and the four neighbours, so the one-pixel halo sums are
+    Borders: with the box filter a sample touches only its own pixel and the four neighbours (the rare sample within 1e-5 of a pixel edge: two pixels and their
+    neighbours -- the payload carries the exact puts of two rows for those), so the halo sums are
     exchanged and added (gpt_proc.cpp:52-56,137-149).  With a wider reconstruction filter (Mitsuba's film default is gaussian) a
     strip's film renders the rows within the filter's reach itself (`gdpt_film_set_rfilter`), so nothing is exchanged and the
     result is bit-identical to a one-GPU render; the price is 2 x reach redundant rows per strip.

@@ -144,8 +144,9 @@ GDPT_API int  gdpt_scene_create_tex(int numTris, const double *verts9, const dou
 GDPT_API void gdpt_scene_destroy(gdpt_scene *s);
 
 /* A film = the five G-PT buffers `-final -throughput -dx -dy -direct` (gpt.cpp:1380) over rows [y0, y1) of the
- * image plus a one-pixel halo row above and below (GPTWorkResult's extraBorder, gpt_proc.cpp:52-56), as
- * per-pixel sample sums on the device.  Single GPU: y0 = 0, y1 = height. */
+ * image plus a halo above and below (GPTWorkResult's border, gpt_proc.cpp:52-56, gpt_wr.cpp:31-44: the filter's 1 + extraBorder 1), as
+ * per-pixel sample sums on the device: one row of neighbour records, and two rows for the exact puts of the rare samples that sit
+ * within 1e-5 of a pixel edge and so land in two pixels (the box filter's radius is 0.5 + 1e-5).  Single GPU: y0 = 0, y1 = height. */
 GDPT_API int  gdpt_film_create(gdpt_scene *s, int y0, int y1, gdpt_film **out);
 GDPT_API void gdpt_film_destroy(gdpt_film *f);
 GDPT_API int  gdpt_film_clear(gdpt_film *f);
@@ -178,7 +179,9 @@ GDPT_API int  gdpt_film_cancelled(gdpt_film *f, int *out);
  * rows just outside it (the neighbour samples that splat into it) -- the reference's block border merged by addition
  * (gpt_proc.cpp:52-56,137-149).  pack(which) writes this strip's boundary payload for the neighbour ABOVE (which = 0) or
  * BELOW (which = 1) into a device buffer of gdpt_film_halo_bytes(); unpack(which, buf) consumes the payload received
- * from the neighbour on that side.  Transport (RCCL send/recv) is the caller's. */
+ * from the neighbour on that side.  Payload: the boundary row's records, then the exact puts this strip's samples made into the
+ * TWO rows beyond it (round 5; one until then, which lost about one put in 50 000 next to a boundary).  Strips need >= 2 rows.
+ * Transport (RCCL send/recv) is the caller's. */
 GDPT_API int  gdpt_film_halo_bytes(gdpt_film *f, size_t *bytes);
 GDPT_API int  gdpt_film_pack_halo(gdpt_film *f, int which, void *devBuf);
 GDPT_API int  gdpt_film_unpack_halo(gdpt_film *f, int which, const void *devBuf);

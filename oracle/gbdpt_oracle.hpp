@@ -194,6 +194,21 @@ inline bool sensorSamplePosition(const Ctx &c, V3 pWorld, V3 dWorld, Float &ox, 
 }
 
 // ---- emitters ------------------------------------------------------------------------------------------------------------------------
+inline Float envInvSurfaceArea(const Scene &sc) { return 1 / (4 * PI * sc.bsRadius * sc.bsRadius); }     // constant.cpp:97-100
+// `envmap` as libbidir's endpoint (round 5): positions as the constant environment has them (uniform on the sphere of createShape, envmap.cpp:331-343,412-430), directions
+// from the map itself: sampleDirection / pdfDirection / evalDirection (envmap.cpp:455-498) importance-sample, price and look up a direction of the map whatever the position
+// (the comment at envmap.cpp:432-454 calls it a compromise); m_power = surfaceArea * m_scale / m_normalization (envmap.cpp:326-328)
+inline Float envMapPower(const Scene &sc) { const Float surfaceArea = 4 * PI * sc.bsRadius * sc.bsRadius; return surfaceArea * sc.envMap.scale / sc.envMap.normalization; }
+inline bool isEnvMap(const Scene &sc, int object) { return sc.envMap.present && object == sc.envIndex; }
+// EnvironmentMap::evalDirection, envmap.cpp:482-498: bilinear on level 0 along -d (map space), times m_normalization (not m_scale); the measure is not consulted
+inline V3 envMapEvalDirection(const Scene &sc, V3 d)
+{
+    const V3 v = -mul3(sc.envMap.toLocal, d);
+    const Float uvx = std::atan2(v.x, -v.z) * INV_TWOPI, uvy = std::acos(std::min(1.0, std::max(-1.0, v.y))) * INV_PI;
+    Float o[3];
+    sc.envMap.mip.evalBilinear(0, uvx, uvy, o);
+    return V3(o[0], o[1], o[2]) * sc.envMap.normalization;
+}
 // Scene::sampleEmitterPosition (scene.cpp:985-1001) -> AreaLight::samplePosition (area.cpp:93-97) -> TriMesh / Rectangle::samplePosition
 inline V3 sampleEmitterPosition(const Ctx &c, PRec &pRec, Float sx, Float sy)
 {
@@ -201,6 +216,14 @@ inline V3 sampleEmitterPosition(const Ctx &c, PRec &pRec, Float sx, Float sy)
     Float emPdf;
     const size_t index = sc.emitterPDF.sampleReuse(sx, emPdf);
     const Emitter &em = sc.emitters[index];
+    if (em.numTris == 0) {                                                                 // ConstantBackgroundEmitter::samplePosition, constant.cpp:110-120
+        const V3 d = squareToUniformSphere(sx, sy);
+        pRec.p = sc.bsCenter + d * sc.bsRadius; pRec.n = -d; pRec.measure = EArea; pRec.pdf = envInvSurfaceArea(sc); pRec.object = (int)index;
+        pRec.pdf *= emPdf;
+        const Float surfaceArea = 4 * PI * sc.bsRadius * sc.bsRadius;
+        if (sc.envMap.present) return V3(envMapPower(sc)) / emPdf;                         // EnvironmentMap::samplePosition, envmap.cpp:412-422: the same sphere, Spectrum(m_power)
+        return (em.radiance * surfaceArea * PI) / emPdf;                                   // m_power, constant.cpp:100
+    }
     if (em.numTris < 0) {                                                                  // PointEmitter::samplePosition, point.cpp:79-87
         pRec.p = em.position; pRec.n = V3(0.0); pRec.pdf = 1.0; pRec.measure = EDiscrete; pRec.object = (int)index; pRec.onSurface = false;
         pRec.pdf *= emPdf;
@@ -237,6 +260,7 @@ inline V3 sampleEmitterPosition(const Ctx &c, PRec &pRec, Float sx, Float sy)
 inline Float pdfEmitterPosition(const Ctx &c, const PRec &pRec, int measure)               // scene.cpp:1003-1006 (pRec.measure = measure, vertex.cpp:925-927)
 {
     if (c.sc.emitters[pRec.object].numTris < 0) return (measure == EDiscrete ? 1.0 : 0.0) * (1.0 * c.sc.emitterPDF.normalization);   // point.cpp:93-95
+    if (c.sc.emitters[pRec.object].numTris == 0) return envInvSurfaceArea(c.sc) * (1.0 * c.sc.emitterPDF.normalization);             // constant.cpp:126-128
     return c.sc.emitters[pRec.object].invSurfaceArea * (1.0 * c.sc.emitterPDF.normalization);
 }
 // Emitter::evalDirection == pdfDirection of an emitter sample: AreaLight (below), PointEmitter::evalDirection / pdfDirection, point.cpp:107-115
@@ -244,7 +268,14 @@ inline Float areaDirection(V3 d, V3 n, int measure);
 inline Float emitterDirection(const Ctx &c, const PRec &pRec, V3 d, int measure)
 {
     if (c.sc.emitters[pRec.object].numTris < 0) return measure == ESolidAngle ? INV_FOURPI : 0.0;
+    if (isEnvMap(c.sc, pRec.object)) return envMapPdfDirection(c.sc.envMap, -mul3(c.sc.envMap.toLocal, d));   // EnvironmentMap::pdfDirection, envmap.cpp:476-480 (no measure test)
     return areaDirection(d, pRec.n, measure);
+}
+// Emitter::evalDirection as a spectrum: the envmap's is coloured (envmap.cpp:482-498), every other emitter's equals its pdfDirection
+inline V3 emitterEvalDirection(const Ctx &c, const PRec &pRec, V3 d, int measure)
+{
+    if (isEnvMap(c.sc, pRec.object)) return envMapEvalDirection(c.sc, d);
+    return V3(emitterDirection(c, pRec, d, measure));
 }
 inline Float areaDirection(V3 d, V3 n, int measure)                                        // AreaLight::evalDirection / pdfDirection, area.cpp:124-142
 {
@@ -266,6 +297,55 @@ inline bool isConnectableGBDPT(const Vertex *va, Float threshold)
     return true;
 }
 
+// ---- the environment emitter as libbidir sees it: a SHAPE ---------------------------------------------------------------------------------
+// Scene::initializeBidirectional asks every emitter for a shape (scene.cpp:397-408); ConstantBackgroundEmitter::createShape (constant.cpp:67-93) answers with a
+// `sphere` of m_sceneBSphere (the bounding sphere of kd-tree + sensor, radius x 1.5) with flipped normals, the emitter as its child and -- Shape::configure gives a
+// light source without a BSDF an all-absorbing one (shape.cpp) -- a `diffuse` BSDF of reflectance 0.  Scene::rayIntersectAll (scene.cpp:736-760) tests it after the
+// kd-tree: a ray that leaves the geometry ends in a SURFACE vertex on that sphere, connectable (a smooth BSDF), black, and castable to an emitter sample.  So the
+// constant environment is an area light whose shape is a sphere.  Its hits carry prim == ENV_PRIM.
+constexpr int ENV_PRIM = -2;
+inline bool hasEnvShape(const Scene &sc) { return sc.envIndex >= 0; }                    // (`constant` and `envmap` alike: constant.cpp:67-93, envmap.cpp:331-376)
+inline int emitterOfPrim(const Scene &sc, int prim) { return prim == ENV_PRIM ? sc.envIndex : sc.tris[prim].emitter; }
+inline int materialOfPrim(const Scene &sc, int prim) { return prim == ENV_PRIM ? -1 : sc.tris[prim].material; }
+inline gpo_material blackDiffuse() { gpo_material m; std::memset(&m, 0, sizeof m); m.type = MAT_DIFFUSE; return m; }
+// Scene::rayIntersectAll(ray, its): the kd-tree, then the special shapes with maxt = the hit found so far (Sphere::rayIntersect / fillIntersectionRecord,
+// sphere.cpp:163-187,209-255: the quadratic in double as there; the sphere encloses everything, so it only ever answers when the kd-tree found nothing)
+inline bool rayIntersectAll(const Scene &sc, const Ray &ray, Intersection &its)
+{
+    const bool result = rayIntersect(sc, ray, its);
+    if (!hasEnvShape(sc)) return result;
+    const Float maxt = result ? its.t : ray.maxt;
+    Float mint = ray.mint;
+    if (mint == Epsilon) mint *= std::max(std::max(std::max(std::abs(ray.o.x), std::abs(ray.o.y)), std::abs(ray.o.z)), Epsilon);
+    const V3 o = ray.o - sc.bsCenter;
+    const Float A = lengthSquared(ray.d), B = 2 * dot(o, ray.d), C = lengthSquared(o) - sc.bsRadius * sc.bsRadius;
+    Float nearT, farT;
+    if (!solveQuadratic(A, B, C, nearT, farT)) return result;
+    if (!(nearT <= maxt && farT >= mint)) return result;
+    Float t;
+    if (nearT < mint) { if (farT > maxt) return result; t = farT; } else t = nearT;
+    its = Intersection();
+    its.t = t; its.prim = ENV_PRIM;
+    its.p = ray.o + ray.d * t;
+    const V3 local = its.p - sc.bsCenter;                                                  // (the shape's transform is translate(centre): the scale went into m_radius, sphere.cpp:108-118)
+    const Float theta = std::acos(std::min((Float)1.0, std::max((Float)-1.0, local.z / sc.bsRadius)));   // math::safe_acos
+    Float phi = std::atan2(local.y, local.x);
+    if (phi < 0) phi += 2 * PI;
+    its.u = phi * (0.5 * INV_PI); its.v = theta * INV_PI;
+    its.dpdu = V3(-local.y, local.x, 0.0) * (2 * PI);
+    its.geoN = normalize(its.p - sc.bsCenter);
+    const Float zrad = std::sqrt(local.x * local.x + local.y * local.y);
+    if (zrad > 0) {
+        const Float invZRad = 1.0 / zrad, cosPhi = local.x * invZRad, sinPhi = local.y * invZRad;
+        its.dpdv = V3(local.z * cosPhi, local.z * sinPhi, -std::sin(theta) * sc.bsRadius) * PI;
+    } else its.dpdv = V3(local.z * 0.0, local.z * 1.0, -std::sin(theta) * sc.bsRadius) * PI;
+    its.geoN = -its.geoN;                                                                  // m_flipNormals
+    its.sh.n = its.geoN;                                                                   // (the reference sets shFrame.n only; s and t are read by nothing that survives
+    coordinateSystem(its.sh.n, its.sh.s, its.sh.t);                                        //  the black BSDF: a frame built from n stands in)
+    its.wi = its.sh.toLocal(-ray.d);
+    return true;
+}
+
 struct Tracer {
     Ctx &c;
     Rng &rng;
@@ -277,13 +357,13 @@ struct Tracer {
     {
         succ->type = ESurfaceInteraction;
         Ray none;
-        succ->mat = matOf(c.sc, succ->its, none);
-        succ->degenerate = !(hasSmooth(succ->mat) || c.sc.tris[succ->its.prim].emitter >= 0);   // edge.cpp:44-45 (no sensor shapes)
+        succ->mat = succ->its.prim == ENV_PRIM ? blackDiffuse() : matOf(c.sc, succ->its, none);
+        succ->degenerate = !(hasSmooth(succ->mat) || emitterOfPrim(c.sc, succ->its.prim) >= 0);   // edge.cpp:44-45 (no sensor shapes)
     }
     // PathEdge::sampleNext, edge.cpp:27-71 (no media)
     bool edgeSampleNext(Edge *e, const Ray &ray, Vertex *succ, int mode) const
     {
-        if (!rayIntersect(c.sc, ray, succ->its)) return false;
+        if (!rayIntersectAll(c.sc, ray, succ->its)) return false;
         fillSurface(succ);
         e->length = succ->its.t;
         if (e->length == 0) return false;
@@ -296,7 +376,7 @@ struct Tracer {
     // PathEdge::perturbDirection, edge.cpp:73-131 (no media: wantMedium is false, desiredType is not consulted otherwise)
     bool edgePerturbDirection(Edge *e, const Ray &ray, Float dist, Vertex *succ, int mode) const
     {
-        const bool surface = rayIntersect(c.sc, ray, succ->its);
+        const bool surface = rayIntersectAll(c.sc, ray, succ->its);
         if (dist <= 0) return false;
         if (!surface) return false;
         fillSurface(succ);
@@ -322,6 +402,8 @@ struct Tracer {
             e->length = length(e->d);
             e->d = e->d / e->length;
             Ray ray(vtp, e->d, vt->isOnSurface() ? Epsilon : 0.0, e->length * (vs->isOnSurface() ? (1 - ShadowEpsilon) : 1.0));
+            // (rayIntersectAll's shadow form also asks the environment's sphere, sphere.cpp:189-207 -- which answers "no" to every segment with both ends inside or
+            //  on it: nearT < mint and farT > maxt.  Every vertex lies inside or on that sphere, so the kd-tree alone decides.)
             if (rayIntersectShadow(c.sc, ray)) return false;
             e->weight[ERadiance] = e->weight[EImportance] = V3(1.0);
             e->pdf[ERadiance] = e->pdf[EImportance] = 1.0;
@@ -440,6 +522,21 @@ struct Tracer {
                 v->weight[EImportance] = result;
                 v->weight[ERadiance] = result * INV_FOURPI;
                 v->pdf[EImportance] = INV_FOURPI;
+                v->pdf[ERadiance] = 1.0;
+                v->measure = ESolidAngle;
+                ray = Ray(v->prec.p, d);
+                break;
+            }
+            if (isEnvMap(c.sc, v->prec.object)) {                                          // EnvironmentMap::sampleDirection, envmap.cpp:455-474
+                V3 value, dl; Float dpdf;
+                envMapSampleDirection(c.sc.envMap, sx, sy, dl, value, dpdf);
+                const V3 d = mul3(c.sc.envMap.toWorld, -dl);
+                if (isZero(value) || dpdf == 0) return false;                               // ("be wary of roundoff errors": Spectrum(0) -> sampleNext fails, vertex.cpp:106-107)
+                const V3 result = (value * c.sc.envMap.normalization) / (dpdf * c.sc.envMap.scale);
+                if (isZero(result)) return false;
+                v->weight[EImportance] = result;
+                v->weight[ERadiance] = result * dpdf * (1.0 / std::abs(dot(d, v->prec.n)));   // (EOnSurface, envmap.cpp:107)
+                v->pdf[EImportance] = dpdf;
                 v->pdf[ERadiance] = 1.0;
                 v->measure = ESolidAngle;
                 ray = Ray(v->prec.p, d);
@@ -608,6 +705,7 @@ struct Tracer {
             if (mode != EImportance || pred != nullptr || succ->type != EEmitterSample) return V3(0.0);
             if (c.sc.emitters[succ->prec.object].numTris < 0)                              // PointEmitter::evalPosition, point.cpp:89-91
                 return measure == EDiscrete ? c.sc.emitters[succ->prec.object].radiance * (4 * PI) : V3(0.0);
+            if (isEnvMap(c.sc, succ->prec.object)) return V3(envMapPower(c.sc) * envInvSurfaceArea(c.sc));   // EnvironmentMap::evalPosition, envmap.cpp:424-426
             return c.sc.emitters[succ->prec.object].radiance * PI;                         // AreaLight::evalPosition, area.cpp:99-101
         case ESensorSupernode:
             if (mode != ERadiance || pred != nullptr || succ->type != ESensorSample) return V3(0.0);
@@ -619,7 +717,7 @@ struct Tracer {
             else if (mode == ERadiance && succ->type == EEmitterSupernode) target = pred->position();
             else return V3(0.0);
             const V3 wo = normalize(target - v->prec.p);
-            V3 result(emitterDirection(c, v->prec, wo, measure == EArea ? ESolidAngle : measure));
+            V3 result = emitterEvalDirection(c, v->prec, wo, measure == EArea ? ESolidAngle : measure);
             const Float dp = std::abs(dot(v->prec.n, wo));
             if (measure != EDiscrete && dp != 0) result = result / dp;
             return result;
@@ -703,7 +801,7 @@ struct Tracer {
         if (desired == v->type) return true;
         if (desired == EEmitterSample) {
             if (v->type != ESurfaceInteraction) return false;
-            const int em = c.sc.tris[v->its.prim].emitter;
+            const int em = emitterOfPrim(c.sc, v->its.prim);
             if (em < 0) return false;
             v->type = desired;
             PRec pRec;                                                                     // PositionSamplingRecord(its), records.inl:154-155
@@ -1320,7 +1418,7 @@ struct Tracer {
             const Float eta = getEta(vertex_old->mat);
             const V3 wi_world = normalize(pred->position() - vertex->position());
             V3 wo_world(0.0);
-            if (c.sc.tris[its_old.prim].material != c.sc.tris[its_new.prim].material) return false;      // its_old.getBSDF() != its_new.getBSDF()
+            if (materialOfPrim(c.sc, its_old.prim) != materialOfPrim(c.sc, its_new.prim)) return false;      // its_old.getBSDF() != its_new.getBSDF()
             if (vertex_old->isConnectable()) {
                 V3 m(0.0);
                 if (reflection) m = normalize(wi_old + wo_old);
@@ -1524,7 +1622,7 @@ struct Tracer {
     {
         connectedPath.clear();
         while (!isConnectableGBDPT(sensorSubpath.v[t], c.cfg.shiftThreshold)) { t--; sensorSubpath.v.pop_back(); sensorSubpath.e.pop_back(); }   // removeAndReleaseLastElement
-        if (sensorSubpath.v[t]->type == ESurfaceInteraction && c.sc.tris[sensorSubpath.v[t]->its.prim].emitter >= 0) s = 0;
+        if (sensorSubpath.v[t]->type == ESurfaceInteraction && emitterOfPrim(c.sc, sensorSubpath.v[t]->its.prim) >= 0) s = 0;
         for (memPointer = 0; memPointer < s; memPointer++) { connectedPath.v.push_back(emitterSubpath.v[memPointer]); connectedPath.e.push_back(emitterSubpath.e[memPointer]); }
         connectedPath.v.push_back(pool.clone(emitterSubpath.v[memPointer]));
         connectedPath.e.push_back(pool.allocEdge());

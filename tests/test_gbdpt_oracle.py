@@ -150,7 +150,7 @@ def test_specular_chains_estimator_expectation(variant):
     O.close()
 
 
-@pytest.mark.parametrize("what", ["thinlens", "thinlens_wide", "point_beside_area", "points_only"])
+@pytest.mark.parametrize("what", ["thinlens", "thinlens_wide", "point_beside_area", "points_only", "environment", "environment_only_glass", "envmap", "envmap_only_rotated"])
 def test_thinlens_sensor_and_point_emitters_estimator_expectation(what):
     """Round 5: the thinlens sensor (thinlens.cpp: aperture position sample, importance through the pixel's focus-plane point, one more emitter step) and `point`
     emitters (point.cpp: discrete position measure, uniform directions, no cosine; no extra sensor step when every emitter is one) in the G-BDPT oracle.  What
@@ -158,7 +158,19 @@ def test_thinlens_sensor_and_point_emitters_estimator_expectation(what):
     layer (it samples the lens in sampleRay and the point light in sampleEmitterDirect) -- and the merged gradients to its finite differences.  A point light is
     also SEEN by the light image (s = 1, t = 1: one bright pixel a path tracer cannot produce): that pixel is left out of the comparison."""
     W, H, spp, md = 20, 15, 256, 4
-    sc = scenes.cornell_box(W, H, "diffuse")
+    sc = scenes.cornell_box(W, H, "glass" if what == "environment_only_glass" else "diffuse")
+    # the `constant` environment: to libbidir a sphere-shaped area light with a black BSDF that every escaping ray hits (scene.cpp:397-408, constant.cpp:67-160); the
+    # path tracer evaluates it on escaping rays and samples it by direction (constant.cpp:163-205) -- no sphere, no surface vertex
+    if what == "environment": sc.environment = ((0.6, 0.7, 0.9), len(sc.emitters))
+    if what == "environment_only_glass": sc.emitters = []; sc.environment = ((0.6, 0.7, 0.9), 0)
+    # the `envmap` environment (round 5, the last endpoint kind): the same sphere, positions uniform on it, but directions importance-sampled FROM THE MAP whatever the
+    # position (envmap.cpp:412-498: a stated compromise) and a coloured evalDirection -- against the path tracer's evalEnvironment / sampleDirect (envmap.cpp:378-410,509-549);
+    # a smooth map (no sun patch): the emitter subpaths of this strategy mostly miss the scene, and a 40x texel would leave the comparison to a handful of paths
+    if what == "envmap": sc.environment_map = dict(rgb=scenes.sky_map(16, 8, sun=1.5), scale=1.3, index=len(sc.emitters))
+    if what == "envmap_only_rotated":
+        sc.emitters = []
+        a = 0.7; rot = [[np.cos(a), 0.0, np.sin(a)], [0.0, 1.0, 0.0], [-np.sin(a), 0.0, np.cos(a)]]
+        sc.environment_map = dict(rgb=scenes.sky_map(16, 8, sun=1.5), scale=2.0, index=0, toWorld=rot)
     if what == "thinlens": sc.thinlens = (40.0, 1100.0)
     if what == "thinlens_wide": sc.thinlens = (120.0, 600.0)
     pl = ("point", (300.0, 400.0, 279.5), (4e4, 3e4, 2e4))        # (off the film's centre line: a splat exactly between two pixels lands in both, imageblock.h)

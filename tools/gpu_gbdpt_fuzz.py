@@ -54,6 +54,14 @@ for seed in range(first, first + count):
             pls = [("point", tuple(float(v) for v in r2.uniform(40.0, 510.0, 3)), tuple(float(v) for v in r2.uniform(2e3, 5e4, 3))) for _ in range(int(r2.integers(1, 3)))]
             mode = int(r2.integers(0, 3))
             sc.emitters = sc.emitters + pls if mode == 0 else (pls + sc.emitters if mode == 1 else pls)
+        if cornell and r2.random() < 0.35:              # a `constant` environment (the box is open at the front), anywhere in the emitter list; now and then the only emitter
+            if r2.random() < 0.25: sc.emitters = []
+            index = int(r2.integers(0, len(sc.emitters) + 1))
+            if r2.random() < 0.5: sc.environment = (tuple(float(v) for v in r2.uniform(0.05, 1.5, 3)), index)
+            else:                                       # an `envmap` one (random small map, now and then with a sun texel; rotated about y)
+                a = float(r2.uniform(0.0, 6.28))
+                sc.environment_map = dict(rgb=scenes.sky_map(int(r2.choice([8, 16, 32])), int(r2.choice([4, 8, 16])), seed=int(r2.integers(0, 1 << 30)), sun=float(r2.choice([1.5, 40.0]))),
+                                          scale=float(r2.uniform(0.3, 2.0)), index=index, toWorld=[[np.cos(a), 0.0, np.sin(a)], [0.0, 1.0, 0.0], [-np.sin(a), 0.0, np.cos(a)]])
     spp = int(rng.integers(1, 4))
     S = G.Scene(sc); O = go.Scene(sc)
     integ = B.GBDPTIntegrator(maxDepth=md, rrDepth=rr, lightImage=li)

@@ -24,8 +24,11 @@ if os.environ.get("GBDPT_FUZZ_ENDPOINTS"):
         pls = [("point", tuple(float(v) for v in r2.uniform(40.0, 510.0, 3)), tuple(float(v) for v in r2.uniform(2e3, 5e4, 3))) for _ in range(int(r2.integers(1, 3)))]
         mode = int(r2.integers(0, 3))
         sc.emitters = sc.emitters + pls if mode == 0 else (pls + sc.emitters if mode == 1 else pls)
+    if cornell and r2.random() < 0.35:
+        if r2.random() < 0.25: sc.emitters = []
+        sc.environment = (tuple(float(v) for v in r2.uniform(0.05, 1.5, 3)), int(r2.integers(0, len(sc.emitters) + 1)))
 spp = int(rng.integers(1, 4))
-print("seed", seed, "W H", W, H, "maxDepth", md, "rrDepth", rr, "lightImage", li, "spp", spp, "thinlens", getattr(sc, "thinlens", None), "emitters", [e[0] if isinstance(e, tuple) else e for e in sc.emitters])
+print("seed", seed, "W H", W, H, "maxDepth", md, "rrDepth", rr, "lightImage", li, "spp", spp, "thinlens", getattr(sc, "thinlens", None), "emitters", [e[0] if isinstance(e, tuple) else e for e in sc.emitters], "environment", getattr(sc, "environment", None))
 S = G.Scene(sc); O = go.Scene(sc)
 integ = B.GBDPTIntegrator(maxDepth=md, rrDepth=rr, lightImage=li)
 cfg = integ.config(spp, 5489 + seed); ocfg = go.gbdpt_config(maxDepth=md, rrDepth=rr, lightImage=li, spp=spp, seed=5489 + seed)
