@@ -57,7 +57,7 @@ for seed in range(first, first + count):
         if cornell and r2.random() < 0.35:              # a `constant` environment (the box is open at the front), anywhere in the emitter list; now and then the only emitter
             if r2.random() < 0.25: sc.emitters = []
             index = int(r2.integers(0, len(sc.emitters) + 1))
-            if r2.random() < 0.5: sc.environment = (tuple(float(v) for v in r2.uniform(0.05, 1.5, 3)), index)
+            if r2.random() < 0.5 or sc.thinlens is not None: sc.environment = (tuple(float(v) for v in r2.uniform(0.05, 1.5, 3)), index)   # (a lens + an envmap: refused at scene creation, the G-PT side's filtered lookup)
             else:                                       # an `envmap` one (random small map, now and then with a sun texel; rotated about y)
                 a = float(r2.uniform(0.0, 6.28))
                 sc.environment_map = dict(rgb=scenes.sky_map(int(r2.choice([8, 16, 32])), int(r2.choice([4, 8, 16])), seed=int(r2.integers(0, 1 << 30)), sun=float(r2.choice([1.5, 40.0]))),
