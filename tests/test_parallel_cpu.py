@@ -16,28 +16,32 @@ NREC = 31
 
 
 class FakeFilm:
-    """rec[NREC][rows+2][W] (row 0 / -1 = halo), spill[5][rows+2][W][4]; same payload layout as the device film."""
+    """rec[NREC][rows+2][W] (row 0 / -1 = halo), spill[5][rows+4][W][4] (rows 0-1 / -2 -1 = the two halo rows of exact puts beyond the strip: a sample within 1e-5
+    of a pixel edge reaches two rows, round 5); same payload layout as the device film: the boundary row's records, then the spill of the near and the far halo row."""
 
     def __init__(self, W, y0, y1, seed):
         rng = np.random.default_rng(seed)
         self.W, self.y0, self.y1 = W, y0, y1
-        rows = y1 - y0 + 2
-        self.rec = rng.standard_normal((NREC, rows, W))
+        rows = y1 - y0
+        self.rec = rng.standard_normal((NREC, rows + 2, W))
         self.rec[:, 0] = 0; self.rec[:, -1] = 0
-        self.spill = rng.standard_normal((5, rows, W, 4))
+        self.spill = rng.standard_normal((5, rows + 4, W, 4))
 
     def halo_bytes(self):
-        return 8 * (NREC * self.W + 5 * self.W * 4)
+        return 8 * (NREC * self.W + 2 * 5 * self.W * 4)
 
     def pack_halo(self, which, t):
-        own, halo = (1, 0) if which == 0 else (-2, -1)
-        t.copy_(torch.from_numpy(np.concatenate([self.rec[:, own].ravel(), self.spill[:, halo].ravel()])))
+        own, near, far = (1, 1, 0) if which == 0 else (-2, -2, -1)
+        t.copy_(torch.from_numpy(np.concatenate([self.rec[:, own].ravel(), self.spill[:, near].ravel(), self.spill[:, far].ravel()])))
 
     def unpack_halo(self, which, t):
-        own, halo = (1, 0) if which == 0 else (-2, -1)
+        halo, own, inside = (0, 2, 3) if which == 0 else (-1, -3, -4)
         a = t.numpy()
-        self.rec[:, halo] = a[:NREC * self.W].reshape(NREC, self.W)
-        self.spill[:, own] += a[NREC * self.W:].reshape(5, self.W, 4)
+        n1, n2 = NREC * self.W, 5 * self.W * 4
+        self.rec[:, halo] = a[:n1].reshape(NREC, self.W)
+        self.spill[:, own] += a[n1:n1 + n2].reshape(5, self.W, 4)                # the neighbour's near halo row is my boundary row,
+        if self.y1 - self.y0 >= 2:
+            self.spill[:, inside] += a[n1 + n2:].reshape(5, self.W, 4)           # its far halo row the one inside it
 
 
 def _free_port():
@@ -60,8 +64,9 @@ def _worker(rank, world, port, W, H, q):
         assert img4.shape == (4, H, W, 3) and all(torch.equal(img4[k], img + 10.0 * k) for k in range(4))
     else:
         assert img4 is None
+    dsp = film.spill - before_spill
     q.put((rank, film.rec[:, 0].copy(), film.rec[:, -1].copy(), film.rec[:, 1].copy(), film.rec[:, -2].copy(),
-           (film.spill - before_spill)[:, 1].copy(), (film.spill - before_spill)[:, -2].copy(), before_spill[:, 0].copy(), before_spill[:, -1].copy(),
+           dsp[:, 2:4].copy(), dsp[:, -4:-2][:, ::-1].copy(), before_spill[:, 0:2][:, ::-1].copy(), before_spill[:, -2:].copy(),     # (boundary row first, then the next one)
            sent, None if img is None else img.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -87,7 +92,7 @@ def test_halo_exchange_and_gather_over_gloo(world):
     assert strips[0][0] == 0 and strips[-1][1] == H and all(a[1] == b[0] for a, b in zip(strips, strips[1:]))
     for r in range(world):
         _, halo_top, halo_bot, own_top, own_bot, dsp_top, dsp_bot, sp_halo_top, sp_halo_bot, sent, img = res[r]
-        if r > 0:      # my top halo row == upper neighbour's last owned row; its bottom-halo spill was added to my first row
+        if r > 0:      # my top halo row == upper neighbour's last owned row; the spill of its two bottom halo rows (near, far) was added to my first and second row
             assert np.array_equal(halo_top, res[r - 1][4]) and np.allclose(dsp_top, res[r - 1][8])
         else:
             assert not halo_top.any() and not dsp_top.any()
@@ -95,7 +100,7 @@ def test_halo_exchange_and_gather_over_gloo(world):
             assert np.array_equal(halo_bot, res[r + 1][3]) and np.allclose(dsp_bot, res[r + 1][7])
         else:
             assert not halo_bot.any() and not dsp_bot.any()
-        assert sent == 8 * (NREC * W + 20 * W) * ((r > 0) + (r < world - 1))
+        assert sent == 8 * (NREC * W + 40 * W) * ((r > 0) + (r < world - 1))
         if r == 0:
             assert img.shape == (H, W, 3)
             for rr, (y0, y1) in enumerate(strips):
@@ -149,28 +154,28 @@ class _ToyFilm:
         self.exchanged = 0
 
     def clear(self):
-        rows = self.y1 - self.y0 + 2
-        self.rec = np.zeros((NREC, rows, self.W)); self.spill = np.zeros((5, rows, self.W, 4))
+        rows = self.y1 - self.y0
+        self.rec = np.zeros((NREC, rows + 2, self.W)); self.spill = np.zeros((5, rows + 4, self.W, 4))     # (one halo row of records, two of exact puts: FakeFilm)
 
     def render(self, spp):
-        lo, hi = (max(0, self.y0 - 1), min(self.H, self.y1 + 1)) if self.own_border else (self.y0, self.y1)
+        lo, hi = (max(0, self.y0 - 2), min(self.H, self.y1 + 2)) if self.own_border else (self.y0, self.y1)     # (own border: every row whose puts reach the strip)
         for y in range(lo, hi):
             x = np.arange(self.W)
             if self.y0 <= y < self.y1 or self.own_border:
                 if self.y0 - 1 <= y <= self.y1:
                     for k in range(NREC):
                         self.rec[k, y - (self.y0 - 1)] = spp * ((k + 1) * 1000 + 7 * y + x)
-            for t in (y - 1, y, y + 1):
-                if 0 <= t < self.H and self.y0 - 1 <= t <= self.y1 and (not self.own_border or self.y0 <= t < self.y1):
+            for t in (y - 2, y - 1, y, y + 1, y + 2):                                  # (a put reaches two rows from its sample's: the box filter's 0.5 + 1e-5 radius)
+                if 0 <= t < self.H and self.y0 - 2 <= t <= self.y1 + 1 and (not self.own_border or self.y0 <= t < self.y1):
                     for b in range(5):
-                        self.spill[b, t - (self.y0 - 1), :, :] += (b + 1) * (3 * y + t) + x[:, None]
+                        self.spill[b, t - (self.y0 - 2), :, :] += (b + 1) * (3 * y + t) + x[:, None]
 
     def sync(self):
         pass
 
     def halo_bytes(self):
         self.exchanged += 1
-        return 8 * (NREC * self.W + 5 * self.W * 4)
+        return 8 * (NREC * self.W + 2 * 5 * self.W * 4)
 
     pack_halo = FakeFilm.pack_halo
     unpack_halo = FakeFilm.unpack_halo
@@ -178,7 +183,7 @@ class _ToyFilm:
     def develop_device(self, b, t):
         r = self.rec[b]
         img = r[1:-1] + 2 * r[:-2] + 3 * r[2:]
-        t.copy_(torch.from_numpy((img[:, :, None] + self.spill[b, 1:-1, :, :3]).astype(np.float32)))
+        t.copy_(torch.from_numpy((img[:, :, None] + self.spill[b, 2:-2, :, :3]).astype(np.float32)))
 
     def stats(self):
         return dict(raysTraced=10 * (self.y1 - self.y0), shadowRaysTraced=self.y1 - self.y0)
@@ -274,7 +279,7 @@ def test_strip_renderer_equals_one_rank(world, own_border, rebalance):
         if own_border:
             assert halo == 0 and exchanged == 0                     # nothing exchanged: the strip rendered its border itself
         else:
-            assert halo == 8 * (NREC * W + 20 * W) * ((r > 0) + (r < world - 1))
+            assert halo == 8 * (NREC * W + 40 * W) * ((r > 0) + (r < world - 1))
     if rebalance:
         assert res[0][4] != parallel.row_strips(H, world) and res[0][4][0][1] > parallel.row_strips(H, world)[0][1]
 
