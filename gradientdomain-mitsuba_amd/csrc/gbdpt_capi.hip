@@ -240,18 +240,30 @@ __global__ __launch_bounds__(TBLK, 2) void k_bd_connect(SceneD S, BdCam cam, BdC
             }
         }
     }
-    if (PHASE != 2) {
-        const unsigned long long mask = __ballot(keep);
-        if (mask) {
-            const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)mask) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(nOut, (unsigned)__popcll(mask));
-            base = __shfl(base, leader);
-            if (keep) out[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = it;
-        }
+    // The survivors' list and the ray counters take ONE atomic per block, not per wave: a phase-3 launch of config 5's frame is 490 k waves that do little else, and
+    // three atomics per wave on three fixed addresses held it at ~12 ns per wave whatever the work (5.8 ms of a 164 ms frame for the camera connections alone).
+    __shared__ unsigned s_keep[TBLK / 64], s_base, s_rays[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long mask = PHASE != 2 ? __ballot(keep) : 0ULL;
+    if (threadIdx.x < 2) s_rays[threadIdx.x] = 0;
+    if (PHASE != 2 && lane == 0) s_keep[wv] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (PHASE != 3) {                                                                       // (phase 3 traces nothing)
+        const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
+        if (lane == 0) { if (a) atomicAdd(&s_rays[0], a); if (b) atomicAdd(&s_rays[1], b); }
     }
-    const unsigned a = __builtin_amdgcn_wave_reduce_add_u32(c.nClosest, 0), b = __builtin_amdgcn_wave_reduce_add_u32(c.nShadow, 0);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 0, (unsigned long long)a); atomicAdd(stats + 1, (unsigned long long)b); }
+    if (PHASE != 2 && threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < TBLK / 64; w++) total += s_keep[w];
+        s_base = total ? atomicAdd(nOut, total) : 0u;
+    }
+    __syncthreads();
+    if (PHASE != 2 && keep) {
+        unsigned base = s_base;
+        for (int w = 0; w < wv; w++) base += s_keep[w];
+        out[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = it;
+    }
+    if (PHASE != 3 && threadIdx.x == 0) { if (s_rays[0]) atomicAdd(stats + 0, (unsigned long long)s_rays[0]); if (s_rays[1]) atomicAdd(stats + 1, (unsigned long long)s_rays[1]); }
 }
 
 // The general form of a sample (specular chains; gbdpt_general.hip.h) in staged launches per pass over <= gsCap listed samples (round 5; round 4 ran a
@@ -618,7 +630,16 @@ int gdpt_gbdpt_film_create(gdpt_scene *s, gdpt_gbdpt_film **out)
     BHIPCHK(hipMalloc((void **)&f->genCount, sizeof(unsigned) * 2));               // entries of the general list
     BHIPCHK(hipMalloc((void **)&f->gCount, sizeof(unsigned) * 16));                // the counters and cursors of a pass (k_bdg_shift)
     f->sceneRadius = s->bsphereRadius;              // m_scene->getBSphere().radius (gpt_capi.hip: kd-tree bounds + sensor + emitters, scene.cpp:386-413)
-    BHIPCHK(hipStreamCreate(&f->stream)); BHIPCHK(hipStreamCreate(&f->gstream));
+    BHIPCHK(hipStreamCreate(&f->stream));
+    // The general form's stream is the frame's critical path (persistent lanes with long tails: ~93 ms of kernels per 2 spp frame of config 5's scene against ~58 ms of
+    // the fast form's connection launches beside it): it gets the device's highest stream priority, so its workgroups are placed first and the fast form's dense grids
+    // fill what is left.  GDPT_BD_GSTREAM_PRIORITY=0: both streams at the default priority (the A/B switch of the measurement in DESIGN.md).
+    {
+        int least = 0, greatest = 0;
+        const char *e = getenv("GDPT_BD_GSTREAM_PRIORITY");
+        if ((e && atoi(e) == 0) || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least) { (void)hipGetLastError(); BHIPCHK(hipStreamCreate(&f->gstream)); }
+        else BHIPCHK(hipStreamCreateWithPriority(&f->gstream, hipStreamDefault, greatest));
+    }
     BHIPCHK(hipEventCreate(&f->e0)); BHIPCHK(hipEventCreate(&f->e1)); BHIPCHK(hipEventCreateWithFlags(&f->eG, hipEventDisableTiming));
     *out = f;
     return gdpt_gbdpt_film_clear(f);
