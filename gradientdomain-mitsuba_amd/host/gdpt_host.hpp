@@ -384,7 +384,7 @@ public:
         const std::vector<std::string> outNames = {"-final", "-throughput", "-dx", "-dy", "-direct"};
         if (!film.setBuffers(outNames)) logError("Cannot render image! G-PT has been called without MultiFilm.");
         const int W = film.getWidth(), H = film.getHeight(), N = (int)m_devices.size();
-        if (N > H) logError("more devices than image rows");
+        if (2 * N > H) logError("strips need at least two rows each (the halo carries the exact puts of two rows beyond a boundary): fewer devices, or a taller image");
         struct Strip { int device = 0, y0 = 0, y1 = 0; gdpt_scene *scene = nullptr; gdpt_film *film = nullptr; void *out[2] = {nullptr, nullptr}, *in[2] = {nullptr, nullptr}; float *imgs = nullptr; std::string error; };
         std::vector<Strip> strips(N);
         for (int r = 0, y = 0; r < N; ++r) {                       // contiguous rows, earlier strips take the remainder (parallel.row_strips)

@@ -189,6 +189,10 @@ class StripRenderer:
     def set_strips(self, strips):
         """(Re)partition the image; every rank must pass the same list."""
         assert len(strips) == self.world and strips[0][0] == 0 and strips[-1][1] == self.height
+        # (the halo carries the exact puts of TWO rows beyond a boundary -- a sample within 1e-5 of a pixel edge reaches that far, include/gdpt_tracer.h -- and the
+        #  neighbour adds the far one to the row INSIDE its boundary row: a one-row strip has none, the put would be lost)
+        if self.world > 1 and min(b - a for a, b in strips) < 2:
+            raise ValueError("strips of the halo exchange need at least two rows each (%d rows over %d ranks: %r)" % (self.height, self.world, list(strips)))
         self.strips = list(strips)
         self.y0, self.y1 = self.strips[self.rank]
         if self.film is not None:
