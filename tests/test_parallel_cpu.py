@@ -381,3 +381,14 @@ def test_gbdpt_strip_renderer_equals_one_rank(world):
     assert sum(res[r][2] for r in range(world)) == whole[2] == 3 * W * H and sum(res[r][1] for r in range(world)) == whole[1]
     assert all(res[r][3] == 8 * 5 * W * H * 7 for r in range(world)) and whole[3] == 0
     assert res[0][4] == parallel.row_strips(H, world)
+
+
+def test_strips_of_one_row_are_refused_for_the_halo_exchange():
+    """The halo carries the exact puts of TWO rows beyond a boundary and the neighbour adds the far one to the row inside its boundary row (include/gdpt_tracer.h):
+    a one-row strip has no such row -- the hosts refuse the partition instead of losing the put (parallel.StripRenderer.set_strips; gdpt_host.hpp renderStrips)."""
+    import types
+    from gradientdomain_mitsuba_amd import parallel as PP
+    stub = types.SimpleNamespace(world=2, height=3, rank=0, film=None)
+    with pytest.raises(ValueError, match="at least two rows"):
+        PP.StripRenderer.set_strips(stub, [(0, 1), (1, 3)])
+    assert PP.rebalance_strips([(0, 4), (4, 8)], [1.0, 30.0], min_rows=2) == [(0, 6), (6, 8)]      # (the rebalance step keeps two rows when asked to)
