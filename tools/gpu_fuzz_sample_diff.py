@@ -35,8 +35,34 @@ for ax in (None, 0, 1, 2):
         else: v[:, ax] *= 1 + k * 2.0 ** -52
         sc2 = copy.deepcopy(sc); sc2.verts = v.reshape(np.asarray(sc.verts).shape)
         O2 = go.Scene(sc2); outs.append(O2.evaluate_point(ocfg, px, py, s)); O2.close()
+def rotated(sc):
+    """The scene (geometry, normals, camera, point lights) turned as a whole by k x 2^-30 rad about each axis (18 variants): the same picture with every number rounded
+    afresh -- unlike the scalings above it also moves the SAMPLED directions (the frames stop being axis-aligned), so it stands in for the one-ulp differences between
+    the device's and glibc's transcendentals.  Scenes whose emitters carry transforms of their own (rectangle lights, an environment map) are left out."""
+    if sc.environment_map is not None or any(isinstance(e[0], str) and e[0] != "point" for e in sc.emitters) or any((not isinstance(e[0], str)) and len(e) > 3 for e in sc.emitters):
+        return
+    v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
+    n0 = None if sc.normals is None else np.asarray(sc.normals, np.float64).reshape(-1, 3)
+    for ax in range(3):
+        i, j = [(1, 2), (2, 0), (0, 1)][ax]
+        for k in (1, -1, 2, -2, 3, -3):
+            th = k * 2.0 ** -30
+            R = np.eye(3); R[i, i] = R[j, j] = np.cos(th); R[i, j] = -np.sin(th); R[j, i] = np.sin(th)
+            sc2 = copy.deepcopy(sc)
+            sc2.verts = (v0 @ R.T).reshape(np.asarray(sc.verts).shape)
+            if n0 is not None: sc2.normals = (n0 @ R.T).reshape(np.asarray(sc.normals).shape)
+            M = np.array(sc.to_world, np.float64).copy(); M[:3, :3] = R @ M[:3, :3]; M[:3, 3] = R @ M[:3, 3]
+            sc2.to_world = M
+            sc2.emitters = [(e[0], tuple(R @ np.asarray(e[1], np.float64)), *e[2:]) if isinstance(e[0], str) else e for e in sc.emitters]
+            yield sc2
+routs = []
+for sc2 in rotated(sc):
+    O2 = go.Scene(sc2); routs.append(O2.evaluate_point(ocfg, px, py, s)); O2.close()
 np.set_printoptions(precision=17, linewidth=200)
 print("rays", g["raysTraced"], g["shadowRaysTraced"], o["raysTraced"], o["shadowRaysTraced"], sorted({(r["raysTraced"], r["shadowRaysTraced"]) for r in outs}))
 for key in ("veryDirect", "throughput", "gradients", "neighbours"):
     sens = np.max([np.abs(r[key] - o[key]) for r in outs], axis=0)
     print(key, "\n device - oracle (relative):\n", (g[key] - o[key]) / np.abs(o[key]).clip(1e-300), "\n oracle's own spread (relative):\n", sens / np.abs(o[key]).clip(1e-300))
+    if routs:
+        rs = np.max([np.abs(r[key] - o[key]) for r in routs], axis=0)
+        print(" oracle's spread under 18 rigid rotations of the scene by k x 2^-30 rad (relative):\n", rs / np.abs(o[key]).clip(1e-300))
