@@ -29,6 +29,29 @@ def perturbed(sc):
             sc2 = copy.deepcopy(sc)
             sc2.verts = v.reshape(np.asarray(sc.verts).shape)
             yield sc2
+    yield from rotated(sc)          # (round 5: and the scene turned as a whole by tiny angles, below)
+
+
+def rotated(sc):
+    """The scene (geometry, normals, camera, point lights) turned as a whole by k x 2^-30 rad about each axis (18 variants): the same picture with every number rounded
+    afresh -- unlike the scalings above it also moves the SAMPLED directions (the frames stop being axis-aligned), so it stands in for the one-ulp differences between
+    the device's and glibc's transcendentals.  Scenes whose emitters carry transforms of their own (rectangle lights, an environment map) are left out."""
+    if sc.environment_map is not None or any(isinstance(e[0], str) and e[0] != "point" for e in sc.emitters) or any((not isinstance(e[0], str)) and len(e) > 3 for e in sc.emitters):
+        return
+    v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
+    n0 = None if sc.normals is None else np.asarray(sc.normals, np.float64).reshape(-1, 3)
+    for ax in range(3):
+        i, j = [(1, 2), (2, 0), (0, 1)][ax]
+        for k in (1, -1, 2, -2, 3, -3):
+            th = k * 2.0 ** -30
+            R = np.eye(3); R[i, i] = R[j, j] = np.cos(th); R[i, j] = -np.sin(th); R[j, i] = np.sin(th)
+            sc2 = copy.deepcopy(sc)
+            sc2.verts = (v0 @ R.T).reshape(np.asarray(sc.verts).shape)
+            if n0 is not None: sc2.normals = (n0 @ R.T).reshape(np.asarray(sc.normals).shape)
+            M = np.array(sc.to_world, np.float64).copy(); M[:3, :3] = R @ M[:3, :3]; M[:3, 3] = R @ M[:3, 3]
+            sc2.to_world = M
+            sc2.emitters = [(e[0], tuple(R @ np.asarray(e[1], np.float64)), *e[2:]) if isinstance(e[0], str) else e for e in sc.emitters]
+            yield sc2
 
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 9000
