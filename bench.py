@@ -282,8 +282,9 @@ def bench_gbdpt(a, rank, local, world, dev):
     render_ms = 0.0
     solve = [0.0, 0.0]
     phases = {}
+    last_out = None
     for _ in range(a.steps):
-        sr.render(a.spp)
+        last_out = sr.render(a.spp)
         general += sr.last["chain"]["generalSamples"]
         assert sr.last["chain"]["overflows"] == 0
         rays += sr.last["rays"]; samples += sr.last["samples"]; render_ms += sr.last["render_ms"]; closest += sr.last["closest_rays"]
@@ -345,6 +346,9 @@ def bench_gbdpt(a, rank, local, world, dev):
                "roofline": roofline, "tracer_bytes": tracer_bytes,
                "roofline_note": "the G-BDPT sampler runs as walk / connect / put launches joined by 11 KB sample records in HBM (DESIGN.md, G-BDPT); the connection kernels (70 % of a frame; one build per item class and phase -- a ray-free filter, the base path, the offsets, each on the survivors of the one before --, MIS weights as recurrences over the record) are latency-bound at 2 waves/SIMD on dependent record and scene-table loads plus fp64 BSDF evaluations -- counter traffic ~0.9 TB/s, a ninth of the HBM peak: no HBM or MFMA fraction applies; the reconstructions are the persistent CG of --config 2"}
         print(json.dumps(out))
+        if a.dump:                               # (tests: the last step's developed sampler buffers and both reconstructions)
+            import numpy as np
+            np.savez(a.dump, strips=np.array(sr.strips), **{k.lstrip("-"): v.cpu().numpy() for k, v in last_out.items()})
     sr.close(); scene.close()
     if world > 1:
         dist.destroy_process_group()

@@ -92,3 +92,21 @@ def test_bench_eight_ranks_of_config4_on_one_device(gpu_required, tmp_path):
     for k in range(4):                                                          # (on the border rows: fp32 images of fp64 sums added in another order)
         assert np.abs(d8["images"][k] - d1["images"][k]).max() <= 1e-5 * max(1.0, float(np.abs(d1["images"][k]).max())), k
     assert np.abs(d8["final"] - d1["final"]).max() <= 1e-3 * max(1.0, float(np.abs(d1["final"]).max()))
+
+
+def test_bench_two_ranks_of_config5_on_one_device(gpu_required, tmp_path):
+    """BASELINE configs[4] with N > 1 -- `bench.py --config 5 --gpus 2`: the G-BDPT sampler over two row strips of camera samples (light-tracing splats of either
+    rank land anywhere: the ranks' whole films are reduced onto rank 0 in one fused fp64 buffer, parallel.GBDPTStripRenderer), develop and both reconstructions on
+    rank 0 -- with the two ranks on this box's one device over gloo (1 spp, the specular scene: the general form runs on both ranks).  Same samples whoever renders
+    them: identical ray counts; the developed buffers equal the one-rank frame to the rounding of fp64 sums added in another order."""
+    one, d1 = run_bench(tmp_path, 1, config=5, spp=1)
+    two, d2 = run_bench(tmp_path, 2, config=5, spp=1)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "G-BDPT" in two["metric"] and "configs[4]" in two["config"]["workload"]
+    assert two["config"]["strip_rows"] == [360, 360] and one["config"]["strip_rows"] == [720]
+    assert two["rays_per_step"] == one["rays_per_step"]
+    assert two["reduce_bytes_per_rank"] == 8 * 5 * 720 * 1280 * 7 and one["reduce_bytes_per_rank"] == 0
+    for k in ("primal", "gradientPosX", "gradientPosY", "gradientNegX", "gradientNegY"):
+        scale = float(np.abs(d1[k]).max())
+        assert np.abs(d2[k] - d1[k]).max() <= 1e-9 * scale, (k, float(np.abs(d2[k] - d1[k]).max()) / scale)
+    for k in ("L2", "L1"):                       # (fp32 solves of inputs that differ in their last bits)
+        assert np.isfinite(d2[k]).all() and np.abs(d2[k] - d1[k]).max() <= 1e-3 * max(1.0, float(np.abs(d1[k]).max())), k
