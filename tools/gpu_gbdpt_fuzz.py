@@ -38,6 +38,8 @@ def rotated(sc):
     the device's and glibc's transcendentals.  Scenes whose emitters carry transforms of their own (rectangle lights, an environment map) are left out."""
     if sc.environment_map is not None or any(isinstance(e[0], str) and e[0] != "point" for e in sc.emitters) or any((not isinstance(e[0], str)) and len(e) > 3 for e in sc.emitters):
         return
+    if sc.environment is not None:       # (to libbidir the environment is a sphere about the scene's AXIS-ALIGNED box: that box is not the same box after a rotation, so the turned scene
+        return                           #  is another scene at the 1e-9 level, not the same one rounded afresh)
     v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
     n0 = None if sc.normals is None else np.asarray(sc.normals, np.float64).reshape(-1, 3)
     for ax in range(3):
