@@ -31,6 +31,8 @@ def rotated(sc):
     the device's and glibc's transcendentals.  Scenes whose emitters carry transforms of their own (rectangle lights, an environment map) are left out."""
     if sc.environment_map is not None or any(isinstance(e[0], str) and e[0] != "point" for e in sc.emitters) or any((not isinstance(e[0], str)) and len(e) > 3 for e in sc.emitters):
         return
+    if sc.environment is not None:       # (the environment's sphere is drawn about the scene's AXIS-ALIGNED box, which is another box after a rotation: the oracle's values move by
+        return                           #  ~4e-10 with the angle itself, not with rounding -- measured; such scenes keep the scalings only)
     v0 = np.asarray(sc.verts, np.float64).reshape(-1, 3)
     n0 = None if sc.normals is None else np.asarray(sc.normals, np.float64).reshape(-1, 3)
     for ax in range(3):
