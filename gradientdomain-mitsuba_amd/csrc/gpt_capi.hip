@@ -1086,9 +1086,19 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #else
 #define GDPT_DEV_DUMP_QUEUE() do { } while (0)
 #endif
+    // A scene none of whose vertices can be classified glossy by getVertexType (gpt.cpp:176-231: no delta BSDF, every rough BSDF's roughness above the
+    // shift threshold -- vertex_is_diffuse in gpt_kernels.hip.h, mirrored here) only ever takes reconnection shifts: its samples leave the first stage after ONE
+    // bounce, which k_first runs with the other connection states and the half-vector shift compiled out (GDPT_NO_FIRST_STAGE=1: k_render<STAGED> as for any scene)
+    bool firstStage = useQueue && wfIters == 0 && !getenv("GDPT_NO_FIRST_STAGE");
+#ifdef GDPT_HANDOFF_CONNECTED
+    firstStage = false;
+#endif
+    for (const MaterialD &m : s->hostMats)
+        if (!(m.type == 0 || (m.type == 2 && !(0.5 * (m.alphaU + m.alphaV) <= c.shiftThreshold)))) firstStage = false;
 #define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
 #define GDPT_STAGED(LDSV, ACCV, WPS, ENVV, SMV) do { \
         if (shift5) GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV); \
+        else if (firstStage) hipLaunchKernelGGL((k_first<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth); \
         else if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         GDPT_DEV_DUMP_QUEUE(); \
@@ -1127,9 +1137,12 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #ifndef GDPT_DEV_HBM_SMOOTH
 #define GDPT_DEV_HBM_SMOOTH true
 #endif
+#ifndef GDPT_DEV_HBM_ENV
+#define GDPT_DEV_HBM_ENV true
+#endif
 #ifdef GDPT_DEV_TWO_BUILDS   /* development only (-DGDPT_DEV_TWO_BUILDS: 1 min of hipcc instead of 5): one build per scene kind */
-        if (useQueue) { if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_STAGED(true, true, 2, false, false); else GDPT_STAGED(true, false, 2, false, false); } else GDPT_STAGED(false, false, 4, true, GDPT_DEV_HBM_SMOOTH); }
-        else if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, true, GDPT_DEV_HBM_SMOOTH);
+        if (useQueue) { if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_STAGED(true, true, 2, false, false); else GDPT_STAGED(true, false, 2, false, false); } else GDPT_STAGED(false, false, 4, GDPT_DEV_HBM_ENV, GDPT_DEV_HBM_SMOOTH); }
+        else if (s->d.ldsScene && !s->perVertex && !s->specialEmitters) { if (accLds) GDPT_LAUNCH(true, true, GDPT_DEV_WPS, false, false); else GDPT_LAUNCH(true, false, GDPT_DEV_WPS, false, false); } else GDPT_LAUNCH(false, false, 4, GDPT_DEV_HBM_ENV, GDPT_DEV_HBM_SMOOTH);
 #else
         if (useQueue) {
             // staged builds: {LDS scene, sums in LDS | LDS scene, sums in registers | HBM scene, sums in registers} x {flat | env | per-vertex}

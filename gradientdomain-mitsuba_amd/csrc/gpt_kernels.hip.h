@@ -50,7 +50,7 @@ constexpr int SLICE_FILL = 2;      // sample slices: aim at this many work items
 constexpr int LOG_CHUNK = 16;      // wider reconstruction filters: samples per pixel logged between two gathers (32 doubles each)
 constexpr int SLICE_MIN_SPP = 8;   // ... but never fewer samples than this per slice (the end of a slice runs with idle lanes)
 constexpr int NREC = 31;           // per-pixel record components
-constexpr int NQ = 62;             // doubles per continuation record (layout: gpt_render.hip.h, q_store / q_load)
+constexpr int NQ = 74;             // doubles per continuation record (layout: gpt_render.hip.h, q_store / q_load)
 constexpr int LDS_SCENE_BYTES = 40 * 1024;   // node + triangle + shading + material + emitter tables of a small scene
 
 struct d3 { Float x, y, z; };

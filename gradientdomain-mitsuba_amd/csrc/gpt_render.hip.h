@@ -181,14 +181,25 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 // One iteration of the main loop of evaluate (gpt.cpp:537-1175).  Returns false when the base path has ended.
 // ENV: the scene may have an environment emitter (compiled out otherwise: its branches cost the closed scenes 5-8 %).
 // SMOOTH: the scene has triangles with per-vertex normals (shading frame and geometric normal depend on the hit).
-// CONN: every offset path is RAY_CONNECTED or dead (the continuation kernel): the other two connection states are compiled out, and
-// with them every use of an offset's own vertex and direction.  The strict-normals test of the offsets (:547-554) is dropped there
-// too: it reads the offset's LAST OWN vertex and direction, which stop changing when the offset connects, and with those very values
-// it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
+// PH: which connection states of an offset path the build carries (the others, and with them their code, are compiled out):
+//   PH_ALL     all three, decided per offset at run time (the general kernel: scenes with specular chains, the single-kernel pipeline, the probes)
+//   PH_CONN    every offset path is RAY_CONNECTED or dead (the wavefront development build's continuation): every use of an offset's own vertex and direction is gone
+//   PH_FIRST   every offset path is RAY_NOT_CONNECTED or dead AND no vertex of the scene can be classified glossy (no delta BSDF, every roughness above
+//              cfg.shiftThreshold -- decided by the host per launch, gpt_capi.hip): the first bounce of a sample in such a scene.  getVertexType (gpt.cpp:176-231)
+//              answers "diffuse" for every vertex there, so the half-vector shift (:987-1126) can never be taken and only the reconnection shift is compiled in
+//   PH_JOINED  every offset path is RAY_RECENTLY_CONNECTED, RAY_CONNECTED or dead (the continuation kernel): the offsets follow the base path arithmetically
+//              (:622-658, :844-888); of an offset's own state only the position of its last own vertex is still read (the re-evaluation at previousMainIts)
+// The strict-normals test of the offsets (:547-554) is dropped in the builds without RAY_NOT_CONNECTED: it reads the offset's LAST OWN vertex and direction,
+// which stop changing when the offset connects, and with those very values it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
 // INL: the cold texture / environment-map lookups are inlined (4-wave builds) or real calls (2-wave builds), see tex_eval in gpt_kernels.hip.h
-template <bool ENV, bool SMOOTH, bool CONN, bool UNROLL, bool INL, class TR, class ACC>
+enum { PH_ALL = 0, PH_CONN = 1, PH_FIRST = 2, PH_JOINED = 3 };
+template <int PH>
+__device__ __forceinline__ int offset_status(const Offset &s) { return PH == PH_CONN ? (int)RAY_CONNECTED : (PH == PH_FIRST ? (int)RAY_NOT_CONNECTED : s.status); }
+template <bool ENV, bool SMOOTH, int PH, bool UNROLL, bool INL, class TR, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, TR &tr, Lane &L, ACC &A)
 {
+    constexpr bool JOINED = (PH == PH_CONN || PH == PH_JOINED);                   // no offset is RAY_NOT_CONNECTED
+    constexpr bool RECON = (PH == PH_FIRST);                                      // every vertex is "diffuse": reconnection shifts only
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
     const TriShade &mts = sv.shade[L.v.prim];
     const Shading msh = shading_at<SMOOTH>(sv, L.v);
@@ -197,7 +208,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     const d3 mainWi = toLocal(mfr, -L.rayD);                                     // its.wi
     if (cfg.strictNormals) {                                                     // :541-556
         if (dot(L.rayD, mGeoN) * mainWi.z >= 0) return false;
-        if (!CONN) {
+        if (!JOINED) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 Offset &s = L.off[i];
@@ -237,7 +248,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                 Float weight = 0;
                 bool assigned = false;          // false: weight and both contributions stay 0 (:613-615 with no branch taken)
                 bool shiftSuccessful = s.alive != 0;
-                const int status = CONN ? (int)RAY_CONNECTED : s.status;
+                const int status = offset_status<PH>(s);
                 if (shiftSuccessful) {
                     if (status == RAY_CONNECTED) {                               // :622-637
                         const Float den = (s.pdf * s.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
@@ -254,10 +265,10 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                         weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                         shiftedContribution = 1.0 * s.throughput * (f * mainEmitterRadiance);
                         assigned = true;
-                    } else {                                                     // :659-705
+                    } else if constexpr (!JOINED) {                              // :659-705
                         const TriShade &sts = sv.shade[s.v.prim];
                         const MaterialD &shiftedBSDF = sv.mats[sts.material];
-                        if (!lightOnSurfaceSA || (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth))) {   // mainAtPointLight || both diffuse, :667-672
+                        if (RECON || !lightOnSurfaceSA || (vertex_is_diffuse(mainBSDF, cfg, ESmooth) && vertex_is_diffuse(shiftedBSDF, cfg, ESmooth))) {   // mainAtPointLight || both diffuse, :667-672
                             const Shading ssh = shading_at<SMOOTH>(sv, s.v);
                             const Frame3 sfr = ssh.fr;
                             DRec sRec;
@@ -354,7 +365,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         bool postponedShiftEnd = false;
         if (s.alive) {
             const Float shiftedPreviousPdf = s.pdf;
-            const int status = CONN ? (int)RAY_CONNECTED : s.status;
+            const int status = offset_status<PH>(s);
             if (status == RAY_CONNECTED) {                                       // :844-861
                 s.throughput = s.throughput * (bs.weight * bs.pdf);
                 s.pdf *= mainBsdfPdf;
@@ -374,14 +385,14 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                 weight = mainWeightNumerator / (GD_D_EPSILON + den + mainWeightDenominator);
                 shiftedContribution = s.throughput * mainEmitterRadiance;
                 assigned = true;
-            } else {                                                             // :889-1126
+            } else if constexpr (!JOINED) {                                      // :889-1126
                 const TriShade &sts = sv.shade[s.v.prim];
                 const MaterialD &shiftedBSDF = sv.mats[sts.material];
                 const Shading ssh = shading_at<SMOOTH>(sv, s.v);
                 const Frame3 sfr = ssh.fr;
                 const bool shiftedVertexDiffuse = vertex_is_diffuse(shiftedBSDF, cfg, bs.sampledType);
                 const d3 shiftedR = reflectance_at<SMOOTH, INL>(sv, shiftedBSDF, s.v, L.depth == 1, &S.cam, L.sx + offset_shift_x(i), L.sy + offset_shift_y(i));   // (depth 1: still the offset's camera-ray hit)
-                if (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse) {
+                if (RECON || (mainVertexDiffuse && mainNextVertexDiffuse && shiftedVertexDiffuse)) {
                     // ---- reconnection shift, :897-986 ----
                     if (!lastSegment || mainHitEmitter) {                        // :901
                         // reconnectShift, gpt.cpp:316-345; environmentShift + testEnvironmentVisibility, :96-114,348-369
@@ -441,7 +452,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
                             }
                         }
                     }
-                } else {
+                } else if constexpr (!RECON) {
                     // ---- half-vector duplication shift, :987-1126 ----
                     d3 shiftedEmitterRadiance = mk(0.0);
                     bool envEnd = false;
@@ -645,13 +656,16 @@ __device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, uns
 }
 
 // ---- continuation records ---------------------------------------------------------------------------------------------------------
-// A sample leaves the general kernel as soon as each of its four offset paths is RAY_CONNECTED or dead (for diffuse and rough scenes:
-// after the second bounce).  From there the offsets are four (throughput, pdf) pairs that follow the base path arithmetically
-// (gpt.cpp:622-637,844-861), so the rest of the base path runs in k_continue: one small state per lane, one code path, waves refilled
-// from the queue as lanes finish -- instead of the general kernel's deep-bounce phase, where under half of a wave's lanes are alive and
-// every bounce drags the code of all three connection states along.  Record = NQ doubles, component-major ([k][slot]):
+// A sample leaves the first-stage kernel as soon as none of its four offset paths is RAY_NOT_CONNECTED any more (round 6; until round 5: as soon as
+// each was RAY_CONNECTED, one bounce later) -- for diffuse and rough scenes after the FIRST bounce.  From there the offsets are four (throughput, pdf)
+// pairs that follow the base path arithmetically (gpt.cpp:622-658,844-888; a RAY_RECENTLY_CONNECTED offset re-evaluates the base vertex's BSDF with the
+// direction from its own last vertex, whose position travels with it), so the rest of the base path runs in k_continue: one small state per lane, two
+// of the three connection states, waves refilled from the queue as lanes finish -- instead of the general kernel's deep-bounce phase, where under half
+// of a wave's lanes are alive and every bounce drags the code of all three connection states along.  Record = NQ doubles, component-major ([k][slot]):
 //   0-2 throughput | 3 pdf | 4 eta | 5-7 v.p | 8-10 rayD | 11-12 v.u, v.v | 13 prim (low 32 bits), depth (high) -- all ones once finished |
-//   14 rng state | 15+4i..18+4i offset i: throughput, pdf | 31 alive mask | 32-61 the sample's 30 sums so far (finished: its final sums)
+//   14 rng state | 15+4i..18+4i offset i: throughput, pdf | 31 alive mask (bits 0-3), RAY_RECENTLY_CONNECTED mask (bits 4-7) |
+//   32-61 the sample's 30 sums so far (finished: its final sums) | 62+3i..64+3i offset i: position of its last own vertex (read while RAY_RECENTLY_CONNECTED)
+// GDPT_HANDOFF_CONNECTED (set by the wavefront development build, whose stages carry RAY_CONNECTED offsets only): the hand-over rule of rounds 2-5.
 constexpr unsigned long long Q_DONE = ~0ULL;
 __device__ __forceinline__ void q_store_main(const FilmD &F, unsigned slot, const Lane &L)
 {
@@ -677,6 +691,11 @@ __device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lan
         const Offset &o = L.off[i];
         qst(&q[(15 + 4 * i) * st], o.throughput.x); qst(&q[(16 + 4 * i) * st], o.throughput.y); qst(&q[(17 + 4 * i) * st], o.throughput.z); qst(&q[(18 + 4 * i) * st], o.pdf);
         alive |= (o.alive ? 1u : 0u) << i;
+#ifndef GDPT_HANDOFF_CONNECTED
+        const bool rc = o.alive && o.status == RAY_RECENTLY_CONNECTED;
+        alive |= (rc ? 16u : 0u) << i;
+        if (rc) { qst(&q[(62 + 3 * i) * st], o.v.p.x); qst(&q[(63 + 3 * i) * st], o.v.p.y); qst(&q[(64 + 3 * i) * st], o.v.p.z); }
+#endif
     }
     qst(&q[31 * st], __longlong_as_double((long long)alive));
 #pragma unroll
@@ -706,6 +725,12 @@ __device__ __forceinline__ void q_load_lane(const FilmD &F, unsigned slot, Lane 
         Offset &o = L.off[i];
         o.throughput = mk(qld(&q[(15 + 4 * i) * st]), qld(&q[(16 + 4 * i) * st]), qld(&q[(17 + 4 * i) * st])); o.pdf = qld(&q[(18 + 4 * i) * st]);
         o.alive = (alive >> i) & 1; o.status = RAY_CONNECTED;
+#ifndef GDPT_HANDOFF_CONNECTED
+        if ((alive >> (4 + i)) & 1) {
+            o.status = RAY_RECENTLY_CONNECTED;
+            o.v.p = mk(qld(&q[(62 + 3 * i) * st]), qld(&q[(63 + 3 * i) * st]), qld(&q[(64 + 3 * i) * st]));
+        }
+#endif
     }
 }
 template <class ACC>
@@ -727,13 +752,23 @@ __device__ __forceinline__ void q_finish(const FilmD &F, unsigned slot, const AC
     for (int k = 0; k < ACC_N; k++) qst(&q[(32 + k) * st], A.get(k));
     qst(&q[13 * st], __longlong_as_double((long long)Q_DONE));
 }
+// the hand-over test: no offset path of the sample is still on its own (RAY_NOT_CONNECTED)
 __device__ __forceinline__ bool all_connected(const Lane &L)
 {
     bool ok = true;
 #pragma unroll
+#ifdef GDPT_HANDOFF_CONNECTED
     for (int i = 0; i < 4; i++) ok = ok && (!L.off[i].alive || L.off[i].status == RAY_CONNECTED);
+#else
+    for (int i = 0; i < 4; i++) ok = ok && (!L.off[i].alive || L.off[i].status != RAY_NOT_CONNECTED);
+#endif
     return ok;
 }
+#ifdef GDPT_HANDOFF_CONNECTED
+constexpr int PH_CONTINUE = PH_CONN;
+#else
+constexpr int PH_CONTINUE = PH_JOINED;
+#endif
 
 // STAGED: the build the staged pipeline launches (gdpt_film_set_pipeline(2)): primary hits come from k_primary and every sample ends in
 // its queue slot, so the primary traversals, finish_path and the exact generic puts (15 inlined copies with atomics) are not in it at all
@@ -789,7 +824,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
         }
         if (active) {
             const InlineTracer tr = {sv, stack};
-            if (!bounce<ENV, SMOOTH, false, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
+            if (!bounce<ENV, SMOOTH, PH_ALL, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
                 active = false;
                 paths++; pathLen += L.depth;
                 // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
@@ -812,6 +847,67 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
     // statistics: wave-level integer reduction, one atomic per wave and counter
     const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
     const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
+    if (lane == 0) {
+        atomicAdd(&F.stats[0], (unsigned long long)c0);
+        atomicAdd(&F.stats[1], (unsigned long long)c1);
+        atomicAdd(&F.stats[2], (unsigned long long)c2);
+        atomicAdd(&F.stats[3], (unsigned long long)c3);
+    }
+}
+
+// The first stage of a sample in a scene WITHOUT glossy vertices (PH_FIRST above; round 6): start_path from k_primary's hits and exactly ONE bounce --
+// five emitter samples, the base path's extension, four reconnections -- then the sample goes to k_continue (its offsets RAY_RECENTLY_CONNECTED or
+// dead) or is over.  Against k_render<STAGED> on such a scene: no second bounce (its temporaries never coexist with the first bounce's state), only
+// the RAY_NOT_CONNECTED code and only the reconnection shift compiled in, and no regeneration logic -- every lane of a wave is at the same point of
+// the same sample index, so the loop over a tile's samples is uniform.  Same work items (tile x sample slice), same slots, same record as k_render.
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_first(SceneD S, ConfigD cfg, FilmD F, int rx0, int ry0, int rx1, int ry1, int tilesX, int tiles, int slices, int stackDepth)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    SceneView sv;
+    int *stack;
+    unsigned char *s_acc;
+    block_setup<LDS_SCENE, ACC_LDS>(S, stackDepth, s_dyn, sv, stack, s_acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int s0 = cfg.sBase + (int)((long long)cfg.sCount * slice / slices), s1 = cfg.sBase + (int)((long long)cfg.sCount * (slice + 1) / slices);
+    const int px = rx0 + tx * 16 + (wave & 1) * 8 + (lane & 7), py = ry0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = px < rx1 && py < ry1;
+    unsigned nClosest = 0, nShadow = 0, paths = 0, pathLen = 0;
+    Acc<ACC_LDS> A;
+    if constexpr (ACC_LDS) A.p = reinterpret_cast<Float *>(s_acc) + threadIdx.x;
+#pragma unroll 1
+    for (int sample = s0; sample < s1; sample++) {
+        if (__hip_atomic_load(F.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;                         // cancelled: no new samples
+        bool handOver = false;
+        const unsigned slot = (unsigned)(sample - cfg.sBase) * F.qPixels + (unsigned)tile * TBLK + threadIdx.x;
+        Lane L;
+        if (valid) {
+            L.nClosest = L.nShadow = 0;
+            bool over = !start_path<ENV, SMOOTH, false, Acc<ACC_LDS>, true>(S, sv, cfg, stack, L, A, px, py, sample, &F, slot);
+            if (!over) {
+                const InlineTracer tr = {sv, stack};
+                over = !bounce<ENV, SMOOTH, PH_FIRST, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A);
+                // an offset that is alive and still on its own: the base path's next segment would have been its last and met no emitter (:901) -- the path
+                // ends at the depth test of the next bounce (:537), before anything else of that bounce is evaluated
+                if (!over && !all_connected(L)) over = true;
+            }
+            nClosest += L.nClosest; nShadow += L.nShadow;
+            if (over) { paths++; pathLen += (unsigned)L.depth; q_finish(F, slot, A); }
+            else { q_store(F, slot, L, A); handOver = true; }
+        }
+        const unsigned long long mask = __ballot(handOver);
+        if (handOver) {
+            const int leader = __ffsll((unsigned long long)mask) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&F.qCount[0], (unsigned)__popcll(mask));
+            base = __shfl(base, leader);
+            F.qList[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = slot;
+        }
+    }
+    const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(nShadow, 0);
+    const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32(paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32(pathLen, 0);
     if (lane == 0) {
         atomicAdd(&F.stats[0], (unsigned long long)c0);
         atomicAdd(&F.stats[1], (unsigned long long)c1);
@@ -894,7 +990,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
         }
         if (__ballot(active) == 0) { if (exhausted) break; continue; }
         const InlineTracer tr = {sv, stack};
-        if (active && !bounce<ENV, SMOOTH, true, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
+        if (active && !bounce<ENV, SMOOTH, PH_CONTINUE, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
             active = false;
             paths++; pathLen += L.depth;
             q_finish(F, slot, A);
@@ -1135,7 +1231,7 @@ __global__ __launch_bounds__(TBLK) void k_eval_point(SceneD S, ConfigD cfg, int 
     Acc<false> A;
     bool active = start_path<true, true, true>(S, sv, cfg, s_stack, L, A, px, py, sample);
     const InlineTracer tr = {sv, s_stack};
-    while (active) active = bounce<true, true, false, false, false>(S, sv, cfg, tr, L, A);
+    while (active) active = bounce<true, true, PH_ALL, false, false>(S, sv, cfg, tr, L, A);
     Float *o = out33;
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_VD + k];
     for (int k = 0; k < 3; k++) *o++ = A.a[ACC_T + k];
