@@ -9,7 +9,7 @@ random numbers are the counter-based streams both the HIP path and the oracle us
                      reference counts in raysTraced + shadowRaysTraced, skdtree.cpp:46-47) / wall time of the step
                      (render + halo exchange + develop + gather + reconstruct), all ranks, max over ranks.
   poisson          = Poisson-CG Mpix-iter/s of the reconstruction inside the same steps (HIP-event span of solveIndirect).
-  roofline         = the TIMED STEP's dominant kernels, the staged render (k_primary + k_render + k_continue + k_fold_cont, 98.8 % of a step):
+  roofline         = the TIMED STEP's dominant kernels, the staged render (k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont, 98.8 % of a step):
                      not an HBM workload (the scene sits in LDS / L2), so its ceiling is VALU issue: wave-instructions of those
                      kernels per step (committed PMC pass of THIS binary, profiles/*_counters.json, keyed by a hash of csrc/) / their launch
                      duration by HIP events, measured live in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles; `traffic` = their FETCH_SIZE x 2
@@ -354,6 +354,89 @@ def bench_gbdpt(a, rank, local, world, dev):
         dist.destroy_process_group()
 
 
+XGMI_LINK_GBS = 64.0     # modelled payload rate of ONE xGMI link in one direction (76.8 GB/s raw per direction, MI355X_MICROARCH.md; ~83 % as payload): what a strip's halo / gather message moves at
+
+
+def strip_study(a):
+    """--strip-study: single-GPU evidence for the N-GPU scaling claim (no 8-GPU node is available to the builder; the driver measures the real curve when one is).
+    For N in {2, 4, 8} every rank's strip of the frame is rendered ALONE on this one device -- the partition parallel.row_strips gives, then the partition
+    parallel.rebalance_strips makes of the measured times, as `bench.py --gpus N` does after its warm-up -- and timed by the film's HIP events.  The step of an
+    N-GPU run is then MODELLED as  max_r(strip render) + halo (pack + unpack measured here, the messages at a stated xGMI rate) + develop of the slowest strip's
+    size (measured) + gather of (N - 1) strips onto rank 0 over N - 1 links at once (modelled: the largest strip's four fp32 images at the stated rate) + the
+    full-frame reconstruction on rank 0 (measured); predicted_speedup[N] = measured 1-GPU step / that.  What the model leaves out: RCCL's per-message set-up
+    (tens of microseconds), the ranks' skew at the barrier, PCIe / host jitter -- all small beside a 100 ms render; what it includes is everything that grows in
+    share as a strip shrinks: sample slices, the refill tail of k_continue on a short queue, the fixed cost of develop / solve."""
+    import torch
+    from gradientdomain_mitsuba_amd import gpt, parallel, scenes
+    import gradientdomain_mitsuba_amd.poisson as P
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    out = {"what": "strip study (bench.py --strip-study): each rank's strip rendered alone on ONE device; N-GPU step modelled from measured parts", "xgmi_link_GBs_modelled": XGMI_LINK_GBS, "configs": {}}
+    for config in a.study_configs:
+        scene_name, w, h, spp_cfg, preset = CONFIGS[config]
+        spp = a.spp if a.spp != SPP else (spp_cfg if config == 2 else min(spp_cfg, 64))
+        desc = scenes.cornell_box(w, h, "diffuse") if scene_name == "cornell" else scenes.atrium(w, h, segments=a.atrium_segments)
+        scene = gpt.Scene(desc, device=0)
+        integ = gpt.GradientPathIntegrator(maxDepth=MAX_DEPTH, reconstructL1=(preset == "L1D"), reconstructL2=(preset != "L1D"))
+        cfg = integ.config(spp)
+
+        def render_strip(y0, y1, reps=2):
+            """-> (best render ms by HIP events, rays, develop ms, halo pack+unpack ms, halo bytes) of rows [y0, y1) rendered into a strip film of their own"""
+            film = gpt.Film(scene, y0, y1)
+            best = 1e30
+            for _ in range(reps):
+                film.clear(); integ.renderBlock(scene, film, cfg, (0, y0, w, y1)); film.sync()
+                best = min(best, film.render_ms())
+            st = film.stats()
+            imgs = torch.empty((4, y1 - y0, w, 3), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i, b in enumerate((1, 2, 3, 4)):
+                film.develop_device(b, imgs[i])
+            film.sync(); torch.cuda.synchronize(); dev_ms = 1e3 * (time.perf_counter() - t0)
+            n = film.halo_bytes() // 8
+            buf = torch.empty(n, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            film.pack_halo(1 if y1 < h else 0, buf); film.sync()
+            film.unpack_halo(1 if y1 < h else 0, buf); film.sync()
+            torch.cuda.synchronize(); halo_ms = 1e3 * (time.perf_counter() - t0)
+            hb = film.halo_bytes()
+            film.close()
+            return best, st["raysTraced"] + st["shadowRaysTraced"], dev_ms, halo_ms, hb
+        # the 1-GPU step: whole frame + reconstruction (what `bench.py` times at N = 1)
+        full_ms, full_rays, full_dev_ms, _, _ = render_strip(0, h)
+        sr = parallel.StripRenderer(scene, integ, 0, 1, dev)
+        sr.render(spp); sr.render(spp)
+        solve_ms = 1e3 * sr.last["solve_s"]
+        t0 = time.perf_counter(); sr.render(spp); torch.cuda.synchronize(); step1_ms = 1e3 * (time.perf_counter() - t0)
+        sr.close()
+        rows = {"workload": "%s %dx%d, %d spp%s, %s" % (scene_name, w, h, spp, "" if spp == spp_cfg else " (configuration: %d; a strip's time is linear in spp above one chunk)" % spp_cfg, preset),
+                "one_gpu": {"render_ms": round(full_ms, 2), "develop_ms": round(full_dev_ms, 3), "solve_ms": round(solve_ms, 3), "step_ms_measured": round(step1_ms, 2), "rays": full_rays}, "N": {}}
+        for N in (2, 4, 8):
+            entry = {}
+            strips = parallel.row_strips(h, N)
+            for label in ("equal_rows", "rebalanced"):
+                res = [render_strip(y0, y1) for (y0, y1) in strips]
+                ms = [r[0] for r in res]
+                rays = sum(r[1] for r in res)
+                slow = max(range(N), key=lambda r: ms[r])
+                halo_msg_ms = 1e3 * res[slow][4] / (XGMI_LINK_GBS * 1e9)                          # both neighbours' messages travel on different links at once
+                gather_ms = 1e3 * max((y1 - y0) for (y0, y1) in strips[1:]) * w * 3 * 4 * 4 / (XGMI_LINK_GBS * 1e9)   # N - 1 senders, one link each, all into rank 0
+                fixed = res[slow][3] + halo_msg_ms + max(r[2] for r in res) + gather_ms + solve_ms
+                step = max(ms) + fixed
+                entry[label] = {"strip_rows": [y1 - y0 for (y0, y1) in strips], "strip_render_ms": [round(v, 2) for v in ms], "max_over_mean": round(max(ms) / (sum(ms) / N), 4),
+                                "sum_of_strips_over_full_frame": round(sum(ms) / full_ms, 4), "rays_sum_equals_frame": rays == full_rays,
+                                "fixed_ms": {"halo_pack_unpack": round(res[slow][3], 3), "halo_messages_modelled": round(halo_msg_ms, 4), "develop": round(max(r[2] for r in res), 3),
+                                             "gather_modelled": round(gather_ms, 3), "solve_on_rank0": round(solve_ms, 3)},
+                                "step_ms_modelled": round(step, 2), "predicted_speedup": round(step1_ms / step, 3), "render_only_speedup": round(full_ms / max(ms), 3)}
+                if label == "equal_rows":
+                    # rank 0 also reconstructs while the others would already render the next frame: its strip is charged with the solve, as StripRenderer.rebalance does
+                    strips = parallel.rebalance_strips(strips, [ms[0] + solve_ms] + ms[1:], min_rows=2)
+            rows["N"][str(N)] = entry
+        out["configs"][str(config)] = rows
+        scene.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,7 +449,12 @@ def main():
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep equal-height strips instead of rebalancing them after the warm-up pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) | gloo (functional runs of the N>1 path on one GPU)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the last step's reconstruction and the four gathered solver images to this .npz (tests)")
+    ap.add_argument("--atrium-segments", type=int, default=48, help="configs 3 / 4: facets per column ring of the atrium (48: 112 908 triangles, the default; 112: 260 364, SURVEY 8d's Sponza size)")
+    ap.add_argument("--strip-study", action="store_true", help="one device: every rank's strip of the frame for N = 2, 4, 8 rendered alone; prints the modelled N-GPU step and predicted speedup (profiles/r06*_strip_study.json)")
+    ap.add_argument("--study-configs", type=int, nargs="+", default=[2, 4], help="--strip-study: the BASELINE configs to study")
     a = ap.parse_args()
+    if a.strip_study:
+        return strip_study(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: launch the N ranks here (one process per GPU, rendezvous on 127.0.0.1), exactly as
         # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` would; rank 0's JSON line is the output.
@@ -404,7 +492,8 @@ def main():
     from gradientdomain_mitsuba_amd import gpt, parallel, scenes
     import gradientdomain_mitsuba_amd.poisson as P
 
-    desc = scenes.cornell_box(W, H, "diffuse") if SCENE == "cornell" else scenes.atrium(W, H)
+    # (--atrium-segments 112: the Sponza-class stand-in at SURVEY 8(d)'s ~262 k triangles -- 260 364 -- instead of the default 48 segments' 112 908)
+    desc = scenes.cornell_box(W, H, "diffuse") if SCENE == "cornell" else scenes.atrium(W, H, segments=a.atrium_segments)
     scene = gpt.Scene(desc, device=local)
     integ = gpt.GradientPathIntegrator(maxDepth=MAX_DEPTH, reconstructL1=(PRESET == "L1D"), reconstructL2=(PRESET != "L1D"))
     prm = P.Params(PRESET, integ.reconstructAlpha)
@@ -483,7 +572,7 @@ def main():
         # --- the render kernel (98.8 % of a step): an issue-slot view, not an HBM one.  Its tables sit in LDS (Cornell) or L2 / Infinity
         # Cache; what limits it is instruction issue under divergence and the latency of its scratch traffic.  Counters per launch come from
         # the committed PMC passes of this binary (null if csrc/ changed since); the launch duration and ray count are this run's.
-        tracer_kernels = ("gdpt_tr::k_primary", "gdpt_tr::k_render", "gdpt_tr::k_continue", "gdpt_tr::k_fold_cont")
+        tracer_kernels = ("gdpt_tr::k_primary", "gdpt_tr::k_first", "gdpt_tr::k_render", "gdpt_tr::k_continue", "gdpt_tr::k_fold_cont")
         res = _kernel_counters(counters, "gdpt_tr::k_resolve")          # once per step: the profile's step count
         per_step = {}
         # (the committed counters are those of the DEFAULT workload, config 2 at its own size and spp: another configuration's step has other
@@ -502,7 +591,7 @@ def main():
                             acc[f] = acc.get(f, 0.0) + n * c[f]
         tracer_issue = {"bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
                         "peak_what": "1024 SIMDs x 2.4 GHz / 4 cycles per fp64 VALU wave-instruction",
-                        "kernels": "k_primary + k_render + k_continue + k_fold_cont (the staged render of one step)", "render_ms_per_step": round(1e3 * launch_s, 3),
+                        "kernels": "k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont (the staged render of one step)", "render_ms_per_step": round(1e3 * launch_s, 3),
                         "counters_file": counters_file if per_step else None}
         if per_step:
             tot = {f: sum(k.get(f, 0.0) for k in per_step.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")}
@@ -567,7 +656,7 @@ def main():
         if tracer_issue.get("frac") is not None:
             roofline = {"bound": "valu-issue", "achieved": tracer_issue["achieved"], "peak": tracer_issue["peak"], "unit": tracer_issue["unit"], "frac": tracer_issue["frac"],
                         "traffic": round(tracer_issue["fabric_traffic_gb_per_step"] * 1e9), "traffic_what": "FETCH_SIZE x 2 + WRITE_SIZE of the step's render kernels, bytes per step (scratch + sample queue; algorithmic film bytes %.2f GB)" % (31 * 8 * 2 * W * H / 1e9),
-                        "kernel": "k_primary + k_render + k_continue + k_fold_cont", "share_of_step": round(launch_s / (wall / a.steps), 4),
+                        "kernel": "k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont", "share_of_step": round(launch_s / (wall / a.steps), 4),
                         "launch_ms_live": round(1e3 * launch_s, 3), "valu_wave_instr_per_step": round(tracer_issue["achieved"] * 1e9 * launch_s),
                         "lane_utilisation": tracer_issue.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": tracer_issue.get("wait_any_frac_of_wave_cycles"),
                         "valu_busy": tracer_issue.get("valu_busy"), "valu_busy_what": tracer_issue.get("valu_busy_what"), "effective_clock_ghz_profiled": tracer_issue.get("effective_clock_ghz_profiled"),
@@ -576,7 +665,7 @@ def main():
                         "what": "the timed step's render kernels: VALU wave-instructions per step (committed PMC pass of this binary) / their launch duration by HIP events in THIS run, against 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction; MFMA is not used (no dense contraction) and the scene is not HBM-resident, so neither the hbm nor the mfma ceiling applies to them"}
         else:
             roofline = dict(tracer_bytes)
-            roofline["kernel"] = "k_primary + k_render + k_continue + k_fold_cont (traversal part)"
+            roofline["kernel"] = "k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont (traversal part)"
             roofline["counters_file"] = None
             roofline["note"] = "no committed PMC pass matches this binary / configuration: the live byte figure of SURVEY 8d-B stands in for the issue-slot view"
         out = {

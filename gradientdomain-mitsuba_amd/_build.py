@@ -31,7 +31,7 @@ if WITH_WAVEFRONT:
 SOURCES = [os.path.join(CSRC, f) for f in UNITS]
 # -ffp-contract=off: the per-element arithmetic contract of csrc/poisson_kernels.hip.h (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", os.environ.get("GDPT_OPT", "-O3"), "-std=c++17", "-ffp-contract=off", "-fPIC",
-         "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")] + (["-DGDPT_WITH_WAVEFRONT"] if WITH_WAVEFRONT else [])
+         "-fvisibility=hidden", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")] + (["-DGDPT_WITH_WAVEFRONT", "-DGDPT_HANDOFF_CONNECTED"] if WITH_WAVEFRONT else [])      # (the wavefront stages carry RAY_CONNECTED offsets only: the hand-over rule of rounds 2-5)
 
 
 STAMP = LIB + ".flags"          # the flags the library was built with: a development build (GDPT_EXTRA_FLAGS) never passes for the product

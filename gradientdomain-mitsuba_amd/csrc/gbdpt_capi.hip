@@ -76,7 +76,8 @@ __device__ void film_put(Float *buf, int stride, int W, int H, Float px, Float p
 // Same arithmetic per connection as the one-lane form (process_sample, kept as the probe); the sums of a sample are added in arrival order
 // instead of (s, t) order: rounding of the last bits only.
 constexpr int BD_ITEMS_PER_SAMPLE = 2 * BD_MAX_DEPTH + (BD_MAX_DEPTH - 1) * BD_MAX_DEPTH / 2 + 2;   // >= the sum over s of the t-range at maxDepth d (pair_range): 2 d + (d - 1) d / 2 (90 at 12, 230 at 20)
-constexpr unsigned BD_CHUNK = 1u << 21;            // most samples per chunk: 23 GB of records, 7.2 GB of item lists (nine lists of 96 x 4 B per sample), 0.25 GB of sums
+constexpr unsigned BD_CHUNK = 1u << 21;            // most samples per chunk (sizeof(Sample) + nine item lists of BD_ITEMS_PER_SAMPLE x 4 B + the sums per sample: the launcher shrinks the
+                                                   // chunk to what the device has free -- at BD_MAX_DEPTH 20 a sample costs 1.6x the record and 2.4x the lists it did at 12)
 
 // The two subpaths of every sample (Path::alternatingRandomWalkFromPixel, path.cpp:548-631) with PERSISTENT lanes: the subpaths of a sample have between
 // 3 and 25 vertices (Russian roulette), and with one sample per lane a wave took as long as its longest pair (40 % lane utilisation).  Here a
@@ -577,6 +578,7 @@ int check_scope(const gdpt_scene *s, const gdpt_gbdpt_config *cfg)
     if (cfg->rrDepth <= 0) return bfail(GDPT_ERR_INVALID, "'rrDepth' must be set to a value greater than zero!");                                           // gbdpt.cpp:99-100
     if (cfg->maxDepth > BD_MAX_DEPTH) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d (a sample's record holds both subpaths; -1 renders as 12, gbdpt_proc.cpp:103-106)", BD_MAX_DEPTH);
     if (cfg->spp <= 0) return bfail(GDPT_ERR_INVALID, "G-BDPT: spp must be positive");
+    if (s->cropped) return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: a film with a crop window is not carried (the sensor's importance and the light image take crop == film)");
     if (s->d.cam.thinlens && (cfg->maxDepth < 0 ? BD_DEFAULT_DEPTH : cfg->maxDepth) > BD_MAX_DEPTH - 1)   // (the extra emitter step of a non-degenerate sensor, gbdpt_proc.cpp:117-118, needs one more record)
         return bfail(GDPT_ERR_UNSUPPORTED, "G-BDPT: maxDepth up to %d with the thinlens sensor", BD_MAX_DEPTH - 1);
     // (round 4: Dirac BSDFs and rough conductors below shiftThreshold are carried -- samples that meet one run the general form, gbdpt_general.hip.h)

@@ -94,7 +94,7 @@ constexpr int GL_POOL = GV_REGION + 4;             // transient records of ONE l
 struct GSamp {
     BV v[GV_POOL]; BE e[GE_POOL];
     int nv, ne;
-    int nvBase, neBase;                            // records in use after the base stage (both subpaths + the clones of createShiftablePath): offset path k takes [nvBase + 28 k, + 28)
+    int nvBase, neBase;                            // records in use after the base stage (both subpaths + the clones of createShiftablePath): offset path k takes [nvBase + GV_REGION k, + GV_REGION) (44 records at BD_MAX_DEPTH 20)
     int voidSample;                                // a pool ran out while the sample's paths were built: its connections are skipped (counted; asserted zero by tests and bench)
     GPath emitter, sensor[5], connect;
     MuRec mu[5];
@@ -166,13 +166,15 @@ struct GTrT {
     __device__ int allocV()
     {
         if (HAS_X && localAlloc) { if (X->nlv >= GL_POOL) { overflow++; return GV_POOL + GL_POOL - 1; } bv_clear(X->lv[X->nlv]); return GV_POOL + X->nlv++; }
-        if (regV >= 0) { if (regV >= regV1 || regV >= GV_POOL) { overflow++; return GV_POOL - 1; } bv_clear(W.v[regV]); return regV++; }
+        // (an overflowing region hands out the last slot of the lane's OWN region again -- the sample is void from here on, but another lane may be building its
+        //  offset path in the next region at this moment and must not see a vertex clobbered under it)
+        if (regV >= 0) { if (regV >= regV1 || regV >= GV_POOL) { overflow++; return regV1 - 1 < GV_POOL ? regV1 - 1 : GV_POOL - 1; } bv_clear(W.v[regV]); return regV++; }
         if (W.nv >= GV_POOL) { overflow++; return GV_POOL - 1; } bv_clear(W.v[W.nv]); return W.nv++;
     }
     __device__ int allocE()
     {
         if (HAS_X && localAlloc) { if (X->nle >= GL_POOL) { overflow++; return GE_POOL + GL_POOL - 1; } be_clear(X->le[X->nle]); return GE_POOL + X->nle++; }
-        if (regV >= 0) { if (regE >= regE1 || regE >= GE_POOL) { overflow++; return GE_POOL - 1; } be_clear(W.e[regE]); return regE++; }
+        if (regV >= 0) { if (regE >= regE1 || regE >= GE_POOL) { overflow++; return regE1 - 1 < GE_POOL ? regE1 - 1 : GE_POOL - 1; } be_clear(W.e[regE]); return regE++; }
         if (W.ne >= GE_POOL) { overflow++; return GE_POOL - 1; } be_clear(W.e[W.ne]); return W.ne++;
     }
     __device__ __forceinline__ BV &PV(int i) { if (!HAS_X) return W.v[i]; return i < GV_POOL ? W.v[i] : X->lv[i - GV_POOL]; }

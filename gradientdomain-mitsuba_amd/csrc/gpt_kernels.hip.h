@@ -158,6 +158,7 @@ struct CameraD {
     int width, height;
     int thinlens, needsTime;// needsTime: shutterClose > shutterOpen -- a sample draws its time sample (Sensor::needsTimeSample, sensor.h:290).  thinlens 1: `thinlens` sensor (thinlens.cpp): rays start on the aperture and pass through the focus point of their pixel
     Float apertureRadius, focusDistance;
+    Float cropX, cropY;     // crop window of the film: image pixel (x, y) = pixel (x + cropX, y + cropY) of the full film, whose size invW / invH / aspect are taken from
 };
 struct SceneD {
     const BvhNode *nodes;
@@ -1090,12 +1091,13 @@ __device__ __forceinline__ Float pdf_emitter_direct(const SceneD &S, const Scene
     return pd * (1.0 * S.emitterNormalization);
 }
 
-// ---- sensor: perspective.cpp:271-298 with the composite of :150-156 written out for crop == film ----------------
+// ---- sensor: perspective.cpp:271-298 with the composite of :150-156 written out (the crop window: sample position in the full film's [0, 1]^2 =
+// (crop-relative position + crop offset) / full size, which is what steps 4+5 of m_cameraToSample undo) ----------------
 // apx, apy: the aperture sample (gpt.cpp:1262-1264), read by the thinlens sensor only (thinlens.cpp:324-361: a point of the aperture disk,
 // squareToUniformDiskConcentric * apertureRadius; the ray goes from there through the pixel's point on the focal plane)
 __device__ __forceinline__ void camera_ray(const CameraD &c, Float px, Float py, Float apx, Float apy, d3 &o, d3 &d, Float &mint, Float &maxt)
 {
-    const Float sxn = px * c.invW, syn = py * c.invH;
+    const Float sxn = (px + c.cropX) * c.invW, syn = (py + c.cropY) * c.invH;
     const d3 nearP = mk((1 - 2 * sxn) * c.nearClip * c.tanHalf, (1 - 2 * syn) / c.aspect * c.nearClip * c.tanHalf, c.nearClip);
     d3 dl, ol = mk(0.0);
     if (c.thinlens) {
@@ -1404,29 +1406,21 @@ __device__ GDPT_COLD_CALL Float envmap_pdf_direction(const EnvMapD &e, d3 d)
 // the two differential directions of the camera ray through film position (sxp, syp): trafo(normalize(nearP + m_dx / m_dy)), perspective.cpp:291-295
 __device__ __forceinline__ void camera_differentials(const CameraD &c, Float sxp, Float syp, d3 &rxD, d3 &ryD)
 {
-    const Float sxn = sxp * c.invW, syn = syp * c.invH;
+    const Float sxn = (sxp + c.cropX) * c.invW, syn = (syp + c.cropY) * c.invH;
     const d3 nearP = mk((1 - 2 * sxn) * c.nearClip * c.tanHalf, (1 - 2 * syn) / c.aspect * c.nearClip * c.tanHalf, c.nearClip);
     const d3 mdx = mk(-2 * c.invW * c.nearClip * c.tanHalf, 0.0, 0.0), mdy = mk(0.0, -2 * c.invH / c.aspect * c.nearClip * c.tanHalf, 0.0);
     const d3 lx = normalize(nearP + mdx), ly = normalize(nearP + mdy);
     rxD = mk(c.m[0] * lx.x + c.m[1] * lx.y + c.m[2] * lx.z, c.m[4] * lx.x + c.m[5] * lx.y + c.m[6] * lx.z, c.m[8] * lx.x + c.m[9] * lx.y + c.m[10] * lx.z);
     ryD = mk(c.m[0] * ly.x + c.m[1] * ly.y + c.m[2] * ly.z, c.m[4] * ly.x + c.m[5] * ly.y + c.m[6] * ly.z, c.m[8] * ly.x + c.m[9] * ly.y + c.m[10] * ly.z);
 }
-// The hit of a CAMERA ray on a textured material: Intersection::getBSDF(ray) runs computePartials first (shape.h; intersection.cpp:5-78:
-// the texture coordinates' change per pixel step, from the two differential rays of perspective.cpp:291-295 and the triangle's dpdu /
-// dpdv), and the lookup is the filtered one.  (sxp, syp) = the film position of this path's camera ray.  A real call like tex_eval.
-template <bool INL>
-__device__ __forceinline__ d3 tex_eval_primary_impl(const SceneView &S, const CameraD &c, const TexD &t, const Vertex &v, d3 geoN, Float tu, Float tv, Float sxp, Float syp)
+// its.dpdu / its.dpdv of a hit on triangle `prim`: the edges, or the UV tangents of a mesh with texture coordinates (skdtree.h:373-380, trimesh.cpp:701-735)
+__device__ __forceinline__ void tri_partials(const SceneView &S, int prim, d3 &dpdu, d3 &dpdv)
 {
-    // differential directions (origins = the camera position)
-    d3 rxD, ryD;
-    camera_differentials(c, sxp, syp, rxD, ryD);
-    const d3 o = mk(c.m[3], c.m[7], c.m[11]);
-    // its.dpdu / its.dpdv: the edges, or the UV tangents of a mesh with texture coordinates (skdtree.h:373-380, trimesh.cpp:701-735)
-    const TriShade &ts = S.shade[v.prim];
+    const TriShade &ts = S.shade[prim];
     const d3 dP1 = ts.p1 - ts.p0, dP2 = ts.p2 - ts.p0;
-    d3 dpdu = dP1, dpdv = dP2;
-    if (S.uv && S.hasUV[v.prim]) {
-        const TriUV q = S.uv[v.prim];
+    dpdu = dP1; dpdv = dP2;
+    if (S.uv && S.hasUV[prim]) {
+        const TriUV q = S.uv[prim];
         const Float dU1x = q.uv[2] - q.uv[0], dU1y = q.uv[3] - q.uv[1], dU2x = q.uv[4] - q.uv[0], dU2y = q.uv[5] - q.uv[1];
         const d3 n = cross(dP1, dP2);
         const Float nlen = len(n), determinant = dU1x * dU2y - dU1y * dU2x;
@@ -1443,6 +1437,19 @@ __device__ __forceinline__ d3 tex_eval_primary_impl(const SceneView &S, const Ca
             }
         }
     }
+}
+// The hit of a CAMERA ray on a textured material: Intersection::getBSDF(ray) runs computePartials first (shape.h; intersection.cpp:5-78:
+// the texture coordinates' change per pixel step, from the two differential rays of perspective.cpp:291-295 and the triangle's dpdu /
+// dpdv), and the lookup is the filtered one.  (sxp, syp) = the film position of this path's camera ray.  A real call like tex_eval.
+template <bool INL>
+__device__ __forceinline__ d3 tex_eval_primary_impl(const SceneView &S, const CameraD &c, const TexD &t, const Vertex &v, d3 geoN, Float tu, Float tv, Float sxp, Float syp)
+{
+    // differential directions (origins = the camera position)
+    d3 rxD, ryD;
+    camera_differentials(c, sxp, syp, rxD, ryD);
+    const d3 o = mk(c.m[3], c.m[7], c.m[11]);
+    d3 dpdu, dpdv;
+    tri_partials(S, v.prim, dpdu, dpdv);
     Float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
     const Float pp = dot(geoN, v.p), po = dot(geoN, o), prx = dot(geoN, rxD), pry = dot(geoN, ryD);
     if (!(is_zero(dpdu) && is_zero(dpdv)) && !(prx == 0 || pry == 0)) {

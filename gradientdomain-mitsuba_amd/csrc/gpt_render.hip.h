@@ -1196,6 +1196,42 @@ __global__ __launch_bounds__(TBLK) void k_intersect(SceneD S, int n, const Float
     tp[4 * i + 1] = h.prim < 0 ? 0.0 : v.p.x; tp[4 * i + 2] = h.prim < 0 ? 0.0 : v.p.y; tp[4 * i + 3] = h.prim < 0 ? 0.0 : v.p.z;
 }
 
+// probe: the filled intersection record of arbitrary rays (fillIntersectionRecord<true>, skdtree.h:343-428) as the render kernels form it -- position by
+// fill_vertex, frames by shading_at, texture coordinates as reflectance_at interpolates them, dpdu / dpdv by tri_partials.  What the reference's own
+// src/tests/test_dgeom.cpp:35-178 asserts on.  rec24 per ray: t, p(3), uv(2), geoFrame.n(3), shFrame.n(3), shFrame.s(3), dpdu(3), dpdv(3), wi(3).
+__global__ __launch_bounds__(TBLK) void k_intersect_record(SceneD S, int n, const Float *__restrict__ od, int *__restrict__ prim, Float *__restrict__ rec24)
+{
+    __shared__ int s_stack[STACK_DEPTH * TBLK];
+    SceneView sv;
+    sv.nodes = S.nodes; sv.isect = S.isect; sv.shade = S.shade; sv.mats = S.mats; sv.emitters = S.emitters; sv.emTris = S.emTris; sv.emCdf = S.emCdf; sv.emitterCdf = S.emitterCdf; sv.rootRef = S.rootRef; sv.boundM = S.boundM; sv.quant = S.quantNodes; sv.leafExit = 1; sv.vn = S.vn; sv.uv = S.uv; sv.hasUV = S.hasUV; sv.tex = S.tex;
+    const int i = blockIdx.x * TBLK + threadIdx.x;
+    if (i >= n) return;
+    const d3 o = mk(od[6 * i], od[6 * i + 1], od[6 * i + 2]), d = mk(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5]);
+    Hit h;
+    trace<false>(sv, s_stack + threadIdx.x, o, d, ray_mint_closest(o, GD_EPSILON), GD_INF, h);
+    Float *r = rec24 + (size_t)24 * i;
+    prim[i] = h.prim < 0 ? -1 : sv.shade[h.prim].origIndex;
+    for (int k = 0; k < 24; k++) r[k] = 0.0;
+    r[0] = h.t;
+    if (h.prim < 0) return;
+    Vertex v;
+    fill_vertex(sv, h, d, v);
+    const Shading sh = shading_at<true>(sv, v);
+    Float tu = v.u, tv = v.v;                                                    // its.uv, skdtree.h:398-405 (as reflectance_at)
+    if (sv.uv && sv.hasUV[v.prim]) {
+        const TriUV t = sv.uv[v.prim];
+        const Float b0 = 1 - v.u - v.v;
+        tu = t.uv[0] * b0 + t.uv[2] * v.u + t.uv[4] * v.v;
+        tv = t.uv[1] * b0 + t.uv[3] * v.u + t.uv[5] * v.v;
+    }
+    d3 dpdu, dpdv;
+    tri_partials(sv, v.prim, dpdu, dpdv);
+    const d3 wi = toLocal(sh.fr, -d);
+    r[1] = v.p.x; r[2] = v.p.y; r[3] = v.p.z; r[4] = tu; r[5] = tv;
+    const d3 out[6] = {sh.geoN, sh.fr.n, sh.fr.s, dpdu, dpdv, wi};
+    for (int k = 0; k < 6; k++) { r[6 + 3 * k] = out[k].x; r[7 + 3 * k] = out[k].y; r[8 + 3 * k] = out[k].z; }
+}
+
 // probe: traversal statistics -- inner nodes fetched and triangles tested, closest-hit and any-hit, summed over n rays (od: origin,
 // direction; maxt = infinity).  sums[0..3] = nodes (closest), tris (closest), nodes (any), tris (any).
 __global__ __launch_bounds__(TBLK) void k_trace_stats(SceneD S, int n, const Float *__restrict__ od, unsigned long long *__restrict__ sums)

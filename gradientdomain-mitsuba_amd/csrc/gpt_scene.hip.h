@@ -15,5 +15,6 @@ struct gdpt_scene {
     bool perVertex = false;         // vertex normals or bitmap textures: the builds that keep a hit's barycentrics
     size_t ldsSceneBytes = 0;
     double bsphereRadius = 0.0;     // Scene::getBSphere().radius after Scene::initializeBidirectional (kd-tree bounds + sensor + emitters, scene.cpp:386-413)
+    bool cropped = false;       // the camera's film has a crop window (gdpt_camera::fullWidth > 0): the G-BDPT entry points refuse it
     std::vector<gdpt_tr::MaterialD> hostMats;   // the material table as uploaded (G-BDPT checks its scope against it)
 };

@@ -764,12 +764,12 @@ struct GbdptRecon {
     unsigned long long stamp = 0;
     int users = 0;                                               // frames in flight on this entry (under g_reconMutex): an entry in use is never evicted
     std::mutex work;                                             // one frame at a time PER ENTRY: hosts that drive several GPUs from several threads solve side by side
-    void drop()
-    {
+    void freeBuffers()                                           // the solvers and images only: the (device, size) key stays, so that frames queued on `work` rebuild into an
+    {                                                            // entry that lookups still match and that eviction still destroys on its own device
         for (auto &p : sv) { if (p) gdpt_poisson_destroy(p); p = nullptr; }
         for (auto &f : in) { if (f) hipFree(f); f = nullptr; }
-        width = height = 0; device = -1;
     }
+    void drop() { freeBuffers(); width = height = 0; device = -1; }   // (an entry that is being erased)
 };
 std::mutex g_reconMutex;                                         // guards the list, not the solves
 std::list<GbdptRecon> g_recon;
@@ -829,7 +829,7 @@ static int gbdpt_reconstruct_core(double *const dev[5], int width, int height, f
             if (!rc && outOnDevice) rc = gdpt_poisson_sync(sv);
             if (!rc && seconds2) seconds2[k] = gdpt_poisson_last_solve_seconds(sv);
         }
-        if (rc) R->drop();                                       // a failed frame leaves nothing half-built behind (the empty entry goes when nobody uses it)
+        if (rc) R->freeBuffers();                                // a failed frame leaves nothing half-built behind (the emptied entry keeps its key; it goes when nobody uses it)
     }
     std::lock_guard<std::mutex> lock(g_reconMutex);
     R->users--;
@@ -845,6 +845,18 @@ int gdpt_gbdpt_reconstruct_release(void)
     const bool have = hipGetDevice(&back) == hipSuccess;
     for (auto it = g_recon.begin(); it != g_recon.end();)      // (an entry with a frame in flight on another thread stays)
         if (it->users == 0) { if (it->device >= 0) (void)hipSetDevice(it->device); it->drop(); it = g_recon.erase(it); } else ++it;
+    if (have) (void)hipSetDevice(back);
+    return GDPT_OK;
+}
+
+int gdpt_gbdpt_reconstruct_release_size(int device, int width, int height)
+{
+    std::lock_guard<std::mutex> lock(g_reconMutex);
+    int back = 0;
+    const bool have = hipGetDevice(&back) == hipSuccess;
+    if (device < 0) device = back;
+    for (auto it = g_recon.begin(); it != g_recon.end();)
+        if (it->users == 0 && it->device == device && it->width == width && it->height == height) { (void)hipSetDevice(it->device); it->drop(); it = g_recon.erase(it); } else ++it;
     if (have) (void)hipSetDevice(back);
     return GDPT_OK;
 }

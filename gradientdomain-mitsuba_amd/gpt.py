@@ -40,7 +40,8 @@ class Environment(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
                 ("width", C.c_int), ("height", C.c_int), ("type", C.c_int), ("apertureRadius", C.c_double), ("focusDistance", C.c_double),
-                ("shutterOpen", C.c_double), ("shutterClose", C.c_double)]
+                ("shutterOpen", C.c_double), ("shutterClose", C.c_double),
+                ("cropOffsetX", C.c_int), ("cropOffsetY", C.c_int), ("fullWidth", C.c_int), ("fullHeight", C.c_int)]
 
 
 class Config(C.Structure):
@@ -101,6 +102,8 @@ class Scene:
             cam.type, cam.apertureRadius, cam.focusDistance = 1, float(desc.thinlens[0]), float(desc.thinlens[1])
         if getattr(desc, "shutter", None):                  # (shutterOpen, shutterClose) of the sensor: an interval of positive length draws a time sample
             cam.shutterOpen, cam.shutterClose = float(desc.shutter[0]), float(desc.shutter[1])
+        if getattr(desc, "crop", None):                     # (cropOffsetX, cropOffsetY, fullWidth, fullHeight): width x height is the crop window of that film
+            cam.cropOffsetX, cam.cropOffsetY, cam.fullWidth, cam.fullHeight = (int(v) for v in desc.crop)
         self._h = C.c_void_p()
         envd = getattr(desc, "environment", None)
         env = None
@@ -151,6 +154,18 @@ class Scene:
         tp = np.empty((n, 4), np.float64)
         check(lib().gdpt_scene_intersect(self._h, n, od.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p), tp.ctypes.data_as(C.c_void_p)))
         return prim, tp[:, 0], tp[:, 1:4]
+
+    def intersect_record(self, origins, dirs):
+        """The filled intersection record of each ray's closest hit as the render kernels form it (fillIntersectionRecord<true>, skdtree.h:343-428):
+        (prim, dict of arrays [n, .]: t, p, uv, geoFrame.n, shFrame.n, shFrame.s, dpdu, dpdv, wi)."""
+        od = np.ascontiguousarray(np.concatenate([np.asarray(origins, np.float64), np.asarray(dirs, np.float64)], axis=1))
+        n = od.shape[0]
+        prim = np.empty(n, np.int32)
+        rec = np.empty((n, 24), np.float64)
+        lib().gdpt_scene_intersect_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(lib().gdpt_scene_intersect_record(self._h, n, od.ctypes.data_as(C.c_void_p), prim.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p)))
+        return prim, {"t": rec[:, 0], "p": rec[:, 1:4], "uv": rec[:, 4:6], "geoFrame.n": rec[:, 6:9], "shFrame.n": rec[:, 9:12], "shFrame.s": rec[:, 12:15],
+                      "dpdu": rec[:, 15:18], "dpdv": rec[:, 18:21], "wi": rec[:, 21:24]}
 
     def bsphere_radius(self):
         """Scene::getBSphere().radius after Scene::initializeBidirectional (scene.cpp:386-413): kd-tree bounds + sensor + emitters."""

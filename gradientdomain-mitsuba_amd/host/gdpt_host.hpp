@@ -220,8 +220,8 @@ class MultiFilm {
 public:
     explicit MultiFilm(const Properties &props)
     {
-        m_width = props.getInteger("width", 768);                                                   // film.cpp defaults
-        m_height = props.getInteger("height", 576);
+        m_width = props.getInteger("cropWidth", props.getInteger("width", 768));                    // film.cpp defaults; the buffers hold the crop window (film.cpp:40-43)
+        m_height = props.getInteger("cropHeight", props.getInteger("height", 576));
         m_fileFormat = props.getString("fileFormat", "openexr");                                    // multifilm.cpp:104
         m_componentFormat = props.getString("componentFormat", "float16");                          // multifilm.cpp:116-117
         m_attachLog = props.getBoolean("attachLog", true);                                           // multifilm.cpp:108
@@ -573,7 +573,7 @@ public:
             logError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
     }
 
-    ~GBDPTIntegrator() { gdpt_gbdpt_reconstruct_release(); }     // (the library keeps a frame size's solvers between render() calls of this integrator)
+    ~GBDPTIntegrator() { if (m_lastW > 0) gdpt_gbdpt_reconstruct_release_size(-1, m_lastW, m_lastH); }     // (the library keeps a frame size's solvers between render() calls: this integrator's own size goes back, nobody else's)
     const Statistics &getStatistics() const { return m_stats; }
 
     /// render (gbdpt.cpp:140-262)
@@ -585,6 +585,8 @@ public:
         if (sd.rfilter.getPluginName() != "box" && !sd.rfilter.getPluginName().empty())
             logError("G-BDPT supports no pixel filter beside the box filter (gbdpt.cpp:70-71)");
         const int W = film.getWidth(), H = film.getHeight();
+        if (m_lastW > 0 && (m_lastW != W || m_lastH != H)) gdpt_gbdpt_reconstruct_release_size(-1, m_lastW, m_lastH);
+        m_lastW = W; m_lastH = H;
         gdpt_scene *scene = nullptr;
         gdpt_gbdpt_film *gf = nullptr;
         GradientPathIntegrator::createScene(sd, -1, &scene);
@@ -615,6 +617,7 @@ public:
 private:
     Statistics m_stats;
     int m_maxDepth, m_rrDepth;
+    int m_lastW = 0, m_lastH = 0;
     bool m_lightImage, m_reconstructL1, m_reconstructL2;
     double m_shiftThreshold, m_reconstructAlpha;
 };

@@ -82,7 +82,7 @@ public:
 		check(gdpt_gbdpt_reconstruct(dev[0].data(), dev[1].data(), dev[2].data(), dev[3].data(), dev[4].data(), W, H, (float) m_reconstructAlpha, -1, recL2.data(), recL1.data()));
 		gdpt_gbdpt_film_destroy(gf);
 		gdpt_scene_destroy(gs);
-		gdpt_gbdpt_reconstruct_release();       /* the library keeps the solvers of a frame size between calls: a render job is one frame, hand them back */
+		gdpt_gbdpt_reconstruct_release_size(-1, W, H);       /* the library keeps the solvers of a frame size between calls: a render job is one frame, hand THIS size back */
 
 		/* setBitmapMulti as gbdpt.cpp:222-247: slots 0 and 5 the reconstructions, 1..4 the gradients, 6 the primal */
 		for (int b = 0; b < 7; ++b) {

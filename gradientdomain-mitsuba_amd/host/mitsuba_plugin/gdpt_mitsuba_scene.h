@@ -240,7 +240,15 @@ inline void flatten(const Scene *scene, const Sensor *sensor, const Vector2i &si
 	const Matrix4x4 &M = pc->getWorldTransform()->eval(0).getMatrix();
 	for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) fs.cam.toWorld[4 * r + c] = M(r, c);
 	fs.cam.fovX = pc->getXFov(); fs.cam.nearClip = pc->getNearClip(); fs.cam.farClip = pc->getFarClip();
-	fs.cam.width = size.x; fs.cam.height = size.y;
+	fs.cam.width = size.x; fs.cam.height = size.y;                                        /* `size` = the film's crop size: what is rendered */
+	{	/* the crop window (perspective.cpp:126-163): the C-ABI takes the rays from the full film's raster */
+		const Film *film = sensor->getFilm();
+		const Vector2i full = film->getSize();
+		const Point2i off = film->getCropOffset();
+		if (full.x != size.x || full.y != size.y || off.x != 0 || off.y != 0) {
+			fs.cam.cropOffsetX = off.x; fs.cam.cropOffsetY = off.y; fs.cam.fullWidth = full.x; fs.cam.fullHeight = full.y;
+		}
+	}
 	fs.cam.shutterOpen = sensor->getShutterOpen();                                         /* sensor.h:275-281; an interval of positive length <=> needsTimeSample() */
 	fs.cam.shutterClose = sensor->getShutterOpen() + sensor->getShutterOpenTime();
 	if (scls == "ThinLens") {                                                              /* thinlens.cpp:236-244: both are plain properties */

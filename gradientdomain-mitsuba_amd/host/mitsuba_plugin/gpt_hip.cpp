@@ -157,9 +157,7 @@ public:
 		}
 		const Vector2i size = film->getCropSize();
 		const int W = size.x, H = size.y;
-		/* the C-ABI's camera has crop == film (include/gdpt_tracer.h, gdpt_camera): a crop window would move every pixel's ray */
-		if (film->getSize().x != W || film->getSize().y != H || film->getCropOffset().x != 0 || film->getCropOffset().y != 0)
-			Log(EError, "gpt_hip: a film with a crop window is not carried (crop %ix%i at (%i, %i) of %ix%i)", W, H, film->getCropOffset().x, film->getCropOffset().y, film->getSize().x, film->getSize().y);
+		/* (a crop window: flatten() hands the film's size and crop offset to the C-ABI's camera, include/gdpt_tracer.h gdpt_camera; W x H is the crop) */
 
 		gdpt_plugin::FlatScene fs;
 		gdpt_plugin::flatten(scene, sensor.get(), size, fs);

@@ -389,8 +389,13 @@ private:
         sd.camera.fovX = fov;
         sd.camera.nearClip = p.getFloat("nearClip", 1e-2);
         sd.camera.farClip = p.getFloat("farClip", 1e4);
-        sd.camera.width = W;
-        sd.camera.height = H;
+        // the film's crop window (film.cpp:34-48): the image that is rendered and written is the crop; the sensor's rays come from the full film's raster
+        const int cropX = sd.film.getInteger("cropOffsetX", 0), cropY = sd.film.getInteger("cropOffsetY", 0);
+        const int cropW = sd.film.getInteger("cropWidth", W), cropH = sd.film.getInteger("cropHeight", H);
+        if (cropX < 0 || cropY < 0 || cropW <= 0 || cropH <= 0 || cropX + cropW > W || cropY + cropH > H) logError("Invalid crop window specification!");   // film.cpp:44-48
+        sd.camera.width = cropW;
+        sd.camera.height = cropH;
+        if (cropX != 0 || cropY != 0 || cropW != W || cropH != H) { sd.camera.cropOffsetX = cropX; sd.camera.cropOffsetY = cropY; sd.camera.fullWidth = W; sd.camera.fullHeight = H; }
         sd.camera.shutterOpen = p.getFloat("shutterOpen", 0.0);            // Sensor::Sensor, sensor.cpp:28-30
         sd.camera.shutterClose = p.getFloat("shutterClose", 0.0);
         if (sd.camera.shutterClose < sd.camera.shutterOpen) logError("Shutter opening time must be less than or equal to the shutter closing time!");   // sensor.cpp:33-35

@@ -9,6 +9,7 @@ rows; the only coupling is the one-pixel halo: a strip needs the per-pixel sampl
 fp32 images (44 MB at 1280x720; the CG at this size is latency-bound and does not profit from splitting -- DESIGN.md).
 `StripRenderer` below is the entry point: one frame = render strip, settle borders, develop, gather, reconstruct on rank 0.
 """
+import os
 import time
 
 import torch
@@ -162,10 +163,17 @@ class StripRenderer:
         self.preset = "L1D" if getattr(integ, "reconstructL1", False) else ("L2D" if getattr(integ, "reconstructL2", False) else None)
         self.solver = solver_factory(self.preset, integ.reconstructAlpha) if (rank == 0 and self.preset) else None
         self.film = None
-        # the gather has a communicator of its own: rank 0 posts its receives BEFORE it renders (they complete while it is still busy with its own strip
-        # instead of being set up after it), which on the halo's communicator would collide with the halo messages (gather_post)
-        self.gather_group = dist.new_group(ranks=list(range(world))) if (world > 1 and dist.is_initialized() and group is None) else group
-        self.early_gather = world > 1 and self.gather_group is not group          # (a caller's own group: no second communicator, the receives are posted after the halo exchange)
+        # The gather's receives: by default rank 0 posts them AFTER the halo exchange, on the halo's own communicator (between one pair of ranks RCCL matches
+        # point-to-point messages in posting order, so nothing can be mistaken; one communicator, nothing pending while a strip renders).
+        # GDPT_EARLY_GATHER=1 (opt-in, round 5's form): a second communicator on which rank 0 posts them BEFORE it renders, so that they complete while it is
+        # still busy with its own strip.  Not the default since round 6: two communicators in concurrent use from one process are not deadlock-safe by
+        # RCCL's own documentation (rank 0's pending receive kernel can occupy the device while the halo exchange needs its own to run), the pending receive
+        # lives for a whole render -- longer than the process group's watchdog timeout for a long frame unless that is raised -- and it has only ever run
+        # over gloo on one device (tests/test_parallel_cpu.py, tests/test_bench_gpu.py): unverified on real multi-GPU RCCL.  Measured worth on one
+        # device over gloo: ~1 ms of a 4K frame's gather set-up.
+        want_early = os.environ.get("GDPT_EARLY_GATHER", "0") == "1"
+        self.gather_group = dist.new_group(ranks=list(range(world))) if (want_early and world > 1 and dist.is_initialized() and group is None) else group
+        self.early_gather = world > 1 and want_early and self.gather_group is not group   # (a caller's own group: no second communicator)
         self.set_strips(strips or row_strips(self.height, world))
         self.last = {}
         self._open_links()

@@ -88,6 +88,7 @@ class Scene:
     material_textures: list = None   # per material: texture index on its reflectance / specularReflectance, -1 = constant
     thinlens: tuple = None       # (apertureRadius, focusDistance) of `<sensor type="thinlens">`; None = `perspective`
     shutter: tuple = None        # (shutterOpen, shutterClose) of the sensor (sensor.cpp:26-38); None = (0, 0): no time sample
+    crop: tuple = None           # (cropOffsetX, cropOffsetY, fullWidth, fullHeight): width x height above is the crop window of a film of that size (film.cpp:34-48); None = no crop
 
     @property
     def ntri(self):

@@ -142,6 +142,9 @@ GDPT_API int  gdpt_gbdpt_reconstruct_device(const double *primal, const double *
 /* Both calls keep, per (device, size, alpha), the three fp32 solver inputs and one solver per preset from one frame to the next (an
  * integrator renders many frames of one size); this frees them (all devices). */
 GDPT_API int  gdpt_gbdpt_reconstruct_release(void);
+/* ... and this frees the idle entries of ONE frame size on ONE device (device < 0: the current one) -- what an integrator hands back when it is done, without
+ * taking the cached solvers of other integrators of the process with it. */
+GDPT_API int  gdpt_gbdpt_reconstruct_release_size(int device, int width, int height);
 
 /* ---- (2) backend-op level ----------------------------------------------------------------- */
 /* Device-pointer forms of the `poisson::Backend` virtuals.  `stream` is a hipStream_t (NULL =

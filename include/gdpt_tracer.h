@@ -62,17 +62,21 @@ typedef struct gdpt_environment {   /* `<emitter type="constant">` (src/emitters
     double toWorld[9];          /* envmap: linear part of the emitter's `toWorld`, row-major (identity: +y is up, u = 0.5 looks along -z)   */
 } gdpt_environment;
 
-typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp) or `thinlens` (thinlens.cpp), crop == film */
+typedef struct gdpt_camera {    /* `perspective` sensor (src/sensors/perspective.cpp) or `thinlens` (thinlens.cpp) */
     double toWorld[16];         /* row-major camera-to-world, Transform::lookAt convention         */
     double fovX;                /* degrees (`fov`, fovAxis = x)                                    */
     double nearClip, farClip;
-    int    width, height;       /* film size in pixels                                             */
+    int    width, height;       /* size of the rendered image in pixels: the film's CROP window (Film::getCropSize; the whole film when there is no crop) */
     int    type;                /* GDPT_SENSOR_PERSPECTIVE (0) | GDPT_SENSOR_THINLENS: `thinlens` (src/sensors/thinlens.cpp), the aperture sample of gpt.cpp:1262-1264 */
     double apertureRadius;      /* thinlens `apertureRadius`                                        */
     double focusDistance;       /* thinlens `focusDistance`                                         */
     double shutterOpen;         /* `shutterOpen` / `shutterClose` (Sensor::Sensor, sensor.cpp:26-38): with shutterClose > shutterOpen every sample draws  */
     double shutterClose;        /*   its time sample (gpt.cpp:1265-1267, gbdpt_proc.cpp:156-157); both 0 = no shutter.  Transforms are static: the time    */
                                 /*   of a ray moves nothing, the draw keeps the sample's random stream where the reference's is                           */
+    int    cropOffsetX, cropOffsetY;   /* the film's crop window (film.cpp `cropOffsetX/Y`, `cropWidth/Height`): pixel (x, y) of the rendered image is pixel          */
+    int    fullWidth, fullHeight;      /*   (x + cropOffsetX, y + cropOffsetY) of a fullWidth x fullHeight film -- the sensor's rays, aspect and pixel differentials  */
+                                       /*   come from the FULL film's raster (perspective.cpp:126-163, steps 4+5 of m_cameraToSample).  fullWidth == 0: no crop      */
+                                       /*   (the film is width x height).  G-PT only: the G-BDPT entry points return GDPT_ERR_UNSUPPORTED for a cropped camera       */
 } gdpt_camera;
 #define GDPT_SENSOR_PERSPECTIVE 0
 #define GDPT_SENSOR_THINLENS    1
@@ -224,7 +228,7 @@ GDPT_API int  gdpt_film_set_occupancy(gdpt_film *f, int wavesPerSimd);
  * stages = 3 (round 4, opt-in, measured SLOWER than 2 -- DESIGN.md): the first GDPT_WF_ITERS (default 6) bounces of the continuation phase run
  * in wavefront form (csrc/gpt_wavefront.hip.h: rays through HBM queues to traversal-only kernels, shading passes that replay the one bounce()
  * around them), k_continue takes what is left; films, ray counts and statistics are bit-identical to stages = 2.
- * refillLanes: idle lanes of a wave of k_continue before they take new records together (0 = keep the current value, default 32).
+ * refillLanes: idle lanes of a wave of k_continue before they take new records together (0 = keep the current value, default 48).
  * Environment: GDPT_NO_CONTINUATION and GDPT_QUEUE_MB (memory budget of the sample queue, default
  * 24576) override at render time (GDPT_NO_CONTINUATION set = stages 0). */
 GDPT_API int  gdpt_film_set_pipeline(gdpt_film *f, int stages, int refillLanes);
@@ -280,6 +284,11 @@ GDPT_API int  gdpt_scene_trace_stats(gdpt_scene *s, int numRays, const double *o
 GDPT_API int  gdpt_scene_layout(gdpt_scene *s, long long out[6]);
 /* Probe for tests: closest hit of one ray on the device -> prim (original triangle index, -1 = miss), t, p[3]. */
 GDPT_API int  gdpt_scene_intersect(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *tp4);
+/* Probe for tests: the FILLED intersection record of each ray's closest hit as the render kernels form it (ShapeKDTree::rayIntersect(ray, its),
+ * src/librender/skdtree.cpp:112-142 + fillIntersectionRecord<true>, include/mitsuba/render/skdtree.h:343-428) -> prim (original triangle index, -1 = miss)
+ * and rec24 = t, its.p(3), its.uv(2), geoFrame.n(3), shFrame.n(3), shFrame.s(3), dpdu(3), dpdv(3), wi(3).  This is what the reference's own
+ * src/tests/test_dgeom.cpp:35-178 asserts on; tests/golden/dgeom_reference.json holds its vectors. */
+GDPT_API int  gdpt_scene_intersect_record(gdpt_scene *s, int numRays, const double *originsDirs6, int *prim, double *rec24);
 
 /* Probe for tests: one sample's raw evaluatePoint outputs (gpt.cpp:397-436): veryDirect(3), throughput(3), gradients[4](12),
  * neighbourThroughputs[4](12), then closest-hit count, any-hit count, final depth. */
@@ -298,13 +307,14 @@ GDPT_API int  gdpt_bsdf_probe(const gdpt_material *m, const double wi[3], int nS
  * src/libbidir: Path::alternatingRandomWalkFromPixel, ManifoldPerturbation::generateOffsetPathGBDPT, Path::miWeight{Base,Grad}NoSweep_GBDPT),
  * accumulated as GBDPTWorkResult / GBDPTProcess::processResult do (gbdpt_wr.h:56-62, gbdpt_proc.cpp:708-763): five camera blocks (rgb, weight)
  * and five full-resolution light images, buffer order of the integrator's MultiFilm (gbdpt.cpp:163): 0 primal, 1 gradient towards (0,-1),
- * 2 (-1,0), 3 (+1,0), 4 (0,+1).  Scope: surface scenes, area emitters, perspective or thinlens sensor, box filter; BSDFs diffuse and rough conductors
+ * 2 (-1,0), 3 (+1,0), 4 (0,+1).  Scope: surface scenes; area, point, constant-environment and envmap emitters (round 5); perspective or thinlens sensor
+ * WITHOUT a crop window (a cropped gdpt_camera returns GDPT_ERR_UNSUPPORTED); box filter; maxDepth <= 20; BSDFs diffuse and rough conductors
  * (one- or two-sided, textured or not) and -- round 4 -- conductor, dielectric and rough conductors below shiftThreshold.  A sample whose
  * surface vertices are all connectable in the sense of Path::isConnectable_GBDPT runs the fast wavefront form; a sample that meets a
  * SPECULAR vertex runs the general form (csrc/gbdpt_general.hip.h): offset paths by ManifoldPerturbation::propagatePerturbation and
  * manifoldWalk (mut_manifold.cpp:989-1227, SpecularManifold manifold.cpp:59-757), Jacobians and MIS weights with SpecularManifold::{G, multiG,
- * det} -- as staged launches over per-sample records in HBM (round 5: DESIGN.md "the general form as staged launches").  Environment / point
- * emitters return GDPT_ERR_UNSUPPORTED.  Same counter-based random streams as the G-PT path, consumed in the reference's order. */
+ * det} -- as staged launches over per-sample records in HBM (round 5: DESIGN.md "the general form as staged launches").
+ * Same counter-based random streams as the G-PT path, consumed in the reference's order. */
 typedef struct gdpt_gbdpt_config {
     int    maxDepth;            /* -1 renders as 12 (gbdpt_proc.cpp:103-106); at most 20 (a sample record holds whole subpaths; 19 with the thinlens sensor) */
     int    rrDepth;             /* 5 (gbdpt.cpp:82)                                                                         */

@@ -168,6 +168,8 @@ typedef struct gpo_camera {
     int type;           // 0 perspective, 1 thinlens (src/sensors/thinlens.cpp)
     double apertureRadius, focusDistance;
     double shutterOpen, shutterClose;   // Sensor::Sensor, sensor.cpp:26-38: shutterClose > shutterOpen <=> needsTimeSample() (sensor.h:290)
+    int cropOffsetX, cropOffsetY;       // the film's crop window (film.cpp:34-48): width x height is the CROP size, the film itself fullWidth x fullHeight
+    int fullWidth, fullHeight;          // (0: no crop).  G-PT only -- the G-BDPT side takes crop == film
 } gpo_camera;
 
 typedef struct gpo_config {
@@ -1324,11 +1326,16 @@ EnvShiftResult environmentShift(const Scene &sc, const Ray &mainRay, V3 shiftSou
 void sampleRay(const Scene &sc, Float px, Float py, Ray &ray, Float apx = 0.5, Float apy = 0.5)
 {
     const gpo_camera &c = sc.cam;
-    const Float sxn = px * (1.0 / c.width), syn = py * (1.0 / c.height);
-    // m_sampleToCamera(Point(sx, sy, 0)) for the composite of perspective.cpp:150-156 with crop == film, written out:
+    // The crop window (perspective.cpp:126-156): pixelSample is relative to the crop, m_invResolution = 1 / cropSize, and steps 4+5 of m_cameraToSample
+    // map the full film's [0, 1]^2 to the crop's -- so the position in the FULL film's unit square is (crop-relative sample + cropOffset) / filmSize;
+    // m_aspect (sensor.cpp) and, through relSize * invResolution, the pixel steps m_dx / m_dy are the full film's too.
+    const int fullW = c.fullWidth > 0 ? c.fullWidth : c.width, fullH = c.fullWidth > 0 ? c.fullHeight : c.height;
+    const Float cropX = c.fullWidth > 0 ? (Float)c.cropOffsetX : 0.0, cropY = c.fullWidth > 0 ? (Float)c.cropOffsetY : 0.0;
+    const Float sxn = (px + cropX) * (1.0 / fullW), syn = (py + cropY) * (1.0 / fullH);
+    // m_sampleToCamera(Point(sx, sy, 0)) for the composite of perspective.cpp:150-156, written out:
     V3 nearP((1 - 2 * sxn) * c.nearClip * sc.tanHalf, (1 - 2 * syn) / sc.aspect * c.nearClip * sc.tanHalf, c.nearClip);
     // m_dx = sampleToCamera(1/width, 0, 0) - sampleToCamera(0), m_dy likewise (perspective.cpp:160-163, thinlens.cpp:171-174), with the same written-out composite
-    const V3 mdx(-2 * (1.0 / c.width) * c.nearClip * sc.tanHalf, 0.0, 0.0), mdy(0.0, -2 * (1.0 / c.height) / sc.aspect * c.nearClip * sc.tanHalf, 0.0);
+    const V3 mdx(-2 * (1.0 / fullW) * c.nearClip * sc.tanHalf, 0.0, 0.0), mdy(0.0, -2 * (1.0 / fullH) / sc.aspect * c.nearClip * sc.tanHalf, 0.0);
     const double *M = c.toWorld;
     V3 d, dx, dy, ol(0.0);
     if (c.type == 1) {
@@ -2011,7 +2018,7 @@ GPO_API gpo_scene *gpo_scene_create(int ntri, const double *verts, const int *tr
     gpo_scene *h = new gpo_scene;
     Scene &sc = h->sc;
     sc.cam = *cam;
-    sc.aspect = (double)cam->width / (double)cam->height;             // sensor.cpp: m_aspect
+    sc.aspect = cam->fullWidth > 0 ? (double)cam->fullWidth / (double)cam->fullHeight : (double)cam->width / (double)cam->height;   // sensor.cpp: m_aspect = the FILM's size, not the crop's
     sc.tanHalf = std::tan((cam->fovX * 0.5) * (PI / 180.0));
     sc.mats.assign(mats, mats + nmat);
     sc.tris.resize(ntri);
@@ -2371,6 +2378,22 @@ GPO_API int gpo_intersect(gpo_scene *h, const double *o, const double *d, double
     out_t_p_wi[4] = its.wi.x; out_t_p_wi[5] = its.wi.y; out_t_p_wi[6] = its.wi.z;
     return its.prim;
 }
+// The filled intersection record of one ray (ShapeKDTree::rayIntersect + fillIntersectionRecord<true>, skdtree.cpp:112-142, skdtree.h:343-428): what
+// the reference's own src/tests/test_dgeom.cpp:35-178 asserts on.  out24 = t, p(3), uv(2), geoFrame.n(3), shFrame.n(3), shFrame.s(3), dpdu(3), dpdv(3), wi(3).
+GPO_API int gpo_intersect_record(gpo_scene *h, const double *o, const double *d, double *out24)
+{
+    Ray r(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]));
+    Intersection its;
+    if (!rayIntersect(h->sc, r, its)) return -1;
+    double *q = out24;
+    *q++ = its.t;
+    const V3 v3[] = {its.p};
+    *q++ = v3[0].x; *q++ = v3[0].y; *q++ = v3[0].z;
+    *q++ = its.u; *q++ = its.v;
+    const V3 rest[] = {its.geoN, its.sh.n, its.sh.s, its.dpdu, its.dpdv, its.wi};
+    for (const V3 &v : rest) { *q++ = v.x; *q++ = v.y; *q++ = v.z; }
+    return its.prim;
+}
 GPO_API void gpo_camera_ray_ap(gpo_scene *h, double px, double py, double apx, double apy, double *out14)
 {   // with the aperture sample and the two differential directions: o(3), d(3), mint, maxt, rxD(3), ryD(3)
     Ray r;
@@ -2506,6 +2529,23 @@ GPO_API void gpo_manifold_probe(gpo_scene *h, const gpo_gbdpt_config *cfg, int p
     gb::Pool pool;
     gb::Tracer tr(ctx, rng, pool);
     tr.manifoldProbe(px, py, delta3, out32);
+}
+// TriMesh::getNormalDerivative(its, dndu, dndv, shadingFrame = true) at the hit of one ray (trimesh.cpp:745-822; the G-BDPT manifold walk's input,
+// manifold.cpp:101-122): out6 = dndu(3), dndv(3).  src/tests/test_dgeom.cpp:112-119,170-176 hold two vectors for it.
+GPO_API int gpo_normal_derivative(gpo_scene *h, const double *o, const double *d, double *out6)
+{
+    Ray r(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]));
+    Intersection its;
+    if (!rayIntersect(h->sc, r, its)) return -1;
+    gpo_gbdpt_config cfg = {12, 5, 1, 1, 0.001, 5489ULL};
+    gb::Ctx ctx{h->sc, gbConfig(&cfg)};
+    Rng rng(cfg.seed, 0, 0);
+    gb::Pool pool;
+    gb::Tracer tr(ctx, rng, pool);
+    V3 dndu, dndv;
+    tr.normalDerivative(its, dndu, dndv);
+    out6[0] = dndu.x; out6[1] = dndu.y; out6[2] = dndu.z; out6[3] = dndv.x; out6[4] = dndv.y; out6[5] = dndv.z;
+    return its.prim;
 }
 GPO_API void gpo_manifold_probe2(gpo_scene *h, const gpo_gbdpt_config *cfg, int px, int py, int sampleIndex, const double *delta3, double *out48)
 {

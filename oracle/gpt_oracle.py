@@ -26,7 +26,8 @@ class Emitter(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("toWorld", C.c_double * 16), ("fovX", C.c_double), ("nearClip", C.c_double), ("farClip", C.c_double),
                 ("width", C.c_int), ("height", C.c_int), ("type", C.c_int), ("apertureRadius", C.c_double), ("focusDistance", C.c_double),
-                ("shutterOpen", C.c_double), ("shutterClose", C.c_double)]
+                ("shutterOpen", C.c_double), ("shutterClose", C.c_double),
+                ("cropOffsetX", C.c_int), ("cropOffsetY", C.c_int), ("fullWidth", C.c_int), ("fullHeight", C.c_int)]
 
 
 class Config(C.Structure):
@@ -126,6 +127,8 @@ def lib():
         L.gpo_fresnel_conductor.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_camera_ray.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.gpo_intersect_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpo_normal_derivative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpo_rng.restype = C.c_double
         L.gpo_rng.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_int]
         L.gpo_reference_pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -164,6 +167,8 @@ class Scene:
             cam.type, cam.apertureRadius, cam.focusDistance = 1, float(desc.thinlens[0]), float(desc.thinlens[1])
         if getattr(desc, "shutter", None):                  # (shutterOpen, shutterClose) of the sensor: an interval of positive length draws a time sample
             cam.shutterOpen, cam.shutterClose = float(desc.shutter[0]), float(desc.shutter[1])
+        if getattr(desc, "crop", None):                     # (cropOffsetX, cropOffsetY, fullWidth, fullHeight): width x height is the crop window of that film
+            cam.cropOffsetX, cam.cropOffsetY, cam.fullWidth, cam.fullHeight = (int(v) for v in desc.crop)
         self.W, self.H = desc.width, desc.height
         self._h = lib().gpo_scene_create(verts.shape[0], _p(verts), _p(tm), len(desc.materials), C.byref(mats),
                                          len(desc.emitters), C.byref(ems), C.byref(cam))
@@ -267,6 +272,21 @@ class Scene:
         out = np.zeros(7)
         prim = lib().gpo_intersect(self._h, _p(_d(o)), _p(_d(d)), _p(out))
         return prim, out[0], out[1:4], out[4:7]
+
+    def intersect_record(self, o, d):
+        """The filled intersection record of one ray (fillIntersectionRecord<true>, skdtree.h:343-428): dict or None for a miss."""
+        out = np.zeros(24)
+        prim = lib().gpo_intersect_record(self._h, _p(_d(o)), _p(_d(d)), _p(out))
+        if prim < 0:
+            return None
+        return {"prim": prim, "t": out[0], "p": out[1:4], "uv": out[4:6], "geoFrame.n": out[6:9], "shFrame.n": out[9:12], "shFrame.s": out[12:15],
+                "dpdu": out[15:18], "dpdv": out[18:21], "wi": out[21:24]}
+
+    def normal_derivative(self, o, d):
+        """TriMesh::getNormalDerivative(its, dndu, dndv, true) at the hit of one ray (trimesh.cpp:745-822): (dndu, dndv) or None."""
+        out = np.zeros(6)
+        prim = lib().gpo_normal_derivative(self._h, _p(_d(o)), _p(_d(d)), _p(out))
+        return None if prim < 0 else (out[0:3], out[3:6])
 
     def camera_ray(self, px, py, ap=None):
         if ap is not None:                                      # with an aperture sample: also the differential directions

@@ -183,7 +183,8 @@ private:
 class Sampler : public ConfigurableObject { public: size_t getSampleCount() const { return 4; } const Class *getClass() const { static Class c("IndependentSampler"); return &c; } };
 class Sensor : public ConfigurableObject {
 public:
-    Film *getFilm() { return &m_film; }
+    Film *getFilm() { return &m_film; }                     // sensor.h:255-258: both overloads
+    const Film *getFilm() const { return &m_film; }
     const AnimatedTransform *getWorldTransform() const { return &m_t; }
     Float getShutterOpen() const { return 0; }              // sensor.h:275
     Float getShutterOpenTime() const { return 0; }          // sensor.h:281

@@ -110,3 +110,21 @@ def test_bench_two_ranks_of_config5_on_one_device(gpu_required, tmp_path):
         assert np.abs(d2[k] - d1[k]).max() <= 1e-9 * scale, (k, float(np.abs(d2[k] - d1[k]).max()) / scale)
     for k in ("L2", "L1"):                       # (fp32 solves of inputs that differ in their last bits)
         assert np.isfinite(d2[k]).all() and np.abs(d2[k] - d1[k]).max() <= 1e-3 * max(1.0, float(np.abs(d1[k]).max())), k
+
+
+def test_strip_study_strips_add_up_to_the_frame(gpu_required):
+    """`bench.py --strip-study` (single-GPU evidence for the N-GPU claim, profiles/r06*_strip_study.json): for N = 2, 4, 8 the strips -- equal rows and the
+    rebalanced partition -- trace exactly the frame's rays between them, cover its rows, and the line carries the modelled step and the predicted speedup
+    with its fixed costs named.  (BASELINE config 1's size at 4 spp: the structure, not the numbers.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--strip-study", "--study-configs", "1", "--spp", "4"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    c = d["configs"]["1"]
+    assert c["one_gpu"]["rays"] > 0 and c["one_gpu"]["step_ms_measured"] > 0
+    for N in ("2", "4", "8"):
+        for label in ("equal_rows", "rebalanced"):
+            e = c["N"][N][label]
+            assert e["rays_sum_equals_frame"] and sum(e["strip_rows"]) == 512 and len(e["strip_render_ms"]) == int(N)
+            assert e["predicted_speedup"] > 0 and set(e["fixed_ms"]) == {"halo_pack_unpack", "halo_messages_modelled", "develop", "gather_modelled", "solve_on_rank0"}
+            assert e["step_ms_modelled"] >= max(e["strip_render_ms"])

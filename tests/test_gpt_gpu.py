@@ -1363,3 +1363,85 @@ def test_thinlens_sensor_argument_checks_and_scope(G):
     assert np.isfinite(B.GBDPTIntegrator(maxDepth=4).render(Sb, 1)["-primal"]).all()
     with pytest.raises(RuntimeError, match="maxDepth up to 19 with the thinlens"):
         B.GBDPTIntegrator(maxDepth=20).render(Sb, 1)
+
+
+def test_intersection_record_matches_reference_dgeom_vectors(G):
+    """SURVEY 8a rows 20, 22, 23 on the HIP path against the vectors the REFERENCE'S OWN test holds (src/tests/test_dgeom.cpp:35-178 ->
+    tests/golden/dgeom_reference.json; tolerances and the two assertions this fork's own code contradicts: tests/test_dgeom_golden.py), then the
+    same record against the oracle on a scene with per-vertex normals and texture coordinates, ray by ray."""
+    from test_dgeom_golden import load_cases, scene_of, check_record
+    for case in load_cases():
+        sc = scene_of(case, with_emitter=True)
+        S, O = G.Scene(sc), go.Scene(sc)
+        prim, rec = S.intersect_record([case["ray"]["o"]], [case["ray"]["d"]])
+        assert prim[0] == 0 and rec["t"][0] == 1.0
+        one = {k: v[0] for k, v in rec.items()}
+        dn = O.normal_derivative(case["ray"]["o"], case["ray"]["d"])        # (getNormalDerivative lives on the G-BDPT side: tests/test_gbdpt_gpu.py holds the device's)
+        assert check_record(case, one, dn) >= 8
+        orec = O.intersect_record(case["ray"]["o"], case["ray"]["d"])
+        for k in ("p", "uv", "geoFrame.n", "shFrame.n", "shFrame.s", "dpdu", "dpdv", "wi"):
+            assert np.allclose(one[k], orec[k], rtol=1e-14, atol=1e-15), (case["name"], k)
+        S.close()
+    sc = scenes.textured_cornell_box(32, 24)
+    smooth = scenes.cornell_box(32, 24, "bent")
+    for desc in (sc, smooth):
+        S, O = G.Scene(desc), go.Scene(desc)
+        rng = np.random.default_rng(5)
+        o = np.tile(np.array([[278.0, 273.0, -500.0]]), (400, 1)) + rng.normal(size=(400, 3)) * 40.0
+        d = rng.normal(size=(400, 3)); d[:, 2] = np.abs(d[:, 2]) + 0.5; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        prim, rec = S.intersect_record(o, d)
+        hits = 0
+        for i in range(400):
+            orec = O.intersect_record(o[i], d[i])
+            assert (orec is None) == (prim[i] < 0)
+            if orec is None:
+                continue
+            hits += 1
+            assert rec["t"][i] == pytest.approx(orec["t"], rel=1e-13)
+            for k in ("p", "uv", "geoFrame.n", "shFrame.n", "shFrame.s", "dpdu", "dpdv", "wi"):
+                assert np.allclose(rec[k][i], orec[k], rtol=1e-11, atol=1e-11), (desc.name, i, k, rec[k][i], orec[k])
+        assert hits > 100
+        S.close()
+
+
+@pytest.mark.parametrize("variant,md,crop,lens", [("diffuse", -1, (10, 7, 64, 48), None), ("glossy", 8, (0, 0, 48, 40), None), ("bent", 6, (23, 17, 50, 38), (25.0, 820.0))])
+def test_crop_window_rays_come_from_the_full_films_raster(G, variant, md, crop, lens):
+    """A film with a crop window (film.cpp:34-48): the rendered image is the crop, the sensor's rays, aspect and pixel differentials are the full
+    film's (perspective.cpp:126-163) and BlockedRenderProcess hands out crop-relative blocks (renderproc.cpp:158-181).  Camera rays of the crop ==
+    those of the full film's pixels; samples and films against the oracle through both pipelines; an invalid window is refused as film.cpp refuses it."""
+    W, H = 24, 18
+    sc = scenes.cornell_box(W, H, variant); sc.crop = crop; sc.thinlens = lens
+    full = scenes.cornell_box(crop[2], crop[3], variant); full.thinlens = lens
+    S, O, OF = G.Scene(sc), go.Scene(sc), go.Scene(full)
+    for (x, y) in ((0.5, 0.5), (3.25, 7.75), (W - 0.5, H - 0.5)):
+        a, b = O.camera_ray(x, y), OF.camera_ray(x + crop[0], y + crop[1])
+        assert all(np.allclose(u, v, rtol=1e-15, atol=0) for u, v in zip(a, b))
+    integ = G.GradientPathIntegrator(maxDepth=md)
+    rng = np.random.default_rng(31)
+    for _ in range(20):
+        px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, 64))
+        g = S.evaluate_point(integ.config(64), px, py, s)
+        o = O.evaluate_point(go.config(maxDepth=md, spp=64), px, py, s)
+        for k in ("veryDirect", "throughput", "gradients", "neighbours"):
+            assert np.allclose(g[k], o[k], rtol=1e-10, atol=1e-14), (variant, px, py, s, k)
+        assert (g["raysTraced"], g["shadowRaysTraced"]) == (o["raysTraced"], o["shadowRaysTraced"])
+    spp = 3
+    oacc, orays = O.render(go.config(maxDepth=md, spp=spp))
+    for pipeline in (2, 0):
+        F = G.Film(S); F.set_pipeline(pipeline)
+        integ.renderBlock(S, F, integ.config(spp), (0, 0, W, H))
+        acc, st = F.accum(), F.stats()
+        F.close()
+        assert (st["raysTraced"], st["shadowRaysTraced"]) == orays
+        for b in range(5):
+            assert close(acc[b], oacc[b]), (pipeline, G.BUFFER_NAMES[b])
+    # the crop is not the uncropped film of its own size: another field of view
+    pacc, _ = go.Scene(scenes.cornell_box(W, H, variant)).render(go.config(maxDepth=md, spp=spp))
+    assert not close(oacc[1], pacc[1], rel=1e-3)
+    bad = scenes.cornell_box(W, H, variant); bad.crop = (50, 0, 64, 48)
+    with pytest.raises(RuntimeError, match="Invalid crop window specification!"):
+        G.Scene(bad)
+    import gradientdomain_mitsuba_amd.gbdpt as B
+    rough = scenes.cornell_box(W, H, "rough"); rough.crop = crop
+    with pytest.raises(RuntimeError, match="crop window"):
+        B.GBDPTIntegrator(maxDepth=4).render(G.Scene(rough), 1)

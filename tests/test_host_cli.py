@@ -690,3 +690,31 @@ def test_cli_shutter_interval_equals_python_mirror(cli, tmp_path, gpu_required):
     xb = str(tmp_path / "shutter_bad.xml"); open(xb, "w").write(xml.replace('value="0.5"', 'value="0.125"'))
     bad = run(cli, "-o", dest + "b", "-D", "width=16", "-D", "height=16", "-D", "spp=1", xb)
     assert bad.returncode == 1 and "Shutter opening time" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cli_crop_window_equals_python_mirror(cli, tmp_path, gpu_required):
+    """`cropOffsetX/Y` + `cropWidth/Height` on the film through the scene reader (film.cpp:34-48; perspective.cpp:126-163) == the Python mirror with the same
+    window: the written images have the crop's size; a window that leaves the film ends with the reference's message."""
+    import shutil
+    import gradientdomain_mitsuba_amd.gpt as G
+    shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    src = open(XML).read()
+    assert '<film type="multifilm">' in src
+    xml = src.replace('<film type="multifilm">', '<film type="multifilm"><integer name="cropOffsetX" value="9"/><integer name="cropOffsetY" value="5"/>'
+                      '<integer name="cropWidth" value="24"/><integer name="cropHeight" value="16"/>')
+    xc = str(tmp_path / "crop.xml"); open(xc, "w").write(xml)
+    dest = str(tmp_path / "crop")
+    r = run(cli, "-o", dest, "-D", "width=40", "-D", "height=30", "-D", "spp=4", "-D", "maxDepth=5", xc)
+    assert r.returncode == 0, r.stderr
+    sc = scenes.cornell_box(24, 16); sc.crop = (9, 5, 40, 30)
+    out = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(sc), 4)
+    for suffix in G.BUFFER_NAMES:
+        img = read_pfm(dest + suffix + ".pfm")
+        assert img.shape[:2] == (16, 24)
+        assert np.allclose(img, out[suffix], rtol=2e-6, atol=1e-7), suffix
+    whole = G.GradientPathIntegrator(maxDepth=5).render(G.Scene(scenes.cornell_box(24, 16)), 4)
+    assert not np.allclose(out["-throughput"], whole["-throughput"], rtol=1e-3)
+    xb = str(tmp_path / "crop_bad.xml"); open(xb, "w").write(xml.replace('name="cropOffsetX" value="9"', 'name="cropOffsetX" value="20"'))
+    bad = run(cli, "-o", dest + "b", "-D", "width=40", "-D", "height=30", "-D", "spp=1", xb)
+    assert bad.returncode == 1 and "Invalid crop window specification!" in bad.stderr

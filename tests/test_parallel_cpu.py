@@ -243,16 +243,18 @@ def _toy_render(rank, world, W, H, film_cls, rebalance):
     return res
 
 
-def _strip_worker(rank, world, port, W, H, own_border, rebalance, q):
+def _strip_worker(rank, world, port, W, H, own_border, rebalance, q, early="0"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["GDPT_EARLY_GATHER"] = early          # "1": the opt-in second communicator with the gather's receives posted before the render (parallel.StripRenderer)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     q.put((rank,) + _toy_render(rank, world, W, H, _ToyFilmOwnBorder if own_border else _ToyFilm, rebalance))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("early", ["0", "1"], ids=["gather-after-halo", "early-gather"])
 @pytest.mark.parametrize("world,own_border,rebalance", [(2, False, False), (3, False, True), (2, True, False), (3, True, True)])
-def test_strip_renderer_equals_one_rank(world, own_border, rebalance):
+def test_strip_renderer_equals_one_rank(world, own_border, rebalance, early):
     """Strips + halo exchange (box filter) or strips that render their own border (wider filters) + gather + solve on rank 0
     give exactly the one-rank image; rebalancing moves the boundaries and changes nothing in the image."""
     W, H = 12, 19
@@ -260,7 +262,7 @@ def test_strip_renderer_equals_one_rank(world, own_border, rebalance):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, W, H, own_border, rebalance, q)) for r in range(world)]
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, W, H, own_border, rebalance, q, early)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

@@ -8,3 +8,9 @@ timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > 
 timeout 600 python bench.py > gpurun_out/${TAG}_bench_config2.json 2> gpurun_out/${TAG}_bench_config2.err
 timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config5.json 2> gpurun_out/${TAG}_bench_config5.err
 for c in 1 2 3 4 5; do cut -c1-700 gpurun_out/${TAG}_bench_config$c.json; tail -2 gpurun_out/${TAG}_bench_config$c.err; done
+# configs 3 / 4 on the atrium at SURVEY 8(d)'s ~262 k triangles as well (round 6): SIZE262=1
+if [ -n "$SIZE262" ]; then
+timeout 700 python bench.py --config 3 --atrium-segments 112 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config3_262k.json 2> gpurun_out/${TAG}_bench_config3_262k.err
+timeout 1000 python bench.py --config 4 --atrium-segments 112 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_config4_262k.json 2> gpurun_out/${TAG}_bench_config4_262k.err
+for c in 3 4; do cut -c1-700 gpurun_out/${TAG}_bench_config${c}_262k.json; tail -2 gpurun_out/${TAG}_bench_config${c}_262k.err; done
+fi

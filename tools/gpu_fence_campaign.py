@@ -4,6 +4,8 @@ every film and ray counter.  Prints the first difference and exits non-zero, or 
 import importlib, os, subprocess, sys, tempfile, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import fuzz_summary  # noqa: E402  (tools/fuzz_summary.py: the battery's one-line JSON record)
 import numpy as np
 b = importlib.import_module("gradientdomain-mitsuba_amd._build")
 
@@ -36,3 +38,4 @@ for lo in range(first, first + count, 500):
             films += 1; identical += int(np.array_equal(a, c))
     print("seeds %d..%d: %d films, %d bit-identical, worst rel %.2e, %.0f s" % (first, lo + n - 1, films, identical, worst, time.time() - t0), flush=True)
 print("OK: seeds %d..%d through -O1 and -O3: %d films, ray counts identical, %d films bit-identical, worst relative difference %.2e" % (first, first + count - 1, films, identical, worst))
+fuzz_summary.emit("gpu_fence_campaign", first, count, 0.0, films=films, bit_identical_films=identical, worst_rel_diff=worst, ray_counts_identical=True)

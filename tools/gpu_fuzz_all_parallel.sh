@@ -11,3 +11,4 @@ for i in 0 1; do timeout -s KILL $LIMIT python tools/gpu_fuzz_features.py $((FIR
 for i in 0 1; do timeout -s KILL $LIMIT python tools/gpu_serial_fuzz.py $((FIRST + 30000 + i * PER)) $((PER / 2)) > gpurun_out/fuzz_all/serial_$i.log 2>&1 & pids="$pids $!"; done
 for p in $pids; do wait $p; done
 for f in gpurun_out/fuzz_all/*.log; do echo "== $f"; tail -2 $f | cut -c1-500; done
+grep -h "^FUZZ_SUMMARY" gpurun_out/fuzz_all/*.log | sed "s/^FUZZ_SUMMARY //" > gpurun_out/fuzz_all/summaries.jsonl; wc -l gpurun_out/fuzz_all/summaries.jsonl

@@ -3,6 +3,8 @@ Per seed: a fuzzed Cornell scene (random materials / settings; every third with 
 point light), 40 evaluatePoint probes and one small whole film (five buffers + both ray counters); every seventh seed the atrium (HBM
 BVH) with a fuzzed camera-independent sample set.  Prints the first mismatch and exits non-zero, or a summary."""
 import sys, time, copy
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import fuzz_summary  # noqa: E402  (tools/ is on sys.path: the script's own directory)
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 from gradientdomain_mitsuba_amd import gpt as G, scenes
@@ -143,3 +145,4 @@ for seed in range(first, first + count):
     if (seed - first) % 20 == 19:
         print("seed %d: %d probes, %d films ok, worst film rel diff %.2e, %.0f s" % (seed, probes, films, worst, time.time() - t0), flush=True)
 print("OK: seeds %d..%d, %d probes (%d outputs beyond 1e-9 on ill-conditioned samples, worst %.1e, each within 20x of the oracle's own sensitivity to few-ulp scalings of the geometry), %d films + %d with a knife-edge ray-count difference (%d film buffers beyond 1e-9, within 20x of the oracle's own spread), worst film rel diff %.2e, %.0f s" % (first, first + count - 1, probes, illcond, worst_ill, films, knife, illfilm, worst, time.time() - t0))
+fuzz_summary.emit("gpu_fuzz_campaign", first, count, time.time() - t0, probes=probes, films=films, ill_conditioned_outputs=illcond, worst_ill_conditioned_rel=worst_ill, knife_edge_ray_count_films=knife, ill_conditioned_film_buffers=illfilm, worst_film_rel_diff=worst, bars="samples rtol 1e-9 / atol 1e-13, films 1e-9 of the buffer scale; beyond: within 20x of the oracle's own sensitivity to few-ulp scalings / 2^-30 rad rotations")

@@ -7,6 +7,8 @@ counters) through the staged and -- every third seed -- the single-kernel pipeli
 Prints the first mismatch and exits non-zero, or a summary."""
 import copy, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import fuzz_summary  # noqa: E402  (tools/fuzz_summary.py: the battery's one-line JSON record)
 import numpy as np
 from gradientdomain_mitsuba_amd import gpt as G, scenes
 from oracle import gpt_oracle as go
@@ -151,3 +153,4 @@ for seed in range(first, first + count):
     S.close(); O.close()
     if (seed - first) % 50 == 49: print("seed %d ok, worst film rel diff %.2e, %.0f s" % (seed, worst, time.time() - t0), flush=True)
 print("OK: seeds %d..%d, %d films with a ray-count difference and equal buffers, %d with an ill-conditioned sample (within 20x of the oracle's own spread), worst other film rel diff %.2e, %.0f s" % (first, first + count - 1, knife, ill, worst, time.time() - t0))
+fuzz_summary.emit("gpu_fuzz_features", first, count, time.time() - t0, knife_edge_ray_count_films=knife, ill_conditioned_films=ill, worst_film_rel_diff=worst)

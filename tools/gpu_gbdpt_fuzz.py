@@ -8,6 +8,8 @@ Veach-class room comes with its glass egg and mirror: samples with specular chai
 GBDPT_FUZZ_ENDPOINTS=1: half of the seeds get a thinlens sensor, most Cornell seeds one or two point emitters beside, before or instead of the area light."""
 import sys, time
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import fuzz_summary  # noqa: E402  (tools/fuzz_summary.py: the battery's one-line JSON record)
 import numpy as np
 from gradientdomain_mitsuba_amd import gpt as G, gbdpt as B, scenes
 from oracle import gpt_oracle as go
@@ -160,3 +162,4 @@ for seed in range(first, first + count):
     if (seed - first) % 20 == 19:
         print("seed %d: %d probes, %d films, %.1f s" % (seed, probes, films, time.time() - t0), flush=True)
 print("OK: seeds %d..%d: %d single samples (%d ill-conditioned: within 20x of the oracle's own spread), %d films; worst relative difference %.2e; %d ray-count knife edges (outputs equal), %d films with a pixel on the estimator's own discontinuity (an in-plane connection; within 20x of the oracle's spread under few-ulp scalings)" % (first, first + count - 1, probes, illcond, films, worst, knife, discont))
+fuzz_summary.emit("gpu_gbdpt_fuzz", first, count, time.time() - t0, samples=probes, ill_conditioned_samples=illcond, films=films, worst_rel_diff=worst, knife_edge_ray_counts=knife, films_on_estimator_discontinuity=discont)

@@ -2,6 +2,8 @@
 columns), presets, alpha, fusion levels, null throughput / direct.  python tools/gpu_poisson_fuzz.py [first [count]]"""
 import sys, time
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import fuzz_summary  # noqa: E402  (tools/fuzz_summary.py: the battery's one-line JSON record)
 import numpy as np
 import gradientdomain_mitsuba_amd.poisson as P
 from oracle import poisson_oracle as po
@@ -64,3 +66,4 @@ for seed in range(first, first + count):
     if not np.isfinite(rec).all() or d > tol:
         print("MISMATCH: seed %d %dx%d %s alpha %g fusion %d direct %s tp %s: max abs diff %g" % (seed, w, h, preset, alpha, fusion, direct is not None, tp is not None, d)); sys.exit(1)
 print("OK: seeds %d..%d, worst abs diff L2D %.2e, L1D %.2e (%d beyond the bar but within 10x of the oracle's own sensitivity to 2^-20 input noise), %.0f s" % (first, first + count - 1, worst["L2D"], worst["L1D"], illcond, time.time() - t0))
+fuzz_summary.emit("gpu_poisson_fuzz", first, count, time.time() - t0, worst_abs_diff_L2D=worst["L2D"], worst_abs_diff_L1D=worst["L1D"], beyond_bar_within_10x_of_oracle_sensitivity=illcond)

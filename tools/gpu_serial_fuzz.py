@@ -40,3 +40,6 @@ for seed in range(first, first + count):
         worst = max(worst, d)
     S.close(); O.close()
 print("seeds %d..%d: %d films equal (worst relative difference %.2e), %d differ; %.0f s" % (first, first + count - 1, count - knife, worst, knife, time.time() - t0))
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import fuzz_summary  # noqa: E402
+fuzz_summary.emit("gpu_serial_fuzz", first, count, time.time() - t0, films_equal=count - knife, worst_rel_diff=worst, films_with_knife_edge_difference=knife)

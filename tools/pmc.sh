@@ -8,5 +8,5 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/c -o r -- "$@" >> $OUT/stdout.log 2>> $OUT/er
 rocprofv3 --pmc WRITE_SIZE -d $OUT/d -o r -- "$@" >> $OUT/stdout.log 2>> $OUT/err.log
 fi
 tail -3 $OUT/stdout.log
-python tools/rocpd_summary.py pmc $(find $OUT -name "*.db") | grep -E "${PMC_GREP:-k_render|k_continue|k_fold|k_primary}" | sort
+python tools/rocpd_summary.py pmc $(find $OUT -name "*.db") | grep -E "${PMC_GREP:-k_render|k_first|k_continue|k_fold|k_primary}" | sort
 find $OUT -name "*.db" -delete

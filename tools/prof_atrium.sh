@@ -13,4 +13,4 @@ timeout 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_IN
 python $R/tools/rocpd_summary.py stats $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.csv
 python $R/tools/rocpd_summary.py pmc $(find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 -name "*.db") > $OUT/pmc.csv
 find $OUT -name "*.db" -delete
-cat $OUT/run.log; head -4 $OUT/kernel_stats.csv; grep k_render $OUT/pmc.csv
+cat $OUT/run.log; head -4 $OUT/kernel_stats.csv; grep -E "k_render|k_first|k_continue" $OUT/pmc.csv

@@ -16,5 +16,5 @@ python tools/rocpd_summary.py stats $(find $OUT/kt -name "*.db" | head -1) > $OU
 python tools/rocpd_summary.py pmc $(find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 -name "*.db") > $OUT/pmc.csv
 python tools/profile_json.py $TAG $OUT/counters.json $(find $OUT/kt -name "*.db" | head -1) $(find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 -name "*.db")
 find $OUT -name "*.db" -size +20M -delete
-head -12 $OUT/kernel_stats.csv; grep -E "k_render|kp_cg|kf_xp_Ax" $OUT/pmc.csv | head -40; tail -1 $OUT/bench_under_rocprof.json | cut -c1-1500
+head -12 $OUT/kernel_stats.csv; grep -E "k_render|k_first|k_continue|kp_cg|kf_xp_Ax" $OUT/pmc.csv | head -40; tail -1 $OUT/bench_under_rocprof.json | cut -c1-1500
 tail -2 $OUT/*.err | cut -c1-300
