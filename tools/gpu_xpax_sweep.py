@@ -29,7 +29,7 @@ print(json.dumps(dict(kus=[float(k) for k in kus], solve_ms=1e3 * sorted(t)[1]))
 ''' % ROOT
 ref = None
 print("%-10s %12s %12s %12s %14s" % ("rows,blk", "kf_xp_Ax us", "kf_r_rz us", "solve ms", "max|x - x_ref|"))
-for var in ("8,1", "8,3", "4,1", "4,3", "4,4", "12,1"):
+for var in (os.environ.get("XPAX_VARIANTS", "8,1 8,3 4,1 4,3 4,4 12,1").split()):
     env = dict(os.environ, GDPT_XPAX=var)
     out = "/tmp/xpax_%s.npy" % var.replace(",", "_")
     r = subprocess.run([sys.executable, "-c", CHILD, out], capture_output=True, text=True, env=env, timeout=280)
