@@ -1105,10 +1105,23 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // A scene none of whose vertices can be classified glossy by getVertexType (gpt.cpp:176-231: no delta BSDF, every rough BSDF's roughness above the
     // shift threshold -- vertex_is_diffuse in gpt_kernels.hip.h, mirrored here) only ever takes reconnection shifts: its samples leave the first stage after ONE
     // bounce, which k_first runs with the other connection states and the half-vector shift compiled out (GDPT_NO_FIRST_STAGE=1: k_render<STAGED> as for any scene)
-    bool firstStage = useQueue && wfIters == 0 && !getenv("GDPT_NO_FIRST_STAGE");
-#ifdef GDPT_HANDOFF_CONNECTED
-    firstStage = false;
+    // The hand-over rule: LDS-resident scenes hand a sample to k_continue as soon as no offset is RAY_NOT_CONNECTED (round 6: config-2 chunk 61.6 -> 57 ms, glossy box
+    // 85.8 -> 76.7 ms); HBM-resident scenes keep rounds 2-5's rule (every offset RAY_CONNECTED) -- measured on the atrium frame: the early rule takes 12.9 ms off the first
+    // stage and puts 14.6 ms onto the 128-register k_continue (61.5 -> 62.5 ms; configs 3 / 4: 2.91 / 2.95 -> 2.84 / 2.85 Gray/s).  GDPT_HANDOFF=early|late overrides (A/B).
+#ifdef GDPT_DEV_TWO_BUILDS     /* (the development dispatch below sends every scene with special emitters or per-vertex data through its one HBM-scene build) */
+    bool early = s->d.ldsScene && !s->perVertex && !s->specialEmitters;
+#else
+    bool early = s->d.ldsScene != 0;        // == the LDSV of the build the dispatch below picks
 #endif
+#if defined(GDPT_DEV_BOTH_HANDOFFS) || defined(GDPT_DEV_CONT2)
+    if (const char *e = getenv("GDPT_HANDOFF")) early = std::strcmp(e, "early") == 0;
+#endif
+#ifdef GDPT_HANDOFF_CONNECTED      /* (the wavefront development build: its stages carry RAY_CONNECTED offsets only) */
+    early = false;
+#endif
+    if (wfIters > 0) early = false;
+    c.handoffEarly = early ? 1 : 0;
+    bool firstStage = useQueue && early && wfIters == 0 && !getenv("GDPT_NO_FIRST_STAGE");
     for (const MaterialD &m : s->hostMats)
         if (!(m.type == 0 || (m.type == 2 && !(0.5 * (m.alphaU + m.alphaV) <= c.shiftThreshold)))) firstStage = false;
 #define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
@@ -1117,14 +1130,31 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     const bool cont2 = !s->d.ldsScene && getenv("GDPT_CONT_WPS") && atoi(getenv("GDPT_CONT_WPS")) == 2;
     const size_t lds2 = (size_t)stackDepth * TBLK * sizeof(int) + accBytes;
 #define GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) do { \
-        if (cont2) hipLaunchKernelGGL((k_continue<false, true, 2, ENVV, SMV>), dim3(s->numCUs * 2), block, lds2, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
-        else hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
+        if (cont2) hipLaunchKernelGGL((k_continue<false, true, 2, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 2), block, lds2, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
+        else if (early) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_JOINED>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
+        else hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_CONN>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
 #else
-#define GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill)
+    // (one k_continue per scene residency: the LDS-scene builds carry RAY_RECENTLY_CONNECTED offsets, the HBM-scene builds do not -- GDPT_HANDOFF needs a -DGDPT_DEV_BOTH_HANDOFFS build)
+#ifdef GDPT_DEV_BOTH_HANDOFFS
+#define GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) do { \
+        if (early) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_JOINED>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
+        else hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_CONN>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
+#else
+#define GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, ((LDSV) ? PH_JOINED : PH_CONN)>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill)
 #endif
+#endif
+    // (k_first exists for the builds that can be handed a sample early: the LDS-scene ones -- a generic lambda so that the HBM-scene instantiations are not even compiled)
+#if defined(GDPT_DEV_BOTH_HANDOFFS) || defined(GDPT_DEV_CONT2)
+    constexpr bool firstEverywhere = true;
+#else
+    constexpr bool firstEverywhere = false;
+#endif
+#define GDPT_FIRST(LDSV, ACCV, WPS, ENVV, SMV) [&](auto ldsC) { \
+        if constexpr (decltype(ldsC)::value || firstEverywhere) hipLaunchKernelGGL((k_first<decltype(ldsC)::value, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth); \
+    }(std::integral_constant<bool, LDSV>{})
 #define GDPT_STAGED(LDSV, ACCV, WPS, ENVV, SMV) do { \
         if (shift5) GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV); \
-        else if (firstStage) hipLaunchKernelGGL((k_first<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth); \
+        else if (firstStage) GDPT_FIRST(LDSV, ACCV, WPS, ENVV, SMV); \
         else if (getenv("GDPT_DEV_GENERAL_KERNEL")) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         GDPT_DEV_DUMP_QUEUE(); \
@@ -1177,7 +1207,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
                 // (round 5 experiment, gdpt_film_set_occupancy(1): the first-bounce stage with the whole register file of a SIMD for ONE wave -- 512 registers,
                 //  no spilled path state -- against the default's two waves x 256 + 1.3 KB of scratch per lane; k_continue keeps its two waves.  DESIGN.md)
                 hipLaunchKernelGGL((k_render<true, true, 1, false, false, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes);
-                hipLaunchKernelGGL((k_continue<true, true, 2, false, false>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill);
+                hipLaunchKernelGGL((k_continue<true, true, 2, false, false, PH_JOINED>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill);
             } else
 #endif
             if (s->d.ldsScene) { if (accLds) GDPT_STAGED_F(true, true, 2); else GDPT_STAGED_F(true, false, 2); }
@@ -1195,6 +1225,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #undef GDPT_LAUNCH_W
 #undef GDPT_LAUNCH
 #undef GDPT_STAGED_F
+#undef GDPT_FIRST
 #undef GDPT_CONT_LAUNCH
 #undef GDPT_STAGED
     if (slices > 1 && !f->d.fValues && !useQueue) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);

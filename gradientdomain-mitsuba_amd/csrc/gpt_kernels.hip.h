@@ -192,6 +192,8 @@ struct ConfigD {
     int maxDepth, rrDepth, strictNormals, spp;
     int regenMin;               // idle lanes of a wave before they start new samples together (tuning, not a reference parameter)
     int sBase, sCount;          // the samples [sBase, sBase + sCount) of every pixel are rendered by this launch (spp = the whole count)
+    int handoffEarly;           // staged pipeline: a sample leaves the first-stage kernel as soon as no offset is RAY_NOT_CONNECTED (1: LDS-resident scenes, round 6) or only
+                                // when every offset is RAY_CONNECTED (0: HBM-resident scenes -- their 128-register k_continue pays more for the extra bounce than the first stage saves)
     Float shiftThreshold;
     unsigned long long seed;
 };

@@ -665,7 +665,7 @@ __device__ __forceinline__ void block_setup(const SceneD &S, int stackDepth, uns
 //   0-2 throughput | 3 pdf | 4 eta | 5-7 v.p | 8-10 rayD | 11-12 v.u, v.v | 13 prim (low 32 bits), depth (high) -- all ones once finished |
 //   14 rng state | 15+4i..18+4i offset i: throughput, pdf | 31 alive mask (bits 0-3), RAY_RECENTLY_CONNECTED mask (bits 4-7) |
 //   32-61 the sample's 30 sums so far (finished: its final sums) | 62+3i..64+3i offset i: position of its last own vertex (read while RAY_RECENTLY_CONNECTED)
-// GDPT_HANDOFF_CONNECTED (set by the wavefront development build, whose stages carry RAY_CONNECTED offsets only): the hand-over rule of rounds 2-5.
+// ConfigD::handoffEarly = 0 (HBM-resident scenes; the wavefront development build, whose stages carry RAY_CONNECTED offsets only): the hand-over rule of rounds 2-5.
 constexpr unsigned long long Q_DONE = ~0ULL;
 __device__ __forceinline__ void q_store_main(const FilmD &F, unsigned slot, const Lane &L)
 {
@@ -691,11 +691,9 @@ __device__ __forceinline__ void q_store(const FilmD &F, unsigned slot, const Lan
         const Offset &o = L.off[i];
         qst(&q[(15 + 4 * i) * st], o.throughput.x); qst(&q[(16 + 4 * i) * st], o.throughput.y); qst(&q[(17 + 4 * i) * st], o.throughput.z); qst(&q[(18 + 4 * i) * st], o.pdf);
         alive |= (o.alive ? 1u : 0u) << i;
-#ifndef GDPT_HANDOFF_CONNECTED
-        const bool rc = o.alive && o.status == RAY_RECENTLY_CONNECTED;
+        const bool rc = o.alive && o.status == RAY_RECENTLY_CONNECTED;          // (only the early hand-over leaves any)
         alive |= (rc ? 16u : 0u) << i;
         if (rc) { qst(&q[(62 + 3 * i) * st], o.v.p.x); qst(&q[(63 + 3 * i) * st], o.v.p.y); qst(&q[(64 + 3 * i) * st], o.v.p.z); }
-#endif
     }
     qst(&q[31 * st], __longlong_as_double((long long)alive));
 #pragma unroll
@@ -725,12 +723,10 @@ __device__ __forceinline__ void q_load_lane(const FilmD &F, unsigned slot, Lane 
         Offset &o = L.off[i];
         o.throughput = mk(qld(&q[(15 + 4 * i) * st]), qld(&q[(16 + 4 * i) * st]), qld(&q[(17 + 4 * i) * st])); o.pdf = qld(&q[(18 + 4 * i) * st]);
         o.alive = (alive >> i) & 1; o.status = RAY_CONNECTED;
-#ifndef GDPT_HANDOFF_CONNECTED
         if ((alive >> (4 + i)) & 1) {
             o.status = RAY_RECENTLY_CONNECTED;
             o.v.p = mk(qld(&q[(62 + 3 * i) * st]), qld(&q[(63 + 3 * i) * st]), qld(&q[(64 + 3 * i) * st]));
         }
-#endif
     }
 }
 template <class ACC>
@@ -752,23 +748,14 @@ __device__ __forceinline__ void q_finish(const FilmD &F, unsigned slot, const AC
     for (int k = 0; k < ACC_N; k++) qst(&q[(32 + k) * st], A.get(k));
     qst(&q[13 * st], __longlong_as_double((long long)Q_DONE));
 }
-// the hand-over test: no offset path of the sample is still on its own (RAY_NOT_CONNECTED)
-__device__ __forceinline__ bool all_connected(const Lane &L)
+// the hand-over test: no offset path of the sample is still on its own (early: RAY_NOT_CONNECTED is what keeps a sample; else anything but RAY_CONNECTED does)
+__device__ __forceinline__ bool all_connected(const Lane &L, bool early)
 {
     bool ok = true;
 #pragma unroll
-#ifdef GDPT_HANDOFF_CONNECTED
-    for (int i = 0; i < 4; i++) ok = ok && (!L.off[i].alive || L.off[i].status == RAY_CONNECTED);
-#else
-    for (int i = 0; i < 4; i++) ok = ok && (!L.off[i].alive || L.off[i].status != RAY_NOT_CONNECTED);
-#endif
+    for (int i = 0; i < 4; i++) ok = ok && (!L.off[i].alive || L.off[i].status == RAY_CONNECTED || (early && L.off[i].status == RAY_RECENTLY_CONNECTED));
     return ok;
 }
-#ifdef GDPT_HANDOFF_CONNECTED
-constexpr int PH_CONTINUE = PH_CONN;
-#else
-constexpr int PH_CONTINUE = PH_JOINED;
-#endif
 
 // STAGED: the build the staged pipeline launches (gdpt_film_set_pipeline(2)): primary hits come from k_primary and every sample ends in
 // its queue slot, so the primary traversals, finish_path and the exact generic puts (15 inlined copies with atomics) are not in it at all
@@ -830,7 +817,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_render(SceneD S, Confi
                 // with a queue every sample's sums go to its slot (coalesced, write-only) and k_fold_cont adds them to the pixel once per
                 // chunk; without one they wait in A for the lane's next regeneration (`pending`)
                 if (STAGED || F.qRec) q_finish(F, slot, A); else pending = true;
-            } else if ((STAGED || F.qRec) && all_connected(L)) {
+            } else if ((STAGED || F.qRec) && all_connected(L, cfg.handoffEarly != 0)) {
                 // every offset is connected or dead: the rest of this base path belongs to k_continue (the sums so far travel with it)
                 q_store(F, slot, L, A);
                 const unsigned long long mask = __ballot(true);
@@ -891,7 +878,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_first(SceneD S, Config
                 over = !bounce<ENV, SMOOTH, PH_FIRST, GDPT_UNROLL_OFFSETS(WAVES_PER_SIMD), (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A);
                 // an offset that is alive and still on its own: the base path's next segment would have been its last and met no emitter (:901) -- the path
                 // ends at the depth test of the next bounce (:537), before anything else of that bounce is evaluated
-                if (!over && !all_connected(L)) over = true;
+                if (!over && !all_connected(L, true)) over = true;
             }
             nClosest += L.nClosest; nShadow += L.nShadow;
             if (over) { paths++; pathLen += (unsigned)L.depth; q_finish(F, slot, A); }
@@ -957,7 +944,8 @@ __global__ __launch_bounds__(TBLK) void k_primary(SceneD S, ConfigD cfg, FilmD F
 // The continuation kernel: persistent waves that run handed-off base paths (all offsets connected or dead) to their end.  A lane that
 // finishes writes the sample's final sums back into its record and marks it; idle lanes take the next entries of the queue together
 // (one atomic per wave and refill), so waves stay dense whatever the path lengths are.
-template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
+// PH: PH_JOINED (the records may hold RAY_RECENTLY_CONNECTED offsets: the early hand-over) or PH_CONN (RAY_CONNECTED only)
+template <bool LDS_SCENE, bool ACC_LDS, int WAVES_PER_SIMD, bool ENV, bool SMOOTH, int PH = PH_JOINED>
 __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, ConfigD cfg, FilmD F, int stackDepth, int refillMin)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -990,7 +978,7 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
         }
         if (__ballot(active) == 0) { if (exhausted) break; continue; }
         const InlineTracer tr = {sv, stack};
-        if (active && !bounce<ENV, SMOOTH, PH_CONTINUE, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
+        if (active && !bounce<ENV, SMOOTH, PH, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A)) {
             active = false;
             paths++; pathLen += L.depth;
             q_finish(F, slot, A);
