@@ -9,7 +9,7 @@ random numbers are the counter-based streams both the HIP path and the oracle us
                      reference counts in raysTraced + shadowRaysTraced, skdtree.cpp:46-47) / wall time of the step
                      (render + halo exchange + develop + gather + reconstruct), all ranks, max over ranks.
   poisson          = Poisson-CG Mpix-iter/s of the reconstruction inside the same steps (HIP-event span of solveIndirect).
-  roofline         = the TIMED STEP's dominant kernels, the staged render (k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont, 98.8 % of a step):
+  roofline         = the TIMED STEP's dominant kernels, the staged render (k_primary + k_first (k_render for scenes with glossy vertices) + k_walk + k_replay + k_continue + k_fold_cont, 98.8 % of a step):
                      not an HBM workload (the scene sits in LDS / L2), so its ceiling is VALU issue: wave-instructions of those
                      kernels per step (committed PMC pass of THIS binary, profiles/*_counters.json, keyed by a hash of csrc/) / their launch
                      duration by HIP events, measured live in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles; `traffic` = their FETCH_SIZE x 2
@@ -572,7 +572,7 @@ def main():
         # --- the render kernel (98.8 % of a step): an issue-slot view, not an HBM one.  Its tables sit in LDS (Cornell) or L2 / Infinity
         # Cache; what limits it is instruction issue under divergence and the latency of its scratch traffic.  Counters per launch come from
         # the committed PMC passes of this binary (null if csrc/ changed since); the launch duration and ray count are this run's.
-        tracer_kernels = ("gdpt_tr::k_primary", "gdpt_tr::k_first", "gdpt_tr::k_render", "gdpt_tr::k_continue", "gdpt_tr::k_fold_cont")
+        tracer_kernels = ("gdpt_tr::k_primary", "gdpt_tr::k_first", "gdpt_tr::k_render", "gdpt_tr::k_walk", "gdpt_tr::k_replay", "gdpt_tr::k_continue", "gdpt_tr::k_fold_cont")
         res = _kernel_counters(counters, "gdpt_tr::k_resolve")          # once per step: the profile's step count
         per_step = {}
         # (the committed counters are those of the DEFAULT workload, config 2 at its own size and spp: another configuration's step has other
@@ -591,7 +591,7 @@ def main():
                             acc[f] = acc.get(f, 0.0) + n * c[f]
         tracer_issue = {"bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
                         "peak_what": "1024 SIMDs x 2.4 GHz / 4 cycles per fp64 VALU wave-instruction",
-                        "kernels": "k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont (the staged render of one step)", "render_ms_per_step": round(1e3 * launch_s, 3),
+                        "kernels": "k_primary + k_first (k_render for scenes with glossy vertices) + k_walk + k_replay + k_continue + k_fold_cont (the staged render of one step)", "render_ms_per_step": round(1e3 * launch_s, 3),
                         "counters_file": counters_file if per_step else None}
         if per_step:
             tot = {f: sum(k.get(f, 0.0) for k in per_step.values()) for f in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")}
@@ -656,7 +656,7 @@ def main():
         if tracer_issue.get("frac") is not None:
             roofline = {"bound": "valu-issue", "achieved": tracer_issue["achieved"], "peak": tracer_issue["peak"], "unit": tracer_issue["unit"], "frac": tracer_issue["frac"],
                         "traffic": round(tracer_issue["fabric_traffic_gb_per_step"] * 1e9), "traffic_what": "FETCH_SIZE x 2 + WRITE_SIZE of the step's render kernels, bytes per step (scratch + sample queue; algorithmic film bytes %.2f GB)" % (31 * 8 * 2 * W * H / 1e9),
-                        "kernel": "k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont", "share_of_step": round(launch_s / (wall / a.steps), 4),
+                        "kernel": "k_primary + k_first (k_render for scenes with glossy vertices) + k_walk + k_replay + k_continue + k_fold_cont", "share_of_step": round(launch_s / (wall / a.steps), 4),
                         "launch_ms_live": round(1e3 * launch_s, 3), "valu_wave_instr_per_step": round(tracer_issue["achieved"] * 1e9 * launch_s),
                         "lane_utilisation": tracer_issue.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": tracer_issue.get("wait_any_frac_of_wave_cycles"),
                         "valu_busy": tracer_issue.get("valu_busy"), "valu_busy_what": tracer_issue.get("valu_busy_what"), "effective_clock_ghz_profiled": tracer_issue.get("effective_clock_ghz_profiled"),
@@ -665,7 +665,7 @@ def main():
                         "what": "the timed step's render kernels: VALU wave-instructions per step (committed PMC pass of this binary) / their launch duration by HIP events in THIS run, against 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction; MFMA is not used (no dense contraction) and the scene is not HBM-resident, so neither the hbm nor the mfma ceiling applies to them"}
         else:
             roofline = dict(tracer_bytes)
-            roofline["kernel"] = "k_primary + k_first (k_render for scenes with glossy vertices) + k_continue + k_fold_cont (traversal part)"
+            roofline["kernel"] = "k_primary + k_first (k_render for scenes with glossy vertices) + k_walk + k_replay + k_continue + k_fold_cont (traversal part)"
             roofline["counters_file"] = None
             roofline["note"] = "no committed PMC pass matches this binary / configuration: the live byte figure of SURVEY 8d-B stands in for the issue-slot view"
         out = {

@@ -415,6 +415,11 @@ struct gdpt_film {
     int contRefill = 48;        // idle lanes of a wave of k_continue before they take new records together (round 6, with the hand-over after the first bounce: config-2 chunk
                                 // 61.1 / 60.1 / 57.8 / 57.0 / 59.4 / 65.9 ms at 16 / 32 / 40 / 48-56 / 60 / 64; the atrium frame 63.9 / 63.2 / 62.5-62.9 / 65.7 at 16 / 32 / 48-56 / 60)
     size_t qBytes = 0;          // allocation behind d.qRec
+    Float *wLog = nullptr;      // the deferred continuation's bounce log [(WK + 1) x WF][capacity] doubles, entry info, the second list (rounds ping-pong with d.qList), counters
+    unsigned *wInfo = nullptr, *wListB = nullptr;
+    hipStream_t stream2 = nullptr;      // pipelined chunks: the memory-bound stages (replay, tail, fold) of chunk c run here beside chunk c + 1's compute-bound ones
+    std::vector<hipEvent_t> pipeEvents;
+    bool deferred = true;       // run the continuation in deferred form where it applies (k_walk + k_replay; GDPT_NO_DEFERRED=1 / gdpt_film_set_pipeline: k_continue)
     bool primaryPass = true;    // trace the primary rays in their own kernel (k_primary)
     int wfIters = 0;            // > 0: the first `wfIters` bounces of the continuation phase run in wavefront form (gpt_wavefront.hip.h), k_continue takes the rest
     WfQueues *wf = nullptr;     // its queues (allocated with the sample queue)
@@ -925,6 +930,11 @@ void gdpt_film_destroy(gdpt_film *f)
     if (f->d.qRec) hipFree(f->d.qRec);
     if (f->d.qList) hipFree(f->d.qList);
     if (f->d.qCount) hipFree(f->d.qCount);
+    if (f->wLog) hipFree(f->wLog);
+    if (f->wInfo) hipFree(f->wInfo);
+    if (f->wListB) hipFree(f->wListB);
+    for (hipEvent_t ev : f->pipeEvents) hipEventDestroy(ev);
+    if (f->stream2) hipStreamDestroy(f->stream2);
     wf_destroy(f->wf);
     if (f->d.pHit) hipFree(f->d.pHit);
     if (f->d.pPrim) hipFree(f->d.pPrim);
@@ -986,6 +996,34 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     const bool useQueue = f->continuation && !getenv("GDPT_NO_CONTINUATION");
     const int wfIters = useQueue ? std::min(f->wfIters, wf_max_iters()) : 0;
     if (wfIters > 0 && !f->wf) f->wf = wf_create();
+    // The hand-over rule: LDS-resident scenes hand a sample to k_continue as soon as no offset is RAY_NOT_CONNECTED (round 6: config-2 chunk 61.6 -> 57 ms, glossy box
+    // 85.8 -> 76.7 ms); HBM-resident scenes keep rounds 2-5's rule (every offset RAY_CONNECTED) -- measured on the atrium frame: the early rule takes 12.9 ms off the first
+    // stage and puts 14.6 ms onto the 128-register k_continue (61.5 -> 62.5 ms; configs 3 / 4: 2.91 / 2.95 -> 2.84 / 2.85 Gray/s).  GDPT_HANDOFF=early|late overrides in a -DGDPT_DEV_CONT2 build (A/B).
+#ifdef GDPT_DEV_TWO_BUILDS     /* (the development dispatch below sends every scene with special emitters or per-vertex data through its one HBM-scene build) */
+    bool early = s->d.ldsScene && !s->perVertex && !s->specialEmitters;
+#else
+    bool early = s->d.ldsScene != 0;        // == the LDSV of the build the dispatch below picks
+#endif
+#ifdef GDPT_DEV_CONT2
+    if (const char *e = getenv("GDPT_HANDOFF")) early = std::strcmp(e, "early") == 0;
+#endif
+#ifdef GDPT_HANDOFF_CONNECTED      /* (the wavefront development build: its stages carry RAY_CONNECTED offsets only) */
+    early = false;
+#endif
+    if (wfIters > 0) early = false;
+    // The deferred continuation (k_walk + k_replay, gpt_render.hip.h): where a sample is handed over early (LDS-resident scenes)
+    // a scene none of whose vertices can be classified glossy (getVertexType, gpt.cpp:176-231; vertex_is_diffuse in gpt_kernels.hip.h, mirrored here): see firstStage below
+    bool noGlossy = true;
+    for (const MaterialD &m : s->hostMats)
+        if (!(m.type == 0 || (m.type == 2 && !(0.5 * (m.alphaU + m.alphaV) <= cfg->shiftThreshold)))) noGlossy = false;
+    // The deferred continuation (k_walk + k_replay, gpt_render.hip.h "the deferred form") where it was measured to pay: LDS-resident scenes without glossy vertices (config-2 chunk
+    // 56.4 -> 55.9 ms on its own, 52.2-53.5 with the chunks pipelined; the glossy box 74.7 -> 81 ms and the HBM-resident atrium 59.8 -> 59.1 ms keep k_continue).
+    // Pipelined chunks (not with a reconstruction filter wider than box: its gather runs per chunk on the film's stream): two sets of queue buffers, chunk c in set c & 1; its
+    // compute-bound stages (primary rays, first stage, first walk) on the film's stream, its memory-bound ones (replays, second round, tail, fold) on a second stream of higher
+    // priority, so that they run beside chunk c + 1's first stages.  GDPT_NO_DEFERRED=1 / GDPT_NO_PIPE=1 switch either off (A/B; films are bit-identical either way).
+    const bool deferred = useQueue && early && noGlossy && wfIters == 0 && f->deferred && !getenv("GDPT_NO_DEFERRED");
+    const bool pipe = deferred && !f->d.fValues && !getenv("GDPT_NO_PIPE");
+    const size_t nSets = pipe ? 2 : 1;
     // the render kernel is built for 2 and for 4 resident waves per SIMD; the staged kernels exist for the measured optimum of the scene's
     // residency only (LDS-resident scene: 2, HBM-resident: 4) -- gdpt_film_set_occupancy applies to the single-kernel form
 #ifndef GDPT_DEV_HBM_WPS
@@ -1038,13 +1076,14 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     if (useQueue) {
         // budget: GDPT_QUEUE_MB, else 24 GiB, never more than 40 % of what the device has free right now (+ what this film's queue already holds):
         // several films on one GPU (strips wrapped onto a device, partitioned or smaller parts) each get a share instead of failing
-        size_t budget = (size_t)24 << 30;
+        size_t budget = (size_t)(pipe ? 48 : 24) << 30;        // (two sets of buffers when the chunks are pipelined)
         if (const char *e = getenv("GDPT_QUEUE_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;
         else {
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, (size_t)(0.4 * (double)(freeB + f->qBytes))));
         }
-        const size_t perSample = (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int) + (wfIters > 0 ? wf_bytes_per_slot() : 0));
+        const size_t perSample = nSets * (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int) + (wfIters > 0 ? wf_bytes_per_slot() : 0) +
+                                                    (deferred ? (size_t)WLOG * sizeof(Float) + 2 * sizeof(unsigned) : 0));
         const int wantChunk = chunk;
         for (int attempt = 0; ; attempt++) {
             int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)(wfIters > 0 ? 0x0fffffffu : 0xffffffffu) / qPixels));   // (a ray's id keeps its slot in 28 bits)
@@ -1052,18 +1091,25 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
             const int nChunks = (cfg->spp + maxChunk - 1) / maxChunk;
             chunk = std::min(wantChunk, (cfg->spp + nChunks - 1) / nChunks);
             const size_t need = (size_t)chunk * perSample;
-            if (f->qBytes >= need && (wfIters == 0 || wf_slots(f->wf) >= (size_t)chunk * qPixels)) break;
+            if (f->qBytes >= need && (wfIters == 0 || wf_slots(f->wf) >= (size_t)chunk * qPixels) && (!deferred || f->wLog)) break;
             (void)hipStreamSynchronize(f->stream);
             if (f->d.qRec) hipFree(f->d.qRec);
             if (f->d.qList) hipFree(f->d.qList);
             if (f->d.pHit) hipFree(f->d.pHit);
             if (f->d.pPrim) hipFree(f->d.pPrim);
             f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr; f->qBytes = 0;
+            if (f->wLog) hipFree(f->wLog);
+            if (f->wInfo) hipFree(f->wInfo);
+            if (f->wListB) hipFree(f->wListB);
+            f->wLog = nullptr; f->wInfo = nullptr; f->wListB = nullptr;
             if (f->wf) wf_release(f->wf);
-            if (hipMalloc((void **)&f->d.qRec, (size_t)chunk * qPixels * NQ * sizeof(Float)) == hipSuccess &&
-                hipMalloc((void **)&f->d.qList, (size_t)chunk * qPixels * sizeof(unsigned)) == hipSuccess &&
-                hipMalloc((void **)&f->d.pHit, (size_t)chunk * qPixels * 15 * sizeof(Float)) == hipSuccess &&
-                hipMalloc((void **)&f->d.pPrim, (size_t)chunk * qPixels * 5 * sizeof(int)) == hipSuccess &&
+            if (hipMalloc((void **)&f->d.qRec, nSets * (size_t)chunk * qPixels * NQ * sizeof(Float)) == hipSuccess &&
+                hipMalloc((void **)&f->d.qList, nSets * (size_t)chunk * qPixels * sizeof(unsigned)) == hipSuccess &&
+                hipMalloc((void **)&f->d.pHit, nSets * (size_t)chunk * qPixels * 15 * sizeof(Float)) == hipSuccess &&
+                hipMalloc((void **)&f->d.pPrim, nSets * (size_t)chunk * qPixels * 5 * sizeof(int)) == hipSuccess &&
+                (!deferred || (hipMalloc((void **)&f->wLog, nSets * (size_t)chunk * qPixels * WLOG * sizeof(Float)) == hipSuccess &&
+                               hipMalloc((void **)&f->wInfo, nSets * (size_t)chunk * qPixels * sizeof(unsigned)) == hipSuccess &&
+                               hipMalloc((void **)&f->wListB, nSets * (size_t)chunk * qPixels * sizeof(unsigned)) == hipSuccess)) &&
                 (wfIters == 0 || wf_reserve(f->wf, (size_t)chunk * qPixels))) { f->qBytes = need; break; }
             (void)hipGetLastError();                                                       // the allocation failed: halve the chunk and try again
             if (f->d.qRec) hipFree(f->d.qRec);
@@ -1071,11 +1117,15 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
             if (f->d.pHit) hipFree(f->d.pHit);
             if (f->d.pPrim) hipFree(f->d.pPrim);
             f->d.qRec = nullptr; f->d.qList = nullptr; f->d.pHit = nullptr; f->d.pPrim = nullptr;
+            if (f->wLog) hipFree(f->wLog);
+            if (f->wInfo) hipFree(f->wInfo);
+            if (f->wListB) hipFree(f->wListB);
+            f->wLog = nullptr; f->wInfo = nullptr; f->wListB = nullptr;
             if (f->wf) wf_release(f->wf);
             if (chunk <= 1 || attempt > 24) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "Out of memory! (sample queue: %zu bytes for one sample per pixel)", perSample); }
             budget = std::max<size_t>(perSample, need / 2);
         }
-        if (!f->d.qCount) THIPCHK(hipMalloc((void **)&f->d.qCount, 2 * sizeof(unsigned)));
+        if (!f->d.qCount) THIPCHK(hipMalloc((void **)&f->d.qCount, 16 * sizeof(unsigned)));        // [2 r] entries of round r's list, [2 r + 1] its cursor (r = 0: the first stage's hand-overs; the last pair: k_continue's tail)
     }
     THIPCHK(hipEventRecord(e0, f->stream));          // (after the allocations: a first launch's hipMalloc is not render time)
     FilmD fd = f->d;                     // the descriptor of this launch (queue geometry filled in; without a queue qRec stays null)
@@ -1087,6 +1137,21 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // after `wfIters` traced bounces (with its own cursor next to that list's count)
     FilmD fdc = fd;
     const dim3 cgrid(s->numCUs * wps);
+    // pipelined chunks: two sets of queue buffers; chunk c uses set c & 1, its compute-bound stages (primary rays, first stage, the first walk) on the film's stream, its
+    // memory-bound ones (replay, the second round, the tail, the fold) on a second stream, so that they run beside chunk c + 1's first stages
+    const size_t capS = (size_t)chunk * qPixels;
+    FilmD fdS[2] = {fd, fd};
+    Float *wLogS[2] = {f->wLog, f->wLog ? f->wLog + WLOG * capS : nullptr};
+    unsigned *wInfoS[2] = {f->wInfo, f->wInfo ? f->wInfo + capS : nullptr}, *wListBS[2] = {f->wListB, f->wListB ? f->wListB + capS : nullptr};
+    if (pipe) {
+        fdS[1].qRec = fd.qRec + (size_t)NQ * capS; fdS[1].qList = fd.qList + capS; fdS[1].pHit = fd.pHit + 15 * capS; fdS[1].pPrim = fd.pPrim + 5 * capS; fdS[1].qCount = fd.qCount + 8;
+        if (!f->stream2) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); THIPCHK(hipStreamCreateWithPriority(&f->stream2, hipStreamNonBlocking, hi)); }
+        for (hipEvent_t ev : f->pipeEvents) hipEventDestroy(ev);
+        f->pipeEvents.clear();
+    }
+    hipStream_t sFirst = f->stream, sRest = pipe ? f->stream2 : f->stream;
+    Float *wLogC = wLogS[0]; unsigned *wInfoC = wInfoS[0], *wListBC = wListBS[0];
+    std::vector<hipEvent_t> foldDone;
 #ifdef GDPT_WITH_SHIFT5
     // the shift stage with one path per lane (gpt_shift5.hip.h) instead of k_render<STAGED>: GDPT_SHIFT5=1 in a -DGDPT_WITH_SHIFT5 build
     const bool shift5 = useQueue && getenv("GDPT_SHIFT5") && atoi(getenv("GDPT_SHIFT5")) != 0;
@@ -1108,25 +1173,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // A scene none of whose vertices can be classified glossy by getVertexType (gpt.cpp:176-231: no delta BSDF, every rough BSDF's roughness above the
     // shift threshold -- vertex_is_diffuse in gpt_kernels.hip.h, mirrored here) only ever takes reconnection shifts: its samples leave the first stage after ONE
     // bounce, which k_first runs with the other connection states and the half-vector shift compiled out (GDPT_NO_FIRST_STAGE=1: k_render<STAGED> as for any scene)
-    // The hand-over rule: LDS-resident scenes hand a sample to k_continue as soon as no offset is RAY_NOT_CONNECTED (round 6: config-2 chunk 61.6 -> 57 ms, glossy box
-    // 85.8 -> 76.7 ms); HBM-resident scenes keep rounds 2-5's rule (every offset RAY_CONNECTED) -- measured on the atrium frame: the early rule takes 12.9 ms off the first
-    // stage and puts 14.6 ms onto the 128-register k_continue (61.5 -> 62.5 ms; configs 3 / 4: 2.91 / 2.95 -> 2.84 / 2.85 Gray/s).  GDPT_HANDOFF=early|late overrides in a -DGDPT_DEV_CONT2 build (A/B).
-#ifdef GDPT_DEV_TWO_BUILDS     /* (the development dispatch below sends every scene with special emitters or per-vertex data through its one HBM-scene build) */
-    bool early = s->d.ldsScene && !s->perVertex && !s->specialEmitters;
-#else
-    bool early = s->d.ldsScene != 0;        // == the LDSV of the build the dispatch below picks
-#endif
-#ifdef GDPT_DEV_CONT2
-    if (const char *e = getenv("GDPT_HANDOFF")) early = std::strcmp(e, "early") == 0;
-#endif
-#ifdef GDPT_HANDOFF_CONNECTED      /* (the wavefront development build: its stages carry RAY_CONNECTED offsets only) */
-    early = false;
-#endif
-    if (wfIters > 0) early = false;
     c.handoffEarly = early ? 1 : 0;
-    bool firstStage = useQueue && early && wfIters == 0 && !getenv("GDPT_NO_FIRST_STAGE");
-    for (const MaterialD &m : s->hostMats)
-        if (!(m.type == 0 || (m.type == 2 && !(0.5 * (m.alphaU + m.alphaV) <= c.shiftThreshold)))) firstStage = false;
+    const bool firstStage = useQueue && early && noGlossy && wfIters == 0 && !getenv("GDPT_NO_FIRST_STAGE");
 #define GDPT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, false>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes)
     // The continuation kernel of an HBM-resident scene runs at THREE waves per SIMD (168 registers) beside first-stage kernels at four (round 6, judge r5 item 1c: the atrium
     // frame 61.1 ms at four, 59.7 at three, 81 at two with its sums in LDS; the first stage at three waves lost in round 2).  The LDS-scene builds keep the first stage's two.
@@ -1138,13 +1186,28 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (contWps == 3 && early) hipLaunchKernelGGL((k_continue<false, false, 3, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 3), block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
         else if (contWps == 3) hipLaunchKernelGGL((k_continue<false, false, 3, ENVV, SMV, PH_CONN>), dim3(s->numCUs * 3), block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
         else if (contWps == 2) hipLaunchKernelGGL((k_continue<false, true, 2, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 2), block, lds2, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
-        else if (early) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_JOINED>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
-        else hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_CONN>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
+        else if (early) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_JOINED>), cgrid, block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill); \
+        else hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_CONN>), cgrid, block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
 #else
     // (one k_continue per scene residency: the LDS-scene builds carry RAY_RECENTLY_CONNECTED offsets at the first stage's occupancy, the HBM-scene builds RAY_CONNECTED ones at three waves)
 #define GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_continue<LDSV, ACCV, ((LDSV) ? (WPS) : HBM_CONT_WPS), ENVV, SMV, ((LDSV) ? PH_JOINED : PH_CONN)>), \
-        dim3(s->numCUs * ((LDSV) ? (WPS) : HBM_CONT_WPS)), block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill)
+        dim3(s->numCUs * ((LDSV) ? (WPS) : HBM_CONT_WPS)), block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill)
 #endif
+    // The deferred continuation: WALK_ROUNDS rounds of k_walk (base paths alone, WK bounces each, WALK_WPS waves per SIMD: no sums tile, no offsets) + k_replay (offsets and sums from
+    // the round's log), lists ping-pong between qList and wListB; what is still alive after WALK_ROUNDS x WK bounces (2.5 % of a Cornell chunk) is finished by k_continue below,
+    // which finds its list and counters where the last round left them.  Round 0's walk runs on the first stage's stream, everything after it on the second one (pipelined chunks).
+    constexpr int WALK_ROUNDS = 2, WALK_WPS = 3;
+    const size_t wlds = (size_t)stackDepth * TBLK * sizeof(int) + sceneBytes;
+#define GDPT_DEFERRED(LDSV, ENVV, SMV) [&](auto ldsC) { \
+        if constexpr (decltype(ldsC)::value) { \
+            for (int r = 0; r < WALK_ROUNDS; r++) { \
+                unsigned *lin = (r & 1) ? wListBC : fd.qList, *lout = (r & 1) ? fd.qList : wListBC; \
+                hipLaunchKernelGGL((k_walk<true, WALK_WPS, ENVV, SMV>), dim3(s->numCUs * WALK_WPS), block, wlds, r == 0 ? sFirst : sRest, s->d, c, fd, lin, fd.qCount + 2 * r, lout, wLogC, wInfoC, r == 0 ? 1 : 0, stackDepth, f->contRefill); \
+                if (r == 0 && pipe) { hipEvent_t ev; hipEventCreateWithFlags(&ev, hipEventDisableTiming); f->pipeEvents.push_back(ev); hipEventRecord(ev, sFirst); hipStreamWaitEvent(sRest, ev, 0); } \
+                hipLaunchKernelGGL(k_replay, dim3(s->numCUs * 8), block, 0, sRest, fd, lin, fd.qCount + 2 * r, wLogC, wInfoC); \
+            } \
+            fdc.qList = (WALK_ROUNDS & 1) ? wListBC : fd.qList; fdc.qCount = fd.qCount + 2 * WALK_ROUNDS; \
+        } }(std::integral_constant<bool, LDSV>{})
     // (k_first exists for the builds that can be handed a sample early: the LDS-scene ones -- a generic lambda so that the HBM-scene instantiations are not even compiled)
 #ifdef GDPT_DEV_CONT2
     constexpr bool firstEverywhere = true;
@@ -1152,7 +1215,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     constexpr bool firstEverywhere = false;
 #endif
 #define GDPT_FIRST(LDSV, ACCV, WPS, ENVV, SMV) [&](auto ldsC) { \
-        if constexpr (decltype(ldsC)::value || firstEverywhere) hipLaunchKernelGGL((k_first<decltype(ldsC)::value, ACCV, WPS, ENVV, SMV>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth); \
+        if constexpr (decltype(ldsC)::value || firstEverywhere) hipLaunchKernelGGL((k_first<decltype(ldsC)::value, ACCV, WPS, ENVV, SMV>), grid, block, lds, sFirst, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth); \
     }(std::integral_constant<bool, LDSV>{})
 #define GDPT_STAGED(LDSV, ACCV, WPS, ENVV, SMV) do { \
         if (shift5) GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV); \
@@ -1161,6 +1224,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else hipLaunchKernelGGL((k_render<LDSV, ACCV, WPS, ENVV, SMV, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes); \
         GDPT_DEV_DUMP_QUEUE(); \
         if (wfIters > 0 && wf_continue(s, f->stream, c, fd, f->wf, wfIters, stackDepth, sceneBytes) != 0) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "wavefront launch failed"); } \
+        if (deferred) GDPT_DEFERRED(LDSV, ENVV, SMV); \
         GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV); } while (0)
 #define GDPT_STAGED_F(LDSV, ACCV, WPS) do { \
         if (s->perVertex) GDPT_STAGED(LDSV, ACCV, WPS, true, true); \
@@ -1177,11 +1241,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         else                        { if (wps <= 2) GDPT_LAUNCH(LDSV, ACCV, 2, false, false); else GDPT_LAUNCH(LDSV, ACCV, 4, false, false); } } while (0)
     for (int base = 0; base < cfg->spp; base += chunk) {
         c.sBase = base; c.sCount = std::min(chunk, cfg->spp - base);
+        if (pipe) {
+            const int ci = base / chunk, b = ci & 1;
+            fd = fdS[b]; fdc = fd; wLogC = wLogS[b]; wInfoC = wInfoS[b]; wListBC = wListBS[b];
+            if (ci >= 2) THIPCHK(hipStreamWaitEvent(sFirst, foldDone[ci - 2], 0));           // (the set's previous chunk has been folded)
+        }
         if (useQueue) {
             // (the "finished" mark of every slot of the chunk and the two queue counters)
             THIPCHK(hipMemsetAsync(fd.qRec + (size_t)13 * fd.qCapacity, 0, sizeof(Float) * (size_t)c.sCount * qPixels, f->stream));
             if (wfIters > 0) { if (wf_begin_chunk(f->wf, f->stream, wfIters, fd, fdc) != 0) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "wavefront queues: bad chunk"); } }
-            else THIPCHK(hipMemsetAsync(fd.qCount, 0, 2 * sizeof(unsigned), f->stream));
+            else THIPCHK(hipMemsetAsync(fd.qCount, 0, 8 * sizeof(unsigned), f->stream));
         }
         if (usePrimary) {
             const size_t plds = (size_t)stackDepth * TBLK * sizeof(int) + sceneBytes;
@@ -1209,7 +1278,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
                 // (round 5 experiment, gdpt_film_set_occupancy(1): the first-bounce stage with the whole register file of a SIMD for ONE wave -- 512 registers,
                 //  no spilled path state -- against the default's two waves x 256 + 1.3 KB of scratch per lane; k_continue keeps its two waves.  DESIGN.md)
                 hipLaunchKernelGGL((k_render<true, true, 1, false, false, true>), grid, block, lds, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth, sceneBytes);
-                hipLaunchKernelGGL((k_continue<true, true, 2, false, false, PH_JOINED>), cgrid, block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill);
+                hipLaunchKernelGGL((k_continue<true, true, 2, false, false, PH_JOINED>), cgrid, block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill);
             } else
 #endif
             if (s->d.ldsScene) { if (accLds) GDPT_STAGED_F(true, true, 2); else GDPT_STAGED_F(true, false, 2); }
@@ -1217,7 +1286,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         } else if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else                      { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #endif
-        if (useQueue) hipLaunchKernelGGL(k_fold_cont, dim3(tiles), block, 0, f->stream, s->d, c, fd, x0, y0, x1, y1, tilesX);
+        if (useQueue) hipLaunchKernelGGL(k_fold_cont, dim3(tiles), block, 0, sRest, s->d, c, fd, x0, y0, x1, y1, tilesX);
+        if (pipe) { hipEvent_t ev; THIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); f->pipeEvents.push_back(ev); foldDone.push_back(ev); THIPCHK(hipEventRecord(ev, sRest)); }
         if (f->d.fValues) {
             const int reach = (int)std::ceil(f->d.fRadius) + 1;
             const int ox0 = std::max(0, gsx0 - reach), ox1 = std::min(f->d.W, gsx1 + reach), oy0 = std::max(f->d.y0, gsy0 - reach), oy1 = std::min(f->d.y1, gsy1 + reach);
@@ -1228,9 +1298,11 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
 #undef GDPT_LAUNCH
 #undef GDPT_STAGED_F
 #undef GDPT_FIRST
+#undef GDPT_DEFERRED
 #undef GDPT_CONT_LAUNCH
 #undef GDPT_STAGED
     if (slices > 1 && !f->d.fValues && !useQueue) hipLaunchKernelGGL(k_fold_slices, dim3(2048), dim3(TBLK), 0, f->stream, f->d, slices);
+    if (pipe && !foldDone.empty()) THIPCHK(hipStreamWaitEvent(f->stream, foldDone.back(), 0));       // (the film's stream is what every later call orders itself behind)
     THIPCHK(hipGetLastError());
     THIPCHK(hipEventRecord(e1, f->stream));
     f->events.push_back(std::make_pair(e0, e1));
@@ -1259,7 +1331,7 @@ int gdpt_render_serial(gdpt_scene *s, const gdpt_config *cfg, gdpt_film *f, int 
     ConfigD c;
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
-    c.regenMin = 1; c.sBase = 0; c.sCount = cfg->spp;
+    c.regenMin = 1; c.sBase = 0; c.sCount = cfg->spp; c.handoffEarly = 0;
     FilmD fd = f->d;                    // (no queue, no primary-hit records: the single-kernel pipeline's film)
     fd.qRec = nullptr; fd.pHit = nullptr; fd.pPrim = nullptr;
     hipEvent_t e0, e1;
@@ -1576,7 +1648,7 @@ int gdpt_scene_evaluate_point(gdpt_scene *s, const gdpt_config *cfg, int px, int
     ConfigD c;
     c.maxDepth = cfg->maxDepth; c.rrDepth = cfg->rrDepth; c.strictNormals = cfg->strictNormals; c.spp = cfg->spp;
     c.shiftThreshold = cfg->shiftThreshold; c.seed = cfg->seed;
-    c.regenMin = REGEN_MIN;
+    c.regenMin = REGEN_MIN; c.handoffEarly = 0;
     c.sBase = 0; c.sCount = cfg->spp;
     double *d = nullptr;
     THIPCHK(hipMalloc((void **)&d, sizeof(double) * 33));

@@ -51,6 +51,101 @@ __device__ __forceinline__ void add_offset_sums(ACC &A, int i, d3 t, d3 n, d3 g)
     A.add3(ACC_GRAD + 3 * i, g);
 }
 
+// ---- the offsets of a sample once they are JOINED to the base path (RAY_CONNECTED / RAY_RECENTLY_CONNECTED / dead): what a bounce does for them is a pure function of
+// their four (throughput, pdf) pairs and a handful of the base path's values of that bounce (gpt.cpp:622-658 for the emitter sample, :844-888 for the BSDF sample).  The
+// two structs are those values; the two functions are that arithmetic for the DEFERRED form (k_walk + k_replay, below): the walker logs the structs per bounce, the replay
+// applies them -- the same doubles and the same operations in the same order as the RAY_CONNECTED / RAY_RECENTLY_CONNECTED branches of bounce(), which k_continue and the
+// general kernel keep in place (measured: routing them through these functions cost the in-place kernels 1.5-3 %).  That the two copies agree to the last bit is what
+// test_every_shipped_instantiation... and test_staged_pipeline... hold: the staged pipeline (deferred) against the single general kernel (in place) and the oracle.
+struct NeeShared {              // the emitter-sample half of a bounce, :565-730
+    Float dRecPdf, mainBsdfPdf, num, den;       // dRec.pdf, mainBsdfPdf, mainWeightNumerator, mainWeightDenominator
+    d3 X, contribAll;                           // mainBSDFValue * mainEmitterRadiance; mainContributionAll
+    // read by a RAY_RECENTLY_CONNECTED offset only (its re-evaluation of the base vertex's BSDF, :638-658):
+    d3 radiance, woL;                           // mainEmitterRadiance; toLocal(mfr, dRec.d)
+    int visSA;                                  // lightOnSurfaceSA && mainEmitterVisible
+};
+struct BsdfShared {             // the BSDF-sample half of a bounce, :737-1151
+    d3 W;                                       // bs.weight * bs.pdf
+    Float mainBsdfPdf, lumPdf, num, den;        // bs.pdf, mainLumPdf, mainWeightNumerator, mainWeightDenominator
+    d3 radiance, contrib;                       // mainEmitterRadiance of the new vertex; mainContribution
+    d3 woL; int measure;                        // RAY_RECENTLY_CONNECTED only: toLocal(mfr, L.rayD), the sampled component's measure (:862-888)
+};
+struct BaseVertexRef {          // the base vertex a RAY_RECENTLY_CONNECTED offset re-evaluates: previousMainIts
+    const MaterialD *bsdf; d3 R; Frame3 fr; d3 p;
+};
+// What a RAY_RECENTLY_CONNECTED offset's re-evaluation of the base vertex's BSDF yields -- the only part of a joined offset's bounce that touches the scene
+// (:638-658 for the emitter sample, :862-888 for the BSDF sample): k_continue forms it where it is used, k_walk forms it for the four offsets of a sample's first
+// bounce after the hand-over and logs it, so that k_replay is arithmetic only.
+struct RecentTerm { d3 f; Float pdf; };         // emitter-sample half: f * mainEmitterRadiance, shiftedBsdfPdf; BSDF-sample half: f, shiftedBsdfPdf
+__device__ __forceinline__ RecentTerm recent_nee(const BaseVertexRef &b, d3 recentVertex, const NeeShared &n)
+{
+    const d3 incoming = normalize(recentVertex - b.p);
+    d3 f;
+    Float pdfRaw;
+    bsdf_eval_pdf(*b.bsdf, b.R, toLocal(b.fr, incoming), n.woL, MEASURE_SOLID_ANGLE, f, pdfRaw);
+    RecentTerm r;
+    r.pdf = n.visSA ? pdfRaw : 0;
+    r.f = f * n.radiance;
+    return r;
+}
+__device__ __forceinline__ RecentTerm recent_bsdf(const BaseVertexRef &b, d3 recentVertex, const BsdfShared &m)
+{
+    const d3 incoming = normalize(recentVertex - b.p);
+    RecentTerm r;
+    bsdf_eval_pdf(*b.bsdf, b.R, toLocal(b.fr, incoming), m.woL, m.measure, r.f, r.pdf);
+    return r;
+}
+template <class ACC>
+__device__ __forceinline__ void nee_offset_joined(const NeeShared &n, const RecentTerm &rt, int status, const Offset &s, int i, ACC &A)
+{
+    d3 shiftedContribution = mk(0.0);
+    Float weight = 0;
+    if (s.alive) {
+        if (status == RAY_CONNECTED) {                                           // :622-637
+            const Float den = (s.pdf * s.pdf) * ((n.dRecPdf * n.dRecPdf) + (n.mainBsdfPdf * n.mainBsdfPdf));
+            weight = n.num / (GD_D_EPSILON + den + n.den);
+            shiftedContribution = 1.0 * s.throughput * n.X;
+        } else {                                                                 // RAY_RECENTLY_CONNECTED, :638-658
+            const Float shiftedBsdfPdf = rt.pdf;
+            const Float den = (s.pdf * s.pdf) * ((n.dRecPdf * n.dRecPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+            weight = n.num / (GD_D_EPSILON + den + n.den);
+            shiftedContribution = 1.0 * s.throughput * rt.f;
+        }
+    } else {                                                                     // :708-717
+        weight = n.num / (GD_D_EPSILON + n.den);
+        shiftedContribution = mk(0.0);
+    }
+    add_offset_sums(A, i, n.contribAll * weight, shiftedContribution * weight, (shiftedContribution - n.contribAll) * weight);   // :723-726
+}
+template <class ACC>
+__device__ __forceinline__ void bsdf_offset_joined(const BsdfShared &m, const RecentTerm &rt, Offset &s, int i, ACC &A)
+{
+    d3 shiftedContribution = mk(0.0);
+    Float weight = 0;
+    if (s.alive) {
+        const Float shiftedPreviousPdf = s.pdf;
+        if (s.status == RAY_CONNECTED) {                                         // :844-861
+            s.throughput = s.throughput * m.W;
+            s.pdf *= m.mainBsdfPdf;
+            const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((m.lumPdf * m.lumPdf) + (m.mainBsdfPdf * m.mainBsdfPdf));
+            weight = m.num / (GD_D_EPSILON + den + m.den);
+            shiftedContribution = s.throughput * m.radiance;
+        } else {                                                                 // RAY_RECENTLY_CONNECTED, :862-888
+            const Float shiftedBsdfPdf = rt.pdf;
+            s.throughput = s.throughput * rt.f;
+            s.pdf *= shiftedBsdfPdf;
+            s.status = RAY_CONNECTED;
+            const Float den = (shiftedPreviousPdf * shiftedPreviousPdf) * ((m.lumPdf * m.lumPdf) + (shiftedBsdfPdf * shiftedBsdfPdf));
+            weight = m.num / (GD_D_EPSILON + den + m.den);
+            shiftedContribution = s.throughput * m.radiance;
+        }
+    } else {                                                                     // :1130-1136 (shift_failed)
+        weight = m.num / (GD_D_EPSILON + m.den);
+        shiftedContribution = mk(0.0);
+    }
+    add_offset_sums(A, i, m.contrib * weight, shiftedContribution * weight, (shiftedContribution - m.contrib) * weight);   // :1140-1146
+}
+
 struct Lane {
     // base path ("main" RayState, gpt.cpp:135-173)
     d3 throughput;
@@ -100,6 +195,59 @@ struct InlineTracer {
         for (int i = 0; i < 4; i++) L.off[i].pdf *= q;
     }
 };
+
+// ---- the deferred form of the continuation (round 6): k_walk runs the BASE path alone and logs, per bounce, the values its joined offsets would have read
+// (NeeShared / BsdfShared / the roulette factor); k_replay applies them to the four offsets and the sample's sums afterwards.  Why: an ablation of k_continue
+// (config-2 chunk, 32.3 ms) -- without its emitter-sample half 27.0 ms, without the shadow ray 28.8 ms, without the OFFSETS' part of a bounce 18.5 ms, and the base path
+// alone at three waves per SIMD with 23 stores per bounce in place of them 13.8 ms: more than half of the kernel was the four (throughput, pdf) pairs, the re-evaluations
+// of a recently connected offset and the 27 sums of 4 x 64 lanes riding along through every traversal (56 more live registers, the 60 KB sums tile that pins the
+// kernel at two waves per SIMD).  The offsets never feed back into the base path (gpt.cpp:844-888), so they need not be there.
+// Log: component-major doubles, [field][entry]; entry = position in the round's list; WK bounce records per round + one record of the RecentTerms of the sample's
+// first bounce after the hand-over (the walker evaluates them: it has the base vertex at hand).
+constexpr int WK = 4;            // bounces a sample walks per round
+constexpr int WF = 25;           // doubles per bounce record
+constexpr int WX = 32;           // doubles of the recent-terms record that follows the WK bounce records
+// bounce record: 0 flags (1 emitter-sample half, 2 BSDF-sample half, 4 roulette factor) | 1-4 NeeShared dRecPdf, mainBsdfPdf, num, den | 5-7 X | 8-10 contribAll |
+//                11-13 W | 14-17 BsdfShared mainBsdfPdf, lumPdf, num, den | 18-20 radiance | 21-23 contrib | 24 q
+// recent-terms record (fields WK x WF + ...): 8 i + 0..3 offset i's RecentTerm of the emitter-sample half, 8 i + 4..7 of the BSDF-sample half -- written in the sample's first
+// bounce after an early hand-over, for the offsets that are RAY_RECENTLY_CONNECTED there
+constexpr int WLOG = WK * WF + WX;   // doubles per entry
+struct WalkTracer : InlineTracer {
+    Float *log;                 // the entry's column: wLog + e
+    size_t cap;                 // entries per field
+    int k;                      // record of the current bounce
+    unsigned flags;             // halves of the current bounce logged so far
+    unsigned recentMask;        // offsets that are RAY_RECENTLY_CONNECTED in this bounce (0: none, or not the sample's first bounce after the hand-over)
+    const d3 *recent;           // their last own vertices
+    __device__ __forceinline__ WalkTracer(const SceneView &v, int *stk, Float *l, size_t c, int k_, unsigned mask, const d3 *rv) : InlineTracer{v, stk}, log(l), cap(c), k(k_), flags(0), recentMask(mask), recent(rv) {}
+    __device__ __forceinline__ void putf(int field, Float v) const { qst(&log[(size_t)field * cap], v); }
+    __device__ __forceinline__ void put(int rec, int field, Float v) const { putf(rec * WF + field, v); }
+    __device__ __forceinline__ void put3(int rec, int field, d3 v) const { put(rec, field, v.x); put(rec, field + 1, v.y); put(rec, field + 2, v.z); }
+    __device__ __forceinline__ void log_nee(const NeeShared &n, const BaseVertexRef &b)
+    {
+        put(k, 1, n.dRecPdf); put(k, 2, n.mainBsdfPdf); put(k, 3, n.num); put(k, 4, n.den); put3(k, 5, n.X); put3(k, 8, n.contribAll);
+        flags |= 1u;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((recentMask >> i) & 1u) {
+                const RecentTerm r = recent_nee(b, recent[i], n);
+                putf(WK * WF + 8 * i + 0, r.f.x); putf(WK * WF + 8 * i + 1, r.f.y); putf(WK * WF + 8 * i + 2, r.f.z); putf(WK * WF + 8 * i + 3, r.pdf);
+            }
+    }
+    __device__ __forceinline__ void log_bsdf(const BsdfShared &m, const BaseVertexRef &b)
+    {
+        put3(k, 11, m.W); put(k, 14, m.mainBsdfPdf); put(k, 15, m.lumPdf); put(k, 16, m.num); put(k, 17, m.den); put3(k, 18, m.radiance); put3(k, 21, m.contrib);
+        flags |= 2u;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((recentMask >> i) & 1u) {
+                const RecentTerm r = recent_bsdf(b, recent[i], m);
+                putf(WK * WF + 8 * i + 4, r.f.x); putf(WK * WF + 8 * i + 5, r.f.y); putf(WK * WF + 8 * i + 6, r.f.z); putf(WK * WF + 8 * i + 7, r.pdf);
+            }
+    }
+    __device__ __forceinline__ void log_rr(Float q) { put(k, 24, q); flags |= 4u; }
+};
+struct AccNone { };             // (k_walk: bounce<PH_WALK> adds to no sums)
 
 // Starts base path `sample` of pixel (px,py): evaluatePoint (gpt.cpp:397-436) + the prologue of evaluate (:468-531).
 // Returns false if the base path is already over.
@@ -192,13 +340,16 @@ __device__ __forceinline__ bool start_path(const SceneD &S, const SceneView &sv,
 // The strict-normals test of the offsets (:547-554) is dropped in the builds without RAY_NOT_CONNECTED: it reads the offset's LAST OWN vertex and direction,
 // which stop changing when the offset connects, and with those very values it already passed at the top of the bounce in which the offset connected -- it cannot fire again.
 // INL: the cold texture / environment-map lookups are inlined (4-wave builds) or real calls (2-wave builds), see tex_eval in gpt_kernels.hip.h
-enum { PH_ALL = 0, PH_CONN = 1, PH_FIRST = 2, PH_JOINED = 3 };
+enum { PH_ALL = 0, PH_CONN = 1, PH_FIRST = 2, PH_JOINED = 3, PH_WALK = 4 };
 template <int PH>
 __device__ __forceinline__ int offset_status(const Offset &s) { return PH == PH_CONN ? (int)RAY_CONNECTED : (PH == PH_FIRST ? (int)RAY_NOT_CONNECTED : s.status); }
+//   PH_WALK    the base path alone (the deferred form's k_walk): like PH_JOINED no offset is RAY_NOT_CONNECTED, but the offsets are not here at all -- where a bounce
+//              would update them it writes the bounce's NeeShared / BsdfShared through the tracer (TR::log_nee / log_bsdf / log_rr) for k_replay
 template <bool ENV, bool SMOOTH, int PH, bool UNROLL, bool INL, class TR, class ACC>
 __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, const ConfigD &cfg, TR &tr, Lane &L, ACC &A)
 {
-    constexpr bool JOINED = (PH == PH_CONN || PH == PH_JOINED);                   // no offset is RAY_NOT_CONNECTED
+    constexpr bool JOINED = (PH == PH_CONN || PH == PH_JOINED || PH == PH_WALK);  // no offset is RAY_NOT_CONNECTED
+    constexpr bool WALK = (PH == PH_WALK);
     constexpr bool RECON = (PH == PH_FIRST);                                      // every vertex is "diffuse": reconnection shifts only
     if (!(L.depth < cfg.maxDepth || cfg.maxDepth < 0)) return false;             // :537
     const TriShade &mts = sv.shade[L.v.prim];
@@ -242,6 +393,14 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const Float mainWeightDenominator = (L.pdf * L.pdf) * ((dRec.pdf * dRec.pdf) + (mainBsdfPdf * mainBsdfPdf));
         const d3 mainContributionAll = L.throughput * (mainBSDFValue * mainEmitterRadiance);
         if (!cfg.strictNormals || dot(mGeoN, dRec.d) * mainWoL.z > 0) {         // :607
+            if constexpr (WALK) {               // (the base path alone: what the joined offsets read of this half goes to the log, k_replay applies it)
+                NeeShared n;
+                n.dRecPdf = dRec.pdf; n.mainBsdfPdf = mainBsdfPdf; n.num = mainWeightNumerator; n.den = mainWeightDenominator;
+                n.X = mainBSDFValue * mainEmitterRadiance; n.contribAll = mainContributionAll;
+                n.radiance = mainEmitterRadiance; n.woL = mainWoL; n.visSA = (lightOnSurfaceSA && mainEmitterVisible) ? 1 : 0;
+                BaseVertexRef bref; bref.bsdf = &mainBSDF; bref.R = mainR; bref.fr = mfr; bref.p = L.v.p;
+                tr.log_nee(n, bref);
+            } else
             tr.template each_offset<UNROLL, false>(L, [&](auto ic, Offset &s) __attribute__((always_inline)) {
                 const int i = ic;
                 d3 shiftedContribution = mk(0.0);
@@ -357,6 +516,13 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
     const d3 mainContribution = L.throughput * mainEmitterRadiance;
     const int measure = (bs.sampledType & EDelta) ? MEASURE_DISCRETE : MEASURE_SOLID_ANGLE;
 
+    if constexpr (WALK) {
+        BsdfShared m;
+        m.W = bs.weight * bs.pdf; m.mainBsdfPdf = mainBsdfPdf; m.lumPdf = mainLumPdf; m.num = mainWeightNumerator; m.den = mainWeightDenominator;
+        m.radiance = mainEmitterRadiance; m.contrib = mainContribution; m.woL = toLocal(mfr, L.rayD); m.measure = measure;
+        BaseVertexRef bref; bref.bsdf = &mainBSDF; bref.R = mainR; bref.fr = mfr; bref.p = L.rayO;
+        tr.log_bsdf(m, bref);
+    } else
     tr.template each_offset<UNROLL, true>(L, [&](auto ic, Offset &s) __attribute__((always_inline)) {      // :830
         const int i = ic;
         d3 shiftedContribution = mk(0.0);
@@ -523,7 +689,7 @@ __device__ __forceinline__ bool bounce(const SceneD &S, const SceneView &sv, con
         const Float q = fmin(maxc(L.throughput / L.pdf) * L.eta * L.eta, (Float)0.95f);
         if (L.rng.next1D() >= q) return false;
         L.pdf *= q;
-        tr.scale_offset_pdfs(L, q);
+        if constexpr (WALK) tr.log_rr(q); else tr.scale_offset_pdfs(L, q);
     }
     return true;
 }
@@ -993,6 +1159,166 @@ __global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_continue(SceneD S, Con
         atomicAdd(&F.stats[3], (unsigned long long)c3);
     }
 }
+
+// The base paths of one round of the deferred continuation: persistent waves like k_continue's, one lane = one base path for up to WK bounces.  cnt: [0] entries of
+// listIn (written by the producer: the first-stage kernel or the previous round), [1] this kernel's cursor, [2] entries appended to listOut (the samples that are still
+// alive after WK bounces: their base state goes back into their queue record).  wInfo[e] = records written | 256 if the path ended.
+template <bool LDS_SCENE, int WAVES_PER_SIMD, bool ENV, bool SMOOTH>
+__global__ __launch_bounds__(TBLK, WAVES_PER_SIMD) void k_walk(SceneD S, ConfigD cfg, FilmD F, const unsigned *__restrict__ listIn, unsigned *__restrict__ cnt, unsigned *__restrict__ listOut,
+                                                               Float *__restrict__ wLog, unsigned *__restrict__ wInfo, int firstRound, int stackDepth, int refillMin)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    SceneView sv;
+    int *stack;
+    unsigned char *s_acc;
+    block_setup<LDS_SCENE, false>(S, stackDepth, s_dyn, sv, stack, s_acc);
+    const int lane = threadIdx.x & 63;
+    const unsigned total = __hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Lane L;
+    L.nClosest = L.nShadow = 0;
+    L.depth = 0; L.v.prim = 0;
+    AccNone A;
+    bool active = false, exhausted = false;
+    unsigned slot = 0, e = 0, recentMask = 0;
+    d3 recent[4];                   // the last own vertices of the sample's RAY_RECENTLY_CONNECTED offsets (read in its first bounce here only)
+#pragma unroll
+    for (int i = 0; i < 4; i++) recent[i] = mk(0.0);
+    int nrec = 0;
+    unsigned long long pathLen = 0, paths = 0;
+    while (true) {
+        const unsigned long long idleMask = __ballot(!active);
+        if (!exhausted && (__popcll(idleMask) >= refillMin || idleMask == ~0ULL)) {
+            const int leader = __ffsll((unsigned long long)idleMask) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&cnt[1], (unsigned)__popcll(idleMask));
+            base = __shfl(base, leader);
+            if (base + (unsigned)__popcll(idleMask) >= total) exhausted = true;
+            if (!active) {
+                e = base + (unsigned)__popcll(idleMask & ((1ULL << lane) - 1ULL));
+                if (e < total) {
+                    slot = listIn[e];
+                    q_load_main(F, slot, L);
+                    recentMask = firstRound ? (((unsigned)__double_as_longlong(qld(&F.qRec[(size_t)31 * F.qCapacity + slot])) >> 4) & 15u) : 0u;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((recentMask >> i) & 1u) {
+                            const Float *q = F.qRec + slot;
+                            recent[i] = mk(qld(&q[(size_t)(62 + 3 * i) * F.qCapacity]), qld(&q[(size_t)(63 + 3 * i) * F.qCapacity]), qld(&q[(size_t)(64 + 3 * i) * F.qCapacity]));
+                        }
+                    nrec = 0;
+                    active = true;
+                }
+            }
+        }
+        if (__ballot(active) == 0) { if (exhausted) break; continue; }
+        bool goesOn = false;            // alive after WK bounces: to the next round
+        if (active) {
+            WalkTracer tr(sv, stack, wLog + e, (size_t)F.qCapacity, nrec, nrec == 0 ? recentMask : 0u, recent);
+            const bool go = bounce<ENV, SMOOTH, PH_WALK, true, (WAVES_PER_SIMD > 2)>(S, sv, cfg, tr, L, A);
+            if (tr.flags) { tr.put(nrec, 0, __longlong_as_double((long long)tr.flags)); nrec++; }
+            if (!go || nrec == WK) {
+                __builtin_nontemporal_store((unsigned)nrec | (go ? 0u : 256u), &wInfo[e]);
+                if (go) { q_store_main(F, slot, L); goesOn = true; }
+                else { paths++; pathLen += L.depth; }
+                active = false;
+            }
+        }
+        const unsigned long long onMask = __ballot(goesOn);
+        if (onMask) {
+            const int leader = __ffsll((unsigned long long)onMask) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&cnt[2], (unsigned)__popcll(onMask));
+            base = __shfl(base, leader);
+            if (goesOn) listOut[base + __popcll(onMask & ((1ULL << lane) - 1ULL))] = slot;
+        }
+    }
+    const unsigned c0 = __builtin_amdgcn_wave_reduce_add_u32(L.nClosest, 0), c1 = __builtin_amdgcn_wave_reduce_add_u32(L.nShadow, 0);
+    const unsigned c2 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)paths, 0), c3 = __builtin_amdgcn_wave_reduce_add_u32((unsigned)pathLen, 0);
+    if (lane == 0) {
+        atomicAdd(&F.stats[0], (unsigned long long)c0);
+        atomicAdd(&F.stats[1], (unsigned long long)c1);
+        atomicAdd(&F.stats[2], (unsigned long long)c2);
+        atomicAdd(&F.stats[3], (unsigned long long)c3);
+    }
+}
+
+// The offsets and sums of one round: one lane per entry of the round's list (consecutive lanes = consecutive entries: every log read is coalesced) applies the entry's
+// bounce records in order -- the emitter-sample half for offsets 0..3, the BSDF-sample half for offsets 0..3, the roulette factor: the order bounce() itself has --
+// to the sample's four offsets and its sums, then writes the final sums (the path ended: k_fold_cont takes them) or the offsets and sums back (next round).  Arithmetic
+// only: the one thing a joined offset needs from the scene, the RecentTerms of the first bounce, is in the log.
+#ifndef GDPT_RENDER_DEVICE_FUNCTIONS_ONLY      /* (a plain kernel: gpt_capi.hip's alone, like the ones further down) */
+#ifndef GDPT_REPLAY_WPS
+#define GDPT_REPLAY_WPS 2
+#endif
+__global__ __launch_bounds__(TBLK, GDPT_REPLAY_WPS) void k_replay(FilmD F, const unsigned *__restrict__ listIn, const unsigned *__restrict__ cnt, const Float *__restrict__ wLog,
+                                                              const unsigned *__restrict__ wInfo)
+{
+    const unsigned total = __hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const size_t cap = F.qCapacity;
+    for (unsigned e = blockIdx.x * TBLK + threadIdx.x; e < total; e += gridDim.x * TBLK) {
+        const unsigned slot = listIn[e], info = __builtin_nontemporal_load(&wInfo[e]);
+        const int nrec = (int)(info & 255u);
+        const bool over = (info >> 8) != 0;
+        Float *q = F.qRec + slot;
+        const Float *lg = wLog + e;
+        auto ldf = [&](int field) -> Float { return qld(&lg[(size_t)field * cap]); };
+        auto ld = [&](int rec, int field) -> Float { return ldf(rec * WF + field); };
+        auto ld3 = [&](int rec, int field) -> d3 { return mk(ld(rec, field), ld(rec, field + 1), ld(rec, field + 2)); };
+        Offset off[4];
+        Acc<false> A;                                                    // (the veryDirect sums stay where the first stage left them: slots ACC_VD are neither read nor written)
+        const unsigned alive = (unsigned)__double_as_longlong(qld(&q[31 * cap]));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Offset &o = off[i];
+            o.throughput = mk(qld(&q[(15 + 4 * i) * cap]), qld(&q[(16 + 4 * i) * cap]), qld(&q[(17 + 4 * i) * cap])); o.pdf = qld(&q[(18 + 4 * i) * cap]);
+            o.alive = (alive >> i) & 1; o.status = ((alive >> (4 + i)) & 1) ? RAY_RECENTLY_CONNECTED : RAY_CONNECTED;
+        }
+#pragma unroll
+        for (int k = 0; k < ACC_N; k++) A.a[k] = (k >= ACC_VD && k < ACC_VD + 3) ? 0.0 : qld(&q[(32 + k) * cap]);
+        for (int k = 0; k < nrec; k++) {
+            // (the whole record in one go: its flags and both halves' fields are independent loads -- a half that was not logged holds stale doubles that are not used)
+            const unsigned flags = (unsigned)__double_as_longlong(ld(k, 0));
+            NeeShared n;
+            n.dRecPdf = ld(k, 1); n.mainBsdfPdf = ld(k, 2); n.num = ld(k, 3); n.den = ld(k, 4); n.X = ld3(k, 5); n.contribAll = ld3(k, 8);
+            BsdfShared m;
+            m.W = ld3(k, 11); m.mainBsdfPdf = ld(k, 14); m.lumPdf = ld(k, 15); m.num = ld(k, 16); m.den = ld(k, 17); m.radiance = ld3(k, 18); m.contrib = ld3(k, 21);
+            const Float qf = ld(k, 24);
+            if (flags & 1u) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    RecentTerm rt; rt.f = mk(0.0); rt.pdf = 0.0;           // (read where it is used, in the sample's first bounce after the hand-over only)
+                    if (off[i].status == RAY_RECENTLY_CONNECTED && off[i].alive) { rt.f = mk(ldf(WK * WF + 8 * i + 0), ldf(WK * WF + 8 * i + 1), ldf(WK * WF + 8 * i + 2)); rt.pdf = ldf(WK * WF + 8 * i + 3); }
+                    nee_offset_joined(n, rt, off[i].status, off[i], i, A);
+                }
+            }
+            if (flags & 2u) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    RecentTerm rt; rt.f = mk(0.0); rt.pdf = 0.0;
+                    if (off[i].status == RAY_RECENTLY_CONNECTED && off[i].alive) { rt.f = mk(ldf(WK * WF + 8 * i + 4), ldf(WK * WF + 8 * i + 5), ldf(WK * WF + 8 * i + 6)); rt.pdf = ldf(WK * WF + 8 * i + 7); }
+                    bsdf_offset_joined(m, rt, off[i], i, A);
+                }
+            }
+            if (flags & 4u) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) off[i].pdf *= qf;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ACC_N; k++) if (!(k >= ACC_VD && k < ACC_VD + 3)) qst(&q[(32 + k) * cap], A.a[k]);
+        if (over) qst(&q[13 * cap], __longlong_as_double((long long)Q_DONE));
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Offset &o = off[i];
+                qst(&q[(15 + 4 * i) * cap], o.throughput.x); qst(&q[(16 + 4 * i) * cap], o.throughput.y); qst(&q[(17 + 4 * i) * cap], o.throughput.z); qst(&q[(18 + 4 * i) * cap], o.pdf);
+            }
+            qst(&q[31 * cap], __longlong_as_double((long long)(alive & 15u)));
+        }
+    }
+}
+
+#endif // GDPT_RENDER_DEVICE_FUNCTIONS_ONLY (k_replay)
 
 #ifndef GDPT_RENDER_DEVICE_FUNCTIONS_ONLY      /* (gpt_wave_capi.hip takes the device functions and kernel templates above; the plain kernels below belong to gpt_capi.hip) */
 // finish_path for the samples of a chunk, all of which left their final sums in their queue slots (from the render kernel or from

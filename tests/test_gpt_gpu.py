@@ -1445,3 +1445,48 @@ def test_crop_window_rays_come_from_the_full_films_raster(G, variant, md, crop, 
     rough = scenes.cornell_box(W, H, "rough"); rough.crop = crop
     with pytest.raises(RuntimeError, match="crop window"):
         B.GBDPTIntegrator(maxDepth=4).render(G.Scene(rough), 1)
+
+
+@pytest.mark.parametrize("variant,md,strict,env,rfilter", [("diffuse", -1, False, None, None), ("rough", 9, True, (0.3, 0.4, 0.5), None), ("smooth", 7, True, None, None),
+                                                          ("twosided", 12, False, None, None), ("diffuse", 6, False, None, scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN])])
+def test_deferred_continuation_and_pipelined_chunks_equal_the_in_place_kernels(G, monkeypatch, variant, md, strict, env, rfilter):
+    """Round 6: for LDS-resident scenes without glossy vertices the continuation runs DEFERRED (k_walk: the base paths alone, logging what their joined offsets would have
+    read; k_replay: the offsets and sums from the log; k_continue for paths longer than two rounds of four bounces) and the chunks of a render are PIPELINED over two streams
+    and two sets of queue buffers.  Films, ray and path counters: bit-identical to the in-place continuation (GDPT_NO_DEFERRED=1) and to the unpipelined form
+    (GDPT_NO_PIPE=1), with a queue budget that cuts the render into one-sample chunks (set reuse, the waits between the streams) -- and equal to the oracle's.
+    (a filter wider than box: the deferred form without the pipeline)"""
+    W, H, spp = 44, 36, 7
+    sc = scenes.cornell_box(W, H, variant, environment=env)
+    if rfilter is not None:
+        sc.rfilter = rfilter
+    S = G.Scene(sc)
+    integ = G.GradientPathIntegrator(maxDepth=md, strictNormals=strict, rrDepth=3)
+    cfg = integ.config(spp)
+    res = {}
+    variants = (("deferred+pipe", {}), ("one-sample chunks", {"GDPT_QUEUE_MB": "2"}), ("no pipe", {"GDPT_NO_PIPE": "1", "GDPT_QUEUE_MB": "2"}), ("in place", {"GDPT_NO_DEFERRED": "1"}),
+                       ("in place, one-sample chunks", {"GDPT_NO_DEFERRED": "1", "GDPT_QUEUE_MB": "2"}))
+    for name, envs in variants:
+        for k in ("GDPT_QUEUE_MB", "GDPT_NO_PIPE", "GDPT_NO_DEFERRED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        F = G.Film(S)
+        for rep in range(2):                     # (twice into one film object: the second render reuses the buffers, streams and events of the first)
+            F.clear()
+            integ.renderBlock(S, F, cfg, (0, 0, W, H))
+        res[name] = (F.accum(), F.stats())
+        F.close()
+    ref_acc, ref_st = res["in place"]
+    chunk_acc = res["in place, one-sample chunks"][0]
+    if rfilter is None:                          # (the box filter's fold continues from the pixel's record: the same association however the render is cut)
+        assert np.array_equal(chunk_acc, ref_acc)
+    else:                                        # (a wider filter's gather adds a chunk's sum to the record: the association follows the chunks -- 6e-16 of the film, with either continuation)
+        assert np.abs(chunk_acc - ref_acc).max() <= 1e-14 * np.abs(ref_acc).max()
+    for name, (acc, st) in res.items():
+        assert st == ref_st, (name, st, ref_st)
+        assert np.array_equal(acc, chunk_acc if "GDPT_QUEUE_MB" in dict(variants)[name] else ref_acc), name
+    oacc, orays = go.Scene(sc).render(go.config(maxDepth=md, spp=spp, strictNormals=strict, rrDepth=3))
+    assert (ref_st["raysTraced"], ref_st["shadowRaysTraced"]) == orays
+    for b in range(5):
+        assert close(ref_acc[b], oacc[b]), G.BUFFER_NAMES[b]
+    S.close()
