@@ -996,13 +996,23 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     const bool useQueue = f->continuation && !getenv("GDPT_NO_CONTINUATION");
     const int wfIters = useQueue ? std::min(f->wfIters, wf_max_iters()) : 0;
     if (wfIters > 0 && !f->wf) f->wf = wf_create();
-    // The hand-over rule: LDS-resident scenes hand a sample to k_continue as soon as no offset is RAY_NOT_CONNECTED (round 6: config-2 chunk 61.6 -> 57 ms, glossy box
-    // 85.8 -> 76.7 ms); HBM-resident scenes keep rounds 2-5's rule (every offset RAY_CONNECTED) -- measured on the atrium frame: the early rule takes 12.9 ms off the first
-    // stage and puts 14.6 ms onto the 128-register k_continue (61.5 -> 62.5 ms; configs 3 / 4: 2.91 / 2.95 -> 2.84 / 2.85 Gray/s).  GDPT_HANDOFF=early|late overrides in a -DGDPT_DEV_CONT2 build (A/B).
+    // A scene none of whose vertices can be classified glossy (getVertexType, gpt.cpp:176-231; vertex_is_diffuse in gpt_kernels.hip.h, mirrored here): the one-bounce first
+    // stage (k_first) and the deferred continuation apply to it.
+    bool noGlossy = true;
+    for (const MaterialD &m : s->hostMats)
+        if (!(m.type == 0 || (m.type == 2 && !(0.5 * (m.alphaU + m.alphaV) <= cfg->shiftThreshold)))) noGlossy = false;
+    // The deferred continuation (k_walk + k_replay, gpt_render.hip.h "the deferred form") for scenes without glossy vertices: LDS-resident ones (config-2 chunk 56.4 -> 55.9 ms
+    // on its own, 52.2-53.5 with the chunks pipelined; the glossy box 74.7 -> 81 ms keeps k_continue) and HBM-resident ones (below).  GDPT_NO_DEFERRED=1 switches it off (A/B).
+    const bool deferrable = useQueue && noGlossy && wfIters == 0 && f->deferred && !getenv("GDPT_NO_DEFERRED");
+    // The hand-over rule: LDS-resident scenes hand a sample to the continuation as soon as no offset is RAY_NOT_CONNECTED (round 6: config-2 chunk 61.6 -> 57 ms, glossy box
+    // 85.8 -> 76.7 ms).  HBM-resident scenes: with the in-place k_continue rounds 2-5's rule (every offset RAY_CONNECTED) -- on the atrium frame the early rule takes 12.9 ms off
+    // the first stage and puts 14.6 ms onto the 128-register k_continue (61.5 -> 62.5 ms) --; with the DEFERRED continuation the early rule, because there the bounce with
+    // RAY_RECENTLY_CONNECTED offsets is the walker's (its recent terms) and the replay's, not a 128-register kernel's: k_first 20.9 ms instead of k_render<STAGED> 33.6, the frame
+    // 59.8 -> 53.8 ms (+11 %), films bit-identical.  GDPT_HANDOFF=early|late overrides in a -DGDPT_DEV_CONT2 build (A/B).
 #ifdef GDPT_DEV_TWO_BUILDS     /* (the development dispatch below sends every scene with special emitters or per-vertex data through its one HBM-scene build) */
-    bool early = s->d.ldsScene && !s->perVertex && !s->specialEmitters;
+    bool early = (s->d.ldsScene && !s->perVertex && !s->specialEmitters) || deferrable;
 #else
-    bool early = s->d.ldsScene != 0;        // == the LDSV of the build the dispatch below picks
+    bool early = s->d.ldsScene != 0 || deferrable;
 #endif
 #ifdef GDPT_DEV_CONT2
     if (const char *e = getenv("GDPT_HANDOFF")) early = std::strcmp(e, "early") == 0;
@@ -1011,17 +1021,10 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     early = false;
 #endif
     if (wfIters > 0) early = false;
-    // The deferred continuation (k_walk + k_replay, gpt_render.hip.h): where a sample is handed over early (LDS-resident scenes)
-    // a scene none of whose vertices can be classified glossy (getVertexType, gpt.cpp:176-231; vertex_is_diffuse in gpt_kernels.hip.h, mirrored here): see firstStage below
-    bool noGlossy = true;
-    for (const MaterialD &m : s->hostMats)
-        if (!(m.type == 0 || (m.type == 2 && !(0.5 * (m.alphaU + m.alphaV) <= cfg->shiftThreshold)))) noGlossy = false;
-    // The deferred continuation (k_walk + k_replay, gpt_render.hip.h "the deferred form") where it was measured to pay: LDS-resident scenes without glossy vertices (config-2 chunk
-    // 56.4 -> 55.9 ms on its own, 52.2-53.5 with the chunks pipelined; the glossy box 74.7 -> 81 ms and the HBM-resident atrium 59.8 -> 59.1 ms keep k_continue).
     // Pipelined chunks (not with a reconstruction filter wider than box: its gather runs per chunk on the film's stream): two sets of queue buffers, chunk c in set c & 1; its
     // compute-bound stages (primary rays, first stage, first walk) on the film's stream, its memory-bound ones (replays, second round, tail, fold) on a second stream of higher
-    // priority, so that they run beside chunk c + 1's first stages.  GDPT_NO_DEFERRED=1 / GDPT_NO_PIPE=1 switch either off (A/B; films are bit-identical either way).
-    const bool deferred = useQueue && early && noGlossy && wfIters == 0 && f->deferred && !getenv("GDPT_NO_DEFERRED");
+    // priority, so that they run beside chunk c + 1's first stages.  GDPT_NO_PIPE=1 switches it off (A/B; films are bit-identical either way).
+    const bool deferred = deferrable && early;
     const bool pipe = deferred && !f->d.fValues && !getenv("GDPT_NO_PIPE");
     const size_t nSets = pipe ? 2 : 1;
     // the render kernel is built for 2 and for 4 resident waves per SIMD; the staged kernels exist for the measured optimum of the scene's
@@ -1183,9 +1186,9 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     const int contWps = s->d.ldsScene ? 0 : (getenv("GDPT_CONT_WPS") ? atoi(getenv("GDPT_CONT_WPS")) : HBM_CONT_WPS);
     const size_t lds2 = (size_t)stackDepth * TBLK * sizeof(int) + accBytes;
 #define GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV) do { \
-        if (contWps == 3 && early) hipLaunchKernelGGL((k_continue<false, false, 3, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 3), block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
-        else if (contWps == 3) hipLaunchKernelGGL((k_continue<false, false, 3, ENVV, SMV, PH_CONN>), dim3(s->numCUs * 3), block, lds, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
-        else if (contWps == 2) hipLaunchKernelGGL((k_continue<false, true, 2, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 2), block, lds2, f->stream, s->d, c, fdc, stackDepth, f->contRefill); \
+        if (contWps == 3 && early) hipLaunchKernelGGL((k_continue<false, false, 3, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 3), block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill); \
+        else if (contWps == 3) hipLaunchKernelGGL((k_continue<false, false, 3, ENVV, SMV, PH_CONN>), dim3(s->numCUs * 3), block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill); \
+        else if (contWps == 2) hipLaunchKernelGGL((k_continue<false, true, 2, ENVV, SMV, PH_JOINED>), dim3(s->numCUs * 2), block, lds2, sRest, s->d, c, fdc, stackDepth, f->contRefill); \
         else if (early) hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_JOINED>), cgrid, block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill); \
         else hipLaunchKernelGGL((k_continue<LDSV, ACCV, WPS, ENVV, SMV, PH_CONN>), cgrid, block, lds, sRest, s->d, c, fdc, stackDepth, f->contRefill); } while (0)
 #else
@@ -1196,27 +1199,21 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // The deferred continuation: WALK_ROUNDS rounds of k_walk (base paths alone, WK bounces each, WALK_WPS waves per SIMD: no sums tile, no offsets) + k_replay (offsets and sums from
     // the round's log), lists ping-pong between qList and wListB; what is still alive after WALK_ROUNDS x WK bounces (2.5 % of a Cornell chunk) is finished by k_continue below,
     // which finds its list and counters where the last round left them.  Round 0's walk runs on the first stage's stream, everything after it on the second one (pipelined chunks).
-    constexpr int WALK_ROUNDS = 2, WALK_WPS = 3;
+    // (the walker of an HBM-resident scene at four waves per SIMD: atrium frame 53.8 ms, at three 55.3)
+    constexpr int WALK_ROUNDS = 2, WALK_WPS = 3, HBM_WALK_WPS = 4;
     const size_t wlds = (size_t)stackDepth * TBLK * sizeof(int) + sceneBytes;
 #define GDPT_DEFERRED(LDSV, ENVV, SMV) [&](auto ldsC) { \
-        if constexpr (decltype(ldsC)::value) { \
+        { \
+            constexpr int WWPS = decltype(ldsC)::value ? WALK_WPS : HBM_WALK_WPS; \
             for (int r = 0; r < WALK_ROUNDS; r++) { \
                 unsigned *lin = (r & 1) ? wListBC : fd.qList, *lout = (r & 1) ? fd.qList : wListBC; \
-                hipLaunchKernelGGL((k_walk<true, WALK_WPS, ENVV, SMV>), dim3(s->numCUs * WALK_WPS), block, wlds, r == 0 ? sFirst : sRest, s->d, c, fd, lin, fd.qCount + 2 * r, lout, wLogC, wInfoC, r == 0 ? 1 : 0, stackDepth, f->contRefill); \
+                hipLaunchKernelGGL((k_walk<decltype(ldsC)::value, WWPS, ENVV, SMV>), dim3(s->numCUs * WWPS), block, wlds, r == 0 ? sFirst : sRest, s->d, c, fd, lin, fd.qCount + 2 * r, lout, wLogC, wInfoC, r == 0 ? 1 : 0, stackDepth, f->contRefill); \
                 if (r == 0 && pipe) { hipEvent_t ev; hipEventCreateWithFlags(&ev, hipEventDisableTiming); f->pipeEvents.push_back(ev); hipEventRecord(ev, sFirst); hipStreamWaitEvent(sRest, ev, 0); } \
                 hipLaunchKernelGGL(k_replay, dim3(s->numCUs * 8), block, 0, sRest, fd, lin, fd.qCount + 2 * r, wLogC, wInfoC); \
             } \
             fdc.qList = (WALK_ROUNDS & 1) ? wListBC : fd.qList; fdc.qCount = fd.qCount + 2 * WALK_ROUNDS; \
         } }(std::integral_constant<bool, LDSV>{})
-    // (k_first exists for the builds that can be handed a sample early: the LDS-scene ones -- a generic lambda so that the HBM-scene instantiations are not even compiled)
-#ifdef GDPT_DEV_CONT2
-    constexpr bool firstEverywhere = true;
-#else
-    constexpr bool firstEverywhere = false;
-#endif
-#define GDPT_FIRST(LDSV, ACCV, WPS, ENVV, SMV) [&](auto ldsC) { \
-        if constexpr (decltype(ldsC)::value || firstEverywhere) hipLaunchKernelGGL((k_first<decltype(ldsC)::value, ACCV, WPS, ENVV, SMV>), grid, block, lds, sFirst, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth); \
-    }(std::integral_constant<bool, LDSV>{})
+#define GDPT_FIRST(LDSV, ACCV, WPS, ENVV, SMV) hipLaunchKernelGGL((k_first<LDSV, ACCV, WPS, ENVV, SMV>), grid, block, lds, sFirst, s->d, c, fd, x0, y0, x1, y1, tilesX, tiles, slices, stackDepth)
 #define GDPT_STAGED(LDSV, ACCV, WPS, ENVV, SMV) do { \
         if (shift5) GDPT_SHIFT5_LAUNCH(LDSV, ENVV, SMV); \
         else if (firstStage) GDPT_FIRST(LDSV, ACCV, WPS, ENVV, SMV); \

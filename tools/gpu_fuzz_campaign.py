@@ -82,7 +82,11 @@ for seed in range(first, first + count):
         px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
         g = S.evaluate_point(cfg, px, py, s); o = O.evaluate_point(ocfg, px, py, s)
         for key in ("veryDirect", "throughput", "gradients", "neighbours"):
-            if not np.allclose(g[key], o[key], rtol=1e-9, atol=1e-13):
+            # (a gradient is the DIFFERENCE of two path contributions, w (f(offset) - f(base)): where they nearly cancel its error relative to itself has no bound in any
+            #  floating-point implementation, so its bar is 1e-9 of the two contributions it is the difference of -- seed 2515818: a base path through an alpha = 0.0023
+            #  conductor lobe, throughput equal to 5e-12, gradient 1/180 of it and "off" by 1.3e-9 of itself)
+            atol = 1e-13 + (1e-9 * (np.abs(o["throughput"])[None, :] + np.abs(o["neighbours"])) if key == "gradients" else 0.0)
+            if not (np.abs(g[key] - o[key]) <= atol + 1e-9 * np.abs(o[key])).all():
                 # ill-conditioned sample (near-specular lobes: D(h) ~ 1/alpha^2)?  Measure the oracle's own sensitivity to few-ulp scalings of
                 # the geometry; a difference within 20x of that is rounding noise of the sample, not of the implementation
                 sens = np.zeros_like(o[key])
@@ -145,4 +149,4 @@ for seed in range(first, first + count):
     if (seed - first) % 20 == 19:
         print("seed %d: %d probes, %d films ok, worst film rel diff %.2e, %.0f s" % (seed, probes, films, worst, time.time() - t0), flush=True)
 print("OK: seeds %d..%d, %d probes (%d outputs beyond 1e-9 on ill-conditioned samples, worst %.1e, each within 20x of the oracle's own sensitivity to few-ulp scalings of the geometry), %d films + %d with a knife-edge ray-count difference (%d film buffers beyond 1e-9, within 20x of the oracle's own spread), worst film rel diff %.2e, %.0f s" % (first, first + count - 1, probes, illcond, worst_ill, films, knife, illfilm, worst, time.time() - t0))
-fuzz_summary.emit("gpu_fuzz_campaign", first, count, time.time() - t0, probes=probes, films=films, ill_conditioned_outputs=illcond, worst_ill_conditioned_rel=worst_ill, knife_edge_ray_count_films=knife, ill_conditioned_film_buffers=illfilm, worst_film_rel_diff=worst, bars="samples rtol 1e-9 / atol 1e-13, films 1e-9 of the buffer scale; beyond: within 20x of the oracle's own sensitivity to few-ulp scalings / 2^-30 rad rotations")
+fuzz_summary.emit("gpu_fuzz_campaign", first, count, time.time() - t0, probes=probes, films=films, ill_conditioned_outputs=illcond, worst_ill_conditioned_rel=worst_ill, knife_edge_ray_count_films=knife, ill_conditioned_film_buffers=illfilm, worst_film_rel_diff=worst, bars="samples rtol 1e-9 / atol 1e-13 (gradients: + 1e-9 of the two contributions they are the difference of), films 1e-9 of the buffer scale; beyond: within 20x of the oracle's own sensitivity to few-ulp scalings / 2^-30 rad rotations")
