@@ -1060,7 +1060,8 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         THIPCHK(hipMemsetAsync(f->d.recExtra, 0, bytes, f->stream));      // planes stay zero between launches (k_fold_slices clears them)
     }
     f->lastSlices = slices;
-    const dim3 grid(tiles * slices), block(TBLK);
+    dim3 grid(tiles * slices);
+    const dim3 block(TBLK);
     // A reconstruction filter wider than box: samples are rendered in chunks into the sample log and gathered after each chunk
     int chunk = cfg->spp;
     if (f->d.fValues) {
@@ -1080,13 +1081,16 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         // budget: GDPT_QUEUE_MB, else 24 GiB, never more than 40 % of what the device has free right now (+ what this film's queue already holds):
         // several films on one GPU (strips wrapped onto a device, partitioned or smaller parts) each get a share instead of failing
         size_t budget = (size_t)(pipe ? 48 : 24) << 30;        // (two sets of buffers when the chunks are pipelined)
+        const size_t perSample = nSets * (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int) + (wfIters > 0 ? wf_bytes_per_slot() : 0) +
+                                                    (deferred ? (size_t)WLOG * sizeof(Float) + 2 * sizeof(unsigned) : 0));
         if (const char *e = getenv("GDPT_QUEUE_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;
         else {
+            // (a chunk of the deferred form holds at least TWO samples per pixel where the memory is there -- a 3840x2160 frame's slots are 30 GB per sample: chunks of one /
+            //  two / three samples 56.8 / 54.2 / 53.7 ms per sample per pixel on the atrium)
+            if (deferred) budget = std::max(budget, 2 * perSample);
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) budget = std::min(budget, std::max<size_t>((size_t)64 << 20, (size_t)(0.4 * (double)(freeB + f->qBytes))));
         }
-        const size_t perSample = nSets * (size_t)qPixels * (NQ * sizeof(Float) + sizeof(unsigned) + 15 * sizeof(Float) + 5 * sizeof(int) + (wfIters > 0 ? wf_bytes_per_slot() : 0) +
-                                                    (deferred ? (size_t)WLOG * sizeof(Float) + 2 * sizeof(unsigned) : 0));
         const int wantChunk = chunk;
         for (int attempt = 0; ; attempt++) {
             int maxChunk = (int)std::max<size_t>(1, std::min<size_t>(budget / perSample, (size_t)(wfIters > 0 ? 0x0fffffffu : 0xffffffffu) / qPixels));   // (a ray's id keeps its slot in 28 bits)
@@ -1128,6 +1132,9 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
             if (chunk <= 1 || attempt > 24) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "Out of memory! (sample queue: %zu bytes for one sample per pixel)", perSample); }
             budget = std::max<size_t>(perSample, need / 2);
         }
+        // Sample slices of a staged launch need samples to slice: two slices of a ONE-sample chunk leave every other block of the first stage without a sample (3840x2160
+        // atrium: 63.2 against 56.8 ms per sample per pixel; chunks of two / three samples: 55.3 / 54.2 against 54.2 / 53.7; from six on no difference) -- one slice below eight.
+        if (f->slices <= 0 && slices > std::max(1, chunk / 4)) { slices = std::max(1, chunk / 4); f->lastSlices = slices; grid = dim3(tiles * slices); }
         if (!f->d.qCount) THIPCHK(hipMalloc((void **)&f->d.qCount, 16 * sizeof(unsigned)));        // [2 r] entries of round r's list, [2 r + 1] its cursor (r = 0: the first stage's hand-overs; the last pair: k_continue's tail)
     }
     THIPCHK(hipEventRecord(e0, f->stream));          // (after the allocations: a first launch's hipMalloc is not render time)
