@@ -102,7 +102,13 @@ for seed in range(first, first + count):
         probes += 1
     F = G.Film(S)
     F.set_slices(int(rng.integers(0, spp + 1))); F.set_regeneration(int(rng.choice([1, 24, 56, 64])))
+    # (round 6: every other film with a sample-queue budget of 2 / 8 / 16 / 24 MiB, i.e. cut into chunks of one to a few samples -- the pipelined chunks' set reuse and stream waits;
+    #  the draw comes from a generator of its own so that the seeds' scenes and probes stay what they were)
+    os.environ.pop("GDPT_QUEUE_MB", None)
+    if seed % 2:
+        os.environ["GDPT_QUEUE_MB"] = str((2, 8, 16, 24)[(seed // 2) % 4])
     integ.renderBlock(S, F, cfg, (0, 0, W, H))
+    os.environ.pop("GDPT_QUEUE_MB", None)
     acc = F.accum(); st = F.stats()
     oacc, orays = O.render(ocfg)
     if (st["raysTraced"], st["shadowRaysTraced"]) != orays:
