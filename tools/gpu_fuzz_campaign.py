@@ -51,6 +51,7 @@ def rotated(sc):
             yield sc2
 
 
+FILM_SCALE = int(os.environ.get("FUZZ_FILM_SCALE", "1")); PROBES = int(os.environ.get("FUZZ_PROBES", "40"))
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 t0 = time.time()
@@ -59,6 +60,7 @@ worst = worst_ill = 0.0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(17, 44)), int(rng.integers(9, 34))
+    W, H = W * FILM_SCALE, H * FILM_SCALE       # (FUZZ_FILM_SCALE=5: films of up to 215 x 165 -- many tiles, waves that refill from long lists, several chunks; same scenes and settings per seed)
     kind = "random"
     kw = dict(seed=seed, environment=(0.5, 0.7, 0.9) if seed % 3 == 0 else None)
     if seed % 5 == 1:
@@ -78,7 +80,7 @@ for seed in range(first, first + count):
     S = G.Scene(sc); O = go.Scene(sc)
     integ = G.GradientPathIntegrator(maxDepth=md, rrDepth=rr, strictNormals=strict, shiftThreshold=thr)
     cfg = integ.config(spp); ocfg = go.config(maxDepth=md, rrDepth=rr, strictNormals=strict, spp=spp, shiftThreshold=thr)
-    for _ in range(40):
+    for _ in range(PROBES):
         px, py, s = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(0, spp))
         g = S.evaluate_point(cfg, px, py, s); o = O.evaluate_point(ocfg, px, py, s)
         for key in ("veryDirect", "throughput", "gradients", "neighbours"):
@@ -155,4 +157,4 @@ for seed in range(first, first + count):
     if (seed - first) % 20 == 19:
         print("seed %d: %d probes, %d films ok, worst film rel diff %.2e, %.0f s" % (seed, probes, films, worst, time.time() - t0), flush=True)
 print("OK: seeds %d..%d, %d probes (%d outputs beyond 1e-9 on ill-conditioned samples, worst %.1e, each within 20x of the oracle's own sensitivity to few-ulp scalings of the geometry), %d films + %d with a knife-edge ray-count difference (%d film buffers beyond 1e-9, within 20x of the oracle's own spread), worst film rel diff %.2e, %.0f s" % (first, first + count - 1, probes, illcond, worst_ill, films, knife, illfilm, worst, time.time() - t0))
-fuzz_summary.emit("gpu_fuzz_campaign", first, count, time.time() - t0, probes=probes, films=films, ill_conditioned_outputs=illcond, worst_ill_conditioned_rel=worst_ill, knife_edge_ray_count_films=knife, ill_conditioned_film_buffers=illfilm, worst_film_rel_diff=worst, bars="samples rtol 1e-9 / atol 1e-13 (gradients: + 1e-9 of the two contributions they are the difference of), films 1e-9 of the buffer scale; beyond: within 20x of the oracle's own sensitivity to few-ulp scalings / 2^-30 rad rotations")
+fuzz_summary.emit("gpu_fuzz_campaign", first, count, time.time() - t0, film_scale=FILM_SCALE, probes=probes, films=films, ill_conditioned_outputs=illcond, worst_ill_conditioned_rel=worst_ill, knife_edge_ray_count_films=knife, ill_conditioned_film_buffers=illfilm, worst_film_rel_diff=worst, bars="samples rtol 1e-9 / atol 1e-13 (gradients: + 1e-9 of the two contributions they are the difference of), films 1e-9 of the buffer scale; beyond: within 20x of the oracle's own sensitivity to few-ulp scalings / 2^-30 rad rotations")
