@@ -599,6 +599,10 @@ def main():
             tracer_issue.update(_valu_busy(tot, sum(k["avg_ms"] for k in per_step.values()) * 1e-3))
             tracer_issue.update({"achieved": round(valu / launch_s / 1e9, 1), "frac": round(valu / launch_s / VALU_ISSUE_PEAK, 4),
                                  "valu_wave_instr_per_ray": round(valu / rays_per_launch, 2),
+                                 # (the chunks of a render are pipelined over two streams: under rocprofv3's kernel trace the launches of a step add up to MORE than the step --
+                                 #  their durations overlap; the live figure above is HIP events around the step's render on the film's stream, which the second stream is joined to)
+                                 "profiled_kernel_ms_sum_per_step": round(sum(k["avg_ms"] for k in per_step.values()), 2),
+                                 "profiled_kernel_ms_sum_what": "sum of the committed kernel trace's launch durations per step; more than render_ms_per_step where consecutive chunks' kernels overlap on the film's two streams",
                                  "lane_utilisation": round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if tot["SQ_ACTIVE_INST_VALU"] else None,
                                  "wait_any_frac_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4) if tot["SQ_WAVE_CYCLES"] else None})
             tb = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
@@ -662,6 +666,7 @@ def main():
                         "valu_busy": tracer_issue.get("valu_busy"), "valu_busy_what": tracer_issue.get("valu_busy_what"), "effective_clock_ghz_profiled": tracer_issue.get("effective_clock_ghz_profiled"),
                         "frac_what": "an UPPER bound on issue use (every VALU instruction priced at the fp64 rate of 4 cycles; fp32 / integer ones issue in 2): valu_busy is the measured busy fraction",
                         "per_kernel": tracer_issue.get("per_kernel"), "counters_file": tracer_issue.get("counters_file"),
+                        "profiled_kernel_ms_sum_per_step": tracer_issue.get("profiled_kernel_ms_sum_per_step"), "profiled_kernel_ms_sum_what": tracer_issue.get("profiled_kernel_ms_sum_what"),
                         "what": "the timed step's render kernels: VALU wave-instructions per step (committed PMC pass of this binary) / their launch duration by HIP events in THIS run, against 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction; MFMA is not used (no dense contraction) and the scene is not HBM-resident, so neither the hbm nor the mfma ceiling applies to them"}
         else:
             roofline = dict(tracer_bytes)
