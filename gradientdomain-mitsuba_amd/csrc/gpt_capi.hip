@@ -1209,9 +1209,10 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
     // (the walker of an HBM-resident scene at four waves per SIMD: atrium frame 53.8 ms, at three 55.3)
     constexpr int WALK_ROUNDS = 2, WALK_WPS = 3, HBM_WALK_WPS = 4;
     const size_t wlds = (size_t)stackDepth * TBLK * sizeof(int) + sceneBytes;
-#define GDPT_DEFERRED(LDSV, ENVV, SMV) [&](auto ldsC) { \
+#define GDPT_DEFERRED(LDSV, ENVV, SMV) GDPT_DEFERRED_W(LDSV, ((LDSV) ? WALK_WPS : HBM_WALK_WPS), ENVV, SMV)
+#define GDPT_DEFERRED_W(LDSV, WWPSV, ENVV, SMV) [&](auto ldsC) { \
         { \
-            constexpr int WWPS = decltype(ldsC)::value ? WALK_WPS : HBM_WALK_WPS; \
+            constexpr int WWPS = WWPSV; \
             for (int r = 0; r < WALK_ROUNDS; r++) { \
                 unsigned *lin = (r & 1) ? wListBC : fd.qList, *lout = (r & 1) ? fd.qList : wListBC; \
                 hipLaunchKernelGGL((k_walk<decltype(ldsC)::value, WWPS, ENVV, SMV>), dim3(s->numCUs * WWPS), block, wlds, r == 0 ? sFirst : sRest, s->d, c, fd, lin, fd.qCount + 2 * r, lout, wLogC, wInfoC, r == 0 ? 1 : 0, stackDepth, f->contRefill); \
@@ -1230,6 +1231,22 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
         if (wfIters > 0 && wf_continue(s, f->stream, c, fd, f->wf, wfIters, stackDepth, sceneBytes) != 0) { hipEventDestroy(e0); hipEventDestroy(e1); return tfail(GDPT_ERR_HIP, "wavefront launch failed"); } \
         if (deferred) GDPT_DEFERRED(LDSV, ENVV, SMV); \
         GDPT_CONT_LAUNCH(LDSV, ACCV, WPS, ENVV, SMV); } while (0)
+    // HBM-resident scenes on the deferred path (k_first + k_walk + k_replay + the k_continue tail; k_render is not on it) run the build of EXACTLY the features they use.  The
+    // builds above fold "per-vertex data" and "special emitters" into one <ENV, SMOOTH> = <true, true> build at four waves per SIMD (k_render's environment-only build at four
+    // waves is the one that faults, below), and that build is where the two features' registers add up: the atrium frame (flat, closed: 53.4 ms through <false, false>) takes
+    // 80.2 ms through it, 82.8 ms with vertex normals on every triangle -- and 61.0 ms through <false, true>, 54.8 ms through <true, false> (round 6, development builds;
+    // films bit-identical).  A scene with both keeps <true, true>, first stage and walker at THREE waves per SIMD (75.4 against 82.8 ms).
+#define GDPT_STAGED_EXACT(WPS, WWPSV, ENVV, SMV) do { \
+        GDPT_FIRST(false, false, WPS, ENVV, SMV); \
+        GDPT_DEV_DUMP_QUEUE(); \
+        GDPT_DEFERRED_W(false, WWPSV, ENVV, SMV); \
+        GDPT_CONT_LAUNCH(false, false, WPS, ENVV, SMV); } while (0)
+#define GDPT_STAGED_HBM() do { \
+        const bool exact = firstStage && deferred && !shift5 && wfIters == 0 && !getenv("GDPT_NO_EXACT_BUILDS"); \
+        if (exact && s->perVertex && !s->specialEmitters) GDPT_STAGED_EXACT(4, HBM_WALK_WPS, false, true); \
+        else if (exact && !s->perVertex && s->specialEmitters) GDPT_STAGED_EXACT(4, HBM_WALK_WPS, true, false); \
+        else if (exact && s->perVertex && s->specialEmitters) GDPT_STAGED_EXACT(3, 3, true, true); \
+        else GDPT_STAGED_F(false, false, 4); } while (0)
 #define GDPT_STAGED_F(LDSV, ACCV, WPS) do { \
         if (s->perVertex) GDPT_STAGED(LDSV, ACCV, WPS, true, true); \
         else if (s->specialEmitters) GDPT_STAGED(LDSV, ACCV, WPS, true, ((WPS) > 2)); /* (4-wave: the per-vertex build, see below) */ \
@@ -1286,7 +1303,7 @@ int gdpt_render_rect(gdpt_scene *s, const gdpt_config *cfg, int x0, int y0, int 
             } else
 #endif
             if (s->d.ldsScene) { if (accLds) GDPT_STAGED_F(true, true, 2); else GDPT_STAGED_F(true, false, 2); }
-            else GDPT_STAGED_F(false, false, 4);
+            else GDPT_STAGED_HBM();
         } else if (s->d.ldsScene) { if (accLds) GDPT_LAUNCH_W(true, true); else GDPT_LAUNCH_W(true, false); }
         else                      { if (accLds) GDPT_LAUNCH_W(false, true); else GDPT_LAUNCH_W(false, false); }
 #endif

@@ -1448,7 +1448,8 @@ def test_crop_window_rays_come_from_the_full_films_raster(G, variant, md, crop, 
 
 
 @pytest.mark.parametrize("variant,md,strict,env,rfilter", [("diffuse", -1, False, None, None), ("rough", 9, True, (0.3, 0.4, 0.5), None), ("smooth", 7, True, None, None),
-                                                          ("twosided", 12, False, None, None), ("diffuse", 6, False, None, scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN])])
+                                                          ("twosided", 12, False, None, None), ("diffuse", 6, False, None, scenes.RFILTER_DEFAULTS[scenes.RFILTER_GAUSSIAN]),
+                                                          ("bent", 5, False, (0.3, 0.4, 0.5), None)])
 @pytest.mark.parametrize("hbm", [False, True])
 def test_deferred_continuation_and_pipelined_chunks_equal_the_in_place_kernels(G, monkeypatch, variant, md, strict, env, rfilter, hbm):
     """Round 6: for LDS-resident scenes without glossy vertices the continuation runs DEFERRED (k_walk: the base paths alone, logging what their joined offsets would have
@@ -1457,7 +1458,9 @@ def test_deferred_continuation_and_pipelined_chunks_equal_the_in_place_kernels(G
     (GDPT_NO_PIPE=1), with a queue budget that cuts the render into one-sample chunks (set reuse, the waits between the streams) -- and equal to the oracle's.
     (a filter wider than box: the deferred form without the pipeline)
     hbm: the scene's tables in HBM (the builds of configs 3 / 4).  There the two forms also differ in WHERE a sample is handed over: with the deferred continuation after its
-    first bounce (k_first; offsets RAY_RECENTLY_CONNECTED), with the in-place one when every offset is RAY_CONNECTED (k_render<STAGED>) -- the films are the same bits."""
+    first bounce (k_first; offsets RAY_RECENTLY_CONNECTED), with the in-place one when every offset is RAY_CONNECTED (k_render<STAGED>) -- the films are the same bits.
+    And the deferred path of an HBM-resident scene runs the build of exactly the features it uses: "smooth" = per-vertex normals only, "rough" + environment = special emitters
+    only, "bent" + environment = both (at three waves per SIMD), against the in-place kernels' folded <true, true> build."""
     if hbm:
         monkeypatch.setenv("GDPT_SCENE_IN_HBM", "1")
     W, H, spp = 44, 36, 7
