@@ -1498,3 +1498,42 @@ def test_deferred_continuation_and_pipelined_chunks_equal_the_in_place_kernels(G
     for b in range(5):
         assert close(ref_acc[b], oacc[b]), G.BUFFER_NAMES[b]
     S.close()
+
+
+@pytest.mark.gpu
+def test_hbm_scene_with_vertex_normals_runs_the_exact_builds_to_the_same_bits(G, monkeypatch):
+    """Round 6 (r06g): an HBM-resident scene with per-vertex data but no special emitters runs <ENV, SMOOTH> = <false, true> builds -- of k_first / k_walk / the k_continue tail on
+    the deferred path (no glossy vertices), of k_render<STAGED> / k_continue on the in-place path (glossy vertices) -- instead of the folded <true, true> build
+    (GDPT_NO_EXACT_BUILDS=1): the same bits, and the oracle's film."""
+    monkeypatch.setenv("GDPT_SCENE_IN_HBM", "1")
+    W, H, spp = 40, 30, 5
+    for variant, md in (("diffuse", 7), ("glossy", 9), ("glass", 8)):
+        sc = scenes.cornell_box(W, H, variant)
+        v = np.asarray(sc.verts, np.float64).reshape(-1, 3, 3)
+        n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]); n /= np.linalg.norm(n, axis=1, keepdims=True)
+        tilt = np.array([0.05, -0.03, 0.04])             # (shading normals that differ from the face normals, per vertex)
+        nv = [n + tilt * (k + 1) * 0.5 for k in range(3)]
+        sc.normals = np.concatenate([a / np.linalg.norm(a, axis=1, keepdims=True) for a in nv], axis=1)
+        for e in sc.emitters:
+            if not isinstance(e[0], str):
+                sc.normals[int(e[0]):int(e[0]) + int(e[1])] = 0.0
+        S = G.Scene(sc)
+        integ = G.GradientPathIntegrator(maxDepth=md, rrDepth=3)
+        cfg = integ.config(spp)
+        res = {}
+        for name, envs in (("exact", {}), ("folded", {"GDPT_NO_EXACT_BUILDS": "1"})):
+            monkeypatch.delenv("GDPT_NO_EXACT_BUILDS", raising=False)
+            for k, val in envs.items():
+                monkeypatch.setenv(k, val)
+            F = G.Film(S)
+            integ.renderBlock(S, F, cfg, (0, 0, W, H))
+            res[name] = (F.accum(), F.stats())
+            F.close()
+        monkeypatch.delenv("GDPT_NO_EXACT_BUILDS", raising=False)
+        assert res["exact"][1] == res["folded"][1], variant
+        assert np.array_equal(res["exact"][0], res["folded"][0]), variant
+        oacc, orays = go.Scene(sc).render(go.config(maxDepth=md, spp=spp, rrDepth=3))
+        assert (res["exact"][1]["raysTraced"], res["exact"][1]["shadowRaysTraced"]) == orays, variant
+        for b in range(5):
+            assert close(res["exact"][0][b], oacc[b]), (variant, G.BUFFER_NAMES[b])
+        S.close()
