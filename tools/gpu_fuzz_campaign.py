@@ -71,6 +71,17 @@ for seed in range(first, first + count):
         sc = scenes.atrium(W, H, columns=int(rng.integers(4, 12)), segments=int(rng.integers(6, 16)))
     else:
         sc = scenes.cornell_box(W, H, kind, **kw)
+    if seed % 5 == 3 and seed % 7 != 0 and kind == "random":
+        # (round 6, r06h: shading normals tilted off the face normals on the RANDOM-material box -- per-vertex data with glossy vertices: the in-place kernels' per-vertex builds, in HBM
+        #  the exact <false, true> ones; a generator of its own, so the other draws of the seed stay what they were)
+        r2 = np.random.default_rng(seed + 7777777)
+        v = np.asarray(sc.verts, np.float64).reshape(-1, 3, 3)
+        n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]); n /= np.linalg.norm(n, axis=1, keepdims=True)
+        nv = [n + r2.uniform(-0.08, 0.08, 3) for _ in range(3)]
+        sc.normals = np.concatenate([a / np.linalg.norm(a, axis=1, keepdims=True) for a in nv], axis=1)
+        for e in sc.emitters:
+            if not isinstance(e[0], str):
+                sc.normals[int(e[0]):int(e[0]) + int(e[1])] = 0.0
     if seed % 9 == 4:                                      # a thin lens instead of the pinhole (two more random numbers per sample, rays from the aperture)
         sc.thinlens = (float(rng.uniform(2.0, 60.0)), float(rng.uniform(300.0, 1500.0))) if seed % 7 else (float(rng.uniform(0.01, 0.3)), float(rng.uniform(2.0, 30.0)))
     if seed % 11 == 3:                                     # a reconstruction filter wider than box (sample log + gather)
